@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X accelerate backend.
+
+Workload (BASELINE.json configs[1]): 8192x8192 RGBA Q16 BlurImage(radius=0,
+sigma=10) — the 79-tap separable Gaussian blur with a Quantum-rounded
+intermediate — on device-resident images.  One *step* = one BlurImage call on
+one 8192x8192 image per rank (independent images shard across ranks with no
+collective: weak scaling).  Metric: Mpixels/s of output, whole job.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel, hipEvent
+timed on the launch stream) and `cpu_baseline` (the compiled reference's own
+OpenMP BlurImage on this host, bounded sample, rank 0 / N=1 only) objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=8192, help="image edge (default: the C2 config)")
+    ap.add_argument("--sigma", type=float, default=10.0)
+    ap.add_argument("--precision", choices=["exact", "fast"], default="exact")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (resize) measurements")
+    return ap.parse_args()
+
+
+def kernel_profile(im, fn, reps):
+    """Average per-launch duration (ms) of every kernel `fn` launches, from the
+    library's hipEvent records on the launch stream."""
+    import ctypes
+    import torch
+    from imagemagick_amd import _lib
+    lib = _lib.load()
+    lib.MhResetProfileRecords()
+    lib.MhSetProfileEnabled(1)
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    lib.MhSetProfileEnabled(0)
+    recs = (_lib.MhKernelProfileRecord * 32)()
+    n = lib.MhGetProfileRecords(recs, 32)
+    out = {}
+    for i in range(min(n, 32)):
+        r = recs[i]
+        out[r.kernel_name.decode()] = {"count": int(r.count), "avg_ms": r.total_ms / max(r.count, 1),
+                                       "min_ms": r.min_ms, "max_ms": r.max_ms}
+    lib.MhResetProfileRecords()
+    return out
+
+
+def cpu_baseline(sigma):
+    """The reference's own CPU/OpenMP BlurImage (oracle/_ref) on a bounded
+    sample of the same workload: same distribution, same sigma, smaller frame."""
+    import numpy as np
+    from oracle import ref
+    if not ref.available(False):
+        return None
+    threads = os.cpu_count() or 1
+    ref.set_thread_limit(threads)
+    rng = np.random.default_rng(42)
+    edge = 1024
+    spent = 0.0
+    best = None
+    while True:
+        px = rng.integers(0, 65536, (edge, edge, 4), dtype=np.uint16)
+        img = ref.RefImage(px)
+        out = img.blur(0.0, sigma)
+        sec = out.last_seconds
+        spent += sec
+        best = (edge, sec)
+        del out, img
+        # grow the sample until one call takes a few seconds, within a ~30 s budget
+        if sec > 4.0 or spent + 4.5 * sec > 30.0 or edge >= 8192:
+            break
+        edge *= 2
+    edge, sec = best
+    return {"value": round(edge * edge / sec / 1e6, 3), "unit": "Mpixels/s",
+            "cores": int(ref.thread_limit()), "kind": "reference",
+            "sample": "%dx%d RGBA Q16 BlurImage(0,%g), reference MagickCore OpenMP path, "
+                      "1 call, %.2f s" % (edge, edge, sigma, sec)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import imagemagick_amd as im
+    im.load()
+    im.set_precision(im.PRECISION_FAST if args.precision == "fast" else im.PRECISION_EXACT)
+
+    n = args.size
+    gen = torch.Generator(device="cuda").manual_seed(42 + rank)
+    # uniform uint16 in every channel incl. alpha: exercises the alpha-weighted path
+    src = torch.randint(-32768, 32768, (n, n, 4), generator=gen, device="cuda",
+                        dtype=torch.int16).view(torch.uint16)
+    image = im.Image(src)
+    out_holder = {}
+
+    def step():
+        out_holder["out"] = im.blur_image(image, 0.0, args.sigma)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        pixels = float(n) * n
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * pixels * args.steps / elapsed / 1e6
+        # dominant kernel, hipEvent-timed on the launch stream (untimed extra reps)
+        prof = kernel_profile(im, step, max(3, min(args.steps, 10)))
+        conv = {k: v for k, v in prof.items() if k.startswith("conv_")}
+        dominant = max(conv, key=lambda k: conv[k]["avg_ms"]) if conv else None
+        roofline = None
+        if dominant:
+            # algorithmic bytes of one pass: read the frame once, write it once
+            bytes_per_launch = 2.0 * pixels * 4 * 2
+            ms = conv[dominant]["avg_ms"]
+            achieved = bytes_per_launch / (ms * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(dominant)
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": traffic, "avg_ms": round(ms, 4),
+                        "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in prof.items()}}
+        result = {
+            "metric": "Mpixels/sec GaussianBlur sigma=10, 8K RGBA Q16",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if args.precision == "exact" else "f32", "data": "synthetic",
+            "config": {"workload": "%dx%d RGBA Q16 BlurImage(radius=0,sigma=%g): 79-tap row pass + "
+                                   "79-tap column pass, Quantum-rounded intermediate, edge clamp, "
+                                   "alpha-weighted colour channels; one independent image per GPU"
+                                   % (n, n, args.sigma),
+                       "precision": args.precision, "images_per_step": world},
+            "roofline": roofline,
+        }
+        if not args.no_extra and world == 1:
+            result["extra"] = extra_measurements(im, torch, args)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args.sigma)
+            except Exception as exc:  # the baseline is a report, never a reason to lose the line
+                result["cpu_baseline"] = {"error": str(exc)}
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def timed(torch, fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def extra_measurements(im, torch, args):
+    """Secondary numbers reported next to the headline (not `value`): the FAST
+    precision blur and the C3 Lanczos 4x resize (8192^2 -> 32768^2, float Quantum)."""
+    extra = {}
+    try:
+        n = args.size
+        gen = torch.Generator(device="cuda").manual_seed(1)
+        src = torch.randint(-32768, 32768, (n, n, 4), generator=gen, device="cuda",
+                            dtype=torch.int16).view(torch.uint16)
+        image = im.Image(src)
+        other = im.PRECISION_EXACT if args.precision == "fast" else im.PRECISION_FAST
+        im.set_precision(other)
+        sec = timed(torch, lambda: im.blur_image(image, 0.0, args.sigma), 5)
+        extra["blur_%s_Mpixels_per_s" % ("exact" if args.precision == "fast" else "fast")] = \
+            round(n * n / sec / 1e6, 1)
+        im.set_precision(im.PRECISION_FAST if args.precision == "fast" else im.PRECISION_EXACT)
+        del src, image
+        torch.cuda.empty_cache()
+        # C3: 8192^2 -> 32768^2 Lanczos, float Quantum (17.2 GB result)
+        m = 8192
+        srcf = torch.rand((m, m, 4), generator=gen, device="cuda", dtype=torch.float32) * 65535.0
+        imgf = im.Image(srcf)
+        holder = {}
+
+        def resize():
+            holder["o"] = None
+            holder["o"] = im.resize_image(imgf, 4 * m, 4 * m, "Lanczos")
+        sec = timed(torch, resize, 3)
+        prof = kernel_profile(im, resize, 2)
+        out_px = 16.0 * m * m
+        extra["resize_lanczos4x_f32_Mpixels_per_s"] = round(out_px / sec / 1e6, 1)
+        extra["resize_kernels_ms"] = {k: round(v["avg_ms"], 3) for k, v in prof.items()}
+        # algorithmic bytes: horizontal pass reads 8192x32768 and writes 32768x32768 float RGBA
+        if "resize_horizontal" in prof:
+            b = (m * 4.0 * m + 16.0 * m * m) * 16
+            extra["resize_horizontal_GBps"] = round(b / (prof["resize_horizontal"]["avg_ms"] * 1e-3) / 1e9, 1)
+        if "resize_vertical" in prof:
+            b = (1.0 * m * m + 4.0 * m * m) * 16
+            extra["resize_vertical_GBps"] = round(b / (prof["resize_vertical"]["avg_ms"] * 1e-3) / 1e9, 1)
+        holder.clear()
+    except Exception as exc:
+        extra["error"] = str(exc)
+    return extra
+
+
+if __name__ == "__main__":
+    main()

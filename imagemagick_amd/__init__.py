@@ -1,0 +1,320 @@
+"""imagemagick_amd — Python binding of libmagickhip.so, the MI355X-native
+MagickCore accelerate backend (see include/magickhip.h).
+
+The functions here mirror the reference's operator names (BlurImage,
+ConvolveImage, MorphologyImage, UnsharpMaskImage, ResizeImage,
+ContrastStretchImage, EqualizeImage, TransformImageColorspace) and do nothing
+but marshal buffers into the C ABI: pixels may be a CUDA/HIP ``torch.Tensor``
+(used in place on the device, on torch's current stream) or a NumPy array
+(host memory, staged by the library).  Layout is the pixel cache's:
+``[rows, columns, channels]``, ``uint16`` (Q16) or ``float32`` (Q16-HDRI).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import (MagickHipError, MhImage, COLORSPACES, MORPHOLOGY, FILTERS,  # noqa: F401
+                   PRECISION_EXACT, PRECISION_FAST, TRAIT_COPY, TRAIT_UPDATE, TRAIT_BLEND,
+                   ALL_CHANNELS, SYNC_CHANNELS)
+
+__all__ = ["Image", "blur_image", "convolve_image", "morphology_image", "morphology_primitive",
+           "unsharp_mask_image", "resize_image", "contrast_stretch_image", "equalize_image",
+           "transform_image_colorspace", "histogram", "apply_lut", "contrast_stretch_lut",
+           "equalize_lut", "is_image_gray", "set_precision", "get_precision", "device_count",
+           "build", "load", "MagickHipError"]
+
+build = _lib.build
+load = _lib.load
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class Image:
+    """A pixel buffer plus the per-image facts the operators need (what the
+    MagickCore shim reads from ``Image``): channel traits, alpha, colourspace."""
+
+    def __init__(self, pixels, colorspace="srgb", has_alpha=None, channel_mask=ALL_CHANNELS,
+                 copy_channels=(), intensity=0):
+        if pixels.ndim == 2:
+            pixels = pixels.reshape(pixels.shape[0], pixels.shape[1], 1)
+        if pixels.ndim != 3:
+            raise ValueError("pixels must be [rows, columns, channels]")
+        self.pixels = pixels
+        self.rows, self.columns, self.channels = (int(s) for s in pixels.shape)
+        if has_alpha is None:
+            has_alpha = self.channels in (2, 4)
+        self.has_alpha = bool(has_alpha)
+        self.colorspace = colorspace.lower()
+        self.channel_mask = channel_mask
+        self.copy_channels = tuple(copy_channels)
+        self.intensity = intensity
+        if _is_torch(pixels):
+            import torch
+            if not pixels.is_contiguous():
+                raise ValueError("pixel tensor must be contiguous")
+            if pixels.dtype == torch.uint16:
+                self.quantum = _lib.QUANTUM_U16
+            elif pixels.dtype == torch.float32:
+                self.quantum = _lib.QUANTUM_F32
+            else:
+                raise ValueError("pixels must be uint16 (Q16) or float32 (Q16-HDRI)")
+            if not pixels.is_cuda:
+                raise ValueError("torch pixels must live on the GPU; pass a NumPy array for host memory")
+            self.memory = _lib.MEMORY_DEVICE
+        else:
+            if not pixels.flags["C_CONTIGUOUS"]:
+                raise ValueError("pixel array must be C-contiguous")
+            if pixels.dtype == np.uint16:
+                self.quantum = _lib.QUANTUM_U16
+            elif pixels.dtype == np.float32:
+                self.quantum = _lib.QUANTUM_F32
+            else:
+                raise ValueError("pixels must be uint16 (Q16) or float32 (Q16-HDRI)")
+            self.memory = _lib.MEMORY_HOST
+
+    # ------------------------------------------------------------------ helpers
+    def _pointer(self):
+        if self.memory == _lib.MEMORY_DEVICE:
+            return self.pixels.data_ptr()
+        return self.pixels.ctypes.data
+
+    def descriptor(self):
+        lib = _lib.load()
+        d = MhImage()
+        lib.MhInitImage(ctypes.byref(d), self._pointer(), self.columns, self.rows, self.channels,
+                        1 if self.has_alpha else 0, self.quantum, self.memory)
+        d.colorspace = COLORSPACES[self.colorspace]
+        d.intensity = self.intensity
+        d.channel_mask = self.channel_mask
+        for c in self.copy_channels:
+            d.channel_traits[c] = TRAIT_COPY
+        if self.memory == _lib.MEMORY_DEVICE:
+            import torch
+            d.device = self.pixels.device.index if self.pixels.device.index is not None else 0
+            d.stream = torch.cuda.current_stream(self.pixels.device).cuda_stream
+        return d
+
+    def like(self, rows=None, columns=None):
+        rows = self.rows if rows is None else rows
+        columns = self.columns if columns is None else columns
+        if self.memory == _lib.MEMORY_DEVICE:
+            import torch
+            px = torch.empty((rows, columns, self.channels), dtype=self.pixels.dtype,
+                             device=self.pixels.device)
+        else:
+            px = np.empty((rows, columns, self.channels), dtype=self.pixels.dtype)
+        return Image(px, self.colorspace, self.has_alpha, self.channel_mask, self.copy_channels,
+                     self.intensity)
+
+    def numpy(self):
+        if self.memory == _lib.MEMORY_DEVICE:
+            import torch
+            t = self.pixels
+            if t.dtype == torch.uint16:
+                return t.view(torch.int16).cpu().numpy().view(np.uint16)
+            return t.cpu().numpy()
+        return self.pixels
+
+
+class _Kernel:
+    def __init__(self, kernel):
+        lib = _lib.load()
+        self.owned = isinstance(kernel, (str, bytes))
+        if self.owned:
+            text = kernel.encode() if isinstance(kernel, str) else kernel
+            self.ptr = lib.MhAcquireKernelInfo(text)
+            if not self.ptr:
+                raise MagickHipError(3, lib.MhGetLastError().decode())
+        else:
+            self.ptr = kernel
+
+    def __enter__(self):
+        return self.ptr
+
+    def __exit__(self, *exc):
+        if self.owned and self.ptr:
+            _lib.load().MhDestroyKernelInfo(self.ptr)
+        return False
+
+
+def kernel_to_numpy(kernel_string, index=0):
+    """Build a kernel list with the product's host builder and return kernel
+    `index` as (values[h,w], x, y, count)."""
+    lib = _lib.load()
+    ptr = lib.MhAcquireKernelInfo(kernel_string.encode())
+    if not ptr:
+        raise MagickHipError(3, lib.MhGetLastError().decode())
+    try:
+        count = 0
+        k = ptr
+        chosen = None
+        while k:
+            if count == index:
+                chosen = k.contents
+            count += 1
+            k = k.contents.next
+        if chosen is None:
+            raise IndexError(index)
+        n = chosen.width * chosen.height
+        values = np.ctypeslib.as_array(chosen.values, shape=(n,)).copy()
+        return values.reshape(chosen.height, chosen.width), chosen.x, chosen.y, count
+    finally:
+        lib.MhDestroyKernelInfo(ptr)
+
+
+# --------------------------------------------------------------------- runtime
+def device_count():
+    return _lib.load().MhDeviceCount()
+
+
+def set_precision(precision):
+    return _lib.load().MhSetPrecision(precision)
+
+
+def get_precision():
+    return _lib.load().MhGetPrecision()
+
+
+# ------------------------------------------------------------------- operators
+def blur_image(image, radius, sigma):
+    """BlurImage(image, radius, sigma) — MagickCore/effect.c:765."""
+    lib = _lib.load()
+    out = image.like()
+    _lib.check(lib.MagickHipBlurImage(ctypes.byref(image.descriptor()),
+                                      ctypes.byref(out.descriptor()), radius, sigma))
+    return out
+
+
+def convolve_image(image, kernel):
+    """ConvolveImage(image, kernel) — MagickCore/effect.c:1170."""
+    lib = _lib.load()
+    out = image.like()
+    with _Kernel(kernel) as k:
+        _lib.check(lib.MagickHipConvolveImage(ctypes.byref(image.descriptor()),
+                                              ctypes.byref(out.descriptor()), k))
+    return out
+
+
+def morphology_image(image, method, iterations, kernel, bias=0.0):
+    """MorphologyImage(image, method, iterations, kernel) — MagickCore/morphology.c:4129."""
+    lib = _lib.load()
+    out = image.like()
+    with _Kernel(kernel) as k:
+        _lib.check(lib.MagickHipMorphologyImage(ctypes.byref(image.descriptor()),
+                                                ctypes.byref(out.descriptor()),
+                                                MORPHOLOGY[method.lower()], iterations, k, bias))
+    return out
+
+
+def morphology_primitive(image, method, kernel, bias=0.0):
+    """One MorphologyPrimitive pass; returns (image, changed)."""
+    lib = _lib.load()
+    out = image.like()
+    changed = ctypes.c_ssize_t(0)
+    with _Kernel(kernel) as k:
+        _lib.check(lib.MagickHipMorphologyPrimitive(ctypes.byref(image.descriptor()),
+                                                    ctypes.byref(out.descriptor()),
+                                                    MORPHOLOGY[method.lower()], k, bias,
+                                                    ctypes.byref(changed)))
+    return out, changed.value
+
+
+def unsharp_mask_image(image, radius, sigma, gain, threshold):
+    """UnsharpMaskImage — MagickCore/effect.c:4256."""
+    lib = _lib.load()
+    out = image.like()
+    _lib.check(lib.MagickHipUnsharpMaskImage(ctypes.byref(image.descriptor()),
+                                             ctypes.byref(out.descriptor()), radius, sigma, gain,
+                                             threshold))
+    return out
+
+
+def resize_image(image, columns, rows, filter="lanczos"):
+    """ResizeImage(image, columns, rows, filter) — MagickCore/resize.c:3761."""
+    lib = _lib.load()
+    out = image.like(rows=rows, columns=columns)
+    _lib.check(lib.MagickHipResizeImage(ctypes.byref(image.descriptor()),
+                                        ctypes.byref(out.descriptor()), FILTERS[filter.lower()]))
+    return out
+
+
+def contrast_stretch_image(image, black_point, white_point):
+    """ContrastStretchImage(image, black, white), in place — MagickCore/enhance.c:1544."""
+    lib = _lib.load()
+    gray = ctypes.c_int(0)
+    _lib.check(lib.MagickHipContrastStretchImage(ctypes.byref(image.descriptor()), black_point,
+                                                 white_point, ctypes.byref(gray)))
+    return image
+
+
+def equalize_image(image):
+    """EqualizeImage(image), in place — MagickCore/enhance.c:2040."""
+    lib = _lib.load()
+    _lib.check(lib.MagickHipEqualizeImage(ctypes.byref(image.descriptor())))
+    return image
+
+
+def transform_image_colorspace(image, colorspace):
+    """TransformImageColorspace(image, colorspace), in place — MagickCore/colorspace.c:1751."""
+    lib = _lib.load()
+    d = image.descriptor()
+    _lib.check(lib.MagickHipTransformImageColorspace(ctypes.byref(d), COLORSPACES[colorspace.lower()]))
+    image.colorspace = colorspace.lower()
+    return image
+
+
+# ------------------------------------------------------------- building blocks
+def histogram(image, intensity_mode, out=None):
+    """Accumulate the 65536-bin histogram of `image` into `out`
+    ([65536, channels] uint64; a CUDA tensor of int64 for device images)."""
+    lib = _lib.load()
+    if image.memory == _lib.MEMORY_DEVICE:
+        import torch
+        if out is None:
+            out = torch.zeros((65536, image.channels), dtype=torch.int64, device=image.pixels.device)
+        ptr = out.data_ptr()
+    else:
+        if out is None:
+            out = np.zeros((65536, image.channels), dtype=np.uint64)
+        ptr = out.ctypes.data
+    _lib.check(lib.MagickHipHistogram(ctypes.byref(image.descriptor()), 1 if intensity_mode else 0, ptr))
+    return out
+
+
+def contrast_stretch_lut(hist, columns, rows, black_point, white_point, quantum):
+    lib = _lib.load()
+    hist = np.ascontiguousarray(hist, dtype=np.uint64)
+    channels = hist.shape[1]
+    lut = np.zeros((65536, channels), dtype=np.float64)
+    mask = ctypes.c_uint32(0)
+    _lib.check(lib.MhContrastStretchLUT(hist.ctypes.data, channels, columns, rows, black_point,
+                                        white_point, quantum, lut.ctypes.data, ctypes.byref(mask)))
+    return lut, mask.value
+
+
+def equalize_lut(hist, quantum):
+    lib = _lib.load()
+    hist = np.ascontiguousarray(hist, dtype=np.uint64)
+    channels = hist.shape[1]
+    lut = np.zeros((65536, channels), dtype=np.float64)
+    mask = ctypes.c_uint32(0)
+    _lib.check(lib.MhEqualizeLUT(hist.ctypes.data, channels, quantum, lut.ctypes.data,
+                                 ctypes.byref(mask)))
+    return lut, mask.value
+
+
+def apply_lut(image, lut, mask):
+    lib = _lib.load()
+    lut = np.ascontiguousarray(lut, dtype=np.float64)
+    _lib.check(lib.MagickHipApplyLUT(ctypes.byref(image.descriptor()), lut.ctypes.data, mask))
+    return image
+
+
+def is_image_gray(image):
+    lib = _lib.load()
+    flag = ctypes.c_int(0)
+    _lib.check(lib.MagickHipIsImageGray(ctypes.byref(image.descriptor()), ctypes.byref(flag)))
+    return bool(flag.value)

@@ -1,0 +1,154 @@
+// Device-side helpers shared by the HIP kernels: Quantum conversion and
+// clamping, pixel vector I/O, arithmetic policies.
+//
+// IMPORTANT: every .hip file is compiled with -ffp-contract=off.  The
+// reference CPU build has no FMA contraction (x86-64 baseline, configure's
+// "-O2 -mtune=core2"), so the EXACT policy must keep every multiply and add a
+// separately rounded IEEE operation, in the CPU's order.  Where a fused
+// multiply-add is wanted (FAST policy) it is written explicitly.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace mh {
+
+constexpr double kEps = 1.0e-12;          // MagickEpsilon, magick-type.h:114
+constexpr double kQR = 65535.0;           // QuantumRange
+constexpr double kQS = 1.0/65535.0;       // QuantumScale, magick-type.h:119
+
+// ----------------------------------------------------------------- Quantum
+template<typename Q> struct QuantumOps;
+
+template<> struct QuantumOps<uint16_t>
+{
+  static constexpr bool is_float=false;
+  // ClampToQuantum, non-HDRI branch: MagickCore/quantum.h:86-97
+  static __device__ __forceinline__ uint16_t clamp(double v)
+  {
+    if (!(v > 0.0))            // NaN or <= 0
+      return 0;
+    if (v >= kQR)
+      return 65535;
+    return (uint16_t) (v+0.5);
+  }
+  // ScaleQuantumToMap, quantum-private.h:504-514 (Q16: identity)
+  static __device__ __forceinline__ unsigned map_index(uint16_t q) { return q; }
+};
+
+template<> struct QuantumOps<float>
+{
+  static constexpr bool is_float=true;
+  // ClampToQuantum, HDRI branch: a plain cast (quantum.h:88-89)
+  static __device__ __forceinline__ float clamp(double v) { return (float) v; }
+  // ScaleQuantumToMap, HDRI branch
+  static __device__ __forceinline__ unsigned map_index(float q)
+  {
+    if (q >= 65535.0f)
+      return 65535u;
+    if (!(q > 0.0f))
+      return 0u;
+    return (unsigned) (q+0.5f);
+  }
+};
+
+// PerceptibleReciprocal, MagickCore/pixel-accessor.h:242-254
+static __device__ __forceinline__ double perceptible_reciprocal(double x)
+{
+  double sign=x < 0.0 ? -1.0 : 1.0;
+  if ((sign*x) >= kEps)
+    return 1.0/x;
+  return sign/kEps;
+}
+
+// ------------------------------------------------------------- pixel I/O
+template<typename Q,int C>
+static __device__ __forceinline__ void load_pixel(const Q *p,Q (&v)[C])
+{
+  constexpr int bytes=(int) sizeof(Q)*C;
+  if constexpr (bytes == 16)
+    {
+      uint4 t=*reinterpret_cast<const uint4 *>(p);
+      __builtin_memcpy(v,&t,16);
+    }
+  else if constexpr (bytes == 8)
+    {
+      uint2 t=*reinterpret_cast<const uint2 *>(p);
+      __builtin_memcpy(v,&t,8);
+    }
+  else if constexpr (bytes == 4)
+    {
+      uint32_t t=*reinterpret_cast<const uint32_t *>(p);
+      __builtin_memcpy(v,&t,4);
+    }
+  else
+    {
+#pragma unroll
+      for (int c=0; c < C; c++)
+        v[c]=p[c];
+    }
+}
+
+template<typename Q,int C>
+static __device__ __forceinline__ void store_pixel(Q *p,const Q (&v)[C])
+{
+  constexpr int bytes=(int) sizeof(Q)*C;
+  if constexpr (bytes == 16)
+    {
+      uint4 t;
+      __builtin_memcpy(&t,v,16);
+      *reinterpret_cast<uint4 *>(p)=t;
+    }
+  else if constexpr (bytes == 8)
+    {
+      uint2 t;
+      __builtin_memcpy(&t,v,8);
+      *reinterpret_cast<uint2 *>(p)=t;
+    }
+  else if constexpr (bytes == 4)
+    {
+      uint32_t t;
+      __builtin_memcpy(&t,v,4);
+      *reinterpret_cast<uint32_t *>(p)=t;
+    }
+  else
+    {
+#pragma unroll
+      for (int c=0; c < C; c++)
+        p[c]=v[c];
+    }
+}
+
+// ------------------------------------------------------ arithmetic policies
+// EXACT: double, separately rounded multiply and add, CPU operation order.
+struct Exact64
+{
+  typedef double T;
+  static constexpr bool premultiply=false;
+  static __device__ __forceinline__ T mul(T a,T b) { return a*b; }
+  static __device__ __forceinline__ T add(T a,T b) { return a+b; }
+  static __device__ __forceinline__ T mac(T acc,T a,T b) { return acc+a*b; }   // two roundings
+};
+
+// FAST: float with explicit FMA; alpha is folded into the colour channels once
+// per input pixel.  Only offered for Q16, where the accumulated error stays
+// well inside one Quantum level (DESIGN.md "Precision").
+struct Fast32
+{
+  typedef float T;
+  static constexpr bool premultiply=true;
+  static __device__ __forceinline__ T mul(T a,T b) { return a*b; }
+  static __device__ __forceinline__ T add(T a,T b) { return a+b; }
+  static __device__ __forceinline__ T mac(T acc,T a,T b) { return __builtin_fmaf(a,b,acc); }
+};
+
+// wave64 sum of a small non-negative count; lane 0 gets the total
+static __device__ __forceinline__ unsigned wave_sum(unsigned v)
+{
+#pragma unroll
+  for (int off=32; off > 0; off>>=1)
+    v+=__shfl_down(v,off,64);
+  return v;
+}
+
+} // namespace mh

@@ -1,0 +1,165 @@
+// Internal (non-ABI) declarations shared by the host runtime and the HIP
+// translation units of libmagickhip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include <cstdarg>
+#include <vector>
+
+#include "magickhip.h"
+
+namespace mh {
+
+// MagickEpsilon / QuantumRange / QuantumScale: MagickCore/magick-type.h:114-119
+constexpr double kMagickEpsilon = 1.0e-12;
+constexpr double kQuantumRange = 65535.0;
+constexpr double kQuantumScale = 1.0/65535.0;
+
+void set_error(const char *fmt,...) __attribute__((format(printf,1,2)));
+MhStatus fail(MhStatus status,const char *fmt,...) __attribute__((format(printf,2,3)));
+
+#define MH_HIP(expr)                                                         \
+  do {                                                                       \
+    hipError_t mh_err_=(expr);                                               \
+    if (mh_err_ != hipSuccess)                                               \
+      return ::mh::fail(MH_DEVICE_ERROR,"%s failed: %s (%s:%d)",#expr,       \
+        hipGetErrorString(mh_err_),__FILE__,__LINE__);                       \
+  } while (0)
+
+#define MH_TRY(expr)                                                         \
+  do { MhStatus mh_st_=(expr); if (mh_st_ != MH_OK) return mh_st_; } while (0)
+
+// ----------------------------------------------------------------- runtime
+MhStatus runtime_ready();                 // lazy MhInitialize + enabled check
+int default_device();
+int device_count();
+MhPrecision precision();
+hipStream_t library_stream(int device);   // non-blocking stream owned by the library
+
+// stream-tagged caching device allocator (workspace / staging)
+MhStatus pool_alloc(int device,size_t bytes,hipStream_t stream,void **ptr);
+void pool_free(int device,void *ptr,hipStream_t stream);
+void pool_trim();
+
+// RAII temp device buffer
+struct Temp
+{
+  int device=-1; hipStream_t stream=nullptr; void *ptr=nullptr;
+  Temp() = default;
+  Temp(const Temp &) = delete; Temp &operator=(const Temp &) = delete;
+  ~Temp() { reset(); }
+  MhStatus alloc(int dev,size_t bytes,hipStream_t s)
+  { reset(); device=dev; stream=s; return pool_alloc(dev,bytes,s,&ptr); }
+  void reset() { if (ptr != nullptr) pool_free(device,ptr,stream); ptr=nullptr; }
+  template<typename T> T *as() const { return static_cast<T *>(ptr); }
+};
+
+// upload a small host table (taps, LUT, tap tables) into a Temp, async on stream.
+// The host bytes are copied into a pinned bounce buffer first so the caller's
+// memory may go away immediately.
+MhStatus upload_table(Temp &dst,int device,hipStream_t stream,const void *host,size_t bytes);
+
+// Resolved, device-resident view of an MhImage for the kernel launchers.
+struct View
+{
+  void *pixels=nullptr;
+  size_t columns=0,rows=0;
+  int channels=0;
+  MhQuantumKind quantum=MH_QUANTUM_U16;
+  int device=0;
+  hipStream_t stream=nullptr;
+  size_t bytes() const
+  { return columns*rows*(size_t) channels*(quantum == MH_QUANTUM_U16 ? 2u : 4u); }
+};
+
+// Brings an MhImage onto the device (HOST memory: pinned-staged
+// hipMemcpyAsync) and writes results back.
+class Resident
+{
+public:
+  Resident() = default;
+  ~Resident();
+  Resident(const Resident &) = delete; Resident &operator=(const Resident &) = delete;
+  // mode: 0 = input (upload), 1 = output (no upload, download on commit),
+  //       2 = in-place (upload and download on commit)
+  MhStatus open(const MhImage *image,int mode,hipStream_t stream_hint,int device_hint);
+  MhStatus commit();          // output/in-place: copy back to host memory and wait
+  View view;
+private:
+  const MhImage *image_=nullptr;
+  int mode_=0;
+  bool staged_=false;
+  bool registered_=false;
+  Temp temp_;
+};
+
+MhStatus validate_image(const MhImage *image,const char *what);
+int resolve_device(const MhImage *image);
+hipStream_t resolve_stream(const MhImage *image,int device);
+
+// per-channel role masks derived from MhImage traits
+struct Roles
+{
+  uint32_t update_mask=0;   // channels computed
+  uint32_t copy_mask=0;     // channels copied from the source (Copy or Undefined trait)
+  bool blend=false;         // alpha-weighted colour channels
+  int alpha=-1;
+};
+Roles channel_roles(const MhImage *src,const MhImage *dst);
+
+MhKernelInfo *acquire_blur_kernels(double radius,double sigma);
+
+// ------------------------------------------------------------ profiling
+struct ProfileScope
+{
+  ProfileScope(const char *name,hipStream_t stream);
+  ~ProfileScope();
+  const char *name; hipStream_t stream; hipEvent_t start=nullptr,stop=nullptr; bool on=false;
+};
+
+// ------------------------------------------------------------ launchers
+// (defined in the .hip translation units)
+
+struct Conv1DParams
+{
+  const double *taps=nullptr;  // kernel values in storage order (as KernelInfo::values)
+  int ntaps=0;
+  int origin=0;                // kernel->x (row kernel) or kernel->y (column kernel)
+  double bias=0.0;
+};
+// One MorphologyPrimitive(Convolve) pass with a 1-D kernel without NaN cells:
+// horizontal (1 x ntaps, morphology.c:2811-2979) or vertical (ntaps x 1,
+// column fast path morphology.c:2654-2807).
+MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
+  const Conv1DParams &params,const Roles &roles,MhPrecision precision,
+  unsigned long long *changed_device);
+
+struct Morph2DParams
+{
+  MhMorphologyMethod method=MH_MORPHOLOGY_UNDEFINED;
+  const MhKernelInfo *kernel=nullptr;
+  double bias=0.0;
+  MhIntensityMethod intensity=MH_INTENSITY_REC709LUMA;
+  MhColorspace colorspace=MH_COLORSPACE_SRGB;
+};
+MhStatus launch_morph2d(const View &src,const View &dst,const Morph2DParams &params,
+  const Roles &roles,unsigned long long *changed_device);
+
+struct TapTable;   // resize contribution table (host), see resize_filter.cpp
+MhStatus launch_resize_pass(const View &src,const View &dst,bool vertical,
+  const TapTable &table,const Roles &roles,MhPrecision precision);
+
+MhStatus launch_unsharp_epilogue(const View &src,const View &blur,const View &dst,
+  double gain,double threshold,const Roles &roles);
+
+MhStatus launch_histogram(const View &src,int intensity_mode,const MhImage *desc,
+  unsigned long long *hist_device);
+MhStatus launch_apply_lut(const View &img,const void *lut_device,uint32_t apply_mask,
+  const Roles &roles);
+MhStatus launch_gray_check(const View &img,const MhImage *desc,unsigned int *flag_device);
+MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,const MhImage *desc);
+MhStatus launch_copy(const View &src,const View &dst);
+
+} // namespace mh

@@ -1,0 +1,430 @@
+// Operator-level entry points: the host-side mirror of the reference's
+// accelerate interface (MagickCore/accelerate-private.h:36-63) plus the hooks
+// the reference lacks (convolve/morphology, colourspace).  Host control flow
+// (kernel lists, compound stages, iteration, pass ordering, LUT construction)
+// stays on the CPU exactly as in the reference; every per-pixel loop runs in a
+// HIP kernel.
+#include "mh_internal.hpp"
+#include "resize_filter.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+namespace mh {
+
+// the accelerate gate, checkAccelerateCondition accelerate.c:110-170, applied
+// to what the descriptor can express
+static MhStatus gate(const MhImage *image,const char *what)
+{
+  MH_TRY(runtime_ready());
+  MH_TRY(validate_image(image,what));
+  return MH_OK;
+}
+
+static MhStatus gate_pair(const MhImage *image,const MhImage *out,const char *what,
+  bool same_geometry)
+{
+  MH_TRY(gate(image,what));
+  MH_TRY(validate_image(out,what));
+  if ((out->number_channels != image->number_channels) ||
+      (out->quantum != image->quantum))
+    return fail(MH_BAD_ARGUMENT,"%s: destination layout differs from source",what);
+  if (same_geometry && ((out->columns != image->columns) || (out->rows != image->rows)))
+    return fail(MH_BAD_ARGUMENT,"%s: destination geometry differs from source",what);
+  if (out->pixels == image->pixels)
+    return fail(MH_BAD_ARGUMENT,"%s: destination aliases source",what);
+  return MH_OK;
+}
+
+// Both images of an operator run on one device and one stream.
+struct Pair
+{
+  Resident src,dst;
+  MhStatus open(const MhImage *image,MhImage *out)
+  {
+    int device=resolve_device(image->memory == MH_MEMORY_DEVICE ? image : out);
+    hipStream_t stream;
+    if (image->memory == MH_MEMORY_DEVICE)
+      stream=(hipStream_t) image->stream;
+    else if (out->memory == MH_MEMORY_DEVICE)
+      stream=(hipStream_t) out->stream;
+    else
+      stream=library_stream(device);
+    MH_TRY(src.open(image,0,stream,device));
+    MH_TRY(dst.open(out,1,stream,device));
+    src.view.stream=stream;
+    dst.view.stream=stream;
+    src.view.device=device;
+    dst.view.device=device;
+    MH_HIP(hipSetDevice(device));
+    return MH_OK;
+  }
+  MhStatus commit()
+  {
+    MH_TRY(dst.commit());
+    MH_TRY(src.commit());
+    return MH_OK;
+  }
+};
+
+static bool kernel_has_nan(const MhKernelInfo *k)
+{
+  for (size_t i=0; i < k->width*k->height; i++)
+    if (std::isnan(k->values[i]))
+      return true;
+  return false;
+}
+
+// One MorphologyPrimitive(curr -> work), morphology.c:2566.  `changed`
+// (optional, device counter, must be zero on entry) accumulates the number of
+// changed channel values.
+static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod method,
+  const MhKernelInfo *kernel,double bias,const Roles &roles,const MhImage *desc,
+  unsigned long long *changed)
+{
+  if ((method == MH_MORPHOLOGY_CONVOLVE) && !kernel_has_nan(kernel) &&
+      ((kernel->width == 1) || (kernel->height == 1)))
+    {
+      Conv1DParams p;
+      p.taps=kernel->values;
+      p.bias=bias;
+      if (kernel->width == 1)
+        {
+          p.ntaps=(int) kernel->height;
+          p.origin=(int) kernel->y;
+          return launch_conv1d(src,dst,true,p,roles,precision(),changed);
+        }
+      p.ntaps=(int) kernel->width;
+      p.origin=(int) kernel->x;
+      return launch_conv1d(src,dst,false,p,roles,precision(),changed);
+    }
+  Morph2DParams p;
+  p.method=method;
+  p.kernel=kernel;
+  p.bias=bias;
+  p.intensity=desc->intensity != 0 ? (MhIntensityMethod) desc->intensity :
+    MH_INTENSITY_REC709LUMA;
+  p.colorspace=(MhColorspace) desc->colorspace;
+  return launch_morph2d(src,dst,p,roles,changed);
+}
+
+struct Stage { MhMorphologyMethod primitive; bool reflected; };
+
+// MorphologyApply, morphology.c:3634-4077, for the methods that need no
+// CompositeImage post-step.
+static MhStatus morphology_apply(const View &src,const View &dst,const MhImage *desc,
+  const Roles &roles,MhMorphologyMethod method,ptrdiff_t iterations,
+  const MhKernelInfo *kernel,double bias,ptrdiff_t *changed_out)
+{
+  if (iterations == 0)
+    return fail(MH_UNSUPPORTED,"morphology: zero iterations is a null operation");
+  size_t kernel_limit=iterations < 0 ? (src.columns > src.rows ? src.columns : src.rows) :
+    (size_t) iterations;
+  size_t method_limit=1;
+  std::vector<Stage> stages;
+  switch (method)
+  {
+    case MH_MORPHOLOGY_CONVOLVE: stages={{MH_MORPHOLOGY_CONVOLVE,false}}; break;
+    case MH_MORPHOLOGY_CORRELATE: stages={{MH_MORPHOLOGY_CONVOLVE,true}}; break;
+    case MH_MORPHOLOGY_ERODE: stages={{MH_MORPHOLOGY_ERODE,false}}; break;
+    case MH_MORPHOLOGY_DILATE: stages={{MH_MORPHOLOGY_DILATE,false}}; break;
+    case MH_MORPHOLOGY_ERODE_INTENSITY: stages={{MH_MORPHOLOGY_ERODE_INTENSITY,false}}; break;
+    case MH_MORPHOLOGY_DILATE_INTENSITY: stages={{MH_MORPHOLOGY_DILATE_INTENSITY,false}}; break;
+    case MH_MORPHOLOGY_ITERATIVE_DISTANCE: stages={{MH_MORPHOLOGY_ITERATIVE_DISTANCE,false}}; break;
+    case MH_MORPHOLOGY_OPEN:
+      stages={{MH_MORPHOLOGY_ERODE,false},{MH_MORPHOLOGY_DILATE,false}}; break;
+    case MH_MORPHOLOGY_OPEN_INTENSITY:
+      stages={{MH_MORPHOLOGY_ERODE_INTENSITY,false},{MH_MORPHOLOGY_DILATE_INTENSITY,false}}; break;
+    case MH_MORPHOLOGY_CLOSE:
+      stages={{MH_MORPHOLOGY_DILATE,true},{MH_MORPHOLOGY_ERODE,true}}; break;
+    case MH_MORPHOLOGY_CLOSE_INTENSITY:
+      stages={{MH_MORPHOLOGY_DILATE_INTENSITY,true},{MH_MORPHOLOGY_ERODE_INTENSITY,true}}; break;
+    case MH_MORPHOLOGY_SMOOTH:
+      stages={{MH_MORPHOLOGY_ERODE,false},{MH_MORPHOLOGY_DILATE,false},
+              {MH_MORPHOLOGY_DILATE,true},{MH_MORPHOLOGY_ERODE,true}}; break;
+    case MH_MORPHOLOGY_HIT_AND_MISS:
+    case MH_MORPHOLOGY_THINNING:
+    case MH_MORPHOLOGY_THICKEN:
+      if ((method == MH_MORPHOLOGY_HIT_AND_MISS) && (kernel->next != nullptr))
+        return fail(MH_UNSUPPORTED,"HitAndMiss with a kernel list needs a Lighten composite");
+      stages={{method,false}};
+      method_limit=kernel_limit;
+      kernel_limit=1;
+      break;
+    default:
+      // EdgeIn/EdgeOut/Edge/TopHat/BottomHat need CompositeImage(Difference);
+      // Distance/Voronoi are sequential (MorphologyPrimitiveDirect).
+      return fail(MH_UNSUPPORTED,"morphology method %d is not accelerated",(int) method);
+  }
+  std::unique_ptr<MhKernelInfo,MhKernelInfo *(*)(MhKernelInfo *)> reflected(nullptr,
+    MhDestroyKernelInfo);
+  bool need_reflected=false;
+  for (const Stage &s : stages)
+    need_reflected|=s.reflected;
+  if (need_reflected)
+    {
+      reflected.reset(MhCloneKernelInfo(kernel));
+      if (!reflected)
+        return fail(MH_OUT_OF_MEMORY,"cannot clone kernel");
+      // RotateKernelInfo(reflected_kernel,180), morphology.c:3790: a plain
+      // reversal of every kernel in the list
+      for (MhKernelInfo *k=reflected.get(); k != nullptr; k=k->next)
+        {
+          size_t n=k->width*k->height;
+          for (size_t i=0,j=n-1; i < j; i++,j--)
+            {
+              double t=k->values[i]; k->values[i]=k->values[j]; k->values[j]=t;
+            }
+          k->x=(ptrdiff_t) k->width-k->x-1;
+          k->y=(ptrdiff_t) k->height-k->y-1;
+        }
+    }
+  size_t nkernels=0;
+  for (const MhKernelInfo *k=kernel; k != nullptr; k=k->next)
+    nkernels++;
+  const bool fixed_count=(kernel_limit == 1) && (method_limit == 1);
+  const size_t planned=nkernels*stages.size();
+
+  Temp scratch,counter;
+  View tmp=dst;
+  tmp.pixels=nullptr;
+  MH_TRY(counter.alloc(src.device,sizeof(unsigned long long),src.stream));
+  unsigned long long *changed_dev=counter.as<unsigned long long>();
+  const View *curr=&src;
+  // choose the first destination so a fixed-length chain ends in `dst`
+  bool next_is_dst=fixed_count ? ((planned & 1u) != 0) : true;
+  size_t total_changed=0;
+  const bool want_counts=!fixed_count || (changed_out != nullptr);
+
+  size_t method_loop=0,method_changed=1;
+  while ((method_loop < method_limit) && (method_changed > 0))
+    {
+      method_loop++;
+      method_changed=0;
+      const MhKernelInfo *norm=kernel,*rflt=reflected.get();
+      while (norm != nullptr)
+        {
+          for (const Stage &stage : stages)
+            {
+              const MhKernelInfo *this_kernel=stage.reflected ? rflt : norm;
+              size_t kernel_loop=0;
+              ptrdiff_t changed=1;
+              while ((kernel_loop < kernel_limit) && (changed > 0))
+                {
+                  kernel_loop++;
+                  const View *target;
+                  if (next_is_dst)
+                    target=&dst;
+                  else
+                    {
+                      if (tmp.pixels == nullptr)
+                        {
+                          MH_TRY(scratch.alloc(src.device,dst.bytes(),src.stream));
+                          tmp.pixels=scratch.ptr;
+                        }
+                      target=&tmp;
+                    }
+                  if (want_counts)
+                    MH_HIP(hipMemsetAsync(changed_dev,0,sizeof(unsigned long long),src.stream));
+                  MH_TRY(primitive(*curr,*target,stage.primitive,this_kernel,bias,roles,desc,
+                    want_counts ? changed_dev : nullptr));
+                  if (want_counts)
+                    {
+                      unsigned long long host=0;
+                      MH_HIP(hipMemcpyAsync(&host,changed_dev,sizeof(host),
+                        hipMemcpyDeviceToHost,src.stream));
+                      MH_HIP(hipStreamSynchronize(src.stream));
+                      // changed/GetImageChannels(image), morphology.c:2806, :3225
+                      changed=(ptrdiff_t) (host/(unsigned long long) src.channels);
+                    }
+                  else
+                    changed=1;
+                  total_changed+=(size_t) changed;
+                  method_changed+=(size_t) changed;
+                  curr=target;
+                  next_is_dst=(curr != &dst);
+                }
+            }
+          norm=norm->next;
+          if (rflt != nullptr)
+            rflt=rflt->next;
+        }
+    }
+  if (curr != &dst)
+    MH_TRY(launch_copy(*curr,dst));
+  if (changed_out != nullptr)
+    *changed_out=(ptrdiff_t) total_changed;
+  return MH_OK;
+}
+
+} // namespace mh
+
+using namespace mh;
+
+extern "C" {
+
+MH_API MhStatus MagickHipMorphologyImage(const MhImage *image,MhImage *morphology_image,
+  MhMorphologyMethod method,ptrdiff_t iterations,const MhKernelInfo *kernel,double bias)
+{
+  MH_TRY(gate_pair(image,morphology_image,"MorphologyImage",true));
+  if ((kernel == nullptr) || (kernel->values == nullptr))
+    return fail(MH_BAD_ARGUMENT,"MorphologyImage: null kernel");
+  Pair pair;
+  MH_TRY(pair.open(image,morphology_image));
+  Roles roles=channel_roles(image,morphology_image);
+  MH_TRY(morphology_apply(pair.src.view,pair.dst.view,image,roles,method,iterations,kernel,
+    bias,nullptr));
+  return pair.commit();
+}
+
+MH_API MhStatus MagickHipMorphologyPrimitive(const MhImage *image,MhImage *morphology_image,
+  MhMorphologyMethod method,const MhKernelInfo *kernel,double bias,ptrdiff_t *changed)
+{
+  MH_TRY(gate_pair(image,morphology_image,"MorphologyPrimitive",true));
+  if ((kernel == nullptr) || (kernel->values == nullptr))
+    return fail(MH_BAD_ARGUMENT,"MorphologyPrimitive: null kernel");
+  switch (method)
+  {
+    case MH_MORPHOLOGY_CONVOLVE: case MH_MORPHOLOGY_ERODE: case MH_MORPHOLOGY_DILATE:
+    case MH_MORPHOLOGY_ERODE_INTENSITY: case MH_MORPHOLOGY_DILATE_INTENSITY:
+    case MH_MORPHOLOGY_ITERATIVE_DISTANCE: case MH_MORPHOLOGY_HIT_AND_MISS:
+    case MH_MORPHOLOGY_THINNING: case MH_MORPHOLOGY_THICKEN:
+      break;
+    default:
+      return fail(MH_BAD_ARGUMENT,"not a primitive morphology method");
+  }
+  Pair pair;
+  MH_TRY(pair.open(image,morphology_image));
+  Roles roles=channel_roles(image,morphology_image);
+  Temp counter;
+  MH_TRY(counter.alloc(pair.src.view.device,sizeof(unsigned long long),pair.src.view.stream));
+  MH_HIP(hipMemsetAsync(counter.ptr,0,sizeof(unsigned long long),pair.src.view.stream));
+  MhKernelInfo single=*kernel;
+  single.next=nullptr;
+  MH_TRY(primitive(pair.src.view,pair.dst.view,method,&single,bias,roles,image,
+    counter.as<unsigned long long>()));
+  unsigned long long host=0;
+  MH_HIP(hipMemcpyAsync(&host,counter.ptr,sizeof(host),hipMemcpyDeviceToHost,
+    pair.src.view.stream));
+  MH_HIP(hipStreamSynchronize(pair.src.view.stream));
+  if (changed != nullptr)
+    *changed=(ptrdiff_t) (host/(unsigned long long) image->number_channels);
+  return pair.commit();
+}
+
+MH_API MhStatus MagickHipConvolveImage(const MhImage *image,MhImage *convolve_image,
+  const MhKernelInfo *kernel)
+{
+  // ConvolveImage, effect.c:1170-1178
+  return MagickHipMorphologyImage(image,convolve_image,MH_MORPHOLOGY_CONVOLVE,1,kernel,0.0);
+}
+
+MH_API MhStatus MagickHipBlurImage(const MhImage *image,MhImage *blur_image,
+  double radius,double sigma)
+{
+  // BlurImage, effect.c:765-796: kernel list "blur:RxS;blur:RxS+90", then ConvolveImage
+  MH_TRY(gate_pair(image,blur_image,"BlurImage",true));
+  MhKernelInfo *kernel=acquire_blur_kernels(radius,sigma);
+  if (kernel == nullptr)
+    return fail(MH_BAD_ARGUMENT,"BlurImage: cannot build the blur kernels");
+  MhStatus status=MagickHipConvolveImage(image,blur_image,kernel);
+  MhDestroyKernelInfo(kernel);
+  return status;
+}
+
+MH_API MhStatus MagickHipUnsharpMaskImage(const MhImage *image,MhImage *unsharp_image,
+  double radius,double sigma,double gain,double threshold)
+{
+  // UnsharpMaskImage, effect.c:4256-4400: blur into the destination, then the
+  // threshold/gain epilogue in place
+  MH_TRY(gate_pair(image,unsharp_image,"UnsharpMaskImage",true));
+  MhKernelInfo *kernel=acquire_blur_kernels(radius,sigma);
+  if (kernel == nullptr)
+    return fail(MH_BAD_ARGUMENT,"UnsharpMaskImage: cannot build the blur kernels");
+  Pair pair;
+  MhStatus status=pair.open(image,unsharp_image);
+  if (status == MH_OK)
+    {
+      Roles roles=channel_roles(image,unsharp_image);
+      status=morphology_apply(pair.src.view,pair.dst.view,image,roles,MH_MORPHOLOGY_CONVOLVE,1,
+        kernel,0.0,nullptr);
+      if (status == MH_OK)
+        status=launch_unsharp_epilogue(pair.src.view,pair.dst.view,pair.dst.view,gain,threshold,
+          roles);
+    }
+  MhDestroyKernelInfo(kernel);
+  if (status != MH_OK)
+    return status;
+  return pair.commit();
+}
+
+// ResizeImage, resize.c:3761-3874
+MH_API MhStatus MagickHipResizeImageWithFilter(const MhImage *image,MhImage *resize_image,
+  const MhResizeFilter *filter)
+{
+  MH_TRY(gate_pair(image,resize_image,"ResizeImage",false));
+  if (filter == nullptr)
+    return fail(MH_BAD_ARGUMENT,"ResizeImage: null filter");
+  const size_t columns=resize_image->columns,rows=resize_image->rows;
+  // resize.c:3804-3805: a multiply by the reciprocal, not a division
+  const double x_factor=(double) ((double) columns*(1.0/(double) image->columns));
+  const double y_factor=(double) ((double) rows*(1.0/(double) image->rows));
+  Pair pair;
+  MH_TRY(pair.open(image,resize_image));
+  // destination traits decide Blend/Copy (resize.c:3494); alpha comes from the source
+  Roles roles=channel_roles(image,resize_image);
+  View filter_view=pair.src.view;
+  Temp scratch;
+  TapTable horizontal,vertical;
+  if (x_factor > y_factor)
+    {
+      // HorizontalFilter then VerticalFilter, resize.c:3846-3853
+      filter_view.columns=columns;
+      filter_view.rows=image->rows;
+      MH_TRY(scratch.alloc(pair.src.view.device,filter_view.bytes(),pair.src.view.stream));
+      filter_view.pixels=scratch.ptr;
+      build_tap_table(horizontal,filter,image->columns,columns,x_factor);
+      build_tap_table(vertical,filter,image->rows,rows,y_factor);
+      MH_TRY(launch_resize_pass(pair.src.view,filter_view,false,horizontal,roles,precision()));
+      MH_TRY(launch_resize_pass(filter_view,pair.dst.view,true,vertical,roles,precision()));
+    }
+  else
+    {
+      filter_view.columns=image->columns;
+      filter_view.rows=rows;
+      MH_TRY(scratch.alloc(pair.src.view.device,filter_view.bytes(),pair.src.view.stream));
+      filter_view.pixels=scratch.ptr;
+      build_tap_table(vertical,filter,image->rows,rows,y_factor);
+      build_tap_table(horizontal,filter,image->columns,columns,x_factor);
+      MH_TRY(launch_resize_pass(pair.src.view,filter_view,true,vertical,roles,precision()));
+      MH_TRY(launch_resize_pass(filter_view,pair.dst.view,false,horizontal,roles,precision()));
+    }
+  return pair.commit();
+}
+
+MH_API MhStatus MagickHipResizeImage(const MhImage *image,MhImage *resize_image,
+  MhFilterType filter)
+{
+  MH_TRY(gate_pair(image,resize_image,"ResizeImage",false));
+  // default filter choice, resize.c:3806-3816
+  MhFilterType type=filter;
+  if (type == MH_FILTER_UNDEFINED)
+    {
+      const double x_factor=(double) ((double) resize_image->columns*(1.0/(double) image->columns));
+      const double y_factor=(double) ((double) resize_image->rows*(1.0/(double) image->rows));
+      type=MH_FILTER_LANCZOS;
+      if ((x_factor == 1.0) && (y_factor == 1.0))
+        type=MH_FILTER_POINT;
+      else if ((image->alpha_trait != MH_TRAIT_UNDEFINED) || ((x_factor*y_factor) > 1.0))
+        type=MH_FILTER_MITCHELL;
+    }
+  MhResizeFilter *f=MhAcquireResizeFilter(type,0);
+  if (f == nullptr)
+    return fail(MH_UNSUPPORTED,"ResizeImage: filter %d is not available",(int) type);
+  MhStatus status=MagickHipResizeImageWithFilter(image,resize_image,f);
+  MhDestroyResizeFilter(f);
+  return status;
+}
+
+} // extern "C"

@@ -1,0 +1,353 @@
+// In-place operators: ContrastStretchImage, EqualizeImage,
+// TransformImageColorspace, and the histogram / LUT building blocks they are
+// made of (exposed so a row-sharded image can all-reduce the histogram between
+// the phases — SURVEY §8e).
+//
+// The histogram and the LUT application are HIP kernels (pointwise.hip); the
+// 65536-entry scans that turn a histogram into a LUT are restated here on the
+// host from MagickCore/enhance.c:1652-1706 (contrast stretch) and :2138-2169
+// (equalize), in the reference's arithmetic.
+#include "mh_internal.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace mh {
+
+static double perceptible_reciprocal(double x)
+{
+  double sign=x < 0.0 ? -1.0 : 1.0;
+  if ((sign*x) >= kMagickEpsilon)
+    return 1.0/x;
+  return sign/kMagickEpsilon;
+}
+
+// ScaleMapToQuantum, quantum-private.h:465-476, result as the Quantum it
+// would be stored in (unsigned short or float), widened to double
+static double scale_map_to_quantum(double value,MhQuantumKind quantum)
+{
+  if (value <= 0.0)
+    return 0.0;
+  if (value >= (double) MH_MAXMAP)
+    return kQuantumRange;
+  if (quantum == MH_QUANTUM_U16)
+    return (double) (unsigned short) (value+0.5);
+  return (double) (float) value;
+}
+
+struct InPlace
+{
+  Resident img;
+  MhStatus open(MhImage *image)
+  {
+    int device=resolve_device(image);
+    hipStream_t stream=image->memory == MH_MEMORY_DEVICE ? (hipStream_t) image->stream :
+      library_stream(device);
+    MH_TRY(img.open(image,2,stream,device));
+    img.view.stream=stream;
+    img.view.device=device;
+    MH_HIP(hipSetDevice(device));
+    return MH_OK;
+  }
+};
+
+static MhStatus check_image(const MhImage *image,const char *what)
+{
+  MH_TRY(runtime_ready());
+  MH_TRY(validate_image(image,what));
+  return MH_OK;
+}
+
+// device histogram -> host
+static MhStatus histogram_to_host(const View &view,int mode,const MhImage *desc,
+  std::vector<unsigned long long> &host)
+{
+  const size_t n=(size_t) MH_HISTOGRAM_BINS*(size_t) view.channels;
+  Temp hist;
+  MH_TRY(hist.alloc(view.device,n*sizeof(unsigned long long),view.stream));
+  MH_HIP(hipMemsetAsync(hist.ptr,0,n*sizeof(unsigned long long),view.stream));
+  MH_TRY(launch_histogram(view,mode,desc,hist.as<unsigned long long>()));
+  host.resize(n);
+  MH_HIP(hipMemcpyAsync(host.data(),hist.ptr,n*sizeof(unsigned long long),
+    hipMemcpyDeviceToHost,view.stream));
+  MH_HIP(hipStreamSynchronize(view.stream));
+  return MH_OK;
+}
+
+// LUT (double, Quantum-valued) -> device LUT in the image's Quantum type -> apply
+static MhStatus apply_lut_host(const View &view,const MhImage *desc,const double *lut,
+  uint32_t apply_mask)
+{
+  const size_t n=(size_t) MH_HISTOGRAM_BINS*(size_t) view.channels;
+  Temp d_lut;
+  if (view.quantum == MH_QUANTUM_U16)
+    {
+      std::vector<unsigned short> q(n);
+      for (size_t i=0; i < n; i++)
+        {
+          // ClampToQuantum of a value that already is a Quantum
+          double v=lut[i];
+          q[i]=(unsigned short) (!(v > 0.0) ? 0 : (v >= kQuantumRange ? 65535 : (unsigned short) (v+0.5)));
+        }
+      MH_TRY(upload_table(d_lut,view.device,view.stream,q.data(),n*sizeof(unsigned short)));
+    }
+  else
+    {
+      std::vector<float> q(n);
+      for (size_t i=0; i < n; i++)
+        q[i]=(float) lut[i];
+      MH_TRY(upload_table(d_lut,view.device,view.stream,q.data(),n*sizeof(float)));
+    }
+  Roles roles=channel_roles(desc,desc);
+  // enhance.c:1781, :2255: only channels whose traits carry Update
+  uint32_t update=0;
+  for (uint32_t c=0; c < desc->number_channels; c++)
+    if ((desc->channel_traits[c] & MH_TRAIT_UPDATE) != 0)
+      update|=1u<<c;
+  roles.update_mask=update;
+  return launch_apply_lut(view,d_lut.ptr,apply_mask,roles);
+}
+
+} // namespace mh
+
+using namespace mh;
+
+extern "C" {
+
+MH_API MhStatus MhContrastStretchLUT(const uint64_t *histogram,uint32_t number_channels,
+  size_t columns,size_t rows,double black_point,double white_point,MhQuantumKind quantum,
+  double *lut,uint32_t *apply_mask)
+{
+  if ((histogram == nullptr) || (lut == nullptr) || (number_channels == 0) ||
+      (number_channels > MH_MAX_CHANNELS))
+    return fail(MH_BAD_ARGUMENT,"ContrastStretchLUT: bad arguments");
+  const size_t C=number_channels;
+  uint32_t mask=0;
+  memset(lut,0,(size_t) MH_HISTOGRAM_BINS*C*sizeof(double));
+  for (size_t i=0; i < C; i++)
+    {
+      // locate the black/white levels, enhance.c:1652-1678.  black[] / white[]
+      // are Quantum-typed in the reference; the indices fit either kind exactly.
+      double intensity=0.0;
+      ptrdiff_t j;
+      for (j=0; j <= (ptrdiff_t) MH_MAXMAP; j++)
+        {
+          intensity+=(double) histogram[C*(size_t) j+i];
+          if (intensity > black_point)
+            break;
+        }
+      const double black=(double) j;
+      intensity=0.0;
+      for (j=(ptrdiff_t) MH_MAXMAP; j != 0; j--)
+        {
+          intensity+=(double) histogram[C*(size_t) j+i];
+          if (intensity > ((double) columns*(double) rows-white_point))
+            break;
+        }
+      const double white=(double) j;
+      // stretch map, enhance.c:1685-1706
+      for (j=0; j <= (ptrdiff_t) MH_MAXMAP; j++)
+        {
+          double gamma=perceptible_reciprocal(white-black);
+          if (j < (ptrdiff_t) black)
+            lut[C*(size_t) j+i]=0.0;
+          else if (j > (ptrdiff_t) white)
+            lut[C*(size_t) j+i]=kQuantumRange;
+          else if (black != white)
+            lut[C*(size_t) j+i]=scale_map_to_quantum(
+              (double) ((double) MH_MAXMAP*gamma*((double) j-black)),quantum);
+        }
+      if (black != white)
+        mask|=1u<<i;
+    }
+  if (apply_mask != nullptr)
+    *apply_mask=mask;
+  return MH_OK;
+}
+
+MH_API MhStatus MhEqualizeLUT(const uint64_t *histogram,uint32_t number_channels,
+  MhQuantumKind quantum,double *lut,uint32_t *apply_mask)
+{
+  if ((histogram == nullptr) || (lut == nullptr) || (number_channels == 0) ||
+      (number_channels > MH_MAX_CHANNELS))
+    return fail(MH_BAD_ARGUMENT,"EqualizeLUT: bad arguments");
+  const size_t C=number_channels;
+  uint32_t mask=0;
+  std::vector<double> map((size_t) MH_HISTOGRAM_BINS);
+  memset(lut,0,(size_t) MH_HISTOGRAM_BINS*C*sizeof(double));
+  for (size_t i=0; i < C; i++)
+    {
+      // integrate, enhance.c:2138-2152
+      double intensity=0.0;
+      for (size_t j=0; j <= MH_MAXMAP; j++)
+        {
+          intensity+=(double) histogram[C*j+i];
+          map[j]=intensity;
+        }
+      const double black=map[0],white=map[MH_MAXMAP];
+      if (black != white)
+        {
+          // enhance.c:2162-2168
+          for (size_t j=0; j <= MH_MAXMAP; j++)
+            lut[C*j+i]=scale_map_to_quantum(
+              (double) (((double) MH_MAXMAP*(map[j]-black))/(white-black)),quantum);
+          mask|=1u<<i;
+        }
+    }
+  if (apply_mask != nullptr)
+    *apply_mask=mask;
+  return MH_OK;
+}
+
+MH_API MhStatus MagickHipHistogram(const MhImage *image,int intensity_mode,uint64_t *histogram)
+{
+  MH_TRY(check_image(image,"Histogram"));
+  if (histogram == nullptr)
+    return fail(MH_BAD_ARGUMENT,"Histogram: null histogram");
+  const size_t n=(size_t) MH_HISTOGRAM_BINS*(size_t) image->number_channels;
+  if (image->memory == MH_MEMORY_DEVICE)
+    {
+      Resident img;
+      MH_TRY(img.open(image,0,nullptr,-1));
+      MH_HIP(hipSetDevice(img.view.device));
+      return launch_histogram(img.view,intensity_mode,image,
+        reinterpret_cast<unsigned long long *>(histogram));
+    }
+  Resident img;
+  int device=resolve_device(image);
+  MH_TRY(img.open(image,0,library_stream(device),device));
+  MH_HIP(hipSetDevice(device));
+  std::vector<unsigned long long> host;
+  MH_TRY(histogram_to_host(img.view,intensity_mode,image,host));
+  for (size_t i=0; i < n; i++)
+    histogram[i]+=host[i];
+  return img.commit();
+}
+
+MH_API MhStatus MagickHipApplyLUT(MhImage *image,const double *lut,uint32_t apply_mask)
+{
+  MH_TRY(check_image(image,"ApplyLUT"));
+  if (lut == nullptr)
+    return fail(MH_BAD_ARGUMENT,"ApplyLUT: null LUT");
+  InPlace io;
+  MH_TRY(io.open(image));
+  MH_TRY(apply_lut_host(io.img.view,image,lut,apply_mask));
+  return io.img.commit();
+}
+
+MH_API MhStatus MagickHipIsImageGray(const MhImage *image,int *is_gray)
+{
+  MH_TRY(check_image(image,"IsImageGray"));
+  if (is_gray == nullptr)
+    return fail(MH_BAD_ARGUMENT,"IsImageGray: null result");
+  const uint32_t colour=image->number_channels-(image->alpha_offset >= 0 ? 1u : 0u);
+  if (colour < 3)
+    {
+      *is_gray=1;
+      return MH_OK;
+    }
+  Resident img;
+  int device=resolve_device(image);
+  MH_TRY(img.open(image,0,image->memory == MH_MEMORY_DEVICE ? (hipStream_t) image->stream :
+    library_stream(device),device));
+  MH_HIP(hipSetDevice(img.view.device));
+  Temp flag;
+  MH_TRY(flag.alloc(img.view.device,sizeof(unsigned int),img.view.stream));
+  MH_HIP(hipMemsetAsync(flag.ptr,0,sizeof(unsigned int),img.view.stream));
+  MH_TRY(launch_gray_check(img.view,image,flag.as<unsigned int>()));
+  unsigned int host=0;
+  MH_HIP(hipMemcpyAsync(&host,flag.ptr,sizeof(host),hipMemcpyDeviceToHost,img.view.stream));
+  MH_HIP(hipStreamSynchronize(img.view.stream));
+  *is_gray=host == 0 ? 1 : 0;
+  return MH_OK;
+}
+
+// ContrastStretchImage, enhance.c:1544-1818
+MH_API MhStatus MagickHipContrastStretchImage(MhImage *image,double black_point,
+  double white_point,int *became_gray)
+{
+  MH_TRY(check_image(image,"ContrastStretchImage"));
+  if (became_gray != nullptr)
+    *became_gray=0;
+  InPlace io;
+  MH_TRY(io.open(image));
+  const View &view=io.img.view;
+  // IdentifyImageType side effect, enhance.c:1586-1588: a colour image whose
+  // pixels are all gray is re-laid-out as a GRAY image by the reference; that
+  // is the caller's job (SetImageColorspace), so hand such images back.
+  const uint32_t colour=image->number_channels-(image->alpha_offset >= 0 ? 1u : 0u);
+  if ((colour >= 3) && ((image->colorspace == MH_COLORSPACE_SRGB) ||
+      (image->colorspace == MH_COLORSPACE_RGB)))
+    {
+      Temp flag;
+      MH_TRY(flag.alloc(view.device,sizeof(unsigned int),view.stream));
+      MH_HIP(hipMemsetAsync(flag.ptr,0,sizeof(unsigned int),view.stream));
+      MH_TRY(launch_gray_check(view,image,flag.as<unsigned int>()));
+      unsigned int host=0;
+      MH_HIP(hipMemcpyAsync(&host,flag.ptr,sizeof(host),hipMemcpyDeviceToHost,view.stream));
+      MH_HIP(hipStreamSynchronize(view.stream));
+      if (host == 0)
+        {
+          if (became_gray != nullptr)
+            *became_gray=1;
+          return fail(MH_UNSUPPORTED,"ContrastStretchImage: image is gray; convert it to the "
+            "GRAY colourspace first (IdentifyImageType, enhance.c:1586)");
+        }
+    }
+  // enhance.c:1637-1643: every channel bins the intensity under the default mask
+  const int mode=image->channel_mask == MH_ALL_CHANNELS ? 1 : 0;
+  std::vector<unsigned long long> hist;
+  MH_TRY(histogram_to_host(view,mode,image,hist));
+  std::vector<double> lut((size_t) MH_HISTOGRAM_BINS*image->number_channels);
+  uint32_t mask=0;
+  MH_TRY(MhContrastStretchLUT(reinterpret_cast<const uint64_t *>(hist.data()),
+    image->number_channels,image->columns,image->rows,black_point,white_point,
+    (MhQuantumKind) image->quantum,lut.data(),&mask));
+  MH_TRY(apply_lut_host(view,image,lut.data(),mask));
+  return io.img.commit();
+}
+
+// EqualizeImage, enhance.c:2040-2280
+MH_API MhStatus MagickHipEqualizeImage(MhImage *image)
+{
+  MH_TRY(check_image(image,"EqualizeImage"));
+  InPlace io;
+  MH_TRY(io.open(image));
+  const View &view=io.img.view;
+  const int mode=(image->channel_mask & MH_SYNC_CHANNELS) != 0 ? 1 : 0;   // enhance.c:2125-2129
+  std::vector<unsigned long long> hist;
+  MH_TRY(histogram_to_host(view,mode,image,hist));
+  std::vector<double> lut((size_t) MH_HISTOGRAM_BINS*image->number_channels);
+  uint32_t mask=0;
+  MH_TRY(MhEqualizeLUT(reinterpret_cast<const uint64_t *>(hist.data()),image->number_channels,
+    (MhQuantumKind) image->quantum,lut.data(),&mask));
+  MH_TRY(apply_lut_host(view,image,lut.data(),mask));
+  return io.img.commit();
+}
+
+// TransformImageColorspace, colorspace.c:1751-1783
+MH_API MhStatus MagickHipTransformImageColorspace(MhImage *image,MhColorspace colorspace)
+{
+  MH_TRY(check_image(image,"TransformImageColorspace"));
+  const MhColorspace from=(MhColorspace) image->colorspace;
+  if (from == colorspace)
+    return MH_OK;
+  auto supported=[](MhColorspace c)
+  {
+    return (c == MH_COLORSPACE_SRGB) || (c == MH_COLORSPACE_RGB) || (c == MH_COLORSPACE_LAB) ||
+      (c == MH_COLORSPACE_XYZ);
+  };
+  if (!supported(from) || !supported(colorspace))
+    return fail(MH_UNSUPPORTED,"colourspace %d -> %d is not accelerated",(int) from,(int) colorspace);
+  const uint32_t colour=image->number_channels-(image->alpha_offset >= 0 ? 1u : 0u);
+  if (colour != 3)
+    return fail(MH_UNSUPPORTED,"colourspace transform needs three colour channels");
+  InPlace io;
+  MH_TRY(io.open(image));
+  MH_TRY(launch_colorspace(io.img.view,from,colorspace,image));
+  MH_TRY(io.img.commit());
+  image->colorspace=(uint32_t) colorspace;
+  return MH_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,701 @@
+// Pointwise and reduction kernels: colourspace transforms, LUT apply,
+// histogram, gray scan, the unsharp-mask epilogue and a plain copy.
+//
+// All of these stream every pixel once (HBM-bound): lanes take consecutive
+// pixels with the widest load the pixel size allows, grid-stride over the
+// image, >= 2048 workgroups.
+//
+// Reference semantics restated from:
+//   DecodePixelGamma / EncodePixelGamma   MagickCore/pixel.c:260-324, :380-451
+//   ConvertRGBToXYZ / XYZToLab / LabToXYZ / XYZToRGB
+//                                          MagickCore/colorspace-private.h:759-779, :1066-1089, :531-557, :72-94
+//   sRGBTransformImage / TransformsRGBImage MagickCore/colorspace.c:1031-1049, :1203-1214, :2373-2381, :2541-2552
+//   GetPixelIntensity                      MagickCore/pixel.c:2356-2455
+//   histogram / LUT apply                  MagickCore/enhance.c:1616-1647, :1778-1788, :2102-2133, :2252-2262
+//   IdentifyImageGray                      MagickCore/attribute.c:1564-1626
+//   UnsharpMaskImage epilogue              MagickCore/effect.c:4343-4372
+#include "mh_internal.hpp"
+#include "device_common.hpp"
+
+namespace mh {
+
+// --------------------------------------------------------------- sRGB gamma
+// x^2.4 via frexp + 9-term Chebyshev + power-of-two table, pixel.c:260-316
+static __device__ double decode_gamma(double x)
+{
+  const double c0=1.7917488588043277509,c1=0.82045614371976854984,
+    c2=0.027694100686325412819,c3=-0.00094244335181762134018,
+    c4=0.000064355540911469709545,c5=-5.7224404636060757485e-06,
+    c6=5.8767669437311184313e-07,c7=-6.6139920053589721168e-08,
+    c8=7.9323242696227458163e-09;
+  int exponent;
+  double t0=1.0;
+  double t1=4.0*frexp(x,&exponent)-3.0;
+  double t2=2.0*t1*t1-t0;
+  double t3=2.0*t1*t2-t1;
+  double t4=2.0*t1*t3-t2;
+  double t5=2.0*t1*t4-t3;
+  double t6=2.0*t1*t5-t4;
+  double t7=2.0*t1*t6-t5;
+  double t8=2.0*t1*t7-t6;
+  double p=c0*t0+c1*t1+c2*t2+c3*t3+c4*t4+c5*t5+c6*t6+c7*t7+c8*t8;
+  int e=exponent-1;
+  int quot=e/5,rem=e%5;            // div(): truncation toward zero
+  if (rem < 0)
+    {
+      quot-=1;
+      rem+=5;
+    }
+  double pw;
+  switch (rem)
+  {
+    case 0: pw=1.0; break;
+    case 1: pw=2.6390158215457883983; break;
+    case 2: pw=6.9644045063689921093; break;
+    case 3: pw=1.8379173679952558018e+01; break;
+    default: pw=4.8502930128332728543e+01; break;
+  }
+  return x*ldexp(pw*p,7*quot);
+}
+
+// x^(5/12), pixel.c:380-443
+static __device__ double encode_gamma(double x)
+{
+  const double c0=1.1758200232996901923,c1=0.16665763094889061230,
+    c2=-0.0083154894939042125035,c3=0.00075187976780420279038,
+    c4=-0.000083240178519391795367,c5=0.000010229209410070008679,
+    c6=-1.3400466409860246e-06,c7=1.8333422241635376682e-07,
+    c8=-2.5878596761348859722e-08;
+  int exponent;
+  double t0=1.0;
+  double t1=4.0*frexp(x,&exponent)-3.0;
+  double t2=2.0*t1*t1-t0;
+  double t3=2.0*t1*t2-t1;
+  double t4=2.0*t1*t3-t2;
+  double t5=2.0*t1*t4-t3;
+  double t6=2.0*t1*t5-t4;
+  double t7=2.0*t1*t6-t5;
+  double t8=2.0*t1*t7-t6;
+  double p=c0*t0+c1*t1+c2*t2+c3*t3+c4*t4+c5*t5+c6*t6+c7*t7+c8*t8;
+  int e=exponent-1;
+  int quot=e/12,rem=e%12;
+  if (rem < 0)
+    {
+      quot-=1;
+      rem+=12;
+    }
+  double pw;
+  switch (rem)
+  {
+    case 0: pw=1.0; break;
+    case 1: pw=1.3348398541700343678; break;
+    case 2: pw=1.7817974362806785482; break;
+    case 3: pw=2.3784142300054420538; break;
+    case 4: pw=3.1748021039363991669; break;
+    case 5: pw=4.2378523774371812394; break;
+    case 6: pw=5.6568542494923805819; break;
+    case 7: pw=7.5509945014535482244; break;
+    case 8: pw=1.0079368399158985525e1; break;
+    case 9: pw=1.3454342644059433809e1; break;
+    case 10: pw=1.7959392772949968275e1; break;
+    default: pw=2.3972913230026907883e1; break;
+  }
+  return ldexp(pw*p,5*quot);
+}
+
+// DecodePixelGamma, pixel.c:318-324
+static __device__ double decode_pixel_gamma(double pixel)
+{
+  if (pixel <= (0.0404482362771076*kQR))
+    return pixel/12.92;
+  return kQR*decode_gamma((double) (kQS*pixel+0.055)/1.055);
+}
+
+// EncodePixelGamma, pixel.c:445-451
+static __device__ double encode_pixel_gamma(double pixel)
+{
+  if (pixel <= (0.0031306684425005883*kQR))
+    return 12.92*pixel;
+  return kQR*(1.055*encode_gamma(kQS*pixel)-0.055);
+}
+
+// D65, colorspace-private.h:25-44
+#define MH_ILL_X 0.95047
+#define MH_ILL_Y 1.00000
+#define MH_ILL_Z 1.08883
+#define MH_CIE_EPSILON (216.0/24389.0)
+#define MH_CIE_K (24389.0/27.0)
+
+// ConvertRGBToXYZ, colorspace-private.h:759-779
+static __device__ void rgb_to_xyz(double red,double green,double blue,double &X,double &Y,double &Z)
+{
+  double r=kQS*decode_pixel_gamma(red);
+  double g=kQS*decode_pixel_gamma(green);
+  double b=kQS*decode_pixel_gamma(blue);
+  X=(0.4123955889674142161*r)+(0.3575834307637148171*g)+(0.1804926473817015735*b);
+  Y=(0.2125862307855955516*r)+(0.7151703037034108499*g)+(0.07220049864333622685*b);
+  Z=(0.01929721549174694484*r)+(0.1191838645808485318*g)+(0.9504971251315797660*b);
+}
+
+// ConvertXYZToRGB, colorspace-private.h:72-94
+static __device__ void xyz_to_rgb(double X,double Y,double Z,double &red,double &green,double &blue)
+{
+  double r=(3.240969941904521*X)+(-1.537383177570093*Y)+(-0.498610760293*Z);
+  double g=(-0.96924363628087*X)+(1.87596750150772*Y)+(0.041555057407175*Z);
+  double b=(0.055630079696993*X)+(-0.20397695888897*Y)+(1.056971514242878*Z);
+  double gb=g < b ? g : b;
+  double mn=r < gb ? r : gb;
+  if (mn < 0.0)
+    {
+      r-=mn;
+      g-=mn;
+      b-=mn;
+    }
+  red=encode_pixel_gamma(kQR*r);
+  green=encode_pixel_gamma(kQR*g);
+  blue=encode_pixel_gamma(kQR*b);
+}
+
+// ConvertXYZToLab, colorspace-private.h:1066-1089
+static __device__ void xyz_to_lab(double X,double Y,double Z,double &L,double &a,double &b)
+{
+  double x,y,z;
+  if ((X/MH_ILL_X) > MH_CIE_EPSILON)
+    x=pow(X/MH_ILL_X,1.0/3.0);
+  else
+    x=(MH_CIE_K*X/MH_ILL_X+16.0)/116.0;
+  if ((Y/MH_ILL_Y) > MH_CIE_EPSILON)
+    y=pow(Y/MH_ILL_Y,1.0/3.0);
+  else
+    y=(MH_CIE_K*Y/MH_ILL_Y+16.0)/116.0;
+  if ((Z/MH_ILL_Z) > MH_CIE_EPSILON)
+    z=pow(Z/MH_ILL_Z,1.0/3.0);
+  else
+    z=(MH_CIE_K*Z/MH_ILL_Z+16.0)/116.0;
+  L=((116.0*y)-16.0)/100.0;
+  a=(500.0*(x-y))/255.0+0.5;
+  b=(200.0*(y-z))/255.0+0.5;
+}
+
+// ConvertLabToXYZ, colorspace-private.h:531-557
+static __device__ void lab_to_xyz(double L,double a,double b,double &X,double &Y,double &Z)
+{
+  double y=(L+16.0)/116.0;
+  double x=y+a/500.0;
+  double z=y-b/200.0;
+  if ((x*x*x) > MH_CIE_EPSILON)
+    x=(x*x*x);
+  else
+    x=(116.0*x-16.0)/MH_CIE_K;
+  if (L > (MH_CIE_K*MH_CIE_EPSILON))
+    y=(y*y*y);
+  else
+    y=L/MH_CIE_K;
+  if ((z*z*z) > MH_CIE_EPSILON)
+    z=(z*z*z);
+  else
+    z=(116.0*z-16.0)/MH_CIE_K;
+  X=MH_ILL_X*x;
+  Y=MH_ILL_Y*y;
+  Z=MH_ILL_Z*z;
+}
+
+enum ColorOp
+{
+  OP_SRGB_TO_RGB,OP_RGB_TO_SRGB,OP_SRGB_TO_LAB,OP_LAB_TO_SRGB,OP_SRGB_TO_XYZ,OP_XYZ_TO_SRGB
+};
+
+template<typename Q,int C,int OP>
+__global__ __launch_bounds__(256)
+void colorspace_kernel(Q *pixels,size_t npixels)
+{
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
+    {
+      Q q[C];
+      load_pixel<Q,C>(pixels+i*C,q);
+      double r=(double) q[0],g=(double) q[1],b=(double) q[2];
+      double o0,o1,o2;
+      if constexpr (OP == OP_SRGB_TO_RGB)
+        {
+          o0=decode_pixel_gamma(r);
+          o1=decode_pixel_gamma(g);
+          o2=decode_pixel_gamma(b);
+        }
+      else if constexpr (OP == OP_RGB_TO_SRGB)
+        {
+          o0=encode_pixel_gamma(r);
+          o1=encode_pixel_gamma(g);
+          o2=encode_pixel_gamma(b);
+        }
+      else if constexpr (OP == OP_SRGB_TO_LAB)
+        {
+          double X,Y,Z,L,a,bb;
+          rgb_to_xyz(r,g,b,X,Y,Z);
+          xyz_to_lab(X,Y,Z,L,a,bb);
+          o0=kQR*L; o1=kQR*a; o2=kQR*bb;          // colorspace.c:1041-1043
+        }
+      else if constexpr (OP == OP_SRGB_TO_XYZ)
+        {
+          double X,Y,Z;
+          rgb_to_xyz(r,g,b,X,Y,Z);
+          o0=kQR*X; o1=kQR*Y; o2=kQR*Z;
+        }
+      else if constexpr (OP == OP_LAB_TO_SRGB)
+        {
+          // ConvertGenericToRGB(QuantumScale*R,...) -> ConvertLabToRGB, colorspace.c:2373-2377
+          double L=kQS*r,a=kQS*g,bb=kQS*b,X,Y,Z;
+          lab_to_xyz(100.0*L,255.0*(a-0.5),255.0*(bb-0.5),X,Y,Z);
+          xyz_to_rgb(X,Y,Z,o0,o1,o2);
+        }
+      else
+        {
+          xyz_to_rgb(kQS*r,kQS*g,kQS*b,o0,o1,o2);
+        }
+      q[0]=QuantumOps<Q>::clamp(o0);
+      q[1]=QuantumOps<Q>::clamp(o1);
+      q[2]=QuantumOps<Q>::clamp(o2);
+      store_pixel<Q,C>(pixels+i*C,q);
+    }
+}
+
+static unsigned stream_grid(size_t npixels)
+{
+  size_t blocks=(npixels+255)/256;
+  if (blocks > 8192)
+    blocks=8192;
+  if (blocks < 1)
+    blocks=1;
+  return (unsigned) blocks;
+}
+
+template<typename Q,int C>
+static MhStatus colorspace_typed(const View &img,int op)
+{
+  const size_t n=img.columns*img.rows;
+  Q *p=static_cast<Q *>(img.pixels);
+  dim3 grid(stream_grid(n)),block(256);
+  ProfileScope prof("colorspace",img.stream);
+  switch (op)
+  {
+    case OP_SRGB_TO_RGB: hipLaunchKernelGGL((colorspace_kernel<Q,C,OP_SRGB_TO_RGB>),grid,block,0,img.stream,p,n); break;
+    case OP_RGB_TO_SRGB: hipLaunchKernelGGL((colorspace_kernel<Q,C,OP_RGB_TO_SRGB>),grid,block,0,img.stream,p,n); break;
+    case OP_SRGB_TO_LAB: hipLaunchKernelGGL((colorspace_kernel<Q,C,OP_SRGB_TO_LAB>),grid,block,0,img.stream,p,n); break;
+    case OP_LAB_TO_SRGB: hipLaunchKernelGGL((colorspace_kernel<Q,C,OP_LAB_TO_SRGB>),grid,block,0,img.stream,p,n); break;
+    case OP_SRGB_TO_XYZ: hipLaunchKernelGGL((colorspace_kernel<Q,C,OP_SRGB_TO_XYZ>),grid,block,0,img.stream,p,n); break;
+    default: hipLaunchKernelGGL((colorspace_kernel<Q,C,OP_XYZ_TO_SRGB>),grid,block,0,img.stream,p,n); break;
+  }
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+static MhStatus colorspace_step(const View &img,int op)
+{
+  if (img.quantum == MH_QUANTUM_U16)
+    return img.channels == 3 ? colorspace_typed<uint16_t,3>(img,op) :
+      colorspace_typed<uint16_t,4>(img,op);
+  return img.channels == 3 ? colorspace_typed<float,3>(img,op) :
+    colorspace_typed<float,4>(img,op);
+}
+
+MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,const MhImage *)
+{
+  if ((img.channels != 3) && (img.channels != 4))
+    return fail(MH_UNSUPPORTED,"colourspace transform needs R,G,B[,A] channels");
+  // TransformImageColorspace, colorspace.c:1751-1783: X -> sRGB -> Y
+  if (from != MH_COLORSPACE_SRGB)
+    {
+      int op;
+      switch (from)
+      {
+        case MH_COLORSPACE_RGB: op=OP_RGB_TO_SRGB; break;
+        case MH_COLORSPACE_LAB: op=OP_LAB_TO_SRGB; break;
+        case MH_COLORSPACE_XYZ: op=OP_XYZ_TO_SRGB; break;
+        default: return fail(MH_UNSUPPORTED,"source colourspace %d is not accelerated",(int) from);
+      }
+      MH_TRY(colorspace_step(img,op));
+    }
+  if (to != MH_COLORSPACE_SRGB)
+    {
+      int op;
+      switch (to)
+      {
+        case MH_COLORSPACE_RGB: op=OP_SRGB_TO_RGB; break;
+        case MH_COLORSPACE_LAB: op=OP_SRGB_TO_LAB; break;
+        case MH_COLORSPACE_XYZ: op=OP_SRGB_TO_XYZ; break;
+        default: return fail(MH_UNSUPPORTED,"target colourspace %d is not accelerated",(int) to);
+      }
+      MH_TRY(colorspace_step(img,op));
+    }
+  return MH_OK;
+}
+
+// ---------------------------------------------------------------- intensity
+struct IntensityParams
+{
+  int method;        // MhIntensityMethod
+  int linear;        // colourspace is linear RGB / LinearGRAY
+  int nonlinear;     // colourspace is sRGB / GRAY
+  int gray;          // R,G,B all live at offset 0 (GRAY / LinearGRAY image)
+};
+
+// GetPixelIntensity, pixel.c:2356-2455
+template<typename Q,int C>
+static __device__ __forceinline__ double pixel_intensity(const Q (&q)[C],const IntensityParams &ip)
+{
+  double red=(double) q[0];
+  if (C == 1)
+    return red;
+  double green=(double) q[(C >= 3) && !ip.gray ? 1 : 0];
+  double blue=(double) q[(C >= 3) && !ip.gray ? 2 : 0];
+  switch (ip.method)
+  {
+    case MH_INTENSITY_AVERAGE:
+      return (red+green+blue)/3.0;
+    case MH_INTENSITY_BRIGHTNESS:
+    {
+      double m=red > green ? red : green;
+      return m > blue ? m : blue;
+    }
+    case MH_INTENSITY_LIGHTNESS:
+    {
+      double mn=red < green ? red : green;
+      mn=mn < blue ? mn : blue;
+      double mx=red > green ? red : green;
+      mx=mx > blue ? mx : blue;
+      return (mn+mx)/2.0;
+    }
+    case MH_INTENSITY_MS:
+      return (red*red+green*green+blue*blue)/(3.0*kQR);
+    case MH_INTENSITY_REC601LUMA:
+      if (ip.linear)
+        {
+          red=encode_pixel_gamma(red);
+          green=encode_pixel_gamma(green);
+          blue=encode_pixel_gamma(blue);
+        }
+      return 0.298839*red+0.586811*green+0.114350*blue;
+    case MH_INTENSITY_REC601LUMINANCE:
+      if (ip.nonlinear)
+        {
+          red=decode_pixel_gamma(red);
+          green=decode_pixel_gamma(green);
+          blue=decode_pixel_gamma(blue);
+        }
+      return 0.298839*red+0.586811*green+0.114350*blue;
+    case MH_INTENSITY_REC709LUMINANCE:
+      if (ip.nonlinear)
+        {
+          red=decode_pixel_gamma(red);
+          green=decode_pixel_gamma(green);
+          blue=decode_pixel_gamma(blue);
+        }
+      return 0.212656*red+0.715158*green+0.072186*blue;
+    case MH_INTENSITY_RMS:
+      return sqrt(red*red+green*green+blue*blue)/sqrt(3.0);
+    default:
+      break;
+  }
+  if (ip.linear)
+    {
+      red=encode_pixel_gamma(red);
+      green=encode_pixel_gamma(green);
+      blue=encode_pixel_gamma(blue);
+    }
+  return 0.212656*red+0.715158*green+0.072186*blue;
+}
+
+static IntensityParams intensity_params(const MhImage *desc)
+{
+  IntensityParams ip;
+  ip.method=(int) desc->intensity;
+  ip.linear=(desc->colorspace == MH_COLORSPACE_RGB) || (desc->colorspace == MH_COLORSPACE_LINEARGRAY);
+  ip.nonlinear=(desc->colorspace == MH_COLORSPACE_SRGB) || (desc->colorspace == MH_COLORSPACE_GRAY);
+  ip.gray=(desc->colorspace == MH_COLORSPACE_GRAY) || (desc->colorspace == MH_COLORSPACE_LINEARGRAY) ||
+    (desc->number_channels < 3);
+  return ip;
+}
+
+// ---------------------------------------------------------------- histogram
+// 65536 bins x C channels of 64-bit counts (0.5-2 MiB) do not fit LDS, so the
+// counts live in global memory (L2 / Infinity-Cache resident) and are updated
+// with device-scope atomics.  Two things keep the atomic traffic down:
+//   * in intensity mode every channel bins the same value, so only channel 0
+//     is accumulated and a 65536-element kernel replicates it afterwards;
+//   * when neighbouring lanes agree on the bin (smooth images, 8-bit data) the
+//     wave folds equal bins first and issues one atomic per distinct bin.
+static __device__ __forceinline__ void histogram_add(unsigned long long *counts,unsigned bin,
+  int stride,int c,bool valid)
+{
+  const int lane=(int) (threadIdx.x & 63);
+  unsigned neighbour=__shfl(bin,(lane+1) & 63,64);
+  unsigned long long agree=__ballot(valid && (neighbour == bin));
+  if (__popcll(agree) < 16)
+    {
+      if (valid)
+        atomicAdd(counts+(size_t) bin*stride+c,1ull);
+      return;
+    }
+  // match-any by leader election over the still-unserved lanes
+  unsigned long long remaining=__ballot(valid);
+  while (remaining != 0)
+    {
+      int leader=__ffsll((long long) remaining)-1;
+      unsigned leader_bin=__shfl(bin,leader,64);
+      unsigned long long same=__ballot(valid && (bin == leader_bin)) & remaining;
+      if (lane == leader)
+        atomicAdd(counts+(size_t) leader_bin*stride+c,(unsigned long long) __popcll(same));
+      remaining&=~same;
+    }
+}
+
+template<typename Q,int C>
+__global__ __launch_bounds__(256)
+void histogram_kernel(const Q *pixels,size_t npixels,int intensity_mode,IntensityParams ip,
+  unsigned long long *counts)
+{
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  const size_t rounds=(npixels+stride-1)/stride;
+  size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x;
+  for (size_t k=0; k < rounds; k++,i+=stride)
+    {
+      const bool valid=i < npixels;
+      Q q[C];
+      load_pixel<Q,C>(pixels+(valid ? i : 0)*C,q);
+      if (intensity_mode)
+        {
+          // ScaleQuantumToMap(ClampToQuantum(intensity)): every channel bins the same value
+          unsigned bin=QuantumOps<Q>::map_index(QuantumOps<Q>::clamp(pixel_intensity<Q,C>(q,ip)));
+          histogram_add(counts,bin,C,0,valid);
+        }
+      else
+        {
+#pragma unroll
+          for (int c=0; c < C; c++)
+            {
+              unsigned bin=QuantumOps<Q>::map_index(QuantumOps<Q>::clamp((double) q[c]));
+              histogram_add(counts,bin,C,c,valid);
+            }
+        }
+    }
+}
+
+// intensity mode: channel 0 holds this call's counts (added on top of what the
+// caller passed in); propagate the increment to the other channels
+__global__ __launch_bounds__(256)
+void histogram_replicate_kernel(unsigned long long *counts,const unsigned long long *before,int channels)
+{
+  unsigned bin=blockIdx.x*blockDim.x+threadIdx.x;
+  if (bin > 65535u)
+    return;
+  unsigned long long delta=counts[(size_t) bin*channels]-before[bin];
+  for (int c=1; c < channels; c++)
+    counts[(size_t) bin*channels+c]+=delta;
+}
+
+__global__ __launch_bounds__(256)
+void histogram_snapshot_kernel(const unsigned long long *counts,unsigned long long *before,int channels)
+{
+  unsigned bin=blockIdx.x*blockDim.x+threadIdx.x;
+  if (bin <= 65535u)
+    before[bin]=counts[(size_t) bin*channels];
+}
+
+template<typename Q,int C>
+static MhStatus histogram_typed(const View &src,int mode,const IntensityParams &ip,
+  unsigned long long *hist)
+{
+  const size_t n=src.columns*src.rows;
+  Temp before;
+  if ((mode != 0) && (C > 1))
+    {
+      MH_TRY(before.alloc(src.device,65536*sizeof(unsigned long long),src.stream));
+      hipLaunchKernelGGL(histogram_snapshot_kernel,dim3(256),dim3(256),0,src.stream,hist,
+        before.as<unsigned long long>(),C);
+    }
+  {
+    ProfileScope prof("histogram",src.stream);
+    hipLaunchKernelGGL((histogram_kernel<Q,C>),dim3(stream_grid(n)),dim3(256),0,src.stream,
+      static_cast<const Q *>(src.pixels),n,mode,ip,hist);
+  }
+  if ((mode != 0) && (C > 1))
+    hipLaunchKernelGGL(histogram_replicate_kernel,dim3(256),dim3(256),0,src.stream,hist,
+      before.as<unsigned long long>(),C);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+MhStatus launch_histogram(const View &src,int intensity_mode,const MhImage *desc,
+  unsigned long long *hist)
+{
+  IntensityParams ip=intensity_params(desc);
+#define MH_CASE(QT) \
+  switch (src.channels) { \
+    case 1: return histogram_typed<QT,1>(src,intensity_mode,ip,hist); \
+    case 2: return histogram_typed<QT,2>(src,intensity_mode,ip,hist); \
+    case 3: return histogram_typed<QT,3>(src,intensity_mode,ip,hist); \
+    default: return histogram_typed<QT,4>(src,intensity_mode,ip,hist); }
+  if (src.quantum == MH_QUANTUM_U16)
+    { MH_CASE(uint16_t) }
+  MH_CASE(float)
+#undef MH_CASE
+}
+
+// ---------------------------------------------------------------- LUT apply
+template<typename Q,int C>
+__global__ __launch_bounds__(256)
+void apply_lut_kernel(Q *pixels,size_t npixels,const Q *lut,uint32_t mask)
+{
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
+    {
+      Q q[C];
+      load_pixel<Q,C>(pixels+i*C,q);
+#pragma unroll
+      for (int c=0; c < C; c++)
+        if ((mask >> c) & 1u)
+          q[c]=lut[(size_t) QuantumOps<Q>::map_index(q[c])*C+c];
+      store_pixel<Q,C>(pixels+i*C,q);
+    }
+}
+
+template<typename Q,int C>
+static MhStatus apply_lut_typed(const View &img,const void *lut,uint32_t mask)
+{
+  const size_t n=img.columns*img.rows;
+  ProfileScope prof("apply_lut",img.stream);
+  hipLaunchKernelGGL((apply_lut_kernel<Q,C>),dim3(stream_grid(n)),dim3(256),0,img.stream,
+    static_cast<Q *>(img.pixels),n,static_cast<const Q *>(lut),mask);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+MhStatus launch_apply_lut(const View &img,const void *lut,uint32_t apply_mask,const Roles &roles)
+{
+  uint32_t mask=apply_mask & roles.update_mask;
+#define MH_CASE(QT) \
+  switch (img.channels) { \
+    case 1: return apply_lut_typed<QT,1>(img,lut,mask); \
+    case 2: return apply_lut_typed<QT,2>(img,lut,mask); \
+    case 3: return apply_lut_typed<QT,3>(img,lut,mask); \
+    default: return apply_lut_typed<QT,4>(img,lut,mask); }
+  if (img.quantum == MH_QUANTUM_U16)
+    { MH_CASE(uint16_t) }
+  MH_CASE(float)
+#undef MH_CASE
+}
+
+// ---------------------------------------------------------------- gray scan
+template<typename Q,int C>
+__global__ __launch_bounds__(256)
+void gray_check_kernel(const Q *pixels,size_t npixels,unsigned int *not_gray)
+{
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  bool bad=false;
+  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
+    {
+      Q q[C];
+      load_pixel<Q,C>(pixels+i*C,q);
+      // IsPixelGray, pixel-accessor.h: |red-green| < eps && |green-blue| < eps
+      double rg=(double) q[0]-(double) q[1],gb=(double) q[1]-(double) q[2];
+      if (!((fabs(rg) < kEps) && (fabs(gb) < kEps)))
+        bad=true;
+    }
+  if (__any(bad) && ((threadIdx.x & 63) == 0))
+    atomicOr(not_gray,1u);
+}
+
+MhStatus launch_gray_check(const View &img,const MhImage *,unsigned int *flag)
+{
+  const size_t n=img.columns*img.rows;
+  dim3 grid(stream_grid(n)),block(256);
+  ProfileScope prof("gray_check",img.stream);
+  if (img.quantum == MH_QUANTUM_U16)
+    {
+      if (img.channels == 3)
+        hipLaunchKernelGGL((gray_check_kernel<uint16_t,3>),grid,block,0,img.stream,
+          static_cast<const uint16_t *>(img.pixels),n,flag);
+      else
+        hipLaunchKernelGGL((gray_check_kernel<uint16_t,4>),grid,block,0,img.stream,
+          static_cast<const uint16_t *>(img.pixels),n,flag);
+    }
+  else
+    {
+      if (img.channels == 3)
+        hipLaunchKernelGGL((gray_check_kernel<float,3>),grid,block,0,img.stream,
+          static_cast<const float *>(img.pixels),n,flag);
+      else
+        hipLaunchKernelGGL((gray_check_kernel<float,4>),grid,block,0,img.stream,
+          static_cast<const float *>(img.pixels),n,flag);
+    }
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+// ------------------------------------------------------- unsharp epilogue
+template<typename Q,int C>
+__global__ __launch_bounds__(256)
+void unsharp_kernel(const Q *src,const Q *blur,Q *dst,size_t npixels,double gain,
+  double quantum_threshold,uint32_t copy_mask)
+{
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
+    {
+      Q p[C],b[C],o[C];
+      load_pixel<Q,C>(src+i*C,p);
+      load_pixel<Q,C>(blur+i*C,b);
+#pragma unroll
+      for (int c=0; c < C; c++)
+        {
+          if ((copy_mask >> c) & 1u)
+            {
+              o[c]=p[c];
+              continue;
+            }
+          // effect.c:4364-4369
+          double pixel=(double) p[c]-(double) b[c];
+          if (fabs(2.0*pixel) < quantum_threshold)
+            pixel=(double) p[c];
+          else
+            pixel=(double) p[c]+gain*pixel;
+          o[c]=QuantumOps<Q>::clamp(pixel);
+        }
+      store_pixel<Q,C>(dst+i*C,o);
+    }
+}
+
+template<typename Q,int C>
+static MhStatus unsharp_typed(const View &src,const View &blur,const View &dst,double gain,
+  double threshold,uint32_t copy_mask)
+{
+  const size_t n=src.columns*src.rows;
+  ProfileScope prof("unsharp_epilogue",src.stream);
+  hipLaunchKernelGGL((unsharp_kernel<Q,C>),dim3(stream_grid(n)),dim3(256),0,src.stream,
+    static_cast<const Q *>(src.pixels),static_cast<const Q *>(blur.pixels),
+    static_cast<Q *>(dst.pixels),n,gain,kQuantumRange*threshold,copy_mask);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+MhStatus launch_unsharp_epilogue(const View &src,const View &blur,const View &dst,double gain,
+  double threshold,const Roles &roles)
+{
+#define MH_CASE(QT) \
+  switch (src.channels) { \
+    case 1: return unsharp_typed<QT,1>(src,blur,dst,gain,threshold,roles.copy_mask); \
+    case 2: return unsharp_typed<QT,2>(src,blur,dst,gain,threshold,roles.copy_mask); \
+    case 3: return unsharp_typed<QT,3>(src,blur,dst,gain,threshold,roles.copy_mask); \
+    default: return unsharp_typed<QT,4>(src,blur,dst,gain,threshold,roles.copy_mask); }
+  if (src.quantum == MH_QUANTUM_U16)
+    { MH_CASE(uint16_t) }
+  MH_CASE(float)
+#undef MH_CASE
+}
+
+MhStatus launch_copy(const View &src,const View &dst)
+{
+  MH_HIP(hipMemcpyAsync(dst.pixels,src.pixels,src.bytes(),hipMemcpyDeviceToDevice,src.stream));
+  return MH_OK;
+}
+
+} // namespace mh

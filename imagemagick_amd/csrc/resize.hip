@@ -1,0 +1,406 @@
+// Separable resampling passes of ResizeImage.
+//
+// Reference semantics restated from HorizontalFilter / VerticalFilter
+// (MagickCore/resize.c:3333-3547, :3549-3759).  The contribution lists (start,
+// count, normalised weights) are built on the host in double precision
+// (resize_filter.cpp) — they depend only on the output index — and each pass
+// evaluates, per output sample o and Update channel c,
+//     plain : out = ClampToQuantum( sum_j w[j] * src[start+j] )
+//     blend : a_j = (w[j]*QuantumScale) * alpha_src[start+j]
+//             out = ClampToQuantum( PerceptibleReciprocal(sum a_j) * sum a_j*src[start+j] )
+//     copy  : out = src[nearest]
+// with the sums in ascending j, as the CPU does.
+//
+// MI355X mapping (a 4x Lanczos enlargement writes 16x the pixels it reads, so
+// both passes are bound by the coalesced output stream):
+//   vertical   lane = output column (loads and stores are whole coalesced row
+//              segments); a lane owns RY consecutive output rows and walks the
+//              union of their source rows once, so each source row is fetched
+//              once per RY outputs instead of once per tap; the weights are
+//              wave-uniform and live in SGPRs.
+//   horizontal lane = output column; a workgroup stages the source span of its
+//              256 output columns x TH rows in LDS with coalesced loads, each
+//              lane keeps its own (per-column) weights in registers across the
+//              TH rows and reads its taps from LDS (neighbouring lanes share
+//              taps, so the reads broadcast).
+#include "mh_internal.hpp"
+#include "resize_filter.hpp"
+#include "device_common.hpp"
+
+namespace mh {
+
+struct ResizeArgs
+{
+  const void *src;
+  void *dst;
+  int src_columns,src_rows;
+  int dst_columns,dst_rows;
+  int out_size;               // size of the resampled axis in dst
+  int max_taps;
+  const int *start;
+  const int *count;
+  const int *nearest;
+  const void *weight;         // T[max_taps][out_size]
+  const void *weight_qs;      // T[max_taps][out_size] : weight*QuantumScale
+  const int *tile_lo;         // horizontal pass: first source column of each 256-column tile
+  const int *tile_span;       //                  and the number of source columns it needs
+  uint32_t copy_mask;
+};
+
+// accumulate one tap into (s[],g)
+template<typename Q,int C,bool BLEND,class A>
+struct ResizeAcc
+{
+  typedef typename A::T T;
+  T s[C];
+  T g;
+  __device__ __forceinline__ void init()
+  {
+#pragma unroll
+    for (int c=0; c < C; c++)
+      s[c]=(T) 0;
+    g=(T) 0;
+  }
+  __device__ __forceinline__ void tap(T w,T wq,const Q (&q)[C])
+  {
+    if constexpr (BLEND)
+      {
+        // alpha=weight*QuantumScale*GetPixelAlpha(); pixel+=alpha*p; gamma+=alpha  (resize.c:3515-3520)
+        T a=A::mul(wq,(T) q[C-1]);
+#pragma unroll
+        for (int c=0; c < C-1; c++)
+          s[c]=A::mac(s[c],a,(T) q[c]);
+        g=A::add(g,a);
+        s[C-1]=A::mac(s[C-1],w,(T) q[C-1]);
+      }
+    else
+      {
+#pragma unroll
+        for (int c=0; c < C; c++)
+          s[c]=A::mac(s[c],w,(T) q[c]);           // resize.c:3503-3505
+      }
+  }
+  __device__ __forceinline__ void finish(const Q (&copy)[C],uint32_t copy_mask,Q (&out)[C]) const
+  {
+#pragma unroll
+    for (int c=0; c < C; c++)
+      {
+        if ((copy_mask >> c) & 1u)
+          {
+            out[c]=copy[c];
+            continue;
+          }
+        double pixel=(double) s[c];
+        if (BLEND && (c != C-1))
+          pixel=perceptible_reciprocal((double) g)*pixel;
+        out[c]=QuantumOps<Q>::clamp(pixel);
+      }
+  }
+};
+
+// ------------------------------------------------------------- vertical pass
+template<typename Q,int C,bool BLEND,class A,int RY>
+__global__ __launch_bounds__(256)
+void resize_vertical_kernel(ResizeArgs args)
+{
+  typedef typename A::T T;
+  const int W=args.dst_columns;            // == src_columns
+  const int lane_x=(int) (blockIdx.x*blockDim.x+threadIdx.x);
+  const int y0=(int) blockIdx.y*RY;
+  const int x=lane_x < W ? lane_x : W-1;
+  const Q *src=static_cast<const Q *>(args.src);
+  Q *dst=static_cast<Q *>(args.dst);
+  const T *weight=static_cast<const T *>(args.weight);
+  const T *weight_qs=static_cast<const T *>(args.weight_qs);
+  const size_t pitch=(size_t) W*C;
+  const int OUT=args.out_size;
+
+  ResizeAcc<Q,C,BLEND,A> acc[RY];
+  int start[RY],count[RY];
+  int lo=0x7fffffff,hi=0;
+#pragma unroll
+  for (int r=0; r < RY; r++)
+    {
+      acc[r].init();
+      int y=y0+r;
+      start[r]=0;
+      count[r]=0;
+      if (y < OUT)
+        {
+          start[r]=args.start[y];
+          count[r]=args.count[y];
+          if (count[r] > 0)
+            {
+              lo=start[r] < lo ? start[r] : lo;
+              hi=(start[r]+count[r]) > hi ? (start[r]+count[r]) : hi;
+            }
+        }
+    }
+  for (int sy=lo; sy < hi; sy++)
+    {
+      Q q[C];
+      load_pixel<Q,C>(src+(size_t) sy*pitch+(size_t) x*C,q);
+#pragma unroll
+      for (int r=0; r < RY; r++)
+        {
+          int j=sy-start[r];
+          if ((j >= 0) && (j < count[r]))
+            {
+              size_t wi=(size_t) j*OUT+(size_t) (y0+r);
+              acc[r].tap(weight[wi],BLEND ? weight_qs[wi] : (T) 0,q);
+            }
+        }
+    }
+  if (lane_x >= W)
+    return;
+#pragma unroll
+  for (int r=0; r < RY; r++)
+    {
+      int y=y0+r;
+      if ((y < OUT) && (count[r] > 0))
+        {
+          Q copy[C],out[C];
+#pragma unroll
+          for (int c=0; c < C; c++)
+            copy[c]=(Q) 0;
+          if (args.copy_mask != 0)
+            load_pixel<Q,C>(src+(size_t) args.nearest[y]*pitch+(size_t) x*C,copy);
+          acc[r].finish(copy,args.copy_mask,out);
+          store_pixel<Q,C>(dst+(size_t) y*pitch+(size_t) x*C,out);
+        }
+    }
+}
+
+// ----------------------------------------------------------- horizontal pass
+template<typename Q,int C,bool BLEND,class A,int MAXT>
+__global__ __launch_bounds__(256)
+void resize_horizontal_kernel(ResizeArgs args,int tile_rows)
+{
+  typedef typename A::T T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Q *tile=reinterpret_cast<Q *>(smem_raw);
+  const int OUT=args.out_size;              // dst_columns
+  const int x0=(int) blockIdx.x*256;
+  const int x=x0+(int) threadIdx.x;
+  const int y0=(int) blockIdx.y*tile_rows;
+  const Q *src=static_cast<const Q *>(args.src);
+  Q *dst=static_cast<Q *>(args.dst);
+  const T *weight=static_cast<const T *>(args.weight);
+  const T *weight_qs=static_cast<const T *>(args.weight_qs);
+  const size_t src_pitch=(size_t) args.src_columns*C;
+  const size_t dst_pitch=(size_t) args.dst_columns*C;
+
+  // source span of this tile (computed on the host, wave-uniform)
+  const int lo=args.tile_lo[blockIdx.x],span=args.tile_span[blockIdx.x];
+  int rows=args.dst_rows-y0;
+  rows=rows < tile_rows ? rows : tile_rows;
+  for (int idx=(int) threadIdx.x; idx < span*rows; idx+=256)
+    {
+      int r=idx/span,i=idx-r*span;
+      Q v[C];
+      load_pixel<Q,C>(src+(size_t) (y0+r)*src_pitch+(size_t) (lo+i)*C,v);
+      store_pixel<Q,C>(tile+((size_t) r*span+i)*C,v);
+    }
+  __syncthreads();
+  if (x >= OUT)
+    return;
+  const int start=args.start[x]-lo;
+  const int count=args.count[x];
+  if (count <= 0)
+    return;
+  const int nearest=args.nearest[x]-lo;
+  T w[MAXT > 0 ? MAXT : 1],wq[MAXT > 0 ? MAXT : 1];
+  if constexpr (MAXT > 0)
+    {
+#pragma unroll
+      for (int j=0; j < MAXT; j++)
+        {
+          w[j]=(T) 0;
+          wq[j]=(T) 0;
+          if (j < count)
+            {
+              w[j]=weight[(size_t) j*OUT+x];
+              if constexpr (BLEND)
+                wq[j]=weight_qs[(size_t) j*OUT+x];
+            }
+        }
+    }
+  for (int r=0; r < rows; r++)
+    {
+      const Q *line=tile+(size_t) r*span*C;
+      ResizeAcc<Q,C,BLEND,A> acc;
+      acc.init();
+      if constexpr (MAXT > 0)
+        {
+#pragma unroll
+          for (int j=0; j < MAXT; j++)
+            if (j < count)
+              {
+                Q q[C];
+                load_pixel<Q,C>(line+(size_t) (start+j)*C,q);
+                acc.tap(w[j],wq[j],q);
+              }
+        }
+      else
+        {
+          for (int j=0; j < count; j++)
+            {
+              Q q[C];
+              load_pixel<Q,C>(line+(size_t) (start+j)*C,q);
+              T wj=weight[(size_t) j*OUT+x];
+              T wqj=BLEND ? weight_qs[(size_t) j*OUT+x] : (T) 0;
+              acc.tap(wj,wqj,q);
+            }
+        }
+      Q copy[C],out[C];
+      load_pixel<Q,C>(line+(size_t) nearest*C,copy);
+      acc.finish(copy,args.copy_mask,out);
+      store_pixel<Q,C>(dst+(size_t) (y0+r)*dst_pitch+(size_t) x*C,out);
+    }
+}
+
+// ---------------------------------------------------------------- launcher
+template<typename Q,int C,bool BLEND,class A>
+static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
+  const TapTable &table,const Roles &roles)
+{
+  typedef typename A::T T;
+  const size_t n=(size_t) table.max_taps*(size_t) table.out_size;
+  std::vector<T> w(n),wq(n);
+  for (size_t i=0; i < n; i++)
+    {
+      w[i]=(T) table.weight[i];
+      wq[i]=(T) (table.weight[i]*kQuantumScale);     // contribution.weight*QuantumScale
+    }
+  Temp d_start,d_count,d_near,d_w,d_wq;
+  const size_t ib=(size_t) table.out_size*sizeof(int);
+  MH_TRY(upload_table(d_start,src.device,src.stream,table.start.data(),ib));
+  MH_TRY(upload_table(d_count,src.device,src.stream,table.count.data(),ib));
+  MH_TRY(upload_table(d_near,src.device,src.stream,table.nearest.data(),ib));
+  MH_TRY(upload_table(d_w,src.device,src.stream,w.data(),n*sizeof(T)));
+  MH_TRY(upload_table(d_wq,src.device,src.stream,wq.data(),n*sizeof(T)));
+
+  ResizeArgs args;
+  args.src=src.pixels;
+  args.dst=dst.pixels;
+  args.src_columns=(int) src.columns;
+  args.src_rows=(int) src.rows;
+  args.dst_columns=(int) dst.columns;
+  args.dst_rows=(int) dst.rows;
+  args.out_size=table.out_size;
+  args.max_taps=table.max_taps;
+  args.start=d_start.as<int>();
+  args.count=d_count.as<int>();
+  args.nearest=d_near.as<int>();
+  args.weight=d_w.ptr;
+  args.weight_qs=d_wq.ptr;
+  args.copy_mask=roles.copy_mask;
+  args.tile_lo=nullptr;
+  args.tile_span=nullptr;
+
+  if (vertical)
+    {
+      constexpr int RY=4;
+      dim3 grid((unsigned) ((dst.columns+255)/256),(unsigned) ((dst.rows+RY-1)/RY));
+      ProfileScope prof("resize_vertical",src.stream);
+      hipLaunchKernelGGL((resize_vertical_kernel<Q,C,BLEND,A,RY>),grid,dim3(256),0,src.stream,args);
+    }
+  else
+    {
+      // widest source span of any 256-column tile decides how many rows fit in LDS
+      int max_span=1;
+      std::vector<int> tile_lo,tile_span;
+      for (int x0=0; x0 < table.out_size; x0+=256)
+        {
+          int xh=(x0+255) < table.out_size ? (x0+255) : table.out_size-1;
+          int lo=table.start[(size_t) x0],hi=0;
+          for (int i=x0; i <= xh; i++)
+            {
+              int s=table.start[(size_t) i],e=s+table.count[(size_t) i];
+              lo=s < lo ? s : lo;
+              hi=e > hi ? e : hi;
+            }
+          if (hi < lo)
+            hi=lo;
+          tile_lo.push_back(lo);
+          tile_span.push_back(hi-lo);
+          if ((hi-lo) > max_span)
+            max_span=hi-lo;
+        }
+      Temp d_lo,d_span;
+      MH_TRY(upload_table(d_lo,src.device,src.stream,tile_lo.data(),tile_lo.size()*sizeof(int)));
+      MH_TRY(upload_table(d_span,src.device,src.stream,tile_span.data(),tile_span.size()*sizeof(int)));
+      args.tile_lo=d_lo.as<int>();
+      args.tile_span=d_span.as<int>();
+      const size_t px=(size_t) C*sizeof(Q);
+      const size_t budget=60u*1024u;
+      if ((size_t) max_span*px > 150u*1024u)
+        return fail(MH_UNSUPPORTED,"resize: source span of %d pixels does not fit LDS",max_span);
+      int tile_rows=(int) (budget/((size_t) max_span*px));
+      tile_rows=tile_rows < 1 ? 1 : (tile_rows > 16 ? 16 : tile_rows);
+      size_t lds=(size_t) max_span*px*(size_t) tile_rows;
+      dim3 grid((unsigned) ((dst.columns+255)/256),(unsigned) ((dst.rows+tile_rows-1)/tile_rows));
+      ProfileScope prof("resize_horizontal",src.stream);
+      if (table.max_taps <= 8)
+        {
+          if (lds > 64u*1024u)
+            MH_HIP(hipFuncSetAttribute(
+              reinterpret_cast<const void *>(&resize_horizontal_kernel<Q,C,BLEND,A,8>),
+              hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+          hipLaunchKernelGGL((resize_horizontal_kernel<Q,C,BLEND,A,8>),grid,dim3(256),lds,
+            src.stream,args,tile_rows);
+        }
+      else
+        {
+          if (lds > 64u*1024u)
+            MH_HIP(hipFuncSetAttribute(
+              reinterpret_cast<const void *>(&resize_horizontal_kernel<Q,C,BLEND,A,0>),
+              hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+          hipLaunchKernelGGL((resize_horizontal_kernel<Q,C,BLEND,A,0>),grid,dim3(256),lds,
+            src.stream,args,tile_rows);
+        }
+    }
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+template<typename Q,class A>
+static MhStatus dispatch(const View &src,const View &dst,bool vertical,const TapTable &table,
+  const Roles &roles)
+{
+  const bool blend=roles.blend && (roles.alpha == src.channels-1);
+  switch (src.channels)
+  {
+    case 1: return launch_typed<Q,1,false,A>(src,dst,vertical,table,roles);
+    case 2:
+      if (blend) return launch_typed<Q,2,true,A>(src,dst,vertical,table,roles);
+      return launch_typed<Q,2,false,A>(src,dst,vertical,table,roles);
+    case 3: return launch_typed<Q,3,false,A>(src,dst,vertical,table,roles);
+    case 4:
+      if (blend) return launch_typed<Q,4,true,A>(src,dst,vertical,table,roles);
+      return launch_typed<Q,4,false,A>(src,dst,vertical,table,roles);
+    default: break;
+  }
+  return fail(MH_UNSUPPORTED,"%d channels",src.channels);
+}
+
+MhStatus launch_resize_pass(const View &src,const View &dst,bool vertical,
+  const TapTable &table,const Roles &roles,MhPrecision prec)
+{
+  if ((src.channels != dst.channels) || (src.quantum != dst.quantum))
+    return fail(MH_BAD_ARGUMENT,"resize: layout mismatch");
+  if (vertical ? ((src.columns != dst.columns) || ((int) dst.rows != table.out_size)) :
+                 ((src.rows != dst.rows) || ((int) dst.columns != table.out_size)))
+    return fail(MH_BAD_ARGUMENT,"resize: geometry mismatch");
+  if (roles.blend && (roles.alpha != src.channels-1))
+    return fail(MH_UNSUPPORTED,"alpha channel must be the last channel");
+  if (src.quantum == MH_QUANTUM_U16)
+    {
+      if (prec == MH_PRECISION_FAST)
+        return dispatch<uint16_t,Fast32>(src,dst,vertical,table,roles);
+      return dispatch<uint16_t,Exact64>(src,dst,vertical,table,roles);
+    }
+  return dispatch<float,Exact64>(src,dst,vertical,table,roles);
+}
+
+} // namespace mh

@@ -1,0 +1,594 @@
+// Host runtime of libmagickhip.so: device discovery, enable/precision state,
+// streams, the workspace pool, host<->HBM staging of pixel-cache buffers and
+// hipEvent kernel profiling.  This replaces what MagickCore/opencl.c does for
+// the reference's OpenCL path (device pick opencl.c:2289-2430, queues
+// opencl.c:656, profiling opencl.c:2704) with a HIP-native equivalent; none of
+// that file's structure is reused.
+#include "mh_internal.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <strings.h>
+
+namespace mh {
+
+// ------------------------------------------------------------------ errors
+static thread_local char g_error[512] = "";
+
+void set_error(const char *fmt,...)
+{
+  va_list ap;
+  va_start(ap,fmt);
+  vsnprintf(g_error,sizeof(g_error),fmt,ap);
+  va_end(ap);
+}
+
+MhStatus fail(MhStatus status,const char *fmt,...)
+{
+  va_list ap;
+  va_start(ap,fmt);
+  vsnprintf(g_error,sizeof(g_error),fmt,ap);
+  va_end(ap);
+  return status;
+}
+
+// ------------------------------------------------------------------- state
+struct PoolBlock { void *ptr; size_t bytes; hipStream_t stream; };
+
+struct DeviceState
+{
+  hipStream_t stream=nullptr;
+  std::multimap<size_t,PoolBlock> free_blocks;   // by capacity
+  std::map<void *,size_t> live;                  // ptr -> capacity
+  size_t cached_bytes=0;
+};
+
+struct Runtime
+{
+  std::once_flag once;
+  MhStatus init_status=MH_NO_DEVICE;
+  int ndevices=0;
+  int default_device=0;
+  int enabled=1;
+  MhPrecision precision=MH_PRECISION_EXACT;
+  std::vector<DeviceState> devices;
+  std::mutex lock;
+  // profiling
+  int profiling=0;
+  struct Pending { const char *name; hipEvent_t start,stop; };
+  std::vector<Pending> pending;
+  struct Rec { unsigned long count=0; double min_ms=1e300,max_ms=0,total_ms=0; };
+  std::map<std::string,Rec> records;
+  std::vector<std::string> record_names;   // stable storage for returned names
+};
+
+static Runtime &rt()
+{
+  static Runtime *r=new Runtime();   // intentionally leaked: safe at exit
+  return *r;
+}
+
+static void do_init()
+{
+  Runtime &r=rt();
+  const char *env=getenv("MAGICK_HIP_DEVICE");
+  if ((env != nullptr) && ((strcasecmp(env,"off") == 0) ||
+      (strcasecmp(env,"false") == 0) || (strcasecmp(env,"cpu") == 0)))
+    r.enabled=0;
+  env=getenv("MAGICK_HIP_PRECISION");
+  if ((env != nullptr) && (strcasecmp(env,"fast") == 0))
+    r.precision=MH_PRECISION_FAST;
+  int n=0;
+  hipError_t err=hipGetDeviceCount(&n);
+  if ((err != hipSuccess) || (n <= 0))
+    {
+      r.ndevices=0;
+      r.init_status=MH_NO_DEVICE;
+      set_error("no HIP device: %s",err != hipSuccess ? hipGetErrorString(err) :
+        "device count is 0");
+      (void) hipGetLastError();
+      return;
+    }
+  r.ndevices=n;
+  r.devices.resize((size_t) n);
+  env=getenv("MAGICK_HIP_DEVICE");
+  if ((env != nullptr) && (env[0] >= '0') && (env[0] <= '9'))
+    {
+      int d=atoi(env);
+      if (d < n)
+        r.default_device=d;
+    }
+  r.init_status=MH_OK;
+}
+
+MhStatus runtime_ready()
+{
+  Runtime &r=rt();
+  std::call_once(r.once,do_init);
+  if (r.enabled == 0)
+    return fail(MH_DISABLED,"magickhip is disabled");
+  if (r.init_status != MH_OK)
+    return fail(r.init_status,"no usable HIP device");
+  return MH_OK;
+}
+
+int default_device() { return rt().default_device; }
+int device_count() { Runtime &r=rt(); std::call_once(r.once,do_init); return r.ndevices; }
+MhPrecision precision() { return rt().precision; }
+
+hipStream_t library_stream(int device)
+{
+  Runtime &r=rt();
+  std::lock_guard<std::mutex> guard(r.lock);
+  DeviceState &d=r.devices[(size_t) device];
+  if (d.stream == nullptr)
+    {
+      int prev=0;
+      (void) hipGetDevice(&prev);
+      (void) hipSetDevice(device);
+      if (hipStreamCreateWithFlags(&d.stream,hipStreamNonBlocking) != hipSuccess)
+        d.stream=nullptr;
+      (void) hipSetDevice(prev);
+    }
+  return d.stream;
+}
+
+// -------------------------------------------------------------------- pool
+static constexpr size_t kPoolGranule = 2u<<20;       // 2 MiB
+static constexpr size_t kPoolSmall = 256;            // alignment of tiny tables
+
+MhStatus pool_alloc(int device,size_t bytes,hipStream_t stream,void **ptr)
+{
+  Runtime &r=rt();
+  if (bytes == 0)
+    bytes=kPoolSmall;
+  size_t capacity=bytes <= (64u<<10) ? ((bytes+kPoolSmall-1)/kPoolSmall)*kPoolSmall :
+    ((bytes+kPoolGranule-1)/kPoolGranule)*kPoolGranule;
+  {
+    std::lock_guard<std::mutex> guard(r.lock);
+    DeviceState &d=r.devices[(size_t) device];
+    auto it=d.free_blocks.lower_bound(capacity);
+    // accept a cached block up to 25% larger than needed
+    if ((it != d.free_blocks.end()) && (it->first <= capacity+capacity/4+kPoolGranule))
+      {
+        PoolBlock b=it->second;
+        d.free_blocks.erase(it);
+        d.cached_bytes-=b.bytes;
+        d.live[b.ptr]=b.bytes;
+        if (b.stream != stream)
+          {
+            // last used on another stream: order behind it
+            (void) hipStreamSynchronize(b.stream);
+          }
+        *ptr=b.ptr;
+        return MH_OK;
+      }
+  }
+  int prev=0;
+  (void) hipGetDevice(&prev);
+  if (prev != device)
+    (void) hipSetDevice(device);
+  void *p=nullptr;
+  hipError_t err=hipMalloc(&p,capacity);
+  if (err != hipSuccess)
+    {
+      (void) hipGetLastError();
+      pool_trim();
+      err=hipMalloc(&p,capacity);
+    }
+  if (prev != device)
+    (void) hipSetDevice(prev);
+  if (err != hipSuccess)
+    {
+      (void) hipGetLastError();
+      return fail(MH_OUT_OF_MEMORY,"hipMalloc(%zu) failed: %s",capacity,
+        hipGetErrorString(err));
+    }
+  {
+    std::lock_guard<std::mutex> guard(r.lock);
+    r.devices[(size_t) device].live[p]=capacity;
+  }
+  *ptr=p;
+  return MH_OK;
+}
+
+void pool_free(int device,void *ptr,hipStream_t stream)
+{
+  if (ptr == nullptr)
+    return;
+  Runtime &r=rt();
+  std::lock_guard<std::mutex> guard(r.lock);
+  DeviceState &d=r.devices[(size_t) device];
+  auto it=d.live.find(ptr);
+  if (it == d.live.end())
+    return;
+  PoolBlock b{ptr,it->second,stream};
+  d.live.erase(it);
+  d.free_blocks.emplace(b.bytes,b);
+  d.cached_bytes+=b.bytes;
+}
+
+void pool_trim()
+{
+  Runtime &r=rt();
+  std::vector<std::pair<int,void *>> victims;
+  {
+    std::lock_guard<std::mutex> guard(r.lock);
+    for (size_t i=0; i < r.devices.size(); i++)
+      {
+        for (auto &kv : r.devices[i].free_blocks)
+          victims.emplace_back((int) i,kv.second.ptr);
+        r.devices[i].free_blocks.clear();
+        r.devices[i].cached_bytes=0;
+      }
+  }
+  if (victims.empty())
+    return;
+  (void) hipDeviceSynchronize();
+  for (auto &v : victims)
+    (void) hipFree(v.second);
+}
+
+MhStatus upload_table(Temp &dst,int device,hipStream_t stream,const void *host,size_t bytes)
+{
+  MH_TRY(dst.alloc(device,bytes,stream));
+  // pageable source: the runtime stages it before returning, so `host` may be
+  // released by the caller right away.
+  MH_HIP(hipMemcpyAsync(dst.ptr,host,bytes,hipMemcpyHostToDevice,stream));
+  return MH_OK;
+}
+
+// ------------------------------------------------------------ image checks
+MhStatus validate_image(const MhImage *image,const char *what)
+{
+  if (image == nullptr)
+    return fail(MH_BAD_ARGUMENT,"%s: null image",what);
+  if ((image->pixels == nullptr) || (image->columns == 0) || (image->rows == 0))
+    return fail(MH_BAD_ARGUMENT,"%s: empty image",what);
+  if ((image->number_channels == 0) || (image->number_channels > MH_MAX_CHANNELS))
+    return fail(MH_UNSUPPORTED,"%s: %u channels (gate admits 1..%d)",what,
+      image->number_channels,MH_MAX_CHANNELS);
+  if ((image->quantum != MH_QUANTUM_U16) && (image->quantum != MH_QUANTUM_F32))
+    return fail(MH_BAD_ARGUMENT,"%s: unknown quantum kind %u",what,image->quantum);
+  if ((image->memory != MH_MEMORY_HOST) && (image->memory != MH_MEMORY_DEVICE))
+    return fail(MH_BAD_ARGUMENT,"%s: unknown memory kind %u",what,image->memory);
+  if ((image->alpha_offset >= (int32_t) image->number_channels))
+    return fail(MH_BAD_ARGUMENT,"%s: alpha offset out of range",what);
+  if ((image->columns > 0x7fffffffu) || (image->rows > 0x7fffffffu))
+    return fail(MH_UNSUPPORTED,"%s: geometry exceeds 2^31",what);
+  return MH_OK;
+}
+
+int resolve_device(const MhImage *image)
+{
+  if ((image != nullptr) && (image->device >= 0) && (image->device < device_count()))
+    return image->device;
+  return default_device();
+}
+
+hipStream_t resolve_stream(const MhImage *image,int device)
+{
+  if ((image != nullptr) && (image->memory == MH_MEMORY_DEVICE))
+    return (hipStream_t) image->stream;     // NULL => the device's null stream
+  return library_stream(device);
+}
+
+Roles channel_roles(const MhImage *src,const MhImage *dst)
+{
+  Roles roles;
+  const MhImage *t=dst != nullptr ? dst : src;
+  roles.alpha=src->alpha_offset;
+  for (uint32_t c=0; c < src->number_channels; c++)
+    {
+      uint32_t st=src->channel_traits[c];
+      uint32_t dt=t->channel_traits[c];
+      if ((st == MH_TRAIT_UNDEFINED) || (dt == MH_TRAIT_UNDEFINED) ||
+          ((st & MH_TRAIT_COPY) != 0))
+        roles.copy_mask|=1u<<c;
+      else
+        roles.update_mask|=1u<<c;
+    }
+  // morphology.c:2743-2744 / :2929-2930: alpha weighting needs the image to
+  // have an active alpha and the destination channel to carry Blend.
+  bool any_blend=false;
+  for (uint32_t c=0; c < src->number_channels; c++)
+    if ((t->channel_traits[c] & MH_TRAIT_BLEND) != 0)
+      any_blend=true;
+  roles.blend=((src->alpha_trait & MH_TRAIT_BLEND) != 0) && any_blend &&
+    (roles.alpha >= 0);
+  return roles;
+}
+
+// ---------------------------------------------------------------- Resident
+Resident::~Resident()
+{
+  if (registered_ && (image_ != nullptr))
+    (void) hipHostUnregister(image_->pixels);
+}
+
+MhStatus Resident::open(const MhImage *image,int mode,hipStream_t stream_hint,int device_hint)
+{
+  image_=image;
+  mode_=mode;
+  view.columns=image->columns;
+  view.rows=image->rows;
+  view.channels=(int) image->number_channels;
+  view.quantum=(MhQuantumKind) image->quantum;
+  if (image->memory == MH_MEMORY_DEVICE)
+    {
+      view.device=resolve_device(image);
+      view.stream=(hipStream_t) image->stream;
+      view.pixels=image->pixels;
+      return MH_OK;
+    }
+  view.device=device_hint >= 0 ? device_hint : resolve_device(image);
+  view.stream=stream_hint != nullptr ? stream_hint : library_stream(view.device);
+  MH_TRY(temp_.alloc(view.device,view.bytes(),view.stream));
+  view.pixels=temp_.ptr;
+  staged_=true;
+  // Pin the pixel-cache block for DMA (cache.c:3754-3758 allocates it with
+  // AcquireAlignedMemory, so page-locking it in place is legal).
+  if (hipHostRegister(image->pixels,view.bytes(),hipHostRegisterDefault) == hipSuccess)
+    registered_=true;
+  else
+    (void) hipGetLastError();
+  if ((mode == 0) || (mode == 2))
+    MH_HIP(hipMemcpyAsync(view.pixels,image->pixels,view.bytes(),
+      hipMemcpyHostToDevice,view.stream));
+  return MH_OK;
+}
+
+MhStatus Resident::commit()
+{
+  if (!staged_)
+    return MH_OK;
+  if ((mode_ == 1) || (mode_ == 2))
+    MH_HIP(hipMemcpyAsync(image_->pixels,view.pixels,view.bytes(),
+      hipMemcpyDeviceToHost,view.stream));
+  MH_HIP(hipStreamSynchronize(view.stream));
+  return MH_OK;
+}
+
+// --------------------------------------------------------------- profiling
+ProfileScope::ProfileScope(const char *n,hipStream_t s) : name(n), stream(s)
+{
+  Runtime &r=rt();
+  if (r.profiling == 0)
+    return;
+  if ((hipEventCreate(&start) != hipSuccess) || (hipEventCreate(&stop) != hipSuccess))
+    return;
+  on=true;
+  (void) hipEventRecord(start,stream);
+}
+
+ProfileScope::~ProfileScope()
+{
+  if (!on)
+    return;
+  (void) hipEventRecord(stop,stream);
+  Runtime &r=rt();
+  std::lock_guard<std::mutex> guard(r.lock);
+  r.pending.push_back({name,start,stop});
+}
+
+static void drain_profile()
+{
+  Runtime &r=rt();
+  std::vector<Runtime::Pending> pending;
+  {
+    std::lock_guard<std::mutex> guard(r.lock);
+    pending.swap(r.pending);
+  }
+  for (auto &p : pending)
+    {
+      float ms=0.0f;
+      if ((hipEventSynchronize(p.stop) == hipSuccess) &&
+          (hipEventElapsedTime(&ms,p.start,p.stop) == hipSuccess))
+        {
+          std::lock_guard<std::mutex> guard(r.lock);
+          Runtime::Rec &rec=r.records[p.name];
+          rec.count++;
+          rec.total_ms+=ms;
+          if (ms < rec.min_ms) rec.min_ms=ms;
+          if (ms > rec.max_ms) rec.max_ms=ms;
+        }
+      (void) hipEventDestroy(p.start);
+      (void) hipEventDestroy(p.stop);
+    }
+}
+
+} // namespace mh
+
+// ===================================================================== C ABI
+using namespace mh;
+
+extern "C" {
+
+MH_API MhStatus MhInitialize(void)
+{
+  Runtime &r=rt();
+  std::call_once(r.once,do_init);
+  return r.init_status;
+}
+
+MH_API void MhTerminus(void)
+{
+  Runtime &r=rt();
+  if (r.init_status != MH_OK)
+    return;
+  drain_profile();
+  pool_trim();
+}
+
+MH_API int MhDeviceCount(void) { return device_count(); }
+
+MH_API MhStatus MhSetDevice(int device)
+{
+  if ((device < 0) || (device >= device_count()))
+    return fail(MH_BAD_ARGUMENT,"device %d out of range",device);
+  rt().default_device=device;
+  return MH_OK;
+}
+
+MH_API int MhGetEnabled(void)
+{
+  Runtime &r=rt();
+  std::call_once(r.once,do_init);
+  return r.enabled;
+}
+
+MH_API int MhSetEnabled(int enabled)
+{
+  Runtime &r=rt();
+  std::call_once(r.once,do_init);
+  r.enabled=enabled != 0 ? 1 : 0;
+  return r.enabled;
+}
+
+MH_API const char *MhGetLastError(void) { return g_error; }
+
+MH_API const char *MhGetVersion(void) { return "magickhip 0.1 (gfx950)"; }
+
+MH_API MhPrecision MhGetPrecision(void)
+{
+  Runtime &r=rt();
+  std::call_once(r.once,do_init);
+  return r.precision;
+}
+
+MH_API MhPrecision MhSetPrecision(MhPrecision p)
+{
+  Runtime &r=rt();
+  std::call_once(r.once,do_init);
+  r.precision=(p == MH_PRECISION_FAST) ? MH_PRECISION_FAST : MH_PRECISION_EXACT;
+  return r.precision;
+}
+
+MH_API MhStatus MhDeviceAlloc(int device,size_t bytes,void **ptr)
+{
+  MH_TRY(runtime_ready());
+  if (ptr == nullptr)
+    return fail(MH_BAD_ARGUMENT,"null ptr");
+  if (device < 0) device=default_device();
+  int prev=0;
+  (void) hipGetDevice(&prev);
+  (void) hipSetDevice(device);
+  hipError_t err=hipMalloc(ptr,bytes);
+  (void) hipSetDevice(prev);
+  if (err != hipSuccess)
+    return fail(MH_OUT_OF_MEMORY,"hipMalloc(%zu): %s",bytes,hipGetErrorString(err));
+  return MH_OK;
+}
+
+MH_API MhStatus MhDeviceFree(int device,void *ptr)
+{
+  (void) device;
+  MH_TRY(runtime_ready());
+  MH_HIP(hipFree(ptr));
+  return MH_OK;
+}
+
+MH_API MhStatus MhUpload(int device,void *dst,const void *src,size_t bytes,void *stream)
+{
+  (void) device;
+  MH_TRY(runtime_ready());
+  MH_HIP(hipMemcpyAsync(dst,src,bytes,hipMemcpyHostToDevice,(hipStream_t) stream));
+  return MH_OK;
+}
+
+MH_API MhStatus MhDownload(int device,void *dst,const void *src,size_t bytes,void *stream)
+{
+  (void) device;
+  MH_TRY(runtime_ready());
+  MH_HIP(hipMemcpyAsync(dst,src,bytes,hipMemcpyDeviceToHost,(hipStream_t) stream));
+  MH_HIP(hipStreamSynchronize((hipStream_t) stream));
+  return MH_OK;
+}
+
+MH_API MhStatus MhSynchronize(int device,void *stream)
+{
+  (void) device;
+  MH_TRY(runtime_ready());
+  MH_HIP(hipStreamSynchronize((hipStream_t) stream));
+  return MH_OK;
+}
+
+MH_API int MhSetProfileEnabled(int enabled)
+{
+  Runtime &r=rt();
+  std::call_once(r.once,do_init);
+  r.profiling=enabled != 0 ? 1 : 0;
+  return r.profiling;
+}
+
+MH_API size_t MhGetProfileRecords(MhKernelProfileRecord *records,size_t capacity)
+{
+  Runtime &r=rt();
+  drain_profile();
+  std::lock_guard<std::mutex> guard(r.lock);
+  r.record_names.clear();
+  r.record_names.reserve(r.records.size());
+  size_t n=0;
+  for (auto &kv : r.records)
+    {
+      if ((records != nullptr) && (n < capacity))
+        {
+          r.record_names.push_back(kv.first);
+          records[n].kernel_name=r.record_names.back().c_str();
+          records[n].count=kv.second.count;
+          records[n].min_ms=kv.second.min_ms;
+          records[n].max_ms=kv.second.max_ms;
+          records[n].total_ms=kv.second.total_ms;
+        }
+      n++;
+    }
+  return n;
+}
+
+MH_API void MhResetProfileRecords(void)
+{
+  Runtime &r=rt();
+  drain_profile();
+  std::lock_guard<std::mutex> guard(r.lock);
+  r.records.clear();
+}
+
+MH_API void MhInitImage(MhImage *image,void *pixels,size_t columns,size_t rows,
+  uint32_t number_channels,int has_alpha,MhQuantumKind quantum,MhMemoryKind memory)
+{
+  memset(image,0,sizeof(*image));
+  image->pixels=pixels;
+  image->columns=columns;
+  image->rows=rows;
+  image->number_channels=number_channels;
+  image->quantum=(uint32_t) quantum;
+  image->memory=(uint32_t) memory;
+  image->device=-1;
+  image->alpha_offset=-1;
+  image->alpha_trait=MH_TRAIT_UNDEFINED;
+  if ((has_alpha != 0) && (number_channels >= 2))
+    {
+      image->alpha_offset=(int32_t) number_channels-1;
+      image->alpha_trait=MH_TRAIT_BLEND;
+    }
+  for (uint32_t c=0; c < number_channels && c < MH_MAX_CHANNELS; c++)
+    {
+      // pixel.c:6338-6383: selected channels are Update; colour channels also
+      // carry Blend when the image has an active alpha channel.
+      uint32_t traits=MH_TRAIT_UPDATE;
+      if ((image->alpha_offset >= 0) && ((int32_t) c != image->alpha_offset))
+        traits|=MH_TRAIT_BLEND;
+      image->channel_traits[c]=traits;
+    }
+  image->colorspace=(number_channels-(has_alpha != 0 ? 1u : 0u)) == 1u ?
+    MH_COLORSPACE_GRAY : MH_COLORSPACE_SRGB;
+  image->intensity=MH_INTENSITY_UNDEFINED;
+  image->channel_mask=MH_ALL_CHANNELS;
+  image->stream=nullptr;
+}
+
+} // extern "C"

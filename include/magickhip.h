@@ -1,0 +1,358 @@
+/*
+  magickhip.h — C ABI of libmagickhip.so, an MI355X (gfx950 / CDNA4) native
+  accelerate backend for MagickCore.
+
+  This is the drop-in boundary: plain C, plain pointers and sizes, no C++ or
+  torch types.  Every operator entry point below replaces (or adds, where the
+  reference has no hook) one `Accelerate*Image()` function of the reference:
+
+    reference interface                           file:line
+    --------------------------------------------  -----------------------------------
+    AccelerateBlurImage                           MagickCore/accelerate-private.h:36-37
+    AccelerateResizeImage                         MagickCore/accelerate-private.h:43-44
+    AccelerateUnsharpMaskImage                    MagickCore/accelerate-private.h:46-47
+    AccelerateContrastStretchImage                MagickCore/accelerate-private.h:52-53
+    AccelerateEqualizeImage                       MagickCore/accelerate-private.h:54
+    (new) convolve / morphology hook              MagickCore/morphology.c:3937, :4219
+    (new) colourspace hook                        MagickCore/colorspace.c:1751
+    checkAccelerateCondition (the gate)           MagickCore/accelerate.c:110-170
+    SetOpenCLEnabled / GetOpenCLEnabled           MagickCore/opencl.h, opencl.c:3192
+    GetOpenCLKernelProfileRecords                 MagickCore/opencl.c:2081
+    KernelInfo                                    MagickCore/morphology.h:100-127
+    MorphologyMethod                              MagickCore/morphology.h:72-98
+    PixelTrait                                    MagickCore/pixel.h:146-152
+    FilterType                                    MagickCore/resample.h:31-69
+
+  Conventions (same as the reference's accelerate layer):
+    * every operator returns MH_OK (0) when it produced the result, and a
+      non-zero MhStatus when it did not — the caller then runs its CPU path,
+      exactly as it does when Accelerate*Image() returns NULL / MagickFalse
+      (MagickCore/effect.c:783-787).  Nothing here throws or aborts.
+    * the caller owns every pixel buffer; the library owns device memory,
+      streams and staging buffers.
+    * pixel layout is the pixel cache's: row-major, channel-interleaved
+      Quantum[rows][columns][number_channels] (MagickCore/cache-private.h:130-226,
+      MagickCore/pixel.c:6132-6205).  Quantum is `unsigned short` (Q16) or
+      `float` (Q16-HDRI) — MagickCore/magick-type.h:80-88.
+    * results are those of the reference CPU path: see DESIGN.md "Parity".
+*/
+#ifndef MAGICKHIP_H
+#define MAGICKHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+#if defined(MAGICKHIP_BUILD)
+#  define MH_API __attribute__((visibility("default")))
+#else
+#  define MH_API
+#endif
+
+#define MH_MAX_CHANNELS 4   /* the accelerate gate admits R[,G,B][,A] only: accelerate.c:142-167 */
+
+typedef enum
+{
+  MH_OK = 0,
+  MH_UNSUPPORTED = 1,     /* gate failed: caller should use the CPU path */
+  MH_NO_DEVICE = 2,
+  MH_BAD_ARGUMENT = 3,
+  MH_OUT_OF_MEMORY = 4,
+  MH_DEVICE_ERROR = 5,
+  MH_DISABLED = 6         /* MhSetEnabled(0) or MAGICK_HIP_DEVICE=off */
+} MhStatus;
+
+typedef enum
+{
+  MH_QUANTUM_U16 = 0,     /* Q16:      Quantum = unsigned short */
+  MH_QUANTUM_F32 = 1      /* Q16-HDRI: Quantum = float, nominal range 0..65535 */
+} MhQuantumKind;
+
+typedef enum
+{
+  MH_MEMORY_HOST = 0,     /* pixels is a host pointer (e.g. CacheInfo::pixels); staged with hipMemcpyAsync */
+  MH_MEMORY_DEVICE = 1    /* pixels is a device pointer on `device`; used in place */
+} MhMemoryKind;
+
+/* PixelTrait bits, MagickCore/pixel.h:146-152 */
+enum
+{
+  MH_TRAIT_UNDEFINED = 0x0,
+  MH_TRAIT_COPY = 0x1,
+  MH_TRAIT_UPDATE = 0x2,
+  MH_TRAIT_BLEND = 0x4
+};
+
+/* ColorspaceType values used on this path, MagickCore/colorspace.h */
+typedef enum
+{
+  MH_COLORSPACE_UNDEFINED = 0,
+  MH_COLORSPACE_GRAY = 3,
+  MH_COLORSPACE_LAB = 11,
+  MH_COLORSPACE_LINEARGRAY = 33,
+  MH_COLORSPACE_RGB = 21,      /* linear RGB */
+  MH_COLORSPACE_SRGB = 23,
+  MH_COLORSPACE_XYZ = 26
+} MhColorspace;
+
+/* PixelIntensityMethod, MagickCore/pixel.h */
+typedef enum
+{
+  MH_INTENSITY_UNDEFINED = 0,
+  MH_INTENSITY_AVERAGE = 1,
+  MH_INTENSITY_BRIGHTNESS = 2,
+  MH_INTENSITY_LIGHTNESS = 3,
+  MH_INTENSITY_MS = 4,
+  MH_INTENSITY_REC601LUMA = 5,
+  MH_INTENSITY_REC601LUMINANCE = 6,
+  MH_INTENSITY_REC709LUMA = 7,
+  MH_INTENSITY_REC709LUMINANCE = 8,
+  MH_INTENSITY_RMS = 9
+} MhIntensityMethod;
+
+/* ChannelType bits that change operator behaviour, MagickCore/pixel.h:60-75 */
+#define MH_ALL_CHANNELS 0x7FFFFFFu
+#define MH_SYNC_CHANNELS 0x20000u
+
+/*
+  One image as the operators see it: what the shim extracts from `Image` /
+  `CacheInfo` (SURVEY §8b "Data access").
+*/
+typedef struct MhImage
+{
+  void *pixels;
+  size_t columns;
+  size_t rows;
+  uint32_t number_channels;                 /* 1..MH_MAX_CHANNELS */
+  uint32_t quantum;                         /* MhQuantumKind */
+  uint32_t memory;                          /* MhMemoryKind */
+  int32_t device;                           /* HIP device ordinal; -1 = library default */
+  uint32_t channel_traits[MH_MAX_CHANNELS]; /* PixelTrait of the channel stored at each offset */
+  int32_t alpha_offset;                     /* offset of the alpha channel, -1 if none (image->alpha_trait undefined) */
+  uint32_t alpha_trait;                     /* image->alpha_trait: MH_TRAIT_BLEND when alpha is active */
+  uint32_t colorspace;                      /* MhColorspace */
+  uint32_t intensity;                       /* MhIntensityMethod; 0 = default (Rec709Luma) */
+  uint32_t channel_mask;                    /* image->channel_mask (ChannelType bits); MH_ALL_CHANNELS by default */
+  void *stream;                             /* hipStream_t to run on; NULL = library stream.  DEVICE images only */
+} MhImage;
+
+/* Fill the traits the way InitializePixelChannelMap does for an image with
+   `number_channels` channels and optional alpha (pixel.c:6132-6205,
+   SetPixelChannelMask pixel.c:6338-6393 with the default channel mask). */
+MH_API void MhInitImage(MhImage *image,void *pixels,size_t columns,size_t rows,
+  uint32_t number_channels,int has_alpha,MhQuantumKind quantum,
+  MhMemoryKind memory);
+
+/* ------------------------------------------------------------------ runtime */
+
+MH_API MhStatus MhInitialize(void);               /* InitializeOpenCL analogue, opencl.c:2430 */
+MH_API void MhTerminus(void);                     /* OpenCLTerminus, opencl.c:2576 */
+MH_API int MhDeviceCount(void);
+MH_API MhStatus MhSetDevice(int device);          /* default device for device=-1 images */
+MH_API int MhGetEnabled(void);                    /* GetOpenCLEnabled */
+MH_API int MhSetEnabled(int enabled);             /* SetOpenCLEnabled, opencl.c:3192; returns new state */
+MH_API const char *MhGetLastError(void);          /* thread-local description of the last non-OK status */
+MH_API const char *MhGetVersion(void);
+
+typedef enum
+{
+  MH_PRECISION_EXACT = 0,  /* FP64, the CPU's operation order, no FMA contraction: bit-identical results */
+  MH_PRECISION_FAST = 1    /* FP32 FMA accumulation where the result is still within +-1 Quantum level (Q16 only) */
+} MhPrecision;
+MH_API MhPrecision MhGetPrecision(void);
+MH_API MhPrecision MhSetPrecision(MhPrecision precision);
+
+/* Device memory helpers for callers that keep images resident. */
+MH_API MhStatus MhDeviceAlloc(int device,size_t bytes,void **ptr);
+MH_API MhStatus MhDeviceFree(int device,void *ptr);
+MH_API MhStatus MhUpload(int device,void *dst_device,const void *src_host,size_t bytes,void *stream);
+MH_API MhStatus MhDownload(int device,void *dst_host,const void *src_device,size_t bytes,void *stream);
+MH_API MhStatus MhSynchronize(int device,void *stream);
+
+/* Kernel profile records (GetOpenCLKernelProfileRecords analogue). */
+typedef struct MhKernelProfileRecord
+{
+  const char *kernel_name;
+  unsigned long count;
+  double min_ms,max_ms,total_ms;   /* hipEvent-timed, only while profiling is enabled */
+} MhKernelProfileRecord;
+MH_API int MhSetProfileEnabled(int enabled);      /* SetOpenCLKernelProfileEnabled, opencl.c:3162 */
+MH_API size_t MhGetProfileRecords(MhKernelProfileRecord *records,size_t capacity);
+MH_API void MhResetProfileRecords(void);
+
+/* ------------------------------------------------------ kernels and filters */
+
+/* KernelInfoType, MagickCore/morphology.h:30-70 (same order) */
+typedef enum
+{
+  MH_KERNEL_UNDEFINED = 0,
+  MH_KERNEL_UNITY, MH_KERNEL_GAUSSIAN, MH_KERNEL_DOG, MH_KERNEL_LOG, MH_KERNEL_BLUR,
+  MH_KERNEL_COMET, MH_KERNEL_BINOMIAL, MH_KERNEL_LAPLACIAN, MH_KERNEL_SOBEL,
+  MH_KERNEL_FREICHEN, MH_KERNEL_ROBERTS, MH_KERNEL_PREWITT, MH_KERNEL_COMPASS,
+  MH_KERNEL_KIRSCH, MH_KERNEL_DIAMOND, MH_KERNEL_SQUARE, MH_KERNEL_RECTANGLE,
+  MH_KERNEL_OCTAGON, MH_KERNEL_DISK, MH_KERNEL_PLUS, MH_KERNEL_CROSS, MH_KERNEL_RING,
+  MH_KERNEL_PEAKS, MH_KERNEL_EDGES, MH_KERNEL_CORNERS, MH_KERNEL_DIAGONALS,
+  MH_KERNEL_LINEENDS, MH_KERNEL_LINEJUNCTIONS, MH_KERNEL_RIDGES, MH_KERNEL_CONVEXHULL,
+  MH_KERNEL_THINSE, MH_KERNEL_SKELETON, MH_KERNEL_CHEBYSHEV, MH_KERNEL_MANHATTAN,
+  MH_KERNEL_OCTAGONAL, MH_KERNEL_EUCLIDEAN, MH_KERNEL_USERDEFINED
+} MhKernelInfoType;
+
+/* Mirror of KernelInfo, MagickCore/morphology.h:100-127.  values is row-major
+   height x width; NaN marks a cell that is not part of the neighbourhood. */
+typedef struct MhKernelInfo
+{
+  MhKernelInfoType type;
+  size_t width,height;
+  ptrdiff_t x,y;
+  double *values;
+  double minimum,maximum,negative_range,positive_range,angle;
+  struct MhKernelInfo *next;
+} MhKernelInfo;
+
+/* AcquireKernelInfo, morphology.c:485: "name:args" or "WxH+X+Y: v,v,..."
+   kernel strings, ';'-separated lists.  NULL on parse failure / unsupported
+   kernel name. */
+MH_API MhKernelInfo *MhAcquireKernelInfo(const char *kernel_string);
+MH_API MhKernelInfo *MhDestroyKernelInfo(MhKernelInfo *kernel);
+MH_API MhKernelInfo *MhCloneKernelInfo(const MhKernelInfo *kernel);
+/* ScaleKernelInfo, morphology.c:4571.  flags: 1 = Normalize, 2 = CorrelateNormalize */
+MH_API void MhScaleKernelInfo(MhKernelInfo *kernel,double scaling_factor,unsigned flags);
+/* GetOptimalKernelWidth1D / 2D, gem.c:262,302 */
+MH_API size_t MhGetOptimalKernelWidth1D(double radius,double sigma);
+MH_API size_t MhGetOptimalKernelWidth2D(double radius,double sigma);
+
+/* MorphologyMethod, MagickCore/morphology.h:72-98 (same values) */
+typedef enum
+{
+  MH_MORPHOLOGY_UNDEFINED = 0,
+  MH_MORPHOLOGY_CONVOLVE, MH_MORPHOLOGY_CORRELATE,
+  MH_MORPHOLOGY_ERODE, MH_MORPHOLOGY_DILATE,
+  MH_MORPHOLOGY_ERODE_INTENSITY, MH_MORPHOLOGY_DILATE_INTENSITY,
+  MH_MORPHOLOGY_ITERATIVE_DISTANCE,
+  MH_MORPHOLOGY_OPEN, MH_MORPHOLOGY_CLOSE,
+  MH_MORPHOLOGY_OPEN_INTENSITY, MH_MORPHOLOGY_CLOSE_INTENSITY,
+  MH_MORPHOLOGY_SMOOTH,
+  MH_MORPHOLOGY_EDGE_IN, MH_MORPHOLOGY_EDGE_OUT, MH_MORPHOLOGY_EDGE,
+  MH_MORPHOLOGY_TOP_HAT, MH_MORPHOLOGY_BOTTOM_HAT,
+  MH_MORPHOLOGY_HIT_AND_MISS, MH_MORPHOLOGY_THINNING, MH_MORPHOLOGY_THICKEN,
+  MH_MORPHOLOGY_DISTANCE, MH_MORPHOLOGY_VORONOI
+} MhMorphologyMethod;
+
+/* FilterType, MagickCore/resample.h:31-69 (same values) */
+typedef enum
+{
+  MH_FILTER_UNDEFINED = 0,
+  MH_FILTER_POINT, MH_FILTER_BOX, MH_FILTER_TRIANGLE, MH_FILTER_HERMITE,
+  MH_FILTER_HANN, MH_FILTER_HAMMING, MH_FILTER_BLACKMAN, MH_FILTER_GAUSSIAN,
+  MH_FILTER_QUADRATIC, MH_FILTER_CUBIC, MH_FILTER_CATROM, MH_FILTER_MITCHELL,
+  MH_FILTER_JINC, MH_FILTER_SINC, MH_FILTER_SINCFAST, MH_FILTER_KAISER,
+  MH_FILTER_WELCH, MH_FILTER_PARZEN, MH_FILTER_BOHMAN, MH_FILTER_BARTLETT,
+  MH_FILTER_LAGRANGE, MH_FILTER_LANCZOS, MH_FILTER_LANCZOSSHARP,
+  MH_FILTER_LANCZOS2, MH_FILTER_LANCZOS2SHARP, MH_FILTER_ROBIDOUX,
+  MH_FILTER_ROBIDOUXSHARP, MH_FILTER_COSINE, MH_FILTER_SPLINE,
+  MH_FILTER_LANCZOSRADIUS, MH_FILTER_CUBICSPLINE, MH_FILTER_MAGICKERNELSHARP2013,
+  MH_FILTER_MAGICKERNELSHARP2021, MH_FILTER_SENTINEL
+} MhFilterType;
+
+/* ResizeFilter (opaque), resize.c:91-108; AcquireResizeFilter resize.c:803
+   (cylindrical = False, no expert `filter:*` artifacts). */
+typedef struct MhResizeFilter MhResizeFilter;
+MH_API MhResizeFilter *MhAcquireResizeFilter(MhFilterType filter,int image_has_alpha_or_enlarging_hint);
+MH_API MhResizeFilter *MhDestroyResizeFilter(MhResizeFilter *filter);
+MH_API double MhGetResizeFilterWeight(const MhResizeFilter *filter,double x);   /* resize.c:1690 */
+MH_API double MhGetResizeFilterSupport(const MhResizeFilter *filter);           /* resize.c:1668 */
+
+/* --------------------------------------------------------------- operators */
+/*
+  New-image operators take a caller-allocated destination whose geometry,
+  quantum kind and channel layout the caller has set (CloneImage in the shim,
+  accelerate.c:239-256); in-place operators mutate `image`.
+*/
+
+/* AccelerateBlurImage: BlurImage(image,radius,sigma), effect.c:765-796. */
+MH_API MhStatus MagickHipBlurImage(const MhImage *image,MhImage *blur_image,
+  double radius,double sigma);
+
+/* ConvolveImage(image,kernel), effect.c:1170 -> MorphologyImage(Convolve,1). */
+MH_API MhStatus MagickHipConvolveImage(const MhImage *image,MhImage *convolve_image,
+  const MhKernelInfo *kernel);
+
+/* MorphologyImage / MorphologyApply, morphology.c:4129 / :3634.  `compose`
+   is unused (Undefined => per-method default) in this version; `bias` is the
+   convolve:bias artifact (0 by default). */
+MH_API MhStatus MagickHipMorphologyImage(const MhImage *image,MhImage *morphology_image,
+  MhMorphologyMethod method,ptrdiff_t iterations,const MhKernelInfo *kernel,
+  double bias);
+
+/* One MorphologyPrimitive pass (morphology.c:2566) with a single kernel;
+   *changed receives the reference's return value. */
+MH_API MhStatus MagickHipMorphologyPrimitive(const MhImage *image,MhImage *morphology_image,
+  MhMorphologyMethod method,const MhKernelInfo *kernel,double bias,
+  ptrdiff_t *changed);
+
+/* AccelerateUnsharpMaskImage: UnsharpMaskImage, effect.c:4256-4400. */
+MH_API MhStatus MagickHipUnsharpMaskImage(const MhImage *image,MhImage *unsharp_image,
+  double radius,double sigma,double gain,double threshold);
+
+/* AccelerateResizeImage: ResizeImage, resize.c:3761-3874.  resize_image
+   carries the target columns/rows. */
+MH_API MhStatus MagickHipResizeImage(const MhImage *image,MhImage *resize_image,
+  MhFilterType filter);
+/* As above with a filter object (what the shim passes after AcquireResizeFilter). */
+MH_API MhStatus MagickHipResizeImageWithFilter(const MhImage *image,MhImage *resize_image,
+  const MhResizeFilter *filter);
+
+/* AccelerateContrastStretchImage: ContrastStretchImage, enhance.c:1544-1818.
+   black_point / white_point are pixel counts as in the MagickCore API.
+   *became_gray (optional) reports the IdentifyImageType side effect
+   (enhance.c:1586-1588): when set, the caller must SetImageColorspace(GRAY). */
+MH_API MhStatus MagickHipContrastStretchImage(MhImage *image,double black_point,
+  double white_point,int *became_gray);
+
+/* AccelerateEqualizeImage: EqualizeImage, enhance.c:2040-2280. */
+MH_API MhStatus MagickHipEqualizeImage(MhImage *image);
+
+/* TransformImageColorspace, colorspace.c:1751 — sRGB <-> linear RGB / Lab / XYZ.
+   On success image->colorspace is updated. */
+MH_API MhStatus MagickHipTransformImageColorspace(MhImage *image,MhColorspace colorspace);
+
+/* ---------------------------------------------------------- building blocks */
+/* Exposed so a row-sharded image (one band per GPU / per process) can run the
+   global-histogram operators with one all-reduce between the phases
+   (SURVEY §8e): histogram -> [all-reduce] -> LUT -> apply. */
+
+#define MH_MAXMAP 65535u
+#define MH_HISTOGRAM_BINS (MH_MAXMAP+1u)
+
+/* histogram[bin*number_channels + c], uint64 counts.
+   mode 0: each channel bins its own value; mode 1: every channel bins the
+   pixel intensity (enhance.c:1637-1643, :2125-2129).  Accumulates into
+   `histogram` (caller zeroes it).  histogram follows image->memory. */
+MH_API MhStatus MagickHipHistogram(const MhImage *image,int intensity_mode,uint64_t *histogram);
+
+/* Host-side LUT builders (pure C, no device).  lut[bin*number_channels + c],
+   in Quantum units as double; apply_mask bit c is cleared when channel c must
+   be left untouched (black == white). */
+MH_API MhStatus MhContrastStretchLUT(const uint64_t *histogram,uint32_t number_channels,
+  size_t columns,size_t rows,double black_point,double white_point,
+  MhQuantumKind quantum,double *lut,uint32_t *apply_mask);
+MH_API MhStatus MhEqualizeLUT(const uint64_t *histogram,uint32_t number_channels,
+  MhQuantumKind quantum,double *lut,uint32_t *apply_mask);
+
+/* q[c] = ClampToQuantum(lut[ScaleQuantumToMap(q[c])*number_channels + c]) for
+   Update channels selected by apply_mask (enhance.c:1778-1788, :2252-2262).
+   `lut` is a host pointer. */
+MH_API MhStatus MagickHipApplyLUT(MhImage *image,const double *lut,uint32_t apply_mask);
+
+/* IdentifyImageGray scan (attribute.c:1564-1626): *is_gray = 1 when every
+   pixel has |R-G| and |G-B| below MagickEpsilon. */
+MH_API MhStatus MagickHipIsImageGray(const MhImage *image,int *is_gray);
+
+#if defined(__cplusplus)
+}
+#endif
+
+#endif /* MAGICKHIP_H */

@@ -1,0 +1,225 @@
+"""TEST INFRASTRUCTURE — ctypes wrapper around the compiled reference oracle
+(oracle/_ref/libmagickref_{q16,q16hdri}.so, built from /root/reference by
+oracle/refbuild/Makefile).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this; the product never does.
+
+Both quantum builds can be loaded in one process (their symbols are kept in
+separate dlopen namespaces with RTLD_LOCAL).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+
+def lib_path(hdri):
+    return os.path.join(_HERE, "_ref", "libmagickref_%s.so" % ("q16hdri" if hdri else "q16"))
+
+
+def available(hdri=False):
+    return os.path.exists(lib_path(hdri))
+
+
+def _load(hdri):
+    key = bool(hdri)
+    if key in _LIBS:
+        return _LIBS[key]
+    path = lib_path(hdri)
+    if not os.path.exists(path):
+        raise RuntimeError("compiled reference oracle missing: %s (make -C oracle/refbuild)" % path)
+    # the reference resolves config XML through this; absent files fall back to built-ins
+    os.environ.setdefault("MAGICK_CONFIGURE_PATH", "/root/reference/config")
+    L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
+    vp, sz, dbl, cp = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_char_p
+    pd = ctypes.POINTER(ctypes.c_double)
+    L.ref_init.restype = ctypes.c_int
+    L.ref_quantum_is_float.restype = ctypes.c_int
+    L.ref_thread_limit.restype = ctypes.c_int
+    L.ref_set_thread_limit.argtypes = [ctypes.c_int]
+    L.ref_last_error.restype = cp
+    L.ref_image_new.restype = vp
+    L.ref_image_new.argtypes = [sz, sz, cp, cp, vp]
+    L.ref_image_free.argtypes = [vp]
+    L.ref_image_info.argtypes = [vp, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz),
+                                 ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                 ctypes.POINTER(ctypes.c_int)]
+    L.ref_colorspace_name.restype = cp
+    L.ref_colorspace_name.argtypes = [ctypes.c_int]
+    L.ref_image_get.argtypes = [vp, vp]
+    L.ref_image_set_channel_mask.argtypes = [vp, cp]
+    L.ref_image_set_artifact.argtypes = [vp, cp, cp]
+    L.ref_image_get_property.restype = cp
+    L.ref_image_get_property.argtypes = [vp, cp]
+    for name, extra in [("ref_blur", [dbl, dbl]), ("ref_gaussian_blur", [dbl, dbl]),
+                        ("ref_unsharp", [dbl, dbl, dbl, dbl]), ("ref_convolve", [cp]),
+                        ("ref_morphology", [cp, ctypes.c_ssize_t, cp]),
+                        ("ref_resize", [sz, sz, cp])]:
+        fn = getattr(L, name)
+        fn.restype = vp
+        fn.argtypes = [vp] + extra + [pd]
+    L.ref_contrast_stretch.argtypes = [vp, dbl, dbl, pd]
+    L.ref_equalize.argtypes = [vp, pd]
+    L.ref_colorspace.argtypes = [vp, cp, pd]
+    L.ref_kernel.argtypes = [cp, ctypes.c_int, ctypes.POINTER(sz), ctypes.POINTER(sz),
+                             ctypes.POINTER(ctypes.c_ssize_t), ctypes.POINTER(ctypes.c_ssize_t),
+                             vp, vp]
+    L.ref_resize_filter_weights.argtypes = [vp, cp, vp, sz, vp, pd]
+    L.ref_pixel_intensity.restype = dbl
+    L.ref_pixel_intensity.argtypes = [vp, vp]
+    L.ref_decode_gamma.restype = dbl
+    L.ref_decode_gamma.argtypes = [dbl]
+    L.ref_encode_gamma.restype = dbl
+    L.ref_encode_gamma.argtypes = [dbl]
+    L.ref_init()
+    _LIBS[key] = L
+    return L
+
+
+_MAPS = {1: "GRAY", 2: "GRAYA", 3: "RGB", 4: "RGBA"}
+
+
+class RefImage:
+    """An image inside the reference's pixel cache."""
+
+    def __init__(self, pixels=None, colorspace="sRGB", handle=None, lib=None, hdri=None):
+        if handle is not None:
+            self.L, self.handle, self.hdri = lib, handle, hdri
+            self.last_seconds = 0.0
+            return
+        pixels = np.ascontiguousarray(pixels)
+        if pixels.ndim == 2:
+            pixels = pixels[:, :, None]
+        self.hdri = pixels.dtype == np.float32
+        if not self.hdri and pixels.dtype != np.uint16:
+            raise ValueError("uint16 or float32 pixels expected")
+        self.L = _load(self.hdri)
+        rows, cols, ch = pixels.shape
+        self.handle = self.L.ref_image_new(cols, rows, _MAPS[ch].encode(), colorspace.encode(),
+                                           pixels.ctypes.data)
+        if not self.handle:
+            raise RuntimeError("ref_image_new failed: %s" % self.L.ref_last_error().decode())
+        self.last_seconds = 0.0
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.L.ref_image_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def info(self):
+        c, r, ch = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        cs, at, ty = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        self.L.ref_image_info(self.handle, ctypes.byref(c), ctypes.byref(r), ctypes.byref(ch),
+                              ctypes.byref(cs), ctypes.byref(at), ctypes.byref(ty))
+        return {"columns": c.value, "rows": r.value, "channels": ch.value,
+                "colorspace": self.L.ref_colorspace_name(cs.value).decode(),
+                "alpha_trait": at.value, "type": ty.value}
+
+    def numpy(self):
+        i = self.info()
+        out = np.empty((i["rows"], i["columns"], i["channels"]),
+                       dtype=np.float32 if self.hdri else np.uint16)
+        if self.L.ref_image_get(self.handle, out.ctypes.data) != 0:
+            raise RuntimeError("ref_image_get failed")
+        return out
+
+    def set_channel_mask(self, channels):
+        self.L.ref_image_set_channel_mask(self.handle, channels.encode())
+        return self
+
+    def set_artifact(self, key, value):
+        self.L.ref_image_set_artifact(self.handle, key.encode(),
+                                      None if value is None else value.encode())
+        return self
+
+    def _new(self, fn, *args):
+        t = ctypes.c_double(0.0)
+        h = fn(self.handle, *args, ctypes.byref(t))
+        if not h:
+            raise RuntimeError("reference operator failed: %s" % self.L.ref_last_error().decode())
+        out = RefImage(handle=h, lib=self.L, hdri=self.hdri)
+        out.last_seconds = t.value
+        return out
+
+    def _inplace(self, fn, *args):
+        t = ctypes.c_double(0.0)
+        if fn(self.handle, *args, ctypes.byref(t)) != 0:
+            raise RuntimeError("reference operator failed: %s" % self.L.ref_last_error().decode())
+        self.last_seconds = t.value
+        return self
+
+    def blur(self, radius, sigma):
+        return self._new(self.L.ref_blur, radius, sigma)
+
+    def gaussian_blur(self, radius, sigma):
+        return self._new(self.L.ref_gaussian_blur, radius, sigma)
+
+    def unsharp(self, radius, sigma, gain, threshold):
+        return self._new(self.L.ref_unsharp, radius, sigma, gain, threshold)
+
+    def convolve(self, kernel):
+        return self._new(self.L.ref_convolve, kernel.encode())
+
+    def morphology(self, method, iterations, kernel):
+        return self._new(self.L.ref_morphology, method.encode(), iterations, kernel.encode())
+
+    def resize(self, columns, rows, filter="Lanczos"):
+        return self._new(self.L.ref_resize, columns, rows, filter.encode())
+
+    def contrast_stretch(self, black, white):
+        return self._inplace(self.L.ref_contrast_stretch, black, white)
+
+    def equalize(self):
+        return self._inplace(self.L.ref_equalize)
+
+    def colorspace(self, name):
+        return self._inplace(self.L.ref_colorspace, name.encode())
+
+    def intensity(self, pixel):
+        px = np.ascontiguousarray(pixel, dtype=np.float32 if self.hdri else np.uint16)
+        return self.L.ref_pixel_intensity(self.handle, px.ctypes.data)
+
+    def filter_weights(self, filter, xs):
+        xs = np.ascontiguousarray(xs, dtype=np.float64)
+        w = np.empty_like(xs)
+        support = ctypes.c_double(0.0)
+        if self.L.ref_resize_filter_weights(self.handle, filter.encode(), xs.ctypes.data, xs.size,
+                                            w.ctypes.data, ctypes.byref(support)) != 0:
+            raise RuntimeError("filter %s rejected" % filter)
+        return w, support.value
+
+
+def kernel(kernel_string, index=0, hdri=False):
+    """(values[h,w], x, y, count) of kernel `index` as the reference builds it."""
+    L = _load(hdri)
+    w, h = ctypes.c_size_t(), ctypes.c_size_t()
+    x, y = ctypes.c_ssize_t(), ctypes.c_ssize_t()
+    n = L.ref_kernel(kernel_string.encode(), index, ctypes.byref(w), ctypes.byref(h),
+                     ctypes.byref(x), ctypes.byref(y), None, None)
+    if n < 0:
+        return None
+    values = np.empty(w.value * h.value, dtype=np.float64)
+    L.ref_kernel(kernel_string.encode(), index, ctypes.byref(w), ctypes.byref(h), ctypes.byref(x),
+                 ctypes.byref(y), values.ctypes.data, None)
+    return values.reshape(h.value, w.value), x.value, y.value, n
+
+
+def thread_limit(hdri=False):
+    return _load(hdri).ref_thread_limit()
+
+
+def set_thread_limit(n, hdri=False):
+    _load(hdri).ref_set_thread_limit(n)
+
+
+def decode_gamma(v, hdri=False):
+    return _load(hdri).ref_decode_gamma(v)
+
+
+def encode_gamma(v, hdri=False):
+    return _load(hdri).ref_encode_gamma(v)

@@ -1,0 +1,100 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def gpu_available():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def im():
+    """The product binding; on a GPU box the native library MUST load."""
+    import imagemagick_amd
+    imagemagick_amd.load()
+    return imagemagick_amd
+
+
+@pytest.fixture(scope="session")
+def refmod():
+    """The compiled reference oracle (oracle/_ref); skip when it was not built."""
+    from oracle import ref
+    if not ref.available(False) or not ref.available(True):
+        pytest.skip("compiled reference oracle (oracle/_ref) is not built")
+    return ref
+
+
+def make_pixels(rows, cols, channels, dtype, seed=42, kind="random"):
+    """Deterministic synthetic Quantum buffers."""
+    rng = np.random.default_rng(seed)
+    if kind == "random":
+        a = rng.integers(0, 65536, (rows, cols, channels), dtype=np.uint16)
+    elif kind == "smooth":
+        y, x = np.mgrid[0:rows, 0:cols]
+        base = (x * 40000.0 / max(cols - 1, 1) + y * 20000.0 / max(rows - 1, 1))
+        a = np.empty((rows, cols, channels), dtype=np.float64)
+        for c in range(channels):
+            a[:, :, c] = base * (0.6 + 0.1 * c) + rng.integers(0, 400, (rows, cols))
+        a = np.clip(a, 0, 65535).astype(np.uint16)
+    elif kind == "opaque":
+        a = rng.integers(0, 65536, (rows, cols, channels), dtype=np.uint16)
+        a[:, :, channels - 1] = 65535
+    elif kind == "binary":
+        a = (rng.random((rows, cols, channels)) > 0.6).astype(np.uint16) * 65535
+    else:
+        raise ValueError(kind)
+    if dtype == np.float32:
+        f = a.astype(np.float32)
+        if kind == "random":
+            f += rng.random((rows, cols, channels), dtype=np.float32)  # non-integral HDRI values
+            f = np.minimum(f, np.float32(65535.0))
+        return np.ascontiguousarray(f)
+    return np.ascontiguousarray(a)
+
+
+def to_device(array):
+    import torch
+    if array.dtype == np.uint16:
+        return torch.from_numpy(array.view(np.int16)).cuda().view(torch.uint16)
+    return torch.from_numpy(array).cuda()
+
+
+def ulp_diff_f32(a, b):
+    """Distance in float32 ULPs (monotone integer mapping of the bit patterns)."""
+    ai = a.astype(np.float32).view(np.int32).astype(np.int64)
+    bi = b.astype(np.float32).view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, -(ai & 0x7FFFFFFF), ai)
+    bi = np.where(bi < 0, -(bi & 0x7FFFFFFF), bi)
+    return np.abs(ai - bi)
+
+
+def assert_parity(got, want, exact=True, what="", max_ulp=0):
+    """EXACT mode: Q16 results are bit-identical; float Quantum results are
+    bit-identical too (max_ulp=0) except where the caller allows 1 float ULP
+    because a libm function (pow in the Lab transform) is evaluated by a
+    different library on the device.  FAST mode (Q16 only): +-1 Quantum level."""
+    assert got.shape == want.shape, "%s shape %s != %s" % (what, got.shape, want.shape)
+    if want.dtype == np.uint16:
+        d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+        limit = 0 if exact else 1
+        assert d.max() <= limit, "%s: max |diff| = %d (limit %d), %d of %d differ" % (
+            what, d.max(), limit, int((d > limit).sum()), d.size)
+        return float((d == 0).mean())
+    u = ulp_diff_f32(got, want)
+    assert u.max() <= max_ulp, "%s: max ULP diff = %d (limit %d), %d of %d over" % (
+        what, u.max(), max_ulp, int((u > max_ulp).sum()), u.size)
+    return float((u == 0).mean())

@@ -1,0 +1,262 @@
+"""GPU parity tests: the HIP path (through the C ABI of libmagickhip.so) against
+the compiled reference CPU implementation (oracle/_ref) on the same seeded
+inputs.  Bar: bit-exact for Q16 and for float Quantum in EXACT precision
+(1 float ULP where device libm `pow` is involved); +-1 level in FAST precision."""
+import numpy as np
+import pytest
+
+from conftest import make_pixels, to_device, assert_parity
+
+pytestmark = pytest.mark.gpu
+
+Q16, HDRI = np.uint16, np.float32
+
+
+def run_pair(im, refmod, pixels, colorspace="sRGB", **image_kw):
+    dev = im.Image(to_device(pixels), colorspace=colorspace, **image_kw)
+    ref = refmod.RefImage(pixels, colorspace)
+    return dev, ref
+
+
+# ------------------------------------------------------------------ BlurImage
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("shape,sigma", [((61, 97, 4), 2.0), ((200, 300, 4), 10.0),
+                                         ((33, 40, 3), 1.5), ((50, 70, 1), 3.0),
+                                         ((45, 64, 2), 2.5), ((1, 1, 4), 2.0),
+                                         ((1, 130, 4), 2.0), ((130, 1, 4), 2.0),
+                                         ((20, 20, 4), 10.0)])
+def test_blur_exact(im, refmod, dtype, shape, sigma):
+    px = make_pixels(*shape, dtype)
+    dev, ref = run_pair(im, refmod, px)
+    got = im.blur_image(dev, 0.0, sigma).numpy()
+    want = ref.blur(0.0, sigma).numpy()
+    assert_parity(got, want, True, "blur %s sigma=%g" % (shape, sigma))
+
+
+def test_blur_radius_argument(im, refmod):
+    px = make_pixels(64, 80, 4, Q16)
+    dev, ref = run_pair(im, refmod, px)
+    assert_parity(im.blur_image(dev, 5.0, 2.0).numpy(), ref.blur(5.0, 2.0).numpy(), True, "blur 5x2")
+
+
+@pytest.mark.parametrize("kind", ["opaque", "smooth"])
+def test_blur_other_distributions(im, refmod, kind):
+    px = make_pixels(120, 150, 4, Q16, kind=kind)
+    dev, ref = run_pair(im, refmod, px)
+    assert_parity(im.blur_image(dev, 0.0, 4.0).numpy(), ref.blur(0.0, 4.0).numpy(), True, kind)
+
+
+def test_blur_fast_precision_within_one_level(im, refmod):
+    px = make_pixels(240, 320, 4, Q16)
+    dev, ref = run_pair(im, refmod, px)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got = im.blur_image(dev, 0.0, 10.0).numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    exact_fraction = assert_parity(got, ref.blur(0.0, 10.0).numpy(), False, "fast blur")
+    assert exact_fraction > 0.95
+
+
+def test_blur_channel_mask_copies_unselected_channels(im, refmod):
+    px = make_pixels(40, 52, 4, Q16)
+    ref = refmod.RefImage(px).set_channel_mask("RG")
+    want = ref.blur(0.0, 2.0).numpy()
+    dev = im.Image(to_device(px), copy_channels=(2, 3))
+    assert_parity(im.blur_image(dev, 0.0, 2.0).numpy(), want, True, "blur -channel RG")
+
+
+def test_blur_host_memory_path(im, refmod):
+    """MH_MEMORY_HOST: the library stages the pixel-cache block itself."""
+    px = make_pixels(90, 111, 4, Q16)
+    want = refmod.RefImage(px).blur(0.0, 3.0).numpy()
+    got = im.blur_image(im.Image(px.copy()), 0.0, 3.0).numpy()
+    assert_parity(got, want, True, "host-memory blur")
+
+
+# ------------------------------------------------- ConvolveImage / Morphology
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("kernel", ["Gaussian:0x1.5", "3x3: 1,2,1 2,4,2 1,2,1",
+                                    "Sobel", "Laplacian:1", "5x1: 1,2,3,2,1", "1x5: 1,2,3,2,1",
+                                    "3x3+0+0: 1,-,1 -,1,- 1,nan,1", "1x3: 1,-,2",
+                                    "DoG:0x2,1", "Binomial:2"])
+def test_convolve(im, refmod, dtype, kernel):
+    px = make_pixels(57, 83, 4, dtype)
+    dev, ref = run_pair(im, refmod, px)
+    assert_parity(im.convolve_image(dev, kernel).numpy(), ref.convolve(kernel).numpy(), True,
+                  "convolve " + kernel)
+
+
+@pytest.mark.parametrize("channels", [1, 2, 3])
+def test_convolve_channel_layouts(im, refmod, channels):
+    px = make_pixels(40, 50, channels, Q16)
+    dev, ref = run_pair(im, refmod, px)
+    k = "Gaussian:0x1"
+    assert_parity(im.convolve_image(dev, k).numpy(), ref.convolve(k).numpy(), True, "convolve C=%d" % channels)
+
+
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("method,kernel,iterations", [
+    ("Dilate", "Disk:5", 1), ("Erode", "Disk:5", 1), ("Dilate", "Disk:15", 1),
+    ("Erode", "Octagon:3", 2), ("Dilate", "Rectangle:5x3+1+1", 1), ("Erode", "Plus:2", 3),
+    ("Open", "Disk:2.5", 1), ("Close", "Diamond:2", 1), ("Smooth", "Square:1", 1),
+    ("ErodeIntensity", "Disk:3", 1), ("DilateIntensity", "Disk:3", 1),
+    ("Correlate", "3x3: 1,2,3 4,5,6 7,8,9", 1), ("Convolve", "3x3: 1,2,3 4,5,6 7,8,9", 1),
+    ("Dilate", "Ring:2,4", 1), ("IterativeDistance", "Chebyshev:1,100", 2),
+])
+def test_morphology(im, refmod, dtype, method, kernel, iterations):
+    px = make_pixels(71, 90, 4, dtype)
+    dev, ref = run_pair(im, refmod, px)
+    got = im.morphology_image(dev, method, iterations, kernel).numpy()
+    want = ref.morphology(method, iterations, kernel).numpy()
+    assert_parity(got, want, True, "%s %s x%d" % (method, kernel, iterations))
+
+
+@pytest.mark.parametrize("method", ["HitAndMiss", "Thinning", "Thicken"])
+def test_hit_and_miss_family(im, refmod, method):
+    px = make_pixels(48, 64, 3, Q16, kind="binary")
+    dev, ref = run_pair(im, refmod, px)
+    kernel = "3x3: 0,1,- 0,1,1 -,1,-"
+    got = im.morphology_image(dev, method, 2, kernel).numpy()
+    want = ref.morphology(method, 2, kernel).numpy()
+    assert_parity(got, want, True, method)
+
+
+def test_morphology_until_convergence(im, refmod):
+    px = make_pixels(40, 40, 1, Q16, kind="binary")
+    dev, ref = run_pair(im, refmod, px)
+    got = im.morphology_image(dev, "Dilate", -1, "Plus:1").numpy()
+    want = ref.morphology("Dilate", -1, "Plus:1").numpy()
+    assert_parity(got, want, True, "dilate until no change")
+
+
+# ----------------------------------------------------------- UnsharpMaskImage
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+def test_unsharp_mask(im, refmod, dtype):
+    px = make_pixels(66, 77, 4, dtype)
+    dev, ref = run_pair(im, refmod, px)
+    got = im.unsharp_mask_image(dev, 0.0, 2.0, 1.0, 0.02).numpy()
+    want = ref.unsharp(0.0, 2.0, 1.0, 0.02).numpy()
+    assert_parity(got, want, True, "unsharp")
+
+
+# ----------------------------------------------------------------- ResizeImage
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("shape,target,filt", [
+    ((16, 24, 4), (96, 64), "Lanczos"), ((40, 50, 4), (17, 23), "Lanczos"),
+    ((31, 45, 4), (90, 31), "Mitchell"), ((31, 45, 3), (20, 70), "Catrom"),
+    ((25, 25, 1), (100, 100), "Triangle"), ((64, 48, 2), (48, 64), "Lanczos"),
+    ((30, 30, 4), (30, 90), "Box"), ((200, 150, 4), (20, 15), "Lanczos"),
+    ((20, 20, 4), (21, 19), "Point"), ((33, 29, 4), (70, 70), "Gaussian"),
+    ((33, 29, 4), (70, 70), "Hann"), ((33, 29, 4), (41, 37), "Spline"),
+])
+def test_resize(im, refmod, dtype, shape, target, filt):
+    px = make_pixels(*shape, dtype)
+    dev, ref = run_pair(im, refmod, px)
+    cols, rows = target
+    got = im.resize_image(dev, cols, rows, filt).numpy()
+    want = ref.resize(cols, rows, filt).numpy()
+    assert_parity(got, want, True, "resize %s -> %s %s" % (shape, target, filt))
+
+
+def test_resize_fast_precision(im, refmod):
+    px = make_pixels(60, 80, 4, Q16)
+    dev, ref = run_pair(im, refmod, px)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got = im.resize_image(dev, 320, 240, "Lanczos").numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert_parity(got, ref.resize(320, 240, "Lanczos").numpy(), False, "fast resize")
+
+
+# ------------------------------------------------------------------ colourspace
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("src,dst", [("sRGB", "RGB"), ("RGB", "sRGB"), ("sRGB", "Lab"),
+                                     ("Lab", "sRGB"), ("sRGB", "XYZ"), ("XYZ", "sRGB"),
+                                     ("RGB", "Lab"), ("Lab", "XYZ")])
+@pytest.mark.parametrize("channels", [3, 4])
+def test_colorspace(im, refmod, dtype, src, dst, channels):
+    px = make_pixels(50, 64, channels, dtype)
+    dev, ref = run_pair(im, refmod, px, colorspace=src)
+    got = im.transform_image_colorspace(dev, dst).numpy()
+    want = ref.colorspace(dst).numpy()
+    uses_pow = "Lab" in (src, dst)
+    assert_parity(got, want, True, "%s->%s" % (src, dst), max_ulp=1 if uses_pow else 0)
+
+
+# ------------------------------------------------ Equalize / ContrastStretch
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("kind", ["random", "smooth"])
+@pytest.mark.parametrize("channels", [1, 2, 3, 4])
+def test_equalize(im, refmod, dtype, kind, channels):
+    px = make_pixels(48, 64, channels, dtype, kind=kind)
+    dev, ref = run_pair(im, refmod, px)
+    got = im.equalize_image(dev).numpy()
+    want = ref.equalize().numpy()
+    assert_parity(got, want, True, "equalize")
+
+
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("kind", ["random", "smooth"])
+@pytest.mark.parametrize("channels", [1, 3, 4])
+def test_contrast_stretch(im, refmod, dtype, kind, channels):
+    rows, cols = 48, 64
+    px = make_pixels(rows, cols, channels, dtype, kind=kind)
+    dev, ref = run_pair(im, refmod, px)
+    black = 0.02 * rows * cols
+    white = rows * cols - 0.01 * rows * cols     # as `-contrast-stretch 2%x1%` passes them
+    got = im.contrast_stretch_image(dev, black, white).numpy()
+    want = ref.contrast_stretch(black, white).numpy()
+    assert_parity(got, want, True, "contrast-stretch")
+
+
+def test_contrast_stretch_per_channel_mask(im, refmod):
+    rows, cols = 40, 40
+    px = make_pixels(rows, cols, 4, Q16, kind="smooth")
+    ref = refmod.RefImage(px).set_channel_mask("RGB")
+    want = ref.contrast_stretch(30.0, rows * cols - 30.0).numpy()
+    dev = im.Image(to_device(px), channel_mask=0x7, copy_channels=(3,))
+    got = im.contrast_stretch_image(dev, 30.0, rows * cols - 30.0).numpy()
+    assert_parity(got, want, True, "contrast-stretch -channel RGB")
+
+
+def test_lab_then_contrast_stretch_chain(im, refmod):
+    """BASELINE config C4's per-image pipeline."""
+    rows, cols = 64, 64
+    px = make_pixels(rows, cols, 4, Q16)
+    dev, ref = run_pair(im, refmod, px)
+    im.transform_image_colorspace(dev, "Lab")
+    im.contrast_stretch_image(dev, 0.02 * rows * cols, rows * cols * 0.99)
+    ref.colorspace("Lab").contrast_stretch(0.02 * rows * cols, rows * cols * 0.99)
+    assert_parity(dev.numpy(), ref.numpy(), True, "Lab + contrast-stretch")
+
+
+def test_histogram_matches_numpy(im):
+    px = make_pixels(100, 120, 4, Q16, kind="smooth")
+    dev = im.Image(to_device(px))
+    h = im.histogram(dev, False).cpu().numpy()
+    for c in range(4):
+        want = np.bincount(px[:, :, c].ravel(), minlength=65536)
+        assert np.array_equal(h[:, c], want)
+
+
+# ------------------------------------------------- full-size property checks
+def test_blur_full_size_properties(im):
+    """BASELINE C2 geometry (8192x8192 RGBA Q16, sigma=10): properties that need
+    no oracle run.  A constant image is a fixed point of the normalised blur;
+    blurring is invariant under transposition for a symmetric separable kernel."""
+    import torch
+    n = 8192
+    const = torch.full((n, n, 4), 12345, dtype=torch.int16, device="cuda").view(torch.uint16)
+    out = im.blur_image(im.Image(const), 0.0, 10.0).pixels
+    assert int((out.view(torch.int16) != 12345).sum()) == 0
+    g = torch.Generator(device="cuda").manual_seed(7)
+    a = torch.randint(0, 32768, (2048, 1024, 4), generator=g, device="cuda", dtype=torch.int16)
+    a[:, :, 3] = -1            # opaque alpha (65535): the two passes then commute exactly enough
+    img = im.Image(a.view(torch.uint16).contiguous())
+    b1 = im.blur_image(img, 0.0, 3.0).pixels.view(torch.int16)
+    at = a.transpose(0, 1).contiguous()
+    b2 = im.blur_image(im.Image(at.view(torch.uint16)), 0.0, 3.0).pixels.view(torch.int16)
+    diff = (b1.transpose(0, 1).to(torch.int32) - b2.to(torch.int32)).abs().max()
+    assert int(diff) <= 1
