@@ -1,0 +1,225 @@
+"""CPU tests (`-m "not gpu"`): pin the oracle (oracle/restate.py, the NumPy
+restatement of the reference algorithms) against
+
+  1. the reference's own scalar known-answer tests (tests/validate.c),
+  2. the reference's own tolerance goldens (PerlMagick/t/filter.t + .miff files),
+  3. outputs of the compiled reference itself on seeded inputs — bit for bit
+     (tests/golden/reference_vectors.npz, made by tests/golden/make_golden.py),
+  4. and, when it is built (this container and the GPU box), the compiled
+     reference oracle/_ref live.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ulp_diff_f32
+from oracle import restate as R
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+QR = 65535.0
+
+
+@pytest.fixture(scope="module")
+def vectors():
+    return np.load(os.path.join(GOLDEN, "reference_vectors.npz"))
+
+
+@pytest.fixture(scope="module")
+def perl():
+    return np.load(os.path.join(GOLDEN, "perlmagick_filter.npz"))
+
+
+def assert_identical(got, want, what, max_ulp=0):
+    assert got.shape == want.shape and got.dtype == want.dtype, what
+    if want.dtype == np.uint16:
+        d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+        assert d.max() == 0, "%s: %d of %d Q16 values differ (max %d)" % (what, (d > 0).sum(), d.size, d.max())
+    else:
+        u = ulp_diff_f32(got, want)
+        assert u.max() <= max_ulp, "%s: max %d float ULP" % (what, u.max())
+
+
+# ------------------------------------------------- 1. reference KATs (validate.c)
+REFERENCE_EPSILON = QR * 1.0e-2        # tests/validate.c:67
+
+
+def test_kat_rgb_to_lab():             # tests/validate.c:242-259 ValidateRGBToLab
+    L, a, b = R.convert_rgb_to_lab(0.545877 * QR, 0.966567 * QR, 0.463759 * QR)
+    assert abs(L - 88.456154 / 100.0) < REFERENCE_EPSILON
+    assert abs(a - (-54.671483 / 255.0 + 0.5)) < REFERENCE_EPSILON
+    assert abs(b - (51.662818 / 255.0 + 0.5)) < REFERENCE_EPSILON
+    # the KAT's epsilon is loose (it is in Quantum units); the published Lab triple itself:
+    assert abs(100.0 * L - 88.456154) < 5e-3
+    assert abs(255.0 * (a - 0.5) + 54.671483) < 5e-3
+    assert abs(255.0 * (b - 0.5) - 51.662818) < 5e-3
+
+
+def test_kat_lab_to_rgb():             # tests/validate.c:227-240 ValidateLabToRGB
+    r, g, b = R.convert_lab_to_rgb(88.456154 / 100.0, -54.671483 / 255 + 0.5, 51.662818 / 255.0 + 0.5)
+    for got, want in ((r, 0.545877), (g, 0.966567), (b, 0.463759)):
+        assert abs(got - want * QR) < REFERENCE_EPSILON
+        assert abs(got / QR - want) < 1e-4
+
+
+def test_kat_rgb_to_xyz():             # tests/validate.c:362-377 ValidateRGBToXYZ
+    x, y, z = R.convert_rgb_to_xyz(0.545877 * QR, 0.966567 * QR, 0.463759 * QR)
+    for got, want in ((x, 0.470646), (y, 0.730178), (z, 0.288324)):
+        assert abs(got - want) < 1e-5
+
+
+def test_kat_xyz_to_rgb():             # tests/validate.c:379-393 ValidateXYZToRGB
+    r, g, b = R.convert_xyz_to_rgb(np.float64(0.470646), np.float64(0.730178), np.float64(0.288324))
+    for got, want in ((r, 0.545877), (g, 0.966567), (b, 0.463759)):
+        assert abs(got - want * QR) < REFERENCE_EPSILON
+        assert abs(got / QR - want) < 1e-4
+
+
+def test_gamma_round_trip_and_against_pow():
+    x = np.linspace(1e-6, 1.0, 4001)
+    assert np.max(np.abs(R.decode_gamma(x)- x ** 2.4)) < 1e-8       # pixel.c:291 "x^2.4 == pow(x,2.4)"
+    assert np.max(np.abs(R.encode_gamma(x) - x ** (1 / 2.4))) < 1e-8
+    q = np.arange(0, 65536, 7, dtype=np.float64)
+    assert np.max(np.abs(R.encode_pixel_gamma(R.decode_pixel_gamma(q)) - q)) < 1e-3
+
+
+# ----------------------------- 2. the reference's tolerance goldens (filter.t)
+def _to_q16(a8):
+    return (a8.astype(np.uint16) * 257)          # ScaleCharToQuantum, quantum-private.h (Q16)
+
+
+def _set_depth_8(q16):
+    """`$image->Clamp(); $image->set(depth=>8)` (PerlMagick/t/subroutines.pl:1195-1196):
+    SetImageDepth requantises each channel to 8 bits, attribute.c."""
+    v = np.floor(q16.astype(np.float64) / 257.0 + 0.5)
+    return (np.clip(v, 0, 255) * 257.0)
+
+
+def _errors(result_q16, golden8):
+    """SetImageColorMetric, MagickCore/compare.c: normalized mean / maximum error."""
+    d = np.abs(_set_depth_8(result_q16) - golden8.astype(np.float64) * 257.0)
+    return (d * d).sum() / QR / QR / d.size, d.max() / QR
+
+
+@pytest.mark.parametrize("name", ["Blur", "Convolve", "Equalize", "Resize", "UnsharpMask"])
+def test_perlmagick_goldens(perl, name):
+    src = _to_q16(perl["input"])
+    if name == "Blur":                            # filter.t:39   Blur('5x2')
+        out = R.blur_image(src, 5.0, 2.0)
+    elif name == "Convolve":                      # filter.t:63
+        k = np.array([0.0625, 0.0625, 0.0625, 0.0625, 0.5, 0.0625, 0.0625, 0.0625, 0.0625]).reshape(3, 3)
+        out, _ = R.morphology_primitive(src, "convolve", k, 1, 1)
+    elif name == "Equalize":                      # filter.t:84
+        out = R.equalize_image(src)
+    elif name == "Resize":                        # filter.t:156  Resize('60%'): 70x46 -> 42x28, Lanczos
+        out = R.resize_image(src, 42, 28, "lanczos")
+    else:                                         # filter.t:201  UnsharpMask('5x2+1'), threshold 0.05
+        out = R.unsharp_mask_image(src, 5.0, 2.0, 1.0, 0.05)
+    mean, maximum = _errors(out, perl[name])
+    mean_max, maximum_max = perl[name + "_bounds"]
+    assert mean <= mean_max + 1e-12 and maximum <= maximum_max + 1e-12, (name, mean, maximum)
+
+
+# ------------------ 3. bit-for-bit against committed outputs of the reference
+CASES = [(tag, ch) for tag in ("q16", "hdri") for ch in (1, 3, 4)]
+
+
+@pytest.mark.parametrize("tag,ch", CASES)
+def test_blur_matches_reference(vectors, tag, ch):
+    px = vectors["%s_c%d_in" % (tag, ch)]
+    for name, (radius, sigma) in {"blur_0x2": (0.0, 2.0), "blur_0x10": (0.0, 10.0),
+                                  "blur_3x1.5": (3.0, 1.5)}.items():
+        assert_identical(R.blur_image(px, radius, sigma), vectors["%s_c%d_%s" % (tag, ch, name)], name)
+
+
+@pytest.mark.parametrize("tag,ch", CASES)
+def test_morphology_matches_reference(vectors, tag, ch):
+    px = vectors["%s_c%d_in" % (tag, ch)]
+    k, x, y = R.disk_kernel(4)
+    assert_identical(R.morphology_primitive(px, "dilate", k, x, y)[0],
+                     vectors["%s_c%d_dilate_disk4" % (tag, ch)], "dilate")
+    assert_identical(R.morphology_primitive(px, "erode", k, x, y)[0],
+                     vectors["%s_c%d_erode_disk4" % (tag, ch)], "erode")
+    nan = float("nan")
+    k = np.array([[1, nan, 1], [2, 4, 2], [1, nan, 3]], dtype=np.float64)
+    assert_identical(R.morphology_primitive(px, "convolve", k, 1, 1)[0],
+                     vectors["%s_c%d_convolve_3x3nan" % (tag, ch)], "convolve with NaN cells")
+
+
+@pytest.mark.parametrize("tag,ch", CASES)
+def test_resize_matches_reference(vectors, tag, ch):
+    px = vectors["%s_c%d_in" % (tag, ch)]
+    for name, (cols, rows, flt) in {"resize_lanczos_up": (101, 75, "lanczos"),
+                                    "resize_lanczos_down": (17, 11, "lanczos"),
+                                    "resize_mitchell": (60, 20, "mitchell"),
+                                    "resize_catrom": (20, 50, "catrom"),
+                                    "resize_triangle": (64, 64, "triangle")}.items():
+        assert_identical(R.resize_image(px, cols, rows, flt), vectors["%s_c%d_%s" % (tag, ch, name)], name)
+
+
+@pytest.mark.parametrize("tag,ch", CASES)
+def test_unsharp_and_histogram_ops_match_reference(vectors, tag, ch):
+    px = vectors["%s_c%d_in" % (tag, ch)]
+    key = "%s_c%d_" % (tag, ch)
+    assert_identical(R.unsharp_mask_image(px, 0.0, 2.0, 1.0, 0.02), vectors[key + "unsharp"], "unsharp")
+    n = px.shape[0] * px.shape[1]
+    assert_identical(R.contrast_stretch_image(px, 0.02 * n, n - 0.01 * n), vectors[key + "cstretch"],
+                     "contrast-stretch")
+    assert_identical(R.equalize_image(px), vectors[key + "equalize"], "equalize")
+
+
+@pytest.mark.parametrize("tag", ["q16", "hdri"])
+def test_histogram_ops_on_smooth_frame(vectors, tag):
+    px = vectors[tag + "_smooth_in"]
+    n = px.shape[0] * px.shape[1]
+    assert_identical(R.contrast_stretch_image(px, 0.02 * n, n - 0.01 * n), vectors[tag + "_smooth_cstretch"],
+                     "contrast-stretch (smooth)")
+    assert_identical(R.equalize_image(px), vectors[tag + "_smooth_equalize"], "equalize (smooth)")
+    lab = R.transform_image_colorspace(px, "srgb", "lab")
+    got = R.contrast_stretch_image(lab, 0.02 * n, n - 0.01 * n, colorspace="lab")
+    assert_identical(got, vectors[tag + "_smooth_lab_cstretch"], "Lab + contrast-stretch (config C4)")
+
+
+@pytest.mark.parametrize("tag,ch", [(t, c) for t, c in CASES if c >= 3])
+@pytest.mark.parametrize("a,b", [("sRGB", "RGB"), ("RGB", "sRGB"), ("sRGB", "Lab"), ("Lab", "sRGB"),
+                                 ("sRGB", "XYZ"), ("XYZ", "sRGB")])
+def test_colorspace_matches_reference(vectors, tag, ch, a, b):
+    px = vectors["%s_c%d_in" % (tag, ch)]
+    want = vectors["%s_c%d_%s_to_%s" % (tag, ch, a, b)]
+    assert_identical(R.transform_image_colorspace(px, a, b), want, "%s->%s" % (a, b))
+
+
+def test_blur_taps_match_reference(vectors):
+    for s, (radius, sigma) in {"blur:0x2": (0, 2.0), "blur:0x10": (0, 10.0), "blur:0x0.5": (0, 0.5),
+                               "blur:4x1.5": (4.0, 1.5)}.items():
+        want = vectors["kernel|" + s].ravel()
+        got = R.blur_kernel(radius, sigma)
+        assert got.size == want.size and np.array_equal(got, want), s
+    assert vectors["kernel|blur:0x10"].size == 79 and vectors["kernel|blur:0x2"].size == 17
+    k, x, y = R.disk_kernel(15)
+    want = vectors["kernel|Disk:15"]
+    assert np.array_equal(np.isnan(k), np.isnan(want)) and np.nansum(k) == 709.0
+
+
+def test_resize_weights_match_reference(vectors):
+    xs = vectors["filter_xs"]
+    for name in ("Lanczos", "Mitchell", "Catrom", "Triangle", "Box"):
+        f = R.ResizeFilter(name)
+        assert f.support == vectors["filter_support|" + name][0]
+        got = np.array([f.weight(x) for x in xs])
+        assert np.array_equal(got, vectors["filter|" + name]), name
+
+
+# ------------------------------- 4. live against the compiled reference (if built)
+def test_restatement_against_live_reference(refmod):
+    rng = np.random.default_rng(99)
+    for dtype in (np.uint16, np.float32):
+        px = rng.integers(0, 65536, (33, 45, 4), dtype=np.uint16)
+        if dtype == np.float32:
+            px = np.minimum(px.astype(np.float32) + rng.random(px.shape, dtype=np.float32), np.float32(65535))
+        assert_identical(R.blur_image(px, 0.0, 3.0), refmod.RefImage(px).blur(0.0, 3.0).numpy(), "blur")
+        assert_identical(R.resize_image(px, 90, 66, "lanczos"),
+                         refmod.RefImage(px).resize(90, 66, "Lanczos").numpy(), "resize")
+        assert_identical(R.transform_image_colorspace(px, "srgb", "lab"),
+                         refmod.RefImage(px).colorspace("Lab").numpy(), "lab")
+        assert_identical(R.equalize_image(px), refmod.RefImage(px).equalize().numpy(), "equalize")
