@@ -30,8 +30,9 @@ def _load(hdri):
     path = lib_path(hdri)
     if not os.path.exists(path):
         raise RuntimeError("compiled reference oracle missing: %s (make -C oracle/refbuild)" % path)
-    # the reference resolves config XML through this; absent files fall back to built-ins
-    os.environ.setdefault("MAGICK_CONFIGURE_PATH", "/root/reference/config")
+    # the reference looks for its config XML here; nothing is installed (and /root/reference
+    # does not exist on the GPU box), so every table falls back to its built-in defaults
+    os.environ.setdefault("MAGICK_CONFIGURE_PATH", os.path.join(_HERE, "_ref", "config"))
     L = ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL)
     vp, sz, dbl, cp = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_char_p
     pd = ctypes.POINTER(ctypes.c_double)

@@ -1,0 +1,166 @@
+"""CPU tests (`-m "not gpu"`) of the product's host side: the C-ABI library
+loads and exports every symbol include/magickhip.h declares, and the host-side
+builders (kernels, resize filters, LUTs — no device work) reproduce the
+reference's tables bit for bit.  No compute entry point is exercised beyond its
+argument/gate handling, which must fail loudly (never fall back to a CPU
+implementation) when no GPU is present."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import gpu_available
+from oracle import restate as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def vectors():
+    return np.load(os.path.join(GOLDEN, "reference_vectors.npz"))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "magickhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#\s*define[^\n]*", "", text)
+    return sorted(set(re.findall(r"MH_API[^;(]*?\b(\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(im):
+    from imagemagick_amd import _lib
+    lib = _lib.load()
+    names = declared_symbols()
+    assert len(names) >= 40
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, "libmagickhip.so lacks %s" % missing
+    bound = {p[0] for p in _lib.PROTOTYPES}
+    assert set(names) == bound, "binding and header disagree: %s" % (set(names) ^ bound)
+
+
+def test_no_torch_or_cxx_types_in_the_abi():
+    text = open(os.path.join(ROOT, "include", "magickhip.h")).read()
+    assert 'extern "C"' in text
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    assert "torch" not in text and "std::" not in text and "hipStream_t" not in text
+
+
+def test_operators_fail_loudly_without_a_device(im):
+    if gpu_available():
+        pytest.skip("a GPU is present")
+    px = np.zeros((8, 8, 4), np.uint16)
+    with pytest.raises(im.MagickHipError) as e:
+        im.blur_image(im.Image(px), 0.0, 2.0)
+    assert e.value.status in (2, 6)           # MH_NO_DEVICE / MH_DISABLED: the caller runs its CPU path
+    assert im.device_count() == 0
+
+
+def test_bad_arguments_are_rejected(im):
+    from imagemagick_amd import _lib
+    lib = _lib.load()
+    d = _lib.MhImage()
+    lib.MhInitImage(ctypes.byref(d), None, 4, 4, 4, 1, 0, 0)
+    assert lib.MagickHipBlurImage(ctypes.byref(d), ctypes.byref(d), 0.0, 1.0) != 0     # NULL pixels
+    assert lib.MagickHipBlurImage(None, None, 0.0, 1.0) != 0
+    assert lib.MhGetLastError() is not None
+    assert lib.MhAcquireKernelInfo(b"NoSuchKernel:3") is None or not lib.MhAcquireKernelInfo(b"NoSuchKernel:3")
+
+
+def test_init_image_traits(im):
+    """InitializePixelChannelMap + default channel mask, pixel.c:6132-6205, :6338-6393."""
+    from imagemagick_amd import _lib
+    lib = _lib.load()
+    d = _lib.MhImage()
+    lib.MhInitImage(ctypes.byref(d), None, 5, 7, 4, 1, 0, 0)
+    assert list(d.channel_traits) == [6, 6, 6, 2] and d.alpha_offset == 3     # Update|Blend x3, Update
+    lib.MhInitImage(ctypes.byref(d), None, 5, 7, 3, 0, 0, 0)
+    assert list(d.channel_traits)[:3] == [2, 2, 2] and d.alpha_offset == -1
+
+
+# ---------------------------------------------------------------- kernel builder
+@pytest.mark.parametrize("spec", ["blur:0x2", "blur:0x10", "blur:0x0.5", "blur:4x1.5", "blur:0x10+90",
+                                  "Disk:15", "Disk:2.5", "Gaussian:0x1.5", "3x3: 1,-,1 2,4,2 1,nan,3"])
+def test_kernel_builder_matches_reference(im, vectors, spec):
+    values, x, y, _ = im.kernel_to_numpy(spec)
+    want = vectors["kernel|" + spec]
+    assert values.shape == want.shape, spec
+    assert np.array_equal(np.isnan(values), np.isnan(want)), spec
+    assert np.array_equal(np.nan_to_num(values), np.nan_to_num(want)), "%s: values differ" % spec
+    assert [x, y] == list(vectors["kernel_origin|" + spec]), spec
+
+
+def test_kernel_builder_matches_oracle(im):
+    for radius, sigma in ((0.0, 2.0), (0.0, 10.0), (0.0, 0.7), (6.0, 3.0)):
+        values, x, y, count = im.kernel_to_numpy("blur:%.20gx%.20g;blur:%.20gx%.20g+90" %
+                                                 (radius, sigma, radius, sigma))
+        assert count == 2
+        want = R.blur_kernel(radius, sigma)
+        assert np.array_equal(values.ravel(), want) and x == (want.size - 1) // 2 and y == 0
+        v2, x2, y2, _ = im.kernel_to_numpy("blur:%.20gx%.20g;blur:%.20gx%.20g+90" %
+                                           (radius, sigma, radius, sigma), 1)
+        assert v2.shape == (want.size, 1) and np.array_equal(v2.ravel(), want) and (x2, y2) == (0, x)
+
+
+def test_optimal_kernel_width(im):
+    from imagemagick_amd import _lib
+    lib = _lib.load()
+    for sigma in (0.3, 0.5, 1.0, 2.0, 3.7, 10.0, 25.0):
+        assert lib.MhGetOptimalKernelWidth1D(0.0, sigma) == R.optimal_kernel_width_1d(0.0, sigma)
+    assert lib.MhGetOptimalKernelWidth1D(0.0, 10.0) == 79          # 79 taps on Q16
+    assert lib.MhGetOptimalKernelWidth1D(0.0, 2.0) == 17
+    assert lib.MhGetOptimalKernelWidth1D(2.2, 1.0) == 7
+
+
+# ----------------------------------------------------------------- resize filter
+FILTERS = ["Lanczos", "Mitchell", "Catrom", "Triangle", "Box", "Gaussian", "Hann", "Spline", "Cubic",
+           "Hermite", "Lanczos2", "LanczosSharp", "Robidoux", "Sinc", "Hamming", "Blackman", "Quadratic"]
+
+
+@pytest.mark.parametrize("name", FILTERS)
+def test_resize_filter_matches_reference(im, vectors, name):
+    from imagemagick_amd import _lib
+    lib = _lib.load()
+    f = lib.MhAcquireResizeFilter(_lib.FILTERS[name.lower()], 0)
+    assert f
+    try:
+        assert lib.MhGetResizeFilterSupport(f) == vectors["filter_support|" + name][0]
+        got = np.array([lib.MhGetResizeFilterWeight(f, float(x)) for x in vectors["filter_xs"]])
+        want = vectors["filter|" + name]
+        # sin/cos-based windows go through libm on both sides: identical here, 2 ULP allowed
+        assert np.allclose(got, want, rtol=0, atol=4.5e-16), "%s: max diff %g" % (name, np.abs(got - want).max())
+        if name in ("Lanczos", "Mitchell", "Catrom", "Triangle", "Box", "Spline", "Cubic", "Hermite",
+                    "Lanczos2", "LanczosSharp", "Robidoux", "Quadratic"):
+            assert np.array_equal(got, want), name          # polynomial filters: bit-identical
+    finally:
+        lib.MhDestroyResizeFilter(f)
+
+
+# -------------------------------------------------------------------- LUT builders
+@pytest.mark.parametrize("hdri", [False, True])
+def test_lut_builders_reproduce_the_operators(im, vectors, hdri):
+    tag = "hdri" if hdri else "q16"
+    px = vectors[tag + "_smooth_in"]
+    rows, cols, ch = px.shape
+    n = rows * cols
+    quantum = 1 if hdri else 0
+    inten = R.pixel_intensity(px)
+    idx = R.scale_quantum_to_map(R.clamp_to_quantum(inten, hdri), hdri)
+    hist = np.zeros((65536, ch), dtype=np.uint64)
+    for c in range(ch):
+        hist[:, c] = np.bincount(idx.ravel(), minlength=65536)
+    own = R.scale_quantum_to_map(px, hdri)
+
+    def apply(lut, mask):
+        out = px.copy()
+        for c in range(ch):
+            if (mask >> c) & 1:
+                out[:, :, c] = R.clamp_to_quantum(lut[own[:, :, c], c], hdri)
+        return out
+
+    lut, mask = im.contrast_stretch_lut(hist, cols, rows, 0.02 * n, n - 0.01 * n, quantum)
+    assert np.array_equal(apply(lut, mask), vectors[tag + "_smooth_cstretch"])
+    lut, mask = im.equalize_lut(hist, quantum)
+    assert np.array_equal(apply(lut, mask), vectors[tag + "_smooth_equalize"])
