@@ -120,6 +120,8 @@ def main():
     # uniform uint16 in every channel incl. alpha: exercises the alpha-weighted path
     src = torch.randint(-32768, 32768, (n, n, 4), generator=gen, device="cuda",
                         dtype=torch.int16).view(torch.uint16)
+    if os.environ.get("MAGICKHIP_BENCH_ZERO"):     # diagnostics only: data-dependent clocking
+        src.zero_()
     image = im.Image(src)
     out_holder = {}
 

@@ -19,6 +19,8 @@
 // one-slot-per-R padding that makes the stride-R reads bank-conflict free.
 #include "mh_internal.hpp"
 #include "device_common.hpp"
+#include <cstdlib>
+#include <type_traits>
 
 namespace mh {
 
@@ -39,7 +41,7 @@ struct Accum
       {
 #pragma unroll
         for (int c=0; c < C; c++)
-          s[r][c]=bias;
+          s[r][c]=A::premultiply ? (T) 0 : bias;
         g[r]=(T) 0;
       }
   }
@@ -53,14 +55,16 @@ struct Accum
     in.a=(T) 0;
     if constexpr (BLEND)
       {
-        // alpha=QuantumScale*GetPixelAlpha(): morphology.c:2766, :2965
-        in.a=A::mul((T) kQS,in.p[C-1]);
         if constexpr (A::premultiply)
           {
+            // gamma*pixel = (sum k*QS*alpha*p)/(sum k*QS*alpha): QuantumScale cancels, so
+            // the FAST policy weights by the raw alpha quantum
 #pragma unroll
             for (int c=0; c < C-1; c++)
-              in.p[c]=A::mul(in.a,in.p[c]);
+              in.p[c]=A::mul(in.p[C-1],in.p[c]);
           }
+        else
+          in.a=A::mul((T) kQS,in.p[C-1]);    // alpha=QuantumScale*GetPixelAlpha(): morphology.c:2766, :2965
       }
     return in;
   }
@@ -74,7 +78,8 @@ struct Accum
 #pragma unroll
             for (int c=0; c < C; c++)
               s[r][c]=A::mac(s[r][c],kv,in.p[c]);
-            g[r]=A::mac(g[r],kv,in.a);
+            // gamma = sum kv*QuantumScale*alpha = QuantumScale*(s[alpha]-bias): no
+            // separate accumulator in this mode (finish() derives it)
           }
         else
           {
@@ -97,9 +102,47 @@ struct Accum
 
   // returns the number of channels that count as "changed" (morphology.c:2772, :3199)
   __device__ __forceinline__ unsigned finish(int r,const Q (&center)[C],uint32_t copy_mask,
-    Q (&out)[C]) const
+    Q (&out)[C],T bias,bool count_changed=true) const
   {
     unsigned changed=0;
+    if constexpr (A::premultiply)
+      {
+        // FAST epilogue, all in f32 and branch-free.  s[] holds the un-biased sums
+        // S_c = sum k*alpha*p (colour), S_a = sum k*alpha; the reference's
+        // gamma*pixel is (bias*QuantumRange + S_c)/S_a, the alpha channel bias + S_a.
+        // v_rcp_f32(0) = inf and 0*inf = NaN convert to 0, which is what
+        // PerceptibleReciprocal's clamp yields for an all-transparent window.
+        static_assert(sizeof(Q) == 2,"the FAST policy is Q16 only");
+        T inv=(T) 1,cbias=bias;
+        if constexpr (BLEND)
+          {
+            inv=__builtin_amdgcn_rcpf(s[r][C-1]);
+            cbias=bias*(T) kQR;
+          }
+#pragma unroll
+        for (int c=0; c < C; c++)
+          {
+            T pixel=s[r][c];
+            if (BLEND && (c != C-1))
+              pixel=(pixel+cbias)*inv;
+            else
+              pixel=pixel+bias;
+            if (count_changed)
+              {
+                // compares the un-normalised sum (morphology.c:2772, :3199)
+                T raw=BLEND && (c != C-1) ? (T) kQS*s[r][c]+bias : s[r][c]+bias;
+                T d=raw-(T) center[c];
+                if (!((copy_mask >> c) & 1u) && ((d < (T) 0 ? -d : d) >= (T) kEps))
+                  changed++;
+              }
+            // ClampToQuantum (quantum.h:86-97): v_cvt_u32_f32 maps NaN and negatives to 0
+            unsigned q=(unsigned) (pixel+(T) 0.5);
+            q=q > 65535u ? 65535u : q;
+            out[c]=((copy_mask >> c) & 1u) ? center[c] : (Q) q;
+          }
+        return changed;
+      }
+    T gsum=g[r];
 #pragma unroll
     for (int c=0; c < C; c++)
       {
@@ -112,12 +155,7 @@ struct Accum
         if (fabs(pixel-(double) center[c]) >= kEps)
           changed++;
         if (BLEND && (c != C-1))
-          {
-            if constexpr (A::premultiply)
-              pixel=(double) (s[r][c]*(T) perceptible_reciprocal((double) g[r]));
-            else
-              pixel=perceptible_reciprocal((double) g[r])*pixel;
-          }
+          pixel=perceptible_reciprocal((double) gsum)*pixel;
         out[c]=QuantumOps<Q>::clamp(pixel);
       }
     return changed;
@@ -135,6 +173,8 @@ struct Conv1DArgs
   uint32_t copy_mask;
   const void *taps;          // T[K], reversed so that taps[v] multiplies input o-shift+v
   unsigned long long *changed;
+  int nblocks;               // blocked kernels: number of U-sample blocks of the padded tap table
+  int ablate;                // MAGICKHIP_ABLATE (profiling only): 1 = fetch samples once, 2 = fetch taps once
 };
 
 // --------------------------------------------------------------- column pass
@@ -238,7 +278,7 @@ void conv_column_kernel(Conv1DArgs args)
         {
           Q center[C],out[C];
           load_pixel<Q,C>(src+(size_t) y*pitch+(size_t) xc*C,center);
-          unsigned ch=acc.finish(r,center,args.copy_mask,out);
+          unsigned ch=acc.finish(r,center,args.copy_mask,out,(T) args.bias);
           if (x < W)
             {
               store_pixel<Q,C>(dst+(size_t) y*pitch+(size_t) x*C,out);
@@ -370,7 +410,7 @@ void conv_row_kernel(Conv1DArgs args)
           Q center[C],out[C];
           int ci=lane*R+r+args.shift;         // strip index of input column x
           load_pixel<Q,C>(strip+(size_t) lds_slot<R>(ci)*C,center);
-          changed+=acc.finish(r,center,args.copy_mask,out);
+          changed+=acc.finish(r,center,args.copy_mask,out,(T) args.bias);
           store_pixel<Q,C>(dst+(size_t) y*pitch+(size_t) x*C,out);
         }
     }
@@ -380,6 +420,450 @@ void conv_row_kernel(Conv1DArgs args)
       if ((lane == 0) && (changed != 0))
         atomicAdd(args.changed,(unsigned long long) changed);
     }
+}
+
+
+// =================================================================== blocked
+// Q16 kernels.  Same register blocking (each lane owns R consecutive outputs
+// along the filter axis and streams the R+K-1 inputs they depend on once),
+// but the input stream is cut into blocks of U samples and the tap table is
+// zero-padded by R-1 entries on both sides: inside a block the tap that
+// output r takes from sample jj is  table[jb + (jj-r+R-1)], a compile-time
+// offset from the wave-uniform block base, so one block needs R+U-1 taps that
+// are fetched with a few scalar loads into SGPRs and every FMA reads its tap
+// from a fixed SGPR.  No per-sample tap reloads, no ramp-up/ramp-down branches
+// (the zero taps make the edge samples contribute nothing; Q16 samples are
+// always finite, so  s + 0*p == s  exactly and the EXACT order is unchanged).
+// The samples of block b+1 are fetched into registers while block b is
+// accumulated.
+//
+// Where the taps live matters on gfx950 (tools/ubench/valu_rate.hip, 4 waves/SIMD):
+// v_fmac_f32 with an SGPR multiplier sustains 64.6 TFLOP/s, the all-VGPR form
+// 122 TFLOP/s.  The f32 policy therefore stages the tap table in LDS once per
+// workgroup and reads each block's R+U-1 taps with broadcast ds_reads into
+// VGPRs; the f64 policy (no such penalty measured) keeps scalar loads.
+template<typename T,bool IN_LDS>
+static __device__ __forceinline__ const T *stage_taps(const Conv1DArgs &args,unsigned char *smem,
+  int count,bool sync_done)
+{
+  const T *global=static_cast<const T *>(args.taps);
+  if constexpr (!IN_LDS)
+    return global;
+  else
+    {
+      T *lds=reinterpret_cast<T *>(smem);
+      for (int i=(int) threadIdx.x; i < count; i+=(int) blockDim.x)
+        lds[i]=global[i];
+      if (!sync_done)
+        __syncthreads();
+      return lds;
+    }
+}
+
+template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES,int DBG=0>
+__global__ __launch_bounds__(64*WAVES)
+void conv_column_blocked(Conv1DArgs args)
+{
+  typedef typename A::T T;
+  typedef Accum<Q,C,BLEND,A,R> Acc;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane=(int) (threadIdx.x & 63);
+  const int wave=__builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const int W=args.columns,H=args.rows;
+  const unsigned ntx=(unsigned) ((W+63)/64);
+  const unsigned nty=(unsigned) ((H+R*WAVES-1)/(R*WAVES));
+  const unsigned total=ntx*nty;
+  const unsigned id=blockIdx.x;
+  const unsigned per=(total+7u)/8u;
+  const unsigned tile=(id & 7u)*per+(id >> 3);       // XCD-aware: see conv_column_kernel
+  if (tile >= total)
+    return;
+  const int tx=(int) (tile/nty),ty=(int) (tile%nty);
+  const int x=tx*64+lane;
+  const int xc=x < W ? x : W-1;
+  const int y0=(ty*WAVES+wave)*R;
+  const Q *src=static_cast<const Q *>(args.src)+(size_t) xc*C;
+  Q *dst=static_cast<Q *>(args.dst);
+  const size_t pitch=(size_t) W*C;
+  const int ybase=y0-args.shift;
+  const int nblocks=args.nblocks;
+  const T *table=stage_taps<T,A::taps_in_lds>(args,smem_raw,nblocks*U+R-1,false);
+  if (y0 >= H)
+    return;
+
+  Acc acc;
+  acc.init((T) args.bias);
+  Q nxt[U][C];
+  // interior tiles (every row this wave touches exists) address row jb+jj as
+  // uniform base + jj*pitch + lane offset: two scalar adds per row and an
+  // SGPR-base load, instead of a clamp and a 64-bit multiply per row
+  const bool interior=(ybase >= 0) && (ybase+nblocks*U <= H);
+  const unsigned lane_off=(unsigned) xc*(unsigned) (C*sizeof(Q));
+  const char *base0=reinterpret_cast<const char *>(args.src);
+  const size_t pitch_bytes=pitch*sizeof(Q);
+  auto fetch=[&](int jb)
+  {
+    if (interior)
+      {
+        const char *rowp=base0+(size_t) (ybase+jb)*pitch_bytes;
+#pragma unroll
+        for (int jj=0; jj < U; jj++)
+          {
+            load_pixel<Q,C>(reinterpret_cast<const Q *>(rowp+lane_off),nxt[jj]);
+            rowp+=pitch_bytes;
+          }
+      }
+    else
+      {
+#pragma unroll
+        for (int jj=0; jj < U; jj++)
+          {
+            int yy=ybase+jb+jj;
+            yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
+            load_pixel<Q,C>(src+(size_t) yy*pitch,nxt[jj]);
+          }
+      }
+  };
+  fetch(0);
+  T tw0[R+U-1];
+  if constexpr ((DBG & 2) != 0)
+    {
+#pragma unroll
+      for (int i=0; i < R+U-1; i++)
+        tw0[i]=table[i];
+    }
+  for (int b=0; b < nblocks; b++)
+    {
+      const int jb=b*U;
+      const int tb=(args.ablate & 2) ? 0 : jb;
+      T tw[R+U-1];
+#pragma unroll
+      for (int i=0; i < R+U-1; i++)
+        tw[i]=(DBG & 2) ? tw0[i] : table[tb+i];
+      Q cur[U][C];
+#pragma unroll
+      for (int jj=0; jj < U; jj++)
+#pragma unroll
+        for (int c=0; c < C; c++)
+          cur[jj][c]=nxt[jj][c];
+      if constexpr ((DBG & 4) == 0)
+        if ((b+1 < nblocks) && !(args.ablate & 1))
+          fetch(jb+U);
+#pragma unroll
+      for (int jj=0; jj < U; jj++)
+        {
+          typename Acc::In in;
+          if constexpr ((DBG & 1) != 0)
+            {
+#pragma unroll
+              for (int c=0; c < C; c++)
+                in.p[c]=(T) __uint_as_float(((unsigned) cur[jj][c] << 7)+0x3f800000u+(unsigned) (b+jj));
+              in.a=(T) 0;
+            }
+          else
+            in=Acc::prepare(cur[jj]);
+#pragma unroll
+          for (int r=0; r < R; r++)
+            acc.tap(r,tw[jj-r+R-1],in);
+        }
+    }
+  if constexpr ((DBG & 8) != 0)
+    {
+      T sum=(T) 0;
+#pragma unroll
+      for (int r=0; r < R; r++)
+#pragma unroll
+        for (int c=0; c < C; c++)
+          sum+=acc.s[r][c];
+      if (x < W)
+        dst[(size_t) y0*pitch+(size_t) x*C]=(Q) sum;
+      return;
+    }
+  unsigned changed=0;
+  // the centre pixel is only needed for the `changed` count and for Copy channels
+  const bool need_center=(args.changed != nullptr) || (args.copy_mask != 0);
+#pragma unroll
+  for (int r=0; r < R; r++)
+    {
+      int y=y0+r;
+      if (y < H)
+        {
+          Q center[C],out[C];
+#pragma unroll
+          for (int c=0; c < C; c++)
+            center[c]=(Q) 0;
+          if (need_center)
+            load_pixel<Q,C>(src+(size_t) y*pitch,center);
+          unsigned ch=acc.finish(r,center,args.copy_mask,out,(T) args.bias,args.changed != nullptr);
+          if (x < W)
+            {
+              store_pixel<Q,C>(dst+(size_t) y*pitch+(size_t) x*C,out);
+              changed+=ch;
+            }
+        }
+    }
+  if (args.changed != nullptr)
+    {
+      changed=wave_sum(changed);
+      if ((lane == 0) && (changed != 0))
+        atomicAdd(args.changed,(unsigned long long) changed);
+    }
+}
+
+// Row pass: a wave stages the 63R+NJ input pixels its 64R outputs depend on in
+// LDS (coalesced global reads), with one padding slot every R samples so the
+// stride-R reads of the 64 lanes fall on distinct banks; blocks are R samples
+// long (U == R) so the slot of sample jb+jj is  base + jb + jb/R + jj.
+template<typename Q,int C,bool BLEND,class A,int R,int WAVES,int DBG=0>
+__global__ __launch_bounds__(64*WAVES)
+void conv_row_blocked(Conv1DArgs args)
+{
+  typedef typename A::T T;
+  typedef Accum<Q,C,BLEND,A,R> Acc;
+  constexpr int U=R;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane=(int) (threadIdx.x & 63);
+  const int wave=__builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const int W=args.columns,H=args.rows;
+  const int nblocks=args.nblocks;
+  const int SEG=64*R;                         // outputs per wave
+  const int NS=63*R+nblocks*U;                // input samples per wave
+  const int slots=NS+NS/R+1;
+  const int table_bytes=A::taps_in_lds ? (((nblocks*U+R-1)*(int) sizeof(T)+15) & ~15) : 0;
+  Q *strip=reinterpret_cast<Q *>(smem_raw+table_bytes)+(size_t) wave*slots*C;
+
+  const unsigned ntx=(unsigned) ((W+SEG-1)/SEG);
+  const unsigned nty=(unsigned) ((H+WAVES-1)/WAVES);
+  const unsigned total=ntx*nty;
+  const unsigned id=blockIdx.x;
+  const unsigned per=(total+7u)/8u;
+  const unsigned tile=(id & 7u)*per+(id >> 3);
+  if (tile >= total)
+    return;
+  const int tx=(int) (tile%ntx),ty=(int) (tile/ntx);
+  const int y=ty*WAVES+wave;
+  const int x0=tx*SEG;
+  const Q *src=static_cast<const Q *>(args.src);
+  Q *dst=static_cast<Q *>(args.dst);
+  const T *table=stage_taps<T,A::taps_in_lds>(args,smem_raw,nblocks*U+R-1,true);
+  const size_t pitch=(size_t) W*C;
+  const bool row_ok=y < H;
+  const Q *row=src+(size_t) (row_ok ? y : H-1)*pitch;
+
+  // stage the strip in batches: all loads of a batch are in flight before the
+  // first LDS store waits for one (a load-store loop would pay one memory
+  // latency per 64 samples)
+  if constexpr ((DBG & 1) == 0)
+  {
+    constexpr int BATCH=10;
+    for (int i0=lane; i0 < NS; i0+=64*BATCH)
+      {
+        Q v[BATCH][C];
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          {
+            int i=i0+64*k;
+            int xx=x0-args.shift+(i < NS ? i : NS-1);
+            xx=xx < 0 ? 0 : (xx > W-1 ? W-1 : xx);
+            load_pixel<Q,C>(row+(size_t) xx*C,v[k]);
+          }
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          {
+            int i=i0+64*k;
+            if (i < NS)
+              store_pixel<Q,C>(strip+(size_t) (i+i/R)*C,v[k]);
+          }
+      }
+  }
+  __syncthreads();
+  if (!row_ok)
+    return;
+
+  Acc acc;
+  acc.init((T) args.bias);
+  const Q *mine=strip+(size_t) lane*(R+1)*C;     // slot of sample lane*R
+  for (int b=0; b < nblocks; b++)
+    {
+      const int jb=b*U;
+      const int tb=(args.ablate & 2) ? 0 : jb;
+      T tw[R+U-1];
+#pragma unroll
+      for (int i=0; i < R+U-1; i++)
+        tw[i]=table[tb+i];
+      const Q *blk=mine+(size_t) ((args.ablate & 1) ? 0 : (jb+b))*C;       // jb + jb/R
+#pragma unroll
+      for (int jj=0; jj < U; jj++)
+        {
+          Q q[C];
+          load_pixel<Q,C>(blk+(size_t) jj*C,q);
+          typename Acc::In in=Acc::prepare(q);
+#pragma unroll
+          for (int r=0; r < R; r++)
+            acc.tap(r,tw[jj-r+R-1],in);
+        }
+    }
+  unsigned changed=0;
+  const int xo=x0+lane*R;
+  if constexpr ((DBG & 2) != 0)
+    {
+      T sum=(T) 0;
+#pragma unroll
+      for (int r=0; r < R; r++)
+#pragma unroll
+        for (int c=0; c < C; c++)
+          sum+=acc.s[r][c];
+      if (xo < W)
+        dst[(size_t) y*pitch+(size_t) xo*C]=(Q) sum;
+      return;
+    }
+#pragma unroll
+  for (int r=0; r < R; r++)
+    {
+      int x=xo+r;
+      if (x < W)
+        {
+          Q center[C],out[C];
+          int ci=lane*R+r+args.shift;           // strip index of input column x
+          load_pixel<Q,C>(strip+(size_t) (ci+ci/R)*C,center);
+          changed+=acc.finish(r,center,args.copy_mask,out,(T) args.bias,args.changed != nullptr);
+          store_pixel<Q,C>(dst+(size_t) y*pitch+(size_t) x*C,out);
+        }
+    }
+  if (args.changed != nullptr)
+    {
+      changed=wave_sum(changed);
+      if ((lane == 0) && (changed != 0))
+        atomicAdd(args.changed,(unsigned long long) changed);
+    }
+}
+
+template<typename Q,int C,bool BLEND,class A,int R,int U>
+static MhStatus launch_blocked(const View &src,const View &dst,bool vertical,
+  const Conv1DParams &p,const Roles &roles,unsigned long long *changed)
+{
+  typedef typename A::T T;
+  constexpr int WAVES=4;
+  const int K=p.ntaps;
+  const int UU=vertical ? U : R;
+  const int NJ=R+K-1;
+  const int nblocks=(NJ+UU-1)/UU;
+  // padded, reversed tap table: entry e multiplies, for output r, the sample
+  // j = e-(R-1)+r; taps are reversed as in launch_one (morphology.c:2746, :2919)
+  std::vector<T> host((size_t) (nblocks*UU+R-1+UU),(T) 0);
+  for (int v=0; v < K; v++)
+    host[(size_t) (v+R-1)]=(T) p.taps[K-1-v];
+  Temp taps;
+  MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(T)));
+
+  Conv1DArgs args;
+  args.src=src.pixels;
+  args.dst=dst.pixels;
+  args.columns=(int) src.columns;
+  args.rows=(int) src.rows;
+  args.ntaps=K;
+  args.shift=K-1-p.origin;
+  args.bias=p.bias;
+  args.copy_mask=roles.copy_mask;
+  args.taps=taps.ptr;
+  args.changed=changed;
+  args.nblocks=nblocks;
+  {
+    const char *e=getenv("MAGICKHIP_ABLATE");
+    args.ablate=e != nullptr ? atoi(e) : 0;
+  }
+  const int W=args.columns,H=args.rows;
+  if (vertical)
+    {
+      unsigned ntx=(unsigned) ((W+63)/64),nty=(unsigned) ((H+R*WAVES-1)/(R*WAVES));
+      unsigned grid=((ntx*nty+7u)/8u)*8u;
+      size_t lds=A::taps_in_lds ? (size_t) (nblocks*UU+R-1)*sizeof(T) : 0;
+      ProfileScope prof("conv_column",src.stream);
+      const char *dbg=getenv("MAGICKHIP_DBG");
+      int d=dbg != nullptr ? atoi(dbg) : 0;
+      if constexpr (std::is_same<A,Fast32>::value && (C == 4) && BLEND)
+        if ((d == 108) || (d == 116))
+          {
+            if (d == 108)
+              {
+                unsigned nty8=(unsigned) ((H+R*8-1)/(R*8)); unsigned g8=((ntx*nty8+7u)/8u)*8u;
+                hipLaunchKernelGGL((conv_column_blocked<Q,C,BLEND,A,R,U,8>),dim3(g8),dim3(64*8),lds,src.stream,args);
+              }
+            else
+              {
+                unsigned nty16=(unsigned) ((H+R*16-1)/(R*16)); unsigned g16=((ntx*nty16+7u)/8u)*8u;
+                hipLaunchKernelGGL((conv_column_blocked<Q,C,BLEND,A,R,U,16>),dim3(g16),dim3(64*16),lds,src.stream,args);
+              }
+            MH_HIP(hipGetLastError());
+            return MH_OK;
+          }
+      if constexpr (std::is_same<A,Fast32>::value && (C == 4) && BLEND)
+        {
+          switch (d)
+          {
+#define MH_DBG_CASE(n) case n: hipLaunchKernelGGL((conv_column_blocked<Q,C,BLEND,A,R,U,WAVES,n>),dim3(grid),dim3(64*WAVES),lds,src.stream,args); break;
+            MH_DBG_CASE(1) MH_DBG_CASE(2) MH_DBG_CASE(3) MH_DBG_CASE(4) MH_DBG_CASE(7) MH_DBG_CASE(8) MH_DBG_CASE(15) MH_DBG_CASE(12) MH_DBG_CASE(9)
+#undef MH_DBG_CASE
+            default: hipLaunchKernelGGL((conv_column_blocked<Q,C,BLEND,A,R,U,WAVES>),dim3(grid),dim3(64*WAVES),lds,src.stream,args);
+          }
+        }
+      else
+      hipLaunchKernelGGL((conv_column_blocked<Q,C,BLEND,A,R,U,WAVES>),dim3(grid),dim3(64*WAVES),lds,
+        src.stream,args);
+    }
+  else
+    {
+      const int SEG=64*R,NS=63*R+nblocks*R,slots=NS+NS/R+1;
+      size_t table_bytes=A::taps_in_lds ? ((((size_t) (nblocks*UU+R-1))*sizeof(T)+15u) & ~(size_t) 15u) : 0;
+      size_t lds=table_bytes+(size_t) WAVES*slots*C*sizeof(Q);
+      if (lds > 160u*1024u)
+        return fail(MH_UNSUPPORTED,"row kernel of %d taps needs %zu bytes of LDS",K,lds);
+      unsigned ntx=(unsigned) ((W+SEG-1)/SEG),nty=(unsigned) ((H+WAVES-1)/WAVES);
+      unsigned grid=((ntx*nty+7u)/8u)*8u;
+      if (lds > 64u*1024u)
+        MH_HIP(hipFuncSetAttribute(
+          reinterpret_cast<const void *>(&conv_row_blocked<Q,C,BLEND,A,R,WAVES>),
+          hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+      ProfileScope prof("conv_row",src.stream);
+      const char *dbg=getenv("MAGICKHIP_DBGR");
+      int d=dbg != nullptr ? atoi(dbg) : 0;
+      if constexpr (std::is_same<A,Fast32>::value && (C == 4) && BLEND)
+        {
+          switch (d)
+          {
+#define MH_DBG_CASE(n) case n: hipLaunchKernelGGL((conv_row_blocked<Q,C,BLEND,A,R,WAVES,n>),dim3(grid),dim3(64*WAVES),lds,src.stream,args); break;
+            MH_DBG_CASE(1) MH_DBG_CASE(2) MH_DBG_CASE(3)
+#undef MH_DBG_CASE
+            default: hipLaunchKernelGGL((conv_row_blocked<Q,C,BLEND,A,R,WAVES>),dim3(grid),dim3(64*WAVES),lds,src.stream,args);
+          }
+        }
+      else
+      hipLaunchKernelGGL((conv_row_blocked<Q,C,BLEND,A,R,WAVES>),dim3(grid),dim3(64*WAVES),lds,
+        src.stream,args);
+    }
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+template<class A,int R,int U>
+static MhStatus dispatch_blocked(const View &src,const View &dst,bool vertical,
+  const Conv1DParams &p,const Roles &roles,unsigned long long *changed)
+{
+  typedef uint16_t Q;
+  const bool blend=roles.blend && (roles.alpha == src.channels-1);
+  switch (src.channels)
+  {
+    case 1: return launch_blocked<Q,1,false,A,R,U>(src,dst,vertical,p,roles,changed);
+    case 2:
+      if (blend) return launch_blocked<Q,2,true,A,R,U>(src,dst,vertical,p,roles,changed);
+      return launch_blocked<Q,2,false,A,R,U>(src,dst,vertical,p,roles,changed);
+    case 3: return launch_blocked<Q,3,false,A,R,U>(src,dst,vertical,p,roles,changed);
+    case 4:
+      if (blend) return launch_blocked<Q,4,true,A,R,U>(src,dst,vertical,p,roles,changed);
+      return launch_blocked<Q,4,false,A,R,U>(src,dst,vertical,p,roles,changed);
+    default: break;
+  }
+  return fail(MH_UNSUPPORTED,"%d channels",src.channels);
 }
 
 // ---------------------------------------------------------------- launcher
@@ -475,8 +959,15 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
   if (src.quantum == MH_QUANTUM_U16)
     {
       if (prec == MH_PRECISION_FAST)
-        return dispatch_channels<uint16_t,Fast32,16>(src,dst,vertical,params,roles,changed);
-      return dispatch_channels<uint16_t,Exact64,8>(src,dst,vertical,params,roles,changed);
+        {
+          const char *e=getenv("MAGICKHIP_U");
+          if ((e != nullptr) && (atoi(e) == 16))
+            return dispatch_blocked<Fast32,16,16>(src,dst,vertical,params,roles,changed);
+          if ((e != nullptr) && (atoi(e) == 4))
+            return dispatch_blocked<Fast32,16,4>(src,dst,vertical,params,roles,changed);
+          return dispatch_blocked<Fast32,16,8>(src,dst,vertical,params,roles,changed);
+        }
+      return dispatch_blocked<Exact64,8,8>(src,dst,vertical,params,roles,changed);
     }
   // float Quantum always accumulates in double: an FP32 sum cannot stay
   // within 1 ULP of a float result.

@@ -125,6 +125,7 @@ struct Exact64
 {
   typedef double T;
   static constexpr bool premultiply=false;
+  static constexpr bool taps_in_lds=false;
   static __device__ __forceinline__ T mul(T a,T b) { return a*b; }
   static __device__ __forceinline__ T add(T a,T b) { return a+b; }
   static __device__ __forceinline__ T mac(T acc,T a,T b) { return acc+a*b; }   // two roundings
@@ -137,6 +138,7 @@ struct Fast32
 {
   typedef float T;
   static constexpr bool premultiply=true;
+  static constexpr bool taps_in_lds=true;
   static __device__ __forceinline__ T mul(T a,T b) { return a*b; }
   static __device__ __forceinline__ T add(T a,T b) { return a+b; }
   static __device__ __forceinline__ T mac(T acc,T a,T b) { return __builtin_fmaf(a,b,acc); }
