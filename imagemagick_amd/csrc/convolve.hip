@@ -29,10 +29,18 @@ template<typename Q,int C,bool BLEND,class A,int R>
 struct Accum
 {
   typedef typename A::T T;
-  T s[R][C];
+  // channel pairs live in 2-element vectors so the f32 policy can issue one
+  // v_pk_fma_f32 per pair: a wave can issue only one VALU instruction per ~4.6
+  // cycles (tools/ubench), so the packed form halves the issue slots a wave needs
+  // and a single ready wave keeps the SIMD's FMA pipe busy.
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  static constexpr int NP=(C+1)/2;
+  V2 sv[R][NP];
   T g[R];
+#define MH_S(r,c) sv[r][(c) >> 1][(c) & 1]
 
-  struct In { T p[C]; T a; };
+  struct In { V2 pv[NP]; T a; };
+#define MH_P(in,c) (in).pv[(c) >> 1][(c) & 1]
 
   __device__ __forceinline__ void init(T bias)
   {
@@ -41,7 +49,7 @@ struct Accum
       {
 #pragma unroll
         for (int c=0; c < C; c++)
-          s[r][c]=A::premultiply ? (T) 0 : bias;
+          MH_S(r,c)=A::premultiply ? (T) 0 : bias;
         g[r]=(T) 0;
       }
   }
@@ -50,8 +58,11 @@ struct Accum
   {
     In in;
 #pragma unroll
+    for (int q2=0; q2 < NP; q2++)
+      in.pv[q2]=V2{(T) 0,(T) 0};
+#pragma unroll
     for (int c=0; c < C; c++)
-      in.p[c]=(T) q[c];
+      MH_P(in,c)=(T) q[c];
     in.a=(T) 0;
     if constexpr (BLEND)
       {
@@ -61,12 +72,22 @@ struct Accum
             // the FAST policy weights by the raw alpha quantum
 #pragma unroll
             for (int c=0; c < C-1; c++)
-              in.p[c]=A::mul(in.p[C-1],in.p[c]);
+              MH_P(in,c)=A::mul(MH_P(in,C-1),MH_P(in,c));
           }
         else
-          in.a=A::mul((T) kQS,in.p[C-1]);    // alpha=QuantumScale*GetPixelAlpha(): morphology.c:2766, :2965
+          in.a=A::mul((T) kQS,MH_P(in,C-1));    // alpha=QuantumScale*GetPixelAlpha(): morphology.c:2766, :2965
       }
     return in;
+  }
+
+  __device__ __forceinline__ void packed_mac(int r,T kv,const In &in)
+  {
+    V2 k2={kv,kv};
+#pragma unroll
+    for (int q=0; q < C/2; q++)
+      sv[r][q]=__builtin_elementwise_fma(k2,in.pv[q],sv[r][q]);
+    if constexpr ((C & 1) != 0)
+      MH_S(r,C-1)=A::mac(MH_S(r,C-1),kv,MH_P(in,C-1));
   }
 
   __device__ __forceinline__ void tap(int r,T kv,const In &in)
@@ -75,9 +96,7 @@ struct Accum
       {
         if constexpr (A::premultiply)
           {
-#pragma unroll
-            for (int c=0; c < C; c++)
-              s[r][c]=A::mac(s[r][c],kv,in.p[c]);
+            packed_mac(r,kv,in);
             // gamma = sum kv*QuantumScale*alpha = QuantumScale*(s[alpha]-bias): no
             // separate accumulator in this mode (finish() derives it)
           }
@@ -87,16 +106,21 @@ struct Accum
             T w=A::mul(in.a,kv);
 #pragma unroll
             for (int c=0; c < C-1; c++)
-              s[r][c]=A::add(s[r][c],A::mul(w,in.p[c]));
+              MH_S(r,c)=A::add(MH_S(r,c),A::mul(w,MH_P(in,c)));
             g[r]=A::add(g[r],w);
-            s[r][C-1]=A::mac(s[r][C-1],kv,in.p[C-1]);      // alpha channel: no weighting
+            MH_S(r,C-1)=A::mac(MH_S(r,C-1),kv,MH_P(in,C-1));      // alpha channel: no weighting
           }
       }
     else
       {
+        if constexpr (A::premultiply)
+          packed_mac(r,kv,in);
+        else
+          {
 #pragma unroll
-        for (int c=0; c < C; c++)
-          s[r][c]=A::mac(s[r][c],kv,in.p[c]);              // morphology.c:2750
+            for (int c=0; c < C; c++)
+              MH_S(r,c)=A::mac(MH_S(r,c),kv,MH_P(in,c));          // morphology.c:2750
+          }
       }
   }
 
@@ -116,13 +140,13 @@ struct Accum
         T inv=(T) 1,cbias=bias;
         if constexpr (BLEND)
           {
-            inv=__builtin_amdgcn_rcpf(s[r][C-1]);
+            inv=__builtin_amdgcn_rcpf(MH_S(r,C-1));
             cbias=bias*(T) kQR;
           }
 #pragma unroll
         for (int c=0; c < C; c++)
           {
-            T pixel=s[r][c];
+            T pixel=MH_S(r,c);
             if (BLEND && (c != C-1))
               pixel=(pixel+cbias)*inv;
             else
@@ -130,7 +154,7 @@ struct Accum
             if (count_changed)
               {
                 // compares the un-normalised sum (morphology.c:2772, :3199)
-                T raw=BLEND && (c != C-1) ? (T) kQS*s[r][c]+bias : s[r][c]+bias;
+                T raw=BLEND && (c != C-1) ? (T) kQS*MH_S(r,c)+bias : MH_S(r,c)+bias;
                 T d=raw-(T) center[c];
                 if (!((copy_mask >> c) & 1u) && ((d < (T) 0 ? -d : d) >= (T) kEps))
                   changed++;
@@ -151,7 +175,7 @@ struct Accum
             out[c]=center[c];
             continue;
           }
-        double pixel=(double) s[r][c];
+        double pixel=(double) MH_S(r,c);
         if (fabs(pixel-(double) center[c]) >= kEps)
           changed++;
         if (BLEND && (c != C-1))
@@ -174,7 +198,6 @@ struct Conv1DArgs
   const void *taps;          // T[K], reversed so that taps[v] multiplies input o-shift+v
   unsigned long long *changed;
   int nblocks;               // blocked kernels: number of U-sample blocks of the padded tap table
-  int ablate;                // MAGICKHIP_ABLATE (profiling only): 1 = fetch samples once, 2 = fetch taps once
 };
 
 // --------------------------------------------------------------- column pass
@@ -460,7 +483,7 @@ static __device__ __forceinline__ const T *stage_taps(const Conv1DArgs &args,uns
     }
 }
 
-template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES,int DBG=0>
+template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_column_blocked(Conv1DArgs args)
 {
@@ -525,59 +548,29 @@ void conv_column_blocked(Conv1DArgs args)
       }
   };
   fetch(0);
-  T tw0[R+U-1];
-  if constexpr ((DBG & 2) != 0)
-    {
-#pragma unroll
-      for (int i=0; i < R+U-1; i++)
-        tw0[i]=table[i];
-    }
   for (int b=0; b < nblocks; b++)
     {
       const int jb=b*U;
-      const int tb=(args.ablate & 2) ? 0 : jb;
       T tw[R+U-1];
 #pragma unroll
       for (int i=0; i < R+U-1; i++)
-        tw[i]=(DBG & 2) ? tw0[i] : table[tb+i];
+        tw[i]=table[jb+i];
       Q cur[U][C];
 #pragma unroll
       for (int jj=0; jj < U; jj++)
 #pragma unroll
         for (int c=0; c < C; c++)
           cur[jj][c]=nxt[jj][c];
-      if constexpr ((DBG & 4) == 0)
-        if ((b+1 < nblocks) && !(args.ablate & 1))
-          fetch(jb+U);
+      if (b+1 < nblocks)
+        fetch(jb+U);
 #pragma unroll
       for (int jj=0; jj < U; jj++)
         {
-          typename Acc::In in;
-          if constexpr ((DBG & 1) != 0)
-            {
-#pragma unroll
-              for (int c=0; c < C; c++)
-                in.p[c]=(T) __uint_as_float(((unsigned) cur[jj][c] << 7)+0x3f800000u+(unsigned) (b+jj));
-              in.a=(T) 0;
-            }
-          else
-            in=Acc::prepare(cur[jj]);
+          typename Acc::In in=Acc::prepare(cur[jj]);
 #pragma unroll
           for (int r=0; r < R; r++)
             acc.tap(r,tw[jj-r+R-1],in);
         }
-    }
-  if constexpr ((DBG & 8) != 0)
-    {
-      T sum=(T) 0;
-#pragma unroll
-      for (int r=0; r < R; r++)
-#pragma unroll
-        for (int c=0; c < C; c++)
-          sum+=acc.s[r][c];
-      if (x < W)
-        dst[(size_t) y0*pitch+(size_t) x*C]=(Q) sum;
-      return;
     }
   unsigned changed=0;
   // the centre pixel is only needed for the `changed` count and for Copy channels
@@ -614,13 +607,13 @@ void conv_column_blocked(Conv1DArgs args)
 // LDS (coalesced global reads), with one padding slot every R samples so the
 // stride-R reads of the 64 lanes fall on distinct banks; blocks are R samples
 // long (U == R) so the slot of sample jb+jj is  base + jb + jb/R + jj.
-template<typename Q,int C,bool BLEND,class A,int R,int WAVES,int DBG=0>
+template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_row_blocked(Conv1DArgs args)
 {
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
-  constexpr int U=R;
+  static_assert((R%U) == 0,"a block of U samples must not straddle an LDS padding slot");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane=(int) (threadIdx.x & 63);
   const int wave=__builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
@@ -653,7 +646,6 @@ void conv_row_blocked(Conv1DArgs args)
   // stage the strip in batches: all loads of a batch are in flight before the
   // first LDS store waits for one (a load-store loop would pay one memory
   // latency per 64 samples)
-  if constexpr ((DBG & 1) == 0)
   {
     constexpr int BATCH=10;
     for (int i0=lane; i0 < NS; i0+=64*BATCH)
@@ -683,21 +675,36 @@ void conv_row_blocked(Conv1DArgs args)
   Acc acc;
   acc.init((T) args.bias);
   const Q *mine=strip+(size_t) lane*(R+1)*C;     // slot of sample lane*R
+  // the samples of block b+1 are read from LDS into registers while block b is
+  // accumulated (sample jb+jj sits in slot jb + jb/R + jj: U divides R)
+  Q nxt[U][C];
+  auto fetch=[&](int jb)
+  {
+    const Q *blk=mine+(size_t) (jb+jb/R)*C;
+#pragma unroll
+    for (int jj=0; jj < U; jj++)
+      load_pixel<Q,C>(blk+(size_t) jj*C,nxt[jj]);
+  };
+  fetch(0);
   for (int b=0; b < nblocks; b++)
     {
       const int jb=b*U;
-      const int tb=(args.ablate & 2) ? 0 : jb;
       T tw[R+U-1];
 #pragma unroll
       for (int i=0; i < R+U-1; i++)
-        tw[i]=table[tb+i];
-      const Q *blk=mine+(size_t) ((args.ablate & 1) ? 0 : (jb+b))*C;       // jb + jb/R
+        tw[i]=table[jb+i];
+      Q cur[U][C];
+#pragma unroll
+      for (int jj=0; jj < U; jj++)
+#pragma unroll
+        for (int c=0; c < C; c++)
+          cur[jj][c]=nxt[jj][c];
+      if (b+1 < nblocks)
+        fetch(jb+U);
 #pragma unroll
       for (int jj=0; jj < U; jj++)
         {
-          Q q[C];
-          load_pixel<Q,C>(blk+(size_t) jj*C,q);
-          typename Acc::In in=Acc::prepare(q);
+          typename Acc::In in=Acc::prepare(cur[jj]);
 #pragma unroll
           for (int r=0; r < R; r++)
             acc.tap(r,tw[jj-r+R-1],in);
@@ -705,18 +712,6 @@ void conv_row_blocked(Conv1DArgs args)
     }
   unsigned changed=0;
   const int xo=x0+lane*R;
-  if constexpr ((DBG & 2) != 0)
-    {
-      T sum=(T) 0;
-#pragma unroll
-      for (int r=0; r < R; r++)
-#pragma unroll
-        for (int c=0; c < C; c++)
-          sum+=acc.s[r][c];
-      if (xo < W)
-        dst[(size_t) y*pitch+(size_t) xo*C]=(Q) sum;
-      return;
-    }
 #pragma unroll
   for (int r=0; r < R; r++)
     {
@@ -745,7 +740,7 @@ static MhStatus launch_blocked(const View &src,const View &dst,bool vertical,
   typedef typename A::T T;
   constexpr int WAVES=4;
   const int K=p.ntaps;
-  const int UU=vertical ? U : R;
+  const int UU=U;
   const int NJ=R+K-1;
   const int nblocks=(NJ+UU-1)/UU;
   // padded, reversed tap table: entry e multiplies, for output r, the sample
@@ -768,10 +763,6 @@ static MhStatus launch_blocked(const View &src,const View &dst,bool vertical,
   args.taps=taps.ptr;
   args.changed=changed;
   args.nblocks=nblocks;
-  {
-    const char *e=getenv("MAGICKHIP_ABLATE");
-    args.ablate=e != nullptr ? atoi(e) : 0;
-  }
   const int W=args.columns,H=args.rows;
   if (vertical)
     {
@@ -779,41 +770,12 @@ static MhStatus launch_blocked(const View &src,const View &dst,bool vertical,
       unsigned grid=((ntx*nty+7u)/8u)*8u;
       size_t lds=A::taps_in_lds ? (size_t) (nblocks*UU+R-1)*sizeof(T) : 0;
       ProfileScope prof("conv_column",src.stream);
-      const char *dbg=getenv("MAGICKHIP_DBG");
-      int d=dbg != nullptr ? atoi(dbg) : 0;
-      if constexpr (std::is_same<A,Fast32>::value && (C == 4) && BLEND)
-        if ((d == 108) || (d == 116))
-          {
-            if (d == 108)
-              {
-                unsigned nty8=(unsigned) ((H+R*8-1)/(R*8)); unsigned g8=((ntx*nty8+7u)/8u)*8u;
-                hipLaunchKernelGGL((conv_column_blocked<Q,C,BLEND,A,R,U,8>),dim3(g8),dim3(64*8),lds,src.stream,args);
-              }
-            else
-              {
-                unsigned nty16=(unsigned) ((H+R*16-1)/(R*16)); unsigned g16=((ntx*nty16+7u)/8u)*8u;
-                hipLaunchKernelGGL((conv_column_blocked<Q,C,BLEND,A,R,U,16>),dim3(g16),dim3(64*16),lds,src.stream,args);
-              }
-            MH_HIP(hipGetLastError());
-            return MH_OK;
-          }
-      if constexpr (std::is_same<A,Fast32>::value && (C == 4) && BLEND)
-        {
-          switch (d)
-          {
-#define MH_DBG_CASE(n) case n: hipLaunchKernelGGL((conv_column_blocked<Q,C,BLEND,A,R,U,WAVES,n>),dim3(grid),dim3(64*WAVES),lds,src.stream,args); break;
-            MH_DBG_CASE(1) MH_DBG_CASE(2) MH_DBG_CASE(3) MH_DBG_CASE(4) MH_DBG_CASE(7) MH_DBG_CASE(8) MH_DBG_CASE(15) MH_DBG_CASE(12) MH_DBG_CASE(9)
-#undef MH_DBG_CASE
-            default: hipLaunchKernelGGL((conv_column_blocked<Q,C,BLEND,A,R,U,WAVES>),dim3(grid),dim3(64*WAVES),lds,src.stream,args);
-          }
-        }
-      else
       hipLaunchKernelGGL((conv_column_blocked<Q,C,BLEND,A,R,U,WAVES>),dim3(grid),dim3(64*WAVES),lds,
         src.stream,args);
     }
   else
     {
-      const int SEG=64*R,NS=63*R+nblocks*R,slots=NS+NS/R+1;
+      const int SEG=64*R,NS=63*R+nblocks*UU,slots=NS+NS/R+1;
       size_t table_bytes=A::taps_in_lds ? ((((size_t) (nblocks*UU+R-1))*sizeof(T)+15u) & ~(size_t) 15u) : 0;
       size_t lds=table_bytes+(size_t) WAVES*slots*C*sizeof(Q);
       if (lds > 160u*1024u)
@@ -822,23 +784,10 @@ static MhStatus launch_blocked(const View &src,const View &dst,bool vertical,
       unsigned grid=((ntx*nty+7u)/8u)*8u;
       if (lds > 64u*1024u)
         MH_HIP(hipFuncSetAttribute(
-          reinterpret_cast<const void *>(&conv_row_blocked<Q,C,BLEND,A,R,WAVES>),
+          reinterpret_cast<const void *>(&conv_row_blocked<Q,C,BLEND,A,R,U,WAVES>),
           hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
       ProfileScope prof("conv_row",src.stream);
-      const char *dbg=getenv("MAGICKHIP_DBGR");
-      int d=dbg != nullptr ? atoi(dbg) : 0;
-      if constexpr (std::is_same<A,Fast32>::value && (C == 4) && BLEND)
-        {
-          switch (d)
-          {
-#define MH_DBG_CASE(n) case n: hipLaunchKernelGGL((conv_row_blocked<Q,C,BLEND,A,R,WAVES,n>),dim3(grid),dim3(64*WAVES),lds,src.stream,args); break;
-            MH_DBG_CASE(1) MH_DBG_CASE(2) MH_DBG_CASE(3)
-#undef MH_DBG_CASE
-            default: hipLaunchKernelGGL((conv_row_blocked<Q,C,BLEND,A,R,WAVES>),dim3(grid),dim3(64*WAVES),lds,src.stream,args);
-          }
-        }
-      else
-      hipLaunchKernelGGL((conv_row_blocked<Q,C,BLEND,A,R,WAVES>),dim3(grid),dim3(64*WAVES),lds,
+      hipLaunchKernelGGL((conv_row_blocked<Q,C,BLEND,A,R,U,WAVES>),dim3(grid),dim3(64*WAVES),lds,
         src.stream,args);
     }
   MH_HIP(hipGetLastError());
@@ -959,14 +908,7 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
   if (src.quantum == MH_QUANTUM_U16)
     {
       if (prec == MH_PRECISION_FAST)
-        {
-          const char *e=getenv("MAGICKHIP_U");
-          if ((e != nullptr) && (atoi(e) == 16))
-            return dispatch_blocked<Fast32,16,16>(src,dst,vertical,params,roles,changed);
-          if ((e != nullptr) && (atoi(e) == 4))
-            return dispatch_blocked<Fast32,16,4>(src,dst,vertical,params,roles,changed);
-          return dispatch_blocked<Fast32,16,8>(src,dst,vertical,params,roles,changed);
-        }
+        return dispatch_blocked<Fast32,16,4>(src,dst,vertical,params,roles,changed);
       return dispatch_blocked<Exact64,8,8>(src,dst,vertical,params,roles,changed);
     }
   // float Quantum always accumulates in double: an FP32 sum cannot stay

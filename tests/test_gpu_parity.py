@@ -159,7 +159,9 @@ def test_resize(im, refmod, dtype, shape, target, filt):
     assert_parity(got, want, True, "resize %s -> %s %s" % (shape, target, filt))
 
 
-def test_resize_fast_precision(im, refmod):
+def test_resize_ignores_fast_precision(im, refmod):
+    """ResizeImage stays fp64 in FAST mode (an f32 first pass cannot keep +-1 through the
+    alpha-weighted second pass): the result is still bit-identical."""
     px = make_pixels(60, 80, 4, Q16)
     dev, ref = run_pair(im, refmod, px)
     im.set_precision(im.PRECISION_FAST)
@@ -167,7 +169,7 @@ def test_resize_fast_precision(im, refmod):
         got = im.resize_image(dev, 320, 240, "Lanczos").numpy()
     finally:
         im.set_precision(im.PRECISION_EXACT)
-    assert_parity(got, ref.resize(320, 240, "Lanczos").numpy(), False, "fast resize")
+    assert_parity(got, ref.resize(320, 240, "Lanczos").numpy(), True, "resize under FAST")
 
 
 # ------------------------------------------------------------------ colourspace
