@@ -245,6 +245,10 @@ def extra_measurements(im, torch, args):
         if "resize_horizontal" in prof:
             b = (m * 4.0 * m + 16.0 * m * m) * 16
             extra["resize_horizontal_GBps"] = round(b / (prof["resize_horizontal"]["avg_ms"] * 1e-3) / 1e9, 1)
+        if "resize_fused" in prof:
+            # fused V+H kernel: reads the 8192^2 source, writes the 32768^2 result (float RGBA)
+            b = (1.0 * m * m + 16.0 * m * m) * 16
+            extra["resize_fused_GBps"] = round(b / (prof["resize_fused"]["avg_ms"] * 1e-3) / 1e9, 1)
         if "resize_vertical" in prof:
             b = (1.0 * m * m + 4.0 * m * m) * 16
             extra["resize_vertical_GBps"] = round(b / (prof["resize_vertical"]["avg_ms"] * 1e-3) / 1e9, 1)

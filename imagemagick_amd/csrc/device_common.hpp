@@ -61,6 +61,21 @@ static __device__ __forceinline__ double perceptible_reciprocal(double x)
   return sign/kEps;
 }
 
+// 1/x to ~1 ulp without the IEEE division sequence (v_rcp_f64 + two Newton steps);
+// same clamp as PerceptibleReciprocal.
+static __device__ __forceinline__ double perceptible_reciprocal_fast(double x)
+{
+  double sign=x < 0.0 ? -1.0 : 1.0;
+  if ((sign*x) < kEps)
+    return sign/kEps;
+  double r=__builtin_amdgcn_rcp(x);
+  double e=__builtin_fma(-x,r,1.0);
+  r=__builtin_fma(r,e,r);
+  e=__builtin_fma(-x,r,1.0);
+  r=__builtin_fma(r,e,r);
+  return r;
+}
+
 // ------------------------------------------------------------- pixel I/O
 template<typename Q,int C>
 static __device__ __forceinline__ void load_pixel(const Q *p,Q (&v)[C])
@@ -129,6 +144,21 @@ struct Exact64
   static __device__ __forceinline__ T mul(T a,T b) { return a*b; }
   static __device__ __forceinline__ T add(T a,T b) { return a+b; }
   static __device__ __forceinline__ T mac(T acc,T a,T b) { return acc+a*b; }   // two roundings
+};
+
+// FAST for the fp64 kernels (resampling): double with fused multiply-adds and a
+// Newton reciprocal.  Results differ from the CPU's separately rounded doubles by
+// ~1e-16 relative, i.e. after the final rounding to Quantum they are identical
+// except when the exact value lies within ~1e-11 of a rounding boundary: Q16
+// output is then off by one level, float output by one float ULP (the +-1 contract).
+struct Fma64
+{
+  typedef double T;
+  static constexpr bool premultiply=false;
+  static constexpr bool taps_in_lds=false;
+  static __device__ __forceinline__ T mul(T a,T b) { return a*b; }
+  static __device__ __forceinline__ T add(T a,T b) { return a+b; }
+  static __device__ __forceinline__ T mac(T acc,T a,T b) { return __builtin_fma(a,b,acc); }
 };
 
 // FAST: float with explicit FMA; alpha is folded into the colour channels once

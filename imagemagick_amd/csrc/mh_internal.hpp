@@ -151,6 +151,11 @@ struct TapTable;   // resize contribution table (host), see resize_filter.cpp
 MhStatus launch_resize_pass(const View &src,const View &dst,bool vertical,
   const TapTable &table,const Roles &roles,MhPrecision precision);
 
+// VerticalFilter + HorizontalFilter in one launch (intermediate kept in LDS);
+// *handled = false when the shape does not fit and nothing was launched.
+MhStatus launch_resize_fused(const View &src,const View &dst,const TapTable &vertical,
+  const TapTable &horizontal,const Roles &roles,MhPrecision precision,bool *handled);
+
 MhStatus launch_unsharp_epilogue(const View &src,const View &blur,const View &dst,
   double gain,double threshold,const Roles &roles);
 

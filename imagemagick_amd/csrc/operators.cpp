@@ -391,14 +391,19 @@ MH_API MhStatus MagickHipResizeImageWithFilter(const MhImage *image,MhImage *res
     }
   else
     {
-      filter_view.columns=image->columns;
-      filter_view.rows=rows;
-      MH_TRY(scratch.alloc(pair.src.view.device,filter_view.bytes(),pair.src.view.stream));
-      filter_view.pixels=scratch.ptr;
       build_tap_table(vertical,filter,image->rows,rows,y_factor);
       build_tap_table(horizontal,filter,image->columns,columns,x_factor);
-      MH_TRY(launch_resize_pass(pair.src.view,filter_view,true,vertical,roles,precision()));
-      MH_TRY(launch_resize_pass(filter_view,pair.dst.view,false,horizontal,roles,precision()));
+      bool fused=false;
+      MH_TRY(launch_resize_fused(pair.src.view,pair.dst.view,vertical,horizontal,roles,precision(),&fused));
+      if (!fused)
+        {
+          filter_view.columns=image->columns;
+          filter_view.rows=rows;
+          MH_TRY(scratch.alloc(pair.src.view.device,filter_view.bytes(),pair.src.view.stream));
+          filter_view.pixels=scratch.ptr;
+          MH_TRY(launch_resize_pass(pair.src.view,filter_view,true,vertical,roles,precision()));
+          MH_TRY(launch_resize_pass(filter_view,pair.dst.view,false,horizontal,roles,precision()));
+        }
     }
   return pair.commit();
 }

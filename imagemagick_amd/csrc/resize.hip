@@ -26,6 +26,8 @@
 #include "mh_internal.hpp"
 #include "resize_filter.hpp"
 #include "device_common.hpp"
+#include <cstdlib>
+#include <type_traits>
 
 namespace mh {
 
@@ -92,7 +94,12 @@ struct ResizeAcc
           }
         double pixel=(double) s[c];
         if (BLEND && (c != C-1))
-          pixel=perceptible_reciprocal((double) g)*pixel;
+          {
+            if constexpr (std::is_same<A,Fma64>::value)
+              pixel=perceptible_reciprocal_fast((double) g)*pixel;
+            else
+              pixel=perceptible_reciprocal((double) g)*pixel;
+          }
         out[c]=QuantumOps<Q>::clamp(pixel);
       }
   }
@@ -259,6 +266,333 @@ void resize_horizontal_kernel(ResizeArgs args,int tile_rows)
     }
 }
 
+
+// ------------------------------------------------------------ fused V-then-H
+// ResizeImage runs VerticalFilter first when x_factor <= y_factor
+// (resize.c:3846-3861).  For enlargements the Quantum-typed intermediate
+// (columns x new rows) is 1/4..1/16 of the result but still costs a full HBM
+// write + read; this kernel keeps it in LDS.  A workgroup owns TW=256 output
+// columns x TH output rows:
+//   1. stage the source patch (row span of the TH rows x column span of the 256
+//      columns, both precomputed on the host) in LDS with coalesced loads;
+//   2. vertical pass into a second LDS tile, TH rows x column-span, one wave per
+//      output row (weights wave-uniform), results rounded to Quantum exactly as
+//      the reference's filter_image holds them;
+//   3. horizontal pass from that tile, lane = output column, weights in
+//      registers, fully coalesced 16-byte (float RGBA) stores.
+// Arithmetic per pass is ResizeAcc's, i.e. the CPU's order.
+struct FusedArgs
+{
+  ResizeArgs v,h;             // v: row tables (out_size = dst_rows), h: column tables
+  const int *row_lo,*row_span;// per row tile: first source row, number of source rows
+  int cstride;                // LDS row stride (pixels) of both tiles = widest column span
+  int rspan_max;              // tallest source row span of any row tile
+};
+
+template<typename Q,int C,bool BLEND,class A,int TH,int MAXT>
+__global__ __launch_bounds__(256)
+void resize_fused_kernel(FusedArgs a)
+{
+  typedef typename A::T T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // LDS: vertical weights of this row tile, then the source patch, then the
+  // Quantum-typed intermediate
+  T *vw=reinterpret_cast<T *>(smem_raw);                 // [MAXT][TH]
+  T *vwq=vw+MAXT*TH;                                     // [MAXT][TH]
+  int *vstart=reinterpret_cast<int *>(vwq+MAXT*TH);      // [TH]
+  int *vcount=vstart+TH;
+  int *vnear=vcount+TH;
+  const int cstride=a.cstride;
+  Q *src_tile=reinterpret_cast<Q *>(vnear+TH+(TH & 1));  // keeps 16-byte alignment (TH is even)
+  Q *mid_tile=src_tile+(size_t) a.rspan_max*cstride*C;
+  const int tid=(int) threadIdx.x;
+  const int X0=(int) blockIdx.x*256,Y0=(int) blockIdx.y*TH;
+  const int clo=a.h.tile_lo[blockIdx.x],cspan=a.h.tile_span[blockIdx.x];
+  const int rlo=a.row_lo[blockIdx.y],rspan=a.row_span[blockIdx.y];
+  int rows=a.h.dst_rows-Y0;
+  rows=rows < TH ? rows : TH;
+  const Q *src=static_cast<const Q *>(a.v.src);
+  Q *dst=static_cast<Q *>(a.h.dst);
+  const size_t src_pitch=(size_t) a.v.src_columns*C;
+  const size_t dst_pitch=(size_t) a.h.dst_columns*C;
+
+  // 0. this tile's vertical tables
+  if (tid < rows)
+    {
+      const int y=Y0+tid,OUTV=a.v.out_size;
+      const T *weight=static_cast<const T *>(a.v.weight);
+      const T *weight_qs=static_cast<const T *>(a.v.weight_qs);
+      const int cnt=a.v.count[y];
+      vstart[tid]=a.v.start[y]-rlo;
+      vcount[tid]=cnt;
+      vnear[tid]=cnt > 0 ? a.v.nearest[y]-rlo : 0;
+#pragma unroll
+      for (int j=0; j < MAXT; j++)
+        {
+          vw[j*TH+tid]=j < cnt ? weight[(size_t) j*OUTV+y] : (T) 0;
+          vwq[j*TH+tid]=(BLEND && (j < cnt)) ? weight_qs[(size_t) j*OUTV+y] : (T) 0;
+        }
+    }
+  // 1. source patch, all loads of a batch in flight before the first LDS store
+  {
+    constexpr int BATCH=6;
+    const int items=rspan*cspan;
+    for (int i0=tid; i0 < items; i0+=256*BATCH)
+      {
+        Q v[BATCH][C];
+        int slot[BATCH];
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          {
+            int idx=i0+256*k;
+            idx=idx < items ? idx : items-1;
+            const int r=idx/cspan,i=idx-r*cspan;
+            slot[k]=r*cstride+i;
+            load_pixel<Q,C>(src+(size_t) (rlo+r)*src_pitch+(size_t) (clo+i)*C,v[k]);
+          }
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          if (i0+256*k < items)
+            store_pixel<Q,C>(src_tile+(size_t) slot[k]*C,v[k]);
+      }
+  }
+  __syncthreads();
+
+  // 2. vertical pass over the (row, source column) items of the tile
+  {
+    const int items=rows*cspan;
+    for (int idx=tid; idx < items; idx+=256)
+      {
+        const int yy=idx/cspan,i=idx-yy*cspan;
+        const int start=vstart[yy],count=vcount[yy];
+        ResizeAcc<Q,C,BLEND,A> acc;
+        acc.init();
+#pragma unroll
+        for (int j=0; j < MAXT; j++)
+          if (j < count)
+            {
+              Q q[C];
+              load_pixel<Q,C>(src_tile+((size_t) (start+j)*cstride+i)*C,q);
+              acc.tap(vw[j*TH+yy],vwq[j*TH+yy],q);
+            }
+        Q copy[C],out[C];
+        load_pixel<Q,C>(src_tile+((size_t) vnear[yy]*cstride+i)*C,copy);
+        acc.finish(copy,a.v.copy_mask,out);
+        store_pixel<Q,C>(mid_tile+((size_t) yy*cstride+i)*C,out);
+      }
+  }
+  __syncthreads();
+
+  // 3. horizontal pass: lane = output column
+  const int OUT=a.h.out_size;
+  const int x=X0+tid;
+  if (x >= OUT)
+    return;
+  const int start=a.h.start[x]-clo;
+  const int count=a.h.count[x];
+  if (count <= 0)
+    return;
+  const int nearest=a.h.nearest[x]-clo;
+  const T *weight=static_cast<const T *>(a.h.weight);
+  const T *weight_qs=static_cast<const T *>(a.h.weight_qs);
+  T w[MAXT],wq[MAXT];
+#pragma unroll
+  for (int j=0; j < MAXT; j++)
+    {
+      w[j]=(T) 0;
+      wq[j]=(T) 0;
+      if (j < count)
+        {
+          w[j]=weight[(size_t) j*OUT+x];
+          if constexpr (BLEND)
+            wq[j]=weight_qs[(size_t) j*OUT+x];
+        }
+    }
+  for (int yy=0; yy < rows; yy++)
+    {
+      const Q *line=mid_tile+(size_t) yy*cstride*C;
+      ResizeAcc<Q,C,BLEND,A> acc;
+      acc.init();
+#pragma unroll
+      for (int j=0; j < MAXT; j++)
+        if (j < count)
+          {
+            Q q[C];
+            load_pixel<Q,C>(line+(size_t) (start+j)*C,q);
+            acc.tap(w[j],wq[j],q);
+          }
+      Q copy[C],out[C];
+      load_pixel<Q,C>(line+(size_t) nearest*C,copy);
+      acc.finish(copy,a.h.copy_mask,out);
+      store_pixel<Q,C>(dst+(size_t) (Y0+yy)*dst_pitch+(size_t) x*C,out);
+    }
+}
+
+// uploads one axis' tables
+struct DeviceTaps
+{
+  Temp start,count,nearest,w,wq;
+  template<typename T>
+  MhStatus upload(const TapTable &table,const View &on,ResizeArgs &args)
+  {
+    const size_t n=(size_t) table.max_taps*(size_t) table.out_size;
+    std::vector<T> hw(n),hwq(n);
+    for (size_t i=0; i < n; i++)
+      {
+        hw[i]=(T) table.weight[i];
+        hwq[i]=(T) (table.weight[i]*kQuantumScale);
+      }
+    const size_t ib=(size_t) table.out_size*sizeof(int);
+    MH_TRY(upload_table(start,on.device,on.stream,table.start.data(),ib));
+    MH_TRY(upload_table(count,on.device,on.stream,table.count.data(),ib));
+    MH_TRY(upload_table(nearest,on.device,on.stream,table.nearest.data(),ib));
+    MH_TRY(upload_table(w,on.device,on.stream,hw.data(),n*sizeof(T)));
+    MH_TRY(upload_table(wq,on.device,on.stream,hwq.data(),n*sizeof(T)));
+    args.out_size=table.out_size;
+    args.max_taps=table.max_taps;
+    args.start=start.as<int>();
+    args.count=count.as<int>();
+    args.nearest=nearest.as<int>();
+    args.weight=w.ptr;
+    args.weight_qs=wq.ptr;
+    return MH_OK;
+  }
+};
+
+// source span [lo, lo+span) of every tile of `tile` consecutive outputs
+static void tile_spans(const TapTable &table,int tile,std::vector<int> &lo_out,std::vector<int> &span_out,
+  int &max_span)
+{
+  max_span=1;
+  for (int o0=0; o0 < table.out_size; o0+=tile)
+    {
+      int oh=(o0+tile-1) < table.out_size ? (o0+tile-1) : table.out_size-1;
+      int lo=table.start[(size_t) o0],hi=0;
+      for (int i=o0; i <= oh; i++)
+        {
+          int s=table.start[(size_t) i],e=s+table.count[(size_t) i];
+          lo=s < lo ? s : lo;
+          hi=e > hi ? e : hi;
+        }
+      if (hi < lo)
+        hi=lo;
+      lo_out.push_back(lo);
+      span_out.push_back(hi-lo);
+      if ((hi-lo) > max_span)
+        max_span=hi-lo;
+    }
+}
+
+template<typename Q,int C,bool BLEND,class A>
+static MhStatus launch_fused_typed(const View &src,const View &dst,const TapTable &vt,
+  const TapTable &ht,const Roles &roles,bool &handled)
+{
+  typedef typename A::T T;
+  constexpr int TH=32,MAXT=8;
+  handled=false;
+  if ((ht.max_taps > MAXT) || (vt.max_taps > MAXT))
+    return MH_OK;
+  std::vector<int> col_lo,col_span,row_lo,row_span;
+  int cmax=1,rmax=1;
+  tile_spans(ht,256,col_lo,col_span,cmax);
+  tile_spans(vt,TH,row_lo,row_span,rmax);
+  const size_t px=(size_t) C*sizeof(Q);
+  const size_t head=2u*MAXT*TH*sizeof(T)+(size_t) (3*TH+(TH & 1))*sizeof(int);
+  const size_t lds=head+((size_t) rmax+(size_t) TH)*(size_t) cmax*px;
+  if (lds > 72u*1024u)          // two workgroups per CU
+    return MH_OK;
+  FusedArgs a;
+  DeviceTaps dv,dh;
+  MH_TRY(dv.template upload<T>(vt,src,a.v));
+  MH_TRY(dh.template upload<T>(ht,src,a.h));
+  Temp d_clo,d_cspan,d_rlo,d_rspan;
+  MH_TRY(upload_table(d_clo,src.device,src.stream,col_lo.data(),col_lo.size()*sizeof(int)));
+  MH_TRY(upload_table(d_cspan,src.device,src.stream,col_span.data(),col_span.size()*sizeof(int)));
+  MH_TRY(upload_table(d_rlo,src.device,src.stream,row_lo.data(),row_lo.size()*sizeof(int)));
+  MH_TRY(upload_table(d_rspan,src.device,src.stream,row_span.data(),row_span.size()*sizeof(int)));
+  a.v.src=src.pixels;
+  a.v.dst=nullptr;
+  a.v.src_columns=(int) src.columns;
+  a.v.src_rows=(int) src.rows;
+  a.v.dst_columns=(int) src.columns;
+  a.v.dst_rows=(int) dst.rows;
+  a.v.copy_mask=roles.copy_mask;
+  a.v.tile_lo=nullptr;
+  a.v.tile_span=nullptr;
+  a.h.src=nullptr;
+  a.h.dst=dst.pixels;
+  a.h.src_columns=(int) src.columns;
+  a.h.src_rows=(int) dst.rows;
+  a.h.dst_columns=(int) dst.columns;
+  a.h.dst_rows=(int) dst.rows;
+  a.h.copy_mask=roles.copy_mask;
+  a.h.tile_lo=d_clo.as<int>();
+  a.h.tile_span=d_cspan.as<int>();
+  a.row_lo=d_rlo.as<int>();
+  a.row_span=d_rspan.as<int>();
+  a.cstride=cmax;
+  a.rspan_max=rmax;
+  dim3 grid((unsigned) ((dst.columns+255)/256),(unsigned) ((dst.rows+TH-1)/TH));
+  if (lds > 64u*1024u)
+    MH_HIP(hipFuncSetAttribute(
+      reinterpret_cast<const void *>(&resize_fused_kernel<Q,C,BLEND,A,TH,MAXT>),
+      hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+  {
+    ProfileScope prof("resize_fused",src.stream);
+    hipLaunchKernelGGL((resize_fused_kernel<Q,C,BLEND,A,TH,MAXT>),grid,dim3(256),lds,src.stream,a);
+  }
+  MH_HIP(hipGetLastError());
+  handled=true;
+  return MH_OK;
+}
+
+template<typename Q,class A>
+static MhStatus dispatch_fused(const View &src,const View &dst,const TapTable &vt,const TapTable &ht,
+  const Roles &roles,bool &handled)
+{
+  const bool blend=roles.blend && (roles.alpha == src.channels-1);
+  switch (src.channels)
+  {
+    case 1: return launch_fused_typed<Q,1,false,A>(src,dst,vt,ht,roles,handled);
+    case 2:
+      if (blend) return launch_fused_typed<Q,2,true,A>(src,dst,vt,ht,roles,handled);
+      return launch_fused_typed<Q,2,false,A>(src,dst,vt,ht,roles,handled);
+    case 3: return launch_fused_typed<Q,3,false,A>(src,dst,vt,ht,roles,handled);
+    case 4:
+      if (blend) return launch_fused_typed<Q,4,true,A>(src,dst,vt,ht,roles,handled);
+      return launch_fused_typed<Q,4,false,A>(src,dst,vt,ht,roles,handled);
+    default: break;
+  }
+  handled=false;
+  return MH_OK;
+}
+
+// VerticalFilter followed by HorizontalFilter in one launch.  *handled is false
+// (and nothing was launched) when the tiles do not fit LDS or the tap count is
+// too large; the caller then runs the two passes separately.
+MhStatus launch_resize_fused(const View &src,const View &dst,const TapTable &vertical,
+  const TapTable &horizontal,const Roles &roles,MhPrecision prec,bool *handled)
+{
+  *handled=false;
+  if ((src.channels != dst.channels) || (src.quantum != dst.quantum))
+    return fail(MH_BAD_ARGUMENT,"resize: layout mismatch");
+  if (roles.blend && (roles.alpha != src.channels-1))
+    return MH_OK;
+  if (((int) dst.rows != vertical.out_size) || ((int) dst.columns != horizontal.out_size))
+    return fail(MH_BAD_ARGUMENT,"resize: geometry mismatch");
+  if (getenv("MAGICKHIP_FUSED_RESIZE") == nullptr)     // measured slower than the two passes
+    return MH_OK;
+  if (prec == MH_PRECISION_FAST)
+    {
+      if (src.quantum == MH_QUANTUM_U16)
+        return dispatch_fused<uint16_t,Fma64>(src,dst,vertical,horizontal,roles,*handled);
+      return dispatch_fused<float,Fma64>(src,dst,vertical,horizontal,roles,*handled);
+    }
+  if (src.quantum == MH_QUANTUM_U16)
+    return dispatch_fused<uint16_t,Exact64>(src,dst,vertical,horizontal,roles,*handled);
+  return dispatch_fused<float,Exact64>(src,dst,vertical,horizontal,roles,*handled);
+}
+
 // ---------------------------------------------------------------- launcher
 template<typename Q,int C,bool BLEND,class A>
 static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
@@ -398,8 +732,15 @@ MhStatus launch_resize_pass(const View &src,const View &dst,bool vertical,
   // Quantum-rounded intermediate to the second pass, and with alpha-weighted
   // channels a +-1 difference in a small intermediate alpha moves the final colour
   // by many levels (measured: 15 levels on uniform-random alpha), so an f32 first
-  // pass cannot keep the +-1 contract; the passes are HBM-bound, not ALU-bound.
-  (void) prec;
+  // pass cannot keep the +-1 contract.  FAST selects the fused-multiply-add fp64
+  // policy (Fma64), whose intermediate differs from the CPU's only when a value
+  // lies within ~1e-11 of a rounding boundary.
+  if (prec == MH_PRECISION_FAST)
+    {
+      if (src.quantum == MH_QUANTUM_U16)
+        return dispatch<uint16_t,Fma64>(src,dst,vertical,table,roles);
+      return dispatch<float,Fma64>(src,dst,vertical,table,roles);
+    }
   if (src.quantum == MH_QUANTUM_U16)
     return dispatch<uint16_t,Exact64>(src,dst,vertical,table,roles);
   return dispatch<float,Exact64>(src,dst,vertical,table,roles);
