@@ -82,6 +82,25 @@ struct ResizeAcc
           s[c]=A::mac(s[c],w,(T) q[c]);           // resize.c:3503-3505
       }
   }
+  // same as tap() for a pixel already converted to T
+  __device__ __forceinline__ void tap_converted(T w,T wq,const T (&p)[C])
+  {
+    if constexpr (BLEND)
+      {
+        T a=A::mul(wq,p[C-1]);
+#pragma unroll
+        for (int c=0; c < C-1; c++)
+          s[c]=A::mac(s[c],a,p[c]);
+        g=A::add(g,a);
+        s[C-1]=A::mac(s[C-1],w,p[C-1]);
+      }
+    else
+      {
+#pragma unroll
+        for (int c=0; c < C; c++)
+          s[c]=A::mac(s[c],w,p[c]);
+      }
+  }
   __device__ __forceinline__ void finish(const Q (&copy)[C],uint32_t copy_mask,Q (&out)[C]) const
   {
 #pragma unroll
@@ -106,55 +125,78 @@ struct ResizeAcc
 };
 
 // ------------------------------------------------------------- vertical pass
+// Dense form: for a tile of RY consecutive output rows the host flattens the
+// contribution lists into a small matrix W[k][r] (k = source row lo+k of the
+// tile's union window, r = output row of the tile; 0 where row k is outside
+// r's window), so the kernel is a loop over the union rows that loads each
+// source row once and feeds all RY accumulators with wave-uniform weights —
+// no per-(row, output) window tests.  Zero weights are exact no-ops
+// (s + 0*p == s) for finite pixels; the EXACT policy still skips them through a
+// per-row bit mask so that a non-finite float pixel outside an output's window
+// cannot leak into it.
+struct VerticalDenseArgs
+{
+  const void *src;
+  void *dst;
+  int columns;                // == source columns
+  int out_rows;
+  int kmax;                   // rows of the widest union window
+  const int *tile_lo;         // [tiles] first source row of the union window
+  const int *tile_rows;       // [tiles] its height (<= kmax)
+  const unsigned *row_mask;   // [tiles][kmax] bit r set: source row k contributes to output r
+  const double *w;            // [tiles][kmax][RY]
+  const double *wq;           // [tiles][kmax][RY]  weight*QuantumScale
+  const int *nearest;         // [out_rows] source row of Copy-trait channels
+  const int *count;           // [out_rows]
+  uint32_t copy_mask;
+};
+
 template<typename Q,int C,bool BLEND,class A,int RY>
 __global__ __launch_bounds__(256)
-void resize_vertical_kernel(ResizeArgs args)
+void resize_vertical_kernel(VerticalDenseArgs args)
 {
   typedef typename A::T T;
-  const int W=args.dst_columns;            // == src_columns
+  constexpr bool kSkipZeros=std::is_same<A,Exact64>::value && QuantumOps<Q>::is_float;
+  const int W=args.columns;
   const int lane_x=(int) (blockIdx.x*blockDim.x+threadIdx.x);
-  const int y0=(int) blockIdx.y*RY;
+  const int tile=(int) blockIdx.y;
+  const int y0=tile*RY;
   const int x=lane_x < W ? lane_x : W-1;
-  const Q *src=static_cast<const Q *>(args.src);
+  const Q *src=static_cast<const Q *>(args.src)+(size_t) x*C;
   Q *dst=static_cast<Q *>(args.dst);
-  const T *weight=static_cast<const T *>(args.weight);
-  const T *weight_qs=static_cast<const T *>(args.weight_qs);
   const size_t pitch=(size_t) W*C;
-  const int OUT=args.out_size;
+  const int lo=args.tile_lo[tile],nrows=args.tile_rows[tile];
+  const size_t tbase=(size_t) tile*(size_t) args.kmax;
+  const double *wt=args.w+tbase*RY;
+  const double *wqt=args.wq+tbase*RY;
+  const unsigned *mask=args.row_mask+tbase;
 
   ResizeAcc<Q,C,BLEND,A> acc[RY];
-  int start[RY],count[RY];
-  int lo=0x7fffffff,hi=0;
 #pragma unroll
   for (int r=0; r < RY; r++)
+    acc[r].init();
+  constexpr int KB=4;                       // source rows fetched per batch
+  for (int k0=0; k0 < nrows; k0+=KB)
     {
-      acc[r].init();
-      int y=y0+r;
-      start[r]=0;
-      count[r]=0;
-      if (y < OUT)
-        {
-          start[r]=args.start[y];
-          count[r]=args.count[y];
-          if (count[r] > 0)
-            {
-              lo=start[r] < lo ? start[r] : lo;
-              hi=(start[r]+count[r]) > hi ? (start[r]+count[r]) : hi;
-            }
-        }
-    }
-  for (int sy=lo; sy < hi; sy++)
-    {
-      Q q[C];
-      load_pixel<Q,C>(src+(size_t) sy*pitch+(size_t) x*C,q);
+      Q q[KB][C];
 #pragma unroll
-      for (int r=0; r < RY; r++)
+      for (int kk=0; kk < KB; kk++)
         {
-          int j=sy-start[r];
-          if ((j >= 0) && (j < count[r]))
+          int k=k0+kk;
+          k=k < nrows ? k : nrows-1;
+          load_pixel<Q,C>(src+(size_t) (lo+k)*pitch,q[kk]);
+        }
+#pragma unroll
+      for (int kk=0; kk < KB; kk++)
+        {
+          const int k=k0+kk;
+          if (k < nrows)
             {
-              size_t wi=(size_t) j*OUT+(size_t) (y0+r);
-              acc[r].tap(weight[wi],BLEND ? weight_qs[wi] : (T) 0,q);
+              const unsigned m=kSkipZeros ? mask[k] : 0xffffffffu;
+#pragma unroll
+              for (int r=0; r < RY; r++)
+                if (!kSkipZeros || ((m >> r) & 1u))
+                  acc[r].tap((T) wt[(size_t) k*RY+r],BLEND ? (T) wqt[(size_t) k*RY+r] : (T) 0,q[kk]);
             }
         }
     }
@@ -164,14 +206,14 @@ void resize_vertical_kernel(ResizeArgs args)
   for (int r=0; r < RY; r++)
     {
       int y=y0+r;
-      if ((y < OUT) && (count[r] > 0))
+      if ((y < args.out_rows) && (args.count[y] > 0))
         {
           Q copy[C],out[C];
 #pragma unroll
           for (int c=0; c < C; c++)
             copy[c]=(Q) 0;
           if (args.copy_mask != 0)
-            load_pixel<Q,C>(src+(size_t) args.nearest[y]*pitch+(size_t) x*C,copy);
+            load_pixel<Q,C>(src+(size_t) args.nearest[y]*pitch,copy);
           acc[r].finish(copy,args.copy_mask,out);
           store_pixel<Q,C>(dst+(size_t) y*pitch+(size_t) x*C,out);
         }
@@ -266,6 +308,118 @@ void resize_horizontal_kernel(ResizeArgs args,int tile_rows)
     }
 }
 
+
+// --------------------------------------------- horizontal pass, converted tile
+// Same tiling as resize_horizontal_kernel, but the staged source span is
+// converted to the accumulation type once, when it is written to LDS (each
+// source sample is used by ~4*taps output pixels of a 4x enlargement, and a
+// Quantum->double conversion costs as much issue time as a multiply-add), and
+// every lane runs the same number of taps (the tile's maximum; the extra taps
+// carry zero weights) so the tap loop has no per-lane predicates.
+template<typename Q,int C,bool BLEND,class A,int MAXT>
+__global__ __launch_bounds__(256)
+void resize_horizontal_cvt_kernel(ResizeArgs args,int tile_rows,int lds_span)
+{
+  typedef typename A::T T;
+  constexpr bool kSkipZeros=std::is_same<A,Exact64>::value && QuantumOps<Q>::is_float;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T *tile=reinterpret_cast<T *>(smem_raw);
+  const int OUT=args.out_size;
+  const int x0=(int) blockIdx.x*256;
+  const int x=x0+(int) threadIdx.x;
+  const int y0=(int) blockIdx.y*tile_rows;
+  const Q *src=static_cast<const Q *>(args.src);
+  Q *dst=static_cast<Q *>(args.dst);
+  const T *weight=static_cast<const T *>(args.weight);
+  const T *weight_qs=static_cast<const T *>(args.weight_qs);
+  const size_t src_pitch=(size_t) args.src_columns*C;
+  const size_t dst_pitch=(size_t) args.dst_columns*C;
+  const int lo=args.tile_lo[blockIdx.x];
+  int rows=args.dst_rows-y0;
+  rows=rows < tile_rows ? rows : tile_rows;
+
+  // stage lds_span columns (the tile's span plus the zero-weight overhang,
+  // clamped to the image) of `rows` rows, converted to T
+  {
+    constexpr int BATCH=4;
+    const int items=lds_span*rows;
+    for (int i0=(int) threadIdx.x; i0 < items; i0+=256*BATCH)
+      {
+        Q v[BATCH][C];
+        int slot[BATCH];
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          {
+            int idx=i0+256*k;
+            idx=idx < items ? idx : items-1;
+            const int r=idx/lds_span,i=idx-r*lds_span;
+            int col=lo+i;
+            col=col < args.src_columns ? col : args.src_columns-1;
+            slot[k]=idx;
+            load_pixel<Q,C>(src+(size_t) (y0+r)*src_pitch+(size_t) col*C,v[k]);
+          }
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          if (i0+256*k < items)
+            {
+#pragma unroll
+              for (int c=0; c < C; c++)
+                tile[(size_t) slot[k]*C+c]=(T) v[k][c];
+            }
+      }
+  }
+  __syncthreads();
+  if (x >= OUT)
+    return;
+  const int start=args.start[x]-lo;
+  const int count=args.count[x];
+  if (count <= 0)
+    return;
+  const int nearest=args.nearest[x]-lo;
+  T w[MAXT],wq[MAXT];
+#pragma unroll
+  for (int j=0; j < MAXT; j++)
+    {
+      w[j]=(T) 0;
+      wq[j]=(T) 0;
+      if (j < count)
+        {
+          w[j]=weight[(size_t) j*OUT+x];
+          if constexpr (BLEND)
+            wq[j]=weight_qs[(size_t) j*OUT+x];
+        }
+    }
+  for (int r=0; r < rows; r++)
+    {
+      const T *line=tile+(size_t) r*lds_span*C+(size_t) start*C;
+      ResizeAcc<Q,C,BLEND,A> acc;
+      acc.init();
+      // all MAXT samples are read first (the staged span has the overhang for it),
+      // so the LDS reads are in flight together instead of one latency per tap
+      T p[MAXT][C];
+#pragma unroll
+      for (int j=0; j < MAXT; j++)
+#pragma unroll
+        for (int c=0; c < C; c++)
+          p[j][c]=line[(size_t) j*C+c];
+#pragma unroll
+      for (int j=0; j < MAXT; j++)
+        if (!kSkipZeros || (j < count))           // zero-weight taps are exact no-ops
+          acc.tap_converted(w[j],wq[j],p[j]);
+      Q copy[C],out[C];
+#pragma unroll
+      for (int c=0; c < C; c++)
+        copy[c]=(Q) 0;
+      if (args.copy_mask != 0)
+        {
+#pragma unroll
+          for (int c=0; c < C; c++)
+            copy[c]=(Q) tile[((size_t) r*lds_span+(size_t) nearest)*C+c];   // exact: it was a Quantum
+        }
+      acc.finish(copy,args.copy_mask,out);
+      store_pixel<Q,C>(dst+(size_t) (y0+r)*dst_pitch+(size_t) x*C,out);
+    }
+}
 
 // ------------------------------------------------------------ fused V-then-H
 // ResizeImage runs VerticalFilter first when x_factor <= y_factor
@@ -635,9 +789,68 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
   if (vertical)
     {
       constexpr int RY=4;
-      dim3 grid((unsigned) ((dst.columns+255)/256),(unsigned) ((dst.rows+RY-1)/RY));
+      const int tiles=(table.out_size+RY-1)/RY;
+      std::vector<int> lo((size_t) tiles,0),nrows((size_t) tiles,0);
+      int kmax=1;
+      for (int t=0; t < tiles; t++)
+        {
+          int l=0x7fffffff,h=0;
+          for (int r=0; r < RY; r++)
+            {
+              int y=t*RY+r;
+              if ((y >= table.out_size) || (table.count[(size_t) y] <= 0))
+                continue;
+              int st=table.start[(size_t) y],en=st+table.count[(size_t) y];
+              l=st < l ? st : l;
+              h=en > h ? en : h;
+            }
+          if (h <= l)
+            { l=0; h=0; }
+          lo[(size_t) t]=l;
+          nrows[(size_t) t]=h-l;
+          kmax=(h-l) > kmax ? (h-l) : kmax;
+        }
+      std::vector<double> dw((size_t) tiles*kmax*RY,0.0),dwq((size_t) tiles*kmax*RY,0.0);
+      std::vector<unsigned> mask((size_t) tiles*kmax,0u);
+      for (int t=0; t < tiles; t++)
+        for (int r=0; r < RY; r++)
+          {
+            int y=t*RY+r;
+            if ((y >= table.out_size) || (table.count[(size_t) y] <= 0))
+              continue;
+            for (int j=0; j < table.count[(size_t) y]; j++)
+              {
+                int k=table.start[(size_t) y]+j-lo[(size_t) t];
+                double wv=table.weight[(size_t) j*table.out_size+(size_t) y];
+                size_t at=((size_t) t*kmax+(size_t) k)*RY+(size_t) r;
+                dw[at]=wv;
+                dwq[at]=wv*kQuantumScale;       // contribution.weight*QuantumScale
+                mask[(size_t) t*kmax+(size_t) k]|=1u << r;
+              }
+          }
+      Temp d_lo,d_rows,d_mask,d_dw,d_dwq;
+      MH_TRY(upload_table(d_lo,src.device,src.stream,lo.data(),lo.size()*sizeof(int)));
+      MH_TRY(upload_table(d_rows,src.device,src.stream,nrows.data(),nrows.size()*sizeof(int)));
+      MH_TRY(upload_table(d_mask,src.device,src.stream,mask.data(),mask.size()*sizeof(unsigned)));
+      MH_TRY(upload_table(d_dw,src.device,src.stream,dw.data(),dw.size()*sizeof(double)));
+      MH_TRY(upload_table(d_dwq,src.device,src.stream,dwq.data(),dwq.size()*sizeof(double)));
+      VerticalDenseArgs va;
+      va.src=src.pixels;
+      va.dst=dst.pixels;
+      va.columns=(int) dst.columns;
+      va.out_rows=table.out_size;
+      va.kmax=kmax;
+      va.tile_lo=d_lo.as<int>();
+      va.tile_rows=d_rows.as<int>();
+      va.row_mask=d_mask.as<unsigned>();
+      va.w=d_dw.as<double>();
+      va.wq=d_dwq.as<double>();
+      va.nearest=d_near.as<int>();
+      va.count=d_count.as<int>();
+      va.copy_mask=roles.copy_mask;
+      dim3 grid((unsigned) ((dst.columns+255)/256),(unsigned) tiles);
       ProfileScope prof("resize_vertical",src.stream);
-      hipLaunchKernelGGL((resize_vertical_kernel<Q,C,BLEND,A,RY>),grid,dim3(256),0,src.stream,args);
+      hipLaunchKernelGGL((resize_vertical_kernel<Q,C,BLEND,A,RY>),grid,dim3(256),0,src.stream,va);
     }
   else
     {
@@ -661,6 +874,25 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
           if ((hi-lo) > max_span)
             max_span=hi-lo;
         }
+      // per tile: the largest tap count (run by every lane of the converted-tile kernel)
+      const size_t ntiles=tile_lo.size();
+      const int maxt=table.max_taps <= 4 ? 4 : (table.max_taps <= 6 ? 6 : 8);
+      int overhang=0;
+      for (size_t t=0; t < ntiles; t++)
+        {
+          int x0t=(int) t*256,xh=(x0t+255) < table.out_size ? (x0t+255) : table.out_size-1;
+          int cmaxt=0,endmax=0;
+          for (int i=x0t; i <= xh; i++)
+            cmaxt=table.count[(size_t) i] > cmaxt ? table.count[(size_t) i] : cmaxt;
+          for (int i=x0t; i <= xh; i++)
+            {
+              int e=table.start[(size_t) i]+maxt;       // the kernel reads MAXT samples per output
+              endmax=e > endmax ? e : endmax;
+            }
+          int over=endmax-(tile_lo[t]+tile_span[t]);
+          overhang=over > overhang ? over : overhang;
+          tile_span.push_back(cmaxt);                 // second half of the array: taps per tile
+        }
       Temp d_lo,d_span;
       MH_TRY(upload_table(d_lo,src.device,src.stream,tile_lo.data(),tile_lo.size()*sizeof(int)));
       MH_TRY(upload_table(d_span,src.device,src.stream,tile_span.data(),tile_span.size()*sizeof(int)));
@@ -668,6 +900,34 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
       args.tile_span=d_span.as<int>();
       const size_t px=(size_t) C*sizeof(Q);
       const size_t budget=60u*1024u;
+      if (table.max_taps <= 8)
+        {
+          const int lds_span=max_span+overhang;
+          const size_t cpx=(size_t) C*sizeof(T);
+          if ((size_t) lds_span*cpx <= 150u*1024u)
+            {
+              int tile_rows=(int) (budget/((size_t) lds_span*cpx));
+              tile_rows=tile_rows < 1 ? 1 : (tile_rows > 16 ? 16 : tile_rows);
+              size_t lds=(size_t) lds_span*cpx*(size_t) tile_rows;
+              dim3 grid((unsigned) ((dst.columns+255)/256),(unsigned) ((dst.rows+tile_rows-1)/tile_rows));
+              ProfileScope prof("resize_horizontal",src.stream);
+#define MH_LAUNCH_H(N)                                                                        \
+              {                                                                                \
+                if (lds > 64u*1024u)                                                           \
+                  MH_HIP(hipFuncSetAttribute(                                                  \
+                    reinterpret_cast<const void *>(&resize_horizontal_cvt_kernel<Q,C,BLEND,A,N>),\
+                    hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));                    \
+                hipLaunchKernelGGL((resize_horizontal_cvt_kernel<Q,C,BLEND,A,N>),grid,dim3(256),lds, \
+                  src.stream,args,tile_rows,lds_span);                                         \
+              }
+              if (maxt == 4) MH_LAUNCH_H(4)
+              else if (maxt == 6) MH_LAUNCH_H(6)
+              else MH_LAUNCH_H(8)
+#undef MH_LAUNCH_H
+              MH_HIP(hipGetLastError());
+              return MH_OK;
+            }
+        }
       if ((size_t) max_span*px > 150u*1024u)
         return fail(MH_UNSUPPORTED,"resize: source span of %d pixels does not fit LDS",max_span);
       int tile_rows=(int) (budget/((size_t) max_span*px));
