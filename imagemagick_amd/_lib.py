@@ -125,6 +125,9 @@ PROTOTYPES = [
     ("MhGetOptimalKernelWidth1D", ctypes.c_size_t, [ctypes.c_double, ctypes.c_double]),
     ("MhGetOptimalKernelWidth2D", ctypes.c_size_t, [ctypes.c_double, ctypes.c_double]),
     ("MhAcquireResizeFilter", ctypes.c_void_p, [ctypes.c_int, ctypes.c_int]),
+    ("MhAcquireResizeFilterFromCallback", ctypes.c_void_p,
+     [ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_void_p, ctypes.c_double), ctypes.c_void_p,
+      ctypes.c_double]),
     ("MhDestroyResizeFilter", ctypes.c_void_p, [ctypes.c_void_p]),
     ("MhGetResizeFilterWeight", ctypes.c_double, [ctypes.c_void_p, ctypes.c_double]),
     ("MhGetResizeFilterSupport", ctypes.c_double, [ctypes.c_void_p]),

@@ -401,13 +401,29 @@ MH_API MhResizeFilter *MhDestroyResizeFilter(MhResizeFilter *filter)
   return nullptr;
 }
 
+MH_API MhResizeFilter *MhAcquireResizeFilterFromCallback(MhResizeWeightFunction weight,
+  void *user,double support)
+{
+  if (weight == nullptr)
+    return nullptr;
+  MhResizeFilter *f=new MhResizeFilter();
+  f->callback=weight;
+  f->callback_user=user;
+  f->callback_support=support;
+  return f;
+}
+
 MH_API double MhGetResizeFilterSupport(const MhResizeFilter *filter)
 {
+  if (filter->callback != nullptr)
+    return filter->callback_support;
   return filter->support*filter->blur;
 }
 
 MH_API double MhGetResizeFilterWeight(const MhResizeFilter *filter,double x)
 {
+  if (filter->callback != nullptr)
+    return filter->callback(filter->callback_user,x);
   double x_blur=fabs((double) x)*perceptible_reciprocal(filter->blur);
   double scale;
   if ((filter->window_support < kEpsilon) || (filter->window_fn == FN_BOX))

@@ -13,6 +13,11 @@ struct MhResizeFilter
   double scale=1.0;
   double blur=1.0;
   double coefficient[7]={0,0,0,0,0,0,0};
+  // MhAcquireResizeFilterFromCallback: weights and support come from the caller
+  // (the MagickCore shim passes the reference's own GetResizeFilterWeight)
+  double (*callback)(void *,double)=nullptr;
+  void *callback_user=nullptr;
+  double callback_support=0.0;
 };
 
 namespace mh {

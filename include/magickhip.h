@@ -261,6 +261,14 @@ typedef enum
    (cylindrical = False, no expert `filter:*` artifacts). */
 typedef struct MhResizeFilter MhResizeFilter;
 MH_API MhResizeFilter *MhAcquireResizeFilter(MhFilterType filter,int image_has_alpha_or_enlarging_hint);
+/* A filter whose weights are evaluated by the caller: the MagickCore shim passes the
+   reference's own GetResizeFilterWeight / GetResizeFilterSupport (resize.c:1690, :1668) for
+   the ResizeFilter AccelerateResizeImage receives (accelerate-private.h:43-44), so expert
+   `filter:*` artifacts are honoured.  The callback runs on the host while the tap tables are
+   built (2*(columns+rows)*taps calls), never on the device. */
+typedef double (*MhResizeWeightFunction)(void *user,double x);
+MH_API MhResizeFilter *MhAcquireResizeFilterFromCallback(MhResizeWeightFunction weight,
+  void *user,double support);
 MH_API MhResizeFilter *MhDestroyResizeFilter(MhResizeFilter *filter);
 MH_API double MhGetResizeFilterWeight(const MhResizeFilter *filter,double x);   /* resize.c:1690 */
 MH_API double MhGetResizeFilterSupport(const MhResizeFilter *filter);           /* resize.c:1668 */

@@ -23,11 +23,17 @@ def available(hdri=False):
     return os.path.exists(lib_path(hdri))
 
 
-def _load(hdri):
-    key = bool(hdri)
+def shim_lib_path(hdri):
+    """MagickCore built with the HIP accelerate backend slotted in (shim/Makefile)."""
+    return os.path.join(os.path.dirname(_HERE), "shim", "_build",
+                        "libMagickCore-hip-%s.so" % ("q16hdri" if hdri else "q16"))
+
+
+def _load(hdri, shim=False):
+    key = (bool(hdri), bool(shim))
     if key in _LIBS:
         return _LIBS[key]
-    path = lib_path(hdri)
+    path = shim_lib_path(hdri) if shim else lib_path(hdri)
     if not os.path.exists(path):
         raise RuntimeError("compiled reference oracle missing: %s (make -C oracle/refbuild)" % path)
     # the reference looks for its config XML here; nothing is installed (and /root/reference
@@ -85,7 +91,7 @@ _MAPS = {1: "GRAY", 2: "GRAYA", 3: "RGB", 4: "RGBA"}
 class RefImage:
     """An image inside the reference's pixel cache."""
 
-    def __init__(self, pixels=None, colorspace="sRGB", handle=None, lib=None, hdri=None):
+    def __init__(self, pixels=None, colorspace="sRGB", handle=None, lib=None, hdri=None, shim=False):
         if handle is not None:
             self.L, self.handle, self.hdri = lib, handle, hdri
             self.last_seconds = 0.0
@@ -96,7 +102,7 @@ class RefImage:
         self.hdri = pixels.dtype == np.float32
         if not self.hdri and pixels.dtype != np.uint16:
             raise ValueError("uint16 or float32 pixels expected")
-        self.L = _load(self.hdri)
+        self.L = _load(self.hdri, shim)
         rows, cols, ch = pixels.shape
         self.handle = self.L.ref_image_new(cols, rows, _MAPS[ch].encode(), colorspace.encode(),
                                            pixels.ctypes.data)

@@ -1,0 +1,60 @@
+"""Drop-in check on the GPU box: MagickCore itself (compiled from the reference with
+shim/accelerate_hip.c + shim/opencl_hip.c in place of accelerate.c / opencl.c) runs
+BlurImage / ResizeImage / EqualizeImage through its own unchanged call sites
+(effect.c:783-787, resize.c:3818-3826, enhance.c:2072-2075), lands in
+libmagickhip.so, and returns what the pure-CPU MagickCore returns."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_pixels, assert_parity
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def shim(refmod, im):
+    if not (os.path.exists(refmod.shim_lib_path(False)) and os.path.exists(refmod.shim_lib_path(True))):
+        pytest.skip("shim/_build is not built (make -C shim, build container only)")
+    os.environ["MAGICK_HIP_LIBRARY"] = os.path.join(ROOT, "imagemagick_amd", "lib", "libmagickhip.so")
+    return refmod
+
+
+def accelerated_calls(refmod, hdri):
+    lib = refmod._load(hdri, True)
+    lib.GetMagickHipAcceleratedCalls.restype = ctypes.c_size_t
+    return lib.GetMagickHipAcceleratedCalls()
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_blur_resize_equalize_through_magickcore(shim, dtype):
+    hdri = dtype == np.float32
+    px = make_pixels(70, 90, 4, dtype)
+    before = accelerated_calls(shim, hdri)
+    gpu = shim.RefImage(px, shim=True)
+    cpu = shim.RefImage(px)
+    assert_parity(gpu.blur(0.0, 3.0).numpy(), cpu.blur(0.0, 3.0).numpy(), True, "BlurImage via MagickCore")
+    assert accelerated_calls(shim, hdri) == before + 1, "BlurImage did not take the accelerated path"
+    assert_parity(gpu.resize(200, 131, "Lanczos").numpy(), cpu.resize(200, 131, "Lanczos").numpy(), True,
+                  "ResizeImage via MagickCore")
+    assert_parity(gpu.resize(41, 33, "Mitchell").numpy(), cpu.resize(41, 33, "Mitchell").numpy(), True,
+                  "ResizeImage (Mitchell) via MagickCore")
+    assert accelerated_calls(shim, hdri) == before + 3
+    smooth = make_pixels(64, 64, 3, dtype, kind="smooth")
+    g, c = shim.RefImage(smooth, shim=True), shim.RefImage(smooth)
+    assert_parity(g.equalize().numpy(), c.equalize().numpy(), True, "EqualizeImage via MagickCore")
+    assert accelerated_calls(shim, hdri) == before + 4
+
+
+def test_gate_falls_back_to_cpu(shim):
+    """An image the gate rejects (a colourspace the backend does not take) silently runs the
+    CPU path — the reference's NULL-return convention."""
+    px = make_pixels(40, 50, 4, np.uint16)
+    before = accelerated_calls(shim, False)
+    gpu = shim.RefImage(px, "Lab", shim=True)
+    cpu = shim.RefImage(px, "Lab")
+    assert_parity(gpu.blur(0.0, 2.0).numpy(), cpu.blur(0.0, 2.0).numpy(), True, "Lab blur (CPU fallback)")
+    assert accelerated_calls(shim, False) == before
