@@ -21,6 +21,8 @@
 #include "device_common.hpp"
 
 #include <cmath>
+#include <cstdlib>
+#include <algorithm>
 
 namespace mh {
 
@@ -385,6 +387,326 @@ static MhStatus launch_channels(int channels,bool blend,int mc,const Morph2DArgs
   return fail(MH_UNSUPPORTED,"%d channels",channels);
 }
 
+
+// ------------------------------------------------ Erode / Dilate, convex flat kernels
+// Disk, Diamond, Octagon, Square, Rectangle, Plus ...: every kernel row's active
+// cells are ONE run [cx-h, cx+h] about a common centre column.  min/max are exact,
+// so any evaluation order gives the reference's bits; instead of visiting every
+// active cell (Disk:15 = 709) the kernel uses
+//     result(x,y) = max_k  M_{h_k}(x+cx, y+dy_k),   M_h(x,y) = max_{|d|<=h} in(x+d, y)
+// and builds the row-window maxima M_h incrementally over the kernel's DISTINCT
+// half-widths h_0 < h_1 < ... (Disk:15: 10 levels):
+//   raw tile (edge-clamped, coalesced loads) -> LDS
+//   for each level l:  phase 1  plane(y,x) = max(plane(y,x), raw(y, x+cx+-d), h_{l-1} < d <= h_l)
+//                      phase 2  every kernel row k of level l: out[r] = max(out[r], plane(y_r+dy_k, x))
+// A 64 x 32 output tile costs ~2*hmax+1 raw reads per tile pixel plus one plane
+// read per (kernel row, output) instead of one read per (active cell, output).
+struct ConvexArgs
+{
+  const void *src;
+  void *dst;
+  int columns,rows;
+  int cx;                     // centre column offset of the runs (dx of the run centres)
+  int hmax;                   // widest half-width
+  int top,bottom;             // kernel rows above / below the output row
+  int nlevels;
+  const int *level_h;         // [nlevels] ascending distinct half-widths
+  const int *level_first;     // [nlevels+1] index into level_dy
+  const int *level_dy;        // dy of every kernel row, grouped by level
+  uint32_t copy_mask;
+  unsigned long long *changed;
+};
+
+constexpr int kCTW=64;        // tile columns (= lanes)
+constexpr int kCTR=32;        // tile rows; each of the 4 waves owns 8 output rows
+
+template<typename Q,int C> struct PixelMinMax
+{
+  static __device__ __forceinline__ void apply(Q (&a)[C],const Q (&b)[C],bool take_max)
+  {
+    if constexpr ((sizeof(Q) == 2) && ((C & 1) == 0))
+      {
+        typedef unsigned short U2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int p=0; p < C/2; p++)
+          {
+            U2 va={(unsigned short) a[2*p],(unsigned short) a[2*p+1]};
+            U2 vb={(unsigned short) b[2*p],(unsigned short) b[2*p+1]};
+            U2 r=take_max ? __builtin_elementwise_max(va,vb) : __builtin_elementwise_min(va,vb);
+            a[2*p]=(Q) r[0];
+            a[2*p+1]=(Q) r[1];
+          }
+      }
+    else
+      {
+#pragma unroll
+        for (int c=0; c < C; c++)
+          {
+            if (take_max)
+              { if (b[c] > a[c]) a[c]=b[c]; }          // morphology.c:3025-3026
+            else
+              { if (b[c] < a[c]) a[c]=b[c]; }          // morphology.c:2997-2998
+          }
+      }
+  }
+};
+
+template<typename Q,int C,bool DILATE>
+__global__ __launch_bounds__(256)
+void morph_convex_kernel(ConvexArgs args)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int W=args.columns,H=args.rows;
+  const int hmax=args.hmax,top=args.top;
+  const int tile_rows=kCTR+top+args.bottom;
+  const int raw_w=kCTW+2*hmax;
+  Q *raw=reinterpret_cast<Q *>(smem_raw);
+  Q *plane=raw+(size_t) tile_rows*raw_w*C;
+  const Q *src=static_cast<const Q *>(args.src);
+  Q *dst=static_cast<Q *>(args.dst);
+  const size_t pitch=(size_t) W*C;
+  const int bx=(int) blockIdx.x*kCTW,by=(int) blockIdx.y*kCTR;
+  const int lane=(int) (threadIdx.x & 63);
+  const int wave=__builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+
+  // raw tile: tile column t is image column bx + cx - hmax + t (edge clamp, cache.c:2663-2679)
+  {
+    constexpr int BATCH=6;
+    const int items=tile_rows*raw_w;
+    for (int i0=(int) threadIdx.x; i0 < items; i0+=256*BATCH)
+      {
+        Q v[BATCH][C];
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          {
+            int idx=i0+256*k;
+            idx=idx < items ? idx : items-1;
+            const int ty=idx/raw_w,tx=idx-ty*raw_w;
+            int sx=bx+args.cx-hmax+tx,sy=by-top+ty;
+            sx=sx < 0 ? 0 : (sx > W-1 ? W-1 : sx);
+            sy=sy < 0 ? 0 : (sy > H-1 ? H-1 : sy);
+            load_pixel<Q,C>(src+(size_t) sy*pitch+(size_t) sx*C,v[k]);
+          }
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          if (i0+256*k < items)
+            store_pixel<Q,C>(raw+(size_t) (i0+256*k)*C,v[k]);
+      }
+  }
+  // accumulators: Erode starts from the output pixel itself, Dilate from 0 (morphology.c:2905-2912)
+  constexpr int R=kCTR/4;
+  const int x=bx+lane;
+  const int xc=x < W ? x : W-1;
+  Q out[R][C],center[R][C];
+#pragma unroll
+  for (int r=0; r < R; r++)
+    {
+      int y=by+wave*R+r;
+      y=y < H ? y : H-1;
+      load_pixel<Q,C>(src+(size_t) y*pitch+(size_t) xc*C,center[r]);
+#pragma unroll
+      for (int c=0; c < C; c++)
+        out[r][c]=DILATE ? (Q) 0 : center[r][c];
+    }
+  __syncthreads();
+
+  int h_prev=-1;
+  for (int l=0; l < args.nlevels; l++)
+    {
+      const int h=args.level_h[l];
+      // phase 1: widen the row-window maxima of every tile row to half-width h
+      for (int ty=wave; ty < tile_rows; ty+=4)
+        {
+          const Q *line=raw+((size_t) ty*raw_w+(size_t) (lane+hmax))*C;
+          Q m[C];
+          if (h_prev < 0)
+            load_pixel<Q,C>(line,m);
+          else
+            load_pixel<Q,C>(plane+((size_t) ty*kCTW+lane)*C,m);
+          for (int d=(h_prev < 0 ? 1 : h_prev+1); d <= h; d++)
+            {
+              Q a[C],b[C];
+              load_pixel<Q,C>(line-(size_t) d*C,a);
+              load_pixel<Q,C>(line+(size_t) d*C,b);
+              PixelMinMax<Q,C>::apply(m,a,DILATE);
+              PixelMinMax<Q,C>::apply(m,b,DILATE);
+            }
+          store_pixel<Q,C>(plane+((size_t) ty*kCTW+lane)*C,m);
+        }
+      __syncthreads();
+      // phase 2: the kernel rows whose run has this half-width
+      for (int i=args.level_first[l]; i < args.level_first[l+1]; i++)
+        {
+          const int dy=args.level_dy[i];
+          const Q *col=plane+((size_t) (wave*R+top+dy)*kCTW+lane)*C;
+#pragma unroll
+          for (int r=0; r < R; r++)
+            {
+              Q v[C];
+              load_pixel<Q,C>(col+(size_t) r*kCTW*C,v);
+              PixelMinMax<Q,C>::apply(out[r],v,DILATE);
+            }
+        }
+      __syncthreads();
+      h_prev=h;
+    }
+  unsigned changed=0;
+#pragma unroll
+  for (int r=0; r < R; r++)
+    {
+      const int y=by+wave*R+r;
+      if ((x < W) && (y < H))
+        {
+          Q res[C];
+#pragma unroll
+          for (int c=0; c < C; c++)
+            {
+              if ((args.copy_mask >> c) & 1u)
+                {
+                  res[c]=center[r][c];
+                  continue;
+                }
+              double pixel=(double) out[r][c];
+              if (fabs(pixel-(double) center[r][c]) >= kEps)
+                changed++;
+              res[c]=QuantumOps<Q>::clamp(pixel);
+            }
+          store_pixel<Q,C>(dst+(size_t) y*pitch+(size_t) x*C,res);
+        }
+    }
+  if (args.changed != nullptr)
+    {
+      changed=wave_sum(changed);
+      if ((lane == 0) && (changed != 0))
+        atomicAdd(args.changed,(unsigned long long) changed);
+    }
+}
+
+template<typename Q,int C>
+static MhStatus launch_convex(bool dilate,const ConvexArgs &args,dim3 grid,size_t lds,hipStream_t stream)
+{
+  if (dilate)
+    {
+      if (lds > 64u*1024u)
+        MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&morph_convex_kernel<Q,C,true>),
+          hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+      hipLaunchKernelGGL((morph_convex_kernel<Q,C,true>),grid,dim3(256),lds,stream,args);
+    }
+  else
+    {
+      if (lds > 64u*1024u)
+        MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&morph_convex_kernel<Q,C,false>),
+          hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+      hipLaunchKernelGGL((morph_convex_kernel<Q,C,false>),grid,dim3(256),lds,stream,args);
+    }
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+// Tries the convex fast path; *handled stays false when the kernel's active cells are
+// not one centred run per row (Ring, Cross, user kernels ...) or the tile does not fit.
+static MhStatus try_convex(const View &src,const View &dst,bool dilate,const std::vector<Cell> &cells,
+  const Roles &roles,unsigned long long *changed,bool *handled)
+{
+  *handled=false;
+  if (cells.size() < 9)                       // tiny kernels: the cell walk is already cheap
+    return MH_OK;
+  int dy_min=0x7fffffff,dy_max=-0x7fffffff;
+  for (const Cell &c : cells)
+    {
+      dy_min=c.dy < dy_min ? c.dy : dy_min;
+      dy_max=c.dy > dy_max ? c.dy : dy_max;
+    }
+  const int span=dy_max-dy_min+1;
+  std::vector<int> lo((size_t) span,0x7fffffff),hi((size_t) span,-0x7fffffff),cnt((size_t) span,0);
+  for (const Cell &c : cells)
+    {
+      size_t k=(size_t) (c.dy-dy_min);
+      lo[k]=c.dx < lo[k] ? c.dx : lo[k];
+      hi[k]=c.dx > hi[k] ? c.dx : hi[k];
+      cnt[k]++;
+    }
+  int centre2=0x7fffffff,hmax=0;
+  for (int k=0; k < span; k++)
+    {
+      if (cnt[(size_t) k] == 0)
+        continue;
+      if (cnt[(size_t) k] != hi[(size_t) k]-lo[(size_t) k]+1)
+        return MH_OK;                                        // a gap in the row
+      int c2=lo[(size_t) k]+hi[(size_t) k];
+      if (centre2 == 0x7fffffff)
+        centre2=c2;
+      if ((c2 != centre2) || ((c2 & 1) != 0))
+        return MH_OK;                                        // runs are not about one centre column
+      int h=(hi[(size_t) k]-lo[(size_t) k])/2;
+      hmax=h > hmax ? h : hmax;
+    }
+  const int cx=centre2/2;
+  const int top=dy_min < 0 ? -dy_min : 0,bottom=dy_max > 0 ? dy_max : 0;
+  if ((dy_min > 0) || (dy_max < 0) || (hmax > 48) || (span > 97))
+    return MH_OK;
+  const size_t px=(size_t) src.channels*(src.quantum == MH_QUANTUM_U16 ? 2u : 4u);
+  const size_t tile_rows=(size_t) (kCTR+top+bottom);
+  const size_t lds=tile_rows*((size_t) (kCTW+2*hmax)+(size_t) kCTW)*px;
+  if (lds > 80u*1024u)                                       // keep two workgroups per CU
+    return MH_OK;
+  // distinct half-widths ascending, kernel rows grouped by level
+  std::vector<int> level_h;
+  for (int k=0; k < span; k++)
+    if (cnt[(size_t) k] != 0)
+      level_h.push_back((hi[(size_t) k]-lo[(size_t) k])/2);
+  std::sort(level_h.begin(),level_h.end());
+  level_h.erase(std::unique(level_h.begin(),level_h.end()),level_h.end());
+  std::vector<int> level_first,level_dy;
+  for (size_t l=0; l < level_h.size(); l++)
+    {
+      level_first.push_back((int) level_dy.size());
+      for (int k=0; k < span; k++)
+        if ((cnt[(size_t) k] != 0) && ((hi[(size_t) k]-lo[(size_t) k])/2 == level_h[l]))
+          level_dy.push_back(k+dy_min);
+    }
+  level_first.push_back((int) level_dy.size());
+  Temp d_h,d_first,d_dy;
+  MH_TRY(upload_table(d_h,src.device,src.stream,level_h.data(),level_h.size()*sizeof(int)));
+  MH_TRY(upload_table(d_first,src.device,src.stream,level_first.data(),level_first.size()*sizeof(int)));
+  MH_TRY(upload_table(d_dy,src.device,src.stream,level_dy.data(),level_dy.size()*sizeof(int)));
+  ConvexArgs a;
+  a.src=src.pixels;
+  a.dst=dst.pixels;
+  a.columns=(int) src.columns;
+  a.rows=(int) src.rows;
+  a.cx=cx;
+  a.hmax=hmax;
+  a.top=top;
+  a.bottom=bottom;
+  a.nlevels=(int) level_h.size();
+  a.level_h=d_h.as<int>();
+  a.level_first=d_first.as<int>();
+  a.level_dy=d_dy.as<int>();
+  a.copy_mask=roles.copy_mask;
+  a.changed=changed;
+  dim3 grid((unsigned) ((src.columns+kCTW-1)/kCTW),(unsigned) ((src.rows+kCTR-1)/kCTR));
+  ProfileScope prof("morph_convex",src.stream);
+  MhStatus st=MH_OK;
+#define MH_CONVEX(QT) \
+  switch (src.channels) \
+  { \
+    case 1: st=launch_convex<QT,1>(dilate,a,grid,lds,src.stream); break; \
+    case 2: st=launch_convex<QT,2>(dilate,a,grid,lds,src.stream); break; \
+    case 3: st=launch_convex<QT,3>(dilate,a,grid,lds,src.stream); break; \
+    case 4: st=launch_convex<QT,4>(dilate,a,grid,lds,src.stream); break; \
+    default: return MH_OK; \
+  }
+  if (src.quantum == MH_QUANTUM_U16)
+    { MH_CONVEX(uint16_t) }
+  else
+    { MH_CONVEX(float) }
+#undef MH_CONVEX
+  MH_TRY(st);
+  *handled=true;
+  return MH_OK;
+}
+
 MhStatus launch_morph2d(const View &src,const View &dst,const Morph2DParams &params,
   const Roles &roles,unsigned long long *changed)
 {
@@ -463,6 +785,13 @@ MhStatus launch_morph2d(const View &src,const View &dst,const Morph2DParams &par
         c.value=value;
         cells.push_back(c);
       }
+  if (((mc == MC_ERODE) || (mc == MC_DILATE)) && (getenv("MAGICKHIP_NO_CONVEX") == nullptr))
+    {
+      bool handled=false;
+      MH_TRY(try_convex(src,dst,mc == MC_DILATE,cells,roles,changed,&handled));
+      if (handled)
+        return MH_OK;
+    }
   Morph2DArgs args;
   args.src=src.pixels;
   args.dst=dst.pixels;
