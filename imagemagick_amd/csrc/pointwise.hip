@@ -16,6 +16,7 @@
 //   UnsharpMaskImage epilogue              MagickCore/effect.c:4343-4372
 #include "mh_internal.hpp"
 #include "device_common.hpp"
+#include <cstdlib>
 
 namespace mh {
 
@@ -501,11 +502,108 @@ void histogram_snapshot_kernel(const unsigned long long *counts,unsigned long lo
     before[bin]=counts[(size_t) bin*channels];
 }
 
+// Intensity mode, LDS-privatised.  65 536 bins do not fit LDS as 32-bit counters
+// (256 KB > 160 KB), so a persistent workgroup (one per CU, 1024 threads) bins its
+// slice of the image twice — bins 0..32767, then 32768..65535 — into a 128 KB LDS
+// table with ds_add (no global atomics: on uniform-random Q16 data the global-atomic
+// kernel above is bound by 16.7 M L2 atomics per 4096^2 image), and writes each
+// half to its own slab; a small kernel sums the slabs into the caller's table
+// (all channels of a bin receive the same count in this mode).  The second read
+// of the slice comes from L2 / Infinity Cache.
+constexpr int kHistHalf=32768;
+
+template<typename Q,int C>
+__global__ __launch_bounds__(1024)
+void histogram_lds_kernel(const Q *pixels,size_t npixels,IntensityParams ip,unsigned *slabs)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned *table=reinterpret_cast<unsigned *>(smem_raw);
+  const size_t per=(npixels+gridDim.x-1)/gridDim.x;
+  const size_t begin=(size_t) blockIdx.x*per;
+  size_t end=begin+per;
+  end=end < npixels ? end : npixels;
+  for (int half=0; half < 2; half++)
+    {
+      for (int i=(int) threadIdx.x; i < kHistHalf; i+=1024)
+        table[i]=0u;
+      __syncthreads();
+      const unsigned base=(unsigned) half*kHistHalf;
+      constexpr int BATCH=4;
+      for (size_t i0=begin+threadIdx.x; i0 < end; i0+=(size_t) 1024*BATCH)
+        {
+          Q q[BATCH][C];
+#pragma unroll
+          for (int k=0; k < BATCH; k++)
+            {
+              size_t i=i0+(size_t) 1024*k;
+              load_pixel<Q,C>(pixels+(i < end ? i : end-1)*C,q[k]);
+            }
+#pragma unroll
+          for (int k=0; k < BATCH; k++)
+            if (i0+(size_t) 1024*k < end)
+              {
+                unsigned bin=QuantumOps<Q>::map_index(QuantumOps<Q>::clamp(pixel_intensity<Q,C>(q[k],ip)));
+                unsigned local=bin-base;
+                if (local < (unsigned) kHistHalf)
+                  atomicAdd(table+local,1u);
+              }
+        }
+      __syncthreads();
+      unsigned *slab=slabs+((size_t) blockIdx.x*2+half)*kHistHalf;
+      for (int i=(int) threadIdx.x; i < kHistHalf; i+=1024)
+        slab[i]=table[i];
+      __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256)
+void histogram_slab_reduce_kernel(const unsigned *slabs,int nblocks,unsigned long long *counts,int channels)
+{
+  const unsigned bin=blockIdx.x*blockDim.x+threadIdx.x;
+  if (bin > 65535u)
+    return;
+  const unsigned half=bin/kHistHalf,local=bin%kHistHalf;
+  unsigned long long sum=0;
+  for (int b=0; b < nblocks; b++)
+    sum+=slabs[((size_t) b*2+half)*kHistHalf+local];
+  for (int c=0; c < channels; c++)
+    counts[(size_t) bin*channels+c]+=sum;
+}
+
+template<typename Q,int C>
+static MhStatus histogram_intensity_lds(const View &src,const IntensityParams &ip,unsigned long long *hist)
+{
+  const size_t n=src.columns*src.rows;
+  int cus=256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop,src.device) == hipSuccess)
+    cus=prop.multiProcessorCount;
+  const int nblocks=cus;
+  Temp slabs;
+  MH_TRY(slabs.alloc(src.device,(size_t) nblocks*2*kHistHalf*sizeof(unsigned),src.stream));
+  const size_t lds=(size_t) kHistHalf*sizeof(unsigned);
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&histogram_lds_kernel<Q,C>),
+    hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+  {
+    ProfileScope prof("histogram",src.stream);
+    hipLaunchKernelGGL((histogram_lds_kernel<Q,C>),dim3(nblocks),dim3(1024),lds,src.stream,
+      static_cast<const Q *>(src.pixels),n,ip,slabs.as<unsigned>());
+    hipLaunchKernelGGL(histogram_slab_reduce_kernel,dim3(256),dim3(256),0,src.stream,
+      slabs.as<unsigned>(),nblocks,hist,C);
+  }
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 template<typename Q,int C>
 static MhStatus histogram_typed(const View &src,int mode,const IntensityParams &ip,
   unsigned long long *hist)
 {
   const size_t n=src.columns*src.rows;
+  // large frames in intensity mode: the LDS-privatised kernel (a frame below ~1 Mpixel
+  // does not amortise the 2 x 256 x 128 KB slab traffic)
+  if ((mode != 0) && (n >= ((size_t) 1 << 20)) && (getenv("MAGICKHIP_NO_LDS_HISTOGRAM") == nullptr))
+    return histogram_intensity_lds<Q,C>(src,ip,hist);
   Temp before;
   if ((mode != 0) && (C > 1))
     {

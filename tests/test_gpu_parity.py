@@ -267,3 +267,20 @@ def test_blur_full_size_properties(im):
     b2 = im.blur_image(im.Image(at.view(torch.uint16)), 0.0, 3.0).pixels.view(torch.int16)
     diff = (b1.transpose(0, 1).to(torch.int32) - b2.to(torch.int32)).abs().max()
     assert int(diff) <= 1
+
+
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("kind", ["random", "smooth"])
+def test_histogram_operators_large_frame(im, refmod, dtype, kind):
+    """Frames of >= 1 Mpixel take the LDS-privatised intensity histogram (two half-range
+    passes per workgroup): same counts, same operators."""
+    rows, cols = 1040, 1100
+    px = make_pixels(rows, cols, 4, dtype, kind=kind)
+    dev, ref = run_pair(im, refmod, px)
+    h = im.histogram(dev, True).cpu().numpy()
+    assert int(h[:, 0].sum()) == rows * cols and np.array_equal(h[:, 0], h[:, 3])
+    assert_parity(im.equalize_image(dev).numpy(), ref.equalize().numpy(), True, "equalize (large)")
+    dev, ref = run_pair(im, refmod, px)
+    n = rows * cols
+    got = im.contrast_stretch_image(dev, 0.02 * n, n - 0.01 * n).numpy()
+    assert_parity(got, ref.contrast_stretch(0.02 * n, n - 0.01 * n).numpy(), True, "contrast-stretch (large)")
