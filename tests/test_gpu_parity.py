@@ -284,3 +284,80 @@ def test_histogram_operators_large_frame(im, refmod, dtype, kind):
     n = rows * cols
     got = im.contrast_stretch_image(dev, 0.02 * n, n - 0.01 * n).numpy()
     assert_parity(got, ref.contrast_stretch(0.02 * n, n - 0.01 * n).numpy(), True, "contrast-stretch (large)")
+
+
+# ----------------------------------- full-size property checks, configs C3 / C4 / C5
+def test_resize_full_size_properties(im):
+    """BASELINE C3 geometry (8192^2 -> 32768^2 Lanczos, float Quantum RGBA, 17 GB result):
+    normalised weights reproduce a constant image exactly, and an image that is constant along
+    x resizes like its 1-D column profile (every output column identical)."""
+    import torch
+    n = 8192
+    const = torch.full((n, n, 4), 4321.0, dtype=torch.float32, device="cuda")
+    out = im.resize_image(im.Image(const), 4 * n, 4 * n, "Lanczos").pixels
+    assert out.shape == (4 * n, 4 * n, 4)
+    assert float((out - 4321.0).abs().max()) == 0.0
+    del out, const
+    torch.cuda.empty_cache()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    profile = torch.rand((n, 1, 4), generator=g, device="cuda") * 60000.0 + 100.0
+    profile[:, :, 3] = 65535.0
+    img = profile.expand(n, 64, 4).contiguous()
+    out = im.resize_image(im.Image(img), 256, 4 * n, "Lanczos").pixels
+    assert float((out - out[:, :1, :]).abs().max()) == 0.0          # columns stay identical
+    tall = im.resize_image(im.Image(profile.contiguous()), 1, 4 * n, "Lanczos").pixels
+    assert float((out[:, :1, :] - tall).abs().max()) == 0.0         # == the 1-D resize of the profile
+
+
+def test_morphology_full_size_properties(im):
+    """BASELINE C5 geometry (16384^2 RGBA Q16, Disk:15): a single bright pixel dilates into the
+    709-cell disk; Erode and Dilate are dual under negation for this symmetric kernel."""
+    import torch
+    n = 16384
+    img = torch.zeros((n, n, 4), dtype=torch.int16, device="cuda")
+    img[5000, 7000, :] = -1                                           # 65535
+    out = im.morphology_image(im.Image(img.view(torch.uint16)), "Dilate", 1, "Disk:15").pixels
+    lit = (out.view(torch.int16)[:, :, 0] != 0)
+    assert int(lit.sum()) == 709
+    ys, xs = torch.nonzero(lit, as_tuple=True)
+    assert int(ys.min()) == 4985 and int(ys.max()) == 5015 and int(xs.min()) == 6985 and int(xs.max()) == 7015
+    del img, out, lit
+    torch.cuda.empty_cache()
+    m = 4096
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = torch.randint(-32768, 32768, (m, m, 4), generator=g, device="cuda", dtype=torch.int16)
+    neg = (~a)                                                        # 65535 - value on the uint16 view
+    dil = im.morphology_image(im.Image(a.view(torch.uint16)), "Dilate", 1, "Disk:15").pixels.view(torch.int16)
+    ero = im.morphology_image(im.Image(neg.contiguous().view(torch.uint16)), "Erode", 1, "Disk:15").pixels.view(torch.int16)
+    assert bool(((~ero) == dil).all())
+
+
+def test_lab_contrast_stretch_full_size_properties(im):
+    """BASELINE C4 geometry (4096^2 RGBA Q16), checked against the oracle without running the
+    oracle at full size: in a gray ramp image (R=G=B=A=v, every v of 0..65535 exactly 256 times)
+    the result of sRGB->Lab + ContrastStretch(2% x 1%) at a pixel depends only on v, and the
+    histogram is 256 x that of a 256x256 image holding each v once — so the full-size device
+    result must equal the oracle's 256x256 result looked up by v."""
+    import torch
+    from oracle import restate as R
+    n = 4096
+    small = np.arange(65536, dtype=np.uint16).reshape(256, 256, 1).repeat(4, axis=2)
+    want = R.transform_image_colorspace(small, "srgb", "lab")
+    want_lab = want.copy()
+    cnt = 256 * 256
+    want = R.contrast_stretch_image(want, 0.02 * cnt, cnt - 0.01 * cnt, colorspace="lab")
+    v = (torch.arange(n * n, device="cuda", dtype=torch.int64) & 0xFFFF).to(torch.int32)
+    ramp = v.to(torch.int16).view(n, n, 1).expand(n, n, 4).contiguous().view(torch.uint16)
+    img = im.Image(ramp)
+    h = im.histogram(img, True)
+    assert int(h[:, 0].sum()) == n * n
+    im.transform_image_colorspace(img, "Lab")
+    lut = torch.from_numpy(want_lab.reshape(65536, 4).astype(np.int32)).cuda()
+    got = img.pixels.view(torch.int16).to(torch.int32) & 0xFFFF
+    d = (got.view(-1, 4) - lut[v.to(torch.int64)]).abs()
+    assert int(d.max()) <= 1 and float((d == 0).float().mean()) > 0.9999, "sRGB->Lab at full size"
+    im.contrast_stretch_image(img, 0.02 * n * n, n * n - 0.01 * n * n)
+    lut = torch.from_numpy(want.reshape(65536, 4).astype(np.int32)).cuda()
+    got = img.pixels.view(torch.int16).to(torch.int32) & 0xFFFF
+    d = (got.view(-1, 4) - lut[v.to(torch.int64)]).abs()
+    assert int(d.max()) <= 1 and float((d == 0).float().mean()) > 0.999, "Lab + ContrastStretch at full size"
