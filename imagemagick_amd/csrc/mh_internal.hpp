@@ -161,8 +161,9 @@ MhStatus launch_unsharp_epilogue(const View &src,const View &blur,const View &ds
 
 MhStatus launch_histogram(const View &src,int intensity_mode,const MhImage *desc,
   unsigned long long *hist_device);
+// shared_column >= 0: every channel selected by apply_mask maps through that one LUT column
 MhStatus launch_apply_lut(const View &img,const void *lut_device,uint32_t apply_mask,
-  const Roles &roles);
+  const Roles &roles,int shared_column);
 MhStatus launch_gray_check(const View &img,const MhImage *desc,unsigned int *flag_device);
 MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,const MhImage *desc);
 MhStatus launch_copy(const View &src,const View &dst);

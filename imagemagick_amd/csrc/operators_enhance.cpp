@@ -80,6 +80,7 @@ static MhStatus apply_lut_host(const View &view,const MhImage *desc,const double
 {
   const size_t n=(size_t) MH_HISTOGRAM_BINS*(size_t) view.channels;
   Temp d_lut;
+  int shared_column=-1;
   if (view.quantum == MH_QUANTUM_U16)
     {
       std::vector<unsigned short> q(n);
@@ -89,6 +90,28 @@ static MhStatus apply_lut_host(const View &view,const MhImage *desc,const double
           double v=lut[i];
           q[i]=(unsigned short) (!(v > 0.0) ? 0 : (v >= kQuantumRange ? 65535 : (unsigned short) (v+0.5)));
         }
+      // do all selected channels share one column?
+      const int C=view.channels;
+      int first=-1;
+      bool same=true;
+      for (int c=0; (c < C) && same; c++)
+        {
+          if (((apply_mask >> c) & 1u) == 0)
+            continue;
+          if (first < 0)
+            {
+              first=c;
+              continue;
+            }
+          for (size_t b=0; b < (size_t) MH_HISTOGRAM_BINS; b++)
+            if (q[b*(size_t) C+(size_t) c] != q[b*(size_t) C+(size_t) first])
+              {
+                same=false;
+                break;
+              }
+        }
+      if (same && (first >= 0))
+        shared_column=first;
       MH_TRY(upload_table(d_lut,view.device,view.stream,q.data(),n*sizeof(unsigned short)));
     }
   else
@@ -105,7 +128,7 @@ static MhStatus apply_lut_host(const View &view,const MhImage *desc,const double
     if ((desc->channel_traits[c] & MH_TRAIT_UPDATE) != 0)
       update|=1u<<c;
   roles.update_mask=update;
-  return launch_apply_lut(view,d_lut.ptr,apply_mask,roles);
+  return launch_apply_lut(view,d_lut.ptr,apply_mask,roles,shared_column);
 }
 
 } // namespace mh

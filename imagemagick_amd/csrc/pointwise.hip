@@ -668,9 +668,77 @@ static MhStatus apply_lut_typed(const View &img,const void *lut,uint32_t mask)
   return MH_OK;
 }
 
-MhStatus launch_apply_lut(const View &img,const void *lut,uint32_t apply_mask,const Roles &roles)
+// Q16, every masked channel maps through the SAME 65536-entry column (the intensity-
+// binned operators give all channels one histogram, hence one LUT: enhance.c:1637-1643):
+// the 128 KB column lives in LDS of a persistent workgroup per CU and the 4 lookups per
+// pixel are LDS reads instead of scattered 2-byte global gathers.
+template<int C>
+__global__ __launch_bounds__(1024)
+void apply_lut_shared_kernel(uint16_t *pixels,size_t npixels,const uint16_t *lut,int column,uint32_t mask)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint16_t *table=reinterpret_cast<uint16_t *>(smem_raw);
+  for (int i=(int) threadIdx.x; i < 65536; i+=1024)
+    table[i]=lut[(size_t) i*C+column];
+  __syncthreads();
+  constexpr int BATCH=4;
+  const size_t stride=(size_t) gridDim.x*1024*BATCH;
+  for (size_t i0=(size_t) blockIdx.x*1024*BATCH+threadIdx.x; i0 < npixels; i0+=stride)
+    {
+      uint16_t q[BATCH][C];
+#pragma unroll
+      for (int k=0; k < BATCH; k++)
+        {
+          size_t i=i0+(size_t) 1024*k;
+          load_pixel<uint16_t,C>(pixels+(i < npixels ? i : npixels-1)*C,q[k]);
+        }
+#pragma unroll
+      for (int k=0; k < BATCH; k++)
+        {
+          size_t i=i0+(size_t) 1024*k;
+          if (i < npixels)
+            {
+#pragma unroll
+              for (int c=0; c < C; c++)
+                if ((mask >> c) & 1u)
+                  q[k][c]=table[q[k][c]];
+              store_pixel<uint16_t,C>(pixels+i*C,q[k]);
+            }
+        }
+    }
+}
+
+template<int C>
+static MhStatus apply_lut_shared(const View &img,const void *lut,int column,uint32_t mask)
+{
+  const size_t n=img.columns*img.rows;
+  int cus=256;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop,img.device) == hipSuccess)
+    cus=prop.multiProcessorCount;
+  const size_t lds=65536*sizeof(uint16_t);
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&apply_lut_shared_kernel<C>),
+    hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+  ProfileScope prof("apply_lut",img.stream);
+  hipLaunchKernelGGL((apply_lut_shared_kernel<C>),dim3(cus),dim3(1024),lds,img.stream,
+    static_cast<uint16_t *>(img.pixels),n,static_cast<const uint16_t *>(lut),column,mask);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+MhStatus launch_apply_lut(const View &img,const void *lut,uint32_t apply_mask,const Roles &roles,
+  int shared_column)
 {
   uint32_t mask=apply_mask & roles.update_mask;
+  if ((shared_column >= 0) && (img.quantum == MH_QUANTUM_U16) &&
+      (img.columns*img.rows >= ((size_t) 1 << 20)))
+    switch (img.channels)
+    {
+      case 1: return apply_lut_shared<1>(img,lut,shared_column,mask);
+      case 2: return apply_lut_shared<2>(img,lut,shared_column,mask);
+      case 3: return apply_lut_shared<3>(img,lut,shared_column,mask);
+      default: return apply_lut_shared<4>(img,lut,shared_column,mask);
+    }
 #define MH_CASE(QT) \
   switch (img.channels) { \
     case 1: return apply_lut_typed<QT,1>(img,lut,mask); \
