@@ -1315,6 +1315,8 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
             return dispatch_tri<Fast32,16,4>(src,dst,vertical,params,roles,changed);
           return dispatch_blocked<Fast32,16,4>(src,dst,vertical,params,roles,changed);
         }
+      if ((params.ntaps >= 16) && (getenv("MAGICKHIP_NO_TRI") == nullptr))
+        return dispatch_tri<Exact64,8,8>(src,dst,vertical,params,roles,changed);
       return dispatch_blocked<Exact64,8,8>(src,dst,vertical,params,roles,changed);
     }
   // float Quantum always accumulates in double: an FP32 sum cannot stay
