@@ -1035,6 +1035,116 @@ void conv_column_tri(Conv1DArgs args)
     }
 }
 
+
+// Column pass with the rows staged through LDS.  In conv_column_tri every wave
+// fetches its own R+K-1 rows, so an image row is requested (R+K-1)/R = 5.9 times
+// (R=16, K=79) and, with a 4 MB L2 per XCD, most of those re-reads go back to the
+// fabric (PMC: 3.47 GB per launch against 1.07 GB algorithmic).  Here a workgroup
+// of WAVES waves stages the WAVES*R+K-1 rows of its 64-column strip once, with
+// batched coalesced loads, and the waves take their samples from LDS (lane = column
+// => each row read is one conflict-free 512-byte ds_read_b64 sweep).
+template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES>
+__global__ __launch_bounds__(64*WAVES)
+void conv_column_lds(Conv1DArgs args)
+{
+  typedef typename A::T T;
+  typedef Accum<Q,C,BLEND,A,R> Acc;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane=(int) (threadIdx.x & 63);
+  const int wave=__builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const int W=args.columns,H=args.rows,K=args.ntaps;
+  const int table_bytes=A::taps_in_lds ? ((K*(int) sizeof(T)+15) & ~15) : 0;
+  Q *tile=reinterpret_cast<Q *>(smem_raw+table_bytes);
+  const unsigned ntx=(unsigned) ((W+63)/64);
+  const unsigned nty=(unsigned) ((H+R*WAVES-1)/(R*WAVES));
+  const unsigned total=ntx*nty;
+  const unsigned id=blockIdx.x;
+  const unsigned per=(total+7u)/8u;
+  const unsigned tile_id=(id & 7u)*per+(id >> 3);    // XCD-aware: see conv_column_kernel
+  if (tile_id >= total)
+    return;
+  const int tx=(int) (tile_id/nty),ty=(int) (tile_id%nty);
+  const int x=tx*64+lane;
+  const int yb=ty*WAVES*R;                             // first output row of the workgroup
+  const int y0=yb+wave*R;
+  const Q *src=static_cast<const Q *>(args.src);
+  Q *dst=static_cast<Q *>(args.dst);
+  const size_t pitch=(size_t) W*C;
+  const T *table=stage_taps<T,A::taps_in_lds>(args,smem_raw,K,true);
+  // stage rows yb-shift .. yb-shift+nrows-1 (edge clamp, cache.c:2663-2679), 64 pixels each
+  const int nrows=WAVES*R+K-1;
+  {
+    constexpr int BATCH=18;
+    const int items=nrows*64;
+    const int x0=tx*64;
+    for (int i0=(int) threadIdx.x; i0 < items; i0+=64*WAVES*BATCH)
+      {
+        Q v[BATCH][C];
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          {
+            int idx=i0+64*WAVES*k;
+            idx=idx < items ? idx : items-1;
+            int yy=yb-args.shift+(idx >> 6),xx=x0+(idx & 63);
+            yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
+            xx=xx > W-1 ? W-1 : xx;
+            load_pixel<Q,C>(src+(size_t) yy*pitch+(size_t) xx*C,v[k]);
+          }
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          if (i0+64*WAVES*k < items)
+            store_pixel<Q,C>(tile+(size_t) (i0+64*WAVES*k)*C,v[k]);
+      }
+  }
+  __syncthreads();
+  if (y0 >= H)
+    return;
+
+  Acc acc;
+  acc.init((T) args.bias);
+  const Q *mine=tile+((size_t) wave*R*64+(size_t) lane)*C;      // sample j lives at mine + j*64*C
+  Q nxt[U][C];
+  auto fetch_u=[&](int pos)
+  {
+#pragma unroll
+    for (int jj=0; jj < U; jj++)
+      {
+        int j=pos+jj;
+        j=j < R+K-1 ? j : R+K-2;                                 // the last prefetch may run over
+        load_pixel<Q,C>(mine+(size_t) j*64*C,nxt[jj]);
+      }
+  };
+  auto fetch_1=[&](int pos)
+  {
+    load_pixel<Q,C>(mine+(size_t) pos*64*C,nxt[0]);
+  };
+  tri_accumulate<Q,C,BLEND,A,R,U>(acc,table,K,fetch_u,fetch_1,nxt);
+
+  unsigned changed=0;
+#pragma unroll
+  for (int r=0; r < R; r++)
+    {
+      int y=y0+r;
+      if (y < H)
+        {
+          Q center[C],out[C];
+          load_pixel<Q,C>(mine+(size_t) (r+args.shift)*64*C,center);   // input row y
+          unsigned ch=acc.finish(r,center,args.copy_mask,out,(T) args.bias,args.changed != nullptr);
+          if (x < W)
+            {
+              store_pixel<Q,C>(dst+(size_t) y*pitch+(size_t) x*C,out);
+              changed+=ch;
+            }
+        }
+    }
+  if (args.changed != nullptr)
+    {
+      changed=wave_sum(changed);
+      if ((lane == 0) && (changed != 0))
+        atomicAdd(args.changed,(unsigned long long) changed);
+    }
+}
+
 template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_row_tri(Conv1DArgs args)
@@ -1168,7 +1278,20 @@ static MhStatus launch_tri(const View &src,const View &dst,bool vertical,
       unsigned ntx=(unsigned) ((W+63)/64),nty=(unsigned) ((H+R*WAVES-1)/(R*WAVES));
       unsigned grid=((ntx*nty+7u)/8u)*8u;
       size_t lds=A::taps_in_lds ? (size_t) K*sizeof(T) : 0;
+      // rows staged once per workgroup through LDS when the strip fits twice per CU
+      size_t table_bytes=A::taps_in_lds ? (((size_t) K*sizeof(T)+15u) & ~(size_t) 15u) : 0;
+      size_t lds_tile=table_bytes+(size_t) (WAVES*R+K-1)*64*C*sizeof(Q);
       ProfileScope prof("conv_column",src.stream);
+      if ((lds_tile <= 80u*1024u) && (getenv("MAGICKHIP_NO_COLUMN_LDS") == nullptr))
+        {
+          if (lds_tile > 64u*1024u)
+            MH_HIP(hipFuncSetAttribute(
+              reinterpret_cast<const void *>(&conv_column_lds<Q,C,BLEND,A,R,U,WAVES>),
+              hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds_tile));
+          hipLaunchKernelGGL((conv_column_lds<Q,C,BLEND,A,R,U,WAVES>),dim3(grid),dim3(64*WAVES),lds_tile,
+            src.stream,args);
+        }
+      else
       hipLaunchKernelGGL((conv_column_tri<Q,C,BLEND,A,R,U,WAVES>),dim3(grid),dim3(64*WAVES),lds,
         src.stream,args);
     }
