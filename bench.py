@@ -210,7 +210,7 @@ def main():
                 alu = {"achieved_tflops": round(flops / (ms * 1e-3) / 1e12, 2), "peak_tflops": peak,
                        "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
                        "note": "algorithmic multiply-adds only (alpha weighting, conversions and the "
-                               "zero-padded ramp taps are extra work, not counted)"}
+                               "epilogue are extra work, not counted)"}
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": traffic, "avg_ms": round(ms, 4),
@@ -255,8 +255,9 @@ def timed(torch, fn, reps):
 
 
 def extra_measurements(im, torch, args):
-    """Secondary numbers reported next to the headline (not `value`): the FAST
-    precision blur and the C3 Lanczos 4x resize (8192^2 -> 32768^2, float Quantum)."""
+    """Secondary numbers reported next to the headline (not `value`): the other precision
+    mode of the blur, the C3 Lanczos 4x resize (8192^2 -> 32768^2, float Quantum), one image of
+    the C4 batch (sRGB->Lab + ContrastStretch) and the two C5 operators."""
     extra = {}
     try:
         n = args.size
@@ -297,6 +298,40 @@ def extra_measurements(im, torch, args):
         if "resize_vertical" in prof:
             b = (1.0 * m * m + 4.0 * m * m) * 16
             extra["resize_vertical_GBps"] = round(b / (prof["resize_vertical"]["avg_ms"] * 1e-3) / 1e9, 1)
+        holder.clear()
+        del srcf, imgf
+        torch.cuda.empty_cache()
+        # C4 (one image of the batch): 4096^2 RGBA Q16 sRGB->Lab + ContrastStretch 2%x1%
+        k = 4096
+        src4 = torch.randint(-32768, 32768, (k, k, 4), generator=gen, device="cuda",
+                             dtype=torch.int16).view(torch.uint16)
+        work = src4.clone()
+
+        def c4():
+            work.copy_(src4)
+            img4 = im.Image(work)
+            im.transform_image_colorspace(img4, "Lab")
+            im.contrast_stretch_image(img4, 0.02 * k * k, k * k - 0.01 * k * k)
+        sec = timed(torch, c4, 5)
+        prof = kernel_profile(im, c4, 3)
+        extra["c4_lab_contrast_stretch_4096_Mpixels_per_s"] = round(k * k / sec / 1e6, 1)
+        extra["c4_kernels_ms"] = {kk: round(v["avg_ms"], 3) for kk, v in prof.items()}
+        del src4, work
+        # C5: 16384^2 RGBA Q16 Dilate Disk:15, then UnsharpMask(0x10+1+0.02)
+        k = 16384
+        src5 = torch.randint(-32768, 32768, (k, k, 4), generator=gen, device="cuda",
+                             dtype=torch.int16).view(torch.uint16)
+        img5 = im.Image(src5)
+
+        def dilate():
+            holder["o"] = im.morphology_image(img5, "Dilate", 1, "Disk:15")
+        sec = timed(torch, dilate, 2)
+        extra["c5_dilate_disk15_16384_Mpixels_per_s"] = round(k * k / sec / 1e6, 1)
+
+        def unsharp():
+            holder["o"] = im.unsharp_mask_image(img5, 0.0, 10.0, 1.0, 0.02)
+        sec = timed(torch, unsharp, 2)
+        extra["c5_unsharp_0x10_16384_Mpixels_per_s"] = round(k * k / sec / 1e6, 1)
         holder.clear()
     except Exception as exc:
         extra["error"] = str(exc)

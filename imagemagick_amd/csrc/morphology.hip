@@ -514,24 +514,47 @@ void morph_convex_kernel(ConvexArgs args)
   for (int l=0; l < args.nlevels; l++)
     {
       const int h=args.level_h[l];
-      // phase 1: widen the row-window maxima of every tile row to half-width h
-      for (int ty=wave; ty < tile_rows; ty+=4)
+      // phase 1: widen the row-window maxima of every tile row to half-width h.  Four
+      // rows per step: their LDS reads are independent, so one latency covers all four.
+      constexpr int RB=4;
+      for (int t0=wave; t0 < tile_rows; t0+=4*RB)
         {
-          const Q *line=raw+((size_t) ty*raw_w+(size_t) (lane+hmax))*C;
-          Q m[C];
-          if (h_prev < 0)
-            load_pixel<Q,C>(line,m);
-          else
-            load_pixel<Q,C>(plane+((size_t) ty*kCTW+lane)*C,m);
+          Q m[RB][C];
+          const Q *line[RB];
+#pragma unroll
+          for (int k=0; k < RB; k++)
+            {
+              int ty=t0+4*k;
+              ty=ty < tile_rows ? ty : tile_rows-1;
+              line[k]=raw+((size_t) ty*raw_w+(size_t) (lane+hmax))*C;
+              if (h_prev < 0)
+                load_pixel<Q,C>(line[k],m[k]);
+              else
+                load_pixel<Q,C>(plane+((size_t) ty*kCTW+lane)*C,m[k]);
+            }
           for (int d=(h_prev < 0 ? 1 : h_prev+1); d <= h; d++)
             {
-              Q a[C],b[C];
-              load_pixel<Q,C>(line-(size_t) d*C,a);
-              load_pixel<Q,C>(line+(size_t) d*C,b);
-              PixelMinMax<Q,C>::apply(m,a,DILATE);
-              PixelMinMax<Q,C>::apply(m,b,DILATE);
+              Q a[RB][C],b[RB][C];
+#pragma unroll
+              for (int k=0; k < RB; k++)
+                {
+                  load_pixel<Q,C>(line[k]-(size_t) d*C,a[k]);
+                  load_pixel<Q,C>(line[k]+(size_t) d*C,b[k]);
+                }
+#pragma unroll
+              for (int k=0; k < RB; k++)
+                {
+                  PixelMinMax<Q,C>::apply(m[k],a[k],DILATE);
+                  PixelMinMax<Q,C>::apply(m[k],b[k],DILATE);
+                }
             }
-          store_pixel<Q,C>(plane+((size_t) ty*kCTW+lane)*C,m);
+#pragma unroll
+          for (int k=0; k < RB; k++)
+            {
+              int ty=t0+4*k;
+              if (ty < tile_rows)
+                store_pixel<Q,C>(plane+((size_t) ty*kCTW+lane)*C,m[k]);
+            }
         }
       __syncthreads();
       // phase 2: the kernel rows whose run has this half-width
