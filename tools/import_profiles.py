@@ -27,10 +27,12 @@ def main(tag):
     src = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
-    if stats:
+    for sub, suffix in (("stats", "_kernel_stats.csv"), ("stats_full", "_kernel_stats_all_configs.csv")):
+        stats = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+        if not stats:
+            continue
         rows = list(csv.DictReader(open(stats[0])))
-        with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w") as f:
+        with open(os.path.join(dst, tag + suffix), "w") as f:
             f.write("kernel,calls,total_ns,average_ns,percentage\n")
             for r in rows:
                 n = r["Name"]
