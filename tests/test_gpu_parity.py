@@ -361,3 +361,44 @@ def test_lab_contrast_stretch_full_size_properties(im):
     got = img.pixels.view(torch.int16).to(torch.int32) & 0xFFFF
     d = (got.view(-1, 4) - lut[v.to(torch.int64)]).abs()
     assert int(d.max()) <= 1 and float((d == 0).float().mean()) > 0.999, "Lab + ContrastStretch at full size"
+
+
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("colorspace", ["RGB", "sRGB"])
+@pytest.mark.parametrize("shape", [(60, 70, 3), (1030, 1040, 4)])
+def test_histogram_operators_linear_rgb(im, refmod, dtype, colorspace, shape):
+    """GetPixelIntensity encodes linear RGB before weighting (pixel.c:2418-2424); the large
+    frame takes the LDS histogram and the shared-column LUT apply."""
+    px = make_pixels(*shape, dtype, kind="smooth")
+    dev, ref = run_pair(im, refmod, px, colorspace=colorspace)
+    assert_parity(im.equalize_image(dev).numpy(), ref.equalize().numpy(), True, "equalize " + colorspace)
+    dev, ref = run_pair(im, refmod, px, colorspace=colorspace)
+    n = shape[0] * shape[1]
+    got = im.contrast_stretch_image(dev, 0.03 * n, n - 0.02 * n).numpy()
+    assert_parity(got, ref.contrast_stretch(0.03 * n, n - 0.02 * n).numpy(), True, "stretch " + colorspace)
+
+
+def test_resize_callback_filter_matches_builtin(im, refmod):
+    """MhAcquireResizeFilterFromCallback (what the MagickCore shim uses): weights supplied by the
+    caller — here the reference's own GetResizeFilterWeight through the oracle driver."""
+    import ctypes
+    from imagemagick_amd import _lib
+    lib = _lib.load()
+    px = make_pixels(40, 52, 4, Q16)
+    ref = refmod.RefImage(px)
+    cb_type = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_void_p, ctypes.c_double)
+
+    def weight(_user, x):
+        return float(ref.filter_weights("Lanczos", [x])[0][0])
+    cb = cb_type(weight)
+    support = ref.filter_weights("Lanczos", [0.0])[1]
+    flt = lib.MhAcquireResizeFilterFromCallback(cb, None, support)
+    assert flt
+    try:
+        src = im.Image(to_device(px))
+        out = src.like(rows=97, columns=130)
+        _lib.check(lib.MagickHipResizeImageWithFilter(ctypes.byref(src.descriptor()),
+                                                      ctypes.byref(out.descriptor()), flt))
+    finally:
+        lib.MhDestroyResizeFilter(flt)
+    assert_parity(out.numpy(), ref.resize(130, 97, "Lanczos").numpy(), True, "callback filter")
