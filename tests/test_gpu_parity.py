@@ -402,3 +402,33 @@ def test_resize_callback_filter_matches_builtin(im, refmod):
     finally:
         lib.MhDestroyResizeFilter(flt)
     assert_parity(out.numpy(), ref.resize(130, 97, "Lanczos").numpy(), True, "callback filter")
+
+
+@pytest.mark.parametrize("case", ["tiny_alpha", "sparse_alpha", "binary_alpha", "checker", "dark", "smooth"])
+@pytest.mark.parametrize("sigma", [2.0, 10.0])
+def test_blur_fast_adversarial(im, refmod, case, sigma):
+    """FAST (f32) BlurImage against the reference on inputs that stress the alpha-weighted
+    normalisation: must stay within +-1 level (the contract of the mode bench.py runs)."""
+    rng = np.random.default_rng(17)
+    rows, cols = 150, 170
+    px = rng.integers(0, 65536, (rows, cols, 4), dtype=np.uint16)
+    if case == "tiny_alpha":
+        px[:, :, 3] = rng.integers(0, 4, (rows, cols))
+    elif case == "sparse_alpha":
+        px[:, :, 3] = np.where(rng.random((rows, cols)) < 0.02, 65535, 0)
+    elif case == "binary_alpha":
+        px[:, :, 3] = np.where(rng.random((rows, cols)) < 0.5, 65535, 0)
+    elif case == "checker":
+        y, x = np.mgrid[0:rows, 0:cols]
+        px[:, :, :3] = (((x + y) & 1) * 65535)[:, :, None]
+    elif case == "dark":
+        px[:, :, :3] = rng.integers(0, 8, (rows, cols, 3))
+    elif case == "smooth":
+        px = make_pixels(rows, cols, 4, Q16, kind="smooth")
+    dev, ref = run_pair(im, refmod, px)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got = im.blur_image(dev, 0.0, sigma).numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert_parity(got, ref.blur(0.0, sigma).numpy(), False, "fast blur %s sigma=%g" % (case, sigma))
