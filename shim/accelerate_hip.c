@@ -11,9 +11,15 @@
   Callers of MagickCore / MagickWand are unchanged.
 
   The work itself happens behind the C ABI of libmagickhip.so
-  (include/magickhip.h), loaded with dlopen on first use: without the library,
-  without a GPU, or with MAGICK_HIP_DEVICE=off every function here returns
-  NULL / MagickFalse and the CPU path runs.
+  (include/magickhip.h), loaded with dlopen on first use (opencl_hip.c): without
+  the library, without a GPU, or with the enable switch off every function here
+  returns NULL / MagickFalse and the CPU path runs.
+
+  Images stay on the device between chained operators: an operator input is
+  uploaded once and its device copy is remembered in CacheInfo::opencl; a result
+  is produced on the device and NOT downloaded — the host block is brought up to
+  date by the cache hooks in opencl_hip.c the first time the CPU accesses the
+  pixels (the reference's own lazy-sync protocol, cache.c:5341-5353).
 
   Nothing of the reference's OpenCL implementation is used: no cl_mem, no
   kernels-as-strings, no OpenCL runtime.
@@ -34,84 +40,12 @@
 
 #if defined(MAGICKCORE_OPENCL_SUPPORT)
 
-#include <dlfcn.h>
 #include <stdlib.h>
-#include "magickhip.h"
+#include "MagickCore/memory_.h"
+#include "MagickCore/opencl-private.h"
+#include "magickhip_shim.h"
 
-/* ------------------------------------------------------------ the library */
-typedef struct _HipLibrary
-{
-  void *handle;
-  MhStatus (*Initialize)(void);
-  void (*InitImage)(MhImage *,void *,size_t,size_t,uint32_t,int,MhQuantumKind,MhMemoryKind);
-  MhStatus (*BlurImage)(const MhImage *,MhImage *,double,double);
-  MhStatus (*UnsharpMaskImage)(const MhImage *,MhImage *,double,double,double,double);
-  MhStatus (*ResizeImageWithFilter)(const MhImage *,MhImage *,const MhResizeFilter *);
-  MhResizeFilter *(*AcquireResizeFilterFromCallback)(MhResizeWeightFunction,void *,double);
-  MhResizeFilter *(*DestroyResizeFilter)(MhResizeFilter *);
-  MhStatus (*ContrastStretchImage)(MhImage *,double,double,int *);
-  MhStatus (*EqualizeImage)(MhImage *);
-  int (*GetEnabled)(void);
-} HipLibrary;
-
-static HipLibrary hip_library;
-static volatile int hip_library_state=0;      /* 0 = untried, 1 = ready, -1 = unavailable */
 static size_t hip_accelerated_calls=0;        /* read by tests through GetMagickHipAcceleratedCalls */
-
-static void *Resolve(void *handle,const char *name,int *missing)
-{
-  void *symbol=dlsym(handle,name);
-  if (symbol == NULL)
-    (*missing)++;
-  return(symbol);
-}
-
-static HipLibrary *AcquireHipLibrary(void)
-{
-  const char
-    *path;
-
-  int
-    missing;
-
-  if (hip_library_state > 0)
-    return(hip_library.GetEnabled() != 0 ? &hip_library : (HipLibrary *) NULL);
-  if (hip_library_state < 0)
-    return((HipLibrary *) NULL);
-  path=getenv("MAGICK_HIP_LIBRARY");
-  if (path == (const char *) NULL)
-    path="libmagickhip.so";
-  hip_library.handle=dlopen(path,RTLD_NOW | RTLD_LOCAL);
-  if (hip_library.handle == NULL)
-    {
-      hip_library_state=(-1);
-      return((HipLibrary *) NULL);
-    }
-  missing=0;
-  *(void **) &hip_library.Initialize=Resolve(hip_library.handle,"MhInitialize",&missing);
-  *(void **) &hip_library.InitImage=Resolve(hip_library.handle,"MhInitImage",&missing);
-  *(void **) &hip_library.BlurImage=Resolve(hip_library.handle,"MagickHipBlurImage",&missing);
-  *(void **) &hip_library.UnsharpMaskImage=Resolve(hip_library.handle,
-    "MagickHipUnsharpMaskImage",&missing);
-  *(void **) &hip_library.ResizeImageWithFilter=Resolve(hip_library.handle,
-    "MagickHipResizeImageWithFilter",&missing);
-  *(void **) &hip_library.AcquireResizeFilterFromCallback=Resolve(hip_library.handle,
-    "MhAcquireResizeFilterFromCallback",&missing);
-  *(void **) &hip_library.DestroyResizeFilter=Resolve(hip_library.handle,
-    "MhDestroyResizeFilter",&missing);
-  *(void **) &hip_library.ContrastStretchImage=Resolve(hip_library.handle,
-    "MagickHipContrastStretchImage",&missing);
-  *(void **) &hip_library.EqualizeImage=Resolve(hip_library.handle,"MagickHipEqualizeImage",
-    &missing);
-  *(void **) &hip_library.GetEnabled=Resolve(hip_library.handle,"MhGetEnabled",&missing);
-  if ((missing != 0) || (hip_library.Initialize() != MH_OK))
-    {
-      hip_library_state=(-1);
-      return((HipLibrary *) NULL);
-    }
-  hip_library_state=1;
-  return(hip_library.GetEnabled() != 0 ? &hip_library : (HipLibrary *) NULL);
-}
 
 MagickExport size_t GetMagickHipAcceleratedCalls(void)
 {
@@ -164,10 +98,10 @@ static MagickBooleanType IsImageAcceleratable(const Image *image)
 }
 
 /*
-  The pixel-cache heap block of an image (what GetAuthenticOpenCLBuffer wraps
-  in a cl_mem, cache.c:1259-1291): a private, materialised memory cache.
+  The pixel cache of an image as a private, materialised memory cache (what
+  GetAuthenticOpenCLBuffer requires, cache.c:1259-1291).
 */
-static Quantum *AcquireHeapPixels(const Image *image,ExceptionInfo *exception)
+static CacheInfo *AcquireHeapCache(const Image *image,ExceptionInfo *exception)
 {
   CacheInfo
     *cache_info;
@@ -176,31 +110,97 @@ static Quantum *AcquireHeapPixels(const Image *image,ExceptionInfo *exception)
   if ((cache_info->type == UndefinedCache) || (cache_info->reference_count > 1))
     {
       if (SyncImagePixelCache((Image *) image,exception) == MagickFalse)
-        return((Quantum *) NULL);
+        return((CacheInfo *) NULL);
       cache_info=(CacheInfo *) image->cache;
     }
-  if ((cache_info->type != MemoryCache) || (cache_info->mapped != MagickFalse))
-    return((Quantum *) NULL);
-  return(cache_info->pixels);
+  if ((cache_info->type != MemoryCache) || (cache_info->mapped != MagickFalse) ||
+      (cache_info->pixels == (Quantum *) NULL))
+    return((CacheInfo *) NULL);
+  return(cache_info);
+}
+
+/*
+  The device copy of an image's pixels.  upload != 0: an operator input — reuse the
+  resident copy, or allocate one and upload the host block (once).  upload == 0: an
+  operator result — allocate only; the host block is stale until the cache hooks
+  download it (record marked dirty).
+*/
+static void *AcquireDevicePixels(HipLibrary *library,const Image *image,const int upload,
+  ExceptionInfo *exception)
+{
+  CacheInfo
+    *cache_info;
+
+  MagickCLCacheInfo
+    info;
+
+  void
+    *device_pixels;
+
+  cache_info=AcquireHeapCache(image,exception);
+  if (cache_info == (CacheInfo *) NULL)
+    return(NULL);
+  LockSemaphoreInfo(cache_info->semaphore);
+  info=cache_info->opencl;
+  if (info != (MagickCLCacheInfo) NULL)
+    {
+      UnlockSemaphoreInfo(cache_info->semaphore);
+      return((void *) info->buffer);            /* resident: no transfer */
+    }
+  device_pixels=NULL;
+  if (library->DeviceAlloc(-1,(size_t) cache_info->length,&device_pixels) != MH_OK)
+    {
+      UnlockSemaphoreInfo(cache_info->semaphore);
+      return(NULL);
+    }
+  if (upload != 0)
+    {
+      if (library->Upload(-1,device_pixels,cache_info->pixels,(size_t) cache_info->length,
+            NULL) != MH_OK)
+        {
+          (void) library->DeviceFree(-1,device_pixels);
+          UnlockSemaphoreInfo(cache_info->semaphore);
+          return(NULL);
+        }
+      CountHipTransfer(1);
+    }
+  info=(MagickCLCacheInfo) AcquireCriticalMemory(sizeof(*info));
+  (void) memset(info,0,sizeof(*info));
+  info->buffer=(cl_mem) device_pixels;
+  info->pixels=cache_info->pixels;
+  info->length=cache_info->length;
+  info->event_count=upload != 0 ? 0U : 1U;      /* dirty: the device copy is the newer one */
+  cache_info->opencl=info;
+  UnlockSemaphoreInfo(cache_info->semaphore);
+  return(device_pixels);
+}
+
+static void MarkDeviceCopyNewer(const Image *image)
+{
+  CacheInfo *cache_info=(CacheInfo *) image->cache;
+  if (cache_info->opencl != (MagickCLCacheInfo) NULL)
+    cache_info->opencl->event_count=1U;
 }
 
 static MagickBooleanType DescribeImage(HipLibrary *library,const Image *image,
-  Quantum *pixels,MhImage *description)
+  void *device_pixels,MhImage *description)
 {
   ssize_t
     i;
 
-  library->InitImage(description,pixels,image->columns,image->rows,
+#if (MAGICKCORE_QUANTUM_DEPTH != 16)
+  return(MagickFalse);
+#endif
+  library->InitImage(description,device_pixels,image->columns,image->rows,
     (uint32_t) image->number_channels,image->alpha_trait != UndefinedPixelTrait ? 1 : 0,
 #if defined(MAGICKCORE_HDRI_SUPPORT)
     MH_QUANTUM_F32,
 #else
     MH_QUANTUM_U16,
 #endif
-    MH_MEMORY_HOST);
-#if (MAGICKCORE_QUANTUM_DEPTH != 16)
-  return(MagickFalse);
-#endif
+    MH_MEMORY_DEVICE);
+  description->device=(-1);
+  description->stream=NULL;                    /* the device's null stream, like the transfers */
   for (i=0; i < (ssize_t) image->number_channels; i++)
   {
     PixelChannel channel = GetPixelChannelChannel(image,i);
@@ -216,9 +216,9 @@ static MagickBooleanType DescribeImage(HipLibrary *library,const Image *image,
   return(MagickTrue);
 }
 
-/* A new image of the given size whose cache is a fresh heap block. */
-static Image *AcquireResultImage(const Image *image,const size_t columns,
-  const size_t rows,Quantum **pixels,ExceptionInfo *exception)
+/* A new image of the given size whose pixels live on the device (host block allocated, stale). */
+static Image *AcquireResultImage(HipLibrary *library,const Image *image,const size_t columns,
+  const size_t rows,void **device_pixels,ExceptionInfo *exception)
 {
   Image
     *result;
@@ -228,8 +228,8 @@ static Image *AcquireResultImage(const Image *image,const size_t columns,
     return((Image *) NULL);
   if (SetImageStorageClass(result,DirectClass,exception) == MagickFalse)
     return(DestroyImage(result));
-  *pixels=AcquireHeapPixels(result,exception);
-  if (*pixels == (Quantum *) NULL)
+  *device_pixels=AcquireDevicePixels(library,result,0,exception);
+  if (*device_pixels == NULL)
     return(DestroyImage(result));
   return(result);
 }
@@ -248,7 +248,7 @@ MagickPrivate Image *AccelerateBlurImage(const Image *image,const double radius,
     source,
     destination;
 
-  Quantum
+  void
     *p,
     *q;
 
@@ -259,10 +259,10 @@ MagickPrivate Image *AccelerateBlurImage(const Image *image,const double radius,
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
     return((Image *) NULL);
-  p=AcquireHeapPixels(image,exception);
-  if (p == (Quantum *) NULL)
+  p=AcquireDevicePixels(library,image,1,exception);
+  if (p == NULL)
     return((Image *) NULL);
-  blur_image=AcquireResultImage(image,image->columns,image->rows,&q,exception);
+  blur_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
   if (blur_image == (Image *) NULL)
     return((Image *) NULL);
   if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
@@ -288,7 +288,7 @@ MagickPrivate Image *AccelerateUnsharpMaskImage(const Image *image,
     source,
     destination;
 
-  Quantum
+  void
     *p,
     *q;
 
@@ -297,10 +297,10 @@ MagickPrivate Image *AccelerateUnsharpMaskImage(const Image *image,
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
     return((Image *) NULL);
-  p=AcquireHeapPixels(image,exception);
-  if (p == (Quantum *) NULL)
+  p=AcquireDevicePixels(library,image,1,exception);
+  if (p == NULL)
     return((Image *) NULL);
-  unsharp_image=AcquireResultImage(image,image->columns,image->rows,&q,exception);
+  unsharp_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
   if (unsharp_image == (Image *) NULL)
     return((Image *) NULL);
   if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
@@ -337,7 +337,7 @@ MagickPrivate Image *AccelerateResizeImage(const Image *image,
   MhStatus
     status;
 
-  Quantum
+  void
     *p,
     *q;
 
@@ -346,10 +346,10 @@ MagickPrivate Image *AccelerateResizeImage(const Image *image,
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
     return((Image *) NULL);
-  p=AcquireHeapPixels(image,exception);
-  if (p == (Quantum *) NULL)
+  p=AcquireDevicePixels(library,image,1,exception);
+  if (p == NULL)
     return((Image *) NULL);
-  resize_image=AcquireResultImage(image,resizedColumns,resizedRows,&q,exception);
+  resize_image=AcquireResultImage(library,image,resizedColumns,resizedRows,&q,exception);
   if (resize_image == (Image *) NULL)
     return((Image *) NULL);
   /* the weights are the reference's own: expert filter:* artifacts included */
@@ -378,7 +378,7 @@ MagickPrivate MagickBooleanType AccelerateEqualizeImage(Image *image,
   MhImage
     description;
 
-  Quantum
+  void
     *q;
 
   if (IsImageAcceleratable(image) == MagickFalse)
@@ -386,11 +386,12 @@ MagickPrivate MagickBooleanType AccelerateEqualizeImage(Image *image,
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
     return(MagickFalse);
-  q=AcquireHeapPixels(image,exception);
-  if ((q == (Quantum *) NULL) ||
+  q=AcquireDevicePixels(library,image,1,exception);
+  if ((q == NULL) ||
       (DescribeImage(library,image,q,&description) == MagickFalse) ||
       (library->EqualizeImage(&description) != MH_OK))
     return(MagickFalse);
+  MarkDeviceCopyNewer(image);
   hip_accelerated_calls++;
   return(MagickTrue);
 }
@@ -407,7 +408,7 @@ MagickPrivate MagickBooleanType AccelerateContrastStretchImage(Image *image,
   MhImage
     description;
 
-  Quantum
+  void
     *q;
 
   if (IsImageAcceleratable(image) == MagickFalse)
@@ -415,12 +416,13 @@ MagickPrivate MagickBooleanType AccelerateContrastStretchImage(Image *image,
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
     return(MagickFalse);
-  q=AcquireHeapPixels(image,exception);
+  q=AcquireDevicePixels(library,image,1,exception);
   became_gray=0;
-  if ((q == (Quantum *) NULL) ||
+  if ((q == NULL) ||
       (DescribeImage(library,image,q,&description) == MagickFalse) ||
       (library->ContrastStretchImage(&description,black_point,white_point,&became_gray) != MH_OK))
     return(MagickFalse);
+  MarkDeviceCopyNewer(image);
   if (became_gray != 0)              /* IdentifyImageType side effect, enhance.c:1586-1588 */
     (void) SetImageColorspace(image,GRAYColorspace,exception);
   hip_accelerated_calls++;

@@ -1,0 +1,39 @@
+/*
+  Shared between shim/accelerate_hip.c and shim/opencl_hip.c: the dlopen'ed
+  libmagickhip.so entry points and the device-residency record kept in
+  CacheInfo::opencl.
+*/
+#ifndef MAGICKHIP_SHIM_H
+#define MAGICKHIP_SHIM_H
+
+#include "magickhip.h"
+
+typedef struct _HipLibrary
+{
+  void *handle;
+  MhStatus (*Initialize)(void);
+  void (*Terminus)(void);
+  int (*GetEnabled)(void);
+  int (*SetEnabled)(int);
+  void (*InitImage)(MhImage *,void *,size_t,size_t,uint32_t,int,MhQuantumKind,MhMemoryKind);
+  MhStatus (*DeviceAlloc)(int,size_t,void **);
+  MhStatus (*DeviceFree)(int,void *);
+  MhStatus (*Upload)(int,void *,const void *,size_t,void *);
+  MhStatus (*Download)(int,void *,const void *,size_t,void *);
+  MhStatus (*Synchronize)(int,void *);
+  MhStatus (*BlurImage)(const MhImage *,MhImage *,double,double);
+  MhStatus (*UnsharpMaskImage)(const MhImage *,MhImage *,double,double,double,double);
+  MhStatus (*ResizeImageWithFilter)(const MhImage *,MhImage *,const MhResizeFilter *);
+  MhResizeFilter *(*AcquireResizeFilterFromCallback)(MhResizeWeightFunction,void *,double);
+  MhResizeFilter *(*DestroyResizeFilter)(MhResizeFilter *);
+  MhStatus (*ContrastStretchImage)(MhImage *,double,double,int *);
+  MhStatus (*EqualizeImage)(MhImage *);
+} HipLibrary;
+
+/* NULL when the library, a GPU or the enable switch is missing: the caller runs the CPU path */
+extern MagickPrivate HipLibrary *AcquireHipLibrary(void);
+
+/* transfer counters, for tests (uploads / downloads of whole pixel caches) */
+extern MagickPrivate void CountHipTransfer(int upload);
+
+#endif

@@ -10,14 +10,27 @@
     public API        GetOpenCLEnabled / SetOpenCLEnabled / GetOpenCLDevices ...
                       (MagickCore/opencl.h:46-72)
 
-  The HIP backend keeps no device-side state inside the pixel cache (every
-  Accelerate*Image() call stages the heap block and synchronises before it
-  returns), so CacheInfo::opencl is never set and the four cache hooks are
-  unreachable stubs.  The enable switch is forwarded to libmagickhip.so; the
-  device list is empty (devices are chosen inside the library).
+  Device residency.  The reference keeps an image on the device across chained
+  operators by hanging a MagickCLCacheInfo off CacheInfo::opencl and calling
+  CopyMagickCLCacheInfo() from every CPU access path (CopyOpenCLBuffer,
+  cache.c:5341; call sites cache.c:1711, :2772, :4080, cache-view.c:160).  This
+  file re-creates that protocol for HIP: accelerate_hip.c attaches a record
+  { device pointer, host pixels, length, dirty } to the pixel cache of operator
+  inputs (uploaded once) and results (NOT downloaded), and the hooks below bring
+  the host block up to date the first time the CPU looks at the pixels:
+
+    CopyMagickCLCacheInfo        dirty ? download : nothing; free the device copy
+    RelinquishMagickCLCacheInfo  free the device copy (and the host block when
+                                 asked: the cache is being destroyed)
+
+  so  BlurImage -> ResizeImage -> EqualizeImage  pays PCIe once each way.
+  The record re-uses the reference's struct (opencl-private.h:42-64): `buffer`
+  holds the device pointer, `event_count` the dirty flag; no cl_* call is made.
 */
 #include "MagickCore/studio.h"
 #include "MagickCore/exception.h"
+#include "MagickCore/memory_.h"
+#include "MagickCore/memory-private.h"
 #include "MagickCore/opencl.h"
 #include "MagickCore/opencl-private.h"
 
@@ -25,25 +38,96 @@
 
 #include <dlfcn.h>
 #include <stdlib.h>
+#include "magickhip_shim.h"
 
+static HipLibrary hip_library;
+static volatile int hip_library_state=0;      /* 0 = untried, 1 = ready, -1 = unavailable */
 static MagickBooleanType hip_enabled = MagickTrue;
+static size_t hip_uploads=0,hip_downloads=0;
 
-static void ForwardEnabled(const MagickBooleanType value)
+static void *Resolve(void *handle,const char *name,int *missing)
 {
-  int (*set_enabled)(int);
-  void *handle;
-  const char *path=getenv("MAGICK_HIP_LIBRARY");
+  void *symbol=dlsym(handle,name);
+  if (symbol == NULL)
+    (*missing)++;
+  return(symbol);
+}
 
-  handle=dlopen(path != (const char *) NULL ? path : "libmagickhip.so",RTLD_NOW | RTLD_NOLOAD);
-  if (handle == NULL)
-    return;
-  *(void **) &set_enabled=dlsym(handle,"MhSetEnabled");
-  if (set_enabled != NULL)
-    (void) set_enabled(value != MagickFalse ? 1 : 0);
-  (void) dlclose(handle);
+MagickPrivate HipLibrary *AcquireHipLibrary(void)
+{
+  const char
+    *path;
+
+  int
+    missing;
+
+  if (hip_enabled == MagickFalse)
+    return((HipLibrary *) NULL);
+  if (hip_library_state > 0)
+    return(hip_library.GetEnabled() != 0 ? &hip_library : (HipLibrary *) NULL);
+  if (hip_library_state < 0)
+    return((HipLibrary *) NULL);
+  path=getenv("MAGICK_HIP_LIBRARY");
+  if (path == (const char *) NULL)
+    path="libmagickhip.so";
+  hip_library.handle=dlopen(path,RTLD_NOW | RTLD_LOCAL);
+  if (hip_library.handle == NULL)
+    {
+      hip_library_state=(-1);
+      return((HipLibrary *) NULL);
+    }
+  missing=0;
+#define MH_RESOLVE(field,name) *(void **) &hip_library.field=Resolve(hip_library.handle,name,&missing)
+  MH_RESOLVE(Initialize,"MhInitialize");
+  MH_RESOLVE(Terminus,"MhTerminus");
+  MH_RESOLVE(GetEnabled,"MhGetEnabled");
+  MH_RESOLVE(SetEnabled,"MhSetEnabled");
+  MH_RESOLVE(InitImage,"MhInitImage");
+  MH_RESOLVE(DeviceAlloc,"MhDeviceAlloc");
+  MH_RESOLVE(DeviceFree,"MhDeviceFree");
+  MH_RESOLVE(Upload,"MhUpload");
+  MH_RESOLVE(Download,"MhDownload");
+  MH_RESOLVE(Synchronize,"MhSynchronize");
+  MH_RESOLVE(BlurImage,"MagickHipBlurImage");
+  MH_RESOLVE(UnsharpMaskImage,"MagickHipUnsharpMaskImage");
+  MH_RESOLVE(ResizeImageWithFilter,"MagickHipResizeImageWithFilter");
+  MH_RESOLVE(AcquireResizeFilterFromCallback,"MhAcquireResizeFilterFromCallback");
+  MH_RESOLVE(DestroyResizeFilter,"MhDestroyResizeFilter");
+  MH_RESOLVE(ContrastStretchImage,"MagickHipContrastStretchImage");
+  MH_RESOLVE(EqualizeImage,"MagickHipEqualizeImage");
+#undef MH_RESOLVE
+  if ((missing != 0) || (hip_library.Initialize() != MH_OK))
+    {
+      hip_library_state=(-1);
+      return((HipLibrary *) NULL);
+    }
+  hip_library_state=1;
+  return(hip_library.GetEnabled() != 0 ? &hip_library : (HipLibrary *) NULL);
+}
+
+MagickPrivate void CountHipTransfer(int upload)
+{
+  if (upload != 0)
+    hip_uploads++;
+  else
+    hip_downloads++;
+}
+
+MagickExport void GetMagickHipTransfers(size_t *uploads,size_t *downloads)
+{
+  *uploads=hip_uploads;
+  *downloads=hip_downloads;
 }
 
 /* ------------------------------------------------------------- cache hooks */
+static void ReleaseDeviceCopy(MagickCLCacheInfo info)
+{
+  if ((info->buffer != (cl_mem) NULL) && (hip_library_state > 0))
+    (void) hip_library.DeviceFree(-1,(void *) info->buffer);
+  info->buffer=(cl_mem) NULL;
+}
+
+/* only GetAuthenticOpenCLBuffer (cache.c:1259) calls this, and nothing in this build calls that */
 MagickPrivate MagickCLCacheInfo AcquireMagickCLCacheInfo(
   MagickCLDevice magick_unused(device),Quantum *magick_unused(pixels),
   const MagickSizeType magick_unused(length))
@@ -51,14 +135,33 @@ MagickPrivate MagickCLCacheInfo AcquireMagickCLCacheInfo(
   return((MagickCLCacheInfo) NULL);
 }
 
+/*
+  The CPU is about to touch the pixels (CopyOpenCLBuffer, cache.c:5341-5353):
+  make the host block current, then drop the device copy — the CPU may write.
+*/
 MagickPrivate MagickCLCacheInfo CopyMagickCLCacheInfo(MagickCLCacheInfo info)
 {
-  return(info);
+  if (info == (MagickCLCacheInfo) NULL)
+    return((MagickCLCacheInfo) NULL);
+  if ((info->event_count != 0) && (info->buffer != (cl_mem) NULL) && (hip_library_state > 0))
+    {
+      (void) hip_library.Download(-1,(void *) info->pixels,(const void *) info->buffer,
+        (size_t) info->length,NULL);
+      (void) hip_library.Synchronize(-1,NULL);
+      CountHipTransfer(0);
+    }
+  return(RelinquishMagickCLCacheInfo(info,MagickFalse));
 }
 
-MagickPrivate MagickCLCacheInfo RelinquishMagickCLCacheInfo(
-  MagickCLCacheInfo magick_unused(info),const MagickBooleanType magick_unused(relinquish_pixels))
+MagickPrivate MagickCLCacheInfo RelinquishMagickCLCacheInfo(MagickCLCacheInfo info,
+  const MagickBooleanType relinquish_pixels)
 {
+  if (info == (MagickCLCacheInfo) NULL)
+    return((MagickCLCacheInfo) NULL);
+  ReleaseDeviceCopy(info);
+  if (relinquish_pixels != MagickFalse)
+    info->pixels=(Quantum *) RelinquishAlignedMemory(info->pixels);   /* as cache.c:985-987 would */
+  (void) RelinquishMagickMemory(info);
   return((MagickCLCacheInfo) NULL);
 }
 
@@ -68,17 +171,8 @@ MagickPrivate void RetainOpenCLMemObject(cl_mem magick_unused(memobj))
 
 MagickPrivate void OpenCLTerminus(void)
 {
-  void (*terminus)(void);
-  void *handle;
-  const char *path=getenv("MAGICK_HIP_LIBRARY");
-
-  handle=dlopen(path != (const char *) NULL ? path : "libmagickhip.so",RTLD_NOW | RTLD_NOLOAD);
-  if (handle == NULL)
-    return;
-  *(void **) &terminus=dlsym(handle,"MhTerminus");
-  if (terminus != NULL)
-    terminus();
-  (void) dlclose(handle);
+  if (hip_library_state > 0)
+    hip_library.Terminus();
 }
 
 /* -------------------------------------------------------------- public API */
@@ -90,7 +184,8 @@ MagickExport MagickBooleanType GetOpenCLEnabled(void)
 MagickExport MagickBooleanType SetOpenCLEnabled(const MagickBooleanType value)
 {
   hip_enabled=value;
-  ForwardEnabled(value);
+  if (hip_library_state > 0)
+    (void) hip_library.SetEnabled(value != MagickFalse ? 1 : 0);
   return(hip_enabled);
 }
 

@@ -58,3 +58,38 @@ def test_gate_falls_back_to_cpu(shim):
     cpu = shim.RefImage(px, "Lab")
     assert_parity(gpu.blur(0.0, 2.0).numpy(), cpu.blur(0.0, 2.0).numpy(), True, "Lab blur (CPU fallback)")
     assert accelerated_calls(shim, False) == before
+
+
+def transfers(refmod, hdri):
+    lib = refmod._load(hdri, True)
+    up, down = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    lib.GetMagickHipTransfers(ctypes.byref(up), ctypes.byref(down))
+    return up.value, down.value
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_chained_operators_stay_on_the_device(shim, dtype):
+    """BlurImage -> ResizeImage -> EqualizeImage through MagickCore: the image is uploaded
+    once, intermediate results are never downloaded, and the host pixel cache is brought up to
+    date lazily when the CPU finally reads it (the reference's CopyOpenCLBuffer protocol,
+    cache.c:5341-5353) — and the pixels still equal the CPU MagickCore's."""
+    hdri = dtype == np.float32
+    px = make_pixels(80, 100, 4, dtype, kind="smooth")
+    up0, down0 = transfers(shim, hdri)
+    g = shim.RefImage(px, shim=True)
+    blurred = g.blur(0.0, 2.5)
+    resized = blurred.resize(150, 120, "Lanczos")
+    resized.equalize()
+    assert transfers(shim, hdri) == (up0 + 1, down0), "chain must not move pixels over PCIe"
+    got = resized.numpy()                       # first CPU access: the one download
+    assert transfers(shim, hdri) == (up0 + 1, down0 + 1)
+    c = shim.RefImage(px).blur(0.0, 2.5).resize(150, 120, "Lanczos")
+    c.equalize()
+    assert_parity(got, c.numpy(), True, "blur -> resize -> equalize chain")
+    # a CPU operator in the middle of a chain sees current pixels (download), then the GPU
+    # path re-uploads: Lab is rejected by the gate, so this blur runs on the CPU
+    mixed = g.blur(0.0, 1.5)
+    mixed.colorspace("Lab")
+    ref_mixed = shim.RefImage(px).blur(0.0, 1.5)
+    ref_mixed.colorspace("Lab")
+    assert_parity(mixed.blur(0.0, 2.0).numpy(), ref_mixed.blur(0.0, 2.0).numpy(), True, "GPU -> CPU -> CPU")
