@@ -20,7 +20,7 @@ from ._lib import (MagickHipError, MhImage, COLORSPACES, MORPHOLOGY, FILTERS,  #
 
 __all__ = ["Image", "blur_image", "convolve_image", "morphology_image", "morphology_primitive",
            "unsharp_mask_image", "resize_image", "contrast_stretch_image", "equalize_image",
-           "transform_image_colorspace", "histogram", "apply_lut", "contrast_stretch_lut",
+           "transform_image_colorspace", "grayscale_image", "function_image", "histogram", "apply_lut", "contrast_stretch_lut",
            "equalize_lut", "is_image_gray", "set_precision", "get_precision", "device_count",
            "build", "load", "MagickHipError"]
 
@@ -263,6 +263,22 @@ def transform_image_colorspace(image, colorspace):
     d = image.descriptor()
     _lib.check(lib.MagickHipTransformImageColorspace(ctypes.byref(d), COLORSPACES[colorspace.lower()]))
     image.colorspace = colorspace.lower()
+    return image
+
+
+def grayscale_image(image, method="rec709luma"):
+    """GrayscaleImage(image, method), in place (first channel) — MagickCore/enhance.c:2476."""
+    lib = _lib.load()
+    _lib.check(lib.MagickHipGrayscaleImage(ctypes.byref(image.descriptor()), _lib.INTENSITY[method.lower()]))
+    return image
+
+
+def function_image(image, function, parameters):
+    """FunctionImage(image, function, parameters), in place — MagickCore/statistic.c:1069."""
+    lib = _lib.load()
+    params = (ctypes.c_double * max(1, len(parameters)))(*parameters)
+    _lib.check(lib.MagickHipFunctionImage(ctypes.byref(image.descriptor()), _lib.FUNCTIONS[function.lower()],
+                                          len(parameters), params))
     return image
 
 

@@ -42,6 +42,11 @@ FILTERS = {name: i for i, name in enumerate([
     "magickernelsharp2021"])}
 
 
+INTENSITY = {"undefined": 0, "average": 1, "brightness": 2, "lightness": 3, "ms": 4, "rec601luma": 5,
+             "rec601luminance": 6, "rec709luma": 7, "rec709luminance": 8, "rms": 9}
+FUNCTIONS = {"arcsin": 1, "arctan": 2, "polynomial": 3, "sinusoid": 4}
+
+
 class MagickHipError(RuntimeError):
     def __init__(self, status, message):
         super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), message))
@@ -150,6 +155,9 @@ PROTOTYPES = [
                                                      ctypes.c_double, _P(ctypes.c_int)]),
     ("MagickHipEqualizeImage", ctypes.c_int, [_P(MhImage)]),
     ("MagickHipTransformImageColorspace", ctypes.c_int, [_P(MhImage), ctypes.c_int]),
+    ("MagickHipGrayscaleImage", ctypes.c_int, [_P(MhImage), ctypes.c_int]),
+    ("MagickHipFunctionImage", ctypes.c_int, [_P(MhImage), ctypes.c_int, ctypes.c_size_t,
+                                              _P(ctypes.c_double)]),
     ("MagickHipHistogram", ctypes.c_int, [_P(MhImage), ctypes.c_int, ctypes.c_void_p]),
     ("MhContrastStretchLUT", ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t,
                                             ctypes.c_size_t, ctypes.c_double, ctypes.c_double,

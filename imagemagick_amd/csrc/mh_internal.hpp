@@ -167,5 +167,7 @@ MhStatus launch_apply_lut(const View &img,const void *lut_device,uint32_t apply_
 MhStatus launch_gray_check(const View &img,const MhImage *desc,unsigned int *flag_device);
 MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,const MhImage *desc);
 MhStatus launch_copy(const View &src,const View &dst);
+MhStatus launch_grayscale(const View &img,int method,const MhImage *desc);
+MhStatus launch_function(const View &img,int function,size_t count,const double *parameters,uint32_t update_mask);
 
 } // namespace mh

@@ -373,4 +373,33 @@ MH_API MhStatus MagickHipTransformImageColorspace(MhImage *image,MhColorspace co
   return MH_OK;
 }
 
+// GrayscaleImage, enhance.c:2476-2660
+MH_API MhStatus MagickHipGrayscaleImage(MhImage *image,MhIntensityMethod method)
+{
+  MH_TRY(check_image(image,"GrayscaleImage"));
+  InPlace io;
+  MH_TRY(io.open(image));
+  MH_TRY(launch_grayscale(io.img.view,(int) method,image));
+  return io.img.commit();
+}
+
+// FunctionImage, statistic.c:1069-1160
+MH_API MhStatus MagickHipFunctionImage(MhImage *image,MhFunction function,
+  size_t number_parameters,const double *parameters)
+{
+  MH_TRY(check_image(image,"FunctionImage"));
+  if ((number_parameters != 0) && (parameters == nullptr))
+    return fail(MH_BAD_ARGUMENT,"FunctionImage: null parameters");
+  if ((function < MH_FUNCTION_ARCSIN) || (function > MH_FUNCTION_SINUSOID))
+    return fail(MH_BAD_ARGUMENT,"FunctionImage: unknown function %d",(int) function);
+  uint32_t update=0;
+  for (uint32_t c=0; c < image->number_channels; c++)
+    if ((image->channel_traits[c] & MH_TRAIT_UPDATE) != 0)
+      update|=1u<<c;
+  InPlace io;
+  MH_TRY(io.open(image));
+  MH_TRY(launch_function(io.img.view,(int) function,number_parameters,parameters,update));
+  return io.img.commit();
+}
+
 } // extern "C"

@@ -774,6 +774,191 @@ MhStatus launch_apply_lut(const View &img,const void *lut,uint32_t apply_mask,co
 #undef MH_CASE
 }
 
+
+// ---------------------------------------------------------------- GrayscaleImage
+// enhance.c:2476-2660: the intensity of (R,G,B) by `method` is written to the Gray
+// (= first) channel only; the caller then switches the image to GRAY / LinearGRAY.
+// Note MS here is (r^2+g^2+b^2)/3 (:2572-2577), unlike GetPixelIntensity's MS.
+template<typename Q,int C>
+__global__ __launch_bounds__(256)
+void grayscale_kernel(Q *pixels,size_t npixels,int method,int is_rgb,int is_srgb)
+{
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
+    {
+      Q q[C];
+      load_pixel<Q,C>(pixels+i*C,q);
+      double red=(double) q[0],green=(double) q[C >= 3 ? 1 : 0],blue=(double) q[C >= 3 ? 2 : 0];
+      double intensity=0.0;
+      switch (method)
+      {
+        case MH_INTENSITY_AVERAGE: intensity=(red+green+blue)/3.0; break;
+        case MH_INTENSITY_BRIGHTNESS:
+        {
+          double m=red > green ? red : green;
+          intensity=m > blue ? m : blue;
+          break;
+        }
+        case MH_INTENSITY_LIGHTNESS:
+        {
+          double mn=red < green ? red : green;
+          mn=mn < blue ? mn : blue;
+          double mx=red > green ? red : green;
+          mx=mx > blue ? mx : blue;
+          intensity=(mn+mx)/2.0;
+          break;
+        }
+        case MH_INTENSITY_MS: intensity=(red*red+green*green+blue*blue)/3.0; break;
+        case MH_INTENSITY_RMS: intensity=sqrt(red*red+green*green+blue*blue)/sqrt(3.0); break;
+        case MH_INTENSITY_REC601LUMA:
+        case MH_INTENSITY_REC601LUMINANCE:
+        {
+          if ((method == MH_INTENSITY_REC601LUMA) ? is_rgb : is_srgb)
+            {
+              if (method == MH_INTENSITY_REC601LUMA)
+                { red=encode_pixel_gamma(red); green=encode_pixel_gamma(green); blue=encode_pixel_gamma(blue); }
+              else
+                { red=decode_pixel_gamma(red); green=decode_pixel_gamma(green); blue=decode_pixel_gamma(blue); }
+            }
+          intensity=0.298839*red+0.586811*green+0.114350*blue;
+          break;
+        }
+        case MH_INTENSITY_REC709LUMINANCE:
+        {
+          if (is_srgb)
+            { red=decode_pixel_gamma(red); green=decode_pixel_gamma(green); blue=decode_pixel_gamma(blue); }
+          intensity=0.212656*red+0.715158*green+0.072186*blue;
+          break;
+        }
+        default:      // Rec709Luma
+        {
+          if (is_rgb)
+            { red=encode_pixel_gamma(red); green=encode_pixel_gamma(green); blue=encode_pixel_gamma(blue); }
+          intensity=0.212656*red+0.715158*green+0.072186*blue;
+          break;
+        }
+      }
+      pixels[i*C]=QuantumOps<Q>::clamp(intensity);       // SetPixelGray: the first channel only
+    }
+}
+
+MhStatus launch_grayscale(const View &img,int method,const MhImage *desc)
+{
+  const size_t n=img.columns*img.rows;
+  const int is_rgb=desc->colorspace == MH_COLORSPACE_RGB;
+  const int is_srgb=desc->colorspace == MH_COLORSPACE_SRGB;
+  ProfileScope prof("grayscale",img.stream);
+#define MH_CASE(QT) \
+  switch (img.channels) { \
+    case 1: hipLaunchKernelGGL((grayscale_kernel<QT,1>),dim3(stream_grid(n)),dim3(256),0,img.stream,static_cast<QT *>(img.pixels),n,method,is_rgb,is_srgb); break; \
+    case 2: hipLaunchKernelGGL((grayscale_kernel<QT,2>),dim3(stream_grid(n)),dim3(256),0,img.stream,static_cast<QT *>(img.pixels),n,method,is_rgb,is_srgb); break; \
+    case 3: hipLaunchKernelGGL((grayscale_kernel<QT,3>),dim3(stream_grid(n)),dim3(256),0,img.stream,static_cast<QT *>(img.pixels),n,method,is_rgb,is_srgb); break; \
+    default: hipLaunchKernelGGL((grayscale_kernel<QT,4>),dim3(stream_grid(n)),dim3(256),0,img.stream,static_cast<QT *>(img.pixels),n,method,is_rgb,is_srgb); break; }
+  if (img.quantum == MH_QUANTUM_U16)
+    { MH_CASE(uint16_t) }
+  else
+    { MH_CASE(float) }
+#undef MH_CASE
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+// ----------------------------------------------------------------- FunctionImage
+// ApplyFunction, statistic.c:975-1067, on every channel selected by `mask`.
+struct FunctionParams
+{
+  int function;               // MhFunction
+  int count;
+  double p[8];
+};
+
+template<typename Q,int C>
+__global__ __launch_bounds__(256)
+void function_kernel(Q *pixels,size_t npixels,FunctionParams fp,uint32_t mask)
+{
+  const double kPi=3.14159265358979323846264338327950288419716939937510;
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
+    {
+      Q q[C];
+      load_pixel<Q,C>(pixels+i*C,q);
+#pragma unroll
+      for (int c=0; c < C; c++)
+        {
+          if (((mask >> c) & 1u) == 0)
+            continue;
+          const double pixel=(double) q[c];
+          double result=0.0;
+          switch (fp.function)
+          {
+            case MH_FUNCTION_POLYNOMIAL:
+              for (int k=0; k < fp.count; k++)
+                result=result*kQS*pixel+fp.p[k];
+              result*=kQR;
+              break;
+            case MH_FUNCTION_SINUSOID:
+            {
+              double frequency=fp.count >= 1 ? fp.p[0] : 1.0,phase=fp.count >= 2 ? fp.p[1] : 0.0;
+              double amplitude=fp.count >= 3 ? fp.p[2] : 0.5,bias=fp.count >= 4 ? fp.p[3] : 0.5;
+              result=kQR*(amplitude*sin(2.0*kPi*(frequency*kQS*pixel+phase/360.0))+bias);
+              break;
+            }
+            case MH_FUNCTION_ARCSIN:
+            {
+              double width=fp.count >= 1 ? fp.p[0] : 1.0,center=fp.count >= 2 ? fp.p[1] : 0.5;
+              double range=fp.count >= 3 ? fp.p[2] : 1.0,bias=fp.count >= 4 ? fp.p[3] : 0.5;
+              result=2.0*perceptible_reciprocal(width)*(kQS*pixel-center);
+              if (result <= -1.0)
+                result=bias-range/2.0;
+              else if (result >= 1.0)
+                result=bias+range/2.0;
+              else
+                result=range/kPi*asin(result)+bias;
+              result*=kQR;
+              break;
+            }
+            case MH_FUNCTION_ARCTAN:
+            {
+              double slope=fp.count >= 1 ? fp.p[0] : 1.0,center=fp.count >= 2 ? fp.p[1] : 0.5;
+              double range=fp.count >= 3 ? fp.p[2] : 1.0,bias=fp.count >= 4 ? fp.p[3] : 0.5;
+              result=kPi*slope*(kQS*pixel-center);
+              result=kQR*(range/kPi*atan(result)+bias);
+              break;
+            }
+            default: break;
+          }
+          q[c]=QuantumOps<Q>::clamp(result);
+        }
+      store_pixel<Q,C>(pixels+i*C,q);
+    }
+}
+
+MhStatus launch_function(const View &img,int function,size_t count,const double *parameters,uint32_t mask)
+{
+  if (count > 8)
+    return fail(MH_UNSUPPORTED,"FunctionImage: more than 8 parameters");
+  FunctionParams fp;
+  fp.function=function;
+  fp.count=(int) count;
+  for (int k=0; k < 8; k++)
+    fp.p[k]=k < (int) count ? parameters[k] : 0.0;
+  const size_t n=img.columns*img.rows;
+  ProfileScope prof("function",img.stream);
+#define MH_CASE(QT) \
+  switch (img.channels) { \
+    case 1: hipLaunchKernelGGL((function_kernel<QT,1>),dim3(stream_grid(n)),dim3(256),0,img.stream,static_cast<QT *>(img.pixels),n,fp,mask); break; \
+    case 2: hipLaunchKernelGGL((function_kernel<QT,2>),dim3(stream_grid(n)),dim3(256),0,img.stream,static_cast<QT *>(img.pixels),n,fp,mask); break; \
+    case 3: hipLaunchKernelGGL((function_kernel<QT,3>),dim3(stream_grid(n)),dim3(256),0,img.stream,static_cast<QT *>(img.pixels),n,fp,mask); break; \
+    default: hipLaunchKernelGGL((function_kernel<QT,4>),dim3(stream_grid(n)),dim3(256),0,img.stream,static_cast<QT *>(img.pixels),n,fp,mask); break; }
+  if (img.quantum == MH_QUANTUM_U16)
+    { MH_CASE(uint16_t) }
+  else
+    { MH_CASE(float) }
+#undef MH_CASE
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 // ---------------------------------------------------------------- gray scan
 template<typename Q,int C>
 __global__ __launch_bounds__(256)

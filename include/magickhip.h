@@ -13,6 +13,8 @@
     AccelerateUnsharpMaskImage                    MagickCore/accelerate-private.h:46-47
     AccelerateContrastStretchImage                MagickCore/accelerate-private.h:52-53
     AccelerateEqualizeImage                       MagickCore/accelerate-private.h:54
+    AccelerateFunctionImage                       MagickCore/accelerate-private.h:56-57
+    AccelerateGrayscaleImage                      MagickCore/accelerate-private.h:58-59
     (new) convolve / morphology hook              MagickCore/morphology.c:3937, :4219
     (new) colourspace hook                        MagickCore/colorspace.c:1751
     checkAccelerateCondition (the gate)           MagickCore/accelerate.c:110-170
@@ -326,6 +328,26 @@ MH_API MhStatus MagickHipEqualizeImage(MhImage *image);
 /* TransformImageColorspace, colorspace.c:1751 — sRGB <-> linear RGB / Lab / XYZ.
    On success image->colorspace is updated. */
 MH_API MhStatus MagickHipTransformImageColorspace(MhImage *image,MhColorspace colorspace);
+
+/* AccelerateGrayscaleImage (accelerate-private.h:58-59): GrayscaleImage, enhance.c:2476-2660.
+   Writes the intensity to the first channel; the caller then sets the image's colourspace to
+   GRAY (LinearGRAY for the two Luminance methods) as enhance.c:2502-2510 does. */
+MH_API MhStatus MagickHipGrayscaleImage(MhImage *image,MhIntensityMethod method);
+
+/* MagickFunction, MagickCore/statistic.h:129-136 (same values) */
+typedef enum
+{
+  MH_FUNCTION_UNDEFINED = 0,
+  MH_FUNCTION_ARCSIN,
+  MH_FUNCTION_ARCTAN,
+  MH_FUNCTION_POLYNOMIAL,
+  MH_FUNCTION_SINUSOID
+} MhFunction;
+
+/* AccelerateFunctionImage (accelerate-private.h:56-57): FunctionImage / ApplyFunction,
+   statistic.c:975-1160, on every channel whose trait carries Update. */
+MH_API MhStatus MagickHipFunctionImage(MhImage *image,MhFunction function,
+  size_t number_parameters,const double *parameters);
 
 /* ---------------------------------------------------------- building blocks */
 /* Exposed so a row-sharded image (one band per GPU / per process) can run the

@@ -70,6 +70,8 @@ def _load(hdri, shim=False):
     L.ref_contrast_stretch.argtypes = [vp, dbl, dbl, pd]
     L.ref_equalize.argtypes = [vp, pd]
     L.ref_colorspace.argtypes = [vp, cp, pd]
+    L.ref_grayscale.argtypes = [vp, cp, pd]
+    L.ref_function.argtypes = [vp, cp, sz, pd, pd]
     L.ref_kernel.argtypes = [cp, ctypes.c_int, ctypes.POINTER(sz), ctypes.POINTER(sz),
                              ctypes.POINTER(ctypes.c_ssize_t), ctypes.POINTER(ctypes.c_ssize_t),
                              vp, vp]
@@ -186,6 +188,13 @@ class RefImage:
 
     def colorspace(self, name):
         return self._inplace(self.L.ref_colorspace, name.encode())
+
+    def grayscale(self, method="Rec709Luma"):
+        return self._inplace(self.L.ref_grayscale, method.encode())
+
+    def function(self, function, parameters):
+        params = (ctypes.c_double * max(1, len(parameters)))(*parameters)
+        return self._inplace(self.L.ref_function, function.encode(), len(parameters), params)
 
     def intensity(self, pixel):
         px = np.ascontiguousarray(pixel, dtype=np.float32 if self.hdri else np.uint16)

@@ -332,6 +332,35 @@ REF_API int ref_colorspace(void *handle,const char *colorspace,double *seconds)
   return(status != MagickFalse ? 0 : -1);
 }
 
+REF_API int ref_grayscale(void *handle,const char *method,double *seconds)
+{
+  MagickBooleanType status;
+  ssize_t m=ParseCommandOption(MagickPixelIntensityOptions,MagickFalse,method);
+  if (m < 0)
+    return(-1);
+  {
+    TIMED_BEGIN;
+    status=GrayscaleImage((Image *) handle,(PixelIntensityMethod) m,ref_exception);
+    TIMED_END;
+  }
+  return(status != MagickFalse ? 0 : -1);
+}
+
+REF_API int ref_function(void *handle,const char *function,size_t count,
+  const double *parameters,double *seconds)
+{
+  MagickBooleanType status;
+  ssize_t f=ParseCommandOption(MagickFunctionOptions,MagickFalse,function);
+  if (f < 0)
+    return(-1);
+  {
+    TIMED_BEGIN;
+    status=FunctionImage((Image *) handle,(MagickFunction) f,count,parameters,ref_exception);
+    TIMED_END;
+  }
+  return(status != MagickFalse ? 0 : -1);
+}
+
 /*
   Host-side builders, exposed so the product's restated builders can be
   checked value-for-value.

@@ -468,17 +468,65 @@ MagickPrivate MagickBooleanType AccelerateContrastImage(Image *magick_unused(ima
   return(MagickFalse);
 }
 
-MagickPrivate MagickBooleanType AccelerateFunctionImage(Image *magick_unused(image),
-  const MagickFunction magick_unused(function),const size_t magick_unused(number_parameters),
-  const double *magick_unused(parameters),ExceptionInfo *magick_unused(exception))
+/* In-place operator on the device copy of `image`; marks that copy as the newer one. */
+static MagickBooleanType AcquireInPlace(const Image *image,HipLibrary **library,
+  MhImage *description,ExceptionInfo *exception)
 {
-  return(MagickFalse);
+  void
+    *q;
+
+  if (IsImageAcceleratable(image) == MagickFalse)
+    return(MagickFalse);
+  *library=AcquireHipLibrary();
+  if (*library == (HipLibrary *) NULL)
+    return(MagickFalse);
+  q=AcquireDevicePixels(*library,image,1,exception);
+  if (q == NULL)
+    return(MagickFalse);
+  return(DescribeImage(*library,image,q,description));
 }
 
-MagickPrivate MagickBooleanType AccelerateGrayscaleImage(Image *magick_unused(image),
-  const PixelIntensityMethod magick_unused(method),ExceptionInfo *magick_unused(exception))
+MagickPrivate MagickBooleanType AccelerateFunctionImage(Image *image,
+  const MagickFunction function,const size_t number_parameters,
+  const double *parameters,ExceptionInfo *exception)
 {
-  return(MagickFalse);
+  HipLibrary
+    *library;
+
+  MhImage
+    description;
+
+  if ((image->storage_class != DirectClass) ||
+      (AcquireInPlace(image,&library,&description,exception) == MagickFalse))
+    return(MagickFalse);
+  /* MagickFunction and MhFunction share their values (statistic.h:129-136) */
+  if (library->FunctionImage(&description,(MhFunction) function,number_parameters,
+        parameters) != MH_OK)
+    return(MagickFalse);
+  MarkDeviceCopyNewer(image);
+  hip_accelerated_calls++;
+  return(MagickTrue);
+}
+
+MagickPrivate MagickBooleanType AccelerateGrayscaleImage(Image *image,
+  const PixelIntensityMethod method,ExceptionInfo *exception)
+{
+  HipLibrary
+    *library;
+
+  MhImage
+    description;
+
+  /* only layouts whose first three channels are R,G,B (GrayscaleImage reads all three) */
+  if ((image->number_channels < 3) ||
+      (AcquireInPlace(image,&library,&description,exception) == MagickFalse))
+    return(MagickFalse);
+  /* PixelIntensityMethod and MhIntensityMethod share their values (pixel.h) */
+  if (library->GrayscaleImage(&description,(MhIntensityMethod) method) != MH_OK)
+    return(MagickFalse);
+  MarkDeviceCopyNewer(image);
+  hip_accelerated_calls++;
+  return(MagickTrue);       /* the caller sets intensity, type and the GRAY colourspace */
 }
 
 MagickPrivate MagickBooleanType AccelerateModulateImage(Image *magick_unused(image),

@@ -28,6 +28,8 @@ typedef struct _HipLibrary
   MhResizeFilter *(*DestroyResizeFilter)(MhResizeFilter *);
   MhStatus (*ContrastStretchImage)(MhImage *,double,double,int *);
   MhStatus (*EqualizeImage)(MhImage *);
+  MhStatus (*GrayscaleImage)(MhImage *,MhIntensityMethod);
+  MhStatus (*FunctionImage)(MhImage *,MhFunction,size_t,const double *);
 } HipLibrary;
 
 /* NULL when the library, a GPU or the enable switch is missing: the caller runs the CPU path */

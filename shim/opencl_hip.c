@@ -95,6 +95,8 @@ MagickPrivate HipLibrary *AcquireHipLibrary(void)
   MH_RESOLVE(DestroyResizeFilter,"MhDestroyResizeFilter");
   MH_RESOLVE(ContrastStretchImage,"MagickHipContrastStretchImage");
   MH_RESOLVE(EqualizeImage,"MagickHipEqualizeImage");
+  MH_RESOLVE(GrayscaleImage,"MagickHipGrayscaleImage");
+  MH_RESOLVE(FunctionImage,"MagickHipFunctionImage");
 #undef MH_RESOLVE
   if ((missing != 0) || (hip_library.Initialize() != MH_OK))
     {

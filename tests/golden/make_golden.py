@@ -92,6 +92,14 @@ def reference_vectors():
             n = px.shape[0] * px.shape[1]
             out[key + "_cstretch"] = ref.RefImage(px).contrast_stretch(0.02 * n, n - 0.01 * n).numpy()
             out[key + "_equalize"] = ref.RefImage(px).equalize().numpy()
+            for fn, params in (("Polynomial", (0.3, -1.2, 1.5, 0.1)), ("Sinusoid", (3.0, 90.0, 0.4, 0.5)),
+                               ("Arcsin", (0.8, 0.45, 1.0, 0.5)), ("Arctan", (4.0, 0.5, 1.0, 0.5))):
+                out[key + "_function_" + fn] = ref.RefImage(px).function(fn, params).numpy()
+            if ch >= 3:
+                for m in ("Rec709Luma", "Rec601Luma", "Rec709Luminance", "Average", "Brightness", "Lightness",
+                          "MS", "RMS"):
+                    out[key + "_gray_" + m] = ref.RefImage(px).grayscale(m).numpy()
+                out[key + "_gray_linear_Rec709Luma"] = ref.RefImage(px, "RGB").grayscale("Rec709Luma").numpy()
             if ch >= 3:
                 for a, b in (("sRGB", "RGB"), ("RGB", "sRGB"), ("sRGB", "Lab"), ("Lab", "sRGB"),
                              ("sRGB", "XYZ"), ("XYZ", "sRGB")):

@@ -432,3 +432,34 @@ def test_blur_fast_adversarial(im, refmod, case, sigma):
     finally:
         im.set_precision(im.PRECISION_EXACT)
     assert_parity(got, ref.blur(0.0, sigma).numpy(), False, "fast blur %s sigma=%g" % (case, sigma))
+
+
+# ------------------------------------------------- GrayscaleImage / FunctionImage
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("method", ["Rec709Luma", "Rec601Luma", "Rec709Luminance", "Rec601Luminance",
+                                    "Average", "Brightness", "Lightness", "MS", "RMS"])
+@pytest.mark.parametrize("colorspace,channels", [("sRGB", 4), ("RGB", 3)])
+def test_grayscale(im, refmod, dtype, method, colorspace, channels):
+    px = make_pixels(37, 50, channels, dtype)
+    dev, ref = run_pair(im, refmod, px, colorspace=colorspace)
+    got = im.grayscale_image(dev, method).numpy()
+    want = ref.grayscale(method).numpy()          # re-laid out as gray[+alpha] by SetImageColorspace
+    assert_parity(np.ascontiguousarray(got[:, :, 0]), np.ascontiguousarray(want[:, :, 0]), True,
+                  "grayscale %s %s" % (method, colorspace))
+    if channels == 4:
+        assert np.array_equal(got[:, :, 3], want[:, :, -1])
+
+
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("function,params", [("Polynomial", (0.3, -1.2, 1.5, 0.1)), ("Polynomial", (2.0, 0.0)),
+                                             ("Sinusoid", (3.0, 90.0, 0.4, 0.5)), ("Sinusoid", (1.0,)),
+                                             ("Arcsin", (0.8, 0.45, 1.0, 0.5)), ("Arctan", (4.0, 0.5, 1.0, 0.5))])
+def test_function(im, refmod, dtype, function, params):
+    px = make_pixels(33, 47, 4, dtype)
+    dev, ref = run_pair(im, refmod, px)
+    got = im.function_image(dev, function, params).numpy()
+    want = ref.function(function, params).numpy()
+    # sin/asin/atan are the device's, not libm's: a last-bit difference of the double flips a
+    # Q16 rounding only on an exact tie; float Quantum may differ by one ULP
+    exact = function == "Polynomial"
+    assert_parity(got, want, exact, "function " + function, max_ulp=0 if exact else 1)

@@ -93,3 +93,20 @@ def test_chained_operators_stay_on_the_device(shim, dtype):
     ref_mixed = shim.RefImage(px).blur(0.0, 1.5)
     ref_mixed.colorspace("Lab")
     assert_parity(mixed.blur(0.0, 2.0).numpy(), ref_mixed.blur(0.0, 2.0).numpy(), True, "GPU -> CPU -> CPU")
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_grayscale_and_function_through_magickcore(shim, dtype):
+    """AccelerateGrayscaleImage / AccelerateFunctionImage have live call sites in the reference
+    (enhance.c:2502-2510, statistic.c:1101-1105)."""
+    hdri = dtype == np.float32
+    px = make_pixels(45, 60, 4, dtype)
+    before = accelerated_calls(shim, hdri)
+    g, c = shim.RefImage(px, shim=True), shim.RefImage(px)
+    assert_parity(g.function("Polynomial", (0.5, -0.2, 0.6)).numpy(), c.function("Polynomial", (0.5, -0.2, 0.6)).numpy(),
+                  True, "FunctionImage via MagickCore")
+    assert accelerated_calls(shim, hdri) == before + 1
+    assert_parity(g.grayscale("Rec709Luma").numpy(), c.grayscale("Rec709Luma").numpy(), True,
+                  "GrayscaleImage via MagickCore")
+    assert accelerated_calls(shim, hdri) == before + 2
+    assert g.info()["colorspace"].lower() == "gray" and g.info()["channels"] == c.info()["channels"]

@@ -189,6 +189,33 @@ def test_colorspace_matches_reference(vectors, tag, ch, a, b):
     assert_identical(R.transform_image_colorspace(px, a, b), want, "%s->%s" % (a, b))
 
 
+FUNCTION_CASES = {"Polynomial": (0.3, -1.2, 1.5, 0.1), "Sinusoid": (3.0, 90.0, 0.4, 0.5),
+                  "Arcsin": (0.8, 0.45, 1.0, 0.5), "Arctan": (4.0, 0.5, 1.0, 0.5)}
+
+
+@pytest.mark.parametrize("tag,ch", CASES)
+def test_function_image_matches_reference(vectors, tag, ch):
+    px = vectors["%s_c%d_in" % (tag, ch)]
+    for fn, params in FUNCTION_CASES.items():
+        want = vectors["%s_c%d_function_%s" % (tag, ch, fn)]
+        # sin/asin/atan come from libm on both sides here: identical
+        assert_identical(R.function_image(px, fn, params), want, "function " + fn)
+
+
+@pytest.mark.parametrize("tag,ch", [(t, c) for t, c in CASES if c >= 3])
+def test_grayscale_image_matches_reference(vectors, tag, ch):
+    px = vectors["%s_c%d_in" % (tag, ch)]
+    for m in ("Rec709Luma", "Rec601Luma", "Rec709Luminance", "Average", "Brightness", "Lightness", "MS", "RMS"):
+        want = vectors["%s_c%d_gray_%s" % (tag, ch, m)]          # re-laid out as gray[+alpha]
+        got = R.grayscale_image(px, m)
+        assert_identical(np.ascontiguousarray(got[:, :, 0]), np.ascontiguousarray(want[:, :, 0]), "gray " + m)
+        if ch == 4:
+            assert np.array_equal(got[:, :, 3], want[:, :, -1])
+    want = vectors["%s_c%d_gray_linear_Rec709Luma" % (tag, ch)]
+    got = R.grayscale_image(px, "Rec709Luma", "rgb")
+    assert_identical(np.ascontiguousarray(got[:, :, 0]), np.ascontiguousarray(want[:, :, 0]), "gray linear")
+
+
 def test_blur_taps_match_reference(vectors):
     for s, (radius, sigma) in {"blur:0x2": (0, 2.0), "blur:0x10": (0, 10.0), "blur:0x0.5": (0, 0.5),
                                "blur:4x1.5": (4.0, 1.5)}.items():
