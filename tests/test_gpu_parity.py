@@ -463,3 +463,37 @@ def test_function(im, refmod, dtype, function, params):
     # Q16 rounding only on an exact tie; float Quantum may differ by one ULP
     exact = function == "Polynomial"
     assert_parity(got, want, exact, "function " + function, max_ulp=0 if exact else 1)
+
+
+def test_operators_are_reentrant_across_threads_and_streams(im, refmod):
+    """SURVEY §8b threading: operators may be called concurrently from user threads; each call
+    here runs on its own torch stream (MhImage::stream) with its own image."""
+    import threading
+    import torch
+    jobs = []
+    for i in range(6):
+        px = make_pixels(120 + 8 * i, 150, 4, Q16, seed=100 + i)
+        jobs.append((px, refmod.RefImage(px).blur(0.0, 3.0).resize(90, 70, "Lanczos").numpy()))
+    results = [None] * len(jobs)
+    errors = []
+
+    def work(k):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                dev = im.Image(to_device(jobs[k][0]))
+                out = im.resize_image(im.blur_image(dev, 0.0, 3.0), 90, 70, "Lanczos")
+                stream.synchronize()
+                results[k] = out.numpy()
+        except Exception as exc:                      # surfaced below
+            errors.append(exc)
+
+    for _ in range(3):
+        threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for k, (_, want) in enumerate(jobs):
+            assert_parity(results[k], want, True, "thread %d" % k)
