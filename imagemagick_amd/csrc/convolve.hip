@@ -70,9 +70,13 @@ struct Accum
           {
             // gamma*pixel = (sum k*QS*alpha*p)/(sum k*QS*alpha): QuantumScale cancels, so
             // the FAST policy weights by the raw alpha quantum
+            // whole channel pairs with one packed multiply, the odd colour channel alone
+            const T alpha=MH_P(in,C-1);
 #pragma unroll
-            for (int c=0; c < C-1; c++)
-              MH_P(in,c)=A::mul(MH_P(in,C-1),MH_P(in,c));
+            for (int q2=0; q2 < (C-1)/2; q2++)
+              in.pv[q2]=in.pv[q2]*V2{alpha,alpha};
+            if constexpr (((C-1) & 1) != 0)
+              MH_P(in,C-2)=A::mul(alpha,MH_P(in,C-2));
           }
         else
           in.a=A::mul((T) kQS,MH_P(in,C-1));    // alpha=QuantumScale*GetPixelAlpha(): morphology.c:2766, :2965
@@ -1227,8 +1231,11 @@ void conv_row_tri(Conv1DArgs args)
 
   unsigned changed=0;
   const int xo=x0+lane*R;
+  // a lane's R outputs are contiguous in the row: store them two pixels (16 bytes for
+  // RGBA Q16) at a time — half the store instructions of this lane-strided pattern
+  constexpr bool kPair=((R & 1) == 0) && (C*sizeof(Q) == 8);
 #pragma unroll
-  for (int r=0; r < R; r++)
+  for (int r=0; r < R; r+=(kPair ? 2 : 1))
     {
       int x=xo+r;
       if (x < W)
@@ -1237,6 +1244,25 @@ void conv_row_tri(Conv1DArgs args)
           int ci=lane*R+r+args.shift;           // strip index of input column x
           load_pixel<Q,C>(strip+(size_t) (ci+ci/R)*C,center);
           changed+=acc.finish(r,center,args.copy_mask,out,(T) args.bias,args.changed != nullptr);
+          if constexpr (kPair)
+            {
+              if (x+1 < W)
+                {
+                  Q center1[C],out1[C];
+                  int c1=ci+1;
+                  load_pixel<Q,C>(strip+(size_t) (c1+c1/R)*C,center1);
+                  changed+=acc.finish(r+1,center1,args.copy_mask,out1,(T) args.bias,args.changed != nullptr);
+                  Q both[2*C];
+#pragma unroll
+                  for (int c=0; c < C; c++)
+                    {
+                      both[c]=out[c];
+                      both[C+c]=out1[c];
+                    }
+                  store_pixel<Q,2*C>(dst+(size_t) y*pitch+(size_t) x*C,both);
+                  continue;
+                }
+            }
           store_pixel<Q,C>(dst+(size_t) y*pitch+(size_t) x*C,out);
         }
     }
