@@ -16,6 +16,7 @@ namespace mh {
 constexpr double kEps = 1.0e-12;          // MagickEpsilon, magick-type.h:114
 constexpr double kQR = 65535.0;           // QuantumRange
 constexpr double kQS = 1.0/65535.0;       // QuantumScale, magick-type.h:119
+constexpr double kInvEps = 1.0/kEps;       // 1/MagickEpsilon, as PerceptibleReciprocal's division yields
 
 // ----------------------------------------------------------------- Quantum
 template<typename Q> struct QuantumOps;
@@ -55,10 +56,13 @@ template<> struct QuantumOps<float>
 // PerceptibleReciprocal, MagickCore/pixel-accessor.h:242-254
 static __device__ __forceinline__ double perceptible_reciprocal(double x)
 {
+  // sign/MagickEpsilon == sign*(1.0/MagickEpsilon) exactly (sign is +-1 and the quotient is
+  // folded by the compiler with IEEE rounding); written as a multiply so that the select does
+  // not evaluate a second fp64 division sequence per pixel
   double sign=x < 0.0 ? -1.0 : 1.0;
   if ((sign*x) >= kEps)
     return 1.0/x;
-  return sign/kEps;
+  return sign*kInvEps;
 }
 
 // 1/x to ~1 ulp without the IEEE division sequence (v_rcp_f64 + two Newton steps);
@@ -67,7 +71,7 @@ static __device__ __forceinline__ double perceptible_reciprocal_fast(double x)
 {
   double sign=x < 0.0 ? -1.0 : 1.0;
   if ((sign*x) < kEps)
-    return sign/kEps;
+    return sign*kInvEps;
   double r=__builtin_amdgcn_rcp(x);
   double e=__builtin_fma(-x,r,1.0);
   r=__builtin_fma(r,e,r);
