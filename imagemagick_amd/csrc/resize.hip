@@ -954,7 +954,10 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
           if ((size_t) lds_span*cpx <= 150u*1024u)
             {
               int tile_rows=(int) (budget/((size_t) lds_span*cpx));
-              tile_rows=tile_rows < 1 ? 1 : (tile_rows > 16 ? 16 : tile_rows);
+              int cap=16;
+              if (const char *e=getenv("MAGICKHIP_HTILE"))
+                cap=atoi(e);
+              tile_rows=tile_rows < 1 ? 1 : (tile_rows > cap ? cap : tile_rows);
               size_t lds=(size_t) lds_span*cpx*(size_t) tile_rows;
               dim3 grid((unsigned) ((dst.columns+255)/256),(unsigned) ((dst.rows+tile_rows-1)/tile_rows));
               ProfileScope prof("resize_horizontal",src.stream);
