@@ -245,7 +245,8 @@ def main():
 
 
 def timed(torch, fn, reps):
-    fn()
+    fn()            # two warm-up calls: the result of call n is released only after call n+1
+    fn()            # allocated its own, so the caching allocator needs two blocks before it is warm
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):

@@ -376,7 +376,6 @@ MH_API MhStatus MagickHipResizeImageWithFilter(const MhImage *image,MhImage *res
   Roles roles=channel_roles(image,resize_image);
   View filter_view=pair.src.view;
   Temp scratch;
-  TapTable horizontal,vertical;
   if (x_factor > y_factor)
     {
       // HorizontalFilter then VerticalFilter, resize.c:3846-3853
@@ -384,25 +383,25 @@ MH_API MhStatus MagickHipResizeImageWithFilter(const MhImage *image,MhImage *res
       filter_view.rows=image->rows;
       MH_TRY(scratch.alloc(pair.src.view.device,filter_view.bytes(),pair.src.view.stream));
       filter_view.pixels=scratch.ptr;
-      build_tap_table(horizontal,filter,image->columns,columns,x_factor);
-      build_tap_table(vertical,filter,image->rows,rows,y_factor);
-      MH_TRY(launch_resize_pass(pair.src.view,filter_view,false,horizontal,roles,precision()));
-      MH_TRY(launch_resize_pass(filter_view,pair.dst.view,true,vertical,roles,precision()));
+      auto horizontal=acquire_tap_table(filter,image->columns,columns,x_factor);
+      auto vertical=acquire_tap_table(filter,image->rows,rows,y_factor);
+      MH_TRY(launch_resize_pass(pair.src.view,filter_view,false,*horizontal,roles,precision()));
+      MH_TRY(launch_resize_pass(filter_view,pair.dst.view,true,*vertical,roles,precision()));
     }
   else
     {
-      build_tap_table(vertical,filter,image->rows,rows,y_factor);
-      build_tap_table(horizontal,filter,image->columns,columns,x_factor);
+      auto vertical=acquire_tap_table(filter,image->rows,rows,y_factor);
+      auto horizontal=acquire_tap_table(filter,image->columns,columns,x_factor);
       bool fused=false;
-      MH_TRY(launch_resize_fused(pair.src.view,pair.dst.view,vertical,horizontal,roles,precision(),&fused));
+      MH_TRY(launch_resize_fused(pair.src.view,pair.dst.view,*vertical,*horizontal,roles,precision(),&fused));
       if (!fused)
         {
           filter_view.columns=image->columns;
           filter_view.rows=rows;
           MH_TRY(scratch.alloc(pair.src.view.device,filter_view.bytes(),pair.src.view.stream));
           filter_view.pixels=scratch.ptr;
-          MH_TRY(launch_resize_pass(pair.src.view,filter_view,true,vertical,roles,precision()));
-          MH_TRY(launch_resize_pass(filter_view,pair.dst.view,false,horizontal,roles,precision()));
+          MH_TRY(launch_resize_pass(pair.src.view,filter_view,true,*vertical,roles,precision()));
+          MH_TRY(launch_resize_pass(filter_view,pair.dst.view,false,*horizontal,roles,precision()));
         }
     }
   return pair.commit();

@@ -6,6 +6,10 @@
 // the reference's operation order: the weights these functions return are
 // compared bit-for-bit with the compiled reference in tests/.
 #include "resize_filter.hpp"
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include <cmath>
 
@@ -277,58 +281,155 @@ void build_tap_table(TapTable &table,const MhResizeFilter *filter,size_t in_size
   table.start.assign(out_size,0);
   table.count.assign(out_size,0);
   table.nearest.assign(out_size,0);
-  std::vector<double> w((size_t) capacity+4);
-  std::vector<std::vector<double>> rows(out_size);
-  int max_taps=0;
-  for (size_t x=0; x < out_size; x++)
+  // One output index is independent of the next and the weighting function is pure (the
+  // reference evaluates it from its OpenMP threads, resize.c:3398-3400), so long tables are
+  // built by a few host threads, straight into the transposed [tap][out] layout: a
+  // 32768-entry Lanczos table costs ~3 ms on one core, which would otherwise exceed the GPU
+  // time of the pass it feeds.
+  const size_t stride=(size_t) capacity+4;
+  table.weight.assign(stride*out_size,0.0);
+  double *weights=table.weight.data();
+  auto build_range=[&](size_t x0,size_t x1,int *range_max)
+  {
+    std::vector<double> w(stride);
+    int local_max=0;
+    for (size_t x=x0; x < x1; x++)
+      {
+        // resize.c:3418-3443
+        double bisect=(double) ((double) x+0.5)/factor+kEpsilon;
+        double lo=bisect-support+0.5;
+        if (lo < 0.0)
+          lo=0.0;
+        double hi=bisect+support+0.5;
+        if (hi > (double) in_size)
+          hi=(double) in_size;
+        ptrdiff_t start=(ptrdiff_t) lo,stop=(ptrdiff_t) hi;
+        ptrdiff_t n=stop-start;
+        if (n < 0)
+          n=0;
+        if ((size_t) n > stride)
+          n=(ptrdiff_t) stride;          // cannot happen: `capacity` bounds the span
+        double density=0.0;
+        for (ptrdiff_t i=0; i < n; i++)
+          {
+            w[(size_t) i]=MhGetResizeFilterWeight(filter,scale*((double) (start+i)-bisect+0.5));
+            density+=w[(size_t) i];
+          }
+        if ((n > 0) && (density != 0.0) && (density != 1.0))
+          {
+            density=perceptible_reciprocal(density);
+            for (ptrdiff_t i=0; i < n; i++)
+              w[(size_t) i]*=density;
+          }
+        for (ptrdiff_t i=0; i < n; i++)
+          weights[(size_t) i*out_size+x]=w[(size_t) i];
+        table.start[x]=(int) start;
+        table.count[x]=(int) n;
+        if (n > 0)
+          {
+            // Copy-trait source index, resize.c:3484-3485
+            double j=bisect;
+            if (j < (double) start)
+              j=(double) start;
+            if (j > (double) stop-1.0)
+              j=(double) stop-1.0;
+            table.nearest[x]=(int) (ptrdiff_t) (j+0.5);
+          }
+        if ((int) n > local_max)
+          local_max=(int) n;
+      }
+    *range_max=local_max;
+  };
+  // ~12 ns per weight on one core; a thread is worth starting for ~16k weights
+  size_t workers=out_size*(size_t) capacity/16384;
+  const size_t hw=std::thread::hardware_concurrency();
+  if (workers > 8)
+    workers=8;
+  if ((hw != 0) && (workers > hw))
+    workers=hw;
+  if (workers < 1)
+    workers=1;
+  std::vector<int> range_max(workers,0);
+  if (workers == 1)
+    build_range(0,out_size,&range_max[0]);
+  else
     {
-      // resize.c:3418-3443
-      double bisect=(double) ((double) x+0.5)/factor+kEpsilon;
-      double lo=bisect-support+0.5;
-      if (lo < 0.0)
-        lo=0.0;
-      double hi=bisect+support+0.5;
-      if (hi > (double) in_size)
-        hi=(double) in_size;
-      ptrdiff_t start=(ptrdiff_t) lo,stop=(ptrdiff_t) hi;
-      ptrdiff_t n=stop-start;
-      if (n < 0)
-        n=0;
-      if ((size_t) n > w.size())
-        w.resize((size_t) n);
-      double density=0.0;
-      for (ptrdiff_t i=0; i < n; i++)
-        {
-          w[(size_t) i]=MhGetResizeFilterWeight(filter,scale*((double) (start+i)-bisect+0.5));
-          density+=w[(size_t) i];
-        }
-      if ((n > 0) && (density != 0.0) && (density != 1.0))
-        {
-          density=perceptible_reciprocal(density);
-          for (ptrdiff_t i=0; i < n; i++)
-            w[(size_t) i]*=density;
-        }
-      table.start[x]=(int) start;
-      table.count[x]=(int) n;
-      if (n > 0)
-        {
-          // Copy-trait source index, resize.c:3484-3485
-          double j=bisect;
-          if (j < (double) start)
-            j=(double) start;
-          if (j > (double) stop-1.0)
-            j=(double) stop-1.0;
-          table.nearest[x]=(int) (ptrdiff_t) (j+0.5);
-        }
-      rows[x].assign(w.begin(),w.begin()+n);
-      if ((int) n > max_taps)
-        max_taps=(int) n;
+      std::vector<std::thread> pool;
+      for (size_t t=1; t < workers; t++)
+        pool.emplace_back(build_range,out_size*t/workers,out_size*(t+1)/workers,&range_max[t]);
+      build_range(0,out_size/workers,&range_max[0]);
+      for (std::thread &t : pool)
+        t.join();
     }
+  int max_taps=0;
+  for (int m : range_max)
+    max_taps=m > max_taps ? m : max_taps;
   table.max_taps=max_taps;
-  table.weight.assign((size_t) max_taps*out_size,0.0);
-  for (size_t x=0; x < out_size; x++)
-    for (size_t i=0; i < rows[x].size(); i++)
-      table.weight[i*out_size+x]=rows[x][i];
+  table.weight.resize((size_t) max_taps*out_size);     // drops the all-zero tail rows
+}
+
+// Contribution tables depend only on the filter's parameters and the two sizes; callers
+// that resize many equally sized images (a thumbnail batch, the benchmark) would rebuild the
+// same table for every image.  A small most-recently-used cache keeps the last few; filters
+// that weigh through a caller's callback are never cached (their identity is opaque).
+namespace {
+struct TapKey
+{
+  int filter_fn,window_fn;
+  double support,window_support,scale,blur,coefficient[7],factor;
+  size_t in_size,out_size;
+  bool operator==(const TapKey &o) const { return memcmp(this,&o,sizeof(TapKey)) == 0; }
+};
+struct TapCache
+{
+  std::mutex lock;
+  std::vector<std::pair<TapKey,std::shared_ptr<const TapTable>>> entries;   // front = most recent
+};
+TapCache &tap_cache() { static TapCache *c=new TapCache(); return *c; }
+constexpr size_t kTapCacheEntries=8;
+}
+
+std::shared_ptr<const TapTable> acquire_tap_table(const MhResizeFilter *filter,size_t in_size,
+  size_t out_size,double factor)
+{
+  if (filter->callback != nullptr)
+    {
+      auto table=std::make_shared<TapTable>();
+      build_tap_table(*table,filter,in_size,out_size,factor);
+      return table;
+    }
+  TapKey key;
+  memset(&key,0,sizeof(key));               // padding bytes take part in the comparison
+  key.filter_fn=filter->filter_fn;
+  key.window_fn=filter->window_fn;
+  key.support=filter->support;
+  key.window_support=filter->window_support;
+  key.scale=filter->scale;
+  key.blur=filter->blur;
+  for (int i=0; i < 7; i++)
+    key.coefficient[i]=filter->coefficient[i];
+  key.factor=factor;
+  key.in_size=in_size;
+  key.out_size=out_size;
+  TapCache &cache=tap_cache();
+  {
+    std::lock_guard<std::mutex> guard(cache.lock);
+    for (size_t i=0; i < cache.entries.size(); i++)
+      if (cache.entries[i].first == key)
+        {
+          auto hit=cache.entries[i];
+          cache.entries.erase(cache.entries.begin()+(ptrdiff_t) i);
+          cache.entries.insert(cache.entries.begin(),hit);
+          return hit.second;
+        }
+  }
+  auto table=std::make_shared<TapTable>();
+  build_tap_table(*table,filter,in_size,out_size,factor);
+  std::lock_guard<std::mutex> guard(cache.lock);
+  cache.entries.insert(cache.entries.begin(),{key,table});
+  if (cache.entries.size() > kTapCacheEntries)
+    cache.entries.pop_back();
+  return table;
 }
 
 } // namespace mh

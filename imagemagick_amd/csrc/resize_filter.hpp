@@ -4,6 +4,8 @@
 
 #include "mh_internal.hpp"
 
+#include <memory>
+
 struct MhResizeFilter
 {
   int filter_fn=0;          // index into the weighting-function switch
@@ -35,6 +37,10 @@ struct TapTable
 };
 
 void build_tap_table(TapTable &table,const MhResizeFilter *filter,size_t in_size,
+  size_t out_size,double factor);
+
+// Shared, possibly cached table (built-in filters are cached by their parameters).
+std::shared_ptr<const TapTable> acquire_tap_table(const MhResizeFilter *filter,size_t in_size,
   size_t out_size,double factor);
 
 } // namespace mh

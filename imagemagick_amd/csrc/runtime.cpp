@@ -39,9 +39,14 @@ MhStatus fail(MhStatus status,const char *fmt,...)
 // ------------------------------------------------------------------- state
 struct PoolBlock { void *ptr; size_t bytes; hipStream_t stream; };
 
+// Page-locked staging block for host->device table uploads; `ready` is recorded behind the
+// copy that last read it, so the block is reusable once the event has completed.
+struct StagingBlock { void *host; size_t bytes; hipEvent_t ready; };
+
 struct DeviceState
 {
   hipStream_t stream=nullptr;
+  std::vector<StagingBlock> staging;
   std::multimap<size_t,PoolBlock> free_blocks;   // by capacity
   std::map<void *,size_t> live;                  // ptr -> capacity
   size_t cached_bytes=0;
@@ -233,10 +238,86 @@ void pool_trim()
     (void) hipFree(v.second);
 }
 
+// Tables above this size go through page-locked staging: a hipMemcpyAsync from pageable
+// memory makes the runtime wait for the stream before it returns (measured: a resize call
+// blocked for the whole GPU time of the previous one), which serialises host and device.
+static constexpr size_t kStageDirect = 2048;
+static constexpr size_t kStageGranule = 64u<<10;
+
+static bool staging_acquire(int device,size_t bytes,StagingBlock *out)
+{
+  Runtime &r=rt();
+  {
+    std::lock_guard<std::mutex> guard(r.lock);
+    std::vector<StagingBlock> &list=r.devices[(size_t) device].staging;
+    for (size_t i=0; i < list.size(); i++)
+      if ((list[i].bytes >= bytes) && (list[i].bytes <= 4*bytes+kStageGranule) &&
+          (hipEventQuery(list[i].ready) == hipSuccess))
+        {
+          *out=list[i];
+          list.erase(list.begin()+(ptrdiff_t) i);
+          return true;
+        }
+    (void) hipGetLastError();            // hipErrorNotReady from the queries
+  }
+  StagingBlock b{nullptr,((bytes+kStageGranule-1)/kStageGranule)*kStageGranule,nullptr};
+  if (hipHostMalloc(&b.host,b.bytes,hipHostMallocDefault) != hipSuccess)
+    {
+      (void) hipGetLastError();
+      return false;
+    }
+  if (hipEventCreateWithFlags(&b.ready,hipEventDisableTiming) != hipSuccess)
+    {
+      (void) hipGetLastError();
+      (void) hipHostFree(b.host);
+      return false;
+    }
+  *out=b;
+  return true;
+}
+
+static void staging_release(int device,const StagingBlock &b)
+{
+  Runtime &r=rt();
+  std::lock_guard<std::mutex> guard(r.lock);
+  r.devices[(size_t) device].staging.push_back(b);
+}
+
+static void staging_trim()
+{
+  Runtime &r=rt();
+  std::vector<StagingBlock> victims;
+  {
+    std::lock_guard<std::mutex> guard(r.lock);
+    for (DeviceState &d : r.devices)
+      {
+        victims.insert(victims.end(),d.staging.begin(),d.staging.end());
+        d.staging.clear();
+      }
+  }
+  for (StagingBlock &b : victims)
+    {
+      (void) hipEventSynchronize(b.ready);
+      (void) hipEventDestroy(b.ready);
+      (void) hipHostFree(b.host);
+    }
+}
+
 MhStatus upload_table(Temp &dst,int device,hipStream_t stream,const void *host,size_t bytes)
 {
   MH_TRY(dst.alloc(device,bytes,stream));
-  // pageable source: the runtime stages it before returning, so `host` may be
+  StagingBlock block;
+  if ((bytes > kStageDirect) && staging_acquire(device,bytes,&block))
+    {
+      memcpy(block.host,host,bytes);
+      hipError_t err=hipMemcpyAsync(dst.ptr,block.host,bytes,hipMemcpyHostToDevice,stream);
+      if (err == hipSuccess)
+        err=hipEventRecord(block.ready,stream);
+      staging_release(device,block);
+      MH_HIP(err);
+      return MH_OK;
+    }
+  // small pageable source: the runtime stages it before returning, so `host` may be
   // released by the caller right away.
   MH_HIP(hipMemcpyAsync(dst.ptr,host,bytes,hipMemcpyHostToDevice,stream));
   return MH_OK;
@@ -422,6 +503,7 @@ MH_API void MhTerminus(void)
     return;
   drain_profile();
   pool_trim();
+  staging_trim();
 }
 
 MH_API int MhDeviceCount(void) { return device_count(); }

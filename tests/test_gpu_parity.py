@@ -159,6 +159,24 @@ def test_resize(im, refmod, dtype, shape, target, filt):
     assert_parity(got, want, True, "resize %s -> %s %s" % (shape, target, filt))
 
 
+def test_resize_contribution_table_cache(im, refmod):
+    """Tables are cached by (filter parameters, sizes): the same geometry with another filter,
+    the same filter with another geometry, and repeats (cache hits, enough distinct keys to
+    evict) must all still match the reference; a long axis takes the threaded builder."""
+    px = make_pixels(30, 5000, 4, Q16)
+    dev, ref = run_pair(im, refmod, px)
+    plan = [("Lanczos", 9000, 20), ("Mitchell", 9000, 20), ("Lanczos", 9000, 20), ("Lanczos", 2500, 45),
+            ("Catrom", 9000, 20), ("Triangle", 9000, 20), ("Hermite", 2500, 45), ("Box", 2500, 45),
+            ("Gaussian", 2500, 45), ("Spline", 2500, 45), ("Hann", 2500, 45), ("Lanczos", 9000, 20),
+            ("Mitchell", 9000, 20)]
+    wanted = {}
+    for filt, cols, rows in plan:
+        if (filt, cols, rows) not in wanted:
+            wanted[(filt, cols, rows)] = ref.resize(cols, rows, filt).numpy()
+        got = im.resize_image(dev, cols, rows, filt).numpy()
+        assert_parity(got, wanted[(filt, cols, rows)], True, "resize %s %dx%d" % (filt, cols, rows))
+
+
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
 @pytest.mark.parametrize("target", [(320, 240), (33, 21)])
 def test_resize_fast_precision(im, refmod, dtype, target):
