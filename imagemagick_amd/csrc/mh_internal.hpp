@@ -35,6 +35,7 @@ MhStatus fail(MhStatus status,const char *fmt,...) __attribute__((format(printf,
 MhStatus runtime_ready();                 // lazy MhInitialize + enabled check
 int default_device();
 int device_count();
+int compute_units(int device);          // cached multiProcessorCount
 MhPrecision precision();
 hipStream_t library_stream(int device);   // non-blocking stream owned by the library
 
@@ -162,8 +163,13 @@ MhStatus launch_unsharp_epilogue(const View &src,const View &blur,const View &ds
 MhStatus launch_histogram(const View &src,int intensity_mode,const MhImage *desc,
   unsigned long long *hist_device);
 // shared_column >= 0: every channel selected by apply_mask maps through that one LUT column
+// device_mask (optional): a device word and-ed into apply_mask inside the kernel
 MhStatus launch_apply_lut(const View &img,const void *lut_device,uint32_t apply_mask,
-  const Roles &roles,int shared_column);
+  const Roles &roles,int shared_column,const uint32_t *device_mask=nullptr);
+// histogram [65536][channels] -> Quantum-typed LUT + per-channel apply mask, on the device
+MhStatus launch_build_lut(const View &img,const unsigned long long *hist_device,bool equalize,
+  double black_point,double white_limit,void *lut_device,uint32_t *mask_device,
+  const unsigned int *colour_flag_device);
 MhStatus launch_gray_check(const View &img,const MhImage *desc,unsigned int *flag_device);
 MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,const MhImage *desc);
 MhStatus launch_copy(const View &src,const View &dst);

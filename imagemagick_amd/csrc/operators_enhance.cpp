@@ -285,6 +285,36 @@ MH_API MhStatus MagickHipIsImageGray(const MhImage *image,int *is_gray)
   return MH_OK;
 }
 
+// histogram -> LUT -> apply, all on the stream, no host round trip.  `colour_flag` (optional)
+// is the gray-scan word: when it says "gray" the LUT builder leaves the mask at zero and the
+// apply kernel touches nothing.
+static MhStatus histogram_lut_apply(const View &view,const MhImage *image,int mode,bool equalize,
+  double black_point,double white_limit,const unsigned int *colour_flag)
+{
+  const size_t n=(size_t) MH_HISTOGRAM_BINS*(size_t) view.channels;
+  Temp hist,lut,mask;
+  MH_TRY(hist.alloc(view.device,n*sizeof(unsigned long long),view.stream));
+  MH_HIP(hipMemsetAsync(hist.ptr,0,n*sizeof(unsigned long long),view.stream));
+  MH_TRY(launch_histogram(view,mode,image,hist.as<unsigned long long>()));
+  MH_TRY(lut.alloc(view.device,n*(view.quantum == MH_QUANTUM_U16 ? sizeof(unsigned short) :
+    sizeof(float)),view.stream));
+  MH_TRY(mask.alloc(view.device,sizeof(uint32_t),view.stream));
+  MH_TRY(launch_build_lut(view,hist.as<unsigned long long>(),equalize,black_point,white_limit,
+    lut.ptr,mask.as<uint32_t>(),colour_flag));
+  Roles roles=channel_roles(image,image);
+  // enhance.c:1781, :2255: only channels whose traits carry Update
+  uint32_t update=0;
+  for (uint32_t c=0; c < image->number_channels; c++)
+    if ((image->channel_traits[c] & MH_TRAIT_UPDATE) != 0)
+      update|=1u<<c;
+  roles.update_mask=update;
+  // intensity binning gives every channel the same histogram, hence the same LUT column
+  int shared_column=-1;
+  if (((mode != 0) || (view.channels == 1)) && (update != 0))
+    shared_column=__builtin_ctz(update);
+  return launch_apply_lut(view,lut.ptr,~0u,roles,shared_column,mask.as<uint32_t>());
+}
+
 // ContrastStretchImage, enhance.c:1544-1818
 MH_API MhStatus MagickHipContrastStretchImage(MhImage *image,double black_point,
   double white_point,int *became_gray)
@@ -297,15 +327,24 @@ MH_API MhStatus MagickHipContrastStretchImage(MhImage *image,double black_point,
   const View &view=io.img.view;
   // IdentifyImageType side effect, enhance.c:1586-1588: a colour image whose
   // pixels are all gray is re-laid-out as a GRAY image by the reference; that
-  // is the caller's job (SetImageColorspace), so hand such images back.
+  // is the caller's job (SetImageColorspace), so hand such images back untouched.
+  // The scan's verdict gates the LUT on the device; the host reads it once, at the end.
   const uint32_t colour=image->number_channels-(image->alpha_offset >= 0 ? 1u : 0u);
-  if ((colour >= 3) && ((image->colorspace == MH_COLORSPACE_SRGB) ||
-      (image->colorspace == MH_COLORSPACE_RGB)))
+  const bool scan=(colour >= 3) && ((image->colorspace == MH_COLORSPACE_SRGB) ||
+    (image->colorspace == MH_COLORSPACE_RGB));
+  Temp flag;
+  if (scan)
     {
-      Temp flag;
       MH_TRY(flag.alloc(view.device,sizeof(unsigned int),view.stream));
       MH_HIP(hipMemsetAsync(flag.ptr,0,sizeof(unsigned int),view.stream));
       MH_TRY(launch_gray_check(view,image,flag.as<unsigned int>()));
+    }
+  // enhance.c:1637-1643: every channel bins the intensity under the default mask
+  const int mode=image->channel_mask == MH_ALL_CHANNELS ? 1 : 0;
+  MH_TRY(histogram_lut_apply(view,image,mode,false,black_point,
+    (double) image->columns*(double) image->rows-white_point,scan ? flag.as<unsigned int>() : nullptr));
+  if (scan)
+    {
       unsigned int host=0;
       MH_HIP(hipMemcpyAsync(&host,flag.ptr,sizeof(host),hipMemcpyDeviceToHost,view.stream));
       MH_HIP(hipStreamSynchronize(view.stream));
@@ -317,16 +356,6 @@ MH_API MhStatus MagickHipContrastStretchImage(MhImage *image,double black_point,
             "GRAY colourspace first (IdentifyImageType, enhance.c:1586)");
         }
     }
-  // enhance.c:1637-1643: every channel bins the intensity under the default mask
-  const int mode=image->channel_mask == MH_ALL_CHANNELS ? 1 : 0;
-  std::vector<unsigned long long> hist;
-  MH_TRY(histogram_to_host(view,mode,image,hist));
-  std::vector<double> lut((size_t) MH_HISTOGRAM_BINS*image->number_channels);
-  uint32_t mask=0;
-  MH_TRY(MhContrastStretchLUT(reinterpret_cast<const uint64_t *>(hist.data()),
-    image->number_channels,image->columns,image->rows,black_point,white_point,
-    (MhQuantumKind) image->quantum,lut.data(),&mask));
-  MH_TRY(apply_lut_host(view,image,lut.data(),mask));
   return io.img.commit();
 }
 
@@ -338,13 +367,7 @@ MH_API MhStatus MagickHipEqualizeImage(MhImage *image)
   MH_TRY(io.open(image));
   const View &view=io.img.view;
   const int mode=(image->channel_mask & MH_SYNC_CHANNELS) != 0 ? 1 : 0;   // enhance.c:2125-2129
-  std::vector<unsigned long long> hist;
-  MH_TRY(histogram_to_host(view,mode,image,hist));
-  std::vector<double> lut((size_t) MH_HISTOGRAM_BINS*image->number_channels);
-  uint32_t mask=0;
-  MH_TRY(MhEqualizeLUT(reinterpret_cast<const uint64_t *>(hist.data()),image->number_channels,
-    (MhQuantumKind) image->quantum,lut.data(),&mask));
-  MH_TRY(apply_lut_host(view,image,lut.data(),mask));
+  MH_TRY(histogram_lut_apply(view,image,mode,true,0.0,0.0,nullptr));
   return io.img.commit();
 }
 

@@ -597,11 +597,7 @@ template<typename Q,int C>
 static MhStatus histogram_intensity_lds(const View &src,const IntensityParams &ip,unsigned long long *hist)
 {
   const size_t n=src.columns*src.rows;
-  int cus=256;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop,src.device) == hipSuccess)
-    cus=prop.multiProcessorCount;
-  const int nblocks=cus;
+  const int nblocks=compute_units(src.device);
   Temp slabs;
   MH_TRY(slabs.alloc(src.device,(size_t) nblocks*2*kHistHalf*sizeof(unsigned),src.stream));
   const size_t lds=(size_t) kHistHalf*sizeof(unsigned);
@@ -662,11 +658,161 @@ MhStatus launch_histogram(const View &src,int intensity_mode,const MhImage *desc
 #undef MH_CASE
 }
 
+// ---------------------------------------------------------------- LUT build
+// The 65536-entry scans that turn a histogram into a LUT (enhance.c:1652-1706 contrast
+// stretch, :2138-2169 equalize) on the device, so the operator never waits for a histogram
+// download: one workgroup per channel, 64 consecutive bins per thread, counts summed as
+// 64-bit integers (the reference adds them as doubles — exact below 2^53, so the order of
+// the additions does not matter) and every floating-point expression written as there.
+struct LutBuildArgs
+{
+  const unsigned long long *hist;     // [65536][channels]
+  int channels;
+  int equalize;                       // 0: contrast stretch, 1: equalize
+  double black_point,white_limit;     // stretch: counts; white_limit = columns*rows-white_point
+  int is_u16;
+  void *lut;                          // Quantum-typed [65536][channels]
+  uint32_t *mask;                     // out: bit c set when channel c has black != white (pre-zeroed)
+  const unsigned int *colour_flag;    // optional: 0 => image is gray => leave every channel alone
+};
+
+__device__ __forceinline__ double lut_scale_map_to_quantum(double value,int is_u16)
+{
+  // ScaleMapToQuantum, quantum-private.h:465-476, as the Quantum it is stored in
+  if (value <= 0.0)
+    return 0.0;
+  if (value >= 65535.0)
+    return 65535.0;
+  if (is_u16)
+    return (double) (unsigned short) (value+0.5);
+  return (double) (float) value;
+}
+
+__global__ __launch_bounds__(1024)
+void build_lut_kernel(LutBuildArgs a)
+{
+  constexpr int PER=64;
+  const int c=(int) blockIdx.x,C=a.channels,t=(int) threadIdx.x;
+  __shared__ unsigned long long scan[1024];
+  __shared__ int black_s,white_s;
+  if ((a.colour_flag != nullptr) && (*a.colour_flag == 0))
+    return;
+  const unsigned long long *column=a.hist+c;
+  unsigned long long own=0;
+  for (int k=0; k < PER; k++)
+    own+=column[(size_t) (t*PER+k)*C];
+  scan[t]=own;
+  if (t == 0)
+    {
+      black_s=65536;
+      white_s=0;
+    }
+  __syncthreads();
+  for (int step=1; step < 1024; step<<=1)          // inclusive scan over the 1024 partial sums
+    {
+      unsigned long long add=t >= step ? scan[t-step] : 0ull;
+      __syncthreads();
+      scan[t]+=add;
+      __syncthreads();
+    }
+  const unsigned long long total=scan[1023];
+  const unsigned long long before=scan[t]-own;     // counts of all bins below this thread's range
+  unsigned short *lut16=static_cast<unsigned short *>(a.lut);
+  float *lut32=static_cast<float *>(a.lut);
+  if (a.equalize != 0)
+    {
+      // integrate, enhance.c:2138-2152; map, :2162-2168
+      const double black=(double) column[0],white=(double) total;
+      if (black == white)
+        return;
+      unsigned long long cum=before;
+      for (int k=0; k < PER; k++)
+        {
+          const int j=t*PER+k;
+          cum+=column[(size_t) j*C];
+          double v=lut_scale_map_to_quantum((double) ((65535.0*((double) cum-black))/(white-black)),a.is_u16);
+          if (a.is_u16)
+            lut16[(size_t) j*C+c]=(unsigned short) v;
+          else
+            lut32[(size_t) j*C+c]=(float) v;
+        }
+      if (t == 0)
+        atomicOr(a.mask,1u<<c);
+      return;
+    }
+  // black / white levels, enhance.c:1652-1678
+  {
+    unsigned long long cum=before;
+    int first_black=65536,last_white=0;
+    for (int k=0; k < PER; k++)
+      {
+        const int j=t*PER+k;
+        const unsigned long long h=column[(size_t) j*C];
+        const unsigned long long from_top=total-cum;     // bins j..65535
+        cum+=h;
+        if (((double) cum > a.black_point) && (j < first_black))
+          first_black=j;
+        if ((j >= 1) && ((double) from_top > a.white_limit))
+          last_white=j;
+      }
+    if (first_black < 65536)
+      atomicMin(&black_s,first_black);
+    if (last_white > 0)
+      atomicMax(&white_s,last_white);
+  }
+  __syncthreads();
+  const double black=(double) black_s,white=(double) white_s;
+  // stretch map, enhance.c:1685-1706
+  const double gamma=perceptible_reciprocal(white-black);
+  for (int k=0; k < PER; k++)
+    {
+      const int j=t*PER+k;
+      double v=0.0;
+      if (j < black_s)
+        v=0.0;
+      else if (j > white_s)
+        v=65535.0;
+      else if (black != white)
+        v=lut_scale_map_to_quantum((double) (65535.0*gamma*((double) j-black)),a.is_u16);
+      if (a.is_u16)
+        lut16[(size_t) j*C+c]=(unsigned short) v;
+      else
+        lut32[(size_t) j*C+c]=(float) v;
+    }
+  if ((t == 0) && (black != white))
+    atomicOr(a.mask,1u<<c);
+}
+
+MhStatus launch_build_lut(const View &img,const unsigned long long *hist,bool equalize,
+  double black_point,double white_limit,void *lut,uint32_t *mask,const unsigned int *colour_flag)
+{
+  LutBuildArgs a;
+  a.hist=hist;
+  a.channels=img.channels;
+  a.equalize=equalize ? 1 : 0;
+  a.black_point=black_point;
+  a.white_limit=white_limit;
+  a.is_u16=img.quantum == MH_QUANTUM_U16 ? 1 : 0;
+  a.lut=lut;
+  a.mask=mask;
+  a.colour_flag=colour_flag;
+  MH_HIP(hipMemsetAsync(mask,0,sizeof(uint32_t),img.stream));
+  ProfileScope prof("build_lut",img.stream);
+  hipLaunchKernelGGL(build_lut_kernel,dim3((unsigned) img.channels),dim3(1024),0,img.stream,a);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 // ---------------------------------------------------------------- LUT apply
 template<typename Q,int C>
 __global__ __launch_bounds__(256)
-void apply_lut_kernel(Q *pixels,size_t npixels,const Q *lut,uint32_t mask)
+void apply_lut_kernel(Q *pixels,size_t npixels,const Q *lut,uint32_t mask,
+  const uint32_t *device_mask)
 {
+  if (device_mask != nullptr)
+    mask&=*device_mask;                 // uniform: written by build_lut_kernel earlier in the stream
+  if (mask == 0)
+    return;
   const size_t stride=(size_t) gridDim.x*blockDim.x;
   for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
     {
@@ -681,12 +827,13 @@ void apply_lut_kernel(Q *pixels,size_t npixels,const Q *lut,uint32_t mask)
 }
 
 template<typename Q,int C>
-static MhStatus apply_lut_typed(const View &img,const void *lut,uint32_t mask)
+static MhStatus apply_lut_typed(const View &img,const void *lut,uint32_t mask,
+  const uint32_t *device_mask)
 {
   const size_t n=img.columns*img.rows;
   ProfileScope prof("apply_lut",img.stream);
   hipLaunchKernelGGL((apply_lut_kernel<Q,C>),dim3(stream_grid(n)),dim3(256),0,img.stream,
-    static_cast<Q *>(img.pixels),n,static_cast<const Q *>(lut),mask);
+    static_cast<Q *>(img.pixels),n,static_cast<const Q *>(lut),mask,device_mask);
   MH_HIP(hipGetLastError());
   return MH_OK;
 }
@@ -697,8 +844,13 @@ static MhStatus apply_lut_typed(const View &img,const void *lut,uint32_t mask)
 // pixel are LDS reads instead of scattered 2-byte global gathers.
 template<int C>
 __global__ __launch_bounds__(1024)
-void apply_lut_shared_kernel(uint16_t *pixels,size_t npixels,const uint16_t *lut,int column,uint32_t mask)
+void apply_lut_shared_kernel(uint16_t *pixels,size_t npixels,const uint16_t *lut,int column,uint32_t mask,
+  const uint32_t *device_mask)
 {
+  if (device_mask != nullptr)
+    mask&=*device_mask;
+  if (mask == 0)
+    return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint16_t *table=reinterpret_cast<uint16_t *>(smem_raw);
   for (int i=(int) threadIdx.x; i < 65536; i+=1024)
@@ -732,42 +884,40 @@ void apply_lut_shared_kernel(uint16_t *pixels,size_t npixels,const uint16_t *lut
 }
 
 template<int C>
-static MhStatus apply_lut_shared(const View &img,const void *lut,int column,uint32_t mask)
+static MhStatus apply_lut_shared(const View &img,const void *lut,int column,uint32_t mask,
+  const uint32_t *device_mask)
 {
   const size_t n=img.columns*img.rows;
-  int cus=256;
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop,img.device) == hipSuccess)
-    cus=prop.multiProcessorCount;
+  const int cus=compute_units(img.device);
   const size_t lds=65536*sizeof(uint16_t);
   MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&apply_lut_shared_kernel<C>),
     hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
   ProfileScope prof("apply_lut",img.stream);
   hipLaunchKernelGGL((apply_lut_shared_kernel<C>),dim3(cus),dim3(1024),lds,img.stream,
-    static_cast<uint16_t *>(img.pixels),n,static_cast<const uint16_t *>(lut),column,mask);
+    static_cast<uint16_t *>(img.pixels),n,static_cast<const uint16_t *>(lut),column,mask,device_mask);
   MH_HIP(hipGetLastError());
   return MH_OK;
 }
 
 MhStatus launch_apply_lut(const View &img,const void *lut,uint32_t apply_mask,const Roles &roles,
-  int shared_column)
+  int shared_column,const uint32_t *device_mask)
 {
   uint32_t mask=apply_mask & roles.update_mask;
   if ((shared_column >= 0) && (img.quantum == MH_QUANTUM_U16) &&
       (img.columns*img.rows >= ((size_t) 1 << 20)))
     switch (img.channels)
     {
-      case 1: return apply_lut_shared<1>(img,lut,shared_column,mask);
-      case 2: return apply_lut_shared<2>(img,lut,shared_column,mask);
-      case 3: return apply_lut_shared<3>(img,lut,shared_column,mask);
-      default: return apply_lut_shared<4>(img,lut,shared_column,mask);
+      case 1: return apply_lut_shared<1>(img,lut,shared_column,mask,device_mask);
+      case 2: return apply_lut_shared<2>(img,lut,shared_column,mask,device_mask);
+      case 3: return apply_lut_shared<3>(img,lut,shared_column,mask,device_mask);
+      default: return apply_lut_shared<4>(img,lut,shared_column,mask,device_mask);
     }
 #define MH_CASE(QT) \
   switch (img.channels) { \
-    case 1: return apply_lut_typed<QT,1>(img,lut,mask); \
-    case 2: return apply_lut_typed<QT,2>(img,lut,mask); \
-    case 3: return apply_lut_typed<QT,3>(img,lut,mask); \
-    default: return apply_lut_typed<QT,4>(img,lut,mask); }
+    case 1: return apply_lut_typed<QT,1>(img,lut,mask,device_mask); \
+    case 2: return apply_lut_typed<QT,2>(img,lut,mask,device_mask); \
+    case 3: return apply_lut_typed<QT,3>(img,lut,mask,device_mask); \
+    default: return apply_lut_typed<QT,4>(img,lut,mask,device_mask); }
   if (img.quantum == MH_QUANTUM_U16)
     { MH_CASE(uint16_t) }
   MH_CASE(float)

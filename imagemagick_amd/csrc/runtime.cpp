@@ -46,6 +46,7 @@ struct StagingBlock { void *host; size_t bytes; hipEvent_t ready; };
 struct DeviceState
 {
   hipStream_t stream=nullptr;
+  int compute_units=0;
   std::vector<StagingBlock> staging;
   std::multimap<size_t,PoolBlock> free_blocks;   // by capacity
   std::map<void *,size_t> live;                  // ptr -> capacity
@@ -124,6 +125,28 @@ MhStatus runtime_ready()
 int default_device() { return rt().default_device; }
 int device_count() { Runtime &r=rt(); std::call_once(r.once,do_init); return r.ndevices; }
 MhPrecision precision() { return rt().precision; }
+
+int compute_units(int device)
+{
+  Runtime &r=rt();
+  std::call_once(r.once,do_init);
+  if ((device < 0) || (device >= r.ndevices))
+    return 256;
+  std::lock_guard<std::mutex> guard(r.lock);
+  DeviceState &d=r.devices[(size_t) device];
+  if (d.compute_units == 0)
+    {
+      int n=0;
+      if ((hipDeviceGetAttribute(&n,hipDeviceAttributeMultiprocessorCount,device) != hipSuccess) ||
+          (n <= 0))
+        {
+          (void) hipGetLastError();
+          n=256;
+        }
+      d.compute_units=n;
+    }
+  return d.compute_units;
+}
 
 hipStream_t library_stream(int device)
 {
