@@ -16,6 +16,9 @@
 //   UnsharpMaskImage epilogue              MagickCore/effect.c:4343-4372
 #include "mh_internal.hpp"
 #include "device_common.hpp"
+
+#include <map>
+#include <mutex>
 #include <cstdlib>
 
 namespace mh {
@@ -229,6 +232,55 @@ enum ColorOp
   OP_SRGB_TO_RGB,OP_RGB_TO_SRGB,OP_SRGB_TO_LAB,OP_LAB_TO_SRGB,OP_SRGB_TO_XYZ,OP_XYZ_TO_SRGB
 };
 
+// Q16 pixels have only 65536 possible sRGB samples, so the transfer functions are tabulated
+// once per device by the same device code that evaluates them per pixel (bit-identical):
+// QuantumScale*DecodePixelGamma(j) as doubles (512 KB, L2-resident) for the XYZ/Lab kernels,
+// and the Quantum-rounded decode / encode columns for sRGB <-> linear RGB, which then run as
+// LUT applications.
+__global__ __launch_bounds__(256)
+void colorspace_table_kernel(double *decode_scaled,uint16_t *decode_q16,uint16_t *encode_q16)
+{
+  const unsigned j=blockIdx.x*blockDim.x+threadIdx.x;
+  if (j > 65535u)
+    return;
+  const double d=decode_pixel_gamma((double) j);
+  decode_scaled[j]=kQS*d;
+  decode_q16[j]=QuantumOps<uint16_t>::clamp(d);
+  encode_q16[j]=QuantumOps<uint16_t>::clamp(encode_pixel_gamma((double) j));
+}
+
+template<int C,int OP>
+__global__ __launch_bounds__(256)
+void colorspace_q16_table_kernel(uint16_t *pixels,size_t npixels,const double *decode_scaled)
+{
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
+    {
+      uint16_t q[C];
+      load_pixel<uint16_t,C>(pixels+i*C,q);
+      // ConvertRGBToXYZ, colorspace-private.h:759-779, with the three decodes looked up
+      const double r=decode_scaled[q[0]],g=decode_scaled[q[1]],b=decode_scaled[q[2]];
+      const double X=(0.4123955889674142161*r)+(0.3575834307637148171*g)+(0.1804926473817015735*b);
+      const double Y=(0.2125862307855955516*r)+(0.7151703037034108499*g)+(0.07220049864333622685*b);
+      const double Z=(0.01929721549174694484*r)+(0.1191838645808485318*g)+(0.9504971251315797660*b);
+      double o0,o1,o2;
+      if constexpr (OP == OP_SRGB_TO_LAB)
+        {
+          double L,a,bb;
+          xyz_to_lab(X,Y,Z,L,a,bb);
+          o0=kQR*L; o1=kQR*a; o2=kQR*bb;
+        }
+      else
+        {
+          o0=kQR*X; o1=kQR*Y; o2=kQR*Z;
+        }
+      q[0]=QuantumOps<uint16_t>::clamp(o0);
+      q[1]=QuantumOps<uint16_t>::clamp(o1);
+      q[2]=QuantumOps<uint16_t>::clamp(o2);
+      store_pixel<uint16_t,C>(pixels+i*C,q);
+    }
+}
+
 template<typename Q,int C,int OP>
 __global__ __launch_bounds__(256)
 void colorspace_kernel(Q *pixels,size_t npixels)
@@ -313,8 +365,89 @@ static MhStatus colorspace_typed(const View &img,int op)
   return MH_OK;
 }
 
+// per-device transfer-function tables (see colorspace_table_kernel); built on first use
+struct ColorTables
+{
+  void *block=nullptr;
+  double *decode_scaled=nullptr;
+  uint16_t *decode_q16=nullptr,*encode_q16=nullptr;
+};
+static std::mutex color_tables_lock;
+static std::map<int,ColorTables> color_tables;
+
+static MhStatus acquire_color_tables(int device,hipStream_t stream,ColorTables *out)
+{
+  std::lock_guard<std::mutex> guard(color_tables_lock);
+  auto it=color_tables.find(device);
+  if (it != color_tables.end())
+    {
+      *out=it->second;
+      return MH_OK;
+    }
+  ColorTables t;
+  MH_HIP(hipMalloc(&t.block,65536*(sizeof(double)+2*sizeof(uint16_t))));
+  t.decode_scaled=static_cast<double *>(t.block);
+  t.decode_q16=reinterpret_cast<uint16_t *>(t.decode_scaled+65536);
+  t.encode_q16=t.decode_q16+65536;
+  hipLaunchKernelGGL(colorspace_table_kernel,dim3(256),dim3(256),0,stream,t.decode_scaled,
+    t.decode_q16,t.encode_q16);
+  hipError_t err=hipGetLastError();
+  if (err == hipSuccess)
+    err=hipStreamSynchronize(stream);      // once per device: other streams may use it next
+  if (err != hipSuccess)
+    {
+      (void) hipFree(t.block);
+      MH_HIP(err);
+    }
+  color_tables[device]=t;
+  *out=t;
+  return MH_OK;
+}
+
+void release_color_tables()
+{
+  std::lock_guard<std::mutex> guard(color_tables_lock);
+  for (auto &kv : color_tables)
+    (void) hipFree(kv.second.block);
+  color_tables.clear();
+}
+
+static MhStatus apply_q16_column(const View &img,const uint16_t *column,uint32_t mask,const char *label);
+
 static MhStatus colorspace_step(const View &img,int op)
 {
+  if ((img.quantum == MH_QUANTUM_U16) && (getenv("MAGICKHIP_NO_COLOR_TABLES") == nullptr) &&
+      ((op == OP_SRGB_TO_RGB) || (op == OP_RGB_TO_SRGB) || (op == OP_SRGB_TO_LAB) ||
+       (op == OP_SRGB_TO_XYZ)))
+    {
+      ColorTables t;
+      MH_TRY(acquire_color_tables(img.device,img.stream,&t));
+      if ((op == OP_SRGB_TO_RGB) || (op == OP_RGB_TO_SRGB))
+        {
+          return apply_q16_column(img,op == OP_SRGB_TO_RGB ? t.decode_q16 : t.encode_q16,0x7u,
+            "colorspace");
+        }
+      const size_t n=img.columns*img.rows;
+      uint16_t *p=static_cast<uint16_t *>(img.pixels);
+      dim3 grid(stream_grid(n)),block(256);
+      ProfileScope prof("colorspace",img.stream);
+      if (img.channels == 3)
+        {
+          if (op == OP_SRGB_TO_LAB)
+            hipLaunchKernelGGL((colorspace_q16_table_kernel<3,OP_SRGB_TO_LAB>),grid,block,0,img.stream,p,n,t.decode_scaled);
+          else
+            hipLaunchKernelGGL((colorspace_q16_table_kernel<3,OP_SRGB_TO_XYZ>),grid,block,0,img.stream,p,n,t.decode_scaled);
+        }
+      else
+        {
+          if (op == OP_SRGB_TO_LAB)
+            hipLaunchKernelGGL((colorspace_q16_table_kernel<4,OP_SRGB_TO_LAB>),grid,block,0,img.stream,p,n,t.decode_scaled);
+          else
+            hipLaunchKernelGGL((colorspace_q16_table_kernel<4,OP_SRGB_TO_XYZ>),grid,block,0,img.stream,p,n,t.decode_scaled);
+        }
+      MH_HIP(hipGetLastError());
+      return MH_OK;
+    }
   if (img.quantum == MH_QUANTUM_U16)
     return img.channels == 3 ? colorspace_typed<uint16_t,3>(img,op) :
       colorspace_typed<uint16_t,4>(img,op);
@@ -579,6 +712,11 @@ void histogram_lds_kernel(const Q *pixels,size_t npixels,IntensityParams ip,unsi
     }
 }
 
+// grid (256, kSlabGroups): block y sums its share of the per-workgroup slabs for 256 bins
+// and adds the partial sum to the caller's table (one 64-bit atomic per bin and channel,
+// kSlabGroups-way contention at most) — 8x the loads in flight of a single pass per bin.
+constexpr int kSlabGroups=8;
+
 __global__ __launch_bounds__(256)
 void histogram_slab_reduce_kernel(const unsigned *slabs,int nblocks,unsigned long long *counts,int channels)
 {
@@ -586,11 +724,16 @@ void histogram_slab_reduce_kernel(const unsigned *slabs,int nblocks,unsigned lon
   if (bin > 65535u)
     return;
   const unsigned half=bin/kHistHalf,local=bin%kHistHalf;
+  const int per=(nblocks+kSlabGroups-1)/kSlabGroups;
+  const int b0=(int) blockIdx.y*per;
+  const int b1=b0+per < nblocks ? b0+per : nblocks;
   unsigned long long sum=0;
-  for (int b=0; b < nblocks; b++)
+#pragma unroll 8
+  for (int b=b0; b < b1; b++)
     sum+=slabs[((size_t) b*2+half)*kHistHalf+local];
-  for (int c=0; c < channels; c++)
-    counts[(size_t) bin*channels+c]+=sum;
+  if (sum != 0)
+    for (int c=0; c < channels; c++)
+      atomicAdd(counts+(size_t) bin*channels+c,sum);
 }
 
 template<typename Q,int C>
@@ -607,7 +750,7 @@ static MhStatus histogram_intensity_lds(const View &src,const IntensityParams &i
     ProfileScope prof("histogram",src.stream);
     hipLaunchKernelGGL((histogram_lds_kernel<Q,C>),dim3(nblocks),dim3(1024),lds,src.stream,
       static_cast<const Q *>(src.pixels),n,ip,slabs.as<unsigned>());
-    hipLaunchKernelGGL(histogram_slab_reduce_kernel,dim3(256),dim3(256),0,src.stream,
+    hipLaunchKernelGGL(histogram_slab_reduce_kernel,dim3(256,kSlabGroups),dim3(256),0,src.stream,
       slabs.as<unsigned>(),nblocks,hist,C);
   }
   MH_HIP(hipGetLastError());
@@ -688,98 +831,157 @@ __device__ __forceinline__ double lut_scale_map_to_quantum(double value,int is_u
   return (double) (float) value;
 }
 
-__global__ __launch_bounds__(1024)
-void build_lut_kernel(LutBuildArgs a)
+// Three small grids of (channels x 64) workgroups, one bin per thread, coalesced:
+//   lut_chunk_sums_kernel   sum of each 1024-bin chunk
+//   lut_scan_kernel         running count of every bin (chunk prefix + workgroup scan);
+//                           equalize writes its map here, stretch records the black / white
+//                           levels (first bin from below / from above whose running count
+//                           passes the threshold) with one atomic per workgroup
+//   lut_stretch_map_kernel  stretch map from the two levels
+constexpr int kLutChunks=64;
+
+struct LutScratch
 {
-  constexpr int PER=64;
-  const int c=(int) blockIdx.x,C=a.channels,t=(int) threadIdx.x;
-  __shared__ unsigned long long scan[1024];
-  __shared__ int black_s,white_s;
-  if ((a.colour_flag != nullptr) && (*a.colour_flag == 0))
-    return;
-  const unsigned long long *column=a.hist+c;
-  unsigned long long own=0;
-  for (int k=0; k < PER; k++)
-    own+=column[(size_t) (t*PER+k)*C];
-  scan[t]=own;
-  if (t == 0)
-    {
-      black_s=65536;
-      white_s=0;
-    }
+  unsigned long long chunk_sum[MH_MAX_CHANNELS][kLutChunks];
+  int black[MH_MAX_CHANNELS],white[MH_MAX_CHANNELS];
+};
+
+__device__ __forceinline__ bool lut_image_is_gray(const LutBuildArgs &a)
+{
+  return (a.colour_flag != nullptr) && (*a.colour_flag == 0);
+}
+
+__device__ __forceinline__ void lut_store(const LutBuildArgs &a,int j,int c,double v)
+{
+  if (a.is_u16)
+    static_cast<unsigned short *>(a.lut)[(size_t) j*a.channels+c]=(unsigned short) v;
+  else
+    static_cast<float *>(a.lut)[(size_t) j*a.channels+c]=(float) v;
+}
+
+// workgroup-wide sum of one 64-bit value per thread (1024 threads); result in every thread
+__device__ __forceinline__ unsigned long long lut_block_sum(unsigned long long v,unsigned long long *shared16)
+{
+  for (int off=32; off > 0; off>>=1)
+    v+=__shfl_xor(v,off,64);
+  if ((threadIdx.x & 63) == 0)
+    shared16[threadIdx.x >> 6]=v;
   __syncthreads();
-  for (int step=1; step < 1024; step<<=1)          // inclusive scan over the 1024 partial sums
+  unsigned long long total=0;
+  for (int w=0; w < 16; w++)
+    total+=shared16[w];
+  __syncthreads();
+  return total;
+}
+
+__global__ __launch_bounds__(1024)
+void lut_chunk_sums_kernel(LutBuildArgs a,LutScratch *scratch)
+{
+  __shared__ unsigned long long wave_sums[16];
+  const int c=(int) blockIdx.x,chunk=(int) blockIdx.y,j=chunk*1024+(int) threadIdx.x;
+  unsigned long long total=lut_block_sum(a.hist[(size_t) j*a.channels+c],wave_sums);
+  if (threadIdx.x == 0)
     {
-      unsigned long long add=t >= step ? scan[t-step] : 0ull;
-      __syncthreads();
-      scan[t]+=add;
-      __syncthreads();
+      scratch->chunk_sum[c][chunk]=total;
+      if (chunk == 0)
+        {
+          scratch->black[c]=65536;
+          scratch->white[c]=0;
+        }
     }
-  const unsigned long long total=scan[1023];
-  const unsigned long long before=scan[t]-own;     // counts of all bins below this thread's range
-  unsigned short *lut16=static_cast<unsigned short *>(a.lut);
-  float *lut32=static_cast<float *>(a.lut);
+}
+
+__global__ __launch_bounds__(1024)
+void lut_scan_kernel(LutBuildArgs a,LutScratch *scratch)
+{
+  __shared__ unsigned long long wave_sums[16];
+  __shared__ unsigned long long prefix_s,total_s;
+  __shared__ int black_s,white_s;
+  if (lut_image_is_gray(a))
+    return;
+  const int c=(int) blockIdx.x,chunk=(int) blockIdx.y,t=(int) threadIdx.x,j=chunk*1024+t;
+  if (t < 64)
+    {
+      // wave 0: counts below this chunk, and of the whole channel
+      unsigned long long v=scratch->chunk_sum[c][t];
+      unsigned long long below=t < chunk ? v : 0ull;
+      for (int off=32; off > 0; off>>=1)
+        {
+          v+=__shfl_xor(v,off,64);
+          below+=__shfl_xor(below,off,64);
+        }
+      if (t == 0)
+        {
+          prefix_s=below;
+          total_s=v;
+          black_s=65536;
+          white_s=0;
+        }
+    }
+  const unsigned long long h=a.hist[(size_t) j*a.channels+c];
+  // inclusive scan of the 1024 bins: within the wave, then across the 16 waves
+  unsigned long long cum=h;
+  const int lane=t & 63;
+  for (int off=1; off < 64; off<<=1)
+    {
+      unsigned long long up=__shfl_up(cum,off,64);
+      if (lane >= off)
+        cum+=up;
+    }
+  if (lane == 63)
+    wave_sums[t >> 6]=cum;
+  __syncthreads();
+  for (int w=0; w < (t >> 6); w++)
+    cum+=wave_sums[w];
+  cum+=prefix_s;
+  const unsigned long long total=total_s;
   if (a.equalize != 0)
     {
       // integrate, enhance.c:2138-2152; map, :2162-2168
-      const double black=(double) column[0],white=(double) total;
+      const double black=(double) a.hist[c],white=(double) total;
       if (black == white)
         return;
-      unsigned long long cum=before;
-      for (int k=0; k < PER; k++)
-        {
-          const int j=t*PER+k;
-          cum+=column[(size_t) j*C];
-          double v=lut_scale_map_to_quantum((double) ((65535.0*((double) cum-black))/(white-black)),a.is_u16);
-          if (a.is_u16)
-            lut16[(size_t) j*C+c]=(unsigned short) v;
-          else
-            lut32[(size_t) j*C+c]=(float) v;
-        }
-      if (t == 0)
+      lut_store(a,j,c,lut_scale_map_to_quantum(
+        (double) ((65535.0*((double) cum-black))/(white-black)),a.is_u16));
+      if (j == 0)
         atomicOr(a.mask,1u<<c);
       return;
     }
   // black / white levels, enhance.c:1652-1678
-  {
-    unsigned long long cum=before;
-    int first_black=65536,last_white=0;
-    for (int k=0; k < PER; k++)
-      {
-        const int j=t*PER+k;
-        const unsigned long long h=column[(size_t) j*C];
-        const unsigned long long from_top=total-cum;     // bins j..65535
-        cum+=h;
-        if (((double) cum > a.black_point) && (j < first_black))
-          first_black=j;
-        if ((j >= 1) && ((double) from_top > a.white_limit))
-          last_white=j;
-      }
-    if (first_black < 65536)
-      atomicMin(&black_s,first_black);
-    if (last_white > 0)
-      atomicMax(&white_s,last_white);
-  }
+  const unsigned long long from_top=total-(cum-h);          // bins j..65535
+  if ((double) cum > a.black_point)
+    atomicMin(&black_s,j);
+  if ((j >= 1) && ((double) from_top > a.white_limit))
+    atomicMax(&white_s,j);
   __syncthreads();
-  const double black=(double) black_s,white=(double) white_s;
+  if (t == 0)
+    {
+      if (black_s < 65536)
+        atomicMin(&scratch->black[c],black_s);
+      if (white_s > 0)
+        atomicMax(&scratch->white[c],white_s);
+    }
+}
+
+__global__ __launch_bounds__(1024)
+void lut_stretch_map_kernel(LutBuildArgs a,const LutScratch *scratch)
+{
+  if (lut_image_is_gray(a))
+    return;
+  const int c=(int) blockIdx.x,j=(int) blockIdx.y*1024+(int) threadIdx.x;
+  const int black_i=scratch->black[c],white_i=scratch->white[c];
+  const double black=(double) black_i,white=(double) white_i;
   // stretch map, enhance.c:1685-1706
   const double gamma=perceptible_reciprocal(white-black);
-  for (int k=0; k < PER; k++)
-    {
-      const int j=t*PER+k;
-      double v=0.0;
-      if (j < black_s)
-        v=0.0;
-      else if (j > white_s)
-        v=65535.0;
-      else if (black != white)
-        v=lut_scale_map_to_quantum((double) (65535.0*gamma*((double) j-black)),a.is_u16);
-      if (a.is_u16)
-        lut16[(size_t) j*C+c]=(unsigned short) v;
-      else
-        lut32[(size_t) j*C+c]=(float) v;
-    }
-  if ((t == 0) && (black != white))
+  double v=0.0;
+  if (j < black_i)
+    v=0.0;
+  else if (j > white_i)
+    v=65535.0;
+  else if (black != white)
+    v=lut_scale_map_to_quantum((double) (65535.0*gamma*((double) j-black)),a.is_u16);
+  lut_store(a,j,c,v);
+  if ((j == 0) && (black != white))
     atomicOr(a.mask,1u<<c);
 }
 
@@ -796,9 +998,15 @@ MhStatus launch_build_lut(const View &img,const unsigned long long *hist,bool eq
   a.lut=lut;
   a.mask=mask;
   a.colour_flag=colour_flag;
+  Temp scratch;
+  MH_TRY(scratch.alloc(img.device,sizeof(LutScratch),img.stream));
   MH_HIP(hipMemsetAsync(mask,0,sizeof(uint32_t),img.stream));
+  const dim3 grid((unsigned) img.channels,kLutChunks);
   ProfileScope prof("build_lut",img.stream);
-  hipLaunchKernelGGL(build_lut_kernel,dim3((unsigned) img.channels),dim3(1024),0,img.stream,a);
+  hipLaunchKernelGGL(lut_chunk_sums_kernel,grid,dim3(1024),0,img.stream,a,scratch.as<LutScratch>());
+  hipLaunchKernelGGL(lut_scan_kernel,grid,dim3(1024),0,img.stream,a,scratch.as<LutScratch>());
+  if (!equalize)
+    hipLaunchKernelGGL(lut_stretch_map_kernel,grid,dim3(1024),0,img.stream,a,scratch.as<LutScratch>());
   MH_HIP(hipGetLastError());
   return MH_OK;
 }
@@ -807,7 +1015,7 @@ MhStatus launch_build_lut(const View &img,const unsigned long long *hist,bool eq
 template<typename Q,int C>
 __global__ __launch_bounds__(256)
 void apply_lut_kernel(Q *pixels,size_t npixels,const Q *lut,uint32_t mask,
-  const uint32_t *device_mask)
+  const uint32_t *device_mask,int lut_stride,int column_step)
 {
   if (device_mask != nullptr)
     mask&=*device_mask;                 // uniform: written by build_lut_kernel earlier in the stream
@@ -821,19 +1029,20 @@ void apply_lut_kernel(Q *pixels,size_t npixels,const Q *lut,uint32_t mask,
 #pragma unroll
       for (int c=0; c < C; c++)
         if ((mask >> c) & 1u)
-          q[c]=lut[(size_t) QuantumOps<Q>::map_index(q[c])*C+c];
+          q[c]=lut[(size_t) QuantumOps<Q>::map_index(q[c])*lut_stride+c*column_step];
       store_pixel<Q,C>(pixels+i*C,q);
     }
 }
 
 template<typename Q,int C>
 static MhStatus apply_lut_typed(const View &img,const void *lut,uint32_t mask,
-  const uint32_t *device_mask)
+  const uint32_t *device_mask,bool single_column=false,const char *label="apply_lut")
 {
   const size_t n=img.columns*img.rows;
-  ProfileScope prof("apply_lut",img.stream);
+  ProfileScope prof(label,img.stream);
   hipLaunchKernelGGL((apply_lut_kernel<Q,C>),dim3(stream_grid(n)),dim3(256),0,img.stream,
-    static_cast<Q *>(img.pixels),n,static_cast<const Q *>(lut),mask,device_mask);
+    static_cast<Q *>(img.pixels),n,static_cast<const Q *>(lut),mask,device_mask,
+    single_column ? 1 : C,single_column ? 0 : 1);
   MH_HIP(hipGetLastError());
   return MH_OK;
 }
@@ -845,7 +1054,7 @@ static MhStatus apply_lut_typed(const View &img,const void *lut,uint32_t mask,
 template<int C>
 __global__ __launch_bounds__(1024)
 void apply_lut_shared_kernel(uint16_t *pixels,size_t npixels,const uint16_t *lut,int column,uint32_t mask,
-  const uint32_t *device_mask)
+  const uint32_t *device_mask,int lut_stride)
 {
   if (device_mask != nullptr)
     mask&=*device_mask;
@@ -854,7 +1063,7 @@ void apply_lut_shared_kernel(uint16_t *pixels,size_t npixels,const uint16_t *lut
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint16_t *table=reinterpret_cast<uint16_t *>(smem_raw);
   for (int i=(int) threadIdx.x; i < 65536; i+=1024)
-    table[i]=lut[(size_t) i*C+column];
+    table[i]=lut[(size_t) i*lut_stride+column];
   __syncthreads();
   constexpr int BATCH=4;
   const size_t stride=(size_t) gridDim.x*1024*BATCH;
@@ -885,16 +1094,17 @@ void apply_lut_shared_kernel(uint16_t *pixels,size_t npixels,const uint16_t *lut
 
 template<int C>
 static MhStatus apply_lut_shared(const View &img,const void *lut,int column,uint32_t mask,
-  const uint32_t *device_mask)
+  const uint32_t *device_mask,bool single_column=false,const char *label="apply_lut")
 {
   const size_t n=img.columns*img.rows;
   const int cus=compute_units(img.device);
   const size_t lds=65536*sizeof(uint16_t);
   MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&apply_lut_shared_kernel<C>),
     hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
-  ProfileScope prof("apply_lut",img.stream);
+  ProfileScope prof(label,img.stream);
   hipLaunchKernelGGL((apply_lut_shared_kernel<C>),dim3(cus),dim3(1024),lds,img.stream,
-    static_cast<uint16_t *>(img.pixels),n,static_cast<const uint16_t *>(lut),column,mask,device_mask);
+    static_cast<uint16_t *>(img.pixels),n,static_cast<const uint16_t *>(lut),single_column ? 0 : column,mask,
+    device_mask,single_column ? 1 : C);
   MH_HIP(hipGetLastError());
   return MH_OK;
 }
@@ -924,6 +1134,16 @@ MhStatus launch_apply_lut(const View &img,const void *lut,uint32_t apply_mask,co
 #undef MH_CASE
 }
 
+
+// one 65536-entry Quantum column applied to the masked channels of a Q16 image
+static MhStatus apply_q16_column(const View &img,const uint16_t *column,uint32_t mask,const char *label)
+{
+  if (img.columns*img.rows >= ((size_t) 1 << 20))
+    return img.channels == 3 ? apply_lut_shared<3>(img,column,0,mask,nullptr,true,label) :
+      apply_lut_shared<4>(img,column,0,mask,nullptr,true,label);
+  return img.channels == 3 ? apply_lut_typed<uint16_t,3>(img,column,mask,nullptr,true,label) :
+    apply_lut_typed<uint16_t,4>(img,column,mask,nullptr,true,label);
+}
 
 // ---------------------------------------------------------------- GrayscaleImage
 // enhance.c:2476-2660: the intensity of (R,G,B) by `method` is written to the Gray

@@ -527,6 +527,7 @@ MH_API void MhTerminus(void)
   drain_profile();
   pool_trim();
   staging_trim();
+  release_color_tables();
 }
 
 MH_API int MhDeviceCount(void) { return device_count(); }
