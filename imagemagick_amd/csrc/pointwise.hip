@@ -169,8 +169,10 @@ static __device__ void xyz_to_rgb(double X,double Y,double Z,double &red,double 
 // ULP the Lab tests allow for float Quantum.
 static __device__ __forceinline__ double cube_root(double t)
 {
-  double y=(double) cbrtf((float) t);
-  const double inv=(double) (1.0f/(3.0f*(float) y*(float) y));
+  // seed: 2^(log2(t)/3) on the transcendental unit (~1e-6 relative), not libm's cbrtf
+  const float seed=__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float) t)*0.333333343f);
+  double y=(double) seed;
+  const double inv=(double) __builtin_amdgcn_rcpf(3.0f*seed*seed);
 #pragma unroll
   for (int it=0; it < 2; it++)
     {
@@ -183,45 +185,63 @@ static __device__ __forceinline__ double cube_root(double t)
   return y;
 }
 
+// x/d for a compile-time constant d without the division sequence: q=RN(x*RN(1/d)) refined
+// twice with exact FMA residuals.  After the first refinement q is a faithful quotient, and
+// a faithful quotient corrected once more by r*RN(1/d) is the correctly rounded one
+// (Markstein's theorem; needs a significand of d that is not all ones — true of every
+// constant used here), i.e. the same double the reference's `/` produces.  Non-finite
+// quotients pass through unrefined (inf-inf would turn them into NaN).
+static __device__ __forceinline__ double div_const(double x,const double d,const double y)
+{
+  double q=x*y;
+  double r=__builtin_fma(-d,q,x);
+  double q1=__builtin_fma(r,y,q);
+  r=__builtin_fma(-d,q1,x);
+  q1=__builtin_fma(r,y,q1);
+  return __builtin_isfinite(q) ? q1 : q;
+}
+#define MH_DIV(x,d) div_const((x),(d),1.0/(d))
+
 // ConvertXYZToLab, colorspace-private.h:1066-1089
 static __device__ void xyz_to_lab(double X,double Y,double Z,double &L,double &a,double &b)
 {
   double x,y,z;
-  if ((X/MH_ILL_X) > MH_CIE_EPSILON)
-    x=cube_root(X/MH_ILL_X);
+  const double xr=MH_DIV(X,MH_ILL_X),yr=Y,zr=MH_DIV(Z,MH_ILL_Z);     // Y/1.0 is Y
+  if (xr > MH_CIE_EPSILON)
+    x=cube_root(xr);
   else
-    x=(MH_CIE_K*X/MH_ILL_X+16.0)/116.0;
-  if ((Y/MH_ILL_Y) > MH_CIE_EPSILON)
-    y=cube_root(Y/MH_ILL_Y);
+    x=MH_DIV(MH_DIV(MH_CIE_K*X,MH_ILL_X)+16.0,116.0);
+  if (yr > MH_CIE_EPSILON)
+    y=cube_root(yr);
   else
-    y=(MH_CIE_K*Y/MH_ILL_Y+16.0)/116.0;
-  if ((Z/MH_ILL_Z) > MH_CIE_EPSILON)
-    z=cube_root(Z/MH_ILL_Z);
+    y=MH_DIV(MH_CIE_K*Y+16.0,116.0);
+  if (zr > MH_CIE_EPSILON)
+    z=cube_root(zr);
   else
-    z=(MH_CIE_K*Z/MH_ILL_Z+16.0)/116.0;
-  L=((116.0*y)-16.0)/100.0;
-  a=(500.0*(x-y))/255.0+0.5;
-  b=(200.0*(y-z))/255.0+0.5;
+    z=MH_DIV(MH_DIV(MH_CIE_K*Z,MH_ILL_Z)+16.0,116.0);
+  L=MH_DIV((116.0*y)-16.0,100.0);
+  a=MH_DIV(500.0*(x-y),255.0)+0.5;
+  b=MH_DIV(200.0*(y-z),255.0)+0.5;
 }
 
 // ConvertLabToXYZ, colorspace-private.h:531-557
 static __device__ void lab_to_xyz(double L,double a,double b,double &X,double &Y,double &Z)
 {
-  double y=(L+16.0)/116.0;
-  double x=y+a/500.0;
-  double z=y-b/200.0;
+  double y=MH_DIV(L+16.0,116.0);
+  double x=y+MH_DIV(a,500.0);
+  double z=y-MH_DIV(b,200.0);
   if ((x*x*x) > MH_CIE_EPSILON)
     x=(x*x*x);
   else
-    x=(116.0*x-16.0)/MH_CIE_K;
+    x=MH_DIV(116.0*x-16.0,MH_CIE_K);
   if (L > (MH_CIE_K*MH_CIE_EPSILON))
     y=(y*y*y);
   else
-    y=L/MH_CIE_K;
+    y=MH_DIV(L,MH_CIE_K);
   if ((z*z*z) > MH_CIE_EPSILON)
     z=(z*z*z);
   else
-    z=(116.0*z-16.0)/MH_CIE_K;
+    z=MH_DIV(116.0*z-16.0,MH_CIE_K);
   X=MH_ILL_X*x;
   Y=MH_ILL_Y*y;
   Z=MH_ILL_Z*z;
@@ -249,47 +269,81 @@ void colorspace_table_kernel(double *decode_scaled,uint16_t *decode_q16,uint16_t
   encode_q16[j]=QuantumOps<uint16_t>::clamp(encode_pixel_gamma((double) j));
 }
 
+// Pointwise kernels keep kPointBatch pixels per lane in flight: with one 8-byte load per lane
+// the latency of the load -> (gather ->) compute -> store chain, not HBM, sets the rate
+// (measured 1.2 TB/s for the Lab kernel before batching).
+constexpr int kPointBatch=4;
+
 template<int C,int OP>
 __global__ __launch_bounds__(256)
-void colorspace_q16_table_kernel(uint16_t *pixels,size_t npixels,const double *decode_scaled)
+void colorspace_q16_table_kernel(uint16_t *__restrict__ pixels,size_t npixels,
+  const double *__restrict__ decode_scaled)
 {
-  const size_t stride=(size_t) gridDim.x*blockDim.x;
-  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
+  const size_t stride=(size_t) gridDim.x*blockDim.x*kPointBatch;
+  for (size_t i0=(size_t) blockIdx.x*blockDim.x*kPointBatch+threadIdx.x; i0 < npixels; i0+=stride)
     {
-      uint16_t q[C];
-      load_pixel<uint16_t,C>(pixels+i*C,q);
+      uint16_t q[kPointBatch][C];
+#pragma unroll
+      for (int k=0; k < kPointBatch; k++)
+        {
+          const size_t i=i0+(size_t) k*blockDim.x;
+          load_pixel<uint16_t,C>(pixels+(i < npixels ? i : npixels-1)*C,q[k]);
+        }
       // ConvertRGBToXYZ, colorspace-private.h:759-779, with the three decodes looked up
-      const double r=decode_scaled[q[0]],g=decode_scaled[q[1]],b=decode_scaled[q[2]];
-      const double X=(0.4123955889674142161*r)+(0.3575834307637148171*g)+(0.1804926473817015735*b);
-      const double Y=(0.2125862307855955516*r)+(0.7151703037034108499*g)+(0.07220049864333622685*b);
-      const double Z=(0.01929721549174694484*r)+(0.1191838645808485318*g)+(0.9504971251315797660*b);
-      double o0,o1,o2;
-      if constexpr (OP == OP_SRGB_TO_LAB)
+      double r[kPointBatch],g[kPointBatch],b[kPointBatch];
+#pragma unroll
+      for (int k=0; k < kPointBatch; k++)
         {
-          double L,a,bb;
-          xyz_to_lab(X,Y,Z,L,a,bb);
-          o0=kQR*L; o1=kQR*a; o2=kQR*bb;
+          r[k]=decode_scaled[q[k][0]];
+          g[k]=decode_scaled[q[k][1]];
+          b[k]=decode_scaled[q[k][2]];
         }
-      else
+#pragma unroll
+      for (int k=0; k < kPointBatch; k++)
         {
-          o0=kQR*X; o1=kQR*Y; o2=kQR*Z;
+          const double X=(0.4123955889674142161*r[k])+(0.3575834307637148171*g[k])+(0.1804926473817015735*b[k]);
+          const double Y=(0.2125862307855955516*r[k])+(0.7151703037034108499*g[k])+(0.07220049864333622685*b[k]);
+          const double Z=(0.01929721549174694484*r[k])+(0.1191838645808485318*g[k])+(0.9504971251315797660*b[k]);
+          double o0,o1,o2;
+          if constexpr (OP == OP_SRGB_TO_LAB)
+            {
+              double L,a,bb;
+              xyz_to_lab(X,Y,Z,L,a,bb);
+              o0=kQR*L; o1=kQR*a; o2=kQR*bb;
+            }
+          else
+            {
+              o0=kQR*X; o1=kQR*Y; o2=kQR*Z;
+            }
+          q[k][0]=QuantumOps<uint16_t>::clamp(o0);
+          q[k][1]=QuantumOps<uint16_t>::clamp(o1);
+          q[k][2]=QuantumOps<uint16_t>::clamp(o2);
+          const size_t i=i0+(size_t) k*blockDim.x;
+          if (i < npixels)
+            store_pixel<uint16_t,C>(pixels+i*C,q[k]);
         }
-      q[0]=QuantumOps<uint16_t>::clamp(o0);
-      q[1]=QuantumOps<uint16_t>::clamp(o1);
-      q[2]=QuantumOps<uint16_t>::clamp(o2);
-      store_pixel<uint16_t,C>(pixels+i*C,q);
     }
 }
 
 template<typename Q,int C,int OP>
 __global__ __launch_bounds__(256)
-void colorspace_kernel(Q *pixels,size_t npixels)
+void colorspace_kernel(Q *__restrict__ pixels,size_t npixels)
 {
-  const size_t stride=(size_t) gridDim.x*blockDim.x;
-  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
+  const size_t stride=(size_t) gridDim.x*blockDim.x*kPointBatch;
+  for (size_t i0=(size_t) blockIdx.x*blockDim.x*kPointBatch+threadIdx.x; i0 < npixels; i0+=stride)
     {
-      Q q[C];
-      load_pixel<Q,C>(pixels+i*C,q);
+      Q qb[kPointBatch][C];
+#pragma unroll
+      for (int k=0; k < kPointBatch; k++)
+        {
+          const size_t ik=i0+(size_t) k*blockDim.x;
+          load_pixel<Q,C>(pixels+(ik < npixels ? ik : npixels-1)*C,qb[k]);
+        }
+#pragma unroll
+      for (int k=0; k < kPointBatch; k++)
+    {
+      const size_t i=i0+(size_t) k*blockDim.x;
+      Q (&q)[C]=qb[k];
       double r=(double) q[0],g=(double) q[1],b=(double) q[2];
       double o0,o1,o2;
       if constexpr (OP == OP_SRGB_TO_RGB)
@@ -331,7 +385,9 @@ void colorspace_kernel(Q *pixels,size_t npixels)
       q[0]=QuantumOps<Q>::clamp(o0);
       q[1]=QuantumOps<Q>::clamp(o1);
       q[2]=QuantumOps<Q>::clamp(o2);
-      store_pixel<Q,C>(pixels+i*C,q);
+      if (i < npixels)
+        store_pixel<Q,C>(pixels+i*C,q);
+    }
     }
 }
 
@@ -350,7 +406,7 @@ static MhStatus colorspace_typed(const View &img,int op)
 {
   const size_t n=img.columns*img.rows;
   Q *p=static_cast<Q *>(img.pixels);
-  dim3 grid(stream_grid(n)),block(256);
+  dim3 grid(stream_grid((n+kPointBatch-1)/kPointBatch)),block(256);
   ProfileScope prof("colorspace",img.stream);
   switch (op)
   {
@@ -429,7 +485,7 @@ static MhStatus colorspace_step(const View &img,int op)
         }
       const size_t n=img.columns*img.rows;
       uint16_t *p=static_cast<uint16_t *>(img.pixels);
-      dim3 grid(stream_grid(n)),block(256);
+      dim3 grid(stream_grid((n+kPointBatch-1)/kPointBatch)),block(256);
       ProfileScope prof("colorspace",img.stream);
       if (img.channels == 3)
         {
