@@ -360,14 +360,32 @@ bool same_kernel(const MhKernelInfo *a,const MhKernelInfo *b)
   return true;
 }
 
-// ExpandRotateKernelInfo, morphology.c:2424-2450: append rotated clones until
-// the rotation returns to the first kernel.
+MhKernelInfo *clone_chain(const MhKernelInfo *k)
+{
+  MhKernelInfo *head=nullptr,*tail=nullptr;
+  for (; k != nullptr; k=k->next)
+    {
+      MhKernelInfo *c=clone_one(k);
+      if (c == nullptr)
+        {
+          destroy_chain(head);
+          return nullptr;
+        }
+      if (head == nullptr) head=c; else tail->next=c;
+      tail=c;
+    }
+  return head;
+}
+
+// ExpandRotateKernelInfo, morphology.c:2424-2450: append rotated clones (of the whole
+// list from the last appended group on, as CloneKernelInfo clones a chain) until the
+// rotation returns to the first kernel.
 void expand_rotate(MhKernelInfo *kernel,double angle)
 {
   MhKernelInfo *last=kernel;
   for (int guard=0; guard < 16; guard++)
     {
-      MhKernelInfo *c=clone_one(last);
+      MhKernelInfo *c=clone_chain(last);
       if (c == nullptr)
         return;
       rotate_kernel(c,angle);
@@ -376,6 +394,23 @@ void expand_rotate(MhKernelInfo *kernel,double angle)
           destroy_chain(c);
           return;
         }
+      last_kernel(last)->next=c;
+      last=c;
+    }
+}
+
+// ExpandMirrorKernelInfo, morphology.c:2332-2361: the list, its 180-degree rotation,
+// the transpose of that, and the 180-degree rotation of the transpose.
+void expand_mirror(MhKernelInfo *kernel)
+{
+  const double angles[3]={180.0,90.0,180.0};
+  MhKernelInfo *last=kernel;
+  for (double angle : angles)
+    {
+      MhKernelInfo *c=clone_chain(last);
+      if (c == nullptr)
+        return;
+      rotate_kernel(c,angle);
       last_kernel(last)->next=c;
       last=c;
     }
@@ -472,6 +507,8 @@ MhKernelInfo *parse_array(const std::string &text)
     expand_rotate(k,45.0);
   else if ((g.flags & kGreater) != 0)
     expand_rotate(k,90.0);
+  else if ((g.flags & kLess) != 0)
+    expand_mirror(k);
   return k;
 }
 
@@ -512,6 +549,128 @@ MhKernelInfo *constant_kernel(MhKernelInfoType type,const char *array,double ang
     return nullptr;
   k->type=type;
   rotate_kernel(k,angle);
+  return k;
+}
+
+MhKernelInfo *acquire_kernel_list(const char *kernel_string);
+
+void retype_chain(MhKernelInfo *k,MhKernelInfoType type)
+{
+  for (; k != nullptr; k=k->next)
+    k->type=type;
+}
+
+// 3x3 hit-and-miss structuring element from 9 cells in raster order:
+// '1' foreground, '0' background, '-' don't care (NaN); origin at the centre.
+MhKernelInfo *structuring_element(MhKernelInfoType type,const char *cells)
+{
+  MhKernelInfo *k=new_kernel(type,3,3);
+  if (k == nullptr)
+    return nullptr;
+  k->x=k->y=1;
+  for (int i=0; i < 9; i++)
+    k->values[i]=cells[i] == '-' ? std::numeric_limits<double>::quiet_NaN() :
+      (cells[i] == '1' ? 1.0 : 0.0);
+  calc_meta(k);
+  return k;
+}
+
+// The thinning structuring elements of D. S. Bloomberg, "Connectivity-Preserving
+// Morphological Image Transformations" (SE_4_n -> 4n, SE_8_n -> 8n, the combined ones
+// 423/823/481/482), as ThinSE:<id> names them (morphology.c:1998-2087).
+struct ThinElement { int id; const char *cells; };
+const ThinElement kThinElements[]={
+  {41,"--10-1--1"},{42,"--10-1-0-"},{43,"-0-0-1--1"},{44,"-0-0-1-0-"},{45,"-010-1-0-"},
+  {46,"-0-0-1-01"},{47,"-110-1-0-"},{48,"--10-10-1"},{49,"0-10-1--1"},
+  {81,"-1-0-1-1-"},{82,"-1-0-10--"},{83,"0--0-1-1-"},{84,"0--0-10--"},{85,"0-10-10--"},
+  {86,"0--0-10-1"},{87,"-1-0-100-"},{88,"-1-0-101-"},{89,"01-0-1-1-"},
+  {423,"--10---0-"},{823,"-1---10--"},{481,"-110-100-"},{482,"0-10-10-1"}
+};
+
+MhKernelInfo *thin_element(MhKernelInfoType type,int id,double angle)
+{
+  const char *cells="0-10-10-1";                  // 482, also the default
+  for (const ThinElement &e : kThinElements)
+    if (e.id == id)
+      cells=e.cells;
+  MhKernelInfo *k=structuring_element(type,cells);
+  if (k != nullptr)
+    rotate_kernel(k,angle);
+  return k;
+}
+
+// a list of structuring elements given as cell strings, typed `type`
+MhKernelInfo *element_list(MhKernelInfoType type,std::initializer_list<const char *> cells)
+{
+  MhKernelInfo *head=nullptr;
+  for (const char *c : cells)
+    {
+      MhKernelInfo *k=structuring_element(type,c);
+      if (k == nullptr)
+        {
+          destroy_chain(head);
+          return nullptr;
+        }
+      if (head == nullptr) head=k; else last_kernel(head)->next=k;
+    }
+  return head;
+}
+
+MhKernelInfo *array_typed(MhKernelInfoType type,const char *array)
+{
+  MhKernelInfo *k=parse_array(array);
+  if (k != nullptr)
+    k->type=type;
+  return k;
+}
+
+// FreiChen, morphology.c:1416-1538: Sobel-like edge kernels with sqrt(2) weights and
+// the nine-kernel orthogonal basis (11..19)
+MhKernelInfo *frei_chen(const Geometry &args)
+{
+  const double sq2=1.41421356237309504880168872420969807856967187537695;
+  const MhKernelInfoType type=MH_KERNEL_FREICHEN;
+  MhKernelInfo *k=nullptr;
+  struct Patch { int index; double value; };
+  auto build=[&](const char *array,std::initializer_list<Patch> patches,bool recalc,double scale)
+  {
+    MhKernelInfo *r=array_typed(type,array);
+    if (r == nullptr)
+      return r;
+    for (const Patch &p : patches)
+      r->values[p.index]=p.value;
+    if (recalc)
+      calc_meta(r);
+    if (scale != 0.0)
+      scale_kernel(r,scale,0u);
+    return r;
+  };
+  const double half_sq2=(double) (1.0/2.0*sq2);
+  switch ((int) args.rho)
+  {
+    default:
+    case 0: k=build("3: 1,0,-1  2,0,-2  1,0,-1",{{3,sq2},{5,-sq2}},true,0.0); break;
+    case 2: k=build("3: 1,2,0  2,0,-2  0,-2,-1",{{1,sq2},{3,sq2},{5,-sq2},{7,-sq2}},true,half_sq2); break;
+    case 10:
+      return acquire_kernel_list("FreiChen:11;FreiChen:12;FreiChen:13;FreiChen:14;FreiChen:15;"
+        "FreiChen:16;FreiChen:17;FreiChen:18;FreiChen:19");
+    case 1:
+    case 11: k=build("3: 1,0,-1  2,0,-2  1,0,-1",{{3,sq2},{5,-sq2}},true,half_sq2); break;
+    case 12: k=build("3: 1,2,1  0,0,0  1,2,1",{{1,sq2},{7,sq2}},true,half_sq2); break;
+    case 13: k=build("3: 2,-1,0  -1,0,1  0,1,-2",{{0,sq2},{8,-sq2}},true,half_sq2); break;
+    case 14: k=build("3: 0,1,-2  -1,0,1  2,-1,0",{{2,-sq2},{6,sq2}},true,half_sq2); break;
+    case 15: k=build("3: 0,-1,0  1,0,1  0,-1,0",{},false,1.0/2.0); break;
+    case 16: k=build("3: 1,0,-1  0,0,0  -1,0,1",{},false,1.0/2.0); break;
+    case 17: k=build("3: 1,-2,1  -2,4,-2  -1,-2,1",{},false,1.0/6.0); break;
+    case 18: k=build("3: -2,1,-2  1,4,1  -2,1,-2",{},false,1.0/6.0); break;
+    case 19: k=build("3: 1,1,1  1,1,1  1,1,1",{},false,1.0/3.0); break;
+  }
+  if (k == nullptr)
+    return nullptr;
+  if (fabs(args.sigma) >= kEpsilon)
+    rotate_kernel(k,args.sigma);                   // the angle argument
+  else if ((args.rho > 30.0) || (args.rho < -30.0))
+    rotate_kernel(k,args.rho);                     // an out-of-range 'type' is an angle
   return k;
 }
 
@@ -678,7 +837,13 @@ MhKernelInfo *builtin(MhKernelInfoType type,const Geometry &args)
         case 1: array="3: 0,-1,0  -1,4,-1  0,-1,0"; break;
         case 2: array="3: -2,1,-2  1,4,1  -2,1,-2"; break;
         case 3: array="3: 1,-2,1  -2,4,-2  1,-2,1"; break;
-        case 5: case 7: case 15: case 19: return nullptr;   // larger constants: not built here
+        case 5: array="5: -4,-1,0,-1,-4  -1,2,3,2,-1  0,3,4,3,0  -1,2,3,2,-1  -4,-1,0,-1,-4"; break;
+        case 7: array="7:-10,-5,-2,-1,-2,-5,-10 -5,0,3,4,3,0,-5 -2,3,6,7,6,3,-2 -1,4,7,8,7,4,-1 "
+          "-2,3,6,7,6,3,-2 -5,0,3,4,3,0,-5 -10,-5,-2,-1,-2,-5,-10"; break;
+        case 15: array="5: 0,0,-1,0,0  0,-1,-2,-1,0  -1,-2,16,-2,-1  0,-1,-2,-1,0  0,0,-1,0,0"; break;
+        case 19: array="9: 0,-1,-1,-2,-2,-2,-1,-1,0  -1,-2,-4,-5,-5,-5,-4,-2,-1  -1,-4,-5,-3,-0,-3,-5,-4,-1  "
+          "-2,-5,-3,12,24,12,-3,-5,-2  -2,-5,-0,24,40,24,-0,-5,-2  -2,-5,-3,12,24,12,-3,-5,-2  "
+          "-1,-4,-5,-3,-0,-3,-5,-4,-1  -1,-2,-4,-5,-5,-5,-4,-2,-1  0,-1,-1,-2,-2,-2,-1,-1,0"; break;
         default: array="3: -1,-1,-1  -1,8,-1  -1,-1,-1"; break;
       }
       k=parse_array(array);
@@ -879,6 +1044,125 @@ MhKernelInfo *builtin(MhKernelInfoType type,const Geometry &args)
       k->maximum=k->values[0];
       break;
     }
+    case MH_KERNEL_FREICHEN:
+      return frei_chen(args);
+    // ---- hit-and-miss kernel sets, morphology.c:1748-2087
+    case MH_KERNEL_THINSE:
+      return thin_element(type,(int) args.rho,args.sigma);
+    case MH_KERNEL_EDGES:
+      k=thin_element(type,482,0.0);
+      if (k == nullptr) return nullptr;
+      expand_mirror(k);
+      return k;
+    case MH_KERNEL_CORNERS:
+      k=thin_element(type,87,0.0);
+      if (k == nullptr) return nullptr;
+      expand_rotate(k,90.0);
+      return k;
+    case MH_KERNEL_DIAGONALS:
+      switch ((int) args.rho)
+      {
+        case 1: k=structuring_element(type,"0000-111-"); break;
+        case 2: k=structuring_element(type,"0010-101-"); break;
+        default:
+          k=element_list(type,{"0000-111-","0010-101-"});
+          if (k == nullptr) return nullptr;
+          expand_mirror(k);
+          return k;
+      }
+      if (k == nullptr) return nullptr;
+      rotate_kernel(k,args.sigma);
+      return k;
+    case MH_KERNEL_LINEENDS:
+      switch ((int) args.rho)
+      {
+        case 1: k=structuring_element(type,"00-01100-"); break;    // 4-connected line ends
+        case 2: k=structuring_element(type,"000010001"); break;    // added for 8-connected lines
+        case 3: k=structuring_element(type,"000011000"); break;    // orthogonal ends only
+        case 4: k=structuring_element(type,"00001-00-"); break;    // traditional
+        default: return acquire_kernel_list("LineEnds:1>;LineEnds:2>");
+      }
+      if (k == nullptr) return nullptr;
+      rotate_kernel(k,args.sigma);
+      return k;
+    case MH_KERNEL_LINEJUNCTIONS:
+      switch ((int) args.rho)
+      {
+        case 1: k=structuring_element(type,"1-1-1--1-"); break;    // Y
+        case 2: k=structuring_element(type,"1---1-1-1"); break;    // diagonal T
+        case 3: k=structuring_element(type,"---111-1-"); break;    // orthogonal T
+        case 4: k=structuring_element(type,"1-1-1-1-1"); break;    // diagonal X
+        case 5: k=structuring_element(type,"-1-111-1-"); break;    // orthogonal X
+        default: return acquire_kernel_list("LineJunctions:1@;LineJunctions:2>");
+      }
+      if (k == nullptr) return nullptr;
+      rotate_kernel(k,args.sigma);
+      return k;
+    case MH_KERNEL_RIDGES:
+      if ((int) args.rho == 2)
+        {
+          k=array_typed(type,"4x1:0,1,1,0");
+          if (k == nullptr) return nullptr;
+          expand_rotate(k,90.0);
+          // the stepped 'thick' lines: listed explicitly, a non-square kernel cannot
+          // be rotated
+          static const char *const kSteps[]={
+            "4x3+1+1:0,1,1,- -,1,1,- -,1,1,0","4x3+2+1:0,1,1,- -,1,1,- -,1,1,0",
+            "4x3+1+1:-,1,1,0 -,1,1,- 0,1,1,-","4x3+2+1:-,1,1,0 -,1,1,- 0,1,1,-",
+            "3x4+1+1:0,-,- 1,1,1 1,1,1 -,-,0","3x4+1+2:0,-,- 1,1,1 1,1,1 -,-,0",
+            "3x4+1+1:-,-,0 1,1,1 1,1,1 0,-,-","3x4+1+2:-,-,0 1,1,1 1,1,1 0,-,-"};
+          for (const char *step : kSteps)
+            {
+              MhKernelInfo *n=array_typed(type,step);
+              if (n == nullptr)
+                {
+                  destroy_chain(k);
+                  return nullptr;
+                }
+              last_kernel(k)->next=n;
+            }
+          return k;
+        }
+      k=array_typed(type,"3x1:0,1,0");
+      if (k == nullptr) return nullptr;
+      expand_rotate(k,90.0);
+      return k;
+    case MH_KERNEL_CONVEXHULL:
+    {
+      k=structuring_element(type,"11-10-1-0");
+      if (k == nullptr) return nullptr;
+      expand_rotate(k,90.0);
+      MhKernelInfo *mirror=structuring_element(type,"11110---0");
+      if (mirror == nullptr)
+        {
+          destroy_chain(k);
+          return nullptr;
+        }
+      expand_rotate(mirror,90.0);
+      last_kernel(k)->next=mirror;
+      return k;
+    }
+    case MH_KERNEL_SKELETON:
+      switch ((int) args.rho)
+      {
+        case 2:
+          k=acquire_kernel_list("ThinSE:482; ThinSE:87x90;");
+          if (k == nullptr) return nullptr;
+          retype_chain(k,type);
+          expand_rotate(k,90.0);
+          return k;
+        case 3:
+          k=acquire_kernel_list("ThinSE:41; ThinSE:42; ThinSE:43");
+          if (k == nullptr) return nullptr;
+          retype_chain(k,type);
+          expand_mirror(k);
+          return k;
+        default:
+          k=thin_element(type,482,0.0);
+          if (k == nullptr) return nullptr;
+          expand_rotate(k,45.0);
+          return k;
+      }
     default:
       return nullptr;
   }
@@ -944,6 +1228,43 @@ MhKernelInfo *parse_named(const std::string &text)
     }
   return k;
 }
+
+// AcquireKernelInfo, morphology.c:485-560: a ';'-separated list of kernels
+MhKernelInfo *acquire_kernel_list(const char *kernel_string)
+{
+  if (kernel_string == nullptr)
+    return nullptr;
+  MhKernelInfo *head=nullptr;
+  std::string all(kernel_string);
+  size_t pos=0;
+  while (pos <= all.size())
+    {
+      size_t semi=all.find(';',pos);
+      std::string part=all.substr(pos,semi == std::string::npos ? std::string::npos : semi-pos);
+      pos=semi == std::string::npos ? all.size()+1 : semi+1;
+      size_t b=0;
+      while ((b < part.size()) && (isspace((unsigned char) part[b]) || (part[b] == '\'')))
+        b++;
+      part=part.substr(b);
+      while (!part.empty() && (isspace((unsigned char) part.back()) || (part.back() == '\'')))
+        part.pop_back();
+      if (part.empty())
+        continue;
+      MhKernelInfo *k=isalpha((unsigned char) part[0]) ? parse_named(part) : parse_array(part);
+      if (k == nullptr)
+        {
+          destroy_chain(head);
+          mh::set_error("cannot build kernel `%s'",part.c_str());
+          return nullptr;
+        }
+      if (head == nullptr)
+        head=k;
+      else
+        last_kernel(head)->next=k;
+    }
+  return head;
+}
+
 
 } // namespace
 
@@ -1030,37 +1351,7 @@ MH_API size_t MhGetOptimalKernelWidth2D(double radius,double sigma)
 
 MH_API MhKernelInfo *MhAcquireKernelInfo(const char *kernel_string)
 {
-  if (kernel_string == nullptr)
-    return nullptr;
-  MhKernelInfo *head=nullptr;
-  std::string all(kernel_string);
-  size_t pos=0;
-  while (pos <= all.size())
-    {
-      size_t semi=all.find(';',pos);
-      std::string part=all.substr(pos,semi == std::string::npos ? std::string::npos : semi-pos);
-      pos=semi == std::string::npos ? all.size()+1 : semi+1;
-      size_t b=0;
-      while ((b < part.size()) && (isspace((unsigned char) part[b]) || (part[b] == '\'')))
-        b++;
-      part=part.substr(b);
-      while (!part.empty() && (isspace((unsigned char) part.back()) || (part.back() == '\'')))
-        part.pop_back();
-      if (part.empty())
-        continue;
-      MhKernelInfo *k=isalpha((unsigned char) part[0]) ? parse_named(part) : parse_array(part);
-      if (k == nullptr)
-        {
-          destroy_chain(head);
-          mh::set_error("cannot build kernel `%s'",part.c_str());
-          return nullptr;
-        }
-      if (head == nullptr)
-        head=k;
-      else
-        last_kernel(head)->next=k;
-    }
-  return head;
+  return acquire_kernel_list(kernel_string);
 }
 
 MH_API MhKernelInfo *MhDestroyKernelInfo(MhKernelInfo *kernel)

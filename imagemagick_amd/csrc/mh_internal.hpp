@@ -170,6 +170,9 @@ MhStatus launch_apply_lut(const View &img,const void *lut_device,uint32_t apply_
 MhStatus launch_build_lut(const View &img,const unsigned long long *hist_device,bool equalize,
   double black_point,double white_limit,void *lut_device,uint32_t *mask_device,
   const unsigned int *colour_flag_device);
+// CompositeImage(canvas,source,Difference|Lighten,clip_to_self,0,0) in place on the canvas
+enum { MH_COMPOSITE_DIFFERENCE=0,MH_COMPOSITE_LIGHTEN=1 };
+MhStatus launch_composite(const View &canvas,const View &source,int kind,const Roles &roles);
 void release_color_tables();          // frees the per-device transfer-function tables
 MhStatus launch_gray_check(const View &img,const MhImage *desc,unsigned int *flag_device);
 MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,const MhImage *desc);

@@ -109,10 +109,60 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
   return launch_morph2d(src,dst,p,roles,changed);
 }
 
-struct Stage { MhMorphologyMethod primitive; bool reflected; };
+// Device images MorphologyApply juggles besides the (read-only) input: the caller's
+// destination plus up to three pooled scratch images, handed out in a preference order so
+// that simple chains end in the destination without a final copy.
+struct MorphologyWorkspace
+{
+  static constexpr int kSlots=4;
+  View slot[kSlots];
+  Temp scratch[kSlots];
+  bool busy[kSlots]={false,false,false,false};
+  int order[kSlots]={0,1,2,3};
+  MorphologyWorkspace(const View &dst,bool destination_first)
+  {
+    for (int i=0; i < kSlots; i++)
+      {
+        slot[i]=dst;
+        if (i != 0)
+          slot[i].pixels=nullptr;
+      }
+    if (!destination_first)
+      {
+        order[0]=1;
+        order[1]=0;
+      }
+  }
+  MhStatus acquire(const View **out)
+  {
+    for (int k=0; k < kSlots; k++)
+      {
+        const int i=order[k];
+        if (busy[i])
+          continue;
+        if (slot[i].pixels == nullptr)
+          {
+            MH_TRY(scratch[i].alloc(slot[0].device,slot[0].bytes(),slot[0].stream));
+            slot[i].pixels=scratch[i].ptr;
+          }
+        busy[i]=true;
+        *out=&slot[i];
+        return MH_OK;
+      }
+    return fail(MH_OUT_OF_MEMORY,"morphology: more than %d images in flight",kSlots);
+  }
+  void release(const View *v)
+  {
+    for (int i=0; i < kSlots; i++)
+      if (v == &slot[i])
+        busy[i]=false;
+  }
+};
 
-// MorphologyApply, morphology.c:3634-4077, for the methods that need no
-// CompositeImage post-step.
+// MorphologyApply, morphology.c:3634-4077: the loops over method iterations, the kernel
+// list, the stages of a compound method and the kernel iterations, with the
+// CompositeImage post-steps (:3986-4013 Difference; :4016-4052 multi-kernel union) as
+// device kernels.  Distance / Voronoi (MorphologyPrimitiveDirect) are not parallel.
 static MhStatus morphology_apply(const View &src,const View &dst,const MhImage *desc,
   const Roles &roles,MhMorphologyMethod method,ptrdiff_t iterations,
   const MhKernelInfo *kernel,double bias,ptrdiff_t *changed_out)
@@ -121,47 +171,45 @@ static MhStatus morphology_apply(const View &src,const View &dst,const MhImage *
     return fail(MH_UNSUPPORTED,"morphology: zero iterations is a null operation");
   size_t kernel_limit=iterations < 0 ? (src.columns > src.rows ? src.columns : src.rows) :
     (size_t) iterations;
-  size_t method_limit=1;
-  std::vector<Stage> stages;
+  size_t method_limit=1,stage_limit=1;
+  int compose=-1;                                   // NoCompositeOp: re-iterate over the list
+  bool need_reflected=false;
   switch (method)
   {
-    case MH_MORPHOLOGY_CONVOLVE: stages={{MH_MORPHOLOGY_CONVOLVE,false}}; break;
-    case MH_MORPHOLOGY_CORRELATE: stages={{MH_MORPHOLOGY_CONVOLVE,true}}; break;
-    case MH_MORPHOLOGY_ERODE: stages={{MH_MORPHOLOGY_ERODE,false}}; break;
-    case MH_MORPHOLOGY_DILATE: stages={{MH_MORPHOLOGY_DILATE,false}}; break;
-    case MH_MORPHOLOGY_ERODE_INTENSITY: stages={{MH_MORPHOLOGY_ERODE_INTENSITY,false}}; break;
-    case MH_MORPHOLOGY_DILATE_INTENSITY: stages={{MH_MORPHOLOGY_DILATE_INTENSITY,false}}; break;
-    case MH_MORPHOLOGY_ITERATIVE_DISTANCE: stages={{MH_MORPHOLOGY_ITERATIVE_DISTANCE,false}}; break;
-    case MH_MORPHOLOGY_OPEN:
-      stages={{MH_MORPHOLOGY_ERODE,false},{MH_MORPHOLOGY_DILATE,false}}; break;
-    case MH_MORPHOLOGY_OPEN_INTENSITY:
-      stages={{MH_MORPHOLOGY_ERODE_INTENSITY,false},{MH_MORPHOLOGY_DILATE_INTENSITY,false}}; break;
-    case MH_MORPHOLOGY_CLOSE:
-      stages={{MH_MORPHOLOGY_DILATE,true},{MH_MORPHOLOGY_ERODE,true}}; break;
-    case MH_MORPHOLOGY_CLOSE_INTENSITY:
-      stages={{MH_MORPHOLOGY_DILATE_INTENSITY,true},{MH_MORPHOLOGY_ERODE_INTENSITY,true}}; break;
+    case MH_MORPHOLOGY_CONVOLVE: case MH_MORPHOLOGY_ERODE: case MH_MORPHOLOGY_DILATE:
+    case MH_MORPHOLOGY_ERODE_INTENSITY: case MH_MORPHOLOGY_DILATE_INTENSITY:
+    case MH_MORPHOLOGY_ITERATIVE_DISTANCE: case MH_MORPHOLOGY_EDGE_IN: case MH_MORPHOLOGY_EDGE_OUT:
+      break;
+    case MH_MORPHOLOGY_CORRELATE:
+      need_reflected=true;
+      break;
     case MH_MORPHOLOGY_SMOOTH:
-      stages={{MH_MORPHOLOGY_ERODE,false},{MH_MORPHOLOGY_DILATE,false},
-              {MH_MORPHOLOGY_DILATE,true},{MH_MORPHOLOGY_ERODE,true}}; break;
+      stage_limit=4;
+      need_reflected=true;
+      break;
+    case MH_MORPHOLOGY_OPEN: case MH_MORPHOLOGY_OPEN_INTENSITY: case MH_MORPHOLOGY_TOP_HAT:
+    case MH_MORPHOLOGY_EDGE:
+      stage_limit=2;
+      break;
+    case MH_MORPHOLOGY_CLOSE: case MH_MORPHOLOGY_CLOSE_INTENSITY: case MH_MORPHOLOGY_BOTTOM_HAT:
+      stage_limit=2;
+      need_reflected=true;
+      break;
     case MH_MORPHOLOGY_HIT_AND_MISS:
-    case MH_MORPHOLOGY_THINNING:
-    case MH_MORPHOLOGY_THICKEN:
-      if ((method == MH_MORPHOLOGY_HIT_AND_MISS) && (kernel->next != nullptr))
-        return fail(MH_UNSUPPORTED,"HitAndMiss with a kernel list needs a Lighten composite");
-      stages={{method,false}};
+      compose=MH_COMPOSITE_LIGHTEN;                 // union of the multi-kernel results
       method_limit=kernel_limit;
       kernel_limit=1;
       break;
+    case MH_MORPHOLOGY_THINNING: case MH_MORPHOLOGY_THICKEN:
+      method_limit=kernel_limit;                    // iterate the whole method
+      kernel_limit=1;
+      break;
     default:
-      // EdgeIn/EdgeOut/Edge/TopHat/BottomHat need CompositeImage(Difference);
-      // Distance/Voronoi are sequential (MorphologyPrimitiveDirect).
+      // Distance/Voronoi are sequential (MorphologyPrimitiveDirect)
       return fail(MH_UNSUPPORTED,"morphology method %d is not accelerated",(int) method);
   }
   std::unique_ptr<MhKernelInfo,MhKernelInfo *(*)(MhKernelInfo *)> reflected(nullptr,
     MhDestroyKernelInfo);
-  bool need_reflected=false;
-  for (const Stage &s : stages)
-    need_reflected|=s.reflected;
   if (need_reflected)
     {
       reflected.reset(MhCloneKernelInfo(kernel));
@@ -184,18 +232,19 @@ static MhStatus morphology_apply(const View &src,const View &dst,const MhImage *
   for (const MhKernelInfo *k=kernel; k != nullptr; k=k->next)
     nkernels++;
   const bool fixed_count=(kernel_limit == 1) && (method_limit == 1);
-  const size_t planned=nkernels*stages.size();
+  // a plain chain of n primitives ping-pongs between two images: start in the destination
+  // when n is odd.  Edge parks its first result and ends in the second image.
+  bool destination_first=true;
+  if (fixed_count && ((nkernels == 1) || (compose < 0)))
+    destination_first=method == MH_MORPHOLOGY_EDGE ? false : (((nkernels*stage_limit) & 1u) != 0);
+  MorphologyWorkspace ws(dst,destination_first);
 
-  Temp scratch,counter;
-  View tmp=dst;
-  tmp.pixels=nullptr;
+  Temp counter;
   MH_TRY(counter.alloc(src.device,sizeof(unsigned long long),src.stream));
   unsigned long long *changed_dev=counter.as<unsigned long long>();
-  const View *curr=&src;
-  // choose the first destination so a fixed-length chain ends in `dst`
-  bool next_is_dst=fixed_count ? ((planned & 1u) != 0) : true;
-  size_t total_changed=0;
   const bool want_counts=!fixed_count || (changed_out != nullptr);
+  const View *curr=&src,*work=nullptr,*save=nullptr,*rslt=nullptr;
+  size_t total_changed=0;
 
   size_t method_loop=0,method_changed=1;
   while ((method_loop < method_limit) && (method_changed > 0))
@@ -205,29 +254,63 @@ static MhStatus morphology_apply(const View &src,const View &dst,const MhImage *
       const MhKernelInfo *norm=kernel,*rflt=reflected.get();
       while (norm != nullptr)
         {
-          for (const Stage &stage : stages)
+          for (size_t stage_loop=1; stage_loop <= stage_limit; stage_loop++)
             {
-              const MhKernelInfo *this_kernel=stage.reflected ? rflt : norm;
+              // primitive of this stage, morphology.c:3829-3907
+              const MhKernelInfo *this_kernel=norm;
+              MhMorphologyMethod prim=method;
+              switch (method)
+              {
+                case MH_MORPHOLOGY_ERODE: case MH_MORPHOLOGY_EDGE_IN:
+                  prim=MH_MORPHOLOGY_ERODE; break;
+                case MH_MORPHOLOGY_DILATE: case MH_MORPHOLOGY_EDGE_OUT:
+                  prim=MH_MORPHOLOGY_DILATE; break;
+                case MH_MORPHOLOGY_OPEN: case MH_MORPHOLOGY_TOP_HAT:
+                  prim=stage_loop == 2 ? MH_MORPHOLOGY_DILATE : MH_MORPHOLOGY_ERODE; break;
+                case MH_MORPHOLOGY_OPEN_INTENSITY:
+                  prim=stage_loop == 2 ? MH_MORPHOLOGY_DILATE_INTENSITY : MH_MORPHOLOGY_ERODE_INTENSITY;
+                  break;
+                case MH_MORPHOLOGY_CLOSE: case MH_MORPHOLOGY_BOTTOM_HAT:
+                  this_kernel=rflt;
+                  prim=stage_loop == 2 ? MH_MORPHOLOGY_ERODE : MH_MORPHOLOGY_DILATE; break;
+                case MH_MORPHOLOGY_CLOSE_INTENSITY:
+                  this_kernel=rflt;
+                  prim=stage_loop == 2 ? MH_MORPHOLOGY_ERODE_INTENSITY : MH_MORPHOLOGY_DILATE_INTENSITY;
+                  break;
+                case MH_MORPHOLOGY_SMOOTH:
+                  if (stage_loop >= 3)
+                    this_kernel=rflt;
+                  prim=((stage_loop == 1) || (stage_loop == 4)) ? MH_MORPHOLOGY_ERODE :
+                    MH_MORPHOLOGY_DILATE;
+                  break;
+                case MH_MORPHOLOGY_EDGE:
+                  prim=MH_MORPHOLOGY_DILATE;
+                  if (stage_loop == 2)
+                    {
+                      save=curr;                    // the dilated image, for the difference
+                      curr=&src;
+                      prim=MH_MORPHOLOGY_ERODE;
+                    }
+                  break;
+                case MH_MORPHOLOGY_CORRELATE:
+                  this_kernel=rflt;
+                  prim=MH_MORPHOLOGY_CONVOLVE;
+                  break;
+                default:
+                  break;
+              }
               size_t kernel_loop=0;
               ptrdiff_t changed=1;
               while ((kernel_loop < kernel_limit) && (changed > 0))
                 {
                   kernel_loop++;
-                  const View *target;
-                  if (next_is_dst)
-                    target=&dst;
-                  else
-                    {
-                      if (tmp.pixels == nullptr)
-                        {
-                          MH_TRY(scratch.alloc(src.device,dst.bytes(),src.stream));
-                          tmp.pixels=scratch.ptr;
-                        }
-                      target=&tmp;
-                    }
+                  if (work == nullptr)
+                    MH_TRY(ws.acquire(&work));
                   if (want_counts)
                     MH_HIP(hipMemsetAsync(changed_dev,0,sizeof(unsigned long long),src.stream));
-                  MH_TRY(primitive(*curr,*target,stage.primitive,this_kernel,bias,roles,desc,
+                  MhKernelInfo single=*this_kernel;
+                  single.next=nullptr;
+                  MH_TRY(primitive(*curr,*work,prim,&single,bias,roles,desc,
                     want_counts ? changed_dev : nullptr));
                   if (want_counts)
                     {
@@ -242,17 +325,51 @@ static MhStatus morphology_apply(const View &src,const View &dst,const MhImage *
                     changed=1;
                   total_changed+=(size_t) changed;
                   method_changed+=(size_t) changed;
-                  curr=target;
-                  next_is_dst=(curr != &dst);
+                  const View *t=work;               // swap, morphology.c:3952-3957
+                  work=curr;
+                  curr=t;
+                  if (work == &src)
+                    work=nullptr;
                 }
+            }
+          // post-processing of the compound methods, morphology.c:3986-4013
+          switch (method)
+          {
+            case MH_MORPHOLOGY_EDGE_IN: case MH_MORPHOLOGY_EDGE_OUT:
+            case MH_MORPHOLOGY_TOP_HAT: case MH_MORPHOLOGY_BOTTOM_HAT:
+              MH_TRY(launch_composite(*curr,src,MH_COMPOSITE_DIFFERENCE,roles));
+              break;
+            case MH_MORPHOLOGY_EDGE:
+              MH_TRY(launch_composite(*curr,*save,MH_COMPOSITE_DIFFERENCE,roles));
+              ws.release(save);
+              save=nullptr;
+              break;
+            default:
+              break;
+          }
+          // multi-kernel handling: re-iterate, or compose the results, :4016-4052
+          if ((kernel->next == nullptr) || (compose < 0))
+            rslt=curr;
+          else if (rslt == nullptr)
+            {
+              rslt=curr;
+              curr=&src;
+            }
+          else
+            {
+              MH_TRY(launch_composite(*rslt,*curr,compose,roles));
+              ws.release(curr);
+              curr=&src;
             }
           norm=norm->next;
           if (rflt != nullptr)
             rflt=rflt->next;
         }
     }
-  if (curr != &dst)
-    MH_TRY(launch_copy(*curr,dst));
+  if (rslt == nullptr)
+    return fail(MH_BAD_ARGUMENT,"morphology: empty kernel list");
+  if (rslt != &ws.slot[0])
+    MH_TRY(launch_copy(*rslt,dst));
   if (changed_out != nullptr)
     *changed_out=(ptrdiff_t) total_changed;
   return MH_OK;

@@ -1201,6 +1201,114 @@ static MhStatus apply_q16_column(const View &img,const uint16_t *column,uint32_t
     apply_lut_typed<uint16_t,4>(img,column,mask,nullptr,true,label);
 }
 
+// ---------------------------------------------------------------- CompositeImage
+// The two mathematical compositions MorphologyApply uses as post-steps (morphology.c:
+// 3986-4044): Difference (EdgeIn/EdgeOut/Edge/TopHat/BottomHat) and Lighten (union of the
+// HitAndMiss results of a kernel list).  Canvas and source have the same geometry, offset
+// 0,0, default artifacts (compose:sync and compose:clamp on): composite.c:2396-2428 (alpha),
+// :2523-2711 (alpha channel), :2716-2751 (Sca/Dca/gamma), :2922-2933 (Difference),
+// :3110-3124 (Lighten), ClampPixel pixel-accessor.h:35-46.
+enum CompositeKind { COMPOSITE_DIFFERENCE=0,COMPOSITE_LIGHTEN=1 };
+
+template<typename Q> static __device__ __forceinline__ Q clamp_pixel(double pixel);
+template<> __device__ __forceinline__ uint16_t clamp_pixel<uint16_t>(double pixel)
+{
+  if (pixel < 0.0)
+    return 0;
+  if (pixel >= kQR)
+    return 65535;
+  return (uint16_t) (pixel+0.5);
+}
+template<> __device__ __forceinline__ float clamp_pixel<float>(double pixel)
+{
+  if (pixel < 0.0)
+    return 0.0f;
+  if (pixel >= kQR)
+    return 65535.0f;
+  return (float) pixel;
+}
+
+template<typename Q,int C,int OP>
+__global__ __launch_bounds__(256)
+void composite_kernel(Q *__restrict__ canvas,const Q *__restrict__ source,size_t npixels,int alpha_index,
+  uint32_t update_mask,uint32_t copy_mask)
+{
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
+    {
+      Q s[C],d[C];
+      load_pixel<Q,C>(source+i*C,s);
+      load_pixel<Q,C>(canvas+i*C,d);
+      // GetPixelAlpha gives OpaqueAlpha for an image without an alpha channel
+      const double Sa=kQS*(alpha_index >= 0 ? (double) s[alpha_index < 0 ? 0 : alpha_index] : kQR);
+      const double Da=kQS*(alpha_index >= 0 ? (double) d[alpha_index < 0 ? 0 : alpha_index] : kQR);
+      double alpha=Sa+Da-Sa*Da;                                  // RoundToUnity
+      alpha=alpha < 0.0 ? 0.0 : (alpha > 1.0 ? 1.0 : alpha);
+      const double gamma=perceptible_reciprocal(OP == COMPOSITE_LIGHTEN ? 1.0-alpha : alpha);
+#pragma unroll
+      for (int c=0; c < C; c++)
+        {
+          if ((c == alpha_index) && (((update_mask >> c) & 1u) != 0))
+            {
+              const double pixel=OP == COMPOSITE_DIFFERENCE ? kQR*fabs(Sa-Da) : kQR*alpha;
+              d[c]=clamp_pixel<Q>(pixel);
+              continue;
+            }
+          if (((copy_mask >> c) & 1u) != 0)
+            continue;                                            // ClampToQuantum(Dc) = Dc
+          const double Sc=(double) s[c],Dc=(double) d[c];
+          const double Sca=kQS*Sa*Sc,Dca=kQS*Da*Dc;
+          double pixel;
+          if (OP == COMPOSITE_DIFFERENCE)
+            {
+              const double a=Sca*Da,b=Dca*Sa;
+              pixel=kQR*gamma*(Sca+Dca-2.0*(a < b ? a : b));
+            }
+          else if ((Sca*Da) > (Dca*Sa))
+            pixel=kQR*(Sca+Dca*(1.0-Sa));
+          else
+            pixel=kQR*(Dca+Sca*(1.0-Da));
+          d[c]=clamp_pixel<Q>(pixel);
+        }
+      store_pixel<Q,C>(canvas+i*C,d);
+    }
+}
+
+template<typename Q,int C>
+static MhStatus composite_typed(const View &canvas,const View &source,int kind,const Roles &roles)
+{
+  const size_t n=canvas.columns*canvas.rows;
+  dim3 grid(stream_grid(n)),block(256);
+  ProfileScope prof("composite",canvas.stream);
+  if (kind == COMPOSITE_DIFFERENCE)
+    hipLaunchKernelGGL((composite_kernel<Q,C,COMPOSITE_DIFFERENCE>),grid,block,0,canvas.stream,
+      static_cast<Q *>(canvas.pixels),static_cast<const Q *>(source.pixels),n,roles.alpha,
+      roles.update_mask,roles.copy_mask);
+  else
+    hipLaunchKernelGGL((composite_kernel<Q,C,COMPOSITE_LIGHTEN>),grid,block,0,canvas.stream,
+      static_cast<Q *>(canvas.pixels),static_cast<const Q *>(source.pixels),n,roles.alpha,
+      roles.update_mask,roles.copy_mask);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+MhStatus launch_composite(const View &canvas,const View &source,int kind,const Roles &roles)
+{
+  if ((canvas.columns != source.columns) || (canvas.rows != source.rows) ||
+      (canvas.channels != source.channels) || (canvas.quantum != source.quantum))
+    return fail(MH_BAD_ARGUMENT,"composite: canvas and source differ in geometry");
+#define MH_CASE(QT) \
+  switch (canvas.channels) { \
+    case 1: return composite_typed<QT,1>(canvas,source,kind,roles); \
+    case 2: return composite_typed<QT,2>(canvas,source,kind,roles); \
+    case 3: return composite_typed<QT,3>(canvas,source,kind,roles); \
+    default: return composite_typed<QT,4>(canvas,source,kind,roles); }
+  if (canvas.quantum == MH_QUANTUM_U16)
+    { MH_CASE(uint16_t) }
+  MH_CASE(float)
+#undef MH_CASE
+}
+
 // ---------------------------------------------------------------- GrayscaleImage
 // enhance.c:2476-2660: the intensity of (R,G,B) by `method` is written to the Gray
 // (= first) channel only; the caller then switches the image to GRAY / LinearGRAY.

@@ -59,6 +59,16 @@ def perlmagick():
     print("perlmagick_filter.npz:", {k: v.shape for k, v in out.items()})
 
 
+KERNEL_LISTS = ["Edges", "Corners", "Diagonals", "Diagonals:1,45", "Diagonals:2", "LineEnds", "LineEnds:3>",
+                "LineEnds:4,90", "LineJunctions", "LineJunctions:3@", "LineJunctions:4", "LineJunctions:5",
+                "Ridges", "Ridges:2", "ConvexHull", "Skeleton", "Skeleton:2", "Skeleton:3", "ThinSE:41",
+                "ThinSE:87x90", "ThinSE:481,180", "ThinSE:423", "FreiChen", "FreiChen:2", "FreiChen:10",
+                "FreiChen:13", "FreiChen:11,90", "FreiChen:45", "Laplacian:5", "Laplacian:7", "Laplacian:15",
+                "Laplacian:19", "Sobel:>", "Sobel:@", "Kirsch:@", "Compass:90",
+                "3x3: 1,2,3 4,5,6 7,8,9 ; 5x1: 1,2,3,2,1", "3x3>: 1,2,3 4,5,6 7,8,9", "3x3@: 0,1,- 0,1,1 -,1,-",
+                "3x3<: 0,1,- 0,1,1 -,1,-", "3x1>: 0,1,0"]
+
+
 def make_pixels(rng, rows, cols, ch, hdri):
     a = rng.integers(0, 65536, (rows, cols, ch), dtype=np.uint16)
     if not hdri:
@@ -82,6 +92,10 @@ def reference_vectors():
             out[key + "_blur_3x1.5"] = ref.RefImage(px).blur(3.0, 1.5).numpy()
             out[key + "_dilate_disk4"] = ref.RefImage(px).morphology("Dilate", 1, "Disk:4").numpy()
             out[key + "_erode_disk4"] = ref.RefImage(px).morphology("Erode", 1, "Disk:4").numpy()
+            for m, k in (("EdgeIn", "Disk:2.5"), ("EdgeOut", "Disk:2.5"), ("Edge", "Disk:2.5"),
+                         ("TopHat", "Disk:2.5"), ("BottomHat", "Disk:2.5"), ("Smooth", "Disk:2.5")):
+                out[key + "_" + m.lower() + "_disk2.5"] = ref.RefImage(px).morphology(m, 1, k).numpy()
+            out[key + "_edge_disk2.5_x2"] = ref.RefImage(px).morphology("Edge", 2, "Disk:2.5").numpy()
             out[key + "_convolve_3x3nan"] = ref.RefImage(px).convolve("3x3: 1,-,1 2,4,2 1,nan,3").numpy()
             out[key + "_resize_lanczos_up"] = ref.RefImage(px).resize(101, 75, "Lanczos").numpy()
             out[key + "_resize_lanczos_down"] = ref.RefImage(px).resize(17, 11, "Lanczos").numpy()
@@ -121,6 +135,15 @@ def reference_vectors():
         values, x, y, _ = ref.kernel(s)
         out["kernel|" + s] = values
         out["kernel_origin|" + s] = np.array([x, y])
+    # kernel lists: every kernel of the named hit-and-miss sets, rotation / mirror expansions
+    for s in KERNEL_LISTS:
+        first = ref.kernel(s)
+        count = first[3]
+        out["kernellist|%s|count" % s] = np.array([count])
+        for i in range(count):
+            values, x, y, _ = ref.kernel(s, i)
+            out["kernellist|%s|%d" % (s, i)] = values
+            out["kernellist_origin|%s|%d" % (s, i)] = np.array([x, y])
     xs = np.linspace(-4.5, 4.5, 181)
     img = ref.RefImage(np.zeros((2, 2, 4), np.uint16))
     for f in ("Lanczos", "Mitchell", "Catrom", "Triangle", "Box", "Gaussian", "Hann", "Spline", "Cubic",

@@ -112,6 +112,46 @@ def test_morphology(im, refmod, dtype, method, kernel, iterations):
     assert_parity(got, want, True, "%s %s x%d" % (method, kernel, iterations))
 
 
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("channels", [1, 3, 4])
+@pytest.mark.parametrize("method,kernel,iterations", [
+    ("EdgeIn", "Disk:2.5", 1), ("EdgeOut", "Octagon:2", 1), ("Edge", "Diamond:2", 1),
+    ("TopHat", "Disk:3", 1), ("BottomHat", "Rectangle:5x3+1+1", 1), ("Edge", "Disk:2", 2),
+    ("TopHat", "Square:1", 3),
+])
+def test_compound_morphology_with_difference(im, refmod, dtype, channels, method, kernel, iterations):
+    """MorphologyApply compound methods whose last step is CompositeImage(Difference)
+    (morphology.c:3986-4013), composited on the device."""
+    px = make_pixels(53, 67, channels, dtype)
+    dev, ref = run_pair(im, refmod, px)
+    got = im.morphology_image(dev, method, iterations, kernel).numpy()
+    want = ref.morphology(method, iterations, kernel).numpy()
+    assert_parity(got, want, True, "%s %s x%d c%d" % (method, kernel, iterations, channels))
+
+
+@pytest.mark.parametrize("method,kernel,iterations", [
+    ("HitAndMiss", "Corners", 1), ("HitAndMiss", "LineEnds", 1), ("HitAndMiss", "Corners", 2),
+    ("Thinning", "Skeleton", 3), ("Thinning", "Skeleton", -1), ("Thicken", "ConvexHull", 2),
+    ("Convolve", "Sobel:>", 1), ("Dilate", "3x3: 0,1,0 1,1,1 0,1,0 ; 3x1: 1,1,1", 1),
+])
+def test_morphology_kernel_lists(im, refmod, method, kernel, iterations):
+    """Kernel lists: re-iteration (Thinning/Thicken/Convolve/Dilate) and the Lighten union of
+    the HitAndMiss results (morphology.c:4016-4052)."""
+    px = make_pixels(48, 64, 3, Q16, kind="binary")
+    dev, ref = run_pair(im, refmod, px)
+    got = im.morphology_image(dev, method, iterations, kernel).numpy()
+    want = ref.morphology(method, iterations, kernel).numpy()
+    assert_parity(got, want, True, "%s %s x%d" % (method, kernel, iterations))
+
+
+def test_hit_and_miss_union_with_alpha(im, refmod):
+    px = make_pixels(40, 52, 4, Q16)
+    dev, ref = run_pair(im, refmod, px)
+    got = im.morphology_image(dev, "HitAndMiss", 1, "Corners").numpy()
+    want = ref.morphology("HitAndMiss", 1, "Corners").numpy()
+    assert_parity(got, want, True, "HitAndMiss Corners RGBA")
+
+
 @pytest.mark.parametrize("method", ["HitAndMiss", "Thinning", "Thicken"])
 def test_hit_and_miss_family(im, refmod, method):
     px = make_pixels(48, 64, 3, Q16, kind="binary")

@@ -92,6 +92,29 @@ def test_kernel_builder_matches_reference(im, vectors, spec):
     assert [x, y] == list(vectors["kernel_origin|" + spec]), spec
 
 
+def _kernel_list_names(vectors):
+    return sorted({k.split("|")[1] for k in vectors.files if k.startswith("kernellist|")})
+
+
+def test_kernel_lists_match_reference(im, vectors):
+    """Every kernel of the hit-and-miss sets (Edges, Corners, Diagonals, LineEnds, LineJunctions,
+    Ridges, ConvexHull, Skeleton, ThinSE), FreiChen, the larger Laplacians and the rotation /
+    mirror expansion flags (>, @, <): values, NaN cells and origins as AcquireKernelInfo builds
+    them (morphology.c:485-560, :1748-2087, :2332-2450, :4258-4429)."""
+    names = _kernel_list_names(vectors)
+    assert len(names) >= 40
+    for spec in names:
+        count = int(vectors["kernellist|%s|count" % spec][0])
+        assert im.kernel_to_numpy(spec)[3] == count, spec
+        for i in range(count):
+            values, x, y, _ = im.kernel_to_numpy(spec, i)
+            want = vectors["kernellist|%s|%d" % (spec, i)]
+            assert values.shape == want.shape, (spec, i)
+            assert np.array_equal(np.isnan(values), np.isnan(want)), (spec, i)
+            assert np.array_equal(np.nan_to_num(values), np.nan_to_num(want)), (spec, i)
+            assert [x, y] == list(vectors["kernellist_origin|%s|%d" % (spec, i)]), (spec, i)
+
+
 def test_kernel_builder_matches_oracle(im):
     for radius, sigma in ((0.0, 2.0), (0.0, 10.0), (0.0, 0.7), (6.0, 3.0)):
         values, x, y, count = im.kernel_to_numpy("blur:%.20gx%.20g;blur:%.20gx%.20g+90" %

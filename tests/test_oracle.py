@@ -147,6 +147,18 @@ def test_morphology_matches_reference(vectors, tag, ch):
 
 
 @pytest.mark.parametrize("tag,ch", CASES)
+def test_compound_morphology_matches_reference(vectors, tag, ch):
+    """MorphologyApply's compound methods with their Difference post-step (CompositeImage)."""
+    px = vectors["%s_c%d_in" % (tag, ch)]
+    k, x, y = R.disk_kernel(2.5)
+    for method in ("EdgeIn", "EdgeOut", "Edge", "TopHat", "BottomHat", "Smooth"):
+        assert_identical(R.morphology_image(px, method, k, x, y),
+                         vectors["%s_c%d_%s_disk2.5" % (tag, ch, method.lower())], method)
+    assert_identical(R.morphology_image(px, "Edge", k, x, y, iterations=2),
+                     vectors["%s_c%d_edge_disk2.5_x2" % (tag, ch)], "Edge x2")
+
+
+@pytest.mark.parametrize("tag,ch", CASES)
 def test_resize_matches_reference(vectors, tag, ch):
     px = vectors["%s_c%d_in" % (tag, ch)]
     for name, (cols, rows, flt) in {"resize_lanczos_up": (101, 75, "lanczos"),
