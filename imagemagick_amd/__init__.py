@@ -20,7 +20,8 @@ from ._lib import (MagickHipError, MhImage, COLORSPACES, MORPHOLOGY, FILTERS,  #
 
 __all__ = ["Image", "blur_image", "convolve_image", "morphology_image", "morphology_primitive",
            "unsharp_mask_image", "resize_image", "contrast_stretch_image", "equalize_image",
-           "transform_image_colorspace", "grayscale_image", "function_image", "histogram", "apply_lut", "contrast_stretch_lut",
+           "transform_image_colorspace", "gaussian_blur_image", "sharpen_image", "edge_image",
+           "emboss_image", "grayscale_image", "function_image", "histogram", "apply_lut", "contrast_stretch_lut",
            "equalize_lut", "is_image_gray", "set_precision", "get_precision", "device_count",
            "build", "load", "MagickHipError"]
 
@@ -220,6 +221,33 @@ def morphology_primitive(image, method, kernel, bias=0.0):
                                                     MORPHOLOGY[method.lower()], k, bias,
                                                     ctypes.byref(changed)))
     return out, changed.value
+
+
+def _pair_operator(name, image, *args):
+    lib = _lib.load()
+    out = image.like()
+    _lib.check(getattr(lib, name)(ctypes.byref(image.descriptor()), ctypes.byref(out.descriptor()), *args))
+    return out
+
+
+def gaussian_blur_image(image, radius, sigma):
+    """GaussianBlurImage — MagickCore/effect.c:1709 (one 2-D kernel, not the separable blur)."""
+    return _pair_operator("MagickHipGaussianBlurImage", image, radius, sigma)
+
+
+def sharpen_image(image, radius, sigma):
+    """SharpenImage — MagickCore/effect.c:3991."""
+    return _pair_operator("MagickHipSharpenImage", image, radius, sigma)
+
+
+def edge_image(image, radius):
+    """EdgeImage — MagickCore/effect.c:1523."""
+    return _pair_operator("MagickHipEdgeImage", image, radius)
+
+
+def emboss_image(image, radius, sigma):
+    """EmbossImage — MagickCore/effect.c:1600 (convolve, then EqualizeImage of the result)."""
+    return _pair_operator("MagickHipEmbossImage", image, radius, sigma)
 
 
 def unsharp_mask_image(image, radius, sigma, gain, threshold):

@@ -1293,6 +1293,106 @@ MhKernelInfo *acquire_blur_kernels(double radius,double sigma)
   return first;
 }
 
+// "gaussian:RxS" (GaussianBlurImage, effect.c:1724-1726) without the string round trip
+MhKernelInfo *acquire_gaussian_kernel(double radius,double sigma)
+{
+  Geometry args;
+  args.rho=radius;
+  args.sigma=sigma;
+  args.flags=kRho|kSigma;
+  return builtin(MH_KERNEL_GAUSSIAN,args);
+}
+
+// Square kernels of the ConvolveImage callers in effect.c; meta-data stays zero as in the
+// reference (memset / fresh AcquireKernelInfo(NULL)), MorphologyApply only reads the values.
+static MhKernelInfo *square_kernel(size_t width)
+{
+  MhKernelInfo *k=new_kernel(MH_KERNEL_USERDEFINED,width,width);
+  if (k == nullptr)
+    return nullptr;
+  k->x=k->y=(ptrdiff_t) (width-1)/2;
+  return k;
+}
+
+static double magick_sigma(double sigma)
+{
+  return fabs(sigma) < kEpsilon ? kEpsilon : sigma;          // MagickSigma, effect.c:96
+}
+
+// SharpenImage, effect.c:4017-4058
+MhKernelInfo *acquire_sharpen_kernel(double radius,double sigma)
+{
+  const size_t width=MhGetOptimalKernelWidth2D(radius,sigma);
+  MhKernelInfo *k=square_kernel(width);
+  if (k == nullptr)
+    return nullptr;
+  const double s=magick_sigma(sigma);
+  const ptrdiff_t j=(ptrdiff_t) (width-1)/2;
+  double normalize=0.0;
+  size_t i=0;
+  for (ptrdiff_t v=-j; v <= j; v++)
+    for (ptrdiff_t u=-j; u <= j; u++)
+      {
+        k->values[i]=(double) (-exp(-((double) u*u+v*v)/(2.0*s*s))/(2.0*kPi*s*s));
+        normalize+=k->values[i];
+        i++;
+      }
+  k->values[i/2]=(double) ((-2.0)*normalize);
+  normalize=0.0;
+  for (i=0; i < width*width; i++)
+    normalize+=k->values[i];
+  const double gamma=perceptible_reciprocal(normalize);
+  for (i=0; i < width*width; i++)
+    k->values[i]*=gamma;
+  return k;
+}
+
+// EdgeImage, effect.c:1541-1563
+MhKernelInfo *acquire_edge_kernel(double radius)
+{
+  const size_t width=MhGetOptimalKernelWidth1D(radius,0.5);
+  MhKernelInfo *k=square_kernel(width);
+  if (k == nullptr)
+    return nullptr;
+  size_t i;
+  for (i=0; i < width*width; i++)
+    k->values[i]=(-1.0);
+  k->values[i/2]=(double) width*width-1.0;
+  return k;
+}
+
+// EmbossImage, effect.c:1633-1672
+MhKernelInfo *acquire_emboss_kernel(double radius,double sigma)
+{
+  const size_t width=MhGetOptimalKernelWidth1D(radius,sigma);
+  MhKernelInfo *k=square_kernel(width);
+  if (k == nullptr)
+    return nullptr;
+  const double s=magick_sigma(sigma);
+  const ptrdiff_t j=(ptrdiff_t) (width-1)/2;
+  ptrdiff_t diagonal=j;
+  size_t i=0;
+  for (ptrdiff_t v=-j; v <= j; v++)
+    {
+      for (ptrdiff_t u=-j; u <= j; u++)
+        {
+          k->values[i]=(double) ((((u < 0) || (v < 0)) ? -8.0 : 8.0)*
+            exp(-((double) u*u+v*v)/(2.0*s*s))/(2.0*kPi*s*s));
+          if (u != diagonal)
+            k->values[i]=0.0;
+          i++;
+        }
+      diagonal--;
+    }
+  double normalize=0.0;
+  for (i=0; i < width*width; i++)
+    normalize+=k->values[i];
+  const double gamma=perceptible_reciprocal(normalize);
+  for (i=0; i < width*width; i++)
+    k->values[i]*=gamma;
+  return k;
+}
+
 } // namespace mh
 
 // ===================================================================== C ABI

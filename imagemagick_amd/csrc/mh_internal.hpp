@@ -111,6 +111,12 @@ struct Roles
 Roles channel_roles(const MhImage *src,const MhImage *dst);
 
 MhKernelInfo *acquire_blur_kernels(double radius,double sigma);
+MhKernelInfo *acquire_gaussian_kernel(double radius,double sigma);
+MhKernelInfo *acquire_sharpen_kernel(double radius,double sigma);
+MhKernelInfo *acquire_edge_kernel(double radius);
+MhKernelInfo *acquire_emboss_kernel(double radius,double sigma);
+// EqualizeImage on a device view (operators_enhance.cpp)
+MhStatus equalize_view(const View &view,const MhImage *image);
 
 // ------------------------------------------------------------ profiling
 struct ProfileScope

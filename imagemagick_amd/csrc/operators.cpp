@@ -5,6 +5,8 @@
 // stays on the CPU exactly as in the reference; every per-pixel loop runs in a
 // HIP kernel.
 #include "mh_internal.hpp"
+
+#include <cstdio>
 #include "resize_filter.hpp"
 
 #include <cmath>
@@ -448,6 +450,58 @@ MH_API MhStatus MagickHipBlurImage(const MhImage *image,MhImage *blur_image,
   MhStatus status=MagickHipConvolveImage(image,blur_image,kernel);
   MhDestroyKernelInfo(kernel);
   return status;
+}
+
+// One square kernel through ConvolveImage; `equalize` adds EmbossImage's EqualizeImage of
+// the result (effect.c:1675-1676), on the device before the result is handed back.
+static MhStatus convolve_with(const MhImage *image,MhImage *out,MhKernelInfo *kernel,
+  const char *what,bool equalize)
+{
+  if (kernel == nullptr)
+    return fail(MH_BAD_ARGUMENT,"%s: cannot build the kernel",what);
+  Pair pair;
+  MhStatus status=pair.open(image,out);
+  if (status == MH_OK)
+    {
+      Roles roles=channel_roles(image,out);
+      status=morphology_apply(pair.src.view,pair.dst.view,image,roles,MH_MORPHOLOGY_CONVOLVE,1,
+        kernel,0.0,nullptr);
+      if ((status == MH_OK) && equalize)
+        status=equalize_view(pair.dst.view,out);
+    }
+  MhDestroyKernelInfo(kernel);
+  if (status != MH_OK)
+    return status;
+  return pair.commit();
+}
+
+MH_API MhStatus MagickHipGaussianBlurImage(const MhImage *image,MhImage *blur_image,
+  double radius,double sigma)
+{
+  // GaussianBlurImage, effect.c:1709-1735: AcquireKernelInfo("gaussian:RxS")
+  MH_TRY(gate_pair(image,blur_image,"GaussianBlurImage",true));
+  return convolve_with(image,blur_image,acquire_gaussian_kernel(radius,sigma),"GaussianBlurImage",
+    false);
+}
+
+MH_API MhStatus MagickHipSharpenImage(const MhImage *image,MhImage *sharp_image,
+  double radius,double sigma)
+{
+  MH_TRY(gate_pair(image,sharp_image,"SharpenImage",true));
+  return convolve_with(image,sharp_image,acquire_sharpen_kernel(radius,sigma),"SharpenImage",false);
+}
+
+MH_API MhStatus MagickHipEdgeImage(const MhImage *image,MhImage *edge_image,double radius)
+{
+  MH_TRY(gate_pair(image,edge_image,"EdgeImage",true));
+  return convolve_with(image,edge_image,acquire_edge_kernel(radius),"EdgeImage",false);
+}
+
+MH_API MhStatus MagickHipEmbossImage(const MhImage *image,MhImage *emboss_image,
+  double radius,double sigma)
+{
+  MH_TRY(gate_pair(image,emboss_image,"EmbossImage",true));
+  return convolve_with(image,emboss_image,acquire_emboss_kernel(radius,sigma),"EmbossImage",true);
 }
 
 MH_API MhStatus MagickHipUnsharpMaskImage(const MhImage *image,MhImage *unsharp_image,

@@ -315,6 +315,16 @@ static MhStatus histogram_lut_apply(const View &view,const MhImage *image,int mo
   return launch_apply_lut(view,lut.ptr,~0u,roles,shared_column,mask.as<uint32_t>());
 }
 
+extern "C++" {
+namespace mh {
+MhStatus equalize_view(const View &view,const MhImage *image)
+{
+  const int mode=(image->channel_mask & MH_SYNC_CHANNELS) != 0 ? 1 : 0;   // enhance.c:2125-2129
+  return histogram_lut_apply(view,image,mode,true,0.0,0.0,nullptr);
+}
+}
+}
+
 // ContrastStretchImage, enhance.c:1544-1818
 MH_API MhStatus MagickHipContrastStretchImage(MhImage *image,double black_point,
   double white_point,int *became_gray)
@@ -366,8 +376,7 @@ MH_API MhStatus MagickHipEqualizeImage(MhImage *image)
   InPlace io;
   MH_TRY(io.open(image));
   const View &view=io.img.view;
-  const int mode=(image->channel_mask & MH_SYNC_CHANNELS) != 0 ? 1 : 0;   // enhance.c:2125-2129
-  MH_TRY(histogram_lut_apply(view,image,mode,true,0.0,0.0,nullptr));
+  MH_TRY(equalize_view(view,image));
   return io.img.commit();
 }
 

@@ -290,6 +290,20 @@ MH_API MhStatus MagickHipBlurImage(const MhImage *image,MhImage *blur_image,
 MH_API MhStatus MagickHipConvolveImage(const MhImage *image,MhImage *convolve_image,
   const MhKernelInfo *kernel);
 
+/* The other callers of ConvolveImage: each builds its kernel on the host
+   exactly as the reference does and runs MorphologyImage(Convolve,1).
+     GaussianBlurImage  effect.c:1709-1735  kernel "gaussian:RxS"
+     SharpenImage       effect.c:3991-4062  negated 2-D gaussian, centre -2*sum, normalised
+     EdgeImage          effect.c:1523-1566  all -1, centre width*width-1 (width from sigma 0.5)
+     EmbossImage        effect.c:1600-1678  anti-diagonal signed gaussian, then EqualizeImage */
+MH_API MhStatus MagickHipGaussianBlurImage(const MhImage *image,MhImage *blur_image,
+  double radius,double sigma);
+MH_API MhStatus MagickHipSharpenImage(const MhImage *image,MhImage *sharp_image,
+  double radius,double sigma);
+MH_API MhStatus MagickHipEdgeImage(const MhImage *image,MhImage *edge_image,double radius);
+MH_API MhStatus MagickHipEmbossImage(const MhImage *image,MhImage *emboss_image,
+  double radius,double sigma);
+
 /* MorphologyImage / MorphologyApply, morphology.c:4129 / :3634.  `compose`
    is unused (Undefined => per-method default) in this version; `bias` is the
    convolve:bias artifact (0 by default). */

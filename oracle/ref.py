@@ -61,6 +61,7 @@ def _load(hdri, shim=False):
     L.ref_image_get_property.restype = cp
     L.ref_image_get_property.argtypes = [vp, cp]
     for name, extra in [("ref_blur", [dbl, dbl]), ("ref_gaussian_blur", [dbl, dbl]),
+                        ("ref_sharpen", [dbl, dbl]), ("ref_emboss", [dbl, dbl]), ("ref_edge", [dbl]),
                         ("ref_unsharp", [dbl, dbl, dbl, dbl]), ("ref_convolve", [cp]),
                         ("ref_morphology", [cp, ctypes.c_ssize_t, cp]),
                         ("ref_resize", [sz, sz, cp])]:
@@ -167,6 +168,15 @@ class RefImage:
 
     def gaussian_blur(self, radius, sigma):
         return self._new(self.L.ref_gaussian_blur, radius, sigma)
+
+    def sharpen(self, radius, sigma):
+        return self._new(self.L.ref_sharpen, radius, sigma)
+
+    def emboss(self, radius, sigma):
+        return self._new(self.L.ref_emboss, radius, sigma)
+
+    def edge(self, radius):
+        return self._new(self.L.ref_edge, radius)
 
     def unsharp(self, radius, sigma, gain, threshold):
         return self._new(self.L.ref_unsharp, radius, sigma, gain, threshold)

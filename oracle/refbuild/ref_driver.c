@@ -223,6 +223,35 @@ REF_API void *ref_blur(const void *handle,double radius,double sigma,
   return((void *) out);
 }
 
+REF_API void *ref_sharpen(const void *handle,double radius,double sigma,
+  double *seconds)
+{
+  Image *out;
+  TIMED_BEGIN;
+  out=SharpenImage((const Image *) handle,radius,sigma,ref_exception);
+  TIMED_END;
+  return((void *) out);
+}
+
+REF_API void *ref_emboss(const void *handle,double radius,double sigma,
+  double *seconds)
+{
+  Image *out;
+  TIMED_BEGIN;
+  out=EmbossImage((const Image *) handle,radius,sigma,ref_exception);
+  TIMED_END;
+  return((void *) out);
+}
+
+REF_API void *ref_edge(const void *handle,double radius,double *seconds)
+{
+  Image *out;
+  TIMED_BEGIN;
+  out=EdgeImage((const Image *) handle,radius,ref_exception);
+  TIMED_END;
+  return((void *) out);
+}
+
 REF_API void *ref_gaussian_blur(const void *handle,double radius,double sigma,
   double *seconds)
 {

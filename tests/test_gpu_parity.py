@@ -170,6 +170,26 @@ def test_morphology_until_convergence(im, refmod):
     assert_parity(got, want, True, "dilate until no change")
 
 
+# ----------------------------------------------------------- the other ConvolveImage callers
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("channels", [3, 4])
+def test_gaussian_blur_sharpen_edge_emboss(im, refmod, dtype, channels):
+    """GaussianBlurImage, SharpenImage, EdgeImage, EmbossImage (effect.c): host-built kernels,
+    one Convolve pass; Emboss also equalizes its result."""
+    px = make_pixels(57, 73, channels, dtype, kind="smooth")
+    dev, ref = run_pair(im, refmod, px)
+    for name, got, want in (
+            ("gaussian 0x1.5", im.gaussian_blur_image(dev, 0.0, 1.5), ref.gaussian_blur(0.0, 1.5)),
+            ("gaussian 2x3", im.gaussian_blur_image(dev, 2.0, 3.0), ref.gaussian_blur(2.0, 3.0)),
+            ("sharpen 0x1", im.sharpen_image(dev, 0.0, 1.0), ref.sharpen(0.0, 1.0)),
+            ("sharpen 3x0.8", im.sharpen_image(dev, 3.0, 0.8), ref.sharpen(3.0, 0.8)),
+            ("edge 0", im.edge_image(dev, 0.0), ref.edge(0.0)),
+            ("edge 2", im.edge_image(dev, 2.0), ref.edge(2.0)),
+            ("emboss 0x1", im.emboss_image(dev, 0.0, 1.0), ref.emboss(0.0, 1.0)),
+            ("emboss 2x0.7", im.emboss_image(dev, 2.0, 0.7), ref.emboss(2.0, 0.7))):
+        assert_parity(got.numpy(), want.numpy(), True, "%s c%d" % (name, channels))
+
+
 # ----------------------------------------------------------- UnsharpMaskImage
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
 def test_unsharp_mask(im, refmod, dtype):
