@@ -37,6 +37,11 @@
 #include "MagickCore/resize-private.h"
 #include "MagickCore/semaphore.h"
 #include "MagickCore/string_.h"
+#include "MagickCore/artifact.h"
+#include "MagickCore/colorspace.h"
+#include "MagickCore/colorspace-private.h"
+#include "MagickCore/composite.h"
+#include "MagickCore/morphology.h"
 
 #if defined(MAGICKCORE_OPENCL_SUPPORT)
 
@@ -59,10 +64,10 @@ MagickExport size_t GetMagickHipAcceleratedCalls(void)
   LinearGRAY; Undefined or Edge virtual pixels; no read, write or composite
   mask; at most four channels laid out R[,G,B][,A].
 */
+static MagickBooleanType IsLayoutAcceleratable(const Image *image);
+
 static MagickBooleanType IsImageAcceleratable(const Image *image)
 {
-  if (image->storage_class != DirectClass)
-    return(MagickFalse);
   switch (image->colorspace)
   {
     case RGBColorspace:
@@ -73,6 +78,18 @@ static MagickBooleanType IsImageAcceleratable(const Image *image)
     default:
       return(MagickFalse);
   }
+  return(IsLayoutAcceleratable(image));
+}
+
+/*
+  The gate without the colourspace condition, for the colourspace transform itself and
+  for the histogram operators on its result ("the colourspace gate must be
+  relaxed for our Lab/linear hooks"; BASELINE config C4 is sRGB->Lab + ContrastStretch).
+*/
+static MagickBooleanType IsLayoutAcceleratable(const Image *image)
+{
+  if (image->storage_class != DirectClass)
+    return(MagickFalse);
   switch (GetImageVirtualPixelMethod(image))
   {
     case UndefinedVirtualPixelMethod:
@@ -381,7 +398,7 @@ MagickPrivate MagickBooleanType AccelerateEqualizeImage(Image *image,
   void
     *q;
 
-  if (IsImageAcceleratable(image) == MagickFalse)
+  if (IsLayoutAcceleratable(image) == MagickFalse)
     return(MagickFalse);
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
@@ -411,7 +428,7 @@ MagickPrivate MagickBooleanType AccelerateContrastStretchImage(Image *image,
   void
     *q;
 
-  if (IsImageAcceleratable(image) == MagickFalse)
+  if (IsLayoutAcceleratable(image) == MagickFalse)
     return(MagickFalse);
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
@@ -427,6 +444,184 @@ MagickPrivate MagickBooleanType AccelerateContrastStretchImage(Image *image,
     (void) SetImageColorspace(image,GRAYColorspace,exception);
   hip_accelerated_calls++;
   return(MagickTrue);
+}
+
+/*
+  MorphologyApply (morphology.c:3634): every caller of MorphologyImage / ConvolveImage
+  (GaussianBlur, Sharpen, Edge, Emboss, -morphology ...) arrives here through the hook
+  shim/patch_hooks.py adds at the top of the reference function.  The KernelInfo list is
+  described in place — MhKernelInfo points at the reference's own value arrays.
+*/
+#define MaxAcceleratedKernels  64
+
+MagickPrivate Image *AccelerateMorphologyApply(const Image *image,
+  const MorphologyMethod method,const ssize_t iterations,const KernelInfo *kernel,
+  const CompositeOperator compose,const double bias,ExceptionInfo *exception)
+{
+  const KernelInfo
+    *k;
+
+  HipLibrary
+    *library;
+
+  Image
+    *morphology_image;
+
+  MhImage
+    source,
+    destination;
+
+  MhKernelInfo
+    kernels[MaxAcceleratedKernels];
+
+  size_t
+    n;
+
+  void
+    *p,
+    *q;
+
+  if ((compose != UndefinedCompositeOp) || (iterations == 0) ||
+      (IsImageAcceleratable(image) == MagickFalse))
+    return((Image *) NULL);
+  n=0;
+  for (k=kernel; k != (const KernelInfo *) NULL; k=k->next)
+  {
+    if (n == MaxAcceleratedKernels)
+      return((Image *) NULL);
+    (void) memset(&kernels[n],0,sizeof(kernels[n]));
+    kernels[n].type=MH_KERNEL_USERDEFINED;
+    kernels[n].width=k->width;
+    kernels[n].height=k->height;
+    kernels[n].x=k->x;
+    kernels[n].y=k->y;
+    kernels[n].values=(double *) k->values;          /* MagickRealType is double */
+    kernels[n].minimum=k->minimum;
+    kernels[n].maximum=k->maximum;
+    kernels[n].negative_range=k->negative_range;
+    kernels[n].positive_range=k->positive_range;
+    kernels[n].angle=k->angle;
+    if (n != 0)
+      kernels[n-1].next=&kernels[n];
+    n++;
+  }
+  library=AcquireHipLibrary();
+  if (library == (HipLibrary *) NULL)
+    return((Image *) NULL);
+  p=AcquireDevicePixels(library,image,1,exception);
+  if (p == NULL)
+    return((Image *) NULL);
+  morphology_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
+  if (morphology_image == (Image *) NULL)
+    return((Image *) NULL);
+  /* MorphologyMethod and MhMorphologyMethod share their values (morphology.h:72-98) */
+  if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
+      (DescribeImage(library,morphology_image,q,&destination) == MagickFalse) ||
+      (library->MorphologyImage(&source,&destination,(MhMorphologyMethod) method,iterations,
+         kernels,bias) != MH_OK))
+    return(DestroyImage(morphology_image));
+  morphology_image->type=image->type;                /* morphology.c:2800, :3222 */
+  hip_accelerated_calls++;
+  return(morphology_image);
+}
+
+/*
+  TransformImageColorspace (colorspace.c:1751) between sRGB, linear RGB, XYZ and Lab with
+  the default illuminant.  The bookkeeping the CPU path does around the pixel loop is
+  kept: X -> sRGB ends in SetImageColorspace(sRGB), sRGB -> Y in SetImageColorspace(Y)
+  (colorspace.c:1052, :2390).
+*/
+static MagickBooleanType IsColorspaceAccelerated(const ColorspaceType colorspace)
+{
+  return(((colorspace == sRGBColorspace) || (colorspace == RGBColorspace) ||
+    (colorspace == XYZColorspace) || (colorspace == LabColorspace)) ? MagickTrue : MagickFalse);
+}
+
+/*
+  SetImageColorspace for an image whose current pixels live on the device.  It ends in
+  SyncImagePixelCache -> GetImagePixelCache, which (a) brings the host block up to date
+  (CopyOpenCLBuffer, cache.c:1711) and (b) re-opens a cache whose recorded colourspace
+  differs from the image's: a new host block plus a copy of the old one (cache.c:3746-3790).
+  Neither is wanted — the pixels are already in the new colourspace and nobody asked for
+  them on the host — so the cache is re-tagged first and the device record is set aside for
+  the duration of the call.  Should the cache have been replaced all the same, the device
+  copy is downloaded into the new block.
+*/
+static MagickBooleanType SetResidentImageColorspace(HipLibrary *library,Image *image,
+  const ColorspaceType colorspace,ExceptionInfo *exception)
+{
+  CacheInfo
+    *cache_info;
+
+  MagickBooleanType
+    status;
+
+  MagickCLCacheInfo
+    info;
+
+  cache_info=(CacheInfo *) image->cache;
+  LockSemaphoreInfo(cache_info->semaphore);
+  info=cache_info->opencl;
+  cache_info->opencl=(MagickCLCacheInfo) NULL;
+  cache_info->colorspace=colorspace;
+  UnlockSemaphoreInfo(cache_info->semaphore);
+  status=SetImageColorspace(image,colorspace,exception);
+  if (info == (MagickCLCacheInfo) NULL)
+    return(status);
+  cache_info=(CacheInfo *) image->cache;
+  LockSemaphoreInfo(cache_info->semaphore);
+  if ((cache_info->type == MemoryCache) && (cache_info->pixels == info->pixels) &&
+      (cache_info->length == info->length) && (cache_info->opencl == (MagickCLCacheInfo) NULL))
+    cache_info->opencl=info;
+  else
+    {
+      if ((cache_info->type == MemoryCache) && (cache_info->pixels != (Quantum *) NULL) &&
+          (cache_info->length == info->length))
+        {
+          if (library->Download(-1,cache_info->pixels,(const void *) info->buffer,
+                (size_t) info->length,NULL) != MH_OK)
+            status=MagickFalse;
+          CountHipTransfer(0);
+        }
+      else
+        status=MagickFalse;
+      (void) library->DeviceFree(-1,(void *) info->buffer);
+      info=(MagickCLCacheInfo) RelinquishMagickMemory(info);
+    }
+  UnlockSemaphoreInfo(cache_info->semaphore);
+  return(status);
+}
+
+MagickPrivate MagickBooleanType AccelerateTransformImageColorspace(Image *image,
+  const ColorspaceType colorspace,ExceptionInfo *exception)
+{
+  HipLibrary
+    *library;
+
+  MhImage
+    description;
+
+  void
+    *q;
+
+  if ((IsColorspaceAccelerated(image->colorspace) == MagickFalse) ||
+      (IsColorspaceAccelerated(colorspace) == MagickFalse) ||
+      (image->colorspace == colorspace) || (image->number_channels < 3) ||
+      (IsLayoutAcceleratable(image) == MagickFalse) ||
+      (GetImageArtifact(image,"color:illuminant") != (const char *) NULL))
+    return(MagickFalse);
+  library=AcquireHipLibrary();
+  if (library == (HipLibrary *) NULL)
+    return(MagickFalse);
+  q=AcquireDevicePixels(library,image,1,exception);
+  /* ColorspaceType and MhColorspace share their values (colorspace.h:27-66) */
+  if ((q == NULL) ||
+      (DescribeImage(library,image,q,&description) == MagickFalse) ||
+      (library->TransformImageColorspace(&description,(MhColorspace) colorspace) != MH_OK))
+    return(MagickFalse);
+  MarkDeviceCopyNewer(image);
+  hip_accelerated_calls++;
+  return(SetResidentImageColorspace(library,image,colorspace,exception));
 }
 
 /* ---- operators outside the hot path: always "not handled", the CPU code runs ---- */

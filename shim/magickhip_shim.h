@@ -30,6 +30,9 @@ typedef struct _HipLibrary
   MhStatus (*EqualizeImage)(MhImage *);
   MhStatus (*GrayscaleImage)(MhImage *,MhIntensityMethod);
   MhStatus (*FunctionImage)(MhImage *,MhFunction,size_t,const double *);
+  MhStatus (*MorphologyImage)(const MhImage *,MhImage *,MhMorphologyMethod,ptrdiff_t,
+    const MhKernelInfo *,double);
+  MhStatus (*TransformImageColorspace)(MhImage *,MhColorspace);
 } HipLibrary;
 
 /* NULL when the library, a GPU or the enable switch is missing: the caller runs the CPU path */

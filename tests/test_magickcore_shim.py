@@ -110,3 +110,71 @@ def test_grayscale_and_function_through_magickcore(shim, dtype):
                   "GrayscaleImage via MagickCore")
     assert accelerated_calls(shim, hdri) == before + 2
     assert g.info()["colorspace"].lower() == "gray" and g.info()["channels"] == c.info()["channels"]
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_morphology_hook_covers_convolve_callers(shim, dtype):
+    """The hook shim/patch_hooks.py adds at the top of MorphologyApply puts every
+    caller of MorphologyImage / ConvolveImage on the device: -morphology, GaussianBlurImage,
+    SharpenImage, EdgeImage, EmbossImage (+ its EqualizeImage), and the re-enabled
+    UnsharpMaskImage stanza (effect.c:4287-4294)."""
+    hdri = dtype == np.float32
+    px = make_pixels(52, 64, 4, dtype, kind="smooth")
+    g, c = shim.RefImage(px, shim=True), shim.RefImage(px)
+    steps = [
+        ("EdgeOut Disk:2.5", lambda i: i.morphology("EdgeOut", 1, "Disk:2.5"), 1),
+        ("Smooth Octagon:2", lambda i: i.morphology("Smooth", 1, "Octagon:2"), 1),
+        ("GaussianBlur 0x1.5", lambda i: i.gaussian_blur(0.0, 1.5), 1),
+        ("Sharpen 0x1", lambda i: i.sharpen(0.0, 1.0), 1),
+        ("Edge 1", lambda i: i.edge(1.0), 1),
+        ("Emboss 0x1", lambda i: i.emboss(0.0, 1.0), 2),
+        ("UnsharpMask 0x2+1+0.02", lambda i: i.unsharp(0.0, 2.0, 1.0, 0.02), 1),
+    ]
+    for name, op, calls in steps:
+        before = accelerated_calls(shim, hdri)
+        got = op(g).numpy()
+        assert accelerated_calls(shim, hdri) == before + calls, name + " did not take the accelerated path"
+        assert_parity(got, op(c).numpy(), True, name + " via MagickCore")
+
+
+def test_hit_and_miss_list_through_magickcore(shim):
+    px = make_pixels(40, 48, 3, np.uint16, kind="binary")
+    before = accelerated_calls(shim, False)
+    g, c = shim.RefImage(px, shim=True), shim.RefImage(px)
+    assert_parity(g.morphology("HitAndMiss", 1, "LineEnds").numpy(), c.morphology("HitAndMiss", 1, "LineEnds").numpy(),
+                  True, "HitAndMiss LineEnds via MagickCore")
+    assert_parity(g.morphology("Thinning", -1, "Skeleton").numpy(), c.morphology("Thinning", -1, "Skeleton").numpy(),
+                  True, "Thinning Skeleton via MagickCore")
+    assert accelerated_calls(shim, False) == before + 2
+    # Distance is sequential: the library declines, MagickCore runs its CPU code
+    assert_parity(g.morphology("Distance", 1, "Euclidean:1").numpy(), c.morphology("Distance", 1, "Euclidean:1").numpy(),
+                  True, "Distance (CPU fallback)")
+    assert accelerated_calls(shim, False) == before + 2
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_colorspace_and_contrast_stretch_chain(shim, dtype):
+    """BASELINE config C4 through MagickCore: TransformImageColorspace(Lab) (new hook,
+    colorspace.c:1751) then ContrastStretchImage (hook added to the caller-less
+    AccelerateContrastStretchImage): one upload, no download until the CPU reads the result."""
+    hdri = dtype == np.float32
+    px = make_pixels(64, 96, 4, dtype, kind="smooth")
+    n = 64 * 96
+    before = accelerated_calls(shim, hdri)
+    up0, down0 = transfers(shim, hdri)
+    g, c = shim.RefImage(px, shim=True), shim.RefImage(px)
+    for image in (g, c):
+        image.colorspace("Lab")
+        image.contrast_stretch(0.02 * n, n - 0.01 * n)
+    assert accelerated_calls(shim, hdri) == before + 2
+    assert transfers(shim, hdri) == (up0 + 1, down0)
+    assert g.info()["colorspace"] == c.info()["colorspace"] and "lab" in g.info()["colorspace"].lower()
+    assert_parity(g.numpy(), c.numpy(), True, "sRGB -> Lab + ContrastStretch via MagickCore", max_ulp=1)
+    assert transfers(shim, hdri) == (up0 + 1, down0 + 1)
+    # a tour of the accelerated colourspaces, two-step transforms included (X -> sRGB -> Y)
+    g, c = shim.RefImage(px, shim=True), shim.RefImage(px)
+    for target in ("XYZ", "Lab", "RGB", "sRGB", "Lab", "XYZ", "sRGB"):
+        g.colorspace(target)
+        c.colorspace(target)
+        assert g.info()["colorspace"] == c.info()["colorspace"], target
+        assert_parity(g.numpy(), c.numpy(), True, "-> %s via MagickCore" % target, max_ulp=1)
