@@ -20,6 +20,7 @@
 #include "mh_internal.hpp"
 #include "device_common.hpp"
 #include <cstdlib>
+#include <vector>
 #include <type_traits>
 
 namespace mh {
@@ -1457,6 +1458,22 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
     {
       if (prec == MH_PRECISION_FAST)
         {
+          // RGBA with alpha-weighted colour channels (BlurImage's case): the banded-matrix
+          // formulation on the f16 matrix cores, convolve_mfma.hip
+          if ((src.channels == 4) && roles.blend && (roles.alpha == 3) && (roles.copy_mask == 0) &&
+              (params.bias == 0.0) && (changed == nullptr) && (getenv("MAGICKHIP_MFMA") != nullptr))
+            {
+              const int K=params.ntaps;
+              std::vector<float> host((size_t) K);
+              for (int v=0; v < K; v++)
+                host[(size_t) v]=(float) params.taps[K-1-v];     // reversed walk, morphology.c:2746
+              Temp taps;
+              MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(float)));
+              bool handled=false;
+              MH_TRY(launch_conv1d_mfma(src,dst,vertical,taps.as<float>(),K,K-1-params.origin,&handled));
+              if (handled)
+                return MH_OK;
+            }
           // long kernels: the triangular kernels with 32 outputs per lane; short ones: blocked
           // K >= R+1: the ramp-free triangular kernels (measured +7.5 % at K=79 on MI355X;
           // R=24/32 variants were slower: 240 VGPRs leave two waves per SIMD)

@@ -143,6 +143,11 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
   const Conv1DParams &params,const Roles &roles,MhPrecision precision,
   unsigned long long *changed_device);
 
+// FAST Q16 RGBA blend pass on the f16 matrix cores (convolve_mfma.hip); *handled=false when
+// the shape is outside its reach and nothing was launched
+MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const float *taps_device,
+  int ntaps,int shift,bool *handled);
+
 struct Morph2DParams
 {
   MhMorphologyMethod method=MH_MORPHOLOGY_UNDEFINED;
