@@ -1461,7 +1461,7 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
           // RGBA with alpha-weighted colour channels (BlurImage's case): the banded-matrix
           // formulation on the f16 matrix cores, convolve_mfma.hip
           if ((src.channels == 4) && roles.blend && (roles.alpha == 3) && (roles.copy_mask == 0) &&
-              (params.bias == 0.0) && (changed == nullptr) && (getenv("MAGICKHIP_MFMA") != nullptr))
+              (params.bias == 0.0) && (changed == nullptr) && (getenv("MAGICKHIP_NO_MFMA") == nullptr))
             {
               const int K=params.ntaps;
               std::vector<float> host((size_t) K);

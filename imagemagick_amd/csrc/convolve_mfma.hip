@@ -26,6 +26,13 @@
 // with e = 4*pixel+channel the four channels of a pixel sit in four consecutive registers
 // of ONE lane, so the gamma division is lane-local.  The tap operands depend only on
 // (lane, k-chunk) and stay in registers for the lifetime of a persistent workgroup.
+//
+// Streaming.  A workgroup walks a strip of 16 units (pixel columns for the column pass,
+// rows for the row pass) along the filter axis in steps of 64 outputs.  The converted
+// samples live in an LDS ring of R = 16*NQ+32 axis positions; a step stages only the 64
+// positions that are new (every input sample is fetched and converted once, not once per
+// tile it overlaps — the first, tile-shaped version of this kernel spent 2.25x the staging
+// work on halos and measured 0.53 ms per pass), multiplies, and leaves.
 #include "mh_internal.hpp"
 #include "device_common.hpp"
 #include <cstdlib>
@@ -44,23 +51,39 @@ struct ConvMfmaArgs
   int ntaps;
   int shift;                 // K-1-origin: offset of the first input sample
   const float *taps;         // float[K], taps[v] multiplies input o-shift+v
-  int tiles_minor,tiles_major,total_tiles;
-  int skip;                  // experiment mask (MAGICKHIP_MFMA_SKIP): 1 multiply, 2 staging, 4 loads, 8 stores
+  int strips,segments,steps_per_segment,steps;   // strips of UNITS units, steps of STEP outputs
 };
 
-// LDS image of a tile: two planes (hi, lo) of f16, entry-major with the filter axis
-// contiguous: plane[channel][unit 0..31][k 0..KR), KR = 32*(NG-1)+16*NQ input positions.
-//   stride S = KR+4 halves: (S/2) mod 64 = 2 mod 8  -> the 32 units of a channel fall into
-//   32 different banks for the 8-byte staging writes;
-//   channel skew of 8 halves -> the four channels of a pixel read different banks.
-template<int NQ,int NG>
+// Strip shape, both passes: 16 units x 64 outputs per step; 4 waves = 2 unit groups x 2
+// output groups.  (32 columns x 32 outputs was tried for the column pass to get 256-byte row
+// segments: no faster, and its ring cannot take the conflict-free line stride below.)
+template<bool VERTICAL> struct StripShape
+{
+  static constexpr int UNITS=16;
+  static constexpr int STEP=64;
+};
+
+// LDS: two planes (hi, lo) of f16, plane[channel][unit 0..15][ring slot 0..R), the filter
+// axis contiguous.  Bank rules (MI355X_MICROARCH.md, LDS): ds_read_b128 is served in four
+// 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... over 64 banks, i.e. each group
+// (4 units x 4 channels of operand lines) must hit 16 different 16-byte slots of a 256-byte
+// bank row.  With the line stride S = 32 mod 128 halves (64 bytes mod 256) the units
+// {0,3,5,6} / {1,2,4,7} of a group land 0/64/128/192 bytes apart, and the channel stride
+// 16*S+8 halves (16 bytes mod 256) fills the slots in between: conflict-free.  (S = R+8
+// measured 77 % of all LDS cycles as bank conflicts, 0.41 ms per pass.)
+template<bool VERTICAL,int NQ>
 struct MfmaGeometry
 {
-  static constexpr int KR=32*(NG-1)+16*NQ;
-  static constexpr int S=KR+8;                 // multiple of 8 halves: 16-byte aligned ds_read_b128
-  static constexpr int CH=32*S+8;              // halves per channel
+  static constexpr int UNITS=StripShape<VERTICAL>::UNITS,STEP=StripShape<VERTICAL>::STEP;
+  static constexpr int R=16*NQ+STEP-32;        // ring positions: STEP outputs + K-1 halo, 16-aligned
+  static constexpr int S=((R-32+127)/128)*128+32;     // >= R, = 32 mod 128
+  static constexpr int CH=UNITS*S+8;           // halves per channel
   static constexpr int PLANE=4*CH;             // halves per plane
-  static constexpr size_t lds_bytes=(size_t) 2*PLANE*sizeof(_Float16);
+  static constexpr int OUT_STRIDE=(UNITS+2)*4; // u16 per output row: 144 bytes, 16-byte aligned,
+                                               // 16 rows spread over 8 bank groups instead of 1
+  static constexpr int OUT=STEP*OUT_STRIDE;    // u16 of the column pass's output tile
+  static constexpr size_t ring_bytes=(size_t) 2*PLANE*sizeof(_Float16);
+  static constexpr size_t out_bytes=(size_t) OUT*sizeof(uint16_t);
 };
 
 // v = hi + lo with hi the top 11 significant bits of v (mantissa truncated in the integer
@@ -77,238 +100,277 @@ static __device__ __forceinline__ void split_f16(float v,_Float16 &hi,_Float16 &
 }
 
 // VERTICAL: units are pixel columns, the filter axis runs down the rows (column pass).
-// Workgroup tile: 32 units x (32*NG) outputs along the axis; wave w owns pixel group w
-// (8 units = 32 entries) and loops over the NG output groups.
-template<bool VERTICAL,int NQ,int NG>
+// 4 waves: wave w multiplies unit group w&1 (8 units = 32 entries) by output group w>>1
+// (32 outputs) of the step.
+template<bool VERTICAL,int NQ>
 __global__ __launch_bounds__(256)
 void conv_mfma_kernel(ConvMfmaArgs args)
 {
-  typedef MfmaGeometry<NQ,NG> G;
+  typedef MfmaGeometry<VERTICAL,NQ> G;
+  constexpr int R=G::R,kStripUnits=G::UNITS,kStepOutputs=G::STEP;
+  constexpr int MG=kStripUnits/8;              // unit groups; output groups = 4/MG
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   _Float16 *plane_hi=reinterpret_cast<_Float16 *>(smem_raw);
   _Float16 *plane_lo=plane_hi+G::PLANE;
-  const int tid=(int) threadIdx.x,lane=tid & 63,wave=tid >> 6;
+  uint16_t *tile_out=reinterpret_cast<uint16_t *>(plane_lo+G::PLANE);      // [64][16][4], column pass
+  const int tid=(int) threadIdx.x,lane=tid & 63;
+  const int wave=__builtin_amdgcn_readfirstlane(tid >> 6);
   const int n=lane & 31,half=lane >> 5;
+  const int mg=wave % MG,ng=wave/MG;
   const int K=args.ntaps;
   const int W=args.columns,H=args.rows;
+  const int axis_length=VERTICAL ? H : W,unit_count=VERTICAL ? W : H;
 
-  // ---- Toeplitz operands: T[q][i] = 256*tap[16q+8*half+i-n]
+  // ---- Toeplitz operands: T[q][i] = 256*tap[16q+8*half+i-n]; taps staged through LDS
   half8 t_hi[NQ],t_lo[NQ];
-#pragma unroll
-  for (int q=0; q < NQ; q++)
-#pragma unroll
-    for (int i=0; i < 8; i++)
-      {
-        const int j=16*q+8*half+i-n;
-        const float t=((j >= 0) && (j < K)) ? 256.0f*args.taps[j] : 0.0f;
-        _Float16 h,l;
-        split_f16(t,h,l);
-        t_hi[q][i]=h;
-        t_lo[q][i]=l;
-      }
-
-  // ---- persistent loop over tiles, a contiguous range per XCD (8 XCDs, round-robin ids)
-  const int nblocks=(int) gridDim.x,xcd=(int) blockIdx.x & 7,slot=(int) blockIdx.x >> 3;
-  const int per_xcd=(args.total_tiles+7)/8,blocks_per_xcd=nblocks >> 3;
-  const int range_begin=xcd*per_xcd;
-  const int range_end=range_begin+per_xcd < args.total_tiles ? range_begin+per_xcd : args.total_tiles;
-  // Raw pixels of a tile, fetched one tile ahead: the global loads of tile i+1 are in flight
-  // while tile i is multiplied, otherwise every tile pays the full load latency five times
-  // (measured: 0.67 ms per pass without the prefetch — latency-, not bandwidth-bound).
-  constexpr int NIT=((G::KR/4)*32+255)/256;
-  uint2 raw[NIT][4];
-  auto fetch=[&](int tile)
   {
-    const int t_major=tile/args.tiles_minor,t_minor=tile-t_major*args.tiles_minor;
-    const int unit0=32*t_major,in0=32*NG*t_minor-args.shift;
+    float *tap_lds=reinterpret_cast<float *>(smem_raw);
+    for (int j=tid; j < K; j+=256)
+      tap_lds[j]=args.taps[j];
+    __syncthreads();
 #pragma unroll
-    for (int it=0; it < NIT; it++)
+    for (int q=0; q < NQ; q++)
+#pragma unroll
+      for (int i=0; i < 8; i++)
+        {
+          const int j=16*q+8*half+i-n;
+          const float t=((j >= 0) && (j < K)) ? 256.0f*tap_lds[j] : 0.0f;
+          _Float16 h,l;
+          split_f16(t,h,l);
+          t_hi[q][i]=h;
+          t_lo[q][i]=l;
+        }
+  }
+
+  // staging role of this thread: 4 consecutive axis positions (`group`) of one unit
+  int stage_unit,stage_group;
+  if (VERTICAL)
+    {
+      // ds_write_b64 is served in contiguous 16-lane groups over 32 banks: 2 units x 8 groups
+      // per 16 lanes write 2 x 64 contiguous bytes, 128 bytes (mod 256) apart
+      stage_unit=8*(wave & 1)+(lane >> 3);
+      stage_group=8*(wave >> 1)+(lane & 7);
+    }
+  else
+    {
+      stage_unit=tid/(kStepOutputs/4);           // adjacent lanes: adjacent x groups of a row
+      stage_group=tid % (kStepOutputs/4);
+    }
+  uint2 raw[4];
+  // fetch the 4 samples at axis positions pos..pos+3 of this thread's unit (edge clamp,
+  // cache.c:2663-2679)
+  auto fetch=[&](uint2 (&buf)[4],int unit0,int pos)
+  {
+#pragma unroll
+    for (int i=0; i < 4; i++)
       {
-        int u=tid+256*it;
-        u=u < (G::KR/4)*32 ? u : (G::KR/4)*32-1;
-        int unit,group;
-        if (VERTICAL)
-          {
-            group=u >> 5;                        // lanes of a wave: 32 adjacent columns
-            unit=u & 31;
-          }
-        else
-          {
-            unit=u/(G::KR/4);                    // lanes of a wave: adjacent x groups of a row
-            group=u-unit*(G::KR/4);
-          }
+        int x=VERTICAL ? unit0+stage_unit : pos+i;
+        int y=VERTICAL ? pos+i : unit0+stage_unit;
+        x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
+        y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
+        buf[i]=*reinterpret_cast<const uint2 *>(args.src+((size_t) y*W+x)*4);
+      }
+  };
+  // convert raw[] and write it to ring slots slot..slot+3 (slot multiple of 4, no wrap inside)
+  auto stage=[&](const uint2 (&buf)[4],int slot)
+  {
+    float v[4][4];
+#pragma unroll
+    for (int i=0; i < 4; i++)
+      {
+        const uint2 r=buf[i];
+        const float alpha=(float) (r.y >> 16)*0.5f;
+        const float weight=alpha*(1.0f/65536.0f);
+        v[0][i]=(float) (r.x & 0xffffu)*weight;
+        v[1][i]=(float) (r.x >> 16)*weight;
+        v[2][i]=(float) (r.y & 0xffffu)*weight;
+        v[3][i]=alpha;
+      }
+#pragma unroll
+    for (int c=0; c < 4; c++)
+      {
+        half4 hi,lo;
 #pragma unroll
         for (int i=0; i < 4; i++)
           {
-            const int pos=in0+4*group+i;
-            int x=VERTICAL ? unit0+unit : pos;
-            int y=VERTICAL ? pos : unit0+unit;
-            x=x < 0 ? 0 : (x > W-1 ? W-1 : x);   // edge clamp, cache.c:2663-2679
-            y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
-            if ((args.skip & 4) == 0)
-              raw[it][i]=*reinterpret_cast<const uint2 *>(args.src+((size_t) y*W+x)*4);
-            else
-              raw[it][i]=make_uint2((unsigned) x,(unsigned) y);
+            _Float16 h,l;
+            split_f16(v[c][i],h,l);
+            hi[i]=h;
+            lo[i]=l;
           }
+        const int at=c*G::CH+stage_unit*G::S+slot;
+        *reinterpret_cast<half4 *>(plane_hi+at)=hi;
+        *reinterpret_cast<half4 *>(plane_lo+at)=lo;
       }
   };
-  const int first_tile=range_begin+slot;
-  if (first_tile < range_end)
-    fetch(first_tile);
-  for (int tile=first_tile; tile < range_end; tile+=blocks_per_xcd)
+
+  const int entry=(n & 3)*G::CH+(8*mg+(n >> 2))*G::S+8*half;    // this lane's operand line
+  const int items=args.strips*args.segments;
+  for (int item=(int) blockIdx.x; item < items; item+=(int) gridDim.x)
     {
-      // tiles_minor runs along the filter axis so that consecutive tiles share their halo
-      const int t_major=tile/args.tiles_minor,t_minor=tile-t_major*args.tiles_minor;
-      const int unit0=32*t_major;                  // first pixel column (V) / row (H)
-      const int out0=32*NG*t_minor;                // first output position along the axis
-      __syncthreads();                             // previous tile's readers are done
-      // ---- stage: 4 consecutive axis positions of one unit per thread and step
-#pragma unroll
-      for (int it=0; it < NIT; it++)
+      const int strip=item/args.segments,segment=item-strip*args.segments;
+      const int unit0=kStripUnits*strip;
+      const int step_begin=segment*args.steps_per_segment;
+      const int step_end=step_begin+args.steps_per_segment < args.steps ?
+        step_begin+args.steps_per_segment : args.steps;
+      const int out_begin=kStepOutputs*step_begin;
+      const int in0=out_begin-args.shift;        // axis position held by ring slot 0
+      __syncthreads();                           // ring and tap_lds readers of the last item are done
+      // ---- prologue: positions [in0, in0+R-64) -> slots [0, R-64)
+      for (int g0=0; g0 < (R-kStepOutputs)/4; g0+=kStepOutputs/4)
         {
-          const int u=tid+256*it;
-          if ((u >= (G::KR/4)*32) || ((args.skip & 2) != 0))
-            break;
-          int unit,group;
+          const int group=g0+stage_group;
+          if (group < (R-kStepOutputs)/4)
+            {
+              fetch(raw,unit0,in0+4*group);
+              stage(raw,4*group);
+            }
+        }
+      // first step's new positions [in0+R-64, in0+R)
+      fetch(raw,unit0,in0+R-kStepOutputs+4*stage_group);
+      stage(raw,R-kStepOutputs+4*stage_group);
+      __syncthreads();                           // the first step's samples are in the ring
+      int base=0;                                // ring slot of the step's first input position
+      for (int step=step_begin; step < step_end; step++)
+        {
+          const int out0=kStepOutputs*step;
+          const bool has_next=step+1 < step_end;
+          // The next step's 64 new positions, in flight during the multiply.  Order matters:
+          // loads and stores share one counter (vmcnt) and complete out of order with respect to
+          // each other, so a load can only be waited for with vmcnt(0) once a store is pending —
+          // this step's stores are therefore issued AFTER the next step's samples are staged.
+          if (has_next)
+            fetch(raw,unit0,in0+(out0-out_begin)+R+4*stage_group);
+          // ---- multiply
+          floatx16 acc;
+#pragma unroll
+          for (int r=0; r < 16; r++)
+            acc[r]=0.0f;
+          int chunk=base+32*ng;                  // wave-uniform
+          chunk=chunk >= R ? chunk-R : chunk;
+#pragma unroll
+          for (int q=0; q < NQ; q++)
+            {
+              const half8 a_hi=*reinterpret_cast<const half8 *>(plane_hi+entry+chunk);
+              const half8 a_lo=*reinterpret_cast<const half8 *>(plane_lo+entry+chunk);
+              acc=__builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi,t_hi[q],acc,0,0,0);
+              acc=__builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo,t_hi[q],acc,0,0,0);
+              acc=__builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi,t_lo[q],acc,0,0,0);
+              chunk+=16;
+              chunk=chunk >= R ? chunk-R : chunk;
+            }
+          // ---- epilogue: lane holds 4 pixels (reg>>2) x 4 channels (reg&3) of output n
+          uint2 result[4];
+#pragma unroll
+          for (int pg=0; pg < 4; pg++)
+            {
+              // S_c = 2^-9 * sum k*alpha*p, S_a = 128 * sum k*alpha:
+              //   gamma*pixel = sum(k*alpha*p)/sum(k*alpha) = 65536 * S_c / S_a
+              // v_rcp_f32(0) = inf and 0*inf = NaN convert to 0: PerceptibleReciprocal's clamp
+              // for an all-transparent window (as the vector FAST epilogue)
+              const float sa=acc[4*pg+3];
+              const float inv=__builtin_amdgcn_rcpf(sa)*65536.0f;
+              unsigned out[4];
+#pragma unroll
+              for (int c=0; c < 4; c++)
+                {
+                  const float pixel=c == 3 ? sa*(1.0f/128.0f) : acc[4*pg+c]*inv;
+                  unsigned q=(unsigned) (pixel+0.5f);        // NaN and negatives -> 0
+                  out[c]=q > 65535u ? 65535u : q;
+                }
+              result[pg]=make_uint2(out[0] | (out[1] << 16),out[2] | (out[3] << 16));
+              if (VERTICAL)
+                {
+                  const int unit_out=8*mg+2*pg+half;         // D row = (reg&3)+8*(reg>>2)+4*half
+                  const int pos_out=32*ng+n;
+                  *reinterpret_cast<uint2 *>(tile_out+(size_t) pos_out*G::OUT_STRIDE+unit_out*4)=result[pg];
+                }
+            }
+          __syncthreads();                       // B2: this step's ring slots may be overwritten
+          if (has_next)
+            {
+              int slot=base+4*stage_group;       // positions in0+R+64j+4g -> slots (64j+4g) mod R
+              slot=slot >= R ? slot-R : slot;
+              stage(raw,slot);
+            }
+          // ---- stores
           if (VERTICAL)
             {
-              group=u >> 5;
-              unit=u & 31;
+              // coalesced copy-out: STEP rows of UNITS pixels, 16 bytes (2 pixels) per thread
+#pragma unroll
+              for (int round=0; round < (kStepOutputs*kStripUnits/2)/256; round++)
+                {
+                  const int u=tid+256*round;
+                  const int row=u/(kStripUnits/2),pair=u % (kStripUnits/2);
+                  const int x=unit0+2*pair,y=out0+row;
+                  const uint16_t *from=tile_out+(size_t) row*G::OUT_STRIDE+2*pair*4;
+                  uint16_t *to=args.dst+((size_t) y*W+x)*4;
+                  if (y < H)
+                    {
+                      if (x+1 < W)
+                        *reinterpret_cast<uint4 *>(to)=*reinterpret_cast<const uint4 *>(from);
+                      else if (x < W)
+                        *reinterpret_cast<uint2 *>(to)=*reinterpret_cast<const uint2 *>(from);
+                    }
+                }
             }
           else
             {
-              unit=u/(G::KR/4);
-              group=u-unit*(G::KR/4);
-            }
-          float v[4][4];
 #pragma unroll
-          for (int i=0; i < 4; i++)
-            {
-              const uint2 r=raw[it][i];
-              const float alpha=(float) (r.y >> 16)*0.5f;
-              const float weight=alpha*(1.0f/65536.0f);
-              v[0][i]=(float) (r.x & 0xffffu)*weight;
-              v[1][i]=(float) (r.x >> 16)*weight;
-              v[2][i]=(float) (r.y & 0xffffu)*weight;
-              v[3][i]=alpha;
-            }
-#pragma unroll
-          for (int c=0; c < 4; c++)
-            {
-              half4 hi,lo;
-#pragma unroll
-              for (int i=0; i < 4; i++)
+              for (int pg=0; pg < 4; pg++)
                 {
-                  _Float16 h,l;
-                  split_f16(v[c][i],h,l);
-                  hi[i]=h;
-                  lo[i]=l;
+                  const int x=out0+32*ng+n,y=unit0+8*mg+2*pg+half;
+                  if ((x < W) && (y < H))
+                    *reinterpret_cast<uint2 *>(args.dst+((size_t) y*W+x)*4)=result[pg];
                 }
-              const int at=c*G::CH+unit*G::S+4*group;
-              *reinterpret_cast<half4 *>(plane_hi+at)=hi;
-              *reinterpret_cast<half4 *>(plane_lo+at)=lo;
             }
-        }
-      if (tile+blocks_per_xcd < range_end)
-        fetch(tile+blocks_per_xcd);
-      __syncthreads();
-      // ---- multiply: wave = pixel group (8 units), loop over the output groups
-      const int unit_local=8*wave+(n >> 2),channel=n & 3;
-      const int entry=channel*G::CH+unit_local*G::S+8*half;
-      floatx16 acc[NG];
-#pragma unroll
-      for (int g=0; g < NG; g++)
-        {
-#pragma unroll
-          for (int r=0; r < 16; r++)
-            acc[g][r]=0.0f;
-#pragma unroll
-          for (int q=0; q < ((args.skip & 1) != 0 ? 0 : NQ); q++)
-            {
-              const half8 a_hi=*reinterpret_cast<const half8 *>(plane_hi+entry+32*g+16*q);
-              const half8 a_lo=*reinterpret_cast<const half8 *>(plane_lo+entry+32*g+16*q);
-              acc[g]=__builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi,t_hi[q],acc[g],0,0,0);
-              acc[g]=__builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo,t_hi[q],acc[g],0,0,0);
-              acc[g]=__builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi,t_lo[q],acc[g],0,0,0);
-            }
-        }
-      if (VERTICAL)
-        __syncthreads();                           // the planes become the output tile
-      // ---- epilogue: lane holds 4 pixels (reg>>2) x 4 channels (reg&3) of output n
-      uint16_t *tile_out=reinterpret_cast<uint16_t *>(smem_raw);      // [32*NG][32][4] (VERTICAL)
-#pragma unroll
-      for (int g=0; g < NG; g++)
-#pragma unroll
-        for (int pg=0; pg < 4; pg++)
-          {
-            // S_c = 2^-9 * sum k*alpha*p, S_a = 128 * sum k*alpha:
-            //   gamma*pixel = sum(k*alpha*p)/sum(k*alpha) = 65536 * S_c / S_a
-            // v_rcp_f32(0) = inf and 0*inf = NaN convert to 0: PerceptibleReciprocal's clamp
-            // for an all-transparent window (as the vector FAST epilogue)
-            const float sa=acc[g][4*pg+3];
-            const float inv=__builtin_amdgcn_rcpf(sa)*65536.0f;
-            uint16_t out[4];
-#pragma unroll
-            for (int c=0; c < 4; c++)
-              {
-                const float pixel=c == 3 ? sa*(1.0f/128.0f) : acc[g][4*pg+c]*inv;
-                unsigned q=(unsigned) (pixel+0.5f);          // NaN and negatives -> 0
-                out[c]=(uint16_t) (q > 65535u ? 65535u : q);
-              }
-            const int unit_out=8*wave+2*pg+half;             // D row = (reg&3)+8*(reg>>2)+4*half
-            const int pos_out=32*g+n;
-            if ((args.skip & 8) != 0)
-              continue;
-            if (VERTICAL)
-              store_pixel<uint16_t,4>(tile_out+((size_t) pos_out*32+unit_out)*4,out);
-            else
-              {
-                const int x=out0+pos_out,y=unit0+unit_out;
-                if ((x < W) && (y < H))
-                  store_pixel<uint16_t,4>(args.dst+((size_t) y*W+x)*4,out);
-              }
-          }
-      if (VERTICAL)
-        {
-          __syncthreads();
-          // coalesced copy-out: 16 bytes (2 pixels) per thread and step, rows of 256 bytes
-          for (int u=tid; u < 32*NG*16; u+=256)
-            {
-              const int row=u >> 4,pair=u & 15;
-              const int x=unit0+2*pair,y=out0+row;
-              if (y >= H)
-                continue;
-              const uint16_t *from=tile_out+((size_t) row*32+2*pair)*4;
-              uint16_t *to=args.dst+((size_t) y*W+x)*4;
-              if (x+1 < W)
-                *reinterpret_cast<uint4 *>(to)=*reinterpret_cast<const uint4 *>(from);
-              else if (x < W)
-                *reinterpret_cast<uint2 *>(to)=*reinterpret_cast<const uint2 *>(from);
-            }
+          base+=kStepOutputs;
+          base=base >= R ? base-R : base;
+          __syncthreads();                       // next step's samples are in the ring; tile_out is free
         }
     }
+  (void) axis_length;
+  (void) unit_count;
 }
 
 template<bool VERTICAL,int NQ>
 static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
 {
-  constexpr int NG=2;
-  typedef MfmaGeometry<NQ,NG> G;
+  typedef MfmaGeometry<VERTICAL,NQ> G;
+  constexpr int kStripUnits=G::UNITS,kStepOutputs=G::STEP;
   const int units=VERTICAL ? args.columns : args.rows;
   const int axis=VERTICAL ? args.rows : args.columns;
-  args.tiles_major=(units+31)/32;
-  args.tiles_minor=(axis+32*NG-1)/(32*NG);
-  args.total_tiles=args.tiles_major*args.tiles_minor;
-  const size_t lds=G::lds_bytes;
-  const int per_cu=lds <= 80u*1024u ? 2 : 1;
-  int nblocks=compute_units(src.device)*per_cu;
-  nblocks=(nblocks/8)*8;
-  if (nblocks < 8)
-    nblocks=8;
-  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<VERTICAL,NQ,NG>),
+  args.strips=(units+kStripUnits-1)/kStripUnits;
+  args.steps=(axis+kStepOutputs-1)/kStepOutputs;
+  const size_t lds=G::ring_bytes+(VERTICAL ? G::out_bytes : 0);
+  int per_cu=(int) ((160u*1024u)/lds);
+  per_cu=per_cu > 3 ? 3 : (per_cu < 1 ? 1 : per_cu);       // 3 measured best (4 does not fit the LDS)
+  if (const char *e=getenv("MAGICKHIP_MFMA_PER_CU"))
+    per_cu=atoi(e);
+  const int nblocks=compute_units(src.device)*per_cu;
+  // Cut the strips into segments so that the work items divide evenly among the resident
+  // workgroups.  A segment re-stages R-64 positions, so it stays at least 8 steps long.
+  const int max_segments=args.steps/8 > 1 ? args.steps/8 : 1;
+  int segments=(nblocks+args.strips-1)/args.strips;
+  segments=segments < 1 ? 1 : (segments > max_segments ? max_segments : segments);
+  for (int s=segments; (s <= segments+8) && (s <= max_segments); s++)
+    if (((long) args.strips*s) % nblocks == 0)
+      {
+        segments=s;
+        break;
+      }
+  if ((((long) args.strips*segments) % nblocks != 0) && ((long) args.strips*segments < 4L*nblocks))
+    {
+      // no even split: at least four items per workgroup bound the imbalance to 25 %
+      int s=(int) ((4L*nblocks+args.strips-1)/args.strips);
+      segments=s > max_segments ? max_segments : s;
+    }
+  args.segments=segments;
+  args.steps_per_segment=(args.steps+segments-1)/segments;
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<VERTICAL,NQ>),
     hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
   ProfileScope prof(VERTICAL ? "conv_column" : "conv_row",src.stream);
-  hipLaunchKernelGGL((conv_mfma_kernel<VERTICAL,NQ,NG>),dim3((unsigned) nblocks),dim3(256),lds,
+  hipLaunchKernelGGL((conv_mfma_kernel<VERTICAL,NQ>),dim3((unsigned) nblocks),dim3(256),lds,
     src.stream,args);
   MH_HIP(hipGetLastError());
   return MH_OK;
@@ -332,7 +394,6 @@ MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const 
   args.ntaps=ntaps;
   args.shift=shift;
   args.taps=taps_device;
-  args.skip=getenv("MAGICKHIP_MFMA_SKIP") != nullptr ? atoi(getenv("MAGICKHIP_MFMA_SKIP")) : 0;
   *handled=true;
 #define MH_NQ(NQV) \
   case NQV: return vertical ? launch_mfma_typed<true,NQV>(src,args) : launch_mfma_typed<false,NQV>(src,args);
