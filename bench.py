@@ -200,16 +200,24 @@ def main():
                     traffic = json.load(open(pmc)).get(dominant)
                 except Exception:
                     traffic = None
-            # a 79-tap pass is ALU-bound, not HBM-bound: also report the FMA rate
-            # against the f32 vector peak.  Algorithmic flops of one pass: pixels*4 channels*taps*2.
+            # also report the arithmetic rate.  FAST forms the sums on the f16 matrix cores
+            # (convolve_mfma.hip: three f16 products per multiply-add, 112-wide Toeplitz band for 79
+            # taps), EXACT on the fp64 vector ALU.  Algorithmic flops of one pass:
+            # pixels * 4 channels * taps * 2.
             taps = 79 if abs(args.sigma - 10.0) < 1e-9 else None
             alu = None
             if taps:
                 flops = pixels * 4 * taps * 2.0
-                peak = 157.3 if args.precision == "fast" else 78.6
+                mfma = args.precision == "fast" and os.environ.get("MAGICKHIP_NO_MFMA") is None
+                peak = 2500.0 if mfma else (157.3 if args.precision == "fast" else 78.6)
                 alu = {"achieved_tflops": round(flops / (ms * 1e-3) / 1e12, 2), "peak_tflops": peak,
                        "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
-                       "note": "algorithmic multiply-adds only (alpha weighting, conversions and the "
+                       "unit": "f16 MFMA dense" if mfma else ("f32 vector" if args.precision == "fast"
+                                                             else "f64 vector"),
+                       "note": "algorithmic multiply-adds only; the matrix-core path executes "
+                               "3 x 112/79 = 4.3x as many (hi/lo operand split, band padding)"
+                               if mfma else
+                               "algorithmic multiply-adds only (alpha weighting, conversions and the "
                                "epilogue are extra work, not counted)"}
             roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -221,7 +229,9 @@ def main():
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64" if args.precision == "exact" else "f32", "data": "synthetic",
+            "dtype": "f64" if args.precision == "exact" else
+                     ("f32" if os.environ.get("MAGICKHIP_NO_MFMA") else "f16x2 products, f32 accumulate"),
+            "data": "synthetic",
             "tolerance": "bit-identical to the reference CPU path" if args.precision == "exact" else
                          "within +-1 Quantum level of the reference CPU path (tests/test_gpu_parity.py)",
             "config": {"workload": "%dx%d RGBA Q16 BlurImage(radius=0,sigma=%g): 79-tap row pass + "

@@ -230,17 +230,18 @@ void conv_mfma_kernel(ConvMfmaArgs args)
       fetch(raw,unit0,in0+R-kStepOutputs+4*stage_group);
       stage(raw,R-kStepOutputs+4*stage_group);
       __syncthreads();                           // the first step's samples are in the ring
+      // The 64 new positions of step j+1 are fetched a whole step ahead, right after step j's
+      // were staged.  Order matters: loads and stores share one counter (vmcnt) and complete out
+      // of order with respect to each other, so once a store is pending a load can only be waited
+      // for with vmcnt(0) — each step therefore issues its stores AFTER it has consumed the
+      // previous fetch and issued the next one, so that wait only ever sees old stores.
+      if (step_begin+1 < step_end)
+        fetch(raw,unit0,in0+R+4*stage_group);
       int base=0;                                // ring slot of the step's first input position
       for (int step=step_begin; step < step_end; step++)
         {
           const int out0=kStepOutputs*step;
           const bool has_next=step+1 < step_end;
-          // The next step's 64 new positions, in flight during the multiply.  Order matters:
-          // loads and stores share one counter (vmcnt) and complete out of order with respect to
-          // each other, so a load can only be waited for with vmcnt(0) once a store is pending —
-          // this step's stores are therefore issued AFTER the next step's samples are staged.
-          if (has_next)
-            fetch(raw,unit0,in0+(out0-out_begin)+R+4*stage_group);
           // ---- multiply
           floatx16 acc;
 #pragma unroll
@@ -292,6 +293,8 @@ void conv_mfma_kernel(ConvMfmaArgs args)
               int slot=base+4*stage_group;       // positions in0+R+64j+4g -> slots (64j+4g) mod R
               slot=slot >= R ? slot-R : slot;
               stage(raw,slot);
+              if (step+2 < step_end)
+                fetch(raw,unit0,in0+(out0-out_begin)+R+kStepOutputs+4*stage_group);
             }
           // ---- stores
           if (VERTICAL)

@@ -20,6 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     name = name.replace("void mh::", "")
+    if name.startswith("conv_mfma_kernel<"):         # <VERTICAL, NQ>: one kernel template, two passes
+        return "conv_column_mfma" if name.startswith("conv_mfma_kernel<true") else "conv_row_mfma"
     return name.split("<")[0].split("(")[0]
 
 
