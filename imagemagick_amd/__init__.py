@@ -21,7 +21,7 @@ from ._lib import (MagickHipError, MhImage, COLORSPACES, MORPHOLOGY, FILTERS,  #
 __all__ = ["Image", "blur_image", "convolve_image", "morphology_image", "morphology_primitive",
            "unsharp_mask_image", "resize_image", "contrast_stretch_image", "equalize_image",
            "transform_image_colorspace", "gaussian_blur_image", "sharpen_image", "edge_image",
-           "emboss_image", "grayscale_image", "function_image", "histogram", "apply_lut", "contrast_stretch_lut",
+           "emboss_image", "contrast_image", "modulate_image", "grayscale_image", "function_image", "histogram", "apply_lut", "contrast_stretch_lut",
            "equalize_lut", "is_image_gray", "set_precision", "get_precision", "device_count",
            "build", "load", "MagickHipError"]
 
@@ -298,6 +298,22 @@ def grayscale_image(image, method="rec709luma"):
     """GrayscaleImage(image, method), in place (first channel) — MagickCore/enhance.c:2476."""
     lib = _lib.load()
     _lib.check(lib.MagickHipGrayscaleImage(ctypes.byref(image.descriptor()), _lib.INTENSITY[method.lower()]))
+    return image
+
+
+def contrast_image(image, sharpen=True):
+    """ContrastImage(image, sharpen), in place — MagickCore/enhance.c:1392."""
+    lib = _lib.load()
+    _lib.check(lib.MagickHipContrastImage(ctypes.byref(image.descriptor()), 1 if sharpen else 0))
+    return image
+
+
+def modulate_image(image, brightness=100.0, saturation=100.0, hue=100.0, colorspace=None):
+    """ModulateImage(image, "brightness,saturation,hue"), in place — MagickCore/enhance.c:3665.
+    colorspace: None / "HSL" (default model) or "HSB"."""
+    lib = _lib.load()
+    model = {None: 0, "hsl": 8, "hsb": 6}[colorspace.lower() if colorspace else None]
+    _lib.check(lib.MagickHipModulateImage(ctypes.byref(image.descriptor()), brightness, saturation, hue, model))
     return image
 
 

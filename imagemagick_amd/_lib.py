@@ -160,6 +160,9 @@ PROTOTYPES = [
     ("MagickHipEqualizeImage", ctypes.c_int, [_P(MhImage)]),
     ("MagickHipTransformImageColorspace", ctypes.c_int, [_P(MhImage), ctypes.c_int]),
     ("MagickHipGrayscaleImage", ctypes.c_int, [_P(MhImage), ctypes.c_int]),
+    ("MagickHipContrastImage", ctypes.c_int, [_P(MhImage), ctypes.c_int]),
+    ("MagickHipModulateImage", ctypes.c_int, [_P(MhImage), ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                              ctypes.c_int]),
     ("MagickHipFunctionImage", ctypes.c_int, [_P(MhImage), ctypes.c_int, ctypes.c_size_t,
                                               _P(ctypes.c_double)]),
     ("MagickHipHistogram", ctypes.c_int, [_P(MhImage), ctypes.c_int, ctypes.c_void_p]),

@@ -184,6 +184,9 @@ MhStatus launch_build_lut(const View &img,const unsigned long long *hist_device,
 // CompositeImage(canvas,source,Difference|Lighten,clip_to_self,0,0) in place on the canvas
 enum { MH_COMPOSITE_DIFFERENCE=0,MH_COMPOSITE_LIGHTEN=1 };
 MhStatus launch_composite(const View &canvas,const View &source,int kind,const Roles &roles);
+MhStatus launch_contrast(const View &img,bool sharpen);
+MhStatus launch_modulate(const View &img,bool hsb,double hue_shift,double saturation_scale,
+  double brightness_scale);
 void release_color_tables();          // frees the per-device transfer-function tables
 MhStatus launch_gray_check(const View &img,const MhImage *desc,unsigned int *flag_device);
 MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,const MhImage *desc);

@@ -405,6 +405,35 @@ MH_API MhStatus MagickHipTransformImageColorspace(MhImage *image,MhColorspace co
   return MH_OK;
 }
 
+// ContrastImage, enhance.c:1392-1480
+MH_API MhStatus MagickHipContrastImage(MhImage *image,int sharpen)
+{
+  MH_TRY(check_image(image,"ContrastImage"));
+  InPlace io;
+  MH_TRY(io.open(image));
+  MH_TRY(launch_contrast(io.img.view,sharpen != 0));
+  return io.img.commit();
+}
+
+// ModulateImage, enhance.c:3665-3900 (HSL and HSB models)
+MH_API MhStatus MagickHipModulateImage(MhImage *image,double percent_brightness,
+  double percent_saturation,double percent_hue,int colorspace)
+{
+  MH_TRY(check_image(image,"ModulateImage"));
+  if ((colorspace != MH_COLORSPACE_UNDEFINED) && (colorspace != MH_COLORSPACE_HSL) &&
+      (colorspace != MH_COLORSPACE_HSB))
+    return fail(MH_UNSUPPORTED,"ModulateImage: colour model %d is not accelerated",colorspace);
+  InPlace io;
+  MH_TRY(io.open(image));
+  // the loop invariants of ModulateHSL / ModulateHSB, enhance.c:3512-3514, :3550-3552
+  const double hue_shift=fmod((percent_hue-100.0),200.0)/200.0;
+  const double saturation_scale=0.01*percent_saturation;
+  const double brightness_scale=0.01*percent_brightness;
+  MH_TRY(launch_modulate(io.img.view,colorspace == MH_COLORSPACE_HSB,hue_shift,saturation_scale,
+    brightness_scale));
+  return io.img.commit();
+}
+
 // GrayscaleImage, enhance.c:2476-2660
 MH_API MhStatus MagickHipGrayscaleImage(MhImage *image,MhIntensityMethod method)
 {

@@ -1309,6 +1309,229 @@ MhStatus launch_composite(const View &canvas,const View &source,int kind,const R
 #undef MH_CASE
 }
 
+// ---------------------------------------------------------------- ContrastImage / ModulateImage
+// HSB and HSL round trips in fp64 exactly as the CPU path writes them (every expression in
+// the reference's order; -ffp-contract=off): ConvertRGBToHSB / ConvertHSBToRGB
+// colorspace-private.h:867-908 / :292-365, ConvertRGBToHSL / ConvertHSLToRGB
+// colorspace.c:597-640 / :307-378.
+static __device__ void rgb_to_hsb(double red,double green,double blue,double &hue,double &saturation,
+  double &brightness)
+{
+  hue=0.0;
+  saturation=0.0;
+  brightness=0.0;
+  double mn=red < green ? red : green;
+  if (blue < mn)
+    mn=blue;
+  double mx=red > green ? red : green;
+  if (blue > mx)
+    mx=blue;
+  if (fabs(mx) < kEps)
+    return;
+  const double delta=mx-mn;
+  saturation=delta/mx;
+  brightness=kQS*mx;
+  if (fabs(delta) < kEps)
+    return;
+  if (fabs(red-mx) < kEps)
+    hue=(green-blue)/delta;
+  else if (fabs(green-mx) < kEps)
+    hue=2.0+(blue-red)/delta;
+  else
+    hue=4.0+(red-green)/delta;
+  hue/=6.0;
+  if (hue < 0.0)
+    hue+=1.0;
+}
+
+static __device__ void hsb_to_rgb(double hue,double saturation,double brightness,double &red,
+  double &green,double &blue)
+{
+  if (fabs(saturation) < kEps)
+    {
+      red=kQR*brightness;
+      green=red;
+      blue=red;
+      return;
+    }
+  const double h=6.0*(hue-floor(hue));
+  const double f=h-floor(h);
+  const double p=brightness*(1.0-saturation);
+  const double q=brightness*(1.0-saturation*f);
+  const double t=brightness*(1.0-(saturation*(1.0-f)));
+  switch ((int) h)
+  {
+    case 1: red=kQR*q; green=kQR*brightness; blue=kQR*p; break;
+    case 2: red=kQR*p; green=kQR*brightness; blue=kQR*t; break;
+    case 3: red=kQR*p; green=kQR*q; blue=kQR*brightness; break;
+    case 4: red=kQR*t; green=kQR*p; blue=kQR*brightness; break;
+    case 5: red=kQR*brightness; green=kQR*p; blue=kQR*q; break;
+    default: red=kQR*brightness; green=kQR*t; blue=kQR*p; break;        // 0
+  }
+}
+
+static __device__ void rgb_to_hsl(double red,double green,double blue,double &hue,double &saturation,
+  double &lightness)
+{
+  const double r=kQS*red,g=kQS*green,b=kQS*blue;
+  const double gb_max=g > b ? g : b,gb_min=g < b ? g : b;
+  const double mx=r > gb_max ? r : gb_max,mn=r < gb_min ? r : gb_min;
+  const double c=mx-mn;
+  lightness=(mx+mn)/2.0;
+  if (c <= 0.0)
+    {
+      hue=0.0;
+      saturation=0.0;
+      return;
+    }
+  if (fabs(mx-r) < kEps)
+    {
+      hue=(g-b)/c;
+      if (g < b)
+        hue+=6.0;
+    }
+  else if (fabs(mx-g) < kEps)
+    hue=2.0+(b-r)/c;
+  else
+    hue=4.0+(r-g)/c;
+  hue*=60.0/360.0;
+  if (lightness <= 0.5)
+    saturation=c*perceptible_reciprocal(2.0*lightness);
+  else
+    saturation=c*perceptible_reciprocal(2.0-2.0*lightness);
+}
+
+static __device__ void hsl_to_rgb(double hue,double saturation,double lightness,double &red,
+  double &green,double &blue)
+{
+  double h=hue*360.0,c;
+  if (lightness <= 0.5)
+    c=2.0*lightness*saturation;
+  else
+    c=(2.0-2.0*lightness)*saturation;
+  const double mn=lightness-0.5*c;
+  h-=360.0*floor(h/360.0);
+  h/=60.0;
+  const double x=c*(1.0-fabs(h-2.0*floor(h/2.0)-1.0));
+  switch ((int) floor(h))
+  {
+    case 1: red=kQR*(mn+x); green=kQR*(mn+c); blue=kQR*mn; break;
+    case 2: red=kQR*mn; green=kQR*(mn+c); blue=kQR*(mn+x); break;
+    case 3: red=kQR*mn; green=kQR*(mn+x); blue=kQR*(mn+c); break;
+    case 4: red=kQR*(mn+x); green=kQR*mn; blue=kQR*(mn+c); break;
+    case 5: red=kQR*(mn+c); green=kQR*mn; blue=kQR*(mn+x); break;
+    default: red=kQR*(mn+c); green=kQR*(mn+x); blue=kQR*mn; break;       // 0
+  }
+}
+
+enum ToneOp { TONE_CONTRAST=0,TONE_MODULATE_HSL=1,TONE_MODULATE_HSB=2 };
+
+struct ToneArgs
+{
+  int op;
+  double sign;                 // Contrast: +1 sharpen, -1 dull
+  double hue_shift,saturation_scale,brightness_scale;      // Modulate
+};
+
+// ContrastImage enhance.c:1370-1390 (per pixel), ModulateHSL / ModulateHSB :3499-3554
+template<typename Q,int C>
+__global__ __launch_bounds__(256)
+void tone_kernel(Q *__restrict__ pixels,size_t npixels,ToneArgs a)
+{
+  const size_t stride=(size_t) gridDim.x*blockDim.x*kPointBatch;
+  for (size_t i0=(size_t) blockIdx.x*blockDim.x*kPointBatch+threadIdx.x; i0 < npixels; i0+=stride)
+    {
+      Q qb[kPointBatch][C];
+#pragma unroll
+      for (int k=0; k < kPointBatch; k++)
+        {
+          const size_t ik=i0+(size_t) k*blockDim.x;
+          load_pixel<Q,C>(pixels+(ik < npixels ? ik : npixels-1)*C,qb[k]);
+        }
+#pragma unroll
+      for (int k=0; k < kPointBatch; k++)
+        {
+          const size_t i=i0+(size_t) k*blockDim.x;
+          double red=(double) qb[k][0],green=(double) qb[k][1],blue=(double) qb[k][2];
+          double hue,saturation,third;
+          if (a.op == TONE_CONTRAST)
+            {
+              rgb_to_hsb(red,green,blue,hue,saturation,third);
+              third+=0.5*a.sign*(0.5*(sin((double) (3.14159265358979323846264338327950288*(third-0.5)))+1.0)-third);
+              third=third > 1.0 ? 1.0 : (third < 0.0 ? 0.0 : third);
+              hsb_to_rgb(hue,saturation,third,red,green,blue);
+            }
+          else if (a.op == TONE_MODULATE_HSB)
+            {
+              rgb_to_hsb(red,green,blue,hue,saturation,third);
+              hue+=a.hue_shift;
+              saturation*=a.saturation_scale;
+              third*=a.brightness_scale;
+              hsb_to_rgb(hue,saturation,third,red,green,blue);
+            }
+          else
+            {
+              rgb_to_hsl(red,green,blue,hue,saturation,third);
+              hue+=a.hue_shift;
+              saturation*=a.saturation_scale;
+              third*=a.brightness_scale;
+              hsl_to_rgb(hue,saturation,third,red,green,blue);
+            }
+          qb[k][0]=QuantumOps<Q>::clamp(red);
+          qb[k][1]=QuantumOps<Q>::clamp(green);
+          qb[k][2]=QuantumOps<Q>::clamp(blue);
+          if (i < npixels)
+            store_pixel<Q,C>(pixels+i*C,qb[k]);
+        }
+    }
+}
+
+static MhStatus launch_tone(const View &img,const ToneArgs &a,const char *label)
+{
+  if ((img.channels != 3) && (img.channels != 4))
+    return fail(MH_UNSUPPORTED,"%s needs R,G,B[,A] channels",label);
+  const size_t n=img.columns*img.rows;
+  dim3 grid(stream_grid((n+kPointBatch-1)/kPointBatch)),block(256);
+  ProfileScope prof(label,img.stream);
+  if (img.quantum == MH_QUANTUM_U16)
+    {
+      if (img.channels == 3)
+        hipLaunchKernelGGL((tone_kernel<uint16_t,3>),grid,block,0,img.stream,static_cast<uint16_t *>(img.pixels),n,a);
+      else
+        hipLaunchKernelGGL((tone_kernel<uint16_t,4>),grid,block,0,img.stream,static_cast<uint16_t *>(img.pixels),n,a);
+    }
+  else
+    {
+      if (img.channels == 3)
+        hipLaunchKernelGGL((tone_kernel<float,3>),grid,block,0,img.stream,static_cast<float *>(img.pixels),n,a);
+      else
+        hipLaunchKernelGGL((tone_kernel<float,4>),grid,block,0,img.stream,static_cast<float *>(img.pixels),n,a);
+    }
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+MhStatus launch_contrast(const View &img,bool sharpen)
+{
+  ToneArgs a;
+  a.op=TONE_CONTRAST;
+  a.sign=sharpen ? 1.0 : -1.0;
+  a.hue_shift=a.saturation_scale=a.brightness_scale=0.0;
+  return launch_tone(img,a,"contrast");
+}
+
+MhStatus launch_modulate(const View &img,bool hsb,double hue_shift,double saturation_scale,
+  double brightness_scale)
+{
+  ToneArgs a;
+  a.op=hsb ? TONE_MODULATE_HSB : TONE_MODULATE_HSL;
+  a.sign=0.0;
+  a.hue_shift=hue_shift;
+  a.saturation_scale=saturation_scale;
+  a.brightness_scale=brightness_scale;
+  return launch_tone(img,a,"modulate");
+}
+
 // ---------------------------------------------------------------- GrayscaleImage
 // enhance.c:2476-2660: the intensity of (R,G,B) by `method` is written to the Gray
 // (= first) channel only; the caller then switches the image to GRAY / LinearGRAY.

@@ -93,6 +93,8 @@ typedef enum
 {
   MH_COLORSPACE_UNDEFINED = 0,
   MH_COLORSPACE_GRAY = 3,
+  MH_COLORSPACE_HSB = 6,       /* ModulateImage colour models only */
+  MH_COLORSPACE_HSL = 8,
   MH_COLORSPACE_LAB = 11,
   MH_COLORSPACE_LINEARGRAY = 33,
   MH_COLORSPACE_RGB = 21,      /* linear RGB */
@@ -357,6 +359,16 @@ typedef enum
   MH_FUNCTION_POLYNOMIAL,
   MH_FUNCTION_SINUSOID
 } MhFunction;
+
+/* AccelerateContrastImage: ContrastImage(image,sharpen), enhance.c:1392-1480 — brightness
+   pushed along a sine in HSB (Contrast(), :1370-1390).  R,G,B[,A] layouts. */
+MH_API MhStatus MagickHipContrastImage(MhImage *image,int sharpen);
+
+/* AccelerateModulateImage: ModulateImage's pixel loop, enhance.c:3776-3860, for the HSL
+   (default, colorspace = MH_COLORSPACE_UNDEFINED or MH_COLORSPACE_HSL) and HSB models.  The
+   three percentages are the parsed "brightness,saturation,hue" geometry (100 = unchanged). */
+MH_API MhStatus MagickHipModulateImage(MhImage *image,double percent_brightness,
+  double percent_saturation,double percent_hue,int colorspace);
 
 /* AccelerateFunctionImage (accelerate-private.h:56-57): FunctionImage / ApplyFunction,
    statistic.c:975-1160, on every channel whose trait carries Update. */

@@ -72,6 +72,8 @@ def _load(hdri, shim=False):
     L.ref_equalize.argtypes = [vp, pd]
     L.ref_colorspace.argtypes = [vp, cp, pd]
     L.ref_grayscale.argtypes = [vp, cp, pd]
+    L.ref_contrast.argtypes = [vp, ctypes.c_int, pd]
+    L.ref_modulate.argtypes = [vp, cp, pd]
     L.ref_function.argtypes = [vp, cp, sz, pd, pd]
     L.ref_kernel.argtypes = [cp, ctypes.c_int, ctypes.POINTER(sz), ctypes.POINTER(sz),
                              ctypes.POINTER(ctypes.c_ssize_t), ctypes.POINTER(ctypes.c_ssize_t),
@@ -201,6 +203,15 @@ class RefImage:
 
     def grayscale(self, method="Rec709Luma"):
         return self._inplace(self.L.ref_grayscale, method.encode())
+
+    def contrast(self, sharpen=True):
+        return self._inplace(self.L.ref_contrast, 1 if sharpen else 0)
+
+    def modulate(self, brightness=100.0, saturation=100.0, hue=100.0, colorspace=None):
+        """ModulateImage("brightness,saturation,hue"); colorspace = the modulate:colorspace artifact."""
+        if colorspace is not None:
+            self.L.ref_image_set_artifact(self.handle, b"modulate:colorspace", colorspace.encode())
+        return self._inplace(self.L.ref_modulate, ("%.17g,%.17g,%.17g" % (brightness, saturation, hue)).encode())
 
     def function(self, function, parameters):
         params = (ctypes.c_double * max(1, len(parameters)))(*parameters)

@@ -361,6 +361,24 @@ REF_API int ref_colorspace(void *handle,const char *colorspace,double *seconds)
   return(status != MagickFalse ? 0 : -1);
 }
 
+REF_API int ref_contrast(void *handle,int sharpen,double *seconds)
+{
+  MagickBooleanType status;
+  TIMED_BEGIN;
+  status=ContrastImage((Image *) handle,sharpen != 0 ? MagickTrue : MagickFalse,ref_exception);
+  TIMED_END;
+  return(status != MagickFalse ? 0 : -1);
+}
+
+REF_API int ref_modulate(void *handle,const char *modulate,double *seconds)
+{
+  MagickBooleanType status;
+  TIMED_BEGIN;
+  status=ModulateImage((Image *) handle,modulate,ref_exception);
+  TIMED_END;
+  return(status != MagickFalse ? 0 : -1);
+}
+
 REF_API int ref_grayscale(void *handle,const char *method,double *seconds)
 {
   MagickBooleanType status;

@@ -657,12 +657,6 @@ MagickPrivate Image *AccelerateWaveletDenoiseImage(const Image *magick_unused(im
   return((Image *) NULL);
 }
 
-MagickPrivate MagickBooleanType AccelerateContrastImage(Image *magick_unused(image),
-  const MagickBooleanType magick_unused(sharpen),ExceptionInfo *magick_unused(exception))
-{
-  return(MagickFalse);
-}
-
 /* In-place operator on the device copy of `image`; marks that copy as the newer one. */
 static MagickBooleanType AcquireInPlace(const Image *image,HipLibrary **library,
   MhImage *description,ExceptionInfo *exception)
@@ -724,12 +718,56 @@ MagickPrivate MagickBooleanType AccelerateGrayscaleImage(Image *image,
   return(MagickTrue);       /* the caller sets intensity, type and the GRAY colourspace */
 }
 
-MagickPrivate MagickBooleanType AccelerateModulateImage(Image *magick_unused(image),
-  const double magick_unused(percent_brightness),const double magick_unused(percent_hue),
-  const double magick_unused(percent_saturation),
-  const ColorspaceType magick_unused(colorspace),ExceptionInfo *magick_unused(exception))
+/* ContrastImage's call site is live in the reference (enhance.c:1412-1415) */
+MagickPrivate MagickBooleanType AccelerateContrastImage(Image *image,
+  const MagickBooleanType sharpen,ExceptionInfo *exception)
 {
-  return(MagickFalse);
+  HipLibrary
+    *library;
+
+  MhImage
+    description;
+
+  if ((image->number_channels < 3) ||
+      (AcquireInPlace(image,&library,&description,exception) == MagickFalse))
+    return(MagickFalse);
+  if (library->ContrastImage(&description,sharpen != MagickFalse ? 1 : 0) != MH_OK)
+    return(MagickFalse);
+  MarkDeviceCopyNewer(image);
+  hip_accelerated_calls++;
+  return(MagickTrue);
+}
+
+/*
+  ModulateImage's call site (enhance.c:3770-3774) passes the parsed percentages and the
+  modulate:colorspace model; HSL (also the default, UndefinedColorspace) and HSB are taken,
+  any other model or a color:illuminant artifact (which resets the model) is left to the CPU.
+*/
+MagickPrivate MagickBooleanType AccelerateModulateImage(Image *image,
+  const double percent_brightness,const double percent_hue,
+  const double percent_saturation,const ColorspaceType colorspace,
+  ExceptionInfo *exception)
+{
+  HipLibrary
+    *library;
+
+  MhImage
+    description;
+
+  if ((colorspace != UndefinedColorspace) && (colorspace != HSLColorspace) &&
+      (colorspace != HSBColorspace))
+    return(MagickFalse);
+  if ((image->number_channels < 3) ||
+      (GetImageArtifact(image,"color:illuminant") != (const char *) NULL) ||
+      (AcquireInPlace(image,&library,&description,exception) == MagickFalse))
+    return(MagickFalse);
+  /* ColorspaceType and MhColorspace share their values (colorspace.h:27-66) */
+  if (library->ModulateImage(&description,percent_brightness,percent_saturation,percent_hue,
+        (int) colorspace) != MH_OK)
+    return(MagickFalse);
+  MarkDeviceCopyNewer(image);
+  hip_accelerated_calls++;
+  return(MagickTrue);
 }
 
 #endif /* MAGICKCORE_OPENCL_SUPPORT */

@@ -97,6 +97,8 @@ MagickPrivate HipLibrary *AcquireHipLibrary(void)
   MH_RESOLVE(EqualizeImage,"MagickHipEqualizeImage");
   MH_RESOLVE(GrayscaleImage,"MagickHipGrayscaleImage");
   MH_RESOLVE(FunctionImage,"MagickHipFunctionImage");
+  MH_RESOLVE(ContrastImage,"MagickHipContrastImage");
+  MH_RESOLVE(ModulateImage,"MagickHipModulateImage");
   MH_RESOLVE(MorphologyImage,"MagickHipMorphologyImage");
   MH_RESOLVE(TransformImageColorspace,"MagickHipTransformImageColorspace");
 #undef MH_RESOLVE

@@ -110,6 +110,12 @@ def reference_vectors():
                                ("Arcsin", (0.8, 0.45, 1.0, 0.5)), ("Arctan", (4.0, 0.5, 1.0, 0.5))):
                 out[key + "_function_" + fn] = ref.RefImage(px).function(fn, params).numpy()
             if ch >= 3:
+                out[key + "_contrast_sharpen"] = ref.RefImage(px).contrast(True).numpy()
+                out[key + "_contrast_dull"] = ref.RefImage(px).contrast(False).numpy()
+                out[key + "_modulate_hsl"] = ref.RefImage(px).modulate(110.0, 80.0, 135.0).numpy()
+                out[key + "_modulate_hsl_dim"] = ref.RefImage(px).modulate(60.0, 150.0, 20.0).numpy()
+                out[key + "_modulate_hsb"] = ref.RefImage(px).modulate(120.0, 70.0, 160.0, "HSB").numpy()
+            if ch >= 3:
                 for m in ("Rec709Luma", "Rec601Luma", "Rec709Luminance", "Average", "Brightness", "Lightness",
                           "MS", "RMS"):
                     out[key + "_gray_" + m] = ref.RefImage(px).grayscale(m).numpy()

@@ -58,6 +58,43 @@ def test_blur_fast_precision_within_one_level(im, refmod):
     assert exact_fraction > 0.95
 
 
+@pytest.mark.parametrize("shape", [(5, 7), (1, 40), (40, 1), (33, 70), (64, 16), (17, 129), (130, 31)])
+@pytest.mark.parametrize("sigma", [0.8, 2.0, 6.5])
+def test_blur_fast_odd_shapes(im, refmod, shape, sigma):
+    """FAST RGBA blur (matrix-core passes) on images smaller than one strip / one step, with
+    partial strips and steps, and kernels from 7 to 53 taps: within +-1 level everywhere,
+    edges included."""
+    px = make_pixels(shape[0], shape[1], 4, Q16, seed=shape[0] * 131 + shape[1])
+    dev, ref = run_pair(im, refmod, px)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got = im.blur_image(dev, 0.0, sigma).numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert_parity(got, ref.blur(0.0, sigma).numpy(), False, "fast blur %s sigma %g" % (shape, sigma))
+
+
+def test_blur_fast_matrix_and_vector_paths_agree_within_one_level(im, refmod):
+    """MAGICKHIP_NO_MFMA=1 selects the f32 vector kernels: both FAST implementations honour the
+    same +-1 contract against the reference (they need not agree with each other exactly)."""
+    import os
+    px = make_pixels(97, 203, 4, Q16, seed=9)
+    dev, ref = run_pair(im, refmod, px)
+    want = ref.blur(0.0, 4.0).numpy()
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        matrix = im.blur_image(dev, 0.0, 4.0).numpy()
+        os.environ["MAGICKHIP_NO_MFMA"] = "1"
+        try:
+            vector = im.blur_image(dev, 0.0, 4.0).numpy()
+        finally:
+            del os.environ["MAGICKHIP_NO_MFMA"]
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert_parity(matrix, want, False, "matrix-core FAST")
+    assert_parity(vector, want, False, "vector FAST")
+
+
 def test_blur_channel_mask_copies_unselected_channels(im, refmod):
     px = make_pixels(40, 52, 4, Q16)
     ref = refmod.RefImage(px).set_channel_mask("RG")
@@ -188,6 +225,34 @@ def test_gaussian_blur_sharpen_edge_emboss(im, refmod, dtype, channels):
             ("emboss 0x1", im.emboss_image(dev, 0.0, 1.0), ref.emboss(0.0, 1.0)),
             ("emboss 2x0.7", im.emboss_image(dev, 2.0, 0.7), ref.emboss(2.0, 0.7))):
         assert_parity(got.numpy(), want.numpy(), True, "%s c%d" % (name, channels))
+
+
+# ----------------------------------------------------------- ContrastImage / ModulateImage
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("channels", [3, 4])
+def test_contrast_and_modulate(im, refmod, dtype, channels):
+    """ContrastImage (HSB sine push) and ModulateImage (HSL default, HSB): fp64 as the CPU path;
+    the one libm call (sin) may differ in the last bit, which Q16 rounding hides and float
+    Quantum may show as 1 ULP."""
+    px = make_pixels(61, 83, channels, dtype)
+    gray = make_pixels(8, 83, channels, dtype)
+    gray[:, :, 1] = gray[:, :, 0]
+    gray[:, :, 2] = gray[:, :, 0]                      # zero saturation rows
+    px = np.concatenate([px, gray], axis=0)
+    for name, run_gpu, run_ref in (
+            ("contrast +", lambda i: im.contrast_image(i, True), lambda r: r.contrast(True)),
+            ("contrast -", lambda i: im.contrast_image(i, False), lambda r: r.contrast(False)),
+            ("modulate 110,80,135", lambda i: im.modulate_image(i, 110.0, 80.0, 135.0),
+             lambda r: r.modulate(110.0, 80.0, 135.0)),
+            ("modulate 60,150,20", lambda i: im.modulate_image(i, 60.0, 150.0, 20.0),
+             lambda r: r.modulate(60.0, 150.0, 20.0)),
+            ("modulate 100,100,100", lambda i: im.modulate_image(i), lambda r: r.modulate()),
+            ("modulate HSB 120,70,160", lambda i: im.modulate_image(i, 120.0, 70.0, 160.0, "HSB"),
+             lambda r: r.modulate(120.0, 70.0, 160.0, "HSB"))):
+        dev, ref = run_pair(im, refmod, px)
+        run_gpu(dev)
+        run_ref(ref)
+        assert_parity(dev.numpy(), ref.numpy(), True, "%s c%d" % (name, channels), max_ulp=1)
 
 
 # ----------------------------------------------------------- UnsharpMaskImage

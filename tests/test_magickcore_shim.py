@@ -178,3 +178,24 @@ def test_colorspace_and_contrast_stretch_chain(shim, dtype):
         c.colorspace(target)
         assert g.info()["colorspace"] == c.info()["colorspace"], target
         assert_parity(g.numpy(), c.numpy(), True, "-> %s via MagickCore" % target, max_ulp=1)
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_contrast_and_modulate_through_magickcore(shim, dtype):
+    """AccelerateContrastImage / AccelerateModulateImage have live call sites in the reference
+    (enhance.c:1412-1415, :3770-3774); a colour model the backend does not take (HWB) falls back."""
+    hdri = dtype == np.float32
+    px = make_pixels(50, 66, 4, dtype)
+    before = accelerated_calls(shim, hdri)
+    g, c = shim.RefImage(px, shim=True), shim.RefImage(px)
+    assert_parity(g.contrast(True).numpy(), c.contrast(True).numpy(), True, "ContrastImage via MagickCore", max_ulp=1)
+    assert accelerated_calls(shim, hdri) == before + 1
+    assert_parity(g.modulate(115.0, 85.0, 140.0).numpy(), c.modulate(115.0, 85.0, 140.0).numpy(), True,
+                  "ModulateImage via MagickCore", max_ulp=1)
+    assert accelerated_calls(shim, hdri) == before + 2
+    assert_parity(g.modulate(90.0, 120.0, 70.0, "HSB").numpy(), c.modulate(90.0, 120.0, 70.0, "HSB").numpy(), True,
+                  "ModulateImage HSB via MagickCore", max_ulp=1)
+    assert accelerated_calls(shim, hdri) == before + 3
+    assert_parity(g.modulate(90.0, 120.0, 70.0, "HWB").numpy(), c.modulate(90.0, 120.0, 70.0, "HWB").numpy(), True,
+                  "ModulateImage HWB (CPU fallback)", max_ulp=1)
+    assert accelerated_calls(shim, hdri) == before + 3

@@ -158,6 +158,23 @@ def test_compound_morphology_matches_reference(vectors, tag, ch):
                      vectors["%s_c%d_edge_disk2.5_x2" % (tag, ch)], "Edge x2")
 
 
+@pytest.mark.parametrize("tag,ch", [c for c in CASES if c[1] >= 3])
+def test_contrast_and_modulate_match_reference(vectors, tag, ch):
+    """ContrastImage / ModulateImage (HSB, HSL round trips).  The restatement calls NumPy's sin
+    where the reference calls libm's: identical here, but allow the last float bit on HDRI."""
+    px = vectors["%s_c%d_in" % (tag, ch)]
+    cases = (("contrast_sharpen", R.contrast_image(px, True)), ("contrast_dull", R.contrast_image(px, False)),
+             ("modulate_hsl", R.modulate_image(px, 110.0, 80.0, 135.0)),
+             ("modulate_hsl_dim", R.modulate_image(px, 60.0, 150.0, 20.0)),
+             ("modulate_hsb", R.modulate_image(px, 120.0, 70.0, 160.0, "hsb")))
+    for name, got in cases:
+        want = vectors["%s_c%d_%s" % (tag, ch, name)]
+        if tag == "hdri":
+            assert_identical(got, want, name, max_ulp=1)
+        else:
+            assert_identical(got, want, name)
+
+
 @pytest.mark.parametrize("tag,ch", CASES)
 def test_resize_matches_reference(vectors, tag, ch):
     px = vectors["%s_c%d_in" % (tag, ch)]
