@@ -21,7 +21,7 @@ from ._lib import (MagickHipError, MhImage, COLORSPACES, MORPHOLOGY, FILTERS,  #
 __all__ = ["Image", "blur_image", "convolve_image", "morphology_image", "morphology_primitive",
            "unsharp_mask_image", "resize_image", "contrast_stretch_image", "equalize_image",
            "transform_image_colorspace", "gaussian_blur_image", "sharpen_image", "edge_image",
-           "emboss_image", "contrast_image", "modulate_image", "grayscale_image", "function_image", "histogram", "apply_lut", "contrast_stretch_lut",
+           "emboss_image", "import_image_pixels", "export_image_pixels", "contrast_image", "modulate_image", "grayscale_image", "function_image", "histogram", "apply_lut", "contrast_stretch_lut",
            "equalize_lut", "is_image_gray", "set_precision", "get_precision", "device_count",
            "build", "load", "MagickHipError"]
 
@@ -299,6 +299,48 @@ def grayscale_image(image, method="rec709luma"):
     lib = _lib.load()
     _lib.check(lib.MagickHipGrayscaleImage(ctypes.byref(image.descriptor()), _lib.INTENSITY[method.lower()]))
     return image
+
+
+# StorageType, MagickCore/pixel.h:146-156
+STORAGE = {"uint8": 1, "float64": 2, "float32": 3, "uint32": 4, "uint64": 5, "uint16": 7}
+_TORCH_STORAGE = {"torch.uint8": 1, "torch.float64": 2, "torch.float32": 3, "torch.uint32": 4, "torch.uint64": 5,
+                  "torch.uint16": 7, "torch.int16": 7, "torch.int32": 4, "torch.int64": 5}
+
+
+def _component_buffer(data):
+    """(pointer, storage, memory kind, height, width, components, keep-alive) of a NumPy array or
+    a CUDA tensor shaped [height, width, components]."""
+    if isinstance(data, np.ndarray):
+        data = np.ascontiguousarray(data)
+        return data.ctypes.data, STORAGE[data.dtype.name], _lib.MEMORY_HOST, data
+    data = data.contiguous()
+    return data.data_ptr(), _TORCH_STORAGE[str(data.dtype)], _lib.MEMORY_DEVICE, data
+
+
+def import_image_pixels(image, x, y, map, data):
+    """ImportImagePixels(image, x, y, width, height, map, type, pixels) — MagickCore/pixel.c:4164.
+    data: [height, width, len(map)] NumPy array (host) or CUDA tensor (device)."""
+    lib = _lib.load()
+    ptr, storage, memory, keep = _component_buffer(data)
+    assert keep.shape[2] == len(map)
+    _lib.check(lib.MagickHipImportImagePixels(ctypes.byref(image.descriptor()), x, y, keep.shape[1], keep.shape[0],
+                                              map.encode(), storage, ptr, memory))
+    return image
+
+
+def export_image_pixels(image, x, y, map, out):
+    """ExportImagePixels into `out` ([height, width, len(map)] NumPy array or CUDA tensor) —
+    MagickCore/pixel.c:1962."""
+    lib = _lib.load()
+    if isinstance(out, np.ndarray):
+        assert out.flags["C_CONTIGUOUS"]
+    else:
+        assert out.is_contiguous()
+    ptr, storage, memory, keep = _component_buffer(out)
+    assert keep.shape[2] == len(map)
+    _lib.check(lib.MagickHipExportImagePixels(ctypes.byref(image.descriptor()), x, y, keep.shape[1], keep.shape[0],
+                                              map.encode(), storage, ptr, memory))
+    return out
 
 
 def contrast_image(image, sharpen=True):

@@ -160,6 +160,12 @@ PROTOTYPES = [
     ("MagickHipEqualizeImage", ctypes.c_int, [_P(MhImage)]),
     ("MagickHipTransformImageColorspace", ctypes.c_int, [_P(MhImage), ctypes.c_int]),
     ("MagickHipGrayscaleImage", ctypes.c_int, [_P(MhImage), ctypes.c_int]),
+    ("MagickHipImportImagePixels", ctypes.c_int, [_P(MhImage), ctypes.c_ssize_t, ctypes.c_ssize_t, ctypes.c_size_t,
+                                                  ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int,
+                                                  ctypes.c_void_p, ctypes.c_int]),
+    ("MagickHipExportImagePixels", ctypes.c_int, [_P(MhImage), ctypes.c_ssize_t, ctypes.c_ssize_t, ctypes.c_size_t,
+                                                  ctypes.c_size_t, ctypes.c_char_p, ctypes.c_int,
+                                                  ctypes.c_void_p, ctypes.c_int]),
     ("MagickHipContrastImage", ctypes.c_int, [_P(MhImage), ctypes.c_int]),
     ("MagickHipModulateImage", ctypes.c_int, [_P(MhImage), ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                               ctypes.c_int]),

@@ -187,6 +187,9 @@ MhStatus launch_composite(const View &canvas,const View &source,int kind,const R
 MhStatus launch_contrast(const View &img,bool sharpen);
 MhStatus launch_modulate(const View &img,bool hsb,double hue_shift,double saturation_scale,
   double brightness_scale);
+size_t storage_size(MhStorageType type,MhQuantumKind quantum);
+MhStatus launch_pixel_io(bool import,const View &img,const MhImage *desc,int x,int y,int width,
+  int height,const char *map,MhStorageType type,void *buffer_device);
 void release_color_tables();          // frees the per-device transfer-function tables
 MhStatus launch_gray_check(const View &img,const MhImage *desc,unsigned int *flag_device);
 MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,const MhImage *desc);

@@ -434,6 +434,72 @@ MH_API MhStatus MagickHipModulateImage(MhImage *image,double percent_brightness,
   return io.img.commit();
 }
 
+// ImportImagePixels / ExportImagePixels, pixel.c:4164 / :1962
+static MhStatus pixel_io(bool import,const MhImage *image,ptrdiff_t x,ptrdiff_t y,size_t width,
+  size_t height,const char *map,MhStorageType type,void *pixels,MhMemoryKind pixels_memory)
+{
+  const char *what=import ? "ImportImagePixels" : "ExportImagePixels";
+  MH_TRY(check_image(image,what));
+  if ((map == nullptr) || (pixels == nullptr))
+    return fail(MH_BAD_ARGUMENT,"%s: null map or pixels",what);
+  if ((width == 0) || (height == 0) || (x < 0) || (y < 0) ||
+      ((size_t) x+width > image->columns) || ((size_t) y+height > image->rows))
+    return fail(MH_UNSUPPORTED,"%s: the region must lie inside the image",what);
+  const size_t element=storage_size(type,(MhQuantumKind) image->quantum);
+  if (element == 0)
+    return fail(MH_BAD_ARGUMENT,"%s: unknown storage type %d",what,(int) type);
+  const size_t bytes=width*height*strlen(map)*element;
+  Resident img;
+  int device=resolve_device(image);
+  hipStream_t stream=image->memory == MH_MEMORY_DEVICE ? (hipStream_t) image->stream :
+    library_stream(device);
+  // import modifies the image (upload + download unless the map covers it: keep it simple,
+  // mode 2); export only reads it
+  MH_TRY(img.open(image,import ? 2 : 0,stream,device));
+  img.view.stream=stream;
+  img.view.device=device;
+  MH_HIP(hipSetDevice(device));
+  Temp staged;
+  void *buffer=pixels;
+  if (pixels_memory == MH_MEMORY_HOST)
+    {
+      MH_TRY(staged.alloc(device,bytes,stream));
+      buffer=staged.ptr;
+      if (import)
+        MH_HIP(hipMemcpyAsync(buffer,pixels,bytes,hipMemcpyHostToDevice,stream));
+      else
+        {
+          // pads the reference leaves untouched must survive the round trip
+          bool has_pad=false;
+          for (const char *m=map; *m != 0; m++)
+            has_pad|=(*m == 'P') || (*m == 'p');
+          if (has_pad)
+            MH_HIP(hipMemcpyAsync(buffer,pixels,bytes,hipMemcpyHostToDevice,stream));
+        }
+    }
+  MH_TRY(launch_pixel_io(import,img.view,image,(int) x,(int) y,(int) width,(int) height,map,type,
+    buffer));
+  if (!import && (pixels_memory == MH_MEMORY_HOST))
+    {
+      MH_HIP(hipMemcpyAsync(pixels,buffer,bytes,hipMemcpyDeviceToHost,stream));
+      MH_HIP(hipStreamSynchronize(stream));
+    }
+  return img.commit();
+}
+
+MH_API MhStatus MagickHipImportImagePixels(MhImage *image,ptrdiff_t x,ptrdiff_t y,size_t width,
+  size_t height,const char *map,MhStorageType type,const void *pixels,MhMemoryKind pixels_memory)
+{
+  return pixel_io(true,image,x,y,width,height,map,type,const_cast<void *>(pixels),pixels_memory);
+}
+
+MH_API MhStatus MagickHipExportImagePixels(const MhImage *image,ptrdiff_t x,ptrdiff_t y,
+  size_t width,size_t height,const char *map,MhStorageType type,void *pixels,
+  MhMemoryKind pixels_memory)
+{
+  return pixel_io(false,image,x,y,width,height,map,type,pixels,pixels_memory);
+}
+
 // GrayscaleImage, enhance.c:2476-2660
 MH_API MhStatus MagickHipGrayscaleImage(MhImage *image,MhIntensityMethod method)
 {

@@ -20,6 +20,8 @@
 #include <map>
 #include <mutex>
 #include <cstdlib>
+#include <cstring>
+#include <strings.h>
 
 namespace mh {
 
@@ -1828,5 +1830,7 @@ MhStatus launch_copy(const View &src,const View &dst)
   MH_HIP(hipMemcpyAsync(dst.pixels,src.pixels,src.bytes(),hipMemcpyDeviceToDevice,src.stream));
   return MH_OK;
 }
+
+#include "pixel_io.inc.hpp"
 
 } // namespace mh

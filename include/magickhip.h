@@ -360,6 +360,27 @@ typedef enum
   MH_FUNCTION_SINUSOID
 } MhFunction;
 
+/* StorageType, MagickCore/pixel.h:146-156 (same values) */
+typedef enum
+{
+  MH_STORAGE_UNDEFINED = 0,
+  MH_STORAGE_CHAR, MH_STORAGE_DOUBLE, MH_STORAGE_FLOAT, MH_STORAGE_LONG, MH_STORAGE_LONGLONG,
+  MH_STORAGE_QUANTUM, MH_STORAGE_SHORT
+} MhStorageType;
+
+/* ImportImagePixels / ExportImagePixels, pixel.c:4164 / :1962: converts between
+   the caller's interleaved component buffer and the Quantum pixels of `image`, for the region
+   x,y,width,height (inside the image).  `map` lists the buffer's components, any order of
+   R,G,B,A,O (= alpha),I (gray / intensity),P (pad); C,M,Y,K are not accelerated.  `pixels` is
+   width*height*strlen(map) tightly packed elements of `type`, in host or device memory
+   (`pixels_memory`).  The image must already have the layout the map implies (alpha channel
+   present for A/O; the reference's side effects on alpha_trait / colourspace are the caller's). */
+MH_API MhStatus MagickHipImportImagePixels(MhImage *image,ptrdiff_t x,ptrdiff_t y,size_t width,
+  size_t height,const char *map,MhStorageType type,const void *pixels,MhMemoryKind pixels_memory);
+MH_API MhStatus MagickHipExportImagePixels(const MhImage *image,ptrdiff_t x,ptrdiff_t y,
+  size_t width,size_t height,const char *map,MhStorageType type,void *pixels,
+  MhMemoryKind pixels_memory);
+
 /* AccelerateContrastImage: ContrastImage(image,sharpen), enhance.c:1392-1480 — brightness
    pushed along a sine in HSB (Contrast(), :1370-1390).  R,G,B[,A] layouts. */
 MH_API MhStatus MagickHipContrastImage(MhImage *image,int sharpen);

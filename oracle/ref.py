@@ -72,6 +72,8 @@ def _load(hdri, shim=False):
     L.ref_equalize.argtypes = [vp, pd]
     L.ref_colorspace.argtypes = [vp, cp, pd]
     L.ref_grayscale.argtypes = [vp, cp, pd]
+    L.ref_import_pixels.argtypes = [vp, ctypes.c_ssize_t, ctypes.c_ssize_t, sz, sz, cp, ctypes.c_int, vp]
+    L.ref_export_pixels.argtypes = [vp, ctypes.c_ssize_t, ctypes.c_ssize_t, sz, sz, cp, ctypes.c_int, vp]
     L.ref_contrast.argtypes = [vp, ctypes.c_int, pd]
     L.ref_modulate.argtypes = [vp, cp, pd]
     L.ref_function.argtypes = [vp, cp, sz, pd, pd]
@@ -91,6 +93,10 @@ def _load(hdri, shim=False):
 
 
 _MAPS = {1: "GRAY", 2: "GRAYA", 3: "RGB", 4: "RGBA"}
+
+
+# StorageType, MagickCore/pixel.h:146-156
+STORAGE = {"uint8": 1, "float64": 2, "float32": 3, "uint32": 4, "uint64": 5, "uint16": 7}
 
 
 class RefImage:
@@ -203,6 +209,22 @@ class RefImage:
 
     def grayscale(self, method="Rec709Luma"):
         return self._inplace(self.L.ref_grayscale, method.encode())
+
+    def import_pixels(self, x, y, map, data):
+        """ImportImagePixels: data is [height, width, len(map)] of uint8/16/32/64, float32/64."""
+        data = np.ascontiguousarray(data)
+        if self.L.ref_import_pixels(self.handle, x, y, data.shape[1], data.shape[0], map.encode(),
+                                    STORAGE[data.dtype.name], data.ctypes.data) != 0:
+            raise RuntimeError("ImportImagePixels failed: %s" % self.L.ref_last_error().decode())
+        return self
+
+    def export_pixels(self, x, y, width, height, map, dtype, out=None):
+        """ExportImagePixels into a new (or the given) [height, width, len(map)] array."""
+        out = np.zeros((height, width, len(map)), dtype=dtype) if out is None else out
+        if self.L.ref_export_pixels(self.handle, x, y, width, height, map.encode(),
+                                    STORAGE[np.dtype(dtype).name], out.ctypes.data) != 0:
+            raise RuntimeError("ExportImagePixels failed: %s" % self.L.ref_last_error().decode())
+        return out
 
     def contrast(self, sharpen=True):
         return self._inplace(self.L.ref_contrast, 1 if sharpen else 0)

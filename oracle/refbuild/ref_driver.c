@@ -361,6 +361,21 @@ REF_API int ref_colorspace(void *handle,const char *colorspace,double *seconds)
   return(status != MagickFalse ? 0 : -1);
 }
 
+/* ImportImagePixels / ExportImagePixels with the reference's StorageType numbering */
+REF_API int ref_import_pixels(void *handle,ssize_t x,ssize_t y,size_t width,size_t height,
+  const char *map,int storage,const void *pixels)
+{
+  return(ImportImagePixels((Image *) handle,x,y,width,height,map,(StorageType) storage,pixels,
+    ref_exception) != MagickFalse ? 0 : -1);
+}
+
+REF_API int ref_export_pixels(const void *handle,ssize_t x,ssize_t y,size_t width,size_t height,
+  const char *map,int storage,void *pixels)
+{
+  return(ExportImagePixels((const Image *) handle,x,y,width,height,map,(StorageType) storage,
+    pixels,ref_exception) != MagickFalse ? 0 : -1);
+}
+
 REF_API int ref_contrast(void *handle,int sharpen,double *seconds)
 {
   MagickBooleanType status;

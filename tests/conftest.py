@@ -30,6 +30,12 @@ def im():
 
 
 @pytest.fixture(scope="session")
+def vectors():
+    """Committed outputs of the reference's own CPU code (tests/golden/make_golden.py)."""
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_vectors.npz"))
+
+
+@pytest.fixture(scope="session")
 def refmod():
     """The compiled reference oracle (oracle/_ref); skip when it was not built."""
     from oracle import ref

@@ -59,6 +59,8 @@ def perlmagick():
     print("perlmagick_filter.npz:", {k: v.shape for k, v in out.items()})
 
 
+IO_TYPES = [("uint8", np.uint8), ("uint16", np.uint16), ("uint32", np.uint32), ("uint64", np.uint64),
+            ("float32", np.float32), ("float64", np.float64)]
 KERNEL_LISTS = ["Edges", "Corners", "Diagonals", "Diagonals:1,45", "Diagonals:2", "LineEnds", "LineEnds:3>",
                 "LineEnds:4,90", "LineJunctions", "LineJunctions:3@", "LineJunctions:4", "LineJunctions:5",
                 "Ridges", "Ridges:2", "ConvexHull", "Skeleton", "Skeleton:2", "Skeleton:3", "ThinSE:41",
@@ -141,6 +143,31 @@ def reference_vectors():
         values, x, y, _ = ref.kernel(s)
         out["kernel|" + s] = values
         out["kernel_origin|" + s] = np.array([x, y])
+    # ImportImagePixels / ExportImagePixels: every storage type, several maps, a sub-region
+    io = np.random.default_rng(77)
+    for hdri in (False, True):
+        tag = "hdri" if hdri else "q16"
+        base = make_pixels(io, 19, 23, 4, hdri)
+        out[tag + "_io_base"] = base
+        gray = make_pixels(io, 19, 23, 2, hdri)
+        out[tag + "_io_gray_base"] = gray
+        for name, dt in IO_TYPES:
+            for m in ("RGBA", "BGRA", "RGB", "ARGB", "BGRP", "RAB"):
+                if dt in (np.float32, np.float64):
+                    data = (io.random((7, 9, len(m))) * 1.3 - 0.15).astype(dt)
+                else:
+                    data = io.integers(0, np.iinfo(dt).max, (7, 9, len(m)), dtype=dt, endpoint=True)
+                out["%s_import|%s|%s|data" % (tag, name, m)] = data
+                out["%s_import|%s|%s" % (tag, name, m)] = ref.RefImage(base).import_pixels(5, 3, m, data).numpy()
+            data = (io.random((7, 9, 2)).astype(dt) if dt in (np.float32, np.float64) else
+                    io.integers(0, np.iinfo(dt).max, (7, 9, 2), dtype=dt, endpoint=True))
+            out["%s_import|%s|IA|data" % (tag, name)] = data
+            out["%s_import|%s|IA" % (tag, name)] = ref.RefImage(gray).import_pixels(5, 3, "IA", data).numpy()
+            for m in ("RGBA", "BGRA", "RGB", "ARGB", "BGRP", "RGBP", "I", "IA", "RPPA"):
+                out["%s_export|%s|%s" % (tag, name, m)] = ref.RefImage(base).export_pixels(4, 2, 11, 8, m, dt)
+            out["%s_export_gray|%s|IA" % (tag, name)] = ref.RefImage(gray).export_pixels(4, 2, 11, 8, "IA", dt)
+        out["%s_export_noalpha|uint16|RGBA" % tag] = ref.RefImage(base[:, :, :3].copy()).export_pixels(
+            0, 0, 23, 19, "RGBA", np.uint16)
     # kernel lists: every kernel of the named hit-and-miss sets, rotation / mirror expansions
     for s in KERNEL_LISTS:
         first = ref.kernel(s)

@@ -175,6 +175,31 @@ def test_contrast_and_modulate_match_reference(vectors, tag, ch):
             assert_identical(got, want, name)
 
 
+IO_TYPES = ["uint8", "uint16", "uint32", "uint64", "float32", "float64"]
+
+
+@pytest.mark.parametrize("tag", ["q16", "hdri"])
+@pytest.mark.parametrize("kind", IO_TYPES)
+def test_import_export_pixels_match_reference(vectors, tag, kind):
+    """ImportImagePixels / ExportImagePixels: every storage type, component orders with pads,
+    alpha first, a repeated channel, gray+alpha images, a sub-region."""
+    base, gray = vectors[tag + "_io_base"], vectors[tag + "_io_gray_base"]
+    for m in ("RGBA", "BGRA", "RGB", "ARGB", "BGRP", "RAB"):
+        data = vectors["%s_import|%s|%s|data" % (tag, kind, m)]
+        assert_identical(R.import_image_pixels(base, 5, 3, m, data), vectors["%s_import|%s|%s" % (tag, kind, m)],
+                         "import %s %s" % (kind, m))
+    data = vectors["%s_import|%s|IA|data" % (tag, kind)]
+    assert_identical(R.import_image_pixels(gray, 5, 3, "IA", data), vectors["%s_import|%s|IA" % (tag, kind)],
+                     "import %s IA" % kind)
+    for m in ("RGBA", "BGRA", "RGB", "ARGB", "BGRP", "RGBP", "I", "IA", "RPPA"):
+        want = vectors["%s_export|%s|%s" % (tag, kind, m)]
+        got = R.export_image_pixels(base, 4, 2, 11, 8, m, want.dtype)
+        assert got.dtype == want.dtype and np.array_equal(got, want), "export %s %s" % (kind, m)
+    want = vectors["%s_export_gray|%s|IA" % (tag, kind)]
+    got = R.export_image_pixels(gray, 4, 2, 11, 8, "IA", want.dtype, colorspace="gray")
+    assert np.array_equal(got, want), "export gray %s IA" % kind
+
+
 @pytest.mark.parametrize("tag,ch", CASES)
 def test_resize_matches_reference(vectors, tag, ch):
     px = vectors["%s_c%d_in" % (tag, ch)]
