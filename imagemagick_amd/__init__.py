@@ -20,7 +20,7 @@ from ._lib import (MagickHipError, MhImage, COLORSPACES, MORPHOLOGY, FILTERS,  #
 
 __all__ = ["Image", "blur_image", "convolve_image", "morphology_image", "morphology_primitive",
            "unsharp_mask_image", "resize_image", "contrast_stretch_image", "equalize_image",
-           "transform_image_colorspace", "gaussian_blur_image", "sharpen_image", "edge_image",
+           "transform_image_colorspace", "motion_blur_image", "gaussian_blur_image", "sharpen_image", "edge_image",
            "emboss_image", "import_image_pixels", "export_image_pixels", "contrast_image", "modulate_image", "grayscale_image", "function_image", "histogram", "apply_lut", "contrast_stretch_lut",
            "equalize_lut", "is_image_gray", "set_precision", "get_precision", "device_count",
            "build", "load", "MagickHipError"]
@@ -141,6 +141,11 @@ class _Kernel:
         return False
 
 
+def optimal_kernel_width_1d(radius, sigma):
+    """GetOptimalKernelWidth1D — MagickCore/gem.c:262 (the tap count BlurImage uses)."""
+    return int(_lib.load().MhGetOptimalKernelWidth1D(radius, sigma))
+
+
 def kernel_to_numpy(kernel_string, index=0):
     """Build a kernel list with the product's host builder and return kernel
     `index` as (values[h,w], x, y, count)."""
@@ -228,6 +233,11 @@ def _pair_operator(name, image, *args):
     out = image.like()
     _lib.check(getattr(lib, name)(ctypes.byref(image.descriptor()), ctypes.byref(out.descriptor()), *args))
     return out
+
+
+def motion_blur_image(image, radius, sigma, angle):
+    """MotionBlurImage(image, radius, sigma, angle) — MagickCore/effect.c:2347."""
+    return _pair_operator("MagickHipMotionBlurImage", image, radius, sigma, angle)
 
 
 def gaussian_blur_image(image, radius, sigma):

@@ -145,6 +145,10 @@ PROTOTYPES = [
     ("MagickHipMorphologyPrimitive", ctypes.c_int, [_P(MhImage), _P(MhImage), ctypes.c_int,
                                                     _P(MhKernelInfo), ctypes.c_double,
                                                     _P(ctypes.c_ssize_t)]),
+    ("MagickHipMotionBlurImage", ctypes.c_int, [_P(MhImage), _P(MhImage), ctypes.c_double, ctypes.c_double,
+                                                ctypes.c_double]),
+    ("MagickHipMotionBlurImageWithKernel", ctypes.c_int, [_P(MhImage), _P(MhImage), ctypes.POINTER(ctypes.c_double),
+                                                          ctypes.c_size_t, ctypes.POINTER(ctypes.c_ssize_t)]),
     ("MagickHipGaussianBlurImage", ctypes.c_int, [_P(MhImage), _P(MhImage), ctypes.c_double, ctypes.c_double]),
     ("MagickHipSharpenImage", ctypes.c_int, [_P(MhImage), _P(MhImage), ctypes.c_double, ctypes.c_double]),
     ("MagickHipEdgeImage", ctypes.c_int, [_P(MhImage), _P(MhImage), ctypes.c_double]),

@@ -190,6 +190,9 @@ MhStatus launch_modulate(const View &img,bool hsb,double hue_shift,double satura
 size_t storage_size(MhStorageType type,MhQuantumKind quantum);
 MhStatus launch_pixel_io(bool import,const View &img,const MhImage *desc,int x,int y,int width,
   int height,const char *map,MhStorageType type,void *buffer_device);
+// MotionBlurImage's pixel loop: `width` taps at integer (x,y) offsets
+MhStatus launch_motion_blur(const View &src,const View &dst,const double *kernel,size_t width,
+  const ptrdiff_t *offsets_xy,const Roles &roles);
 void release_color_tables();          // frees the per-device transfer-function tables
 MhStatus launch_gray_check(const View &img,const MhImage *desc,unsigned int *flag_device);
 MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,const MhImage *desc);

@@ -452,6 +452,47 @@ MH_API MhStatus MagickHipBlurImage(const MhImage *image,MhImage *blur_image,
   return status;
 }
 
+MH_API MhStatus MagickHipMotionBlurImageWithKernel(const MhImage *image,MhImage *blur_image,
+  const double *kernel,size_t width,const ptrdiff_t *offsets_xy)
+{
+  MH_TRY(gate_pair(image,blur_image,"MotionBlurImage",true));
+  if ((kernel == nullptr) || (offsets_xy == nullptr) || (width == 0))
+    return fail(MH_BAD_ARGUMENT,"MotionBlurImage: null kernel or offsets");
+  Pair pair;
+  MH_TRY(pair.open(image,blur_image));
+  Roles roles=channel_roles(image,blur_image);
+  MH_TRY(launch_motion_blur(pair.src.view,pair.dst.view,kernel,width,offsets_xy,roles));
+  return pair.commit();
+}
+
+MH_API MhStatus MagickHipMotionBlurImage(const MhImage *image,MhImage *blur_image,double radius,
+  double sigma,double angle)
+{
+  // effect.c:2378-2393: width, kernel and the offsets along the motion direction
+  const size_t width=MhGetOptimalKernelWidth1D(radius,sigma);
+  const double s=fabs(sigma) < 1.0e-12 ? 1.0e-12 : sigma;          // MagickSigma
+  const double sq2pi=2.50662827463100024161235523934010416269302368164062;
+  std::vector<double> kernel(width);
+  double normalize=0.0;
+  for (size_t i=0; i < width; i++)
+    {
+      kernel[i]=(double) (exp((-((double) i*i)/(double) (2.0*s*s)))/(sq2pi*s));
+      normalize+=kernel[i];
+    }
+  for (size_t i=0; i < width; i++)
+    kernel[i]/=normalize;
+  const double pi=3.1415926535897932384626433832795028841971693993751058209749445923078164062;
+  const double radians=(double) (pi*angle/180.0);                   // DegreesToRadians
+  const double px=(double) width*sin(radians),py=(double) width*cos(radians);
+  std::vector<ptrdiff_t> offsets(2*width);
+  for (size_t w=0; w < width; w++)
+    {
+      offsets[2*w]=(ptrdiff_t) ceil((double) ((double) w*py)/hypot(px,py)-0.5);
+      offsets[2*w+1]=(ptrdiff_t) ceil((double) ((double) w*px)/hypot(px,py)-0.5);
+    }
+  return MagickHipMotionBlurImageWithKernel(image,blur_image,kernel.data(),width,offsets.data());
+}
+
 // One square kernel through ConvolveImage; `equalize` adds EmbossImage's EqualizeImage of
 // the result (effect.c:1675-1676), on the device before the result is handed back.
 static MhStatus convolve_with(const MhImage *image,MhImage *out,MhKernelInfo *kernel,

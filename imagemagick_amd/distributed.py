@@ -36,6 +36,50 @@ def band_with_halo(rows, rank, world, reach_above, reach_below):
     return (begin, end), (max(0, begin - reach_above), min(rows, end + reach_below))
 
 
+def stencil_reach(operator, **kw):
+    """Rows a stencil operator reads above / below an output row: (reach_above, reach_below).
+    blur / unsharp: both separable passes reach (K-1)/2 rows (only the column pass crosses
+    bands, but it consumes row-pass output, which is computed band-locally from the same
+    rows — so a band needs exactly the column reach); morphology: the kernel's extent around
+    its origin, times the number of primitive applications."""
+    import imagemagick_amd as im
+    if operator in ("blur", "unsharp"):
+        width = im.optimal_kernel_width_1d(kw.get("radius", 0.0), kw["sigma"])
+        return (width - 1) // 2, (width - 1) // 2
+    if operator == "morphology":
+        values, kx, ky, count = im.kernel_to_numpy(kw["kernel"])
+        if count != 1:
+            raise ValueError("row-sharded morphology takes a single kernel")
+        height = values.shape[0]
+        stages = {"erode": 1, "dilate": 1, "convolve": 1, "open": 2, "close": 2, "smooth": 4, "edgein": 1,
+                  "edgeout": 1, "edge": 1, "tophat": 2, "bottomhat": 2}[kw["method"].lower()]
+        n = stages * max(1, int(kw.get("iterations", 1)))
+        # the reflected kernel of Dilate / Convolve swaps the two reaches: take the larger for both
+        reach = max(ky, height - 1 - ky)
+        return n * reach, n * reach
+    raise ValueError(operator)
+
+
+def run_on_band(pixels, rank, world, reach, operator):
+    """One rank's share of a row-sharded stencil operator (BASELINE config C5 on 8 GPUs): take
+    the rows this rank owns plus its halo out of the host image `pixels` ([rows, cols, ch] NumPy),
+    upload, run `operator(image) -> image` on the GPU, and return (own_begin, own_end, rows) —
+    the owned output rows as a NumPy array.  Bands at the image border rely on the kernels' own
+    edge clamp; interior bands never see a clamped row inside their owned range because the halo
+    covers the operator's full reach."""
+    import torch
+    import imagemagick_amd as im
+    rows = pixels.shape[0]
+    (begin, end), (lo, hi) = band_with_halo(rows, rank, world, reach[0], reach[1])
+    band = np.ascontiguousarray(pixels[lo:hi])
+    if band.dtype == np.uint16:
+        dev = torch.from_numpy(band.view(np.int16)).cuda().view(torch.uint16)
+    else:
+        dev = torch.from_numpy(band).cuda()
+    out = operator(im.Image(dev)).numpy()
+    return begin, end, out[begin - lo:end - lo]
+
+
 def all_reduce_histogram(histogram, group=None):
     """Sum a [65536, channels] count table over the process group, in place.
     Accepts a CUDA int64 tensor (RCCL) or a NumPy uint64 array (gloo, CPU tests)."""

@@ -306,6 +306,15 @@ MH_API MhStatus MagickHipEdgeImage(const MhImage *image,MhImage *edge_image,doub
 MH_API MhStatus MagickHipEmbossImage(const MhImage *image,MhImage *emboss_image,
   double radius,double sigma);
 
+/* AccelerateMotionBlurImage: MotionBlurImage, effect.c:2347-2560.  The first form builds the
+   kernel (GetMotionBlurKernel, :2316-2345) and the offsets along `angle` (:2385-2393) itself;
+   the second takes them from the caller, as the reference's accelerate hook does
+   (`offsets_xy` = width pairs x,y). */
+MH_API MhStatus MagickHipMotionBlurImage(const MhImage *image,MhImage *blur_image,double radius,
+  double sigma,double angle);
+MH_API MhStatus MagickHipMotionBlurImageWithKernel(const MhImage *image,MhImage *blur_image,
+  const double *kernel,size_t width,const ptrdiff_t *offsets_xy);
+
 /* MorphologyImage / MorphologyApply, morphology.c:4129 / :3634.  `compose`
    is unused (Undefined => per-method default) in this version; `bias` is the
    convolve:bias artifact (0 by default). */

@@ -638,11 +638,64 @@ MagickPrivate Image *AccelerateLocalContrastImage(const Image *magick_unused(ima
   return((Image *) NULL);
 }
 
-MagickPrivate Image *AccelerateMotionBlurImage(const Image *magick_unused(image),
-  const double *magick_unused(kernel),const size_t magick_unused(width),
-  const OffsetInfo *magick_unused(offset),ExceptionInfo *magick_unused(exception))
+/* MotionBlurImage hands its kernel and offsets to the hook (effect.c:2397-2404) */
+MagickPrivate Image *AccelerateMotionBlurImage(const Image *image,const double *kernel,
+  const size_t width,const OffsetInfo *offset,ExceptionInfo *exception)
 {
-  return((Image *) NULL);
+  HipLibrary
+    *library;
+
+  Image
+    *blur_image;
+
+  MhImage
+    source,
+    destination;
+
+  MhStatus
+    status;
+
+  ptrdiff_t
+    *offsets;
+
+  size_t
+    i;
+
+  void
+    *p,
+    *q;
+
+  if ((IsImageAcceleratable(image) == MagickFalse) || (width == 0))
+    return((Image *) NULL);
+  library=AcquireHipLibrary();
+  if (library == (HipLibrary *) NULL)
+    return((Image *) NULL);
+  offsets=(ptrdiff_t *) AcquireQuantumMemory(width,2*sizeof(*offsets));
+  if (offsets == (ptrdiff_t *) NULL)
+    return((Image *) NULL);
+  for (i=0; i < width; i++)
+  {
+    offsets[2*i]=(ptrdiff_t) offset[i].x;
+    offsets[2*i+1]=(ptrdiff_t) offset[i].y;
+  }
+  blur_image=(Image *) NULL;
+  status=MH_BAD_ARGUMENT;
+  p=AcquireDevicePixels(library,image,1,exception);
+  if (p != NULL)
+    blur_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
+  if ((blur_image != (Image *) NULL) &&
+      (DescribeImage(library,image,p,&source) != MagickFalse) &&
+      (DescribeImage(library,blur_image,q,&destination) != MagickFalse))
+    status=library->MotionBlurImageWithKernel(&source,&destination,kernel,width,offsets);
+  offsets=(ptrdiff_t *) RelinquishMagickMemory(offsets);
+  if (status != MH_OK)
+    {
+      if (blur_image != (Image *) NULL)
+        blur_image=DestroyImage(blur_image);
+      return((Image *) NULL);
+    }
+  hip_accelerated_calls++;
+  return(blur_image);
 }
 
 MagickPrivate Image *AccelerateRotationalBlurImage(const Image *magick_unused(image),

@@ -30,6 +30,8 @@ typedef struct _HipLibrary
   MhStatus (*EqualizeImage)(MhImage *);
   MhStatus (*GrayscaleImage)(MhImage *,MhIntensityMethod);
   MhStatus (*FunctionImage)(MhImage *,MhFunction,size_t,const double *);
+  MhStatus (*MotionBlurImageWithKernel)(const MhImage *,MhImage *,const double *,size_t,
+    const ptrdiff_t *);
   MhStatus (*ContrastImage)(MhImage *,int);
   MhStatus (*ModulateImage)(MhImage *,double,double,double,int);
   MhStatus (*MorphologyImage)(const MhImage *,MhImage *,MhMorphologyMethod,ptrdiff_t,

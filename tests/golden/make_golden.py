@@ -104,6 +104,9 @@ def reference_vectors():
             out[key + "_resize_mitchell"] = ref.RefImage(px).resize(60, 20, "Mitchell").numpy()
             out[key + "_resize_catrom"] = ref.RefImage(px).resize(20, 50, "Catrom").numpy()
             out[key + "_resize_triangle"] = ref.RefImage(px).resize(64, 64, "Triangle").numpy()
+            out[key + "_motion_0x3+30"] = ref.RefImage(px).motion_blur(0.0, 3.0, 30.0).numpy()
+            out[key + "_motion_0x1.5-110"] = ref.RefImage(px).motion_blur(0.0, 1.5, -110.0).numpy()
+            out[key + "_motion_4x2+90"] = ref.RefImage(px).motion_blur(4.0, 2.0, 90.0).numpy()
             out[key + "_unsharp"] = ref.RefImage(px).unsharp(0.0, 2.0, 1.0, 0.02).numpy()
             n = px.shape[0] * px.shape[1]
             out[key + "_cstretch"] = ref.RefImage(px).contrast_stretch(0.02 * n, n - 0.01 * n).numpy()

@@ -114,3 +114,31 @@ def test_equalize_band_single_rank_on_gpu(im, refmod):
         assert np.array_equal(dev.numpy(), refmod.RefImage(px).contrast_stretch(0.02 * n, n - 0.01 * n).numpy())
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_row_sharded_stencils_match_whole_image(im, refmod, world):
+    """BASELINE config C5 on N GPUs, rehearsed on one: every rank's band (owned rows + halo,
+    `distributed.run_on_band`) goes through the GPU separately and the stitched result must be
+    the whole-image result bit for bit — blur (EXACT), Dilate with a disk, a compound method and
+    UnsharpMask; odd row counts so that bands are uneven."""
+    from conftest import make_pixels
+    from imagemagick_amd import distributed as D
+    px = make_pixels(173, 96, 4, np.uint16)
+    cases = [
+        ("blur 0x3", D.stencil_reach("blur", sigma=3.0), lambda i: im.blur_image(i, 0.0, 3.0),
+         lambda r: r.blur(0.0, 3.0)),
+        ("dilate disk:5", D.stencil_reach("morphology", method="Dilate", kernel="Disk:5"),
+         lambda i: im.morphology_image(i, "Dilate", 1, "Disk:5"), lambda r: r.morphology("Dilate", 1, "Disk:5")),
+        ("smooth octagon:2", D.stencil_reach("morphology", method="Smooth", kernel="Octagon:2"),
+         lambda i: im.morphology_image(i, "Smooth", 1, "Octagon:2"), lambda r: r.morphology("Smooth", 1, "Octagon:2")),
+        ("unsharp 0x2", D.stencil_reach("unsharp", sigma=2.0), lambda i: im.unsharp_mask_image(i, 0.0, 2.0, 1.0, 0.02),
+         lambda r: r.unsharp(0.0, 2.0, 1.0, 0.02)),
+    ]
+    for name, reach, gpu_op, ref_op in cases:
+        merged = np.empty_like(px)
+        for rank in range(world):
+            begin, end, rows = D.run_on_band(px, rank, world, reach, gpu_op)
+            merged[begin:end] = rows
+        assert np.array_equal(merged, ref_op(refmod.RefImage(px)).numpy()), "%s over %d bands" % (name, world)

@@ -207,6 +207,17 @@ def test_morphology_until_convergence(im, refmod):
     assert_parity(got, want, True, "dilate until no change")
 
 
+# ----------------------------------------------------------- MotionBlurImage
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("channels", [1, 3, 4])
+@pytest.mark.parametrize("args", [(0.0, 3.0, 30.0), (0.0, 1.5, -110.0), (4.0, 2.0, 90.0), (0.0, 6.0, 200.0)])
+def test_motion_blur(im, refmod, dtype, channels, args):
+    px = make_pixels(47, 61, channels, dtype)
+    dev, ref = run_pair(im, refmod, px)
+    got = im.motion_blur_image(dev, *args).numpy()
+    assert_parity(got, ref.motion_blur(*args).numpy(), True, "motion blur %s c%d" % (args, channels))
+
+
 # ----------------------------------------------------------- the other ConvolveImage callers
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
 @pytest.mark.parametrize("channels", [3, 4])

@@ -175,6 +175,14 @@ def test_contrast_and_modulate_match_reference(vectors, tag, ch):
             assert_identical(got, want, name)
 
 
+@pytest.mark.parametrize("tag,ch", CASES)
+def test_motion_blur_matches_reference(vectors, tag, ch):
+    px = vectors["%s_c%d_in" % (tag, ch)]
+    for name, args in (("motion_0x3+30", (0.0, 3.0, 30.0)), ("motion_0x1.5-110", (0.0, 1.5, -110.0)),
+                       ("motion_4x2+90", (4.0, 2.0, 90.0))):
+        assert_identical(R.motion_blur_image(px, *args), vectors["%s_c%d_%s" % (tag, ch, name)], name)
+
+
 IO_TYPES = ["uint8", "uint16", "uint32", "uint64", "float32", "float64"]
 
 
