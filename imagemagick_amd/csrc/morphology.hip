@@ -973,4 +973,120 @@ MhStatus launch_motion_blur(const View &src,const View &dst,const double *kernel
   return motion_typed<float>(src,roles.blend,a);
 }
 
+// ---------------------------------------------------------------- RotationalBlurImage
+// effect.c:3209-3430: every pixel is the (alpha-weighted) mean of samples on the arc through it
+// around the image centre; the sample stride grows towards the centre.  cos/sin tables come
+// from the host (libm, as the reference); the coordinate expressions, the (ssize_t) casts and
+// the accumulation order are the reference's.
+struct RotationalArgs
+{
+  const void *src;
+  void *dst;
+  int columns,rows;
+  int n;
+  const double *cos_theta,*sin_theta;
+  double center_x,center_y,blur_radius;
+  uint32_t copy_mask;
+  int has_alpha;               // the image has an alpha channel (last channel)
+};
+
+template<typename Q,int C>
+__global__ __launch_bounds__(256)
+void rotational_blur_kernel(RotationalArgs a)
+{
+  const int x=(int) (blockIdx.x*blockDim.x+threadIdx.x),y=(int) blockIdx.y;
+  if (x >= a.columns)
+    return;
+  const Q *src=static_cast<const Q *>(a.src);
+  const double cx=(double) x-a.center_x,cy=(double) y-a.center_y;
+  // hypot of two half-integers: x*x+y*y is exact in fp64, so sqrt is the correctly rounded hypot
+  const double radius=sqrt(cx*cx+cy*cy);
+  size_t step=1;
+  if (radius != 0)
+    {
+      step=(size_t) (a.blur_radius/radius);
+      if (step == 0)
+        step=1;
+      else if (step >= (size_t) a.n)
+        step=(size_t) a.n-1;
+    }
+  double plain[C],weighted[C],gamma_plain=0.0,gamma_alpha=0.0;
+#pragma unroll
+  for (int c=0; c < C; c++)
+    {
+      plain[c]=0.0;
+      weighted[c]=0.0;
+    }
+  for (size_t j=0; j < (size_t) a.n; j+=step)
+    {
+      long sx=(long) (a.center_x+cx*a.cos_theta[j]-cy*a.sin_theta[j]+0.5);
+      long sy=(long) (a.center_y+cx*a.sin_theta[j]+cy*a.cos_theta[j]+0.5);
+      sx=sx < 0 ? 0 : (sx > a.columns-1 ? a.columns-1 : sx);      // cache.c:2663-2679
+      sy=sy < 0 ? 0 : (sy > a.rows-1 ? a.rows-1 : sy);
+      Q r[C];
+      load_pixel<Q,C>(src+((size_t) sy*a.columns+(size_t) sx)*C,r);
+      const double alpha=a.has_alpha ? kQS*(double) r[C-1] : 1.0;
+#pragma unroll
+      for (int c=0; c < C; c++)
+        {
+          plain[c]+=(double) r[c];
+          weighted[c]+=alpha*(double) r[c];
+        }
+      gamma_plain+=1.0;
+      gamma_alpha+=alpha;
+    }
+  Q centre[C],out[C];
+  load_pixel<Q,C>(src+((size_t) y*a.columns+x)*C,centre);
+  const double gp=perceptible_reciprocal(gamma_plain),ga=perceptible_reciprocal(gamma_alpha);
+#pragma unroll
+  for (int c=0; c < C; c++)
+    {
+      if ((a.copy_mask >> c) & 1u)
+        out[c]=centre[c];
+      else if (!a.has_alpha || (c == C-1))
+        out[c]=QuantumOps<Q>::clamp(gp*plain[c]);
+      else
+        out[c]=QuantumOps<Q>::clamp(ga*weighted[c]);
+    }
+  store_pixel<Q,C>(static_cast<Q *>(a.dst)+((size_t) y*a.columns+x)*C,out);
+}
+
+MhStatus launch_rotational_blur(const View &src,const View &dst,const double *cos_theta,
+  const double *sin_theta,size_t n,double blur_radius,const Roles &roles)
+{
+  Temp d_cos,d_sin;
+  MH_TRY(upload_table(d_cos,src.device,src.stream,cos_theta,n*sizeof(double)));
+  MH_TRY(upload_table(d_sin,src.device,src.stream,sin_theta,n*sizeof(double)));
+  RotationalArgs a;
+  a.src=src.pixels;
+  a.dst=dst.pixels;
+  a.columns=(int) src.columns;
+  a.rows=(int) src.rows;
+  a.n=(int) n;
+  a.cos_theta=d_cos.as<double>();
+  a.sin_theta=d_sin.as<double>();
+  a.center_x=(double) (src.columns-1)/2.0;
+  a.center_y=(double) (src.rows-1)/2.0;
+  a.blur_radius=blur_radius;
+  a.copy_mask=roles.copy_mask;
+  a.has_alpha=roles.alpha >= 0 ? 1 : 0;
+  if ((roles.alpha >= 0) && (roles.alpha != src.channels-1))
+    return fail(MH_UNSUPPORTED,"alpha channel must be the last channel");
+  dim3 grid((unsigned) ((a.columns+255)/256),(unsigned) a.rows),block(256);
+  ProfileScope prof("rotational_blur",src.stream);
+#define MH_CASE(QT) \
+  switch (src.channels) { \
+    case 1: hipLaunchKernelGGL((rotational_blur_kernel<QT,1>),grid,block,0,src.stream,a); break; \
+    case 2: hipLaunchKernelGGL((rotational_blur_kernel<QT,2>),grid,block,0,src.stream,a); break; \
+    case 3: hipLaunchKernelGGL((rotational_blur_kernel<QT,3>),grid,block,0,src.stream,a); break; \
+    default: hipLaunchKernelGGL((rotational_blur_kernel<QT,4>),grid,block,0,src.stream,a); break; }
+  if (src.quantum == MH_QUANTUM_U16)
+    { MH_CASE(uint16_t) }
+  else
+    { MH_CASE(float) }
+#undef MH_CASE
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 } // namespace mh

@@ -452,6 +452,33 @@ MH_API MhStatus MagickHipBlurImage(const MhImage *image,MhImage *blur_image,
   return status;
 }
 
+MH_API MhStatus MagickHipRotationalBlurImage(const MhImage *image,MhImage *blur_image,double angle)
+{
+  MH_TRY(gate_pair(image,blur_image,"RotationalBlurImage",true));
+  // effect.c:3256-3276: sample count and the rotation tables (host libm, as the reference)
+  const double pi=3.1415926535897932384626433832795028841971693993751058209749445923078164062;
+  const double radians=(double) (pi*angle/180.0);
+  const double center_x=(double) (image->columns-1)/2.0,center_y=(double) (image->rows-1)/2.0;
+  const double blur_radius=hypot(center_x,center_y);
+  const size_t n=(size_t) fabs(4.0*radians*sqrt((double) blur_radius)+2UL);
+  if ((n < 2) || (n > (1u << 24)))
+    return fail(MH_UNSUPPORTED,"RotationalBlurImage: %zu samples per pixel",n);
+  const double theta=radians/(double) (n-1);
+  const double offset=theta*(double) (n-1)/2.0;
+  std::vector<double> cos_theta(n),sin_theta(n);
+  for (size_t w=0; w < n; w++)
+    {
+      cos_theta[w]=cos((double) (theta*(double) w-offset));
+      sin_theta[w]=sin((double) (theta*(double) w-offset));
+    }
+  Pair pair;
+  MH_TRY(pair.open(image,blur_image));
+  Roles roles=channel_roles(image,blur_image);
+  MH_TRY(launch_rotational_blur(pair.src.view,pair.dst.view,cos_theta.data(),sin_theta.data(),n,
+    blur_radius,roles));
+  return pair.commit();
+}
+
 MH_API MhStatus MagickHipMotionBlurImageWithKernel(const MhImage *image,MhImage *blur_image,
   const double *kernel,size_t width,const ptrdiff_t *offsets_xy)
 {

@@ -306,6 +306,9 @@ MH_API MhStatus MagickHipEdgeImage(const MhImage *image,MhImage *edge_image,doub
 MH_API MhStatus MagickHipEmbossImage(const MhImage *image,MhImage *emboss_image,
   double radius,double sigma);
 
+/* AccelerateRotationalBlurImage: RotationalBlurImage(image,angle), effect.c:3209-3430. */
+MH_API MhStatus MagickHipRotationalBlurImage(const MhImage *image,MhImage *blur_image,double angle);
+
 /* AccelerateMotionBlurImage: MotionBlurImage, effect.c:2347-2560.  The first form builds the
    kernel (GetMotionBlurKernel, :2316-2345) and the offsets along `angle` (:2385-2393) itself;
    the second takes them from the caller, as the reference's accelerate hook does

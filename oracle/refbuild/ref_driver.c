@@ -252,6 +252,15 @@ REF_API void *ref_edge(const void *handle,double radius,double *seconds)
   return((void *) out);
 }
 
+REF_API void *ref_rotational_blur(const void *handle,double angle,double *seconds)
+{
+  Image *out;
+  TIMED_BEGIN;
+  out=RotationalBlurImage((const Image *) handle,angle,ref_exception);
+  TIMED_END;
+  return((void *) out);
+}
+
 REF_API void *ref_motion_blur(const void *handle,double radius,double sigma,double angle,
   double *seconds)
 {

@@ -698,10 +698,41 @@ MagickPrivate Image *AccelerateMotionBlurImage(const Image *image,const double *
   return(blur_image);
 }
 
-MagickPrivate Image *AccelerateRotationalBlurImage(const Image *magick_unused(image),
-  const double magick_unused(angle),ExceptionInfo *magick_unused(exception))
+/* RotationalBlurImage's call site: effect.c:3241-3245 */
+MagickPrivate Image *AccelerateRotationalBlurImage(const Image *image,const double angle,
+  ExceptionInfo *exception)
 {
-  return((Image *) NULL);
+  HipLibrary
+    *library;
+
+  Image
+    *blur_image;
+
+  MhImage
+    source,
+    destination;
+
+  void
+    *p,
+    *q;
+
+  if (IsImageAcceleratable(image) == MagickFalse)
+    return((Image *) NULL);
+  library=AcquireHipLibrary();
+  if (library == (HipLibrary *) NULL)
+    return((Image *) NULL);
+  p=AcquireDevicePixels(library,image,1,exception);
+  if (p == NULL)
+    return((Image *) NULL);
+  blur_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
+  if (blur_image == (Image *) NULL)
+    return((Image *) NULL);
+  if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
+      (DescribeImage(library,blur_image,q,&destination) == MagickFalse) ||
+      (library->RotationalBlurImage(&source,&destination,angle) != MH_OK))
+    return(DestroyImage(blur_image));
+  hip_accelerated_calls++;
+  return(blur_image);
 }
 
 MagickPrivate Image *AccelerateWaveletDenoiseImage(const Image *magick_unused(image),

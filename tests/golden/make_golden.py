@@ -104,6 +104,8 @@ def reference_vectors():
             out[key + "_resize_mitchell"] = ref.RefImage(px).resize(60, 20, "Mitchell").numpy()
             out[key + "_resize_catrom"] = ref.RefImage(px).resize(20, 50, "Catrom").numpy()
             out[key + "_resize_triangle"] = ref.RefImage(px).resize(64, 64, "Triangle").numpy()
+            out[key + "_rotational_12"] = ref.RefImage(px).rotational_blur(12.0).numpy()
+            out[key + "_rotational_-40"] = ref.RefImage(px).rotational_blur(-40.0).numpy()
             out[key + "_motion_0x3+30"] = ref.RefImage(px).motion_blur(0.0, 3.0, 30.0).numpy()
             out[key + "_motion_0x1.5-110"] = ref.RefImage(px).motion_blur(0.0, 1.5, -110.0).numpy()
             out[key + "_motion_4x2+90"] = ref.RefImage(px).motion_blur(4.0, 2.0, 90.0).numpy()

@@ -207,6 +207,17 @@ def test_morphology_until_convergence(im, refmod):
     assert_parity(got, want, True, "dilate until no change")
 
 
+# ----------------------------------------------------------- RotationalBlurImage
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("channels", [1, 2, 3, 4])
+@pytest.mark.parametrize("angle", [12.0, -40.0, 3.0, 200.0])
+def test_rotational_blur(im, refmod, dtype, channels, angle):
+    px = make_pixels(53, 71, channels, dtype)
+    dev, ref = run_pair(im, refmod, px)
+    got = im.rotational_blur_image(dev, angle).numpy()
+    assert_parity(got, ref.rotational_blur(angle).numpy(), True, "rotational blur %g c%d" % (angle, channels))
+
+
 # ----------------------------------------------------------- MotionBlurImage
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
 @pytest.mark.parametrize("channels", [1, 3, 4])

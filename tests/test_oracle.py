@@ -176,6 +176,13 @@ def test_contrast_and_modulate_match_reference(vectors, tag, ch):
 
 
 @pytest.mark.parametrize("tag,ch", CASES)
+def test_rotational_blur_matches_reference(vectors, tag, ch):
+    px = vectors["%s_c%d_in" % (tag, ch)]
+    for name, angle in (("rotational_12", 12.0), ("rotational_-40", -40.0)):
+        assert_identical(R.rotational_blur_image(px, angle), vectors["%s_c%d_%s" % (tag, ch, name)], name)
+
+
+@pytest.mark.parametrize("tag,ch", CASES)
 def test_motion_blur_matches_reference(vectors, tag, ch):
     px = vectors["%s_c%d_in" % (tag, ch)]
     for name, args in (("motion_0x3+30", (0.0, 3.0, 30.0)), ("motion_0x1.5-110", (0.0, 1.5, -110.0)),
