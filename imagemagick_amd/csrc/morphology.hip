@@ -419,7 +419,8 @@ struct ConvexArgs
 };
 
 constexpr int kCTW=64;        // tile columns (= lanes)
-constexpr int kCTR=32;        // tile rows; each of the 4 waves owns 8 output rows
+constexpr int kCTR=32;        // tile rows; each of the kCWaves waves owns kCTR/kCWaves output rows
+constexpr int kCWaves=8;      // 512 threads on the same LDS tile: 4 waves per SIMD with two tiles per CU
 
 template<typename Q,int C> struct PixelMinMax
 {
@@ -453,7 +454,7 @@ template<typename Q,int C> struct PixelMinMax
 };
 
 template<typename Q,int C,bool DILATE>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(64*kCWaves)
 void morph_convex_kernel(ConvexArgs args)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -474,13 +475,13 @@ void morph_convex_kernel(ConvexArgs args)
   {
     constexpr int BATCH=6;
     const int items=tile_rows*raw_w;
-    for (int i0=(int) threadIdx.x; i0 < items; i0+=256*BATCH)
+    for (int i0=(int) threadIdx.x; i0 < items; i0+=64*kCWaves*BATCH)
       {
         Q v[BATCH][C];
 #pragma unroll
         for (int k=0; k < BATCH; k++)
           {
-            int idx=i0+256*k;
+            int idx=i0+64*kCWaves*k;
             idx=idx < items ? idx : items-1;
             const int ty=idx/raw_w,tx=idx-ty*raw_w;
             int sx=bx+args.cx-hmax+tx,sy=by-top+ty;
@@ -490,12 +491,12 @@ void morph_convex_kernel(ConvexArgs args)
           }
 #pragma unroll
         for (int k=0; k < BATCH; k++)
-          if (i0+256*k < items)
-            store_pixel<Q,C>(raw+(size_t) (i0+256*k)*C,v[k]);
+          if (i0+64*kCWaves*k < items)
+            store_pixel<Q,C>(raw+(size_t) (i0+64*kCWaves*k)*C,v[k]);
       }
   }
   // accumulators: Erode starts from the output pixel itself, Dilate from 0 (morphology.c:2905-2912)
-  constexpr int R=kCTR/4;
+  constexpr int R=kCTR/kCWaves;
   const int x=bx+lane;
   const int xc=x < W ? x : W-1;
   Q out[R][C],center[R][C];
@@ -518,14 +519,14 @@ void morph_convex_kernel(ConvexArgs args)
       // phase 1: widen the row-window maxima of every tile row to half-width h.  Four
       // rows per step: their LDS reads are independent, so one latency covers all four.
       constexpr int RB=4;
-      for (int t0=wave; t0 < tile_rows; t0+=4*RB)
+      for (int t0=wave; t0 < tile_rows; t0+=kCWaves*RB)
         {
           Q m[RB][C];
           const Q *line[RB];
 #pragma unroll
           for (int k=0; k < RB; k++)
             {
-              int ty=t0+4*k;
+              int ty=t0+kCWaves*k;
               ty=ty < tile_rows ? ty : tile_rows-1;
               line[k]=raw+((size_t) ty*raw_w+(size_t) (lane+hmax))*C;
               if (h_prev < 0)
@@ -552,7 +553,7 @@ void morph_convex_kernel(ConvexArgs args)
 #pragma unroll
           for (int k=0; k < RB; k++)
             {
-              int ty=t0+4*k;
+              int ty=t0+kCWaves*k;
               if (ty < tile_rows)
                 store_pixel<Q,C>(plane+((size_t) ty*kCTW+lane)*C,m[k]);
             }
@@ -614,14 +615,14 @@ static MhStatus launch_convex(bool dilate,const ConvexArgs &args,dim3 grid,size_
       if (lds > 64u*1024u)
         MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&morph_convex_kernel<Q,C,true>),
           hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
-      hipLaunchKernelGGL((morph_convex_kernel<Q,C,true>),grid,dim3(256),lds,stream,args);
+      hipLaunchKernelGGL((morph_convex_kernel<Q,C,true>),grid,dim3(64*kCWaves),lds,stream,args);
     }
   else
     {
       if (lds > 64u*1024u)
         MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&morph_convex_kernel<Q,C,false>),
           hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
-      hipLaunchKernelGGL((morph_convex_kernel<Q,C,false>),grid,dim3(256),lds,stream,args);
+      hipLaunchKernelGGL((morph_convex_kernel<Q,C,false>),grid,dim3(64*kCWaves),lds,stream,args);
     }
   MH_HIP(hipGetLastError());
   return MH_OK;
