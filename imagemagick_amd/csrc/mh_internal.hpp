@@ -195,6 +195,8 @@ MhStatus launch_motion_blur(const View &src,const View &dst,const double *kernel
   const ptrdiff_t *offsets_xy,const Roles &roles);
 MhStatus launch_rotational_blur(const View &src,const View &dst,const double *cos_theta,
   const double *sin_theta,size_t n,double blur_radius,const Roles &roles);
+MhStatus launch_local_contrast(const View &src,const View &dst,double radius,double strength,
+  const Roles &roles);
 void release_color_tables();          // frees the per-device transfer-function tables
 MhStatus launch_gray_check(const View &img,const MhImage *desc,unsigned int *flag_device);
 MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,const MhImage *desc);

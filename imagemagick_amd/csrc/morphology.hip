@@ -1090,4 +1090,138 @@ MhStatus launch_rotational_blur(const View &src,const View &dst,const double *co
   return MH_OK;
 }
 
+// ---------------------------------------------------------------- LocalContrastImage
+// effect.c:1760-2010, literally: a vertical then a horizontal pass of the same (lopsided)
+// triangular weighting — weights 1..w on the first w samples, then w+1, w, ..., 3 on the
+// next w-1 — over the float luma, with a float intermediate image of columns+2w whose
+// padding mirrors the neighbouring columns; then R,G,B are scaled by
+// (luma + (luma-blurred)*strength/100)/luma.
+struct LocalContrastArgs
+{
+  const void *src;
+  void *dst;
+  float *inter;                // rows x (columns+2w)
+  int columns,rows,channels,w;
+  double total_weight,strength_scale;
+  uint32_t copy_mask;
+  int colour;                  // 3 for R,G,B[,A], 1 for gray[,A]
+};
+
+template<typename Q>
+static __device__ __forceinline__ float luma_of(const Q *p,int colour)
+{
+  // GetPixelLuma, pixel-accessor.h:304-315, narrowed to float as the scanline buffer does
+  const double r=(double) p[0],g=(double) p[colour >= 3 ? 1 : 0],b=(double) p[colour >= 3 ? 2 : 0];
+  return (float) (0.212656*r+0.715158*g+0.072186*b);
+}
+
+static __device__ __forceinline__ double lopsided_sum(const float *pix,long stride,int w)
+{
+  double weight=1.0,sum=0;
+  for (int i=0; i < w; i++)
+    {
+      sum+=weight*((double) *pix);
+      pix+=stride;
+      weight+=1.0;
+    }
+  for (int i=w+1; i < (2*w); i++)
+    {
+      sum+=weight*((double) *pix);
+      pix+=stride;
+      weight-=1.0;
+    }
+  return sum;
+}
+
+template<typename Q>
+__global__ __launch_bounds__(256)
+void local_contrast_luma_kernel(LocalContrastArgs a,float *luma)       // luma: (rows+2w) x columns
+{
+  const int x=(int) (blockIdx.x*blockDim.x+threadIdx.x),yy=(int) blockIdx.y;
+  if (x >= a.columns)
+    return;
+  int y=yy-a.w;
+  y=y < 0 ? 0 : (y > a.rows-1 ? a.rows-1 : y);                        // cache.c:2663-2679
+  luma[(size_t) yy*a.columns+x]=luma_of<Q>(static_cast<const Q *>(a.src)+((size_t) y*a.columns+x)*a.channels,a.colour);
+}
+
+__global__ __launch_bounds__(256)
+void local_contrast_vertical_kernel(LocalContrastArgs a,const float *luma)
+{
+  const int x=(int) (blockIdx.x*blockDim.x+threadIdx.x),y=(int) blockIdx.y;
+  if (x >= a.columns)
+    return;
+  const size_t pitch=(size_t) a.columns+2*(size_t) a.w;
+  const double sum=lopsided_sum(luma+(size_t) y*a.columns+x,a.columns,a.w);
+  float *out=a.inter+(size_t) y*pitch+(size_t) x+(size_t) a.w;
+  const float value=(float) (sum/a.total_weight);
+  *out=value;
+  if ((x <= a.w) && (x != 0))                                          // mirror into the padding
+    *(out-(x*2))=value;
+  if ((x > a.columns-a.w-2) && (x != a.columns-1))
+    *(out+((size_t) (a.columns-x-1)*2))=value;
+}
+
+template<typename Q>
+__global__ __launch_bounds__(256)
+void local_contrast_horizontal_kernel(LocalContrastArgs a)
+{
+  const int x=(int) (blockIdx.x*blockDim.x+threadIdx.x),y=(int) blockIdx.y;
+  if (x >= a.columns)
+    return;
+  const size_t pitch=(size_t) a.columns+2*(size_t) a.w;
+  const double sum=lopsided_sum(a.inter+(size_t) y*pitch+x,1,a.w);
+  const Q *p=static_cast<const Q *>(a.src)+((size_t) y*a.columns+x)*a.channels;
+  Q *q=static_cast<Q *>(a.dst)+((size_t) y*a.columns+x)*a.channels;
+  const double src_val=(double) luma_of<Q>(p,a.colour);
+  double mult=(src_val-(sum/a.total_weight))*a.strength_scale;
+  mult=(src_val+mult)/src_val;
+  for (int c=0; c < a.channels; c++)
+    {
+      const bool colour_channel=c < a.colour;
+      if (colour_channel && (((a.copy_mask >> c) & 1u) == 0))
+        q[c]=QuantumOps<Q>::clamp((double) p[c]*mult);
+      else
+        q[c]=p[c];
+    }
+}
+
+MhStatus launch_local_contrast(const View &src,const View &dst,double radius,double strength,
+  const Roles &roles)
+{
+  LocalContrastArgs a;
+  a.src=src.pixels;
+  a.dst=dst.pixels;
+  a.columns=(int) src.columns;
+  a.rows=(int) src.rows;
+  a.channels=src.channels;
+  const long longest=(long) (src.columns > src.rows ? src.columns : src.rows);
+  a.w=(int) (long) ((double) longest*0.002*fabs(radius));
+  if ((a.w < 1) || (a.columns <= 2*a.w+2))
+    return fail(MH_UNSUPPORTED,"LocalContrastImage: blur width %d on %d columns is left to the CPU",
+      a.w,a.columns);
+  a.total_weight=(double) (float) ((a.w+1)*(a.w+1));
+  a.strength_scale=strength/100.0;
+  a.copy_mask=roles.copy_mask;
+  a.colour=src.channels-(roles.alpha >= 0 ? 1 : 0) >= 3 ? 3 : 1;
+  Temp inter,luma;
+  MH_TRY(inter.alloc(src.device,(size_t) a.rows*((size_t) a.columns+2*(size_t) a.w)*sizeof(float),src.stream));
+  MH_TRY(luma.alloc(src.device,((size_t) a.rows+2*(size_t) a.w)*(size_t) a.columns*sizeof(float),src.stream));
+  a.inter=inter.as<float>();
+  const dim3 block(256);
+  const unsigned gx=(unsigned) ((a.columns+255)/256);
+  ProfileScope prof("local_contrast",src.stream);
+  if (src.quantum == MH_QUANTUM_U16)
+    hipLaunchKernelGGL((local_contrast_luma_kernel<uint16_t>),dim3(gx,(unsigned) (a.rows+2*a.w)),block,0,src.stream,a,luma.as<float>());
+  else
+    hipLaunchKernelGGL((local_contrast_luma_kernel<float>),dim3(gx,(unsigned) (a.rows+2*a.w)),block,0,src.stream,a,luma.as<float>());
+  hipLaunchKernelGGL(local_contrast_vertical_kernel,dim3(gx,(unsigned) a.rows),block,0,src.stream,a,luma.as<float>());
+  if (src.quantum == MH_QUANTUM_U16)
+    hipLaunchKernelGGL((local_contrast_horizontal_kernel<uint16_t>),dim3(gx,(unsigned) a.rows),block,0,src.stream,a);
+  else
+    hipLaunchKernelGGL((local_contrast_horizontal_kernel<float>),dim3(gx,(unsigned) a.rows),block,0,src.stream,a);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 } // namespace mh

@@ -452,6 +452,17 @@ MH_API MhStatus MagickHipBlurImage(const MhImage *image,MhImage *blur_image,
   return status;
 }
 
+MH_API MhStatus MagickHipLocalContrastImage(const MhImage *image,MhImage *contrast_image,
+  double radius,double strength)
+{
+  MH_TRY(gate_pair(image,contrast_image,"LocalContrastImage",true));
+  Pair pair;
+  MH_TRY(pair.open(image,contrast_image));
+  Roles roles=channel_roles(image,contrast_image);
+  MH_TRY(launch_local_contrast(pair.src.view,pair.dst.view,radius,strength,roles));
+  return pair.commit();
+}
+
 MH_API MhStatus MagickHipRotationalBlurImage(const MhImage *image,MhImage *blur_image,double angle)
 {
   MH_TRY(gate_pair(image,blur_image,"RotationalBlurImage",true));

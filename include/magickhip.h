@@ -306,6 +306,12 @@ MH_API MhStatus MagickHipEdgeImage(const MhImage *image,MhImage *edge_image,doub
 MH_API MhStatus MagickHipEmbossImage(const MhImage *image,MhImage *emboss_image,
   double radius,double sigma);
 
+/* AccelerateLocalContrastImage: LocalContrastImage(image,radius,strength), effect.c:1760-2010.
+   MH_UNSUPPORTED (CPU path) when the blur width 0.002*max(columns,rows)*|radius| is 0 or does
+   not leave room for the mirrored padding. */
+MH_API MhStatus MagickHipLocalContrastImage(const MhImage *image,MhImage *contrast_image,
+  double radius,double strength);
+
 /* AccelerateRotationalBlurImage: RotationalBlurImage(image,angle), effect.c:3209-3430. */
 MH_API MhStatus MagickHipRotationalBlurImage(const MhImage *image,MhImage *blur_image,double angle);
 

@@ -252,6 +252,15 @@ REF_API void *ref_edge(const void *handle,double radius,double *seconds)
   return((void *) out);
 }
 
+REF_API void *ref_local_contrast(const void *handle,double radius,double strength,double *seconds)
+{
+  Image *out;
+  TIMED_BEGIN;
+  out=LocalContrastImage((const Image *) handle,radius,strength,ref_exception);
+  TIMED_END;
+  return((void *) out);
+}
+
 REF_API void *ref_rotational_blur(const void *handle,double angle,double *seconds)
 {
   Image *out;

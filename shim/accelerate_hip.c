@@ -631,11 +631,41 @@ MagickPrivate Image *AccelerateDespeckleImage(const Image *magick_unused(image),
   return((Image *) NULL);
 }
 
-MagickPrivate Image *AccelerateLocalContrastImage(const Image *magick_unused(image),
-  const double magick_unused(radius),const double magick_unused(strength),
-  ExceptionInfo *magick_unused(exception))
+/* LocalContrastImage's call site: effect.c:1794-1798 */
+MagickPrivate Image *AccelerateLocalContrastImage(const Image *image,const double radius,
+  const double strength,ExceptionInfo *exception)
 {
-  return((Image *) NULL);
+  HipLibrary
+    *library;
+
+  Image
+    *contrast_image;
+
+  MhImage
+    source,
+    destination;
+
+  void
+    *p,
+    *q;
+
+  if (IsImageAcceleratable(image) == MagickFalse)
+    return((Image *) NULL);
+  library=AcquireHipLibrary();
+  if (library == (HipLibrary *) NULL)
+    return((Image *) NULL);
+  p=AcquireDevicePixels(library,image,1,exception);
+  if (p == NULL)
+    return((Image *) NULL);
+  contrast_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
+  if (contrast_image == (Image *) NULL)
+    return((Image *) NULL);
+  if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
+      (DescribeImage(library,contrast_image,q,&destination) == MagickFalse) ||
+      (library->LocalContrastImage(&source,&destination,radius,strength) != MH_OK))
+    return(DestroyImage(contrast_image));
+  hip_accelerated_calls++;
+  return(contrast_image);
 }
 
 /* MotionBlurImage hands its kernel and offsets to the hook (effect.c:2397-2404) */

@@ -104,6 +104,8 @@ def reference_vectors():
             out[key + "_resize_mitchell"] = ref.RefImage(px).resize(60, 20, "Mitchell").numpy()
             out[key + "_resize_catrom"] = ref.RefImage(px).resize(20, 50, "Catrom").numpy()
             out[key + "_resize_triangle"] = ref.RefImage(px).resize(64, 64, "Triangle").numpy()
+            out[key + "_localcontrast_60x40"] = ref.RefImage(px).local_contrast(60.0, 40.0).numpy()
+            out[key + "_localcontrast_30x-25"] = ref.RefImage(px).local_contrast(30.0, -25.0).numpy()
             out[key + "_rotational_12"] = ref.RefImage(px).rotational_blur(12.0).numpy()
             out[key + "_rotational_-40"] = ref.RefImage(px).rotational_blur(-40.0).numpy()
             out[key + "_motion_0x3+30"] = ref.RefImage(px).motion_blur(0.0, 3.0, 30.0).numpy()

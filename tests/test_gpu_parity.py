@@ -207,6 +207,22 @@ def test_morphology_until_convergence(im, refmod):
     assert_parity(got, want, True, "dilate until no change")
 
 
+# ----------------------------------------------------------- LocalContrastImage
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("channels", [1, 2, 3, 4])
+@pytest.mark.parametrize("args", [(60.0, 40.0), (30.0, -25.0), (110.0, 100.0)])
+def test_local_contrast(im, refmod, dtype, channels, args):
+    px = make_pixels(67, 91, channels, dtype)
+    px[5:9, 7:11, :] = 0                                  # zero luma: the gain divides by it
+    dev, ref = run_pair(im, refmod, px)
+    got = im.local_contrast_image(dev, *args).numpy()
+    want = ref.local_contrast(*args).numpy()
+    if dtype == HDRI:                                      # NaN where 0/0; compare the rest bit for bit
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        got, want = np.nan_to_num(got), np.nan_to_num(want)
+    assert_parity(got, want, True, "local contrast %s c%d" % (args, channels))
+
+
 # ----------------------------------------------------------- RotationalBlurImage
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
 @pytest.mark.parametrize("channels", [1, 2, 3, 4])

@@ -176,6 +176,13 @@ def test_contrast_and_modulate_match_reference(vectors, tag, ch):
 
 
 @pytest.mark.parametrize("tag,ch", CASES)
+def test_local_contrast_matches_reference(vectors, tag, ch):
+    px = vectors["%s_c%d_in" % (tag, ch)]
+    for name, args in (("localcontrast_60x40", (60.0, 40.0)), ("localcontrast_30x-25", (30.0, -25.0))):
+        assert_identical(R.local_contrast_image(px, *args), vectors["%s_c%d_%s" % (tag, ch, name)], name)
+
+
+@pytest.mark.parametrize("tag,ch", CASES)
 def test_rotational_blur_matches_reference(vectors, tag, ch):
     px = vectors["%s_c%d_in" % (tag, ch)]
     for name, angle in (("rotational_12", 12.0), ("rotational_-40", -40.0)):
