@@ -1224,4 +1224,126 @@ MhStatus launch_local_contrast(const View &src,const View &dst,double radius,dou
   return MH_OK;
 }
 
+// ---------------------------------------------------------------- DespeckleImage
+// effect.c:1211-1306 (Hull) and :1308-1490: per channel, 16 Hull calls (4 directions x
+// {+,-} offset x {raise, lower}), each two data-parallel sweeps between two zero-bordered
+// (columns+2) x (rows+2) planes.  All channels are swept together (they never interact);
+// the step is ScaleCharToQuantum(1) = 257, the guard ScaleCharToQuantum(2) = 514.
+template<typename Q,int C>
+__global__ __launch_bounds__(256)
+void despeckle_load_kernel(const Q *src,Q *f,Q *g,int columns,int rows)
+{
+  const int px=(int) (blockIdx.x*blockDim.x+threadIdx.x),py=(int) blockIdx.y;     // padded coordinates
+  if (px >= columns+2)
+    return;
+  Q v[C];
+#pragma unroll
+  for (int c=0; c < C; c++)
+    v[c]=(Q) 0;
+  Q zero[C];
+#pragma unroll
+  for (int c=0; c < C; c++)
+    zero[c]=(Q) 0;
+  if ((px >= 1) && (px <= columns) && (py >= 1) && (py <= rows))
+    load_pixel<Q,C>(src+((size_t) (py-1)*columns+(px-1))*C,v);
+  store_pixel<Q,C>(f+((size_t) py*(columns+2)+px)*C,v);
+  store_pixel<Q,C>(g+((size_t) py*(columns+2)+px)*C,zero);
+}
+
+// SECOND=false: g = f raised/lowered where the neighbour at +offset in f calls for it;
+// SECOND=true:  f = g raised/lowered where the neighbours at -offset and +offset in g do
+template<typename Q,int C,bool SECOND>
+__global__ __launch_bounds__(256)
+void hull_kernel(const Q *from,Q *to,int columns,int rows,int offset,int polarity)
+{
+  const int x=(int) (blockIdx.x*blockDim.x+threadIdx.x),y=(int) blockIdx.y;
+  if (x >= columns)
+    return;
+  const size_t i=((size_t) (y+1)*(columns+2)+(size_t) (x+1));
+  Q centre[C],r[C],s[C],out[C];
+  load_pixel<Q,C>(from+i*C,centre);
+  load_pixel<Q,C>(from+(size_t) ((long) i+offset)*C,r);
+  if (SECOND)
+    load_pixel<Q,C>(from+(size_t) ((long) i-offset)*C,s);
+#pragma unroll
+  for (int c=0; c < C; c++)
+    {
+      double v=(double) centre[c];
+      if (polarity > 0)
+        {
+          if (SECOND ? (((double) s[c] >= (v+514.0)) && ((double) r[c] > v)) : ((double) r[c] >= (v+514.0)))
+            v+=257.0;
+        }
+      else
+        {
+          if (SECOND ? (((double) s[c] <= (v-514.0)) && ((double) r[c] < v)) : ((double) r[c] <= (v-514.0)))
+            v-=257.0;
+        }
+      out[c]=(Q) v;
+    }
+  store_pixel<Q,C>(to+i*C,out);
+}
+
+template<typename Q,int C>
+__global__ __launch_bounds__(256)
+void despeckle_store_kernel(const Q *f,const Q *src,Q *dst,int columns,int rows,uint32_t copy_mask)
+{
+  const int x=(int) (blockIdx.x*blockDim.x+threadIdx.x),y=(int) blockIdx.y;
+  if (x >= columns)
+    return;
+  Q v[C],original[C];
+  load_pixel<Q,C>(f+((size_t) (y+1)*(columns+2)+(x+1))*C,v);
+  load_pixel<Q,C>(src+((size_t) y*columns+x)*C,original);
+#pragma unroll
+  for (int c=0; c < C; c++)
+    if ((copy_mask >> c) & 1u)
+      v[c]=original[c];
+  store_pixel<Q,C>(dst+((size_t) y*columns+x)*C,v);
+}
+
+template<typename Q,int C>
+static MhStatus despeckle_typed(const View &src,const View &dst,const Roles &roles)
+{
+  const int W=(int) src.columns,H=(int) src.rows;
+  const size_t plane=(size_t) (W+2)*(size_t) (H+2)*C*sizeof(Q);
+  Temp tf,tg;
+  MH_TRY(tf.alloc(src.device,plane,src.stream));
+  MH_TRY(tg.alloc(src.device,plane,src.stream));
+  Q *f=tf.as<Q>(),*g=tg.as<Q>();
+  const dim3 block(256);
+  ProfileScope prof("despeckle",src.stream);
+  hipLaunchKernelGGL((despeckle_load_kernel<Q,C>),dim3((unsigned) ((W+2+255)/256),(unsigned) (H+2)),block,0,
+    src.stream,static_cast<const Q *>(src.pixels),f,g,W,H);
+  const dim3 grid((unsigned) ((W+255)/256),(unsigned) H);
+  static const int X[4]={0,1,1,-1},Y[4]={1,0,1,1};
+  for (int k=0; k < 4; k++)
+    {
+      const int offset=Y[k]*(W+2)+X[k];
+      const int sequence[4][2]={{offset,1},{-offset,1},{-offset,-1},{offset,-1}};
+      for (const auto &call : sequence)
+        {
+          hipLaunchKernelGGL((hull_kernel<Q,C,false>),grid,block,0,src.stream,f,g,W,H,call[0],call[1]);
+          hipLaunchKernelGGL((hull_kernel<Q,C,true>),grid,block,0,src.stream,g,f,W,H,call[0],call[1]);
+        }
+    }
+  hipLaunchKernelGGL((despeckle_store_kernel<Q,C>),grid,block,0,src.stream,f,static_cast<const Q *>(src.pixels),
+    static_cast<Q *>(dst.pixels),W,H,roles.copy_mask);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+MhStatus launch_despeckle(const View &src,const View &dst,const Roles &roles)
+{
+#define MH_CASE(QT) \
+  switch (src.channels) { \
+    case 1: return despeckle_typed<QT,1>(src,dst,roles); \
+    case 2: return despeckle_typed<QT,2>(src,dst,roles); \
+    case 3: return despeckle_typed<QT,3>(src,dst,roles); \
+    default: return despeckle_typed<QT,4>(src,dst,roles); }
+  if (src.quantum == MH_QUANTUM_U16)
+    { MH_CASE(uint16_t) }
+  MH_CASE(float)
+#undef MH_CASE
+}
+
 } // namespace mh

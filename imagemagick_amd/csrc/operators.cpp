@@ -452,6 +452,16 @@ MH_API MhStatus MagickHipBlurImage(const MhImage *image,MhImage *blur_image,
   return status;
 }
 
+MH_API MhStatus MagickHipDespeckleImage(const MhImage *image,MhImage *despeckle_image)
+{
+  MH_TRY(gate_pair(image,despeckle_image,"DespeckleImage",true));
+  Pair pair;
+  MH_TRY(pair.open(image,despeckle_image));
+  Roles roles=channel_roles(image,despeckle_image);
+  MH_TRY(launch_despeckle(pair.src.view,pair.dst.view,roles));
+  return pair.commit();
+}
+
 MH_API MhStatus MagickHipLocalContrastImage(const MhImage *image,MhImage *contrast_image,
   double radius,double strength)
 {

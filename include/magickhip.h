@@ -306,6 +306,9 @@ MH_API MhStatus MagickHipEdgeImage(const MhImage *image,MhImage *edge_image,doub
 MH_API MhStatus MagickHipEmbossImage(const MhImage *image,MhImage *emboss_image,
   double radius,double sigma);
 
+/* AccelerateDespeckleImage: DespeckleImage(image), effect.c:1308-1490 (16 Hull sweeps). */
+MH_API MhStatus MagickHipDespeckleImage(const MhImage *image,MhImage *despeckle_image);
+
 /* AccelerateLocalContrastImage: LocalContrastImage(image,radius,strength), effect.c:1760-2010.
    MH_UNSUPPORTED (CPU path) when the blur width 0.002*max(columns,rows)*|radius| is 0 or does
    not leave room for the mirrored padding. */

@@ -252,6 +252,15 @@ REF_API void *ref_edge(const void *handle,double radius,double *seconds)
   return((void *) out);
 }
 
+REF_API void *ref_despeckle(const void *handle,double *seconds)
+{
+  Image *out;
+  TIMED_BEGIN;
+  out=DespeckleImage((const Image *) handle,ref_exception);
+  TIMED_END;
+  return((void *) out);
+}
+
 REF_API void *ref_local_contrast(const void *handle,double radius,double strength,double *seconds)
 {
   Image *out;

@@ -625,10 +625,41 @@ MagickPrivate MagickBooleanType AccelerateTransformImageColorspace(Image *image,
 }
 
 /* ---- operators outside the hot path: always "not handled", the CPU code runs ---- */
-MagickPrivate Image *AccelerateDespeckleImage(const Image *magick_unused(image),
-  ExceptionInfo *magick_unused(exception))
+/* DespeckleImage's call site: effect.c:1342-1346 */
+MagickPrivate Image *AccelerateDespeckleImage(const Image *image,ExceptionInfo *exception)
 {
-  return((Image *) NULL);
+  HipLibrary
+    *library;
+
+  Image
+    *despeckle_image;
+
+  MhImage
+    source,
+    destination;
+
+  void
+    *p,
+    *q;
+
+  if (IsImageAcceleratable(image) == MagickFalse)
+    return((Image *) NULL);
+  library=AcquireHipLibrary();
+  if (library == (HipLibrary *) NULL)
+    return((Image *) NULL);
+  p=AcquireDevicePixels(library,image,1,exception);
+  if (p == NULL)
+    return((Image *) NULL);
+  despeckle_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
+  if (despeckle_image == (Image *) NULL)
+    return((Image *) NULL);
+  if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
+      (DescribeImage(library,despeckle_image,q,&destination) == MagickFalse) ||
+      (library->DespeckleImage(&source,&destination) != MH_OK))
+    return(DestroyImage(despeckle_image));
+  despeckle_image->type=image->type;       /* effect.c:1486 */
+  hip_accelerated_calls++;
+  return(despeckle_image);
 }
 
 /* LocalContrastImage's call site: effect.c:1794-1798 */

@@ -104,6 +104,7 @@ def reference_vectors():
             out[key + "_resize_mitchell"] = ref.RefImage(px).resize(60, 20, "Mitchell").numpy()
             out[key + "_resize_catrom"] = ref.RefImage(px).resize(20, 50, "Catrom").numpy()
             out[key + "_resize_triangle"] = ref.RefImage(px).resize(64, 64, "Triangle").numpy()
+            out[key + "_despeckle"] = ref.RefImage(px).despeckle().numpy()
             out[key + "_localcontrast_60x40"] = ref.RefImage(px).local_contrast(60.0, 40.0).numpy()
             out[key + "_localcontrast_30x-25"] = ref.RefImage(px).local_contrast(30.0, -25.0).numpy()
             out[key + "_rotational_12"] = ref.RefImage(px).rotational_blur(12.0).numpy()
@@ -141,6 +142,7 @@ def reference_vectors():
         out[tag + "_smooth_in"] = smooth
         n = 40 * 48
         out[tag + "_smooth_cstretch"] = ref.RefImage(smooth).contrast_stretch(0.02 * n, n - 0.01 * n).numpy()
+        out[tag + "_smooth_despeckle"] = ref.RefImage(smooth).despeckle().numpy()
         out[tag + "_smooth_equalize"] = ref.RefImage(smooth).equalize().numpy()
         out[tag + "_smooth_lab_cstretch"] = ref.RefImage(smooth).colorspace("Lab").contrast_stretch(
             0.02 * n, n - 0.01 * n).numpy()

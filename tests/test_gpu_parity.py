@@ -207,6 +207,16 @@ def test_morphology_until_convergence(im, refmod):
     assert_parity(got, want, True, "dilate until no change")
 
 
+# ----------------------------------------------------------- DespeckleImage
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("channels", [1, 2, 3, 4])
+@pytest.mark.parametrize("kind", ["random", "smooth"])
+def test_despeckle(im, refmod, dtype, channels, kind):
+    px = make_pixels(58, 77, channels, dtype, kind=kind)
+    dev, ref = run_pair(im, refmod, px)
+    assert_parity(im.despeckle_image(dev).numpy(), ref.despeckle().numpy(), True, "despeckle %s c%d" % (kind, channels))
+
+
 # ----------------------------------------------------------- LocalContrastImage
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
 @pytest.mark.parametrize("channels", [1, 2, 3, 4])

@@ -176,6 +176,15 @@ def test_contrast_and_modulate_match_reference(vectors, tag, ch):
 
 
 @pytest.mark.parametrize("tag,ch", CASES)
+def test_despeckle_matches_reference(vectors, tag, ch):
+    px = vectors["%s_c%d_in" % (tag, ch)]
+    assert_identical(R.despeckle_image(px), vectors["%s_c%d_despeckle" % (tag, ch)], "despeckle")
+    if ch == 4:
+        smooth = vectors[tag + "_smooth_in"]
+        assert_identical(R.despeckle_image(smooth), vectors[tag + "_smooth_despeckle"], "despeckle (smooth)")
+
+
+@pytest.mark.parametrize("tag,ch", CASES)
 def test_local_contrast_matches_reference(vectors, tag, ch):
     px = vectors["%s_c%d_in" % (tag, ch)]
     for name, args in (("localcontrast_60x40", (60.0, 40.0)), ("localcontrast_30x-25", (30.0, -25.0))):
