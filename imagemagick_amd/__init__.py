@@ -20,7 +20,7 @@ from ._lib import (MagickHipError, MhImage, COLORSPACES, MORPHOLOGY, FILTERS,  #
 
 __all__ = ["Image", "blur_image", "convolve_image", "morphology_image", "morphology_primitive",
            "unsharp_mask_image", "resize_image", "contrast_stretch_image", "equalize_image",
-           "transform_image_colorspace", "despeckle_image", "local_contrast_image", "rotational_blur_image", "motion_blur_image", "gaussian_blur_image", "sharpen_image", "edge_image",
+           "transform_image_colorspace", "wavelet_denoise_image", "despeckle_image", "local_contrast_image", "rotational_blur_image", "motion_blur_image", "gaussian_blur_image", "sharpen_image", "edge_image",
            "emboss_image", "import_image_pixels", "export_image_pixels", "contrast_image", "modulate_image", "grayscale_image", "function_image", "histogram", "apply_lut", "contrast_stretch_lut",
            "equalize_lut", "is_image_gray", "set_precision", "get_precision", "device_count",
            "build", "load", "MagickHipError"]
@@ -233,6 +233,11 @@ def _pair_operator(name, image, *args):
     out = image.like()
     _lib.check(getattr(lib, name)(ctypes.byref(image.descriptor()), ctypes.byref(out.descriptor()), *args))
     return out
+
+
+def wavelet_denoise_image(image, threshold, softness=0.0):
+    """WaveletDenoiseImage(image, threshold, softness) — MagickCore/visual-effects.c:3520."""
+    return _pair_operator("MagickHipWaveletDenoiseImage", image, threshold, softness)
 
 
 def despeckle_image(image):

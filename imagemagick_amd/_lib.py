@@ -145,6 +145,7 @@ PROTOTYPES = [
     ("MagickHipMorphologyPrimitive", ctypes.c_int, [_P(MhImage), _P(MhImage), ctypes.c_int,
                                                     _P(MhKernelInfo), ctypes.c_double,
                                                     _P(ctypes.c_ssize_t)]),
+    ("MagickHipWaveletDenoiseImage", ctypes.c_int, [_P(MhImage), _P(MhImage), ctypes.c_double, ctypes.c_double]),
     ("MagickHipDespeckleImage", ctypes.c_int, [_P(MhImage), _P(MhImage)]),
     ("MagickHipLocalContrastImage", ctypes.c_int, [_P(MhImage), _P(MhImage), ctypes.c_double, ctypes.c_double]),
     ("MagickHipRotationalBlurImage", ctypes.c_int, [_P(MhImage), _P(MhImage), ctypes.c_double]),

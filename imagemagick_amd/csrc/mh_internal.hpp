@@ -198,6 +198,8 @@ MhStatus launch_rotational_blur(const View &src,const View &dst,const double *co
 MhStatus launch_local_contrast(const View &src,const View &dst,double radius,double strength,
   const Roles &roles);
 MhStatus launch_despeckle(const View &src,const View &dst,const Roles &roles);
+MhStatus launch_wavelet_denoise(const View &src,const View &dst,double threshold,double softness,
+  const Roles &roles);
 void release_color_tables();          // frees the per-device transfer-function tables
 MhStatus launch_gray_check(const View &img,const MhImage *desc,unsigned int *flag_device);
 MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,const MhImage *desc);

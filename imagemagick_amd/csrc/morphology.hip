@@ -1346,4 +1346,138 @@ MhStatus launch_despeckle(const View &src,const View &dst,const Roles &roles)
 #undef MH_CASE
 }
 
+// ---------------------------------------------------------------- WaveletDenoiseImage
+// visual-effects.c:3478-3760: five levels of the a-trous "hat" transform (rows, then columns)
+// on float planes of the colour channels, soft thresholding of each detail band, and the
+// reconstruction.  All arithmetic is the reference's float arithmetic, expression by
+// expression (HatTransform's three index ranges in closed form).
+static __device__ __forceinline__ float hat_value(const float *line,long stride,int i,int extent,int scale)
+{
+  const float centre=line[(long) i*stride];
+  if (i < scale)
+    return 0.25f*(centre+centre+line[(long) (scale-i)*stride]+line[(long) (scale+i)*stride]);
+  if (i < extent-scale)
+    return 0.25f*(2.0f*centre+line[(long) (i-scale)*stride]+line[(long) (i+scale)*stride]);
+  return 0.25f*(centre+centre+line[(long) (i-scale)*stride]+line[(long) (2*extent-2-scale-i)*stride]);
+}
+
+template<typename Q>
+__global__ __launch_bounds__(256)
+void wavelet_load_kernel(const Q *src,float *plane,size_t npixels,int channels,int colour)
+{
+  const size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x;
+  if (i >= npixels)
+    return;
+  for (int c=0; c < colour; c++)
+    plane[i*colour+c]=(float) src[i*channels+c];
+}
+
+// ROWS: out(x,y) from the row y of `in`; else from the column x
+template<bool ROWS>
+__global__ __launch_bounds__(256)
+void wavelet_hat_kernel(const float *in,float *out,int columns,int rows,int colour,int scale)
+{
+  const int xc=(int) (blockIdx.x*blockDim.x+threadIdx.x),y=(int) blockIdx.y;     // xc = x*colour+c
+  if (xc >= columns*colour)
+    return;
+  const int x=xc/colour,c=xc-x*colour;
+  const size_t pitch=(size_t) columns*colour;
+  float v;
+  if (ROWS)
+    v=hat_value(in+(size_t) y*pitch+c,colour,x,columns,scale);
+  else
+    v=hat_value(in+(size_t) x*colour+c,(long) pitch,y,rows,scale);
+  out[(size_t) y*pitch+xc]=v;
+}
+
+__global__ __launch_bounds__(256)
+void wavelet_threshold_kernel(float *high,const float *low,float *base,size_t count,double magnitude,
+  double softness,int accumulate)
+{
+  const size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x;
+  if (i >= count)
+    return;
+  float h=high[i];
+  h-=low[i];
+  if ((double) h < -magnitude)
+    h+=(float) (magnitude-softness*magnitude);
+  else if ((double) h > magnitude)
+    h-=(float) (magnitude-softness*magnitude);
+  else
+    h*=(float) softness;
+  high[i]=h;
+  if (accumulate != 0)
+    base[i]+=h;
+}
+
+template<typename Q>
+__global__ __launch_bounds__(256)
+void wavelet_store_kernel(const Q *src,Q *dst,const float *base,const float *low,size_t npixels,int channels,
+  int colour,uint32_t copy_mask)
+{
+  const size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x;
+  if (i >= npixels)
+    return;
+  for (int c=0; c < channels; c++)
+    {
+      // every colour channel is rebuilt, whatever its traits (visual-effects.c:3590-3598 only
+      // skips channels that are not R, G or B)
+      if (c < colour)
+        dst[i*channels+c]=QuantumOps<Q>::clamp((double) base[i*colour+c]+(double) low[i*colour+c]);
+      else
+        dst[i*channels+c]=src[i*channels+c];
+    }
+}
+
+MhStatus launch_wavelet_denoise(const View &src,const View &dst,double threshold,double softness,
+  const Roles &roles)
+{
+  const int W=(int) src.columns,H=(int) src.rows;
+  if ((W < 33) || (H < 33))
+    return fail(MH_UNSUPPORTED,"WaveletDenoiseImage: %dx%d is below two spans of the coarsest level",W,H);
+  const int colour=src.channels-(roles.alpha >= 0 ? 1 : 0) >= 3 ? 3 : 1;
+  const size_t n=(size_t) W*H,count=n*(size_t) colour;
+  Temp planes[4];
+  float *plane[4];
+  for (int k=0; k < 4; k++)
+    {
+      MH_TRY(planes[k].alloc(src.device,count*sizeof(float),src.stream));
+      plane[k]=planes[k].as<float>();
+    }
+  static const float noise_levels[]={0.8002f,0.2735f,0.1202f,0.0585f,0.0291f,0.0152f,0.0080f,0.0044f};
+  const dim3 block(256);
+  const unsigned pixel_blocks=(unsigned) ((n+255)/256),value_blocks=(unsigned) ((count+255)/256);
+  ProfileScope prof("wavelet_denoise",src.stream);
+  if (src.quantum == MH_QUANTUM_U16)
+    hipLaunchKernelGGL((wavelet_load_kernel<uint16_t>),dim3(pixel_blocks),block,0,src.stream,
+      static_cast<const uint16_t *>(src.pixels),plane[0],n,src.channels,colour);
+  else
+    hipLaunchKernelGGL((wavelet_load_kernel<float>),dim3(pixel_blocks),block,0,src.stream,
+      static_cast<const float *>(src.pixels),plane[0],n,src.channels,colour);
+  const dim3 grid((unsigned) ((W*colour+255)/256),(unsigned) H);
+  int high=0,low=1;
+  for (int level=0; level < 5; level++)
+    {
+      low=(level & 1)+1;                             // low_pass = number_pixels*((level & 0x01)+1)
+      hipLaunchKernelGGL((wavelet_hat_kernel<true>),grid,block,0,src.stream,plane[high],plane[3],W,H,colour,
+        1 << level);
+      hipLaunchKernelGGL((wavelet_hat_kernel<false>),grid,block,0,src.stream,plane[3],plane[low],W,H,colour,
+        1 << level);
+      const double magnitude=threshold*(double) noise_levels[level];
+      hipLaunchKernelGGL(wavelet_threshold_kernel,dim3(value_blocks),block,0,src.stream,plane[high],plane[low],
+        plane[0],count,magnitude,softness,high != 0 ? 1 : 0);
+      high=low;
+    }
+  if (src.quantum == MH_QUANTUM_U16)
+    hipLaunchKernelGGL((wavelet_store_kernel<uint16_t>),dim3(pixel_blocks),block,0,src.stream,
+      static_cast<const uint16_t *>(src.pixels),static_cast<uint16_t *>(dst.pixels),plane[0],plane[low],n,
+      src.channels,colour,roles.copy_mask);
+  else
+    hipLaunchKernelGGL((wavelet_store_kernel<float>),dim3(pixel_blocks),block,0,src.stream,
+      static_cast<const float *>(src.pixels),static_cast<float *>(dst.pixels),plane[0],plane[low],n,
+      src.channels,colour,roles.copy_mask);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 } // namespace mh

@@ -452,6 +452,17 @@ MH_API MhStatus MagickHipBlurImage(const MhImage *image,MhImage *blur_image,
   return status;
 }
 
+MH_API MhStatus MagickHipWaveletDenoiseImage(const MhImage *image,MhImage *noise_image,
+  double threshold,double softness)
+{
+  MH_TRY(gate_pair(image,noise_image,"WaveletDenoiseImage",true));
+  Pair pair;
+  MH_TRY(pair.open(image,noise_image));
+  Roles roles=channel_roles(image,noise_image);
+  MH_TRY(launch_wavelet_denoise(pair.src.view,pair.dst.view,threshold,softness,roles));
+  return pair.commit();
+}
+
 MH_API MhStatus MagickHipDespeckleImage(const MhImage *image,MhImage *despeckle_image)
 {
   MH_TRY(gate_pair(image,despeckle_image,"DespeckleImage",true));

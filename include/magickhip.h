@@ -306,6 +306,12 @@ MH_API MhStatus MagickHipEdgeImage(const MhImage *image,MhImage *edge_image,doub
 MH_API MhStatus MagickHipEmbossImage(const MhImage *image,MhImage *emboss_image,
   double radius,double sigma);
 
+/* AccelerateWaveletDenoiseImage: WaveletDenoiseImage(image,threshold,softness),
+   visual-effects.c:3520-3760.  (The reference's hook drops `softness`; the shim's build-time
+   patch passes it.)  Images below 33 pixels on a side are left to the CPU. */
+MH_API MhStatus MagickHipWaveletDenoiseImage(const MhImage *image,MhImage *noise_image,
+  double threshold,double softness);
+
 /* AccelerateDespeckleImage: DespeckleImage(image), effect.c:1308-1490 (16 Hull sweeps). */
 MH_API MhStatus MagickHipDespeckleImage(const MhImage *image,MhImage *despeckle_image);
 

@@ -61,7 +61,7 @@ def _load(hdri, shim=False):
     L.ref_image_get_property.restype = cp
     L.ref_image_get_property.argtypes = [vp, cp]
     for name, extra in [("ref_blur", [dbl, dbl]), ("ref_gaussian_blur", [dbl, dbl]),
-                        ("ref_sharpen", [dbl, dbl]), ("ref_motion_blur", [dbl, dbl, dbl]), ("ref_rotational_blur", [dbl]), ("ref_local_contrast", [dbl, dbl]), ("ref_despeckle", []), ("ref_emboss", [dbl, dbl]), ("ref_edge", [dbl]),
+                        ("ref_sharpen", [dbl, dbl]), ("ref_motion_blur", [dbl, dbl, dbl]), ("ref_rotational_blur", [dbl]), ("ref_local_contrast", [dbl, dbl]), ("ref_despeckle", []), ("ref_wavelet_denoise", [dbl, dbl]), ("ref_emboss", [dbl, dbl]), ("ref_edge", [dbl]),
                         ("ref_unsharp", [dbl, dbl, dbl, dbl]), ("ref_convolve", [cp]),
                         ("ref_morphology", [cp, ctypes.c_ssize_t, cp]),
                         ("ref_resize", [sz, sz, cp])]:
@@ -176,6 +176,9 @@ class RefImage:
 
     def gaussian_blur(self, radius, sigma):
         return self._new(self.L.ref_gaussian_blur, radius, sigma)
+
+    def wavelet_denoise(self, threshold, softness=0.0):
+        return self._new(self.L.ref_wavelet_denoise, threshold, softness)
 
     def despeckle(self):
         return self._new(self.L.ref_despeckle)

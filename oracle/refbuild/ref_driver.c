@@ -252,6 +252,16 @@ REF_API void *ref_edge(const void *handle,double radius,double *seconds)
   return((void *) out);
 }
 
+REF_API void *ref_wavelet_denoise(const void *handle,double threshold,double softness,
+  double *seconds)
+{
+  Image *out;
+  TIMED_BEGIN;
+  out=WaveletDenoiseImage((const Image *) handle,threshold,softness,ref_exception);
+  TIMED_END;
+  return((void *) out);
+}
+
 REF_API void *ref_despeckle(const void *handle,double *seconds)
 {
   Image *out;

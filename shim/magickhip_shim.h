@@ -32,6 +32,7 @@ typedef struct _HipLibrary
   MhStatus (*FunctionImage)(MhImage *,MhFunction,size_t,const double *);
   MhStatus (*MotionBlurImageWithKernel)(const MhImage *,MhImage *,const double *,size_t,
     const ptrdiff_t *);
+  MhStatus (*WaveletDenoiseImage)(const MhImage *,MhImage *,double,double);
   MhStatus (*DespeckleImage)(const MhImage *,MhImage *);
   MhStatus (*LocalContrastImage)(const MhImage *,MhImage *,double,double);
   MhStatus (*RotationalBlurImage)(const MhImage *,MhImage *,double);

@@ -98,6 +98,7 @@ MagickPrivate HipLibrary *AcquireHipLibrary(void)
   MH_RESOLVE(GrayscaleImage,"MagickHipGrayscaleImage");
   MH_RESOLVE(FunctionImage,"MagickHipFunctionImage");
   MH_RESOLVE(MotionBlurImageWithKernel,"MagickHipMotionBlurImageWithKernel");
+  MH_RESOLVE(WaveletDenoiseImage,"MagickHipWaveletDenoiseImage");
   MH_RESOLVE(DespeckleImage,"MagickHipDespeckleImage");
   MH_RESOLVE(LocalContrastImage,"MagickHipLocalContrastImage");
   MH_RESOLVE(RotationalBlurImage,"MagickHipRotationalBlurImage");

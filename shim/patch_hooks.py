@@ -2,7 +2,7 @@
 """Generates, at build time, copies of four MagickCore sources with the accelerate call
 sites the reference does not have (or has commented out) switched in — SURVEY 8b: "new hooks
 for Morphology and Colorspace", the disabled UnsharpMask stanza, the caller-less
-ContrastStretch.  Each hook is the reference's own three-line idiom
+ContrastStretch, WaveletDenoise's hook without its softness argument.  Each hook is the reference's own three-line idiom
 (effect.c:783-787).  The copies are written under shim/_build/ (never committed, never
 shipped); the reference tree is only read.
 
@@ -16,6 +16,12 @@ MORPHOLOGY_PROTOTYPE = '''
 #if defined(MAGICKCORE_OPENCL_SUPPORT)
 extern MagickPrivate Image *AccelerateMorphologyApply(const Image *,const MorphologyMethod,
   const ssize_t,const KernelInfo *,const CompositeOperator,const double,ExceptionInfo *);
+#endif
+'''
+WAVELET_PROTOTYPE = '''
+#if defined(MAGICKCORE_OPENCL_SUPPORT)
+extern MagickPrivate Image *AccelerateWaveletDenoiseImageSoft(const Image *,const double,
+  const double,ExceptionInfo *);
 #endif
 '''
 COLORSPACE_PROTOTYPE = '''
@@ -88,11 +94,19 @@ def colorspace(text):
     return text[:begin] + body + text[end:]
 
 
+def visual_effects(text):
+    # the reference's hook drops `softness`; pass it (the CPU result depends on it)
+    text = after_includes(text, WAVELET_PROTOTYPE)
+    return once(text, "  noise_image=AccelerateWaveletDenoiseImage(image,threshold,exception);\n",
+                "  noise_image=AccelerateWaveletDenoiseImageSoft(image,threshold,softness,exception);\n",
+                "visual-effects.c")
+
+
 def main():
     source, out = sys.argv[1], sys.argv[2]
     os.makedirs(out, exist_ok=True)
     for name, fn in (("morphology.c", morphology), ("effect.c", effect), ("enhance.c", enhance),
-                     ("colorspace.c", colorspace)):
+                     ("colorspace.c", colorspace), ("visual-effects.c", visual_effects)):
         text = open(os.path.join(source, name), encoding="latin-1").read()
         patched = fn(text)
         with open(os.path.join(out, name), "w", encoding="latin-1") as f:

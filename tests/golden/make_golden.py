@@ -142,6 +142,11 @@ def reference_vectors():
         out[tag + "_smooth_in"] = smooth
         n = 40 * 48
         out[tag + "_smooth_cstretch"] = ref.RefImage(smooth).contrast_stretch(0.02 * n, n - 0.01 * n).numpy()
+        noisy = make_pixels(rng, 45, 50, 4, hdri)
+        out[tag + "_wavelet_in"] = noisy
+        out[tag + "_wavelet_5000x0"] = ref.RefImage(noisy).wavelet_denoise(5000.0, 0.0).numpy()
+        out[tag + "_wavelet_9000x0.4"] = ref.RefImage(noisy).wavelet_denoise(9000.0, 0.4).numpy()
+        out[tag + "_smooth_wavelet_800x0.2"] = ref.RefImage(smooth).wavelet_denoise(800.0, 0.2).numpy()
         out[tag + "_smooth_despeckle"] = ref.RefImage(smooth).despeckle().numpy()
         out[tag + "_smooth_equalize"] = ref.RefImage(smooth).equalize().numpy()
         out[tag + "_smooth_lab_cstretch"] = ref.RefImage(smooth).colorspace("Lab").contrast_stretch(

@@ -207,6 +207,17 @@ def test_morphology_until_convergence(im, refmod):
     assert_parity(got, want, True, "dilate until no change")
 
 
+# ----------------------------------------------------------- WaveletDenoiseImage
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("channels", [1, 2, 3, 4])
+@pytest.mark.parametrize("args", [(5000.0, 0.0), (9000.0, 0.4), (300.0, 1.0)])
+def test_wavelet_denoise(im, refmod, dtype, channels, args):
+    px = make_pixels(45, 70, channels, dtype)
+    dev, ref = run_pair(im, refmod, px)
+    got = im.wavelet_denoise_image(dev, *args).numpy()
+    assert_parity(got, ref.wavelet_denoise(*args).numpy(), True, "wavelet denoise %s c%d" % (args, channels))
+
+
 # ----------------------------------------------------------- DespeckleImage
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
 @pytest.mark.parametrize("channels", [1, 2, 3, 4])

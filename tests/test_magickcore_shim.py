@@ -133,6 +133,7 @@ def test_morphology_hook_covers_convolve_callers(shim, dtype):
         ("RotationalBlur 15", lambda i: i.rotational_blur(15.0), 1),
         ("LocalContrast 80x50", lambda i: i.local_contrast(80.0, 50.0), 1),
         ("Despeckle", lambda i: i.despeckle(), 1),
+        ("WaveletDenoise 4000x0.3", lambda i: i.wavelet_denoise(4000.0, 0.3), 1),
     ]
     for name, op, calls in steps:
         before = accelerated_calls(shim, hdri)

@@ -175,6 +175,15 @@ def test_contrast_and_modulate_match_reference(vectors, tag, ch):
             assert_identical(got, want, name)
 
 
+@pytest.mark.parametrize("tag", ["q16", "hdri"])
+def test_wavelet_denoise_matches_reference(vectors, tag):
+    noisy, smooth = vectors[tag + "_wavelet_in"], vectors[tag + "_smooth_in"]
+    assert_identical(R.wavelet_denoise_image(noisy, 5000.0, 0.0), vectors[tag + "_wavelet_5000x0"], "wavelet 5000")
+    assert_identical(R.wavelet_denoise_image(noisy, 9000.0, 0.4), vectors[tag + "_wavelet_9000x0.4"], "wavelet 9000x0.4")
+    assert_identical(R.wavelet_denoise_image(smooth, 800.0, 0.2), vectors[tag + "_smooth_wavelet_800x0.2"],
+                     "wavelet smooth")
+
+
 @pytest.mark.parametrize("tag,ch", CASES)
 def test_despeckle_matches_reference(vectors, tag, ch):
     px = vectors["%s_c%d_in" % (tag, ch)]
