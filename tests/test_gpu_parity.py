@@ -530,6 +530,33 @@ def test_blur_full_size_properties(im):
     assert int(diff) <= 1
 
 
+def test_blur_fast_full_size_against_exact(im):
+    """BASELINE C2 at full size, the configuration bench.py times: the FAST result (matrix-core
+    passes, 128 ring steps per strip, every strip and segment boundary of the 8192^2 frame) must
+    stay within +-1 level of the EXACT result — which the small-size tests pin bit for bit to
+    the reference — on uniform-random RGBA including tiny and zero alpha; and a constant image
+    must come back unchanged."""
+    import torch
+    n = 8192
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = torch.randint(-32768, 32768, (n, n, 4), generator=g, device="cuda", dtype=torch.int16)
+    a[: n // 8, :, 3] = torch.randint(0, 4, (n // 8, n), generator=g, device="cuda", dtype=torch.int16)   # tiny alpha
+    a[n // 8: n // 4, :, 3] = 0                                                                    # transparent band
+    img = im.Image(a.view(torch.uint16))
+    exact = im.blur_image(img, 0.0, 10.0).pixels.view(torch.int16).to(torch.int32) & 0xffff
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        fast = im.blur_image(img, 0.0, 10.0).pixels.view(torch.int16).to(torch.int32) & 0xffff
+        const = torch.full((n, n, 4), 23456, dtype=torch.int16, device="cuda").view(torch.uint16)
+        same = im.blur_image(im.Image(const), 0.0, 10.0).pixels
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    d = (fast - exact).abs()
+    assert int(d.max()) <= 1, "max |FAST - EXACT| = %d, %d samples over" % (int(d.max()), int((d > 1).sum()))
+    assert float((d == 0).double().mean()) > 0.98
+    assert int((same.view(torch.int16) != 23456).sum()) == 0
+
+
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
 @pytest.mark.parametrize("kind", ["random", "smooth"])
 def test_histogram_operators_large_frame(im, refmod, dtype, kind):
