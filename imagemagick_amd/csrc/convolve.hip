@@ -1458,9 +1458,11 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
     {
       if (prec == MH_PRECISION_FAST)
         {
-          // RGBA with alpha-weighted colour channels (BlurImage's case): the banded-matrix
-          // formulation on the f16 matrix cores, convolve_mfma.hip
-          if ((src.channels == 4) && roles.blend && (roles.alpha == 3) && (roles.copy_mask == 0) &&
+          // RGBA with alpha-weighted colour channels (BlurImage's case), or 3/4 independent
+          // channels (RGB, CMYK): the banded-matrix formulation on the f16 matrix cores,
+          // convolve_mfma.hip
+          if ((roles.blend ? (src.channels == 4) && (roles.alpha == 3) :
+               (src.channels == 3) || (src.channels == 4)) && (roles.copy_mask == 0) &&
               (params.bias == 0.0) && (changed == nullptr) && (getenv("MAGICKHIP_NO_MFMA") == nullptr))
             {
               const int K=params.ntaps;
@@ -1470,7 +1472,7 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
               Temp taps;
               MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(float)));
               bool handled=false;
-              MH_TRY(launch_conv1d_mfma(src,dst,vertical,taps.as<float>(),K,K-1-params.origin,&handled));
+              MH_TRY(launch_conv1d_mfma(src,dst,vertical,taps.as<float>(),K,K-1-params.origin,roles.blend,&handled));
               if (handled)
                 return MH_OK;
             }

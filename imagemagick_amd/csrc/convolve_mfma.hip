@@ -102,10 +102,20 @@ static __device__ __forceinline__ void split_f16(float v,_Float16 &hi,_Float16 &
 // VERTICAL: units are pixel columns, the filter axis runs down the rows (column pass).
 // 4 waves: wave w multiplies unit group w&1 (8 units = 32 entries) by output group w>>1
 // (32 outputs) of the step.
-template<bool VERTICAL,int NQ>
+// MODE: what the four entries of a pixel are
+//   MFMA_BLEND4  R,G,B weighted by alpha + alpha itself; the epilogue divides by the alpha sum
+//   MFMA_PLAIN4  four independent channels (RGBA without alpha weighting)
+//   MFMA_PLAIN3  three independent channels of a 6-byte pixel (RGB), the fourth entry is zero
+// In the plain modes a sample is a 16-bit integer, so hi (top 11 bits) + lo (the other 5) is exact.
+enum MfmaMode { MFMA_BLEND4=0,MFMA_PLAIN4=1,MFMA_PLAIN3=2 };
+
+struct __attribute__((packed,aligned(2))) Rgb16 { uint16_t c[3]; };
+
+template<bool VERTICAL,int NQ,int MODE>
 __global__ __launch_bounds__(256)
 void conv_mfma_kernel(ConvMfmaArgs args)
 {
+  constexpr int PX=MODE == MFMA_PLAIN3 ? 3 : 4;    // u16 per pixel in memory
   typedef MfmaGeometry<VERTICAL,NQ> G;
   constexpr int R=G::R,kStripUnits=G::UNITS,kStepOutputs=G::STEP;
   constexpr int MG=kStripUnits/8;              // unit groups; output groups = 4/MG
@@ -119,7 +129,6 @@ void conv_mfma_kernel(ConvMfmaArgs args)
   const int mg=wave % MG,ng=wave/MG;
   const int K=args.ntaps;
   const int W=args.columns,H=args.rows;
-  const int axis_length=VERTICAL ? H : W,unit_count=VERTICAL ? W : H;
 
   // ---- Toeplitz operands: T[q][i] = 256*tap[16q+8*half+i-n]; taps staged through LDS
   half8 t_hi[NQ],t_lo[NQ];
@@ -168,7 +177,14 @@ void conv_mfma_kernel(ConvMfmaArgs args)
         int y=VERTICAL ? pos+i : unit0+stage_unit;
         x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
         y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
-        buf[i]=*reinterpret_cast<const uint2 *>(args.src+((size_t) y*W+x)*4);
+        if (MODE == MFMA_PLAIN3)
+          {
+            Rgb16 p;
+            __builtin_memcpy(&p,args.src+((size_t) y*W+x)*3,sizeof(p));
+            buf[i]=make_uint2((unsigned) p.c[0] | ((unsigned) p.c[1] << 16),(unsigned) p.c[2]);
+          }
+        else
+          buf[i]=*reinterpret_cast<const uint2 *>(args.src+((size_t) y*W+x)*4);
       }
   };
   // convert raw[] and write it to ring slots slot..slot+3 (slot multiple of 4, no wrap inside)
@@ -179,12 +195,23 @@ void conv_mfma_kernel(ConvMfmaArgs args)
     for (int i=0; i < 4; i++)
       {
         const uint2 r=buf[i];
-        const float alpha=(float) (r.y >> 16)*0.5f;
-        const float weight=alpha*(1.0f/65536.0f);
-        v[0][i]=(float) (r.x & 0xffffu)*weight;
-        v[1][i]=(float) (r.x >> 16)*weight;
-        v[2][i]=(float) (r.y & 0xffffu)*weight;
-        v[3][i]=alpha;
+        if (MODE == MFMA_BLEND4)
+          {
+            const float alpha=(float) (r.y >> 16)*0.5f;
+            const float weight=alpha*(1.0f/65536.0f);
+            v[0][i]=(float) (r.x & 0xffffu)*weight;
+            v[1][i]=(float) (r.x >> 16)*weight;
+            v[2][i]=(float) (r.y & 0xffffu)*weight;
+            v[3][i]=alpha;
+          }
+        else
+          {
+            // scaled by 1/2 like the alpha entry of the blend mode: 65535 stays inside f16
+            v[0][i]=(float) (r.x & 0xffffu)*0.5f;
+            v[1][i]=(float) (r.x >> 16)*0.5f;
+            v[2][i]=(float) (r.y & 0xffffu)*0.5f;
+            v[3][i]=(float) (r.y >> 16)*0.5f;
+          }
       }
 #pragma unroll
     for (int c=0; c < 4; c++)
@@ -269,13 +296,14 @@ void conv_mfma_kernel(ConvMfmaArgs args)
               //   gamma*pixel = sum(k*alpha*p)/sum(k*alpha) = 65536 * S_c / S_a
               // v_rcp_f32(0) = inf and 0*inf = NaN convert to 0: PerceptibleReciprocal's clamp
               // for an all-transparent window (as the vector FAST epilogue)
+              // plain modes: S_c = 128 * sum k*p
               const float sa=acc[4*pg+3];
-              const float inv=__builtin_amdgcn_rcpf(sa)*65536.0f;
+              const float inv=MODE == MFMA_BLEND4 ? __builtin_amdgcn_rcpf(sa)*65536.0f : 1.0f/128.0f;
               unsigned out[4];
 #pragma unroll
               for (int c=0; c < 4; c++)
                 {
-                  const float pixel=c == 3 ? sa*(1.0f/128.0f) : acc[4*pg+c]*inv;
+                  const float pixel=(c == 3) && (MODE == MFMA_BLEND4) ? sa*(1.0f/128.0f) : acc[4*pg+c]*inv;
                   unsigned q=(unsigned) (pixel+0.5f);        // NaN and negatives -> 0
                   out[c]=q > 65535u ? 65535u : q;
                 }
@@ -284,7 +312,15 @@ void conv_mfma_kernel(ConvMfmaArgs args)
                 {
                   const int unit_out=8*mg+2*pg+half;         // D row = (reg&3)+8*(reg>>2)+4*half
                   const int pos_out=32*ng+n;
-                  *reinterpret_cast<uint2 *>(tile_out+(size_t) pos_out*G::OUT_STRIDE+unit_out*4)=result[pg];
+                  uint16_t *to=tile_out+(size_t) pos_out*G::OUT_STRIDE+unit_out*PX;
+                  if (MODE == MFMA_PLAIN3)
+                    {
+                      to[0]=(uint16_t) out[0];
+                      to[1]=(uint16_t) out[1];
+                      to[2]=(uint16_t) out[2];
+                    }
+                  else
+                    *reinterpret_cast<uint2 *>(to)=result[pg];
                 }
             }
           __syncthreads();                       // B2: this step's ring slots may be overwritten
@@ -297,7 +333,38 @@ void conv_mfma_kernel(ConvMfmaArgs args)
                 fetch(raw,unit0,in0+(out0-out_begin)+R+kStepOutputs+4*stage_group);
             }
           // ---- stores
-          if (VERTICAL)
+          if (VERTICAL && (MODE == MFMA_PLAIN3))
+            {
+              // STEP rows of UNITS*3 samples (96 bytes).  Rows start 8-byte aligned when the
+              // row pitch 6*W is a multiple of 8
+              constexpr int ROW=kStripUnits*3;
+              uint16_t *row0=args.dst+((size_t) out0*W+unit0)*3;
+              const int valid=(W-unit0)*3 < ROW ? (W-unit0)*3 : ROW;       // samples inside the image
+              if ((W & 3) == 0)
+                {
+#pragma unroll
+                  for (int round=0; round < (kStepOutputs*ROW/4)/256; round++)
+                    {
+                      const int u=tid+256*round;
+                      const int row=u/(ROW/4),e=4*(u % (ROW/4));
+                      if ((out0+row < H) && (e < valid))        // valid is a multiple of 4 here
+                        *reinterpret_cast<uint2 *>(row0+(size_t) row*W*3+e)=
+                          *reinterpret_cast<const uint2 *>(tile_out+(size_t) row*G::OUT_STRIDE+e);
+                    }
+                }
+              else
+                {
+#pragma unroll 4
+                  for (int round=0; round < (kStepOutputs*ROW)/256; round++)
+                    {
+                      const int u=tid+256*round;
+                      const int row=u/ROW,e=u % ROW;
+                      if ((out0+row < H) && (e < valid))
+                        row0[(size_t) row*W*3+e]=tile_out[(size_t) row*G::OUT_STRIDE+e];
+                    }
+                }
+            }
+          else if (VERTICAL)
             {
               // coalesced copy-out: STEP rows of UNITS pixels, 16 bytes (2 pixels) per thread
 #pragma unroll
@@ -324,7 +391,18 @@ void conv_mfma_kernel(ConvMfmaArgs args)
                 {
                   const int x=out0+32*ng+n,y=unit0+8*mg+2*pg+half;
                   if ((x < W) && (y < H))
-                    *reinterpret_cast<uint2 *>(args.dst+((size_t) y*W+x)*4)=result[pg];
+                    {
+                      if (MODE == MFMA_PLAIN3)
+                        {
+                          Rgb16 p;
+                          p.c[0]=(uint16_t) (result[pg].x & 0xffffu);
+                          p.c[1]=(uint16_t) (result[pg].x >> 16);
+                          p.c[2]=(uint16_t) (result[pg].y & 0xffffu);
+                          __builtin_memcpy(args.dst+((size_t) y*W+x)*3,&p,sizeof(p));
+                        }
+                      else
+                        *reinterpret_cast<uint2 *>(args.dst+((size_t) y*W+x)*4)=result[pg];
+                    }
                 }
             }
           base+=kStepOutputs;
@@ -332,11 +410,9 @@ void conv_mfma_kernel(ConvMfmaArgs args)
           __syncthreads();                       // next step's samples are in the ring; tile_out is free
         }
     }
-  (void) axis_length;
-  (void) unit_count;
 }
 
-template<bool VERTICAL,int NQ>
+template<bool VERTICAL,int NQ,int MODE>
 static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
 {
   typedef MfmaGeometry<VERTICAL,NQ> G;
@@ -370,10 +446,10 @@ static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
     }
   args.segments=segments;
   args.steps_per_segment=(args.steps+segments-1)/segments;
-  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<VERTICAL,NQ>),
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<VERTICAL,NQ,MODE>),
     hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
   ProfileScope prof(VERTICAL ? "conv_column" : "conv_row",src.stream);
-  hipLaunchKernelGGL((conv_mfma_kernel<VERTICAL,NQ>),dim3((unsigned) nblocks),dim3(256),lds,
+  hipLaunchKernelGGL((conv_mfma_kernel<VERTICAL,NQ,MODE>),dim3((unsigned) nblocks),dim3(256),lds,
     src.stream,args);
   MH_HIP(hipGetLastError());
   return MH_OK;
@@ -381,11 +457,14 @@ static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
 
 // *handled = false: shape outside this kernel's reach, nothing launched
 MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const float *taps_device,
-  int ntaps,int shift,bool *handled)
+  int ntaps,int shift,bool blend,bool *handled)
 {
   *handled=false;
-  if ((src.quantum != MH_QUANTUM_U16) || (src.channels != 4) || (ntaps < 2))
+  if ((src.quantum != MH_QUANTUM_U16) || (ntaps < 2))
     return MH_OK;
+  if ((src.channels != 4) && ((src.channels != 3) || blend))
+    return MH_OK;
+  const int mode=blend ? MFMA_BLEND4 : (src.channels == 4 ? MFMA_PLAIN4 : MFMA_PLAIN3);
   const int nq=(ntaps+31+15)/16;                 // 32 outputs + K-1 halo, in 16-sample chunks
   if (nq > 9)
     return MH_OK;
@@ -399,14 +478,22 @@ MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const 
   args.taps=taps_device;
   *handled=true;
 #define MH_NQ(NQV) \
-  case NQV: return vertical ? launch_mfma_typed<true,NQV>(src,args) : launch_mfma_typed<false,NQV>(src,args);
-  switch (nq)
+  case NQV: \
+    if (mode == MFMA_BLEND4) \
+      return vertical ? launch_mfma_typed<true,NQV,MFMA_BLEND4>(src,args) : \
+        launch_mfma_typed<false,NQV,MFMA_BLEND4>(src,args); \
+    if (mode == MFMA_PLAIN4) \
+      return vertical ? launch_mfma_typed<true,NQV,MFMA_PLAIN4>(src,args) : \
+        launch_mfma_typed<false,NQV,MFMA_PLAIN4>(src,args); \
+    return vertical ? launch_mfma_typed<true,NQV,MFMA_PLAIN3>(src,args) : \
+      launch_mfma_typed<false,NQV,MFMA_PLAIN3>(src,args);
+  switch (nq < 3 ? 3 : nq)
   {
     MH_NQ(3) MH_NQ(4) MH_NQ(5) MH_NQ(6) MH_NQ(7) MH_NQ(8) MH_NQ(9)
     default: break;
   }
 #undef MH_NQ
-  return vertical ? launch_mfma_typed<true,3>(src,args) : launch_mfma_typed<false,3>(src,args);
+  return fail(MH_UNSUPPORTED,"conv1d (matrix cores): kernel length outside the dispatch table");
 }
 
 } // namespace mh

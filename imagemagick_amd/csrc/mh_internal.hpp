@@ -146,7 +146,7 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
 // FAST Q16 RGBA blend pass on the f16 matrix cores (convolve_mfma.hip); *handled=false when
 // the shape is outside its reach and nothing was launched
 MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const float *taps_device,
-  int ntaps,int shift,bool *handled);
+  int ntaps,int shift,bool blend,bool *handled);
 
 struct Morph2DParams
 {

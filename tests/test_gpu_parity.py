@@ -74,6 +74,60 @@ def test_blur_fast_odd_shapes(im, refmod, shape, sigma):
     assert_parity(got, ref.blur(0.0, sigma).numpy(), False, "fast blur %s sigma %g" % (shape, sigma))
 
 
+@pytest.mark.parametrize("shape", [(5, 7), (1, 40), (40, 1), (33, 70), (64, 16), (17, 129), (130, 31),
+                                   (70, 66), (67, 132)])
+@pytest.mark.parametrize("sigma", [0.8, 2.0, 6.5])
+def test_blur_fast_rgb_without_alpha(im, refmod, shape, sigma):
+    """FAST blur of a 3-channel (6-byte pixel) image: the matrix-core passes in their plain
+    mode, with row pitches that are and are not multiples of 8 bytes."""
+    px = make_pixels(shape[0], shape[1], 3, Q16, seed=shape[0] * 17 + shape[1])
+    dev, ref = run_pair(im, refmod, px)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got = im.blur_image(dev, 0.0, sigma).numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert_parity(got, ref.blur(0.0, sigma).numpy(), False, "fast RGB blur %s sigma %g" % (shape, sigma))
+
+
+@pytest.mark.parametrize("shape", [(33, 70), (17, 129), (130, 31)])
+@pytest.mark.parametrize("sigma", [1.5, 6.5])
+def test_blur_fast_four_plain_channels(im, refmod, shape, sigma):
+    """Four channels without an alpha trait (CMYK's layout): every channel is convolved on its
+    own, so the result must match the reference's RGB blur of the first three channels and its
+    gray blur of the fourth."""
+    px = make_pixels(shape[0], shape[1], 4, Q16, seed=shape[1])
+    px[::7, ::5, 3] = 0
+    want = np.concatenate([refmod.RefImage(px[:, :, :3].copy()).blur(0.0, sigma).numpy(),
+                           refmod.RefImage(px[:, :, 3].copy()).blur(0.0, sigma).numpy().reshape(shape + (1,))],
+                          axis=2)
+    dev = im.Image(to_device(px), has_alpha=False)
+    assert_parity(im.blur_image(dev, 0.0, sigma).numpy(), want, True, "plain 4-channel blur")
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got = im.blur_image(dev, 0.0, sigma).numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert_parity(got, want, False, "fast plain 4-channel blur")
+
+
+def test_convolve_fast_signed_separable_kernel_plain_channels(im):
+    """A separable kernel with negative taps through the plain matrix-core mode: FAST within
+    +-1 level of EXACT, clamping at both ends of the range included."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(5)
+    a = torch.randint(-32768, 32768, (301, 260, 3), generator=g, device="cuda", dtype=torch.int16)
+    img = im.Image(a.view(torch.uint16))
+    kernel = "9x1: -0.05,-0.1,0.15,0.25,0.5,0.25,0.15,-0.1,-0.05"
+    exact = im.convolve_image(img, kernel).pixels.view(torch.int16).to(torch.int32) & 0xffff
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        fast = im.convolve_image(img, kernel).pixels.view(torch.int16).to(torch.int32) & 0xffff
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert int((fast - exact).abs().max()) <= 1
+
+
 def test_blur_fast_matrix_and_vector_paths_agree_within_one_level(im, refmod):
     """MAGICKHIP_NO_MFMA=1 selects the f32 vector kernels: both FAST implementations honour the
     same +-1 contract against the reference (they need not agree with each other exactly)."""
