@@ -10,7 +10,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmagickhip.so")
+# MAGICKHIP_LIBRARY: load another build of the library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("MAGICKHIP_LIBRARY") or os.path.join(_HERE, "lib", "libmagickhip.so")
 
 MH_MAX_CHANNELS = 4
 MH_OK = 0

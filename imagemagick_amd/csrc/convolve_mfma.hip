@@ -99,6 +99,30 @@ static __device__ __forceinline__ void split_f16(float v,_Float16 &hi,_Float16 &
   lo=(_Float16) (v-top);
 }
 
+// y*W+x for rows and columns below 2^24 and fewer than 2^32 pixels (launch_conv1d_mfma checks):
+// one full-rate v_mad_u32_u24 instead of a 64-bit multiply
+static __device__ __forceinline__ size_t pixel_index(int y,int W,int x)
+{
+  return (size_t) (__umul24((unsigned) y,(unsigned) W)+(unsigned) x);
+}
+
+// The same split for two non-negative values at once, packed for the LDS planes.
+// v_cvt_pkrtz_f16_f32 truncates (for v >= 0 that is the mantissa mask above) and packs both hi
+// halves; v_fma_mix_f32 reads an f16 half as an operand, so lo = v - hi is one instruction.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ void split_f16_pair(f32x2 v,unsigned &hi,unsigned &lo)
+{
+  hi=__builtin_bit_cast(unsigned,__builtin_amdgcn_cvt_pkrtz(v[0],v[1]));
+  float l0,l1;
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi),"v"(v[0]));
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi),"v"(v[1]));
+  typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+  half2v l;
+  l[0]=(_Float16) l0;
+  l[1]=(_Float16) l1;
+  lo=__builtin_bit_cast(unsigned,l);
+}
+
 // VERTICAL: units are pixel columns, the filter axis runs down the rows (column pass).
 // 4 waves: wave w multiplies unit group w&1 (8 units = 32 entries) by output group w>>1
 // (32 outputs) of the step.
@@ -110,6 +134,7 @@ static __device__ __forceinline__ void split_f16(float v,_Float16 &hi,_Float16 &
 enum MfmaMode { MFMA_BLEND4=0,MFMA_PLAIN4=1,MFMA_PLAIN3=2 };
 
 struct __attribute__((packed,aligned(2))) Rgb16 { uint16_t c[3]; };
+typedef unsigned short pknorm2 __attribute__((ext_vector_type(2)));
 
 template<bool VERTICAL,int NQ,int MODE>
 __global__ __launch_bounds__(256)
@@ -177,57 +202,57 @@ void conv_mfma_kernel(ConvMfmaArgs args)
         int y=VERTICAL ? pos+i : unit0+stage_unit;
         x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
         y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
+        const size_t at=pixel_index(y,W,x);
         if (MODE == MFMA_PLAIN3)
           {
             Rgb16 p;
-            __builtin_memcpy(&p,args.src+((size_t) y*W+x)*3,sizeof(p));
+            __builtin_memcpy(&p,args.src+at*3,sizeof(p));
             buf[i]=make_uint2((unsigned) p.c[0] | ((unsigned) p.c[1] << 16),(unsigned) p.c[2]);
           }
         else
-          buf[i]=*reinterpret_cast<const uint2 *>(args.src+((size_t) y*W+x)*4);
+          buf[i]=*reinterpret_cast<const uint2 *>(args.src+at*4);
       }
   };
-  // convert raw[] and write it to ring slots slot..slot+3 (slot multiple of 4, no wrap inside)
+  // convert raw[] and write it to ring slots slot..slot+3 (slot multiple of 4, no wrap inside).
+  // Values are handled as pairs of neighbouring positions: packed f32 multiplies, one
+  // v_cvt_pkrtz_f16_f32 per pair for the hi halves and one v_cvt_pk_f16_f32 for the lo halves.
   auto stage=[&](const uint2 (&buf)[4],int slot)
   {
-    float v[4][4];
+    f32x2 v[4][2];
 #pragma unroll
-    for (int i=0; i < 4; i++)
+    for (int j=0; j < 2; j++)
       {
-        const uint2 r=buf[i];
+        const uint2 r0=buf[2*j],r1=buf[2*j+1];
+        const f32x2 c0={(float) (r0.x & 0xffffu),(float) (r1.x & 0xffffu)};
+        const f32x2 c1={(float) (r0.x >> 16),(float) (r1.x >> 16)};
+        const f32x2 c2={(float) (r0.y & 0xffffu),(float) (r1.y & 0xffffu)};
+        const f32x2 c3={(float) (r0.y >> 16),(float) (r1.y >> 16)};
         if (MODE == MFMA_BLEND4)
           {
-            const float alpha=(float) (r.y >> 16)*0.5f;
-            const float weight=alpha*(1.0f/65536.0f);
-            v[0][i]=(float) (r.x & 0xffffu)*weight;
-            v[1][i]=(float) (r.x >> 16)*weight;
-            v[2][i]=(float) (r.y & 0xffffu)*weight;
-            v[3][i]=alpha;
+            const f32x2 weight=c3*(0.5f/65536.0f);
+            v[0][j]=c0*weight;
+            v[1][j]=c1*weight;
+            v[2][j]=c2*weight;
+            v[3][j]=c3*0.5f;
           }
         else
           {
             // scaled by 1/2 like the alpha entry of the blend mode: 65535 stays inside f16
-            v[0][i]=(float) (r.x & 0xffffu)*0.5f;
-            v[1][i]=(float) (r.x >> 16)*0.5f;
-            v[2][i]=(float) (r.y & 0xffffu)*0.5f;
-            v[3][i]=(float) (r.y >> 16)*0.5f;
+            v[0][j]=c0*0.5f;
+            v[1][j]=c1*0.5f;
+            v[2][j]=c2*0.5f;
+            v[3][j]=c3*0.5f;
           }
       }
 #pragma unroll
     for (int c=0; c < 4; c++)
       {
-        half4 hi,lo;
-#pragma unroll
-        for (int i=0; i < 4; i++)
-          {
-            _Float16 h,l;
-            split_f16(v[c][i],h,l);
-            hi[i]=h;
-            lo[i]=l;
-          }
+        uint2 hi,lo;
+        split_f16_pair(v[c][0],hi.x,lo.x);
+        split_f16_pair(v[c][1],hi.y,lo.y);
         const int at=c*G::CH+stage_unit*G::S+slot;
-        *reinterpret_cast<half4 *>(plane_hi+at)=hi;
-        *reinterpret_cast<half4 *>(plane_lo+at)=lo;
+        *reinterpret_cast<uint2 *>(plane_hi+at)=hi;
+        *reinterpret_cast<uint2 *>(plane_lo+at)=lo;
       }
   };
 
@@ -297,17 +322,18 @@ void conv_mfma_kernel(ConvMfmaArgs args)
               // v_rcp_f32(0) = inf and 0*inf = NaN convert to 0: PerceptibleReciprocal's clamp
               // for an all-transparent window (as the vector FAST epilogue)
               // plain modes: S_c = 128 * sum k*p
+              // v_cvt_pknorm_u16_f32 rounds 65535*x to the nearest level, clamps to [0,65535],
+              // maps NaN to 0 and packs two results: the whole quantisation in one instruction
               const float sa=acc[4*pg+3];
-              const float inv=MODE == MFMA_BLEND4 ? __builtin_amdgcn_rcpf(sa)*65536.0f : 1.0f/128.0f;
-              unsigned out[4];
-#pragma unroll
-              for (int c=0; c < 4; c++)
-                {
-                  const float pixel=(c == 3) && (MODE == MFMA_BLEND4) ? sa*(1.0f/128.0f) : acc[4*pg+c]*inv;
-                  unsigned q=(unsigned) (pixel+0.5f);        // NaN and negatives -> 0
-                  out[c]=q > 65535u ? 65535u : q;
-                }
-              result[pg]=make_uint2(out[0] | (out[1] << 16),out[2] | (out[3] << 16));
+              constexpr float unit=1.0f/(128.0f*65535.0f);
+              const float inv=MODE == MFMA_BLEND4 ? __builtin_amdgcn_rcpf(sa)*(65536.0f/65535.0f) : unit;
+              const f32x2 scale01={inv,inv};
+              const f32x2 scale23={inv,MODE == MFMA_BLEND4 ? unit : inv};
+              const f32x2 p01=f32x2{acc[4*pg+0],acc[4*pg+1]}*scale01;
+              const f32x2 p23=f32x2{acc[4*pg+2],sa}*scale23;
+              const pknorm2 lo2=__builtin_amdgcn_cvt_pknorm_u16(p01[0],p01[1]);
+              const pknorm2 hi2=__builtin_amdgcn_cvt_pknorm_u16(p23[0],p23[1]);
+              result[pg]=make_uint2(__builtin_bit_cast(unsigned,lo2),__builtin_bit_cast(unsigned,hi2));
               if (VERTICAL)
                 {
                   const int unit_out=8*mg+2*pg+half;         // D row = (reg&3)+8*(reg>>2)+4*half
@@ -315,9 +341,9 @@ void conv_mfma_kernel(ConvMfmaArgs args)
                   uint16_t *to=tile_out+(size_t) pos_out*G::OUT_STRIDE+unit_out*PX;
                   if (MODE == MFMA_PLAIN3)
                     {
-                      to[0]=(uint16_t) out[0];
-                      to[1]=(uint16_t) out[1];
-                      to[2]=(uint16_t) out[2];
+                      to[0]=(uint16_t) (result[pg].x & 0xffffu);
+                      to[1]=(uint16_t) (result[pg].x >> 16);
+                      to[2]=(uint16_t) (result[pg].y & 0xffffu);
                     }
                   else
                     *reinterpret_cast<uint2 *>(to)=result[pg];
@@ -338,7 +364,7 @@ void conv_mfma_kernel(ConvMfmaArgs args)
               // STEP rows of UNITS*3 samples (96 bytes).  Rows start 8-byte aligned when the
               // row pitch 6*W is a multiple of 8
               constexpr int ROW=kStripUnits*3;
-              uint16_t *row0=args.dst+((size_t) out0*W+unit0)*3;
+              uint16_t *row0=args.dst+pixel_index(out0,W,unit0)*3;
               const int valid=(W-unit0)*3 < ROW ? (W-unit0)*3 : ROW;       // samples inside the image
               if ((W & 3) == 0)
                 {
@@ -348,7 +374,7 @@ void conv_mfma_kernel(ConvMfmaArgs args)
                       const int u=tid+256*round;
                       const int row=u/(ROW/4),e=4*(u % (ROW/4));
                       if ((out0+row < H) && (e < valid))        // valid is a multiple of 4 here
-                        *reinterpret_cast<uint2 *>(row0+(size_t) row*W*3+e)=
+                        *reinterpret_cast<uint2 *>(row0+pixel_index(row,W,0)*3+e)=
                           *reinterpret_cast<const uint2 *>(tile_out+(size_t) row*G::OUT_STRIDE+e);
                     }
                 }
@@ -360,7 +386,7 @@ void conv_mfma_kernel(ConvMfmaArgs args)
                       const int u=tid+256*round;
                       const int row=u/ROW,e=u % ROW;
                       if ((out0+row < H) && (e < valid))
-                        row0[(size_t) row*W*3+e]=tile_out[(size_t) row*G::OUT_STRIDE+e];
+                        row0[pixel_index(row,W,0)*3+e]=tile_out[(size_t) row*G::OUT_STRIDE+e];
                     }
                 }
             }
@@ -374,7 +400,7 @@ void conv_mfma_kernel(ConvMfmaArgs args)
                   const int row=u/(kStripUnits/2),pair=u % (kStripUnits/2);
                   const int x=unit0+2*pair,y=out0+row;
                   const uint16_t *from=tile_out+(size_t) row*G::OUT_STRIDE+2*pair*4;
-                  uint16_t *to=args.dst+((size_t) y*W+x)*4;
+                  uint16_t *to=args.dst+pixel_index(y,W,x)*4;
                   if (y < H)
                     {
                       if (x+1 < W)
@@ -398,10 +424,10 @@ void conv_mfma_kernel(ConvMfmaArgs args)
                           p.c[0]=(uint16_t) (result[pg].x & 0xffffu);
                           p.c[1]=(uint16_t) (result[pg].x >> 16);
                           p.c[2]=(uint16_t) (result[pg].y & 0xffffu);
-                          __builtin_memcpy(args.dst+((size_t) y*W+x)*3,&p,sizeof(p));
+                          __builtin_memcpy(args.dst+pixel_index(y,W,x)*3,&p,sizeof(p));
                         }
                       else
-                        *reinterpret_cast<uint2 *>(args.dst+((size_t) y*W+x)*4)=result[pg];
+                        *reinterpret_cast<uint2 *>(args.dst+pixel_index(y,W,x)*4)=result[pg];
                     }
                 }
             }
@@ -464,6 +490,9 @@ MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const 
     return MH_OK;
   if ((src.channels != 4) && ((src.channels != 3) || blend))
     return MH_OK;
+  if ((src.columns >= (1u << 24)) || (src.rows >= (1u << 24)) ||
+      ((unsigned long long) src.columns*src.rows >= (1ull << 32)))
+    return MH_OK;                                // pixel_index()
   const int mode=blend ? MFMA_BLEND4 : (src.channels == 4 ? MFMA_PLAIN4 : MFMA_PLAIN3);
   const int nq=(ntaps+31+15)/16;                 // 32 outputs + K-1 halo, in 16-sample chunks
   if (nq > 9)
