@@ -284,6 +284,20 @@ def extra_measurements(im, torch, args):
         im.set_precision(im.PRECISION_FAST if args.precision == "fast" else im.PRECISION_EXACT)
         del src, image
         torch.cuda.empty_cache()
+        # The kernels' speed depends on the data (the same instruction stream runs ~20 % faster on
+        # an all-zero frame: clocks, i.e. power): the headline uses uniform noise, the worst case;
+        # a smooth frame (low-frequency waves + 1 % noise, varying alpha) is closer to a photograph
+        yy, xx = torch.meshgrid(torch.arange(n, device="cuda", dtype=torch.float32),
+                                torch.arange(n, device="cuda", dtype=torch.float32), indexing="ij")
+        smooth = torch.stack([torch.sin(xx * 0.003 + c) * torch.cos(yy * 0.002 - c) for c in range(4)], dim=2)
+        smooth = (smooth * 0.45 + 0.5) * 65535.0 + torch.randn((n, n, 4), generator=gen, device="cuda") * 600.0
+        smooth = smooth.clamp_(0, 65535).to(torch.int32).to(torch.int16).view(torch.uint16).contiguous()
+        del yy, xx
+        image = im.Image(smooth)
+        sec = timed(torch, lambda: im.blur_image(image, 0.0, args.sigma), 5)
+        extra["blur_smooth_frame_Mpixels_per_s"] = round(n * n / sec / 1e6, 1)
+        del smooth, image
+        torch.cuda.empty_cache()
         # C3: 8192^2 -> 32768^2 Lanczos, float Quantum (17.2 GB result)
         m = 8192
         srcf = torch.rand((m, m, 4), generator=gen, device="cuda", dtype=torch.float32) * 65535.0
