@@ -93,6 +93,7 @@ private:
   int mode_=0;
   bool staged_=false;
   bool registered_=false;
+  bool pipelined_=false;
   Temp temp_;
 };
 
