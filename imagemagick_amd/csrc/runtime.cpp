@@ -714,17 +714,20 @@ MH_API MhStatus MhDeviceFree(int device,void *ptr)
 
 MH_API MhStatus MhUpload(int device,void *dst,const void *src,size_t bytes,void *stream)
 {
-  (void) device;
   MH_TRY(runtime_ready());
+  if ((bytes >= 2*kPiece) && (device >= 0) && (device < device_count()))
+    return transfer_image(device,(hipStream_t) stream,dst,const_cast<void *>(src),bytes,true);
   MH_HIP(hipMemcpyAsync(dst,src,bytes,hipMemcpyHostToDevice,(hipStream_t) stream));
   return MH_OK;
 }
 
 MH_API MhStatus MhDownload(int device,void *dst,const void *src,size_t bytes,void *stream)
 {
-  (void) device;
   MH_TRY(runtime_ready());
-  MH_HIP(hipMemcpyAsync(dst,src,bytes,hipMemcpyDeviceToHost,(hipStream_t) stream));
+  if ((bytes >= 2*kPiece) && (device >= 0) && (device < device_count()))
+    MH_TRY(transfer_image(device,(hipStream_t) stream,const_cast<void *>(src),dst,bytes,false));
+  else
+    MH_HIP(hipMemcpyAsync(dst,src,bytes,hipMemcpyDeviceToHost,(hipStream_t) stream));
   MH_HIP(hipStreamSynchronize((hipStream_t) stream));
   return MH_OK;
 }

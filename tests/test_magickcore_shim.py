@@ -49,6 +49,19 @@ def test_blur_resize_equalize_through_magickcore(shim, dtype):
     assert accelerated_calls(shim, hdri) == before + 4
 
 
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_large_frame_moves_through_the_staged_transfers(shim, dtype):
+    """A frame of several 4 MiB pieces (1100x1300 RGBA: 11 MB as Q16, 23 MB as float) goes up
+    and comes down through MhUpload / MhDownload's threaded staging; ragged last piece included."""
+    hdri = dtype == np.float32
+    px = make_pixels(1100, 1301, 4, dtype, seed=3)
+    before = accelerated_calls(shim, hdri)
+    gpu = shim.RefImage(px, shim=True)
+    cpu = shim.RefImage(px)
+    assert_parity(gpu.blur(0.0, 1.5).numpy(), cpu.blur(0.0, 1.5).numpy(), True, "BlurImage, large frame")
+    assert accelerated_calls(shim, hdri) == before + 1
+
+
 def test_gate_falls_back_to_cpu(shim):
     """An image the gate rejects (a colourspace the backend does not take) silently runs the
     CPU path — the reference's NULL-return convention."""
