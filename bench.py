@@ -39,6 +39,9 @@ def parse_args():
                          "order, bit-identical")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (resize) measurements")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo rehearses the N>1 control "
+                         "flow on a box with fewer GPUs than ranks: ranks then share devices)")
     return ap.parse_args()
 
 
@@ -136,10 +139,15 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    if args.backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     import imagemagick_amd as im
     im.load()
