@@ -441,9 +441,11 @@ MhStatus transfer_image(int device,hipStream_t stream,void *dev,void *host,size_
     workers,upload);
   for (std::thread &t : pool)
     t.join();
-  for (MhStatus st : status)
-    if (st != MH_OK)
-      return st;
+  // error text is per thread: restate a worker's failure for the caller's thread
+  for (size_t t=0; t < workers; t++)
+    if (status[t] != MH_OK)
+      return t == 0 ? status[t] : fail(status[t],"host transfer: a staging thread failed (%s)",
+        upload ? "upload" : "download");
   return MH_OK;
 }
 
