@@ -169,7 +169,11 @@ typedef enum
 MH_API MhPrecision MhGetPrecision(void);
 MH_API MhPrecision MhSetPrecision(MhPrecision precision);
 
-/* Device memory helpers for callers that keep images resident. */
+/* Device memory helpers for callers that keep images resident.  MhUpload returns once the
+   transfer is enqueued on `stream` and `src_host` may be reused; MhDownload returns once
+   `dst_host` holds the data.  Pageable host blocks of 8 MiB and more move through page-locked
+   staging buffers on a few host threads (replaces opencl.c's clEnqueueMapBuffer round trips,
+   MagickCore/cache.c:5341-5353). */
 MH_API MhStatus MhDeviceAlloc(int device,size_t bytes,void **ptr);
 MH_API MhStatus MhDeviceFree(int device,void *ptr);
 MH_API MhStatus MhUpload(int device,void *dst_device,const void *src_host,size_t bytes,void *stream);
