@@ -292,7 +292,12 @@ def extra_measurements(im, torch, args):
         extra["blur_%s_Mpixels_per_s" % ("exact" if args.precision == "fast" else "fast")] = \
             round(n * n / sec / 1e6, 1)
         im.set_precision(im.PRECISION_FAST if args.precision == "fast" else im.PRECISION_EXACT)
-        del src, image
+        # reference point for the roofline: what a plain device copy of the same frame reaches
+        # (read 537 MB + write 537 MB, torch's copy kernel)
+        mirror = torch.empty_like(src)
+        sec = timed(torch, lambda: mirror.copy_(src), 10)
+        extra["device_copy_GBps"] = round(2.0 * src.numel() * 2 / sec / 1e9, 1)
+        del mirror, src, image
         torch.cuda.empty_cache()
         # The kernels' speed depends on the data (the same instruction stream runs ~20 % faster on
         # an all-zero frame: clocks, i.e. power): the headline uses uniform noise, the worst case;

@@ -64,20 +64,50 @@ template<bool VERTICAL> struct StripShape
 };
 
 // LDS: two planes (hi, lo) of f16, plane[channel][unit 0..15][ring slot 0..R), the filter
-// axis contiguous.  Bank rules (MI355X_MICROARCH.md, LDS): ds_read_b128 is served in four
-// 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... over 64 banks, i.e. each group
-// (4 units x 4 channels of operand lines) must hit 16 different 16-byte slots of a 256-byte
-// bank row.  With the line stride S = 32 mod 128 halves (64 bytes mod 256) the units
-// {0,3,5,6} / {1,2,4,7} of a group land 0/64/128/192 bytes apart, and the channel stride
-// 16*S+8 halves (16 bytes mod 256) fills the slots in between: conflict-free.  (S = R+8
-// measured 77 % of all LDS cycles as bank conflicts, 0.41 ms per pass.)
+// axis contiguous: line stride S halves, channel stride CH = 16*S+PAD halves.  Bank rules
+// (MI355X_MICROARCH.md, LDS):
+//  * ds_read_b128 (the operand lines) is served in four 16-lane groups {0-3,12-15,20-27},
+//    {4-11,16-19,28-31}, ... over 64 banks: the 4 units x 4 channels of a group must hit 16
+//    different 16-byte slots of a 256-byte bank row (reads_conflict_free below checks a
+//    candidate at compile time).  (S = R+8 with PAD = 8 measured 77 % of all LDS cycles as
+//    bank conflicts, 0.41 ms per pass.)
+//  * ds_write_b64 (staging) is served in contiguous 16-lane groups over 32 banks.  The row
+//    pass writes 128 contiguous bytes per group whatever S is; the column pass writes 2 units
+//    x 64 bytes, conflict-free when the line stride is 64 bytes mod 128.
+// Row pass: the smallest conflict-free-read layout — S = R, PAD = 8 when R = 32 mod 64,
+// else S = R+8, PAD = 32.  Column pass: the smallest S >= R that is 32 mod 64 halves, PAD = 8
+// (conflict-free reads and writes).  A smaller ring means more workgroups per CU: 24 KB for
+// up to 33 taps, 39 KB (row) for the 79 taps of sigma = 10.
+static constexpr bool reads_conflict_free(int S,int PAD)
+{
+  const int group[2][4]={{0,3,5,6},{1,2,4,7}};
+  const int CH=16*S+PAD;
+  for (int mg=0; mg < 2; mg++)
+    for (int g=0; g < 2; g++)
+      {
+        unsigned seen=0;
+        for (int i=0; i < 4; i++)
+          for (int c=0; c < 4; c++)
+            {
+              const int bytes=(c*CH+(8*mg+group[g][i])*S)*2;
+              const unsigned slot=1u << ((bytes % 256)/16);
+              if ((seen & slot) != 0)
+                return false;
+              seen|=slot;
+            }
+      }
+  return true;
+}
+
 template<bool VERTICAL,int NQ>
 struct MfmaGeometry
 {
   static constexpr int UNITS=StripShape<VERTICAL>::UNITS,STEP=StripShape<VERTICAL>::STEP;
   static constexpr int R=16*NQ+STEP-32;        // ring positions: STEP outputs + K-1 halo, 16-aligned
-  static constexpr int S=((R-32+127)/128)*128+32;     // >= R, = 32 mod 128
-  static constexpr int CH=UNITS*S+8;           // halves per channel
+  static constexpr int S=VERTICAL ? ((R-32+63)/64)*64+32 : (R % 64 == 32 ? R : R+8);
+  static constexpr int PAD=VERTICAL || (R % 64 == 32) ? 8 : 32;
+  static_assert((S >= R) && (S % 8 == 0) && reads_conflict_free(S,PAD),"ring layout with LDS bank conflicts");
+  static constexpr int CH=UNITS*S+PAD;         // halves per channel
   static constexpr int PLANE=4*CH;             // halves per plane
   static constexpr int OUT_STRIDE=(UNITS+2)*4; // u16 per output row: 144 bytes, 16-byte aligned,
                                                // 16 rows spread over 8 bank groups instead of 1
@@ -448,10 +478,24 @@ static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
   args.strips=(units+kStripUnits-1)/kStripUnits;
   args.steps=(axis+kStepOutputs-1)/kStepOutputs;
   const size_t lds=G::ring_bytes+(VERTICAL ? G::out_bytes : 0);
-  int per_cu=(int) ((160u*1024u)/lds);
-  per_cu=per_cu > 3 ? 3 : (per_cu < 1 ? 1 : per_cu);       // 3 measured best (4 does not fit the LDS)
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<VERTICAL,NQ,MODE>),
+    hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+  // The grid is persistent (every workgroup walks its share of the items), so it must not
+  // exceed what is resident at once: LDS and registers decide, asked once per instantiation
+  static int resident=0;
+  if (resident == 0)
+    {
+      int n=0;
+      MH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n,
+        reinterpret_cast<const void *>(&conv_mfma_kernel<VERTICAL,NQ,MODE>),256,lds));
+      resident=n < 1 ? 1 : n;
+    }
+  // three per CU even where four fit (row pass up to 79 taps, both passes up to 33): measured
+  // 0.515 / 0.559 ms (3 / 4 per CU, sigma 4) and 0.538 / 0.543 ms (sigma 10) — the passes run
+  // against the power limit, more waves in flight only lower the clock
+  int per_cu=resident > 3 ? 3 : resident;
   if (const char *e=getenv("MAGICKHIP_MFMA_PER_CU"))
-    per_cu=atoi(e);
+    per_cu=atoi(e) < 1 ? 1 : (atoi(e) < per_cu ? atoi(e) : per_cu);
   const int nblocks=compute_units(src.device)*per_cu;
   // Cut the strips into segments so that the work items divide evenly among the resident
   // workgroups.  A segment re-stages R-64 positions, so it stays at least 8 steps long.
@@ -472,8 +516,6 @@ static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
     }
   args.segments=segments;
   args.steps_per_segment=(args.steps+segments-1)/segments;
-  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<VERTICAL,NQ,MODE>),
-    hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
   ProfileScope prof(VERTICAL ? "conv_column" : "conv_row",src.stream);
   hipLaunchKernelGGL((conv_mfma_kernel<VERTICAL,NQ,MODE>),dim3((unsigned) nblocks),dim3(256),lds,
     src.stream,args);

@@ -128,6 +128,21 @@ def test_convolve_fast_signed_separable_kernel_plain_channels(im):
     assert int((fast - exact).abs().max()) <= 1
 
 
+@pytest.mark.parametrize("channels", [4, 3])
+@pytest.mark.parametrize("sigma", [3.2, 5.0, 8.0, 11.0, 14.0])
+def test_blur_fast_every_ring_size(im, refmod, channels, sigma):
+    """One sigma per ring geometry of the matrix-core kernel not covered above (tap counts 27,
+    41, 65, 87 and 111: 5 to 9 sixteen-sample chunks, each with its own LDS layout)."""
+    px = make_pixels(150, 140, channels, Q16, seed=int(sigma * 10))
+    dev, ref = run_pair(im, refmod, px)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got = im.blur_image(dev, 0.0, sigma).numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert_parity(got, ref.blur(0.0, sigma).numpy(), False, "fast blur sigma %g, %d channels" % (sigma, channels))
+
+
 def test_blur_fast_matrix_and_vector_paths_agree_within_one_level(im, refmod):
     """MAGICKHIP_NO_MFMA=1 selects the f32 vector kernels: both FAST implementations honour the
     same +-1 contract against the reference (they need not agree with each other exactly)."""
