@@ -35,7 +35,10 @@
 // work on halos and measured 0.53 ms per pass), multiplies, and leaves.
 #include "mh_internal.hpp"
 #include "device_common.hpp"
+#include <cstdio>
 #include <cstdlib>
+#include <string>
+#include <vector>
 
 namespace mh {
 
@@ -47,6 +50,7 @@ struct ConvMfmaArgs
 {
   const uint16_t *src;
   uint16_t *dst;
+  unsigned long long *trace;   // diagnostic builds only
   int columns,rows;
   int ntaps;
   int shift;                 // K-1-origin: offset of the first input sample
@@ -56,7 +60,8 @@ struct ConvMfmaArgs
 
 // Strip shape, both passes: 16 units x 64 outputs per step; 4 waves = 2 unit groups x 2
 // output groups.  (32 columns x 32 outputs was tried for the column pass to get 256-byte row
-// segments: no faster, and its ring cannot take the conflict-free line stride below.)
+// segments, and 8 rows x 128 outputs for the row pass to get 1 KB row segments and a 28 KB
+// ring: neither is faster.)
 template<bool VERTICAL> struct StripShape
 {
   static constexpr int UNITS=16;
@@ -162,6 +167,22 @@ static __device__ __forceinline__ void split_f16_pair(f32x2 v,unsigned &hi,unsig
 //   MFMA_PLAIN3  three independent channels of a 6-byte pixel (RGB), the fourth entry is zero
 // In the plain modes a sample is a 16-bit integer, so hi (top 11 bits) + lo (the other 5) is exact.
 enum MfmaMode { MFMA_BLEND4=0,MFMA_PLAIN4=1,MFMA_PLAIN3=2 };
+
+// Diagnostic build only (-DMH_MFMA_TRACE, tools/trace_blur_steps.py): wave 0 of a few workgroups
+// records the shader clock at the phase boundaries of its first steps.
+#ifdef MH_MFMA_TRACE
+#define MH_TRACE_MARK(id) \
+  do { \
+    if ((trace != nullptr) && (trace_step < 48)) \
+      { \
+        const unsigned long long now=__builtin_readcyclecounter(); \
+        if (lane == 0) \
+          trace[trace_step*8+(id)]=now; \
+      } \
+  } while (0)
+#else
+#define MH_TRACE_MARK(id) do { } while (0)
+#endif
 
 struct __attribute__((packed,aligned(2))) Rgb16 { uint16_t c[3]; };
 typedef unsigned short pknorm2 __attribute__((ext_vector_type(2)));
@@ -287,6 +308,12 @@ void conv_mfma_kernel(ConvMfmaArgs args)
   };
 
   const int entry=(n & 3)*G::CH+(8*mg+(n >> 2))*G::S+8*half;    // this lane's operand line
+#ifdef MH_MFMA_TRACE
+  unsigned long long *trace=nullptr;
+  int trace_step=0;
+  if ((args.trace != nullptr) && (wave == 0) && ((blockIdx.x % 97) == 0) && (blockIdx.x/97 < 8))
+    trace=args.trace+(size_t) (blockIdx.x/97)*48*8;
+#endif
   const int items=args.strips*args.segments;
   for (int item=(int) blockIdx.x; item < items; item+=(int) gridDim.x)
     {
@@ -324,6 +351,7 @@ void conv_mfma_kernel(ConvMfmaArgs args)
         {
           const int out0=kStepOutputs*step;
           const bool has_next=step+1 < step_end;
+          MH_TRACE_MARK(0);
           // ---- multiply
           floatx16 acc;
 #pragma unroll
@@ -379,15 +407,29 @@ void conv_mfma_kernel(ConvMfmaArgs args)
                     *reinterpret_cast<uint2 *>(to)=result[pg];
                 }
             }
+#ifdef MH_MFMA_TRACE
+          asm volatile("s_nop 0" :: "v"(result[0].x),"v"(result[3].y));      // the epilogue has issued
+#endif
+          MH_TRACE_MARK(1);
           __syncthreads();                       // B2: this step's ring slots may be overwritten
+          MH_TRACE_MARK(2);
           if (has_next)
             {
               int slot=base+4*stage_group;       // positions in0+R+64j+4g -> slots (64j+4g) mod R
               slot=slot >= R ? slot-R : slot;
+#ifdef MH_MFMA_TRACE
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              MH_TRACE_MARK(3);
+#endif
               stage(raw,slot);
+#ifdef MH_MFMA_TRACE
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              MH_TRACE_MARK(4);
+#endif
               if (step+2 < step_end)
                 fetch(raw,unit0,in0+(out0-out_begin)+R+kStepOutputs+4*stage_group);
             }
+          MH_TRACE_MARK(5);
           // ---- stores
           if (VERTICAL && (MODE == MFMA_PLAIN3))
             {
@@ -463,7 +505,12 @@ void conv_mfma_kernel(ConvMfmaArgs args)
             }
           base+=kStepOutputs;
           base=base >= R ? base-R : base;
+          MH_TRACE_MARK(6);
           __syncthreads();                       // next step's samples are in the ring; tile_out is free
+          MH_TRACE_MARK(7);
+#ifdef MH_MFMA_TRACE
+          trace_step++;
+#endif
         }
     }
 }
@@ -516,10 +563,37 @@ static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
     }
   args.segments=segments;
   args.steps_per_segment=(args.steps+segments-1)/segments;
+#ifdef MH_MFMA_TRACE
+  args.trace=nullptr;
+  const char *trace_path=getenv("MAGICKHIP_MFMA_TRACE");
+  const size_t trace_bytes=8u*48u*8u*sizeof(unsigned long long);
+  if (trace_path != nullptr)
+    {
+      MH_HIP(hipMalloc(reinterpret_cast<void **>(&args.trace),trace_bytes));
+      MH_HIP(hipMemsetAsync(args.trace,0,trace_bytes,src.stream));
+    }
+#else
+  args.trace=nullptr;
+#endif
   ProfileScope prof(VERTICAL ? "conv_column" : "conv_row",src.stream);
   hipLaunchKernelGGL((conv_mfma_kernel<VERTICAL,NQ,MODE>),dim3((unsigned) nblocks),dim3(256),lds,
     src.stream,args);
   MH_HIP(hipGetLastError());
+#ifdef MH_MFMA_TRACE
+  if (args.trace != nullptr)
+    {
+      std::vector<unsigned long long> host(trace_bytes/sizeof(unsigned long long));
+      MH_HIP(hipMemcpyAsync(host.data(),args.trace,trace_bytes,hipMemcpyDeviceToHost,src.stream));
+      MH_HIP(hipStreamSynchronize(src.stream));
+      MH_HIP(hipFree(args.trace));
+      std::string path=std::string(trace_path)+(VERTICAL ? ".column" : ".row");
+      if (FILE *f=fopen(path.c_str(),"wb"))
+        {
+          fwrite(host.data(),1,trace_bytes,f);
+          fclose(f);
+        }
+    }
+#endif
   return MH_OK;
 }
 
