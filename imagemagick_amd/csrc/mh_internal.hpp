@@ -205,6 +205,9 @@ void release_color_tables();          // frees the per-device transfer-function 
 MhStatus launch_gray_check(const View &img,const MhImage *desc,unsigned int *flag_device);
 MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,const MhImage *desc);
 MhStatus launch_copy(const View &src,const View &dst);
+// FAST separable 2-D convolution (pointwise.hip): Q16 -> float sums, float sums -> Q16
+MhStatus launch_premultiply(const View &src,const View &sums,bool blend);
+MhStatus launch_separable_finish(const View &sums,const View &dst,bool blend);
 MhStatus launch_grayscale(const View &img,int method,const MhImage *desc);
 MhStatus launch_function(const View &img,int function,size_t count,const double *parameters,uint32_t update_mask);
 

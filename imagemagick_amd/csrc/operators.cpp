@@ -78,6 +78,79 @@ static bool kernel_has_nan(const MhKernelInfo *k)
   return false;
 }
 
+// k[y][x] = column[y]*row[x] to within rounding?  (Gaussian:RxS, Square/Rectangle/Unity scaled
+// kernels, outer products in general.)  The pivot is the largest cell; row = its kernel row,
+// column = its kernel column divided by the pivot.
+static bool rank_one_factors(const MhKernelInfo *k,std::vector<double> &row,std::vector<double> &column)
+{
+  const size_t w=k->width,h=k->height;
+  size_t pivot=0;
+  double largest=0.0;
+  for (size_t i=0; i < w*h; i++)
+    if (std::fabs(k->values[i]) > largest)
+      {
+        largest=std::fabs(k->values[i]);
+        pivot=i;
+      }
+  if (!(largest > 0.0) || !std::isfinite(largest))
+    return false;
+  const size_t py=pivot/w,px=pivot % w;
+  row.assign(k->values+py*w,k->values+(py+1)*w);
+  column.resize(h);
+  for (size_t y=0; y < h; y++)
+    column[y]=k->values[y*w+px]/k->values[pivot];
+  for (size_t y=0; y < h; y++)
+    for (size_t x=0; x < w; x++)
+      if (std::fabs(k->values[y*w+x]-column[y]*row[x]) > 1.0e-13*largest)
+        return false;
+  return true;
+}
+
+// FAST precision, Q16, a 2-D Convolve kernel that is an outer product: two 1-D passes over
+// float sums instead of width*height taps per pixel (GaussianBlurImage 0x10: 79+79 instead of
+// 6241).  Same window, same edge clamp (clamping is per axis) and one division at the end as in
+// morphology.c:2892-2979; the float intermediate keeps the result within +-1 level.
+// *handled = false: not this case, nothing launched.
+static MhStatus separable_convolve(const View &src,const View &dst,const MhKernelInfo *kernel,
+  const Roles &roles,bool *handled)
+{
+  *handled=false;
+  if ((precision() != MH_PRECISION_FAST) || (src.quantum != MH_QUANTUM_U16) ||
+      (kernel->width < 2) || (kernel->height < 2) || (roles.copy_mask != 0) ||
+      (src.channels < 1) || (src.channels > 4) || (getenv("MAGICKHIP_NO_SEPARABLE") != nullptr))
+    return MH_OK;
+  const bool blend=roles.blend && (roles.alpha == src.channels-1) &&
+    ((src.channels == 2) || (src.channels == 4));
+  if (roles.blend && !blend)
+    return MH_OK;
+  std::vector<double> row,column;
+  if (!rank_one_factors(kernel,row,column))
+    return MH_OK;
+  View sums=src,work=src;
+  sums.quantum=MH_QUANTUM_F32;
+  work.quantum=MH_QUANTUM_F32;
+  Temp sums_memory,work_memory;
+  MH_TRY(sums_memory.alloc(src.device,sums.bytes(),src.stream));
+  MH_TRY(work_memory.alloc(src.device,work.bytes(),src.stream));
+  sums.pixels=sums_memory.ptr;
+  work.pixels=work_memory.ptr;
+  Roles plain;
+  plain.update_mask=(1u << src.channels)-1u;
+  Conv1DParams horizontal,vertical;
+  horizontal.taps=row.data();
+  horizontal.ntaps=(int) kernel->width;
+  horizontal.origin=(int) kernel->x;
+  vertical.taps=column.data();
+  vertical.ntaps=(int) kernel->height;
+  vertical.origin=(int) kernel->y;
+  MH_TRY(launch_premultiply(src,sums,blend));
+  MH_TRY(launch_conv1d(sums,work,false,horizontal,plain,MH_PRECISION_FAST,nullptr));
+  MH_TRY(launch_conv1d(work,sums,true,vertical,plain,MH_PRECISION_FAST,nullptr));
+  MH_TRY(launch_separable_finish(sums,dst,blend));
+  *handled=true;
+  return MH_OK;
+}
+
 // One MorphologyPrimitive(curr -> work), morphology.c:2566.  `changed`
 // (optional, device counter, must be zero on entry) accumulates the number of
 // changed channel values.
@@ -100,6 +173,14 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
       p.ntaps=(int) kernel->width;
       p.origin=(int) kernel->x;
       return launch_conv1d(src,dst,false,p,roles,precision(),changed);
+    }
+  if ((method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
+      !kernel_has_nan(kernel))
+    {
+      bool handled=false;
+      MH_TRY(separable_convolve(src,dst,kernel,roles,&handled));
+      if (handled)
+        return MH_OK;
     }
   Morph2DParams p;
   p.method=method;

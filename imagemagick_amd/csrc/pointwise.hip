@@ -1825,6 +1825,95 @@ MhStatus launch_unsharp_epilogue(const View &src,const View &blur,const View &ds
 #undef MH_CASE
 }
 
+// ------------------------------------------- separable 2-D convolution, FAST
+// A rank-1 2-D kernel (Gaussian:RxS ...) is run as a row and a column pass over float sums.
+// The reference's 2-D loop (morphology.c:2892-2979) forms sum k*alpha*p and sum k*alpha over
+// the whole window and divides once, so the passes must carry the *undivided* sums:
+// premultiply_kernel writes alpha*p (alpha = QuantumScale*a) and a as floats, the two 1-D
+// passes convolve those as plain channels, separable_finish_kernel divides and quantises.
+template<int C,bool BLEND>
+__global__ __launch_bounds__(256)
+void premultiply_kernel(const uint16_t *src,float *dst,size_t npixels)
+{
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
+    {
+      uint16_t p[C];
+      float o[C];
+      load_pixel<uint16_t,C>(src+i*C,p);
+      const float alpha=BLEND ? (float) p[C-1]*(1.0f/65535.0f) : 1.0f;
+#pragma unroll
+      for (int c=0; c < C; c++)
+        o[c]=BLEND && (c < C-1) ? alpha*(float) p[c] : (float) p[c];
+      store_pixel<float,C>(dst+i*C,o);
+    }
+}
+
+template<int C,bool BLEND>
+__global__ __launch_bounds__(256)
+void separable_finish_kernel(const float *sums,uint16_t *dst,size_t npixels)
+{
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
+    {
+      float v[C];
+      uint16_t o[C];
+      load_pixel<float,C>(sums+i*C,v);
+      // gamma = 1/sum(k*alpha) = 65535/v[alpha]; an all-transparent window has zero sums: 0
+      const float gamma=BLEND ? (v[C-1] > 0.0f ? 65535.0f/v[C-1] : 0.0f) : 1.0f;
+#pragma unroll
+      for (int c=0; c < C; c++)
+        {
+          const float pixel=BLEND && (c < C-1) ? gamma*v[c] : v[c];
+          const float q=floorf(pixel+0.5f);
+          o[c]=(uint16_t) (q < 0.0f ? 0.0f : (q > 65535.0f ? 65535.0f : q));
+        }
+      store_pixel<uint16_t,C>(dst+i*C,o);
+    }
+}
+
+MhStatus launch_premultiply(const View &src,const View &sums,bool blend)
+{
+  const size_t n=src.columns*src.rows;
+  const uint16_t *in=static_cast<const uint16_t *>(src.pixels);
+  float *out=static_cast<float *>(sums.pixels);
+  ProfileScope prof("premultiply",src.stream);
+#define MH_CASE(CV,BV) \
+  hipLaunchKernelGGL((premultiply_kernel<CV,BV>),dim3(stream_grid(n)),dim3(256),0,src.stream,in,out,n)
+  switch (src.channels)
+  {
+    case 1: MH_CASE(1,false); break;
+    case 2: if (blend) MH_CASE(2,true); else MH_CASE(2,false); break;
+    case 3: MH_CASE(3,false); break;
+    case 4: if (blend) MH_CASE(4,true); else MH_CASE(4,false); break;
+    default: return fail(MH_UNSUPPORTED,"separable convolution: %d channels",src.channels);
+  }
+#undef MH_CASE
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+MhStatus launch_separable_finish(const View &sums,const View &dst,bool blend)
+{
+  const size_t n=dst.columns*dst.rows;
+  const float *in=static_cast<const float *>(sums.pixels);
+  uint16_t *out=static_cast<uint16_t *>(dst.pixels);
+  ProfileScope prof("separable_finish",dst.stream);
+#define MH_CASE(CV,BV) \
+  hipLaunchKernelGGL((separable_finish_kernel<CV,BV>),dim3(stream_grid(n)),dim3(256),0,dst.stream,in,out,n)
+  switch (dst.channels)
+  {
+    case 1: MH_CASE(1,false); break;
+    case 2: if (blend) MH_CASE(2,true); else MH_CASE(2,false); break;
+    case 3: MH_CASE(3,false); break;
+    case 4: if (blend) MH_CASE(4,true); else MH_CASE(4,false); break;
+    default: return fail(MH_UNSUPPORTED,"separable convolution: %d channels",dst.channels);
+  }
+#undef MH_CASE
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 MhStatus launch_copy(const View &src,const View &dst)
 {
   MH_HIP(hipMemcpyAsync(dst.pixels,src.pixels,src.bytes(),hipMemcpyDeviceToDevice,src.stream));

@@ -143,6 +143,63 @@ def test_blur_fast_every_ring_size(im, refmod, channels, sigma):
     assert_parity(got, ref.blur(0.0, sigma).numpy(), False, "fast blur sigma %g, %d channels" % (sigma, channels))
 
 
+@pytest.mark.parametrize("channels", [1, 2, 3, 4])
+@pytest.mark.parametrize("radius,sigma", [(0.0, 1.5), (0.0, 4.0), (2.0, 3.0)])
+def test_gaussian_blur_fast_is_separated(im, refmod, channels, radius, sigma):
+    """FAST GaussianBlurImage: the 2-D Gaussian kernel is an outer product, so the library runs
+    it as a row and a column pass over float sums (one division at the end, as the reference's
+    2-D loop) instead of width x height taps per pixel: within +-1 level of the reference's
+    2-D result, on random data, edges included."""
+    px = make_pixels(83, 96, channels, Q16, seed=channels * 7 + int(sigma * 10))
+    dev, ref = run_pair(im, refmod, px)
+    want = ref.gaussian_blur(radius, sigma).numpy()
+    import bench
+    holder = {}
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        launched = set(bench.kernel_profile(im, lambda: holder.update(out=im.gaussian_blur_image(dev, radius, sigma)), 1))
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    got = holder["out"].numpy()
+    assert "separable_finish" in launched and "premultiply" in launched, launched
+    assert_parity(got, want, False, "fast gaussian %gx%g c%d" % (radius, sigma, channels))
+
+
+@pytest.mark.parametrize("case", ["transparent_band", "tiny_alpha", "checker"])
+def test_gaussian_blur_fast_alpha_cases(im, refmod, case):
+    rng = np.random.default_rng(5)
+    rows, cols = 90, 110
+    px = rng.integers(0, 65536, (rows, cols, 4), dtype=np.uint16)
+    if case == "transparent_band":
+        px[20:60, :, 3] = 0
+    elif case == "tiny_alpha":
+        px[:, :, 3] = rng.integers(0, 4, (rows, cols))
+    else:
+        y, x = np.mgrid[0:rows, 0:cols]
+        px[:, :, 3] = ((x + y) & 1) * 65535
+    dev, ref = run_pair(im, refmod, px)
+    want = ref.gaussian_blur(0.0, 2.5).numpy()
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got = im.gaussian_blur_image(dev, 0.0, 2.5).numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert_parity(got, want, False, "fast gaussian, %s" % case)
+
+
+def test_convolve_fast_non_separable_kernel_stays_exact(im, refmod):
+    """A kernel that is not an outer product takes the generic 2-D kernel in FAST mode too."""
+    px = make_pixels(60, 71, 4, Q16, seed=2)
+    dev, ref = run_pair(im, refmod, px)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        for kernel in ("Disk:2.5", "3x3: 0,1,0 1,-3,1 0,1,1", "Gaussian:0x1.2"):
+            got = im.convolve_image(dev, kernel).numpy()
+            assert_parity(got, ref.convolve(kernel).numpy(), kernel != "Gaussian:0x1.2", "fast convolve %s" % kernel)
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+
+
 def test_blur_fast_matrix_and_vector_paths_agree_within_one_level(im, refmod):
     """MAGICKHIP_NO_MFMA=1 selects the f32 vector kernels: both FAST implementations honour the
     same +-1 contract against the reference (they need not agree with each other exactly)."""
