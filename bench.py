@@ -292,6 +292,10 @@ def extra_measurements(im, torch, args):
         extra["blur_%s_Mpixels_per_s" % ("exact" if args.precision == "fast" else "fast")] = \
             round(n * n / sec / 1e6, 1)
         im.set_precision(im.PRECISION_FAST if args.precision == "fast" else im.PRECISION_EXACT)
+        # GaussianBlurImage: the 2-D Gaussian kernel, separated in FAST mode
+        if args.precision == "fast":
+            sec = timed(torch, lambda: im.gaussian_blur_image(image, 0.0, args.sigma), 5)
+            extra["gaussian_blur_2d_kernel_Mpixels_per_s"] = round(n * n / sec / 1e6, 1)
         # reference point for the roofline: what a plain device copy of the same frame reaches
         # (read 537 MB + write 537 MB, torch's copy kernel)
         mirror = torch.empty_like(src)

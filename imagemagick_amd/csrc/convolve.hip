@@ -1443,6 +1443,23 @@ static MhStatus dispatch_channels(const View &src,const View &dst,bool vertical,
   return fail(MH_UNSUPPORTED,"%d channels",src.channels);
 }
 
+MhStatus launch_conv1d_sums(const View &src,const View &dst,bool vertical,const Conv1DParams &params,
+  bool blend,bool *handled)
+{
+  *handled=false;
+  if ((params.ntaps < 2) || (params.origin < 0) || (params.origin >= params.ntaps) ||
+      (getenv("MAGICKHIP_NO_MFMA") != nullptr))
+    return MH_OK;
+  const int K=params.ntaps;
+  std::vector<float> host((size_t) K);
+  for (int v=0; v < K; v++)
+    host[(size_t) v]=(float) params.taps[K-1-v];     // reversed walk, morphology.c:2746
+  Temp taps;
+  MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(float)));
+  return launch_conv1d_mfma(src,dst,vertical,taps.as<float>(),K,K-1-params.origin,blend,vertical ? 2 : 1,
+    handled);
+}
+
 MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
   const Conv1DParams &params,const Roles &roles,MhPrecision prec,
   unsigned long long *changed)
@@ -1472,7 +1489,7 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
               Temp taps;
               MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(float)));
               bool handled=false;
-              MH_TRY(launch_conv1d_mfma(src,dst,vertical,taps.as<float>(),K,K-1-params.origin,roles.blend,&handled));
+              MH_TRY(launch_conv1d_mfma(src,dst,vertical,taps.as<float>(),K,K-1-params.origin,roles.blend,0,&handled));
               if (handled)
                 return MH_OK;
             }

@@ -38,6 +38,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace mh {
@@ -187,10 +188,22 @@ enum MfmaMode { MFMA_BLEND4=0,MFMA_PLAIN4=1,MFMA_PLAIN3=2 };
 struct __attribute__((packed,aligned(2))) Rgb16 { uint16_t c[3]; };
 typedef unsigned short pknorm2 __attribute__((ext_vector_type(2)));
 
-template<bool VERTICAL,int NQ,int MODE>
+// IO: what a pass reads and writes
+//   MFMA_Q16       Quantum pixels in, Quantum pixels out (BlurImage's passes)
+//   MFMA_TO_SUMS   row pass of a separated 2-D kernel: Quantum pixels in, the four undivided
+//                  f32 sums of a pixel out (16 bytes)
+//   MFMA_FROM_SUMS column pass of a separated 2-D kernel: those sums in, Quantum pixels out —
+//                  one division for the whole 2-D window, as morphology.c:2892-2979
+enum MfmaIo { MFMA_Q16=0,MFMA_TO_SUMS=1,MFMA_FROM_SUMS=2 };
+
+template<bool VERTICAL,int NQ,int MODE,int IO>
 __global__ __launch_bounds__(256)
 void conv_mfma_kernel(ConvMfmaArgs args)
 {
+  static_assert((IO == MFMA_Q16) || ((IO == MFMA_TO_SUMS) && !VERTICAL) ||
+    ((IO == MFMA_FROM_SUMS) && VERTICAL),"sums are written by a row pass and read by a column pass");
+  static_assert((IO == MFMA_Q16) || (MODE != MFMA_PLAIN3),"the sums layout has four channels");
+  typedef typename std::conditional<IO == MFMA_FROM_SUMS,uint4,uint2>::type Raw;
   constexpr int PX=MODE == MFMA_PLAIN3 ? 3 : 4;    // u16 per pixel in memory
   typedef MfmaGeometry<VERTICAL,NQ> G;
   constexpr int R=G::R,kStripUnits=G::UNITS,kStepOutputs=G::STEP;
@@ -241,10 +254,10 @@ void conv_mfma_kernel(ConvMfmaArgs args)
       stage_unit=tid/(kStepOutputs/4);           // adjacent lanes: adjacent x groups of a row
       stage_group=tid % (kStepOutputs/4);
     }
-  uint2 raw[4];
+  Raw raw[4];
   // fetch the 4 samples at axis positions pos..pos+3 of this thread's unit (edge clamp,
   // cache.c:2663-2679)
-  auto fetch=[&](uint2 (&buf)[4],int unit0,int pos)
+  auto fetch=[&](Raw (&buf)[4],int unit0,int pos)
   {
 #pragma unroll
     for (int i=0; i < 4; i++)
@@ -254,7 +267,9 @@ void conv_mfma_kernel(ConvMfmaArgs args)
         x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
         y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
         const size_t at=pixel_index(y,W,x);
-        if (MODE == MFMA_PLAIN3)
+        if constexpr (IO == MFMA_FROM_SUMS)
+          buf[i]=*reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(args.src)+at*4);
+        else if constexpr (MODE == MFMA_PLAIN3)
           {
             Rgb16 p;
             __builtin_memcpy(&p,args.src+at*3,sizeof(p));
@@ -267,17 +282,30 @@ void conv_mfma_kernel(ConvMfmaArgs args)
   // convert raw[] and write it to ring slots slot..slot+3 (slot multiple of 4, no wrap inside).
   // Values are handled as pairs of neighbouring positions: packed f32 multiplies, one
   // v_cvt_pkrtz_f16_f32 per pair for the hi halves and one v_cvt_pk_f16_f32 for the lo halves.
-  auto stage=[&](const uint2 (&buf)[4],int slot)
+  auto stage=[&](const Raw (&buf)[4],int slot)
   {
     f32x2 v[4][2];
 #pragma unroll
     for (int j=0; j < 2; j++)
       {
-        const uint2 r0=buf[2*j],r1=buf[2*j+1];
-        const f32x2 c0={(float) (r0.x & 0xffffu),(float) (r1.x & 0xffffu)};
-        const f32x2 c1={(float) (r0.x >> 16),(float) (r1.x >> 16)};
-        const f32x2 c2={(float) (r0.y & 0xffffu),(float) (r1.y & 0xffffu)};
-        const f32x2 c3={(float) (r0.y >> 16),(float) (r1.y >> 16)};
+        if constexpr (IO == MFMA_FROM_SUMS)
+          {
+            // the row pass left sums of 256*tap*v with v < 32768: 1/256 brings them back under
+            // the f16 range; the factor is common to colour and alpha sums (it cancels in the
+            // division) and equals the taps' own factor 256 (so the epilogues stay as they are)
+            const float scale=1.0f/256.0f;
+            const uint4 r0=buf[2*j],r1=buf[2*j+1];
+            v[0][j]=f32x2{__builtin_bit_cast(float,r0.x),__builtin_bit_cast(float,r1.x)}*scale;
+            v[1][j]=f32x2{__builtin_bit_cast(float,r0.y),__builtin_bit_cast(float,r1.y)}*scale;
+            v[2][j]=f32x2{__builtin_bit_cast(float,r0.z),__builtin_bit_cast(float,r1.z)}*scale;
+            v[3][j]=f32x2{__builtin_bit_cast(float,r0.w),__builtin_bit_cast(float,r1.w)}*scale;
+            continue;
+          }
+        const unsigned r0x=buf[2*j].x,r0y=buf[2*j].y,r1x=buf[2*j+1].x,r1y=buf[2*j+1].y;
+        const f32x2 c0={(float) (r0x & 0xffffu),(float) (r1x & 0xffffu)};
+        const f32x2 c1={(float) (r0x >> 16),(float) (r1x >> 16)};
+        const f32x2 c2={(float) (r0y & 0xffffu),(float) (r1y & 0xffffu)};
+        const f32x2 c3={(float) (r0y >> 16),(float) (r1y >> 16)};
         if (MODE == MFMA_BLEND4)
           {
             const f32x2 weight=c3*(0.5f/65536.0f);
@@ -372,6 +400,21 @@ void conv_mfma_kernel(ConvMfmaArgs args)
             }
           // ---- epilogue: lane holds 4 pixels (reg>>2) x 4 channels (reg&3) of output n
           uint2 result[4];
+          if constexpr (IO == MFMA_TO_SUMS)
+            {
+              // the undivided sums, 16 bytes per pixel, 512 contiguous bytes per 32 lanes
+#pragma unroll
+              for (int pg=0; pg < 4; pg++)
+                {
+                  const int x=out0+32*ng+n,y=unit0+8*mg+2*pg+half;
+                  if ((x < W) && (y < H))
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(args.dst)+pixel_index(y,W,x)*4)=
+                      make_float4(acc[4*pg+0],acc[4*pg+1],acc[4*pg+2],acc[4*pg+3]);
+                  result[pg]=make_uint2(0u,0u);
+                }
+            }
+          else
+          {
 #pragma unroll
           for (int pg=0; pg < 4; pg++)
             {
@@ -407,6 +450,7 @@ void conv_mfma_kernel(ConvMfmaArgs args)
                     *reinterpret_cast<uint2 *>(to)=result[pg];
                 }
             }
+          }
 #ifdef MH_MFMA_TRACE
           asm volatile("s_nop 0" :: "v"(result[0].x),"v"(result[3].y));      // the epilogue has issued
 #endif
@@ -482,7 +526,7 @@ void conv_mfma_kernel(ConvMfmaArgs args)
                     }
                 }
             }
-          else
+          else if constexpr (IO != MFMA_TO_SUMS)     // (the sums went out with the epilogue)
             {
 #pragma unroll
               for (int pg=0; pg < 4; pg++)
@@ -515,7 +559,7 @@ void conv_mfma_kernel(ConvMfmaArgs args)
     }
 }
 
-template<bool VERTICAL,int NQ,int MODE>
+template<bool VERTICAL,int NQ,int MODE,int IO>
 static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
 {
   typedef MfmaGeometry<VERTICAL,NQ> G;
@@ -525,7 +569,7 @@ static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
   args.strips=(units+kStripUnits-1)/kStripUnits;
   args.steps=(axis+kStepOutputs-1)/kStepOutputs;
   const size_t lds=G::ring_bytes+(VERTICAL ? G::out_bytes : 0);
-  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<VERTICAL,NQ,MODE>),
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<VERTICAL,NQ,MODE,IO>),
     hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
   // The grid is persistent (every workgroup walks its share of the items), so it must not
   // exceed what is resident at once: LDS and registers decide, asked once per instantiation
@@ -534,7 +578,7 @@ static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
     {
       int n=0;
       MH_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n,
-        reinterpret_cast<const void *>(&conv_mfma_kernel<VERTICAL,NQ,MODE>),256,lds));
+        reinterpret_cast<const void *>(&conv_mfma_kernel<VERTICAL,NQ,MODE,IO>),256,lds));
       resident=n < 1 ? 1 : n;
     }
   // three per CU even where four fit (row pass up to 79 taps, both passes up to 33): measured
@@ -576,7 +620,7 @@ static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
   args.trace=nullptr;
 #endif
   ProfileScope prof(VERTICAL ? "conv_column" : "conv_row",src.stream);
-  hipLaunchKernelGGL((conv_mfma_kernel<VERTICAL,NQ,MODE>),dim3((unsigned) nblocks),dim3(256),lds,
+  hipLaunchKernelGGL((conv_mfma_kernel<VERTICAL,NQ,MODE,IO>),dim3((unsigned) nblocks),dim3(256),lds,
     src.stream,args);
   MH_HIP(hipGetLastError());
 #ifdef MH_MFMA_TRACE
@@ -598,12 +642,22 @@ static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
 }
 
 // *handled = false: shape outside this kernel's reach, nothing launched
+// io: MFMA_Q16 (src and dst Quantum), MFMA_TO_SUMS (row pass: src Quantum, dst float sums) or
+// MFMA_FROM_SUMS (column pass: src float sums, dst Quantum); the geometry is that of src
 MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const float *taps_device,
-  int ntaps,int shift,bool blend,bool *handled)
+  int ntaps,int shift,bool blend,int io,bool *handled)
 {
   *handled=false;
-  if ((src.quantum != MH_QUANTUM_U16) || (ntaps < 2))
+  const View &quantum_side=io == MFMA_FROM_SUMS ? dst : src;
+  if ((quantum_side.quantum != MH_QUANTUM_U16) || (ntaps < 2))
     return MH_OK;
+  if (io != MFMA_Q16)
+    {
+      const View &sums_side=io == MFMA_FROM_SUMS ? src : dst;
+      if ((sums_side.quantum != MH_QUANTUM_F32) || (src.channels != 4) || (dst.channels != 4) ||
+          (vertical != (io == MFMA_FROM_SUMS)))
+        return MH_OK;
+    }
   if ((src.channels != 4) && ((src.channels != 3) || blend))
     return MH_OK;
   if ((src.columns >= (1u << 24)) || (src.rows >= (1u << 24)) ||
@@ -624,14 +678,20 @@ MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const 
   *handled=true;
 #define MH_NQ(NQV) \
   case NQV: \
+    if (io == MFMA_TO_SUMS) \
+      return mode == MFMA_BLEND4 ? launch_mfma_typed<false,NQV,MFMA_BLEND4,MFMA_TO_SUMS>(src,args) : \
+        launch_mfma_typed<false,NQV,MFMA_PLAIN4,MFMA_TO_SUMS>(src,args); \
+    if (io == MFMA_FROM_SUMS) \
+      return mode == MFMA_BLEND4 ? launch_mfma_typed<true,NQV,MFMA_BLEND4,MFMA_FROM_SUMS>(src,args) : \
+        launch_mfma_typed<true,NQV,MFMA_PLAIN4,MFMA_FROM_SUMS>(src,args); \
     if (mode == MFMA_BLEND4) \
-      return vertical ? launch_mfma_typed<true,NQV,MFMA_BLEND4>(src,args) : \
-        launch_mfma_typed<false,NQV,MFMA_BLEND4>(src,args); \
+      return vertical ? launch_mfma_typed<true,NQV,MFMA_BLEND4,MFMA_Q16>(src,args) : \
+        launch_mfma_typed<false,NQV,MFMA_BLEND4,MFMA_Q16>(src,args); \
     if (mode == MFMA_PLAIN4) \
-      return vertical ? launch_mfma_typed<true,NQV,MFMA_PLAIN4>(src,args) : \
-        launch_mfma_typed<false,NQV,MFMA_PLAIN4>(src,args); \
-    return vertical ? launch_mfma_typed<true,NQV,MFMA_PLAIN3>(src,args) : \
-      launch_mfma_typed<false,NQV,MFMA_PLAIN3>(src,args);
+      return vertical ? launch_mfma_typed<true,NQV,MFMA_PLAIN4,MFMA_Q16>(src,args) : \
+        launch_mfma_typed<false,NQV,MFMA_PLAIN4,MFMA_Q16>(src,args); \
+    return vertical ? launch_mfma_typed<true,NQV,MFMA_PLAIN3,MFMA_Q16>(src,args) : \
+      launch_mfma_typed<false,NQV,MFMA_PLAIN3,MFMA_Q16>(src,args);
   switch (nq < 3 ? 3 : nq)
   {
     MH_NQ(3) MH_NQ(4) MH_NQ(5) MH_NQ(6) MH_NQ(7) MH_NQ(8) MH_NQ(9)

@@ -144,10 +144,15 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
   const Conv1DParams &params,const Roles &roles,MhPrecision precision,
   unsigned long long *changed_device);
 
-// FAST Q16 RGBA blend pass on the f16 matrix cores (convolve_mfma.hip); *handled=false when
-// the shape is outside its reach and nothing was launched
+// FAST Q16 pass on the f16 matrix cores (convolve_mfma.hip); *handled=false when the shape is
+// outside its reach and nothing was launched.  io: 0 = Quantum in and out, 1 = row pass writing
+// the undivided float sums of a separated 2-D kernel, 2 = column pass reading them.
 MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const float *taps_device,
-  int ntaps,int shift,bool blend,bool *handled);
+  int ntaps,int shift,bool blend,int io,bool *handled);
+// One pass of a separated 2-D kernel through launch_conv1d_mfma (taps uploaded here):
+// vertical = false: src Quantum RGBA -> dst float sums; vertical = true: the reverse
+MhStatus launch_conv1d_sums(const View &src,const View &dst,bool vertical,const Conv1DParams &params,
+  bool blend,bool *handled);
 
 struct Morph2DParams
 {

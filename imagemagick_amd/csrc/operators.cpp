@@ -126,6 +126,33 @@ static MhStatus separable_convolve(const View &src,const View &dst,const MhKerne
   std::vector<double> row,column;
   if (!rank_one_factors(kernel,row,column))
     return MH_OK;
+  if (src.channels == 4)
+    {
+      // both passes on the matrix cores: Quantum pixels -> float sums -> Quantum pixels
+      View sums=src;
+      sums.quantum=MH_QUANTUM_F32;
+      Temp memory;
+      MH_TRY(memory.alloc(src.device,sums.bytes(),src.stream));
+      sums.pixels=memory.ptr;
+      Conv1DParams horizontal,vertical;
+      horizontal.taps=row.data();
+      horizontal.ntaps=(int) kernel->width;
+      horizontal.origin=(int) kernel->x;
+      vertical.taps=column.data();
+      vertical.ntaps=(int) kernel->height;
+      vertical.origin=(int) kernel->y;
+      bool first=false,second=false;
+      MH_TRY(launch_conv1d_sums(src,sums,false,horizontal,blend,&first));
+      if (first)
+        {
+          MH_TRY(launch_conv1d_sums(sums,dst,true,vertical,blend,&second));
+          if (second)
+            {
+              *handled=true;
+              return MH_OK;
+            }
+        }
+    }
   View sums=src,work=src;
   sums.quantum=MH_QUANTUM_F32;
   work.quantum=MH_QUANTUM_F32;

@@ -161,8 +161,32 @@ def test_gaussian_blur_fast_is_separated(im, refmod, channels, radius, sigma):
     finally:
         im.set_precision(im.PRECISION_EXACT)
     got = holder["out"].numpy()
-    assert "separable_finish" in launched and "premultiply" in launched, launched
+    if channels == 4:       # both passes on the matrix cores, float sums in between
+        assert launched == {"conv_row", "conv_column"}, launched
+    else:
+        assert "separable_finish" in launched and "premultiply" in launched, launched
     assert_parity(got, want, False, "fast gaussian %gx%g c%d" % (radius, sigma, channels))
+
+
+def test_gaussian_blur_fast_opaque_and_plain_four_channels(im, refmod):
+    """Fully opaque alpha (the largest sums the float intermediate carries) and four channels
+    without an alpha trait through the matrix-core sums passes."""
+    px = make_pixels(120, 150, 4, Q16, seed=12)
+    px[:, :, 3] = 65535
+    px[:40, :, :3] = 65535
+    dev, ref = run_pair(im, refmod, px)
+    want = ref.gaussian_blur(0.0, 6.0).numpy()
+    plain_want = np.concatenate([refmod.RefImage(px[:, :, :3].copy()).gaussian_blur(0.0, 6.0).numpy(),
+                                 refmod.RefImage(px[:, :, 3].copy()).gaussian_blur(0.0, 6.0).numpy().reshape(120, 150, 1)],
+                                axis=2)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got = im.gaussian_blur_image(dev, 0.0, 6.0).numpy()
+        plain = im.gaussian_blur_image(im.Image(to_device(px), has_alpha=False), 0.0, 6.0).numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert_parity(got, want, False, "fast gaussian, opaque")
+    assert_parity(plain, plain_want, False, "fast gaussian, four plain channels")
 
 
 @pytest.mark.parametrize("case", ["transparent_band", "tiny_alpha", "checker"])
