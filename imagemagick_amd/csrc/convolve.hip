@@ -1460,6 +1460,24 @@ MhStatus launch_conv1d_sums(const View &src,const View &dst,bool vertical,const 
     handled);
 }
 
+MhStatus launch_conv1d_unsharp(const View &rows,const View &dst,const View &original,
+  const Conv1DParams &params,bool blend,double gain,double threshold,bool *handled)
+{
+  *handled=false;
+  if ((params.ntaps < 2) || (params.origin < 0) || (params.origin >= params.ntaps) ||
+      (params.bias != 0.0) || (getenv("MAGICKHIP_NO_MFMA") != nullptr) ||
+      (getenv("MAGICKHIP_NO_FUSED_UNSHARP") != nullptr))
+    return MH_OK;
+  const int K=params.ntaps;
+  std::vector<float> host((size_t) K);
+  for (int v=0; v < K; v++)
+    host[(size_t) v]=(float) params.taps[K-1-v];     // reversed walk, morphology.c:2746
+  Temp taps;
+  MH_TRY(upload_table(taps,rows.device,rows.stream,host.data(),host.size()*sizeof(float)));
+  return launch_conv1d_mfma(rows,dst,true,taps.as<float>(),K,K-1-params.origin,blend,3,handled,
+    &original,gain,threshold);
+}
+
 MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
   const Conv1DParams &params,const Roles &roles,MhPrecision prec,
   unsigned long long *changed)

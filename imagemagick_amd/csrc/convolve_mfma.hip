@@ -35,6 +35,7 @@
 // work on halos and measured 0.53 ms per pass), multiplies, and leaves.
 #include "mh_internal.hpp"
 #include "device_common.hpp"
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -52,6 +53,9 @@ struct ConvMfmaArgs
   const uint16_t *src;
   uint16_t *dst;
   unsigned long long *trace;   // diagnostic builds only
+  const uint16_t *orig;        // MFMA_UNSHARP: the unblurred frame
+  float gain;                  // MFMA_UNSHARP
+  int threshold;               // MFMA_UNSHARP: ceil(QuantumRange*threshold), see unsharp_pair
   int columns,rows;
   int ntaps;
   int shift;                 // K-1-origin: offset of the first input sample
@@ -194,14 +198,40 @@ typedef unsigned short pknorm2 __attribute__((ext_vector_type(2)));
 //                  f32 sums of a pixel out (16 bytes)
 //   MFMA_FROM_SUMS column pass of a separated 2-D kernel: those sums in, Quantum pixels out —
 //                  one division for the whole 2-D window, as morphology.c:2892-2979
-enum MfmaIo { MFMA_Q16=0,MFMA_TO_SUMS=1,MFMA_FROM_SUMS=2 };
+//   MFMA_UNSHARP   column pass of UnsharpMaskImage: the blurred sample never reaches memory,
+//                  the copy-out applies effect.c:4364-4369 against the unblurred frame
+enum MfmaIo { MFMA_Q16=0,MFMA_TO_SUMS=1,MFMA_FROM_SUMS=2,MFMA_UNSHARP=3 };
+
+// UnsharpMaskImage's epilogue for one Quantum-rounded blurred sample b of the sample p
+// (effect.c:4364-4369): p if |2(p-b)| < QuantumRange*threshold, else p+gain*(p-b), clamped and
+// rounded.  2(p-b) is an integer, so comparing it with the ceiling of the threshold is exact.
+static __device__ __forceinline__ unsigned unsharp_sample(unsigned p,unsigned b,float gain,int threshold)
+{
+  const int d=(int) p-(int) b;
+  const int twice=d < 0 ? -2*d : 2*d;
+  // ClampToQuantum: round half up (gain*d has exact halves for gains like 2.5, so the
+  // round-to-even of v_cvt_pknorm would differ from the reference on every such tie)
+  const float sharpened=(float) p+gain*(float) d+0.5f;
+  const unsigned level=(unsigned) (sharpened < 0.0f ? 0.0f : sharpened);
+  return twice < threshold ? p : (level > 65535u ? 65535u : level);
+}
+
+static __device__ __forceinline__ uint2 unsharp_pixel(uint2 p,uint2 b,float gain,int threshold)
+{
+  return make_uint2(
+    unsharp_sample(p.x & 0xffffu,b.x & 0xffffu,gain,threshold) |
+      (unsharp_sample(p.x >> 16,b.x >> 16,gain,threshold) << 16),
+    unsharp_sample(p.y & 0xffffu,b.y & 0xffffu,gain,threshold) |
+      (unsharp_sample(p.y >> 16,b.y >> 16,gain,threshold) << 16));
+}
 
 template<bool VERTICAL,int NQ,int MODE,int IO>
 __global__ __launch_bounds__(256)
 void conv_mfma_kernel(ConvMfmaArgs args)
 {
   static_assert((IO == MFMA_Q16) || ((IO == MFMA_TO_SUMS) && !VERTICAL) ||
-    ((IO == MFMA_FROM_SUMS) && VERTICAL),"sums are written by a row pass and read by a column pass");
+    (((IO == MFMA_FROM_SUMS) || (IO == MFMA_UNSHARP)) && VERTICAL),
+    "sums are written by a row pass and read by a column pass; the unsharp epilogue is a column pass's");
   static_assert((IO == MFMA_Q16) || (MODE != MFMA_PLAIN3),"the sums layout has four channels");
   typedef typename std::conditional<IO == MFMA_FROM_SUMS,uint4,uint2>::type Raw;
   constexpr int PX=MODE == MFMA_PLAIN3 ? 3 : 4;    // u16 per pixel in memory
@@ -380,6 +410,22 @@ void conv_mfma_kernel(ConvMfmaArgs args)
           const int out0=kStepOutputs*step;
           const bool has_next=step+1 < step_end;
           MH_TRACE_MARK(0);
+          // MFMA_UNSHARP: the unblurred pixels of this step's outputs, fetched now and used by the
+          // copy-out at the end of the step (always a valid 16-byte pair: clamped, W >= 2)
+          uint4 original[(kStepOutputs*kStripUnits/2)/256];
+          if constexpr (IO == MFMA_UNSHARP)
+            {
+#pragma unroll
+              for (int round=0; round < (kStepOutputs*kStripUnits/2)/256; round++)
+                {
+                  const int u=tid+256*round;
+                  const int row=u/(kStripUnits/2),pair=u % (kStripUnits/2);
+                  int x=unit0+2*pair,y=out0+row;
+                  x=x > W-2 ? W-2 : x;
+                  y=y > H-1 ? H-1 : y;
+                  original[round]=*reinterpret_cast<const uint4 *>(args.orig+pixel_index(y,W,x)*4);
+                }
+            }
           // ---- multiply
           floatx16 acc;
 #pragma unroll
@@ -517,12 +563,24 @@ void conv_mfma_kernel(ConvMfmaArgs args)
                   const int x=unit0+2*pair,y=out0+row;
                   const uint16_t *from=tile_out+(size_t) row*G::OUT_STRIDE+2*pair*4;
                   uint16_t *to=args.dst+pixel_index(y,W,x)*4;
+                  uint4 value=*reinterpret_cast<const uint4 *>(from);
+                  if constexpr (IO == MFMA_UNSHARP)
+                    {
+                      uint4 p=original[round];
+                      if (x > W-2)               // the last pixel of an odd row: second half of the clamped pair
+                        p=make_uint4(p.z,p.w,p.z,p.w);
+                      const uint2 first=unsharp_pixel(make_uint2(p.x,p.y),make_uint2(value.x,value.y),
+                        args.gain,args.threshold);
+                      const uint2 second=unsharp_pixel(make_uint2(p.z,p.w),make_uint2(value.z,value.w),
+                        args.gain,args.threshold);
+                      value=make_uint4(first.x,first.y,second.x,second.y);
+                    }
                   if (y < H)
                     {
                       if (x+1 < W)
-                        *reinterpret_cast<uint4 *>(to)=*reinterpret_cast<const uint4 *>(from);
+                        *reinterpret_cast<uint4 *>(to)=value;
                       else if (x < W)
-                        *reinterpret_cast<uint2 *>(to)=*reinterpret_cast<const uint2 *>(from);
+                        *reinterpret_cast<uint2 *>(to)=make_uint2(value.x,value.y);
                     }
                 }
             }
@@ -645,13 +703,17 @@ static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
 // io: MFMA_Q16 (src and dst Quantum), MFMA_TO_SUMS (row pass: src Quantum, dst float sums) or
 // MFMA_FROM_SUMS (column pass: src float sums, dst Quantum); the geometry is that of src
 MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const float *taps_device,
-  int ntaps,int shift,bool blend,int io,bool *handled)
+  int ntaps,int shift,bool blend,int io,bool *handled,const View *unsharp_original,double gain,
+  double threshold)
 {
   *handled=false;
+  if ((io == MFMA_UNSHARP) && ((unsharp_original == nullptr) || !vertical || (src.channels != 4) ||
+      (src.columns < 2) || (unsharp_original->quantum != MH_QUANTUM_U16)))
+    return MH_OK;
   const View &quantum_side=io == MFMA_FROM_SUMS ? dst : src;
   if ((quantum_side.quantum != MH_QUANTUM_U16) || (ntaps < 2))
     return MH_OK;
-  if (io != MFMA_Q16)
+  if ((io == MFMA_TO_SUMS) || (io == MFMA_FROM_SUMS))
     {
       const View &sums_side=io == MFMA_FROM_SUMS ? src : dst;
       if ((sums_side.quantum != MH_QUANTUM_F32) || (src.channels != 4) || (dst.channels != 4) ||
@@ -675,12 +737,25 @@ MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const 
   args.ntaps=ntaps;
   args.shift=shift;
   args.taps=taps_device;
+  args.orig=nullptr;
+  args.gain=0.0f;
+  args.threshold=0;
+  if (io == MFMA_UNSHARP)
+    {
+      args.orig=static_cast<const uint16_t *>(unsharp_original->pixels);
+      args.gain=(float) gain;
+      const double level=std::ceil(65535.0*threshold);
+      args.threshold=level > 131072.0 ? 131072 : (level < 0.0 ? 0 : (int) level);
+    }
   *handled=true;
 #define MH_NQ(NQV) \
   case NQV: \
     if (io == MFMA_TO_SUMS) \
       return mode == MFMA_BLEND4 ? launch_mfma_typed<false,NQV,MFMA_BLEND4,MFMA_TO_SUMS>(src,args) : \
         launch_mfma_typed<false,NQV,MFMA_PLAIN4,MFMA_TO_SUMS>(src,args); \
+    if (io == MFMA_UNSHARP) \
+      return mode == MFMA_BLEND4 ? launch_mfma_typed<true,NQV,MFMA_BLEND4,MFMA_UNSHARP>(src,args) : \
+        launch_mfma_typed<true,NQV,MFMA_PLAIN4,MFMA_UNSHARP>(src,args); \
     if (io == MFMA_FROM_SUMS) \
       return mode == MFMA_BLEND4 ? launch_mfma_typed<true,NQV,MFMA_BLEND4,MFMA_FROM_SUMS>(src,args) : \
         launch_mfma_typed<true,NQV,MFMA_PLAIN4,MFMA_FROM_SUMS>(src,args); \

@@ -147,8 +147,14 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
 // FAST Q16 pass on the f16 matrix cores (convolve_mfma.hip); *handled=false when the shape is
 // outside its reach and nothing was launched.  io: 0 = Quantum in and out, 1 = row pass writing
 // the undivided float sums of a separated 2-D kernel, 2 = column pass reading them.
+// 3 = column pass of UnsharpMaskImage fused with its epilogue (unsharp_original, gain, threshold).
 MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const float *taps_device,
-  int ntaps,int shift,bool blend,int io,bool *handled);
+  int ntaps,int shift,bool blend,int io,bool *handled,const View *unsharp_original=nullptr,
+  double gain=0.0,double threshold=0.0);
+// UnsharpMaskImage's column pass + epilogue in one launch: rows = the row pass's result,
+// original = the unblurred frame (effect.c:4343-4372)
+MhStatus launch_conv1d_unsharp(const View &rows,const View &dst,const View &original,
+  const Conv1DParams &params,bool blend,double gain,double threshold,bool *handled);
 // One pass of a separated 2-D kernel through launch_conv1d_mfma (taps uploaded here):
 // vertical = false: src Quantum RGBA -> dst float sums; vertical = true: the reverse
 MhStatus launch_conv1d_sums(const View &src,const View &dst,bool vertical,const Conv1DParams &params,

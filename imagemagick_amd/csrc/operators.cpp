@@ -712,6 +712,41 @@ MH_API MhStatus MagickHipEmbossImage(const MhImage *image,MhImage *emboss_image,
   return convolve_with(image,emboss_image,acquire_emboss_kernel(radius,sigma),"EmbossImage",true);
 }
 
+// FAST, Q16, four channels: the row pass as in BlurImage, then the column pass with the
+// threshold/gain epilogue applied while its results are copied out — the blurred frame is never
+// written or re-read (2 of the 5 frame transfers of the three-kernel form).
+static MhStatus unsharp_fused(const View &src,const View &dst,const MhKernelInfo *kernels,
+  const Roles &roles,double gain,double threshold,bool *fused)
+{
+  *fused=false;
+  const MhKernelInfo *horizontal=kernels,*vertical=kernels != nullptr ? kernels->next : nullptr;
+  if ((precision() != MH_PRECISION_FAST) || (src.quantum != MH_QUANTUM_U16) || (src.channels != 4) ||
+      (src.columns < 2) || (getenv("MAGICKHIP_NO_FUSED_UNSHARP") != nullptr) ||
+      (getenv("MAGICKHIP_NO_MFMA") != nullptr) ||
+      (roles.copy_mask != 0) || (horizontal == nullptr) || (vertical == nullptr) ||
+      (vertical->next != nullptr) || (horizontal->height != 1) || (vertical->width != 1) ||
+      kernel_has_nan(horizontal) || kernel_has_nan(vertical))
+    return MH_OK;
+  if (roles.blend && (roles.alpha != 3))
+    return MH_OK;
+  View rows=src;
+  Temp memory;
+  MH_TRY(memory.alloc(src.device,rows.bytes(),src.stream));
+  rows.pixels=memory.ptr;
+  Conv1DParams first,second;
+  first.taps=horizontal->values;
+  first.ntaps=(int) horizontal->width;
+  first.origin=(int) horizontal->x;
+  second.taps=vertical->values;
+  second.ntaps=(int) vertical->height;
+  second.origin=(int) vertical->y;
+  if ((second.ntaps < 2) || (second.ntaps > 113))
+    return MH_OK;                                // outside the matrix-core kernel's reach
+  MH_TRY(launch_conv1d(src,rows,false,first,roles,MH_PRECISION_FAST,nullptr));
+  MH_TRY(launch_conv1d_unsharp(rows,dst,src,second,roles.blend,gain,threshold,fused));
+  return MH_OK;
+}
+
 MH_API MhStatus MagickHipUnsharpMaskImage(const MhImage *image,MhImage *unsharp_image,
   double radius,double sigma,double gain,double threshold)
 {
@@ -726,11 +761,16 @@ MH_API MhStatus MagickHipUnsharpMaskImage(const MhImage *image,MhImage *unsharp_
   if (status == MH_OK)
     {
       Roles roles=channel_roles(image,unsharp_image);
-      status=morphology_apply(pair.src.view,pair.dst.view,image,roles,MH_MORPHOLOGY_CONVOLVE,1,
-        kernel,0.0,nullptr);
-      if (status == MH_OK)
-        status=launch_unsharp_epilogue(pair.src.view,pair.dst.view,pair.dst.view,gain,threshold,
-          roles);
+      bool fused=false;
+      status=unsharp_fused(pair.src.view,pair.dst.view,kernel,roles,gain,threshold,&fused);
+      if ((status == MH_OK) && !fused)
+        {
+          status=morphology_apply(pair.src.view,pair.dst.view,image,roles,MH_MORPHOLOGY_CONVOLVE,1,
+            kernel,0.0,nullptr);
+          if (status == MH_OK)
+            status=launch_unsharp_epilogue(pair.src.view,pair.dst.view,pair.dst.view,gain,threshold,
+              roles);
+        }
     }
   MhDestroyKernelInfo(kernel);
   if (status != MH_OK)

@@ -224,6 +224,65 @@ def test_convolve_fast_non_separable_kernel_stays_exact(im, refmod):
         im.set_precision(im.PRECISION_EXACT)
 
 
+@pytest.mark.parametrize("shape", [(64, 80), (33, 71), (2, 2), (70, 2), (1, 40), (129, 17)])
+@pytest.mark.parametrize("gain,threshold", [(1.0, 0.02), (2.5, 0.0), (0.6, 0.2), (1.3, 1.0 / 65535.0)])
+def test_unsharp_mask_fast_fused(im, refmod, shape, gain, threshold):
+    """FAST UnsharpMaskImage on RGBA Q16: the column pass applies the threshold/gain epilogue
+    while it copies its results out (no blurred frame in memory).  A blurred sample that
+    differs by one level from the reference's moves the result by at most 1+gain levels, and
+    can flip the threshold test only when 2|p-b| sits on the threshold itself."""
+    import bench
+    px = make_pixels(shape[0], shape[1], 4, Q16, seed=shape[0] + 3 * shape[1])
+    dev, ref = run_pair(im, refmod, px)
+    want = ref.unsharp(0.0, 2.0, gain, threshold).numpy().astype(np.int64)
+    blurred = ref.blur(0.0, 2.0).numpy().astype(np.int64)
+    holder = {}
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        launched = set(bench.kernel_profile(
+            im, lambda: holder.update(out=im.unsharp_mask_image(dev, 0.0, 2.0, gain, threshold)), 1))
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    if shape[1] >= 2:
+        assert launched == {"conv_row", "conv_column"}, launched
+    got = holder["out"].numpy().astype(np.int64)
+    diff = np.abs(got - want)
+    limit = int(np.ceil(1.0 + gain))
+    level = 65535.0 * threshold
+    on_the_edge = np.abs(2 * np.abs(px.astype(np.int64) - blurred) - level) <= 2.0
+    assert int(diff[~on_the_edge].max(initial=0)) <= limit, (int(diff[~on_the_edge].max()), limit)
+    if diff.size >= 2000:
+        assert float((diff == 0).mean()) > 0.97
+
+
+def test_unsharp_mask_fast_four_plain_channels_and_fallbacks(im, refmod):
+    """Four channels without alpha take the fused pass too; RGB (three channels) and the
+    MAGICKHIP_NO_FUSED_UNSHARP switch take the three-kernel form: same contract."""
+    import os
+    px = make_pixels(90, 75, 4, Q16, seed=8)
+    want4 = np.concatenate([refmod.RefImage(px[:, :, :3].copy()).unsharp(0.0, 3.0, 1.5, 0.01).numpy(),
+                            refmod.RefImage(px[:, :, 3].copy()).unsharp(0.0, 3.0, 1.5, 0.01).numpy().reshape(90, 75, 1)],
+                           axis=2).astype(np.int64)
+    rgb = px[:, :, :3].copy()
+    want3 = refmod.RefImage(rgb).unsharp(0.0, 3.0, 1.5, 0.01).numpy().astype(np.int64)
+    want_blend = refmod.RefImage(px).unsharp(0.0, 3.0, 1.5, 0.01).numpy().astype(np.int64)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got4 = im.unsharp_mask_image(im.Image(to_device(px), has_alpha=False), 0.0, 3.0, 1.5, 0.01).numpy()
+        got3 = im.unsharp_mask_image(im.Image(to_device(rgb)), 0.0, 3.0, 1.5, 0.01).numpy()
+        os.environ["MAGICKHIP_NO_FUSED_UNSHARP"] = "1"
+        try:
+            unfused = im.unsharp_mask_image(im.Image(to_device(px)), 0.0, 3.0, 1.5, 0.01).numpy()
+        finally:
+            del os.environ["MAGICKHIP_NO_FUSED_UNSHARP"]
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    for name, got, want in (("plain4", got4, want4), ("rgb", got3, want3), ("unfused", unfused, want_blend)):
+        diff = np.abs(got.astype(np.int64) - want)
+        assert float((diff <= 3).mean()) > 0.999, name
+        assert float((diff == 0).mean()) > 0.9, name
+
+
 def test_blur_fast_matrix_and_vector_paths_agree_within_one_level(im, refmod):
     """MAGICKHIP_NO_MFMA=1 selects the f32 vector kernels: both FAST implementations honour the
     same +-1 contract against the reference (they need not agree with each other exactly)."""
