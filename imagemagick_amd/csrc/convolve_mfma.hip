@@ -285,6 +285,29 @@ void conv_mfma_kernel(ConvMfmaArgs args)
       stage_group=tid % (kStepOutputs/4);
     }
   Raw raw[4];
+  // MFMA_UNSHARP: the unblurred pixels of one step's outputs, in the copy-out's thread layout
+  // (always a valid 16-byte pair: clamped, W >= 2)
+  constexpr int kOriginals=IO == MFMA_UNSHARP ? (G::STEP*G::UNITS/2)/256 : 1;
+  uint4 original[kOriginals];
+#pragma unroll
+  for (int round=0; round < kOriginals; round++)
+    original[round]=make_uint4(0u,0u,0u,0u);
+  auto fetch_original=[&](int unit0,int first_output)
+  {
+    if constexpr (IO == MFMA_UNSHARP)
+      {
+#pragma unroll
+        for (int round=0; round < kOriginals; round++)
+          {
+            const int u=tid+256*round;
+            const int row=u/(G::UNITS/2),pair=u % (G::UNITS/2);
+            int x=unit0+2*pair,y=first_output+row;
+            x=x > args.columns-2 ? args.columns-2 : x;
+            y=y > args.rows-1 ? args.rows-1 : y;
+            original[round]=*reinterpret_cast<const uint4 *>(args.orig+pixel_index(y,args.columns,x)*4);
+          }
+      }
+  };
   // fetch the 4 samples at axis positions pos..pos+3 of this thread's unit (edge clamp,
   // cache.c:2663-2679)
   auto fetch=[&](Raw (&buf)[4],int unit0,int pos)
@@ -404,28 +427,19 @@ void conv_mfma_kernel(ConvMfmaArgs args)
       // previous fetch and issued the next one, so that wait only ever sees old stores.
       if (step_begin+1 < step_end)
         fetch(raw,unit0,in0+R+4*stage_group);
+      fetch_original(unit0,out_begin);
       int base=0;                                // ring slot of the step's first input position
       for (int step=step_begin; step < step_end; step++)
         {
           const int out0=kStepOutputs*step;
           const bool has_next=step+1 < step_end;
           MH_TRACE_MARK(0);
-          // MFMA_UNSHARP: the unblurred pixels of this step's outputs, fetched now and used by the
-          // copy-out at the end of the step (always a valid 16-byte pair: clamped, W >= 2)
-          uint4 original[(kStepOutputs*kStripUnits/2)/256];
-          if constexpr (IO == MFMA_UNSHARP)
-            {
+          // MFMA_UNSHARP: this step's unblurred pixels were fetched a step ago, together with the
+          // samples of the next step; keep them aside, the registers are refilled below
+          uint4 mine[kOriginals];
 #pragma unroll
-              for (int round=0; round < (kStepOutputs*kStripUnits/2)/256; round++)
-                {
-                  const int u=tid+256*round;
-                  const int row=u/(kStripUnits/2),pair=u % (kStripUnits/2);
-                  int x=unit0+2*pair,y=out0+row;
-                  x=x > W-2 ? W-2 : x;
-                  y=y > H-1 ? H-1 : y;
-                  original[round]=*reinterpret_cast<const uint4 *>(args.orig+pixel_index(y,W,x)*4);
-                }
-            }
+          for (int round=0; round < kOriginals; round++)
+            mine[round]=original[round];
           // ---- multiply
           floatx16 acc;
 #pragma unroll
@@ -518,6 +532,7 @@ void conv_mfma_kernel(ConvMfmaArgs args)
 #endif
               if (step+2 < step_end)
                 fetch(raw,unit0,in0+(out0-out_begin)+R+kStepOutputs+4*stage_group);
+              fetch_original(unit0,out0+kStepOutputs);
             }
           MH_TRACE_MARK(5);
           // ---- stores
@@ -566,7 +581,7 @@ void conv_mfma_kernel(ConvMfmaArgs args)
                   uint4 value=*reinterpret_cast<const uint4 *>(from);
                   if constexpr (IO == MFMA_UNSHARP)
                     {
-                      uint4 p=original[round];
+                      uint4 p=mine[round];
                       if (x > W-2)               // the last pixel of an odd row: second half of the clamped pair
                         p=make_uint4(p.z,p.w,p.z,p.w);
                       const uint2 first=unsharp_pixel(make_uint2(p.x,p.y),make_uint2(value.x,value.y),
