@@ -232,7 +232,8 @@ void conv_mfma_kernel(ConvMfmaArgs args)
   static_assert((IO == MFMA_Q16) || ((IO == MFMA_TO_SUMS) && !VERTICAL) ||
     (((IO == MFMA_FROM_SUMS) || (IO == MFMA_UNSHARP)) && VERTICAL),
     "sums are written by a row pass and read by a column pass; the unsharp epilogue is a column pass's");
-  static_assert((IO == MFMA_Q16) || (MODE != MFMA_PLAIN3),"the sums layout has four channels");
+  static_assert((IO != MFMA_UNSHARP) || (MODE != MFMA_PLAIN3),"the fused unsharp copy-out handles 8-byte pixels");
+  // (the sums always have four floats per pixel; for RGB the fourth is zero)
   typedef typename std::conditional<IO == MFMA_FROM_SUMS,uint4,uint2>::type Raw;
   constexpr int PX=MODE == MFMA_PLAIN3 ? 3 : 4;    // u16 per pixel in memory
   typedef MfmaGeometry<VERTICAL,NQ> G;
@@ -723,6 +724,7 @@ MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const 
 {
   *handled=false;
   if ((io == MFMA_UNSHARP) && ((unsharp_original == nullptr) || !vertical || (src.channels != 4) ||
+      (dst.channels != 4) ||
       (src.columns < 2) || (unsharp_original->quantum != MH_QUANTUM_U16)))
     return MH_OK;
   const View &quantum_side=io == MFMA_FROM_SUMS ? dst : src;
@@ -731,16 +733,16 @@ MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const 
   if ((io == MFMA_TO_SUMS) || (io == MFMA_FROM_SUMS))
     {
       const View &sums_side=io == MFMA_FROM_SUMS ? src : dst;
-      if ((sums_side.quantum != MH_QUANTUM_F32) || (src.channels != 4) || (dst.channels != 4) ||
+      if ((sums_side.quantum != MH_QUANTUM_F32) || (sums_side.channels != 4) ||
           (vertical != (io == MFMA_FROM_SUMS)))
         return MH_OK;
     }
-  if ((src.channels != 4) && ((src.channels != 3) || blend))
+  if ((quantum_side.channels != 4) && ((quantum_side.channels != 3) || blend))
     return MH_OK;
   if ((src.columns >= (1u << 24)) || (src.rows >= (1u << 24)) ||
       ((unsigned long long) src.columns*src.rows >= (1ull << 32)))
     return MH_OK;                                // pixel_index()
-  const int mode=blend ? MFMA_BLEND4 : (src.channels == 4 ? MFMA_PLAIN4 : MFMA_PLAIN3);
+  const int mode=blend ? MFMA_BLEND4 : (quantum_side.channels == 4 ? MFMA_PLAIN4 : MFMA_PLAIN3);
   const int nq=(ntaps+31+15)/16;                 // 32 outputs + K-1 halo, in 16-sample chunks
   if (nq > 9)
     return MH_OK;
@@ -767,13 +769,15 @@ MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const 
   case NQV: \
     if (io == MFMA_TO_SUMS) \
       return mode == MFMA_BLEND4 ? launch_mfma_typed<false,NQV,MFMA_BLEND4,MFMA_TO_SUMS>(src,args) : \
-        launch_mfma_typed<false,NQV,MFMA_PLAIN4,MFMA_TO_SUMS>(src,args); \
+        (mode == MFMA_PLAIN4 ? launch_mfma_typed<false,NQV,MFMA_PLAIN4,MFMA_TO_SUMS>(src,args) : \
+         launch_mfma_typed<false,NQV,MFMA_PLAIN3,MFMA_TO_SUMS>(src,args)); \
     if (io == MFMA_UNSHARP) \
       return mode == MFMA_BLEND4 ? launch_mfma_typed<true,NQV,MFMA_BLEND4,MFMA_UNSHARP>(src,args) : \
         launch_mfma_typed<true,NQV,MFMA_PLAIN4,MFMA_UNSHARP>(src,args); \
     if (io == MFMA_FROM_SUMS) \
       return mode == MFMA_BLEND4 ? launch_mfma_typed<true,NQV,MFMA_BLEND4,MFMA_FROM_SUMS>(src,args) : \
-        launch_mfma_typed<true,NQV,MFMA_PLAIN4,MFMA_FROM_SUMS>(src,args); \
+        (mode == MFMA_PLAIN4 ? launch_mfma_typed<true,NQV,MFMA_PLAIN4,MFMA_FROM_SUMS>(src,args) : \
+         launch_mfma_typed<true,NQV,MFMA_PLAIN3,MFMA_FROM_SUMS>(src,args)); \
     if (mode == MFMA_BLEND4) \
       return vertical ? launch_mfma_typed<true,NQV,MFMA_BLEND4,MFMA_Q16>(src,args) : \
         launch_mfma_typed<false,NQV,MFMA_BLEND4,MFMA_Q16>(src,args); \

@@ -126,11 +126,13 @@ static MhStatus separable_convolve(const View &src,const View &dst,const MhKerne
   std::vector<double> row,column;
   if (!rank_one_factors(kernel,row,column))
     return MH_OK;
-  if (src.channels == 4)
+  if ((src.channels == 4) || ((src.channels == 3) && !blend))
     {
-      // both passes on the matrix cores: Quantum pixels -> float sums -> Quantum pixels
+      // both passes on the matrix cores: Quantum pixels -> float sums -> Quantum pixels (four
+      // floats per pixel; the fourth is zero for RGB)
       View sums=src;
       sums.quantum=MH_QUANTUM_F32;
+      sums.channels=4;
       Temp memory;
       MH_TRY(memory.alloc(src.device,sums.bytes(),src.stream));
       sums.pixels=memory.ptr;
