@@ -211,6 +211,25 @@ def test_gaussian_blur_fast_alpha_cases(im, refmod, case):
     assert_parity(got, want, False, "fast gaussian, %s" % case)
 
 
+@pytest.mark.parametrize("channels", [3, 4, 2])
+def test_convolve_fast_outer_product_kernel_with_offset_origin(im, refmod, channels):
+    """A hand-written outer-product kernel (5 x 3, origin off centre, unnormalised) is separated
+    like the Gaussian: the origin of each axis and the reversed walk must carry over."""
+    import bench
+    kernel = ("5x3+1+2: 0.01,0.02,0.03,0.02,0.01 0.02,0.04,0.06,0.04,0.02 0.03,0.06,0.09,0.06,0.03")
+    px = make_pixels(77, 93, channels, Q16, seed=channels)
+    dev, ref = run_pair(im, refmod, px)
+    want = ref.convolve(kernel).numpy()
+    holder = {}
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        launched = set(bench.kernel_profile(im, lambda: holder.update(out=im.convolve_image(dev, kernel)), 1))
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert "morph2d" not in launched, launched
+    assert_parity(holder["out"].numpy(), want, False, "outer-product kernel, %d channels" % channels)
+
+
 def test_convolve_fast_non_separable_kernel_stays_exact(im, refmod):
     """A kernel that is not an outer product takes the generic 2-D kernel in FAST mode too."""
     px = make_pixels(60, 71, 4, Q16, seed=2)
