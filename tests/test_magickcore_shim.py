@@ -62,6 +62,28 @@ def test_large_frame_moves_through_the_staged_transfers(shim, dtype):
     assert accelerated_calls(shim, hdri) == before + 1
 
 
+def test_fast_precision_through_magickcore(shim, im):
+    """MAGICK_HIP_PRECISION=fast (here: MhSetPrecision on the library instance the shim loaded):
+    MagickCore's own BlurImage, GaussianBlurImage (a 2-D kernel, separated by the library) and
+    UnsharpMaskImage (fused column pass) stay within the FAST contract of the CPU MagickCore."""
+    px = make_pixels(96, 120, 4, np.uint16, seed=21)
+    before = accelerated_calls(shim, False)
+    gpu = shim.RefImage(px, shim=True)
+    cpu = shim.RefImage(px)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        blur = gpu.blur(0.0, 3.0).numpy()
+        gauss = gpu.gaussian_blur(0.0, 2.0).numpy()
+        unsharp = gpu.unsharp(0.0, 2.0, 1.0, 0.02).numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert accelerated_calls(shim, False) >= before + 3
+    assert_parity(blur, cpu.blur(0.0, 3.0).numpy(), False, "FAST BlurImage via MagickCore")
+    assert_parity(gauss, cpu.gaussian_blur(0.0, 2.0).numpy(), False, "FAST GaussianBlurImage via MagickCore")
+    diff = np.abs(unsharp.astype(np.int64) - cpu.unsharp(0.0, 2.0, 1.0, 0.02).numpy().astype(np.int64))
+    assert float((diff <= 2).mean()) > 0.999 and float((diff == 0).mean()) > 0.97
+
+
 def test_gate_falls_back_to_cpu(shim):
     """An image the gate rejects (a colourspace the backend does not take) silently runs the
     CPU path — the reference's NULL-return convention."""
