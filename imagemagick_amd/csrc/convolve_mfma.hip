@@ -1,5 +1,10 @@
-// Separable-convolution pass on the matrix cores (FAST precision, Q16 RGBA with
-// alpha-weighted colour channels — BlurImage's case, MagickCore/morphology.c:2654-2979).
+// Separable-convolution pass on the matrix cores (FAST precision, Q16: RGBA with
+// alpha-weighted colour channels — BlurImage's case, MagickCore/morphology.c:2654-2979 —,
+// RGB and four plain channels; template parameter MODE).  The same kernel also runs
+//   * the two passes of a separated 2-D kernel (GaussianBlurImage), which hand the undivided
+//     f32 sums from the row pass to the column pass (IO = MFMA_TO_SUMS / MFMA_FROM_SUMS), and
+//   * UnsharpMaskImage's column pass with its threshold/gain epilogue fused into the copy-out
+//     (IO = MFMA_UNSHARP, effect.c:4364-4369).
 //
 // A K-tap 1-D convolution of a tile is a banded (Toeplitz) matrix product
 //
