@@ -146,6 +146,24 @@ def optimal_kernel_width_1d(radius, sigma):
     return int(_lib.load().MhGetOptimalKernelWidth1D(radius, sigma))
 
 
+def kernel_outer_product_factors(kernel_string):
+    """(row, column) when the first kernel of the string is an outer product column x row —
+    what FAST ConvolveImage separates into two 1-D passes — else None."""
+    lib = _lib.load()
+    ptr = lib.MhAcquireKernelInfo(kernel_string.encode())
+    if not ptr:
+        raise MagickHipError(3, lib.MhGetLastError().decode())
+    try:
+        k = ptr.contents
+        row = np.empty(k.width, dtype=np.float64)
+        column = np.empty(k.height, dtype=np.float64)
+        ok = lib.MhKernelOuterProductFactors(ptr, row.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                             column.ctypes.data_as(ctypes.POINTER(ctypes.c_double)))
+        return (row, column) if ok else None
+    finally:
+        lib.MhDestroyKernelInfo(ptr)
+
+
 def kernel_to_numpy(kernel_string, index=0):
     """Build a kernel list with the product's host builder and return kernel
     `index` as (values[h,w], x, y, count)."""

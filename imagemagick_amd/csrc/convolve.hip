@@ -1489,6 +1489,16 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
     return fail(MH_UNSUPPORTED,"alpha channel must be the last channel");
   if ((params.ntaps < 1) || (params.origin < 0) || (params.origin >= params.ntaps))
     return fail(MH_BAD_ARGUMENT,"conv1d: bad kernel geometry");
+  // Alpha-weighted channels with taps of both signs: sum(k*alpha) can come out near zero, where
+  // the reference's PerceptibleReciprocal clamp decides the pixel and no reduced-precision sum
+  // stays within a level of it.  FAST keeps to the fp64 kernels there.
+  if ((prec == MH_PRECISION_FAST) && roles.blend)
+    for (int v=0; v < params.ntaps; v++)
+      if (params.taps[v] < 0.0)
+        {
+          prec=MH_PRECISION_EXACT;
+          break;
+        }
   if (src.quantum == MH_QUANTUM_U16)
     {
       if (prec == MH_PRECISION_FAST)

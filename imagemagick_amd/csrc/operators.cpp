@@ -106,6 +106,23 @@ static bool rank_one_factors(const MhKernelInfo *k,std::vector<double> &row,std:
   return true;
 }
 
+extern "C" MH_API int MhKernelOuterProductFactors(const MhKernelInfo *kernel,double *row,double *column)
+{
+  if ((kernel == nullptr) || (kernel->values == nullptr) || (kernel->width == 0) || (kernel->height == 0))
+    return 0;
+  for (size_t i=0; i < kernel->width*kernel->height; i++)
+    if (std::isnan(kernel->values[i]))
+      return 0;
+  std::vector<double> r,c;
+  if (!rank_one_factors(kernel,r,c))
+    return 0;
+  if (row != nullptr)
+    std::memcpy(row,r.data(),r.size()*sizeof(double));
+  if (column != nullptr)
+    std::memcpy(column,c.data(),c.size()*sizeof(double));
+  return 1;
+}
+
 // FAST precision, Q16, a 2-D Convolve kernel that is an outer product: two 1-D passes over
 // float sums instead of width*height taps per pixel (GaussianBlurImage 0x10: 79+79 instead of
 // 6241).  Same window, same edge clamp (clamping is per axis) and one division at the end as in
@@ -126,6 +143,19 @@ static MhStatus separable_convolve(const View &src,const View &dst,const MhKerne
   std::vector<double> row,column;
   if (!rank_one_factors(kernel,row,column))
     return MH_OK;
+  if (blend)
+    {
+      // alpha-weighted sums with cells of both signs (Sobel ...): sum(k*alpha) may vanish, the
+      // reference's reciprocal clamp then decides the pixel — the generic fp64 kernel's job
+      bool positive=false,negative=false;
+      for (size_t i=0; i < kernel->width*kernel->height; i++)
+        {
+          positive=positive || (kernel->values[i] > 0.0);
+          negative=negative || (kernel->values[i] < 0.0);
+        }
+      if (positive && negative)
+        return MH_OK;
+    }
   if ((src.channels == 4) || ((src.channels == 3) && !blend))
     {
       // both passes on the matrix cores: Quantum pixels -> float sums -> Quantum pixels (four

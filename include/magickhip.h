@@ -231,6 +231,11 @@ MH_API void MhScaleKernelInfo(MhKernelInfo *kernel,double scaling_factor,unsigne
 /* GetOptimalKernelWidth1D / 2D, gem.c:262,302 */
 MH_API size_t MhGetOptimalKernelWidth1D(double radius,double sigma);
 MH_API size_t MhGetOptimalKernelWidth2D(double radius,double sigma);
+/* Is the 2-D kernel an outer product column[y]*row[x] (to 1e-13 of its largest cell, no NaN
+   cells)?  Returns 1 and fills row[width] / column[height] (either may be NULL), else 0.  FAST
+   ConvolveImage runs such kernels (Gaussian:RxS, i.e. GaussianBlurImage) as two 1-D passes
+   with one division at the end instead of morphology.c:2892-2979's width*height taps. */
+MH_API int MhKernelOuterProductFactors(const MhKernelInfo *kernel,double *row,double *column);
 
 /* MorphologyMethod, MagickCore/morphology.h:72-98 (same values) */
 typedef enum

@@ -230,6 +230,24 @@ def test_convolve_fast_outer_product_kernel_with_offset_origin(im, refmod, chann
     assert_parity(holder["out"].numpy(), want, False, "outer-product kernel, %d channels" % channels)
 
 
+def test_convolve_fast_signed_outer_product_kernel(im, refmod):
+    """Sobel is an outer product with cells of both signs: plain channels (RGB) are separated
+    (+-1), alpha-weighted channels (RGBA) stay on the fp64 kernels in FAST mode (identical),
+    because sum(k*alpha) can vanish there."""
+    rgb = make_pixels(70, 81, 3, Q16, seed=31)
+    rgba = make_pixels(70, 81, 4, Q16, seed=32)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got3 = im.convolve_image(im.Image(to_device(rgb)), "Sobel").numpy()
+        got4 = im.convolve_image(im.Image(to_device(rgba)), "Sobel").numpy()
+        row4 = im.convolve_image(im.Image(to_device(rgba)), "3x1: -1,0,1").numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert_parity(got3, refmod.RefImage(rgb).convolve("Sobel").numpy(), False, "fast Sobel, RGB")
+    assert_parity(got4, refmod.RefImage(rgba).convolve("Sobel").numpy(), True, "fast Sobel, RGBA")
+    assert_parity(row4, refmod.RefImage(rgba).convolve("3x1: -1,0,1").numpy(), True, "fast signed row kernel, RGBA")
+
+
 def test_convolve_fast_non_separable_kernel_stays_exact(im, refmod):
     """A kernel that is not an outer product takes the generic 2-D kernel in FAST mode too."""
     px = make_pixels(60, 71, 4, Q16, seed=2)
