@@ -1456,8 +1456,8 @@ MhStatus launch_conv1d_sums(const View &src,const View &dst,bool vertical,const 
     host[(size_t) v]=(float) params.taps[K-1-v];     // reversed walk, morphology.c:2746
   Temp taps;
   MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(float)));
-  return launch_conv1d_mfma(src,dst,vertical,taps.as<float>(),K,K-1-params.origin,blend,vertical ? 2 : 1,
-    handled);
+  return launch_conv1d_mfma(src,dst,vertical,taps.as<float>(),K,K-1-params.origin,blend,
+    vertical ? MFMA_FROM_SUMS : MFMA_TO_SUMS,handled);
 }
 
 MhStatus launch_conv1d_unsharp(const View &rows,const View &dst,const View &original,
@@ -1474,8 +1474,8 @@ MhStatus launch_conv1d_unsharp(const View &rows,const View &dst,const View &orig
     host[(size_t) v]=(float) params.taps[K-1-v];     // reversed walk, morphology.c:2746
   Temp taps;
   MH_TRY(upload_table(taps,rows.device,rows.stream,host.data(),host.size()*sizeof(float)));
-  return launch_conv1d_mfma(rows,dst,true,taps.as<float>(),K,K-1-params.origin,blend,3,handled,
-    &original,gain,threshold);
+  return launch_conv1d_mfma(rows,dst,true,taps.as<float>(),K,K-1-params.origin,blend,MFMA_UNSHARP,
+    handled,&original,gain,threshold);
 }
 
 MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
@@ -1517,7 +1517,7 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
               Temp taps;
               MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(float)));
               bool handled=false;
-              MH_TRY(launch_conv1d_mfma(src,dst,vertical,taps.as<float>(),K,K-1-params.origin,roles.blend,0,&handled));
+              MH_TRY(launch_conv1d_mfma(src,dst,vertical,taps.as<float>(),K,K-1-params.origin,roles.blend,MFMA_Q16,&handled));
               if (handled)
                 return MH_OK;
             }

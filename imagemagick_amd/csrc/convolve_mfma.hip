@@ -197,15 +197,7 @@ enum MfmaMode { MFMA_BLEND4=0,MFMA_PLAIN4=1,MFMA_PLAIN3=2 };
 struct __attribute__((packed,aligned(2))) Rgb16 { uint16_t c[3]; };
 typedef unsigned short pknorm2 __attribute__((ext_vector_type(2)));
 
-// IO: what a pass reads and writes
-//   MFMA_Q16       Quantum pixels in, Quantum pixels out (BlurImage's passes)
-//   MFMA_TO_SUMS   row pass of a separated 2-D kernel: Quantum pixels in, the four undivided
-//                  f32 sums of a pixel out (16 bytes)
-//   MFMA_FROM_SUMS column pass of a separated 2-D kernel: those sums in, Quantum pixels out —
-//                  one division for the whole 2-D window, as morphology.c:2892-2979
-//   MFMA_UNSHARP   column pass of UnsharpMaskImage: the blurred sample never reaches memory,
-//                  the copy-out applies effect.c:4364-4369 against the unblurred frame
-enum MfmaIo { MFMA_Q16=0,MFMA_TO_SUMS=1,MFMA_FROM_SUMS=2,MFMA_UNSHARP=3 };
+// IO (enum MfmaIo, mh_internal.hpp): what a pass reads and writes.
 
 // UnsharpMaskImage's epilogue for one Quantum-rounded blurred sample b of the sample p
 // (effect.c:4364-4369): p if |2(p-b)| < QuantumRange*threshold, else p+gain*(p-b), clamped and

@@ -144,10 +144,18 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
   const Conv1DParams &params,const Roles &roles,MhPrecision precision,
   unsigned long long *changed_device);
 
+// What a matrix-core pass reads and writes
+//   MFMA_Q16       Quantum pixels in, Quantum pixels out (BlurImage's passes)
+//   MFMA_TO_SUMS   row pass of a separated 2-D kernel: Quantum pixels in, the four undivided
+//                  f32 sums of a pixel out (16 bytes)
+//   MFMA_FROM_SUMS column pass of a separated 2-D kernel: those sums in, Quantum pixels out —
+//                  one division for the whole 2-D window, as morphology.c:2892-2979
+//   MFMA_UNSHARP   column pass of UnsharpMaskImage: the blurred sample never reaches memory,
+//                  the copy-out applies effect.c:4364-4369 against the unblurred frame
+//                  (unsharp_original, gain, threshold)
+enum MfmaIo { MFMA_Q16=0,MFMA_TO_SUMS=1,MFMA_FROM_SUMS=2,MFMA_UNSHARP=3 };
 // FAST Q16 pass on the f16 matrix cores (convolve_mfma.hip); *handled=false when the shape is
-// outside its reach and nothing was launched.  io: 0 = Quantum in and out, 1 = row pass writing
-// the undivided float sums of a separated 2-D kernel, 2 = column pass reading them.
-// 3 = column pass of UnsharpMaskImage fused with its epilogue (unsharp_original, gain, threshold).
+// outside its reach and nothing was launched.  io: an MfmaIo.
 MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const float *taps_device,
   int ntaps,int shift,bool blend,int io,bool *handled,const View *unsharp_original=nullptr,
   double gain=0.0,double threshold=0.0);

@@ -376,24 +376,21 @@ static MhStatus transfer_slice(int device,hipStream_t stream,char *dev,char *hos
       const size_t len=bytes-off < kPiece ? bytes-off : kPiece;
       StagingBlock &b=block[turn];
       hipError_t err=hipEventSynchronize(b.ready);          // the buffer's last transfer is done
-      if (upload)
+      if ((err == hipSuccess) && upload)
         {
           memcpy(b.host,host+off,len);
-          if (err == hipSuccess)
-            err=hipMemcpyAsync(dev+off,b.host,len,hipMemcpyHostToDevice,stream);
+          err=hipMemcpyAsync(dev+off,b.host,len,hipMemcpyHostToDevice,stream);
         }
-      else
-        {
-          if (err == hipSuccess)
-            err=hipMemcpyAsync(b.host,dev+off,len,hipMemcpyDeviceToHost,stream);
-        }
+      else if (err == hipSuccess)
+        err=hipMemcpyAsync(b.host,dev+off,len,hipMemcpyDeviceToHost,stream);
       if (err == hipSuccess)
         err=hipEventRecord(b.ready,stream);
       if ((err == hipSuccess) && !upload && (pending >= 0))
         {
           // while this piece is in flight, hand the previous one to the caller's block
           err=hipEventSynchronize(block[pending].ready);
-          memcpy(host+pending_off,block[pending].host,pending_len);
+          if (err == hipSuccess)
+            memcpy(host+pending_off,block[pending].host,pending_len);
         }
       if (err != hipSuccess)
         status=fail(MH_DEVICE_ERROR,"host transfer: %s",hipGetErrorString(err));
