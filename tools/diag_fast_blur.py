@@ -1,5 +1,6 @@
+import os
 import torch, sys
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import imagemagick_amd as im
 def run(n):
     g = torch.Generator(device="cuda").manual_seed(11)

@@ -1,5 +1,5 @@
 import sys,os,time,torch
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import imagemagick_amd as im, bench
 im.set_precision(im.PRECISION_FAST)
 n=8192

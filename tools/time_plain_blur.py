@@ -1,5 +1,5 @@
 import torch, time, os, sys
-sys.path.insert(0,'/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import imagemagick_amd as im
 im.set_precision(im.PRECISION_FAST)
 def run(ch, alpha, n=8192):
