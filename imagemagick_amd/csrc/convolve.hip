@@ -1511,13 +1511,20 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
               (params.bias == 0.0) && (changed == nullptr) && (getenv("MAGICKHIP_NO_MFMA") == nullptr))
             {
               const int K=params.ntaps;
-              std::vector<float> host((size_t) K);
+              // one table: K doubles (the exact recomputation of ambiguous small alpha levels),
+              // then K floats; both in the reversed walk of morphology.c:2746
+              std::vector<double> host((size_t) K+((size_t) K+1)/2);
+              float *host_floats=reinterpret_cast<float *>(host.data()+K);
               for (int v=0; v < K; v++)
-                host[(size_t) v]=(float) params.taps[K-1-v];     // reversed walk, morphology.c:2746
+                {
+                  host[(size_t) v]=params.taps[K-1-v];
+                  host_floats[v]=(float) params.taps[K-1-v];
+                }
               Temp taps;
-              MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(float)));
+              MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(double)));
               bool handled=false;
-              MH_TRY(launch_conv1d_mfma(src,dst,vertical,taps.as<float>(),K,K-1-params.origin,roles.blend,MFMA_Q16,&handled));
+              MH_TRY(launch_conv1d_mfma(src,dst,vertical,reinterpret_cast<const float *>(taps.as<double>()+K),K,
+                K-1-params.origin,roles.blend,MFMA_Q16,&handled,nullptr,0.0,0.0,taps.as<double>()));
               if (handled)
                 return MH_OK;
             }

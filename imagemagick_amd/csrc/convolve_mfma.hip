@@ -40,6 +40,7 @@
 // work on halos and measured 0.53 ms per pass), multiplies, and leaves.
 #include "mh_internal.hpp"
 #include "device_common.hpp"
+#include "mfma_common.hpp"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -48,10 +49,6 @@
 #include <vector>
 
 namespace mh {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 struct ConvMfmaArgs
 {
@@ -65,6 +62,7 @@ struct ConvMfmaArgs
   int ntaps;
   int shift;                 // K-1-origin: offset of the first input sample
   const float *taps;         // float[K], taps[v] multiplies input o-shift+v
+  const double *taps64;      // the same taps as doubles: exact_alpha_level (row pass, blend mode)
   int strips,segments,steps_per_segment,steps;   // strips of UNITS units, steps of STEP outputs
 };
 
@@ -131,52 +129,10 @@ struct MfmaGeometry
   static constexpr size_t out_bytes=(size_t) OUT*sizeof(uint16_t);
 };
 
-// v = hi + lo with hi the top 11 significant bits of v (mantissa truncated in the integer
-// domain, so the f32 -> f16 conversion of hi is exact whatever its rounding rule) and lo the
-// remainder.  Converting v itself and subtracting the result back is NOT safe: on gfx950 the
-// packed and the scalar f32 -> f16 conversions the compiler mixes disagree on ties (measured:
-// v = 9060.0 between 9056 and 9064 stored one neighbour and subtracted the other, an error
-// of a whole f16 ulp in one sample, +-3 Quantum levels after the pass).
-static __device__ __forceinline__ void split_f16(float v,_Float16 &hi,_Float16 &lo)
-{
-  const float top=__builtin_bit_cast(float,__builtin_bit_cast(unsigned,v) & 0xffffe000u);
-  hi=(_Float16) top;
-  lo=(_Float16) (v-top);
-}
-
-// y*W+x for rows and columns below 2^24 and fewer than 2^32 pixels (launch_conv1d_mfma checks):
-// one full-rate v_mad_u32_u24 instead of a 64-bit multiply
-static __device__ __forceinline__ size_t pixel_index(int y,int W,int x)
-{
-  return (size_t) (__umul24((unsigned) y,(unsigned) W)+(unsigned) x);
-}
-
-// The same split for two non-negative values at once, packed for the LDS planes.
-// v_cvt_pkrtz_f16_f32 truncates (for v >= 0 that is the mantissa mask above) and packs both hi
-// halves; v_fma_mix_f32 reads an f16 half as an operand, so lo = v - hi is one instruction.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-static __device__ __forceinline__ void split_f16_pair(f32x2 v,unsigned &hi,unsigned &lo)
-{
-  hi=__builtin_bit_cast(unsigned,__builtin_amdgcn_cvt_pkrtz(v[0],v[1]));
-  float l0,l1;
-  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi),"v"(v[0]));
-  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi),"v"(v[1]));
-  typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-  half2v l;
-  l[0]=(_Float16) l0;
-  l[1]=(_Float16) l1;
-  lo=__builtin_bit_cast(unsigned,l);
-}
-
 // VERTICAL: units are pixel columns, the filter axis runs down the rows (column pass).
 // 4 waves: wave w multiplies unit group w&1 (8 units = 32 entries) by output group w>>1
 // (32 outputs) of the step.
-// MODE: what the four entries of a pixel are
-//   MFMA_BLEND4  R,G,B weighted by alpha + alpha itself; the epilogue divides by the alpha sum
-//   MFMA_PLAIN4  four independent channels (RGBA without alpha weighting)
-//   MFMA_PLAIN3  three independent channels of a 6-byte pixel (RGB), the fourth entry is zero
-// In the plain modes a sample is a 16-bit integer, so hi (top 11 bits) + lo (the other 5) is exact.
-enum MfmaMode { MFMA_BLEND4=0,MFMA_PLAIN4=1,MFMA_PLAIN3=2 };
+// MODE: an MfmaMode (mfma_common.hpp).
 
 // Diagnostic build only (-DMH_MFMA_TRACE, tools/trace_blur_steps.py): wave 0 of a few workgroups
 // records the shader clock at the phase boundaries of its first steps.
@@ -195,7 +151,6 @@ enum MfmaMode { MFMA_BLEND4=0,MFMA_PLAIN4=1,MFMA_PLAIN3=2 };
 #endif
 
 struct __attribute__((packed,aligned(2))) Rgb16 { uint16_t c[3]; };
-typedef unsigned short pknorm2 __attribute__((ext_vector_type(2)));
 
 // IO (enum MfmaIo, mh_internal.hpp): what a pass reads and writes.
 
@@ -493,6 +448,21 @@ void conv_mfma_kernel(ConvMfmaArgs args)
               const pknorm2 lo2=__builtin_amdgcn_cvt_pknorm_u16(p01[0],p01[1]);
               const pknorm2 hi2=__builtin_amdgcn_cvt_pknorm_u16(p23[0],p23[1]);
               result[pg]=make_uint2(__builtin_bit_cast(unsigned,lo2),__builtin_bit_cast(unsigned,hi2));
+              if constexpr ((MODE == MFMA_BLEND4) && !VERTICAL && (IO == MFMA_Q16))
+                {
+                  // the row pass's alpha becomes a weight in the column pass: exact where it is small
+                  // and the f32 sum cannot decide the level (mfma_common.hpp)
+                  if ((args.taps64 != nullptr) && alpha_sum_is_ambiguous(sa))
+                    {
+                      const int x=out0+32*ng+n,y=unit0+8*mg+2*pg+half;
+                      if ((x < W) && (y < H))
+                        {
+                          const unsigned level=exact_alpha_level(args.src,pixel_index(y,W,0),1,W,x-args.shift,
+                            args.taps64,K);
+                          result[pg].y=(result[pg].y & 0xffffu) | (level << 16);
+                        }
+                    }
+                }
               if (VERTICAL)
                 {
                   const int unit_out=8*mg+2*pg+half;         // D row = (reg&3)+8*(reg>>2)+4*half
@@ -717,7 +687,7 @@ static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
 // MFMA_FROM_SUMS (column pass: src float sums, dst Quantum); the geometry is that of src
 MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const float *taps_device,
   int ntaps,int shift,bool blend,int io,bool *handled,const View *unsharp_original,double gain,
-  double threshold)
+  double threshold,const double *taps64_device)
 {
   *handled=false;
   if ((io == MFMA_UNSHARP) && ((unsharp_original == nullptr) || !vertical || (src.channels != 4) ||
@@ -751,6 +721,7 @@ MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const 
   args.ntaps=ntaps;
   args.shift=shift;
   args.taps=taps_device;
+  args.taps64=taps64_device;
   args.orig=nullptr;
   args.gain=0.0f;
   args.threshold=0;

@@ -1,0 +1,170 @@
+// Device helpers shared by the matrix-core convolution kernels (convolve_mfma.hip: one pass
+// per launch; convolve_fused.hip: BlurImage's two passes in one launch).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace mh {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short pknorm2 __attribute__((ext_vector_type(2)));
+
+// What the four entries of a pixel are
+//   MFMA_BLEND4  R,G,B weighted by alpha + alpha itself; the epilogue divides by the alpha sum
+//   MFMA_PLAIN4  four independent channels (RGBA without alpha weighting)
+//   MFMA_PLAIN3  three independent channels of a 6-byte pixel (RGB), the fourth entry is zero
+// In the plain modes a sample is a 16-bit integer, so hi (top 11 bits) + lo (the other 5) is exact.
+enum MfmaMode { MFMA_BLEND4=0,MFMA_PLAIN4=1,MFMA_PLAIN3=2 };
+
+// v = hi + lo with hi the top 11 significant bits of v (mantissa truncated in the integer
+// domain, so the f32 -> f16 conversion of hi is exact whatever its rounding rule) and lo the
+// remainder.  Converting v itself and subtracting the result back is NOT safe: on gfx950 the
+// packed and the scalar f32 -> f16 conversions the compiler mixes disagree on ties (measured:
+// v = 9060.0 between 9056 and 9064 stored one neighbour and subtracted the other, an error
+// of a whole f16 ulp in one sample, +-3 Quantum levels after the pass).
+static __device__ __forceinline__ void split_f16(float v,_Float16 &hi,_Float16 &lo)
+{
+  const float top=__builtin_bit_cast(float,__builtin_bit_cast(unsigned,v) & 0xffffe000u);
+  hi=(_Float16) top;
+  lo=(_Float16) (v-top);
+}
+
+// y*W+x for rows and columns below 2^24 and fewer than 2^32 pixels (the launchers check):
+// one full-rate v_mad_u32_u24 instead of a 64-bit multiply
+static __device__ __forceinline__ size_t pixel_index(int y,int W,int x)
+{
+  return (size_t) (__umul24((unsigned) y,(unsigned) W)+(unsigned) x);
+}
+
+// The same split for two non-negative values at once, packed for the LDS planes.
+// v_cvt_pkrtz_f16_f32 truncates (for v >= 0 that is the mantissa mask above) and packs both hi
+// halves; v_fma_mix_f32 reads an f16 half as an operand, so lo = v - hi is one instruction.
+static __device__ __forceinline__ void split_f16_pair(f32x2 v,unsigned &hi,unsigned &lo)
+{
+  hi=__builtin_bit_cast(unsigned,__builtin_amdgcn_cvt_pkrtz(v[0],v[1]));
+  float l0,l1;
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi),"v"(v[0]));
+  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi),"v"(v[1]));
+  typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+  half2v l;
+  l[0]=(_Float16) l0;
+  l[1]=(_Float16) l1;
+  lo=__builtin_bit_cast(unsigned,l);
+}
+
+// Toeplitz tap operand of chunk q for output n (lane & 31) and k-half (lane >> 5):
+// T[i] = 256*tap[16q+8*half+i-n], split into hi and lo f16 terms.  tap_lds: float[K] in LDS.
+static __device__ __forceinline__ void toeplitz_operand(const float *tap_lds,int K,int q,int half,int n,
+  half8 &t_hi,half8 &t_lo)
+{
+#pragma unroll
+  for (int i=0; i < 8; i++)
+    {
+      const int j=16*q+8*half+i-n;
+      const float t=((j >= 0) && (j < K)) ? 256.0f*tap_lds[j] : 0.0f;
+      _Float16 h,l;
+      split_f16(t,h,l);
+      t_hi[i]=h;
+      t_lo[i]=l;
+    }
+}
+
+// Four samples (positions p..p+3) of four channels, raw Quantum pixels r[0..3] -> the
+// matrix-core sample values v[channel][pair], pairs of neighbouring positions:
+//   MFMA_BLEND4: alpha*p*2^-17 for the colour channels, alpha/2 for alpha
+//   plain:       p/2 (65535 stays inside the f16 range)
+template<int MODE>
+static __device__ __forceinline__ void quantum_to_samples(const uint2 (&r)[4],f32x2 (&v)[4][2])
+{
+#pragma unroll
+  for (int j=0; j < 2; j++)
+    {
+      const unsigned r0x=r[2*j].x,r0y=r[2*j].y,r1x=r[2*j+1].x,r1y=r[2*j+1].y;
+      const f32x2 c0={(float) (r0x & 0xffffu),(float) (r1x & 0xffffu)};
+      const f32x2 c1={(float) (r0x >> 16),(float) (r1x >> 16)};
+      const f32x2 c2={(float) (r0y & 0xffffu),(float) (r1y & 0xffffu)};
+      const f32x2 c3={(float) (r0y >> 16),(float) (r1y >> 16)};
+      if (MODE == MFMA_BLEND4)
+        {
+          const f32x2 weight=c3*(0.5f/65536.0f);
+          v[0][j]=c0*weight;
+          v[1][j]=c1*weight;
+          v[2][j]=c2*weight;
+          v[3][j]=c3*0.5f;
+        }
+      else
+        {
+          v[0][j]=c0*0.5f;
+          v[1][j]=c1*0.5f;
+          v[2][j]=c2*0.5f;
+          v[3][j]=c3*0.5f;
+        }
+    }
+}
+
+// The epilogue of one pixel: the four f32 sums of a 1-D pass -> four Quantum levels, packed.
+//   S_c = 2^-9 * sum k*alpha*p, S_a = 128 * sum k*alpha:
+//     gamma*pixel = sum(k*alpha*p)/sum(k*alpha) = 65536 * S_c / S_a
+//   v_rcp_f32(0) = inf and 0*inf = NaN convert to 0: PerceptibleReciprocal's clamp for an
+//   all-transparent window.  Plain modes: S_c = 128 * sum k*p.
+// v_cvt_pknorm_u16_f32 rounds 65535*x to the nearest level, clamps to [0,65535], maps NaN to 0
+// and packs two results: the whole quantisation in one instruction.
+template<int MODE>
+static __device__ __forceinline__ uint2 sums_to_quantum(float s0,float s1,float s2,float sa)
+{
+  constexpr float unit=1.0f/(128.0f*65535.0f);
+  const float inv=MODE == MFMA_BLEND4 ? __builtin_amdgcn_rcpf(sa)*(65536.0f/65535.0f) : unit;
+  const f32x2 scale01={inv,inv};
+  const f32x2 scale23={inv,MODE == MFMA_BLEND4 ? unit : inv};
+  const f32x2 p01=f32x2{s0,s1}*scale01;
+  const f32x2 p23=f32x2{s2,sa}*scale23;
+  const pknorm2 lo2=__builtin_amdgcn_cvt_pknorm_u16(p01[0],p01[1]);
+  const pknorm2 hi2=__builtin_amdgcn_cvt_pknorm_u16(p23[0],p23[1]);
+  return make_uint2(__builtin_bit_cast(unsigned,lo2),__builtin_bit_cast(unsigned,hi2));
+}
+
+// BlurImage's row pass hands a Quantum-rounded alpha to the column pass, where it is a WEIGHT:
+// one level more or less in an alpha of a few levels changes that sample's weight by tens of
+// per cent, and the second pass turns that into many levels of colour.  The f32 alpha sum is
+// within alpha_sum_error levels of the exact sum below kSmallAlpha levels (22-bit operands,
+// f32 accumulation of <= 4*3*NQ partial sums); when it lies closer than that to a rounding tie
+// the level is recomputed as the reference does (fp64, its operation order,
+// morphology.c:2941-2951 with the alpha channel's own Update trait) — the intermediate alpha is
+// then bit-identical to the reference's wherever it can matter.
+constexpr float kSmallAlpha=8192.0f;
+constexpr float kAlphaSumError=0.0625f;
+
+static __device__ __forceinline__ bool alpha_sum_is_ambiguous(float sa)
+{
+  const float levels=sa*(1.0f/128.0f);
+  const float fraction=levels-__builtin_floorf(levels);
+  return (levels < kSmallAlpha) && (__builtin_fabsf(fraction-0.5f) < kAlphaSumError);
+}
+
+// sum over v of taps64[v]*alpha(position o-shift+v), edge-clamped, in the reference's order
+// (kernel walked backwards = taps64 forwards), one rounding per multiply and per add
+// (-ffp-contract=off), then ClampToQuantum.  `stride` = distance between consecutive
+// positions in pixels (1 along a row, W down a column).
+static __device__ __forceinline__ unsigned exact_alpha_level(const uint16_t *src,size_t line0,int stride,
+  int extent,int first,const double *taps64,int K)
+{
+  double sum=0.0;
+  for (int v=0; v < K; v++)
+    {
+      int at=first+v;
+      at=at < 0 ? 0 : (at > extent-1 ? extent-1 : at);
+      const double alpha=(double) src[(line0+(size_t) at*(size_t) stride)*4+3];
+      sum=sum+taps64[v]*alpha;
+    }
+  if (!(sum > 0.0))
+    return 0u;
+  if (sum >= 65535.0)
+    return 65535u;
+  return (unsigned) (sum+0.5);
+}
+
+} // namespace mh

@@ -158,7 +158,14 @@ enum MfmaIo { MFMA_Q16=0,MFMA_TO_SUMS=1,MFMA_FROM_SUMS=2,MFMA_UNSHARP=3 };
 // outside its reach and nothing was launched.  io: an MfmaIo.
 MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const float *taps_device,
   int ntaps,int shift,bool blend,int io,bool *handled,const View *unsharp_original=nullptr,
-  double gain=0.0,double threshold=0.0);
+  double gain=0.0,double threshold=0.0,const double *taps64_device=nullptr);
+// BlurImage's two passes in one launch (convolve_fused.hip): the row pass's Quantum-rounded
+// result stays in an LDS ring and never reaches HBM.  taps in the reversed walk of
+// morphology.c:2746 (taps[v] multiplies the input at o-shift+v), as floats and as doubles
+// (the doubles feed the exact recomputation of ambiguous small alpha levels).
+// *handled=false when the shape is outside the kernel's reach and nothing was launched.
+MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_device,
+  const double *taps64_device,int ntaps,int shift,bool blend,bool *handled);
 // UnsharpMaskImage's column pass + epilogue in one launch: rows = the row pass's result,
 // original = the unblurred frame (effect.c:4343-4372)
 MhStatus launch_conv1d_unsharp(const View &rows,const View &dst,const View &original,

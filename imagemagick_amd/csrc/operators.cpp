@@ -301,6 +301,48 @@ struct MorphologyWorkspace
   }
 };
 
+// BlurImage's kernel list — a 1 x K row kernel followed by the same taps as a K x 1 column
+// kernel (effect.c:765-796, "blur:RxS;blur:RxS+90") — in FAST precision on Q16 RGBA: both passes
+// in one launch, the Quantum-rounded intermediate stays in LDS (convolve_fused.hip).
+// *handled = false: not this case, nothing launched.
+static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *kernel,
+  const Roles &roles,double bias,bool *handled)
+{
+  *handled=false;
+  if ((precision() != MH_PRECISION_FAST) || (src.quantum != MH_QUANTUM_U16) || (src.channels != 4) ||
+      (roles.copy_mask != 0) || (bias != 0.0) || (getenv("MAGICKHIP_NO_MFMA") != nullptr) ||
+      (getenv("MAGICKHIP_NO_FUSED_BLUR") != nullptr))
+    return MH_OK;
+  if (roles.blend && (roles.alpha != 3))
+    return MH_OK;
+  const MhKernelInfo *row=kernel,*column=kernel->next;
+  if ((column == nullptr) || (column->next != nullptr) || (row->height != 1) || (column->width != 1) ||
+      (row->width != column->height) || (row->width < 2) || (row->x != column->y) ||
+      (row->x < 0) || ((size_t) row->x >= row->width))
+    return MH_OK;
+  const int K=(int) row->width;
+  for (int v=0; v < K; v++)
+    {
+      if (std::isnan(row->values[v]) || (row->values[v] != column->values[v]))
+        return MH_OK;
+      // alpha-weighted sums with taps of both signs stay on the fp64 kernels (launch_conv1d)
+      if (roles.blend && (row->values[v] < 0.0))
+        return MH_OK;
+    }
+  // one table: K doubles, then K floats; both in the reversed walk of morphology.c:2746
+  std::vector<double> host((size_t) K+((size_t) K+1)/2);
+  float *host_floats=reinterpret_cast<float *>(host.data()+K);
+  for (int v=0; v < K; v++)
+    {
+      host[(size_t) v]=row->values[K-1-v];
+      host_floats[v]=(float) row->values[K-1-v];
+    }
+  Temp taps;
+  MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(double)));
+  return launch_blur_fused(src,dst,reinterpret_cast<const float *>(taps.as<double>()+K),taps.as<double>(),
+    K,K-1-(int) row->x,roles.blend,handled);
+}
+
 // MorphologyApply, morphology.c:3634-4077: the loops over method iterations, the kernel
 // list, the stages of a compound method and the kernel iterations, with the
 // CompositeImage post-steps (:3986-4013 Difference; :4016-4052 multi-kernel union) as
@@ -311,6 +353,14 @@ static MhStatus morphology_apply(const View &src,const View &dst,const MhImage *
 {
   if (iterations == 0)
     return fail(MH_UNSUPPORTED,"morphology: zero iterations is a null operation");
+  if ((method == MH_MORPHOLOGY_CONVOLVE) && (iterations == 1) && (changed_out == nullptr) &&
+      (kernel->next != nullptr))
+    {
+      bool handled=false;
+      MH_TRY(fused_blur(src,dst,kernel,roles,bias,&handled));
+      if (handled)
+        return MH_OK;
+    }
   size_t kernel_limit=iterations < 0 ? (src.columns > src.rows ? src.columns : src.rows) :
     (size_t) iterations;
   size_t method_limit=1,stage_limit=1;

@@ -1,0 +1,189 @@
+"""BASELINE.json's configurations at their REAL sizes against the compiled reference
+(oracle/_ref): C2 8192^2 blur, C3 8192^2 -> 32768^2 Lanczos (float Quantum), C4 4096^2
+sRGB->Lab + ContrastStretch, C5 16384^2 Dilate Disk:15 and UnsharpMask.
+
+The device runs the whole frame, so every strip / segment / tile boundary of the full-size
+launch grids is on the checked path.  The reference runs the whole frame where that takes
+seconds on the GPU box's cores (C2: 13 s, C4), and bands of it where it does not:
+  * translation-invariant stencils (Dilate, UnsharpMask): crops with the operator's reach as
+    halo, compared on their interior;
+  * resize: crops that START at row 0 / column 0 (the contribution windows are computed from
+    absolute coordinates with an added 1e-12, so only a crop with the same origin reproduces
+    them bit for bit), compared up to the filter support before the crop's far edge.
+Bar: EXACT bit-identical; FAST within +-1 Quantum level (1 float ULP for float Quantum) with no
+exempted region."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import to_device, ulp_diff_f32
+
+pytestmark = pytest.mark.gpu
+
+
+def _levels(t):
+    import torch
+    return t.view(torch.int16).to(torch.int32) & 0xffff
+
+
+def _compare_q16(got_dev, want_np, exact, what):
+    """got_dev: device uint16 tensor; want_np: host uint16 array of the same shape."""
+    import torch
+    want = torch.from_numpy(want_np.view(np.int16)).cuda()
+    d = (_levels(got_dev) - _levels(want.view(torch.uint16))).abs()
+    worst = int(d.max())
+    same = float((d == 0).double().mean())
+    limit = 0 if exact else 1
+    assert worst <= limit, "%s: max |device - reference| = %d (limit %d), %d samples over" % (
+        what, worst, limit, int((d > limit).sum()))
+    return same
+
+
+@pytest.fixture(scope="module")
+def c2_case(refmod):
+    """8192^2 uniform-random RGBA with a band of tiny alpha (0..3 levels: the row pass's alpha
+    lands on rounding ties there), a band of small alpha (0..600 levels), a fully transparent
+    band and an opaque band; and the reference's BlurImage(0,10) of it."""
+    n = 8192
+    rng = np.random.default_rng(2024)
+    px = rng.integers(0, 65536, (n, n, 4), dtype=np.uint16)
+    px[: n // 16, :, 3] = rng.integers(0, 4, (n // 16, n))
+    px[n // 16: n // 8, :, 3] = rng.integers(0, 600, (n // 16, n))
+    px[n // 8: n // 8 + 200, :, 3] = 0
+    px[n // 4: n // 4 + 300, :, 3] = 65535
+    refmod.set_thread_limit(os.cpu_count() or 1)
+    want = refmod.RefImage(px).blur(0.0, 10.0).numpy()
+    return px, want
+
+
+def test_c2_blur_exact_full_size(im, c2_case):
+    px, want = c2_case
+    got = im.blur_image(im.Image(to_device(px)), 0.0, 10.0).pixels
+    _compare_q16(got, want, True, "C2 BlurImage EXACT")
+
+
+@pytest.mark.parametrize("path", ["fused", "two_pass", "vector"])
+def test_c2_blur_fast_full_size(im, c2_case, path):
+    """The mode bench.py times, on every path FAST can take: both passes in one launch
+    (convolve_fused.hip), one launch per pass on the matrix cores, and the f32 vector kernels."""
+    px, want = c2_case
+    env = {"fused": {}, "two_pass": {"MAGICKHIP_NO_FUSED_BLUR": "1"}, "vector": {"MAGICKHIP_NO_MFMA": "1"}}[path]
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got = im.blur_image(im.Image(to_device(px)), 0.0, 10.0).pixels
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    same = _compare_q16(got, want, False, "C2 BlurImage FAST (%s)" % path)
+    assert same > 0.97
+
+
+def test_c3_resize_full_size(im, refmod):
+    """8192^2 -> 32768^2 Lanczos, float Quantum RGBA (17 GB result) against the reference on the
+    top band (all columns) and the left band (all rows)."""
+    import torch
+    n, band = 8192, 72
+    g = torch.Generator(device="cuda").manual_seed(33)
+    src = torch.rand((n, n, 4), generator=g, device="cuda", dtype=torch.float32) * 65535.0
+    src[:, : n // 2, 3] = 65535.0                     # half opaque, half varying alpha
+    refmod.set_thread_limit(os.cpu_count() or 1, True)
+    top = src[:band].cpu().numpy()
+    left = src[:, :band].contiguous().cpu().numpy()
+    want_top = refmod.RefImage(top).resize(4 * n, 4 * band, "Lanczos").numpy()
+    want_left = refmod.RefImage(left).resize(4 * band, 4 * n, "Lanczos").numpy()
+    keep = 4 * (band - 8)                             # Lanczos support 3 source pixels (+ margin)
+    for precision, limit in ((im.PRECISION_EXACT, 0), (im.PRECISION_FAST, 1)):
+        im.set_precision(precision)
+        try:
+            out = im.resize_image(im.Image(src), 4 * n, 4 * n, "Lanczos").pixels
+        finally:
+            im.set_precision(im.PRECISION_EXACT)
+        got_top = out[:keep].cpu().numpy()
+        got_left = out[:, :keep].contiguous().cpu().numpy()
+        del out
+        torch.cuda.empty_cache()
+        for name, got, want in (("top band", got_top, want_top[:keep]), ("left band", got_left, want_left[:, :keep])):
+            u = ulp_diff_f32(got, want)
+            assert u.max() <= limit, "C3 resize %s, precision %d: max ULP diff %d, %d samples over" % (
+                name, precision, u.max(), int((u > limit).sum()))
+
+
+def test_c4_lab_contrast_stretch_full_size(im, refmod):
+    """One 4096^2 image of the C4 batch against the reference run on the whole frame."""
+    n = 4096
+    rng = np.random.default_rng(44)
+    px = rng.integers(0, 65536, (n, n, 4), dtype=np.uint16)
+    refmod.set_thread_limit(os.cpu_count() or 1)
+    ref = refmod.RefImage(px).colorspace("Lab")
+    want_lab = ref.numpy()
+    want = ref.contrast_stretch(0.02 * n * n, n * n - 0.01 * n * n).numpy()
+    img = im.Image(to_device(px))
+    im.transform_image_colorspace(img, "Lab")
+    _compare_q16(img.pixels, want_lab, True, "C4 sRGB->Lab")
+    im.contrast_stretch_image(img, 0.02 * n * n, n * n - 0.01 * n * n)
+    _compare_q16(img.pixels, want, True, "C4 Lab + ContrastStretch")
+
+
+def _band_starts(n, band):
+    return [0, n // 2 - band // 2, n - band]
+
+
+def test_c5_dilate_disk15_full_size(im, refmod):
+    """16384^2 RGBA Q16 Dilate Disk:15 (the convex-kernel fast path): three full-width bands and
+    one full-height band of the reference, 15-pixel halo."""
+    import torch
+    n, band, reach = 16384, 192, 15
+    rng = np.random.default_rng(55)
+    px = rng.integers(0, 65536, (n, n, 4), dtype=np.uint16)
+    refmod.set_thread_limit(os.cpu_count() or 1)
+    out = im.morphology_image(im.Image(to_device(px)), "Dilate", 1, "Disk:15").pixels
+    for y0 in _band_starts(n, band):
+        lo, hi = max(y0 - reach, 0), min(y0 + band + reach, n)
+        want = refmod.RefImage(px[lo:hi]).morphology("Dilate", 1, "Disk:15").numpy()
+        _compare_q16(out[y0:y0 + band], want[y0 - lo:y0 - lo + band], True, "C5 Dilate rows %d.." % y0)
+    x0 = n // 3
+    lo, hi = x0 - reach, x0 + 64 + reach
+    want = refmod.RefImage(np.ascontiguousarray(px[:, lo:hi])).morphology("Dilate", 1, "Disk:15").numpy()
+    _compare_q16(out[:, x0:x0 + 64].contiguous(), np.ascontiguousarray(want[:, reach:reach + 64]), True,
+                 "C5 Dilate columns %d.." % x0)
+
+
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+def test_c5_unsharp_full_size(im, refmod, precision):
+    """16384^2 RGBA Q16 UnsharpMask(0x10+1.0+0.02): bands of the reference with the blur's
+    39-pixel reach as halo.  FAST: a blurred sample one level off moves the result by at most
+    1+gain levels (effect.c:4364-4369)."""
+    import torch
+    n, band, reach = 16384, 128, 39
+    rng = np.random.default_rng(56)
+    px = rng.integers(0, 65536, (n, n, 4), dtype=np.uint16)
+    px[:, : n // 4, 3] = 65535
+    refmod.set_thread_limit(os.cpu_count() or 1)
+    im.set_precision(im.PRECISION_FAST if precision == "fast" else im.PRECISION_EXACT)
+    try:
+        out = im.unsharp_mask_image(im.Image(to_device(px)), 0.0, 10.0, 1.0, 0.02).pixels
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    limit = 0 if precision == "exact" else 2
+    level = 65535.0 * 0.02
+    for y0 in _band_starts(n, band):
+        lo, hi = max(y0 - reach, 0), min(y0 + band + reach, n)
+        crop = refmod.RefImage(px[lo:hi])
+        want = crop.unsharp(0.0, 10.0, 1.0, 0.02).numpy()[y0 - lo:y0 - lo + band].astype(np.int64)
+        got = out[y0:y0 + band].cpu().numpy().astype(np.int64)
+        d = np.abs(got - want)
+        if precision == "fast":
+            # a blurred sample one level off can flip the threshold test only when 2|p-b| sits
+            # on the threshold itself (a discontinuity of the operator, the reference's too)
+            blurred = crop.blur(0.0, 10.0).numpy()[y0 - lo:y0 - lo + band].astype(np.int64)
+            on_the_edge = np.abs(2 * np.abs(px[y0:y0 + band].astype(np.int64) - blurred) - level) <= 2.0
+            d = np.where(on_the_edge, 0, d)
+            assert float((d == 0).mean()) > 0.97
+        assert int(d.max()) <= limit, "C5 UnsharpMask %s rows %d..: max diff %d" % (precision, y0, int(d.max()))

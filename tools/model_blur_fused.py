@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Functional model of convolve_fused.hip's index maps (no GPU needed): LDS planes, the lane ->
+operand-line / accumulator-register maps of v_mfma_f32_32x32x16_f16, the ring-group schedule
+and the work-item decomposition, executed lane by lane in NumPy with float64 "matrix cores"
+(operands unsplit), and compared with the oracle's BlurImage.  Index bugs show up here; the
+f16 operand split and the f32 accumulation are the GPU tests' business.
+
+    python tools/model_blur_fused.py [rows cols sigma]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def layout(extent, units, channel_major):
+    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
+              list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32))]
+
+    def ok(S, PAD):
+        CH = units * S + PAD
+        for g in groups:
+            seen = set()
+            for lane in g:
+                ch, unit = (lane >> 3, lane & 7) if channel_major else (lane & 3, lane >> 2)
+                slot = (((ch * CH + unit * S) * 2) % 256) // 16
+                if slot in seen:
+                    return False
+                seen.add(slot)
+        return True
+    for S in range(extent, extent + 65, 8):
+        for PAD in range(8, 65, 8):
+            if ok(S, PAD):
+                return S, PAD
+    return extent, 8
+
+
+def mfma(acc, a_lines, b_lines):
+    """acc[lane][reg] += A x B for one 32x32x16 product.  a_lines[lane] / b_lines[lane]: the 8
+    operand values of a lane.  A: row = lane&31, k = 8*(lane>>5)+i; B: column = lane&31, same k;
+    D: column = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)."""
+    A = np.zeros((32, 16))
+    B = np.zeros((16, 32))
+    for lane in range(64):
+        A[lane & 31, 8 * (lane >> 5):8 * (lane >> 5) + 8] = a_lines[lane]
+        B[8 * (lane >> 5):8 * (lane >> 5) + 8, lane & 31] = b_lines[lane]
+    D = A @ B
+    for lane in range(64):
+        for reg in range(16):
+            acc[lane, reg] += D[(reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), lane & 31]
+
+
+def quantize(v):
+    v = np.where(np.isnan(v) | (v <= 0), 0.0, v)
+    return np.minimum(np.floor(v + 0.5), 65535.0)
+
+
+def run(px, taps, origin, blend=True, segments=1):
+    H, W, _ = px.shape
+    K = len(taps)
+    shift = K - 1 - origin
+    rev = taps[::-1].copy()                       # taps[v] multiplies input o-shift+v
+    NQ = max(3, (K + 31 + 15) // 16)
+    assert NQ <= 7
+    COLS, GROUP, BLOCK = 64, 16, 32
+    RC, XS = 16 * NQ, 16 * NQ + 32
+    SR, PADR = layout(XS, GROUP, True)
+    SC, PADC = layout(RC, COLS, False)
+    CHR, CHC = GROUP * SR + PADR, COLS * SC + PADC
+    OUT_STRIDE = COLS * 4 + 8
+    lds = 2 * 2 * 4 * (CHR + CHC)
+    GPR = XS // 4
+    FETCH_GROUPS = GROUP * GPR
+    strips = (W + COLS - 1) // COLS
+    blocks = (H + BLOCK - 1) // BLOCK
+    bps = (blocks + segments - 1) // segments
+    segments = (blocks + bps - 1) // bps
+    out = np.zeros((H, W, 4))
+    lanes = np.arange(64)
+    n_of, half_of = lanes & 31, lanes >> 5
+    # Toeplitz operands per chunk and lane
+    T = np.zeros((NQ, 64, 8))
+    for q in range(NQ):
+        for lane in range(64):
+            for i in range(8):
+                j = 16 * q + 8 * half_of[lane] + i - n_of[lane]
+                T[q, lane, i] = rev[j] if 0 <= j < K else 0.0
+
+    def samples(p):                               # [.., 4] Quantum -> sample values
+        p = p.astype(np.float64)
+        if blend:
+            v = p.copy()
+            v[..., :3] = p[..., :3] * p[..., 3:4]     # alpha*p (scale factors dropped)
+            return v
+        return p
+
+    def epilogue(s):                              # [.., 4] sums -> Quantum
+        if blend:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                c = s[..., :3] / s[..., 3:4]
+            return quantize(np.concatenate([c, s[..., 3:4]], axis=-1))
+        return quantize(s)
+
+    for item in range(strips * segments):
+        segment, strip = divmod(item, strips)
+        x0 = COLS * strip
+        block_begin = segment * bps
+        block_end = min(block_begin + bps, blocks)
+        nblocks = block_end - block_begin
+        out_begin = BLOCK * block_begin
+        in0, xin0 = out_begin - shift, x0 - shift
+        ngroups = 2 * (nblocks - 1) + NQ
+        ring = np.full(4 * CHC, np.nan)
+        stage = np.full(4 * CHR, np.nan)
+        for g in range(ngroups):
+            stage[:] = np.nan
+            for idx in range(FETCH_GROUPS):
+                row, xg = divmod(idx, GPR)
+                y = min(max(in0 + GROUP * g + row, 0), H - 1)
+                for i in range(4):
+                    x = min(max(xin0 + 4 * xg + i, 0), W - 1)
+                    v = samples(px[y, x])
+                    for c in range(4):
+                        stage[c * CHR + row * SR + 4 * xg + i] = v[c]
+            for wave in range(4):
+                rmg, rng = wave & 1, wave >> 1
+                acc = np.zeros((64, 16))
+                for q in range(NQ):
+                    a = np.zeros((64, 8))
+                    for lane in range(64):
+                        n, half = n_of[lane], half_of[lane]
+                        entry = (n >> 3) * CHR + (8 * rmg + (n & 7)) * SR + 32 * rng + 8 * half + 16 * q
+                        a[lane] = stage[entry:entry + 8]
+                    assert not np.isnan(a).any()
+                    mfma(acc, a, T[q])
+                for lane in range(64):
+                    n, half = n_of[lane], half_of[lane]
+                    sums = np.stack([acc[lane, 4 * c + np.arange(4)] for c in range(4)], axis=-1)   # [i][c]
+                    v = samples(epilogue(sums))
+                    slot = (g % NQ) * GROUP + 8 * rmg + 4 * half
+                    at0 = (32 * rng + n) * SC + slot
+                    for c in range(4):
+                        ring[c * CHC + at0:c * CHC + at0 + 4] = v[:, c]
+            if g >= NQ - 1 and ((g - (NQ - 1)) & 1) == 0:
+                block = (g - (NQ - 1)) >> 1
+                tile = np.full(BLOCK * OUT_STRIDE, np.nan)
+                for wave in range(4):
+                    for t in range(2):
+                        cg = 2 * wave + t
+                        acc = np.zeros((64, 16))
+                        group = (2 * block) % NQ
+                        for q in range(NQ):
+                            a = np.zeros((64, 8))
+                            for lane in range(64):
+                                n, half = n_of[lane], half_of[lane]
+                                at = (n & 3) * CHC + (n >> 2) * SC + 8 * half + 8 * cg * SC + GROUP * group
+                                a[lane] = ring[at:at + 8]
+                            assert not np.isnan(a).any()
+                            mfma(acc, a, T[q])
+                            group = 0 if group + 1 == NQ else group + 1
+                        for lane in range(64):
+                            n, half = n_of[lane], half_of[lane]
+                            for pg in range(4):
+                                r = epilogue(acc[lane, 4 * pg:4 * pg + 4])
+                                at = n * OUT_STRIDE + (8 * cg + 2 * pg + half) * 4
+                                tile[at:at + 4] = r
+                y0 = out_begin + BLOCK * block
+                for u in range(BLOCK * COLS // 2):
+                    row, pair = u >> 5, u & 31
+                    x, y = x0 + 2 * pair, y0 + row
+                    if y < H:
+                        for k in range(2):
+                            if x + k < W:
+                                at = row * OUT_STRIDE + (2 * pair + k) * 4
+                                out[y, x + k] = tile[at:at + 4]
+    return out.astype(np.uint16), lds
+
+
+def main():
+    from oracle import restate
+    rows, cols, sigma = 70, 100, 2.0
+    if len(sys.argv) > 3:
+        rows, cols, sigma = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3])
+    rng = np.random.default_rng(5)
+    px = rng.integers(0, 65536, (rows, cols, 4), dtype=np.uint16)
+    taps = restate.blur_kernel(0.0, sigma)
+    K = len(taps)
+    for segments in (1, 2):
+        got, lds = run(px, np.asarray(taps, dtype=np.float64), (K - 1) // 2, True, segments)
+        want = restate.blur_image(px, 0.0, sigma)
+        d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+        print("K=%d segments=%d LDS=%d bytes: max |model - oracle| = %d, identical %.4f"
+              % (K, segments, lds, d.max(), (d == 0).mean()))
+        assert d.max() <= 1
+
+
+if __name__ == "__main__":
+    main()
