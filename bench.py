@@ -193,7 +193,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * pixels * args.steps / elapsed / 1e6
         # dominant kernel: hipEvent-timed on the launch stream, over the timed steps themselves
-        conv = {k: v for k, v in prof.items() if k.startswith("conv_")}
+        conv = {k: v for k, v in prof.items() if k.startswith("conv_") or k == "blur_fused"}
         dominant = max(conv, key=lambda k: conv[k]["avg_ms"]) if conv else None
         roofline = None
         if dominant:

@@ -1443,6 +1443,61 @@ static MhStatus dispatch_channels(const View &src,const View &dst,bool vertical,
   return fail(MH_UNSUPPORTED,"%d channels",src.channels);
 }
 
+// FAST row pass of an alpha-weighted layout on the f32 vector kernels: the Quantum-rounded alpha
+// it writes becomes a WEIGHT in a following column pass (BlurImage), where one level more or
+// less in a small alpha moves the colour by many levels.  This audit recomputes every alpha
+// result below kSmallAlpha (+1) levels as the reference does — fp64, its operation order
+// (morphology.c:2941-2951), ClampToQuantum — so the intermediate alpha is bit-identical to the
+// reference's wherever a level matters (the matrix-core kernels do the same inside their
+// epilogue, mfma_common.hpp).  Frames without small alpha only pay one read of the alpha
+// samples.
+template<int C>
+__global__ __launch_bounds__(256)
+void conv_row_alpha_audit_kernel(const uint16_t *src,uint16_t *dst,int columns,int rows,
+  const double *taps64,int K,int shift)
+{
+  const size_t total=(size_t) columns*(size_t) rows;
+  for (size_t at=(size_t) blockIdx.x*256u+threadIdx.x; at < total; at+=(size_t) gridDim.x*256u)
+    {
+      if (dst[at*C+(C-1)] > 8192u)
+        continue;
+      const size_t y=at/(size_t) columns;
+      const int x=(int) (at-y*(size_t) columns);
+      const uint16_t *line=src+y*(size_t) columns*C;
+      double sum=0.0;
+      for (int v=0; v < K; v++)
+        {
+          int xx=x-shift+v;
+          xx=xx < 0 ? 0 : (xx > columns-1 ? columns-1 : xx);
+          sum=sum+taps64[v]*(double) line[(size_t) xx*C+(C-1)];
+        }
+      dst[at*C+(C-1)]=QuantumOps<uint16_t>::clamp(sum);
+    }
+}
+
+static MhStatus launch_row_alpha_audit(const View &src,const View &dst,const Conv1DParams &params)
+{
+  const int K=params.ntaps;
+  std::vector<double> host((size_t) K);
+  for (int v=0; v < K; v++)
+    host[(size_t) v]=params.taps[K-1-v];             // reversed walk, morphology.c:2746
+  Temp taps;
+  MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(double)));
+  const size_t total=src.columns*src.rows;
+  const unsigned blocks=(unsigned) ((total+255)/256 < 8192 ? (total+255)/256 : 8192);
+  ProfileScope prof("conv_row_alpha_audit",src.stream);
+  if (src.channels == 4)
+    hipLaunchKernelGGL((conv_row_alpha_audit_kernel<4>),dim3(blocks),dim3(256),0,src.stream,
+      static_cast<const uint16_t *>(src.pixels),static_cast<uint16_t *>(dst.pixels),(int) src.columns,
+      (int) src.rows,taps.as<double>(),K,K-1-params.origin);
+  else
+    hipLaunchKernelGGL((conv_row_alpha_audit_kernel<2>),dim3(blocks),dim3(256),0,src.stream,
+      static_cast<const uint16_t *>(src.pixels),static_cast<uint16_t *>(dst.pixels),(int) src.columns,
+      (int) src.rows,taps.as<double>(),K,K-1-params.origin);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 MhStatus launch_conv1d_sums(const View &src,const View &dst,bool vertical,const Conv1DParams &params,
   bool blend,bool *handled)
 {
@@ -1532,8 +1587,14 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
           // K >= R+1: the ramp-free triangular kernels (measured +7.5 % at K=79 on MI355X;
           // R=24/32 variants were slower: 240 VGPRs leave two waves per SIMD)
           if ((params.ntaps >= 24) && (getenv("MAGICKHIP_NO_TRI") == nullptr))
-            return dispatch_tri<Fast32,16,4>(src,dst,vertical,params,roles,changed);
-          return dispatch_blocked<Fast32,16,4>(src,dst,vertical,params,roles,changed);
+            MH_TRY((dispatch_tri<Fast32,16,4>(src,dst,vertical,params,roles,changed)));
+          else
+            MH_TRY((dispatch_blocked<Fast32,16,4>(src,dst,vertical,params,roles,changed)));
+          // alpha-weighted layouts (gray + alpha, RGBA): small alpha results exact, see above
+          if (!vertical && roles.blend && (params.bias == 0.0) && ((roles.copy_mask >> roles.alpha) & 1u) == 0 &&
+              ((src.channels == 2) || (src.channels == 4)))
+            MH_TRY(launch_row_alpha_audit(src,dst,params));
+          return MH_OK;
         }
       if ((params.ntaps >= 16) && (getenv("MAGICKHIP_NO_TRI") == nullptr))
         return dispatch_tri<Exact64,8,8>(src,dst,vertical,params,roles,changed);

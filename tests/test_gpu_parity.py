@@ -784,10 +784,10 @@ def test_blur_fast_full_size_against_exact(im):
 
     * each pass on its own (the row kernel, and the column kernel fed EXACT's intermediate)
       within +-1 level everywhere, tiny alpha included;
-    * the two-pass blur within +-1 level wherever alpha is not tiny;
-    * in the tiny-alpha band a +-1 difference in an intermediate alpha of 1..2 levels changes
-      that sample's weight by half and is amplified by the second pass (the reference has the
-      same discontinuity), so there only the fraction of such samples is bounded;
+    * the two-pass blur within +-1 level EVERYWHERE: the row pass recomputes an alpha below 8192
+      levels exactly (fp64, the reference's order) whenever its f32 sum lies too close to a
+      rounding tie to decide the level (mfma_common.hpp), so the weights the column pass sees
+      are the reference's own wherever one level matters;
     * a constant image comes back unchanged."""
     import torch
     n = 8192
@@ -822,12 +822,9 @@ def test_blur_fast_full_size_against_exact(im):
         m, same_fraction, _ = worst(got, want)
         assert m <= 1, "%s: max |FAST - EXACT| = %d" % (name, m)
         assert same_fraction > 0.98, name
-    opaque = slice(n // 4 + 64, n)
-    m, same_fraction, _ = worst(fast[opaque], exact[opaque])
-    assert m <= 1, "blur: max |FAST - EXACT| = %d where alpha is not tiny" % m
+    m, same_fraction, _ = worst(fast, exact)
+    assert m <= 1, "blur: max |FAST - EXACT| = %d" % m           # tiny-alpha band included
     assert same_fraction > 0.98
-    _, _, d = worst(fast[: n // 4 + 64], exact[: n // 4 + 64])
-    assert float((d > 1).double().mean()) < 1e-4
     assert int((same.view(torch.int16) != 23456).sum()) == 0
 
 
