@@ -159,7 +159,9 @@ MH_API MhStatus MhContrastStretchLUT(const uint64_t *histogram,uint32_t number_c
           if (intensity > black_point)
             break;
         }
-      const double black=(double) j;
+      // black[i]=(Quantum) j, enhance.c:1668: when no bin exceeds black_point the scan ends with
+      // j = MaxMap+1, which the Q16 build stores as (unsigned short) 65536 = 0
+      const double black=quantum == MH_QUANTUM_U16 ? (double) (j & 0xffff) : (double) j;
       intensity=0.0;
       for (j=(ptrdiff_t) MH_MAXMAP; j != 0; j--)
         {

@@ -1027,7 +1027,10 @@ void lut_stretch_map_kernel(LutBuildArgs a,const LutScratch *scratch)
   if (lut_image_is_gray(a))
     return;
   const int c=(int) blockIdx.x,j=(int) blockIdx.y*1024+(int) threadIdx.x;
-  const int black_i=scratch->black[c],white_i=scratch->white[c];
+  // black[i]=(Quantum) j, enhance.c:1668: a scan that found no bin above black_point ends with
+  // j = 65536, which the Q16 build stores as (unsigned short) 65536 = 0
+  const int black_i=((a.is_u16 != 0) && (scratch->black[c] == 65536)) ? 0 : scratch->black[c];
+  const int white_i=scratch->white[c];
   const double black=(double) black_i,white=(double) white_i;
   // stretch map, enhance.c:1685-1706
   const double gamma=perceptible_reciprocal(white-black);

@@ -52,9 +52,12 @@
 
 static size_t hip_accelerated_calls=0;        /* read by tests through GetMagickHipAcceleratedCalls */
 
+/* operators run concurrently on different images: the counter is atomic */
+#define CountAcceleratedCall() ((void) __atomic_fetch_add(&hip_accelerated_calls,1,__ATOMIC_RELAXED))
+
 MagickExport size_t GetMagickHipAcceleratedCalls(void)
 {
-  return(hip_accelerated_calls);
+  return(__atomic_load_n(&hip_accelerated_calls,__ATOMIC_RELAXED));
 }
 
 /* ------------------------------------------------------------------ gates */
@@ -195,8 +198,11 @@ static void *AcquireDevicePixels(HipLibrary *library,const Image *image,const in
 static void MarkDeviceCopyNewer(const Image *image)
 {
   CacheInfo *cache_info=(CacheInfo *) image->cache;
+  /* the cache hooks read and clear the flag under the same semaphore (CopyOpenCLBuffer) */
+  LockSemaphoreInfo(cache_info->semaphore);
   if (cache_info->opencl != (MagickCLCacheInfo) NULL)
     cache_info->opencl->event_count=1U;
+  UnlockSemaphoreInfo(cache_info->semaphore);
 }
 
 static MagickBooleanType DescribeImage(HipLibrary *library,const Image *image,
@@ -251,6 +257,24 @@ static Image *AcquireResultImage(HipLibrary *library,const Image *image,const si
   return(result);
 }
 
+/*
+  BlurImage and UnsharpMaskImage reach MorphologyImage on the CPU path (effect.c:1170 ->
+  morphology.c:4164-4206), which honours these artifacts: convolve:bias and convolve:scale
+  change the kernel, morphology:compose the way the two kernels' results combine,
+  morphology:showKernel prints it.  The Accelerate* entry points sit in front of that code, so
+  with any of them set they decline; the CPU BlurImage then arrives at the MorphologyApply hook
+  with the scaled kernel and the bias, and is accelerated there.
+*/
+static MagickBooleanType HasMorphologyArtifacts(const Image *image)
+{
+  if ((GetImageArtifact(image,"convolve:bias") != (const char *) NULL) ||
+      (GetImageArtifact(image,"convolve:scale") != (const char *) NULL) ||
+      (GetImageArtifact(image,"morphology:compose") != (const char *) NULL) ||
+      (GetImageArtifact(image,"morphology:showKernel") != (const char *) NULL))
+    return(MagickTrue);
+  return(MagickFalse);
+}
+
 /* ------------------------------------------------------------- operators */
 MagickPrivate Image *AccelerateBlurImage(const Image *image,const double radius,
   const double sigma,ExceptionInfo *exception)
@@ -271,7 +295,7 @@ MagickPrivate Image *AccelerateBlurImage(const Image *image,const double radius,
 
   assert(image != NULL);
   assert(exception != (ExceptionInfo *) NULL);
-  if (IsImageAcceleratable(image) == MagickFalse)
+  if ((IsImageAcceleratable(image) == MagickFalse) || (HasMorphologyArtifacts(image) != MagickFalse))
     return((Image *) NULL);
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
@@ -287,7 +311,7 @@ MagickPrivate Image *AccelerateBlurImage(const Image *image,const double radius,
       (library->BlurImage(&source,&destination,radius,sigma) != MH_OK))
     return(DestroyImage(blur_image));
   blur_image->type=image->type;      /* as MorphologyPrimitive does, morphology.c:2800 */
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(blur_image);
 }
 
@@ -309,7 +333,7 @@ MagickPrivate Image *AccelerateUnsharpMaskImage(const Image *image,
     *p,
     *q;
 
-  if (IsImageAcceleratable(image) == MagickFalse)
+  if ((IsImageAcceleratable(image) == MagickFalse) || (HasMorphologyArtifacts(image) != MagickFalse))
     return((Image *) NULL);
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
@@ -325,7 +349,7 @@ MagickPrivate Image *AccelerateUnsharpMaskImage(const Image *image,
       (library->UnsharpMaskImage(&source,&destination,radius,sigma,gain,threshold) != MH_OK))
     return(DestroyImage(unsharp_image));
   unsharp_image->type=image->type;   /* effect.c:4385 */
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(unsharp_image);
 }
 
@@ -382,7 +406,7 @@ MagickPrivate Image *AccelerateResizeImage(const Image *image,
   if (status != MH_OK)
     return(DestroyImage(resize_image));
   resize_image->type=image->type;    /* resize.c:3872 */
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(resize_image);
 }
 
@@ -409,7 +433,7 @@ MagickPrivate MagickBooleanType AccelerateEqualizeImage(Image *image,
       (library->EqualizeImage(&description) != MH_OK))
     return(MagickFalse);
   MarkDeviceCopyNewer(image);
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(MagickTrue);
 }
 
@@ -442,7 +466,7 @@ MagickPrivate MagickBooleanType AccelerateContrastStretchImage(Image *image,
   MarkDeviceCopyNewer(image);
   if (became_gray != 0)              /* IdentifyImageType side effect, enhance.c:1586-1588 */
     (void) SetImageColorspace(image,GRAYColorspace,exception);
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(MagickTrue);
 }
 
@@ -521,7 +545,7 @@ MagickPrivate Image *AccelerateMorphologyApply(const Image *image,
          kernels,bias) != MH_OK))
     return(DestroyImage(morphology_image));
   morphology_image->type=image->type;                /* morphology.c:2800, :3222 */
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(morphology_image);
 }
 
@@ -620,7 +644,7 @@ MagickPrivate MagickBooleanType AccelerateTransformImageColorspace(Image *image,
       (library->TransformImageColorspace(&description,(MhColorspace) colorspace) != MH_OK))
     return(MagickFalse);
   MarkDeviceCopyNewer(image);
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(SetResidentImageColorspace(library,image,colorspace,exception));
 }
 
@@ -658,7 +682,7 @@ MagickPrivate Image *AccelerateDespeckleImage(const Image *image,ExceptionInfo *
       (library->DespeckleImage(&source,&destination) != MH_OK))
     return(DestroyImage(despeckle_image));
   despeckle_image->type=image->type;       /* effect.c:1486 */
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(despeckle_image);
 }
 
@@ -695,7 +719,7 @@ MagickPrivate Image *AccelerateLocalContrastImage(const Image *image,const doubl
       (DescribeImage(library,contrast_image,q,&destination) == MagickFalse) ||
       (library->LocalContrastImage(&source,&destination,radius,strength) != MH_OK))
     return(DestroyImage(contrast_image));
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(contrast_image);
 }
 
@@ -755,7 +779,7 @@ MagickPrivate Image *AccelerateMotionBlurImage(const Image *image,const double *
         blur_image=DestroyImage(blur_image);
       return((Image *) NULL);
     }
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(blur_image);
 }
 
@@ -792,7 +816,7 @@ MagickPrivate Image *AccelerateRotationalBlurImage(const Image *image,const doub
       (DescribeImage(library,blur_image,q,&destination) == MagickFalse) ||
       (library->RotationalBlurImage(&source,&destination,angle) != MH_OK))
     return(DestroyImage(blur_image));
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(blur_image);
 }
 
@@ -839,7 +863,7 @@ MagickPrivate Image *AccelerateWaveletDenoiseImageSoft(const Image *image,
       (DescribeImage(library,noise_image,q,&destination) == MagickFalse) ||
       (library->WaveletDenoiseImage(&source,&destination,threshold,softness) != MH_OK))
     return(DestroyImage(noise_image));
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(noise_image);
 }
 
@@ -879,7 +903,7 @@ MagickPrivate MagickBooleanType AccelerateFunctionImage(Image *image,
         parameters) != MH_OK)
     return(MagickFalse);
   MarkDeviceCopyNewer(image);
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(MagickTrue);
 }
 
@@ -900,7 +924,7 @@ MagickPrivate MagickBooleanType AccelerateGrayscaleImage(Image *image,
   if (library->GrayscaleImage(&description,(MhIntensityMethod) method) != MH_OK)
     return(MagickFalse);
   MarkDeviceCopyNewer(image);
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(MagickTrue);       /* the caller sets intensity, type and the GRAY colourspace */
 }
 
@@ -920,7 +944,7 @@ MagickPrivate MagickBooleanType AccelerateContrastImage(Image *image,
   if (library->ContrastImage(&description,sharpen != MagickFalse ? 1 : 0) != MH_OK)
     return(MagickFalse);
   MarkDeviceCopyNewer(image);
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(MagickTrue);
 }
 
@@ -952,7 +976,7 @@ MagickPrivate MagickBooleanType AccelerateModulateImage(Image *image,
         (int) colorspace) != MH_OK)
     return(MagickFalse);
   MarkDeviceCopyNewer(image);
-  hip_accelerated_calls++;
+  CountAcceleratedCall();
   return(MagickTrue);
 }
 

@@ -33,6 +33,7 @@
 #include "MagickCore/memory-private.h"
 #include "MagickCore/opencl.h"
 #include "MagickCore/opencl-private.h"
+#include "MagickCore/semaphore.h"
 
 #if defined(MAGICKCORE_OPENCL_SUPPORT)
 
@@ -44,6 +45,7 @@ static HipLibrary hip_library;
 static volatile int hip_library_state=0;      /* 0 = untried, 1 = ready, -1 = unavailable */
 static MagickBooleanType hip_enabled = MagickTrue;
 static size_t hip_uploads=0,hip_downloads=0;
+static SemaphoreInfo *hip_library_semaphore=(SemaphoreInfo *) NULL;
 
 static void *Resolve(void *handle,const char *name,int *missing)
 {
@@ -53,7 +55,32 @@ static void *Resolve(void *handle,const char *name,int *missing)
   return(symbol);
 }
 
+static void LoadHipLibrary(void);
+
 MagickPrivate HipLibrary *AcquireHipLibrary(void)
+{
+  if (hip_enabled == MagickFalse)
+    return((HipLibrary *) NULL);
+  if (__atomic_load_n(&hip_library_state,__ATOMIC_ACQUIRE) > 0)
+    return(hip_library.GetEnabled() != 0 ? &hip_library : (HipLibrary *) NULL);
+  if (__atomic_load_n(&hip_library_state,__ATOMIC_ACQUIRE) < 0)
+    return((HipLibrary *) NULL);
+  /*
+    First use: one thread loads the library and fills the function table, concurrent first
+    callers wait for it (operators run concurrently on different images).
+  */
+  if (hip_library_semaphore == (SemaphoreInfo *) NULL)
+    ActivateSemaphoreInfo(&hip_library_semaphore);
+  LockSemaphoreInfo(hip_library_semaphore);
+  if (hip_library_state == 0)
+    LoadHipLibrary();
+  UnlockSemaphoreInfo(hip_library_semaphore);
+  if (hip_library_state > 0)
+    return(hip_library.GetEnabled() != 0 ? &hip_library : (HipLibrary *) NULL);
+  return((HipLibrary *) NULL);
+}
+
+static void LoadHipLibrary(void)
 {
   const char
     *path;
@@ -61,20 +88,14 @@ MagickPrivate HipLibrary *AcquireHipLibrary(void)
   int
     missing;
 
-  if (hip_enabled == MagickFalse)
-    return((HipLibrary *) NULL);
-  if (hip_library_state > 0)
-    return(hip_library.GetEnabled() != 0 ? &hip_library : (HipLibrary *) NULL);
-  if (hip_library_state < 0)
-    return((HipLibrary *) NULL);
   path=getenv("MAGICK_HIP_LIBRARY");
   if (path == (const char *) NULL)
     path="libmagickhip.so";
   hip_library.handle=dlopen(path,RTLD_NOW | RTLD_LOCAL);
   if (hip_library.handle == NULL)
     {
-      hip_library_state=(-1);
-      return((HipLibrary *) NULL);
+      __atomic_store_n(&hip_library_state,-1,__ATOMIC_RELEASE);
+      return;
     }
   missing=0;
 #define MH_RESOLVE(field,name) *(void **) &hip_library.field=Resolve(hip_library.handle,name,&missing)
@@ -109,25 +130,24 @@ MagickPrivate HipLibrary *AcquireHipLibrary(void)
 #undef MH_RESOLVE
   if ((missing != 0) || (hip_library.Initialize() != MH_OK))
     {
-      hip_library_state=(-1);
-      return((HipLibrary *) NULL);
+      __atomic_store_n(&hip_library_state,-1,__ATOMIC_RELEASE);
+      return;
     }
-  hip_library_state=1;
-  return(hip_library.GetEnabled() != 0 ? &hip_library : (HipLibrary *) NULL);
+  __atomic_store_n(&hip_library_state,1,__ATOMIC_RELEASE);
 }
 
 MagickPrivate void CountHipTransfer(int upload)
 {
   if (upload != 0)
-    hip_uploads++;
+    (void) __atomic_fetch_add(&hip_uploads,1,__ATOMIC_RELAXED);
   else
-    hip_downloads++;
+    (void) __atomic_fetch_add(&hip_downloads,1,__ATOMIC_RELAXED);
 }
 
 MagickExport void GetMagickHipTransfers(size_t *uploads,size_t *downloads)
 {
-  *uploads=hip_uploads;
-  *downloads=hip_downloads;
+  *uploads=__atomic_load_n(&hip_uploads,__ATOMIC_RELAXED);
+  *downloads=__atomic_load_n(&hip_downloads,__ATOMIC_RELAXED);
 }
 
 /* ------------------------------------------------------------- cache hooks */

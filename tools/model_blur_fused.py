@@ -70,7 +70,6 @@ def run(px, taps, origin, blend=True, segments=1):
     SR, PADR = layout(XS, GROUP, True)
     SC, PADC = layout(RC, COLS, False)
     CHR, CHC = GROUP * SR + PADR, COLS * SC + PADC
-    OUT_STRIDE = COLS * 4 + 8
     lds = 2 * 2 * 4 * (CHR + CHC)
     GPR = XS // 4
     FETCH_GROUPS = GROUP * GPR
@@ -146,8 +145,8 @@ def run(px, taps, origin, blend=True, segments=1):
                         ring[c * CHC + at0:c * CHC + at0 + 4] = v[:, c]
             if g >= NQ - 1 and ((g - (NQ - 1)) & 1) == 0:
                 block = (g - (NQ - 1)) >> 1
-                tile = np.full(BLOCK * OUT_STRIDE, np.nan)
                 for wave in range(4):
+                    accs = []
                     for t in range(2):
                         cg = 2 * wave + t
                         acc = np.zeros((64, 16))
@@ -161,21 +160,25 @@ def run(px, taps, origin, blend=True, segments=1):
                             assert not np.isnan(a).any()
                             mfma(acc, a, T[q])
                             group = 0 if group + 1 == NQ else group + 1
-                        for lane in range(64):
-                            n, half = n_of[lane], half_of[lane]
-                            for pg in range(4):
-                                r = epilogue(acc[lane, 4 * pg:4 * pg + 4])
-                                at = n * OUT_STRIDE + (8 * cg + 2 * pg + half) * 4
-                                tile[at:at + 4] = r
-                y0 = out_begin + BLOCK * block
-                for u in range(BLOCK * COLS // 2):
-                    row, pair = u >> 5, u & 31
-                    x, y = x0 + 2 * pair, y0 + row
-                    if y < H:
-                        for k in range(2):
-                            if x + k < W:
-                                at = row * OUT_STRIDE + (2 * pair + k) * 4
-                                out[y, x + k] = tile[at:at + 4]
+                        accs.append(acc)
+                    for t in range(2):
+                        result = np.stack([epilogue(accs[t][:, 4 * pg:4 * pg + 4]) for pg in range(4)], axis=1)  # [lane][pg][c]
+                        for pair in range(2):
+                            # v_permlane32_swap(vdst = result[pair], src0 = result[pair+2]): lanes 32..63 of
+                            # vdst <-> lanes 0..31 of src0
+                            vdst, src0 = result[:, pair].copy(), result[:, pair + 2].copy()
+                            new_vdst, new_src0 = vdst.copy(), src0.copy()
+                            new_vdst[32:] = src0[:32]
+                            new_src0[:32] = vdst[32:]
+                            for lane in range(64):
+                                n, half = n_of[lane], half_of[lane]
+                                x = x0 + 8 * (2 * wave + t) + 4 * half + 2 * pair
+                                y = out_begin + BLOCK * block + n
+                                if y < H:
+                                    if x < W:
+                                        out[y, x] = new_vdst[lane]
+                                    if x + 1 < W:
+                                        out[y, x + 1] = new_src0[lane]
     return out.astype(np.uint16), lds
 
 

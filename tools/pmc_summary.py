@@ -16,7 +16,7 @@ def main(root):
             short = name.split("(")[0].replace("void mh::", "")[:70]
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k in sorted(acc):
-        if "conv" not in k and "resize" not in k and "morph" not in k and "hist" not in k and "lut" not in k \
+        if "conv" not in k and "blur" not in k and "resize" not in k and "morph" not in k and "hist" not in k and "lut" not in k \
            and "color" not in k:
             continue
         print(k)
