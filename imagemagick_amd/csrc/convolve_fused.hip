@@ -386,6 +386,290 @@ static MhStatus launch_fused_typed(const View &src,BlurFusedArgs &args)
   return MH_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second form: the same walk on v_mfma_f32_16x16x32_f16 tiles with SIXTEEN waves per workgroup.
+//
+// The 32x32 form above keeps one wave on each SIMD (its operand registers leave room for no
+// more), and the counters show what that costs (profiles/r2b_*): the matrix pipe is busy 22 % of
+// the time, 28 % is spent at barriers and waitcnts, and half of all cycles go to the VALU
+// stream (conversions, epilogues, address arithmetic) issuing at ~7.6 cycles per instruction —
+// with a single wave on a SIMD every dependent instruction waits out the ALU latency and nothing
+// overlaps the MFMA chains.  16x16x32 tiles need a third of the operand registers (a 32-sample
+// chunk per instruction: three chunks cover the 79 taps' 94-sample band against seven 16-sample
+// chunks for a 32-output tile), so a wave fits in 128 VGPRs and four of them share a SIMD:
+//
+//   row pass     entries e = 4*channel + row    (16 = 4 rows x 4 channels), 16 outputs along x:
+//                16 tiles per 16-row group, one per wave.  D (row = 4*(lane>>4)+reg, col =
+//                lane&15) leaves a lane four consecutive rows of ONE channel of one column — one
+//                8-byte ring store per plane; the alpha sums a colour lane divides by sit in
+//                lanes 48..63 and come over with four ds_bpermute.
+//   column pass  entries e = 4*column + channel (16 = 4 columns x 4 channels), 16 outputs along
+//                y: 16 tiles per 16-row block, one per wave; a lane ends up with the four channels
+//                of one pixel (lane-local division) and stores its 8 bytes.
+//
+// Ring: NG = 2*NC groups of 16 rows (a 16-output tile reads 32*NC rows); every loop iteration
+// is the same: stage group g+..., row pass of group g, column pass of block g-(NG-1).
+template<int NC>
+struct Fused16Geometry
+{
+  static constexpr int COLS=64;                // strip width
+  static constexpr int GROUP=16;               // rows per iteration: one ring group, one output block
+  static constexpr int NG=2*NC;                // ring groups
+  static constexpr int RC=GROUP*NG;            // ring rows = 32*NC: the band of a 16-output tile
+  static constexpr int XS=32*NC+48;            // staged columns: 64 outputs + band
+  static constexpr int SR=XS,PADR=64;          // conflict-free ds_read_b128 (tools/ubench/gen_bank.py rules)
+  static constexpr int SC=RC+8,PADC=8;         // 2-way on reads and on the 8-byte ring stores
+  static constexpr int CHR=GROUP*SR+PADR;
+  static constexpr int CHC=COLS*SC+PADC;
+  static constexpr int STAGE_PLANE=4*CHR,RING_PLANE=4*CHC;
+  static constexpr size_t lds_bytes=(size_t) 2*(STAGE_PLANE+RING_PLANE)*sizeof(_Float16);
+  static_assert(lds_bytes <= 163840,"more than the 160 KiB of a CU");
+  static constexpr int GROUPS_PER_ROW=XS/4;
+  static constexpr int FETCH_GROUPS=GROUP*GROUPS_PER_ROW;
+  static_assert(FETCH_GROUPS <= 1024,"one staging round");
+};
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template<int NC,int MODE>
+__global__ __launch_bounds__(1024)
+void blur_fused16_kernel(BlurFusedArgs args)
+{
+  static_assert((MODE == MFMA_BLEND4) || (MODE == MFMA_PLAIN4),"8-byte pixels");
+  typedef Fused16Geometry<NC> G;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *ring_hi=reinterpret_cast<_Float16 *>(smem_raw);
+  _Float16 *ring_lo=ring_hi+G::RING_PLANE;
+  _Float16 *stage_hi=ring_lo+G::RING_PLANE;
+  _Float16 *stage_lo=stage_hi+G::STAGE_PLANE;
+  const int tid=(int) threadIdx.x,lane=tid & 63;
+  const int wave=__builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n=lane & 15,kq=lane >> 4;
+  const int K=args.ntaps;
+  const int W=args.columns,H=args.rows;
+
+  const int items=args.strips*args.segments;
+  const int item=((int) blockIdx.x & 7)*args.items_per_xcd+((int) blockIdx.x >> 3);
+  if (item >= items)
+    return;
+  const int segment=item/args.strips,strip=item-segment*args.strips;
+  const int x0=G::COLS*strip;
+  const int block_begin=segment*args.blocks_per_segment;
+  const int block_end=block_begin+args.blocks_per_segment < args.blocks ?
+    block_begin+args.blocks_per_segment : args.blocks;
+  const int nblocks=block_end-block_begin;     // blocks of 16 output rows
+  const int out_begin=G::GROUP*block_begin;
+  const int in0=out_begin-args.shift;
+  const int xin0=x0-args.shift;
+  const int ngroups=nblocks+G::NG-1;
+
+  // ---- Toeplitz operands: T[c][i] = 256*tap[32c+8*kq+i-n]
+  half8 t_hi[NC],t_lo[NC];
+  {
+    float *tap_lds=reinterpret_cast<float *>(stage_hi);
+    for (int j=tid; j < K; j+=1024)
+      tap_lds[j]=args.taps[j];
+    __syncthreads();
+#pragma unroll
+    for (int c=0; c < NC; c++)
+#pragma unroll
+      for (int i=0; i < 8; i++)
+        {
+          int j=32*c+8*kq+i-n;
+          const bool inside=(j >= 0) && (j < K);
+          j=inside ? j : 0;
+          const float t=inside ? 256.0f*tap_lds[j] : 0.0f;
+          _Float16 h,l;
+          split_f16(t,h,l);
+          t_hi[c][i]=h;
+          t_lo[c][i]=l;
+        }
+    __syncthreads();                             // tap_lds is the staging plane
+  }
+
+  // ---- staging: thread -> (row, 4 consecutive columns) of the 16 x XS source window
+  const bool stager=tid < G::FETCH_GROUPS;     // wave-uniform (FETCH_GROUPS is a multiple of 64)
+  const int srow=tid/G::GROUPS_PER_ROW,sxg=tid-srow*G::GROUPS_PER_ROW;
+  uint2 raw[4];
+  auto fetch=[&](int g)
+  {
+    if (stager)
+      {
+        int y=in0+G::GROUP*g+srow;
+        y=y < 0 ? 0 : (y > H-1 ? H-1 : y);       // the intermediate's edge clamp (cache.c:2663-2679)
+#pragma unroll
+        for (int i=0; i < 4; i++)
+          {
+            int x=xin0+4*sxg+i;
+            x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
+            raw[i]=*reinterpret_cast<const uint2 *>(args.src+pixel_index(y,W,x)*4);
+          }
+      }
+  };
+  auto stage=[&]()
+  {
+    if (stager)
+      {
+        f32x2 v[4][2];
+        quantum_to_samples<MODE>(raw,v);
+#pragma unroll
+        for (int c=0; c < 4; c++)
+          {
+            uint2 hi,lo;
+            split_f16_pair(v[c][0],hi.x,lo.x);
+            split_f16_pair(v[c][1],hi.y,lo.y);
+            const int at=c*G::CHR+srow*G::SR+4*sxg;
+            *reinterpret_cast<uint2 *>(stage_hi+at)=hi;
+            *reinterpret_cast<uint2 *>(stage_lo+at)=lo;
+          }
+      }
+  };
+
+  // row pass: wave = row quad (4 rows) x output tile (16 columns); entry e = 4*channel+row
+  const int rq=wave & 3,ot=wave >> 2;
+  const int row_entry=(n >> 2)*G::CHR+(4*rq+(n & 3))*G::SR+16*ot+8*kq;
+  // column pass: wave = column quad; entry e = 4*column+channel; a 32-row chunk spans two ring
+  // groups: k 0..15 (kq 0,1) in the first, k 16..31 (kq 2,3) in the next
+  const int col_entry=(n & 3)*G::CHC+(4*wave+(n >> 2))*G::SC+8*(kq & 1);
+
+  fetch(0);
+  for (int g=0; g < ngroups; g++)
+    {
+      stage();
+      if (g+1 < ngroups)
+        fetch(g+1);
+      __syncthreads();                           // X: staged; every wave is past the column pass of g-1
+      // ---- row pass of ring group g
+      {
+        half8 a_hi[NC],a_lo[NC];
+#pragma unroll
+        for (int c=0; c < NC; c++)
+          {
+            a_hi[c]=*reinterpret_cast<const half8 *>(stage_hi+row_entry+32*c);
+            a_lo[c]=*reinterpret_cast<const half8 *>(stage_lo+row_entry+32*c);
+          }
+        floatx4 acc={0.0f,0.0f,0.0f,0.0f};
+#pragma unroll
+        for (int c=0; c < NC; c++)
+          {
+            acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_hi[c],acc,0,0,0);
+            acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[c],t_hi[c],acc,0,0,0);
+            acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_lo[c],acc,0,0,0);
+          }
+        // lane (n, kq): channel kq of the pixels (x0+16*ot+n, rows 4*rq+r), r = register
+        constexpr float unit=1.0f/(128.0f*65535.0f);
+        f32x2 v[2];                              // the column pass's samples, pairs of rows
+        if constexpr (MODE == MFMA_BLEND4)
+          {
+            float sa[4];
+#pragma unroll
+            for (int r=0; r < 4; r++)
+              sa[r]=__shfl(acc[r],48+n,64);      // the alpha sums of this column live in lanes 48..63
+            float scale[4];
+#pragma unroll
+            for (int r=0; r < 4; r++)
+              scale[r]=kq == 3 ? unit : __builtin_amdgcn_rcpf(sa[r])*(65536.0f/65535.0f);
+            const pknorm2 q01=__builtin_amdgcn_cvt_pknorm_u16(acc[0]*scale[0],acc[1]*scale[1]);
+            const pknorm2 q23=__builtin_amdgcn_cvt_pknorm_u16(acc[2]*scale[2],acc[3]*scale[3]);
+            const pknorm2 a01=__builtin_amdgcn_cvt_pknorm_u16(sa[0]*unit,sa[1]*unit);
+            const pknorm2 a23=__builtin_amdgcn_cvt_pknorm_u16(sa[2]*unit,sa[3]*unit);
+            unsigned level[4]={a01[0],a01[1],a23[0],a23[1]};
+            // the row pass's alpha becomes a weight: exact where it is small and the f32 sum
+            // cannot decide the level (mfma_common.hpp); the four lanes of a pixel agree
+#pragma unroll
+            for (int r=0; r < 4; r++)
+              if (alpha_sum_is_ambiguous(sa[r]))
+                {
+                  const int x=x0+16*ot+n;
+                  int y=in0+G::GROUP*g+4*rq+r;
+                  y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
+                  if (x < W)
+                    level[r]=exact_alpha_level(args.src,pixel_index(y,W,0),1,W,x-args.shift,args.taps64,K);
+                }
+            const float value[4]={(float) q01[0],(float) q01[1],(float) q23[0],(float) q23[1]};
+#pragma unroll
+            for (int j=0; j < 2; j++)
+              {
+                const f32x2 alpha={(float) level[2*j],(float) level[2*j+1]};
+                const f32x2 colour={value[2*j],value[2*j+1]};
+                const f32x2 weight=alpha*(0.5f/65536.0f);
+                v[j]=kq == 3 ? alpha*0.5f : colour*weight;
+              }
+          }
+        else
+          {
+            const pknorm2 q01=__builtin_amdgcn_cvt_pknorm_u16(acc[0]*unit,acc[1]*unit);
+            const pknorm2 q23=__builtin_amdgcn_cvt_pknorm_u16(acc[2]*unit,acc[3]*unit);
+            v[0]=f32x2{(float) q01[0],(float) q01[1]}*0.5f;
+            v[1]=f32x2{(float) q23[0],(float) q23[1]}*0.5f;
+          }
+        uint2 hi,lo;
+        split_f16_pair(v[0],hi.x,lo.x);
+        split_f16_pair(v[1],hi.y,lo.y);
+        const int at=kq*G::CHC+(16*ot+n)*G::SC+(g % G::NG)*G::GROUP+4*rq;
+        *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
+        *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
+      }
+      __syncthreads();                           // Y: ring group g complete, staging reads done
+      if (g >= G::NG-1)
+        {
+          // ---- column pass of output rows out_begin+16*block .. +16
+          const int block=g-(G::NG-1);
+          half8 a_hi[NC],a_lo[NC];
+#pragma unroll
+          for (int c=0; c < NC; c++)
+            {
+              int group=block+2*c+(kq >> 1);
+              group=group % G::NG;
+              const int at=col_entry+G::GROUP*group;
+              a_hi[c]=*reinterpret_cast<const half8 *>(ring_hi+at);
+              a_lo[c]=*reinterpret_cast<const half8 *>(ring_lo+at);
+            }
+          floatx4 acc={0.0f,0.0f,0.0f,0.0f};
+#pragma unroll
+          for (int c=0; c < NC; c++)
+            {
+              acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_hi[c],acc,0,0,0);
+              acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[c],t_hi[c],acc,0,0,0);
+              acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_lo[c],acc,0,0,0);
+            }
+          // lane (n, kq): the four channels (registers) of pixel (column 4*wave+kq, row n)
+          const uint2 result=sums_to_quantum<MODE>(acc[0],acc[1],acc[2],acc[3]);
+          const int x=x0+4*wave+kq,y=out_begin+G::GROUP*block+n;
+          if ((x < W) && (y < H))
+            *reinterpret_cast<uint2 *>(args.dst+pixel_index(y,W,x)*4)=result;
+        }
+    }
+}
+
+template<int NC,int MODE>
+static MhStatus launch_fused16_typed(const View &src,BlurFusedArgs &args)
+{
+  typedef Fused16Geometry<NC> G;
+  args.strips=(args.columns+G::COLS-1)/G::COLS;
+  args.blocks=(args.rows+G::GROUP-1)/G::GROUP;
+  // Cut the strips so that every CU gets a work item.  A segment recomputes NG-1 ring groups
+  // (the K-1 halo rows of its first block), so it stays at least 16 blocks long.
+  const int cus=compute_units(src.device);
+  const int max_segments=args.blocks/16 > 1 ? args.blocks/16 : 1;
+  int segments=(cus+args.strips-1)/args.strips;
+  segments=segments < 1 ? 1 : (segments > max_segments ? max_segments : segments);
+  if (const char *e=getenv("MAGICKHIP_FUSED_SEGMENTS"))
+    segments=atoi(e) < 1 ? 1 : (atoi(e) > args.blocks ? args.blocks : atoi(e));
+  args.blocks_per_segment=(args.blocks+segments-1)/segments;
+  args.segments=(args.blocks+args.blocks_per_segment-1)/args.blocks_per_segment;   // no empty segment
+  const int items=args.strips*args.segments;
+  args.items_per_xcd=(items+7)/8;
+  const size_t lds=G::lds_bytes;
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&blur_fused16_kernel<NC,MODE>),
+    hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+  ProfileScope prof("blur_fused",src.stream);
+  hipLaunchKernelGGL((blur_fused16_kernel<NC,MODE>),dim3((unsigned) (8*args.items_per_xcd)),dim3(1024),lds,
+    src.stream,args);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_device,
   const double *taps64_device,int ntaps,int shift,bool blend,bool *handled)
 {
@@ -409,6 +693,16 @@ MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_dev
   args.taps=taps_device;
   args.taps64=taps64_device;
   *handled=true;
+  if (getenv("MAGICKHIP_FUSED_32") == nullptr)
+    {
+      const int nc=(ntaps+15+31)/32;             // 16 outputs + K-1 halo, in 32-sample chunks
+      if (nc == 1)
+        return blend ? launch_fused16_typed<1,MFMA_BLEND4>(src,args) : launch_fused16_typed<1,MFMA_PLAIN4>(src,args);
+      if (nc == 2)
+        return blend ? launch_fused16_typed<2,MFMA_BLEND4>(src,args) : launch_fused16_typed<2,MFMA_PLAIN4>(src,args);
+      if (nc == 3)
+        return blend ? launch_fused16_typed<3,MFMA_BLEND4>(src,args) : launch_fused16_typed<3,MFMA_PLAIN4>(src,args);
+    }
 #define MH_NQ(NQV) \
   case NQV: \
     return blend ? launch_fused_typed<NQV,MFMA_BLEND4>(src,args) : launch_fused_typed<NQV,MFMA_PLAIN4>(src,args);

@@ -44,6 +44,36 @@ MhStatus pool_alloc(int device,size_t bytes,hipStream_t stream,void **ptr);
 void pool_free(int device,void *ptr,hipStream_t stream);
 void pool_trim();
 
+// Makes `device` HIP's current device for the caller's thread and puts the previous one back
+// when it goes out of scope: an operator on a cuda:1 image must not leave the host thread (a
+// MagickCore caller's, or torch's) on device 1.
+struct DeviceGuard
+{
+  int previous=-1;
+  DeviceGuard() = default;
+  DeviceGuard(const DeviceGuard &) = delete; DeviceGuard &operator=(const DeviceGuard &) = delete;
+  ~DeviceGuard() { leave(); }
+  hipError_t enter(int device)
+  {
+    leave();
+    int current=-1;
+    if ((hipGetDevice(&current) == hipSuccess) && (current != device))
+      {
+        hipError_t err=hipSetDevice(device);
+        if (err != hipSuccess)
+          return err;
+        previous=current;
+      }
+    return hipSuccess;
+  }
+  void leave()
+  {
+    if (previous >= 0)
+      (void) hipSetDevice(previous);
+    previous=-1;
+  }
+};
+
 // RAII temp device buffer
 struct Temp
 {

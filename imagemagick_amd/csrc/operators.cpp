@@ -42,6 +42,7 @@ static MhStatus gate_pair(const MhImage *image,const MhImage *out,const char *wh
 // Both images of an operator run on one device and one stream.
 struct Pair
 {
+  DeviceGuard guard;         // declared first: the device is restored after src/dst are gone
   Resident src,dst;
   MhStatus open(const MhImage *image,MhImage *out)
   {
@@ -59,7 +60,7 @@ struct Pair
     dst.view.stream=stream;
     src.view.device=device;
     dst.view.device=device;
-    MH_HIP(hipSetDevice(device));
+    MH_HIP(guard.enter(device));
     return MH_OK;
   }
   MhStatus commit()

@@ -37,6 +37,7 @@ static double scale_map_to_quantum(double value,MhQuantumKind quantum)
 
 struct InPlace
 {
+  DeviceGuard guard;         // declared first: the device is restored after img is gone
   Resident img;
   MhStatus open(MhImage *image)
   {
@@ -46,7 +47,7 @@ struct InPlace
     MH_TRY(img.open(image,2,stream,device));
     img.view.stream=stream;
     img.view.device=device;
-    MH_HIP(hipSetDevice(device));
+    MH_HIP(guard.enter(device));
     return MH_OK;
   }
 };
@@ -230,18 +231,19 @@ MH_API MhStatus MagickHipHistogram(const MhImage *image,int intensity_mode,uint6
   if (histogram == nullptr)
     return fail(MH_BAD_ARGUMENT,"Histogram: null histogram");
   const size_t n=(size_t) MH_HISTOGRAM_BINS*(size_t) image->number_channels;
+  DeviceGuard guard;
   if (image->memory == MH_MEMORY_DEVICE)
     {
       Resident img;
       MH_TRY(img.open(image,0,nullptr,-1));
-      MH_HIP(hipSetDevice(img.view.device));
+      MH_HIP(guard.enter(img.view.device));
       return launch_histogram(img.view,intensity_mode,image,
         reinterpret_cast<unsigned long long *>(histogram));
     }
   Resident img;
   int device=resolve_device(image);
   MH_TRY(img.open(image,0,library_stream(device),device));
-  MH_HIP(hipSetDevice(device));
+  MH_HIP(guard.enter(device));
   std::vector<unsigned long long> host;
   MH_TRY(histogram_to_host(img.view,intensity_mode,image,host));
   for (size_t i=0; i < n; i++)
@@ -271,11 +273,12 @@ MH_API MhStatus MagickHipIsImageGray(const MhImage *image,int *is_gray)
       *is_gray=1;
       return MH_OK;
     }
+  DeviceGuard guard;
   Resident img;
   int device=resolve_device(image);
   MH_TRY(img.open(image,0,image->memory == MH_MEMORY_DEVICE ? (hipStream_t) image->stream :
     library_stream(device),device));
-  MH_HIP(hipSetDevice(img.view.device));
+  MH_HIP(guard.enter(img.view.device));
   Temp flag;
   MH_TRY(flag.alloc(img.view.device,sizeof(unsigned int),img.view.stream));
   MH_HIP(hipMemsetAsync(flag.ptr,0,sizeof(unsigned int),img.view.stream));
@@ -451,6 +454,7 @@ static MhStatus pixel_io(bool import,const MhImage *image,ptrdiff_t x,ptrdiff_t 
   if (element == 0)
     return fail(MH_BAD_ARGUMENT,"%s: unknown storage type %d",what,(int) type);
   const size_t bytes=width*height*strlen(map)*element;
+  DeviceGuard guard;
   Resident img;
   int device=resolve_device(image);
   hipStream_t stream=image->memory == MH_MEMORY_DEVICE ? (hipStream_t) image->stream :
@@ -460,7 +464,7 @@ static MhStatus pixel_io(bool import,const MhImage *image,ptrdiff_t x,ptrdiff_t 
   MH_TRY(img.open(image,import ? 2 : 0,stream,device));
   img.view.stream=stream;
   img.view.device=device;
-  MH_HIP(hipSetDevice(device));
+  MH_HIP(guard.enter(device));
   Temp staged;
   void *buffer=pixels;
   if (pixels_memory == MH_MEMORY_HOST)

@@ -359,7 +359,8 @@ static constexpr size_t kPiece = 4u<<20;
 static MhStatus transfer_slice(int device,hipStream_t stream,char *dev,char *host,size_t bytes,
   size_t first,size_t stride,bool upload)
 {
-  if (hipSetDevice(device) != hipSuccess)
+  DeviceGuard guard;        // slice 0 runs on the caller's own thread
+  if (guard.enter(device) != hipSuccess)
     return fail(MH_DEVICE_ERROR,"hipSetDevice(%d) failed",device);
   StagingBlock block[2];
   int have=0;
@@ -693,11 +694,18 @@ MH_API MhStatus MhDeviceAlloc(int device,size_t bytes,void **ptr)
   if (ptr == nullptr)
     return fail(MH_BAD_ARGUMENT,"null ptr");
   if (device < 0) device=default_device();
-  int prev=0;
-  (void) hipGetDevice(&prev);
-  (void) hipSetDevice(device);
+  DeviceGuard guard;
+  MH_HIP(guard.enter(device));
   hipError_t err=hipMalloc(ptr,bytes);
-  (void) hipSetDevice(prev);
+  if (err != hipSuccess)
+    {
+      // the workspace pool may be holding the memory: give its cached blocks back and retry
+      // (as pool_alloc does), so a caller's image allocation does not fail — and the MagickCore
+      // shim fall back to the CPU — because of scratch space nobody is using
+      (void) hipGetLastError();
+      pool_trim();
+      err=hipMalloc(ptr,bytes);
+    }
   if (err != hipSuccess)
     return fail(MH_OUT_OF_MEMORY,"hipMalloc(%zu): %s",bytes,hipGetErrorString(err));
   return MH_OK;

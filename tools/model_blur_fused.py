@@ -182,6 +182,131 @@ def run(px, taps, origin, blend=True, segments=1):
     return out.astype(np.uint16), lds
 
 
+def mfma16(acc, a_lines, b_lines):
+    """acc[lane][reg] += A x B for one 16x16x32 product.  A: row = lane&15, k = 8*(lane>>4)+i;
+    B: column = lane&15, same k; D: column = lane&15, row = 4*(lane>>4)+reg."""
+    A = np.zeros((16, 32))
+    B = np.zeros((32, 16))
+    for lane in range(64):
+        A[lane & 15, 8 * (lane >> 4):8 * (lane >> 4) + 8] = a_lines[lane]
+        B[8 * (lane >> 4):8 * (lane >> 4) + 8, lane & 15] = b_lines[lane]
+    D = A @ B
+    for lane in range(64):
+        for reg in range(4):
+            acc[lane, reg] += D[4 * (lane >> 4) + reg, lane & 15]
+
+
+def run16(px, taps, origin, blend=True, segments=1):
+    """blur_fused16_kernel: 16 waves, 16x16x32 tiles, NG = 2*NC ring groups, one row group and one
+    column block of 16 rows per iteration."""
+    H, W, _ = px.shape
+    K = len(taps)
+    shift = K - 1 - origin
+    rev = taps[::-1].copy()
+    NC = (K + 15 + 31) // 32
+    assert NC <= 3
+    COLS, GROUP = 64, 16
+    NG = 2 * NC
+    RC, XS = GROUP * NG, 32 * NC + 48
+    SR, PADR, SC, PADC = XS, 64, RC + 8, 8
+    CHR, CHC = GROUP * SR + PADR, COLS * SC + PADC
+    lds = 2 * 2 * 4 * (CHR + CHC)
+    GPR = XS // 4
+    FETCH_GROUPS = GROUP * GPR
+    strips = (W + COLS - 1) // COLS
+    blocks = (H + GROUP - 1) // GROUP
+    bps = (blocks + segments - 1) // segments
+    segments = (blocks + bps - 1) // bps
+    out = np.zeros((H, W, 4))
+    lanes = np.arange(64)
+    n_of, kq_of = lanes & 15, lanes >> 4
+    T = np.zeros((NC, 64, 8))
+    for c in range(NC):
+        for lane in range(64):
+            for i in range(8):
+                j = 32 * c + 8 * kq_of[lane] + i - n_of[lane]
+                T[c, lane, i] = rev[j] if 0 <= j < K else 0.0
+
+    def samples(p):
+        p = p.astype(np.float64)
+        if blend:
+            v = p.copy()
+            v[..., :3] = p[..., :3] * p[..., 3:4]
+            return v
+        return p
+
+    for item in range(strips * segments):
+        segment, strip = divmod(item, strips)
+        x0 = COLS * strip
+        block_begin = segment * bps
+        block_end = min(block_begin + bps, blocks)
+        nblocks = block_end - block_begin
+        out_begin = GROUP * block_begin
+        in0, xin0 = out_begin - shift, x0 - shift
+        ngroups = nblocks + NG - 1
+        ring = np.full(4 * CHC, np.nan)
+        for g in range(ngroups):
+            stage = np.full(4 * CHR, np.nan)
+            for tid in range(FETCH_GROUPS):
+                row, xg = divmod(tid, GPR)
+                y = min(max(in0 + GROUP * g + row, 0), H - 1)
+                for i in range(4):
+                    x = min(max(xin0 + 4 * xg + i, 0), W - 1)
+                    v = samples(px[y, x])
+                    for c in range(4):
+                        stage[c * CHR + row * SR + 4 * xg + i] = v[c]
+            for wave in range(16):
+                rq, ot = wave & 3, wave >> 2
+                acc = np.zeros((64, 4))
+                for c in range(NC):
+                    a = np.zeros((64, 8))
+                    for lane in range(64):
+                        n, kq = n_of[lane], kq_of[lane]
+                        entry = (n >> 2) * CHR + (4 * rq + (n & 3)) * SR + 16 * ot + 8 * kq + 32 * c
+                        a[lane] = stage[entry:entry + 8]
+                    assert not np.isnan(a).any()
+                    mfma16(acc, a, T[c])
+                for lane in range(64):
+                    n, kq = n_of[lane], kq_of[lane]
+                    if blend:
+                        sa = acc[48 + n]                      # __shfl(acc[r], 48+n)
+                        level = quantize(sa)
+                        if kq == 3:
+                            v = level
+                        else:
+                            with np.errstate(divide="ignore", invalid="ignore"):
+                                v = quantize(acc[lane] / sa) * level
+                    else:
+                        v = quantize(acc[lane])
+                    at = kq * CHC + (16 * ot + n) * SC + (g % NG) * GROUP + 4 * rq
+                    ring[at:at + 4] = v
+            if g >= NG - 1:
+                block = g - (NG - 1)
+                for wave in range(16):
+                    acc = np.zeros((64, 4))
+                    for c in range(NC):
+                        a = np.zeros((64, 8))
+                        for lane in range(64):
+                            n, kq = n_of[lane], kq_of[lane]
+                            group = (block + 2 * c + (kq >> 1)) % NG
+                            at = (n & 3) * CHC + (4 * wave + (n >> 2)) * SC + 8 * (kq & 1) + GROUP * group
+                            a[lane] = ring[at:at + 8]
+                        assert not np.isnan(a).any()
+                        mfma16(acc, a, T[c])
+                    for lane in range(64):
+                        n, kq = n_of[lane], kq_of[lane]
+                        s4 = acc[lane]
+                        if blend:
+                            with np.errstate(divide="ignore", invalid="ignore"):
+                                r = quantize(np.concatenate([s4[:3] / s4[3], s4[3:4]]))
+                        else:
+                            r = quantize(s4)
+                        x, y = x0 + 4 * wave + kq, out_begin + GROUP * block + n
+                        if x < W and y < H:
+                            out[y, x] = r
+    return out.astype(np.uint16), lds
+
+
 def main():
     from oracle import restate
     rows, cols, sigma = 70, 100, 2.0
@@ -191,12 +316,12 @@ def main():
     px = rng.integers(0, 65536, (rows, cols, 4), dtype=np.uint16)
     taps = restate.blur_kernel(0.0, sigma)
     K = len(taps)
-    for segments in (1, 2):
-        got, lds = run(px, np.asarray(taps, dtype=np.float64), (K - 1) // 2, True, segments)
+    for form, segments in ((run, 1), (run, 2), (run16, 1), (run16, 2)):
+        got, lds = form(px, np.asarray(taps, dtype=np.float64), (K - 1) // 2, True, segments)
         want = restate.blur_image(px, 0.0, sigma)
         d = np.abs(got.astype(np.int64) - want.astype(np.int64))
-        print("K=%d segments=%d LDS=%d bytes: max |model - oracle| = %d, identical %.4f"
-              % (K, segments, lds, d.max(), (d == 0).mean()))
+        print("%s K=%d segments=%d LDS=%d bytes: max |model - oracle| = %d, identical %.4f"
+              % (form.__name__, K, segments, lds, d.max(), (d == 0).mean()))
         assert d.max() <= 1
 
 
