@@ -531,6 +531,8 @@ void blur_fused16_kernel(BlurFusedArgs args)
   // column pass: wave = column quad; entry e = 4*column+channel; a 32-row chunk spans two ring
   // groups: k 0..15 (kq 0,1) in the first, k 16..31 (kq 2,3) in the next
   const int col_entry=(n & 3)*G::CHC+(4*wave+(n >> 2))*G::SC+8*(kq & 1);
+  const int ring_entry=kq*G::CHC+(16*ot+n)*G::SC+4*rq;     // the row pass's ring store
+  int ring_group=0;                            // g mod NG (wave-uniform)
 
   fetch(0);
   for (int g=0; g < ngroups; g++)
@@ -561,40 +563,49 @@ void blur_fused16_kernel(BlurFusedArgs args)
         f32x2 v[2];                              // the column pass's samples, pairs of rows
         if constexpr (MODE == MFMA_BLEND4)
           {
-            float sa[4];
-#pragma unroll
-            for (int r=0; r < 4; r++)
-              sa[r]=__shfl(acc[r],48+n,64);      // the alpha sums of this column live in lanes 48..63
-            float scale[4];
-#pragma unroll
-            for (int r=0; r < 4; r++)
-              scale[r]=kq == 3 ? unit : __builtin_amdgcn_rcpf(sa[r])*(65536.0f/65535.0f);
-            const pknorm2 q01=__builtin_amdgcn_cvt_pknorm_u16(acc[0]*scale[0],acc[1]*scale[1]);
-            const pknorm2 q23=__builtin_amdgcn_cvt_pknorm_u16(acc[2]*scale[2],acc[3]*scale[3]);
-            const pknorm2 a01=__builtin_amdgcn_cvt_pknorm_u16(sa[0]*unit,sa[1]*unit);
-            const pknorm2 a23=__builtin_amdgcn_cvt_pknorm_u16(sa[2]*unit,sa[3]*unit);
-            unsigned level[4]={a01[0],a01[1],a23[0],a23[1]};
+            // the alpha sums of this column live in lanes 48..63
+            const f32x2 sa01={__shfl(acc[0],48+n,64),__shfl(acc[1],48+n,64)};
+            const f32x2 sa23={__shfl(acc[2],48+n,64),__shfl(acc[3],48+n,64)};
+            // Quantum-rounded colour = 65536*S_c/S_a and alpha = S_a/128 (sums_to_quantum); an alpha
+            // lane computes a meaningless (but finite: NaN -> 0) "colour" and drops it below
+            const f32x2 inv01={__builtin_amdgcn_rcpf(sa01[0]),__builtin_amdgcn_rcpf(sa01[1])};
+            const f32x2 inv23={__builtin_amdgcn_rcpf(sa23[0]),__builtin_amdgcn_rcpf(sa23[1])};
+            const f32x2 p01=f32x2{acc[0],acc[1]}*(inv01*(65536.0f/65535.0f));
+            const f32x2 p23=f32x2{acc[2],acc[3]}*(inv23*(65536.0f/65535.0f));
+            const pknorm2 q01=__builtin_amdgcn_cvt_pknorm_u16(p01[0],p01[1]);
+            const pknorm2 q23=__builtin_amdgcn_cvt_pknorm_u16(p23[0],p23[1]);
+            const f32x2 l01=sa01*unit,l23=sa23*unit;
+            const pknorm2 a01=__builtin_amdgcn_cvt_pknorm_u16(l01[0],l01[1]);
+            const pknorm2 a23=__builtin_amdgcn_cvt_pknorm_u16(l23[0],l23[1]);
+            f32x2 alpha01={(float) a01[0],(float) a01[1]};
+            f32x2 alpha23={(float) a23[0],(float) a23[1]};
             // the row pass's alpha becomes a weight: exact where it is small and the f32 sum
-            // cannot decide the level (mfma_common.hpp); the four lanes of a pixel agree
-#pragma unroll
-            for (int r=0; r < 4; r++)
-              if (alpha_sum_is_ambiguous(sa[r]))
-                {
-                  const int x=x0+16*ot+n;
-                  int y=in0+G::GROUP*g+4*rq+r;
-                  y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
-                  if (x < W)
-                    level[r]=exact_alpha_level(args.src,pixel_index(y,W,0),1,W,x-args.shift,args.taps64,K);
-                }
-            const float value[4]={(float) q01[0],(float) q01[1],(float) q23[0],(float) q23[1]};
-#pragma unroll
-            for (int j=0; j < 2; j++)
+            // cannot decide the level (mfma_common.hpp); the four lanes of a pixel agree.  One
+            // comparison per lane unless the column holds small alpha.
+            const float smallest=__builtin_fminf(__builtin_fminf(sa01[0],sa01[1]),__builtin_fminf(sa23[0],sa23[1]));
+            if (smallest < kSmallAlpha*128.0f)
               {
-                const f32x2 alpha={(float) level[2*j],(float) level[2*j+1]};
-                const f32x2 colour={value[2*j],value[2*j+1]};
-                const f32x2 weight=alpha*(0.5f/65536.0f);
-                v[j]=kq == 3 ? alpha*0.5f : colour*weight;
+                const float sa[4]={sa01[0],sa01[1],sa23[0],sa23[1]};
+                float exact[4]={alpha01[0],alpha01[1],alpha23[0],alpha23[1]};
+#pragma unroll
+                for (int r=0; r < 4; r++)
+                  if (alpha_sum_is_ambiguous(sa[r]))
+                    {
+                      const int x=x0+16*ot+n;
+                      int y=in0+G::GROUP*g+4*rq+r;
+                      y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
+                      if (x < W)
+                        exact[r]=(float) exact_alpha_level(args.src,pixel_index(y,W,0),1,W,x-args.shift,args.taps64,K);
+                    }
+                alpha01=f32x2{exact[0],exact[1]};
+                alpha23=f32x2{exact[2],exact[3]};
               }
+            // sample = alpha*colour*2^-17 (colour lanes) or alpha/2 (alpha lanes): alpha*(colour*c1+c2)
+            const float c1=kq == 3 ? 0.0f : 0.5f/65536.0f,c2=kq == 3 ? 0.5f : 0.0f;
+            const f32x2 colour01={(float) q01[0],(float) q01[1]};
+            const f32x2 colour23={(float) q23[0],(float) q23[1]};
+            v[0]=alpha01*__builtin_elementwise_fma(colour01,f32x2{c1,c1},f32x2{c2,c2});
+            v[1]=alpha23*__builtin_elementwise_fma(colour23,f32x2{c1,c1},f32x2{c2,c2});
           }
         else
           {
@@ -606,7 +617,7 @@ void blur_fused16_kernel(BlurFusedArgs args)
         uint2 hi,lo;
         split_f16_pair(v[0],hi.x,lo.x);
         split_f16_pair(v[1],hi.y,lo.y);
-        const int at=kq*G::CHC+(16*ot+n)*G::SC+(g % G::NG)*G::GROUP+4*rq;
+        const int at=ring_entry+ring_group*G::GROUP;
         *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
         *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
       }
@@ -616,12 +627,15 @@ void blur_fused16_kernel(BlurFusedArgs args)
           // ---- column pass of output rows out_begin+16*block .. +16
           const int block=g-(G::NG-1);
           half8 a_hi[NC],a_lo[NC];
+          // block mod NG = (g+1) mod NG: the group this iteration's row pass did NOT write last
+          const int first=ring_group+1 == G::NG ? 0 : ring_group+1;
 #pragma unroll
           for (int c=0; c < NC; c++)
             {
-              int group=block+2*c+(kq >> 1);
-              group=group % G::NG;
-              const int at=col_entry+G::GROUP*group;
+              // (first + 2c + (kq>>1)) mod NG for a value below 2*NG: min with the wrapped difference
+              const unsigned wide=(unsigned) (first+2*c+(kq >> 1));
+              const unsigned group=wide < wide-(unsigned) G::NG ? wide : wide-(unsigned) G::NG;
+              const int at=col_entry+G::GROUP*(int) group;
               a_hi[c]=*reinterpret_cast<const half8 *>(ring_hi+at);
               a_lo[c]=*reinterpret_cast<const half8 *>(ring_lo+at);
             }
@@ -639,6 +653,7 @@ void blur_fused16_kernel(BlurFusedArgs args)
           if ((x < W) && (y < H))
             *reinterpret_cast<uint2 *>(args.dst+pixel_index(y,W,x)*4)=result;
         }
+      ring_group=ring_group+1 == G::NG ? 0 : ring_group+1;
     }
 }
 

@@ -288,7 +288,8 @@ def run16(px, taps, origin, blend=True, segments=1):
                         a = np.zeros((64, 8))
                         for lane in range(64):
                             n, kq = n_of[lane], kq_of[lane]
-                            group = (block + 2 * c + (kq >> 1)) % NG
+                            wide = ((g % NG) + 1) % NG + 2 * c + (kq >> 1)      # block mod NG = (g+1) mod NG
+                            group = wide if wide < NG else wide - NG
                             at = (n & 3) * CHC + (4 * wave + (n >> 2)) * SC + 8 * (kq & 1) + GROUP * group
                             a[lane] = ring[at:at + 8]
                         assert not np.isnan(a).any()
