@@ -407,15 +407,22 @@ static MhStatus launch_fused_typed(const View &src,BlurFusedArgs &args)
 //                y: 16 tiles per 16-row block, one per wave; a lane ends up with the four channels
 //                of one pixel (lane-local division) and stores its 8 bytes.
 //
-// Ring: NG = 2*NC groups of 16 rows (a 16-output tile reads 32*NC rows); every loop iteration
-// is the same: stage group g+..., row pass of group g, column pass of block g-(NG-1).
+// Ring: a 16-output column tile reads NG = 2*NC groups of 16 rows; the ring holds one more
+// (NR = NG+1), so the column pass of block g-NG only needs groups the PREVIOUS iterations
+// wrote and runs in the same barrier interval as the staging of group g:
+//   iteration g:  stage group g, fetch group g+1, column pass of block g-NG (store) | X |
+//                 row pass of group g -> ring slot g mod NR | Y
+// With the column pass after the row pass of the same iteration (NR = NG) its store sat right in
+// front of the next iteration's wait for the staged loads — gfx9 has one counter for loads and
+// stores, so that wait also waited out the store's round trip: 0.50 ms against 0.xx ms.
 template<int NC>
 struct Fused16Geometry
 {
   static constexpr int COLS=64;                // strip width
   static constexpr int GROUP=16;               // rows per iteration: one ring group, one output block
-  static constexpr int NG=2*NC;                // ring groups
-  static constexpr int RC=GROUP*NG;            // ring rows = 32*NC: the band of a 16-output tile
+  static constexpr int NG=2*NC;                // ring groups a 16-output tile reads: 32*NC rows
+  static constexpr int NR=NG+1;                // ring groups held
+  static constexpr int RC=GROUP*NR;            // ring rows
   static constexpr int XS=32*NC+48;            // staged columns: 64 outputs + band
   static constexpr int SR=XS,PADR=64;          // conflict-free ds_read_b128 (tools/ubench/gen_bank.py rules)
   static constexpr int SC=RC+8,PADC=8;         // 2-way on reads and on the 8-byte ring stores
@@ -532,15 +539,51 @@ void blur_fused16_kernel(BlurFusedArgs args)
   // groups: k 0..15 (kq 0,1) in the first, k 16..31 (kq 2,3) in the next
   const int col_entry=(n & 3)*G::CHC+(4*wave+(n >> 2))*G::SC+8*(kq & 1);
   const int ring_entry=kq*G::CHC+(16*ot+n)*G::SC+4*rq;     // the row pass's ring store
-  int ring_group=0;                            // g mod NG (wave-uniform)
+  int ring_group=0;                            // g mod NR (wave-uniform)
 
   fetch(0);
-  for (int g=0; g < ngroups; g++)
+  for (int g=0; g <= ngroups; g++)
     {
-      stage();
-      if (g+1 < ngroups)
-        fetch(g+1);
-      __syncthreads();                           // X: staged; every wave is past the column pass of g-1
+      if (g < ngroups)
+        {
+          stage();
+          if (g+1 < ngroups)
+            fetch(g+1);
+        }
+      if (g >= G::NG)
+        {
+          // ---- column pass of output rows out_begin+16*block .. +16
+          const int block=g-G::NG;
+          half8 a_hi[NC],a_lo[NC];
+          // block mod NR = (g+1) mod NR (NR = NG+1): the oldest group the ring still holds
+          const int first=ring_group+1 == G::NR ? 0 : ring_group+1;
+#pragma unroll
+          for (int c=0; c < NC; c++)
+            {
+              // (first + 2c + (kq>>1)) mod NR for a value below 2*NR: min with the wrapped difference
+              const unsigned wide=(unsigned) (first+2*c+(kq >> 1));
+              const unsigned group=wide < wide-(unsigned) G::NR ? wide : wide-(unsigned) G::NR;
+              const int at=col_entry+G::GROUP*(int) group;
+              a_hi[c]=*reinterpret_cast<const half8 *>(ring_hi+at);
+              a_lo[c]=*reinterpret_cast<const half8 *>(ring_lo+at);
+            }
+          floatx4 acc={0.0f,0.0f,0.0f,0.0f};
+#pragma unroll
+          for (int c=0; c < NC; c++)
+            {
+              acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_hi[c],acc,0,0,0);
+              acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[c],t_hi[c],acc,0,0,0);
+              acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_lo[c],acc,0,0,0);
+            }
+          // lane (n, kq): the four channels (registers) of pixel (column 4*wave+kq, row n)
+          const uint2 result=sums_to_quantum<MODE>(acc[0],acc[1],acc[2],acc[3]);
+          const int x=x0+4*wave+kq,y=out_begin+G::GROUP*block+n;
+          if ((x < W) && (y < H))
+            *reinterpret_cast<uint2 *>(args.dst+pixel_index(y,W,x)*4)=result;
+        }
+      if (g == ngroups)
+        break;
+      __syncthreads();                           // X: staged; every wave is past the column pass
       // ---- row pass of ring group g
       {
         half8 a_hi[NC],a_lo[NC];
@@ -622,38 +665,7 @@ void blur_fused16_kernel(BlurFusedArgs args)
         *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
       }
       __syncthreads();                           // Y: ring group g complete, staging reads done
-      if (g >= G::NG-1)
-        {
-          // ---- column pass of output rows out_begin+16*block .. +16
-          const int block=g-(G::NG-1);
-          half8 a_hi[NC],a_lo[NC];
-          // block mod NG = (g+1) mod NG: the group this iteration's row pass did NOT write last
-          const int first=ring_group+1 == G::NG ? 0 : ring_group+1;
-#pragma unroll
-          for (int c=0; c < NC; c++)
-            {
-              // (first + 2c + (kq>>1)) mod NG for a value below 2*NG: min with the wrapped difference
-              const unsigned wide=(unsigned) (first+2*c+(kq >> 1));
-              const unsigned group=wide < wide-(unsigned) G::NG ? wide : wide-(unsigned) G::NG;
-              const int at=col_entry+G::GROUP*(int) group;
-              a_hi[c]=*reinterpret_cast<const half8 *>(ring_hi+at);
-              a_lo[c]=*reinterpret_cast<const half8 *>(ring_lo+at);
-            }
-          floatx4 acc={0.0f,0.0f,0.0f,0.0f};
-#pragma unroll
-          for (int c=0; c < NC; c++)
-            {
-              acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_hi[c],acc,0,0,0);
-              acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[c],t_hi[c],acc,0,0,0);
-              acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_lo[c],acc,0,0,0);
-            }
-          // lane (n, kq): the four channels (registers) of pixel (column 4*wave+kq, row n)
-          const uint2 result=sums_to_quantum<MODE>(acc[0],acc[1],acc[2],acc[3]);
-          const int x=x0+4*wave+kq,y=out_begin+G::GROUP*block+n;
-          if ((x < W) && (y < H))
-            *reinterpret_cast<uint2 *>(args.dst+pixel_index(y,W,x)*4)=result;
-        }
-      ring_group=ring_group+1 == G::NG ? 0 : ring_group+1;
+      ring_group=ring_group+1 == G::NR ? 0 : ring_group+1;
     }
 }
 

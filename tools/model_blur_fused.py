@@ -197,8 +197,8 @@ def mfma16(acc, a_lines, b_lines):
 
 
 def run16(px, taps, origin, blend=True, segments=1):
-    """blur_fused16_kernel: 16 waves, 16x16x32 tiles, NG = 2*NC ring groups, one row group and one
-    column block of 16 rows per iteration."""
+    """blur_fused16_kernel: 16 waves, 16x16x32 tiles; a column tile reads NG = 2*NC ring groups, the
+    ring holds NR = NG+1; iteration g: stage g, column block g-NG, row group g."""
     H, W, _ = px.shape
     K = len(taps)
     shift = K - 1 - origin
@@ -207,7 +207,8 @@ def run16(px, taps, origin, blend=True, segments=1):
     assert NC <= 3
     COLS, GROUP = 64, 16
     NG = 2 * NC
-    RC, XS = GROUP * NG, 32 * NC + 48
+    NR = NG + 1
+    RC, XS = GROUP * NR, 32 * NC + 48
     SR, PADR, SC, PADC = XS, 64, RC + 8, 8
     CHR, CHC = GROUP * SR + PADR, COLS * SC + PADC
     lds = 2 * 2 * 4 * (CHR + CHC)
@@ -245,16 +246,44 @@ def run16(px, taps, origin, blend=True, segments=1):
         in0, xin0 = out_begin - shift, x0 - shift
         ngroups = nblocks + NG - 1
         ring = np.full(4 * CHC, np.nan)
-        for g in range(ngroups):
-            stage = np.full(4 * CHR, np.nan)
-            for tid in range(FETCH_GROUPS):
-                row, xg = divmod(tid, GPR)
-                y = min(max(in0 + GROUP * g + row, 0), H - 1)
-                for i in range(4):
-                    x = min(max(xin0 + 4 * xg + i, 0), W - 1)
-                    v = samples(px[y, x])
-                    for c in range(4):
-                        stage[c * CHR + row * SR + 4 * xg + i] = v[c]
+        for g in range(ngroups + 1):
+            if g < ngroups:
+                stage = np.full(4 * CHR, np.nan)
+                for tid in range(FETCH_GROUPS):
+                    row, xg = divmod(tid, GPR)
+                    y = min(max(in0 + GROUP * g + row, 0), H - 1)
+                    for i in range(4):
+                        x = min(max(xin0 + 4 * xg + i, 0), W - 1)
+                        v = samples(px[y, x])
+                        for c in range(4):
+                            stage[c * CHR + row * SR + 4 * xg + i] = v[c]
+            if g >= NG:
+                block = g - NG
+                for wave in range(16):
+                    acc = np.zeros((64, 4))
+                    for c in range(NC):
+                        a = np.zeros((64, 8))
+                        for lane in range(64):
+                            n, kq = n_of[lane], kq_of[lane]
+                            wide = ((g % NR) + 1) % NR + 2 * c + (kq >> 1)      # block mod NR = (g+1) mod NR
+                            group = wide if wide < NR else wide - NR
+                            at = (n & 3) * CHC + (4 * wave + (n >> 2)) * SC + 8 * (kq & 1) + GROUP * group
+                            a[lane] = ring[at:at + 8]
+                        assert not np.isnan(a).any()
+                        mfma16(acc, a, T[c])
+                    for lane in range(64):
+                        n, kq = n_of[lane], kq_of[lane]
+                        s4 = acc[lane]
+                        if blend:
+                            with np.errstate(divide="ignore", invalid="ignore"):
+                                r = quantize(np.concatenate([s4[:3] / s4[3], s4[3:4]]))
+                        else:
+                            r = quantize(s4)
+                        x, y = x0 + 4 * wave + kq, out_begin + GROUP * block + n
+                        if x < W and y < H:
+                            out[y, x] = r
+            if g == ngroups:
+                break
             for wave in range(16):
                 rq, ot = wave & 3, wave >> 2
                 acc = np.zeros((64, 4))
@@ -278,33 +307,8 @@ def run16(px, taps, origin, blend=True, segments=1):
                                 v = quantize(acc[lane] / sa) * level
                     else:
                         v = quantize(acc[lane])
-                    at = kq * CHC + (16 * ot + n) * SC + (g % NG) * GROUP + 4 * rq
+                    at = kq * CHC + (16 * ot + n) * SC + (g % NR) * GROUP + 4 * rq
                     ring[at:at + 4] = v
-            if g >= NG - 1:
-                block = g - (NG - 1)
-                for wave in range(16):
-                    acc = np.zeros((64, 4))
-                    for c in range(NC):
-                        a = np.zeros((64, 8))
-                        for lane in range(64):
-                            n, kq = n_of[lane], kq_of[lane]
-                            wide = ((g % NG) + 1) % NG + 2 * c + (kq >> 1)      # block mod NG = (g+1) mod NG
-                            group = wide if wide < NG else wide - NG
-                            at = (n & 3) * CHC + (4 * wave + (n >> 2)) * SC + 8 * (kq & 1) + GROUP * group
-                            a[lane] = ring[at:at + 8]
-                        assert not np.isnan(a).any()
-                        mfma16(acc, a, T[c])
-                    for lane in range(64):
-                        n, kq = n_of[lane], kq_of[lane]
-                        s4 = acc[lane]
-                        if blend:
-                            with np.errstate(divide="ignore", invalid="ignore"):
-                                r = quantize(np.concatenate([s4[:3] / s4[3], s4[3:4]]))
-                        else:
-                            r = quantize(s4)
-                        x, y = x0 + 4 * wave + kq, out_begin + GROUP * block + n
-                        if x < W and y < H:
-                            out[y, x] = r
     return out.astype(np.uint16), lds
 
 
