@@ -415,6 +415,51 @@ static MhStatus launch_fused_typed(const View &src,BlurFusedArgs &args)
 // With the column pass after the row pass of the same iteration (NR = NG) its store sat right in
 // front of the next iteration's wait for the staged loads — gfx9 has one counter for loads and
 // stores, so that wait also waited out the store's round trip: 0.50 ms against 0.xx ms.
+// Worst number of operand lines of one ds_read_b128 lane group (see fused_reads_conflict_free)
+// that share a 16-byte slot of the 256-byte bank row, for the 16x16x32 operand map: entry =
+// lane&15, k quarter = lane>>4.  ring: the k quarters 2,3 sit in the next ring group.
+static constexpr int fused16_read_degree(int S,int PAD,int units,bool channel_major,bool ring)
+{
+  const int CH=units*S+PAD;
+  int worst=1;
+  for (int g=0; g < 4; g++)
+    {
+      int count[16]={0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
+      for (int i=0; i < 16; i++)
+        {
+          const int base=(g & 1) == 0 ? (i < 4 ? i : (i < 8 ? i+8 : i+12)) : (i < 8 ? i+4 : (i < 12 ? i+8 : i+16));
+          const int lane=base+32*(g >> 1);
+          const int e=lane & 15,kq=lane >> 4;
+          const int channel=channel_major ? e >> 2 : e & 3;
+          const int unit=channel_major ? e & 3 : e >> 2;
+          const int offset=ring ? 16*(kq >> 1)+8*(kq & 1) : 8*kq;
+          const int bytes=(channel*CH+unit*S+offset)*2;
+          const int slot=(bytes % 256)/16;
+          count[slot]++;
+          worst=count[slot] > worst ? count[slot] : worst;
+        }
+    }
+  return worst;
+}
+
+// line stride (>= extent, multiple of 8 halves) and channel padding with the fewest read
+// conflicts; encoded S*256+PAD
+static constexpr int fused16_layout(int extent,int units,bool channel_major,bool ring)
+{
+  int best=extent*256+8,best_degree=99;
+  for (int S=extent; S <= extent+16; S+=8)
+    for (int PAD=8; PAD <= 64; PAD+=8)
+      {
+        const int degree=fused16_read_degree(S,PAD,units,channel_major,ring);
+        if (degree < best_degree)
+          {
+            best_degree=degree;
+            best=S*256+PAD;
+          }
+      }
+  return best;
+}
+
 template<int NC>
 struct Fused16Geometry
 {
@@ -424,8 +469,8 @@ struct Fused16Geometry
   static constexpr int NR=NG+1;                // ring groups held
   static constexpr int RC=GROUP*NR;            // ring rows
   static constexpr int XS=32*NC+48;            // staged columns: 64 outputs + band
-  static constexpr int SR=XS,PADR=64;          // conflict-free ds_read_b128 (tools/ubench/gen_bank.py rules)
-  static constexpr int SC=RC+8,PADC=8;         // 2-way on reads and on the 8-byte ring stores
+  static constexpr int SR=fused16_layout(XS,GROUP,true,false)/256,PADR=fused16_layout(XS,GROUP,true,false) % 256;
+  static constexpr int SC=fused16_layout(RC,COLS,false,true)/256,PADC=fused16_layout(RC,COLS,false,true) % 256;
   static constexpr int CHR=GROUP*SR+PADR;
   static constexpr int CHC=COLS*SC+PADC;
   static constexpr int STAGE_PLANE=4*CHR,RING_PLANE=4*CHC;

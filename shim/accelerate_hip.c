@@ -68,6 +68,7 @@ MagickExport size_t GetMagickHipAcceleratedCalls(void)
   mask; at most four channels laid out R[,G,B][,A].
 */
 static MagickBooleanType IsLayoutAcceleratable(const Image *image);
+static MagickBooleanType IsHistogramOperatorAcceleratable(const Image *image);
 
 static MagickBooleanType IsImageAcceleratable(const Image *image)
 {
@@ -422,7 +423,7 @@ MagickPrivate MagickBooleanType AccelerateEqualizeImage(Image *image,
   void
     *q;
 
-  if (IsLayoutAcceleratable(image) == MagickFalse)
+  if (IsHistogramOperatorAcceleratable(image) == MagickFalse)
     return(MagickFalse);
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
@@ -435,6 +436,31 @@ MagickPrivate MagickBooleanType AccelerateEqualizeImage(Image *image,
   MarkDeviceCopyNewer(image);
   CountAcceleratedCall();
   return(MagickTrue);
+}
+
+/*
+  ContrastStretchImage and EqualizeImage start with IdentifyImageType (enhance.c:1586-1588):
+  for every sRGB-compatible colourspace an all-gray colour image is first re-laid-out as a GRAY
+  image.  The library runs that scan for sRGB and RGB (and hands an all-gray image back to the
+  CPU path); the other compatible colourspaces (Adobe98, DisplayP3, ProPhoto, scRGB,
+  Transparent) therefore stay on the CPU.  Lab / XYZ (BASELINE config C4) are not
+  sRGB-compatible: no scan, accelerated.
+*/
+static MagickBooleanType IsHistogramOperatorAcceleratable(const Image *image)
+{
+  switch (image->colorspace)
+  {
+    case sRGBColorspace:
+    case RGBColorspace:
+    case GRAYColorspace:
+    case LinearGRAYColorspace:
+    case LabColorspace:
+    case XYZColorspace:
+      break;
+    default:
+      return(MagickFalse);
+  }
+  return(IsLayoutAcceleratable(image));
 }
 
 MagickPrivate MagickBooleanType AccelerateContrastStretchImage(Image *image,
@@ -452,7 +478,7 @@ MagickPrivate MagickBooleanType AccelerateContrastStretchImage(Image *image,
   void
     *q;
 
-  if (IsLayoutAcceleratable(image) == MagickFalse)
+  if (IsHistogramOperatorAcceleratable(image) == MagickFalse)
     return(MagickFalse);
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
@@ -463,9 +489,9 @@ MagickPrivate MagickBooleanType AccelerateContrastStretchImage(Image *image,
       (DescribeImage(library,image,q,&description) == MagickFalse) ||
       (library->ContrastStretchImage(&description,black_point,white_point,&became_gray) != MH_OK))
     return(MagickFalse);
+  /* (an all-gray colour image comes back as MH_UNSUPPORTED above: the CPU path then does the
+     IdentifyImageType re-layout itself, enhance.c:1586-1588) */
   MarkDeviceCopyNewer(image);
-  if (became_gray != 0)              /* IdentifyImageType side effect, enhance.c:1586-1588 */
-    (void) SetImageColorspace(image,GRAYColorspace,exception);
   CountAcceleratedCall();
   return(MagickTrue);
 }

@@ -209,7 +209,7 @@ def run16(px, taps, origin, blend=True, segments=1):
     NG = 2 * NC
     NR = NG + 1
     RC, XS = GROUP * NR, 32 * NC + 48
-    SR, PADR, SC, PADC = XS, 64, RC + 8, 8
+    SR, PADR, SC, PADC = XS, 64, RC, 32            # what fused16_layout picks
     CHR, CHC = GROUP * SR + PADR, COLS * SC + PADC
     lds = 2 * 2 * 4 * (CHR + CHC)
     GPR = XS // 4
