@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the MI355X accelerate backend.
 
-Workload (BASELINE.json configs[1]): 8192x8192 RGBA Q16 BlurImage(radius=0,
-sigma=10) — the 79-tap separable Gaussian blur with a Quantum-rounded
-intermediate — on device-resident images.  One *step* = one BlurImage call on
-one 8192x8192 image per rank (independent images shard across ranks with no
-collective: weak scaling).  Metric: Mpixels/s of output, whole job.
+Default workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+8192x8192 RGBA Q16 BlurImage(radius=0, sigma=10) — the 79-tap separable Gaussian blur with its
+Quantum-rounded intermediate — on device-resident images.  One *step* = one BlurImage call on
+one 8192x8192 image per rank (independent images shard across ranks with no collective: weak
+scaling).  `value` = Mpixels/s of output, whole job.
 
-    python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 with the `roofline` (dominant kernel, hipEvent
-timed on the launch stream) and `cpu_baseline` (the compiled reference's own
-OpenMP BlurImage on this host, bounded sample, rank 0 / N=1 only) objects.
+Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
+  roofline      the dominant kernel of the headline: algorithmic bytes / hipEvent-timed launch
+  modes         both precision modes of the blur as first-class objects, each with its roofline
+  resize        BASELINE's other half of the metric: C3, 8192^2 -> 32768^2 Lanczos, float Quantum
+  configs       C4 (sRGB->Lab + ContrastStretch), C5 (Dilate Disk:15, UnsharpMask): Mpixels/s,
+                one roofline object per kernel, and the reference's CPU figure beside each
+  sustained     >= 2 s of back-to-back blur calls (power-limit behaviour)
+  cpu_baseline  the compiled reference's OpenMP BlurImage on this host (bounded sample)
+
+Other configurations as the step (`--config`): c4 = the batch of 512 images sharded over the
+ranks (strong scaling, no collective), c5 = one 16384^2 image row-sharded over the ranks with
+halo rows (Dilate Disk:15 + UnsharpMask; strong scaling), equalize = one 16384^2 image
+row-sharded, EqualizeImage with the one all-reduce of the 65536 x channels table over RCCL.
 """
 import argparse
 import json
@@ -24,27 +34,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+METRIC = "Mpixels/sec GaussianBlur σ=10 + Lanczos 4× resize, 8K RGBA; %HBM-roofline"
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--size", type=int, default=8192, help="image edge (default: the C2 config)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=["c2", "c4", "c5", "equalize"], default="c2",
+                    help="what one step is (default c2: the headline blur)")
+    ap.add_argument("--size", type=int, default=0, help="image edge (default: the config's own)")
     ap.add_argument("--sigma", type=float, default=10.0)
     ap.add_argument("--precision", choices=["exact", "fast"], default="fast",
-                    help="fast: f32 accumulation, results within +-1 Quantum level of the reference (the "
-                         "tolerance BASELINE.json's north_star states); exact: fp64 in the CPU's operation "
-                         "order, bit-identical")
+                    help="fast: f16x2 products on the matrix cores, f32 accumulation, results within +-1 "
+                         "Quantum level of the reference (the tolerance BASELINE.json's north_star states); "
+                         "exact: fp64 in the CPU's operation order, bit-identical")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (resize) measurements")
+    ap.add_argument("--no-extra", action="store_true", help="headline only: no modes / resize / configs")
+    ap.add_argument("--sustain", type=float, default=2.0, help="seconds of back-to-back calls (0: skip)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo rehearses the N>1 control "
                          "flow on a box with fewer GPUs than ranks: ranks then share devices)")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------ profiling
 def profile_begin():
     """Start recording a hipEvent pair around every kernel the library launches, on the
     stream it launches them on (asynchronous: nothing waits until the records are read)."""
@@ -61,10 +76,10 @@ def profile_end():
     lib = _lib.load()
     torch.cuda.synchronize()
     lib.MhSetProfileEnabled(0)
-    recs = (_lib.MhKernelProfileRecord * 32)()
-    n = lib.MhGetProfileRecords(recs, 32)
+    recs = (_lib.MhKernelProfileRecord * 48)()
+    n = lib.MhGetProfileRecords(recs, 48)
     out = {}
-    for i in range(min(n, 32)):
+    for i in range(min(n, 48)):
         r = recs[i]
         out[r.kernel_name.decode()] = {"count": int(r.count), "avg_ms": r.total_ms / max(r.count, 1),
                                        "min_ms": r.min_ms, "max_ms": r.max_ms}
@@ -75,50 +90,83 @@ def profile_end():
 def kernel_profile(im, fn, reps):
     """Average per-launch duration (ms) of every kernel `fn` launches, from the
     library's hipEvent records on the launch stream."""
-    import ctypes
-    import torch
-    from imagemagick_amd import _lib
-    lib = _lib.load()
-    lib.MhResetProfileRecords()
-    lib.MhSetProfileEnabled(1)
+    profile_begin()
+    for _ in range(reps):
+        fn()
+    return profile_end()
+
+
+def timed(torch, fn, reps):
+    fn()            # two warm-up calls: the result of call n is released only after call n+1
+    fn()            # allocated its own, so the caching allocator needs two blocks before it is warm
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for _ in range(reps):
         fn()
     torch.cuda.synchronize()
-    lib.MhSetProfileEnabled(0)
-    recs = (_lib.MhKernelProfileRecord * 32)()
-    n = lib.MhGetProfileRecords(recs, 32)
+    return (time.perf_counter() - t0) / reps
+
+
+_TRAFFIC = None
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch from the PMC passes kept under profiles/ (FETCH_SIZE doubled as the
+    guide prescribes for gfx950, + WRITE_SIZE; tools/import_profiles.py writes the file)."""
+    global _TRAFFIC
+    if _TRAFFIC is None:
+        try:
+            _TRAFFIC = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        except Exception:
+            _TRAFFIC = {}
+    return _TRAFFIC.get(kernel)
+
+
+def roofline(kernel, algorithmic_bytes, avg_ms, traffic_key=None):
+    achieved = algorithmic_bytes / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": pmc_traffic(traffic_key or kernel), "avg_ms": round(avg_ms, 4),
+            "algorithmic_bytes": int(algorithmic_bytes)}
+
+
+def kernel_rooflines(prof, bytes_by_kernel, prefix=""):
     out = {}
-    for i in range(min(n, 32)):
-        r = recs[i]
-        out[r.kernel_name.decode()] = {"count": int(r.count), "avg_ms": r.total_ms / max(r.count, 1),
-                                       "min_ms": r.min_ms, "max_ms": r.max_ms}
-    lib.MhResetProfileRecords()
+    for name, rec in prof.items():
+        if name in bytes_by_kernel:
+            out[name] = roofline(name, bytes_by_kernel[name], rec["avg_ms"], prefix + name)
+        else:
+            out[name] = {"avg_ms": round(rec["avg_ms"], 4)}
     return out
 
 
-def cpu_baseline(sigma):
-    """The reference's own CPU/OpenMP BlurImage (oracle/_ref) on a bounded
-    sample of the same workload: same distribution, same sigma, smaller frame."""
-    import numpy as np
+# ------------------------------------------------------------------ CPU baselines
+def _ref():
     from oracle import ref
     if not ref.available(False):
         return None
-    threads = os.cpu_count() or 1
-    ref.set_thread_limit(threads)
+    return ref
+
+
+def cpu_baseline_blur(sigma):
+    """The reference's own CPU/OpenMP BlurImage (oracle/_ref) on a bounded
+    sample of the same workload: same distribution, same sigma, smaller frame."""
+    import numpy as np
+    ref = _ref()
+    if ref is None:
+        return None
+    ref.set_thread_limit(os.cpu_count() or 1)
     rng = np.random.default_rng(42)
-    edge = 1024
-    spent = 0.0
-    best = None
+    edge, spent, best = 1024, 0.0, None
     while True:
         px = rng.integers(0, 65536, (edge, edge, 4), dtype=np.uint16)
-        img = ref.RefImage(px)
-        out = img.blur(0.0, sigma)
+        out = ref.RefImage(px).blur(0.0, sigma)
         sec = out.last_seconds
         spent += sec
         best = (edge, sec)
-        del out, img
-        # grow the sample until one call takes a few seconds, within a ~30 s budget
-        if sec > 4.0 or spent + 4.5 * sec > 30.0 or edge >= 8192:
+        del out
+        # grow the sample until one call takes a few seconds, within a ~20 s budget
+        if sec > 3.0 or spent + 4.5 * sec > 20.0 or edge >= 8192:
             break
         edge *= 2
     edge, sec = best
@@ -126,6 +174,321 @@ def cpu_baseline(sigma):
             "cores": int(ref.thread_limit()), "kind": "reference",
             "sample": "%dx%d RGBA Q16 BlurImage(0,%g), reference MagickCore OpenMP path, "
                       "1 call, %.2f s" % (edge, edge, sigma, sec)}
+
+
+def cpu_baseline_configs():
+    """The reference's OpenMP path on bounded samples of C3 / C4 / C5 (a few seconds each)."""
+    import numpy as np
+    ref = _ref()
+    if ref is None:
+        return {}
+    threads = os.cpu_count() or 1
+    ref.set_thread_limit(threads)
+    ref.set_thread_limit(threads, True)
+    rng = np.random.default_rng(43)
+    out = {}
+
+    def entry(value_px, sec, sample, hdri=False):
+        return {"value": round(value_px / sec / 1e6, 3), "unit": "Mpixels/s",
+                "cores": int(ref.thread_limit(hdri)), "kind": "reference",
+                "sample": "%s, reference MagickCore OpenMP path, 1 call, %.2f s" % (sample, sec)}
+    try:
+        m = 2048
+        src = (rng.random((m, m, 4), dtype=np.float32) * 65535.0).astype(np.float32)
+        r = ref.RefImage(src).resize(4 * m, 4 * m, "Lanczos")
+        out["c3_resize"] = entry(16.0 * m * m, r.last_seconds,
+                                 "%dx%d -> %dx%d Lanczos ResizeImage, float Quantum RGBA" % (m, m, 4 * m, 4 * m), True)
+        del r, src
+        k = 4096
+        px = rng.integers(0, 65536, (k, k, 4), dtype=np.uint16)
+        img = ref.RefImage(px)
+        img.colorspace("Lab")
+        sec = img.last_seconds
+        img.contrast_stretch(0.02 * k * k, k * k - 0.01 * k * k)
+        sec += img.last_seconds
+        out["c4_lab_contrast_stretch"] = entry(float(k) * k, sec, "%dx%d RGBA Q16 sRGB->Lab + ContrastStretch 2%%x1%%" % (k, k))
+        del img
+        d = 2048
+        px = rng.integers(0, 65536, (d, d, 4), dtype=np.uint16)
+        r = ref.RefImage(px).morphology("Dilate", 1, "Disk:15")
+        out["c5_dilate_disk15"] = entry(float(d) * d, r.last_seconds, "%dx%d RGBA Q16 Dilate Disk:15" % (d, d))
+        del r
+        u = 4096
+        px = rng.integers(0, 65536, (u, u, 4), dtype=np.uint16)
+        r = ref.RefImage(px).unsharp(0.0, 10.0, 1.0, 0.02)
+        out["c5_unsharp"] = entry(float(u) * u, r.last_seconds, "%dx%d RGBA Q16 UnsharpMask(0x10+1+0.02)" % (u, u))
+        del r
+    except Exception as exc:   # a baseline is a report, never a reason to lose the line
+        out["error"] = str(exc)
+    return out
+
+
+# ------------------------------------------------------------------ workloads
+def random_q16(torch, gen, rows, cols):
+    # uniform uint16 in every channel incl. alpha: exercises the alpha-weighted path (SURVEY 8d)
+    return torch.randint(-32768, 32768, (rows, cols, 4), generator=gen, device="cuda",
+                         dtype=torch.int16).view(torch.uint16)
+
+
+def blur_mode(im, torch, image, sigma, precision, reps):
+    """One precision mode of the blur as a first-class object: rate + roofline of its dominant kernel."""
+    pixels = float(image.rows) * image.columns
+    im.set_precision(im.PRECISION_FAST if precision == "fast" else im.PRECISION_EXACT)
+    holder = {}
+
+    def call():
+        holder["o"] = im.blur_image(image, 0.0, sigma)
+    sec = timed(torch, call, reps)
+    prof = kernel_profile(im, call, max(2, reps // 2))
+    conv = {k: v for k, v in prof.items() if k.startswith("conv_") or k == "blur_fused"}
+    dominant = max(conv, key=lambda k: conv[k]["avg_ms"])
+    frame = pixels * 8.0
+    # algorithmic bytes per launch: a pass (or the fused operator) reads the frame once and writes it once
+    out = {"Mpixels_per_s": round(pixels / sec / 1e6, 1), "ms": round(sec * 1e3, 4),
+           "dtype": "f64" if precision == "exact" else "f16x2 products, f32 accumulate",
+           "tolerance": "bit-identical to the reference CPU path" if precision == "exact" else
+                        "within +-1 Quantum level of the reference CPU path (full-size comparison: "
+                        "tests/test_gpu_fullsize.py)",
+           "launches": "one (row + column pass fused, intermediate in LDS)" if dominant == "blur_fused"
+                       else "two (row pass, column pass; intermediate through HBM)",
+           "roofline": roofline(dominant, 2.0 * frame, conv[dominant]["avg_ms"],
+                                ("exact:" if precision == "exact" else "") + dominant),
+           "operator_frac_of_compulsory_bytes": round(2.0 * frame / sec / 1e9 / HBM_PEAK_GBS, 4),
+           "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in prof.items()}}
+    holder.clear()
+    return out
+
+
+def resize_config(im, torch, gen):
+    """C3: 8192^2 -> 32768^2 Lanczos, float Quantum RGBA (17.2 GB result)."""
+    m = 8192
+    srcf = torch.rand((m, m, 4), generator=gen, device="cuda", dtype=torch.float32) * 65535.0
+    imgf = im.Image(srcf)
+    holder = {}
+
+    def resize():
+        holder["o"] = None
+        holder["o"] = im.resize_image(imgf, 4 * m, 4 * m, "Lanczos")
+    sec = timed(torch, resize, 3)
+    prof = kernel_profile(im, resize, 2)
+    holder.clear()
+    out_px = 16.0 * m * m
+    px16 = 16.0                                   # bytes per float RGBA pixel
+    bytes_by_kernel = {
+        "resize_vertical": (1.0 * m * m + 4.0 * m * m) * px16,       # 8192^2 in, 8192x32768 out
+        "resize_horizontal": (4.0 * m * m + 16.0 * m * m) * px16,    # 8192x32768 in, 32768^2 out
+        "resize_fused": (1.0 * m * m + 16.0 * m * m) * px16,
+    }
+    kernels = kernel_rooflines(prof, bytes_by_kernel)
+    kernel_ms = sum(v["avg_ms"] for v in prof.values())
+    dominant = max(prof, key=lambda k: prof[k]["avg_ms"])
+    compulsory = (1.0 * m * m + 16.0 * m * m) * px16
+    return {"workload": "8192x8192 -> 32768x32768 Lanczos ResizeImage, float Quantum RGBA (BASELINE configs[2])",
+            "Mpixels_per_s": round(out_px / sec / 1e6, 1), "ms": round(sec * 1e3, 3),
+            "kernel_only_Mpixels_per_s": round(out_px / (kernel_ms * 1e-3) / 1e6, 1),
+            "dtype": "f64 accumulation, float Quantum", "roofline": kernels.get(dominant),
+            "operator_frac_of_compulsory_bytes": round(compulsory / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "kernels": kernels}
+
+
+def c4_config(im, torch, gen):
+    """One image of the C4 batch: 4096^2 RGBA Q16 sRGB->Lab + ContrastStretch 2%x1%."""
+    k = 4096
+    src4 = random_q16(torch, gen, k, k)
+    work = src4.clone()
+
+    def c4():
+        work.copy_(src4)
+        img4 = im.Image(work)
+        im.transform_image_colorspace(img4, "Lab")
+        im.contrast_stretch_image(img4, 0.02 * k * k, k * k - 0.01 * k * k)
+    sec = timed(torch, c4, 5)
+    prof = kernel_profile(im, c4, 3)
+    frame = float(k) * k * 8.0
+    bytes_by_kernel = {"colorspace": 2.0 * frame, "histogram": frame / 4.0, "apply_lut": 2.0 * frame,
+                       "gray_check": frame}
+    kernels = kernel_rooflines(prof, bytes_by_kernel, "c4:")
+    kernel_ms = sum(v["avg_ms"] for v in prof.values())
+    return {"workload": "4096x4096 RGBA Q16 sRGB->Lab + ContrastStretch 2%x1% (one image of BASELINE configs[3])",
+            "Mpixels_per_s": round(k * k / sec / 1e6, 1), "ms": round(sec * 1e3, 4),
+            "kernel_only_ms": round(kernel_ms, 4),
+            "operator_frac_of_compulsory_bytes": round(4.0 * frame / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "compulsory_bytes": int(4.0 * frame), "kernels": kernels}
+
+
+def c5_config(im, torch, gen):
+    """C5: 16384^2 RGBA Q16 Dilate Disk:15, then UnsharpMask(0x10+1+0.02)."""
+    k = 16384
+    src5 = random_q16(torch, gen, k, k)
+    img5 = im.Image(src5)
+    holder = {}
+    frame = float(k) * k * 8.0
+    out = {}
+
+    def dilate():
+        holder["o"] = im.morphology_image(img5, "Dilate", 1, "Disk:15")
+    sec = timed(torch, dilate, 2)
+    prof = kernel_profile(im, dilate, 2)
+    out["c5_dilate_disk15"] = {
+        "workload": "16384x16384 RGBA Q16 MorphologyImage(Dilate, Disk:15) (BASELINE configs[4])",
+        "Mpixels_per_s": round(k * k / sec / 1e6, 1), "ms": round(sec * 1e3, 3),
+        "kernels": kernel_rooflines(prof, {"morph_convex": 2.0 * frame, "morph2d": 2.0 * frame}, "c5:")}
+    holder.clear()
+
+    def unsharp():
+        holder["o"] = im.unsharp_mask_image(img5, 0.0, 10.0, 1.0, 0.02)
+    sec = timed(torch, unsharp, 2)
+    prof = kernel_profile(im, unsharp, 2)
+    # row pass: frame in, frame out; fused column pass: intermediate + original in, frame out
+    out["c5_unsharp"] = {
+        "workload": "16384x16384 RGBA Q16 UnsharpMaskImage(0x10+1.0+0.02) (BASELINE configs[4])",
+        "Mpixels_per_s": round(k * k / sec / 1e6, 1), "ms": round(sec * 1e3, 3),
+        "operator_frac_of_compulsory_bytes": round(2.0 * frame / sec / 1e9 / HBM_PEAK_GBS, 4),
+        "kernels": kernel_rooflines(prof, {"conv_row": 2.0 * frame, "conv_column": 3.0 * frame,
+                                           "unsharp_epilogue": 3.0 * frame}, "c5:")}
+    holder.clear()
+    return out
+
+
+def extra_measurements(im, torch, args, image):
+    """What the line reports next to the headline."""
+    extra, result = {}, {}
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    n = image.rows
+    try:
+        result["modes"] = {p: blur_mode(im, torch, image, args.sigma, p, 6) for p in ("fast", "exact")}
+        im.set_precision(im.PRECISION_FAST if args.precision == "fast" else im.PRECISION_EXACT)
+        if args.sustain > 0:
+            # sustained rate: back-to-back calls for >= args.sustain seconds (clocks settle against
+            # the power limit within the first tens of milliseconds)
+            holder = {}
+            calls, t0 = 0, time.perf_counter()
+            while True:
+                for _ in range(100):
+                    holder["o"] = im.blur_image(image, 0.0, args.sigma)
+                calls += 100
+                torch.cuda.synchronize()
+                elapsed = time.perf_counter() - t0
+                if elapsed >= args.sustain:
+                    break
+            result["sustained"] = {"seconds": round(elapsed, 2), "calls": calls,
+                                   "Mpixels_per_s": round(calls * float(n) * n / elapsed / 1e6, 1)}
+            holder.clear()
+        if args.precision == "fast":
+            sec = timed(torch, lambda: im.gaussian_blur_image(image, 0.0, args.sigma), 5)
+            extra["gaussian_blur_2d_kernel_Mpixels_per_s"] = round(n * n / sec / 1e6, 1)
+        # reference point for the roofline: what a plain device copy of the same frame reaches
+        mirror = torch.empty_like(image.pixels)
+        sec = timed(torch, lambda: mirror.copy_(image.pixels), 10)
+        extra["device_copy_GBps"] = round(2.0 * image.pixels.numel() * 2 / sec / 1e9, 1)
+        del mirror
+        # the same call on a host (pixel-cache) buffer: upload + kernels + download, what a single
+        # un-chained operator costs through the MagickCore shim (DESIGN.md section 6)
+        host = image.pixels.view(torch.int16).cpu().numpy().view("uint16")
+        host_image = im.Image(host)
+        im.blur_image(host_image, 0.0, args.sigma)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            im.blur_image(host_image, 0.0, args.sigma)
+        extra["blur_host_buffers_Mpixels_per_s"] = round(2 * n * n / (time.perf_counter() - t0) / 1e6, 1)
+        del host, host_image
+        torch.cuda.empty_cache()
+        result["resize"] = resize_config(im, torch, gen)
+        torch.cuda.empty_cache()
+        configs = {"c4_lab_contrast_stretch": c4_config(im, torch, gen)}
+        torch.cuda.empty_cache()
+        configs.update(c5_config(im, torch, gen))
+        torch.cuda.empty_cache()
+        result["configs"] = configs
+    except Exception as exc:
+        extra["error"] = "%s: %s" % (type(exc).__name__, exc)
+    result["extra"] = extra
+    return result
+
+
+# ------------------------------------------------------------------ N-rank configurations
+def shard_range(total, rank, world):
+    """Contiguous share of `total` units for `rank` (as imagemagick_amd.distributed.shard_range)."""
+    return total * rank // world, total * (rank + 1) // world
+
+
+def make_step(im, torch, dist, args, rank, world):
+    """-> (step function, units per step for the whole job, description, scaling)."""
+    gen = torch.Generator(device="cuda").manual_seed(42 + rank)
+    if args.config == "c2":
+        n = args.size or 8192
+        src = random_q16(torch, gen, n, n)
+        if os.environ.get("MAGICKHIP_BENCH_ZERO"):     # diagnostics only: data-dependent clocking
+            src.zero_()
+        image = im.Image(src)
+        holder = {}
+
+        def step():
+            holder["out"] = im.blur_image(image, 0.0, args.sigma)
+        workload = ("%dx%d RGBA Q16 BlurImage(radius=0,sigma=%g): 79-tap row pass + 79-tap column pass, "
+                    "Quantum-rounded intermediate, edge clamp, alpha-weighted colour channels; one "
+                    "independent image per GPU (BASELINE configs[1])" % (n, n, args.sigma))
+        return step, float(n) * n * world, workload, "weak", image
+    if args.config == "c4":
+        # the batch of 512 independent images, sharded over the ranks: no collective.  A rank keeps a
+        # pool of distinct images resident and walks its share of the batch through
+        # MagickHipBatchImages (device-resident, in place, worker threads x streams).
+        k = args.size or 4096
+        batch = 512
+        lo, hi = shard_range(batch, rank, world)
+        pool = [random_q16(torch, gen, k, k) for _ in range(min(8, hi - lo))]
+        work = [p.clone() for p in pool]
+        images = [im.Image(work[i % len(work)]) for i in range(hi - lo)]
+
+        def step():
+            for w, p in zip(work, pool):
+                w.copy_(p)
+            for image in images:
+                image.colorspace = "srgb"
+            torch.cuda.synchronize()
+            # (images that share a buffer would race: one image per buffer per call)
+            for first in range(0, len(images), len(work)):
+                chunk = images[first:first + len(work)]
+                if first:
+                    for w, p in zip(work, pool):
+                        w.copy_(p)
+                    for image in chunk:
+                        image.colorspace = "srgb"
+                    torch.cuda.synchronize()
+                im.batch_images([("colorspace", "Lab"), ("contraststretch", 0.02 * k * k, k * k - 0.01 * k * k)],
+                                chunk, devices=1, streams_per_device=2)
+        workload = ("batch of %d independent %dx%d RGBA Q16 images, sRGB->Lab + ContrastStretch 2%%x1%%, "
+                    "sharded over the ranks, MagickHipBatchImages per rank (BASELINE configs[3])" % (batch, k, k))
+        return step, float(batch) * k * k, workload, "strong", None
+    n = args.size or 16384
+    lo, hi = shard_range(n, rank, world)
+    if args.config == "c5":
+        # one image, row bands with halo rows: Dilate Disk:15 (reach 15) then UnsharpMask 0x10
+        # (reach 39).  Each rank holds its band plus 54 halo rows of the SOURCE and recomputes the
+        # dilated halo itself: no exchange, no collective (SURVEY 8e, "upload overlapping bands").
+        reach_a, reach_b = 15, 39
+        top, bottom = min(lo, reach_a + reach_b), min(n - hi, reach_a + reach_b)
+        band = random_q16(torch, gen, hi - lo + top + bottom, n)
+        image = im.Image(band)
+        holder = {}
+
+        def step():
+            dilated = im.morphology_image(image, "Dilate", 1, "Disk:15")
+            holder["out"] = im.unsharp_mask_image(dilated, 0.0, 10.0, 1.0, 0.02)
+        workload = ("%dx%d RGBA Q16 Dilate Disk:15 + UnsharpMask(0x10+1+0.02), row-sharded over the ranks "
+                    "with 54 halo rows (BASELINE configs[4])" % (n, n))
+        return step, float(n) * n, workload, "strong", None
+    # equalize: local histogram over the owned rows -> ONE all-reduce of the table (RCCL) -> the
+    # identical LUT on every rank -> local apply
+    band = random_q16(torch, gen, hi - lo, n)
+    image = im.Image(band)
+    from imagemagick_amd import distributed as D
+
+    def step():
+        D.equalize_band(image, dist if world > 1 else None)
+    workload = ("%dx%d RGBA Q16 EqualizeImage, row-sharded over the ranks, one all-reduce of the "
+                "65536 x 4 table" % (n, n))
+    return step, float(n) * n, workload, "strong", None
 
 
 def main():
@@ -153,18 +516,7 @@ def main():
     im.load()
     im.set_precision(im.PRECISION_FAST if args.precision == "fast" else im.PRECISION_EXACT)
 
-    n = args.size
-    gen = torch.Generator(device="cuda").manual_seed(42 + rank)
-    # uniform uint16 in every channel incl. alpha: exercises the alpha-weighted path
-    src = torch.randint(-32768, 32768, (n, n, 4), generator=gen, device="cuda",
-                        dtype=torch.int16).view(torch.uint16)
-    if os.environ.get("MAGICKHIP_BENCH_ZERO"):     # diagnostics only: data-dependent clocking
-        src.zero_()
-    image = im.Image(src)
-    out_holder = {}
-
-    def step():
-        out_holder["out"] = im.blur_image(image, 0.0, args.sigma)
+    step, units, workload, scaling, image = make_step(im, torch, dist, args, rank, world)
 
     for _ in range(args.warmup):
         step()
@@ -187,208 +539,72 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    result = None
     if rank == 0:
-        pixels = float(n) * n
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * pixels * args.steps / elapsed / 1e6
-        # dominant kernel: hipEvent-timed on the launch stream, over the timed steps themselves
-        conv = {k: v for k, v in prof.items() if k.startswith("conv_") or k == "blur_fused"}
-        dominant = max(conv, key=lambda k: conv[k]["avg_ms"]) if conv else None
-        roofline = None
-        if dominant:
-            # algorithmic bytes of one pass: read the frame once, write it once
-            bytes_per_launch = 2.0 * pixels * 4 * 2
-            ms = conv[dominant]["avg_ms"]
-            achieved = bytes_per_launch / (ms * 1e-3) / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get(dominant)
-                except Exception:
-                    traffic = None
-            # also report the arithmetic rate.  FAST forms the sums on the f16 matrix cores
-            # (convolve_mfma.hip: three f16 products per multiply-add, 112-wide Toeplitz band for 79
-            # taps), EXACT on the fp64 vector ALU.  Algorithmic flops of one pass:
-            # pixels * 4 channels * taps * 2.
-            taps = 79 if abs(args.sigma - 10.0) < 1e-9 else None
-            alu = None
-            if taps:
-                flops = pixels * 4 * taps * 2.0
-                mfma = args.precision == "fast" and os.environ.get("MAGICKHIP_NO_MFMA") is None
-                peak = 2500.0 if mfma else (157.3 if args.precision == "fast" else 78.6)
-                alu = {"achieved_tflops": round(flops / (ms * 1e-3) / 1e12, 2), "peak_tflops": peak,
-                       "frac": round(flops / (ms * 1e-3) / 1e12 / peak, 4),
-                       "unit": "f16 MFMA dense" if mfma else ("f32 vector" if args.precision == "fast"
-                                                             else "f64 vector"),
-                       "note": "algorithmic multiply-adds only; the matrix-core path executes "
-                               "3 x 112/79 = 4.3x as many (hi/lo operand split, band padding)"
-                               if mfma else
-                               "algorithmic multiply-adds only (alpha weighting, conversions and the "
-                               "epilogue are extra work, not counted)"}
-            roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": traffic, "avg_ms": round(ms, 4),
-                        "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in prof.items()},
-                        "alu": alu}
+        value = units * args.steps / elapsed / 1e6
         result = {
-            "metric": "Mpixels/sec GaussianBlur sigma=10, 8K RGBA Q16",
+            "metric": METRIC if args.config == "c2" else "Mpixels/sec, config " + args.config,
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
+            "scaling": scaling, "vs_baseline": None,
             "dtype": "f64" if args.precision == "exact" else
                      ("f32" if os.environ.get("MAGICKHIP_NO_MFMA") else "f16x2 products, f32 accumulate"),
             "data": "synthetic",
             "tolerance": "bit-identical to the reference CPU path" if args.precision == "exact" else
-                         "each pass within +-1 Quantum level of the reference CPU pass on the same input; the two-pass "
-                         "blur within +-1 wherever the intermediate alpha exceeds a few levels "
-                         "(tests/test_gpu_parity.py, DESIGN.md section 2)",
-            "config": {"workload": "%dx%d RGBA Q16 BlurImage(radius=0,sigma=%g): 79-tap row pass + "
-                                   "79-tap column pass, Quantum-rounded intermediate, edge clamp, "
-                                   "alpha-weighted colour channels; one independent image per GPU"
-                                   % (n, n, args.sigma),
-                       "precision": args.precision, "images_per_step": world},
-            "roofline": roofline,
+                         "within +-1 Quantum level of the reference CPU path everywhere (8192^2 comparison with "
+                         "the compiled reference incl. tiny-alpha bands: tests/test_gpu_fullsize.py; the row "
+                         "pass recomputes small alpha results exactly, DESIGN.md section 2)",
+            "config": {"workload": workload, "precision": args.precision, "images_per_step": world
+                       if args.config == "c2" else None, "config": args.config},
         }
-        if not args.no_extra and world == 1:
-            result["extra"] = extra_measurements(im, torch, args)
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                result["cpu_baseline"] = cpu_baseline(args.sigma)
-            except Exception as exc:  # the baseline is a report, never a reason to lose the line
-                result["cpu_baseline"] = {"error": str(exc)}
+        if args.config == "c2":
+            n = image.rows
+            frame = float(n) * n * 8.0
+            conv = {k: v for k, v in prof.items() if k.startswith("conv_") or k == "blur_fused"}
+            if conv:
+                dominant = max(conv, key=lambda k: conv[k]["avg_ms"])
+                # algorithmic bytes of one launch: the frame read once and written once (the fused
+                # kernel is the whole operator: this IS BASELINE's compulsory 1.074 GB)
+                roof = roofline(dominant, 2.0 * frame, conv[dominant]["avg_ms"],
+                                ("exact:" if args.precision == "exact" else "") + dominant)
+                roof["kernels_ms"] = {k: round(v["avg_ms"], 4) for k, v in prof.items()}
+                taps = 79 if abs(args.sigma - 10.0) < 1e-9 else None
+                if taps:
+                    # the arithmetic beside the stream: matrix cores in FAST, fp64 vector ALU in EXACT
+                    passes = 2.0 if dominant == "blur_fused" else 1.0
+                    flops = passes * float(n) * n * 4 * taps * 2.0
+                    mfma = args.precision == "fast" and os.environ.get("MAGICKHIP_NO_MFMA") is None
+                    peak = 2500.0 if mfma else (157.3 if args.precision == "fast" else 78.6)
+                    tflops = flops / (conv[dominant]["avg_ms"] * 1e-3) / 1e12
+                    roof["alu"] = {"achieved_tflops": round(tflops, 2), "peak_tflops": peak,
+                                   "frac": round(tflops / peak, 4),
+                                   "unit": "f16 MFMA dense" if mfma else
+                                           ("f32 vector" if args.precision == "fast" else "f64 vector"),
+                                   "note": "algorithmic multiply-adds only; the matrix-core path executes "
+                                           "3 x 96/79 = 3.6x as many (hi/lo operand split, band padding)"
+                                           if mfma else "algorithmic multiply-adds only"}
+                result["roofline"] = roof
+            if not args.no_extra and world == 1:
+                result.update(extra_measurements(im, torch, args, image))
+            if world == 1 and not args.no_cpu_baseline:
+                try:
+                    result["cpu_baseline"] = cpu_baseline_blur(args.sigma)
+                    if not args.no_extra:
+                        for name, entry in cpu_baseline_configs().items():
+                            if name == "c3_resize" and "resize" in result:
+                                result["resize"]["cpu_baseline"] = entry
+                            elif name in result.get("configs", {}):
+                                result["configs"][name]["cpu_baseline"] = entry
+                            elif name == "error":
+                                result.setdefault("extra", {})["cpu_baseline_error"] = entry
+                except Exception as exc:  # the baseline is a report, never a reason to lose the line
+                    result["cpu_baseline"] = {"error": str(exc)}
+        else:
+            result["kernels_ms"] = {k: round(v["avg_ms"], 4) for k, v in prof.items()}
         print(json.dumps(result), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def timed(torch, fn, reps):
-    fn()            # two warm-up calls: the result of call n is released only after call n+1
-    fn()            # allocated its own, so the caching allocator needs two blocks before it is warm
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps
-
-
-def extra_measurements(im, torch, args):
-    """Secondary numbers reported next to the headline (not `value`): the other precision
-    mode of the blur, the C3 Lanczos 4x resize (8192^2 -> 32768^2, float Quantum), one image of
-    the C4 batch (sRGB->Lab + ContrastStretch) and the two C5 operators."""
-    extra = {}
-    try:
-        n = args.size
-        gen = torch.Generator(device="cuda").manual_seed(1)
-        src = torch.randint(-32768, 32768, (n, n, 4), generator=gen, device="cuda",
-                            dtype=torch.int16).view(torch.uint16)
-        image = im.Image(src)
-        other = im.PRECISION_EXACT if args.precision == "fast" else im.PRECISION_FAST
-        im.set_precision(other)
-        sec = timed(torch, lambda: im.blur_image(image, 0.0, args.sigma), 5)
-        extra["blur_%s_Mpixels_per_s" % ("exact" if args.precision == "fast" else "fast")] = \
-            round(n * n / sec / 1e6, 1)
-        im.set_precision(im.PRECISION_FAST if args.precision == "fast" else im.PRECISION_EXACT)
-        # GaussianBlurImage: the 2-D Gaussian kernel, separated in FAST mode (DESIGN.md 4.2)
-        if args.precision == "fast":
-            sec = timed(torch, lambda: im.gaussian_blur_image(image, 0.0, args.sigma), 5)
-            extra["gaussian_blur_2d_kernel_Mpixels_per_s"] = round(n * n / sec / 1e6, 1)
-        # reference point for the roofline: what a plain device copy of the same frame reaches
-        # (read 537 MB + write 537 MB, torch's copy kernel)
-        mirror = torch.empty_like(src)
-        sec = timed(torch, lambda: mirror.copy_(src), 10)
-        extra["device_copy_GBps"] = round(2.0 * src.numel() * 2 / sec / 1e9, 1)
-        del mirror, src, image
-        torch.cuda.empty_cache()
-        # The kernels' speed depends on the data (the same instruction stream runs ~20 % faster on
-        # an all-zero frame: clocks, i.e. power): the headline uses uniform noise, the worst case;
-        # a smooth frame (low-frequency waves + 1 % noise, varying alpha) is closer to a photograph
-        yy, xx = torch.meshgrid(torch.arange(n, device="cuda", dtype=torch.float32),
-                                torch.arange(n, device="cuda", dtype=torch.float32), indexing="ij")
-        smooth = torch.stack([torch.sin(xx * 0.003 + c) * torch.cos(yy * 0.002 - c) for c in range(4)], dim=2)
-        smooth = (smooth * 0.45 + 0.5) * 65535.0 + torch.randn((n, n, 4), generator=gen, device="cuda") * 600.0
-        smooth = smooth.clamp_(0, 65535).to(torch.int32).to(torch.int16).view(torch.uint16).contiguous()
-        del yy, xx
-        image = im.Image(smooth)
-        sec = timed(torch, lambda: im.blur_image(image, 0.0, args.sigma), 5)
-        extra["blur_smooth_frame_Mpixels_per_s"] = round(n * n / sec / 1e6, 1)
-        # the same call on a host (pixel-cache) buffer: upload + both passes + download, what a
-        # single un-chained operator costs through the MagickCore shim (DESIGN.md section 6)
-        host = smooth.view(torch.int16).cpu().numpy().view("uint16")
-        host_image = im.Image(host)
-        im.blur_image(host_image, 0.0, args.sigma)
-        t0 = time.perf_counter()
-        for _ in range(2):
-            im.blur_image(host_image, 0.0, args.sigma)
-        extra["blur_host_buffers_Mpixels_per_s"] = round(2 * n * n / (time.perf_counter() - t0) / 1e6, 1)
-        del smooth, image, host, host_image
-        torch.cuda.empty_cache()
-        # C3: 8192^2 -> 32768^2 Lanczos, float Quantum (17.2 GB result)
-        m = 8192
-        srcf = torch.rand((m, m, 4), generator=gen, device="cuda", dtype=torch.float32) * 65535.0
-        imgf = im.Image(srcf)
-        holder = {}
-
-        def resize():
-            holder["o"] = None
-            holder["o"] = im.resize_image(imgf, 4 * m, 4 * m, "Lanczos")
-        sec = timed(torch, resize, 3)
-        prof = kernel_profile(im, resize, 2)
-        out_px = 16.0 * m * m
-        extra["resize_lanczos4x_f32_Mpixels_per_s"] = round(out_px / sec / 1e6, 1)
-        extra["resize_kernels_ms"] = {k: round(v["avg_ms"], 3) for k, v in prof.items()}
-        # algorithmic bytes: horizontal pass reads 8192x32768 and writes 32768x32768 float RGBA
-        if "resize_horizontal" in prof:
-            b = (m * 4.0 * m + 16.0 * m * m) * 16
-            extra["resize_horizontal_GBps"] = round(b / (prof["resize_horizontal"]["avg_ms"] * 1e-3) / 1e9, 1)
-        if "resize_fused" in prof:
-            # fused V+H kernel: reads the 8192^2 source, writes the 32768^2 result (float RGBA)
-            b = (1.0 * m * m + 16.0 * m * m) * 16
-            extra["resize_fused_GBps"] = round(b / (prof["resize_fused"]["avg_ms"] * 1e-3) / 1e9, 1)
-        if "resize_vertical" in prof:
-            b = (1.0 * m * m + 4.0 * m * m) * 16
-            extra["resize_vertical_GBps"] = round(b / (prof["resize_vertical"]["avg_ms"] * 1e-3) / 1e9, 1)
-        holder.clear()
-        del srcf, imgf
-        torch.cuda.empty_cache()
-        # C4 (one image of the batch): 4096^2 RGBA Q16 sRGB->Lab + ContrastStretch 2%x1%
-        k = 4096
-        src4 = torch.randint(-32768, 32768, (k, k, 4), generator=gen, device="cuda",
-                             dtype=torch.int16).view(torch.uint16)
-        work = src4.clone()
-
-        def c4():
-            work.copy_(src4)
-            img4 = im.Image(work)
-            im.transform_image_colorspace(img4, "Lab")
-            im.contrast_stretch_image(img4, 0.02 * k * k, k * k - 0.01 * k * k)
-        sec = timed(torch, c4, 5)
-        prof = kernel_profile(im, c4, 3)
-        extra["c4_lab_contrast_stretch_4096_Mpixels_per_s"] = round(k * k / sec / 1e6, 1)
-        extra["c4_kernels_ms"] = {kk: round(v["avg_ms"], 3) for kk, v in prof.items()}
-        del src4, work
-        # C5: 16384^2 RGBA Q16 Dilate Disk:15, then UnsharpMask(0x10+1+0.02)
-        k = 16384
-        src5 = torch.randint(-32768, 32768, (k, k, 4), generator=gen, device="cuda",
-                             dtype=torch.int16).view(torch.uint16)
-        img5 = im.Image(src5)
-
-        def dilate():
-            holder["o"] = im.morphology_image(img5, "Dilate", 1, "Disk:15")
-        sec = timed(torch, dilate, 2)
-        extra["c5_dilate_disk15_16384_Mpixels_per_s"] = round(k * k / sec / 1e6, 1)
-
-        def unsharp():
-            holder["o"] = im.unsharp_mask_image(img5, 0.0, 10.0, 1.0, 0.02)
-        sec = timed(torch, unsharp, 2)
-        extra["c5_unsharp_0x10_16384_Mpixels_per_s"] = round(k * k / sec / 1e6, 1)
-        holder.clear()
-    except Exception as exc:
-        extra["error"] = str(exc)
-    return extra
 
 
 if __name__ == "__main__":

@@ -468,3 +468,72 @@ def is_image_gray(image):
     flag = ctypes.c_int(0)
     _lib.check(lib.MagickHipIsImageGray(ctypes.byref(image.descriptor()), ctypes.byref(flag)))
     return bool(flag.value)
+
+
+# ------------------------------------------------------- batches / several GPUs
+def _operators(chain):
+    """[("colorspace", "Lab"), ("contraststretch", black, white), ("blur", 0, 10), ("morphology",
+    "Dilate", 1, "Disk:15"), ("unsharpmask", 0, 10, 1.0, 0.02), ("resize", columns, rows, "Lanczos"),
+    ("equalize",)] -> an MhOperator array (and the byte strings it points at)."""
+    ops = (_lib.MhOperator * len(chain))()
+    keep = []
+    for i, step in enumerate(chain):
+        name = step[0].lower()
+        ops[i].kind = _lib.OPERATORS[name]
+        args = list(step[1:])
+        if name == "colorspace":
+            args = [COLORSPACES[args[0].lower()]]
+        elif name == "morphology":
+            text = args[2].encode()
+            keep.append(text)
+            ops[i].text = text
+            args = [MORPHOLOGY[args[0].lower()], args[1]]
+        elif name == "resize":
+            args = [args[0], args[1], FILTERS[args[2].lower()] if len(args) > 2 else FILTERS["lanczos"]]
+        for k, a in enumerate(args):
+            ops[i].args[k] = float(a)
+    return ops, keep
+
+
+def _report(r):
+    return {"devices": int(r.devices), "workers": int(r.workers), "used_rccl": bool(r.used_rccl),
+            "halo_exchanges": int(r.halo_exchanges),
+            "images_per_device": [int(r.images_per_device[d]) for d in range(int(r.devices))],
+            "seconds": float(r.seconds)}
+
+
+def batch_images(chain, images, results=None, devices=0, streams_per_device=0):
+    """MagickHipBatchImages: the operator chain on every image, images spread over `devices`
+    logical devices (0 = all GPUs) x `streams_per_device` host threads.  results=None: in place."""
+    lib = _lib.load()
+    ops, keep = _operators(chain)
+    src = (MhImage * len(images))(*[im.descriptor() for im in images])
+    dst = None
+    if results is not None:
+        dst = (MhImage * len(results))(*[im.descriptor() for im in results])
+    report = _lib.MhBatchReport()
+    _lib.check(lib.MagickHipBatchImages(ops, len(chain), src, dst, len(images), devices,
+                                        streams_per_device, ctypes.byref(report)))
+    out = results if results is not None else images
+    descs = dst if dst is not None else src
+    names = {v: k for k, v in COLORSPACES.items()}
+    for im, d in zip(out, descs):
+        im.colorspace = names.get(int(d.colorspace), im.colorspace)
+    return _report(report)
+
+
+def sharded_image(chain, image, result=None, devices=0):
+    """MagickHipShardedImage: the chain on ONE image cut into `devices` row bands (halo exchange
+    between bands before every stencil, one all-reduce of the histogram table for
+    ContrastStretch / Equalize).  Returns (result image, report)."""
+    lib = _lib.load()
+    ops, keep = _operators(chain)
+    if result is None:
+        result = image.like()
+    src, dst = image.descriptor(), result.descriptor()
+    report = _lib.MhBatchReport()
+    _lib.check(lib.MagickHipShardedImage(ops, len(chain), ctypes.byref(src), ctypes.byref(dst), devices,
+                                         ctypes.byref(report)))
+    names = {v: k for k, v in COLORSPACES.items()}
+    result.colorspace = names.get(int(dst.colorspace), result.colorspace)
+    return result, _report(report)

@@ -99,6 +99,20 @@ class MhKernelProfileRecord(ctypes.Structure):
                 ("total_ms", ctypes.c_double)]
 
 
+class MhOperator(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_uint32), ("args", ctypes.c_double * 4), ("text", ctypes.c_char_p)]
+
+
+class MhBatchReport(ctypes.Structure):
+    _fields_ = [("devices", ctypes.c_uint32), ("workers", ctypes.c_uint32), ("used_rccl", ctypes.c_uint32),
+                ("halo_exchanges", ctypes.c_uint32), ("images_per_device", ctypes.c_uint64 * 16),
+                ("seconds", ctypes.c_double)]
+
+
+OPERATORS = {"blur": 1, "gaussianblur": 2, "unsharpmask": 3, "resize": 4, "morphology": 5,
+             "colorspace": 6, "contraststretch": 7, "equalize": 8}
+
+
 # every symbol include/magickhip.h declares: (name, restype, argtypes)
 _P = ctypes.POINTER
 PROTOTYPES = [
@@ -190,6 +204,10 @@ PROTOTYPES = [
                                      ctypes.c_void_p, _P(ctypes.c_uint32)]),
     ("MagickHipApplyLUT", ctypes.c_int, [_P(MhImage), ctypes.c_void_p, ctypes.c_uint32]),
     ("MagickHipIsImageGray", ctypes.c_int, [_P(MhImage), _P(ctypes.c_int)]),
+    ("MagickHipBatchImages", ctypes.c_int, [_P(MhOperator), ctypes.c_size_t, _P(MhImage), _P(MhImage),
+                                            ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _P(MhBatchReport)]),
+    ("MagickHipShardedImage", ctypes.c_int, [_P(MhOperator), ctypes.c_size_t, _P(MhImage), _P(MhImage),
+                                             ctypes.c_int, _P(MhBatchReport)]),
 ]
 
 _lib = None

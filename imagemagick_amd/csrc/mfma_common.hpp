@@ -42,18 +42,16 @@ static __device__ __forceinline__ size_t pixel_index(int y,int W,int x)
 
 // The same split for two non-negative values at once, packed for the LDS planes.
 // v_cvt_pkrtz_f16_f32 truncates (for v >= 0 that is the mantissa mask above) and packs both hi
-// halves; v_fma_mix_f32 reads an f16 half as an operand, so lo = v - hi is one instruction.
+// halves; v_fma_mixlo_f16 / v_fma_mixhi_f16 read an f16 half as an operand and write the
+// rounded f16 result into the low / high half of the destination: lo = v - hi, packed, in two
+// instructions (the f32 difference is exact, the rounding to f16 is the only one).
 static __device__ __forceinline__ void split_f16_pair(f32x2 v,unsigned &hi,unsigned &lo)
 {
   hi=__builtin_bit_cast(unsigned,__builtin_amdgcn_cvt_pkrtz(v[0],v[1]));
-  float l0,l1;
-  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi),"v"(v[0]));
-  asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi),"v"(v[1]));
-  typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-  half2v l;
-  l[0]=(_Float16) l0;
-  l[1]=(_Float16) l1;
-  lo=__builtin_bit_cast(unsigned,l);
+  unsigned packed;
+  asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(packed) : "v"(hi),"v"(v[0]));
+  asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(packed) : "v"(hi),"v"(v[1]));
+  lo=packed;
 }
 
 // Toeplitz tap operand of chunk q for output n (lane & 31) and k-half (lane >> 5):

@@ -238,6 +238,13 @@ MhStatus launch_apply_lut(const View &img,const void *lut_device,uint32_t apply_
 MhStatus launch_build_lut(const View &img,const unsigned long long *hist_device,bool equalize,
   double black_point,double white_limit,void *lut_device,uint32_t *mask_device,
   const unsigned int *colour_flag_device);
+// (operators_enhance.cpp) device histogram -> LUT -> apply: the second half of
+// ContrastStretchImage / EqualizeImage
+MhStatus apply_histogram_lut(const View &view,const MhImage *image,const unsigned long long *hist,
+  int mode,bool equalize,double black_point,double white_limit,const unsigned int *colour_flag=nullptr);
+// dst[i] += src[i] (histogram tables of the bands of a row-sharded image)
+MhStatus launch_table_add(unsigned long long *dst,const unsigned long long *src,size_t count,
+  int device,hipStream_t stream);
 // CompositeImage(canvas,source,Difference|Lighten,clip_to_self,0,0) in place on the canvas
 enum { MH_COMPOSITE_DIFFERENCE=0,MH_COMPOSITE_LIGHTEN=1 };
 MhStatus launch_composite(const View &canvas,const View &source,int kind,const Roles &roles);

@@ -132,6 +132,33 @@ static MhStatus apply_lut_host(const View &view,const MhImage *desc,const double
   return launch_apply_lut(view,d_lut.ptr,apply_mask,roles,shared_column);
 }
 
+// histogram [65536][channels] on the device -> LUT -> apply, all on the stream (the second
+// half of ContrastStretchImage / EqualizeImage; MagickHipShardedImage calls it with a table
+// that was all-reduced over the row bands of one image)
+MhStatus apply_histogram_lut(const View &view,const MhImage *image,const unsigned long long *hist,
+  int mode,bool equalize,double black_point,double white_limit,const unsigned int *colour_flag)
+{
+  const size_t n=(size_t) MH_HISTOGRAM_BINS*(size_t) view.channels;
+  Temp lut,mask;
+  MH_TRY(lut.alloc(view.device,n*(view.quantum == MH_QUANTUM_U16 ? sizeof(unsigned short) :
+    sizeof(float)),view.stream));
+  MH_TRY(mask.alloc(view.device,sizeof(uint32_t),view.stream));
+  MH_TRY(launch_build_lut(view,hist,equalize,black_point,white_limit,
+    lut.ptr,mask.as<uint32_t>(),colour_flag));
+  Roles roles=channel_roles(image,image);
+  // enhance.c:1781, :2255: only channels whose traits carry Update
+  uint32_t update=0;
+  for (uint32_t c=0; c < image->number_channels; c++)
+    if ((image->channel_traits[c] & MH_TRAIT_UPDATE) != 0)
+      update|=1u<<c;
+  roles.update_mask=update;
+  // intensity binning gives every channel the same histogram, hence the same LUT column
+  int shared_column=-1;
+  if (((mode != 0) || (view.channels == 1)) && (update != 0))
+    shared_column=__builtin_ctz(update);
+  return launch_apply_lut(view,lut.ptr,~0u,roles,shared_column,mask.as<uint32_t>());
+}
+
 } // namespace mh
 
 using namespace mh;
@@ -297,27 +324,12 @@ static MhStatus histogram_lut_apply(const View &view,const MhImage *image,int mo
   double black_point,double white_limit,const unsigned int *colour_flag)
 {
   const size_t n=(size_t) MH_HISTOGRAM_BINS*(size_t) view.channels;
-  Temp hist,lut,mask;
+  Temp hist;
   MH_TRY(hist.alloc(view.device,n*sizeof(unsigned long long),view.stream));
   MH_HIP(hipMemsetAsync(hist.ptr,0,n*sizeof(unsigned long long),view.stream));
   MH_TRY(launch_histogram(view,mode,image,hist.as<unsigned long long>()));
-  MH_TRY(lut.alloc(view.device,n*(view.quantum == MH_QUANTUM_U16 ? sizeof(unsigned short) :
-    sizeof(float)),view.stream));
-  MH_TRY(mask.alloc(view.device,sizeof(uint32_t),view.stream));
-  MH_TRY(launch_build_lut(view,hist.as<unsigned long long>(),equalize,black_point,white_limit,
-    lut.ptr,mask.as<uint32_t>(),colour_flag));
-  Roles roles=channel_roles(image,image);
-  // enhance.c:1781, :2255: only channels whose traits carry Update
-  uint32_t update=0;
-  for (uint32_t c=0; c < image->number_channels; c++)
-    if ((image->channel_traits[c] & MH_TRAIT_UPDATE) != 0)
-      update|=1u<<c;
-  roles.update_mask=update;
-  // intensity binning gives every channel the same histogram, hence the same LUT column
-  int shared_column=-1;
-  if (((mode != 0) || (view.channels == 1)) && (update != 0))
-    shared_column=__builtin_ctz(update);
-  return launch_apply_lut(view,lut.ptr,~0u,roles,shared_column,mask.as<uint32_t>());
+  return apply_histogram_lut(view,image,hist.as<unsigned long long>(),mode,equalize,black_point,
+    white_limit,colour_flag);
 }
 
 extern "C++" {

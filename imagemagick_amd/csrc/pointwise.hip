@@ -1046,6 +1046,24 @@ void lut_stretch_map_kernel(LutBuildArgs a,const LutScratch *scratch)
     atomicOr(a.mask,1u<<c);
 }
 
+__global__ __launch_bounds__(256)
+void table_add_kernel(unsigned long long *dst,const unsigned long long *src,size_t count)
+{
+  for (size_t i=(size_t) blockIdx.x*256u+threadIdx.x; i < count; i+=(size_t) gridDim.x*256u)
+    dst[i]+=src[i];
+}
+
+MhStatus launch_table_add(unsigned long long *dst,const unsigned long long *src,size_t count,
+  int device,hipStream_t stream)
+{
+  DeviceGuard guard;
+  MH_HIP(guard.enter(device));
+  const unsigned blocks=(unsigned) ((count+255)/256 < 1024 ? (count+255)/256 : 1024);
+  hipLaunchKernelGGL(table_add_kernel,dim3(blocks == 0 ? 1u : blocks),dim3(256),0,stream,dst,src,count);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 MhStatus launch_build_lut(const View &img,const unsigned long long *hist,bool equalize,
   double black_point,double white_limit,void *lut,uint32_t *mask,const unsigned int *colour_flag)
 {

@@ -464,6 +464,72 @@ MH_API MhStatus MagickHipApplyLUT(MhImage *image,const double *lut,uint32_t appl
    pixel has |R-G| and |G-B| below MagickEpsilon. */
 MH_API MhStatus MagickHipIsImageGray(const MhImage *image,int *is_gray);
 
+/* ------------------------------------------------- batches and several GPUs */
+/*
+  SURVEY section 8e.  The reference arbitrates devices and in-order queues per call
+  (RequestOpenCLDevice, MagickCore/opencl.c:3056-3102; AcquireOpenCLCommandQueue, :656; 16
+  queues per device, opencl-private.h:70) but hands every operator exactly one device.  These
+  two entry points take a CHAIN of operators and spread the work over the GPUs of the node
+  from plain C:
+
+    MagickHipBatchImages    independent images (BASELINE config C4): a work queue over
+                            devices x streams_per_device host threads, each with its own
+                            stream, so the upload of one image, the kernels of another and the
+                            download of a third overlap on every device.  No collective.
+    MagickHipShardedImage   ONE large image cut into row bands, one per device (config C5):
+                            stencil operators exchange their halo rows between neighbouring
+                            bands with hipMemcpyPeerAsync before each pass; ContrastStretch and
+                            Equalize bin their band, all-reduce the 65536 x channels table
+                            (RCCL ncclAllReduce when the bands sit on different GPUs and
+                            librccl loads, peer copies + an add kernel otherwise) and build and
+                            apply the identical LUT on every device.
+
+  number_devices <= 0 means MhDeviceCount().  More logical devices than physical ones are
+  mapped round-robin (logical d runs on physical d mod MhDeviceCount()): that is how the test
+  suite rehearses both entry points on a single GPU.
+*/
+typedef enum
+{
+  MH_OP_BLUR = 1,              /* args: radius, sigma */
+  MH_OP_GAUSSIAN_BLUR = 2,     /* args: radius, sigma */
+  MH_OP_UNSHARP_MASK = 3,      /* args: radius, sigma, gain, threshold */
+  MH_OP_RESIZE = 4,            /* args: columns, rows, MhFilterType        (batch only) */
+  MH_OP_MORPHOLOGY = 5,        /* args: MhMorphologyMethod, iterations; text: kernel string */
+  MH_OP_COLORSPACE = 6,        /* args: MhColorspace */
+  MH_OP_CONTRAST_STRETCH = 7,  /* args: black_point, white_point (pixel counts, enhance.c:1544) */
+  MH_OP_EQUALIZE = 8
+} MhOperatorKind;
+
+typedef struct MhOperator
+{
+  uint32_t kind;               /* MhOperatorKind */
+  double args[4];
+  const char *text;
+} MhOperator;
+
+typedef struct MhBatchReport
+{
+  uint32_t devices;            /* logical devices used */
+  uint32_t workers;            /* host threads = devices x streams per device */
+  uint32_t used_rccl;          /* MagickHipShardedImage: the table went through ncclAllReduce */
+  uint32_t halo_exchanges;     /* MagickHipShardedImage: hipMemcpyPeerAsync halo copies issued */
+  uint64_t images_per_device[16];
+  double seconds;              /* wall time of the call */
+} MhBatchReport;
+
+/* results[i] = operators(images[i]).  images / results: host or device memory; results[i]
+   carries the geometry of the chain's output (equal to the input's unless the chain resizes).
+   results == NULL: the chain must keep the geometry and images[i] is overwritten.
+   Returns the first non-OK status of any image (the others still run). */
+MH_API MhStatus MagickHipBatchImages(const MhOperator *operators,size_t number_operators,
+  const MhImage *images,MhImage *results,size_t number_images,int number_devices,
+  int streams_per_device,MhBatchReport *report);
+
+/* result = operators(image) with the rows of `image` sharded over number_devices bands.
+   Geometry-preserving operators only (no MH_OP_RESIZE); host or device memory. */
+MH_API MhStatus MagickHipShardedImage(const MhOperator *operators,size_t number_operators,
+  const MhImage *image,MhImage *result,int number_devices,MhBatchReport *report);
+
 #if defined(__cplusplus)
 }
 #endif
