@@ -485,7 +485,7 @@ def make_step(im, torch, dist, args, rank, world):
     from imagemagick_amd import distributed as D
 
     def step():
-        D.equalize_band(image, dist if world > 1 else None)
+        D.equalize_band(image, None, total_rows=n)
     workload = ("%dx%d RGBA Q16 EqualizeImage, row-sharded over the ranks, one all-reduce of the "
                 "65536 x 4 table" % (n, n))
     return step, float(n) * n, workload, "strong", None

@@ -470,6 +470,18 @@ def is_image_gray(image):
     return bool(flag.value)
 
 
+def apply_histogram(image, hist, intensity_mode, equalize, black_point=0.0, white_point=0.0, image_rows=0):
+    """MagickHipApplyHistogram: LUT construction + application on the device from a histogram the
+    caller holds (a CUDA int64/uint64 tensor for device images, a NumPy uint64 array for host ones)."""
+    lib = _lib.load()
+    d = image.descriptor()
+    pointer = hist.data_ptr() if _is_torch(hist) else hist.ctypes.data
+    _lib.check(lib.MagickHipApplyHistogram(ctypes.byref(d), pointer, 1 if intensity_mode else 0,
+                                           1 if equalize else 0, float(black_point), float(white_point),
+                                           int(image_rows)))
+    return image
+
+
 # ------------------------------------------------------- batches / several GPUs
 def _operators(chain):
     """[("colorspace", "Lab"), ("contraststretch", black, white), ("blur", 0, 10), ("morphology",

@@ -204,6 +204,8 @@ PROTOTYPES = [
                                      ctypes.c_void_p, _P(ctypes.c_uint32)]),
     ("MagickHipApplyLUT", ctypes.c_int, [_P(MhImage), ctypes.c_void_p, ctypes.c_uint32]),
     ("MagickHipIsImageGray", ctypes.c_int, [_P(MhImage), _P(ctypes.c_int)]),
+    ("MagickHipApplyHistogram", ctypes.c_int, [_P(MhImage), ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_double, ctypes.c_double, ctypes.c_size_t]),
     ("MagickHipBatchImages", ctypes.c_int, [_P(MhOperator), ctypes.c_size_t, _P(MhImage), _P(MhImage),
                                             ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _P(MhBatchReport)]),
     ("MagickHipShardedImage", ctypes.c_int, [_P(MhOperator), ctypes.c_size_t, _P(MhImage), _P(MhImage),

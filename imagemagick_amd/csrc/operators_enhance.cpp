@@ -386,6 +386,32 @@ MH_API MhStatus MagickHipContrastStretchImage(MhImage *image,double black_point,
   return io.img.commit();
 }
 
+// The second half of EqualizeImage / ContrastStretchImage for a caller that holds the histogram
+// (the all-reduced table of a row-sharded image): LUT construction and application on the
+// device, nothing comes back to the host.
+MH_API MhStatus MagickHipApplyHistogram(MhImage *image,const uint64_t *histogram,int intensity_mode,
+  int equalize,double black_point,double white_point,size_t image_rows)
+{
+  MH_TRY(check_image(image,"ApplyHistogram"));
+  if (histogram == nullptr)
+    return fail(MH_BAD_ARGUMENT,"ApplyHistogram: null histogram");
+  InPlace io;
+  MH_TRY(io.open(image));
+  const View &view=io.img.view;
+  const size_t n=(size_t) MH_HISTOGRAM_BINS*(size_t) view.channels;
+  Temp table;
+  const unsigned long long *device_table=reinterpret_cast<const unsigned long long *>(histogram);
+  if (image->memory == MH_MEMORY_HOST)
+    {
+      MH_TRY(upload_table(table,view.device,view.stream,histogram,n*sizeof(unsigned long long)));
+      device_table=table.as<unsigned long long>();
+    }
+  const double rows=(double) (image_rows == 0 ? image->rows : image_rows);
+  MH_TRY(apply_histogram_lut(view,image,device_table,intensity_mode != 0 ? 1 : 0,equalize != 0,black_point,
+    (double) image->columns*rows-white_point,nullptr));
+  return io.img.commit();
+}
+
 // EqualizeImage, enhance.c:2040-2280
 MH_API MhStatus MagickHipEqualizeImage(MhImage *image)
 {

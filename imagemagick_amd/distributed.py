@@ -6,8 +6,9 @@
 * One image row-sharded across ranks, global-histogram operators
   (EqualizeImage / ContrastStretchImage): every rank bins its own band on its GPU,
   the (MaxMap+1) x channels table is summed with ONE all-reduce — the only
-  collective of the design — every rank builds the identical LUT on the host with
-  the library's LUT builders and applies it to its band.
+  collective of the design — every rank builds the identical LUT and applies it to its
+  band: on the device for device images (MagickHipApplyHistogram; the table never leaves
+  HBM), with the library's host LUT builders for host arrays (the CPU tests).
 * Stencil operators on a row-sharded image need halo rows: `band_with_halo` gives
   the row range a rank must hold (own rows + kernel reach), the caller uploads
   overlapping bands (the pixel cache lives on the host).
@@ -85,6 +86,8 @@ def all_reduce_histogram(histogram, group=None):
     Accepts a CUDA int64 tensor (RCCL) or a NumPy uint64 array (gloo, CPU tests)."""
     import torch
     import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return histogram                                             # a single rank: nothing to sum
     if isinstance(histogram, np.ndarray):
         t = torch.from_numpy(histogram.view(np.int64))
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
@@ -98,15 +101,18 @@ def all_reduce_histogram(histogram, group=None):
     return histogram
 
 
-def equalize_band(image, group=None):
+def equalize_band(image, group=None, total_rows=0):
     """EqualizeImage on this rank's band of a row-sharded image (enhance.c:2040-2280):
-    local histogram on the GPU -> all-reduce -> identical LUT on every rank -> apply."""
+    local histogram on the GPU -> all-reduce -> identical LUT on every rank -> apply.
+    Device images never leave the device: the table is all-reduced where it lies (RCCL) and
+    the LUT is built and applied by the library's device kernels."""
     import imagemagick_amd as im
     sync = (image.channel_mask & _lib.SYNC_CHANNELS) != 0
     hist = im.histogram(image, sync)
     all_reduce_histogram(hist, group)
-    host = hist.cpu().numpy().view(np.uint64) if not isinstance(hist, np.ndarray) else hist
-    lut, mask = im.equalize_lut(host, image.quantum)
+    if not isinstance(hist, np.ndarray):
+        return im.apply_histogram(image, hist, sync, True, image_rows=total_rows)
+    lut, mask = im.equalize_lut(hist, image.quantum)
     return im.apply_lut(image, lut, mask)
 
 
@@ -114,9 +120,11 @@ def contrast_stretch_band(image, total_columns, total_rows, black_point, white_p
     """ContrastStretchImage on this rank's band (enhance.c:1544-1818); black/white points
     are pixel counts of the WHOLE image, as the MagickCore API defines them."""
     import imagemagick_amd as im
-    hist = im.histogram(image, image.channel_mask == _lib.ALL_CHANNELS)
+    mode = image.channel_mask == _lib.ALL_CHANNELS
+    hist = im.histogram(image, mode)
     all_reduce_histogram(hist, group)
-    host = hist.cpu().numpy().view(np.uint64) if not isinstance(hist, np.ndarray) else hist
-    lut, mask = im.contrast_stretch_lut(host, total_columns, total_rows, black_point, white_point,
+    if not isinstance(hist, np.ndarray):
+        return im.apply_histogram(image, hist, mode, False, black_point, white_point, image_rows=total_rows)
+    lut, mask = im.contrast_stretch_lut(hist, total_columns, total_rows, black_point, white_point,
                                         image.quantum)
     return im.apply_lut(image, lut, mask)

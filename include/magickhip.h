@@ -460,6 +460,14 @@ MH_API MhStatus MhEqualizeLUT(const uint64_t *histogram,uint32_t number_channels
    `lut` is a host pointer. */
 MH_API MhStatus MagickHipApplyLUT(MhImage *image,const double *lut,uint32_t apply_mask);
 
+/* The second half of EqualizeImage (equalize != 0) / ContrastStretchImage for a caller that
+   already holds the histogram — e.g. the table all-reduced over the row bands of a sharded
+   image: LUT construction (enhance.c:1652-1706, :2138-2169) and application on the
+   device.  `histogram` follows image->memory; image_rows = rows of the WHOLE image (0: this
+   image's), whose pixel count the white point refers to. */
+MH_API MhStatus MagickHipApplyHistogram(MhImage *image,const uint64_t *histogram,int intensity_mode,
+  int equalize,double black_point,double white_point,size_t image_rows);
+
 /* IdentifyImageGray scan (attribute.c:1564-1626): *is_gray = 1 when every
    pixel has |R-G| and |G-B| below MagickEpsilon. */
 MH_API MhStatus MagickHipIsImageGray(const MhImage *image,int *is_gray);
