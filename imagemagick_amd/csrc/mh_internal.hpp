@@ -245,6 +245,11 @@ MhStatus apply_histogram_lut(const View &view,const MhImage *image,const unsigne
 // dst[i] += src[i] (histogram tables of the bands of a row-sharded image)
 MhStatus launch_table_add(unsigned long long *dst,const unsigned long long *src,size_t count,
   int device,hipStream_t stream);
+// (batch.cpp) a new-image stencil operator on host memory as a pipeline of row bands: uploads,
+// kernels and downloads of different bands overlap.  kernel: the list of an MH_OP_MORPHOLOGY
+// operator (op.text unused then); args[2] = bias.  *handled = false: run the whole-frame path.
+MhStatus host_banded_operator(const MhOperator &op,const MhKernelInfo *kernel,const MhImage *image,
+  MhImage *result,bool *handled);
 // CompositeImage(canvas,source,Difference|Lighten,clip_to_self,0,0) in place on the canvas
 enum { MH_COMPOSITE_DIFFERENCE=0,MH_COMPOSITE_LIGHTEN=1 };
 MhStatus launch_composite(const View &canvas,const View &source,int kind,const Roles &roles);

@@ -580,6 +580,20 @@ MH_API MhStatus MagickHipMorphologyImage(const MhImage *image,MhImage *morpholog
   MH_TRY(gate_pair(image,morphology_image,"MorphologyImage",true));
   if ((kernel == nullptr) || (kernel->values == nullptr))
     return fail(MH_BAD_ARGUMENT,"MorphologyImage: null kernel");
+  {
+    // host memory: row bands through a pipeline of uploads, kernels and downloads (batch.cpp)
+    MhOperator op;
+    op.kind=MH_OP_MORPHOLOGY;
+    op.args[0]=(double) method;
+    op.args[1]=(double) iterations;
+    op.args[2]=bias;
+    op.args[3]=0.0;
+    op.text=nullptr;
+    bool handled=false;
+    MH_TRY(host_banded_operator(op,kernel,image,morphology_image,&handled));
+    if (handled)
+      return MH_OK;
+  }
   Pair pair;
   MH_TRY(pair.open(image,morphology_image));
   Roles roles=channel_roles(image,morphology_image);
@@ -836,6 +850,20 @@ MH_API MhStatus MagickHipUnsharpMaskImage(const MhImage *image,MhImage *unsharp_
   // UnsharpMaskImage, effect.c:4256-4400: blur into the destination, then the
   // threshold/gain epilogue in place
   MH_TRY(gate_pair(image,unsharp_image,"UnsharpMaskImage",true));
+  {
+    // host memory: row bands through a pipeline of uploads, kernels and downloads (batch.cpp)
+    MhOperator op;
+    op.kind=MH_OP_UNSHARP_MASK;
+    op.args[0]=radius;
+    op.args[1]=sigma;
+    op.args[2]=gain;
+    op.args[3]=threshold;
+    op.text=nullptr;
+    bool handled=false;
+    MH_TRY(host_banded_operator(op,nullptr,image,unsharp_image,&handled));
+    if (handled)
+      return MH_OK;
+  }
   MhKernelInfo *kernel=acquire_blur_kernels(radius,sigma);
   if (kernel == nullptr)
     return fail(MH_BAD_ARGUMENT,"UnsharpMaskImage: cannot build the blur kernels");

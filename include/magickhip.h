@@ -502,7 +502,7 @@ typedef enum
   MH_OP_GAUSSIAN_BLUR = 2,     /* args: radius, sigma */
   MH_OP_UNSHARP_MASK = 3,      /* args: radius, sigma, gain, threshold */
   MH_OP_RESIZE = 4,            /* args: columns, rows, MhFilterType        (batch only) */
-  MH_OP_MORPHOLOGY = 5,        /* args: MhMorphologyMethod, iterations; text: kernel string */
+  MH_OP_MORPHOLOGY = 5,        /* args: MhMorphologyMethod, iterations, bias; text: kernel string */
   MH_OP_COLORSPACE = 6,        /* args: MhColorspace */
   MH_OP_CONTRAST_STRETCH = 7,  /* args: black_point, white_point (pixel counts, enhance.c:1544) */
   MH_OP_EQUALIZE = 8
