@@ -400,9 +400,10 @@ def contrast_image(image, sharpen=True):
 
 def modulate_image(image, brightness=100.0, saturation=100.0, hue=100.0, colorspace=None):
     """ModulateImage(image, "brightness,saturation,hue"), in place — MagickCore/enhance.c:3665.
-    colorspace: None / "HSL" (default model) or "HSB"."""
+    colorspace: None / "HSL" (default model), "HSB", "HCL", "HCLp", "HSI", "HSV", "HWB", "LCH",
+    "LCHab" or "LCHuv" (enhance.c:3826-3890)."""
     lib = _lib.load()
-    model = {None: 0, "hsl": 8, "hsb": 6}[colorspace.lower() if colorspace else None]
+    model = 0 if not colorspace else COLORSPACES[colorspace.lower()]
     _lib.check(lib.MagickHipModulateImage(ctypes.byref(image.descriptor()), brightness, saturation, hue, model))
     return image
 

@@ -256,6 +256,11 @@ MhStatus launch_composite(const View &canvas,const View &source,int kind,const R
 MhStatus launch_contrast(const View &img,bool sharpen);
 MhStatus launch_modulate(const View &img,bool hsb,double hue_shift,double saturation_scale,
   double brightness_scale);
+// ModulateImage's other colour models (HCL, HCLp, HSI, HSV, HWB, LCH/LCHab, LCHuv)
+MhStatus launch_modulate_generic(const View &img,MhColorspace colorspace,double hue_shift,
+  double saturation_scale,double brightness_scale);
+// sRGB, linear RGB, Lab, XYZ and the pointwise colourspaces of ConvertRGBToGeneric
+bool colorspace_is_accelerated(MhColorspace c);
 size_t storage_size(MhStorageType type,MhQuantumKind quantum);
 MhStatus launch_pixel_io(bool import,const View &img,const MhImage *desc,int x,int y,int width,
   int height,const char *map,MhStorageType type,void *buffer_device);

@@ -430,12 +430,7 @@ MH_API MhStatus MagickHipTransformImageColorspace(MhImage *image,MhColorspace co
   const MhColorspace from=(MhColorspace) image->colorspace;
   if (from == colorspace)
     return MH_OK;
-  auto supported=[](MhColorspace c)
-  {
-    return (c == MH_COLORSPACE_SRGB) || (c == MH_COLORSPACE_RGB) || (c == MH_COLORSPACE_LAB) ||
-      (c == MH_COLORSPACE_XYZ);
-  };
-  if (!supported(from) || !supported(colorspace))
+  if (!colorspace_is_accelerated(from) || !colorspace_is_accelerated(colorspace))
     return fail(MH_UNSUPPORTED,"colourspace %d -> %d is not accelerated",(int) from,(int) colorspace);
   const uint32_t colour=image->number_channels-(image->alpha_offset >= 0 ? 1u : 0u);
   if (colour != 3)
@@ -463,17 +458,32 @@ MH_API MhStatus MagickHipModulateImage(MhImage *image,double percent_brightness,
   double percent_saturation,double percent_hue,int colorspace)
 {
   MH_TRY(check_image(image,"ModulateImage"));
-  if ((colorspace != MH_COLORSPACE_UNDEFINED) && (colorspace != MH_COLORSPACE_HSL) &&
-      (colorspace != MH_COLORSPACE_HSB))
-    return fail(MH_UNSUPPORTED,"ModulateImage: colour model %d is not accelerated",colorspace);
+  bool generic=false;
+  switch (colorspace)
+  {
+    case MH_COLORSPACE_UNDEFINED: case MH_COLORSPACE_HSL: case MH_COLORSPACE_HSB:
+      break;
+    case MH_COLORSPACE_HCL: case MH_COLORSPACE_HCLP: case MH_COLORSPACE_HSI: case MH_COLORSPACE_HSV:
+    case MH_COLORSPACE_HWB: case MH_COLORSPACE_LCH: case MH_COLORSPACE_LCHAB: case MH_COLORSPACE_LCHUV:
+      generic=true;                               // enhance.c:3826-3890
+      break;
+    default:
+      // (any other value falls into ModulateHSL's `default:` in the reference; the shim maps
+      // those to HSL before calling)
+      return fail(MH_UNSUPPORTED,"ModulateImage: colour model %d is not accelerated",colorspace);
+  }
   InPlace io;
   MH_TRY(io.open(image));
-  // the loop invariants of ModulateHSL / ModulateHSB, enhance.c:3512-3514, :3550-3552
+  // the loop invariants of the Modulate* helpers, enhance.c:3462-3632
   const double hue_shift=fmod((percent_hue-100.0),200.0)/200.0;
   const double saturation_scale=0.01*percent_saturation;
   const double brightness_scale=0.01*percent_brightness;
-  MH_TRY(launch_modulate(io.img.view,colorspace == MH_COLORSPACE_HSB,hue_shift,saturation_scale,
-    brightness_scale));
+  if (generic)
+    MH_TRY(launch_modulate_generic(io.img.view,(MhColorspace) colorspace,hue_shift,saturation_scale,
+      brightness_scale));
+  else
+    MH_TRY(launch_modulate(io.img.view,colorspace == MH_COLORSPACE_HSB,hue_shift,saturation_scale,
+      brightness_scale));
   return io.img.commit();
 }
 

@@ -513,6 +513,10 @@ static MhStatus colorspace_step(const View &img,int op)
     colorspace_typed<float,4>(img,op);
 }
 
+// (defined with the generic colourspace kernels further down)
+static bool colorspace_is_generic(MhColorspace c);
+static MhStatus colorspace_generic_forward_or_inverse(const View &img,MhColorspace colorspace,bool forward);
+
 MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,const MhImage *)
 {
   if ((img.channels != 3) && (img.channels != 4))
@@ -520,27 +524,39 @@ MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,con
   // TransformImageColorspace, colorspace.c:1751-1783: X -> sRGB -> Y
   if (from != MH_COLORSPACE_SRGB)
     {
-      int op;
+      int op=-1;
       switch (from)
       {
         case MH_COLORSPACE_RGB: op=OP_RGB_TO_SRGB; break;
         case MH_COLORSPACE_LAB: op=OP_LAB_TO_SRGB; break;
         case MH_COLORSPACE_XYZ: op=OP_XYZ_TO_SRGB; break;
-        default: return fail(MH_UNSUPPORTED,"source colourspace %d is not accelerated",(int) from);
+        default:
+          if (!colorspace_is_generic(from))
+            return fail(MH_UNSUPPORTED,"source colourspace %d is not accelerated",(int) from);
+          break;
       }
-      MH_TRY(colorspace_step(img,op));
+      if (op >= 0)
+        MH_TRY(colorspace_step(img,op));
+      else
+        MH_TRY(colorspace_generic_forward_or_inverse(img,from,false));
     }
   if (to != MH_COLORSPACE_SRGB)
     {
-      int op;
+      int op=-1;
       switch (to)
       {
         case MH_COLORSPACE_RGB: op=OP_SRGB_TO_RGB; break;
         case MH_COLORSPACE_LAB: op=OP_SRGB_TO_LAB; break;
         case MH_COLORSPACE_XYZ: op=OP_SRGB_TO_XYZ; break;
-        default: return fail(MH_UNSUPPORTED,"target colourspace %d is not accelerated",(int) to);
+        default:
+          if (!colorspace_is_generic(to))
+            return fail(MH_UNSUPPORTED,"target colourspace %d is not accelerated",(int) to);
+          break;
       }
-      MH_TRY(colorspace_step(img,op));
+      if (op >= 0)
+        MH_TRY(colorspace_step(img,op));
+      else
+        MH_TRY(colorspace_generic_forward_or_inverse(img,to,true));
     }
   return MH_OK;
 }
@@ -1555,6 +1571,96 @@ MhStatus launch_modulate(const View &img,bool hsb,double hue_shift,double satura
   return launch_tone(img,a,"modulate");
 }
 
+// ---------------------------------------------------------------- the other pointwise colourspaces
+constexpr double kPi=3.1415926535897932384626433832795028841971693993751058209749445923078164062;   // MagickPI
+#include "colorspace_generic.inc.hpp"
+
+static bool generic_colorspace(MhColorspace c)
+{
+  switch (c)
+  {
+    case MH_COLORSPACE_CMY: case MH_COLORSPACE_HCL: case MH_COLORSPACE_HCLP: case MH_COLORSPACE_HSB:
+    case MH_COLORSPACE_HSI: case MH_COLORSPACE_HSL: case MH_COLORSPACE_HSV: case MH_COLORSPACE_HWB:
+    case MH_COLORSPACE_LCH: case MH_COLORSPACE_LCHAB: case MH_COLORSPACE_LCHUV: case MH_COLORSPACE_LMS:
+    case MH_COLORSPACE_LUV: case MH_COLORSPACE_XYY: case MH_COLORSPACE_YCBCR: case MH_COLORSPACE_YDBDR:
+    case MH_COLORSPACE_YIQ: case MH_COLORSPACE_YPBPR: case MH_COLORSPACE_YUV: case MH_COLORSPACE_JZAZBZ:
+    case MH_COLORSPACE_DISPLAYP3: case MH_COLORSPACE_ADOBE98: case MH_COLORSPACE_PROPHOTO:
+    case MH_COLORSPACE_OKLAB: case MH_COLORSPACE_OKLCH: case MH_COLORSPACE_CAT02LMS:
+      return true;
+    default:
+      return false;
+  }
+}
+
+bool colorspace_is_accelerated(MhColorspace c)
+{
+  return (c == MH_COLORSPACE_SRGB) || (c == MH_COLORSPACE_RGB) || (c == MH_COLORSPACE_LAB) ||
+    (c == MH_COLORSPACE_XYZ) || generic_colorspace(c);
+}
+
+template<typename Q,int C>
+static MhStatus colorspace_generic_typed(const View &img,MhColorspace colorspace,bool forward,
+  double white_luminance)
+{
+  const size_t n=img.columns*img.rows;
+  dim3 grid(stream_grid(n)),block(256);
+  ProfileScope prof("colorspace",img.stream);
+  if (forward)
+    hipLaunchKernelGGL((colorspace_generic_kernel<Q,C,true>),grid,block,0,img.stream,
+      static_cast<Q *>(img.pixels),n,(int) colorspace,white_luminance);
+  else
+    hipLaunchKernelGGL((colorspace_generic_kernel<Q,C,false>),grid,block,0,img.stream,
+      static_cast<Q *>(img.pixels),n,(int) colorspace,white_luminance);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+static MhStatus colorspace_generic_step(const View &img,MhColorspace colorspace,bool forward)
+{
+  const double white_luminance=10000.0;          // colorspace.c:993 (no "white-luminance" property)
+  if (img.quantum == MH_QUANTUM_U16)
+    return img.channels == 3 ? colorspace_generic_typed<uint16_t,3>(img,colorspace,forward,white_luminance) :
+      colorspace_generic_typed<uint16_t,4>(img,colorspace,forward,white_luminance);
+  return img.channels == 3 ? colorspace_generic_typed<float,3>(img,colorspace,forward,white_luminance) :
+    colorspace_generic_typed<float,4>(img,colorspace,forward,white_luminance);
+}
+
+static bool colorspace_is_generic(MhColorspace c) { return generic_colorspace(c); }
+static MhStatus colorspace_generic_forward_or_inverse(const View &img,MhColorspace colorspace,bool forward)
+{
+  return colorspace_generic_step(img,colorspace,forward);
+}
+
+MhStatus launch_modulate_generic(const View &img,MhColorspace colorspace,double hue_shift,
+  double saturation_scale,double brightness_scale)
+{
+  if ((img.channels != 3) && (img.channels != 4))
+    return fail(MH_UNSUPPORTED,"modulate needs R,G,B[,A] channels");
+  const size_t n=img.columns*img.rows;
+  dim3 grid(stream_grid(n)),block(256);
+  ProfileScope prof("modulate",img.stream);
+#define MH_MODULATE(QT,CH) \
+  hipLaunchKernelGGL((modulate_generic_kernel<QT,CH>),grid,block,0,img.stream,static_cast<QT *>(img.pixels),n, \
+    (int) colorspace,hue_shift,saturation_scale,brightness_scale)
+  if (img.quantum == MH_QUANTUM_U16)
+    {
+      if (img.channels == 3)
+        MH_MODULATE(uint16_t,3);
+      else
+        MH_MODULATE(uint16_t,4);
+    }
+  else
+    {
+      if (img.channels == 3)
+        MH_MODULATE(float,3);
+      else
+        MH_MODULATE(float,4);
+    }
+#undef MH_MODULATE
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 // ---------------------------------------------------------------- GrayscaleImage
 // enhance.c:2476-2660: the intensity of (R,G,B) by `method` is written to the Gray
 // (= first) channel only; the caller then switches the image to GRAY / LinearGRAY.
@@ -1656,7 +1762,7 @@ template<typename Q,int C>
 __global__ __launch_bounds__(256)
 void function_kernel(Q *pixels,size_t npixels,FunctionParams fp,uint32_t mask)
 {
-  const double kPi=3.14159265358979323846264338327950288419716939937510;
+  // (kPi: MagickPI, defined with the colourspace helpers)
   const size_t stride=(size_t) gridDim.x*blockDim.x;
   for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
     {

@@ -88,18 +88,46 @@ enum
   MH_TRAIT_BLEND = 0x4
 };
 
-/* ColorspaceType values used on this path, MagickCore/colorspace.h */
+/* ColorspaceType, MagickCore/colorspace.h:25-67 (same values).  TransformImageColorspace is
+   accelerated between sRGB and every pointwise colourspace of ConvertRGBToGeneric /
+   ConvertGenericToRGB (colorspace.c:411-595, :122-305) plus linear RGB; GRAY / LinearGRAY only
+   describe single-channel images; CMYK, Log, OHTA, Rec601/709YCbCr, scRGB, YCC, Transparent
+   stay on the CPU path. */
 typedef enum
 {
   MH_COLORSPACE_UNDEFINED = 0,
+  MH_COLORSPACE_CMY = 1,
   MH_COLORSPACE_GRAY = 3,
-  MH_COLORSPACE_HSB = 6,       /* ModulateImage colour models only */
+  MH_COLORSPACE_HCL = 4,
+  MH_COLORSPACE_HCLP = 5,
+  MH_COLORSPACE_HSB = 6,
+  MH_COLORSPACE_HSI = 7,
   MH_COLORSPACE_HSL = 8,
+  MH_COLORSPACE_HSV = 9,
+  MH_COLORSPACE_HWB = 10,
   MH_COLORSPACE_LAB = 11,
-  MH_COLORSPACE_LINEARGRAY = 33,
+  MH_COLORSPACE_LCH = 12,      /* alias of LCHab in the pixel loops (colorspace.c:488-489) */
+  MH_COLORSPACE_LCHAB = 13,
+  MH_COLORSPACE_LCHUV = 14,
+  MH_COLORSPACE_LMS = 16,
+  MH_COLORSPACE_LUV = 17,
   MH_COLORSPACE_RGB = 21,      /* linear RGB */
   MH_COLORSPACE_SRGB = 23,
-  MH_COLORSPACE_XYZ = 26
+  MH_COLORSPACE_XYY = 25,
+  MH_COLORSPACE_XYZ = 26,
+  MH_COLORSPACE_YCBCR = 27,
+  MH_COLORSPACE_YDBDR = 29,
+  MH_COLORSPACE_YIQ = 30,
+  MH_COLORSPACE_YPBPR = 31,
+  MH_COLORSPACE_YUV = 32,
+  MH_COLORSPACE_LINEARGRAY = 33,
+  MH_COLORSPACE_JZAZBZ = 34,
+  MH_COLORSPACE_DISPLAYP3 = 35,
+  MH_COLORSPACE_ADOBE98 = 36,
+  MH_COLORSPACE_PROPHOTO = 37,
+  MH_COLORSPACE_OKLAB = 38,
+  MH_COLORSPACE_OKLCH = 39,
+  MH_COLORSPACE_CAT02LMS = 40
 } MhColorspace;
 
 /* PixelIntensityMethod, MagickCore/pixel.h */

@@ -583,8 +583,23 @@ MagickPrivate Image *AccelerateMorphologyApply(const Image *image,
 */
 static MagickBooleanType IsColorspaceAccelerated(const ColorspaceType colorspace)
 {
-  return(((colorspace == sRGBColorspace) || (colorspace == RGBColorspace) ||
-    (colorspace == XYZColorspace) || (colorspace == LabColorspace)) ? MagickTrue : MagickFalse);
+  /* sRGB, linear RGB and the pointwise colourspaces of ConvertRGBToGeneric /
+     ConvertGenericToRGB (colorspace.c:958-985, :2292-2319) */
+  switch (colorspace)
+  {
+    case sRGBColorspace: case RGBColorspace: case XYZColorspace: case LabColorspace:
+    case CMYColorspace: case HCLColorspace: case HCLpColorspace: case HSBColorspace:
+    case HSIColorspace: case HSLColorspace: case HSVColorspace: case HWBColorspace:
+    case LCHColorspace: case LCHabColorspace: case LCHuvColorspace: case LMSColorspace:
+    case LuvColorspace: case xyYColorspace: case YCbCrColorspace: case YDbDrColorspace:
+    case YIQColorspace: case YPbPrColorspace: case YUVColorspace: case JzazbzColorspace:
+    case DisplayP3Colorspace: case Adobe98Colorspace: case ProPhotoColorspace:
+    case OklabColorspace: case OklchColorspace: case CAT02LMSColorspace:
+      return(MagickTrue);
+    default:
+      break;
+  }
+  return(MagickFalse);
 }
 
 /*
@@ -658,8 +673,9 @@ MagickPrivate MagickBooleanType AccelerateTransformImageColorspace(Image *image,
       (IsColorspaceAccelerated(colorspace) == MagickFalse) ||
       (image->colorspace == colorspace) || (image->number_channels < 3) ||
       (IsLayoutAcceleratable(image) == MagickFalse) ||
-      (GetImageArtifact(image,"color:illuminant") != (const char *) NULL))
-    return(MagickFalse);
+      (GetImageArtifact(image,"color:illuminant") != (const char *) NULL) ||
+      (GetImageProperty(image,"white-luminance",exception) != (const char *) NULL))
+    return(MagickFalse);          /* D65 and the default Jzazbz white luminance only (colorspace.c:993-995) */
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
     return(MagickFalse);
@@ -976,8 +992,9 @@ MagickPrivate MagickBooleanType AccelerateContrastImage(Image *image,
 
 /*
   ModulateImage's call site (enhance.c:3770-3774) passes the parsed percentages and the
-  modulate:colorspace model; HSL (also the default, UndefinedColorspace) and HSB are taken,
-  any other model or a color:illuminant artifact (which resets the model) is left to the CPU.
+  modulate:colorspace model: all nine models of the reference are taken (HSL is also the
+  default for every other value); a color:illuminant artifact (which resets the model and the
+  illuminant) is left to the CPU.
 */
 MagickPrivate MagickBooleanType AccelerateModulateImage(Image *image,
   const double percent_brightness,const double percent_hue,
@@ -990,16 +1007,28 @@ MagickPrivate MagickBooleanType AccelerateModulateImage(Image *image,
   MhImage
     description;
 
-  if ((colorspace != UndefinedColorspace) && (colorspace != HSLColorspace) &&
-      (colorspace != HSBColorspace))
-    return(MagickFalse);
+  ColorspaceType
+    model;
+
+  /* the nine models of enhance.c:3826-3890; every other value takes ModulateHSL's `default:` */
+  switch (colorspace)
+  {
+    case HCLColorspace: case HCLpColorspace: case HSBColorspace: case HSIColorspace:
+    case HSVColorspace: case HWBColorspace: case LCHColorspace: case LCHabColorspace:
+    case LCHuvColorspace:
+      model=colorspace;
+      break;
+    default:
+      model=HSLColorspace;
+      break;
+  }
   if ((image->number_channels < 3) ||
       (GetImageArtifact(image,"color:illuminant") != (const char *) NULL) ||
       (AcquireInPlace(image,&library,&description,exception) == MagickFalse))
     return(MagickFalse);
   /* ColorspaceType and MhColorspace share their values (colorspace.h:27-66) */
   if (library->ModulateImage(&description,percent_brightness,percent_saturation,percent_hue,
-        (int) colorspace) != MH_OK)
+        (int) model) != MH_OK)
     return(MagickFalse);
   MarkDeviceCopyNewer(image);
   CountAcceleratedCall();

@@ -1,0 +1,71 @@
+"""The pointwise colourspaces of ConvertRGBToGeneric / ConvertGenericToRGB
+(MagickCore/colorspace.c:411-595, :122-305) and ModulateImage's colour models
+(enhance.c:3826-3890) against the compiled reference.  Q16 results are bit-identical (a last-bit
+difference of a device pow / atan2 / cbrt flips a Quantum rounding only on an exact tie); float
+Quantum results may differ by one float ULP for the same reason."""
+import numpy as np
+import pytest
+
+from conftest import make_pixels, to_device, assert_parity
+
+pytestmark = pytest.mark.gpu
+
+Q16, HDRI = np.uint16, np.float32
+
+SPACES = ["CMY", "HCL", "HCLp", "HSB", "HSI", "HSL", "HSV", "HWB", "LCH", "LCHab", "LCHuv", "LMS", "Luv",
+          "xyY", "YCbCr", "YDbDr", "YIQ", "YPbPr", "YUV", "Jzazbz", "DisplayP3", "Adobe98", "ProPhoto",
+          "OkLab", "OkLCH", "CAT02LMS"]
+
+
+def special_pixels(px):
+    """Rows of the cases the hue models branch on: grays, black, white, primaries, equal pairs."""
+    top = 65535 if px.dtype == np.uint16 else 65535.0
+    cases = [(0, 0, 0), (top, top, top), (top, 0, 0), (0, top, 0), (0, 0, top), (top, top, 0), (0, top, top),
+             (top, 0, top), (1234, 1234, 1234), (40000, 40000, 100), (100, 40000, 40000), (40000, 100, 40000),
+             (1, 0, 0), (0, 1, 0), (65534, 65535, 65533)]
+    for i, c in enumerate(cases):
+        px[0, i % px.shape[1], :3] = c
+    return px
+
+
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("space", SPACES)
+def test_srgb_to_colorspace(im, refmod, space, dtype):
+    px = special_pixels(make_pixels(41, 53, 4, dtype, seed=len(space) * 7 + 1))
+    dev = im.Image(to_device(px), colorspace="sRGB")
+    im.transform_image_colorspace(dev, space)
+    want = refmod.RefImage(px, "sRGB").colorspace(space).numpy()
+    assert_parity(dev.numpy(), want, True, "sRGB -> %s" % space, max_ulp=1)
+    assert np.array_equal(dev.numpy()[:, :, 3], px[:, :, 3])          # alpha untouched
+
+
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("space", SPACES)
+def test_colorspace_to_srgb(im, refmod, space, dtype):
+    px = special_pixels(make_pixels(37, 45, 3, dtype, seed=len(space) * 11 + 3))
+    dev = im.Image(to_device(px), colorspace=space)
+    im.transform_image_colorspace(dev, "sRGB")
+    want = refmod.RefImage(px, space).colorspace("sRGB").numpy()
+    assert_parity(dev.numpy(), want, True, "%s -> sRGB" % space, max_ulp=1)
+
+
+@pytest.mark.parametrize("pair", [("HSL", "Lab"), ("YUV", "RGB"), ("OkLab", "LCHuv"), ("XYZ", "HWB")])
+def test_colorspace_to_colorspace_goes_through_srgb(im, refmod, pair):
+    """TransformImageColorspace X -> Y is X -> sRGB -> Y (colorspace.c:1751-1783), each step
+    rounded to Quantum."""
+    px = make_pixels(30, 40, 4, Q16, seed=9)
+    dev = im.Image(to_device(px), colorspace=pair[0])
+    im.transform_image_colorspace(dev, pair[1])
+    want = refmod.RefImage(px, pair[0]).colorspace(pair[1]).numpy()
+    assert_parity(dev.numpy(), want, True, "%s -> %s" % pair)
+
+
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("model", ["HCL", "HCLp", "HSB", "HSI", "HSL", "HSV", "HWB", "LCH", "LCHab", "LCHuv"])
+@pytest.mark.parametrize("percent", [(120.0, 80.0, 130.0), (90.0, 150.0, 100.0)])
+def test_modulate_colour_models(im, refmod, model, percent, dtype):
+    px = special_pixels(make_pixels(33, 47, 4, dtype, seed=21))
+    dev = im.Image(to_device(px))
+    im.modulate_image(dev, percent[0], percent[1], percent[2], model)
+    want = refmod.RefImage(px).modulate(percent[0], percent[1], percent[2], model).numpy()
+    assert_parity(dev.numpy(), want, True, "modulate %s %s" % (model, percent), max_ulp=1)
