@@ -25,6 +25,66 @@
 
 namespace mh {
 
+// One output sample of a 1-D Convolve pass exactly as the reference forms it: the kernel walked
+// backwards over the edge-clamped window, every multiply and add separately rounded
+// (morphology.c:2743-2776 column path, :2941-2977 row path), PerceptibleReciprocal, ClampToQuantum.
+// taps: reversed doubles (taps[v] multiplies the input at o-shift+v).  Used by the Tie64 policy
+// for the few results its fused sums cannot decide.
+template<typename Q,int C,bool BLEND>
+static __device__ __noinline__ Q conv1d_reference_sample(const Q *src,int W,int H,bool vertical,int x,int y,
+  int c,const double *taps,int K,int shift,double bias)
+{
+  double pixel=bias,gamma=0.0;
+  const bool weighted=BLEND && (c != C-1);
+  for (int v=0; v < K; v++)
+    {
+      int xx=x,yy=y;
+      if (vertical)
+        {
+          yy=y-shift+v;
+          yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
+        }
+      else
+        {
+          xx=x-shift+v;
+          xx=xx < 0 ? 0 : (xx > W-1 ? W-1 : xx);
+        }
+      const Q *p=src+((size_t) yy*(size_t) W+(size_t) xx)*C;
+      if (weighted)
+        {
+          const double alpha=kQS*(double) p[C-1];
+          pixel+=alpha*taps[v]*(double) p[c];
+          gamma+=alpha*taps[v];
+        }
+      else
+        pixel+=taps[v]*(double) p[c];
+    }
+  if (weighted)
+    pixel=perceptible_reciprocal(gamma)*pixel;
+  return QuantumOps<Q>::clamp(pixel);
+}
+
+// finish()'s fallback for policies without a tie check
+struct NoReference
+{
+  __device__ __forceinline__ unsigned operator()(int) const { return 0u; }
+};
+
+// ... and the real one: output (x,y) of a pass over `src`
+template<typename Q,int C,bool BLEND>
+struct ReferenceSample
+{
+  const Q *src;
+  const double *taps;
+  int W,H,K,shift,x,y;
+  bool vertical;
+  double bias;
+  __device__ __forceinline__ unsigned operator()(int c) const
+  {
+    return (unsigned) conv1d_reference_sample<Q,C,BLEND>(src,W,H,vertical,x,y,c,taps,K,shift,bias);
+  }
+};
+
 // ---------------------------------------------------------------- Accum
 template<typename Q,int C,bool BLEND,class A,int R>
 struct Accum
@@ -130,11 +190,48 @@ struct Accum
   }
 
   // returns the number of channels that count as "changed" (morphology.c:2772, :3199)
+  // reference(c): the sample recomputed in the reference's order (Tie64's doubtful results)
+  template<class Reference=NoReference>
   __device__ __forceinline__ unsigned finish(int r,const Q (&center)[C],uint32_t copy_mask,
-    Q (&out)[C],T bias,bool count_changed=true) const
+    Q (&out)[C],T bias,bool count_changed=true,const Reference &reference=Reference()) const
   {
     unsigned changed=0;
-    if constexpr (A::premultiply)
+    if constexpr (A::tie_check)
+      {
+        // fused fp64 sums of alpha-premultiplied samples (bias 0, no change count: the launcher
+        // sends everything else to Exact64).  S_c = sum k*alpha*p, S_a = sum k*alpha.
+        static_assert((sizeof(Q) == 2) && (sizeof(T) == 8),"the tie check is for Q16 sums in fp64");
+        T inverse=(T) 1;
+        bool doubtful=false;
+        if constexpr (BLEND)
+          {
+            const T sa=MH_S(r,C-1);
+            // PerceptibleReciprocal acts below MagickEpsilon (the reference's gamma is QuantumScale*S_a)
+            doubtful=(sa != (T) 0) && !((T) kQS*sa >= (T) kEps);
+            inverse=sa == (T) 0 ? (T) 0 : perceptible_reciprocal_fast(sa);
+          }
+#pragma unroll
+        for (int c=0; c < C; c++)
+          {
+            if ((copy_mask >> c) & 1u)
+              {
+                out[c]=center[c];
+                continue;
+              }
+            T value=MH_S(r,c);
+            if (BLEND && (c != C-1))
+              value=value*inverse;
+            const T shifted=value+(T) 0.5;
+            const T fraction=shifted-__builtin_floor(shifted);
+            const bool tie=(fraction < (T) kTieMargin) || (fraction > (T) 1-(T) kTieMargin);
+            Q level=QuantumOps<Q>::clamp(value);
+            if (tie || (doubtful && BLEND && (c != C-1)))
+              level=(Q) reference(c);
+            out[c]=level;
+          }
+        return 0;
+      }
+    else if constexpr (A::premultiply)
       {
         // FAST epilogue, all in f32 and branch-free.  s[] holds the un-biased sums
         // S_c = sum k*alpha*p (colour), S_a = sum k*alpha; the reference's
@@ -204,6 +301,16 @@ struct Conv1DArgs
   unsigned long long *changed;
   int nblocks;               // blocked kernels: number of U-sample blocks of the padded tap table
 };
+
+template<typename Q,int C,bool BLEND,class A>
+static __device__ __forceinline__ auto make_reference(const Conv1DArgs &args,bool vertical,int x,int y)
+{
+  if constexpr (A::tie_check)
+    return ReferenceSample<Q,C,BLEND>{static_cast<const Q *>(args.src),static_cast<const double *>(args.taps),
+      args.columns,args.rows,args.ntaps,args.shift,x,y,vertical,args.bias};
+  else
+    return NoReference();
+}
 
 // --------------------------------------------------------------- column pass
 template<typename Q,int C,bool BLEND,class A,int R,int WAVES>
@@ -1024,7 +1131,8 @@ void conv_column_tri(Conv1DArgs args)
             center[c]=(Q) 0;
           if (need_center)
             load_pixel<Q,C>(src+(size_t) y*pitch,center);
-          unsigned ch=acc.finish(r,center,args.copy_mask,out,(T) args.bias,args.changed != nullptr);
+          unsigned ch=acc.finish(r,center,args.copy_mask,out,(T) args.bias,args.changed != nullptr,
+            make_reference<Q,C,BLEND,A>(args,true,xc,y));
           if (x < W)
             {
               store_pixel<Q,C>(dst+(size_t) y*pitch+(size_t) x*C,out);
@@ -1134,7 +1242,8 @@ void conv_column_lds(Conv1DArgs args)
         {
           Q center[C],out[C];
           load_pixel<Q,C>(mine+(size_t) (r+args.shift)*64*C,center);   // input row y
-          unsigned ch=acc.finish(r,center,args.copy_mask,out,(T) args.bias,args.changed != nullptr);
+          unsigned ch=acc.finish(r,center,args.copy_mask,out,(T) args.bias,args.changed != nullptr,
+            make_reference<Q,C,BLEND,A>(args,true,x < W ? x : W-1,y));
           if (x < W)
             {
               store_pixel<Q,C>(dst+(size_t) y*pitch+(size_t) x*C,out);
@@ -1244,7 +1353,8 @@ void conv_row_tri(Conv1DArgs args)
           Q center[C],out[C];
           int ci=lane*R+r+args.shift;           // strip index of input column x
           load_pixel<Q,C>(strip+(size_t) (ci+ci/R)*C,center);
-          changed+=acc.finish(r,center,args.copy_mask,out,(T) args.bias,args.changed != nullptr);
+          changed+=acc.finish(r,center,args.copy_mask,out,(T) args.bias,args.changed != nullptr,
+            make_reference<Q,C,BLEND,A>(args,false,x,y));
           if constexpr (kPair)
             {
               if (x+1 < W)
@@ -1252,7 +1362,8 @@ void conv_row_tri(Conv1DArgs args)
                   Q center1[C],out1[C];
                   int c1=ci+1;
                   load_pixel<Q,C>(strip+(size_t) (c1+c1/R)*C,center1);
-                  changed+=acc.finish(r+1,center1,args.copy_mask,out1,(T) args.bias,args.changed != nullptr);
+                  changed+=acc.finish(r+1,center1,args.copy_mask,out1,(T) args.bias,args.changed != nullptr,
+                    make_reference<Q,C,BLEND,A>(args,false,x+1,y));
                   Q both[2*C];
 #pragma unroll
                   for (int c=0; c < C; c++)
@@ -1597,7 +1708,18 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
           return MH_OK;
         }
       if ((params.ntaps >= 16) && (getenv("MAGICKHIP_NO_TRI") == nullptr))
-        return dispatch_tri<Exact64,8,8>(src,dst,vertical,params,roles,changed);
+        {
+          // fused sums + reference-order recomputation of the results they cannot decide: the
+          // same bits at less than half the fp64 work (device_common.hpp, Tie64).  Positive taps
+          // only (a weighted sum of both signs can cancel: the error bound is relative to the
+          // sum of magnitudes, not to the result), no bias, no change count.
+          bool positive=true;
+          for (int v=0; v < params.ntaps; v++)
+            positive=positive && (params.taps[v] >= 0.0);
+          if (positive && (params.bias == 0.0) && (changed == nullptr) && (getenv("MAGICKHIP_NO_TIE64") == nullptr))
+            return dispatch_tri<Tie64,8,8>(src,dst,vertical,params,roles,changed);
+          return dispatch_tri<Exact64,8,8>(src,dst,vertical,params,roles,changed);
+        }
       return dispatch_blocked<Exact64,8,8>(src,dst,vertical,params,roles,changed);
     }
   // float Quantum always accumulates in double: an FP32 sum cannot stay

@@ -145,6 +145,7 @@ struct Exact64
   typedef double T;
   static constexpr bool premultiply=false;
   static constexpr bool taps_in_lds=false;
+  static constexpr bool tie_check=false;
   static __device__ __forceinline__ T mul(T a,T b) { return a*b; }
   static __device__ __forceinline__ T add(T a,T b) { return a+b; }
   static __device__ __forceinline__ T mac(T acc,T a,T b) { return acc+a*b; }   // two roundings
@@ -160,10 +161,31 @@ struct Fma64
   typedef double T;
   static constexpr bool premultiply=false;
   static constexpr bool taps_in_lds=false;
+  static constexpr bool tie_check=false;
   static __device__ __forceinline__ T mul(T a,T b) { return a*b; }
   static __device__ __forceinline__ T add(T a,T b) { return a+b; }
   static __device__ __forceinline__ T mac(T acc,T a,T b) { return __builtin_fma(a,b,acc); }
 };
+
+// EXACT results at less than half the fp64 work: the sums are formed with fused multiply-adds
+// over alpha-premultiplied samples (alpha*p is an exact integer below 2^32, so a tap costs one FMA
+// per channel instead of the reference's multiply, multiply, add, add), which agrees with the
+// reference's separately rounded sums to ~1e-14 relative — 1e-9 Quantum levels.  Rounding to a
+// Quantum level can then only differ when the value lies within 1e-9 of a rounding tie; every
+// result within kTieMargin (1e-6) of a tie, and every pixel whose alpha sum is small enough for
+// PerceptibleReciprocal's clamp to act, is recomputed in the reference's own operation order
+// (about two samples per million).  The output is bit-identical to Exact64's; Q16 only.
+struct Tie64
+{
+  typedef double T;
+  static constexpr bool premultiply=true;
+  static constexpr bool taps_in_lds=false;
+  static constexpr bool tie_check=true;
+  static __device__ __forceinline__ T mul(T a,T b) { return a*b; }
+  static __device__ __forceinline__ T add(T a,T b) { return a+b; }
+  static __device__ __forceinline__ T mac(T acc,T a,T b) { return __builtin_fma(a,b,acc); }
+};
+constexpr double kTieMargin=1.0e-6;
 
 // FAST: float with explicit FMA; alpha is folded into the colour channels once
 // per input pixel.  Only offered for Q16, where the accumulated error stays
@@ -173,6 +195,7 @@ struct Fast32
   typedef float T;
   static constexpr bool premultiply=true;
   static constexpr bool taps_in_lds=true;
+  static constexpr bool tie_check=false;
   static __device__ __forceinline__ T mul(T a,T b) { return a*b; }
   static __device__ __forceinline__ T add(T a,T b) { return a+b; }
   static __device__ __forceinline__ T mac(T acc,T a,T b) { return __builtin_fmaf(a,b,acc); }

@@ -33,6 +33,27 @@ def test_blur_exact(im, refmod, dtype, shape, sigma):
     assert_parity(got, want, True, "blur %s sigma=%g" % (shape, sigma))
 
 
+@pytest.mark.parametrize("pattern", ["columns", "rows", "checker", "alpha"])
+@pytest.mark.parametrize("sigma", [3.0, 10.0])
+def test_blur_exact_on_rounding_ties(im, refmod, pattern, sigma):
+    """EXACT forms its sums with fused multiply-adds and recomputes, in the reference's own
+    operation order, every result that lies within 1e-6 of a rounding tie (device_common.hpp,
+    Tie64).  Images that alternate between v and v+1 put the blurred value on a tie (the even and
+    the odd taps of a Gaussian each sum to 1/2 to within 1e-16) almost everywhere: the reference's
+    level there is decided by the last bits of ITS summation, and the result must still be
+    bit-identical."""
+    rows, cols = 96, 130
+    y, x = np.mgrid[0:rows, 0:cols]
+    base = {"columns": x & 1, "rows": y & 1, "checker": (x + y) & 1, "alpha": x & 1}[pattern]
+    px = np.empty((rows, cols, 4), dtype=np.uint16)
+    for c, level in enumerate((1000, 32767, 65534)):
+        px[:, :, c] = level + base
+    px[:, :, 3] = 65535 if pattern != "alpha" else 40000 + (y & 1)
+    dev, ref = run_pair(im, refmod, px)
+    assert_parity(im.blur_image(dev, 0.0, sigma).numpy(), ref.blur(0.0, sigma).numpy(), True,
+                  "blur on ties, %s sigma %g" % (pattern, sigma))
+
+
 def test_blur_radius_argument(im, refmod):
     px = make_pixels(64, 80, 4, Q16)
     dev, ref = run_pair(im, refmod, px)
