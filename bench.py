@@ -33,6 +33,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP64_VALU_PEAK_TFLOPS = 78.6      # 1/2 of the guide's 157.3 TFLOP/s fp32 vector peak
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 METRIC = "Mpixels/sec GaussianBlur σ=10 + Lanczos 4× resize, 8K RGBA; %HBM-roofline"
 
@@ -255,6 +256,17 @@ def blur_mode(im, torch, image, sigma, precision, reps):
                                 ("exact:" if precision == "exact" else "") + dominant),
            "operator_frac_of_compulsory_bytes": round(2.0 * frame / sec / 1e9 / HBM_PEAK_GBS, 4),
            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in prof.items()}}
+    if precision == "exact":
+        # the fp64 kernels are bound by the vector unit, not by HBM: K taps x 4 channels of
+        # v_fma_f64 per pixel per pass (v_fma_f64 issues at half the fp32 rate: 256 CUs x 4 SIMDs
+        # x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s)
+        ntaps = im.optimal_kernel_width_1d(0.0, sigma)
+        flops = pixels * 4.0 * ntaps * 2.0
+        achieved = flops / (conv[dominant]["avg_ms"] * 1e-3) / 1e12
+        out["compute_roofline"] = {"bound": "valu_f64", "kernel": dominant, "achieved": round(achieved, 2),
+                                   "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(achieved / FP64_VALU_PEAK_TFLOPS, 4),
+                                   "flops_per_launch": int(flops), "taps": int(ntaps)}
     holder.clear()
     return out
 
@@ -390,7 +402,20 @@ def extra_measurements(im, torch, args, image):
         t0 = time.perf_counter()
         for _ in range(2):
             im.blur_image(host_image, 0.0, args.sigma)
-        extra["blur_host_buffers_Mpixels_per_s"] = round(2 * n * n / (time.perf_counter() - t0) / 1e6, 1)
+        # (every call faults in a fresh 537 MB result array: the kernel's page faults, not the link)
+        extra["blur_host_buffers_new_result_Mpixels_per_s"] = round(2 * n * n / (time.perf_counter() - t0) / 1e6, 1)
+        # ... and into a destination that already exists, which is MagickCore's situation: the
+        # result image's pixel cache is allocated (and touched) by CloneImage before the operator runs
+        host_out = host_image.like()
+        host_out.pixels[:] = 0
+        im.blur_image(host_image, 0.0, args.sigma, out=host_out)
+        t0 = time.perf_counter()
+        for _ in range(4):
+            im.blur_image(host_image, 0.0, args.sigma, out=host_out)
+        extra["blur_host_buffers_Mpixels_per_s"] = round(4 * n * n / (time.perf_counter() - t0) / 1e6, 1)
+        extra["host_link"] = ("PCIe: 57 GB/s either direction, 57 GB/s combined when both run (half duplex on "
+                              "this box, tools/pcie_probe.py): 1.07 GB per 8192^2 call = 18.8 ms at best")
+        del host_out
         del host, host_image
         torch.cuda.empty_cache()
         result["resize"] = resize_config(im, torch, gen)

@@ -203,10 +203,13 @@ def get_precision():
 
 
 # ------------------------------------------------------------------- operators
-def blur_image(image, radius, sigma):
-    """BlurImage(image, radius, sigma) — MagickCore/effect.c:765."""
+def blur_image(image, radius, sigma, out=None):
+    """BlurImage(image, radius, sigma) — MagickCore/effect.c:765.  `out`: an Image of the same
+    geometry to receive the result (what MagickCore does: the destination is a pixel cache that
+    already exists), instead of a freshly allocated one."""
     lib = _lib.load()
-    out = image.like()
+    if out is None:
+        out = image.like()
     _lib.check(lib.MagickHipBlurImage(ctypes.byref(image.descriptor()),
                                       ctypes.byref(out.descriptor()), radius, sigma))
     return out

@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/profiles_<tag>/ (tools/collect_profiles_r2.sh, run on the GPU box) into the
+committed files under profiles/:
+   <tag>_kernel_stats.csv              rocprofv3 --stats of the headline command (per kernel)
+   <tag>_kernel_stats_all_configs.csv  the same for the whole default bench command
+   <tag>_pmc.csv                       per workload and kernel: mean FETCH_SIZE / WRITE_SIZE per launch
+   pmc_traffic.json                    HBM bytes per launch keyed the way bench.py looks them up
+                                       (FETCH_SIZE is in KiB and counts half the bytes of a wide
+                                       coalesced stream on gfx950: x2; WRITE_SIZE is KiB:
+                                       /opt/skills/guides/MI355X_MICROARCH.md, HBM section)
+   <tag>_bench.json                    the bench line of the same box
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# HIP kernel name -> the label the library's launch records (and bench.py) use
+LABELS = [
+    (r"blur_fused", "blur_fused"),
+    (r"conv_mfma_kernel<true", "conv_column"), (r"conv_mfma_kernel<false", "conv_row"),
+    (r"conv_column_", "conv_column"), (r"conv_row_alpha_audit", "conv_row_alpha_audit"), (r"conv_row_", "conv_row"),
+    (r"resize_vertical", "resize_vertical"), (r"resize_horizontal", "resize_horizontal"),
+    (r"resize_fused", "resize_fused"),
+    (r"colorspace_", "colorspace"), (r"histogram_", "histogram"), (r"apply_lut", "apply_lut"),
+    (r"lut_", "build_lut"), (r"gray_", "gray_check"),
+    (r"morph_convex", "morph_convex"), (r"morph2d", "morph2d"), (r"unsharp_kernel", "unsharp_epilogue"),
+]
+PREFIX = {"fast": "", "exact": "exact:", "resize": "", "c4": "c4:", "c5": "c5:"}
+
+
+def label(name):
+    name = name.replace("void ", "").replace("mh::", "")
+    for pattern, lab in LABELS:
+        if re.match(pattern, name):
+            return lab
+    return None
+
+
+def main(tag):
+    src = os.path.join(ROOT, "gpurun_out", "profiles_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    for sub, suffix in (("stats", "_kernel_stats.csv"), ("stats_full", "_kernel_stats_all_configs.csv")):
+        stats = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+        if not stats:
+            continue
+        rows = list(csv.DictReader(open(stats[0])))
+        with open(os.path.join(dst, tag + suffix), "w") as f:
+            f.write("kernel,calls,total_ns,average_ns,percentage\n")
+            for r in rows:
+                n = r["Name"]
+                n = n if len(n) < 140 else n[:137] + "..."
+                f.write('"%s",%s,%s,%s,%s\n' % (n.replace('"', "'"), r["Calls"], r["TotalDurationNs"],
+                                                r["AverageNs"], r["Percentage"]))
+    traffic, detail = {}, {}
+    with open(os.path.join(dst, tag + "_pmc.csv"), "w") as f:
+        f.write("workload,kernel,label,counter,mean_per_launch,launches\n")
+        for w, prefix in PREFIX.items():
+            acc = defaultdict(lambda: defaultdict(list))
+            full = {}
+            for path in glob.glob(os.path.join(src, "pmc_%s_*" % w, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(path)):
+                    lab = label(r["Kernel_Name"])
+                    if lab is None:
+                        continue
+                    acc[lab][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    full[lab] = r["Kernel_Name"].split("(")[0].replace("void ", "")[:90]
+            for lab in sorted(acc):
+                for c in sorted(acc[lab]):
+                    v = acc[lab][c]
+                    f.write('%s,"%s",%s,%s,%.6g,%d\n' % (w, full[lab], lab, c, sum(v) / len(v), len(v)))
+                if "FETCH_SIZE" in acc[lab] and "WRITE_SIZE" in acc[lab]:
+                    fetch = sum(acc[lab]["FETCH_SIZE"]) / len(acc[lab]["FETCH_SIZE"]) * 1024.0 * 2.0
+                    write = sum(acc[lab]["WRITE_SIZE"]) / len(acc[lab]["WRITE_SIZE"]) * 1024.0
+                    traffic[prefix + lab] = round(fetch + write)
+                    detail[prefix + lab] = {"kernel": full[lab], "fetch_bytes": round(fetch), "write_bytes": round(write)}
+    traffic["_detail"] = detail
+    traffic["_source"] = "profiles/%s_pmc.csv (tools/collect_profiles_r2.sh + tools/import_profiles_r2.py)" % tag
+    json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    bench = os.path.join(src, "bench.json")
+    if os.path.exists(bench):
+        lines = [l for l in open(bench).read().splitlines() if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, tag + "_bench.json"), "w").write(lines[-1] + "\n")
+    print(json.dumps({k: v for k, v in traffic.items() if not k.startswith("_")}, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r2")
