@@ -317,7 +317,7 @@ def c4_config(im, torch, gen):
     sec = timed(torch, c4, 5)
     prof = kernel_profile(im, c4, 3)
     frame = float(k) * k * 8.0
-    bytes_by_kernel = {"colorspace": 2.0 * frame, "histogram": frame / 4.0, "apply_lut": 2.0 * frame,
+    bytes_by_kernel = {"colorspace": 2.0 * frame, "histogram": frame, "apply_lut": 2.0 * frame,
                        "gray_check": frame}
     kernels = kernel_rooflines(prof, bytes_by_kernel, "c4:")
     kernel_ms = sum(v["avg_ms"] for v in prof.values())

@@ -54,6 +54,8 @@ struct BlurFusedArgs
   int blocks;                // ceil(rows/32) output blocks per strip
   int blocks_per_segment;
   int items_per_xcd;         // ceil(strips*segments/8)
+  float gain;                // UnsharpMaskImage's epilogue (blur_fused16_kernel<.., UNSHARP>)
+  int threshold;             // ceil(QuantumRange*threshold), see unsharp_sample
 };
 
 // ds_read_b128 is served in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32)
@@ -483,7 +485,7 @@ struct Fused16Geometry
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-template<int NC,int MODE>
+template<int NC,int MODE,bool UNSHARP>
 __global__ __launch_bounds__(1024)
 void blur_fused16_kernel(BlurFusedArgs args)
 {
@@ -585,16 +587,29 @@ void blur_fused16_kernel(BlurFusedArgs args)
   const int col_entry=(n & 3)*G::CHC+(4*wave+(n >> 2))*G::SC+8*(kq & 1);
   const int ring_entry=kq*G::CHC+(16*ot+n)*G::SC+4*rq;     // the row pass's ring store
   int ring_group=0;                            // g mod NR (wave-uniform)
+  // UNSHARP: the unblurred pixel of the lane's column-pass output (effect.c:4364-4369), fetched
+  // one iteration ahead, behind the staging loads, so that the wait the staging does anyway
+  // covers it (the strip's rows left the CU 32*NC rows ago: an L2 / MALL hit)
+  uint2 original=make_uint2(0u,0u);
+  auto fetch_original=[&](int block)
+  {
+    const int x=x0+4*wave+kq,y=out_begin+G::GROUP*block+n;
+    if ((block >= 0) && (block < nblocks) && (x < W) && (y < H))
+      original=*reinterpret_cast<const uint2 *>(args.src+pixel_index(y,W,x)*4);
+  };
 
   fetch(0);
   for (int g=0; g <= ngroups; g++)
     {
+      uint2 unblurred=original;
       if (g < ngroups)
         {
           stage();
           if (g+1 < ngroups)
             fetch(g+1);
         }
+      if constexpr (UNSHARP)
+        fetch_original(g+1-G::NG);
       if (g >= G::NG)
         {
           // ---- column pass of output rows out_begin+16*block .. +16
@@ -621,7 +636,9 @@ void blur_fused16_kernel(BlurFusedArgs args)
               acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_lo[c],acc,0,0,0);
             }
           // lane (n, kq): the four channels (registers) of pixel (column 4*wave+kq, row n)
-          const uint2 result=sums_to_quantum<MODE>(acc[0],acc[1],acc[2],acc[3]);
+          uint2 result=sums_to_quantum<MODE>(acc[0],acc[1],acc[2],acc[3]);
+          if constexpr (UNSHARP)
+            result=unsharp_pixel(unblurred,result,args.gain,args.threshold);
           const int x=x0+4*wave+kq,y=out_begin+G::GROUP*block+n;
           if ((x < W) && (y < H))
             *reinterpret_cast<uint2 *>(args.dst+pixel_index(y,W,x)*4)=result;
@@ -714,7 +731,7 @@ void blur_fused16_kernel(BlurFusedArgs args)
     }
 }
 
-template<int NC,int MODE>
+template<int NC,int MODE,bool UNSHARP>
 static MhStatus launch_fused16_typed(const View &src,BlurFusedArgs &args)
 {
   typedef Fused16Geometry<NC> G;
@@ -733,17 +750,30 @@ static MhStatus launch_fused16_typed(const View &src,BlurFusedArgs &args)
   const int items=args.strips*args.segments;
   args.items_per_xcd=(items+7)/8;
   const size_t lds=G::lds_bytes;
-  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&blur_fused16_kernel<NC,MODE>),
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&blur_fused16_kernel<NC,MODE,UNSHARP>),
     hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
-  ProfileScope prof("blur_fused",src.stream);
-  hipLaunchKernelGGL((blur_fused16_kernel<NC,MODE>),dim3((unsigned) (8*args.items_per_xcd)),dim3(1024),lds,
+  ProfileScope prof(UNSHARP ? "unsharp_fused" : "blur_fused",src.stream);
+  hipLaunchKernelGGL((blur_fused16_kernel<NC,MODE,UNSHARP>),dim3((unsigned) (8*args.items_per_xcd)),dim3(1024),lds,
     src.stream,args);
   MH_HIP(hipGetLastError());
   return MH_OK;
 }
 
+template<int NC>
+static MhStatus launch_fused16(const View &src,BlurFusedArgs &args,bool blend,bool unsharp)
+{
+  if (unsharp)
+    return blend ? launch_fused16_typed<NC,MFMA_BLEND4,true>(src,args) :
+      launch_fused16_typed<NC,MFMA_PLAIN4,true>(src,args);
+  return blend ? launch_fused16_typed<NC,MFMA_BLEND4,false>(src,args) :
+    launch_fused16_typed<NC,MFMA_PLAIN4,false>(src,args);
+}
+
+// unsharp: UnsharpMaskImage(gain, threshold) of src with this blur, in the same launch (the
+// column pass's copy-out applies effect.c:4364-4369 against the unblurred pixel).
 MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_device,
-  const double *taps64_device,int ntaps,int shift,bool blend,bool *handled)
+  const double *taps64_device,int ntaps,int shift,bool blend,bool *handled,bool unsharp,double gain,
+  double threshold)
 {
   *handled=false;
   if ((src.quantum != MH_QUANTUM_U16) || (dst.quantum != MH_QUANTUM_U16) || (src.channels != 4) ||
@@ -764,16 +794,26 @@ MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_dev
   args.shift=shift;
   args.taps=taps_device;
   args.taps64=taps64_device;
+  args.gain=(float) gain;
+  {
+    const double level=std::ceil(65535.0*threshold);
+    args.threshold=level > 131072.0 ? 131072 : (level < 0.0 ? 0 : (int) level);
+  }
   *handled=true;
-  if (getenv("MAGICKHIP_FUSED_32") == nullptr)
+  if ((getenv("MAGICKHIP_FUSED_32") == nullptr) || unsharp)
     {
       const int nc=(ntaps+15+31)/32;             // 16 outputs + K-1 halo, in 32-sample chunks
       if (nc == 1)
-        return blend ? launch_fused16_typed<1,MFMA_BLEND4>(src,args) : launch_fused16_typed<1,MFMA_PLAIN4>(src,args);
+        return launch_fused16<1>(src,args,blend,unsharp);
       if (nc == 2)
-        return blend ? launch_fused16_typed<2,MFMA_BLEND4>(src,args) : launch_fused16_typed<2,MFMA_PLAIN4>(src,args);
+        return launch_fused16<2>(src,args,blend,unsharp);
       if (nc == 3)
-        return blend ? launch_fused16_typed<3,MFMA_BLEND4>(src,args) : launch_fused16_typed<3,MFMA_PLAIN4>(src,args);
+        return launch_fused16<3>(src,args,blend,unsharp);
+    }
+  if (unsharp)
+    {
+      *handled=false;                            // wider kernels: row pass + fused column pass
+      return MH_OK;
     }
 #define MH_NQ(NQV) \
   case NQV: \

@@ -165,4 +165,27 @@ static __device__ __forceinline__ unsigned exact_alpha_level(const uint16_t *src
   return (unsigned) (sum+0.5);
 }
 
+// UnsharpMaskImage's epilogue for one Quantum-rounded blurred sample b of the sample p
+// (effect.c:4364-4369): p if |2(p-b)| < QuantumRange*threshold, else p+gain*(p-b), clamped and
+// rounded.  2(p-b) is an integer, so comparing it with the ceiling of the threshold is exact.
+static __device__ __forceinline__ unsigned unsharp_sample(unsigned p,unsigned b,float gain,int threshold)
+{
+  const int d=(int) p-(int) b;
+  const int twice=d < 0 ? -2*d : 2*d;
+  // ClampToQuantum: round half up (gain*d has exact halves for gains like 2.5, so the
+  // round-to-even of v_cvt_pknorm would differ from the reference on every such tie)
+  const float sharpened=(float) p+gain*(float) d+0.5f;
+  const unsigned level=(unsigned) (sharpened < 0.0f ? 0.0f : sharpened);
+  return twice < threshold ? p : (level > 65535u ? 65535u : level);
+}
+
+static __device__ __forceinline__ uint2 unsharp_pixel(uint2 p,uint2 b,float gain,int threshold)
+{
+  return make_uint2(
+    unsharp_sample(p.x & 0xffffu,b.x & 0xffffu,gain,threshold) |
+      (unsharp_sample(p.x >> 16,b.x >> 16,gain,threshold) << 16),
+    unsharp_sample(p.y & 0xffffu,b.y & 0xffffu,gain,threshold) |
+      (unsharp_sample(p.y >> 16,b.y >> 16,gain,threshold) << 16));
+}
+
 } // namespace mh

@@ -62,24 +62,33 @@ def main(tag):
     with open(os.path.join(dst, tag + "_pmc.csv"), "w") as f:
         f.write("workload,kernel,label,counter,mean_per_launch,launches\n")
         for w, prefix in PREFIX.items():
-            acc = defaultdict(lambda: defaultdict(list))
-            full = {}
+            # label -> kernel name -> counter -> values (a label can cover several kernels, each
+            # launched once per operator call: histogram = binning + slab reduce, build_lut = 3)
+            acc = defaultdict(lambda: defaultdict(lambda: defaultdict(list)))
             for path in glob.glob(os.path.join(src, "pmc_%s_*" % w, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(path)):
                     lab = label(r["Kernel_Name"])
                     if lab is None:
                         continue
-                    acc[lab][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                    full[lab] = r["Kernel_Name"].split("(")[0].replace("void ", "")[:90]
+                    name = r["Kernel_Name"].split("(")[0].replace("void ", "")[:90]
+                    acc[lab][name][r["Counter_Name"]].append(float(r["Counter_Value"]))
             for lab in sorted(acc):
-                for c in sorted(acc[lab]):
-                    v = acc[lab][c]
-                    f.write('%s,"%s",%s,%s,%.6g,%d\n' % (w, full[lab], lab, c, sum(v) / len(v), len(v)))
-                if "FETCH_SIZE" in acc[lab] and "WRITE_SIZE" in acc[lab]:
-                    fetch = sum(acc[lab]["FETCH_SIZE"]) / len(acc[lab]["FETCH_SIZE"]) * 1024.0 * 2.0
-                    write = sum(acc[lab]["WRITE_SIZE"]) / len(acc[lab]["WRITE_SIZE"]) * 1024.0
+                fetch = write = 0.0
+                complete = True
+                for name in sorted(acc[lab]):
+                    for c in sorted(acc[lab][name]):
+                        v = acc[lab][name][c]
+                        f.write('%s,"%s",%s,%s,%.6g,%d\n' % (w, name, lab, c, sum(v) / len(v), len(v)))
+                    k = acc[lab][name]
+                    if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+                        fetch += sum(k["FETCH_SIZE"]) / len(k["FETCH_SIZE"]) * 1024.0 * 2.0
+                        write += sum(k["WRITE_SIZE"]) / len(k["WRITE_SIZE"]) * 1024.0
+                    else:
+                        complete = False
+                if complete:
                     traffic[prefix + lab] = round(fetch + write)
-                    detail[prefix + lab] = {"kernel": full[lab], "fetch_bytes": round(fetch), "write_bytes": round(write)}
+                    detail[prefix + lab] = {"kernels": sorted(acc[lab]), "fetch_bytes": round(fetch),
+                                            "write_bytes": round(write)}
     traffic["_detail"] = detail
     traffic["_source"] = "profiles/%s_pmc.csv (tools/collect_profiles_r2.sh + tools/import_profiles_r2.py)" % tag
     json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
