@@ -195,7 +195,8 @@ MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const 
 // (the doubles feed the exact recomputation of ambiguous small alpha levels).
 // *handled=false when the shape is outside the kernel's reach and nothing was launched.
 MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_device,
-  const double *taps64_device,int ntaps,int shift,bool blend,bool *handled);
+  const double *taps64_device,int ntaps,int shift,bool blend,bool *handled,bool unsharp=false,
+  double gain=0.0,double threshold=0.0);
 // UnsharpMaskImage's column pass + epilogue in one launch: rows = the row pass's result,
 // original = the unblurred frame (effect.c:4343-4372)
 MhStatus launch_conv1d_unsharp(const View &rows,const View &dst,const View &original,

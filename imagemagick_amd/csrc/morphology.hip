@@ -630,6 +630,380 @@ static MhStatus launch_convex(bool dilate,const ConvexArgs &args,dim3 grid,size_
     launch_convex_waves<Q,C,false,8>(args,grid,lds,stream);
 }
 
+// ------------------------------------------------ Erode / Dilate, symmetric convex kernels
+// A flat kernel whose rows are centred runs, symmetric about a centre row, with half-widths that do
+// not grow away from it (Disk, Square, Rectangle, Diamond, Octagon, Plus ...) is the union of the
+// centred rectangles  Rect(h_l, v_l),  h_0 < h_1 < ... < h_L  the distinct half-widths and v_l the
+// largest |dy| whose row is at least h_l wide (v_0 > v_1 > ... > v_L).  With Row(h) = Row(h_0) +
+// Row(h_1-h_0) + ... (Minkowski sums) and because dilation distributes over unions,
+//     out = Row(h_0)[ Col(v_0) in  v  Row(h_1-h_0)[ Col(v_1) in  v  ... Row(h_L-h_{L-1})[ Col(v_L) in ] ] ]
+// evaluated from the inside out:   C <- Col(v_l) in  (widened from Col(v_{l+1}) in: v_l grows),
+//                                  S <- Row(h_l-h_{l-1})[ C v S ].
+// 2 v_0 + 2 h_L + L+1 compares per pixel (Disk:15: 71 against the 709 cells), all min/max, so
+// the result has the reference's bits (morphology.c:2980-3036) whatever the order.
+//
+// MI355X mapping: lane = two adjacent columns, a wave = 128 columns x SY rows held in VGPRs (C
+// and S).  Col() reads the lane's own columns of the staged tile (ds_read_b128, conflict free,
+// wave-uniform row offsets); Row(d) is d applications of Row(1), whose two neighbour columns
+// that live in the next lane come over with one v_mov_b32_dpp wave_shr:1 / wave_shl:1 each — no
+// LDS traffic and no barrier between the levels.  The columns within hmax of the wave's edges
+// fill with garbage (one per Row(1)) and are not stored: a workgroup produces 128-2*hmax columns.
+struct RectsArgs
+{
+  const uint16_t *src;
+  uint16_t *dst;
+  int columns,rows;
+  int cx,cy;                  // centre of the shape relative to the output pixel
+  int hmax,vmax;              // half-width of the widest row, half-height
+  int nlevels;
+  int tiles_x,tiles_y,tiles_per_xcd;
+  uint32_t copy_mask;
+  unsigned long long *changed;
+  unsigned char widen[64];    // [nlevels]  h_l - h_{l-1}  (h_{-1} = 0)
+  unsigned char reach[64];    // [nlevels]  v_l
+};
+
+template<bool DILATE>
+static __device__ __forceinline__ uint32_t pk_pick(uint32_t a,uint32_t b)
+{
+  typedef unsigned short U2 __attribute__((ext_vector_type(2)));
+  const U2 va=__builtin_bit_cast(U2,a),vb=__builtin_bit_cast(U2,b);
+  return __builtin_bit_cast(uint32_t,DILATE ? __builtin_elementwise_max(va,vb) : __builtin_elementwise_min(va,vb));
+}
+
+template<int C,bool DILATE,int SY,int NWAVES>
+__global__ __launch_bounds__(64*NWAVES)
+void morph_rects_kernel(RectsArgs args)
+{
+  static_assert((C == 2) || (C == 4),"whole 32-bit words per pixel");
+  constexpr int SX=2;                          // columns per lane
+  constexpr int NW=C/2;                        // 32-bit words per pixel
+  constexpr int WPR=SX*NW;                     // words a lane holds per row
+  constexpr int TH=SY*NWAVES;                  // output rows per workgroup
+  typedef uint32_t Group __attribute__((ext_vector_type(WPR)));
+  typedef Group __attribute__((aligned(4))) LooseGroup;      // global memory: pixel alignment only
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Group *tile=reinterpret_cast<Group *>(smem_raw);           // [TH+2*vmax][64]
+  const int W=args.columns,H=args.rows;
+  const int hmax=args.hmax,vmax=args.vmax;
+  const int tid=(int) threadIdx.x,lane=tid & 63;
+  const int wave=__builtin_amdgcn_readfirstlane(tid >> 6);
+  // consecutive workgroup ids go to different XCDs: give each XCD a contiguous run of tiles,
+  // row-major, so that the halo a tile shares with its neighbours is in that XCD's L2
+  const int id=((int) blockIdx.x & 7)*args.tiles_per_xcd+((int) blockIdx.x >> 3);
+  if (id >= args.tiles_x*args.tiles_y)
+    return;
+  const int tile_y=id/args.tiles_x,tile_x=id-tile_y*args.tiles_x;
+  const int valid_w=64*SX-2*hmax;
+  const int bx=tile_x*valid_w,by=tile_y*TH;
+  const int tile_rows=TH+2*vmax;
+  const size_t pitch=(size_t) W*C;
+
+  // ---- stage the edge-clamped source window (cache.c:2663-2679): tile column t is image
+  // column bx+cx-hmax+t, tile row q is image row by+cy-vmax+q
+  {
+    // a thread keeps its column pair and walks down the rows NWAVES apart: the column clamp and
+    // the in-frame test are done once, a row costs its clamp and one 32-bit offset (the host
+    // checks that the frame is below 4 GiB)
+    const int sx=bx+args.cx-hmax+SX*lane,sy0=by+args.cy-vmax;
+    const bool inside=(sx >= 0) && (sx+SX-1 <= W-1);
+    unsigned xoff[SX];
+#pragma unroll
+    for (int j=0; j < SX; j++)
+      {
+        int x=sx+j;
+        x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
+        xoff[j]=(unsigned) x*(unsigned) (C*sizeof(uint16_t));
+      }
+    const unsigned row_bytes=(unsigned) W*(unsigned) (C*sizeof(uint16_t));
+    const unsigned char *base=reinterpret_cast<const unsigned char *>(args.src);
+    constexpr int BATCH=NWAVES >= 16 ? 5 : (NWAVES >= 12 ? 4 : 7);  // Disk:15: 13 (6 waves) or 7 (12 waves) rows per thread, two round trips
+    for (int q0=wave; q0 < tile_rows; q0+=NWAVES*BATCH)
+      {
+        Group g[BATCH];
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          {
+            int q=q0+NWAVES*k;
+            q=q < tile_rows ? q : tile_rows-1;
+            int sy=sy0+q;
+            sy=sy < 0 ? 0 : (sy > H-1 ? H-1 : sy);
+            const unsigned char *row=base+(unsigned) sy*row_bytes;
+            if (inside)
+              g[k]=*reinterpret_cast<const LooseGroup *>(row+xoff[0]);
+            else
+              {
+#pragma unroll
+                for (int j=0; j < SX; j++)
+#pragma unroll
+                  for (int w=0; w < NW; w++)
+                    g[k][j*NW+w]=*reinterpret_cast<const uint32_t *>(row+xoff[j]+4*w);
+              }
+          }
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          if (q0+NWAVES*k < tile_rows)
+            tile[(q0+NWAVES*k)*64+lane]=g[k];
+      }
+  }
+  __syncthreads();
+
+  // ---- the wave's SY output rows: tile rows wave*SY+vmax+i
+  const Group *centre=tile+(size_t) (wave*SY+vmax)*64+lane;
+  uint32_t column[SY][WPR],spread[SY][WPR];    // C and S of the header
+#pragma unroll
+  for (int i=0; i < SY; i++)
+    {
+      const Group g=centre[i*64];
+#pragma unroll
+      for (int p=0; p < WPR; p++)
+        {
+          column[i][p]=g[p];
+          spread[i][p]=DILATE ? 0u : 0xffffffffu;
+        }
+    }
+  int folded=0;                                // rows +-1..folded are in `column`
+  for (int l=args.nlevels-1; l >= 0; l--)
+    {
+      const int reach=(int) args.reach[l];
+      for (int k=folded+1; k <= reach; k++)
+        {
+          Group above[SY],below[SY];
+#pragma unroll
+          for (int i=0; i < SY; i++)
+            {
+              above[i]=centre[(i-k)*64];
+              below[i]=centre[(i+k)*64];
+            }
+#pragma unroll
+          for (int i=0; i < SY; i++)
+#pragma unroll
+            for (int p=0; p < WPR; p++)
+              column[i][p]=pk_pick<DILATE>(pk_pick<DILATE>(column[i][p],above[i][p]),below[i][p]);
+        }
+      folded=reach > folded ? reach : folded;
+#pragma unroll
+      for (int i=0; i < SY; i++)
+#pragma unroll
+        for (int p=0; p < WPR; p++)
+          spread[i][p]=pk_pick<DILATE>(spread[i][p],column[i][p]);
+      const int widen=(int) args.widen[l];
+      for (int step=0; step < widen; step++)
+        {
+          // Row(1): every column takes in its two neighbours
+#pragma unroll
+          for (int i=0; i < SY; i++)
+            {
+              uint32_t next[WPR];
+#pragma unroll
+              for (int p=0; p < WPR; p++)
+                {
+                  const int j=p/NW;
+                  // wave_shr:1 — lane n reads lane n-1 (0x138); wave_shl:1 — lane n reads lane n+1 (0x130)
+                  const uint32_t left=j > 0 ? spread[i][p-NW] :
+                    (uint32_t) __builtin_amdgcn_mov_dpp((int) spread[i][p+(SX-1)*NW],0x138,0xf,0xf,true);
+                  const uint32_t right=j < SX-1 ? spread[i][p+NW] :
+                    (uint32_t) __builtin_amdgcn_mov_dpp((int) spread[i][p-(SX-1)*NW],0x130,0xf,0xf,true);
+                  next[p]=pk_pick<DILATE>(pk_pick<DILATE>(left,spread[i][p]),right);
+                }
+#pragma unroll
+              for (int p=0; p < WPR; p++)
+                spread[i][p]=next[p];
+            }
+        }
+    }
+
+  // ---- copy out: morphology.c:3180-3196 (channels without the update trait keep the source
+  // value; `changed` counts the updated samples that differ from the source)
+  unsigned changed=0;
+  const int u0=SX*lane-hmax;                   // first of the lane's columns within the valid span
+  const bool centred=(args.cx == 0) && (args.cy == 0);
+  if (DILATE && (args.copy_mask == 0u) && (args.changed == nullptr))
+    {
+      // every channel updated, nobody counts: the maxima are the result
+      const bool whole=(u0 >= 0) && (u0+SX-1 < valid_w) && (bx+u0+SX-1 < W);
+#pragma unroll
+      for (int i=0; i < SY; i++)
+        {
+          const int y=by+wave*SY+i;
+          if (y >= H)
+            break;
+          unsigned char *out=reinterpret_cast<unsigned char *>(args.dst)+(unsigned) y*((unsigned) W*(unsigned) (C*sizeof(uint16_t)));
+          Group result;
+#pragma unroll
+          for (int p=0; p < WPR; p++)
+            result[p]=spread[i][p];
+          if (whole)
+            *reinterpret_cast<LooseGroup *>(out+(unsigned) (bx+u0)*(unsigned) (C*sizeof(uint16_t)))=result;
+          else
+            {
+#pragma unroll
+              for (int j=0; j < SX; j++)
+                if ((u0+j >= 0) && (u0+j < valid_w) && (bx+u0+j < W))
+#pragma unroll
+                  for (int w=0; w < NW; w++)
+                    *reinterpret_cast<uint32_t *>(out+(unsigned) (bx+u0+j)*(unsigned) (C*sizeof(uint16_t))+4*w)=result[j*NW+w];
+            }
+        }
+      return;
+    }
+#pragma unroll
+  for (int i=0; i < SY; i++)
+    {
+      const int y=by+wave*SY+i;
+      if (y >= H)
+        break;
+      uint16_t *out_row=args.dst+(size_t) y*pitch;
+      const uint16_t *in_row=args.src+(size_t) y*pitch;
+      bool ok[SX];
+#pragma unroll
+      for (int j=0; j < SX; j++)
+        ok[j]=(u0+j >= 0) && (u0+j < valid_w) && (bx+u0+j < W);
+      Group original;
+      bool all=true;
+#pragma unroll
+      for (int j=0; j < SX; j++)
+        all=all && ok[j];
+      if (centred)
+        original=centre[i*64];                 // the output pixel is the centre of its own window
+      else if (all)
+        original=*reinterpret_cast<const LooseGroup *>(in_row+(size_t) (bx+u0)*C);
+      else
+        {
+#pragma unroll
+          for (int j=0; j < SX; j++)
+#pragma unroll
+            for (int w=0; w < NW; w++)
+              original[j*NW+w]=ok[j] ? *reinterpret_cast<const uint32_t *>(in_row+(size_t) (bx+u0+j)*C+2*w) : 0u;
+        }
+      Group result;
+#pragma unroll
+      for (int p=0; p < WPR; p++)
+        {
+          // Erode starts from the output pixel itself (morphology.c:2905-2912)
+          const uint32_t value=DILATE ? spread[i][p] : pk_pick<false>(spread[i][p],original[p]);
+          const int c0=2*(p % NW);             // channels of this word's halves
+          uint32_t keep=0u;
+          keep|=((args.copy_mask >> c0) & 1u) != 0u ? 0x0000ffffu : 0u;
+          keep|=((args.copy_mask >> (c0+1)) & 1u) != 0u ? 0xffff0000u : 0u;
+          result[p]=(original[p] & keep) | (value & ~keep);
+          const uint32_t differs=(value ^ original[p]) & ~keep;
+          if (ok[p/NW])
+            changed+=((differs & 0xffffu) != 0u ? 1u : 0u)+((differs >> 16) != 0u ? 1u : 0u);
+        }
+      if (all)
+        *reinterpret_cast<LooseGroup *>(out_row+(size_t) (bx+u0)*C)=result;
+      else
+        {
+#pragma unroll
+          for (int j=0; j < SX; j++)
+            if (ok[j])
+#pragma unroll
+              for (int w=0; w < NW; w++)
+                *reinterpret_cast<uint32_t *>(out_row+(size_t) (bx+u0+j)*C+2*w)=result[j*NW+w];
+        }
+    }
+  if (args.changed != nullptr)
+    {
+      changed=wave_sum(changed);
+      if ((lane == 0) && (changed != 0))
+        atomicAdd(args.changed,(unsigned long long) changed);
+    }
+}
+
+template<int C,bool DILATE,int SY,int WAVES>
+static MhStatus launch_rects_typed(const RectsArgs &args,size_t lds,hipStream_t stream)
+{
+  const dim3 grid((unsigned) (8*args.tiles_per_xcd)),block(64*WAVES);
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&morph_rects_kernel<C,DILATE,SY,WAVES>),
+    hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+  hipLaunchKernelGGL((morph_rects_kernel<C,DILATE,SY,WAVES>),grid,block,lds,stream,args);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+// shape: 0 = 6 waves x 8 rows, 1 = 12 waves x 4 rows, 3 = 16 waves x 3 rows (48 output rows
+// each), 2 = 12 waves x 8 rows
+template<int C>
+static MhStatus launch_rects(bool dilate,int shape,const RectsArgs &args,size_t lds,hipStream_t stream)
+{
+  if (shape == 3)
+    return dilate ? launch_rects_typed<C,true,3,16>(args,lds,stream) : launch_rects_typed<C,false,3,16>(args,lds,stream);
+  if (shape == 2)
+    return dilate ? launch_rects_typed<C,true,8,12>(args,lds,stream) : launch_rects_typed<C,false,8,12>(args,lds,stream);
+  if (shape == 1)
+    return dilate ? launch_rects_typed<C,true,4,12>(args,lds,stream) : launch_rects_typed<C,false,4,12>(args,lds,stream);
+  return dilate ? launch_rects_typed<C,true,8,6>(args,lds,stream) : launch_rects_typed<C,false,8,6>(args,lds,stream);
+}
+
+// half[k]: half-width of kernel row dy_min+k (every row non-empty, runs centred on cx).  Handles
+// the kernel when its rows are symmetric about the middle row and do not widen away from it.
+static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std::vector<int> &half,
+  int cx,int dy_min,const Roles &roles,unsigned long long *changed,bool *handled)
+{
+  *handled=false;
+  const int span=(int) half.size();
+  if ((src.quantum != MH_QUANTUM_U16) || ((src.channels != 4) && (src.channels != 2)) || ((span & 1) == 0) ||
+      (getenv("MAGICKHIP_NO_RECTS") != nullptr))
+    return MH_OK;
+  const int vmax=span/2;
+  for (int d=0; d <= vmax; d++)
+    {
+      if (half[(size_t) (vmax+d)] != half[(size_t) (vmax-d)])
+        return MH_OK;
+      if ((d > 0) && (half[(size_t) (vmax+d)] > half[(size_t) (vmax+d-1)]))
+        return MH_OK;
+    }
+  const int hmax=half[(size_t) vmax];
+  const size_t row_lds=64u*2u*(size_t) src.channels*sizeof(uint16_t);
+  int shape=1;
+  if (const char *e=getenv("MAGICKHIP_RECTS_SHAPE"))
+    shape=(atoi(e) >= 0) && (atoi(e) <= 3) ? atoi(e) : 0;
+  const int th=shape == 2 ? 96 : 48;
+  const size_t lds=(size_t) (th+2*vmax)*row_lds;
+  if ((hmax > 32) || (lds > 160u*1024u) ||
+      ((unsigned long long) src.columns*src.rows*src.channels*sizeof(uint16_t) >= (1ull << 32)))
+    return MH_OK;
+  RectsArgs a;
+  // levels: distinct half-widths ascending; reach = the outermost row at least that wide
+  std::vector<int> widths(half.begin()+vmax,half.end());
+  std::sort(widths.begin(),widths.end());
+  widths.erase(std::unique(widths.begin(),widths.end()),widths.end());
+  if (widths.size() > 64)
+    return MH_OK;
+  a.nlevels=(int) widths.size();
+  for (size_t l=0; l < widths.size(); l++)
+    {
+      int reach=0;
+      for (int d=0; d <= vmax; d++)
+        if (half[(size_t) (vmax+d)] >= widths[l])
+          reach=d;
+      a.widen[l]=(unsigned char) (widths[l]-(l == 0 ? 0 : widths[l-1]));
+      a.reach[l]=(unsigned char) reach;
+    }
+  a.src=static_cast<const uint16_t *>(src.pixels);
+  a.dst=static_cast<uint16_t *>(dst.pixels);
+  a.columns=(int) src.columns;
+  a.rows=(int) src.rows;
+  a.cx=cx;
+  a.cy=dy_min+vmax;
+  a.hmax=hmax;
+  a.vmax=vmax;
+  const int valid_w=128-2*hmax;
+  a.tiles_x=((int) src.columns+valid_w-1)/valid_w;
+  a.tiles_y=((int) src.rows+th-1)/th;
+  a.tiles_per_xcd=(a.tiles_x*a.tiles_y+7)/8;
+  a.copy_mask=roles.copy_mask;
+  a.changed=changed;
+  ProfileScope prof("morph_rects",src.stream);
+  if (src.channels == 4)
+    MH_TRY(launch_rects<4>(dilate,shape,a,lds,src.stream));
+  else
+    MH_TRY(launch_rects<2>(dilate,shape,a,lds,src.stream));
+  *handled=true;
+  return MH_OK;
+}
+
 // Tries the convex fast path; *handled stays false when the kernel's active cells are
 // not one centred run per row (Ring, Cross, user kernels ...) or the tile does not fit.
 static MhStatus try_convex(const View &src,const View &dst,bool dilate,const std::vector<Cell> &cells,
@@ -672,6 +1046,22 @@ static MhStatus try_convex(const View &src,const View &dst,bool dilate,const std
   const int top=dy_min < 0 ? -dy_min : 0,bottom=dy_max > 0 ? dy_max : 0;
   if ((dy_min > 0) || (dy_max < 0) || (hmax > 48) || (span > 97))
     return MH_OK;
+  {
+    // symmetric shapes: the union-of-rectangles kernel
+    std::vector<int> half((size_t) span,-1);
+    bool full=true;
+    for (int k=0; k < span; k++)
+      {
+        full=full && (cnt[(size_t) k] != 0);
+        half[(size_t) k]=(hi[(size_t) k]-lo[(size_t) k])/2;
+      }
+    if (full && (src.columns < (1u << 30)) && (src.rows < (1u << 30)))
+      {
+        MH_TRY(try_rects(src,dst,dilate,half,cx,dy_min,roles,changed,handled));
+        if (*handled)
+          return MH_OK;
+      }
+  }
   const size_t px=(size_t) src.channels*(src.quantum == MH_QUANTUM_U16 ? 2u : 4u);
   const size_t tile_rows=(size_t) (kCTR+top+bottom);
   const size_t lds=tile_rows*((size_t) (kCTW+2*hmax)+(size_t) kCTW)*px;

@@ -307,7 +307,7 @@ struct MorphologyWorkspace
 // in one launch, the Quantum-rounded intermediate stays in LDS (convolve_fused.hip).
 // *handled = false: not this case, nothing launched.
 static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *kernel,
-  const Roles &roles,double bias,bool *handled)
+  const Roles &roles,double bias,bool *handled,bool unsharp=false,double gain=0.0,double threshold=0.0)
 {
   *handled=false;
   if ((precision() != MH_PRECISION_FAST) || (src.quantum != MH_QUANTUM_U16) || (src.channels != 4) ||
@@ -341,7 +341,7 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
   Temp taps;
   MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(double)));
   return launch_blur_fused(src,dst,reinterpret_cast<const float *>(taps.as<double>()+K),taps.as<double>(),
-    K,K-1-(int) row->x,roles.blend,handled);
+    K,K-1-(int) row->x,roles.blend,handled,unsharp,gain,threshold);
 }
 
 // MorphologyApply, morphology.c:3634-4077: the loops over method iterations, the kernel
@@ -825,6 +825,10 @@ static MhStatus unsharp_fused(const View &src,const View &dst,const MhKernelInfo
       kernel_has_nan(horizontal) || kernel_has_nan(vertical))
     return MH_OK;
   if (roles.blend && (roles.alpha != 3))
+    return MH_OK;
+  // one launch: both passes and the epilogue (convolve_fused.hip), kernels of up to 81 taps
+  MH_TRY(fused_blur(src,dst,kernels,roles,0.0,fused,true,gain,threshold));
+  if (*fused)
     return MH_OK;
   View rows=src;
   Temp memory;

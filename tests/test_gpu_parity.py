@@ -284,12 +284,16 @@ def test_convolve_fast_non_separable_kernel_stays_exact(im, refmod):
 
 @pytest.mark.parametrize("shape", [(64, 80), (33, 71), (2, 2), (70, 2), (1, 40), (129, 17)])
 @pytest.mark.parametrize("gain,threshold", [(1.0, 0.02), (2.5, 0.0), (0.6, 0.2), (1.3, 1.0 / 65535.0)])
-def test_unsharp_mask_fast_fused(im, refmod, shape, gain, threshold):
+@pytest.mark.parametrize("single_launch", [True, False])
+def test_unsharp_mask_fast_fused(im, refmod, shape, gain, threshold, single_launch, monkeypatch):
     """FAST UnsharpMaskImage on RGBA Q16: the column pass applies the threshold/gain epilogue
-    while it copies its results out (no blurred frame in memory).  A blurred sample that
-    differs by one level from the reference's moves the result by at most 1+gain levels, and
-    can flip the threshold test only when 2|p-b| sits on the threshold itself."""
+    while it copies its results out (no blurred frame in memory) — in the one launch that does
+    both passes (convolve_fused.hip), or, with that switched off, after a separate row pass.  A
+    blurred sample that differs by one level from the reference's moves the result by at most
+    1+gain levels, and can flip the threshold test only when 2|p-b| sits on the threshold itself."""
     import bench
+    if not single_launch:
+        monkeypatch.setenv("MAGICKHIP_NO_FUSED_BLUR", "1")
     px = make_pixels(shape[0], shape[1], 4, Q16, seed=shape[0] + 3 * shape[1])
     dev, ref = run_pair(im, refmod, px)
     want = ref.unsharp(0.0, 2.0, gain, threshold).numpy().astype(np.int64)
@@ -302,7 +306,7 @@ def test_unsharp_mask_fast_fused(im, refmod, shape, gain, threshold):
     finally:
         im.set_precision(im.PRECISION_EXACT)
     if shape[1] >= 2:
-        assert launched == {"conv_row", "conv_column"}, launched
+        assert launched == ({"unsharp_fused"} if single_launch else {"conv_row", "conv_column"}), launched
     got = holder["out"].numpy().astype(np.int64)
     diff = np.abs(got - want)
     limit = int(np.ceil(1.0 + gain))
@@ -414,6 +418,45 @@ def test_morphology(im, refmod, dtype, method, kernel, iterations):
     got = im.morphology_image(dev, method, iterations, kernel).numpy()
     want = ref.morphology(method, iterations, kernel).numpy()
     assert_parity(got, want, True, "%s %s x%d" % (method, kernel, iterations))
+
+
+@pytest.mark.parametrize("channels", [4, 2])
+@pytest.mark.parametrize("method,kernel", [
+    ("Dilate", "Disk:15"), ("Erode", "Disk:15"), ("Dilate", "Disk:7.3"), ("Erode", "Octagon:6"),
+    ("Dilate", "Diamond:9"), ("Erode", "Square:4"), ("Dilate", "Rectangle:9x5+2+1"), ("Dilate", "Plus:11"),
+    ("Erode", "Rectangle:1x9"), ("Dilate", "Rectangle:13x1"), ("Dilate", "Disk:31"),
+])
+def test_symmetric_convex_kernels_over_several_tiles(im, refmod, method, kernel, channels, monkeypatch):
+    """Erode / Dilate with a kernel that is a union of centred rectangles (morph_rects_kernel:
+    column windows from the staged tile, row windows across lanes) on a frame that spans several
+    workgroup tiles in both directions, ragged at the right and bottom edges; bit-identical to
+    the reference and to the plane-per-width kernel it replaces."""
+    import bench
+    px = make_pixels(131, 277, channels, Q16, seed=len(kernel) + channels)
+    dev, ref = run_pair(im, refmod, px)
+    holder = {}
+    launched = set(bench.kernel_profile(
+        im, lambda: holder.update(out=im.morphology_image(dev, method, 1, kernel)), 1))
+    assert launched == {"morph_rects"}, launched
+    want = ref.morphology(method, 1, kernel).numpy()
+    assert_parity(holder["out"].numpy(), want, True, "%s %s c%d" % (method, kernel, channels))
+    monkeypatch.setenv("MAGICKHIP_NO_RECTS", "1")
+    assert_parity(im.morphology_image(dev, method, 1, kernel).numpy(), want, True, "%s %s (planes)" % (method, kernel))
+
+
+def test_symmetric_convex_kernel_channel_mask_and_change_count(im, refmod):
+    """Channels without the update trait keep the source value; an unbounded iteration count
+    stops on the `changed` count of the kernel (morphology.c:3180-3196, :3892-3905)."""
+    px = make_pixels(90, 140, 4, Q16, seed=77)
+    dev = im.Image(to_device(px), copy_channels=(1, 3))
+    ref = refmod.RefImage(px).set_channel_mask("RB")
+    got = im.morphology_image(dev, "Dilate", 1, "Disk:6").numpy()
+    assert_parity(got, ref.morphology("Dilate", 1, "Disk:6").numpy(), True, "Dilate Disk:6 -channel RB")
+    sparse = np.zeros((60, 70, 4), dtype=np.uint16)
+    sparse[30, 35] = 65535
+    dev, ref = run_pair(im, refmod, sparse)
+    assert_parity(im.morphology_image(dev, "Dilate", -1, "Square:2").numpy(),
+                  ref.morphology("Dilate", -1, "Square:2").numpy(), True, "Dilate Square:2 until stable")
 
 
 @pytest.mark.parametrize("dtype", [Q16, HDRI])

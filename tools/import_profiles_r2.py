@@ -22,14 +22,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # HIP kernel name -> the label the library's launch records (and bench.py) use
 LABELS = [
-    (r"blur_fused", "blur_fused"),
+    (r"blur_fused16_kernel<\d+, \d+, true>", "unsharp_fused"), (r"blur_fused", "blur_fused"),
     (r"conv_mfma_kernel<true", "conv_column"), (r"conv_mfma_kernel<false", "conv_row"),
     (r"conv_column_", "conv_column"), (r"conv_row_alpha_audit", "conv_row_alpha_audit"), (r"conv_row_", "conv_row"),
     (r"resize_vertical", "resize_vertical"), (r"resize_horizontal", "resize_horizontal"),
     (r"resize_fused", "resize_fused"),
     (r"colorspace_", "colorspace"), (r"histogram_", "histogram"), (r"apply_lut", "apply_lut"),
     (r"lut_", "build_lut"), (r"gray_", "gray_check"),
-    (r"morph_convex", "morph_convex"), (r"morph2d", "morph2d"), (r"unsharp_kernel", "unsharp_epilogue"),
+    (r"morph_rects", "morph_rects"), (r"morph_convex", "morph_convex"), (r"morph2d", "morph2d"), (r"unsharp_kernel", "unsharp_epilogue"),
 ]
 PREFIX = {"fast": "", "exact": "exact:", "resize": "", "c4": "c4:", "c5": "c5:"}
 
