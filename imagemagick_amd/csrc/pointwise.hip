@@ -327,6 +327,75 @@ void colorspace_q16_table_kernel(uint16_t *__restrict__ pixels,size_t npixels,
     }
 }
 
+// FAST sRGB -> Lab on RGBA Q16 (config C4): the same expressions in f32 with the hardware
+// log2 / exp2 for the 2.4 power and the cube roots.  Error budget in Quantum levels: the decode is
+// good to 1e-6 relative, the cube roots to 3e-7, so L (x 65535 * 1.16) is within 0.03 and a, b
+// (x 65535 * 500/255 of a difference of two roots) within 0.1 of the fp64 value: the rounded
+// level differs from the reference's by at most one (MH_PRECISION_FAST's contract).  ~80 VALU
+// slots per pixel against ~400 fp64-rate slots of the table kernel: the kernel becomes a stream.
+static __device__ __forceinline__ float srgb_decode_fast(float x)
+{
+  // DecodePixelGamma, pixel.c:318-324, on [0,1]
+  const float curve=__builtin_amdgcn_exp2f(2.4f*__builtin_amdgcn_logf((x+0.055f)*(1.0f/1.055f)));
+  return x <= 0.0404482362771076f ? x*(1.0f/12.92f) : curve;
+}
+
+static __device__ __forceinline__ float lab_f_fast(float t)
+{
+  // ConvertXYZToLab, colorspace-private.h:1066-1089: cube root above epsilon, linear below
+  const float root=__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(t)*(1.0f/3.0f));
+  return t > (float) MH_CIE_EPSILON ? root : (((float) MH_CIE_K)*t+16.0f)*(1.0f/116.0f);
+}
+
+static __device__ __forceinline__ uint2 srgb_to_lab_fast_pixel(uint2 px)
+{
+  constexpr float qs=1.0f/65535.0f;
+  const float r=srgb_decode_fast((float) (px.x & 0xffffu)*qs);
+  const float g=srgb_decode_fast((float) (px.x >> 16)*qs);
+  const float b=srgb_decode_fast((float) (px.y & 0xffffu)*qs);
+  const float X=0.4123955889674142161f*r+0.3575834307637148171f*g+0.1804926473817015735f*b;
+  const float Y=0.2125862307855955516f*r+0.7151703037034108499f*g+0.07220049864333622685f*b;
+  const float Z=0.01929721549174694484f*r+0.1191838645808485318f*g+0.9504971251315797660f*b;
+  const float fx=lab_f_fast(X*(float) (1.0/MH_ILL_X)),fy=lab_f_fast(Y),fz=lab_f_fast(Z*(float) (1.0/MH_ILL_Z));
+  const float L=(116.0f*fy-16.0f)*0.01f;
+  const float a=(500.0f/255.0f)*(fx-fy)+0.5f;
+  const float bb=(200.0f/255.0f)*(fy-fz)+0.5f;
+  // ClampToQuantum: v_cvt_pknorm_u16 clamps to [0,1] and rounds to nearest
+  typedef unsigned short pk2 __attribute__((ext_vector_type(2)));
+  const pk2 la=__builtin_amdgcn_cvt_pknorm_u16(L,a);
+  const pk2 b0=__builtin_amdgcn_cvt_pknorm_u16(bb,0.0f);
+  return make_uint2((unsigned) la[0] | ((unsigned) la[1] << 16),(unsigned) b0[0] | (px.y & 0xffff0000u));
+}
+
+__global__ __launch_bounds__(256)
+void colorspace_lab_fast_kernel(uint4 *__restrict__ pairs,size_t npairs,uint2 *__restrict__ last)
+{
+  // two 8-byte pixels per lane and load; `last` is the odd pixel of the frame, if any
+  constexpr int BATCH=4;
+  const size_t stride=(size_t) gridDim.x*blockDim.x*BATCH;
+  for (size_t i0=(size_t) blockIdx.x*blockDim.x*BATCH+threadIdx.x; i0 < npairs; i0+=stride)
+    {
+      uint4 v[BATCH];
+#pragma unroll
+      for (int k=0; k < BATCH; k++)
+        {
+          const size_t i=i0+(size_t) k*blockDim.x;
+          v[k]=pairs[i < npairs ? i : npairs-1];
+        }
+#pragma unroll
+      for (int k=0; k < BATCH; k++)
+        {
+          const uint2 first=srgb_to_lab_fast_pixel(make_uint2(v[k].x,v[k].y));
+          const uint2 second=srgb_to_lab_fast_pixel(make_uint2(v[k].z,v[k].w));
+          const size_t i=i0+(size_t) k*blockDim.x;
+          if (i < npairs)
+            pairs[i]=make_uint4(first.x,first.y,second.x,second.y);
+        }
+    }
+  if ((last != nullptr) && (blockIdx.x == 0) && (threadIdx.x == 0))
+    *last=srgb_to_lab_fast_pixel(*last);
+}
+
 template<typename Q,int C,int OP>
 __global__ __launch_bounds__(256)
 void colorspace_kernel(Q *__restrict__ pixels,size_t npixels)
@@ -474,6 +543,25 @@ static MhStatus apply_q16_column(const View &img,const uint16_t *column,uint32_t
 
 static MhStatus colorspace_step(const View &img,int op)
 {
+  if ((op == OP_SRGB_TO_LAB) && (img.quantum == MH_QUANTUM_U16) && (img.channels == 4) &&
+      (precision() == MH_PRECISION_FAST) && (getenv("MAGICKHIP_NO_FAST_LAB") == nullptr) &&
+      ((reinterpret_cast<uintptr_t>(img.pixels) & 15u) == 0))
+    {
+      const size_t n=img.columns*img.rows,npairs=n/2;
+      uint2 *last=(n & 1) != 0 ? static_cast<uint2 *>(img.pixels)+(n-1) : nullptr;
+      if (npairs == 0)
+        {
+          hipLaunchKernelGGL(colorspace_lab_fast_kernel,dim3(1),dim3(256),0,img.stream,
+            static_cast<uint4 *>(img.pixels),(size_t) 0,last);
+          MH_HIP(hipGetLastError());
+          return MH_OK;
+        }
+      ProfileScope prof("colorspace",img.stream);
+      hipLaunchKernelGGL(colorspace_lab_fast_kernel,dim3(stream_grid((npairs+3)/4)),dim3(256),0,img.stream,
+        static_cast<uint4 *>(img.pixels),npairs,last);
+      MH_HIP(hipGetLastError());
+      return MH_OK;
+    }
   if ((img.quantum == MH_QUANTUM_U16) && (getenv("MAGICKHIP_NO_COLOR_TABLES") == nullptr) &&
       ((op == OP_SRGB_TO_RGB) || (op == OP_RGB_TO_SRGB) || (op == OP_SRGB_TO_LAB) ||
        (op == OP_SRGB_TO_XYZ)))
@@ -831,6 +919,168 @@ static MhStatus histogram_intensity_lds(const View &src,const IntensityParams &i
   return MH_OK;
 }
 
+// Intensity mode on Q16, one pass: 65 536 sixteen-bit counters DO fit (128 KB), two to a
+// 32-bit LDS word, incremented with ds_add_u32 of 1 or 1<<16.  A workgroup bins at most 65 534
+// pixels into its table, so no counter can wrap into its neighbour; the handful of pixels of an
+// over-full share go straight to the caller's table with global atomics.  Each workgroup then
+// writes its packed table (128 KB) to its slab and histogram_packed_reduce_kernel sums the slabs:
+// the frame is read once, against twice by the 32-bit half-range kernel below.
+constexpr unsigned kPackedCapacity=65534u;     // even: the RGBA path loads pixel pairs
+
+// the shared tail of the packed-table kernels: LDS table -> the workgroup's slab
+static __device__ __forceinline__ void packed_table_to_slab(const unsigned *table,unsigned *slabs)
+{
+  uint4 *slab=reinterpret_cast<uint4 *>(slabs+(size_t) blockIdx.x*32768);
+  const uint4 *packed=reinterpret_cast<const uint4 *>(table);
+  for (int i=(int) threadIdx.x; i < 8192; i+=1024)
+    slab[i]=packed[i];
+}
+
+template<int C>
+__global__ __launch_bounds__(1024)
+void histogram_packed_kernel(const uint16_t *pixels,size_t npixels,IntensityParams ip,unsigned *slabs,
+  unsigned long long *counts,int wide)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned *table=reinterpret_cast<unsigned *>(smem_raw);
+  for (int i=(int) threadIdx.x; i < 32768; i+=1024)
+    table[i]=0u;
+  __syncthreads();
+  size_t per=(npixels+gridDim.x-1)/gridDim.x;
+  per+=per & 1;                                // shares start on a pixel pair
+  size_t begin=(size_t) blockIdx.x*per;
+  begin=begin < npixels ? begin : npixels;
+  size_t end=begin+per;
+  end=end < npixels ? end : npixels;
+  const size_t packed_end=end-begin > kPackedCapacity ? begin+kPackedCapacity : end;
+  auto count=[&](const uint16_t (&q)[C])
+  {
+    const unsigned bin=QuantumOps<uint16_t>::map_index(QuantumOps<uint16_t>::clamp(pixel_intensity<uint16_t,C>(q,ip)));
+    atomicAdd(table+(bin >> 1),(bin & 1u) != 0u ? 0x10000u : 1u);
+  };
+  size_t done=begin;                           // pixels [begin, done) are in the LDS table
+  if constexpr (C == 4)
+    if (wide != 0)
+      {
+        // 16-byte loads: two RGBA pixels per lane, eight loads in flight
+        constexpr int BATCH=8;
+        const uint4 *pairs=reinterpret_cast<const uint4 *>(pixels)+begin/2;
+        const size_t npairs=(packed_end-begin)/2;
+        for (size_t i0=threadIdx.x; i0 < npairs; i0+=(size_t) 1024*BATCH)
+          {
+            uint4 v[BATCH];
+#pragma unroll
+            for (int k=0; k < BATCH; k++)
+              {
+                const size_t i=i0+(size_t) 1024*k;
+                v[k]=pairs[i < npairs ? i : npairs-1];
+              }
+#pragma unroll
+            for (int k=0; k < BATCH; k++)
+              if (i0+(size_t) 1024*k < npairs)
+                {
+                  const uint16_t a[4]={(uint16_t) v[k].x,(uint16_t) (v[k].x >> 16),(uint16_t) v[k].y,(uint16_t) (v[k].y >> 16)};
+                  const uint16_t b[4]={(uint16_t) v[k].z,(uint16_t) (v[k].z >> 16),(uint16_t) v[k].w,(uint16_t) (v[k].w >> 16)};
+                  count(a);
+                  count(b);
+                }
+          }
+        done=begin+2*npairs;
+      }
+  constexpr int BATCH=4;
+  for (size_t i0=done+threadIdx.x; i0 < end; i0+=(size_t) 1024*BATCH)
+    {
+      uint16_t q[BATCH][C];
+#pragma unroll
+      for (int k=0; k < BATCH; k++)
+        {
+          const size_t i=i0+(size_t) 1024*k;
+          load_pixel<uint16_t,C>(pixels+(i < end ? i : end-1)*C,q[k]);
+        }
+#pragma unroll
+      for (int k=0; k < BATCH; k++)
+        {
+          const size_t i=i0+(size_t) 1024*k;
+          if (i >= end)
+            continue;
+          if (i < packed_end)
+            count(q[k]);
+          else
+            {
+              // beyond what the 16-bit counters may hold: the caller's table directly
+              const unsigned bin=QuantumOps<uint16_t>::map_index(QuantumOps<uint16_t>::clamp(pixel_intensity<uint16_t,C>(q[k],ip)));
+              for (int c=0; c < C; c++)
+                atomicAdd(counts+(size_t) bin*C+c,1ull);
+            }
+        }
+    }
+  __syncthreads();
+  packed_table_to_slab(table,slabs);
+}
+
+// One workgroup per 256 bins: thread (bin, quarter) sums a quarter of the packed slabs, the four
+// partial sums meet in LDS and one thread per bin adds the total to every channel of the caller's
+// table (no atomics: a bin belongs to one thread).
+__global__ __launch_bounds__(1024)
+void histogram_packed_reduce_kernel(const unsigned *slabs,int nblocks,unsigned long long *counts,int channels)
+{
+  __shared__ unsigned partial[4][256];
+  const unsigned local=threadIdx.x & 255u,quarter=threadIdx.x >> 8;
+  const unsigned bin=blockIdx.x*256u+local;
+  const int per=(nblocks+3)/4;
+  const int b0=(int) quarter*per;
+  const int b1=b0+per < nblocks ? b0+per : nblocks;
+  const unsigned shift=16u*(bin & 1u);
+  unsigned sum=0;                              // at most 65 534 per slab: 65 536 slabs fit 32 bits
+#pragma unroll 8
+  for (int b=b0; b < b1; b++)
+    sum+=(slabs[(size_t) b*32768+(bin >> 1)] >> shift) & 0xffffu;
+  partial[quarter][local]=sum;
+  __syncthreads();
+  if (quarter == 0)
+    {
+      const unsigned long long total=(unsigned long long) partial[0][local]+partial[1][local]+partial[2][local]+partial[3][local];
+      if (total != 0)
+        for (int c=0; c < channels; c++)
+          counts[(size_t) bin*channels+c]+=total;
+    }
+}
+
+// workgroups of the packed-table kernels for a frame of n pixels (0: too many slabs)
+static size_t packed_histogram_blocks(int device,size_t n)
+{
+  // one workgroup per CU when a share fits the 16-bit counters (plus a few pixels of slack that
+  // go through global atomics), more workgroups otherwise
+  size_t nblocks=(size_t) compute_units(device);
+  if ((n+nblocks-1)/nblocks > kPackedCapacity+256u)
+    nblocks=(n+kPackedCapacity-1)/kPackedCapacity;
+  return nblocks > 65536 ? 0 : nblocks;
+}
+
+template<int C>
+static MhStatus histogram_intensity_packed(const View &src,const IntensityParams &ip,unsigned long long *hist)
+{
+  const size_t n=src.columns*src.rows;
+  const size_t nblocks=packed_histogram_blocks(src.device,n);
+  if (nblocks == 0)
+    return histogram_intensity_lds<uint16_t,C>(src,ip,hist);
+  Temp slabs;
+  MH_TRY(slabs.alloc(src.device,nblocks*32768*sizeof(unsigned),src.stream));
+  const size_t lds=32768*sizeof(unsigned);
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&histogram_packed_kernel<C>),
+    hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+  const int wide=(C == 4) && ((reinterpret_cast<uintptr_t>(src.pixels) & 15u) == 0) ? 1 : 0;
+  {
+    ProfileScope prof("histogram",src.stream);
+    hipLaunchKernelGGL((histogram_packed_kernel<C>),dim3((unsigned) nblocks),dim3(1024),lds,src.stream,
+      static_cast<const uint16_t *>(src.pixels),n,ip,slabs.as<unsigned>(),hist,wide);
+    hipLaunchKernelGGL(histogram_packed_reduce_kernel,dim3(256),dim3(1024),0,src.stream,
+      slabs.as<unsigned>(),(int) nblocks,hist,C);
+  }
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 template<typename Q,int C>
 static MhStatus histogram_typed(const View &src,int mode,const IntensityParams &ip,
   unsigned long long *hist)
@@ -839,7 +1089,12 @@ static MhStatus histogram_typed(const View &src,int mode,const IntensityParams &
   // large frames in intensity mode: the LDS-privatised kernel (a frame below ~1 Mpixel
   // does not amortise the 2 x 256 x 128 KB slab traffic)
   if ((mode != 0) && (n >= ((size_t) 1 << 20)) && (getenv("MAGICKHIP_NO_LDS_HISTOGRAM") == nullptr))
-    return histogram_intensity_lds<Q,C>(src,ip,hist);
+    {
+      if constexpr (sizeof(Q) == 2)
+        if ((getenv("MAGICKHIP_NO_PACKED_HISTOGRAM") == nullptr) && (n < ((size_t) 1 << 31)))
+          return histogram_intensity_packed<C>(src,ip,hist);
+      return histogram_intensity_lds<Q,C>(src,ip,hist);
+    }
   Temp before;
   if ((mode != 0) && (C > 1))
     {

@@ -131,6 +131,36 @@ def test_c4_lab_contrast_stretch_full_size(im, refmod):
     _compare_q16(img.pixels, want, True, "C4 Lab + ContrastStretch")
 
 
+def test_c4_fast_lab_within_one_level_and_stretch_exact(im, refmod):
+    """FAST sRGB->Lab computes in f32 (colorspace_lab_fast_kernel): every sample within one level
+    of the reference's fp64 result on the whole 4096^2 frame.  ContrastStretch is integer counts
+    and an fp64 map in both precisions: given that same Lab frame it is bit-identical to the
+    reference's (the one-pass packed histogram included)."""
+    n = 4096
+    rng = np.random.default_rng(45)
+    px = rng.integers(0, 65536, (n, n, 4), dtype=np.uint16)
+    px[0, :4096:16, :3] = 0                       # black, and the dark linear segments of both curves
+    px[1, :, 0] = np.arange(n, dtype=np.uint16)
+    px[1, :, 1] = np.arange(n, dtype=np.uint16) // 3
+    px[1, :, 2] = 5
+    px[2, :, :3] = (np.arange(n, dtype=np.uint32) * 16 + 7).astype(np.uint16)[:, None]      # grays
+    px[3, :64, :3] = 65535
+    refmod.set_thread_limit(os.cpu_count() or 1)
+    want_lab = refmod.RefImage(px).colorspace("Lab").numpy()
+    img = im.Image(to_device(px))
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        im.transform_image_colorspace(img, "Lab")
+        _compare_q16(img.pixels, want_lab, False, "C4 FAST sRGB->Lab")
+        got_lab = img.numpy().copy()
+        assert float((got_lab == want_lab).mean()) > 0.9
+        im.contrast_stretch_image(img, 0.02 * n * n, n * n - 0.01 * n * n)
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    want = refmod.RefImage(got_lab, "Lab").contrast_stretch(0.02 * n * n, n * n - 0.01 * n * n).numpy()
+    _compare_q16(img.pixels, want, True, "C4 ContrastStretch of the FAST Lab frame")
+
+
 def _band_starts(n, band):
     return [0, n // 2 - band // 2, n - band]
 

@@ -789,6 +789,37 @@ def test_contrast_stretch(im, refmod, dtype, kind, channels):
     assert_parity(got, want, True, "contrast-stretch")
 
 
+@pytest.mark.parametrize("shape", [(1100, 1000), (1024, 1025), (3000, 5600)])
+@pytest.mark.parametrize("kind", ["random", "flat", "two-level"])
+def test_intensity_histogram_packed_counters(im, refmod, shape, kind, monkeypatch):
+    """Frames above a megapixel bin their intensity in one pass into 16-bit LDS counters, two to a
+    word (histogram_packed_kernel); a share of more than 65 535 pixels per workgroup, a frame that
+    is ONE level (every pixel of a workgroup in one counter) and an odd pixel count must give the
+    same table as the 32-bit half-range kernel and the reference's ContrastStretch / Equalize."""
+    rows, cols = shape
+    if kind == "random":
+        px = make_pixels(rows, cols, 4, Q16, seed=rows)
+    elif kind == "flat":
+        px = np.full((rows, cols, 4), 31111, dtype=np.uint16)
+        px[rows // 2, cols // 3] = (1, 2, 3, 4)
+    else:
+        px = np.where((np.arange(rows * cols).reshape(rows, cols, 1) % 7) < 3, 65535, 2).astype(np.uint16)
+        px = np.ascontiguousarray(np.broadcast_to(px, (rows, cols, 4)))
+        px[1, 1] = (9, 8, 7, 6)                  # (an all-gray frame is the CPU path's: SetImageGray)
+    n = rows * cols
+    want_stretch = refmod.RefImage(px).contrast_stretch(0.02 * n, n - 0.01 * n).numpy()
+    want_equal = refmod.RefImage(px).equalize().numpy()
+    for packed in (True, False):
+        if not packed:
+            monkeypatch.setenv("MAGICKHIP_NO_PACKED_HISTOGRAM", "1")
+        dev = im.Image(to_device(px))
+        im.contrast_stretch_image(dev, 0.02 * n, n - 0.01 * n)
+        assert_parity(dev.numpy(), want_stretch, True, "contrast stretch %s packed=%s" % (kind, packed))
+        dev = im.Image(to_device(px))
+        im.equalize_image(dev)
+        assert_parity(dev.numpy(), want_equal, True, "equalize %s packed=%s" % (kind, packed))
+
+
 def test_contrast_stretch_per_channel_mask(im, refmod):
     rows, cols = 40, 40
     px = make_pixels(rows, cols, 4, Q16, kind="smooth")
