@@ -336,6 +336,17 @@ def equalize_image(image):
     return image
 
 
+def transform_colorspace_contrast_stretch_image(image, colorspace, black_point, white_point):
+    """TransformImageColorspace then ContrastStretchImage as one call (the two calls' results; a
+    FAST sRGB -> Lab of an RGBA Q16 frame shares its pass over the pixels with the histogram)."""
+    lib = _lib.load()
+    d = image.descriptor()
+    _lib.check(lib.MagickHipTransformColorspaceContrastStretchImage(
+        ctypes.byref(d), COLORSPACES[colorspace.lower()], black_point, white_point))
+    image.colorspace = colorspace.lower()
+    return image
+
+
 def transform_image_colorspace(image, colorspace):
     """TransformImageColorspace(image, colorspace), in place — MagickCore/colorspace.c:1751."""
     lib = _lib.load()

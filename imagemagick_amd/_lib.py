@@ -209,6 +209,8 @@ PROTOTYPES = [
     ("MagickHipIsImageGray", ctypes.c_int, [_P(MhImage), _P(ctypes.c_int)]),
     ("MagickHipApplyHistogram", ctypes.c_int, [_P(MhImage), ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_double, ctypes.c_double, ctypes.c_size_t]),
+    ("MagickHipTransformColorspaceContrastStretchImage", ctypes.c_int,
+     [_P(MhImage), ctypes.c_int, ctypes.c_double, ctypes.c_double]),
     ("MagickHipBatchImages", ctypes.c_int, [_P(MhOperator), ctypes.c_size_t, _P(MhImage), _P(MhImage),
                                             ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _P(MhBatchReport)]),
     ("MagickHipShardedImage", ctypes.c_int, [_P(MhOperator), ctypes.c_size_t, _P(MhImage), _P(MhImage),

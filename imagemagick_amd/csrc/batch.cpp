@@ -537,7 +537,19 @@ MH_API MhStatus MagickHipBatchImages(const MhOperator *operators,size_t number_o
             else
               status=working_copy(images[i],device,stream,cur);
             for (size_t k=0; (status == MH_OK) && (k < chain.size()); k++)
-              status=apply_operator(chain[k],cur);
+              {
+                // a colourspace transform directly followed by a contrast stretch: one entry point
+                // (they share the pass over the pixels where the library has a fused kernel)
+                if ((chain[k].op.kind == MH_OP_COLORSPACE) && (k+1 < chain.size()) &&
+                    (chain[k+1].op.kind == MH_OP_CONTRAST_STRETCH))
+                  {
+                    status=MagickHipTransformColorspaceContrastStretchImage(&cur.image,
+                      (MhColorspace) (int) chain[k].op.args[0],chain[k+1].op.args[0],chain[k+1].op.args[1]);
+                    k++;
+                    continue;
+                  }
+                status=apply_operator(chain[k],cur);
+              }
             if (status == MH_OK)
               {
                 MhImage *target=results != nullptr ? &results[i] : const_cast<MhImage *>(&images[i]);

@@ -443,6 +443,41 @@ MH_API MhStatus MagickHipTransformImageColorspace(MhImage *image,MhColorspace co
   return MH_OK;
 }
 
+// TransformImageColorspace followed by ContrastStretchImage, as one call.  The results are those
+// of the two calls; what the pair can share is the pass over the pixels: FAST sRGB -> Lab on
+// RGBA Q16 converts and bins the intensity of what it stores in the same kernel (pointwise.hip,
+// lab_histogram_fast_kernel).  MagickHipBatchImages uses it for adjacent operators of a chain.
+MH_API MhStatus MagickHipTransformColorspaceContrastStretchImage(MhImage *image,MhColorspace colorspace,
+  double black_point,double white_point)
+{
+  MH_TRY(check_image(image,"TransformColorspaceContrastStretchImage"));
+  const uint32_t colour=image->number_channels-(image->alpha_offset >= 0 ? 1u : 0u);
+  if (((MhColorspace) image->colorspace == MH_COLORSPACE_SRGB) && (colorspace == MH_COLORSPACE_LAB) &&
+      (colour == 3) && (image->channel_mask == MH_ALL_CHANNELS) && (image->memory == MH_MEMORY_DEVICE))
+    {
+      InPlace io;
+      MH_TRY(io.open(image));
+      const View &view=io.img.view;
+      const size_t n=(size_t) MH_HISTOGRAM_BINS*(size_t) view.channels;
+      Temp hist;
+      MH_TRY(hist.alloc(view.device,n*sizeof(unsigned long long),view.stream));
+      MH_HIP(hipMemsetAsync(hist.ptr,0,n*sizeof(unsigned long long),view.stream));
+      MhImage lab=*image;
+      lab.colorspace=(uint32_t) MH_COLORSPACE_LAB;
+      bool fused=false;
+      MH_TRY(launch_lab_fast_with_histogram(view,&lab,hist.as<unsigned long long>(),&fused));
+      if (fused)
+        {
+          image->colorspace=(uint32_t) MH_COLORSPACE_LAB;
+          MH_TRY(apply_histogram_lut(view,image,hist.as<unsigned long long>(),1,false,black_point,
+            (double) image->columns*(double) image->rows-white_point,nullptr));
+          return io.img.commit();
+        }
+    }
+  MH_TRY(MagickHipTransformImageColorspace(image,colorspace));
+  return MagickHipContrastStretchImage(image,black_point,white_point,nullptr);
+}
+
 // ContrastImage, enhance.c:1392-1480
 MH_API MhStatus MagickHipContrastImage(MhImage *image,int sharpen)
 {

@@ -1081,6 +1081,112 @@ static MhStatus histogram_intensity_packed(const View &src,const IntensityParams
   return MH_OK;
 }
 
+// sRGB -> Lab (FAST, RGBA Q16) and the intensity histogram of the Lab frame in ONE pass over the
+// pixels: what TransformImageColorspace followed by ContrastStretchImage / EqualizeImage needs
+// (config C4) at one frame read and one frame write.  Converts as colorspace_lab_fast_kernel
+// and bins the values it stores as histogram_packed_kernel does, so the table is exactly the
+// histogram of the frame it leaves behind.
+__global__ __launch_bounds__(1024)
+void lab_histogram_fast_kernel(uint16_t *pixels,size_t npixels,IntensityParams ip,unsigned *slabs,
+  unsigned long long *counts)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned *table=reinterpret_cast<unsigned *>(smem_raw);
+  for (int i=(int) threadIdx.x; i < 32768; i+=1024)
+    table[i]=0u;
+  __syncthreads();
+  size_t per=(npixels+gridDim.x-1)/gridDim.x;
+  per+=per & 1;
+  size_t begin=(size_t) blockIdx.x*per;
+  begin=begin < npixels ? begin : npixels;
+  size_t end=begin+per;
+  end=end < npixels ? end : npixels;
+  const size_t packed_end=end-begin > kPackedCapacity ? begin+kPackedCapacity : end;
+  auto bin_of=[&](uint2 px) -> unsigned
+  {
+    const uint16_t q[4]={(uint16_t) px.x,(uint16_t) (px.x >> 16),(uint16_t) px.y,(uint16_t) (px.y >> 16)};
+    return QuantumOps<uint16_t>::map_index(QuantumOps<uint16_t>::clamp(pixel_intensity<uint16_t,4>(q,ip)));
+  };
+  auto count=[&](uint2 px)
+  {
+    const unsigned bin=bin_of(px);
+    atomicAdd(table+(bin >> 1),(bin & 1u) != 0u ? 0x10000u : 1u);
+  };
+  constexpr int BATCH=8;
+  uint4 *pairs=reinterpret_cast<uint4 *>(pixels)+begin/2;
+  const size_t npairs=(packed_end-begin)/2;
+  for (size_t i0=threadIdx.x; i0 < npairs; i0+=(size_t) 1024*BATCH)
+    {
+      uint4 v[BATCH];
+#pragma unroll
+      for (int k=0; k < BATCH; k++)
+        {
+          const size_t i=i0+(size_t) 1024*k;
+          v[k]=pairs[i < npairs ? i : npairs-1];
+        }
+#pragma unroll
+      for (int k=0; k < BATCH; k++)
+        if (i0+(size_t) 1024*k < npairs)
+          {
+            const uint2 first=srgb_to_lab_fast_pixel(make_uint2(v[k].x,v[k].y));
+            const uint2 second=srgb_to_lab_fast_pixel(make_uint2(v[k].z,v[k].w));
+            pairs[i0+(size_t) 1024*k]=make_uint4(first.x,first.y,second.x,second.y);
+            count(first);
+            count(second);
+          }
+    }
+  // the pixels past the pairs (an odd one, or a share beyond the 16-bit counters' capacity)
+  uint2 *single=reinterpret_cast<uint2 *>(pixels);
+  for (size_t i=begin+2*npairs+threadIdx.x; i < end; i+=1024)
+    {
+      const uint2 lab=srgb_to_lab_fast_pixel(single[i]);
+      single[i]=lab;
+      if (i < packed_end)
+        count(lab);
+      else
+        {
+          const unsigned bin=bin_of(lab);
+          for (int c=0; c < 4; c++)
+            atomicAdd(counts+(size_t) bin*4+c,1ull);
+        }
+    }
+  __syncthreads();
+  packed_table_to_slab(table,slabs);
+}
+
+// *fused stays false when the frame does not qualify (the caller then runs the two operators)
+MhStatus launch_lab_fast_with_histogram(const View &img,const MhImage *lab_desc,unsigned long long *hist,
+  bool *fused)
+{
+  *fused=false;
+  const size_t n=img.columns*img.rows;
+  if ((img.quantum != MH_QUANTUM_U16) || (img.channels != 4) || (precision() != MH_PRECISION_FAST) ||
+      (n < ((size_t) 1 << 20)) || (n >= ((size_t) 1 << 31)) ||
+      ((reinterpret_cast<uintptr_t>(img.pixels) & 15u) != 0) ||
+      (getenv("MAGICKHIP_NO_FAST_LAB") != nullptr) || (getenv("MAGICKHIP_NO_PACKED_HISTOGRAM") != nullptr) ||
+      (getenv("MAGICKHIP_NO_LDS_HISTOGRAM") != nullptr) || (getenv("MAGICKHIP_NO_FUSED_LAB_HISTOGRAM") != nullptr))
+    return MH_OK;
+  const size_t nblocks=packed_histogram_blocks(img.device,n);
+  if (nblocks == 0)
+    return MH_OK;
+  const IntensityParams ip=intensity_params(lab_desc);
+  Temp slabs;
+  MH_TRY(slabs.alloc(img.device,nblocks*32768*sizeof(unsigned),img.stream));
+  const size_t lds=32768*sizeof(unsigned);
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lab_histogram_fast_kernel),
+    hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+  {
+    ProfileScope prof("colorspace_histogram",img.stream);
+    hipLaunchKernelGGL(lab_histogram_fast_kernel,dim3((unsigned) nblocks),dim3(1024),lds,img.stream,
+      static_cast<uint16_t *>(img.pixels),n,ip,slabs.as<unsigned>(),hist);
+    hipLaunchKernelGGL(histogram_packed_reduce_kernel,dim3(256),dim3(1024),0,img.stream,
+      slabs.as<unsigned>(),(int) nblocks,hist,4);
+  }
+  MH_HIP(hipGetLastError());
+  *fused=true;
+  return MH_OK;
+}
+
 template<typename Q,int C>
 static MhStatus histogram_typed(const View &src,int mode,const IntensityParams &ip,
   unsigned long long *hist)

@@ -496,6 +496,16 @@ MH_API MhStatus MagickHipApplyLUT(MhImage *image,const double *lut,uint32_t appl
 MH_API MhStatus MagickHipApplyHistogram(MhImage *image,const uint64_t *histogram,int intensity_mode,
   int equalize,double black_point,double white_point,size_t image_rows);
 
+/* TransformImageColorspace(image, colorspace) followed by ContrastStretchImage(image, black_point,
+   white_point) — colorspace.c:1751-1783 then enhance.c:1544-1818 — as one call with the two
+   calls' results.  What the pair can share is the pass over the pixels: a FAST sRGB -> Lab of a
+   device-resident RGBA Q16 frame converts and bins the intensity of what it stores in one kernel
+   (BASELINE configs[3]: one frame read + one frame write before the map is applied).  Any other
+   combination runs the two operators one after the other.  MagickHipBatchImages uses it for
+   adjacent MH_OP_COLORSPACE / MH_OP_CONTRAST_STRETCH operators. */
+MH_API MhStatus MagickHipTransformColorspaceContrastStretchImage(MhImage *image,MhColorspace colorspace,
+  double black_point,double white_point);
+
 /* IdentifyImageGray scan (attribute.c:1564-1626): *is_gray = 1 when every
    pixel has |R-G| and |G-B| below MagickEpsilon. */
 MH_API MhStatus MagickHipIsImageGray(const MhImage *image,int *is_gray);

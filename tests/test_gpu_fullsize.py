@@ -159,6 +159,23 @@ def test_c4_fast_lab_within_one_level_and_stretch_exact(im, refmod):
         im.set_precision(im.PRECISION_EXACT)
     want = refmod.RefImage(got_lab, "Lab").contrast_stretch(0.02 * n * n, n * n - 0.01 * n * n).numpy()
     _compare_q16(img.pixels, want, True, "C4 ContrastStretch of the FAST Lab frame")
+    # the one-call form converts and bins in one kernel: the same frame, bit for bit
+    import bench
+    fused = im.Image(to_device(px))
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        launched = set(bench.kernel_profile(im, lambda: im.transform_colorspace_contrast_stretch_image(
+            fused, "Lab", 0.02 * n * n, n * n - 0.01 * n * n), 1))
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert "colorspace_histogram" in launched and "histogram" not in launched, launched
+    assert fused.colorspace == "lab"
+    _compare_q16(fused.pixels, want, True, "C4 fused sRGB->Lab + ContrastStretch")
+    # ... and EXACT (or any frame the fused kernel does not take) is the two operators in sequence
+    plain = im.Image(to_device(px[:700, :900].copy()))
+    im.transform_colorspace_contrast_stretch_image(plain, "Lab", 100.0, 200.0)
+    want_plain = refmod.RefImage(px[:700, :900].copy()).colorspace("Lab").contrast_stretch(100.0, 200.0).numpy()
+    _compare_q16(plain.pixels, want_plain, True, "one-call form, EXACT")
 
 
 def _band_starts(n, band):
