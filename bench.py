@@ -312,13 +312,14 @@ def c4_config(im, torch, gen):
     def c4():
         work.copy_(src4)
         img4 = im.Image(work)
-        im.transform_image_colorspace(img4, "Lab")
-        im.contrast_stretch_image(img4, 0.02 * k * k, k * k - 0.01 * k * k)
+        # TransformImageColorspace + ContrastStretchImage as the one call a chain makes
+        # (MagickHipBatchImages pairs them the same way): FAST converts and bins in one kernel
+        im.transform_colorspace_contrast_stretch_image(img4, "Lab", 0.02 * k * k, k * k - 0.01 * k * k)
     sec = timed(torch, c4, 5)
     prof = kernel_profile(im, c4, 3)
     frame = float(k) * k * 8.0
-    bytes_by_kernel = {"colorspace": 2.0 * frame, "histogram": frame, "apply_lut": 2.0 * frame,
-                       "gray_check": frame}
+    bytes_by_kernel = {"colorspace_histogram": 2.0 * frame, "colorspace": 2.0 * frame, "histogram": frame,
+                       "apply_lut": 2.0 * frame, "gray_check": frame}
     kernels = kernel_rooflines(prof, bytes_by_kernel, "c4:")
     kernel_ms = sum(v["avg_ms"] for v in prof.values())
     return {"workload": "4096x4096 RGBA Q16 sRGB->Lab + ContrastStretch 2%x1% (one image of BASELINE configs[3])",

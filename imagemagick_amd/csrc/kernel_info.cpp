@@ -8,10 +8,10 @@
 // is validated value-for-value against the compiled reference in
 // tests/test_kernel_info.py.
 //
-// Not built here (returns NULL => caller falls back): FreiChen, the 5x5+
-// Laplacian/LoG constants, and the hit-and-miss kernel families (Edges,
-// Corners, Diagonals, LineEnds, LineJunctions, Ridges, ConvexHull, ThinSE,
-// Skeleton).
+// Every name of morphology.c's KernelInfoType table is built, including the FreiChen set, the
+// Laplacian / LoG constants and the hit-and-miss families (Edges, Corners, Diagonals, LineEnds,
+// LineJunctions, Ridges, ConvexHull, ThinSE, Skeleton) with their rotation expansions; a string
+// that MagickCore's own parser would reject returns NULL here too (the caller falls back).
 #include "mh_internal.hpp"
 
 #include <cctype>

@@ -735,6 +735,39 @@ static IntensityParams intensity_params(const MhImage *desc)
   return ip;
 }
 
+// The default method on a frame that needs no gamma step (Rec709Luma of sRGB, Lab ... pixels),
+// pixel.c:2446-2454 — three products and two sums, against the whole switch above inlined at
+// every call site (the packed-table kernels evaluate 16 pixels per thread and step: 67 000
+// instructions of ISA with the switch, and an instruction-cache-bound loop).
+static bool intensity_is_plain_luma(const IntensityParams &ip,int channels)
+{
+  switch (ip.method)
+  {
+    case MH_INTENSITY_AVERAGE: case MH_INTENSITY_BRIGHTNESS: case MH_INTENSITY_LIGHTNESS: case MH_INTENSITY_MS:
+    case MH_INTENSITY_REC601LUMA: case MH_INTENSITY_REC601LUMINANCE: case MH_INTENSITY_REC709LUMINANCE:
+    case MH_INTENSITY_RMS:
+      return false;
+    default:
+      break;
+  }
+  return (channels >= 3) && (ip.linear == 0) && (ip.gray == 0);
+}
+
+template<typename Q,int C>
+static __device__ __noinline__ double pixel_intensity_call(const Q (&q)[C],const IntensityParams &ip)
+{
+  return pixel_intensity<Q,C>(q,ip);
+}
+
+template<bool PLAIN,typename Q,int C>
+static __device__ __forceinline__ double pixel_intensity_of(const Q (&q)[C],const IntensityParams &ip)
+{
+  if constexpr (PLAIN && (C >= 3))
+    return 0.212656*(double) q[0]+0.715158*(double) q[1]+0.072186*(double) q[2];
+  else
+    return pixel_intensity_call<Q,C>(q,ip);
+}
+
 // ---------------------------------------------------------------- histogram
 // 65536 bins x C channels of 64-bit counts (0.5-2 MiB) do not fit LDS, so the
 // counts live in global memory (L2 / Infinity-Cache resident) and are updated
@@ -936,7 +969,7 @@ static __device__ __forceinline__ void packed_table_to_slab(const unsigned *tabl
     slab[i]=packed[i];
 }
 
-template<int C>
+template<int C,bool PLAIN>
 __global__ __launch_bounds__(1024)
 void histogram_packed_kernel(const uint16_t *pixels,size_t npixels,IntensityParams ip,unsigned *slabs,
   unsigned long long *counts,int wide)
@@ -955,7 +988,7 @@ void histogram_packed_kernel(const uint16_t *pixels,size_t npixels,IntensityPara
   const size_t packed_end=end-begin > kPackedCapacity ? begin+kPackedCapacity : end;
   auto count=[&](const uint16_t (&q)[C])
   {
-    const unsigned bin=QuantumOps<uint16_t>::map_index(QuantumOps<uint16_t>::clamp(pixel_intensity<uint16_t,C>(q,ip)));
+    const unsigned bin=QuantumOps<uint16_t>::map_index(QuantumOps<uint16_t>::clamp(pixel_intensity_of<PLAIN,uint16_t,C>(q,ip)));
     atomicAdd(table+(bin >> 1),(bin & 1u) != 0u ? 0x10000u : 1u);
   };
   size_t done=begin;                           // pixels [begin, done) are in the LDS table
@@ -1008,7 +1041,7 @@ void histogram_packed_kernel(const uint16_t *pixels,size_t npixels,IntensityPara
           else
             {
               // beyond what the 16-bit counters may hold: the caller's table directly
-              const unsigned bin=QuantumOps<uint16_t>::map_index(QuantumOps<uint16_t>::clamp(pixel_intensity<uint16_t,C>(q[k],ip)));
+              const unsigned bin=QuantumOps<uint16_t>::map_index(QuantumOps<uint16_t>::clamp(pixel_intensity_of<PLAIN,uint16_t,C>(q[k],ip)));
               for (int c=0; c < C; c++)
                 atomicAdd(counts+(size_t) bin*C+c,1ull);
             }
@@ -1067,13 +1100,19 @@ static MhStatus histogram_intensity_packed(const View &src,const IntensityParams
   Temp slabs;
   MH_TRY(slabs.alloc(src.device,nblocks*32768*sizeof(unsigned),src.stream));
   const size_t lds=32768*sizeof(unsigned);
-  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&histogram_packed_kernel<C>),
+  const bool plain=intensity_is_plain_luma(ip,C);
+  MH_HIP(hipFuncSetAttribute(plain ? reinterpret_cast<const void *>(&histogram_packed_kernel<C,true>) :
+    reinterpret_cast<const void *>(&histogram_packed_kernel<C,false>),
     hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
   const int wide=(C == 4) && ((reinterpret_cast<uintptr_t>(src.pixels) & 15u) == 0) ? 1 : 0;
   {
     ProfileScope prof("histogram",src.stream);
-    hipLaunchKernelGGL((histogram_packed_kernel<C>),dim3((unsigned) nblocks),dim3(1024),lds,src.stream,
-      static_cast<const uint16_t *>(src.pixels),n,ip,slabs.as<unsigned>(),hist,wide);
+    if (plain)
+      hipLaunchKernelGGL((histogram_packed_kernel<C,true>),dim3((unsigned) nblocks),dim3(1024),lds,src.stream,
+        static_cast<const uint16_t *>(src.pixels),n,ip,slabs.as<unsigned>(),hist,wide);
+    else
+      hipLaunchKernelGGL((histogram_packed_kernel<C,false>),dim3((unsigned) nblocks),dim3(1024),lds,src.stream,
+        static_cast<const uint16_t *>(src.pixels),n,ip,slabs.as<unsigned>(),hist,wide);
     hipLaunchKernelGGL(histogram_packed_reduce_kernel,dim3(256),dim3(1024),0,src.stream,
       slabs.as<unsigned>(),(int) nblocks,hist,C);
   }
@@ -1086,6 +1125,7 @@ static MhStatus histogram_intensity_packed(const View &src,const IntensityParams
 // (config C4) at one frame read and one frame write.  Converts as colorspace_lab_fast_kernel
 // and bins the values it stores as histogram_packed_kernel does, so the table is exactly the
 // histogram of the frame it leaves behind.
+template<bool PLAIN>
 __global__ __launch_bounds__(1024)
 void lab_histogram_fast_kernel(uint16_t *pixels,size_t npixels,IntensityParams ip,unsigned *slabs,
   unsigned long long *counts)
@@ -1105,7 +1145,7 @@ void lab_histogram_fast_kernel(uint16_t *pixels,size_t npixels,IntensityParams i
   auto bin_of=[&](uint2 px) -> unsigned
   {
     const uint16_t q[4]={(uint16_t) px.x,(uint16_t) (px.x >> 16),(uint16_t) px.y,(uint16_t) (px.y >> 16)};
-    return QuantumOps<uint16_t>::map_index(QuantumOps<uint16_t>::clamp(pixel_intensity<uint16_t,4>(q,ip)));
+    return QuantumOps<uint16_t>::map_index(QuantumOps<uint16_t>::clamp(pixel_intensity_of<PLAIN,uint16_t,4>(q,ip)));
   };
   auto count=[&](uint2 px)
   {
@@ -1173,12 +1213,18 @@ MhStatus launch_lab_fast_with_histogram(const View &img,const MhImage *lab_desc,
   Temp slabs;
   MH_TRY(slabs.alloc(img.device,nblocks*32768*sizeof(unsigned),img.stream));
   const size_t lds=32768*sizeof(unsigned);
-  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&lab_histogram_fast_kernel),
+  const bool plain=intensity_is_plain_luma(ip,4);
+  MH_HIP(hipFuncSetAttribute(plain ? reinterpret_cast<const void *>(&lab_histogram_fast_kernel<true>) :
+    reinterpret_cast<const void *>(&lab_histogram_fast_kernel<false>),
     hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
   {
     ProfileScope prof("colorspace_histogram",img.stream);
-    hipLaunchKernelGGL(lab_histogram_fast_kernel,dim3((unsigned) nblocks),dim3(1024),lds,img.stream,
-      static_cast<uint16_t *>(img.pixels),n,ip,slabs.as<unsigned>(),hist);
+    if (plain)
+      hipLaunchKernelGGL(lab_histogram_fast_kernel<true>,dim3((unsigned) nblocks),dim3(1024),lds,img.stream,
+        static_cast<uint16_t *>(img.pixels),n,ip,slabs.as<unsigned>(),hist);
+    else
+      hipLaunchKernelGGL(lab_histogram_fast_kernel<false>,dim3((unsigned) nblocks),dim3(1024),lds,img.stream,
+        static_cast<uint16_t *>(img.pixels),n,ip,slabs.as<unsigned>(),hist);
     hipLaunchKernelGGL(histogram_packed_reduce_kernel,dim3(256),dim3(1024),0,img.stream,
       slabs.as<unsigned>(),(int) nblocks,hist,4);
   }

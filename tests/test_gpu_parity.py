@@ -940,6 +940,15 @@ def test_histogram_operators_large_frame(im, refmod, dtype, kind):
     assert_parity(got, ref.contrast_stretch(0.02 * n, n - 0.01 * n).numpy(), True, "contrast-stretch (large)")
 
 
+def test_histogram_large_frame_linear_rgb_intensity(im, refmod):
+    """A linear-RGB frame's intensity goes through EncodePixelGamma (pixel.c:2446-2452): the
+    packed-table kernel's general form (the whole GetPixelIntensity switch behind a call)."""
+    rows, cols = 1030, 1050
+    px = make_pixels(rows, cols, 4, Q16, seed=5)
+    dev, ref = run_pair(im, refmod, px, colorspace="RGB")
+    assert_parity(im.equalize_image(dev).numpy(), ref.equalize().numpy(), True, "equalize (large, linear RGB)")
+
+
 # ----------------------------------- full-size property checks, configs C3 / C4 / C5
 def test_resize_full_size_properties(im):
     """BASELINE C3 geometry (8192^2 -> 32768^2 Lanczos, float Quantum RGBA, 17 GB result):

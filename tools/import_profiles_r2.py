@@ -27,7 +27,8 @@ LABELS = [
     (r"conv_column_", "conv_column"), (r"conv_row_alpha_audit", "conv_row_alpha_audit"), (r"conv_row_", "conv_row"),
     (r"resize_vertical", "resize_vertical"), (r"resize_horizontal", "resize_horizontal"),
     (r"resize_fused", "resize_fused"),
-    (r"colorspace_", "colorspace"), (r"histogram_", "histogram"), (r"apply_lut", "apply_lut"),
+    (r"lab_histogram_fast", "colorspace_histogram"), (r"colorspace_", "colorspace"),
+    (r"histogram_packed_reduce", "colorspace_histogram"), (r"histogram_", "histogram"), (r"apply_lut", "apply_lut"),
     (r"lut_", "build_lut"), (r"gray_", "gray_check"),
     (r"morph_rects", "morph_rects"), (r"morph_convex", "morph_convex"), (r"morph2d", "morph2d"), (r"unsharp_kernel", "unsharp_epilogue"),
 ]
