@@ -522,6 +522,9 @@ def make_step(im, torch, dist, args, rank, world):
 
 def main():
     args = parse_args()
+    if os.environ.get("MAGICKHIP_BENCH_WATCHDOG"):      # diagnostics: dump every thread's stack and exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["MAGICKHIP_BENCH_WATCHDOG"]), exit=True)
     import torch
     import torch.distributed as dist
 
@@ -551,10 +554,24 @@ def main():
     # it to its sustained state before the W warm-up steps the contract counts (MAGICKHIP_BENCH_RAMP=0
     # skips it)
     ramp = float(os.environ.get("MAGICKHIP_BENCH_RAMP", "0.3"))
-    t_ramp = time.perf_counter()
-    while ramp > 0 and time.perf_counter() - t_ramp < ramp:
+    if distributed and ramp > 0:
+        # every rank must run the SAME number of steps (a step may hold a collective): rank 0
+        # times one step and broadcasts the count
+        t_ramp = time.perf_counter()
         step()
         torch.cuda.synchronize()
+        one = max(time.perf_counter() - t_ramp, 1e-4)
+        count = torch.tensor([min(int(ramp / one) + 1, 10000)], dtype=torch.int64,
+                             device="cuda" if args.backend == "nccl" else "cpu")
+        dist.broadcast(count, src=0)
+        for _ in range(int(count.item())):
+            step()
+        torch.cuda.synchronize()
+    else:
+        t_ramp = time.perf_counter()
+        while ramp > 0 and time.perf_counter() - t_ramp < ramp:
+            step()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

@@ -223,7 +223,8 @@ def test_colorspace_and_contrast_stretch_chain(shim, dtype):
 @pytest.mark.parametrize("dtype", [np.uint16, np.float32])
 def test_contrast_and_modulate_through_magickcore(shim, dtype):
     """AccelerateContrastImage / AccelerateModulateImage have live call sites in the reference
-    (enhance.c:1412-1415, :3770-3774); a colour model the backend does not take (HWB) falls back."""
+    (enhance.c:1412-1415, :3770-3774); ModulateImage's other colour models (here HWB,
+    enhance.c:3826-3890) are accelerated too since round 2."""
     hdri = dtype == np.float32
     px = make_pixels(50, 66, 4, dtype)
     before = accelerated_calls(shim, hdri)
@@ -237,5 +238,5 @@ def test_contrast_and_modulate_through_magickcore(shim, dtype):
                   "ModulateImage HSB via MagickCore", max_ulp=1)
     assert accelerated_calls(shim, hdri) == before + 3
     assert_parity(g.modulate(90.0, 120.0, 70.0, "HWB").numpy(), c.modulate(90.0, 120.0, 70.0, "HWB").numpy(), True,
-                  "ModulateImage HWB (CPU fallback)", max_ulp=1)
-    assert accelerated_calls(shim, hdri) == before + 3
+                  "ModulateImage HWB via MagickCore", max_ulp=1)
+    assert accelerated_calls(shim, hdri) == before + 4
