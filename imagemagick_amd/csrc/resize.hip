@@ -27,6 +27,7 @@
 #include "resize_filter.hpp"
 #include "device_common.hpp"
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace mh {
@@ -629,6 +630,204 @@ void resize_fused_kernel(FusedArgs a)
     }
 }
 
+// ------------------------------------------- fused V-then-H, vertical pass in the staging
+// The horizontal pass above is bound by its 16x output stream, not by arithmetic; its staging
+// phase reads the Quantum-typed intermediate (columns x new rows) that VerticalFilter wrote a
+// moment ago.  This form computes those intermediate samples instead of reading them: a staging
+// thread evaluates VerticalFilter for its (tile row, source column) from the source rows —
+// an 11 x 78 pixel patch per 256 x 16 output tile at 4x, served by the L1 — rounds the result to
+// Quantum exactly as the reference's filter image holds it (resize.c:3535-3543) and stores it
+// converted, and the horizontal part is unchanged.  The 4.3 GB intermediate of config C3 is
+// neither written nor read and the vertical launch disappears; results are those of the two
+// passes, operation by operation.
+struct FusedStageArgs
+{
+  ResizeArgs h;               // column tables; src unused, dst = the result
+  ResizeArgs v;               // row tables; src = the source image
+};
+
+constexpr int kFusedRows=16;  // tile rows (rows of vertical tables in LDS)
+
+template<typename Q,int C,bool BLEND,class A,int MAXT,int VMAXT,int ITEMS>
+__global__ __launch_bounds__(256)
+void resize_fused_stage_kernel(FusedStageArgs a,int tile_rows,int lds_span)
+{
+  typedef typename A::T T;
+  constexpr bool kSkipZeros=std::is_same<A,Exact64>::value && QuantumOps<Q>::is_float;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T *vw=reinterpret_cast<T *>(smem_raw);                  // [VMAXT][kFusedRows]
+  T *vwq=vw+VMAXT*kFusedRows;                             // [VMAXT][kFusedRows]
+  int *vstart=reinterpret_cast<int *>(vwq+VMAXT*kFusedRows);
+  int *vcount=vstart+kFusedRows;
+  int *vnear=vcount+kFusedRows;
+  T *tile=reinterpret_cast<T *>(vnear+kFusedRows+4);      // (3*16+4 ints: 16-byte aligned)
+  Q *patch=reinterpret_cast<Q *>(tile);                   // the source rows, before the tile exists
+  const ResizeArgs &args=a.h;
+  const int OUT=args.out_size;
+  const int x0=(int) blockIdx.x*256;
+  const int x=x0+(int) threadIdx.x;
+  const int y0=(int) blockIdx.y*tile_rows;
+  const Q *src=static_cast<const Q *>(a.v.src);
+  Q *dst=static_cast<Q *>(args.dst);
+  const T *weight=static_cast<const T *>(args.weight);
+  const T *weight_qs=static_cast<const T *>(args.weight_qs);
+  const size_t src_pitch=(size_t) a.v.src_columns*C;
+  const size_t dst_pitch=(size_t) args.dst_columns*C;
+  const int lo=args.tile_lo[blockIdx.x];
+  int rows=args.dst_rows-y0;
+  rows=rows < tile_rows ? rows : tile_rows;
+  const int last_row=a.v.src_rows-1;
+  // source rows of the tile: contribution starts do not decrease with y (resize.c:3623-3626), and
+  // the vertical taps read VMAXT rows from each start (zero weights past `count`)
+  const int row_lo=a.v.start[y0];
+  int row_hi=a.v.start[y0+rows-1]+VMAXT-1;
+  row_hi=row_hi < last_row ? row_hi : last_row;
+  const int patch_rows=row_hi-row_lo+1;
+
+  // the vertical tables of this tile's rows
+  if ((int) threadIdx.x < rows)
+    {
+      const int r=(int) threadIdx.x,y=y0+r,OUTV=a.v.out_size;
+      const T *vweight=static_cast<const T *>(a.v.weight);
+      const T *vweight_qs=static_cast<const T *>(a.v.weight_qs);
+      const int cnt=a.v.count[y];
+      vstart[r]=a.v.start[y]-row_lo;
+      vcount[r]=cnt;
+      vnear[r]=cnt > 0 ? a.v.nearest[y]-row_lo : 0;
+#pragma unroll
+      for (int j=0; j < VMAXT; j++)
+        {
+          vw[j*kFusedRows+r]=j < cnt ? vweight[(size_t) j*OUTV+y] : (T) 0;
+          vwq[j*kFusedRows+r]=(BLEND && (j < cnt)) ? vweight_qs[(size_t) j*OUTV+y] : (T) 0;
+        }
+    }
+  // the source patch: patch_rows x lds_span pixels, coalesced row segments
+  {
+    constexpr int BATCH=4;
+    const int items=patch_rows*lds_span;
+    for (int i0=(int) threadIdx.x; i0 < items; i0+=256*BATCH)
+      {
+        Q v[BATCH][C];
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          {
+            int idx=i0+256*k;
+            idx=idx < items ? idx : items-1;
+            const int r=idx/lds_span,i=idx-r*lds_span;
+            int col=lo+i;
+            col=col < a.v.src_columns ? col : a.v.src_columns-1;
+            load_pixel<Q,C>(src+(size_t) (row_lo+r)*src_pitch+(size_t) col*C,v[k]);
+          }
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          if (i0+256*k < items)
+            store_pixel<Q,C>(patch+(size_t) (i0+256*k)*C,v[k]);
+      }
+  }
+  __syncthreads();
+
+  // VerticalFilter of (tile row r, patch column i) out of the patch, into registers
+  Q mid[ITEMS][C];
+  {
+    const int items=lds_span*rows;
+    const int patch_last=patch_rows-1;
+#pragma unroll
+    for (int k=0; k < ITEMS; k++)
+      {
+        int idx=(int) threadIdx.x+256*k;
+        idx=idx < items ? idx : items-1;
+        const int r=idx/lds_span,i=idx-r*lds_span;
+        const int start=vstart[r],count=vcount[r];
+        const Q *column=patch+(size_t) i*C;
+        Q p[VMAXT][C];
+#pragma unroll
+        for (int j=0; j < VMAXT; j++)
+          {
+            int row=start+j;                       // taps past `count` carry zero weights
+            row=row < patch_last ? row : patch_last;
+            load_pixel<Q,C>(column+(size_t) row*lds_span*C,p[j]);
+          }
+        ResizeAcc<Q,C,BLEND,A> acc;
+        acc.init();
+#pragma unroll
+        for (int j=0; j < VMAXT; j++)
+          if (!kSkipZeros || (j < count))
+            acc.tap(vw[j*kFusedRows+r],vwq[j*kFusedRows+r],p[j]);
+        Q copy[C];
+#pragma unroll
+        for (int c=0; c < C; c++)
+          copy[c]=(Q) 0;
+        if (a.v.copy_mask != 0)
+          load_pixel<Q,C>(column+(size_t) vnear[r]*lds_span*C,copy);
+        acc.finish(copy,a.v.copy_mask,mid[k]);
+      }
+  }
+  __syncthreads();                                   // every read of the patch is done
+  {
+    const int items=lds_span*rows;
+#pragma unroll
+    for (int k=0; k < ITEMS; k++)
+      {
+        const int idx=(int) threadIdx.x+256*k;
+        if (idx < items)
+          {
+#pragma unroll
+            for (int c=0; c < C; c++)
+              tile[(size_t) idx*C+c]=(T) mid[k][c];
+          }
+      }
+  }
+  __syncthreads();
+  if (x >= OUT)
+    return;
+  const int start=args.start[x]-lo;
+  const int count=args.count[x];
+  if (count <= 0)
+    return;
+  const int nearest=args.nearest[x]-lo;
+  T w[MAXT],wq[MAXT];
+#pragma unroll
+  for (int j=0; j < MAXT; j++)
+    {
+      w[j]=(T) 0;
+      wq[j]=(T) 0;
+      if (j < count)
+        {
+          w[j]=weight[(size_t) j*OUT+x];
+          if constexpr (BLEND)
+            wq[j]=weight_qs[(size_t) j*OUT+x];
+        }
+    }
+  for (int r=0; r < rows; r++)
+    {
+      const T *line=tile+(size_t) r*lds_span*C+(size_t) start*C;
+      ResizeAcc<Q,C,BLEND,A> acc;
+      acc.init();
+      T p[MAXT][C];
+#pragma unroll
+      for (int j=0; j < MAXT; j++)
+#pragma unroll
+        for (int c=0; c < C; c++)
+          p[j][c]=line[(size_t) j*C+c];
+#pragma unroll
+      for (int j=0; j < MAXT; j++)
+        if (!kSkipZeros || (j < count))
+          acc.tap_converted(w[j],wq[j],p[j]);
+      Q copy[C],out[C];
+#pragma unroll
+      for (int c=0; c < C; c++)
+        copy[c]=(Q) 0;
+      if (args.copy_mask != 0)
+        {
+#pragma unroll
+          for (int c=0; c < C; c++)
+            copy[c]=(Q) tile[((size_t) r*lds_span+(size_t) nearest)*C+c];
+        }
+      acc.finish(copy,args.copy_mask,out);
+      store_pixel<Q,C>(dst+(size_t) (y0+r)*dst_pitch+(size_t) x*C,out);
+    }
+}
+
 // uploads one axis' tables
 struct DeviceTaps
 {
@@ -768,6 +967,144 @@ static MhStatus dispatch_fused(const View &src,const View &dst,const TapTable &v
   return MH_OK;
 }
 
+// the horizontal tiling of the converted-tile kernels: first source column and tap count of
+// every 256-column tile, the LDS span (widest tile span + the zero-weight overhang)
+static void horizontal_tiles(const TapTable &table,int maxt,std::vector<int> &tile_lo,int &lds_span)
+{
+  int max_span=1,overhang=0;
+  std::vector<int> span;
+  for (int x0=0; x0 < table.out_size; x0+=256)
+    {
+      int xh=(x0+255) < table.out_size ? (x0+255) : table.out_size-1;
+      int lo=table.start[(size_t) x0],hi=0,endmax=0;
+      for (int i=x0; i <= xh; i++)
+        {
+          int st=table.start[(size_t) i],e=st+table.count[(size_t) i];
+          lo=st < lo ? st : lo;
+          hi=e > hi ? e : hi;
+          endmax=(st+maxt) > endmax ? (st+maxt) : endmax;
+        }
+      if (hi < lo)
+        hi=lo;
+      tile_lo.push_back(lo);
+      max_span=(hi-lo) > max_span ? (hi-lo) : max_span;
+      overhang=(endmax-hi) > overhang ? (endmax-hi) : overhang;
+    }
+  lds_span=max_span+overhang;
+}
+
+template<typename Q,int C,bool BLEND,class A>
+static MhStatus launch_fused_stage_typed(const View &src,const View &dst,const TapTable &vt,
+  const TapTable &ht,const Roles &roles,bool &handled)
+{
+  typedef typename A::T T;
+  handled=false;
+  if ((ht.max_taps > 8) || (vt.max_taps > 8))
+    return MH_OK;
+  const int maxt=ht.max_taps <= 4 ? 4 : (ht.max_taps <= 6 ? 6 : 8);
+  std::vector<int> tile_lo;
+  int lds_span=1;
+  horizontal_tiles(ht,maxt,tile_lo,lds_span);
+  const size_t cpx=(size_t) C*sizeof(T);
+  const size_t head=2u*8u*kFusedRows*sizeof(T)+(size_t) (3*kFusedRows+4)*sizeof(int);
+  // four workgroups per CU (as the horizontal kernel): 40 KB each, tables included
+  int tile_rows=(int) ((40u*1024u-head)/((size_t) lds_span*cpx));
+  if (const char *e=getenv("MAGICKHIP_FUSED_TILE_ROWS"))
+    tile_rows=atoi(e);
+  tile_rows=tile_rows > kFusedRows ? kFusedRows : tile_rows;
+  if (tile_rows < 4)
+    return MH_OK;                                // a wide source span: the two passes
+  const size_t lds=head+(size_t) lds_span*cpx*(size_t) tile_rows;
+  // the source patch of a tile is staged in the memory its intermediate tile will occupy
+  int patch_rows=1;
+  for (int y0=0; y0 < vt.out_size; y0+=tile_rows)
+    {
+      const int yl=(y0+tile_rows-1) < vt.out_size ? (y0+tile_rows-1) : vt.out_size-1;
+      const int span=vt.start[(size_t) yl]+8-vt.start[(size_t) y0];
+      patch_rows=span > patch_rows ? span : patch_rows;
+      for (int y=y0; y < yl; y++)
+        if (vt.start[(size_t) y+1] < vt.start[(size_t) y])
+          return MH_OK;                          // (never for MagickCore's contribution lists)
+    }
+  if ((size_t) patch_rows*sizeof(Q) > (size_t) tile_rows*sizeof(T))
+    return MH_OK;
+  const int items=(lds_span*tile_rows+255)/256;
+  if (items > 10)
+    return MH_OK;
+  FusedStageArgs a;
+  DeviceTaps dv,dh;
+  MH_TRY(dv.template upload<T>(vt,src,a.v));
+  MH_TRY(dh.template upload<T>(ht,src,a.h));
+  Temp d_lo;
+  MH_TRY(upload_table(d_lo,src.device,src.stream,tile_lo.data(),tile_lo.size()*sizeof(int)));
+  a.v.src=src.pixels;
+  a.v.dst=nullptr;
+  a.v.src_columns=(int) src.columns;
+  a.v.src_rows=(int) src.rows;
+  a.v.dst_columns=(int) src.columns;
+  a.v.dst_rows=(int) dst.rows;
+  a.v.copy_mask=roles.copy_mask;
+  a.v.tile_lo=nullptr;
+  a.v.tile_span=nullptr;
+  a.h.src=nullptr;
+  a.h.dst=dst.pixels;
+  a.h.src_columns=(int) src.columns;
+  a.h.src_rows=(int) dst.rows;
+  a.h.dst_columns=(int) dst.columns;
+  a.h.dst_rows=(int) dst.rows;
+  a.h.copy_mask=roles.copy_mask;
+  a.h.tile_lo=d_lo.as<int>();
+  a.h.tile_span=nullptr;
+  dim3 grid((unsigned) ((dst.columns+255)/256),(unsigned) ((dst.rows+tile_rows-1)/tile_rows));
+  ProfileScope prof("resize_fused",src.stream);
+#define MH_LAUNCH_F(N,I)                                                                        \
+  {                                                                                              \
+    if (lds > 64u*1024u)                                                                         \
+      MH_HIP(hipFuncSetAttribute(                                                                \
+        reinterpret_cast<const void *>(&resize_fused_stage_kernel<Q,C,BLEND,A,N,8,I>),          \
+        hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));                                  \
+    hipLaunchKernelGGL((resize_fused_stage_kernel<Q,C,BLEND,A,N,8,I>),grid,dim3(256),lds,src.stream, \
+      a,tile_rows,lds_span);                                                                     \
+  }
+  if (items <= 5)
+    {
+      if (maxt == 4) MH_LAUNCH_F(4,5)
+      else if (maxt == 6) MH_LAUNCH_F(6,5)
+      else MH_LAUNCH_F(8,5)
+    }
+  else
+    {
+      if (maxt == 4) MH_LAUNCH_F(4,10)
+      else if (maxt == 6) MH_LAUNCH_F(6,10)
+      else MH_LAUNCH_F(8,10)
+    }
+#undef MH_LAUNCH_F
+  MH_HIP(hipGetLastError());
+  handled=true;
+  return MH_OK;
+}
+
+template<typename Q,class A>
+static MhStatus dispatch_fused_stage(const View &src,const View &dst,const TapTable &vt,const TapTable &ht,
+  const Roles &roles,bool &handled)
+{
+  const bool blend=roles.blend && (roles.alpha == src.channels-1);
+  switch (src.channels)
+  {
+    case 1: return launch_fused_stage_typed<Q,1,false,A>(src,dst,vt,ht,roles,handled);
+    case 2:
+      if (blend) return launch_fused_stage_typed<Q,2,true,A>(src,dst,vt,ht,roles,handled);
+      return launch_fused_stage_typed<Q,2,false,A>(src,dst,vt,ht,roles,handled);
+    case 3: return launch_fused_stage_typed<Q,3,false,A>(src,dst,vt,ht,roles,handled);
+    case 4:
+      if (blend) return launch_fused_stage_typed<Q,4,true,A>(src,dst,vt,ht,roles,handled);
+      return launch_fused_stage_typed<Q,4,false,A>(src,dst,vt,ht,roles,handled);
+    default: break;
+  }
+  handled=false;
+  return MH_OK;
+}
+
 // VerticalFilter followed by HorizontalFilter in one launch.  *handled is false
 // (and nothing was launched) when the tiles do not fit LDS or the tap count is
 // too large; the caller then runs the two passes separately.
@@ -781,8 +1118,30 @@ MhStatus launch_resize_fused(const View &src,const View &dst,const TapTable &ver
     return MH_OK;
   if (((int) dst.rows != vertical.out_size) || ((int) dst.columns != horizontal.out_size))
     return fail(MH_BAD_ARGUMENT,"resize: geometry mismatch");
-  if (getenv("MAGICKHIP_FUSED_RESIZE") == nullptr)     // measured slower than the two passes
+  // Both fused forms are opt-in: measured on config C3 the one launch takes as long as the two
+  // passes together (stage form 6.04 ms against 4.62 + 1.35; the first form 8.6 ms) — the passes
+  // are bound by fp64 issue and LDS reads, not by the 8.6 GB of intermediate traffic a fused
+  // kernel saves.  MAGICKHIP_FUSED_RESIZE=stage | 1 selects them.
+  const char *choice=getenv("MAGICKHIP_FUSED_RESIZE");
+  if (choice == nullptr)
     return MH_OK;
+  if (strcmp(choice,"stage") == 0)
+    {
+      // enlargements (the vertical pass's source patch of a tile is small and L1-resident): the
+      // vertical pass inside the horizontal kernel's staging
+      if ((dst.rows < 2*src.rows) || (dst.columns < src.columns))
+        return MH_OK;
+      if (prec == MH_PRECISION_FAST)
+        {
+          if (src.quantum == MH_QUANTUM_U16)
+            return dispatch_fused_stage<uint16_t,Fma64>(src,dst,vertical,horizontal,roles,*handled);
+          return dispatch_fused_stage<float,Fma64>(src,dst,vertical,horizontal,roles,*handled);
+        }
+      if (src.quantum == MH_QUANTUM_U16)
+        return dispatch_fused_stage<uint16_t,Exact64>(src,dst,vertical,horizontal,roles,*handled);
+      return dispatch_fused_stage<float,Exact64>(src,dst,vertical,horizontal,roles,*handled);
+    }
+  // the first fused kernel: both tiles in LDS
   if (prec == MH_PRECISION_FAST)
     {
       if (src.quantum == MH_QUANTUM_U16)
@@ -923,7 +1282,8 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
         }
       // per tile: the largest tap count (run by every lane of the converted-tile kernel)
       const size_t ntiles=tile_lo.size();
-      const int maxt=table.max_taps <= 4 ? 4 : (table.max_taps <= 6 ? 6 : 8);
+      // (a 4x Lanczos enlargement has 6 or 7 contributions per output: 7 taps, not 8)
+      const int maxt=table.max_taps <= 4 ? 4 : (table.max_taps <= 6 ? 6 : (table.max_taps <= 7 ? 7 : 8));
       int overhang=0;
       for (size_t t=0; t < ntiles; t++)
         {
@@ -972,6 +1332,7 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
               }
               if (maxt == 4) MH_LAUNCH_H(4)
               else if (maxt == 6) MH_LAUNCH_H(6)
+              else if (maxt == 7) MH_LAUNCH_H(7)
               else MH_LAUNCH_H(8)
 #undef MH_LAUNCH_H
               MH_HIP(hipGetLastError());

@@ -27,3 +27,15 @@ for _ in range(reps):
 torch.cuda.synchronize()
 sec = (time.perf_counter() - t0) / reps
 print("resize %dx%d -> x4 %s: %.3f ms  %.1f Mpixels/s out" % (m, m, prec, sec * 1e3, 16.0 * m * m / sec / 1e6))
+
+from bench import kernel_profile
+hold = {}
+
+
+def call():
+    hold["o"] = None
+    hold["o"] = im.resize_image(img, 4 * m, 4 * m, "Lanczos")
+
+
+prof = kernel_profile(im, call, 2)
+print("   kernels(ms):", {k: round(v["avg_ms"], 3) for k, v in prof.items()})
