@@ -54,6 +54,30 @@ def test_blur_exact_on_rounding_ties(im, refmod, pattern, sigma):
                   "blur on ties, %s sigma %g" % (pattern, sigma))
 
 
+@pytest.mark.parametrize("sigma", [0.303, 2.0, 10.05])
+def test_blur_fast_structured_ties_bound(im, refmod, sigma):
+    """The hard bound of the two-pass FAST blur.  A checkerboard of two
+    levels (alpha included) and a frame of 0..3-level alpha put row-pass values on exact rounding
+    ties over whole windows, so the +-1 differences of the intermediate can line up: the composite
+    may then reach 2, never more, and stays within 1 on all but a few samples."""
+    rows, cols = 133, 310
+    rng = np.random.default_rng(31)
+    checker = np.empty((rows, cols, 4), dtype=np.uint16)
+    checker[:] = (np.add.outer(np.arange(rows), np.arange(cols)) % 2 * 40000 + 100)[:, :, None]
+    sparse = rng.integers(0, 65536, (rows, cols, 4), dtype=np.uint16)
+    sparse[:, :, 3] = rng.integers(0, 4, (rows, cols), dtype=np.uint16)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        for name, px in (("checkerboard", checker), ("0..3-level alpha", sparse)):
+            dev, ref = run_pair(im, refmod, px)
+            d = np.abs(im.blur_image(dev, 0.0, sigma).numpy().astype(np.int64) -
+                       ref.blur(0.0, sigma).numpy().astype(np.int64))
+            assert d.max() <= 2, "%s sigma %g: max %d" % (name, sigma, d.max())
+            assert float((d <= 1).mean()) > 0.999, "%s sigma %g: %d samples beyond 1" % (name, sigma, int((d > 1).sum()))
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+
+
 def test_blur_radius_argument(im, refmod):
     px = make_pixels(64, 80, 4, Q16)
     dev, ref = run_pair(im, refmod, px)

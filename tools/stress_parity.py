@@ -1,0 +1,117 @@
+#!/usr/bin/env python3
+"""Randomised differential run against the compiled reference (not part of the suite: minutes of
+CPU reference time).  Shapes, kernel lengths and operators are drawn at random, every result
+is compared with the reference: FAST blur / unsharp within +-1 (unsharp: 1+gain off the threshold
+edge), EXACT and the morphology / histogram operators bit-identical.
+   python tools/stress_parity.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import imagemagick_amd as im
+from oracle import ref as refmod
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+im.load()
+refmod.set_thread_limit(os.cpu_count() or 1)
+
+
+def dev(px, **kw):
+    t = torch.from_numpy(px.view(np.int16)).cuda().view(torch.uint16)
+    return im.Image(t, **kw)
+
+
+def pixels(rows, cols, kind):
+    px = rng.integers(0, 65536, (rows, cols, 4), dtype=np.uint16)
+    if kind == 1:
+        px[:, :, 3] = 65535
+    elif kind == 2:
+        px[:, :, 3] = rng.integers(0, 4, (rows, cols), dtype=np.uint16)          # tiny alpha
+    elif kind == 3:
+        px[:, :, 3] = np.where(rng.random((rows, cols)) < 0.5, 0, 65535)          # binary alpha
+    elif kind == 4:
+        px[:] = (np.add.outer(np.arange(rows), np.arange(cols)) % 2 * 40000 + 100)[:, :, None]
+    return px
+
+
+def check(name, got, want, limit, detail):
+    d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    if d.max(initial=0) > limit:
+        bad = np.argwhere(d > limit)
+        print("MISMATCH %s %s: max %d (limit %d), %d samples, first at %s" % (
+            name, detail, d.max(), limit, len(bad), bad[0].tolist()), flush=True)
+        return 1
+    return 0
+
+
+t0 = time.time()
+cases = failures = 0
+while time.time() - t0 < budget:
+    rows, cols = int(rng.integers(1, 260)), int(rng.integers(1, 330))
+    if rng.random() < 0.2:
+        rows, cols = int(rng.integers(1, 40)), int(rng.integers(300, 1400))
+    kind = int(rng.integers(0, 5))
+    px = pixels(rows, cols, kind)
+    op = int(rng.integers(0, 6))
+    detail = "%dx%d kind %d" % (rows, cols, kind)
+    ref = refmod.RefImage(px)
+    if op == 0:                                    # FAST blur, every kernel length of the fused launch
+        sigma = float(rng.uniform(0.3, 13.4))
+        im.set_precision(im.PRECISION_FAST)
+        got = im.blur_image(dev(px), 0.0, sigma).numpy()
+        im.set_precision(im.PRECISION_EXACT)
+        failures += check("fast blur", got, ref.blur(0.0, sigma).numpy(), 1, detail + " sigma %.3f" % sigma)
+    elif op == 1:                                  # EXACT blur (Tie64)
+        sigma = float(rng.uniform(0.3, 13.4))
+        got = im.blur_image(dev(px), 0.0, sigma).numpy()
+        failures += check("exact blur", got, ref.blur(0.0, sigma).numpy(), 0, detail + " sigma %.3f" % sigma)
+    elif op == 2:                                  # FAST unsharp in the fused launch
+        sigma = float(rng.uniform(0.5, 12.0))
+        gain, threshold = float(rng.uniform(0.3, 3.0)), float(rng.uniform(0.0, 0.2))
+        im.set_precision(im.PRECISION_FAST)
+        got = im.unsharp_mask_image(dev(px), 0.0, sigma, gain, threshold).numpy()
+        im.set_precision(im.PRECISION_EXACT)
+        want = ref.unsharp(0.0, sigma, gain, threshold).numpy()
+        blurred = ref.blur(0.0, sigma).numpy().astype(np.int64)
+        edge = np.abs(2 * np.abs(px.astype(np.int64) - blurred) - 65535.0 * threshold) <= 2.0
+        d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+        d[edge] = 0
+        failures += check("fast unsharp", d, np.zeros_like(d), int(np.ceil(1.0 + gain)),
+                          detail + " sigma %.3f gain %.2f thr %.3f" % (sigma, gain, threshold))
+    elif op == 3:                                  # symmetric convex kernels (rects)
+        family = ["Disk:%.1f" % rng.uniform(0.5, 16.0), "Square:%d" % rng.integers(1, 9),
+                  "Diamond:%d" % rng.integers(1, 12), "Octagon:%d" % rng.integers(1, 10),
+                  "Plus:%d" % rng.integers(1, 12), "Rectangle:%dx%d" % (2 * rng.integers(0, 9) + 1, 2 * rng.integers(0, 9) + 1)]
+        kernel = family[int(rng.integers(0, len(family)))]
+        method = "Dilate" if rng.random() < 0.5 else "Erode"
+        got = im.morphology_image(dev(px), method, 1, kernel).numpy()
+        failures += check(method, got, ref.morphology(method, 1, kernel).numpy(), 0, detail + " " + kernel)
+    elif op == 4:                                  # histogram operators above a megapixel
+        rows2, cols2 = int(rng.integers(1000, 1500)), int(rng.integers(1050, 1900))
+        px2 = pixels(rows2, cols2, int(rng.integers(0, 4)))
+        px2[0, 0] = (1, 2, 3, 4)
+        n = rows2 * cols2
+        black, white = float(rng.uniform(0, 0.1)) * n, n - float(rng.uniform(0, 0.1)) * n
+        if rng.random() < 0.5:
+            got = im.contrast_stretch_image(dev(px2), black, white).numpy()
+            want = refmod.RefImage(px2).contrast_stretch(black, white).numpy()
+        else:
+            got = im.equalize_image(dev(px2)).numpy()
+            want = refmod.RefImage(px2).equalize().numpy()
+        failures += check("histogram op", got, want, 0, "%dx%d" % (rows2, cols2))
+    else:                                          # FAST Lab
+        im.set_precision(im.PRECISION_FAST)
+        d2 = dev(px)
+        im.transform_image_colorspace(d2, "Lab")
+        im.set_precision(im.PRECISION_EXACT)
+        failures += check("fast lab", d2.numpy(), ref.colorspace("Lab").numpy(), 1, detail)
+    cases += 1
+print("%d cases, %d failures, %.0f s" % (cases, failures, time.time() - t0))
+sys.exit(1 if failures else 0)
