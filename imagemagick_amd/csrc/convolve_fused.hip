@@ -489,7 +489,29 @@ template<int NC,int MODE,bool UNSHARP>
 __global__ __launch_bounds__(1024)
 void blur_fused16_kernel(BlurFusedArgs args)
 {
-  static_assert((MODE == MFMA_BLEND4) || (MODE == MFMA_PLAIN4),"8-byte pixels");
+  // MFMA_PLAIN3 (RGB, 6-byte pixels) runs as four plain channels whose fourth is zero: only the
+  // pixel loads and stores differ
+  constexpr int PX=MODE == MFMA_PLAIN3 ? 3 : 4;          // u16 per pixel in memory
+  constexpr int SAMPLES=MODE == MFMA_PLAIN3 ? MFMA_PLAIN4 : MODE;
+  // (6-byte pixels are 2-byte aligned; global memory takes dword accesses at that alignment)
+  typedef unsigned __attribute__((aligned(2))) LooseDword;
+  auto load_pixel16=[&](const uint16_t *at) -> uint2
+  {
+    if constexpr (MODE == MFMA_PLAIN3)
+      return make_uint2(*reinterpret_cast<const LooseDword *>(at),(unsigned) at[2]);
+    else
+      return *reinterpret_cast<const uint2 *>(at);
+  };
+  auto store_pixel16=[&](uint16_t *at,uint2 value)
+  {
+    if constexpr (MODE == MFMA_PLAIN3)
+      {
+        *reinterpret_cast<LooseDword *>(at)=value.x;
+        at[2]=(uint16_t) value.y;
+      }
+    else
+      *reinterpret_cast<uint2 *>(at)=value;
+  };
   typedef Fused16Geometry<NC> G;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   _Float16 *ring_hi=reinterpret_cast<_Float16 *>(smem_raw);
@@ -551,12 +573,27 @@ void blur_fused16_kernel(BlurFusedArgs args)
       {
         int y=in0+G::GROUP*g+srow;
         y=y < 0 ? 0 : (y > H-1 ? H-1 : y);       // the intermediate's edge clamp (cache.c:2663-2679)
-#pragma unroll
-        for (int i=0; i < 4; i++)
+        const int xs=xin0+4*sxg;
+        if ((MODE == MFMA_PLAIN3) && (xs >= 0) && (xs+3 <= W-1))
           {
-            int x=xin0+4*sxg+i;
-            x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
-            raw[i]=*reinterpret_cast<const uint2 *>(args.src+pixel_index(y,W,x)*4);
+            // four RGB pixels = 24 contiguous bytes: three 8-byte loads, re-cut into pixels
+            const uint16_t *at=args.src+pixel_index(y,W,xs)*3;
+            const LooseDword *words=reinterpret_cast<const LooseDword *>(at);
+            const uint2 a=make_uint2(words[0],words[1]),b=make_uint2(words[2],words[3]),c=make_uint2(words[4],words[5]);
+            raw[0]=make_uint2(a.x,a.y & 0xffffu);
+            raw[1]=make_uint2((a.y >> 16) | (b.x << 16),b.x >> 16);
+            raw[2]=make_uint2(b.y,c.x & 0xffffu);
+            raw[3]=make_uint2((c.x >> 16) | (c.y << 16),c.y >> 16);
+          }
+        else
+          {
+#pragma unroll
+            for (int i=0; i < 4; i++)
+              {
+                int x=xs+i;
+                x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
+                raw[i]=load_pixel16(args.src+pixel_index(y,W,x)*PX);
+              }
           }
       }
   };
@@ -565,7 +602,7 @@ void blur_fused16_kernel(BlurFusedArgs args)
     if (stager)
       {
         f32x2 v[4][2];
-        quantum_to_samples<MODE>(raw,v);
+        quantum_to_samples<SAMPLES>(raw,v);
 #pragma unroll
         for (int c=0; c < 4; c++)
           {
@@ -595,7 +632,7 @@ void blur_fused16_kernel(BlurFusedArgs args)
   {
     const int x=x0+4*wave+kq,y=out_begin+G::GROUP*block+n;
     if ((block >= 0) && (block < nblocks) && (x < W) && (y < H))
-      original=*reinterpret_cast<const uint2 *>(args.src+pixel_index(y,W,x)*4);
+      original=load_pixel16(args.src+pixel_index(y,W,x)*PX);
   };
 
   fetch(0);
@@ -636,12 +673,12 @@ void blur_fused16_kernel(BlurFusedArgs args)
               acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_lo[c],acc,0,0,0);
             }
           // lane (n, kq): the four channels (registers) of pixel (column 4*wave+kq, row n)
-          uint2 result=sums_to_quantum<MODE>(acc[0],acc[1],acc[2],acc[3]);
+          uint2 result=sums_to_quantum<SAMPLES>(acc[0],acc[1],acc[2],acc[3]);
           if constexpr (UNSHARP)
             result=unsharp_pixel(unblurred,result,args.gain,args.threshold);
           const int x=x0+4*wave+kq,y=out_begin+G::GROUP*block+n;
           if ((x < W) && (y < H))
-            *reinterpret_cast<uint2 *>(args.dst+pixel_index(y,W,x)*4)=result;
+            store_pixel16(args.dst+pixel_index(y,W,x)*PX,result);
         }
       if (g == ngroups)
         break;
@@ -762,6 +799,9 @@ static MhStatus launch_fused16_typed(const View &src,BlurFusedArgs &args)
 template<int NC>
 static MhStatus launch_fused16(const View &src,BlurFusedArgs &args,bool blend,bool unsharp)
 {
+  if (src.channels == 3)
+    return unsharp ? launch_fused16_typed<NC,MFMA_PLAIN3,true>(src,args) :
+      launch_fused16_typed<NC,MFMA_PLAIN3,false>(src,args);
   if (unsharp)
     return blend ? launch_fused16_typed<NC,MFMA_BLEND4,true>(src,args) :
       launch_fused16_typed<NC,MFMA_PLAIN4,true>(src,args);
@@ -776,8 +816,9 @@ MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_dev
   double threshold)
 {
   *handled=false;
-  if ((src.quantum != MH_QUANTUM_U16) || (dst.quantum != MH_QUANTUM_U16) || (src.channels != 4) ||
-      (dst.channels != 4) || (src.columns != dst.columns) || (src.rows != dst.rows) || (ntaps < 2))
+  if ((src.quantum != MH_QUANTUM_U16) || (dst.quantum != MH_QUANTUM_U16) ||
+      ((src.channels != 4) && ((src.channels != 3) || blend)) ||
+      (dst.channels != src.channels) || (src.columns != dst.columns) || (src.rows != dst.rows) || (ntaps < 2))
     return MH_OK;
   if ((src.columns >= (1u << 24)) || (src.rows >= (1u << 24)) ||
       ((unsigned long long) src.columns*src.rows >= (1ull << 32)))
@@ -800,7 +841,7 @@ MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_dev
     args.threshold=level > 131072.0 ? 131072 : (level < 0.0 ? 0 : (int) level);
   }
   *handled=true;
-  if ((getenv("MAGICKHIP_FUSED_32") == nullptr) || unsharp)
+  if ((getenv("MAGICKHIP_FUSED_32") == nullptr) || unsharp || (src.channels != 4))
     {
       const int nc=(ntaps+15+31)/32;             // 16 outputs + K-1 halo, in 32-sample chunks
       if (nc == 1)
@@ -810,9 +851,9 @@ MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_dev
       if (nc == 3)
         return launch_fused16<3>(src,args,blend,unsharp);
     }
-  if (unsharp)
+  if (unsharp || (src.channels != 4))
     {
-      *handled=false;                            // wider kernels: row pass + fused column pass
+      *handled=false;                            // wider kernels, RGB: row pass + (fused) column pass
       return MH_OK;
     }
 #define MH_NQ(NQV) \

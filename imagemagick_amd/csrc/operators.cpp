@@ -310,11 +310,18 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
   const Roles &roles,double bias,bool *handled,bool unsharp=false,double gain=0.0,double threshold=0.0)
 {
   *handled=false;
-  if ((precision() != MH_PRECISION_FAST) || (src.quantum != MH_QUANTUM_U16) || (src.channels != 4) ||
+  if ((precision() != MH_PRECISION_FAST) || (src.quantum != MH_QUANTUM_U16) ||
+      ((src.channels != 4) && (src.channels != 3)) ||
       (roles.copy_mask != 0) || (bias != 0.0) || (getenv("MAGICKHIP_NO_MFMA") != nullptr) ||
       (getenv("MAGICKHIP_NO_FUSED_BLUR") != nullptr))
     return MH_OK;
-  if (roles.blend && (roles.alpha != 3))
+  if (roles.blend && ((roles.alpha != 3) || (src.channels != 4)))
+    return MH_OK;
+  // RGB (6-byte pixels): the one launch is measured level with the two matrix-core launches
+  // for BlurImage (0.68 against 0.67 ms at 8192^2: its 6-byte loads and stores are narrower)
+  // and ahead of them for UnsharpMaskImage (0.85 against 0.95 ms), so only the latter takes it
+  // by default; MAGICKHIP_FUSED_RGB=1 sends both
+  if ((src.channels == 3) && !unsharp && (getenv("MAGICKHIP_FUSED_RGB") == nullptr))
     return MH_OK;
   const MhKernelInfo *row=kernel,*column=kernel->next;
   if ((column == nullptr) || (column->next != nullptr) || (row->height != 1) || (column->width != 1) ||
@@ -817,19 +824,23 @@ static MhStatus unsharp_fused(const View &src,const View &dst,const MhKernelInfo
 {
   *fused=false;
   const MhKernelInfo *horizontal=kernels,*vertical=kernels != nullptr ? kernels->next : nullptr;
-  if ((precision() != MH_PRECISION_FAST) || (src.quantum != MH_QUANTUM_U16) || (src.channels != 4) ||
+  if ((precision() != MH_PRECISION_FAST) || (src.quantum != MH_QUANTUM_U16) ||
+      ((src.channels != 4) && (src.channels != 3)) ||
       (src.columns < 2) || (getenv("MAGICKHIP_NO_FUSED_UNSHARP") != nullptr) ||
       (getenv("MAGICKHIP_NO_MFMA") != nullptr) ||
       (roles.copy_mask != 0) || (horizontal == nullptr) || (vertical == nullptr) ||
       (vertical->next != nullptr) || (horizontal->height != 1) || (vertical->width != 1) ||
       kernel_has_nan(horizontal) || kernel_has_nan(vertical))
     return MH_OK;
-  if (roles.blend && (roles.alpha != 3))
+  if (roles.blend && ((roles.alpha != 3) || (src.channels != 4)))
     return MH_OK;
-  // one launch: both passes and the epilogue (convolve_fused.hip), kernels of up to 81 taps
+  // one launch: both passes and the epilogue (convolve_fused.hip), kernels of up to 81 taps,
+  // RGBA / four plain channels / RGB
   MH_TRY(fused_blur(src,dst,kernels,roles,0.0,fused,true,gain,threshold));
   if (*fused)
     return MH_OK;
+  if (src.channels != 4)
+    return MH_OK;                                // the two-launch form copies 8-byte pixels out
   View rows=src;
   Temp memory;
   MH_TRY(memory.alloc(src.device,rows.bytes(),src.stream));

@@ -173,6 +173,37 @@ def test_convolve_fast_signed_separable_kernel_plain_channels(im):
     assert int((fast - exact).abs().max()) <= 1
 
 
+@pytest.mark.parametrize("shape", [(150, 331), (70, 64), (33, 65), (1, 200), (200, 1), (17, 2)])
+@pytest.mark.parametrize("sigma", [0.6, 2.5, 10.0])
+def test_blur_and_unsharp_fast_rgb_single_launch(im, refmod, shape, sigma, monkeypatch):
+    """RGB (6-byte pixels, no alpha) through the single-launch fused kernel as four plain channels
+    whose fourth is zero (MFMA_PLAIN3: only the pixel loads and stores differ): UnsharpMaskImage
+    by default, BlurImage with MAGICKHIP_FUSED_RGB=1 (measured level with its two-launch form);
+    strips and segments ragged at both edges."""
+    import bench
+    monkeypatch.setenv("MAGICKHIP_FUSED_RGB", "1")
+    px = make_pixels(shape[0], shape[1], 3, Q16, seed=shape[0] + shape[1])
+    dev, ref = run_pair(im, refmod, px)
+    holder = {}
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        launched = set(bench.kernel_profile(im, lambda: holder.update(b=im.blur_image(dev, 0.0, sigma)), 1))
+        if shape[1] >= 2 and shape[0] >= 2:
+            assert launched == {"blur_fused"}, launched
+        launched = set(bench.kernel_profile(
+            im, lambda: holder.update(u=im.unsharp_mask_image(dev, 0.0, sigma, 1.5, 0.01)), 1))
+        if shape[1] >= 2 and shape[0] >= 2:
+            assert launched == {"unsharp_fused"}, launched
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert_parity(holder["b"].numpy(), ref.blur(0.0, sigma).numpy(), False, "fast RGB blur %s" % (shape,))
+    want = ref.unsharp(0.0, sigma, 1.5, 0.01).numpy().astype(np.int64)
+    blurred = ref.blur(0.0, sigma).numpy().astype(np.int64)
+    on_the_edge = np.abs(2 * np.abs(px.astype(np.int64) - blurred) - 65535.0 * 0.01) <= 2.0
+    diff = np.abs(holder["u"].numpy().astype(np.int64) - want)
+    assert int(diff[~on_the_edge].max(initial=0)) <= 3
+
+
 @pytest.mark.parametrize("channels", [4, 3])
 @pytest.mark.parametrize("sigma", [3.2, 5.0, 8.0, 11.0, 14.0])
 def test_blur_fast_every_ring_size(im, refmod, channels, sigma):
