@@ -485,7 +485,7 @@ def make_step(im, torch, dist, args, rank, world):
                         image.colorspace = "srgb"
                     torch.cuda.synchronize()
                 im.batch_images([("colorspace", "Lab"), ("contraststretch", 0.02 * k * k, k * k - 0.01 * k * k)],
-                                chunk, devices=1, streams_per_device=2)
+                                chunk, devices=1, streams_per_device=int(os.environ.get("MAGICKHIP_BENCH_C4_STREAMS", "2")))
         workload = ("batch of %d independent %dx%d RGBA Q16 images, sRGB->Lab + ContrastStretch 2%%x1%%, "
                     "sharded over the ranks, MagickHipBatchImages per rank (BASELINE configs[3])" % (batch, k, k))
         return step, float(batch) * k * k, workload, "strong", None
