@@ -121,7 +121,10 @@ class Image:
 
 
 class _Kernel:
-    def __init__(self, kernel):
+    def __init__(self, kernel, scale=None):
+        """`scale`: None, or (factor, flags) for ScaleKernelInfo — ("!" normalise = flag 1,
+        "^" correlate-normalise = flag 2): what `-define convolve:scale=...` does to the kernel
+        MorphologyImage is about to use (morphology.c:4144-4160)."""
         lib = _lib.load()
         self.owned = isinstance(kernel, (str, bytes))
         if self.owned:
@@ -129,6 +132,8 @@ class _Kernel:
             self.ptr = lib.MhAcquireKernelInfo(text)
             if not self.ptr:
                 raise MagickHipError(3, lib.MhGetLastError().decode())
+            if scale is not None:
+                lib.MhScaleKernelInfo(self.ptr, float(scale[0]), int(scale[1]))
         else:
             self.ptr = kernel
 
@@ -225,11 +230,12 @@ def convolve_image(image, kernel):
     return out
 
 
-def morphology_image(image, method, iterations, kernel, bias=0.0):
-    """MorphologyImage(image, method, iterations, kernel) — MagickCore/morphology.c:4129."""
+def morphology_image(image, method, iterations, kernel, bias=0.0, scale=None):
+    """MorphologyImage(image, method, iterations, kernel) — MagickCore/morphology.c:4129.
+    scale=(1.0, 1) is `-define convolve:scale='!'` (the kernel normalised before use)."""
     lib = _lib.load()
     out = image.like()
-    with _Kernel(kernel) as k:
+    with _Kernel(kernel, scale) as k:
         _lib.check(lib.MagickHipMorphologyImage(ctypes.byref(image.descriptor()),
                                                 ctypes.byref(out.descriptor()),
                                                 MORPHOLOGY[method.lower()], iterations, k, bias))

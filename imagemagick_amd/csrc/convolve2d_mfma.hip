@@ -1,0 +1,273 @@
+// Non-separable 2-D ConvolveMorphology on the f16 matrix cores (FAST, Q16, 8-byte pixels).
+//
+// Reference: the reflected-kernel loops of MorphologyPrimitive, MagickCore/morphology.c:2925-2979
+// (a w x h weighted sum per channel, alpha-weighted for Blend channels, NaN cells skipped) with
+// the epilogue :3195-3198.  SURVEY section 8d asks for C5's `ConvolveMorphology Disk:15` as the
+// MAC-bound variant: 16384^2 x 4 channels x 709 active cells.
+//
+// Formulation: one kernel ROW is a 1-D horizontal convolution, i.e. the banded (Toeplitz) product
+// of convolve_mfma.hip / convolve_fused.hip; the h rows accumulate into the same f32 tile:
+//     D[e][n] += sum_k  data_v[e][k] * T_v[k][n],    T_v[k][n] = 256 * tap[v][k-n]
+// for v = 0..h-1, where entry e = 4*row + channel pairs output row r with source row r+v.
+// Operands are hi/lo-split f16 with three products per term (mfma_common.hpp); the scale
+// factors and the epilogue are those of the 1-D passes.
+//
+// MI355X mapping.  A workgroup (8 waves) owns 64 output columns x 32 output rows:
+//   * the (32+h-1) x (64+w-1) source window is staged ONCE in LDS as alpha-premultiplied hi/lo
+//     f16 planes [channel][row][column] — 119 KB for 31 x 31; the stride comes from the same
+//     bank-conflict search as the fused blur's planes;
+//   * wave = one quad of output rows (entries e = 4*row+channel: D hands a lane the four
+//     channels of one pixel, so the division by the alpha sum is lane-local and the result
+//     leaves as one 8-byte store) x the four 16-column tiles of the strip.  The Toeplitz operand
+//     of a (kernel row, 32-sample chunk) is the same for every tile: it is read once per wave
+//     and used for 4 tiles; the data blocks of tile t chunk c and tile t+2 chunk c-1 are the
+//     same 16 x 32 samples: six loads feed eight products;
+//   * the Toeplitz operands cannot live in registers (31 rows x 16 VGPRs), and a lane's eight
+//     taps tap[v][32c+8kq+i-n] start at an address that depends on n: the table is kept in LDS
+//     in four copies shifted by 0..3 taps, which makes every lane's window 8-byte aligned
+//     (two ds_read_b64); 40 KB for 31 x 31.
+// 24 MFMAs per kernel row and wave against 12 + 8 LDS reads: the matrix pipe is the bound
+// (16384^2, 31 x 31: 5.1 ms of v_mfma_f32_16x16x32_f16 at 100 %).
+#include "mh_internal.hpp"
+#include "device_common.hpp"
+#include "mfma_common.hpp"
+#include <vector>
+#include <cmath>
+#include <cstdlib>
+
+namespace mh {
+
+struct Conv2DArgs
+{
+  const uint16_t *src;
+  uint16_t *dst;
+  int columns,rows;
+  int kw,kh;                  // kernel size
+  int shiftx,shifty;          // output (x,y) reads source (x-shiftx+u, y-shifty+v)
+  const float *taps;          // float[kh][kw], already in the walk order of the sums (reflected)
+  int stage_rows;             // 32+kh-1
+  int stride,plane;           // LDS row stride and channel-plane size of the staged window (halves)
+  int strips,groups,items_per_xcd;
+};
+
+constexpr int kC2Rows=32;     // output rows per workgroup
+constexpr int kC2Cols=64;     // output columns per workgroup
+
+template<int NC>
+struct Conv2DGeometry
+{
+  static constexpr int TL=32*NC+16;              // entries of one (shift, kernel row) of the tap table
+  static constexpr int XS=16*3+32*(NC-1)+32;     // staged columns: the last tile's last chunk ends here
+  static constexpr int BLOCKS=4+2*(NC-1);        // distinct 16 x 32 data blocks per kernel row
+};
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+template<int NC,int MODE>
+__global__ __launch_bounds__(512)
+void conv2d_mfma_kernel(Conv2DArgs args)
+{
+  static_assert((MODE == MFMA_BLEND4) || (MODE == MFMA_PLAIN4),"8-byte pixels");
+  typedef Conv2DGeometry<NC> G;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int SR=args.stride,CH=args.plane;
+  _Float16 *stage_hi=reinterpret_cast<_Float16 *>(smem_raw);
+  _Float16 *stage_lo=stage_hi+4*CH;
+  _Float16 *taps_hi=stage_lo+4*CH;               // [4 shifts][kh][TL]
+  _Float16 *taps_lo=taps_hi+4*args.kh*G::TL;
+  const int tid=(int) threadIdx.x,lane=tid & 63;
+  const int wave=__builtin_amdgcn_readfirstlane(tid >> 6);
+  const int W=args.columns,H=args.rows;
+  const int items=args.strips*args.groups;
+  const int item=((int) blockIdx.x & 7)*args.items_per_xcd+((int) blockIdx.x >> 3);
+  if (item >= items)
+    return;
+  const int group=item/args.strips,strip=item-group*args.strips;
+  const int x0=kC2Cols*strip,y0=kC2Rows*group;
+  const int xin0=x0-args.shiftx,yin0=y0-args.shifty;
+
+  // ---- tap tables: copy b holds T[v][m] = 256*tap[v][m-16-b], zero outside the kernel row
+  {
+    const int total=4*args.kh*G::TL;
+    for (int idx=tid; idx < total; idx+=512)
+      {
+        const int b=idx/(args.kh*G::TL),rem=idx-b*args.kh*G::TL;
+        const int v=rem/G::TL,m=rem-v*G::TL;
+        const int t=m-16-b;
+        const float value=((t >= 0) && (t < args.kw)) ? 256.0f*args.taps[v*args.kw+t] : 0.0f;
+        _Float16 h,l;
+        split_f16(value,h,l);
+        taps_hi[idx]=h;
+        taps_lo[idx]=l;
+      }
+  }
+  // ---- the source window, edge-clamped (cache.c:2663-2679), four pixels per thread and step
+  {
+    constexpr int QUADS=G::XS/4;
+    const int total=args.stage_rows*QUADS;
+    for (int idx=tid; idx < total; idx+=512)
+      {
+        const int row=idx/QUADS,quad=idx-row*QUADS;
+        int y=yin0+row;
+        y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
+        uint2 raw[4];
+#pragma unroll
+        for (int i=0; i < 4; i++)
+          {
+            int x=xin0+4*quad+i;
+            x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
+            raw[i]=*reinterpret_cast<const uint2 *>(args.src+pixel_index(y,W,x)*4);
+          }
+        f32x2 v[4][2];
+        quantum_to_samples<MODE>(raw,v);
+#pragma unroll
+        for (int c=0; c < 4; c++)
+          {
+            uint2 hi,lo;
+            split_f16_pair(v[c][0],hi.x,lo.x);
+            split_f16_pair(v[c][1],hi.y,lo.y);
+            const int at=c*CH+row*SR+4*quad;
+            *reinterpret_cast<uint2 *>(stage_hi+at)=hi;
+            *reinterpret_cast<uint2 *>(stage_lo+at)=lo;
+          }
+      }
+  }
+  __syncthreads();
+
+  // ---- wave = row quad `wave`, tiles 0..3; lane (e, kq): entry e = 4*row+channel
+  const int e=lane & 15,kq=lane >> 4;
+  const int a_base=(e & 3)*CH+(4*wave+(e >> 2))*SR+8*kq;
+  // Toeplitz window of lane (n = e, kq): taps 32c+8kq+i-n = T_b[32c + 8kq - 4a + 16 + i], n = 4a+b
+  const int t_base=(e & 3)*args.kh*G::TL+8*kq-4*(e >> 2)+16;
+  floatx4 acc[4];
+#pragma unroll
+  for (int t=0; t < 4; t++)
+    acc[t]=floatx4{0.0f,0.0f,0.0f,0.0f};
+  for (int v=0; v < args.kh; v++)
+    {
+      half8 b_hi[NC],b_lo[NC];
+#pragma unroll
+      for (int c=0; c < NC; c++)
+        {
+          const int at=t_base+v*G::TL+32*c;
+          const half4 h0=*reinterpret_cast<const half4 *>(taps_hi+at);
+          const half4 h1=*reinterpret_cast<const half4 *>(taps_hi+at+4);
+          const half4 l0=*reinterpret_cast<const half4 *>(taps_lo+at);
+          const half4 l1=*reinterpret_cast<const half4 *>(taps_lo+at+4);
+          b_hi[c]=half8{h0[0],h0[1],h0[2],h0[3],h1[0],h1[1],h1[2],h1[3]};
+          b_lo[c]=half8{l0[0],l0[1],l0[2],l0[3],l1[0],l1[1],l1[2],l1[3]};
+        }
+      half8 a_hi[G::BLOCKS],a_lo[G::BLOCKS];
+      const int row_at=a_base+v*SR;
+#pragma unroll
+      for (int q=0; q < G::BLOCKS; q++)
+        {
+          a_hi[q]=*reinterpret_cast<const half8 *>(stage_hi+row_at+16*q);
+          a_lo[q]=*reinterpret_cast<const half8 *>(stage_lo+row_at+16*q);
+        }
+#pragma unroll
+      for (int c=0; c < NC; c++)
+#pragma unroll
+        for (int t=0; t < 4; t++)
+          {
+            const int q=t+2*c;                     // tile t, chunk c: columns 16t+32c
+            acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[q],b_hi[c],acc[t],0,0,0);
+            acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[q],b_hi[c],acc[t],0,0,0);
+            acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[q],b_lo[c],acc[t],0,0,0);
+          }
+    }
+  // ---- D: lane (n, kq) holds the four channels of pixel (row 4*wave+kq, column 16t+n)
+  const int y=y0+4*wave+kq;
+  if (y < H)
+    {
+#pragma unroll
+      for (int t=0; t < 4; t++)
+        {
+          const int x=x0+16*t+e;
+          if (x < W)
+            *reinterpret_cast<uint2 *>(args.dst+pixel_index(y,W,x)*4)=
+              sums_to_quantum<MODE>(acc[t][0],acc[t][1],acc[t][2],acc[t][3]);
+        }
+    }
+}
+
+template<int NC,int MODE>
+static MhStatus launch_conv2d_typed(const View &src,Conv2DArgs &args,size_t lds)
+{
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2d_mfma_kernel<NC,MODE>),
+    hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+  ProfileScope prof("conv2d_mfma",src.stream);
+  hipLaunchKernelGGL((conv2d_mfma_kernel<NC,MODE>),dim3((unsigned) (8*args.items_per_xcd)),dim3(512),lds,
+    src.stream,args);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+// w x h Convolve of an RGBA (alpha-weighted colour, alpha last) or four-plain-channel Q16 frame.
+// *handled stays false (nothing launched) when the kernel or the frame does not qualify.
+MhStatus launch_conv2d_mfma(const View &src,const View &dst,const MhKernelInfo *kernel,bool blend,
+  bool *handled)
+{
+  *handled=false;
+  if ((src.quantum != MH_QUANTUM_U16) || (dst.quantum != MH_QUANTUM_U16) || (src.channels != 4) ||
+      (dst.channels != 4) || (src.columns != dst.columns) || (src.rows != dst.rows))
+    return MH_OK;
+  if ((src.columns >= (1u << 24)) || (src.rows >= (1u << 24)) ||
+      ((unsigned long long) src.columns*src.rows >= (1ull << 32)))
+    return MH_OK;                                // pixel_index()
+  const int kw=(int) kernel->width,kh=(int) kernel->height;
+  // below 5 x 5 the generic kernel's 25 taps are cheaper than a staged window
+  if ((kw < 2) || (kh < 2) || (kw*kh < 25) || (kw > 49) || (kh > 64) || (kernel->x < 0) || (kernel->y < 0) ||
+      (kernel->x >= kw) || (kernel->y >= kh))
+    return MH_OK;
+  const int nc=(16+kw-1+31)/32;                  // 16 outputs + kw-1 halo, in 32-sample chunks
+  if (nc > 2)
+    return MH_OK;
+  // the reflected walk of morphology.c:2925: cell (v,u) carries values[(kh-1-v)*kw+(kw-1-u)]
+  std::vector<float> taps((size_t) kw*kh);
+  for (int v=0; v < kh; v++)
+    for (int u=0; u < kw; u++)
+      {
+        const double value=kernel->values[(size_t) (kh-1-v)*kw+(size_t) (kw-1-u)];
+        if (std::isnan(value))
+          taps[(size_t) v*kw+u]=0.0f;            // `if (!IsNaN(*k))`: the cell is skipped
+        else
+          {
+            // alpha-weighted sums with taps of both signs stay on the fp64 kernels (cancellation)
+            if (blend && (value < 0.0))
+              return MH_OK;
+            taps[(size_t) v*kw+u]=(float) value;
+          }
+      }
+  Conv2DArgs args;
+  args.src=static_cast<const uint16_t *>(src.pixels);
+  args.dst=static_cast<uint16_t *>(dst.pixels);
+  args.columns=(int) src.columns;
+  args.rows=(int) src.rows;
+  args.kw=kw;
+  args.kh=kh;
+  args.shiftx=kw-1-(int) kernel->x;
+  args.shifty=kh-1-(int) kernel->y;
+  args.stage_rows=kC2Rows+kh-1;
+  const int xs=nc == 1 ? Conv2DGeometry<1>::XS : Conv2DGeometry<2>::XS;
+  const int tl=nc == 1 ? Conv2DGeometry<1>::TL : Conv2DGeometry<2>::TL;
+  const int layout=fused16_layout(xs,args.stage_rows,false,false);
+  args.stride=layout/256;
+  args.plane=args.stage_rows*args.stride+layout % 256;
+  const size_t lds=((size_t) 2*4*args.plane+(size_t) 2*4*kh*tl)*sizeof(_Float16);
+  if (lds > 160u*1024u)
+    return MH_OK;
+  Temp table;
+  MH_TRY(upload_table(table,src.device,src.stream,taps.data(),taps.size()*sizeof(float)));
+  args.taps=table.as<float>();
+  args.strips=(args.columns+kC2Cols-1)/kC2Cols;
+  args.groups=(args.rows+kC2Rows-1)/kC2Rows;
+  args.items_per_xcd=(args.strips*args.groups+7)/8;
+  *handled=true;
+  if (nc == 1)
+    return blend ? launch_conv2d_typed<1,MFMA_BLEND4>(src,args,lds) : launch_conv2d_typed<1,MFMA_PLAIN4>(src,args,lds);
+  return blend ? launch_conv2d_typed<2,MFMA_BLEND4>(src,args,lds) : launch_conv2d_typed<2,MFMA_PLAIN4>(src,args,lds);
+}
+
+} // namespace mh

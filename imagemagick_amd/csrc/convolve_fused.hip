@@ -417,51 +417,7 @@ static MhStatus launch_fused_typed(const View &src,BlurFusedArgs &args)
 // With the column pass after the row pass of the same iteration (NR = NG) its store sat right in
 // front of the next iteration's wait for the staged loads — gfx9 has one counter for loads and
 // stores, so that wait also waited out the store's round trip: 0.50 ms against 0.xx ms.
-// Worst number of operand lines of one ds_read_b128 lane group (see fused_reads_conflict_free)
-// that share a 16-byte slot of the 256-byte bank row, for the 16x16x32 operand map: entry =
-// lane&15, k quarter = lane>>4.  ring: the k quarters 2,3 sit in the next ring group.
-static constexpr int fused16_read_degree(int S,int PAD,int units,bool channel_major,bool ring)
-{
-  const int CH=units*S+PAD;
-  int worst=1;
-  for (int g=0; g < 4; g++)
-    {
-      int count[16]={0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
-      for (int i=0; i < 16; i++)
-        {
-          const int base=(g & 1) == 0 ? (i < 4 ? i : (i < 8 ? i+8 : i+12)) : (i < 8 ? i+4 : (i < 12 ? i+8 : i+16));
-          const int lane=base+32*(g >> 1);
-          const int e=lane & 15,kq=lane >> 4;
-          const int channel=channel_major ? e >> 2 : e & 3;
-          const int unit=channel_major ? e & 3 : e >> 2;
-          const int offset=ring ? 16*(kq >> 1)+8*(kq & 1) : 8*kq;
-          const int bytes=(channel*CH+unit*S+offset)*2;
-          const int slot=(bytes % 256)/16;
-          count[slot]++;
-          worst=count[slot] > worst ? count[slot] : worst;
-        }
-    }
-  return worst;
-}
-
-// line stride (>= extent, multiple of 8 halves) and channel padding with the fewest read
-// conflicts; encoded S*256+PAD
-static constexpr int fused16_layout(int extent,int units,bool channel_major,bool ring)
-{
-  int best=extent*256+8,best_degree=99;
-  for (int S=extent; S <= extent+16; S+=8)
-    for (int PAD=8; PAD <= 64; PAD+=8)
-      {
-        const int degree=fused16_read_degree(S,PAD,units,channel_major,ring);
-        if (degree < best_degree)
-          {
-            best_degree=degree;
-            best=S*256+PAD;
-          }
-      }
-  return best;
-}
-
+// (fused16_read_degree / fused16_layout: mfma_common.hpp)
 template<int NC>
 struct Fused16Geometry
 {

@@ -194,6 +194,8 @@ MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const 
 // morphology.c:2746 (taps[v] multiplies the input at o-shift+v), as floats and as doubles
 // (the doubles feed the exact recomputation of ambiguous small alpha levels).
 // *handled=false when the shape is outside the kernel's reach and nothing was launched.
+MhStatus launch_conv2d_mfma(const View &src,const View &dst,const MhKernelInfo *kernel,bool blend,
+  bool *handled);
 MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_device,
   const double *taps64_device,int ntaps,int shift,bool blend,bool *handled,bool unsharp=false,
   double gain=0.0,double threshold=0.0);

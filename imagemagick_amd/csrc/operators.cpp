@@ -242,6 +242,18 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
       if (handled)
         return MH_OK;
     }
+  // FAST, Q16, RGBA (alpha-weighted, alpha last) or four plain channels, kernels of 5 x 5 and
+  // more: the w x h sum as h banded products on the matrix cores (convolve2d_mfma.hip)
+  if ((method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
+      (precision() == MH_PRECISION_FAST) && (src.quantum == MH_QUANTUM_U16) && (src.channels == 4) &&
+      (roles.copy_mask == 0) && (!roles.blend || (roles.alpha == 3)) &&
+      (getenv("MAGICKHIP_NO_MFMA") == nullptr) && (getenv("MAGICKHIP_NO_MFMA_2D") == nullptr))
+    {
+      bool handled=false;
+      MH_TRY(launch_conv2d_mfma(src,dst,kernel,roles.blend,&handled));
+      if (handled)
+        return MH_OK;
+    }
   Morph2DParams p;
   p.method=method;
   p.kernel=kernel;

@@ -325,16 +325,59 @@ def test_convolve_fast_signed_outer_product_kernel(im, refmod):
 
 
 def test_convolve_fast_non_separable_kernel_stays_exact(im, refmod):
-    """A kernel that is not an outer product takes the generic 2-D kernel in FAST mode too."""
+    """A kernel that is not an outer product and is too small (or has taps of both signs under
+    alpha weighting) for the matrix-core 2-D kernel takes the generic fp64 kernel in FAST mode
+    too: bit-identical.  Disk:2.5 (5 x 5) is the smallest the matrix-core kernel takes: +-1."""
     px = make_pixels(60, 71, 4, Q16, seed=2)
     dev, ref = run_pair(im, refmod, px)
     im.set_precision(im.PRECISION_FAST)
     try:
-        for kernel in ("Disk:2.5", "3x3: 0,1,0 1,-3,1 0,1,1", "Gaussian:0x1.2"):
+        for kernel in ("Disk:2.5", "3x3: 0,1,0 1,-3,1 0,1,1", "Gaussian:0x1.2",
+                       "5x5: 1,1,1,1,1 1,1,1,1,1 1,1,-9,1,1 1,1,1,1,1 1,1,1,1,1"):
             got = im.convolve_image(dev, kernel).numpy()
-            assert_parity(got, ref.convolve(kernel).numpy(), kernel != "Gaussian:0x1.2", "fast convolve %s" % kernel)
+            exact = kernel not in ("Gaussian:0x1.2", "Disk:2.5")
+            assert_parity(got, ref.convolve(kernel).numpy(), exact, "fast convolve %s" % kernel)
     finally:
         im.set_precision(im.PRECISION_EXACT)
+
+
+@pytest.mark.parametrize("alpha", [True, False])
+@pytest.mark.parametrize("kernel", ["Disk:15", "Disk:7.3", "Octagon:5", "Diamond:4", "Plus:3",
+                                    "7x5: 1,2,3,4,3,2,1 2,4,6,8,6,4,2 3,6,9,13,9,6,2 2,4,6,8,6,4,2 1,2,3,4,3,2,1",
+                                    "6x6+1+4: 1,0,2,nan,1,3 0,1,1,2,nan,1 2,2,0,1,1,1 nan,1,3,1,0,2 1,1,1,1,2,0 3,0,1,2,1,1",
+                                    "Ring:10,14"])
+def test_convolve_2d_fast_on_matrix_cores(im, refmod, kernel, alpha, monkeypatch):
+    """FAST ConvolveMorphology with a non-separable kernel of 5 x 5 cells or more (RGBA with
+    alpha-weighted colour, or four plain channels): the w x h sum as h banded products on the
+    matrix cores (convolve2d_mfma.hip) — flat disks, weighted and asymmetric user kernels, NaN
+    cells, origins off centre, frames ragged against the 64 x 32 tiles; the kernel normalised as
+    `-define convolve:scale='!'` does.  Within one level of the reference, and of the generic
+    kernel it replaces."""
+    import bench
+    px = make_pixels(75, 150, 4, Q16, seed=len(kernel))
+    if alpha:
+        px[10:30, 20:60, 3] = np.random.default_rng(3).integers(0, 4, (20, 40))       # tiny alpha
+        px[40:50, 100:140, 3] = 0                                                         # transparent
+    dev = im.Image(to_device(px), has_alpha=alpha)
+    ref = refmod.RefImage(px) if alpha else None
+    holder = {}
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        launched = set(bench.kernel_profile(
+            im, lambda: holder.update(out=im.morphology_image(dev, "Convolve", 1, kernel, scale=(1.0, 1))), 1))
+        monkeypatch.setenv("MAGICKHIP_NO_MFMA_2D", "1")
+        generic = im.morphology_image(dev, "Convolve", 1, kernel, scale=(1.0, 1)).numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert launched == {"conv2d_mfma"}, launched
+    got = holder["out"].numpy()
+    if alpha:
+        want = ref.set_artifact("convolve:scale", "!").morphology("Convolve", 1, kernel).numpy()
+    else:
+        want = np.concatenate([refmod.RefImage(px[:, :, c].copy()).set_artifact("convolve:scale", "!")
+                               .morphology("Convolve", 1, kernel).numpy().reshape(75, 150, 1) for c in range(4)], axis=2)
+    assert_parity(got, want, False, "2-D convolve %s alpha=%s" % (kernel, alpha))
+    assert_parity(generic, want, False, "generic 2-D convolve %s" % kernel)
 
 
 @pytest.mark.parametrize("shape", [(64, 80), (33, 71), (2, 2), (70, 2), (1, 40), (129, 17)])
