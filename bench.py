@@ -214,6 +214,10 @@ def cpu_baseline_configs():
         r = ref.RefImage(px).morphology("Dilate", 1, "Disk:15")
         out["c5_dilate_disk15"] = entry(float(d) * d, r.last_seconds, "%dx%d RGBA Q16 Dilate Disk:15" % (d, d))
         del r
+        r = ref.RefImage(px).set_artifact("convolve:scale", "!").morphology("Convolve", 1, "Disk:15")
+        out["c5_convolve_disk15"] = entry(float(d) * d, r.last_seconds,
+                                          "%dx%d RGBA Q16 Convolve Disk:15, convolve:scale='!'" % (d, d))
+        del r
         u = 4096
         px = rng.integers(0, 65536, (u, u, 4), dtype=np.uint16)
         r = ref.RefImage(px).unsharp(0.0, 10.0, 1.0, 0.02)
@@ -347,6 +351,22 @@ def c5_config(im, torch, gen):
         "Mpixels_per_s": round(k * k / sec / 1e6, 1), "ms": round(sec * 1e3, 3),
         "kernels": kernel_rooflines(prof, {"morph_rects": 2.0 * frame, "morph_convex": 2.0 * frame,
                                            "morph2d": 2.0 * frame}, "c5:")}
+    holder.clear()
+
+    def convolve():
+        holder["o"] = im.morphology_image(img5, "Convolve", 1, "Disk:15", scale=(1.0, 1))
+    sec = timed(torch, convolve, 2)
+    prof = kernel_profile(im, convolve, 2)
+    macs = float(k) * k * 4.0 * 709.0
+    out["c5_convolve_disk15"] = {
+        "workload": "16384x16384 RGBA Q16 MorphologyImage(Convolve, Disk:15) with convolve:scale='!' — the MAC-bound "
+                    "variant of BASELINE configs[4] (SURVEY 8d): 709 active cells per channel and pixel",
+        "Mpixels_per_s": round(k * k / sec / 1e6, 1), "ms": round(sec * 1e3, 3),
+        "kernels": kernel_rooflines(prof, {"conv2d_mfma": 2.0 * frame, "morph2d": 2.0 * frame}, "c5:"),
+        "alu": {"bound": "mfma", "unit": "TFLOP/s", "peak": 2500.0,
+                "achieved": round(2.0 * macs / sec / 1e12, 1), "frac": round(2.0 * macs / sec / 1e12 / 2500.0, 4),
+                "note": "algorithmic multiply-adds only; the banded matrix-core form executes 3 x 31 x 64 / 709 = 8.4x "
+                        "as many (hi/lo operand split, band and kernel-row padding)"}}
     holder.clear()
 
     def unsharp():

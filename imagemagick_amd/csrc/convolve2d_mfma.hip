@@ -27,7 +27,8 @@
 //     in four copies shifted by 0..3 taps, which makes every lane's window 8-byte aligned
 //     (two ds_read_b64); 40 KB for 31 x 31.
 // 24 MFMAs per kernel row and wave against 12 + 8 LDS reads: the matrix pipe is the bound
-// (16384^2, 31 x 31: 5.1 ms of v_mfma_f32_16x16x32_f16 at 100 %).
+// (16384^2, 31 x 31: 5.4 ms of v_mfma_f32_16x16x32_f16 at 100 %; measured 9.7 ms against 127 ms
+// for the generic 2-D kernel, tools/time_convolve2d.py).
 #include "mh_internal.hpp"
 #include "device_common.hpp"
 #include "mfma_common.hpp"
@@ -44,7 +45,7 @@ struct Conv2DArgs
   int columns,rows;
   int kw,kh;                  // kernel size
   int shiftx,shifty;          // output (x,y) reads source (x-shiftx+u, y-shifty+v)
-  const float *taps;          // float[kh][kw], already in the walk order of the sums (reflected)
+  const float *taps;          // float[4][kh][TL]: the four shifted Toeplitz tables, 256*tap, reflected walk
   int stage_rows;             // 32+kh-1
   int stride,plane;           // LDS row stride and channel-plane size of the staged window (halves)
   int strips,groups,items_per_xcd;
@@ -88,48 +89,61 @@ void conv2d_mfma_kernel(Conv2DArgs args)
   const int xin0=x0-args.shiftx,yin0=y0-args.shifty;
 
   // ---- tap tables: copy b holds T[v][m] = 256*tap[v][m-16-b], zero outside the kernel row
+  // (laid out by the host: args.taps is float[4][kh][TL])
   {
     const int total=4*args.kh*G::TL;
     for (int idx=tid; idx < total; idx+=512)
       {
-        const int b=idx/(args.kh*G::TL),rem=idx-b*args.kh*G::TL;
-        const int v=rem/G::TL,m=rem-v*G::TL;
-        const int t=m-16-b;
-        const float value=((t >= 0) && (t < args.kw)) ? 256.0f*args.taps[v*args.kw+t] : 0.0f;
         _Float16 h,l;
-        split_f16(value,h,l);
+        split_f16(args.taps[idx],h,l);
         taps_hi[idx]=h;
         taps_lo[idx]=l;
       }
   }
-  // ---- the source window, edge-clamped (cache.c:2663-2679), four pixels per thread and step
+  // ---- the source window, edge-clamped (cache.c:2663-2679), four pixels per thread and item;
+  // every load of the thread is in flight before the first conversion
   {
     constexpr int QUADS=G::XS/4;
+    constexpr int ITEMS=4;                       // (32+63) rows x 28 quads / 512 threads < 6: two rounds at most
     const int total=args.stage_rows*QUADS;
-    for (int idx=tid; idx < total; idx+=512)
+    for (int i0=tid; i0 < total; i0+=512*ITEMS)
       {
-        const int row=idx/QUADS,quad=idx-row*QUADS;
-        int y=yin0+row;
-        y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
-        uint2 raw[4];
+        uint2 raw[ITEMS][4];
 #pragma unroll
-        for (int i=0; i < 4; i++)
+        for (int k=0; k < ITEMS; k++)
           {
-            int x=xin0+4*quad+i;
-            x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
-            raw[i]=*reinterpret_cast<const uint2 *>(args.src+pixel_index(y,W,x)*4);
+            int idx=i0+512*k;
+            idx=idx < total ? idx : total-1;
+            const int row=idx/QUADS,quad=idx-row*QUADS;
+            int y=yin0+row;
+            y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
+#pragma unroll
+            for (int i=0; i < 4; i++)
+              {
+                int x=xin0+4*quad+i;
+                x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
+                raw[k][i]=*reinterpret_cast<const uint2 *>(args.src+pixel_index(y,W,x)*4);
+              }
           }
-        f32x2 v[4][2];
-        quantum_to_samples<MODE>(raw,v);
 #pragma unroll
-        for (int c=0; c < 4; c++)
+        for (int k=0; k < ITEMS; k++)
           {
-            uint2 hi,lo;
-            split_f16_pair(v[c][0],hi.x,lo.x);
-            split_f16_pair(v[c][1],hi.y,lo.y);
-            const int at=c*CH+row*SR+4*quad;
-            *reinterpret_cast<uint2 *>(stage_hi+at)=hi;
-            *reinterpret_cast<uint2 *>(stage_lo+at)=lo;
+            const int idx=i0+512*k;
+            if (idx >= total)
+              continue;
+            const int row=idx/QUADS,quad=idx-row*QUADS;
+            f32x2 v[4][2];
+            quantum_to_samples<MODE>(raw[k],v);
+#pragma unroll
+            for (int c=0; c < 4; c++)
+              {
+                uint2 hi,lo;
+                split_f16_pair(v[c][0],hi.x,lo.x);
+                split_f16_pair(v[c][1],hi.y,lo.y);
+                const int at=c*CH+row*SR+4*quad;
+                *reinterpret_cast<uint2 *>(stage_hi+at)=hi;
+                *reinterpret_cast<uint2 *>(stage_lo+at)=lo;
+              }
           }
       }
   }
@@ -144,38 +158,66 @@ void conv2d_mfma_kernel(Conv2DArgs args)
 #pragma unroll
   for (int t=0; t < 4; t++)
     acc[t]=floatx4{0.0f,0.0f,0.0f,0.0f};
-  for (int v=0; v < args.kh; v++)
+  // The operands of kernel row v+1 are read while the 24 products of row v run (two register
+  // sets, the loop unrolled by two), so that the LDS latency of a row's 20 reads does not sit in
+  // front of its first product.  (Measured neutral at two waves per SIMD — 9.7 ms either way for
+  // Disk:15 on 16384^2, 55 % of the matrix pipe at nominal clock: what is left is the staging of
+  // the next window, which one workgroup per CU cannot overlap with its products.)
+  struct Operands
+  {
+    half8 b_hi[NC],b_lo[NC];
+    half8 a_hi[G::BLOCKS],a_lo[G::BLOCKS];
+  };
+  auto fetch=[&](Operands &o,int v)
+  {
+#pragma unroll
+    for (int c=0; c < NC; c++)
+      {
+        const int at=t_base+v*G::TL+32*c;
+        const half4 h0=*reinterpret_cast<const half4 *>(taps_hi+at);
+        const half4 h1=*reinterpret_cast<const half4 *>(taps_hi+at+4);
+        const half4 l0=*reinterpret_cast<const half4 *>(taps_lo+at);
+        const half4 l1=*reinterpret_cast<const half4 *>(taps_lo+at+4);
+        o.b_hi[c]=half8{h0[0],h0[1],h0[2],h0[3],h1[0],h1[1],h1[2],h1[3]};
+        o.b_lo[c]=half8{l0[0],l0[1],l0[2],l0[3],l1[0],l1[1],l1[2],l1[3]};
+      }
+    const int row_at=a_base+v*SR;
+#pragma unroll
+    for (int q=0; q < G::BLOCKS; q++)
+      {
+        o.a_hi[q]=*reinterpret_cast<const half8 *>(stage_hi+row_at+16*q);
+        o.a_lo[q]=*reinterpret_cast<const half8 *>(stage_lo+row_at+16*q);
+      }
+  };
+  auto multiply=[&](const Operands &o)
+  {
+#pragma unroll
+    for (int c=0; c < NC; c++)
+#pragma unroll
+      for (int t=0; t < 4; t++)
+        {
+          const int q=t+2*c;                       // tile t, chunk c: columns 16t+32c
+          acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(o.a_hi[q],o.b_hi[c],acc[t],0,0,0);
+          acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(o.a_lo[q],o.b_hi[c],acc[t],0,0,0);
+          acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(o.a_hi[q],o.b_lo[c],acc[t],0,0,0);
+        }
+  };
+  Operands even,odd;
+  fetch(even,0);
+  for (int v=0; v < args.kh; v+=2)
     {
-      half8 b_hi[NC],b_lo[NC];
-#pragma unroll
-      for (int c=0; c < NC; c++)
-        {
-          const int at=t_base+v*G::TL+32*c;
-          const half4 h0=*reinterpret_cast<const half4 *>(taps_hi+at);
-          const half4 h1=*reinterpret_cast<const half4 *>(taps_hi+at+4);
-          const half4 l0=*reinterpret_cast<const half4 *>(taps_lo+at);
-          const half4 l1=*reinterpret_cast<const half4 *>(taps_lo+at+4);
-          b_hi[c]=half8{h0[0],h0[1],h0[2],h0[3],h1[0],h1[1],h1[2],h1[3]};
-          b_lo[c]=half8{l0[0],l0[1],l0[2],l0[3],l1[0],l1[1],l1[2],l1[3]};
-        }
-      half8 a_hi[G::BLOCKS],a_lo[G::BLOCKS];
-      const int row_at=a_base+v*SR;
-#pragma unroll
-      for (int q=0; q < G::BLOCKS; q++)
-        {
-          a_hi[q]=*reinterpret_cast<const half8 *>(stage_hi+row_at+16*q);
-          a_lo[q]=*reinterpret_cast<const half8 *>(stage_lo+row_at+16*q);
-        }
-#pragma unroll
-      for (int c=0; c < NC; c++)
-#pragma unroll
-        for (int t=0; t < 4; t++)
-          {
-            const int q=t+2*c;                     // tile t, chunk c: columns 16t+32c
-            acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[q],b_hi[c],acc[t],0,0,0);
-            acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[q],b_hi[c],acc[t],0,0,0);
-            acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[q],b_lo[c],acc[t],0,0,0);
-          }
+      const int next=v+1 < args.kh ? v+1 : v;       // (a harmless re-read at the tail)
+      fetch(odd,next);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(even);
+      __builtin_amdgcn_sched_barrier(0);
+      if (v+1 >= args.kh)
+        break;
+      const int after=v+2 < args.kh ? v+2 : v+1;
+      fetch(even,after);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(odd);
+      __builtin_amdgcn_sched_barrier(0);
     }
   // ---- D: lane (n, kq) holds the four channels of pixel (row 4*wave+kq, column 16t+n)
   const int y=y0+4*wave+kq;
@@ -258,8 +300,18 @@ MhStatus launch_conv2d_mfma(const View &src,const View &dst,const MhKernelInfo *
   const size_t lds=((size_t) 2*4*args.plane+(size_t) 2*4*kh*tl)*sizeof(_Float16);
   if (lds > 160u*1024u)
     return MH_OK;
+  // copy b of the table: T[v][m] = 256*tap[v][m-16-b] (conv2d_mfma_kernel)
+  std::vector<float> shifted((size_t) 4*kh*tl,0.0f);
+  for (int b=0; b < 4; b++)
+    for (int v=0; v < kh; v++)
+      for (int m=0; m < tl; m++)
+        {
+          const int t=m-16-b;
+          if ((t >= 0) && (t < kw))
+            shifted[((size_t) b*kh+(size_t) v)*tl+(size_t) m]=256.0f*taps[(size_t) v*kw+t];
+        }
   Temp table;
-  MH_TRY(upload_table(table,src.device,src.stream,taps.data(),taps.size()*sizeof(float)));
+  MH_TRY(upload_table(table,src.device,src.stream,shifted.data(),shifted.size()*sizeof(float)));
   args.taps=table.as<float>();
   args.strips=(args.columns+kC2Cols-1)/kC2Cols;
   args.groups=(args.rows+kC2Rows-1)/kC2Rows;

@@ -30,7 +30,7 @@ LABELS = [
     (r"lab_histogram_fast", "colorspace_histogram"), (r"colorspace_", "colorspace"),
     (r"histogram_packed_reduce", "colorspace_histogram"), (r"histogram_", "histogram"), (r"apply_lut", "apply_lut"),
     (r"lut_", "build_lut"), (r"gray_", "gray_check"),
-    (r"morph_rects", "morph_rects"), (r"morph_convex", "morph_convex"), (r"morph2d", "morph2d"), (r"unsharp_kernel", "unsharp_epilogue"),
+    (r"conv2d_mfma", "conv2d_mfma"), (r"morph_rects", "morph_rects"), (r"morph_convex", "morph_convex"), (r"morph2d", "morph2d"), (r"unsharp_kernel", "unsharp_epilogue"),
 ]
 PREFIX = {"fast": "", "exact": "exact:", "resize": "", "c4": "c4:", "c5": "c5:"}
 

@@ -49,6 +49,13 @@ if "c5" in which:
     print("C5 Dilate Disk:15 %d^2: %.3f ms  %.1f Mpixels/s  kernels(ms): %s" % (
         n, sec * 1e3, n * n / sec / 1e6, {k: round(v["avg_ms"], 3) for k, v in prof.items()}))
 
+    def convolve():
+        hold["o"] = im.morphology_image(img, "Convolve", 1, "Disk:15", scale=(1.0, 1))
+    sec = timed(torch, convolve, 2)
+    prof = kernel_profile(im, convolve, 2)
+    print("C5 Convolve Disk:15 %d^2: %.3f ms  %.1f Mpixels/s  kernels(ms): %s" % (
+        n, sec * 1e3, n * n / sec / 1e6, {k: round(v["avg_ms"], 3) for k, v in prof.items()}))
+
     def unsharp():
         hold["o"] = im.unsharp_mask_image(img, 0.0, 10.0, 1.0, 0.02)
     sec = timed(torch, unsharp, 2)

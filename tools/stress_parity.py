@@ -59,7 +59,7 @@ while time.time() - t0 < budget:
         rows, cols = int(rng.integers(1, 40)), int(rng.integers(300, 1400))
     kind = int(rng.integers(0, 5))
     px = pixels(rows, cols, kind)
-    op = int(rng.integers(0, 6))
+    op = int(rng.integers(0, 7))
     detail = "%dx%d kind %d" % (rows, cols, kind)
     ref = refmod.RefImage(px)
     if op == 0:                                    # FAST blur, every kernel length of the fused launch
@@ -106,6 +106,16 @@ while time.time() - t0 < budget:
             got = im.equalize_image(dev(px2)).numpy()
             want = refmod.RefImage(px2).equalize().numpy()
         failures += check("histogram op", got, want, 0, "%dx%d" % (rows2, cols2))
+    elif op == 5:                                  # FAST 2-D convolve on the matrix cores
+        family = ["Disk:%.1f" % rng.uniform(2.0, 15.9), "Octagon:%d" % rng.integers(2, 12),
+                  "Diamond:%d" % rng.integers(2, 14), "Plus:%d" % rng.integers(2, 14),
+                  "Ring:%d,%d" % (rng.integers(2, 6), rng.integers(7, 15))]
+        kernel = family[int(rng.integers(0, len(family)))]
+        im.set_precision(im.PRECISION_FAST)
+        got = im.morphology_image(dev(px), "Convolve", 1, kernel, scale=(1.0, 1)).numpy()
+        im.set_precision(im.PRECISION_EXACT)
+        want = ref.set_artifact("convolve:scale", "!").morphology("Convolve", 1, kernel).numpy()
+        failures += check("fast convolve 2-D", got, want, 1, detail + " " + kernel)
     else:                                          # FAST Lab
         im.set_precision(im.PRECISION_FAST)
         d2 = dev(px)
