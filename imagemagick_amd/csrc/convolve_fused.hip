@@ -37,6 +37,9 @@
 #include "device_common.hpp"
 #include "mfma_common.hpp"
 #include <cstdlib>
+#include <cstdio>
+#include <string>
+#include <vector>
 
 namespace mh {
 
@@ -56,7 +59,25 @@ struct BlurFusedArgs
   int items_per_xcd;         // ceil(strips*segments/8)
   float gain;                // UnsharpMaskImage's epilogue (blur_fused16_kernel<.., UNSHARP>)
   int threshold;             // ceil(QuantumRange*threshold), see unsharp_sample
+  unsigned long long *trace; // diagnostic build (-DMH_FUSED_TRACE) only
 };
+
+// Diagnostic build only (-DMH_FUSED_TRACE, tools/trace_fused_blur.py): waves 0, 4, 8 and 12 of
+// the first four workgroups stamp the shader clock at the phase boundaries of 48 steady-state
+// iterations: trace[block][wave>>2][iteration][mark].
+#ifdef MH_FUSED_TRACE
+#define MH_FTRACE_MARK(id) \
+  do { \
+    if (traced && (g >= 64) && (g < 112)) \
+      { \
+        const unsigned long long now=__builtin_readcyclecounter(); \
+        if (lane == 0) \
+          args.trace[((((int) blockIdx.x*4+(wave >> 2))*48)+(g-64))*10+(id)]=now; \
+      } \
+  } while (0)
+#else
+#define MH_FTRACE_MARK(id) do { } while (0)
+#endif
 
 // ds_read_b128 is served in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32)
 // over 64 banks (MI355X_MICROARCH.md, LDS): the 16 operand lines of a group must hit 16
@@ -494,6 +515,9 @@ void blur_fused16_kernel(BlurFusedArgs args)
   const int in0=out_begin-args.shift;
   const int xin0=x0-args.shift;
   const int ngroups=nblocks+G::NG-1;
+#ifdef MH_FUSED_TRACE
+  const bool traced=(args.trace != nullptr) && (blockIdx.x < 4) && ((wave & 3) == 0);
+#endif
 
   // ---- Toeplitz operands: T[c][i] = 256*tap[32c+8*kq+i-n]
   half8 t_hi[NC],t_lo[NC];
@@ -557,14 +581,24 @@ void blur_fused16_kernel(BlurFusedArgs args)
   {
     if (stager)
       {
+#ifdef MH_FUSED_PACKED
         f32x2 v[4][2];
         quantum_to_samples<SAMPLES>(raw,v);
+#else
+        float v[4][4];                           // scalar f32: packed f32 does not issue beside MFMAs
+        quantum_to_samples_scalar<SAMPLES>(raw,v);
+#endif
 #pragma unroll
         for (int c=0; c < 4; c++)
           {
             uint2 hi,lo;
+#ifdef MH_FUSED_PACKED
             split_f16_pair(v[c][0],hi.x,lo.x);
             split_f16_pair(v[c][1],hi.y,lo.y);
+#else
+            split_f16_pair_scalar(v[c][0],v[c][1],hi.x,lo.x);
+            split_f16_pair_scalar(v[c][2],v[c][3],hi.y,lo.y);
+#endif
             const int at=c*G::CHR+srow*G::SR+4*sxg;
             *reinterpret_cast<uint2 *>(stage_hi+at)=hi;
             *reinterpret_cast<uint2 *>(stage_lo+at)=lo;
@@ -595,12 +629,22 @@ void blur_fused16_kernel(BlurFusedArgs args)
   for (int g=0; g <= ngroups; g++)
     {
       uint2 unblurred=original;
+      MH_FTRACE_MARK(0);
       if (g < ngroups)
         {
+#ifdef MH_FUSED_TRACE
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          MH_FTRACE_MARK(1);
+#endif
           stage();
+#ifdef MH_FUSED_TRACE
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          MH_FTRACE_MARK(2);
+#endif
           if (g+1 < ngroups)
             fetch(g+1);
         }
+      MH_FTRACE_MARK(3);
       if constexpr (UNSHARP)
         fetch_original(g+1-G::NG);
       if (g >= G::NG)
@@ -629,16 +673,22 @@ void blur_fused16_kernel(BlurFusedArgs args)
               acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_lo[c],acc,0,0,0);
             }
           // lane (n, kq): the four channels (registers) of pixel (column 4*wave+kq, row n)
+#ifdef MH_FUSED_PACKED
           uint2 result=sums_to_quantum<SAMPLES>(acc[0],acc[1],acc[2],acc[3]);
+#else
+          uint2 result=sums_to_quantum_scalar<SAMPLES>(acc[0],acc[1],acc[2],acc[3]);
+#endif
           if constexpr (UNSHARP)
             result=unsharp_pixel(unblurred,result,args.gain,args.threshold);
           const int x=x0+4*wave+kq,y=out_begin+G::GROUP*block+n;
           if ((x < W) && (y < H))
             store_pixel16(args.dst+pixel_index(y,W,x)*PX,result);
         }
+      MH_FTRACE_MARK(4);
       if (g == ngroups)
         break;
       __syncthreads();                           // X: staged; every wave is past the column pass
+      MH_FTRACE_MARK(5);
       // ---- row pass of ring group g
       {
         half8 a_hi[NC],a_lo[NC];
@@ -656,8 +706,13 @@ void blur_fused16_kernel(BlurFusedArgs args)
             acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[c],t_hi[c],acc,0,0,0);
             acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_lo[c],acc,0,0,0);
           }
+#ifdef MH_FUSED_TRACE
+        asm volatile("s_nop 0" :: "v"(acc[0]),"v"(acc[3]));      // the chain has completed
+        MH_FTRACE_MARK(6);
+#endif
         // lane (n, kq): channel kq of the pixels (x0+16*ot+n, rows 4*rq+r), r = register
         constexpr float unit=1.0f/(128.0f*65535.0f);
+#ifdef MH_FUSED_PACKED
         f32x2 v[2];                              // the column pass's samples, pairs of rows
         if constexpr (MODE == MFMA_BLEND4)
           {
@@ -715,11 +770,75 @@ void blur_fused16_kernel(BlurFusedArgs args)
         uint2 hi,lo;
         split_f16_pair(v[0],hi.x,lo.x);
         split_f16_pair(v[1],hi.y,lo.y);
+#else
+        // (scalar f32 throughout: a packed-f32 instruction waits for the SIMD's matrix pipe)
+        float v[4];                              // the column pass's samples, four consecutive rows
+        if constexpr (MODE == MFMA_BLEND4)
+          {
+            // the alpha sums of this column live in lanes 48..63
+            float sa[4],alpha[4],colour[4];
+#pragma unroll
+            for (int r=0; r < 4; r++)
+              sa[r]=__shfl(acc[r],48+n,64);
+            // Quantum-rounded colour = 65536*S_c/S_a and alpha = S_a/128 (sums_to_quantum); an alpha
+            // lane computes a meaningless (but finite: NaN -> 0) "colour" and drops it below
+            float p[4],l[4];
+#pragma unroll
+            for (int r=0; r < 4; r++)
+              {
+                p[r]=acc[r]*(__builtin_amdgcn_rcpf(sa[r])*(65536.0f/65535.0f));
+                l[r]=sa[r]*unit;
+              }
+            const pknorm2 q01=__builtin_amdgcn_cvt_pknorm_u16(p[0],p[1]);
+            const pknorm2 q23=__builtin_amdgcn_cvt_pknorm_u16(p[2],p[3]);
+            const pknorm2 a01=__builtin_amdgcn_cvt_pknorm_u16(l[0],l[1]);
+            const pknorm2 a23=__builtin_amdgcn_cvt_pknorm_u16(l[2],l[3]);
+            alpha[0]=(float) a01[0]; alpha[1]=(float) a01[1]; alpha[2]=(float) a23[0]; alpha[3]=(float) a23[1];
+            colour[0]=(float) q01[0]; colour[1]=(float) q01[1]; colour[2]=(float) q23[0]; colour[3]=(float) q23[1];
+            // the row pass's alpha becomes a weight: exact where it is small and the f32 sum
+            // cannot decide the level (mfma_common.hpp); the four lanes of a pixel agree.  One
+            // comparison per lane unless the column holds small alpha.
+            const float smallest=__builtin_fminf(__builtin_fminf(sa[0],sa[1]),__builtin_fminf(sa[2],sa[3]));
+            if (smallest < kSmallAlpha*128.0f)
+              {
+#pragma unroll
+                for (int r=0; r < 4; r++)
+                  if (alpha_sum_is_ambiguous(sa[r]))
+                    {
+                      const int x=x0+16*ot+n;
+                      int y=in0+G::GROUP*g+4*rq+r;
+                      y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
+                      if (x < W)
+                        alpha[r]=(float) exact_alpha_level(args.src,pixel_index(y,W,0),1,W,x-args.shift,args.taps64,K);
+                    }
+              }
+            // sample = alpha*colour*2^-17 (colour lanes) or alpha/2 (alpha lanes): alpha*(colour*c1+c2)
+            const float c1=kq == 3 ? 0.0f : 0.5f/65536.0f,c2=kq == 3 ? 0.5f : 0.0f;
+#pragma unroll
+            for (int r=0; r < 4; r++)
+              v[r]=alpha[r]*__builtin_fmaf(colour[r],c1,c2);
+          }
+        else
+          {
+            const pknorm2 q01=__builtin_amdgcn_cvt_pknorm_u16(acc[0]*unit,acc[1]*unit);
+            const pknorm2 q23=__builtin_amdgcn_cvt_pknorm_u16(acc[2]*unit,acc[3]*unit);
+            v[0]=(float) q01[0]*0.5f; v[1]=(float) q01[1]*0.5f;
+            v[2]=(float) q23[0]*0.5f; v[3]=(float) q23[1]*0.5f;
+          }
+        uint2 hi,lo;
+        split_f16_pair_scalar(v[0],v[1],hi.x,lo.x);
+        split_f16_pair_scalar(v[2],v[3],hi.y,lo.y);
+#endif
         const int at=ring_entry+ring_group*G::GROUP;
         *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
         *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
       }
+#ifdef MH_FUSED_TRACE
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      MH_FTRACE_MARK(7);
+#endif
       __syncthreads();                           // Y: ring group g complete, staging reads done
+      MH_FTRACE_MARK(8);
       ring_group=ring_group+1 == G::NR ? 0 : ring_group+1;
     }
 }
@@ -745,10 +864,35 @@ static MhStatus launch_fused16_typed(const View &src,BlurFusedArgs &args)
   const size_t lds=G::lds_bytes;
   MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&blur_fused16_kernel<NC,MODE,UNSHARP>),
     hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
-  ProfileScope prof(UNSHARP ? "unsharp_fused" : "blur_fused",src.stream);
-  hipLaunchKernelGGL((blur_fused16_kernel<NC,MODE,UNSHARP>),dim3((unsigned) (8*args.items_per_xcd)),dim3(1024),lds,
-    src.stream,args);
-  MH_HIP(hipGetLastError());
+#ifdef MH_FUSED_TRACE
+  const char *trace_path=getenv("MAGICKHIP_FUSED_TRACE");
+  const size_t trace_bytes=4u*4u*48u*10u*sizeof(unsigned long long);
+  if (trace_path != nullptr)
+    {
+      MH_HIP(hipMalloc(reinterpret_cast<void **>(&args.trace),trace_bytes));
+      MH_HIP(hipMemsetAsync(args.trace,0,trace_bytes,src.stream));
+    }
+#endif
+  {
+    ProfileScope prof(UNSHARP ? "unsharp_fused" : "blur_fused",src.stream);
+    hipLaunchKernelGGL((blur_fused16_kernel<NC,MODE,UNSHARP>),dim3((unsigned) (8*args.items_per_xcd)),dim3(1024),lds,
+      src.stream,args);
+    MH_HIP(hipGetLastError());
+  }
+#ifdef MH_FUSED_TRACE
+  if (args.trace != nullptr)
+    {
+      std::vector<unsigned long long> host(trace_bytes/sizeof(unsigned long long));
+      MH_HIP(hipMemcpyAsync(host.data(),args.trace,trace_bytes,hipMemcpyDeviceToHost,src.stream));
+      MH_HIP(hipStreamSynchronize(src.stream));
+      MH_HIP(hipFree(args.trace));
+      if (FILE *f=fopen(trace_path,"wb"))
+        {
+          fwrite(host.data(),1,trace_bytes,f);
+          fclose(f);
+        }
+    }
+#endif
   return MH_OK;
 }
 
@@ -783,6 +927,7 @@ MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_dev
   if (nq > 7)
     return MH_OK;
   BlurFusedArgs args;
+  args.trace=nullptr;
   args.src=static_cast<const uint16_t *>(src.pixels);
   args.dst=static_cast<uint16_t *>(dst.pixels);
   args.columns=(int) src.columns;
