@@ -448,7 +448,12 @@ struct Fused16Geometry
   static constexpr int NR=NG+1;                // ring groups held
   static constexpr int RC=GROUP*NR;            // ring rows
   static constexpr int XS=32*NC+48;            // staged columns: 64 outputs + band
-  static constexpr int SR=fused16_layout(XS,GROUP,true,false)/256,PADR=fused16_layout(XS,GROUP,true,false) % 256;
+#ifdef MH_FUSED_BPERMUTE
+  static constexpr bool ROW_CHANNEL_MAJOR=true;   // row pass entries e = 4*channel + row
+#else
+  static constexpr bool ROW_CHANNEL_MAJOR=false;  // row pass entries e = 4*row + channel
+#endif
+  static constexpr int SR=fused16_layout(XS,GROUP,ROW_CHANNEL_MAJOR,false)/256,PADR=fused16_layout(XS,GROUP,ROW_CHANNEL_MAJOR,false) % 256;
   static constexpr int SC=fused16_layout(RC,COLS,false,true)/256,PADC=fused16_layout(RC,COLS,false,true) % 256;
   static constexpr int CHR=GROUP*SR+PADR;
   static constexpr int CHC=COLS*SC+PADC;
@@ -565,6 +570,19 @@ void blur_fused16_kernel(BlurFusedArgs args)
             raw[2]=make_uint2(b.y,c.x & 0xffffu);
             raw[3]=make_uint2((c.x >> 16) | (c.y << 16),c.y >> 16);
           }
+#ifndef MH_FUSED_NARROW_FETCH
+        else if ((MODE != MFMA_PLAIN3) && (xs >= 0) && (xs+3 <= W-1))
+          {
+            // four 8-byte pixels = 32 contiguous bytes: two 16-byte loads, one address
+            const uint4 *at=reinterpret_cast<const uint4 *>(args.src+pixel_index(y,W,xs)*4);
+            typedef uint4 __attribute__((aligned(8))) LooseQuad;
+            const uint4 a=*reinterpret_cast<const LooseQuad *>(at),b=*reinterpret_cast<const LooseQuad *>(at+1);
+            raw[0]=make_uint2(a.x,a.y);
+            raw[1]=make_uint2(a.z,a.w);
+            raw[2]=make_uint2(b.x,b.y);
+            raw[3]=make_uint2(b.z,b.w);
+          }
+#endif
         else
           {
 #pragma unroll
@@ -581,24 +599,14 @@ void blur_fused16_kernel(BlurFusedArgs args)
   {
     if (stager)
       {
-#ifdef MH_FUSED_PACKED
         f32x2 v[4][2];
         quantum_to_samples<SAMPLES>(raw,v);
-#else
-        float v[4][4];                           // scalar f32: packed f32 does not issue beside MFMAs
-        quantum_to_samples_scalar<SAMPLES>(raw,v);
-#endif
 #pragma unroll
         for (int c=0; c < 4; c++)
           {
             uint2 hi,lo;
-#ifdef MH_FUSED_PACKED
             split_f16_pair(v[c][0],hi.x,lo.x);
             split_f16_pair(v[c][1],hi.y,lo.y);
-#else
-            split_f16_pair_scalar(v[c][0],v[c][1],hi.x,lo.x);
-            split_f16_pair_scalar(v[c][2],v[c][3],hi.y,lo.y);
-#endif
             const int at=c*G::CHR+srow*G::SR+4*sxg;
             *reinterpret_cast<uint2 *>(stage_hi+at)=hi;
             *reinterpret_cast<uint2 *>(stage_lo+at)=lo;
@@ -608,7 +616,13 @@ void blur_fused16_kernel(BlurFusedArgs args)
 
   // row pass: wave = row quad (4 rows) x output tile (16 columns); entry e = 4*channel+row
   const int rq=wave & 3,ot=wave >> 2;
+#ifdef MH_FUSED_BPERMUTE
   const int row_entry=(n >> 2)*G::CHR+(4*rq+(n & 3))*G::SR+16*ot+8*kq;
+#else
+  // entries e = 4*row + channel: D then hands a lane the four channels of ONE pixel, so the
+  // division by the alpha sum is lane-local (as in the column pass)
+  const int row_entry=(n & 3)*G::CHR+(4*rq+(n >> 2))*G::SR+16*ot+8*kq;
+#endif
   // column pass: wave = column quad; entry e = 4*column+channel; a 32-row chunk spans two ring
   // groups: k 0..15 (kq 0,1) in the first, k 16..31 (kq 2,3) in the next
   const int col_entry=(n & 3)*G::CHC+(4*wave+(n >> 2))*G::SC+8*(kq & 1);
@@ -651,9 +665,10 @@ void blur_fused16_kernel(BlurFusedArgs args)
         {
           // ---- column pass of output rows out_begin+16*block .. +16
           const int block=g-G::NG;
-          half8 a_hi[NC],a_lo[NC];
           // block mod NR = (g+1) mod NR (NR = NG+1): the oldest group the ring still holds
           const int first=ring_group+1 == G::NR ? 0 : ring_group+1;
+          floatx4 acc={0.0f,0.0f,0.0f,0.0f};
+          half8 a_hi[NC],a_lo[NC];
 #pragma unroll
           for (int c=0; c < NC; c++)
             {
@@ -664,7 +679,9 @@ void blur_fused16_kernel(BlurFusedArgs args)
               a_hi[c]=*reinterpret_cast<const half8 *>(ring_hi+at);
               a_lo[c]=*reinterpret_cast<const half8 *>(ring_lo+at);
             }
-          floatx4 acc={0.0f,0.0f,0.0f,0.0f};
+#ifdef MH_FUSED_PRIO
+          __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
           for (int c=0; c < NC; c++)
             {
@@ -672,12 +689,11 @@ void blur_fused16_kernel(BlurFusedArgs args)
               acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[c],t_hi[c],acc,0,0,0);
               acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_lo[c],acc,0,0,0);
             }
-          // lane (n, kq): the four channels (registers) of pixel (column 4*wave+kq, row n)
-#ifdef MH_FUSED_PACKED
-          uint2 result=sums_to_quantum<SAMPLES>(acc[0],acc[1],acc[2],acc[3]);
-#else
-          uint2 result=sums_to_quantum_scalar<SAMPLES>(acc[0],acc[1],acc[2],acc[3]);
+#ifdef MH_FUSED_PRIO
+          __builtin_amdgcn_s_setprio(0);
 #endif
+          // lane (n, kq): the four channels (registers) of pixel (column 4*wave+kq, row n)
+          uint2 result=sums_to_quantum<SAMPLES>(acc[0],acc[1],acc[2],acc[3]);
           if constexpr (UNSHARP)
             result=unsharp_pixel(unblurred,result,args.gain,args.threshold);
           const int x=x0+4*wave+kq,y=out_begin+G::GROUP*block+n;
@@ -699,6 +715,9 @@ void blur_fused16_kernel(BlurFusedArgs args)
             a_lo[c]=*reinterpret_cast<const half8 *>(stage_lo+row_entry+32*c);
           }
         floatx4 acc={0.0f,0.0f,0.0f,0.0f};
+#ifdef MH_FUSED_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int c=0; c < NC; c++)
           {
@@ -706,13 +725,63 @@ void blur_fused16_kernel(BlurFusedArgs args)
             acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[c],t_hi[c],acc,0,0,0);
             acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_lo[c],acc,0,0,0);
           }
+#ifdef MH_FUSED_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef MH_FUSED_TRACE
         asm volatile("s_nop 0" :: "v"(acc[0]),"v"(acc[3]));      // the chain has completed
         MH_FTRACE_MARK(6);
 #endif
+#ifndef MH_FUSED_BPERMUTE
+        // lane (n, kq): the four channels (registers) of pixel (column x0+16*ot+n, row 4*rq+kq).
+        // Quantum-rounded colour = 65536*S_c/S_a and alpha = S_a/128 (sums_to_quantum); the
+        // column pass's samples: alpha*colour*2^-17 and alpha/2 (plain: level/2).
+        float v[4];
+        {
+          const uint2 q=sums_to_quantum<SAMPLES>(acc[0],acc[1],acc[2],acc[3]);
+          const f32x2 c01={(float) (q.x & 0xffffu),(float) (q.x >> 16)};
+          const f32x2 c23={(float) (q.y & 0xffffu),(float) (q.y >> 16)};
+          if constexpr (MODE == MFMA_BLEND4)
+            {
+              // the row pass's alpha becomes a weight: exact where it is small and the f32 sum
+              // cannot decide the level (mfma_common.hpp)
+              float alpha=c23[1];
+              if ((acc[3] < kSmallAlpha*128.0f) && alpha_sum_is_ambiguous(acc[3]))
+                {
+                  const int x=x0+16*ot+n;
+                  int y=in0+G::GROUP*g+4*rq+kq;
+                  y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
+                  if (x < W)
+                    alpha=(float) exact_alpha_level(args.src,pixel_index(y,W,0),1,W,x-args.shift,args.taps64,K);
+                }
+              const float weight=alpha*(0.5f/65536.0f);
+              const f32x2 v01=c01*f32x2{weight,weight};
+              v[0]=v01[0]; v[1]=v01[1];
+              v[2]=c23[0]*weight;
+              v[3]=alpha*0.5f;
+            }
+          else
+            {
+              const f32x2 v01=c01*0.5f,v23=c23*0.5f;
+              v[0]=v01[0]; v[1]=v01[1]; v[2]=v23[0]; v[3]=v23[1];
+            }
+        }
+        // 4x4 transpose between the registers (channels) and the four 16-lane rows (pixel rows):
+        // v_permlane32_swap on (0,2),(1,3), v_permlane16_swap on (0,1),(2,3).  Afterwards lane
+        // (n, kq) holds channel kq of rows 4*rq+0..3 — four consecutive rows for one 8-byte ring
+        // store per plane.
+        // (inline asm: hipcc of ROCm 7.2 loses the second result of a v_permlane16_swap builtin
+        // that follows a v_permlane32_swap builtin; s_nop 1 = the two wait states a swap needs
+        // after a VALU write of its operands)
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
+                     "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"
+                     : "+v"(v[0]),"+v"(v[1]),"+v"(v[2]),"+v"(v[3]));
+        uint2 hi,lo;
+        split_f16_pair(f32x2{v[0],v[1]},hi.x,lo.x);
+        split_f16_pair(f32x2{v[2],v[3]},hi.y,lo.y);
+#else
         // lane (n, kq): channel kq of the pixels (x0+16*ot+n, rows 4*rq+r), r = register
         constexpr float unit=1.0f/(128.0f*65535.0f);
-#ifdef MH_FUSED_PACKED
         f32x2 v[2];                              // the column pass's samples, pairs of rows
         if constexpr (MODE == MFMA_BLEND4)
           {
@@ -770,64 +839,6 @@ void blur_fused16_kernel(BlurFusedArgs args)
         uint2 hi,lo;
         split_f16_pair(v[0],hi.x,lo.x);
         split_f16_pair(v[1],hi.y,lo.y);
-#else
-        // (scalar f32 throughout: a packed-f32 instruction waits for the SIMD's matrix pipe)
-        float v[4];                              // the column pass's samples, four consecutive rows
-        if constexpr (MODE == MFMA_BLEND4)
-          {
-            // the alpha sums of this column live in lanes 48..63
-            float sa[4],alpha[4],colour[4];
-#pragma unroll
-            for (int r=0; r < 4; r++)
-              sa[r]=__shfl(acc[r],48+n,64);
-            // Quantum-rounded colour = 65536*S_c/S_a and alpha = S_a/128 (sums_to_quantum); an alpha
-            // lane computes a meaningless (but finite: NaN -> 0) "colour" and drops it below
-            float p[4],l[4];
-#pragma unroll
-            for (int r=0; r < 4; r++)
-              {
-                p[r]=acc[r]*(__builtin_amdgcn_rcpf(sa[r])*(65536.0f/65535.0f));
-                l[r]=sa[r]*unit;
-              }
-            const pknorm2 q01=__builtin_amdgcn_cvt_pknorm_u16(p[0],p[1]);
-            const pknorm2 q23=__builtin_amdgcn_cvt_pknorm_u16(p[2],p[3]);
-            const pknorm2 a01=__builtin_amdgcn_cvt_pknorm_u16(l[0],l[1]);
-            const pknorm2 a23=__builtin_amdgcn_cvt_pknorm_u16(l[2],l[3]);
-            alpha[0]=(float) a01[0]; alpha[1]=(float) a01[1]; alpha[2]=(float) a23[0]; alpha[3]=(float) a23[1];
-            colour[0]=(float) q01[0]; colour[1]=(float) q01[1]; colour[2]=(float) q23[0]; colour[3]=(float) q23[1];
-            // the row pass's alpha becomes a weight: exact where it is small and the f32 sum
-            // cannot decide the level (mfma_common.hpp); the four lanes of a pixel agree.  One
-            // comparison per lane unless the column holds small alpha.
-            const float smallest=__builtin_fminf(__builtin_fminf(sa[0],sa[1]),__builtin_fminf(sa[2],sa[3]));
-            if (smallest < kSmallAlpha*128.0f)
-              {
-#pragma unroll
-                for (int r=0; r < 4; r++)
-                  if (alpha_sum_is_ambiguous(sa[r]))
-                    {
-                      const int x=x0+16*ot+n;
-                      int y=in0+G::GROUP*g+4*rq+r;
-                      y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
-                      if (x < W)
-                        alpha[r]=(float) exact_alpha_level(args.src,pixel_index(y,W,0),1,W,x-args.shift,args.taps64,K);
-                    }
-              }
-            // sample = alpha*colour*2^-17 (colour lanes) or alpha/2 (alpha lanes): alpha*(colour*c1+c2)
-            const float c1=kq == 3 ? 0.0f : 0.5f/65536.0f,c2=kq == 3 ? 0.5f : 0.0f;
-#pragma unroll
-            for (int r=0; r < 4; r++)
-              v[r]=alpha[r]*__builtin_fmaf(colour[r],c1,c2);
-          }
-        else
-          {
-            const pknorm2 q01=__builtin_amdgcn_cvt_pknorm_u16(acc[0]*unit,acc[1]*unit);
-            const pknorm2 q23=__builtin_amdgcn_cvt_pknorm_u16(acc[2]*unit,acc[3]*unit);
-            v[0]=(float) q01[0]*0.5f; v[1]=(float) q01[1]*0.5f;
-            v[2]=(float) q23[0]*0.5f; v[3]=(float) q23[1]*0.5f;
-          }
-        uint2 hi,lo;
-        split_f16_pair_scalar(v[0],v[1],hi.x,lo.x);
-        split_f16_pair_scalar(v[2],v[3],hi.y,lo.y);
 #endif
         const int at=ring_entry+ring_group*G::GROUP;
         *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
