@@ -65,6 +65,15 @@ struct BlurFusedArgs
 // Diagnostic build only (-DMH_FUSED_TRACE, tools/trace_fused_blur.py): waves 0, 4, 8 and 12 of
 // the first four workgroups stamp the shader clock at the phase boundaries of 48 steady-state
 // iterations: trace[block][wave>>2][iteration][mark].
+// Diagnostic builds only (-DMH_FUSED_KNOCK=bits, tools/gpu_knock.sh): parts of the iteration are
+// skipped at run time (behind a test the compiler cannot fold) to see what each costs.  The
+// results are wrong.  1 result stores, 2 source fetches after the first, 4 staging conversion,
+// 8 column pass, 16 row pass MFMAs, 32 row epilogue arithmetic, 64 the whole row pass
+#ifdef MH_FUSED_KNOCK
+#define MH_KNOCKED(bit) ((((MH_FUSED_KNOCK) & (bit)) != 0) && (args.threshold == 0))
+#else
+#define MH_KNOCKED(bit) false
+#endif
 #ifdef MH_FUSED_TRACE
 #define MH_FTRACE_MARK(id) \
   do { \
@@ -458,7 +467,15 @@ struct Fused16Geometry
   static constexpr int CHR=GROUP*SR+PADR;
   static constexpr int CHC=COLS*SC+PADC;
   static constexpr int STAGE_PLANE=4*CHR,RING_PLANE=4*CHC;
-  static constexpr size_t lds_bytes=(size_t) 2*(STAGE_PLANE+RING_PLANE)*sizeof(_Float16);
+  static constexpr size_t planes_bytes=(size_t) 2*(STAGE_PLANE+RING_PLANE)*sizeof(_Float16);
+  // the column pass's 16 x 64 result pixels on their way to row-contiguous stores; 65 pixels per
+  // row: the 16 rows a quarter-wave writes fall into 16 different bank pairs
+  static constexpr int OUT_STRIDE=COLS+1;
+#ifdef MH_FUSED_DIRECT_STORE
+  static constexpr size_t lds_bytes=planes_bytes;
+#else
+  static constexpr size_t lds_bytes=planes_bytes+(size_t) GROUP*OUT_STRIDE*sizeof(uint2);
+#endif
   static_assert(lds_bytes <= 163840,"more than the 160 KiB of a CU");
   static constexpr int GROUPS_PER_ROW=XS/4;
   static constexpr int FETCH_GROUPS=GROUP*GROUPS_PER_ROW;
@@ -500,6 +517,9 @@ void blur_fused16_kernel(BlurFusedArgs args)
   _Float16 *ring_lo=ring_hi+G::RING_PLANE;
   _Float16 *stage_hi=ring_lo+G::RING_PLANE;
   _Float16 *stage_lo=stage_hi+G::STAGE_PLANE;
+#ifndef MH_FUSED_DIRECT_STORE
+  uint2 *out_tile=reinterpret_cast<uint2 *>(smem_raw+G::planes_bytes);
+#endif
   const int tid=(int) threadIdx.x,lane=tid & 63;
   const int wave=__builtin_amdgcn_readfirstlane(tid >> 6);
   const int n=lane & 15,kq=lane >> 4;
@@ -625,24 +645,72 @@ void blur_fused16_kernel(BlurFusedArgs args)
 #endif
   // column pass: wave = column quad; entry e = 4*column+channel; a 32-row chunk spans two ring
   // groups: k 0..15 (kq 0,1) in the first, k 16..31 (kq 2,3) in the next
-  const int col_entry=(n & 3)*G::CHC+(4*wave+(n >> 2))*G::SC+8*(kq & 1);
+#ifdef MH_FUSED_COLUMN_PER_WAVE
+  constexpr int CT=1;                          // column tiles a wave may own
+  const int ctile0=wave,ctiles=1;
+#else
+  // The staging waves (tid < FETCH_GROUPS: 9 of 16 for 79 taps) convert and stage; the column
+  // pass's sixteen tiles (four columns each) belong to the OTHER waves, two or three apiece.  A
+  // staging wave's chain per iteration is then wait - convert - stage - fetch and a tile wave's
+  // two or three short multiplies, side by side on every SIMD (wave w runs on SIMD w & 3: each
+  // SIMD holds two or three staging waves and one or two tile waves).  Before, every wave owned
+  // one tile and the staging waves started theirs after staging: the others waited for them.
+  static_assert((G::FETCH_GROUPS % 64) == 0,"whole staging waves");
+  constexpr int TILE_WAVES=16-G::FETCH_GROUPS/64;
+  constexpr int CT=(16+TILE_WAVES-1)/TILE_WAVES;
+  const int tile_wave=wave-(16-TILE_WAVES);    // < 0: a staging wave
+  const int ctiles=tile_wave < 0 ? 0 : 16/TILE_WAVES+(tile_wave < 16 % TILE_WAVES ? 1 : 0);
+  const int ctile0=tile_wave < 0 ? 0 : tile_wave*(16/TILE_WAVES)+(tile_wave < 16 % TILE_WAVES ? tile_wave : 16 % TILE_WAVES);
+#endif
+  const int col_entry=(n & 3)*G::CHC+(4*ctile0+(n >> 2))*G::SC+8*(kq & 1);
   const int ring_entry=kq*G::CHC+(16*ot+n)*G::SC+4*rq;     // the row pass's ring store
   int ring_group=0;                            // g mod NR (wave-uniform)
+#ifdef MH_FUSED_DIRECT_STORE
   // UNSHARP: the unblurred pixel of the lane's column-pass output (effect.c:4364-4369), fetched
   // one iteration ahead, behind the staging loads, so that the wait the staging does anyway
   // covers it (the strip's rows left the CU 32*NC rows ago: an L2 / MALL hit)
+  uint2 original[CT];
+#pragma unroll
+  for (int t=0; t < CT; t++)
+    original[t]=make_uint2(0u,0u);
+  auto fetch_original=[&](int block)
+  {
+#pragma unroll
+    for (int t=0; t < CT; t++)
+      {
+        const int x=x0+4*(ctile0+t)+kq,y=out_begin+G::GROUP*block+n;
+        if ((t < ctiles) && (block >= 0) && (block < nblocks) && (x < W) && (y < H))
+          original[t]=load_pixel16(args.src+pixel_index(y,W,x)*PX);
+      }
+  };
+#else
+  // The column pass leaves its 16 x 64 pixels in out_tile; after barrier X wave w stores row w:
+  // 64 lanes x 8 bytes = one contiguous 512-byte segment (the tiles' own lanes hold 16 ROWS of
+  // 4 pixels each: 64 separate 8-byte writes per store instruction, 1024 partial-line write
+  // requests per iteration and CU, and the memory pipe's queue backed up into the staging waves'
+  // fetches).  UNSHARP: the unblurred pixel (effect.c:4364-4369) of that lane, fetched at the
+  // top of the iteration (the strip's rows left the CU 32*NC rows ago: an L2 / MALL hit).
   uint2 original=make_uint2(0u,0u);
   auto fetch_original=[&](int block)
   {
-    const int x=x0+4*wave+kq,y=out_begin+G::GROUP*block+n;
+    const int x=x0+lane,y=out_begin+G::GROUP*block+wave;
     if ((block >= 0) && (block < nblocks) && (x < W) && (y < H))
       original=load_pixel16(args.src+pixel_index(y,W,x)*PX);
   };
+#endif
 
   fetch(0);
   for (int g=0; g <= ngroups; g++)
     {
-      uint2 unblurred=original;
+#ifdef MH_FUSED_DIRECT_STORE
+      uint2 unblurred[CT];
+#pragma unroll
+      for (int t=0; t < CT; t++)
+        unblurred[t]=original[t];
+#else
+      if constexpr (UNSHARP)
+        fetch_original(g-G::NG);
+#endif
       MH_FTRACE_MARK(0);
       if (g < ngroups)
         {
@@ -650,62 +718,90 @@ void blur_fused16_kernel(BlurFusedArgs args)
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           MH_FTRACE_MARK(1);
 #endif
-          stage();
+          if (!(MH_KNOCKED(4) && (g > 1)))
+            stage();
 #ifdef MH_FUSED_TRACE
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           MH_FTRACE_MARK(2);
 #endif
-          if (g+1 < ngroups)
+          if ((g+1 < ngroups) && !(MH_KNOCKED(2) && (g > 1)))
             fetch(g+1);
         }
       MH_FTRACE_MARK(3);
+#ifdef MH_FUSED_DIRECT_STORE
       if constexpr (UNSHARP)
         fetch_original(g+1-G::NG);
-      if (g >= G::NG)
+#endif
+      if ((g >= G::NG) && !MH_KNOCKED(8))
         {
           // ---- column pass of output rows out_begin+16*block .. +16
           const int block=g-G::NG;
           // block mod NR = (g+1) mod NR (NR = NG+1): the oldest group the ring still holds
           const int first=ring_group+1 == G::NR ? 0 : ring_group+1;
-          floatx4 acc={0.0f,0.0f,0.0f,0.0f};
-          half8 a_hi[NC],a_lo[NC];
+          // the ring group of chunk c for this lane: (first + 2c + (kq>>1)) mod NR for a value
+          // below 2*NR: min with the wrapped difference
+          int chunk_at[NC];
 #pragma unroll
           for (int c=0; c < NC; c++)
             {
-              // (first + 2c + (kq>>1)) mod NR for a value below 2*NR: min with the wrapped difference
               const unsigned wide=(unsigned) (first+2*c+(kq >> 1));
               const unsigned group=wide < wide-(unsigned) G::NR ? wide : wide-(unsigned) G::NR;
-              const int at=col_entry+G::GROUP*(int) group;
-              a_hi[c]=*reinterpret_cast<const half8 *>(ring_hi+at);
-              a_lo[c]=*reinterpret_cast<const half8 *>(ring_lo+at);
+              chunk_at[c]=col_entry+G::GROUP*(int) group;
             }
-#ifdef MH_FUSED_PRIO
-          __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
-          for (int c=0; c < NC; c++)
-            {
-              acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_hi[c],acc,0,0,0);
-              acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[c],t_hi[c],acc,0,0,0);
-              acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_lo[c],acc,0,0,0);
-            }
-#ifdef MH_FUSED_PRIO
-          __builtin_amdgcn_s_setprio(0);
+          for (int t=0; t < CT; t++)
+            if (t < ctiles)
+              {
+                floatx4 acc={0.0f,0.0f,0.0f,0.0f};
+                half8 a_hi[NC],a_lo[NC];
+#pragma unroll
+                for (int c=0; c < NC; c++)
+                  {
+                    a_hi[c]=*reinterpret_cast<const half8 *>(ring_hi+chunk_at[c]+4*t*G::SC);
+                    a_lo[c]=*reinterpret_cast<const half8 *>(ring_lo+chunk_at[c]+4*t*G::SC);
+                  }
+#pragma unroll
+                for (int c=0; c < NC; c++)
+                  {
+                    acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_hi[c],acc,0,0,0);
+                    acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[c],t_hi[c],acc,0,0,0);
+                    acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_lo[c],acc,0,0,0);
+                  }
+                // lane (n, kq): the four channels (registers) of pixel (column 4*tile+kq, row n)
+                uint2 result=sums_to_quantum<SAMPLES>(acc[0],acc[1],acc[2],acc[3]);
+#ifdef MH_FUSED_DIRECT_STORE
+                if constexpr (UNSHARP)
+                  result=unsharp_pixel(unblurred[t],result,args.gain,args.threshold);
+                const int x=x0+4*(ctile0+t)+kq,y=out_begin+G::GROUP*block+n;
+                if ((x < W) && (y < H))
+                  store_pixel16(args.dst+pixel_index(y,W,x)*PX,result);
+#else
+                out_tile[n*G::OUT_STRIDE+4*(ctile0+t)+kq]=result;
 #endif
-          // lane (n, kq): the four channels (registers) of pixel (column 4*wave+kq, row n)
-          uint2 result=sums_to_quantum<SAMPLES>(acc[0],acc[1],acc[2],acc[3]);
-          if constexpr (UNSHARP)
-            result=unsharp_pixel(unblurred,result,args.gain,args.threshold);
-          const int x=x0+4*wave+kq,y=out_begin+G::GROUP*block+n;
-          if ((x < W) && (y < H))
-            store_pixel16(args.dst+pixel_index(y,W,x)*PX,result);
+              }
         }
       MH_FTRACE_MARK(4);
+#ifdef MH_FUSED_DIRECT_STORE
       if (g == ngroups)
         break;
       __syncthreads();                           // X: staged; every wave is past the column pass
+#else
+      __syncthreads();                           // X: staged; the column pass's pixels are in out_tile
+      if (g >= G::NG)
+        {
+          uint2 result=out_tile[wave*G::OUT_STRIDE+lane];
+          if constexpr (UNSHARP)
+            result=unsharp_pixel(original,result,args.gain,args.threshold);
+          const int x=x0+lane,y=out_begin+G::GROUP*(g-G::NG)+wave;
+          if ((x < W) && (y < H) && !MH_KNOCKED(1))
+            store_pixel16(args.dst+pixel_index(y,W,x)*PX,result);
+        }
+      if (g == ngroups)
+        break;
+#endif
       MH_FTRACE_MARK(5);
       // ---- row pass of ring group g
+      if (!MH_KNOCKED(64))
       {
         half8 a_hi[NC],a_lo[NC];
 #pragma unroll
@@ -715,9 +811,10 @@ void blur_fused16_kernel(BlurFusedArgs args)
             a_lo[c]=*reinterpret_cast<const half8 *>(stage_lo+row_entry+32*c);
           }
         floatx4 acc={0.0f,0.0f,0.0f,0.0f};
-#ifdef MH_FUSED_PRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
+        if (MH_KNOCKED(16))
+          acc=floatx4{(float) a_hi[0][0],(float) a_lo[1 % NC][1],(float) a_hi[(NC-1)][2],1024.0f+(float) a_lo[0][3]};
+        else
+          {
 #pragma unroll
         for (int c=0; c < NC; c++)
           {
@@ -725,9 +822,7 @@ void blur_fused16_kernel(BlurFusedArgs args)
             acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[c],t_hi[c],acc,0,0,0);
             acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_lo[c],acc,0,0,0);
           }
-#ifdef MH_FUSED_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
+          }
 #ifdef MH_FUSED_TRACE
         asm volatile("s_nop 0" :: "v"(acc[0]),"v"(acc[3]));      // the chain has completed
         MH_FTRACE_MARK(6);
@@ -737,6 +832,11 @@ void blur_fused16_kernel(BlurFusedArgs args)
         // Quantum-rounded colour = 65536*S_c/S_a and alpha = S_a/128 (sums_to_quantum); the
         // column pass's samples: alpha*colour*2^-17 and alpha/2 (plain: level/2).
         float v[4];
+        if (MH_KNOCKED(32))
+          {
+            v[0]=acc[0]; v[1]=acc[1]; v[2]=acc[2]; v[3]=acc[3];
+          }
+        else
         {
           const uint2 q=sums_to_quantum<SAMPLES>(acc[0],acc[1],acc[2],acc[3]);
           const f32x2 c01={(float) (q.x & 0xffffu),(float) (q.x >> 16)};
