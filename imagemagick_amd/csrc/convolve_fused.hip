@@ -430,23 +430,32 @@ static MhStatus launch_fused_typed(const View &src,BlurFusedArgs &args)
 // chunk per instruction: three chunks cover the 79 taps' 94-sample band against seven 16-sample
 // chunks for a 32-output tile), so a wave fits in 128 VGPRs and four of them share a SIMD:
 //
-//   row pass     entries e = 4*channel + row    (16 = 4 rows x 4 channels), 16 outputs along x:
+//   row pass     entries e = 4*row + channel    (16 = 4 rows x 4 channels), 16 outputs along x:
 //                16 tiles per 16-row group, one per wave.  D (row = 4*(lane>>4)+reg, col =
-//                lane&15) leaves a lane four consecutive rows of ONE channel of one column — one
-//                8-byte ring store per plane; the alpha sums a colour lane divides by sit in
-//                lanes 48..63 and come over with four ds_bpermute.
+//                lane&15) leaves a lane the four channels of ONE pixel: the division by the alpha
+//                sum, the Quantum rounding and the exact small-alpha test are lane-local.  A 4x4
+//                transpose between registers and the four 16-lane rows (2 v_permlane32_swap + 2
+//                v_permlane16_swap) then gives each lane four consecutive rows of one channel —
+//                one 8-byte ring store per plane.  (Round 2b had e = 4*channel+row: no
+//                transpose, but the alpha sums came over with four ds_bpermute and every lane
+//                repeated the division: 10 % slower.)
 //   column pass  entries e = 4*column + channel (16 = 4 columns x 4 channels), 16 outputs along
-//                y: 16 tiles per 16-row block, one per wave; a lane ends up with the four channels
-//                of one pixel (lane-local division) and stores its 8 bytes.
+//                y: 16 tiles per 16-row block; a lane ends up with the four channels of one pixel
+//                (lane-local division).  The tiles belong to the waves that do NOT stage (two or
+//                three apiece, below), and the pixels go through a 16 x 64 LDS tile so that,
+//                after the barrier, wave w stores row w as one contiguous 512-byte segment (in the
+//                shadow of the row pass's MFMA chain) instead of 64 separate 8-byte writes.
 //
 // Ring: a 16-output column tile reads NG = 2*NC groups of 16 rows; the ring holds one more
 // (NR = NG+1), so the column pass of block g-NG only needs groups the PREVIOUS iterations
 // wrote and runs in the same barrier interval as the staging of group g:
-//   iteration g:  stage group g, fetch group g+1, column pass of block g-NG (store) | X |
-//                 row pass of group g -> ring slot g mod NR | Y
-// With the column pass after the row pass of the same iteration (NR = NG) its store sat right in
-// front of the next iteration's wait for the staged loads — gfx9 has one counter for loads and
-// stores, so that wait also waited out the store's round trip: 0.50 ms against 0.xx ms.
+//   iteration g:  staging waves: stage group g, fetch group g+1 | tile waves: column pass of
+//                 block g-NG -> out_tile | X | row pass of group g -> ring slot g mod NR, store of
+//                 out_tile's rows | Y
+// What the knock-out builds say (-DMH_FUSED_KNOCK, tools/gpu_ab2.sh; profiles/r2_notes): the costs
+// of the parts ADD UP (result stores 10 %, source fetches 10 %, staging conversion 13 %, column
+// pass 18 %, row pass 33 %, barriers and loop 16 %): with four waves on a SIMD and two barriers
+// per group the iteration is a chain of latencies, not a throughput limit.
 // (fused16_read_degree / fused16_layout: mfma_common.hpp)
 template<int NC>
 struct Fused16Geometry
@@ -457,11 +466,7 @@ struct Fused16Geometry
   static constexpr int NR=NG+1;                // ring groups held
   static constexpr int RC=GROUP*NR;            // ring rows
   static constexpr int XS=32*NC+48;            // staged columns: 64 outputs + band
-#ifdef MH_FUSED_BPERMUTE
-  static constexpr bool ROW_CHANNEL_MAJOR=true;   // row pass entries e = 4*channel + row
-#else
   static constexpr bool ROW_CHANNEL_MAJOR=false;  // row pass entries e = 4*row + channel
-#endif
   static constexpr int SR=fused16_layout(XS,GROUP,ROW_CHANNEL_MAJOR,false)/256,PADR=fused16_layout(XS,GROUP,ROW_CHANNEL_MAJOR,false) % 256;
   static constexpr int SC=fused16_layout(RC,COLS,false,true)/256,PADC=fused16_layout(RC,COLS,false,true) % 256;
   static constexpr int CHR=GROUP*SR+PADR;
@@ -471,11 +476,7 @@ struct Fused16Geometry
   // the column pass's 16 x 64 result pixels on their way to row-contiguous stores; 65 pixels per
   // row: the 16 rows a quarter-wave writes fall into 16 different bank pairs
   static constexpr int OUT_STRIDE=COLS+1;
-#ifdef MH_FUSED_DIRECT_STORE
-  static constexpr size_t lds_bytes=planes_bytes;
-#else
   static constexpr size_t lds_bytes=planes_bytes+(size_t) GROUP*OUT_STRIDE*sizeof(uint2);
-#endif
   static_assert(lds_bytes <= 163840,"more than the 160 KiB of a CU");
   static constexpr int GROUPS_PER_ROW=XS/4;
   static constexpr int FETCH_GROUPS=GROUP*GROUPS_PER_ROW;
@@ -517,9 +518,7 @@ void blur_fused16_kernel(BlurFusedArgs args)
   _Float16 *ring_lo=ring_hi+G::RING_PLANE;
   _Float16 *stage_hi=ring_lo+G::RING_PLANE;
   _Float16 *stage_lo=stage_hi+G::STAGE_PLANE;
-#ifndef MH_FUSED_DIRECT_STORE
   uint2 *out_tile=reinterpret_cast<uint2 *>(smem_raw+G::planes_bytes);
-#endif
   const int tid=(int) threadIdx.x,lane=tid & 63;
   const int wave=__builtin_amdgcn_readfirstlane(tid >> 6);
   const int n=lane & 15,kq=lane >> 4;
@@ -590,7 +589,6 @@ void blur_fused16_kernel(BlurFusedArgs args)
             raw[2]=make_uint2(b.y,c.x & 0xffffu);
             raw[3]=make_uint2((c.x >> 16) | (c.y << 16),c.y >> 16);
           }
-#ifndef MH_FUSED_NARROW_FETCH
         else if ((MODE != MFMA_PLAIN3) && (xs >= 0) && (xs+3 <= W-1))
           {
             // four 8-byte pixels = 32 contiguous bytes: two 16-byte loads, one address
@@ -602,7 +600,6 @@ void blur_fused16_kernel(BlurFusedArgs args)
             raw[2]=make_uint2(b.x,b.y);
             raw[3]=make_uint2(b.z,b.w);
           }
-#endif
         else
           {
 #pragma unroll
@@ -636,19 +633,11 @@ void blur_fused16_kernel(BlurFusedArgs args)
 
   // row pass: wave = row quad (4 rows) x output tile (16 columns); entry e = 4*channel+row
   const int rq=wave & 3,ot=wave >> 2;
-#ifdef MH_FUSED_BPERMUTE
-  const int row_entry=(n >> 2)*G::CHR+(4*rq+(n & 3))*G::SR+16*ot+8*kq;
-#else
   // entries e = 4*row + channel: D then hands a lane the four channels of ONE pixel, so the
   // division by the alpha sum is lane-local (as in the column pass)
   const int row_entry=(n & 3)*G::CHR+(4*rq+(n >> 2))*G::SR+16*ot+8*kq;
-#endif
   // column pass: wave = column quad; entry e = 4*column+channel; a 32-row chunk spans two ring
   // groups: k 0..15 (kq 0,1) in the first, k 16..31 (kq 2,3) in the next
-#ifdef MH_FUSED_COLUMN_PER_WAVE
-  constexpr int CT=1;                          // column tiles a wave may own
-  const int ctile0=wave,ctiles=1;
-#else
   // The staging waves (tid < FETCH_GROUPS: 9 of 16 for 79 taps) convert and stage; the column
   // pass's sixteen tiles (four columns each) belong to the OTHER waves, two or three apiece.  A
   // staging wave's chain per iteration is then wait - convert - stage - fetch and a tile wave's
@@ -661,29 +650,9 @@ void blur_fused16_kernel(BlurFusedArgs args)
   const int tile_wave=wave-(16-TILE_WAVES);    // < 0: a staging wave
   const int ctiles=tile_wave < 0 ? 0 : 16/TILE_WAVES+(tile_wave < 16 % TILE_WAVES ? 1 : 0);
   const int ctile0=tile_wave < 0 ? 0 : tile_wave*(16/TILE_WAVES)+(tile_wave < 16 % TILE_WAVES ? tile_wave : 16 % TILE_WAVES);
-#endif
   const int col_entry=(n & 3)*G::CHC+(4*ctile0+(n >> 2))*G::SC+8*(kq & 1);
   const int ring_entry=kq*G::CHC+(16*ot+n)*G::SC+4*rq;     // the row pass's ring store
   int ring_group=0;                            // g mod NR (wave-uniform)
-#ifdef MH_FUSED_DIRECT_STORE
-  // UNSHARP: the unblurred pixel of the lane's column-pass output (effect.c:4364-4369), fetched
-  // one iteration ahead, behind the staging loads, so that the wait the staging does anyway
-  // covers it (the strip's rows left the CU 32*NC rows ago: an L2 / MALL hit)
-  uint2 original[CT];
-#pragma unroll
-  for (int t=0; t < CT; t++)
-    original[t]=make_uint2(0u,0u);
-  auto fetch_original=[&](int block)
-  {
-#pragma unroll
-    for (int t=0; t < CT; t++)
-      {
-        const int x=x0+4*(ctile0+t)+kq,y=out_begin+G::GROUP*block+n;
-        if ((t < ctiles) && (block >= 0) && (block < nblocks) && (x < W) && (y < H))
-          original[t]=load_pixel16(args.src+pixel_index(y,W,x)*PX);
-      }
-  };
-#else
   // The column pass leaves its 16 x 64 pixels in out_tile; after barrier X wave w stores row w:
   // 64 lanes x 8 bytes = one contiguous 512-byte segment (the tiles' own lanes hold 16 ROWS of
   // 4 pixels each: 64 separate 8-byte writes per store instruction, 1024 partial-line write
@@ -697,20 +666,12 @@ void blur_fused16_kernel(BlurFusedArgs args)
     if ((block >= 0) && (block < nblocks) && (x < W) && (y < H))
       original=load_pixel16(args.src+pixel_index(y,W,x)*PX);
   };
-#endif
 
   fetch(0);
   for (int g=0; g <= ngroups; g++)
     {
-#ifdef MH_FUSED_DIRECT_STORE
-      uint2 unblurred[CT];
-#pragma unroll
-      for (int t=0; t < CT; t++)
-        unblurred[t]=original[t];
-#else
       if constexpr (UNSHARP)
         fetch_original(g-G::NG);
-#endif
       MH_FTRACE_MARK(0);
       if (g < ngroups)
         {
@@ -728,14 +689,9 @@ void blur_fused16_kernel(BlurFusedArgs args)
             fetch(g+1);
         }
       MH_FTRACE_MARK(3);
-#ifdef MH_FUSED_DIRECT_STORE
-      if constexpr (UNSHARP)
-        fetch_original(g+1-G::NG);
-#endif
       if ((g >= G::NG) && !MH_KNOCKED(8))
         {
-          // ---- column pass of output rows out_begin+16*block .. +16
-          const int block=g-G::NG;
+          // ---- column pass of output rows out_begin+16*(g-NG) .. +16
           // block mod NR = (g+1) mod NR (NR = NG+1): the oldest group the ring still holds
           const int first=ring_group+1 == G::NR ? 0 : ring_group+1;
           // the ring group of chunk c for this lane: (first + 2c + (kq>>1)) mod NR for a value
@@ -769,36 +725,28 @@ void blur_fused16_kernel(BlurFusedArgs args)
                   }
                 // lane (n, kq): the four channels (registers) of pixel (column 4*tile+kq, row n)
                 uint2 result=sums_to_quantum<SAMPLES>(acc[0],acc[1],acc[2],acc[3]);
-#ifdef MH_FUSED_DIRECT_STORE
-                if constexpr (UNSHARP)
-                  result=unsharp_pixel(unblurred[t],result,args.gain,args.threshold);
-                const int x=x0+4*(ctile0+t)+kq,y=out_begin+G::GROUP*block+n;
-                if ((x < W) && (y < H))
-                  store_pixel16(args.dst+pixel_index(y,W,x)*PX,result);
-#else
                 out_tile[n*G::OUT_STRIDE+4*(ctile0+t)+kq]=result;
-#endif
               }
         }
       MH_FTRACE_MARK(4);
-#ifdef MH_FUSED_DIRECT_STORE
-      if (g == ngroups)
-        break;
-      __syncthreads();                           // X: staged; every wave is past the column pass
-#else
       __syncthreads();                           // X: staged; the column pass's pixels are in out_tile
-      if (g >= G::NG)
-        {
-          uint2 result=out_tile[wave*G::OUT_STRIDE+lane];
-          if constexpr (UNSHARP)
-            result=unsharp_pixel(original,result,args.gain,args.threshold);
-          const int x=x0+lane,y=out_begin+G::GROUP*(g-G::NG)+wave;
-          if ((x < W) && (y < H) && !MH_KNOCKED(1))
-            store_pixel16(args.dst+pixel_index(y,W,x)*PX,result);
-        }
+      auto store_row=[&]()
+      {
+        if (g >= G::NG)
+          {
+            uint2 result=out_tile[wave*G::OUT_STRIDE+lane];
+            if constexpr (UNSHARP)
+              result=unsharp_pixel(original,result,args.gain,args.threshold);
+            const int x=x0+lane,y=out_begin+G::GROUP*(g-G::NG)+wave;
+            if ((x < W) && (y < H) && !MH_KNOCKED(1))
+              store_pixel16(args.dst+pixel_index(y,W,x)*PX,result);
+          }
+      };
       if (g == ngroups)
-        break;
-#endif
+        {
+          store_row();
+          break;
+        }
       MH_FTRACE_MARK(5);
       // ---- row pass of ring group g
       if (!MH_KNOCKED(64))
@@ -823,11 +771,13 @@ void blur_fused16_kernel(BlurFusedArgs args)
             acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_lo[c],acc,0,0,0);
           }
           }
+        // the store of the column pass's row in the shadow of the MFMA chain (its LDS read and
+        // address arithmetic need no matrix result)
+        store_row();
 #ifdef MH_FUSED_TRACE
         asm volatile("s_nop 0" :: "v"(acc[0]),"v"(acc[3]));      // the chain has completed
         MH_FTRACE_MARK(6);
 #endif
-#ifndef MH_FUSED_BPERMUTE
         // lane (n, kq): the four channels (registers) of pixel (column x0+16*ot+n, row 4*rq+kq).
         // Quantum-rounded colour = 65536*S_c/S_a and alpha = S_a/128 (sums_to_quantum); the
         // column pass's samples: alpha*colour*2^-17 and alpha/2 (plain: level/2).
@@ -879,67 +829,6 @@ void blur_fused16_kernel(BlurFusedArgs args)
         uint2 hi,lo;
         split_f16_pair(f32x2{v[0],v[1]},hi.x,lo.x);
         split_f16_pair(f32x2{v[2],v[3]},hi.y,lo.y);
-#else
-        // lane (n, kq): channel kq of the pixels (x0+16*ot+n, rows 4*rq+r), r = register
-        constexpr float unit=1.0f/(128.0f*65535.0f);
-        f32x2 v[2];                              // the column pass's samples, pairs of rows
-        if constexpr (MODE == MFMA_BLEND4)
-          {
-            // the alpha sums of this column live in lanes 48..63
-            const f32x2 sa01={__shfl(acc[0],48+n,64),__shfl(acc[1],48+n,64)};
-            const f32x2 sa23={__shfl(acc[2],48+n,64),__shfl(acc[3],48+n,64)};
-            // Quantum-rounded colour = 65536*S_c/S_a and alpha = S_a/128 (sums_to_quantum); an alpha
-            // lane computes a meaningless (but finite: NaN -> 0) "colour" and drops it below
-            const f32x2 inv01={__builtin_amdgcn_rcpf(sa01[0]),__builtin_amdgcn_rcpf(sa01[1])};
-            const f32x2 inv23={__builtin_amdgcn_rcpf(sa23[0]),__builtin_amdgcn_rcpf(sa23[1])};
-            const f32x2 p01=f32x2{acc[0],acc[1]}*(inv01*(65536.0f/65535.0f));
-            const f32x2 p23=f32x2{acc[2],acc[3]}*(inv23*(65536.0f/65535.0f));
-            const pknorm2 q01=__builtin_amdgcn_cvt_pknorm_u16(p01[0],p01[1]);
-            const pknorm2 q23=__builtin_amdgcn_cvt_pknorm_u16(p23[0],p23[1]);
-            const f32x2 l01=sa01*unit,l23=sa23*unit;
-            const pknorm2 a01=__builtin_amdgcn_cvt_pknorm_u16(l01[0],l01[1]);
-            const pknorm2 a23=__builtin_amdgcn_cvt_pknorm_u16(l23[0],l23[1]);
-            f32x2 alpha01={(float) a01[0],(float) a01[1]};
-            f32x2 alpha23={(float) a23[0],(float) a23[1]};
-            // the row pass's alpha becomes a weight: exact where it is small and the f32 sum
-            // cannot decide the level (mfma_common.hpp); the four lanes of a pixel agree.  One
-            // comparison per lane unless the column holds small alpha.
-            const float smallest=__builtin_fminf(__builtin_fminf(sa01[0],sa01[1]),__builtin_fminf(sa23[0],sa23[1]));
-            if (smallest < kSmallAlpha*128.0f)
-              {
-                const float sa[4]={sa01[0],sa01[1],sa23[0],sa23[1]};
-                float exact[4]={alpha01[0],alpha01[1],alpha23[0],alpha23[1]};
-#pragma unroll
-                for (int r=0; r < 4; r++)
-                  if (alpha_sum_is_ambiguous(sa[r]))
-                    {
-                      const int x=x0+16*ot+n;
-                      int y=in0+G::GROUP*g+4*rq+r;
-                      y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
-                      if (x < W)
-                        exact[r]=(float) exact_alpha_level(args.src,pixel_index(y,W,0),1,W,x-args.shift,args.taps64,K);
-                    }
-                alpha01=f32x2{exact[0],exact[1]};
-                alpha23=f32x2{exact[2],exact[3]};
-              }
-            // sample = alpha*colour*2^-17 (colour lanes) or alpha/2 (alpha lanes): alpha*(colour*c1+c2)
-            const float c1=kq == 3 ? 0.0f : 0.5f/65536.0f,c2=kq == 3 ? 0.5f : 0.0f;
-            const f32x2 colour01={(float) q01[0],(float) q01[1]};
-            const f32x2 colour23={(float) q23[0],(float) q23[1]};
-            v[0]=alpha01*__builtin_elementwise_fma(colour01,f32x2{c1,c1},f32x2{c2,c2});
-            v[1]=alpha23*__builtin_elementwise_fma(colour23,f32x2{c1,c1},f32x2{c2,c2});
-          }
-        else
-          {
-            const pknorm2 q01=__builtin_amdgcn_cvt_pknorm_u16(acc[0]*unit,acc[1]*unit);
-            const pknorm2 q23=__builtin_amdgcn_cvt_pknorm_u16(acc[2]*unit,acc[3]*unit);
-            v[0]=f32x2{(float) q01[0],(float) q01[1]}*0.5f;
-            v[1]=f32x2{(float) q23[0],(float) q23[1]}*0.5f;
-          }
-        uint2 hi,lo;
-        split_f16_pair(v[0],hi.x,lo.x);
-        split_f16_pair(v[1],hi.y,lo.y);
-#endif
         const int at=ring_entry+ring_group*G::GROUP;
         *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
         *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
