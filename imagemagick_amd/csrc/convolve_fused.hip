@@ -468,9 +468,17 @@ struct Fused16Geometry
   static constexpr int XS=32*NC+48;            // staged columns: 64 outputs + band
   static constexpr bool ROW_CHANNEL_MAJOR=false;  // row pass entries e = 4*row + channel
   static constexpr int SR=fused16_layout(XS,GROUP,ROW_CHANNEL_MAJOR,false)/256,PADR=fused16_layout(XS,GROUP,ROW_CHANNEL_MAJOR,false) % 256;
-  static constexpr int SC=fused16_layout(RC,COLS,false,true)/256,PADC=fused16_layout(RC,COLS,false,true) % 256;
+  // Ring plane of a channel: [8-row octet][column][8 rows].  A column-pass lane's 8 operand rows
+  // are one 16-byte unit; the 16 lanes of a ds_read_b128 group (4 columns x 4 channels) land in 16
+  // different slots of a bank row when the channel stride is 4 units mod 16 (PADC = 32 halves);
+  // the row pass's 8-byte stores (16 consecutive columns per lane group) are 2-way conflicted.
+  // (Round 2b kept a column's rows in one line of SC halves: its stores were 4-way conflicted —
+  // SQ_LDS_BANK_CONFLICT 63 % of the LDS cycles, 385 of them per iteration, right in front of
+  // barrier Y.)
+  static constexpr int OB=COLS*8;              // halves per octet block
+  static constexpr int SC=8,PADC=32;
   static constexpr int CHR=GROUP*SR+PADR;
-  static constexpr int CHC=COLS*SC+PADC;
+  static constexpr int CHC=(RC/8)*OB+PADC;
   static constexpr int STAGE_PLANE=4*CHR,RING_PLANE=4*CHC;
   static constexpr size_t planes_bytes=(size_t) 2*(STAGE_PLANE+RING_PLANE)*sizeof(_Float16);
   // the column pass's 16 x 64 result pixels on their way to row-contiguous stores; 65 pixels per
@@ -650,8 +658,9 @@ void blur_fused16_kernel(BlurFusedArgs args)
   const int tile_wave=wave-(16-TILE_WAVES);    // < 0: a staging wave
   const int ctiles=tile_wave < 0 ? 0 : 16/TILE_WAVES+(tile_wave < 16 % TILE_WAVES ? 1 : 0);
   const int ctile0=tile_wave < 0 ? 0 : tile_wave*(16/TILE_WAVES)+(tile_wave < 16 % TILE_WAVES ? tile_wave : 16 % TILE_WAVES);
-  const int col_entry=(n & 3)*G::CHC+(4*ctile0+(n >> 2))*G::SC+8*(kq & 1);
-  const int ring_entry=kq*G::CHC+(16*ot+n)*G::SC+4*rq;     // the row pass's ring store
+  constexpr int GROUP_STRIDE=2*G::OB;
+  const int col_entry=(n & 3)*G::CHC+(4*ctile0+(n >> 2))*8+(kq & 1)*G::OB;
+  const int ring_entry=kq*G::CHC+(rq >> 1)*G::OB+(16*ot+n)*8+4*(rq & 1);   // the row pass's ring store
   int ring_group=0;                            // g mod NR (wave-uniform)
   // The column pass leaves its 16 x 64 pixels in out_tile; after barrier X wave w stores row w:
   // 64 lanes x 8 bytes = one contiguous 512-byte segment (the tiles' own lanes hold 16 ROWS of
@@ -702,7 +711,7 @@ void blur_fused16_kernel(BlurFusedArgs args)
             {
               const unsigned wide=(unsigned) (first+2*c+(kq >> 1));
               const unsigned group=wide < wide-(unsigned) G::NR ? wide : wide-(unsigned) G::NR;
-              chunk_at[c]=col_entry+G::GROUP*(int) group;
+              chunk_at[c]=col_entry+GROUP_STRIDE*(int) group;
             }
 #pragma unroll
           for (int t=0; t < CT; t++)
@@ -829,7 +838,7 @@ void blur_fused16_kernel(BlurFusedArgs args)
         uint2 hi,lo;
         split_f16_pair(f32x2{v[0],v[1]},hi.x,lo.x);
         split_f16_pair(f32x2{v[2],v[3]},hi.y,lo.y);
-        const int at=ring_entry+ring_group*G::GROUP;
+        const int at=ring_entry+ring_group*GROUP_STRIDE;
         *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
         *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
       }

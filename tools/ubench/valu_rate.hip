@@ -51,6 +51,19 @@ __global__ __launch_bounds__(256) void rate(float *out,const float *taps,unsigne
           for (int i=0; i < NACC; i+=2)
             asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(*(double *) &acc[i]) : "v"(*(double *) &acc[(i+2)%NACC]), "v"(*(double *) &acc[(i+4)%NACC]));
         }
+      else if constexpr (MODE == 6)     // v_fmac_f64 with an SGPR-pair multiplier (the EXACT kernels' tap form)
+        {
+          const double td=(double) t0;
+#pragma unroll
+          for (int i=0; i < NACC; i+=2)
+            asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(*(double *) &acc[i]) : "s"(td), "v"(*(double *) &acc[(i+2)%NACC]));
+        }
+      else if constexpr (MODE == 7)     // v_cvt_f64_u32
+        {
+#pragma unroll
+          for (int i=0; i < NACC; i+=2)
+            asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(*(double *) &acc[i]) : "v"(acc[(i+3)%NACC]));
+        }
       else if constexpr (MODE == 5)     // v_mul_f64 + v_add_f64 pairs (EXACT path)
         {
 #pragma unroll
@@ -165,6 +178,8 @@ int main()
       run<3>("v_pk_fma_f32 sgpr-bcast",4,NACC/2,bpc);
       run<4>("v_fma_f64",2,NACC/2,bpc);
       run<5>("v_mul_f64+v_add_f64",1,NACC/2,bpc);
+      run<6>("v_fmac_f64 sgpr",2,NACC/2,bpc);
+      run<7>("v_cvt_f64_u32 (1 op/instr)",1,NACC/2,bpc);
       run_block<false>("blur block, taps in VGPRs",bpc);
       run_block<true>("blur block, taps in SGPRs",bpc);
     }
