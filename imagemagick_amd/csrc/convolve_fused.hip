@@ -600,13 +600,14 @@ void blur_fused16_kernel(BlurFusedArgs args)
         else if ((MODE != MFMA_PLAIN3) && (xs >= 0) && (xs+3 <= W-1))
           {
             // four 8-byte pixels = 32 contiguous bytes: two 16-byte loads, one address
-            const uint4 *at=reinterpret_cast<const uint4 *>(args.src+pixel_index(y,W,xs)*4);
-            typedef uint4 __attribute__((aligned(8))) LooseQuad;
-            const uint4 a=*reinterpret_cast<const LooseQuad *>(at),b=*reinterpret_cast<const LooseQuad *>(at+1);
-            raw[0]=make_uint2(a.x,a.y);
-            raw[1]=make_uint2(a.z,a.w);
-            raw[2]=make_uint2(b.x,b.y);
-            raw[3]=make_uint2(b.z,b.w);
+            // (pixel alignment only: 8 bytes)
+            typedef unsigned LooseQuad __attribute__((ext_vector_type(4),aligned(8)));
+            const LooseQuad *at=reinterpret_cast<const LooseQuad *>(args.src+pixel_index(y,W,xs)*4);
+            const LooseQuad a=at[0],b=at[1];
+            raw[0]=make_uint2(a[0],a[1]);
+            raw[1]=make_uint2(a[2],a[3]);
+            raw[2]=make_uint2(b[0],b[1]);
+            raw[3]=make_uint2(b[2],b[3]);
           }
         else
           {
