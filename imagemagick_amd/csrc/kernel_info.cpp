@@ -6,7 +6,7 @@
 // shim hands the reference's own KernelInfo values to the operators, so this
 // file only serves standalone callers (bench, tests, the Python binding); it
 // is validated value-for-value against the compiled reference in
-// tests/test_kernel_info.py.
+// tests/test_host.py (CPU) and tests/test_gpu_parity.py (the operators that use them).
 //
 // Every name of morphology.c's KernelInfoType table is built, including the FreiChen set, the
 // Laplacian / LoG constants and the hit-and-miss families (Edges, Corners, Diagonals, LineEnds,

@@ -1296,7 +1296,7 @@ struct LutBuildArgs
   double black_point,white_limit;     // stretch: counts; white_limit = columns*rows-white_point
   int is_u16;
   void *lut;                          // Quantum-typed [65536][channels]
-  uint32_t *mask;                     // out: bit c set when channel c has black != white (pre-zeroed)
+  uint32_t *mask;                     // out: bit c set when channel c has black != white
   const unsigned int *colour_flag;    // optional: 0 => image is gray => leave every channel alone
 };
 
@@ -1368,6 +1368,11 @@ void lut_chunk_sums_kernel(LutBuildArgs a,LutScratch *scratch)
         {
           scratch->black[c]=65536;
           scratch->white[c]=0;
+          // this channel's bit of the mask and, once, the bits above the channels (the later
+          // kernels of the stream set the bit again; a memset would be one more launch)
+          atomicAnd(a.mask,~(1u << c));
+          if (c == 0)
+            atomicAnd(a.mask,a.channels >= 32 ? 0xffffffffu : (1u << a.channels)-1u);
         }
     }
 }
@@ -1502,7 +1507,6 @@ MhStatus launch_build_lut(const View &img,const unsigned long long *hist,bool eq
   a.colour_flag=colour_flag;
   Temp scratch;
   MH_TRY(scratch.alloc(img.device,sizeof(LutScratch),img.stream));
-  MH_HIP(hipMemsetAsync(mask,0,sizeof(uint32_t),img.stream));
   const dim3 grid((unsigned) img.channels,kLutChunks);
   ProfileScope prof("build_lut",img.stream);
   hipLaunchKernelGGL(lut_chunk_sums_kernel,grid,dim3(1024),0,img.stream,a,scratch.as<LutScratch>());
