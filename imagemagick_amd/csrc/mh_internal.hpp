@@ -92,6 +92,29 @@ struct Temp
 // memory may go away immediately.
 MhStatus upload_table(Temp &dst,int device,hipStream_t stream,const void *host,size_t bytes);
 
+// Several host tables as ONE device block and ONE host-to-device copy (a resize pass has ten
+// tables: ten stream-ordered copies cost 150-300 us of idle GPU between two kernels of a few
+// milliseconds).  add() the parts (the host memory must stay valid until upload()), upload(),
+// then at<T>(index).
+class TableBundle
+{
+public:
+  size_t add(const void *host,size_t bytes)
+  {
+    parts_.push_back({host,bytes,total_});
+    total_+=(bytes+255u) & ~(size_t) 255u;
+    return parts_.size()-1;
+  }
+  MhStatus upload(int device,hipStream_t stream);
+  template<typename T> T *at(size_t index) const
+  { return reinterpret_cast<T *>(static_cast<char *>(block_.ptr)+parts_[index].offset); }
+private:
+  struct Part { const void *host; size_t bytes,offset; };
+  std::vector<Part> parts_;
+  size_t total_=0;
+  Temp block_;
+};
+
 // Resolved, device-resident view of an MhImage for the kernel launchers.
 struct View
 {

@@ -25,6 +25,8 @@
 //              taps, so the reads broadcast).
 #include "mh_internal.hpp"
 #include "resize_filter.hpp"
+#include <memory>
+#include <mutex>
 #include "device_common.hpp"
 #include <cstdlib>
 #include <cstring>
@@ -1154,11 +1156,35 @@ MhStatus launch_resize_fused(const View &src,const View &dst,const TapTable &ver
 }
 
 // ---------------------------------------------------------------- launcher
-template<typename Q,int C,bool BLEND,class A>
-static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
-  const TapTable &table,const Roles &roles)
+// Everything a resize pass reads besides the pixels, resident on the device: the contribution
+// lists, the per-tile dense weight matrices of the vertical kernel or the per-tile spans of the
+// horizontal one, and the launch geometry that follows from them.  Built once per (contribution
+// table, axis, weight type) and kept (a pass of config C3 uploads 4 MB: 70-140 us of idle GPU in
+// front of a 1.3 ms kernel, and ~0.5 ms of host loops per call).
+struct PassTables
 {
-  typedef typename A::T T;
+  TableBundle tables;
+  size_t i_start=0,i_count=0,i_near=0,i_w=0,i_wq=0;
+  // vertical: dense W[tile][k][RY]
+  size_t i_lo=0,i_rows=0,i_mask=0,i_dw=0,i_dwq=0;
+  int tiles=0,kmax=1;
+  // horizontal: per 256-column tile
+  size_t i_tile_lo=0,i_tile_span=0;
+  int max_span=1,overhang=0,maxt=8;
+  hipEvent_t ready=nullptr;          // the upload, for callers on another stream
+  ~PassTables()
+  {
+    if (ready != nullptr)
+      (void) hipEventDestroy(ready);
+  }
+};
+
+constexpr int kVerticalRows=4;      // output rows per tile of resize_vertical_kernel
+
+template<typename T>
+static MhStatus build_pass_tables(PassTables &p,const TapTable &table,bool vertical,int device,
+  hipStream_t stream)
+{
   const size_t n=(size_t) table.max_taps*(size_t) table.out_size;
   std::vector<T> w(n),wq(n);
   for (size_t i=0; i < n; i++)
@@ -1166,37 +1192,21 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
       w[i]=(T) table.weight[i];
       wq[i]=(T) (table.weight[i]*kQuantumScale);     // contribution.weight*QuantumScale
     }
-  Temp d_start,d_count,d_near,d_w,d_wq;
   const size_t ib=(size_t) table.out_size*sizeof(int);
-  MH_TRY(upload_table(d_start,src.device,src.stream,table.start.data(),ib));
-  MH_TRY(upload_table(d_count,src.device,src.stream,table.count.data(),ib));
-  MH_TRY(upload_table(d_near,src.device,src.stream,table.nearest.data(),ib));
-  MH_TRY(upload_table(d_w,src.device,src.stream,w.data(),n*sizeof(T)));
-  MH_TRY(upload_table(d_wq,src.device,src.stream,wq.data(),n*sizeof(T)));
-
-  ResizeArgs args;
-  args.src=src.pixels;
-  args.dst=dst.pixels;
-  args.src_columns=(int) src.columns;
-  args.src_rows=(int) src.rows;
-  args.dst_columns=(int) dst.columns;
-  args.dst_rows=(int) dst.rows;
-  args.out_size=table.out_size;
-  args.max_taps=table.max_taps;
-  args.start=d_start.as<int>();
-  args.count=d_count.as<int>();
-  args.nearest=d_near.as<int>();
-  args.weight=d_w.ptr;
-  args.weight_qs=d_wq.ptr;
-  args.copy_mask=roles.copy_mask;
-  args.tile_lo=nullptr;
-  args.tile_span=nullptr;
-
+  p.i_start=p.tables.add(table.start.data(),ib);
+  p.i_count=p.tables.add(table.count.data(),ib);
+  p.i_near=p.tables.add(table.nearest.data(),ib);
+  p.i_w=p.tables.add(w.data(),n*sizeof(T));
+  p.i_wq=p.tables.add(wq.data(),n*sizeof(T));
+  std::vector<int> lo,nrows,tile_lo,tile_span;
+  std::vector<double> dw,dwq;
+  std::vector<unsigned> mask;
   if (vertical)
     {
-      constexpr int RY=4;
+      constexpr int RY=kVerticalRows;
       const int tiles=(table.out_size+RY-1)/RY;
-      std::vector<int> lo((size_t) tiles,0),nrows((size_t) tiles,0);
+      lo.assign((size_t) tiles,0);
+      nrows.assign((size_t) tiles,0);
       int kmax=1;
       for (int t=0; t < tiles; t++)
         {
@@ -1216,8 +1226,9 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
           nrows[(size_t) t]=h-l;
           kmax=(h-l) > kmax ? (h-l) : kmax;
         }
-      std::vector<double> dw((size_t) tiles*kmax*RY,0.0),dwq((size_t) tiles*kmax*RY,0.0);
-      std::vector<unsigned> mask((size_t) tiles*kmax,0u);
+      dw.assign((size_t) tiles*kmax*RY,0.0);
+      dwq.assign((size_t) tiles*kmax*RY,0.0);
+      mask.assign((size_t) tiles*kmax,0u);
       for (int t=0; t < tiles; t++)
         for (int r=0; r < RY; r++)
           {
@@ -1234,51 +1245,34 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
                 mask[(size_t) t*kmax+(size_t) k]|=1u << r;
               }
           }
-      Temp d_lo,d_rows,d_mask,d_dw,d_dwq;
-      MH_TRY(upload_table(d_lo,src.device,src.stream,lo.data(),lo.size()*sizeof(int)));
-      MH_TRY(upload_table(d_rows,src.device,src.stream,nrows.data(),nrows.size()*sizeof(int)));
-      MH_TRY(upload_table(d_mask,src.device,src.stream,mask.data(),mask.size()*sizeof(unsigned)));
-      MH_TRY(upload_table(d_dw,src.device,src.stream,dw.data(),dw.size()*sizeof(double)));
-      MH_TRY(upload_table(d_dwq,src.device,src.stream,dwq.data(),dwq.size()*sizeof(double)));
-      VerticalDenseArgs va;
-      va.src=src.pixels;
-      va.dst=dst.pixels;
-      va.columns=(int) dst.columns;
-      va.out_rows=table.out_size;
-      va.kmax=kmax;
-      va.tile_lo=d_lo.as<int>();
-      va.tile_rows=d_rows.as<int>();
-      va.row_mask=d_mask.as<unsigned>();
-      va.w=d_dw.as<double>();
-      va.wq=d_dwq.as<double>();
-      va.nearest=d_near.as<int>();
-      va.count=d_count.as<int>();
-      va.copy_mask=roles.copy_mask;
-      dim3 grid((unsigned) ((dst.columns+255)/256),(unsigned) tiles);
-      ProfileScope prof("resize_vertical",src.stream);
-      hipLaunchKernelGGL((resize_vertical_kernel<Q,C,BLEND,A,RY>),grid,dim3(256),0,src.stream,va);
+      p.tiles=tiles;
+      p.kmax=kmax;
+      p.i_lo=p.tables.add(lo.data(),lo.size()*sizeof(int));
+      p.i_rows=p.tables.add(nrows.data(),nrows.size()*sizeof(int));
+      p.i_mask=p.tables.add(mask.data(),mask.size()*sizeof(unsigned));
+      p.i_dw=p.tables.add(dw.data(),dw.size()*sizeof(double));
+      p.i_dwq=p.tables.add(dwq.data(),dwq.size()*sizeof(double));
     }
   else
     {
       // widest source span of any 256-column tile decides how many rows fit in LDS
       int max_span=1;
-      std::vector<int> tile_lo,tile_span;
       for (int x0=0; x0 < table.out_size; x0+=256)
         {
           int xh=(x0+255) < table.out_size ? (x0+255) : table.out_size-1;
-          int lo=table.start[(size_t) x0],hi=0;
+          int l=table.start[(size_t) x0],hi=0;
           for (int i=x0; i <= xh; i++)
             {
-              int s=table.start[(size_t) i],e=s+table.count[(size_t) i];
-              lo=s < lo ? s : lo;
+              int st=table.start[(size_t) i],e=st+table.count[(size_t) i];
+              l=st < l ? st : l;
               hi=e > hi ? e : hi;
             }
-          if (hi < lo)
-            hi=lo;
-          tile_lo.push_back(lo);
-          tile_span.push_back(hi-lo);
-          if ((hi-lo) > max_span)
-            max_span=hi-lo;
+          if (hi < l)
+            hi=l;
+          tile_lo.push_back(l);
+          tile_span.push_back(hi-l);
+          if ((hi-l) > max_span)
+            max_span=hi-l;
         }
       // per tile: the largest tap count (run by every lane of the converted-tile kernel)
       const size_t ntiles=tile_lo.size();
@@ -1300,11 +1294,110 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
           overhang=over > overhang ? over : overhang;
           tile_span.push_back(cmaxt);                 // second half of the array: taps per tile
         }
-      Temp d_lo,d_span;
-      MH_TRY(upload_table(d_lo,src.device,src.stream,tile_lo.data(),tile_lo.size()*sizeof(int)));
-      MH_TRY(upload_table(d_span,src.device,src.stream,tile_span.data(),tile_span.size()*sizeof(int)));
-      args.tile_lo=d_lo.as<int>();
-      args.tile_span=d_span.as<int>();
+      p.max_span=max_span;
+      p.overhang=overhang;
+      p.maxt=maxt;
+      p.i_tile_lo=p.tables.add(tile_lo.data(),tile_lo.size()*sizeof(int));
+      p.i_tile_span=p.tables.add(tile_span.data(),tile_span.size()*sizeof(int));
+    }
+  MH_TRY(p.tables.upload(device,stream));
+  MH_HIP(hipEventCreateWithFlags(&p.ready,hipEventDisableTiming));
+  MH_HIP(hipEventRecord(p.ready,stream));
+  return MH_OK;
+}
+
+// cached by the serial number of a shared contribution table (resize_filter.cpp); tables built
+// for one call (serial 0: the MagickCore shim's callback filters) are not kept
+template<typename T>
+static MhStatus acquire_pass_tables(std::shared_ptr<PassTables> *out,const TapTable &table,bool vertical,
+  int device,hipStream_t stream)
+{
+  struct Entry { unsigned long long serial; int device; bool vertical; size_t weight_bytes; std::shared_ptr<PassTables> tables; };
+  // (never destroyed: at process exit the runtime the device blocks belong to may be gone)
+  static std::mutex &lock=*new std::mutex;
+  static std::vector<Entry> &entries=*new std::vector<Entry>;
+  constexpr size_t kEntries=8;
+  if (table.serial != 0)
+    {
+      std::lock_guard<std::mutex> guard(lock);
+      for (size_t i=0; i < entries.size(); i++)
+        if ((entries[i].serial == table.serial) && (entries[i].device == device) &&
+            (entries[i].vertical == vertical) && (entries[i].weight_bytes == sizeof(T)))
+          {
+            Entry hit=entries[i];
+            entries.erase(entries.begin()+(ptrdiff_t) i);
+            entries.insert(entries.begin(),hit);
+            *out=hit.tables;
+            MH_HIP(hipStreamWaitEvent(stream,hit.tables->ready,0));
+            return MH_OK;
+          }
+    }
+  auto built=std::make_shared<PassTables>();
+  MH_TRY(build_pass_tables<T>(*built,table,vertical,device,stream));
+  *out=built;
+  if (table.serial != 0)
+    {
+      std::lock_guard<std::mutex> guard(lock);
+      entries.insert(entries.begin(),Entry{table.serial,device,vertical,sizeof(T),built});
+      if (entries.size() > kEntries)
+        entries.pop_back();
+    }
+  return MH_OK;
+}
+
+template<typename Q,int C,bool BLEND,class A>
+static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
+  const TapTable &table,const Roles &roles)
+{
+  typedef typename A::T T;
+  std::shared_ptr<PassTables> pass;
+  MH_TRY(acquire_pass_tables<T>(&pass,table,vertical,src.device,src.stream));
+  const TableBundle &tables=pass->tables;
+
+  ResizeArgs args;
+  args.src=src.pixels;
+  args.dst=dst.pixels;
+  args.src_columns=(int) src.columns;
+  args.src_rows=(int) src.rows;
+  args.dst_columns=(int) dst.columns;
+  args.dst_rows=(int) dst.rows;
+  args.out_size=table.out_size;
+  args.max_taps=table.max_taps;
+  args.copy_mask=roles.copy_mask;
+  args.start=tables.at<int>(pass->i_start);
+  args.count=tables.at<int>(pass->i_count);
+  args.nearest=tables.at<int>(pass->i_near);
+  args.weight=tables.at<void>(pass->i_w);
+  args.weight_qs=tables.at<void>(pass->i_wq);
+  args.tile_lo=nullptr;
+  args.tile_span=nullptr;
+
+  if (vertical)
+    {
+      constexpr int RY=kVerticalRows;
+      VerticalDenseArgs va;
+      va.src=src.pixels;
+      va.dst=dst.pixels;
+      va.columns=(int) dst.columns;
+      va.out_rows=table.out_size;
+      va.kmax=pass->kmax;
+      va.tile_lo=tables.at<int>(pass->i_lo);
+      va.tile_rows=tables.at<int>(pass->i_rows);
+      va.row_mask=tables.at<unsigned>(pass->i_mask);
+      va.w=tables.at<double>(pass->i_dw);
+      va.wq=tables.at<double>(pass->i_dwq);
+      va.nearest=tables.at<int>(pass->i_near);
+      va.count=tables.at<int>(pass->i_count);
+      va.copy_mask=roles.copy_mask;
+      dim3 grid((unsigned) ((dst.columns+255)/256),(unsigned) pass->tiles);
+      ProfileScope prof("resize_vertical",src.stream);
+      hipLaunchKernelGGL((resize_vertical_kernel<Q,C,BLEND,A,RY>),grid,dim3(256),0,src.stream,va);
+    }
+  else
+    {
+      const int max_span=pass->max_span,overhang=pass->overhang,maxt=pass->maxt;
+      args.tile_lo=tables.at<int>(pass->i_tile_lo);
+      args.tile_span=tables.at<int>(pass->i_tile_span);
       const size_t px=(size_t) C*sizeof(Q);
       const size_t budget=60u*1024u;
       if (table.max_taps <= 8)

@@ -8,6 +8,7 @@
 #include "resize_filter.hpp"
 #include <cstring>
 #include <memory>
+#include <atomic>
 #include <mutex>
 #include <thread>
 
@@ -425,6 +426,8 @@ std::shared_ptr<const TapTable> acquire_tap_table(const MhResizeFilter *filter,s
   }
   auto table=std::make_shared<TapTable>();
   build_tap_table(*table,filter,in_size,out_size,factor);
+  static std::atomic<unsigned long long> next_serial{1};
+  table->serial=next_serial.fetch_add(1);
   std::lock_guard<std::mutex> guard(cache.lock);
   cache.entries.insert(cache.entries.begin(),{key,table});
   if (cache.entries.size() > kTapCacheEntries)

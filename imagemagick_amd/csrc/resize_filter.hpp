@@ -34,6 +34,9 @@ struct TapTable
   std::vector<int> count;        // number of taps per output (0 => output untouched)
   std::vector<int> nearest;      // source index used by Copy-trait channels
   std::vector<double> weight;    // [tap][out] : normalised weights (transposed for coalescing)
+  // nonzero for a table the cache of acquire_tap_table shares between calls: the key under which
+  // the resize launchers keep its device-side copies
+  unsigned long long serial=0;
 };
 
 void build_tap_table(TapTable &table,const MhResizeFilter *filter,size_t in_size,

@@ -347,6 +347,29 @@ MhStatus upload_table(Temp &dst,int device,hipStream_t stream,const void *host,s
   return MH_OK;
 }
 
+MhStatus TableBundle::upload(int device,hipStream_t stream)
+{
+  if (total_ == 0)
+    return MH_OK;
+  MH_TRY(block_.alloc(device,total_,stream));
+  StagingBlock block;
+  if (staging_acquire(device,total_,&block))
+    {
+      for (const Part &part : parts_)
+        memcpy(static_cast<char *>(block.host)+part.offset,part.host,part.bytes);
+      hipError_t err=hipMemcpyAsync(block_.ptr,block.host,total_,hipMemcpyHostToDevice,stream);
+      if (err == hipSuccess)
+        err=hipEventRecord(block.ready,stream);
+      staging_release(device,block);
+      MH_HIP(err);
+      return MH_OK;
+    }
+  for (const Part &part : parts_)
+    MH_HIP(hipMemcpyAsync(static_cast<char *>(block_.ptr)+part.offset,part.host,part.bytes,
+      hipMemcpyHostToDevice,stream));
+  return MH_OK;
+}
+
 // Whole-image transfers between a pageable host block (the pixel cache) and device memory.
 // Page-locking the block in place (hipHostRegister) costs more than the transfer itself for a
 // one-shot call (measured: 8192^2 RGBA Q16 BlurImage on host buffers 58.8 ms against 44.1 ms), so the
