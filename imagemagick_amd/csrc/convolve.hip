@@ -1686,11 +1686,12 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
                   host[(size_t) v]=params.taps[K-1-v];
                   host_floats[v]=(float) params.taps[K-1-v];
                 }
-              Temp taps;
-              MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(double)));
+              const void *taps=nullptr;
+              MH_TRY(shared_table(src.device,src.stream,host.data(),host.size()*sizeof(double),&taps));
+              const double *taps64=static_cast<const double *>(taps);
               bool handled=false;
-              MH_TRY(launch_conv1d_mfma(src,dst,vertical,reinterpret_cast<const float *>(taps.as<double>()+K),K,
-                K-1-params.origin,roles.blend,MFMA_Q16,&handled,nullptr,0.0,0.0,taps.as<double>()));
+              MH_TRY(launch_conv1d_mfma(src,dst,vertical,reinterpret_cast<const float *>(taps64+K),K,
+                K-1-params.origin,roles.blend,MFMA_Q16,&handled,nullptr,0.0,0.0,taps64));
               if (handled)
                 return MH_OK;
             }

@@ -92,6 +92,12 @@ struct Temp
 // memory may go away immediately.
 MhStatus upload_table(Temp &dst,int device,hipStream_t stream,const void *host,size_t bytes);
 
+// A small read-only table (filter taps) that many calls share: looked up by content, uploaded on
+// the first use and kept on the device (a BlurImage call otherwise pays a copy and two queue
+// gaps, ~10 us, in front of a 0.43 ms kernel).  *device_ptr stays valid for work enqueued on
+// `stream` by this call.
+MhStatus shared_table(int device,hipStream_t stream,const void *host,size_t bytes,const void **device_ptr);
+
 // Several host tables as ONE device block and ONE host-to-device copy (a resize pass has ten
 // tables: ten stream-ordered copies cost 150-300 us of idle GPU between two kernels of a few
 // milliseconds).  add() the parts (the host memory must stay valid until upload()), upload(),

@@ -357,9 +357,10 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
       host[(size_t) v]=row->values[K-1-v];
       host_floats[v]=(float) row->values[K-1-v];
     }
-  Temp taps;
-  MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(double)));
-  return launch_blur_fused(src,dst,reinterpret_cast<const float *>(taps.as<double>()+K),taps.as<double>(),
+  const void *taps=nullptr;
+  MH_TRY(shared_table(src.device,src.stream,host.data(),host.size()*sizeof(double),&taps));
+  const double *taps64=static_cast<const double *>(taps);
+  return launch_blur_fused(src,dst,reinterpret_cast<const float *>(taps64+K),taps64,
     K,K-1-(int) row->x,roles.blend,handled,unsharp,gain,threshold);
 }
 

@@ -347,6 +347,67 @@ MhStatus upload_table(Temp &dst,int device,hipStream_t stream,const void *host,s
   return MH_OK;
 }
 
+MhStatus shared_table(int device,hipStream_t stream,const void *host,size_t bytes,const void **device_ptr)
+{
+  struct Entry
+  {
+    int device;
+    std::vector<unsigned char> content;
+    void *ptr;
+    hipEvent_t ready;
+    hipStream_t stream;
+  };
+  constexpr size_t kEntries=32;
+  // (never destroyed: the blocks belong to a runtime that may be gone at process exit)
+  static std::mutex &lock=*new std::mutex;
+  static std::vector<Entry> &entries=*new std::vector<Entry>;
+  std::lock_guard<std::mutex> guard(lock);
+  for (size_t i=0; i < entries.size(); i++)
+    if ((entries[i].device == device) && (entries[i].content.size() == bytes) &&
+        (memcmp(entries[i].content.data(),host,bytes) == 0))
+      {
+        Entry hit=std::move(entries[i]);
+        entries.erase(entries.begin()+(ptrdiff_t) i);
+        entries.insert(entries.begin(),std::move(hit));
+        if (entries[0].stream != stream)
+          MH_HIP(hipStreamWaitEvent(stream,entries[0].ready,0));
+        *device_ptr=entries[0].ptr;
+        return MH_OK;
+      }
+  DeviceGuard device_guard;
+  MH_HIP(device_guard.enter(device));
+  Entry e;
+  e.device=device;
+  e.content.assign(static_cast<const unsigned char *>(host),static_cast<const unsigned char *>(host)+bytes);
+  e.ptr=nullptr;
+  e.ready=nullptr;
+  e.stream=stream;
+  MH_HIP(hipMalloc(&e.ptr,bytes < 256 ? 256 : bytes));
+  // the entry owns the bytes: the pageable copy may be staged whenever the runtime likes
+  hipError_t err=hipMemcpyAsync(e.ptr,e.content.data(),bytes,hipMemcpyHostToDevice,stream);
+  if (err == hipSuccess)
+    err=hipEventCreateWithFlags(&e.ready,hipEventDisableTiming);
+  if (err == hipSuccess)
+    err=hipEventRecord(e.ready,stream);
+  if (err != hipSuccess)
+    {
+      (void) hipFree(e.ptr);
+      if (e.ready != nullptr)
+        (void) hipEventDestroy(e.ready);
+      MH_HIP(err);
+    }
+  *device_ptr=e.ptr;
+  entries.insert(entries.begin(),std::move(e));
+  if (entries.size() > kEntries)
+    {
+      // hipFree waits for the device: nothing can still read the evicted block
+      (void) hipFree(entries.back().ptr);
+      (void) hipEventDestroy(entries.back().ready);
+      entries.pop_back();
+    }
+  return MH_OK;
+}
+
 MhStatus TableBundle::upload(int device,hipStream_t stream)
 {
   if (total_ == 0)
