@@ -1,38 +1,19 @@
 // BlurImage's two passes in ONE launch (FAST precision, Q16 RGBA: alpha-weighted colour or
-// four plain channels).  MagickCore/effect.c:765-796 -> morphology.c:2811-2979 (row kernel)
+// four plain channels, RGB).  MagickCore/effect.c:765-796 -> morphology.c:2811-2979 (row kernel)
 // -> :2654-2807 (column kernel) with the Quantum-rounded intermediate of :4012-4022.
 //
 // The two launches of convolve_mfma.hip move the intermediate frame through HBM once in each
 // direction: half of all bytes of a blur.  Here a workgroup owns a strip of 64 pixel columns
 // and walks it downwards; the row pass's Quantum-rounded results go straight into an LDS ring
-// of 16*NQ rows in the column pass's operand format, and the column pass runs out of that
-// ring.  HBM sees the source once (plus the K-1 halo columns of a strip, which neighbouring
-// strips fetch at the same time: L2 / Infinity-Cache hits) and the result once.
+// in the column pass's operand format, and the column pass runs out of that ring.  HBM sees
+// the source once (plus the K-1 halo columns of a strip, which neighbouring strips fetch at the
+// same time: L2 / Infinity-Cache hits) and the result once.
 //
-// Both passes are the banded (Toeplitz) matrix product of convolve_mfma.hip on
-// v_mfma_f32_32x32x16_f16 with hi/lo-split f16 operands (same precision argument, same
-// epilogue; mfma_common.hpp):
-//
-//   row pass     entries e = 8*channel + row     (32 = 8 rows x 4 channels), 32 outputs along x
-//   column pass  entries e = 4*column + channel  (32 = 8 columns x 4 channels), 32 outputs along y
-//
-// The row pass's D layout (row = (reg&3)+8*(reg>>2)+4*(lane>>5), col = lane&31) then leaves a
-// lane with four CONSECUTIVE rows of one column for each channel: after the epilogue those four
-// results are split again and written as one 8-byte LDS store per channel and plane into the
-// column ring, whose filter axis (y) is contiguous.
-//
-// Schedule of a work item (strip, segment of output rows), NQ = ring groups of 16 rows:
-//   for g = 0 .. 2*(blocks-1)+NQ-1:
-//     stage    16 source rows x (64+16*NQ-32) columns -> staging planes (fetched one group ahead)
-//     row pass 2 row groups x 2 output groups = 4 tiles, one per wave -> ring group g mod NQ
-//     if g >= NQ-1 and g-(NQ-1) even:  column pass of output block (g-NQ+1)/2:
-//       8 column groups x 32 rows = 8 tiles, two per wave (interleaved accumulators) ->
-//       half-wave swap (v_permlane32_swap) -> 16-byte stores, a full 128-byte line per row and wave
-// Two barriers per group: X (staged) and Y (ring group written).  One wave per SIMD: nothing but
-// the wave's own instruction stream hides latency, so every MFMA chain is preceded by ALL its
-// operand reads (the compiler's own order keeps one chunk in flight and exposes the LDS latency
-// of each: 0.67 ms per 8192^2 blur against 0.xx ms this way).
-// LDS (K <= 81): ring 2 x 61.7 KB + staging 2 x 20 KB = 163,328 bytes, one workgroup per CU.
+// Both passes are the banded (Toeplitz) matrix product of convolve_mfma.hip with hi/lo-split f16
+// operands (same precision argument, same epilogue; mfma_common.hpp).  The first version of this
+// file used v_mfma_f32_32x32x16_f16 tiles with one wave per SIMD (0.67 ms per 8192^2 blur: every
+// dependent instruction waited out the ALU latency; removed in round 2c); the kernel below uses
+// 16x16x32 tiles and sixteen waves.
 #include "mh_internal.hpp"
 #include "device_common.hpp"
 #include "mfma_common.hpp"
@@ -88,347 +69,16 @@ struct BlurFusedArgs
 #define MH_FTRACE_MARK(id) do { } while (0)
 #endif
 
-// ds_read_b128 is served in four 16-lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32)
-// over 64 banks (MI355X_MICROARCH.md, LDS): the 16 operand lines of a group must hit 16
-// different 16-byte slots of a 256-byte bank row.  A line = channel*CH + unit*S halves,
-// CH = UNITS*S+PAD; entry -> (channel, unit) is e>>3,e&7 (channel major, the row pass) or
-// e&3,e>>2 (unit major, the column pass).
-static constexpr bool fused_reads_conflict_free(int S,int PAD,int units,bool channel_major)
-{
-  const int CH=units*S+PAD;
-  for (int g=0; g < 2; g++)
-    {
-      unsigned seen=0;
-      for (int i=0; i < 16; i++)
-        {
-          const int lane=g == 0 ? (i < 4 ? i : (i < 8 ? i+8 : i+12)) : (i < 8 ? i+4 : (i < 12 ? i+8 : i+16));
-          const int channel=channel_major ? lane >> 3 : lane & 3;
-          const int unit=channel_major ? lane & 7 : lane >> 2;
-          const int bytes=(channel*CH+unit*S)*2;
-          const unsigned slot=1u << ((bytes % 256)/16);
-          if ((seen & slot) != 0)
-            return false;
-          seen|=slot;
-        }
-    }
-  return true;
-}
-
-// smallest line stride S >= extent (multiple of 8 halves = 16 bytes) with a channel padding
-// that makes the operand reads conflict-free; encoded S*256+PAD
-static constexpr int fused_layout(int extent,int units,bool channel_major)
-{
-  for (int S=extent; S <= extent+64; S+=8)
-    for (int PAD=8; PAD <= 64; PAD+=8)
-      if (fused_reads_conflict_free(S,PAD,units,channel_major))
-        return S*256+PAD;
-  return extent*256+8;
-}
-
-template<int NQ>
-struct FusedGeometry
-{
-  static constexpr int COLS=64;                // strip width = outputs of a row-pass step
-  static constexpr int GROUP=16;               // rows per row-pass step = one ring group
-  static constexpr int BLOCK=32;               // output rows per column-pass step
-  static constexpr int RC=16*NQ;               // ring rows: 32 outputs + K-1 halo
-  static constexpr int XS=16*NQ+32;            // staged columns: 64 outputs + K-1 halo
-  static constexpr int SR=fused_layout(XS,GROUP,true)/256,PADR=fused_layout(XS,GROUP,true) % 256;
-  static constexpr int SC=fused_layout(RC,COLS,false)/256,PADC=fused_layout(RC,COLS,false) % 256;
-  static constexpr int CHR=GROUP*SR+PADR;      // halves per channel, staging planes
-  static constexpr int CHC=COLS*SC+PADC;       // halves per channel, ring planes
-  static constexpr int STAGE_PLANE=4*CHR,RING_PLANE=4*CHC;
-  static constexpr size_t ring_bytes=(size_t) 2*RING_PLANE*sizeof(_Float16);
-  static constexpr size_t stage_bytes=(size_t) 2*STAGE_PLANE*sizeof(_Float16);
-  static constexpr size_t lds_bytes=ring_bytes+stage_bytes;
-  static_assert(fused_reads_conflict_free(SR,PADR,GROUP,true),"staging layout with LDS bank conflicts");
-  static_assert(fused_reads_conflict_free(SC,PADC,COLS,false),"ring layout with LDS bank conflicts");
-  static_assert(lds_bytes <= 163840,"more than the 160 KiB of a CU");
-  static constexpr int GROUPS_PER_ROW=XS/4;    // staging work: 4 columns of one row
-  static constexpr int FETCH_GROUPS=GROUP*GROUPS_PER_ROW;
-  static constexpr int FETCH_ROUNDS=(FETCH_GROUPS+255)/256;
-};
-
-template<int NQ,int MODE>
-__global__ __launch_bounds__(256)
-void blur_fused_kernel(BlurFusedArgs args)
-{
-  static_assert((MODE == MFMA_BLEND4) || (MODE == MFMA_PLAIN4),"8-byte pixels");
-  typedef FusedGeometry<NQ> G;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  _Float16 *ring_hi=reinterpret_cast<_Float16 *>(smem_raw);
-  _Float16 *ring_lo=ring_hi+G::RING_PLANE;
-  _Float16 *stage_hi=ring_lo+G::RING_PLANE;
-  _Float16 *stage_lo=stage_hi+G::STAGE_PLANE;
-  const int tid=(int) threadIdx.x,lane=tid & 63;
-  const int wave=__builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n=lane & 31,half=lane >> 5;
-  const int K=args.ntaps;
-  const int W=args.columns,H=args.rows;
-
-  // work item: blocks of one XCD (blockIdx % 8) take neighbouring strips of one segment, so the
-  // halo columns two strips share are fetched into one L2
-  const int items=args.strips*args.segments;
-  const int item=((int) blockIdx.x & 7)*args.items_per_xcd+((int) blockIdx.x >> 3);
-  if (item >= items)
-    return;
-  const int segment=item/args.strips,strip=item-segment*args.strips;
-  const int x0=G::COLS*strip;
-  const int block_begin=segment*args.blocks_per_segment;
-  const int block_end=block_begin+args.blocks_per_segment < args.blocks ?
-    block_begin+args.blocks_per_segment : args.blocks;
-  const int nblocks=block_end-block_begin;
-  const int out_begin=G::BLOCK*block_begin;
-  const int in0=out_begin-args.shift;          // intermediate row held by ring group 0, row 0
-  const int xin0=x0-args.shift;                // source column of staging position 0
-  const int ngroups=2*(nblocks-1)+NQ;
-
-  // ---- Toeplitz operands (both passes use the same taps), staged through LDS
-  half8 t_hi[NQ],t_lo[NQ];
-  {
-    float *tap_lds=reinterpret_cast<float *>(stage_hi);
-    for (int j=tid; j < K; j+=256)
-      tap_lds[j]=args.taps[j];
-    __syncthreads();
-#pragma unroll
-    for (int q=0; q < NQ; q++)
-      toeplitz_operand(tap_lds,K,q,half,n,t_hi[q],t_lo[q]);
-  }
-
-  // ---- staging: thread -> (row, 4 consecutive columns) of the 16 x XS source window
-  uint2 raw[G::FETCH_ROUNDS][4];
-  auto fetch=[&](int g)
-  {
-#pragma unroll
-    for (int round=0; round < G::FETCH_ROUNDS; round++)
-      {
-        const int idx=tid+256*round;
-        if (idx < G::FETCH_GROUPS)               // wave-uniform: 256*round is a multiple of 64
-          {
-            const int row=idx/G::GROUPS_PER_ROW,xg=idx-row*G::GROUPS_PER_ROW;
-            int y=in0+G::GROUP*g+row;
-            y=y < 0 ? 0 : (y > H-1 ? H-1 : y);   // the intermediate's edge clamp (cache.c:2663-2679)
-#pragma unroll
-            for (int i=0; i < 4; i++)
-              {
-                int x=xin0+4*xg+i;
-                x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
-                raw[round][i]=*reinterpret_cast<const uint2 *>(args.src+pixel_index(y,W,x)*4);
-              }
-          }
-      }
-  };
-  auto stage=[&]()
-  {
-#pragma unroll
-    for (int round=0; round < G::FETCH_ROUNDS; round++)
-      {
-        const int idx=tid+256*round;
-        if (idx < G::FETCH_GROUPS)
-          {
-            const int row=idx/G::GROUPS_PER_ROW,xg=idx-row*G::GROUPS_PER_ROW;
-            f32x2 v[4][2];
-            quantum_to_samples<MODE>(raw[round],v);
-#pragma unroll
-            for (int c=0; c < 4; c++)
-              {
-                uint2 hi,lo;
-                split_f16_pair(v[c][0],hi.x,lo.x);
-                split_f16_pair(v[c][1],hi.y,lo.y);
-                const int at=c*G::CHR+row*G::SR+4*xg;
-                *reinterpret_cast<uint2 *>(stage_hi+at)=hi;
-                *reinterpret_cast<uint2 *>(stage_lo+at)=lo;
-              }
-          }
-      }
-  };
-
-  // row pass: wave = row group (8 rows) x output group (32 columns)
-  const int rmg=wave & 1,rng=wave >> 1;
-  const int row_entry=(n >> 3)*G::CHR+(8*rmg+(n & 7))*G::SR+32*rng+8*half;
-  // column pass: wave -> column groups 2*wave, 2*wave+1 (8 columns each); e = 4*column+channel
-  const int col_entry=(n & 3)*G::CHC+(n >> 2)*G::SC+8*half;
-
-  fetch(0);
-  for (int g=0; g < ngroups; g++)
-    {
-      // (the staging planes are free: every wave has passed barrier Y of group g-1)
-      stage();
-      if (g+1 < ngroups)
-        fetch(g+1);
-      __syncthreads();                           // X: staged; every wave is past the column pass of g-1
-      // ---- row pass of ring group g: all operand lines first, then the 3*NQ products
-      {
-        half8 a_hi[NQ],a_lo[NQ];
-#pragma unroll
-        for (int q=0; q < NQ; q++)
-          {
-            a_hi[q]=*reinterpret_cast<const half8 *>(stage_hi+row_entry+16*q);
-            a_lo[q]=*reinterpret_cast<const half8 *>(stage_lo+row_entry+16*q);
-          }
-        __builtin_amdgcn_sched_barrier(0);
-        floatx16 acc;
-#pragma unroll
-        for (int r=0; r < 16; r++)
-          acc[r]=0.0f;
-#pragma unroll
-        for (int q=0; q < NQ; q++)
-          {
-            acc=__builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[q],t_hi[q],acc,0,0,0);
-            acc=__builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[q],t_hi[q],acc,0,0,0);
-            acc=__builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[q],t_lo[q],acc,0,0,0);
-          }
-        // lane: column x = x0+32*rng+n, rows 8*rmg+4*half+i (i = 0..3); acc[4*channel+i]
-        uint2 quantum[4];
-#pragma unroll
-        for (int i=0; i < 4; i++)
-          {
-            const float sa=acc[12+i];
-            quantum[i]=sums_to_quantum<MODE>(acc[i],acc[4+i],acc[8+i],sa);
-            if constexpr (MODE == MFMA_BLEND4)
-              {
-                if (alpha_sum_is_ambiguous(sa))
-                  {
-                    const int x=x0+32*rng+n;
-                    int y=in0+G::GROUP*g+8*rmg+4*half+i;
-                    y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
-                    if (x < W)
-                      {
-                        const unsigned level=exact_alpha_level(args.src,pixel_index(y,W,0),1,W,x-args.shift,
-                          args.taps64,K);
-                        quantum[i].y=(quantum[i].y & 0xffffu) | (level << 16);
-                      }
-                  }
-              }
-          }
-        // the Quantum-rounded intermediate, as column-pass samples: pairs of consecutive rows
-        f32x2 v[4][2];
-        quantum_to_samples<MODE>(quantum,v);
-        const int slot=(g % NQ)*G::GROUP+8*rmg+4*half;
-        const int at0=(32*rng+n)*G::SC+slot;
-#pragma unroll
-        for (int c=0; c < 4; c++)
-          {
-            uint2 hi,lo;
-            split_f16_pair(v[c][0],hi.x,lo.x);
-            split_f16_pair(v[c][1],hi.y,lo.y);
-            *reinterpret_cast<uint2 *>(ring_hi+c*G::CHC+at0)=hi;
-            *reinterpret_cast<uint2 *>(ring_lo+c*G::CHC+at0)=lo;
-          }
-      }
-      __syncthreads();                           // Y: ring group g complete, staging reads done
-      if ((g >= NQ-1) && (((g-(NQ-1)) & 1) == 0))
-        {
-          // ---- column pass of output rows out_begin+32*block .. +32: this wave's two column
-          // groups side by side (independent accumulators), all operand lines first
-          const int block=(g-(NQ-1)) >> 1;
-          half8 a_hi[2][NQ],a_lo[2][NQ];
-          {
-            int group=(2*block) % NQ;            // ring group of chunk 0 (wave-uniform)
-#pragma unroll
-            for (int q=0; q < NQ; q++)
-              {
-#pragma unroll
-                for (int t=0; t < 2; t++)
-                  {
-                    const int at=col_entry+8*(2*wave+t)*G::SC+G::GROUP*group;
-                    a_hi[t][q]=*reinterpret_cast<const half8 *>(ring_hi+at);
-                    a_lo[t][q]=*reinterpret_cast<const half8 *>(ring_lo+at);
-                  }
-                group=group+1 == NQ ? 0 : group+1;
-              }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          floatx16 acc[2];
-#pragma unroll
-          for (int t=0; t < 2; t++)
-#pragma unroll
-            for (int r=0; r < 16; r++)
-              acc[t][r]=0.0f;
-#pragma unroll
-          for (int q=0; q < NQ; q++)
-            {
-              acc[0]=__builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][q],t_hi[q],acc[0],0,0,0);
-              acc[1]=__builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][q],t_hi[q],acc[1],0,0,0);
-              acc[0]=__builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[0][q],t_hi[q],acc[0],0,0,0);
-              acc[1]=__builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[1][q],t_hi[q],acc[1],0,0,0);
-              acc[0]=__builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[0][q],t_lo[q],acc[0],0,0,0);
-              acc[1]=__builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[1][q],t_lo[q],acc[1],0,0,0);
-            }
-          // lane (n, half): output row n, columns 8*cg+2*pg+half (pg = 0..3); acc[t][4*pg+channel].
-          // v_permlane32_swap exchanges the pg 0,1 pixels of the upper half-wave with the pg 2,3
-          // pixels of the lower one: a lane then owns two pairs of neighbouring pixels of its row
-          // (columns 0-1, 2-3 for half 0; 4-5, 6-7 for half 1) = two 16-byte stores; the two column
-          // groups of a wave make one full 128-byte line of each of the 32 rows.
-          const int y=out_begin+G::BLOCK*block+n;
-#pragma unroll
-          for (int t=0; t < 2; t++)
-            {
-              uint2 result[4];
-#pragma unroll
-              for (int pg=0; pg < 4; pg++)
-                result[pg]=sums_to_quantum<MODE>(acc[t][4*pg+0],acc[t][4*pg+1],acc[t][4*pg+2],acc[t][4*pg+3]);
-#pragma unroll
-              for (int pair=0; pair < 2; pair++)
-                {
-                  const auto sx=__builtin_amdgcn_permlane32_swap(result[pair].x,result[pair+2].x,false,false);
-                  const auto sy=__builtin_amdgcn_permlane32_swap(result[pair].y,result[pair+2].y,false,false);
-                  const uint4 value=make_uint4(sx[0],sy[0],sx[1],sy[1]);
-                  const int x=x0+8*(2*wave+t)+4*half+2*pair;
-                  if (y < H)
-                    {
-                      uint16_t *to=args.dst+pixel_index(y,W,x)*4;
-                      if (x+1 < W)
-                        *reinterpret_cast<uint4 *>(to)=value;
-                      else if (x < W)
-                        *reinterpret_cast<uint2 *>(to)=make_uint2(value.x,value.y);
-                    }
-                }
-            }
-        }
-    }
-}
-
-template<int NQ,int MODE>
-static MhStatus launch_fused_typed(const View &src,BlurFusedArgs &args)
-{
-  typedef FusedGeometry<NQ> G;
-  args.strips=(args.columns+G::COLS-1)/G::COLS;
-  args.blocks=(args.rows+G::BLOCK-1)/G::BLOCK;
-  // Cut the strips so that every CU gets a work item.  A segment recomputes NQ-2 ring groups
-  // (the K-1 halo rows of its first block), so it stays at least 8 blocks long.
-  const int cus=compute_units(src.device);
-  const int max_segments=args.blocks/8 > 1 ? args.blocks/8 : 1;
-  int segments=(cus+args.strips-1)/args.strips;
-  segments=segments < 1 ? 1 : (segments > max_segments ? max_segments : segments);
-  if (const char *e=getenv("MAGICKHIP_FUSED_SEGMENTS"))
-    segments=atoi(e) < 1 ? 1 : (atoi(e) > args.blocks ? args.blocks : atoi(e));
-  args.segments=segments;
-  args.blocks_per_segment=(args.blocks+segments-1)/segments;
-  args.segments=(args.blocks+args.blocks_per_segment-1)/args.blocks_per_segment;   // no empty segment
-  const int items=args.strips*args.segments;
-  args.items_per_xcd=(items+7)/8;
-  const size_t lds=G::lds_bytes;
-  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&blur_fused_kernel<NQ,MODE>),
-    hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
-  ProfileScope prof("blur_fused",src.stream);
-  hipLaunchKernelGGL((blur_fused_kernel<NQ,MODE>),dim3((unsigned) (8*args.items_per_xcd)),dim3(256),lds,
-    src.stream,args);
-  MH_HIP(hipGetLastError());
-  return MH_OK;
-}
-
 // ---------------------------------------------------------------------------------------------
-// Second form: the same walk on v_mfma_f32_16x16x32_f16 tiles with SIXTEEN waves per workgroup.
+// The walk on v_mfma_f32_16x16x32_f16 tiles with SIXTEEN waves per workgroup.
 //
-// The 32x32 form above keeps one wave on each SIMD (its operand registers leave room for no
-// more), and the counters show what that costs (profiles/r2b_*): the matrix pipe is busy 22 % of
-// the time, 28 % is spent at barriers and waitcnts, and half of all cycles go to the VALU
-// stream (conversions, epilogues, address arithmetic) issuing at ~7.6 cycles per instruction —
-// with a single wave on a SIMD every dependent instruction waits out the ALU latency and nothing
-// overlaps the MFMA chains.  16x16x32 tiles need a third of the operand registers (a 32-sample
-// chunk per instruction: three chunks cover the 79 taps' 94-sample band against seven 16-sample
-// chunks for a 32-output tile), so a wave fits in 128 VGPRs and four of them share a SIMD:
+// A 32x32x16 form keeps one wave on each SIMD (its operand registers leave room for no more),
+// and the counters showed what that costs (profiles/r2b_*): the matrix pipe busy 22 % of the
+// time, 28 % spent at barriers and waitcnts, and half of all cycles going to the VALU stream
+// (conversions, epilogues, address arithmetic) issuing at ~7.6 cycles per instruction.  16x16x32
+// tiles need a third of the operand registers (a 32-sample chunk per instruction: three chunks
+// cover the 79 taps' 94-sample band against seven 16-sample chunks for a 32-output tile), so a
+// wave fits in 128 VGPRs and four of them share a SIMD:
 //
 //   row pass     entries e = 4*row + channel    (16 = 4 rows x 4 channels), 16 outputs along x:
 //                16 tiles per 16-row group, one per wave.  D (row = 4*(lane>>4)+reg, col =
@@ -933,9 +583,8 @@ MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_dev
   if ((src.columns >= (1u << 24)) || (src.rows >= (1u << 24)) ||
       ((unsigned long long) src.columns*src.rows >= (1ull << 32)))
     return MH_OK;                                // pixel_index()
-  const int nq=(ntaps+31+15)/16;                 // 32 outputs + K-1 halo, in 16-sample chunks
-  if (nq > 7)
-    return MH_OK;
+  if (ntaps > 81)
+    return MH_OK;                                // three 32-sample chunks hold 94 band slots
   BlurFusedArgs args;
   args.trace=nullptr;
   args.src=static_cast<const uint16_t *>(src.pixels);
@@ -952,31 +601,14 @@ MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_dev
     args.threshold=level > 131072.0 ? 131072 : (level < 0.0 ? 0 : (int) level);
   }
   *handled=true;
-  if ((getenv("MAGICKHIP_FUSED_32") == nullptr) || unsharp || (src.channels != 4))
-    {
-      const int nc=(ntaps+15+31)/32;             // 16 outputs + K-1 halo, in 32-sample chunks
-      if (nc == 1)
-        return launch_fused16<1>(src,args,blend,unsharp);
-      if (nc == 2)
-        return launch_fused16<2>(src,args,blend,unsharp);
-      if (nc == 3)
-        return launch_fused16<3>(src,args,blend,unsharp);
-    }
-  if (unsharp || (src.channels != 4))
-    {
-      *handled=false;                            // wider kernels, RGB: row pass + (fused) column pass
-      return MH_OK;
-    }
-#define MH_NQ(NQV) \
-  case NQV: \
-    return blend ? launch_fused_typed<NQV,MFMA_BLEND4>(src,args) : launch_fused_typed<NQV,MFMA_PLAIN4>(src,args);
-  switch (nq < 3 ? 3 : nq)
-  {
-    MH_NQ(3) MH_NQ(4) MH_NQ(5) MH_NQ(6) MH_NQ(7)
-    default: break;
-  }
-#undef MH_NQ
-  *handled=false;
+  const int nc=(ntaps+15+31)/32;                 // 16 outputs + K-1 halo, in 32-sample chunks
+  if (nc == 1)
+    return launch_fused16<1>(src,args,blend,unsharp);
+  if (nc == 2)
+    return launch_fused16<2>(src,args,blend,unsharp);
+  if (nc == 3)
+    return launch_fused16<3>(src,args,blend,unsharp);
+  *handled=false;                                // wider kernels: row pass + (fused) column pass
   return MH_OK;
 }
 
