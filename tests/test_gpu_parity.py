@@ -103,6 +103,22 @@ def test_blur_fast_precision_within_one_level(im, refmod):
     assert exact_fraction > 0.95
 
 
+def test_blur_fast_tap_tables_are_kept_by_content(im, refmod):
+    """The FAST blur keeps its tap tables on the device, looked up by content (runtime.cpp,
+    shared_table: 32 entries): more distinct kernels than entries, then the first ones again
+    (evicted and rebuilt), every result against the reference."""
+    px = make_pixels(48, 96, 4, Q16)
+    dev, ref = run_pair(im, refmod, px)
+    sigmas = [0.5 + 0.11 * i for i in range(40)] + [0.5, 0.61, 4.79]
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        for sigma in sigmas:
+            got = im.blur_image(dev, 0.0, sigma).numpy()
+            assert_parity(got, ref.blur(0.0, sigma).numpy(), False, "fast blur sigma %g" % sigma)
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+
+
 @pytest.mark.parametrize("shape", [(5, 7), (1, 40), (40, 1), (33, 70), (64, 16), (17, 129), (130, 31)])
 @pytest.mark.parametrize("sigma", [0.8, 2.0, 6.5])
 def test_blur_fast_odd_shapes(im, refmod, shape, sigma):
