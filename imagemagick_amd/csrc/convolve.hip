@@ -1391,7 +1391,11 @@ static MhStatus launch_tri(const View &src,const View &dst,bool vertical,
   const Conv1DParams &p,const Roles &roles,unsigned long long *changed)
 {
   typedef typename A::T T;
-  constexpr int WAVES=4;
+  // fp64 policies: eight waves share a staged strip (142 rows for 79 taps: 73 KB, two workgroups
+  // per CU): the K-1 halo rows are staged per 64 output rows instead of per 32 and every SIMD
+  // holds four waves instead of two — conv_column 1.43 -> 1.21 ms on 8192^2 (Tie64).  The f32
+  // policy measured slower with 8 and 16 waves and stays at four.
+  constexpr int WAVES=sizeof(T) == 8 ? 8 : 4;
   const int K=p.ntaps;
   std::vector<T> host((size_t) K);
   for (int v=0; v < K; v++)
