@@ -1386,16 +1386,11 @@ void conv_row_tri(Conv1DArgs args)
     }
 }
 
-template<typename Q,int C,bool BLEND,class A,int R,int U>
-static MhStatus launch_tri(const View &src,const View &dst,bool vertical,
+template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES>
+static MhStatus launch_tri_waves(const View &src,const View &dst,bool vertical,
   const Conv1DParams &p,const Roles &roles,unsigned long long *changed)
 {
   typedef typename A::T T;
-  // fp64 policies: eight waves share a staged strip (142 rows for 79 taps: 73 KB, two workgroups
-  // per CU): the K-1 halo rows are staged per 64 output rows instead of per 32 and every SIMD
-  // holds four waves instead of two — conv_column 1.43 -> 1.21 ms on 8192^2 (Tie64).  The f32
-  // policy measured slower with 8 and 16 waves and stays at four.
-  constexpr int WAVES=sizeof(T) == 8 ? 8 : 4;
   const int K=p.ntaps;
   std::vector<T> host((size_t) K);
   for (int v=0; v < K; v++)
@@ -1456,6 +1451,24 @@ static MhStatus launch_tri(const View &src,const View &dst,bool vertical,
     }
   MH_HIP(hipGetLastError());
   return MH_OK;
+}
+
+template<typename Q,int C,bool BLEND,class A,int R,int U>
+static MhStatus launch_tri(const View &src,const View &dst,bool vertical,
+  const Conv1DParams &p,const Roles &roles,unsigned long long *changed)
+{
+  typedef typename A::T T;
+  // fp64 column pass: eight waves share a staged strip when it still fits twice per CU (142
+  // rows for 79 taps: 73 KB): the K-1 halo rows are staged per 64 output rows instead of per 32
+  // and every SIMD holds four waves instead of two — conv_column 1.43 -> 1.21 ms on 8192^2
+  // (Tie64).  The f32 policy measured slower with 8 and 16 waves and stays at four.
+  if ((sizeof(T) == 8) && vertical)
+    {
+      const size_t table_bytes=A::taps_in_lds ? (((size_t) p.ntaps*sizeof(T)+15u) & ~(size_t) 15u) : 0;
+      if (table_bytes+(size_t) (8*R+p.ntaps-1)*64*C*sizeof(Q) <= 80u*1024u)
+        return launch_tri_waves<Q,C,BLEND,A,R,U,8>(src,dst,vertical,p,roles,changed);
+    }
+  return launch_tri_waves<Q,C,BLEND,A,R,U,4>(src,dst,vertical,p,roles,changed);
 }
 
 template<class A,int R,int U>
