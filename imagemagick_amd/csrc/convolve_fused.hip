@@ -18,6 +18,7 @@
 #include "device_common.hpp"
 #include "mfma_common.hpp"
 #include <cstdlib>
+#include <type_traits>
 #include <cstdio>
 #include <string>
 #include <vector>
@@ -364,29 +365,43 @@ void blur_fused16_kernel(BlurFusedArgs args)
               const unsigned group=wide < wide-(unsigned) G::NR ? wide : wide-(unsigned) G::NR;
               chunk_at[c]=col_entry+GROUP_STRIDE*(int) group;
             }
+          // the wave's tiles side by side: their MFMA chains are independent and interleave
+          auto column_tiles=[&](auto count)
+          {
+            constexpr int N=decltype(count)::value;
+            floatx4 acc[N > 0 ? N : 1];
 #pragma unroll
-          for (int t=0; t < CT; t++)
-            if (t < ctiles)
+            for (int t=0; t < N; t++)
+              acc[t]=floatx4{0.0f,0.0f,0.0f,0.0f};
+#pragma unroll
+            for (int c=0; c < NC; c++)
               {
-                floatx4 acc={0.0f,0.0f,0.0f,0.0f};
-                half8 a_hi[NC],a_lo[NC];
+                half8 a_hi[N > 0 ? N : 1],a_lo[N > 0 ? N : 1];
 #pragma unroll
-                for (int c=0; c < NC; c++)
+                for (int t=0; t < N; t++)
                   {
-                    a_hi[c]=*reinterpret_cast<const half8 *>(ring_hi+chunk_at[c]+4*t*G::SC);
-                    a_lo[c]=*reinterpret_cast<const half8 *>(ring_lo+chunk_at[c]+4*t*G::SC);
+                    a_hi[t]=*reinterpret_cast<const half8 *>(ring_hi+chunk_at[c]+4*t*G::SC);
+                    a_lo[t]=*reinterpret_cast<const half8 *>(ring_lo+chunk_at[c]+4*t*G::SC);
                   }
 #pragma unroll
-                for (int c=0; c < NC; c++)
-                  {
-                    acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_hi[c],acc,0,0,0);
-                    acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[c],t_hi[c],acc,0,0,0);
-                    acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[c],t_lo[c],acc,0,0,0);
-                  }
-                // lane (n, kq): the four channels (registers) of pixel (column 4*tile+kq, row n)
-                uint2 result=sums_to_quantum<SAMPLES>(acc[0],acc[1],acc[2],acc[3]);
-                out_tile[n*G::OUT_STRIDE+4*(ctile0+t)+kq]=result;
+                for (int t=0; t < N; t++)
+                  acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[t],t_hi[c],acc[t],0,0,0);
+#pragma unroll
+                for (int t=0; t < N; t++)
+                  acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[t],t_hi[c],acc[t],0,0,0);
+#pragma unroll
+                for (int t=0; t < N; t++)
+                  acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[t],t_lo[c],acc[t],0,0,0);
               }
+            // lane (n, kq): the four channels (registers) of pixel (column 4*tile+kq, row n)
+#pragma unroll
+            for (int t=0; t < N; t++)
+              out_tile[n*G::OUT_STRIDE+4*(ctile0+t)+kq]=sums_to_quantum<SAMPLES>(acc[t][0],acc[t][1],acc[t][2],acc[t][3]);
+          };
+          if (ctiles == CT)
+            column_tiles(std::integral_constant<int,CT>{});
+          else if (ctiles == CT-1)
+            column_tiles(std::integral_constant<int,CT-1>{});
         }
       MH_FTRACE_MARK(4);
       __syncthreads();                           // X: staged; the column pass's pixels are in out_tile
