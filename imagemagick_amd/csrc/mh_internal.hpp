@@ -97,6 +97,8 @@ MhStatus upload_table(Temp &dst,int device,hipStream_t stream,const void *host,s
 // gaps, ~10 us, in front of a 0.43 ms kernel).  *device_ptr stays valid for work enqueued on
 // `stream` by this call.
 MhStatus shared_table(int device,hipStream_t stream,const void *host,size_t bytes,const void **device_ptr);
+void release_shared_tables();       // MhTerminus
+void release_resize_tables();       // the resize launchers' device-side tables (resize.hip)
 
 // Several host tables as ONE device block and ONE host-to-device copy (a resize pass has ten
 // tables: ten stream-ordered copies cost 150-300 us of idle GPU between two kernels of a few

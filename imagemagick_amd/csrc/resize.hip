@@ -1308,14 +1308,24 @@ static MhStatus build_pass_tables(PassTables &p,const TapTable &table,bool verti
 
 // cached by the serial number of a shared contribution table (resize_filter.cpp); tables built
 // for one call (serial 0: the MagickCore shim's callback filters) are not kept
+struct PassTablesEntry { unsigned long long serial; int device; bool vertical; size_t weight_bytes; std::shared_ptr<PassTables> tables; };
+// (never destroyed: at process exit the runtime the device blocks belong to may be gone)
+static std::mutex &pass_tables_lock() { static std::mutex &m=*new std::mutex; return m; }
+static std::vector<PassTablesEntry> &pass_tables() { static std::vector<PassTablesEntry> &v=*new std::vector<PassTablesEntry>; return v; }
+
+void release_resize_tables()
+{
+  std::lock_guard<std::mutex> guard(pass_tables_lock());
+  pass_tables().clear();
+}
+
 template<typename T>
 static MhStatus acquire_pass_tables(std::shared_ptr<PassTables> *out,const TapTable &table,bool vertical,
   int device,hipStream_t stream)
 {
-  struct Entry { unsigned long long serial; int device; bool vertical; size_t weight_bytes; std::shared_ptr<PassTables> tables; };
-  // (never destroyed: at process exit the runtime the device blocks belong to may be gone)
-  static std::mutex &lock=*new std::mutex;
-  static std::vector<Entry> &entries=*new std::vector<Entry>;
+  typedef PassTablesEntry Entry;
+  std::mutex &lock=pass_tables_lock();
+  std::vector<Entry> &entries=pass_tables();
   constexpr size_t kEntries=8;
   if (table.serial != 0)
     {

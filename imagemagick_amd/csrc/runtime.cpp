@@ -347,21 +347,37 @@ MhStatus upload_table(Temp &dst,int device,hipStream_t stream,const void *host,s
   return MH_OK;
 }
 
+namespace {
+struct SharedTable
+{
+  int device;
+  std::vector<unsigned char> content;
+  void *ptr;
+  hipEvent_t ready;
+  hipStream_t stream;
+};
+// (never destroyed: the blocks belong to a runtime that may be gone at process exit)
+std::mutex &shared_tables_lock() { static std::mutex &m=*new std::mutex; return m; }
+std::vector<SharedTable> &shared_tables() { static std::vector<SharedTable> &v=*new std::vector<SharedTable>; return v; }
+}
+
+void release_shared_tables()
+{
+  std::lock_guard<std::mutex> guard(shared_tables_lock());
+  for (SharedTable &e : shared_tables())
+    {
+      (void) hipFree(e.ptr);
+      (void) hipEventDestroy(e.ready);
+    }
+  shared_tables().clear();
+}
+
 MhStatus shared_table(int device,hipStream_t stream,const void *host,size_t bytes,const void **device_ptr)
 {
-  struct Entry
-  {
-    int device;
-    std::vector<unsigned char> content;
-    void *ptr;
-    hipEvent_t ready;
-    hipStream_t stream;
-  };
+  typedef SharedTable Entry;
   constexpr size_t kEntries=32;
-  // (never destroyed: the blocks belong to a runtime that may be gone at process exit)
-  static std::mutex &lock=*new std::mutex;
-  static std::vector<Entry> &entries=*new std::vector<Entry>;
-  std::lock_guard<std::mutex> guard(lock);
+  std::vector<Entry> &entries=shared_tables();
+  std::lock_guard<std::mutex> guard(shared_tables_lock());
   for (size_t i=0; i < entries.size(); i++)
     if ((entries[i].device == device) && (entries[i].content.size() == bytes) &&
         (memcmp(entries[i].content.data(),host,bytes) == 0))
@@ -723,6 +739,8 @@ MH_API void MhTerminus(void)
   if (r.init_status != MH_OK)
     return;
   drain_profile();
+  release_shared_tables();
+  release_resize_tables();
   pool_trim();
   staging_trim();
   release_color_tables();
