@@ -3,12 +3,12 @@
 CPU reference time).  Shapes, kernel lengths and operators are drawn at random, every result
 is compared with the reference: FAST blur / unsharp within +-1 (unsharp: 1+gain off the threshold
 edge), EXACT and the morphology / histogram operators bit-identical.
-   python tools/stress_parity.py [seconds] [seed]"""
+   python tests/stress_parity.py [seconds] [seed]"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repository root
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
