@@ -245,7 +245,7 @@ def blur_mode(im, torch, image, sigma, precision, reps):
         holder["o"] = im.blur_image(image, 0.0, sigma)
     sec = timed(torch, call, reps)
     prof = kernel_profile(im, call, max(2, reps // 2))
-    conv = {k: v for k, v in prof.items() if k.startswith("conv_") or k == "blur_fused"}
+    conv = {k: v for k, v in prof.items() if k.startswith("conv_") or k.startswith("blur_fused")}
     dominant = max(conv, key=lambda k: conv[k]["avg_ms"])
     frame = pixels * 8.0
     # algorithmic bytes per launch: a pass (or the fused operator) reads the frame once and writes it once
@@ -254,7 +254,7 @@ def blur_mode(im, torch, image, sigma, precision, reps):
            "tolerance": "bit-identical to the reference CPU path" if precision == "exact" else
                         "per pass within +-1 Quantum level of the reference CPU path; two-pass result +-1 on the "
                         "full-size frame (tests/test_gpu_fullsize.py), bound +-2 (DESIGN.md section 2)",
-           "launches": "one (row + column pass fused, intermediate in LDS)" if dominant == "blur_fused"
+           "launches": "one (row + column pass fused, intermediate in LDS)" if dominant.startswith("blur_fused")
                        else "two (row pass, column pass; intermediate through HBM)",
            "roofline": roofline(dominant, 2.0 * frame, conv[dominant]["avg_ms"],
                                 ("exact:" if precision == "exact" else "") + dominant),
@@ -635,7 +635,7 @@ def main():
         if args.config == "c2":
             n = image.rows
             frame = float(n) * n * 8.0
-            conv = {k: v for k, v in prof.items() if k.startswith("conv_") or k == "blur_fused"}
+            conv = {k: v for k, v in prof.items() if k.startswith("conv_") or k.startswith("blur_fused")}
             if conv:
                 dominant = max(conv, key=lambda k: conv[k]["avg_ms"])
                 # algorithmic bytes of one launch: the frame read once and written once (the fused
@@ -646,7 +646,7 @@ def main():
                 taps = 79 if abs(args.sigma - 10.0) < 1e-9 else None
                 if taps:
                     # the arithmetic beside the stream: matrix cores in FAST, fp64 vector ALU in EXACT
-                    passes = 2.0 if dominant == "blur_fused" else 1.0
+                    passes = 2.0 if dominant.startswith("blur_fused") else 1.0
                     flops = passes * float(n) * n * 4 * taps * 2.0
                     mfma = args.precision == "fast" and os.environ.get("MAGICKHIP_NO_MFMA") is None
                     peak = 2500.0 if mfma else (157.3 if args.precision == "fast" else 78.6)

@@ -141,6 +141,7 @@ PROTOTYPES = [
     ("MhSetProfileEnabled", ctypes.c_int, [ctypes.c_int]),
     ("MhGetProfileRecords", ctypes.c_size_t, [_P(MhKernelProfileRecord), ctypes.c_size_t]),
     ("MhResetProfileRecords", None, []),
+    ("MhExactBlurRecomputed", ctypes.c_ulonglong, [ctypes.c_int]),
     ("MhAcquireKernelInfo", _P(MhKernelInfo), [ctypes.c_char_p]),
     ("MhDestroyKernelInfo", _P(MhKernelInfo), [_P(MhKernelInfo)]),
     ("MhCloneKernelInfo", _P(MhKernelInfo), [_P(MhKernelInfo)]),

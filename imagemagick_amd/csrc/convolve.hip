@@ -25,44 +25,7 @@
 
 namespace mh {
 
-// One output sample of a 1-D Convolve pass exactly as the reference forms it: the kernel walked
-// backwards over the edge-clamped window, every multiply and add separately rounded
-// (morphology.c:2743-2776 column path, :2941-2977 row path), PerceptibleReciprocal, ClampToQuantum.
-// taps: reversed doubles (taps[v] multiplies the input at o-shift+v).  Used by the Tie64 policy
-// for the few results its fused sums cannot decide.
-template<typename Q,int C,bool BLEND>
-static __device__ __noinline__ Q conv1d_reference_sample(const Q *src,int W,int H,bool vertical,int x,int y,
-  int c,const double *taps,int K,int shift,double bias)
-{
-  double pixel=bias,gamma=0.0;
-  const bool weighted=BLEND && (c != C-1);
-  for (int v=0; v < K; v++)
-    {
-      int xx=x,yy=y;
-      if (vertical)
-        {
-          yy=y-shift+v;
-          yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
-        }
-      else
-        {
-          xx=x-shift+v;
-          xx=xx < 0 ? 0 : (xx > W-1 ? W-1 : xx);
-        }
-      const Q *p=src+((size_t) yy*(size_t) W+(size_t) xx)*C;
-      if (weighted)
-        {
-          const double alpha=kQS*(double) p[C-1];
-          pixel+=alpha*taps[v]*(double) p[c];
-          gamma+=alpha*taps[v];
-        }
-      else
-        pixel+=taps[v]*(double) p[c];
-    }
-  if (weighted)
-    pixel=perceptible_reciprocal(gamma)*pixel;
-  return QuantumOps<Q>::clamp(pixel);
-}
+// (conv1d_reference_sample: device_common.hpp)
 
 // finish()'s fallback for policies without a tie check
 struct NoReference

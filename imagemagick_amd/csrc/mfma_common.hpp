@@ -234,4 +234,41 @@ static constexpr int fused16_layout(int extent,int units,bool channel_major,bool
 }
 
 
+// LDS geometry of the fused BlurImage walk on 16x16 tiles (convolve_fused.hip,
+// convolve_fused_exact.hip): a strip of 64 columns, groups of 16 rows, a ring of NR groups.
+template<int NC>
+struct Fused16Geometry
+{
+  static constexpr int COLS=64;                // strip width
+  static constexpr int GROUP=16;               // rows per iteration: one ring group, one output block
+  static constexpr int NG=2*NC;                // ring groups a 16-output tile reads: 32*NC rows
+  static constexpr int NR=NG+1;                // ring groups held
+  static constexpr int RC=GROUP*NR;            // ring rows
+  static constexpr int XS=32*NC+48;            // staged columns: 64 outputs + band
+  static constexpr bool ROW_CHANNEL_MAJOR=false;  // row pass entries e = 4*row + channel
+  static constexpr int SR=fused16_layout(XS,GROUP,ROW_CHANNEL_MAJOR,false)/256,PADR=fused16_layout(XS,GROUP,ROW_CHANNEL_MAJOR,false) % 256;
+  // Ring plane of a channel: [8-row octet][column][8 rows].  A column-pass lane's 8 operand rows
+  // are one 16-byte unit; the 16 lanes of a ds_read_b128 group (4 columns x 4 channels) land in 16
+  // different slots of a bank row when the channel stride is 4 units mod 16 (PADC = 32 halves);
+  // the row pass's 8-byte stores (16 consecutive columns per lane group) are 2-way conflicted.
+  // (Round 2b kept a column's rows in one line of SC halves: its stores were 4-way conflicted —
+  // SQ_LDS_BANK_CONFLICT 63 % of the LDS cycles, 385 of them per iteration, right in front of
+  // barrier Y.)
+  static constexpr int OB=COLS*8;              // halves per octet block
+  static constexpr int SC=8,PADC=32;
+  static constexpr int CHR=GROUP*SR+PADR;
+  static constexpr int CHC=(RC/8)*OB+PADC;
+  static constexpr int STAGE_PLANE=4*CHR,RING_PLANE=4*CHC;
+  static constexpr size_t planes_bytes=(size_t) 2*(STAGE_PLANE+RING_PLANE)*sizeof(_Float16);
+  // the column pass's 16 x 64 result pixels on their way to row-contiguous stores; 65 pixels per
+  // row: the 16 rows a quarter-wave writes fall into 16 different bank pairs
+  static constexpr int OUT_STRIDE=COLS+1;
+  static constexpr size_t lds_bytes=planes_bytes+(size_t) GROUP*OUT_STRIDE*sizeof(uint2);
+  static_assert(lds_bytes <= 163840,"more than the 160 KiB of a CU");
+  static constexpr int GROUPS_PER_ROW=XS/4;
+  static constexpr int FETCH_GROUPS=GROUP*GROUPS_PER_ROW;
+  static_assert(FETCH_GROUPS <= 1024,"one staging round");
+};
+
+
 } // namespace mh

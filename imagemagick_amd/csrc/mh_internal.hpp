@@ -230,6 +230,16 @@ MhStatus launch_conv2d_mfma(const View &src,const View &dst,const MhKernelInfo *
 MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_device,
   const double *taps64_device,int ntaps,int shift,bool blend,bool *handled,bool unsharp=false,
   double gain=0.0,double threshold=0.0);
+// The same walk with an exact-integer row pass (convolve_fused_exact.hip): taps = HOST doubles in
+// the reversed walk, all positive.  exact_column = true: both passes exact, the result is
+// bit-identical to the reference (MH_PRECISION_EXACT); false: exact row pass + f16 column pass,
+// within +-1 level by construction (MH_PRECISION_FAST).  recomputed_device (optional): a device
+// counter that receives the number of samples recomputed in the reference's operation order.
+constexpr int kExactDigits=5;            // balanced signed 8-bit digits of a fixed-point tap
+constexpr int kExactDigitPitch=96;       // digits of one weight, padded (K <= 81)
+MhStatus launch_blur_fused_exact(const View &src,const View &dst,const double *taps,int ntaps,int shift,
+  bool blend,bool exact_column,bool *handled,bool unsharp=false,double gain=0.0,double threshold=0.0,
+  unsigned long long *recomputed_device=nullptr);
 // UnsharpMaskImage's column pass + epilogue in one launch: rows = the row pass's result,
 // original = the unblurred frame (effect.c:4343-4372)
 MhStatus launch_conv1d_unsharp(const View &rows,const View &dst,const View &original,

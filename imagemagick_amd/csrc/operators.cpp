@@ -322,18 +322,16 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
   const Roles &roles,double bias,bool *handled,bool unsharp=false,double gain=0.0,double threshold=0.0)
 {
   *handled=false;
-  if ((precision() != MH_PRECISION_FAST) || (src.quantum != MH_QUANTUM_U16) ||
-      ((src.channels != 4) && (src.channels != 3)) ||
-      (roles.copy_mask != 0) || (bias != 0.0) || (getenv("MAGICKHIP_NO_MFMA") != nullptr) ||
-      (getenv("MAGICKHIP_NO_FUSED_BLUR") != nullptr))
+  // (switches for tests and A/B runs; four getenv calls cost well under a microsecond)
+  const bool no_mfma=getenv("MAGICKHIP_NO_MFMA") != nullptr;
+  const bool no_fused=getenv("MAGICKHIP_NO_FUSED_BLUR") != nullptr;
+  const bool no_exact_mfma=getenv("MAGICKHIP_NO_EXACT_MFMA") != nullptr;
+  const bool fused_rgb=getenv("MAGICKHIP_FUSED_RGB") != nullptr;
+  const bool exact=precision() == MH_PRECISION_EXACT;
+  if ((src.quantum != MH_QUANTUM_U16) || ((src.channels != 4) && (src.channels != 3)) ||
+      (roles.copy_mask != 0) || (bias != 0.0) || no_mfma || no_fused || (exact && no_exact_mfma))
     return MH_OK;
   if (roles.blend && ((roles.alpha != 3) || (src.channels != 4)))
-    return MH_OK;
-  // RGB (6-byte pixels): the one launch is measured level with the two matrix-core launches
-  // for BlurImage (0.68 against 0.67 ms at 8192^2: its 6-byte loads and stores are narrower)
-  // and ahead of them for UnsharpMaskImage (0.85 against 0.95 ms), so only the latter takes it
-  // by default; MAGICKHIP_FUSED_RGB=1 sends both
-  if ((src.channels == 3) && !unsharp && (getenv("MAGICKHIP_FUSED_RGB") == nullptr))
     return MH_OK;
   const MhKernelInfo *row=kernel,*column=kernel->next;
   if ((column == nullptr) || (column->next != nullptr) || (row->height != 1) || (column->width != 1) ||
@@ -349,6 +347,28 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
       if (roles.blend && (row->values[v] < 0.0))
         return MH_OK;
     }
+  // The exact-integer row pass on the matrix cores (convolve_fused_exact.hip), positive taps:
+  // EXACT = both passes exact, bit-identical to the reference; FAST = exact row pass + f16
+  // column pass, +-1 level by construction.  MAGICKHIP_NO_EXACT_MFMA=1 keeps round 2's paths
+  // (EXACT: the fp64 vector kernels; FAST: f16 products in both passes).
+  if (!no_exact_mfma)
+    {
+      std::vector<double> reversed((size_t) K);
+      for (int v=0; v < K; v++)
+        reversed[(size_t) v]=row->values[K-1-v];
+      MH_TRY(launch_blur_fused_exact(src,dst,reversed.data(),K,K-1-(int) row->x,roles.blend,exact,handled,
+        unsharp,gain,threshold,nullptr));
+      if (*handled)
+        return MH_OK;
+    }
+  if (exact)
+    return MH_OK;                                // the fp64 vector kernels (launch_conv1d)
+  // RGB (6-byte pixels): the one f16 launch is measured level with the two matrix-core launches
+  // for BlurImage (0.68 against 0.67 ms at 8192^2: its 6-byte loads and stores are narrower)
+  // and ahead of them for UnsharpMaskImage (0.85 against 0.95 ms), so only the latter takes it
+  // by default; MAGICKHIP_FUSED_RGB=1 sends both
+  if ((src.channels == 3) && !unsharp && !fused_rgb)
+    return MH_OK;
   // one table: K doubles, then K floats; both in the reversed walk of morphology.c:2746
   std::vector<double> host((size_t) K+((size_t) K+1)/2);
   float *host_floats=reinterpret_cast<float *>(host.data()+K);
@@ -837,7 +857,7 @@ static MhStatus unsharp_fused(const View &src,const View &dst,const MhKernelInfo
 {
   *fused=false;
   const MhKernelInfo *horizontal=kernels,*vertical=kernels != nullptr ? kernels->next : nullptr;
-  if ((precision() != MH_PRECISION_FAST) || (src.quantum != MH_QUANTUM_U16) ||
+  if ((src.quantum != MH_QUANTUM_U16) ||
       ((src.channels != 4) && (src.channels != 3)) ||
       (src.columns < 2) || (getenv("MAGICKHIP_NO_FUSED_UNSHARP") != nullptr) ||
       (getenv("MAGICKHIP_NO_MFMA") != nullptr) ||
@@ -852,6 +872,8 @@ static MhStatus unsharp_fused(const View &src,const View &dst,const MhKernelInfo
   MH_TRY(fused_blur(src,dst,kernels,roles,0.0,fused,true,gain,threshold));
   if (*fused)
     return MH_OK;
+  if (precision() != MH_PRECISION_FAST)
+    return MH_OK;                                // EXACT: blur + unsharp_epilogue
   if (src.channels != 4)
     return MH_OK;                                // the two-launch form copies 8-byte pixels out
   View rows=src;

@@ -219,6 +219,12 @@ MH_API int MhSetProfileEnabled(int enabled);      /* SetOpenCLKernelProfileEnabl
 MH_API size_t MhGetProfileRecords(MhKernelProfileRecord *records,size_t capacity);
 MH_API void MhResetProfileRecords(void);
 
+/* Diagnostics of the exact-integer blur (convolve_fused_exact.hip): the number of samples whose
+   level the integer sums' error bound could not decide and that were recomputed in the
+   reference's own operation order (morphology.c:2746-2764).  enable != 0 starts counting on the
+   current device (the counter is read and reset by every call); returns the count so far. */
+MH_API unsigned long long MhExactBlurRecomputed(int enable);
+
 /* ------------------------------------------------------ kernels and filters */
 
 /* KernelInfoType, MagickCore/morphology.h:30-70 (same order) */

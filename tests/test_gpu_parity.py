@@ -205,11 +205,11 @@ def test_blur_and_unsharp_fast_rgb_single_launch(im, refmod, shape, sigma, monke
     try:
         launched = set(bench.kernel_profile(im, lambda: holder.update(b=im.blur_image(dev, 0.0, sigma)), 1))
         if shape[1] >= 2 and shape[0] >= 2:
-            assert launched == {"blur_fused"}, launched
+            assert launched == {"blur_fused_exact_row"}, launched
         launched = set(bench.kernel_profile(
             im, lambda: holder.update(u=im.unsharp_mask_image(dev, 0.0, sigma, 1.5, 0.01)), 1))
         if shape[1] >= 2 and shape[0] >= 2:
-            assert launched == {"unsharp_fused"}, launched
+            assert launched == {"unsharp_fused_exact_row"}, launched
     finally:
         im.set_precision(im.PRECISION_EXACT)
     assert_parity(holder["b"].numpy(), ref.blur(0.0, sigma).numpy(), False, "fast RGB blur %s" % (shape,))
@@ -420,7 +420,7 @@ def test_unsharp_mask_fast_fused(im, refmod, shape, gain, threshold, single_laun
     finally:
         im.set_precision(im.PRECISION_EXACT)
     if shape[1] >= 2:
-        assert launched == ({"unsharp_fused"} if single_launch else {"conv_row", "conv_column"}), launched
+        assert launched == ({"unsharp_fused_exact_row"} if single_launch else {"conv_row", "conv_column"}), launched
     got = holder["out"].numpy().astype(np.int64)
     diff = np.abs(got - want)
     limit = int(np.ceil(1.0 + gain))

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Numerical model (CPU, NumPy) of the exact integer matrix-core blur pass sketched in DESIGN.md
-section 8: Q16 samples as bytes, the taps as four balanced signed 8-bit digits, every digit product
-accumulated exactly in integers (what v_mfma_i32_16x16x64_i8 does), the weight classes combined in
-fp64, and a tie window that scales with 1/alpha deciding which results must be recomputed in the
-reference's order.  It checks, on random and on adversarial rows, that every result outside the
-window rounds to the level the reference's own fp64 loop (morphology.c:2746-2764, restated here
-operation by operation) produces, and prints how many samples fall inside the window.
+"""Numerical model (CPU, NumPy) of the exact-integer matrix-core blur pass of
+imagemagick_amd/csrc/convolve_fused_exact.hip, with the same constants as its host side
+(plan_exact_taps): Q16 samples alpha*p (32 bits) and alpha*2^16 as four signed bytes, the taps as
+five balanced signed 8-bit digits of rint(k*2^F), the digit products of weight class i+j >= 3
+accumulated exactly in integers (what v_mfma_i32_16x16x64_i8 does), the classes combined in fp64,
+and an ambiguity window 65536*(E_N+E_D)/D + 4e-9 that decides which results must be recomputed in
+the reference's operation order.  It checks, on random and on adversarial rows, that every result
+OUTSIDE the window rounds to the level the reference's own fp64 loop (morphology.c:2746-2764,
+restated here operation by operation) produces, and prints how many samples fall inside.
 
     python tools/model_exact_i8.py [sigma] [rows]
 """
@@ -18,6 +20,7 @@ sigma = float(sys.argv[1]) if len(sys.argv) > 1 else 10.0
 rows = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 W = 2048
 QS = 1.0 / 65535.0
+DIGITS = 5
 
 
 def blur_taps(sigma):
@@ -60,80 +63,107 @@ def reference_pass(px, taps):
     return np.clip(np.floor(out + 0.5), 0, 65535), out
 
 
-def integer_pass(px, taps):
-    """Digit products accumulated exactly (Python/NumPy int64 stands in for the i32 tiles: the
-    bound 79*255*127 < 2^22 per tile is asserted), then the classes combined in fp64."""
+def plan(taps):
+    """plan_exact_taps of convolve_fused_exact.hip."""
     K = len(taps)
-    # the finest fixed point whose largest tap still fits four balanced digits (-2^31 .. 2^31-129)
-    frac_bits = int(math.floor(math.log2((2.0 ** 31 - 129.0) / taps.max())))
-    q = np.rint(taps * (1 << frac_bits)).astype(np.int64)            # fixed-point taps
+    F = math.frexp(5.4e11 / taps.max())[1] - 1
+    scaled = np.ldexp(taps, F)
+    nearest = np.rint(scaled)
+    quantisation = float(np.abs(scaled - nearest).sum())
+    rest = nearest.astype(np.int64)
     digits = []
-    rest = q.copy()
-    for _ in range(4):                                                # balanced digits -128..127
-        d = ((rest + 128) % 256) - 128
+    for _ in range(DIGITS):
+        d = ((rest + 128) & 255) - 128
         digits.append(d)
         rest = (rest - d) >> 8
-    assert (rest == 0).all(), "taps need more than four digits"
+    assert (rest == 0).all()
+    magnitude = [float(np.abs(d).sum()) for d in digits]
+    signed = [float(d.sum()) for d in digits]
+    unit = math.ldexp(1.0, -F)
+
+    def offset_of(i0):
+        return sum(128.0 * signed[j] * math.ldexp(1.0, 8 * (i + j - 3))
+                   for i in range(i0, 4) for j in range(DIGITS) if i + j >= 3)
+
+    def dropped_of(i0):
+        return unit * sum(255.0 * magnitude[j] * math.ldexp(1.0, 8 * (i + j))
+                          for i in range(i0, 4) for j in range(DIGITS) if i + j <= 2)
+
+    e_colour = quantisation * unit * 65535.0 * 65535.0 + dropped_of(0)
+    e_shifted = quantisation * unit * 65535.0 * 65536.0 + dropped_of(2)
+    m_unit = math.ldexp(1.0, 24 - F)
+    return dict(F=F, digits=digits, offset=offset_of(0), alpha_scale=math.ldexp(1.0, 8 - F),
+                alpha_window=e_shifted / 65536.0 + 4.0e-9,
+                colour_window=1.002 * 65536.0 * (e_colour + e_shifted) / m_unit,
+                alpha_floor=1024.0 * e_shifted / m_unit, e_colour=e_colour, e_shifted=e_shifted,
+                smallest_ok=taps.min() * 65536.0 > 8.0 * e_shifted)
+
+
+def integer_pass(px, taps, p):
+    """The kernel's arithmetic: signed bytes x balanced digits, classes i+j >= 3, exact."""
+    K = len(taps)
     pad = np.pad(px, ((0, 0), (K // 2, K // 2), (0, 0)), mode="edge").astype(np.int64)
     n = px.shape[1]
-    prod = pad[:, :, :3] * pad[:, :, 3:4]                             # alpha*p, 32 bits
-    sums = []
-    for values, nbytes in ((prod, 4), (pad[:, :, 3:4], 2)):
-        total = np.zeros(values.shape[:1] + (n, values.shape[2]), dtype=object)
-        for i in range(nbytes):
-            byte = (values >> (8 * i)) & 0xff
-            signed = byte - 128                                       # x ^ 0x80 as a signed byte
-            for j, d in enumerate(digits):
-                tile = np.zeros(values.shape[:1] + (n, values.shape[2]), dtype=np.int64)
-                for v in range(K):
-                    tile += signed[:, v:v + n, :] * d[v]
-                assert np.abs(tile).max() < (1 << 22)
-                tile += 128 * int(d.sum())                            # the offset: a constant per digit
-                total = total + tile.astype(object) * (1 << (8 * (i + j)))
-        sums.append(total)
-    scale = float(1 << frac_bits)
-    s_colour = np.array(sums[0], dtype=np.float64) / scale           # sum k*alpha*p
-    s_alpha = np.array(sums[1], dtype=np.float64)[:, :, 0] / scale   # sum k*alpha
+    samples = np.empty(pad.shape, dtype=np.int64)
+    samples[:, :, :3] = pad[:, :, :3] * pad[:, :, 3:4]                # alpha*p
+    samples[:, :, 3] = pad[:, :, 3] << 16                             # alpha*2^16
+    M = np.zeros(px.shape, dtype=object)
+    for i in range(4):
+        signed_byte = ((samples >> (8 * i)) & 0xff) - 128             # b ^ 0x80 as a signed byte
+        for j, d in enumerate(p["digits"]):
+            if i + j < 3:
+                continue
+            tile = np.zeros(px.shape, dtype=np.int64)
+            for v in range(K):
+                tile += signed_byte[:, v:v + n, :] * d[v]
+            assert np.abs(tile).max() < (1 << 23)
+            M = M + tile.astype(object) * (1 << (8 * (i + j - 3)))
+    M = np.array(M, dtype=np.float64) + p["offset"]                   # exact: |M| < 2^53
+    Ma = M[:, :, 3]
     value = np.empty(px.shape, dtype=np.float64)
+    window = np.empty(px.shape, dtype=np.float64)
     with np.errstate(divide="ignore", invalid="ignore"):
+        r = np.where(Ma > 0, 1.0 / np.where(Ma > 0, Ma, 1.0), 0.0)
         for c in range(3):
-            value[:, :, c] = np.where(s_alpha > 0, s_colour[:, :, c] / s_alpha, 0.0)
-    value[:, :, 3] = s_alpha
-    # tap quantisation: |error of sum k*x| <= K * 2^-(frac_bits+1) * max x
-    err_colour = K * 2.0 ** -(frac_bits + 1) * 65535.0 * 65535.0
-    err_alpha = K * 2.0 ** -(frac_bits + 1) * 65535.0
-    with np.errstate(divide="ignore"):
-        window = np.empty(px.shape, dtype=np.float64)
-        bound = np.where(s_alpha > 0, (err_colour + 65535.0 * err_alpha) / np.maximum(s_alpha, 1e-30), np.inf)
-        for c in range(3):
-            window[:, :, c] = bound + 1e-9
-        window[:, :, 3] = err_alpha + 1e-9
+            value[:, :, c] = M[:, :, c] * (65536.0 * r)
+            window[:, :, c] = np.where(Ma >= p["alpha_floor"], p["colour_window"] * r + 4.0e-9, np.inf)
+            window[:, :, c] = np.where(Ma == 0, 0.0, window[:, :, c])  # all-transparent: level 0, certain
+    value[:, :, 3] = Ma * p["alpha_scale"]
+    window[:, :, 3] = np.where(Ma == 0, 0.0, np.where(Ma >= p["alpha_floor"], p["alpha_window"], np.inf))
     return value, window
 
 
-def run(name, px, taps):
+def run(name, px, taps, p):
     want, exact_value = reference_pass(px, taps)
-    value, window = integer_pass(px, taps)
-    level = np.clip(np.floor(value + 0.5), 0, 65535)
-    frac = value + 0.5 - np.floor(value + 0.5)
-    doubtful = np.minimum(frac, 1.0 - frac) <= window                # within the window of a rounding tie
+    value, window = integer_pass(px, taps, p)
+    shifted = value + 0.5
+    level = np.clip(np.floor(shifted), 0, 65535)
+    frac = shifted - np.floor(shifted)
+    doubtful = (frac < window) | (frac > 1.0 - window)
     wrong = (level != want) & ~doubtful
-    print("%-28s samples %8d   doubtful %7d (%.4f %%)   wrong outside the window %d   max |value - reference| %.2e" %
+    print("%-28s samples %8d   doubtful %7d (%.5f %%)   wrong outside the window %d   max |value - reference| %.2e" %
           (name, px.size, int(doubtful.sum()), 100.0 * doubtful.mean(), int(wrong.sum()),
            float(np.nanmax(np.abs(np.where(np.isfinite(value), value, 0) - np.where(np.isfinite(exact_value), exact_value, 0))))))
     return int(wrong.sum())
 
 
 taps = blur_taps(sigma)
-print("sigma %g: %d taps" % (sigma, len(taps)))
+p = plan(taps)
+print("sigma %g: %d taps, F = %d, E_colour %.4f, E_shifted %.4f (sample units), opaque colour window %.2e level, eligible %s" %
+      (sigma, len(taps), p["F"], p["e_colour"], p["e_shifted"],
+       p["colour_window"] / (65535.0 * 65536.0 / math.ldexp(1.0, 24 - p["F"])) + 4e-9, p["smallest_ok"]))
 rng = np.random.default_rng(5)
 bad = 0
-bad += run("random RGBA", rng.integers(0, 65536, (rows, W, 4)), taps)
+bad += run("random RGBA", rng.integers(0, 65536, (rows, W, 4)), taps, p)
 opaque = rng.integers(0, 65536, (rows, W, 4)); opaque[:, :, 3] = 65535
-bad += run("opaque", opaque, taps)
+bad += run("opaque", opaque, taps, p)
 tiny = rng.integers(0, 65536, (rows, W, 4)); tiny[:, :, 3] = rng.integers(0, 4, (rows, W))
-bad += run("alpha 0..3", tiny, taps)
+bad += run("alpha 0..3", tiny, taps, p)
+sparse = rng.integers(0, 65536, (rows, W, 4)); sparse[:, :, 3] = np.where(rng.random((rows, W)) < 0.01, 65535, 0)
+bad += run("alpha sparse (1 %)", sparse, taps, p)
+band = rng.integers(0, 65536, (rows, W, 4)); band[:, : W // 2, 3] = 0
+bad += run("half transparent", band, taps, p)
 checker = np.empty((rows, W, 4), dtype=np.int64)
 checker[:] = ((np.add.outer(np.arange(rows), np.arange(W)) % 2) * 40000 + 100)[:, :, None]
-bad += run("checkerboard (exact ties)", checker, taps)
+bad += run("checkerboard (exact ties)", checker, taps, p)
 sys.exit(1 if bad else 0)

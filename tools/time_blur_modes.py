@@ -1,0 +1,38 @@
+"""BlurImage(0,sigma) on n^2 RGBA Q16 in the mode the environment selects; one line per call.
+    python tools/time_blur_modes.py exact|fast [n] [sigma] [channels]
+MAGICKHIP_NO_EXACT_MFMA=1 selects round 2's kernels (EXACT: fp64 vector passes; FAST: f16 products
+in both passes)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import imagemagick_amd as im
+from imagemagick_amd import _lib
+from bench import kernel_profile, timed
+lib = im.load()
+mode = sys.argv[1] if len(sys.argv) > 1 else "exact"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
+sigma = float(sys.argv[3]) if len(sys.argv) > 3 else 10.0
+channels = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+im.set_precision(im.PRECISION_EXACT if mode == "exact" else im.PRECISION_FAST)
+gen = torch.Generator(device="cuda").manual_seed(3)
+a = torch.randint(-32768, 32768, (n, n, channels), generator=gen, device="cuda", dtype=torch.int16).view(torch.uint16)
+if os.environ.get("OPAQUE") and channels == 4:
+    a = a.clone()
+    a.view(torch.int16)[:, :, 3] = -1
+img = im.Image(a)
+out = img.like()
+def f():
+    im.blur_image(img, 0.0, sigma, out=out)
+# clock ramp
+for _ in range(30):
+    f()
+torch.cuda.synchronize()
+lib.MhExactBlurRecomputed(1)
+f()
+recomputed = lib.MhExactBlurRecomputed(0)
+sec = timed(torch, f, 50)
+prof = kernel_profile(im, f, 5)
+print("%-5s n=%d sigma=%g ch=%d %s: %.4f ms  %.1f Mpixel/s  recomputed %d of %d samples  kernels(ms) %s" % (
+    mode, n, sigma, channels, "old" if os.environ.get("MAGICKHIP_NO_EXACT_MFMA") else "i8",
+    sec * 1e3, n * n / sec / 1e6, recomputed, n * n * channels * 2,
+    {k: round(v["avg_ms"], 4) for k, v in prof.items()}), flush=True)
