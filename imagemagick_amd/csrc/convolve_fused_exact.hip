@@ -152,31 +152,57 @@ static __device__ __forceinline__ void byte_planes(const unsigned (&x)[4],unsign
   p[3]=__builtin_amdgcn_perm(h23,h01,0x07060302u);
 }
 
-// the kept digit products of one 64-slot chunk: a[i] = byte plane i of the samples, t[j] = digit
-// j of the Toeplitz taps, class i+j-3.  Consecutive instructions write different tiles.
-template<bool PLAIN>
+// The kept digit products of one 64-slot chunk: a[i] = byte plane i of the samples, t[j] = digit
+// j of the Toeplitz taps, class i+j-3.  The order keeps three other instructions between two
+// that write the same tile (a dependent v_mfma waits for its predecessor's passes; with that
+// distance a wave's chain issues back to back), also across the chunk boundary (SECOND).
+template<bool PLAIN,bool SECOND>
 static __device__ __forceinline__ void exact_products(const intx4 (&a)[4],const intx4 (&t)[5],intx4 (&acc)[5])
 {
+  if constexpr (PLAIN)
+    {
+      constexpr int order[9][2]={{3,0},{3,1},{3,2},{3,3},{3,4},{2,1},{2,2},{2,3},{2,4}};
 #pragma unroll
-  for (int i=PLAIN ? 2 : 0; i < 4; i++)
+      for (int k=0; k < 9; k++)
+        acc[order[k][0]+order[k][1]-3]=__builtin_amdgcn_mfma_i32_16x16x64_i8(a[order[k][0]],t[order[k][1]],
+          acc[order[k][0]+order[k][1]-3],0,0,0);
+    }
+  else if constexpr (!SECOND)
+    {
+      constexpr int order[14][2]={{3,0},{3,1},{3,2},{3,3},{2,1},{2,2},{2,3},{3,4},{1,2},{1,3},{1,4},{2,4},{0,3},{0,4}};
 #pragma unroll
-    for (int j=0; j < 5; j++)
-      if (i+j >= 3)
-        acc[i+j-3]=__builtin_amdgcn_mfma_i32_16x16x64_i8(a[i],t[j],acc[i+j-3],0,0,0);
+      for (int k=0; k < 14; k++)
+        acc[order[k][0]+order[k][1]-3]=__builtin_amdgcn_mfma_i32_16x16x64_i8(a[order[k][0]],t[order[k][1]],
+          acc[order[k][0]+order[k][1]-3],0,0,0);
+    }
+  else
+    {
+      constexpr int order[14][2]={{3,2},{3,3},{3,0},{3,1},{2,3},{2,1},{2,2},{1,4},{1,2},{1,3},{2,4},{0,3},{0,4},{3,4}};
+#pragma unroll
+      for (int k=0; k < 14; k++)
+        acc[order[k][0]+order[k][1]-3]=__builtin_amdgcn_mfma_i32_16x16x64_i8(a[order[k][0]],t[order[k][1]],
+          acc[order[k][0]+order[k][1]-3],0,0,0);
+    }
 }
 
-// The five class tiles of one lane's pixel (register = channel) -> the four Quantum levels and a
-// mask of the channels whose level the error bound cannot decide.
-//   M = sum_c acc_c * 2^(8c)  (exact: integers below 2^53; the tiles start at the offset constants
-//   class_init[c]), in units of 2^(24-F)
-//   BLEND: level_c = round(65536*M_c/M_a), level_a = round(M_a*alpha_scale); plain: the latter
+// Wait states between a chain's last v_mfma and the first VALU read of a tile.  hipcc (ROCm 7.2)
+// pads them per basic block; a branch target that begins with such a read got `s_nop 0` (seen with
+// store_row's branch between the row chain and its sums: during the first lap of the ring, where
+// the branch is taken, channel 0 of the sums came from a tile still in the pipe).  The asm "uses"
+// every tile, so nothing that reads one can be scheduled above it.
+static __device__ __forceinline__ void settle_tiles(intx4 (&acc)[5])
+{
+  asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]),"+v"(acc[1]),"+v"(acc[2]),"+v"(acc[3]),"+v"(acc[4]));
+}
+
+// The five class tiles of one lane's pixel (register = channel) -> the exact sums
+//   M = sum_c acc_c * 2^(8c)  (integers below 2^53; the tiles start at the offset constants
+//   class_init[c]), in units of 2^(24-F).
 // Partial sums in i32: with b in [0,255] and |d| <= 128 a product's sum over K <= 81 taps is below
 // 2.65e6, so class 4 + 256 * class 5 (4 and 3 products) stays below 2.04e9 < 2^31.
-template<bool BLEND>
-static __device__ __forceinline__ unsigned exact_levels(const intx4 (&acc)[5],const BlurExactArgs &args,
-  unsigned (&q)[4])
+static __device__ __forceinline__ void exact_sums(intx4 (&acc)[5],double (&M)[4])
 {
-  double M[4];
+  settle_tiles(acc);
 #pragma unroll
   for (int ch=0; ch < 4; ch++)
     {
@@ -184,33 +210,33 @@ static __device__ __forceinline__ unsigned exact_levels(const intx4 (&acc)[5],co
       const int top=acc[3][ch]+(acc[4][ch] << 8);
       M[ch]=__builtin_fma((double) top,16777216.0,__builtin_fma((double) mid,256.0,(double) acc[0][ch]));
     }
+}
+
+// ... -> the four Quantum levels and a mask of the channels whose level the error bound cannot
+// decide.  BLEND: level_c = round(65536*M_c/M_a), level_a = round(M_a*alpha_scale); plain: the
+// latter for every channel.  Branch-free: M_a = 0 (every alpha of the window is zero; the host
+// checked that the smallest tap times one alpha level is far above the error bound) gives
+// 0*inf = NaN, which converts to level 0 and compares as "not doubtful" — PerceptibleReciprocal's
+// clamp times pixel = 0.
+template<bool BLEND>
+static __device__ __forceinline__ unsigned exact_levels(const double (&M)[4],const BlurExactArgs &args,
+  unsigned (&q)[4])
+{
   unsigned doubtful=0u;
   // level = ClampToQuantum(value) (quantum.h:86-97: v_cvt_u32_f64 truncates value+0.5 >= 0 and
-  // maps negatives to 0); doubtful when the fraction of value+0.5 lies within `window` of 0 or 1
+  // maps negatives and NaN to 0); doubtful when the fraction of value+0.5 lies within the window
+  // of 0 or 1
   auto level_of=[&](double value,double half_window,int ch)
   {
     const double shifted=value+0.5;
     const unsigned level=(unsigned) shifted;
     q[ch]=level > 65535u ? 65535u : level;
     const double fraction=__builtin_amdgcn_fract(shifted);
-    if (__builtin_fabs(fraction-0.5) > half_window)
-      doubtful|=1u << ch;
+    doubtful|=__builtin_fabs(fraction-0.5) > half_window ? 1u << ch : 0u;
   };
   if constexpr (BLEND)
     {
       const double Ma=M[3];
-      if (Ma == 0.0)
-        {
-          // every alpha of the window is zero (the host checked that the smallest tap times one
-          // alpha level is far above the error bound): pixel = 0, PerceptibleReciprocal's clamp
-          q[0]=q[1]=q[2]=q[3]=0u;
-          return 0u;
-        }
-      if (!(Ma >= args.alpha_floor))
-        {
-          q[0]=q[1]=q[2]=q[3]=0u;
-          return 15u;
-        }
       double r=__builtin_amdgcn_rcp(Ma);
       double e=__builtin_fma(-Ma,r,1.0);
       r=__builtin_fma(r,e,r);
@@ -223,6 +249,8 @@ static __device__ __forceinline__ unsigned exact_levels(const intx4 (&acc)[5],co
       for (int ch=0; ch < 3; ch++)
         level_of(M[ch]*scale,half_window,ch);
       level_of(Ma*args.alpha_scale,args.alpha_half_window,3);
+      // an alpha sum the bound says nothing about (tiny or, by the dropped classes, negative)
+      doubtful=((Ma >= args.alpha_floor) || (Ma == 0.0)) ? doubtful : 15u;
     }
   else
     {
@@ -396,10 +424,14 @@ void blur_fused_exact_kernel(BlurExactArgs args)
           }
         else
           {
+            // (the strips at the left and right image edges only; opaque to the optimiser so that
+            // the four clamped columns are not kept in registers across the whole walk)
+            int edge=xs;
+            asm volatile("" : "+v"(edge));
 #pragma unroll
             for (int i=0; i < 4; i++)
               {
-                int x=xs+i;
+                int x=edge+i;
                 x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
                 raw[i]=load_pixel16(args.src+pixel_index(y,W,x)*PX);
               }
@@ -525,60 +557,131 @@ void blur_fused_exact_kernel(BlurExactArgs args)
     return (unsigned) QuantumOps<uint16_t>::clamp(pixel);
   };
 
+  // ---- The walk, software-pipelined over the two barrier intervals of an iteration so that every
+  // interval pairs one matrix chain with the INDEPENDENT epilogue of the other pass (the chain of
+  // a wave and the epilogue that consumes it never share an interval: four waves of a SIMD that
+  // all run chain -> epilogue in lockstep leave the matrix pipe idle during the epilogues and the
+  // vector pipe idle during the chains — measured 41 % matrix-pipe time, 40 % of the wave cycles
+  // parked).  Iteration g:
+  //   interval A: stage group g, fetch g+1 | store the rows of block cb-1 | column chain of block
+  //               cb = g-NG-1 (ring groups cb..cb+NG-1, all written before) -> sums
+  //               || row epilogue of group g-1 (sums -> levels -> ring slot)
+  //   interval B: row chain of group g -> sums  || column epilogue of block cb -> out_tile
+  // Sums (4 doubles per pass) are what crosses a barrier.  The ring holds NR = NG+1 groups:
+  // g-NG-1 .. g-1.  Out-of-range iterations (pipeline fill and drain) run on whatever the planes
+  // hold and their results are not stored.
+  double sums_row[4]={0.0,0.0,0.0,0.0},sums_col[4]={0.0,0.0,0.0,0.0};
+  auto init_tiles=[&](intx4 (&acc)[5])
+  {
+#pragma unroll
+    for (int c=0; c < 5; c++)
+      acc[c]=intx4{args.class_init[c],args.class_init[c],args.class_init[c],args.class_init[c]};
+  };
+  auto store_row=[&](int block)
+  {
+    if ((block >= 0) && (block < nblocks))
+      {
+        uint2 result=out_tile[wave*G::OUT_STRIDE+lane];
+        if constexpr (UNSHARP)
+          result=unsharp_pixel(original,result,args.gain,args.threshold);
+        const int x=x0+lane,y=out_begin+G::GROUP*block+wave;
+        if ((x < W) && (y < H))
+          store_pixel16(args.dst+pixel_index(y,W,x)*PX,result);
+      }
+  };
   fetch(0);
-  for (int g=0; g <= ngroups; g++)
+  for (int g=0; g <= ngroups+1; g++)
     {
-      if constexpr (UNSHARP)
-        fetch_original(g-G::NG);
+      const int cb=g-G::NG-1;                    // the column pass's block of this iteration
+      const int first=ring_group;                // ring slot of group cb: (g-NG-1) mod NR = g mod NR
+      const int previous=ring_group == 0 ? G::NR-1 : ring_group-1;   // ring slot of group g-1
+      if constexpr (COLX)
+        {
+          // the rows of block cb-1 (out_tile was written in the previous interval B)
+          store_row(cb-1);
+          if constexpr (UNSHARP)
+            fetch_original(cb);
+        }
+      else if constexpr (UNSHARP)
+        fetch_original(cb);
       if (g < ngroups)
         {
           stage_group();
           if (g+1 < ngroups)
             fetch(g+1);
         }
-      if (g >= G::NG)
+      // ======================================================================== interval A
+      if constexpr (COLX)
         {
-          // ---- column pass of output rows out_begin+16*(g-NG) .. +16
-          // block mod NR = (g+1) mod NR (NR = NG+1): the oldest group the ring still holds
-          const int first=ring_group+1 == G::NR ? 0 : ring_group+1;
-          if constexpr (COLX)
+          intx4 acc[5];
+          init_tiles(acc);
+#pragma unroll
+          for (int c=0; c < G::NX; c++)
             {
-              intx4 acc[5];
+              // ring group of this lane's 16 rows: (first + 4c + kq) mod NR.  Beyond the NG groups
+              // of the band the digits are zero: whatever the slot holds is multiplied by 0
+              unsigned group=(unsigned) (first+4*c+kq);
+              group=group >= (unsigned) G::NR ? group-(unsigned) G::NR : group;
+              group=group >= (unsigned) G::NR ? group-(unsigned) G::NR : group;
+              const unsigned char *from=ring+col_entryx+(int) group*(G::COLS*16);
+              intx4 a[4];
 #pragma unroll
-              for (int c=0; c < 5; c++)
-                acc[c]=intx4{args.class_init[c],args.class_init[c],args.class_init[c],args.class_init[c]};
-#pragma unroll
-              for (int c=0; c < G::NX; c++)
-                {
-                  // ring group of this lane's 16 rows: (first + 4c + kq) mod NR.  Beyond the NG
-                  // groups of the band the digits are zero: whatever the slot holds is multiplied by 0
-                  unsigned group=(unsigned) (first+4*c+kq);
-                  group=group >= (unsigned) G::NR ? group-(unsigned) G::NR : group;
-                  group=group >= (unsigned) G::NR ? group-(unsigned) G::NR : group;
-                  const unsigned char *from=ring+col_entryx+(int) group*(G::COLS*16);
-                  intx4 a[4];
-#pragma unroll
-                  for (int i=BLEND ? 0 : 2; i < 4; i++)
-                    a[i]=*reinterpret_cast<const intx4 *>(from+i*G::RINGX_PLANE);
-                  exact_products<!BLEND>(a,t[c],acc);
-                }
-              // lane (n, kq): the four channels (registers) of pixel (column 4*wave+kq, row n)
-              unsigned q[4];
-              unsigned doubtful=exact_levels<BLEND>(acc,args,q);
-              const int x=x0+4*wave+kq,y=out_begin+G::GROUP*(g-G::NG)+n;
-              if ((doubtful != 0u) && (x < W) && (y < H))
-                {
-#pragma unroll
-                  for (int ch=0; ch < 4; ch++)
-                    if ((doubtful >> ch) & 1u)
-                      {
-                        q[ch]=ring_reference(first,n,4*wave+kq,ch);
-                        recomputed++;
-                      }
-                }
-              out_tile[n*G::OUT_STRIDE+4*wave+kq]=make_uint2(q[0] | (q[1] << 16),q[2] | (q[3] << 16));
+              for (int i=BLEND ? 0 : 2; i < 4; i++)
+                a[i]=*reinterpret_cast<const intx4 *>(from+i*G::RINGX_PLANE);
+              if (c == 0)
+                exact_products<!BLEND,false>(a,t[c],acc);
+              else
+                exact_products<!BLEND,true>(a,t[c],acc);
             }
-          else
+          // ---- row epilogue of group g-1 (independent of the chain above)
+          {
+            unsigned q[4];
+            unsigned doubtful=exact_levels<BLEND>(sums_row,args,q);
+            exact_sums(acc,sums_col);
+            const int x=x0+16*ot+n;
+            if ((doubtful != 0u) && (g >= 1) && (g-1 < ngroups) && (x < W))
+              {
+                int y=in0+G::GROUP*(g-1)+4*rq+kq;
+                y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
+#pragma unroll
+                for (int ch=0; ch < PX; ch++)
+                  if ((doubtful >> ch) & 1u)
+                    {
+                      q[ch]=(unsigned) conv1d_reference_sample<uint16_t,PX,BLEND>(args.src,W,H,false,x,y,ch,
+                        args.taps64,K,args.shift,0.0);
+                      recomputed++;
+                    }
+              }
+            // the column pass's samples of this pixel, as signed bytes
+            unsigned v[4];
+            if constexpr (BLEND)
+              {
+                v[0]=__umul24(q[0],q[3]);
+                v[1]=__umul24(q[1],q[3]);
+                v[2]=__umul24(q[2],q[3]);
+                v[3]=q[3] << 16;
+              }
+            else
+              {
+                v[0]=q[0] << 16; v[1]=q[1] << 16; v[2]=q[2] << 16; v[3]=q[3] << 16;
+              }
+            // 4x4 transpose between the registers (channels) and the four 16-lane rows (pixel rows)
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
+                         "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"
+                         : "+v"(v[0]),"+v"(v[1]),"+v"(v[2]),"+v"(v[3]));
+            // lane (n, kq): channel kq of rows 4*rq+0..3 -> one dword per byte plane
+            unsigned p[4];
+            byte_planes(v,p);
+            unsigned char *to=ring+ring_entryx+previous*(G::COLS*16);
+#pragma unroll
+            for (int i=0; i < 4; i++)
+              *reinterpret_cast<unsigned *>(to+i*G::RINGX_PLANE)=p[i] ^ 0x80808080u;
+          }
+        }
+      else
+        {
+          // ---- f16 column pass of block cb, whole (products, division, rounding) -> out_tile
+          if ((cb >= 0) && (cb < nblocks))
             {
               int chunk_at[NC];
 #pragma unroll
@@ -624,52 +727,15 @@ void blur_fused_exact_kernel(BlurExactArgs args)
               else if (ctiles == CT-1)
                 column_tiles(std::integral_constant<int,CT-1>{});
             }
-        }
-      __syncthreads();                           // X: staged; the column pass's pixels are in out_tile
-      auto store_row=[&]()
-      {
-        if (g >= G::NG)
+          // ---- row epilogue of group g-1: exact levels -> the f16 column pass's samples
           {
-            uint2 result=out_tile[wave*G::OUT_STRIDE+lane];
-            if constexpr (UNSHARP)
-              result=unsharp_pixel(original,result,args.gain,args.threshold);
-            const int x=x0+lane,y=out_begin+G::GROUP*(g-G::NG)+wave;
-            if ((x < W) && (y < H))
-              store_pixel16(args.dst+pixel_index(y,W,x)*PX,result);
-          }
-      };
-      if (g == ngroups)
-        {
-          store_row();
-          break;
-        }
-      // ---- row pass of ring group g: exact
-      {
-        intx4 acc[5];
-#pragma unroll
-        for (int c=0; c < 5; c++)
-          acc[c]=intx4{args.class_init[c],args.class_init[c],args.class_init[c],args.class_init[c]};
-#pragma unroll
-        for (int c=0; c < G::NX; c++)
-          {
-            intx4 a[4];
-#pragma unroll
-            for (int i=BLEND ? 0 : 2; i < 4; i++)
-              a[i]=*reinterpret_cast<const intx4 *>(stage+i*G::STAGE_PLANE+row_entry+64*c);
-            exact_products<!BLEND>(a,t[c],acc);
-          }
-        // the store of the column pass's row in the shadow of the matrix chain
-        store_row();
-        // lane (n, kq): the four channels (registers) of pixel (column x0+16*ot+n, row 4*rq+kq)
-        unsigned q[4];
-        unsigned doubtful=exact_levels<BLEND>(acc,args,q);
-        if (doubtful != 0u)
-          {
+            unsigned q[4];
+            unsigned doubtful=exact_levels<BLEND>(sums_row,args,q);
             const int x=x0+16*ot+n;
-            int y=in0+G::GROUP*g+4*rq+kq;
-            y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
-            if (x < W)
+            if ((doubtful != 0u) && (g >= 1) && (g-1 < ngroups) && (x < W))
               {
+                int y=in0+G::GROUP*(g-1)+4*rq+kq;
+                y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
 #pragma unroll
                 for (int ch=0; ch < PX; ch++)
                   if ((doubtful >> ch) & 1u)
@@ -679,37 +745,7 @@ void blur_fused_exact_kernel(BlurExactArgs args)
                       recomputed++;
                     }
               }
-          }
-        if constexpr (COLX)
-          {
-            // the column pass's samples of this pixel, as signed bytes
-            unsigned v[4];
-            if constexpr (BLEND)
-              {
-                v[0]=__umul24(q[0],q[3]);
-                v[1]=__umul24(q[1],q[3]);
-                v[2]=__umul24(q[2],q[3]);
-                v[3]=q[3] << 16;
-              }
-            else
-              {
-                v[0]=q[0] << 16; v[1]=q[1] << 16; v[2]=q[2] << 16; v[3]=q[3] << 16;
-              }
-            // 4x4 transpose between the registers (channels) and the four 16-lane rows (pixel rows)
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
-                         "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"
-                         : "+v"(v[0]),"+v"(v[1]),"+v"(v[2]),"+v"(v[3]));
-            // lane (n, kq): channel kq of rows 4*rq+0..3 -> one dword per byte plane
-            unsigned p[4];
-            byte_planes(v,p);
-            unsigned char *to=ring+ring_entryx+ring_group*(G::COLS*16);
-#pragma unroll
-            for (int i=0; i < 4; i++)
-              *reinterpret_cast<unsigned *>(to+i*G::RINGX_PLANE)=p[i] ^ 0x80808080u;
-          }
-        else
-          {
-            // the f16 column pass's samples: alpha*colour*2^-17 and alpha/2 (plain: level/2)
+            // alpha*colour*2^-17 and alpha/2 (plain: level/2)
             float v[4];
             const f32x2 c01={(float) q[0],(float) q[1]};
             const f32x2 c23={(float) q[2],(float) q[3]};
@@ -733,14 +769,61 @@ void blur_fused_exact_kernel(BlurExactArgs args)
             uint2 hi,lo;
             split_f16_pair(f32x2{v[0],v[1]},hi.x,lo.x);
             split_f16_pair(f32x2{v[2],v[3]},hi.y,lo.y);
-            const int at=ring_entry16+ring_group*GROUP_STRIDE;
+            const int at=ring_entry16+previous*GROUP_STRIDE;
             *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
             *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
           }
+        }
+      __syncthreads();                           // X: group g staged, ring group g-1 complete
+      // ======================================================================== interval B
+      {
+        // ---- row chain of group g
+        intx4 acc[5];
+        init_tiles(acc);
+#pragma unroll
+        for (int c=0; c < G::NX; c++)
+          {
+            intx4 a[4];
+#pragma unroll
+            for (int i=BLEND ? 0 : 2; i < 4; i++)
+              a[i]=*reinterpret_cast<const intx4 *>(stage+i*G::STAGE_PLANE+row_entry+64*c);
+            if (c == 0)
+              exact_products<!BLEND,false>(a,t[c],acc);
+            else
+              exact_products<!BLEND,true>(a,t[c],acc);
+          }
+        if constexpr (COLX)
+          {
+            // ---- column epilogue of block cb (independent of the chain above)
+            // lane (n, kq): the four channels (registers) of pixel (column 4*wave+kq, row n)
+            unsigned q[4];
+            unsigned doubtful=exact_levels<BLEND>(sums_col,args,q);
+            exact_sums(acc,sums_row);
+            const int x=x0+4*wave+kq,y=out_begin+G::GROUP*cb+n;
+            if ((doubtful != 0u) && (cb >= 0) && (x < W) && (y < H))
+              {
+#pragma unroll
+                for (int ch=0; ch < 4; ch++)
+                  if ((doubtful >> ch) & 1u)
+                    {
+                      q[ch]=ring_reference(first,n,4*wave+kq,ch);
+                      recomputed++;
+                    }
+              }
+            out_tile[n*G::OUT_STRIDE+4*wave+kq]=make_uint2(q[0] | (q[1] << 16),q[2] | (q[3] << 16));
+          }
+        else
+          {
+            // the store of the column pass's row in the shadow of the matrix chain
+            store_row(cb);
+            exact_sums(acc,sums_row);
+          }
       }
-      __syncthreads();                           // Y: ring group g complete, staging reads done
+      __syncthreads();                           // Y: out_tile complete, staging and ring reads done
       ring_group=ring_group+1 == G::NR ? 0 : ring_group+1;
     }
+  if constexpr (COLX)
+    store_row(nblocks-1);
   if ((args.recomputed != nullptr) && (recomputed != 0u))
     atomicAdd(args.recomputed,(unsigned long long) recomputed);
 }
