@@ -40,6 +40,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 #include <type_traits>
 #include <vector>
 
@@ -58,7 +59,7 @@ struct BlurExactArgs
   const double *taps64;      // double[K], taps64[v] multiplies input o-shift+v (the recomputation)
   const float *taps;         // the same as floats (COLX = false: the f16 column pass)
   const signed char *digits; // [kExactDigits][kExactDigitPitch]: balanced digits of rint(k*2^F)
-  int class_init[5];         // class c's tile starts at 128 * sum over its kept products of sum_v d_j[v]
+  double offset;             // 128 * sum over the kept products of sum_v d_j[v] * 2^(8(i+j-3))
   double alpha_scale;        // level of a plain / alpha sum = M * alpha_scale  (2^(8-F))
   double colour_window;      // colour level ambiguous within colour_window / M_alpha of a tie
   double alpha_half_window;  // plain / alpha level ambiguous within alpha_window of a tie: 0.5 - alpha_window
@@ -71,7 +72,25 @@ struct BlurExactArgs
   float gain;                // UnsharpMaskImage's epilogue
   int threshold;             // ceil(QuantumRange*threshold), see unsharp_sample
   unsigned long long *recomputed;   // optional device counter of recomputed samples (diagnostics)
+  unsigned long long *trace;        // diagnostic build (-DMH_EXACT_TRACE) only
 };
+
+// Diagnostic build only (-DMH_EXACT_TRACE, tools/trace_exact_blur.py): waves 0, 4, 8 and 12 of the
+// first four workgroups stamp the shader clock at the phase boundaries of 48 steady-state
+// iterations: trace[block][wave>>2][iteration][mark].
+#ifdef MH_EXACT_TRACE
+#define MH_XTRACE_MARK(id) \
+  do { \
+    if (traced && (g >= 64) && (g < 112)) \
+      { \
+        const unsigned long long now=__builtin_readcyclecounter(); \
+        if (lane == 0) \
+          args.trace[((((int) blockIdx.x*4+(wave >> 2))*48)+(g-64))*12+(id)]=now; \
+      } \
+  } while (0)
+#else
+#define MH_XTRACE_MARK(id) do { } while (0)
+#endif
 
 // worst number of ds_read_b128 lines of a lane group that share a 16-byte slot, for the row
 // pass's byte-plane operand: entry e = lane&15 -> channel e&3, row e>>2; k quarter = lane>>4
@@ -152,36 +171,56 @@ static __device__ __forceinline__ void byte_planes(const unsigned (&x)[4],unsign
   p[3]=__builtin_amdgcn_perm(h23,h01,0x07060302u);
 }
 
-// The kept digit products of one 64-slot chunk: a[i] = byte plane i of the samples, t[j] = digit
-// j of the Toeplitz taps, class i+j-3.  The order keeps three other instructions between two
-// that write the same tile (a dependent v_mfma waits for its predecessor's passes; with that
-// distance a wave's chain issues back to back), also across the chunk boundary (SECOND).
-template<bool PLAIN,bool SECOND>
-static __device__ __forceinline__ void exact_products(const intx4 (&a)[4],const intx4 (&t)[5],intx4 (&acc)[5])
+// The kept digit products of one chunk of the band: a[i] = byte plane i of the samples, t[j] =
+// digit j of the Toeplitz taps, class i+j-3.  First chunk: 64 slots (v_mfma_i32_16x16x64_i8,
+// 16 bytes per lane); second chunk (kernels of more than 49 taps): 32 slots
+// (v_mfma_i32_16x16x32_i8, 8 bytes per lane: 64+32 slots hold the 96-slot band of 81 taps, at
+// the same instruction time and half the operand registers).  The order keeps three other
+// instructions between two that write the same tile (a dependent v_mfma waits for its
+// predecessor's passes), also across the chunk boundary.
+static __device__ __forceinline__ intx4 digit_product(intx4 a,intx4 t,intx4 acc)
+{
+  return __builtin_amdgcn_mfma_i32_16x16x64_i8(a,t,acc,0,0,0);
+}
+static __device__ __forceinline__ intx4 digit_product(long a,long t,intx4 acc)
+{
+  return __builtin_amdgcn_mfma_i32_16x16x32_i8(a,t,acc,0,0,0);
+}
+// Second chunk of the band: 32 slots of the legacy-K instruction (the bare instruction issues at
+// the rate of the 64-slot one, tools/ubench/mfma_i8_shapes.hip, and the operands take half the
+// registers: no spills at four waves per SIMD), or — -DMH_EXACT_K64 — 64 slots, half of them
+// zero taps.
+#ifndef MH_EXACT_K64
+typedef long SecondOperand;
+constexpr int kSecondBytes=8;
+#else
+typedef intx4 SecondOperand;
+constexpr int kSecondBytes=16;
+#endif
+
+template<bool PLAIN,bool SECOND,typename Operand>
+static __device__ __forceinline__ void exact_products(const Operand (&a)[4],const Operand (&t)[5],intx4 (&acc)[5])
 {
   if constexpr (PLAIN)
     {
       constexpr int order[9][2]={{3,0},{3,1},{3,2},{3,3},{3,4},{2,1},{2,2},{2,3},{2,4}};
 #pragma unroll
       for (int k=0; k < 9; k++)
-        acc[order[k][0]+order[k][1]-3]=__builtin_amdgcn_mfma_i32_16x16x64_i8(a[order[k][0]],t[order[k][1]],
-          acc[order[k][0]+order[k][1]-3],0,0,0);
+        acc[order[k][0]+order[k][1]-3]=digit_product(a[order[k][0]],t[order[k][1]],acc[order[k][0]+order[k][1]-3]);
     }
   else if constexpr (!SECOND)
     {
       constexpr int order[14][2]={{3,0},{3,1},{3,2},{3,3},{2,1},{2,2},{2,3},{3,4},{1,2},{1,3},{1,4},{2,4},{0,3},{0,4}};
 #pragma unroll
       for (int k=0; k < 14; k++)
-        acc[order[k][0]+order[k][1]-3]=__builtin_amdgcn_mfma_i32_16x16x64_i8(a[order[k][0]],t[order[k][1]],
-          acc[order[k][0]+order[k][1]-3],0,0,0);
+        acc[order[k][0]+order[k][1]-3]=digit_product(a[order[k][0]],t[order[k][1]],acc[order[k][0]+order[k][1]-3]);
     }
   else
     {
       constexpr int order[14][2]={{3,2},{3,3},{3,0},{3,1},{2,3},{2,1},{2,2},{1,4},{1,2},{1,3},{2,4},{0,3},{0,4},{3,4}};
 #pragma unroll
       for (int k=0; k < 14; k++)
-        acc[order[k][0]+order[k][1]-3]=__builtin_amdgcn_mfma_i32_16x16x64_i8(a[order[k][0]],t[order[k][1]],
-          acc[order[k][0]+order[k][1]-3],0,0,0);
+        acc[order[k][0]+order[k][1]-3]=digit_product(a[order[k][0]],t[order[k][1]],acc[order[k][0]+order[k][1]-3]);
     }
 }
 
@@ -196,11 +235,11 @@ static __device__ __forceinline__ void settle_tiles(intx4 (&acc)[5])
 }
 
 // The five class tiles of one lane's pixel (register = channel) -> the exact sums
-//   M = sum_c acc_c * 2^(8c)  (integers below 2^53; the tiles start at the offset constants
-//   class_init[c]), in units of 2^(24-F).
-// Partial sums in i32: with b in [0,255] and |d| <= 128 a product's sum over K <= 81 taps is below
-// 2.65e6, so class 4 + 256 * class 5 (4 and 3 products) stays below 2.04e9 < 2^31.
-static __device__ __forceinline__ void exact_sums(intx4 (&acc)[5],double (&M)[4])
+//   M = sum_c acc_c * 2^(8c) + offset  (integers below 2^53; offset = the constant
+//   128 * sum(digit) of the signed-byte samples), in units of 2^(24-F).
+// Partial sums in i32: a product's sum over K <= 81 taps is below 81*128*128 = 1.33e6, so
+// class 4 + 256 * class 5 (4 and 3 products) stays below 1.03e9 < 2^31.
+static __device__ __forceinline__ void exact_sums(intx4 (&acc)[5],double offset,double (&M)[4])
 {
   settle_tiles(acc);
 #pragma unroll
@@ -208,31 +247,27 @@ static __device__ __forceinline__ void exact_sums(intx4 (&acc)[5],double (&M)[4]
     {
       const int mid=acc[1][ch]+(acc[2][ch] << 8);
       const int top=acc[3][ch]+(acc[4][ch] << 8);
-      M[ch]=__builtin_fma((double) top,16777216.0,__builtin_fma((double) mid,256.0,(double) acc[0][ch]));
+      M[ch]=__builtin_fma((double) top,16777216.0,__builtin_fma((double) mid,256.0,(double) acc[0][ch]+offset));
     }
 }
 
-// ... -> the four Quantum levels and a mask of the channels whose level the error bound cannot
-// decide.  BLEND: level_c = round(65536*M_c/M_a), level_a = round(M_a*alpha_scale); plain: the
-// latter for every channel.  Branch-free: M_a = 0 (every alpha of the window is zero; the host
-// checked that the smallest tap times one alpha level is far above the error bound) gives
-// 0*inf = NaN, which converts to level 0 and compares as "not doubtful" — PerceptibleReciprocal's
-// clamp times pixel = 0.
+// ... -> the four Quantum levels, and whether any of them is one the error bound cannot decide.
+// BLEND: level_c = round(65536*M_c/M_a), level_a = round(M_a*alpha_scale); plain: the latter
+// for every channel.  Branch-free: M_a = 0 (every alpha of the window is zero; the host checked
+// that the smallest tap times one alpha level is far above the error bound) gives 0*inf = NaN,
+// which converts to level 0 and compares as "not doubtful" — PerceptibleReciprocal's clamp times
+// pixel = 0.  ClampToQuantum (quantum.h:86-97) = v_cvt_u32_f64 of value+0.5: it truncates, maps
+// negatives and NaN to 0, and the values cannot exceed 65535.5 by more than the error bound.
 template<bool BLEND>
-static __device__ __forceinline__ unsigned exact_levels(const double (&M)[4],const BlurExactArgs &args,
+static __device__ __forceinline__ bool exact_levels(const double (&M)[4],const BlurExactArgs &args,
   unsigned (&q)[4])
 {
-  unsigned doubtful=0u;
-  // level = ClampToQuantum(value) (quantum.h:86-97: v_cvt_u32_f64 truncates value+0.5 >= 0 and
-  // maps negatives and NaN to 0); doubtful when the fraction of value+0.5 lies within the window
-  // of 0 or 1
-  auto level_of=[&](double value,double half_window,int ch)
+  bool doubtful=false;
+  // doubtful: the fraction of value+0.5 lies within the window of 0 or 1
+  auto level_of=[&](double shifted,double half_window,int ch)
   {
-    const double shifted=value+0.5;
-    const unsigned level=(unsigned) shifted;
-    q[ch]=level > 65535u ? 65535u : level;
-    const double fraction=__builtin_amdgcn_fract(shifted);
-    doubtful|=__builtin_fabs(fraction-0.5) > half_window ? 1u << ch : 0u;
+    q[ch]=(unsigned) shifted;
+    doubtful=doubtful || (__builtin_fabs(__builtin_amdgcn_fract(shifted)-0.5) > half_window);
   };
   if constexpr (BLEND)
     {
@@ -247,18 +282,162 @@ static __device__ __forceinline__ unsigned exact_levels(const double (&M)[4],con
       const double scale=65536.0*r;
 #pragma unroll
       for (int ch=0; ch < 3; ch++)
-        level_of(M[ch]*scale,half_window,ch);
-      level_of(Ma*args.alpha_scale,args.alpha_half_window,3);
+        level_of(__builtin_fma(M[ch],scale,0.5),half_window,ch);
+      level_of(__builtin_fma(Ma,args.alpha_scale,0.5),args.alpha_half_window,3);
       // an alpha sum the bound says nothing about (tiny or, by the dropped classes, negative)
-      doubtful=((Ma >= args.alpha_floor) || (Ma == 0.0)) ? doubtful : 15u;
+      doubtful=doubtful || !((Ma >= args.alpha_floor) || (Ma == 0.0));
     }
   else
     {
 #pragma unroll
       for (int ch=0; ch < 4; ch++)
-        level_of(M[ch]*args.alpha_scale,args.alpha_half_window,ch);
+        level_of(__builtin_fma(M[ch],args.alpha_scale,0.5),args.alpha_half_window,ch);
     }
   return doubtful;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The pixels the integer sums cannot decide (a few per million).  Fifteen other waves wait at the
+// next barrier for the wave that handles one, so the WHOLE wave handles it: lane v fetches the
+// window's sample v (and v+64), and
+//   step 2  the pixel's sums once more, in fp64 with fused multiply-adds over the EXACT taps,
+//           reduced over the wave.  That value is within 2e-9 level of the real one, the
+//           reference's own result (79 separately rounded operations) within another 2e-9: unless
+//           it lies within 1e-8 of a rounding tie, its level is the reference's.
+//   step 3  (some tens of pixels per 8192^2 frame) the reference's loop itself: every lane forms
+//           its tap's terms with the reference's operations (alpha = QuantumScale*a, alpha*k,
+//           (alpha*k)*p: each rounded once, independent of the order), and the sums run over the
+//           lanes in the reference's order (morphology.c:2743-2776, :2941-2977).
+// No dependent memory accesses, no calls: about two microseconds per pixel.
+constexpr double kSecondWindow=1.0e-8;
+
+static __device__ __forceinline__ double wave_total(double value)
+{
+#pragma unroll
+  for (int step=1; step < 64; step<<=1)
+    value+=__shfl_xor(value,step,64);
+  return value;
+}
+
+static __device__ __forceinline__ double lane_value(double value,int source)
+{
+  const unsigned long long bits=__builtin_bit_cast(unsigned long long,value);
+  const unsigned lo=(unsigned) __builtin_amdgcn_readlane((int) (unsigned) bits,source);
+  const unsigned hi=(unsigned) __builtin_amdgcn_readlane((int) (unsigned) (bits >> 32),source);
+  return __builtin_bit_cast(double,((unsigned long long) hi << 32) | (unsigned long long) lo);
+}
+
+// mine: this lane's pixel needs it.  fetch(source_lane, v, levels): the four Quantum levels of
+// sample v of the window of source_lane's pixel (CHANNELS of them meaningful).  q: this lane's
+// levels, replaced when `mine`.  Returns the number of pixels handled (wave-uniform).
+template<bool BLEND,int CHANNELS,class Fetch>
+static __device__ __forceinline__ unsigned settle_doubtful_pixels(bool mine,int lane,const double *taps,int K,
+  const Fetch &fetch,unsigned (&q)[4])
+{
+  unsigned long long todo=__ballot(mine);
+  unsigned handled=0u;
+  while (todo != 0ull)
+    {
+      const int source=(int) __builtin_ctzll(todo);
+      todo&=todo-1ull;
+      handled++;
+      // this lane's one or two samples of the window
+      unsigned level[2][4];
+      double tap[2];
+#pragma unroll
+      for (int half=0; half < 2; half++)
+        {
+          const int v=lane+64*half;
+          const bool inside=v < K;
+          tap[half]=inside ? taps[v] : 0.0;
+          fetch(source,inside ? v : 0,level[half]);
+        }
+      unsigned result[4];
+      bool certain=true;
+      {
+        double sum[4];
+#pragma unroll
+        for (int c=0; c < 4; c++)
+          {
+            double part=0.0;
+#pragma unroll
+            for (int half=0; half < 2; half++)
+              {
+                // alpha*p is an exact integer below 2^32
+                const unsigned sample=(BLEND && (c != 3)) ? level[half][c]*level[half][3] : level[half][c];
+                part=__builtin_fma(tap[half],(double) sample,part);
+              }
+            sum[c]=c < CHANNELS ? wave_total(part) : 0.0;
+          }
+        double scale=1.0;
+        if constexpr (BLEND)
+          scale=sum[3] > 0.0 ? 1.0/sum[3] : 0.0;   // all-transparent window: colour 0
+#pragma unroll
+        for (int c=0; c < 4; c++)
+          {
+            const double value=(BLEND && (c != 3)) ? sum[c]*scale : sum[c];
+            const double shifted=value+0.5;
+            const double whole=__builtin_floor(shifted);
+            const double fraction=shifted-whole;
+            certain=certain && (fraction > kSecondWindow) && (fraction < 1.0-kSecondWindow);
+            result[c]=whole >= 65535.0 ? 65535u : (whole > 0.0 ? (unsigned) whole : 0u);
+          }
+        // PerceptibleReciprocal's branch (gamma = QuantumScale*S_a below 1e-12) is the reference's
+        if constexpr (BLEND)
+          certain=certain && ((sum[3] == 0.0) || (sum[3] > 1.0e-6));
+      }
+      if (!certain)                              // wave-uniform: every lane holds the same sums
+        {
+          double term[2][4],weight[2];
+#pragma unroll
+          for (int half=0; half < 2; half++)
+            {
+              if constexpr (BLEND)
+                {
+                  const double alpha=kQS*(double) level[half][3];
+                  weight[half]=alpha*tap[half];
+#pragma unroll
+                  for (int c=0; c < 3; c++)
+                    term[half][c]=weight[half]*(double) level[half][c];
+                  term[half][3]=tap[half]*(double) level[half][3];
+                }
+              else
+                {
+                  weight[half]=0.0;
+#pragma unroll
+                  for (int c=0; c < 4; c++)
+                    term[half][c]=tap[half]*(double) level[half][c];
+                }
+            }
+          double sum[4]={0.0,0.0,0.0,0.0},gamma=0.0;
+          for (int v=0; v < K; v++)
+            {
+              const int from=v & 63;
+#pragma unroll
+              for (int c=0; c < CHANNELS; c++)
+                sum[c]+=lane_value(v < 64 ? term[0][c] : term[1][c],from);
+              if constexpr (BLEND)
+                gamma+=lane_value(v < 64 ? weight[0] : weight[1],from);
+            }
+          if constexpr (BLEND)
+            {
+              const double g=perceptible_reciprocal(gamma);
+#pragma unroll
+              for (int c=0; c < 3; c++)
+                sum[c]=g*sum[c];
+            }
+#pragma unroll
+          for (int c=0; c < 4; c++)
+            result[c]=(unsigned) QuantumOps<uint16_t>::clamp(sum[c]);
+        }
+      if (lane == source)
+        {
+#pragma unroll
+          for (int c=0; c < 4; c++)
+            q[c]=result[c];
+        }
+    }
+  return handled;
 }
 
 template<int NC,int MODE,bool UNSHARP,bool COLX>
@@ -327,12 +506,16 @@ void blur_fused_exact_kernel(BlurExactArgs args)
   const int in0=out_begin-args.shift;
   const int xin0=x0-args.shift;
   const int ngroups=nblocks+G::NG-1;
+#ifdef MH_EXACT_TRACE
+  const bool traced=(args.trace != nullptr) && (blockIdx.x < 4) && ((wave & 3) == 0);
+#endif
 
   // ---- Toeplitz operands.  Digit j of chunk c for output n, k quarter kq: bytes b = 0..15 hold
   // d_j[64c+16kq+b-n] (0 outside the kernel).  Whatever order the instruction gives the 64 slots
   // of a chunk, it is the same for both operands: slot (kq, b) of the samples is position
   // 64c+16kq+b.  COLX = false: also the f16 operands of the column pass (convolve_fused.hip).
-  intx4 t[G::NX][kExactDigits];
+  intx4 t0[kExactDigits];                       // slots 0..63: 16 per k quarter
+  SecondOperand t1[kExactDigits];               // slots from 64: 8 or 16 per k quarter (NX = 2 only)
   half8 t_hi[COLX ? 1 : NC],t_lo[COLX ? 1 : NC];
   {
     constexpr int DL=176;                        // digit line: tap v at [16+v], zeros around
@@ -347,20 +530,27 @@ void blur_fused_exact_kernel(BlurExactArgs args)
       for (int j=tid; j < K; j+=1024)
         tap_lds[j]=args.taps[j];
     __syncthreads();
+    auto packed=[&](const signed char *from) -> unsigned
+    {
+      return (unsigned) (unsigned char) from[0] | ((unsigned) (unsigned char) from[1] << 8) |
+        ((unsigned) (unsigned char) from[2] << 16) | ((unsigned) (unsigned char) from[3] << 24);
+    };
 #pragma unroll
-    for (int c=0; c < G::NX; c++)
+    for (int j=0; j < kExactDigits; j++)
+      {
+        const signed char *from=digit_lds+j*DL+16+16*kq-n;
 #pragma unroll
-      for (int j=0; j < kExactDigits; j++)
-        {
-          const signed char *from=digit_lds+j*DL+16+64*c+16*kq-n;
+        for (int w=0; w < 4; w++)
+          t0[j][w]=(int) packed(from+4*w);
+        const signed char *next=digit_lds+j*DL+16+64+kSecondBytes*kq-n;
+#ifndef MH_EXACT_K64
+        t1[j]=G::NX == 2 ? (long) (((unsigned long) packed(next+4) << 32) | (unsigned long) packed(next)) : 0l;
+#else
 #pragma unroll
-          for (int w=0; w < 4; w++)
-            {
-              const unsigned packed=(unsigned) (unsigned char) from[4*w] | ((unsigned) (unsigned char) from[4*w+1] << 8) |
-                ((unsigned) (unsigned char) from[4*w+2] << 16) | ((unsigned) (unsigned char) from[4*w+3] << 24);
-              t[c][j][w]=(int) packed;
-            }
-        }
+        for (int w=0; w < 4; w++)
+          t1[j][w]=G::NX == 2 ? (int) packed(next+4*w) : 0;
+#endif
+      }
     if constexpr (!COLX)
       {
 #pragma unroll
@@ -519,44 +709,6 @@ void blur_fused_exact_kernel(BlurExactArgs args)
   };
   unsigned recomputed=0u;
 
-  // One sample of the column pass exactly as the reference forms it (morphology.c:2743-2776), from
-  // the exact intermediate in the ring: rows first_row+v of `column`, v = 0..K-1.
-  auto ring_reference=[&](int first_group,int first_row,int column,int ch) -> unsigned
-  {
-    double pixel=0.0,gamma=0.0;
-    for (int v=0; v < K; v++)
-      {
-        const int row=first_row+v;
-        unsigned group=(unsigned) (first_group+(row >> 4));
-        while (group >= (unsigned) G::NR)
-          group-=(unsigned) G::NR;
-        const unsigned char *at=ring+((int) group*G::COLS+column)*16+(row & 15);
-        auto sample=[&](int channel) -> unsigned
-        {
-          const unsigned char *p=at+channel*G::CHU;
-          return ((unsigned) p[0] | ((unsigned) p[G::RINGX_PLANE] << 8) | ((unsigned) p[2*G::RINGX_PLANE] << 16) |
-            ((unsigned) p[3*G::RINGX_PLANE] << 24)) ^ 0x80808080u;
-        };
-        if (BLEND && (ch != 3))
-          {
-            const unsigned a=sample(3) >> 16;
-            if (a != 0u)
-              {
-                // alpha*p / alpha: an exact quotient, so the correctly rounded division returns p
-                const double p=(double) sample(ch)/(double) a;
-                const double alpha=kQS*(double) a;
-                pixel+=alpha*args.taps64[v]*p;
-                gamma+=alpha*args.taps64[v];
-              }
-          }
-        else
-          pixel+=args.taps64[v]*(double) (sample(ch) >> 16);
-      }
-    if (BLEND && (ch != 3))
-      pixel=perceptible_reciprocal(gamma)*pixel;
-    return (unsigned) QuantumOps<uint16_t>::clamp(pixel);
-  };
-
   // ---- The walk, software-pipelined over the two barrier intervals of an iteration so that every
   // interval pairs one matrix chain with the INDEPENDENT epilogue of the other pass (the chain of
   // a wave and the epilogue that consumes it never share an interval: four waves of a SIMD that
@@ -575,7 +727,7 @@ void blur_fused_exact_kernel(BlurExactArgs args)
   {
 #pragma unroll
     for (int c=0; c < 5; c++)
-      acc[c]=intx4{args.class_init[c],args.class_init[c],args.class_init[c],args.class_init[c]};
+      acc[c]=intx4{0,0,0,0};
   };
   auto store_row=[&](int block)
   {
@@ -604,54 +756,81 @@ void blur_fused_exact_kernel(BlurExactArgs args)
         }
       else if constexpr (UNSHARP)
         fetch_original(cb);
+      MH_XTRACE_MARK(0);
       if (g < ngroups)
         {
+#ifdef MH_EXACT_TRACE
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          MH_XTRACE_MARK(1);
+#endif
           stage_group();
+#ifdef MH_EXACT_TRACE
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          MH_XTRACE_MARK(2);
+#endif
           if (g+1 < ngroups)
             fetch(g+1);
         }
+      MH_XTRACE_MARK(3);
       // ======================================================================== interval A
       if constexpr (COLX)
         {
           intx4 acc[5];
           init_tiles(acc);
+          {
+            // ring group of this lane's 16 rows of the first chunk: (first + kq) mod NR
+            unsigned group=(unsigned) (first+kq);
+            group=group >= (unsigned) G::NR ? group-(unsigned) G::NR : group;
+            const unsigned char *from=ring+col_entryx+(int) group*(G::COLS*16);
+            intx4 a[4];
 #pragma unroll
-          for (int c=0; c < G::NX; c++)
+            for (int i=BLEND ? 0 : 2; i < 4; i++)
+              a[i]=*reinterpret_cast<const intx4 *>(from+i*G::RINGX_PLANE);
+            exact_products<!BLEND,false>(a,t0,acc);
+          }
+          if constexpr (G::NX == 2)
             {
-              // ring group of this lane's 16 rows: (first + 4c + kq) mod NR.  Beyond the NG groups
-              // of the band the digits are zero: whatever the slot holds is multiplied by 0
-              unsigned group=(unsigned) (first+4*c+kq);
+              // second chunk
+#ifndef MH_EXACT_K64
+              // rows 64..95: 8 rows per lane, groups first+4 and first+5
+              unsigned group=(unsigned) (first+4+(kq >> 1));
+              group=group >= (unsigned) G::NR ? group-(unsigned) G::NR : group;
+              const unsigned char *from=ring+col_entryx+(int) group*(G::COLS*16)+8*(kq & 1);
+#else
+              // rows 64..127: group (first + 4 + kq) mod NR.  Beyond the NG groups of the band the
+              // digits are zero: whatever the slot holds is multiplied by 0
+              unsigned group=(unsigned) (first+4+kq);
               group=group >= (unsigned) G::NR ? group-(unsigned) G::NR : group;
               group=group >= (unsigned) G::NR ? group-(unsigned) G::NR : group;
               const unsigned char *from=ring+col_entryx+(int) group*(G::COLS*16);
-              intx4 a[4];
+#endif
+              SecondOperand a[4];
 #pragma unroll
               for (int i=BLEND ? 0 : 2; i < 4; i++)
-                a[i]=*reinterpret_cast<const intx4 *>(from+i*G::RINGX_PLANE);
-              if (c == 0)
-                exact_products<!BLEND,false>(a,t[c],acc);
-              else
-                exact_products<!BLEND,true>(a,t[c],acc);
+                a[i]=*reinterpret_cast<const SecondOperand *>(from+i*G::RINGX_PLANE);
+              exact_products<!BLEND,true>(a,t1,acc);
             }
           // ---- row epilogue of group g-1 (independent of the chain above)
           {
             unsigned q[4];
-            unsigned doubtful=exact_levels<BLEND>(sums_row,args,q);
-            exact_sums(acc,sums_col);
+            const bool doubtful=exact_levels<BLEND>(sums_row,args,q);
+            exact_sums(acc,args.offset,sums_col);
             const int x=x0+16*ot+n;
-            if ((doubtful != 0u) && (g >= 1) && (g-1 < ngroups) && (x < W))
+            {
+              // source pixel (y clamped like the intermediate's rows) of lane `from`, sample v
+              auto fetch=[&](int from,int v,unsigned (&level)[4])
               {
-                int y=in0+G::GROUP*(g-1)+4*rq+kq;
-                y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
-#pragma unroll
-                for (int ch=0; ch < PX; ch++)
-                  if ((doubtful >> ch) & 1u)
-                    {
-                      q[ch]=(unsigned) conv1d_reference_sample<uint16_t,PX,BLEND>(args.src,W,H,false,x,y,ch,
-                        args.taps64,K,args.shift,0.0);
-                      recomputed++;
-                    }
-              }
+                int yy=in0+G::GROUP*(g-1)+4*rq+(from >> 4);
+                yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
+                int xx=x0+16*ot+(from & 15)-args.shift+v;
+                xx=xx < 0 ? 0 : (xx > W-1 ? W-1 : xx);
+                const uint2 pixel=load_pixel16(args.src+pixel_index(yy,W,xx)*PX);
+                level[0]=pixel.x & 0xffffu; level[1]=pixel.x >> 16; level[2]=pixel.y & 0xffffu;
+                level[3]=PX == 4 ? pixel.y >> 16 : 0u;
+              };
+              recomputed+=settle_doubtful_pixels<BLEND,PX>(doubtful && (g >= 1) && (g-1 < ngroups) && (x < W),lane,
+                args.taps64,K,fetch,q);
+            }
             // the column pass's samples of this pixel, as signed bytes
             unsigned v[4];
             if constexpr (BLEND)
@@ -730,21 +909,23 @@ void blur_fused_exact_kernel(BlurExactArgs args)
           // ---- row epilogue of group g-1: exact levels -> the f16 column pass's samples
           {
             unsigned q[4];
-            unsigned doubtful=exact_levels<BLEND>(sums_row,args,q);
+            const bool doubtful=exact_levels<BLEND>(sums_row,args,q);
             const int x=x0+16*ot+n;
-            if ((doubtful != 0u) && (g >= 1) && (g-1 < ngroups) && (x < W))
+            {
+              // source pixel (y clamped like the intermediate's rows) of lane `from`, sample v
+              auto fetch=[&](int from,int v,unsigned (&level)[4])
               {
-                int y=in0+G::GROUP*(g-1)+4*rq+kq;
-                y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
-#pragma unroll
-                for (int ch=0; ch < PX; ch++)
-                  if ((doubtful >> ch) & 1u)
-                    {
-                      q[ch]=(unsigned) conv1d_reference_sample<uint16_t,PX,BLEND>(args.src,W,H,false,x,y,ch,
-                        args.taps64,K,args.shift,0.0);
-                      recomputed++;
-                    }
-              }
+                int yy=in0+G::GROUP*(g-1)+4*rq+(from >> 4);
+                yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
+                int xx=x0+16*ot+(from & 15)-args.shift+v;
+                xx=xx < 0 ? 0 : (xx > W-1 ? W-1 : xx);
+                const uint2 pixel=load_pixel16(args.src+pixel_index(yy,W,xx)*PX);
+                level[0]=pixel.x & 0xffffu; level[1]=pixel.x >> 16; level[2]=pixel.y & 0xffffu;
+                level[3]=PX == 4 ? pixel.y >> 16 : 0u;
+              };
+              recomputed+=settle_doubtful_pixels<BLEND,PX>(doubtful && (g >= 1) && (g-1 < ngroups) && (x < W),lane,
+                args.taps64,K,fetch,q);
+            }
             // alpha*colour*2^-17 and alpha/2 (plain: level/2)
             float v[4];
             const f32x2 c01={(float) q[0],(float) q[1]};
@@ -774,57 +955,98 @@ void blur_fused_exact_kernel(BlurExactArgs args)
             *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
           }
         }
+#ifdef MH_EXACT_TRACE
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      MH_XTRACE_MARK(4);
       __syncthreads();                           // X: group g staged, ring group g-1 complete
+      MH_XTRACE_MARK(5);
       // ======================================================================== interval B
       {
         // ---- row chain of group g
         intx4 acc[5];
         init_tiles(acc);
+        {
+          intx4 a[4];
 #pragma unroll
-        for (int c=0; c < G::NX; c++)
+          for (int i=BLEND ? 0 : 2; i < 4; i++)
+            a[i]=*reinterpret_cast<const intx4 *>(stage+i*G::STAGE_PLANE+row_entry);
+          exact_products<!BLEND,false>(a,t0,acc);
+        }
+        if constexpr (G::NX == 2)
           {
-            intx4 a[4];
+            SecondOperand a[4];
 #pragma unroll
             for (int i=BLEND ? 0 : 2; i < 4; i++)
-              a[i]=*reinterpret_cast<const intx4 *>(stage+i*G::STAGE_PLANE+row_entry+64*c);
-            if (c == 0)
-              exact_products<!BLEND,false>(a,t[c],acc);
-            else
-              exact_products<!BLEND,true>(a,t[c],acc);
+              a[i]=*reinterpret_cast<const SecondOperand *>(stage+i*G::STAGE_PLANE+row_entry+64-(16-kSecondBytes)*kq);
+            exact_products<!BLEND,true>(a,t1,acc);
           }
         if constexpr (COLX)
           {
             // ---- column epilogue of block cb (independent of the chain above)
             // lane (n, kq): the four channels (registers) of pixel (column 4*wave+kq, row n)
             unsigned q[4];
-            unsigned doubtful=exact_levels<BLEND>(sums_col,args,q);
-            exact_sums(acc,sums_row);
+            const bool doubtful=exact_levels<BLEND>(sums_col,args,q);
+            exact_sums(acc,args.offset,sums_row);
             const int x=x0+4*wave+kq,y=out_begin+G::GROUP*cb+n;
-            if ((doubtful != 0u) && (cb >= 0) && (x < W) && (y < H))
+            {
+              // the exact intermediate out of the ring: pixel column 4*wave + (from>>4), output row
+              // from&15 of the block -> ring row (from&15)+v.  Samples alpha*p (colour; p is the
+              // exact quotient) and alpha*2^16 / p*2^16.
+              auto fetch=[&](int from,int v,unsigned (&level)[4])
               {
+                const int row=(from & 15)+v;
+                int group=first+(row >> 4);
+                group=group >= G::NR ? group-G::NR : group;
+                group=group >= G::NR ? group-G::NR : group;
+                const unsigned char *at=ring+(group*G::COLS+4*wave+(from >> 4))*16+(row & 15);
+                unsigned sample[4];
 #pragma unroll
-                for (int ch=0; ch < 4; ch++)
-                  if ((doubtful >> ch) & 1u)
-                    {
-                      q[ch]=ring_reference(first,n,4*wave+kq,ch);
-                      recomputed++;
-                    }
-              }
+                for (int c=0; c < 4; c++)
+                  {
+                    const unsigned char *p=at+c*G::CHU;
+                    sample[c]=(((BLEND && (c != 3)) ? ((unsigned) p[0] | ((unsigned) p[G::RINGX_PLANE] << 8)) : 0x8080u) |
+                      ((unsigned) p[2*G::RINGX_PLANE] << 16) | ((unsigned) p[3*G::RINGX_PLANE] << 24)) ^ 0x80808080u;
+                  }
+                if constexpr (BLEND)
+                  {
+                    const unsigned a=sample[3] >> 16;
+                    const double inverse=a != 0u ? 1.0/(double) a : 0.0;
+#pragma unroll
+                    for (int c=0; c < 3; c++)
+                      level[c]=(unsigned) ((double) sample[c]*inverse+0.5);   // alpha*p / alpha
+                    level[3]=a;
+                  }
+                else
+                  {
+#pragma unroll
+                    for (int c=0; c < 4; c++)
+                      level[c]=sample[c] >> 16;
+                  }
+              };
+              recomputed+=settle_doubtful_pixels<BLEND,4>(doubtful && (cb >= 0) && (x < W) && (y < H),lane,
+                args.taps64,K,fetch,q);
+            }
             out_tile[n*G::OUT_STRIDE+4*wave+kq]=make_uint2(q[0] | (q[1] << 16),q[2] | (q[3] << 16));
           }
         else
           {
             // the store of the column pass's row in the shadow of the matrix chain
             store_row(cb);
-            exact_sums(acc,sums_row);
+            exact_sums(acc,args.offset,sums_row);
           }
       }
+#ifdef MH_EXACT_TRACE
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+      MH_XTRACE_MARK(6);
       __syncthreads();                           // Y: out_tile complete, staging and ring reads done
+      MH_XTRACE_MARK(7);
       ring_group=ring_group+1 == G::NR ? 0 : ring_group+1;
     }
   if constexpr (COLX)
     store_row(nblocks-1);
-  if ((args.recomputed != nullptr) && (recomputed != 0u))
+  if ((args.recomputed != nullptr) && (recomputed != 0u) && (lane == 0))     // a wave-uniform count
     atomicAdd(args.recomputed,(unsigned long long) recomputed);
 }
 
@@ -836,7 +1058,7 @@ struct ExactTapPlan
   bool ok=false;
   int fraction_bits=0;
   std::vector<signed char> digits;     // [kExactDigits][kExactDigitPitch]
-  int init_blend[5]={0,0,0,0,0},init_plain[5]={0,0,0,0,0};
+  double offset_blend=0.0,offset_plain=0.0;
   double alpha_scale=0.0;
   double colour_window=0.0,alpha_window_blend=0.0,alpha_window_plain=0.0,alpha_floor=0.0;
 };
@@ -885,20 +1107,17 @@ static ExactTapPlan plan_exact_taps(const double *taps,int K)
     }
   const double unit=std::ldexp(1.0,-F);                      // 2^-F
   // kept products: blend i = 0..3, plain i = 2..3; j = 0..4; i+j >= 3; weight 2^(8(i+j-3))
-  auto init_of=[&](int i0,int (&init)[5])
+  auto offset_of=[&](int i0)
   {
-    for (int c=0; c < 5; c++)
-      {
-        double total=0.0;
-        for (int i=i0; i < 4; i++)
-          for (int j=0; j < kExactDigits; j++)
-            if (i+j == c+3)
-              total+=128.0*signed_sum[j];
-        init[c]=(int) total;                      // |total| <= 128*4*81*128
-      }
+    double total=0.0;
+    for (int i=i0; i < 4; i++)
+      for (int j=0; j < kExactDigits; j++)
+        if (i+j >= 3)
+          total+=128.0*signed_sum[j]*std::ldexp(1.0,8*(i+j-3));
+    return total;
   };
-  init_of(0,plan.init_blend);
-  init_of(2,plan.init_plain);
+  plan.offset_blend=offset_of(0);
+  plan.offset_plain=offset_of(2);
   // dropped products (i+j <= 2): |sum_v b_i d_j| <= 255 * sum_v |d_j|, weight 2^(8(i+j)) * 2^-F
   auto dropped_of=[&](int i0)
   {
@@ -992,11 +1211,36 @@ static MhStatus launch_exact_typed(const View &src,BlurExactArgs &args)
         hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
       attribute_set[slot]=true;
     }
+#ifdef MH_EXACT_TRACE
+  const char *trace_path=getenv("MAGICKHIP_EXACT_TRACE");
+  const size_t trace_bytes=4u*4u*48u*12u*sizeof(unsigned long long);
+  if (trace_path != nullptr)
+    {
+      MH_HIP(hipMalloc(reinterpret_cast<void **>(&args.trace),trace_bytes));
+      MH_HIP(hipMemsetAsync(args.trace,0,trace_bytes,src.stream));
+    }
+#endif
+  {
   ProfileScope prof(UNSHARP ? (COLX ? "unsharp_fused_exact" : "unsharp_fused_exact_row") :
     (COLX ? "blur_fused_exact" : "blur_fused_exact_row"),src.stream);
   hipLaunchKernelGGL((blur_fused_exact_kernel<NC,MODE,UNSHARP,COLX>),dim3((unsigned) (8*args.items_per_xcd)),
     dim3(1024),lds,src.stream,args);
   MH_HIP(hipGetLastError());
+  }
+#ifdef MH_EXACT_TRACE
+  if (args.trace != nullptr)
+    {
+      std::vector<unsigned long long> host(trace_bytes/sizeof(unsigned long long));
+      MH_HIP(hipMemcpyAsync(host.data(),args.trace,trace_bytes,hipMemcpyDeviceToHost,src.stream));
+      MH_HIP(hipStreamSynchronize(src.stream));
+      MH_HIP(hipFree(args.trace));
+      if (FILE *f=fopen(trace_path,"wb"))
+        {
+          fwrite(host.data(),1,trace_bytes,f);
+          fclose(f);
+        }
+    }
+#endif
   return MH_OK;
 }
 
@@ -1045,8 +1289,7 @@ MhStatus launch_blur_fused_exact(const View &src,const View &dst,const double *t
   args.taps64=device.taps64;
   args.taps=device.taps;
   args.digits=device.digits;
-  for (int c=0; c < 5; c++)
-    args.class_init[c]=blend ? plan.init_blend[c] : plan.init_plain[c];
+  args.offset=blend ? plan.offset_blend : plan.offset_plain;
   args.alpha_scale=plan.alpha_scale;
   args.colour_window=plan.colour_window;
   args.alpha_half_window=0.5-(blend ? plan.alpha_window_blend : plan.alpha_window_plain);
@@ -1057,6 +1300,7 @@ MhStatus launch_blur_fused_exact(const View &src,const View &dst,const double *t
     args.threshold=level > 131072.0 ? 131072 : (level < 0.0 ? 0 : (int) level);
   }
   args.recomputed=recomputed_device;
+  args.trace=nullptr;
   if ((args.recomputed == nullptr) && g_count_recomputed && (src.device >= 0) && (src.device < 64))
     args.recomputed=g_recomputed[src.device];
   *handled=true;
