@@ -214,9 +214,14 @@ static MhStatus separable_convolve(const View &src,const View &dst,const MhKerne
 // One MorphologyPrimitive(curr -> work), morphology.c:2566.  `changed`
 // (optional, device counter, must be zero on entry) accumulates the number of
 // changed channel values.
+// mode: the precision of THIS primitive.  MH_PRECISION_FAST is the caller's choice only for a
+// primitive whose result leaves the operator; one that feeds another primitive (the row pass of
+// BlurImage, the first kernels of a list, all but the last iteration) runs EXACT, so that the
+// Quantum-rounded intermediate is the reference's own and the FAST result is within +-1 level of
+// the reference by construction.
 static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod method,
   const MhKernelInfo *kernel,double bias,const Roles &roles,const MhImage *desc,
-  unsigned long long *changed)
+  unsigned long long *changed,MhPrecision mode)
 {
   if ((method == MH_MORPHOLOGY_CONVOLVE) && !kernel_has_nan(kernel) &&
       ((kernel->width == 1) || (kernel->height == 1)))
@@ -228,14 +233,14 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
         {
           p.ntaps=(int) kernel->height;
           p.origin=(int) kernel->y;
-          return launch_conv1d(src,dst,true,p,roles,precision(),changed);
+          return launch_conv1d(src,dst,true,p,roles,mode,changed);
         }
       p.ntaps=(int) kernel->width;
       p.origin=(int) kernel->x;
-      return launch_conv1d(src,dst,false,p,roles,precision(),changed);
+      return launch_conv1d(src,dst,false,p,roles,mode,changed);
     }
   if ((method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
-      !kernel_has_nan(kernel))
+      (mode == MH_PRECISION_FAST) && !kernel_has_nan(kernel))
     {
       bool handled=false;
       MH_TRY(separable_convolve(src,dst,kernel,roles,&handled));
@@ -245,7 +250,7 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
   // FAST, Q16, RGBA (alpha-weighted, alpha last) or four plain channels, kernels of 5 x 5 and
   // more: the w x h sum as h banded products on the matrix cores (convolve2d_mfma.hip)
   if ((method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
-      (precision() == MH_PRECISION_FAST) && (src.quantum == MH_QUANTUM_U16) && (src.channels == 4) &&
+      (mode == MH_PRECISION_FAST) && (src.quantum == MH_QUANTUM_U16) && (src.channels == 4) &&
       (roles.copy_mask == 0) && (!roles.blend || (roles.alpha == 3)) &&
       (getenv("MAGICKHIP_NO_MFMA") == nullptr) && (getenv("MAGICKHIP_NO_MFMA_2D") == nullptr))
     {
@@ -543,8 +548,11 @@ static MhStatus morphology_apply(const View &src,const View &dst,const MhImage *
                     MH_HIP(hipMemsetAsync(changed_dev,0,sizeof(unsigned long long),src.stream));
                   MhKernelInfo single=*this_kernel;
                   single.next=nullptr;
+                  // FAST belongs to the primitive whose result leaves the operator
+                  const bool feeds_another=(compose >= 0) || (iterations < 0) || (norm->next != nullptr) ||
+                    (stage_loop != stage_limit) || (kernel_loop != kernel_limit) || (method_limit != 1);
                   MH_TRY(primitive(*curr,*work,prim,&single,bias,roles,desc,
-                    want_counts ? changed_dev : nullptr));
+                    want_counts ? changed_dev : nullptr,feeds_another ? MH_PRECISION_EXACT : precision()));
                   if (want_counts)
                     {
                       unsigned long long host=0;
@@ -667,7 +675,7 @@ MH_API MhStatus MagickHipMorphologyPrimitive(const MhImage *image,MhImage *morph
   MhKernelInfo single=*kernel;
   single.next=nullptr;
   MH_TRY(primitive(pair.src.view,pair.dst.view,method,&single,bias,roles,image,
-    counter.as<unsigned long long>()));
+    counter.as<unsigned long long>(),precision()));
   unsigned long long host=0;
   MH_HIP(hipMemcpyAsync(&host,counter.ptr,sizeof(host),hipMemcpyDeviceToHost,
     pair.src.view.stream));
@@ -889,7 +897,8 @@ static MhStatus unsharp_fused(const View &src,const View &dst,const MhKernelInfo
   second.origin=(int) vertical->y;
   if ((second.ntaps < 2) || (second.ntaps > 113))
     return MH_OK;                                // outside the matrix-core kernel's reach
-  MH_TRY(launch_conv1d(src,rows,false,first,roles,MH_PRECISION_FAST,nullptr));
+  // (the intermediate is the reference's own: exact row pass)
+  MH_TRY(launch_conv1d(src,rows,false,first,roles,MH_PRECISION_EXACT,nullptr));
   MH_TRY(launch_conv1d_unsharp(rows,dst,src,second,roles.blend,gain,threshold,fused));
   return MH_OK;
 }

@@ -51,6 +51,9 @@ def check(name, got, want, limit, detail):
     return 0
 
 
+# STRESS_OPS=0,1,2 restricts the operators (0 FAST blur, 1 EXACT blur, 2 FAST unsharp, 3 Erode/Dilate,
+# 4 histogram operators, 5 FAST 2-D convolve, 6 FAST Lab)
+only_ops = [int(t) for t in os.environ.get("STRESS_OPS", "").split(",") if t.strip()]
 t0 = time.time()
 cases = failures = 0
 while time.time() - t0 < budget:
@@ -60,6 +63,8 @@ while time.time() - t0 < budget:
     kind = int(rng.integers(0, 5))
     px = pixels(rows, cols, kind)
     op = int(rng.integers(0, 7))
+    if only_ops:
+        op = only_ops[int(rng.integers(0, len(only_ops)))]
     detail = "%dx%d kind %d" % (rows, cols, kind)
     ref = refmod.RefImage(px)
     if op == 0:                                    # FAST blur, every kernel length of the fused launch
