@@ -703,10 +703,13 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = profile_end()
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if distributed:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in every]
+        elapsed = max(float(t.item()) for t in every)          # the job is as slow as its slowest rank
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -719,6 +722,12 @@ def main():
             "dtype": config_dtype(args),
             "data": "synthetic",
             "tolerance": config_tolerance(args),
+            "per_rank_ms_per_step": [round(t, 4) for t in per_rank_ms],
+            "collective": ({"backend": args.backend, "used_rccl": args.backend == "nccl",
+                            "what": "one all-reduce of the 65536 x channels histogram table per step"}
+                           if (distributed and args.config == "equalize") else
+                           {"backend": args.backend if distributed else None, "used_rccl": False,
+                            "what": "none: independent images / row bands with recomputed halos"}),
             "config": {"workload": workload, "precision": args.precision, "images_per_step": world
                        if args.config == "c2" else None, "config": args.config, "clock_ramp_seconds": ramp},
         }

@@ -38,7 +38,10 @@ class Image:
     MagickCore shim reads from ``Image``): channel traits, alpha, colourspace."""
 
     def __init__(self, pixels, colorspace="srgb", has_alpha=None, channel_mask=ALL_CHANNELS,
-                 copy_channels=(), intensity=0):
+                 copy_channels=(), intensity=0, stream=None):
+        # stream: the raw HIP stream handle the pixels belong to (device memory; default: torch's
+        # current stream of the tensor's device when a descriptor is made)
+        self.stream = stream
         if pixels.ndim == 2:
             pixels = pixels.reshape(pixels.shape[0], pixels.shape[1], 1)
         if pixels.ndim != 3:
@@ -95,7 +98,8 @@ class Image:
         if self.memory == _lib.MEMORY_DEVICE:
             import torch
             d.device = self.pixels.device.index if self.pixels.device.index is not None else 0
-            d.stream = torch.cuda.current_stream(self.pixels.device).cuda_stream
+            d.stream = self.stream if self.stream is not None else \
+                torch.cuda.current_stream(self.pixels.device).cuda_stream
         return d
 
     def like(self, rows=None, columns=None):

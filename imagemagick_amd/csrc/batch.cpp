@@ -37,6 +37,22 @@ namespace mh {
 static std::mutex g_stream_lock;
 static std::map<std::pair<int,int>,hipStream_t> g_streams;
 
+// MhTerminus: after the pools (whose blocks the streams tagged) have been trimmed
+void release_batch_streams()
+{
+  std::lock_guard<std::mutex> guard(g_stream_lock);
+  for (auto &entry : g_streams)
+    {
+      DeviceGuard device;
+      if (device.enter(entry.first.first) == hipSuccess)
+        {
+          (void) hipStreamSynchronize(entry.second);
+          (void) hipStreamDestroy(entry.second);
+        }
+    }
+  g_streams.clear();
+}
+
 static hipStream_t batch_stream(int physical,int index)
 {
   std::lock_guard<std::mutex> guard(g_stream_lock);
@@ -218,6 +234,30 @@ static MhStatus apply_operator(const PreparedOperator &p,Working &cur)
   return MH_OK;
 }
 
+// A device-resident image belongs to the CALLER's stream (image.stream; null = the default
+// stream of image.device): work the caller has enqueued there — a kernel still filling the
+// tensor, a previous reader of the result buffer — must be ordered before anything this
+// library enqueues on its own worker streams.  The wait is a device-side event, not a host sync.
+static MhStatus wait_for_caller(const MhImage &image,hipStream_t mine)
+{
+  if (image.memory != MH_MEMORY_DEVICE)
+    return MH_OK;
+  const int home=resolve_device(&image);
+  hipStream_t theirs=resolve_stream(&image,home);
+  if (theirs == mine)
+    return MH_OK;
+  DeviceGuard guard;
+  MH_HIP(guard.enter(home));
+  hipEvent_t event=nullptr;
+  MH_HIP(hipEventCreateWithFlags(&event,hipEventDisableTiming));
+  hipError_t err=hipEventRecord(event,theirs);
+  if (err == hipSuccess)
+    err=hipStreamWaitEvent(mine,event,0);
+  (void) hipEventDestroy(event);                  // released once the wait has consumed it
+  MH_HIP(err);
+  return MH_OK;
+}
+
 // Bring `source` onto (device, stream) as a pool-owned working copy.
 static MhStatus working_copy(const MhImage &source,int device,hipStream_t stream,Working &out)
 {
@@ -234,7 +274,12 @@ static MhStatus working_copy(const MhImage &source,int device,hipStream_t stream
   out.owned=true;
   if (source.memory == MH_MEMORY_HOST)
     return MhUpload(device,memory,source.pixels,bytes,stream);
-  MH_HIP(hipMemcpyAsync(memory,source.pixels,bytes,hipMemcpyDeviceToDevice,stream));
+  MH_TRY(wait_for_caller(source,stream));
+  const int home=resolve_device(&source);
+  if (home == device)
+    MH_HIP(hipMemcpyAsync(memory,source.pixels,bytes,hipMemcpyDeviceToDevice,stream));
+  else                                            // works with and without peer access
+    MH_HIP(hipMemcpyPeerAsync(memory,device,source.pixels,home,bytes,stream));
   return MH_OK;
 }
 
@@ -251,7 +296,15 @@ static MhStatus deliver(const Working &cur,MhImage &result)
   else
     {
       if (result.pixels != cur.image.pixels)
-        MH_HIP(hipMemcpyAsync(result.pixels,cur.image.pixels,bytes,hipMemcpyDeviceToDevice,cur.stream));
+        {
+          MH_TRY(wait_for_caller(result,cur.stream));       // earlier readers / writers of the buffer
+          const int home=resolve_device(&result);
+          if (home == cur.device)
+            MH_HIP(hipMemcpyAsync(result.pixels,cur.image.pixels,bytes,hipMemcpyDeviceToDevice,cur.stream));
+          else
+            MH_HIP(hipMemcpyPeerAsync(result.pixels,home,cur.image.pixels,cur.device,bytes,cur.stream));
+        }
+      // the caller's stream is not ours: the result is complete when this returns
       MH_HIP(hipStreamSynchronize(cur.stream));
     }
   result.colorspace=cur.image.colorspace;
@@ -307,6 +360,21 @@ static Rccl &rccl()
   return r;
 }
 
+// communicators by device set (all_reduce_tables), destroyed by MhTerminus
+static std::mutex g_comm_lock;
+static std::map<std::vector<int>,std::vector<ncclComm_t>> g_comms;
+
+void release_rccl_communicators()
+{
+  std::lock_guard<std::mutex> guard(g_comm_lock);
+  Rccl &r=rccl();
+  for (auto &entry : g_comms)
+    for (ncclComm_t comm : entry.second)
+      if (r.CommDestroy != nullptr)
+        (void) r.CommDestroy(comm);
+  g_comms.clear();
+}
+
 // Band b's table (device memory on band b's device, stream b) becomes the sum over all bands.
 struct TableView { unsigned long long *table; int device; hipStream_t stream; };
 
@@ -322,23 +390,30 @@ static MhStatus all_reduce_tables(std::vector<TableView> &bands,size_t count,boo
   Rccl &r=rccl();
   if (distinct && r.ready)
     {
-      // one communicator per call over exactly these devices (2 MB tables: latency-bound)
+      // one communicator per set of devices, created on the first use and kept until MhTerminus
+      // (ncclCommInitAll costs tens to hundreds of milliseconds; the all-reduce of a 2 MB table
+      // is latency-bound)
       std::vector<int> devices;
       for (const TableView &v : bands)
         devices.push_back(v.device);
-      std::vector<ncclComm_t> comms(bands.size());
-      if (r.CommInitAll(comms.data(),(int) bands.size(),devices.data()) == ncclSuccess)
+      std::lock_guard<std::mutex> guard(g_comm_lock);       // also serialises collectives on a set
+      auto it=g_comms.find(devices);
+      if (it == g_comms.end())
         {
+          std::vector<ncclComm_t> comms(bands.size());
+          if (r.CommInitAll(comms.data(),(int) bands.size(),devices.data()) == ncclSuccess)
+            it=g_comms.emplace(devices,std::move(comms)).first;
+        }
+      if (it != g_comms.end())
+        {
+          const std::vector<ncclComm_t> &comms=it->second;
           bool ok=r.GroupStart() == ncclSuccess;
           for (size_t b=0; ok && (b < bands.size()); b++)
             ok=r.AllReduce(bands[b].table,bands[b].table,count,ncclUint64,ncclSum,comms[b],
               bands[b].stream) == ncclSuccess;
           ok=(r.GroupEnd() == ncclSuccess) && ok;
           for (size_t b=0; b < bands.size(); b++)
-            {
-              (void) hipStreamSynchronize(bands[b].stream);
-              (void) r.CommDestroy(comms[b]);
-            }
+            ok=(hipStreamSynchronize(bands[b].stream) == hipSuccess) && ok;
           if (ok)
             {
               *used_rccl=true;
@@ -381,6 +456,13 @@ MhStatus host_banded_operator(const MhOperator &op,const MhKernelInfo *kernel,co
   *handled=false;
   if ((image->memory != MH_MEMORY_HOST) || (result->memory != MH_MEMORY_HOST) ||
       (getenv("MAGICKHIP_NO_BANDED") != nullptr))
+    return MH_OK;
+  // the bands are described by the SOURCE's descriptor: a result with other channel traits, alpha
+  // trait or channel mask (the whole-frame path honours them, channel_roles(image, result)) keeps
+  // that path
+  if ((result->alpha_trait != image->alpha_trait) || (result->channel_mask != image->channel_mask) ||
+      (result->number_channels != image->number_channels) ||
+      (memcmp(result->channel_traits,image->channel_traits,sizeof(image->channel_traits)) != 0))
     return MH_OK;
   const size_t row_bytes=image->columns*(size_t) image->number_channels*
     (image->quantum == MH_QUANTUM_U16 ? 2u : 4u);
@@ -525,14 +607,27 @@ MH_API MhStatus MagickHipBatchImages(const MhOperator *operators,size_t number_o
           {
             // a device-resident input that is not to be overwritten is worked on as a copy
             const bool in_place=(results == nullptr) && (images[i].memory == MH_MEMORY_DEVICE);
+            DeviceGuard home_guard;
             if (in_place)
               {
-                cur.image=images[i];
-                cur.image.stream=stream;
-                cur.image.device=device;
-                cur.device=device;
-                cur.stream=stream;
-                cur.owned=false;
+                // The kernels dereference the caller's memory: they must run on the GPU that
+                // owns it (no peer access is ever enabled; a kernel of another GPU would fault).
+                // The worker lends its thread and a stream of THAT device.
+                const int home=resolve_device(&images[i]);
+                hipStream_t home_stream=home == device ? stream :
+                  batch_stream(home,(int) (w/(size_t) devices)+8*(logical/physical));
+                if ((home_stream == nullptr) || (home_guard.enter(home) != hipSuccess))
+                  status=fail(MH_DEVICE_ERROR,"BatchImages: cannot set up device %d",home);
+                else
+                  {
+                    cur.image=images[i];
+                    cur.image.stream=home_stream;
+                    cur.image.device=home;
+                    cur.device=home;
+                    cur.stream=home_stream;
+                    cur.owned=false;
+                    status=wait_for_caller(images[i],home_stream);
+                  }
               }
             else
               status=working_copy(images[i],device,stream,cur);
@@ -555,8 +650,8 @@ MH_API MhStatus MagickHipBatchImages(const MhOperator *operators,size_t number_o
                 MhImage *target=results != nullptr ? &results[i] : const_cast<MhImage *>(&images[i]);
                 status=deliver(cur,*target);
               }
-            else
-              (void) hipStreamSynchronize(stream);
+            else if (cur.stream != nullptr)
+              (void) hipStreamSynchronize(cur.stream);
             cur.release();
           }
         if (status != MH_OK)
@@ -817,7 +912,8 @@ MH_API MhStatus MagickHipShardedImage(const MhOperator *operators,size_t number_
       const size_t bytes=(band.y1-band.y0)*row_bytes;
       if (result->memory == MH_MEMORY_HOST)
         status=MhDownload(band.device,to,from,bytes,band.stream);
-      else if ((hipMemcpyPeerAsync(to,result->device < 0 ? default_device() : result->device,from,
+      else if ((wait_for_caller(*result,band.stream) != MH_OK) ||
+               (hipMemcpyPeerAsync(to,result->device < 0 ? default_device() : result->device,from,
                   band.device,bytes,band.stream) != hipSuccess) ||
                (hipStreamSynchronize(band.stream) != hipSuccess))
         status=fail(MH_DEVICE_ERROR,"ShardedImage: cannot deliver band %d",b);

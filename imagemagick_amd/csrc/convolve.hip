@@ -1667,7 +1667,8 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
                   host_floats[v]=(float) params.taps[K-1-v];
                 }
               const void *taps=nullptr;
-              MH_TRY(shared_table(src.device,src.stream,host.data(),host.size()*sizeof(double),&taps));
+              std::shared_ptr<void> keep;       // until the launch below is enqueued
+              MH_TRY(shared_table(src.device,src.stream,host.data(),host.size()*sizeof(double),&taps,&keep));
               const double *taps64=static_cast<const double *>(taps);
               bool handled=false;
               MH_TRY(launch_conv1d_mfma(src,dst,vertical,reinterpret_cast<const float *>(taps64+K),K,

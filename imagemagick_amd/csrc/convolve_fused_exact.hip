@@ -1154,6 +1154,7 @@ struct ExactDeviceTaps
   const double *taps64=nullptr;
   const float *taps=nullptr;
   const signed char *digits=nullptr;
+  std::shared_ptr<void> keep;           // the device block, until the launch is enqueued
 };
 
 static MhStatus upload_exact_taps(const View &src,const double *taps,int K,const ExactTapPlan &plan,
@@ -1171,7 +1172,7 @@ static MhStatus upload_exact_taps(const View &src,const double *taps,int K,const
     }
   std::memcpy(host_digits,plan.digits.data(),plan.digits.size());
   const void *device=nullptr;
-  MH_TRY(shared_table(src.device,src.stream,host.data(),host.size()*sizeof(double),&device));
+  MH_TRY(shared_table(src.device,src.stream,host.data(),host.size()*sizeof(double),&device,&out->keep));
   out->taps64=static_cast<const double *>(device);
   out->taps=reinterpret_cast<const float *>(out->taps64+doubles);
   out->digits=reinterpret_cast<const signed char *>(out->taps64+doubles+floats);

@@ -7,6 +7,7 @@
 #include <cstddef>
 #include <cstdarg>
 #include <vector>
+#include <memory>
 
 #include "magickhip.h"
 
@@ -95,10 +96,15 @@ MhStatus upload_table(Temp &dst,int device,hipStream_t stream,const void *host,s
 // A small read-only table (filter taps) that many calls share: looked up by content, uploaded on
 // the first use and kept on the device (a BlurImage call otherwise pays a copy and two queue
 // gaps, ~10 us, in front of a 0.43 ms kernel).  *device_ptr stays valid for work enqueued on
-// `stream` by this call.
-MhStatus shared_table(int device,hipStream_t stream,const void *host,size_t bytes,const void **device_ptr);
+// `stream` by this call as long as the caller holds *keep (the cache may evict the entry — a
+// thread with 32 newer tables in between — but the device block is freed only when the last
+// holder lets go, and hipFree then waits for the kernels already enqueued on it).
+MhStatus shared_table(int device,hipStream_t stream,const void *host,size_t bytes,const void **device_ptr,
+  std::shared_ptr<void> *keep=nullptr);
 void release_shared_tables();       // MhTerminus
 void release_resize_tables();       // the resize launchers' device-side tables (resize.hip)
+void release_batch_streams();       // the worker streams of batch.cpp (after the pools were trimmed)
+void release_rccl_communicators();  // batch.cpp's cached communicators
 
 // Several host tables as ONE device block and ONE host-to-device copy (a resize pass has ten
 // tables: ten stream-ordered copies cost 150-300 us of idle GPU between two kernels of a few

@@ -383,7 +383,8 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
       host_floats[v]=(float) row->values[K-1-v];
     }
   const void *taps=nullptr;
-  MH_TRY(shared_table(src.device,src.stream,host.data(),host.size()*sizeof(double),&taps));
+  std::shared_ptr<void> keep;                   // until the launch below is enqueued
+  MH_TRY(shared_table(src.device,src.stream,host.data(),host.size()*sizeof(double),&taps,&keep));
   const double *taps64=static_cast<const double *>(taps);
   return launch_blur_fused(src,dst,reinterpret_cast<const float *>(taps64+K),taps64,
     K,K-1-(int) row->x,roles.blend,handled,unsharp,gain,threshold);

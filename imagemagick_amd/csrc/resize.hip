@@ -1172,8 +1172,18 @@ struct PassTables
   size_t i_tile_lo=0,i_tile_span=0;
   int max_span=1,overhang=0,maxt=8;
   hipEvent_t ready=nullptr;          // the upload, for callers on another stream
+  int device=-1;
   ~PassTables()
   {
+    // The tables are shared across streams; their block goes back to a pool that tags it with
+    // the BUILDER's stream only.  Evictions are rare (more than eight geometries in flight):
+    // wait for the device, so that no kernel of another stream can still be reading them.
+    if (device >= 0)
+      {
+        DeviceGuard guard;
+        if (guard.enter(device) == hipSuccess)
+          (void) hipDeviceSynchronize();
+      }
     if (ready != nullptr)
       (void) hipEventDestroy(ready);
   }
@@ -1301,6 +1311,7 @@ static MhStatus build_pass_tables(PassTables &p,const TapTable &table,bool verti
       p.i_tile_span=p.tables.add(tile_span.data(),tile_span.size()*sizeof(int));
     }
   MH_TRY(p.tables.upload(device,stream));
+  p.device=device;
   MH_HIP(hipEventCreateWithFlags(&p.ready,hipEventDisableTiming));
   MH_HIP(hipEventRecord(p.ready,stream));
   return MH_OK;

@@ -177,6 +177,8 @@ MhStatus pool_alloc(int device,size_t bytes,hipStream_t stream,void **ptr)
     bytes=kPoolSmall;
   size_t capacity=bytes <= (64u<<10) ? ((bytes+kPoolSmall-1)/kPoolSmall)*kPoolSmall :
     ((bytes+kPoolGranule-1)/kPoolGranule)*kPoolGranule;
+  bool reused=false;
+  hipStream_t reused_from=nullptr;
   {
     std::lock_guard<std::mutex> guard(r.lock);
     DeviceState &d=r.devices[(size_t) device];
@@ -188,15 +190,19 @@ MhStatus pool_alloc(int device,size_t bytes,hipStream_t stream,void **ptr)
         d.free_blocks.erase(it);
         d.cached_bytes-=b.bytes;
         d.live[b.ptr]=b.bytes;
-        if (b.stream != stream)
-          {
-            // last used on another stream: order behind it
-            (void) hipStreamSynchronize(b.stream);
-          }
         *ptr=b.ptr;
-        return MH_OK;
+        reused_from=b.stream;
+        reused=true;
       }
   }
+  if (reused)
+    {
+      // last used on another stream: order behind it — outside the runtime lock, so that the
+      // workers of the other devices and streams keep allocating meanwhile
+      if (reused_from != stream)
+        (void) hipStreamSynchronize(reused_from);
+      return MH_OK;
+    }
   int prev=0;
   (void) hipGetDevice(&prev);
   if (prev != device)
@@ -348,12 +354,25 @@ MhStatus upload_table(Temp &dst,int device,hipStream_t stream,const void *host,s
 }
 
 namespace {
+// the device block of a shared table: freed when the cache AND every caller that is about to
+// launch a kernel on it have let go (hipFree then waits for whatever is enqueued)
+struct SharedBlock
+{
+  void *ptr=nullptr;
+  hipEvent_t ready=nullptr;
+  ~SharedBlock()
+  {
+    if (ptr != nullptr)
+      (void) hipFree(ptr);
+    if (ready != nullptr)
+      (void) hipEventDestroy(ready);
+  }
+};
 struct SharedTable
 {
   int device;
   std::vector<unsigned char> content;
-  void *ptr;
-  hipEvent_t ready;
+  std::shared_ptr<SharedBlock> block;
   hipStream_t stream;
 };
 // (never destroyed: the blocks belong to a runtime that may be gone at process exit)
@@ -364,15 +383,11 @@ std::vector<SharedTable> &shared_tables() { static std::vector<SharedTable> &v=*
 void release_shared_tables()
 {
   std::lock_guard<std::mutex> guard(shared_tables_lock());
-  for (SharedTable &e : shared_tables())
-    {
-      (void) hipFree(e.ptr);
-      (void) hipEventDestroy(e.ready);
-    }
   shared_tables().clear();
 }
 
-MhStatus shared_table(int device,hipStream_t stream,const void *host,size_t bytes,const void **device_ptr)
+MhStatus shared_table(int device,hipStream_t stream,const void *host,size_t bytes,const void **device_ptr,
+  std::shared_ptr<void> *keep)
 {
   typedef SharedTable Entry;
   constexpr size_t kEntries=32;
@@ -386,8 +401,10 @@ MhStatus shared_table(int device,hipStream_t stream,const void *host,size_t byte
         entries.erase(entries.begin()+(ptrdiff_t) i);
         entries.insert(entries.begin(),std::move(hit));
         if (entries[0].stream != stream)
-          MH_HIP(hipStreamWaitEvent(stream,entries[0].ready,0));
-        *device_ptr=entries[0].ptr;
+          MH_HIP(hipStreamWaitEvent(stream,entries[0].block->ready,0));
+        *device_ptr=entries[0].block->ptr;
+        if (keep != nullptr)
+          *keep=entries[0].block;
         return MH_OK;
       }
   DeviceGuard device_guard;
@@ -395,32 +412,19 @@ MhStatus shared_table(int device,hipStream_t stream,const void *host,size_t byte
   Entry e;
   e.device=device;
   e.content.assign(static_cast<const unsigned char *>(host),static_cast<const unsigned char *>(host)+bytes);
-  e.ptr=nullptr;
-  e.ready=nullptr;
+  e.block=std::make_shared<SharedBlock>();
   e.stream=stream;
-  MH_HIP(hipMalloc(&e.ptr,bytes < 256 ? 256 : bytes));
+  MH_HIP(hipMalloc(&e.block->ptr,bytes < 256 ? 256 : bytes));
   // the entry owns the bytes: the pageable copy may be staged whenever the runtime likes
-  hipError_t err=hipMemcpyAsync(e.ptr,e.content.data(),bytes,hipMemcpyHostToDevice,stream);
-  if (err == hipSuccess)
-    err=hipEventCreateWithFlags(&e.ready,hipEventDisableTiming);
-  if (err == hipSuccess)
-    err=hipEventRecord(e.ready,stream);
-  if (err != hipSuccess)
-    {
-      (void) hipFree(e.ptr);
-      if (e.ready != nullptr)
-        (void) hipEventDestroy(e.ready);
-      MH_HIP(err);
-    }
-  *device_ptr=e.ptr;
+  MH_HIP(hipMemcpyAsync(e.block->ptr,e.content.data(),bytes,hipMemcpyHostToDevice,stream));
+  MH_HIP(hipEventCreateWithFlags(&e.block->ready,hipEventDisableTiming));
+  MH_HIP(hipEventRecord(e.block->ready,stream));
+  *device_ptr=e.block->ptr;
+  if (keep != nullptr)
+    *keep=e.block;
   entries.insert(entries.begin(),std::move(e));
   if (entries.size() > kEntries)
-    {
-      // hipFree waits for the device: nothing can still read the evicted block
-      (void) hipFree(entries.back().ptr);
-      (void) hipEventDestroy(entries.back().ready);
-      entries.pop_back();
-    }
+    entries.pop_back();            // the block goes when its last holder lets go (SharedBlock)
   return MH_OK;
 }
 
@@ -739,11 +743,13 @@ MH_API void MhTerminus(void)
   if (r.init_status != MH_OK)
     return;
   drain_profile();
+  release_rccl_communicators();
   release_shared_tables();
   release_resize_tables();
   pool_trim();
   staging_trim();
   release_color_tables();
+  release_batch_streams();
 }
 
 MH_API int MhDeviceCount(void) { return device_count(); }
