@@ -234,15 +234,23 @@ def convolve_image(image, kernel):
     return out
 
 
-def morphology_image(image, method, iterations, kernel, bias=0.0, scale=None):
+MORPHOLOGY_COMPOSE = {None: 0, "undefined": 0, "none": 1, "no": 1, "lighten": 2, "difference": 3}
+
+
+def morphology_image(image, method, iterations, kernel, bias=0.0, scale=None, compose=None):
     """MorphologyImage(image, method, iterations, kernel) — MagickCore/morphology.c:4129.
-    scale=(1.0, 1) is `-define convolve:scale='!'` (the kernel normalised before use)."""
+    scale=(1.0, 1) is `-define convolve:scale='!'` (the kernel normalised before use);
+    compose is `-define morphology:compose=` (None: the method's default; "None", "Lighten",
+    "Difference": how the results of a kernel list are merged; any other operator raises
+    MagickHipError: the CPU path's business)."""
     lib = _lib.load()
     out = image.like()
+    key = compose.lower() if isinstance(compose, str) else compose
     with _Kernel(kernel, scale) as k:
-        _lib.check(lib.MagickHipMorphologyImage(ctypes.byref(image.descriptor()),
-                                                ctypes.byref(out.descriptor()),
-                                                MORPHOLOGY[method.lower()], iterations, k, bias))
+        _lib.check(lib.MagickHipMorphologyImageCompose(ctypes.byref(image.descriptor()),
+                                                       ctypes.byref(out.descriptor()),
+                                                       MORPHOLOGY[method.lower()], iterations, k, bias,
+                                                       MORPHOLOGY_COMPOSE.get(key, 4)))
     return out
 
 

@@ -162,6 +162,9 @@ PROTOTYPES = [
     ("MagickHipMorphologyImage", ctypes.c_int, [_P(MhImage), _P(MhImage), ctypes.c_int,
                                                 ctypes.c_ssize_t, _P(MhKernelInfo),
                                                 ctypes.c_double]),
+    ("MagickHipMorphologyImageCompose", ctypes.c_int, [_P(MhImage), _P(MhImage), ctypes.c_int,
+                                                       ctypes.c_ssize_t, _P(MhKernelInfo),
+                                                       ctypes.c_double, ctypes.c_int]),
     ("MagickHipMorphologyPrimitive", ctypes.c_int, [_P(MhImage), _P(MhImage), ctypes.c_int,
                                                     _P(MhKernelInfo), ctypes.c_double,
                                                     _P(ctypes.c_ssize_t)]),

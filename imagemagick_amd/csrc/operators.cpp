@@ -396,12 +396,16 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
 // device kernels.  Distance / Voronoi (MorphologyPrimitiveDirect) are not parallel.
 static MhStatus morphology_apply(const View &src,const View &dst,const MhImage *desc,
   const Roles &roles,MhMorphologyMethod method,ptrdiff_t iterations,
-  const MhKernelInfo *kernel,double bias,ptrdiff_t *changed_out)
+  const MhKernelInfo *kernel,double bias,ptrdiff_t *changed_out,
+  MhMorphologyCompose compose_override=MH_MORPHOLOGY_COMPOSE_DEFAULT)
 {
   if (iterations == 0)
     return fail(MH_UNSUPPORTED,"morphology: zero iterations is a null operation");
+  // (a kernel list whose results are COMPOSED instead of re-iterated is not BlurImage's list)
+  const bool reiterate=(compose_override == MH_MORPHOLOGY_COMPOSE_DEFAULT) ||
+    (compose_override == MH_MORPHOLOGY_COMPOSE_NONE);
   if ((method == MH_MORPHOLOGY_CONVOLVE) && (iterations == 1) && (changed_out == nullptr) &&
-      (kernel->next != nullptr))
+      (kernel->next != nullptr) && reiterate)
     {
       bool handled=false;
       MH_TRY(fused_blur(src,dst,kernel,roles,bias,&handled));
@@ -446,6 +450,17 @@ static MhStatus morphology_apply(const View &src,const View &dst,const MhImage *
     default:
       // Distance/Voronoi are sequential (MorphologyPrimitiveDirect)
       return fail(MH_UNSUPPORTED,"morphology method %d is not accelerated",(int) method);
+  }
+  // the user's morphology:compose (morphology.c:3779-3782, :4206-4215): how the results of the
+  // kernels of a list are merged — overrides the method's default, nothing else
+  switch (compose_override)
+  {
+    case MH_MORPHOLOGY_COMPOSE_DEFAULT: break;
+    case MH_MORPHOLOGY_COMPOSE_NONE: compose=-1; break;
+    case MH_MORPHOLOGY_COMPOSE_LIGHTEN: compose=MH_COMPOSITE_LIGHTEN; break;
+    case MH_MORPHOLOGY_COMPOSE_DIFFERENCE: compose=MH_COMPOSITE_DIFFERENCE; break;
+    default:
+      return fail(MH_UNSUPPORTED,"morphology:compose operator %d is not accelerated",(int) compose_override);
   }
   std::unique_ptr<MhKernelInfo,MhKernelInfo *(*)(MhKernelInfo *)> reflected(nullptr,
     MhDestroyKernelInfo);
@@ -626,9 +641,18 @@ extern "C" {
 MH_API MhStatus MagickHipMorphologyImage(const MhImage *image,MhImage *morphology_image,
   MhMorphologyMethod method,ptrdiff_t iterations,const MhKernelInfo *kernel,double bias)
 {
+  return MagickHipMorphologyImageCompose(image,morphology_image,method,iterations,kernel,bias,
+    MH_MORPHOLOGY_COMPOSE_DEFAULT);
+}
+
+MH_API MhStatus MagickHipMorphologyImageCompose(const MhImage *image,MhImage *morphology_image,
+  MhMorphologyMethod method,ptrdiff_t iterations,const MhKernelInfo *kernel,double bias,
+  MhMorphologyCompose compose)
+{
   MH_TRY(gate_pair(image,morphology_image,"MorphologyImage",true));
   if ((kernel == nullptr) || (kernel->values == nullptr))
     return fail(MH_BAD_ARGUMENT,"MorphologyImage: null kernel");
+  if (compose == MH_MORPHOLOGY_COMPOSE_DEFAULT)
   {
     // host memory: row bands through a pipeline of uploads, kernels and downloads (batch.cpp)
     MhOperator op;
@@ -647,7 +671,7 @@ MH_API MhStatus MagickHipMorphologyImage(const MhImage *image,MhImage *morpholog
   MH_TRY(pair.open(image,morphology_image));
   Roles roles=channel_roles(image,morphology_image);
   MH_TRY(morphology_apply(pair.src.view,pair.dst.view,image,roles,method,iterations,kernel,
-    bias,nullptr));
+    bias,nullptr,compose));
   return pair.commit();
 }
 

@@ -430,6 +430,26 @@ MH_API MhStatus MagickHipTransformImageColorspace(MhImage *image,MhColorspace co
   const MhColorspace from=(MhColorspace) image->colorspace;
   if (from == colorspace)
     return MH_OK;
+  if ((colorspace == MH_COLORSPACE_GRAY) || (colorspace == MH_COLORSPACE_LINEARGRAY))
+    {
+      // sRGB -> GRAY / LinearGRAY (colorspace.c:843-957): gray = 0.212656 R + 0.715158 G +
+      // 0.072186 B of the samples (GRAY) or of their gamma-decoded values (LinearGRAY), written
+      // into the gray (= first) channel — the expression, operation by operation, of
+      // GetPixelIntensity's Rec709Luma / Rec709Luminance on an sRGB image (pixel.c:2219-2235),
+      // i.e. GrayscaleImage's kernel.  The channel LAYOUT stays: re-laying the pixels out as one
+      // gray channel is SetImageColorspace's part (the caller's, as after GrayscaleImage,
+      // enhance.c:2648-2652).
+      const uint32_t colours=image->number_channels-(image->alpha_offset >= 0 ? 1u : 0u);
+      if ((from != MH_COLORSPACE_SRGB) || (colours != 3))
+        return fail(MH_UNSUPPORTED,"colourspace %d -> gray: only from sRGB with three colour channels",(int) from);
+      InPlace io;
+      MH_TRY(io.open(image));
+      MH_TRY(launch_grayscale(io.img.view,colorspace == MH_COLORSPACE_GRAY ? (int) MH_INTENSITY_REC709LUMA :
+        (int) MH_INTENSITY_REC709LUMINANCE,image));
+      MH_TRY(io.img.commit());
+      image->colorspace=(uint32_t) colorspace;
+      return MH_OK;
+    }
   if (!colorspace_is_accelerated(from) || !colorspace_is_accelerated(colorspace))
     return fail(MH_UNSUPPORTED,"colourspace %d -> %d is not accelerated",(int) from,(int) colorspace);
   const uint32_t colour=image->number_channels-(image->alpha_offset >= 0 ? 1u : 0u);

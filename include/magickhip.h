@@ -376,12 +376,28 @@ MH_API MhStatus MagickHipMotionBlurImage(const MhImage *image,MhImage *blur_imag
 MH_API MhStatus MagickHipMotionBlurImageWithKernel(const MhImage *image,MhImage *blur_image,
   const double *kernel,size_t width,const ptrdiff_t *offsets_xy);
 
-/* MorphologyImage / MorphologyApply, morphology.c:4129 / :3634.  `compose`
-   is unused (Undefined => per-method default) in this version; `bias` is the
+/* MorphologyImage / MorphologyApply, morphology.c:4129 / :3634, with the per-method default
+   handling of multi-kernel results (re-iterate; HitAndMiss: Lighten union); `bias` is the
    convolve:bias artifact (0 by default). */
 MH_API MhStatus MagickHipMorphologyImage(const MhImage *image,MhImage *morphology_image,
   MhMorphologyMethod method,ptrdiff_t iterations,const MhKernelInfo *kernel,
   double bias);
+
+/* The same with the user's `morphology:compose` (morphology.c:4206-4215, :3779-3782): how the
+   results of the kernels of a list are merged.  DEFAULT = UndefinedCompositeOp, NONE =
+   NoCompositeOp (re-iterate the previous result), LIGHTEN / DIFFERENCE = CompositeImage with that
+   operator.  Other operators: MH_UNSUPPORTED (the CPU path runs). */
+typedef enum
+{
+  MH_MORPHOLOGY_COMPOSE_DEFAULT = 0,
+  MH_MORPHOLOGY_COMPOSE_NONE = 1,
+  MH_MORPHOLOGY_COMPOSE_LIGHTEN = 2,
+  MH_MORPHOLOGY_COMPOSE_DIFFERENCE = 3,
+  MH_MORPHOLOGY_COMPOSE_OTHER = 4
+} MhMorphologyCompose;
+MH_API MhStatus MagickHipMorphologyImageCompose(const MhImage *image,MhImage *morphology_image,
+  MhMorphologyMethod method,ptrdiff_t iterations,const MhKernelInfo *kernel,
+  double bias,MhMorphologyCompose compose);
 
 /* One MorphologyPrimitive pass (morphology.c:2566) with a single kernel;
    *changed receives the reference's return value. */

@@ -60,6 +60,68 @@ MagickExport size_t GetMagickHipAcceleratedCalls(void)
   return(__atomic_load_n(&hip_accelerated_calls,__ATOMIC_RELAXED));
 }
 
+/*
+  `-debug accelerate` (AccelerateEvent, MagickCore/log.h:37-57): which path an operator took.
+  Accepted calls name the operator and the image; declined calls say why — the gate that failed
+  (the conditions of accelerate.c:110-170), or that the library / the device / the operator
+  itself returned "not handled" — and MagickCore then runs its CPU path.
+*/
+static const char *DescribeGate(const Image *image)
+{
+  if (image == (const Image *) NULL)
+    return("no image");
+  if (image->storage_class != DirectClass)
+    return("PseudoClass image");
+  if ((GetImageArtifact(image,"convolve:bias") != (const char *) NULL) ||
+      (GetImageArtifact(image,"convolve:scale") != (const char *) NULL) ||
+      (GetImageArtifact(image,"morphology:compose") != (const char *) NULL) ||
+      (GetImageArtifact(image,"morphology:showKernel") != (const char *) NULL))
+    return("a convolve: / morphology: artifact is set (Blur, UnsharpMask and Convolve hooks decline; "
+      "MorphologyApply honours bias, scale and the compose operators None, Lighten, Difference)");
+  switch (GetImageVirtualPixelMethod(image))
+  {
+    case UndefinedVirtualPixelMethod:
+    case EdgeVirtualPixelMethod:
+      break;
+    default:
+      return("virtual pixel method other than Undefined / Edge");
+  }
+  if ((image->channels & (ReadMaskChannel | WriteMaskChannel | CompositeMaskChannel)) != 0)
+    return("read, write or composite mask");
+  if ((image->number_channels < 1) || (image->number_channels > 4))
+    return("more than four channels");
+  switch (image->colorspace)
+  {
+    case RGBColorspace:
+    case sRGBColorspace:
+    case GRAYColorspace:
+    case LinearGRAYColorspace:
+      break;
+    default:
+      return("colourspace outside sRGB / RGB / GRAY / LinearGRAY (or channel layout, artifacts, device, operator arguments)");
+  }
+  return("channel layout, artifacts, device or operator arguments outside the backend's reach");
+}
+
+static void LogAccelerated(const char *function,const Image *image)
+{
+  if (IsEventLogging() != MagickFalse)
+    (void) LogMagickEvent(AccelerateEvent,GetMagickModule(),
+      "%s: accelerated on the HIP backend (%.20gx%.20g, %.20g channels, %s)",function,
+      (double) image->columns,(double) image->rows,(double) image->number_channels,
+      image->filename);
+}
+
+static void LogDeclined(const char *function,const int line,const Image *image)
+{
+  if (IsEventLogging() != MagickFalse)
+    (void) LogMagickEvent(AccelerateEvent,GetMagickModule(),
+      "%s: not accelerated, the CPU path runs (shim line %d: %s)",function,line,DescribeGate(image));
+}
+
+#define HipAccepted(image) (CountAcceleratedCall(),LogAccelerated(__func__,(image)))
+#define HipDeclined(image,value) (LogDeclined(__func__,__LINE__,(image)),(value))
+
 /* ------------------------------------------------------------------ gates */
 /*
   What the backend can take, the same conditions the reference's accelerate
@@ -251,10 +313,10 @@ static Image *AcquireResultImage(HipLibrary *library,const Image *image,const si
   if (result == (Image *) NULL)
     return((Image *) NULL);
   if (SetImageStorageClass(result,DirectClass,exception) == MagickFalse)
-    return(DestroyImage(result));
+    return(HipDeclined(image,DestroyImage(result)));
   *device_pixels=AcquireDevicePixels(library,result,0,exception);
   if (*device_pixels == NULL)
-    return(DestroyImage(result));
+    return(HipDeclined(image,DestroyImage(result)));
   return(result);
 }
 
@@ -297,22 +359,22 @@ MagickPrivate Image *AccelerateBlurImage(const Image *image,const double radius,
   assert(image != NULL);
   assert(exception != (ExceptionInfo *) NULL);
   if ((IsImageAcceleratable(image) == MagickFalse) || (HasMorphologyArtifacts(image) != MagickFalse))
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   p=AcquireDevicePixels(library,image,1,exception);
   if (p == NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   blur_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
   if (blur_image == (Image *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
       (DescribeImage(library,blur_image,q,&destination) == MagickFalse) ||
       (library->BlurImage(&source,&destination,radius,sigma) != MH_OK))
-    return(DestroyImage(blur_image));
+    return(HipDeclined(image,DestroyImage(blur_image)));
   blur_image->type=image->type;      /* as MorphologyPrimitive does, morphology.c:2800 */
-  CountAcceleratedCall();
+  HipAccepted(image);
   return(blur_image);
 }
 
@@ -335,22 +397,22 @@ MagickPrivate Image *AccelerateUnsharpMaskImage(const Image *image,
     *q;
 
   if ((IsImageAcceleratable(image) == MagickFalse) || (HasMorphologyArtifacts(image) != MagickFalse))
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   p=AcquireDevicePixels(library,image,1,exception);
   if (p == NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   unsharp_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
   if (unsharp_image == (Image *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
       (DescribeImage(library,unsharp_image,q,&destination) == MagickFalse) ||
       (library->UnsharpMaskImage(&source,&destination,radius,sigma,gain,threshold) != MH_OK))
-    return(DestroyImage(unsharp_image));
+    return(HipDeclined(image,DestroyImage(unsharp_image)));
   unsharp_image->type=image->type;   /* effect.c:4385 */
-  CountAcceleratedCall();
+  HipAccepted(image);
   return(unsharp_image);
 }
 
@@ -384,16 +446,16 @@ MagickPrivate Image *AccelerateResizeImage(const Image *image,
     *q;
 
   if (IsImageAcceleratable(image) == MagickFalse)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   p=AcquireDevicePixels(library,image,1,exception);
   if (p == NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   resize_image=AcquireResultImage(library,image,resizedColumns,resizedRows,&q,exception);
   if (resize_image == (Image *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   /* the weights are the reference's own: expert filter:* artifacts included */
   filter=library->AcquireResizeFilterFromCallback(ReferenceFilterWeight,
     (void *) resizeFilter,GetResizeFilterSupport(resizeFilter));
@@ -405,9 +467,9 @@ MagickPrivate Image *AccelerateResizeImage(const Image *image,
   if (filter != (MhResizeFilter *) NULL)
     (void) library->DestroyResizeFilter(filter);
   if (status != MH_OK)
-    return(DestroyImage(resize_image));
+    return(HipDeclined(image,DestroyImage(resize_image)));
   resize_image->type=image->type;    /* resize.c:3872 */
-  CountAcceleratedCall();
+  HipAccepted(image);
   return(resize_image);
 }
 
@@ -424,17 +486,17 @@ MagickPrivate MagickBooleanType AccelerateEqualizeImage(Image *image,
     *q;
 
   if (IsHistogramOperatorAcceleratable(image) == MagickFalse)
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   q=AcquireDevicePixels(library,image,1,exception);
   if ((q == NULL) ||
       (DescribeImage(library,image,q,&description) == MagickFalse) ||
       (library->EqualizeImage(&description) != MH_OK))
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   MarkDeviceCopyNewer(image);
-  CountAcceleratedCall();
+  HipAccepted(image);
   return(MagickTrue);
 }
 
@@ -458,7 +520,7 @@ static MagickBooleanType IsHistogramOperatorAcceleratable(const Image *image)
     case XYZColorspace:
       break;
     default:
-      return(MagickFalse);
+      return(HipDeclined(image,MagickFalse));
   }
   return(IsLayoutAcceleratable(image));
 }
@@ -479,20 +541,20 @@ MagickPrivate MagickBooleanType AccelerateContrastStretchImage(Image *image,
     *q;
 
   if (IsHistogramOperatorAcceleratable(image) == MagickFalse)
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   q=AcquireDevicePixels(library,image,1,exception);
   became_gray=0;
   if ((q == NULL) ||
       (DescribeImage(library,image,q,&description) == MagickFalse) ||
       (library->ContrastStretchImage(&description,black_point,white_point,&became_gray) != MH_OK))
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   /* (an all-gray colour image comes back as MH_UNSUPPORTED above: the CPU path then does the
      IdentifyImageType re-layout itself, enhance.c:1586-1588) */
   MarkDeviceCopyNewer(image);
-  CountAcceleratedCall();
+  HipAccepted(image);
   return(MagickTrue);
 }
 
@@ -524,6 +586,9 @@ MagickPrivate Image *AccelerateMorphologyApply(const Image *image,
   MhKernelInfo
     kernels[MaxAcceleratedKernels];
 
+  MhMorphologyCompose
+    override;
+
   size_t
     n;
 
@@ -531,14 +596,22 @@ MagickPrivate Image *AccelerateMorphologyApply(const Image *image,
     *p,
     *q;
 
-  if ((compose != UndefinedCompositeOp) || (iterations == 0) ||
-      (IsImageAcceleratable(image) == MagickFalse))
-    return((Image *) NULL);
+  /* the user's morphology:compose (morphology.c:4206): the operators the backend composes with */
+  switch (compose)
+  {
+    case UndefinedCompositeOp: override=MH_MORPHOLOGY_COMPOSE_DEFAULT; break;
+    case NoCompositeOp: override=MH_MORPHOLOGY_COMPOSE_NONE; break;
+    case LightenCompositeOp: override=MH_MORPHOLOGY_COMPOSE_LIGHTEN; break;
+    case DifferenceCompositeOp: override=MH_MORPHOLOGY_COMPOSE_DIFFERENCE; break;
+    default: return(HipDeclined(image,(Image *) NULL));
+  }
+  if ((iterations == 0) || (IsImageAcceleratable(image) == MagickFalse))
+    return(HipDeclined(image,(Image *) NULL));
   n=0;
   for (k=kernel; k != (const KernelInfo *) NULL; k=k->next)
   {
     if (n == MaxAcceleratedKernels)
-      return((Image *) NULL);
+      return(HipDeclined(image,(Image *) NULL));
     (void) memset(&kernels[n],0,sizeof(kernels[n]));
     kernels[n].type=MH_KERNEL_USERDEFINED;
     kernels[n].width=k->width;
@@ -557,21 +630,21 @@ MagickPrivate Image *AccelerateMorphologyApply(const Image *image,
   }
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   p=AcquireDevicePixels(library,image,1,exception);
   if (p == NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   morphology_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
   if (morphology_image == (Image *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   /* MorphologyMethod and MhMorphologyMethod share their values (morphology.h:72-98) */
   if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
       (DescribeImage(library,morphology_image,q,&destination) == MagickFalse) ||
-      (library->MorphologyImage(&source,&destination,(MhMorphologyMethod) method,iterations,
-         kernels,bias) != MH_OK))
-    return(DestroyImage(morphology_image));
+      (library->MorphologyImageCompose(&source,&destination,(MhMorphologyMethod) method,iterations,
+         kernels,bias,override) != MH_OK))
+    return(HipDeclined(image,DestroyImage(morphology_image)));
   morphology_image->type=image->type;                /* morphology.c:2800, :3222 */
-  CountAcceleratedCall();
+  HipAccepted(image);
   return(morphology_image);
 }
 
@@ -669,24 +742,48 @@ MagickPrivate MagickBooleanType AccelerateTransformImageColorspace(Image *image,
   void
     *q;
 
+  if (((colorspace == GRAYColorspace) || (colorspace == LinearGRAYColorspace)) &&
+      (image->colorspace == sRGBColorspace) && (image->number_channels >= 3) &&
+      (IsLayoutAcceleratable(image) != MagickFalse))
+    {
+      /*
+        sRGB -> GRAY / LinearGRAY (colorspace.c:843-957): the gray value into the first channel
+        on the device; SetImageColorspace then re-lays the pixel cache out as one gray channel
+        (it finds the device copy newer and fetches it first: CopyOpenCLBuffer, cache.c:1711) —
+        the same hand-over as after AccelerateGrayscaleImage (enhance.c:2500-2510).
+      */
+      library=AcquireHipLibrary();
+      if (library == (HipLibrary *) NULL)
+        return(HipDeclined(image,MagickFalse));
+      q=AcquireDevicePixels(library,image,1,exception);
+      if ((q == NULL) || (DescribeImage(library,image,q,&description) == MagickFalse) ||
+          (library->TransformImageColorspace(&description,(MhColorspace) colorspace) != MH_OK))
+        return(HipDeclined(image,MagickFalse));
+      MarkDeviceCopyNewer(image);
+      HipAccepted(image);
+      if (SetImageColorspace(image,colorspace,exception) == MagickFalse)
+        return(MagickFalse);
+      image->type=GrayscaleType;
+      return(MagickTrue);
+    }
   if ((IsColorspaceAccelerated(image->colorspace) == MagickFalse) ||
       (IsColorspaceAccelerated(colorspace) == MagickFalse) ||
       (image->colorspace == colorspace) || (image->number_channels < 3) ||
       (IsLayoutAcceleratable(image) == MagickFalse) ||
       (GetImageArtifact(image,"color:illuminant") != (const char *) NULL) ||
       (GetImageProperty(image,"white-luminance",exception) != (const char *) NULL))
-    return(MagickFalse);          /* D65 and the default Jzazbz white luminance only (colorspace.c:993-995) */
+    return(HipDeclined(image,MagickFalse));          /* D65 and the default Jzazbz white luminance only (colorspace.c:993-995) */
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   q=AcquireDevicePixels(library,image,1,exception);
   /* ColorspaceType and MhColorspace share their values (colorspace.h:27-66) */
   if ((q == NULL) ||
       (DescribeImage(library,image,q,&description) == MagickFalse) ||
       (library->TransformImageColorspace(&description,(MhColorspace) colorspace) != MH_OK))
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   MarkDeviceCopyNewer(image);
-  CountAcceleratedCall();
+  HipAccepted(image);
   return(SetResidentImageColorspace(library,image,colorspace,exception));
 }
 
@@ -709,22 +806,22 @@ MagickPrivate Image *AccelerateDespeckleImage(const Image *image,ExceptionInfo *
     *q;
 
   if (IsImageAcceleratable(image) == MagickFalse)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   p=AcquireDevicePixels(library,image,1,exception);
   if (p == NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   despeckle_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
   if (despeckle_image == (Image *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
       (DescribeImage(library,despeckle_image,q,&destination) == MagickFalse) ||
       (library->DespeckleImage(&source,&destination) != MH_OK))
-    return(DestroyImage(despeckle_image));
+    return(HipDeclined(image,DestroyImage(despeckle_image)));
   despeckle_image->type=image->type;       /* effect.c:1486 */
-  CountAcceleratedCall();
+  HipAccepted(image);
   return(despeckle_image);
 }
 
@@ -747,21 +844,21 @@ MagickPrivate Image *AccelerateLocalContrastImage(const Image *image,const doubl
     *q;
 
   if (IsImageAcceleratable(image) == MagickFalse)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   p=AcquireDevicePixels(library,image,1,exception);
   if (p == NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   contrast_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
   if (contrast_image == (Image *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
       (DescribeImage(library,contrast_image,q,&destination) == MagickFalse) ||
       (library->LocalContrastImage(&source,&destination,radius,strength) != MH_OK))
-    return(DestroyImage(contrast_image));
-  CountAcceleratedCall();
+    return(HipDeclined(image,DestroyImage(contrast_image)));
+  HipAccepted(image);
   return(contrast_image);
 }
 
@@ -793,13 +890,13 @@ MagickPrivate Image *AccelerateMotionBlurImage(const Image *image,const double *
     *q;
 
   if ((IsImageAcceleratable(image) == MagickFalse) || (width == 0))
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   offsets=(ptrdiff_t *) AcquireQuantumMemory(width,2*sizeof(*offsets));
   if (offsets == (ptrdiff_t *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   for (i=0; i < width; i++)
   {
     offsets[2*i]=(ptrdiff_t) offset[i].x;
@@ -819,9 +916,9 @@ MagickPrivate Image *AccelerateMotionBlurImage(const Image *image,const double *
     {
       if (blur_image != (Image *) NULL)
         blur_image=DestroyImage(blur_image);
-      return((Image *) NULL);
+      return(HipDeclined(image,(Image *) NULL));
     }
-  CountAcceleratedCall();
+  HipAccepted(image);
   return(blur_image);
 }
 
@@ -844,21 +941,21 @@ MagickPrivate Image *AccelerateRotationalBlurImage(const Image *image,const doub
     *q;
 
   if (IsImageAcceleratable(image) == MagickFalse)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   p=AcquireDevicePixels(library,image,1,exception);
   if (p == NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   blur_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
   if (blur_image == (Image *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
       (DescribeImage(library,blur_image,q,&destination) == MagickFalse) ||
       (library->RotationalBlurImage(&source,&destination,angle) != MH_OK))
-    return(DestroyImage(blur_image));
-  CountAcceleratedCall();
+    return(HipDeclined(image,DestroyImage(blur_image)));
+  HipAccepted(image);
   return(blur_image);
 }
 
@@ -891,21 +988,21 @@ MagickPrivate Image *AccelerateWaveletDenoiseImageSoft(const Image *image,
     *q;
 
   if (IsImageAcceleratable(image) == MagickFalse)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   library=AcquireHipLibrary();
   if (library == (HipLibrary *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   p=AcquireDevicePixels(library,image,1,exception);
   if (p == NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   noise_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
   if (noise_image == (Image *) NULL)
-    return((Image *) NULL);
+    return(HipDeclined(image,(Image *) NULL));
   if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
       (DescribeImage(library,noise_image,q,&destination) == MagickFalse) ||
       (library->WaveletDenoiseImage(&source,&destination,threshold,softness) != MH_OK))
-    return(DestroyImage(noise_image));
-  CountAcceleratedCall();
+    return(HipDeclined(image,DestroyImage(noise_image)));
+  HipAccepted(image);
   return(noise_image);
 }
 
@@ -917,13 +1014,13 @@ static MagickBooleanType AcquireInPlace(const Image *image,HipLibrary **library,
     *q;
 
   if (IsImageAcceleratable(image) == MagickFalse)
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   *library=AcquireHipLibrary();
   if (*library == (HipLibrary *) NULL)
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   q=AcquireDevicePixels(*library,image,1,exception);
   if (q == NULL)
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   return(DescribeImage(*library,image,q,description));
 }
 
@@ -939,13 +1036,13 @@ MagickPrivate MagickBooleanType AccelerateFunctionImage(Image *image,
 
   if ((image->storage_class != DirectClass) ||
       (AcquireInPlace(image,&library,&description,exception) == MagickFalse))
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   /* MagickFunction and MhFunction share their values (statistic.h:129-136) */
   if (library->FunctionImage(&description,(MhFunction) function,number_parameters,
         parameters) != MH_OK)
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   MarkDeviceCopyNewer(image);
-  CountAcceleratedCall();
+  HipAccepted(image);
   return(MagickTrue);
 }
 
@@ -961,12 +1058,12 @@ MagickPrivate MagickBooleanType AccelerateGrayscaleImage(Image *image,
   /* only layouts whose first three channels are R,G,B (GrayscaleImage reads all three) */
   if ((image->number_channels < 3) ||
       (AcquireInPlace(image,&library,&description,exception) == MagickFalse))
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   /* PixelIntensityMethod and MhIntensityMethod share their values (pixel.h) */
   if (library->GrayscaleImage(&description,(MhIntensityMethod) method) != MH_OK)
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   MarkDeviceCopyNewer(image);
-  CountAcceleratedCall();
+  HipAccepted(image);
   return(MagickTrue);       /* the caller sets intensity, type and the GRAY colourspace */
 }
 
@@ -982,11 +1079,11 @@ MagickPrivate MagickBooleanType AccelerateContrastImage(Image *image,
 
   if ((image->number_channels < 3) ||
       (AcquireInPlace(image,&library,&description,exception) == MagickFalse))
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   if (library->ContrastImage(&description,sharpen != MagickFalse ? 1 : 0) != MH_OK)
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   MarkDeviceCopyNewer(image);
-  CountAcceleratedCall();
+  HipAccepted(image);
   return(MagickTrue);
 }
 
@@ -1025,13 +1122,13 @@ MagickPrivate MagickBooleanType AccelerateModulateImage(Image *image,
   if ((image->number_channels < 3) ||
       (GetImageArtifact(image,"color:illuminant") != (const char *) NULL) ||
       (AcquireInPlace(image,&library,&description,exception) == MagickFalse))
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   /* ColorspaceType and MhColorspace share their values (colorspace.h:27-66) */
   if (library->ModulateImage(&description,percent_brightness,percent_saturation,percent_hue,
         (int) model) != MH_OK)
-    return(MagickFalse);
+    return(HipDeclined(image,MagickFalse));
   MarkDeviceCopyNewer(image);
-  CountAcceleratedCall();
+  HipAccepted(image);
   return(MagickTrue);
 }
 

@@ -40,6 +40,8 @@ typedef struct _HipLibrary
   MhStatus (*ModulateImage)(MhImage *,double,double,double,int);
   MhStatus (*MorphologyImage)(const MhImage *,MhImage *,MhMorphologyMethod,ptrdiff_t,
     const MhKernelInfo *,double);
+  MhStatus (*MorphologyImageCompose)(const MhImage *,MhImage *,MhMorphologyMethod,ptrdiff_t,
+    const MhKernelInfo *,double,MhMorphologyCompose);
   MhStatus (*TransformImageColorspace)(MhImage *,MhColorspace);
 } HipLibrary;
 

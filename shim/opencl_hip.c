@@ -126,6 +126,7 @@ static void LoadHipLibrary(void)
   MH_RESOLVE(ContrastImage,"MagickHipContrastImage");
   MH_RESOLVE(ModulateImage,"MagickHipModulateImage");
   MH_RESOLVE(MorphologyImage,"MagickHipMorphologyImage");
+  MH_RESOLVE(MorphologyImageCompose,"MagickHipMorphologyImageCompose");
   MH_RESOLVE(TransformImageColorspace,"MagickHipTransformImageColorspace");
 #undef MH_RESOLVE
   if ((missing != 0) || (hip_library.Initialize() != MH_OK))

@@ -636,6 +636,29 @@ def test_morphology_kernel_lists(im, refmod, method, kernel, iterations):
     assert_parity(got, want, True, "%s %s x%d" % (method, kernel, iterations))
 
 
+@pytest.mark.parametrize("method,kernel,compose", [
+    ("Convolve", "Sobel:>", "Lighten"),            # compass list: the strongest response per pixel
+    ("Convolve", "3x3: 0,1,0 1,2,1 0,1,0;3x3: 1,0,1 0,2,0 1,0,1", "Difference"),
+    ("HitAndMiss", "LineEnds", "None"),            # the union replaced by re-iteration
+    ("Dilate", "Plus:1;Square:1", "Lighten"),
+    ("Erode", "Diamond:2;Ring:1,2", "None"),
+])
+def test_morphology_compose_override(im, refmod, method, kernel, compose):
+    """The user's `-define morphology:compose=` (morphology.c:4206-4215, :3779-3782) for the
+    operators the backend composes with; any other operator is declined."""
+    px = make_pixels(56, 72, 4, Q16, seed=len(kernel))
+    dev, ref = run_pair(im, refmod, px)
+    scale = (1.0, 1) if method == "Convolve" else None
+    got = im.morphology_image(dev, method, 1, kernel, scale=scale, compose=compose).numpy()
+    ref.set_artifact("morphology:compose", compose)
+    if scale is not None:
+        ref.set_artifact("convolve:scale", "!")
+    want = ref.morphology(method, 1, kernel).numpy()
+    assert_parity(got, want, True, "%s %s compose %s" % (method, kernel, compose))
+    with pytest.raises(im.MagickHipError):
+        im.morphology_image(dev, method, 1, kernel, scale=scale, compose="Plus")
+
+
 def test_hit_and_miss_union_with_alpha(im, refmod):
     px = make_pixels(40, 52, 4, Q16)
     dev, ref = run_pair(im, refmod, px)
@@ -1279,6 +1302,25 @@ def test_grayscale(im, refmod, dtype, method, colorspace, channels):
                   "grayscale %s %s" % (method, colorspace))
     if channels == 4:
         assert np.array_equal(got[:, :, 3], want[:, :, -1])
+
+
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("target", ["Gray", "LinearGray"])
+@pytest.mark.parametrize("channels", [3, 4])
+def test_colorspace_srgb_to_gray(im, refmod, dtype, target, channels):
+    """sRGB -> GRAY / LinearGRAY (colorspace.c:843-957) through the library: the gray value in the
+    first channel (the layout change to one channel is SetImageColorspace's, the caller's part)."""
+    px = make_pixels(41, 57, channels, dtype, seed=channels)
+    dev, ref = run_pair(im, refmod, px)
+    im.transform_image_colorspace(dev, target)
+    want = ref.colorspace(target).numpy()         # gray[+alpha]
+    got = dev.numpy()
+    assert_parity(np.ascontiguousarray(got[:, :, 0]), np.ascontiguousarray(want[:, :, 0]), True,
+                  "sRGB -> %s" % target, max_ulp=1)
+    if channels == 4:
+        assert np.array_equal(got[:, :, 3], want[:, :, -1])
+    with pytest.raises(im.MagickHipError):        # only from sRGB
+        im.transform_image_colorspace(im.Image(to_device(px), colorspace="Lab"), target)
 
 
 @pytest.mark.parametrize("dtype", [Q16, HDRI])

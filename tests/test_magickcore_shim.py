@@ -240,3 +240,54 @@ def test_contrast_and_modulate_through_magickcore(shim, dtype):
     assert_parity(g.modulate(90.0, 120.0, 70.0, "HWB").numpy(), c.modulate(90.0, 120.0, 70.0, "HWB").numpy(), True,
                   "ModulateImage HWB via MagickCore", max_ulp=1)
     assert accelerated_calls(shim, hdri) == before + 4
+
+
+def test_accelerate_events_are_logged(shim, tmp_path):
+    """`-debug accelerate` (LogMagickEvent(AccelerateEvent, ...), MagickCore/log.h:37-57): the shim
+    says which path an operator took — accepted on the HIP backend, or declined and why."""
+    import sys
+    lib = shim._load(False, True)
+    if not hasattr(lib, "SetLogEventMask"):
+        pytest.skip("the shim's MagickCore does not export SetLogEventMask")
+    lib.SetLogEventMask.restype = ctypes.c_int
+    lib.SetLogEventMask.argtypes = [ctypes.c_char_p]
+    px = make_pixels(48, 60, 4, np.uint16)
+    capture = tmp_path / "accelerate.log"
+    sys.stderr.flush()
+    saved = os.dup(2)
+    fd = os.open(str(capture), os.O_WRONLY | os.O_CREAT | os.O_TRUNC)
+    try:
+        os.dup2(fd, 2)
+        lib.SetLogEventMask(b"Accelerate")
+        image = shim.RefImage(px, shim=True)
+        image.blur(0.0, 2.0)                                           # accepted
+        image.set_artifact("convolve:scale", "2").blur(0.0, 2.0)       # declined: an artifact is set
+    finally:
+        lib.SetLogEventMask(b"None")
+        os.dup2(saved, 2)
+        os.close(fd)
+        os.close(saved)
+    text = capture.read_text(errors="replace")
+    assert "AccelerateBlurImage: accelerated on the HIP backend" in text, text[-2000:]
+    assert "AccelerateBlurImage: not accelerated, the CPU path runs" in text, text[-2000:]
+    assert "artifact is set" in text
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+@pytest.mark.parametrize("target", ["Gray", "LinearGray"])
+def test_srgb_to_gray_through_magickcore(shim, dtype, target):
+    """TransformImageColorspace(GRAY / LinearGRAY) (colorspace.c:843-957): the gray values are
+    formed on the device, MagickCore's own SetImageColorspace re-lays the cache out as one gray
+    (+ alpha) channel and finds the device copy first."""
+    hdri = dtype == np.float32
+    px = make_pixels(50, 66, 4, dtype, seed=12)
+    before = accelerated_calls(shim, hdri)
+    g, c = shim.RefImage(px, shim=True), shim.RefImage(px)
+    g.colorspace(target)
+    c.colorspace(target)
+    assert accelerated_calls(shim, hdri) == before + 1, "the GRAY transform did not take the accelerated path"
+    assert g.info()["colorspace"] == c.info()["colorspace"]
+    assert g.numpy().shape == c.numpy().shape
+    assert_parity(g.numpy(), c.numpy(), True, "sRGB -> %s via MagickCore" % target, max_ulp=1)
+    # and the gray image goes on through the accelerated operators (the gate admits GRAY)
+    assert_parity(g.blur(0.0, 2.0).numpy(), c.blur(0.0, 2.0).numpy(), True, "BlurImage of the gray image")
