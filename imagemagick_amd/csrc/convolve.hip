@@ -42,9 +42,9 @@ struct ReferenceSample
   int W,H,K,shift,x,y;
   bool vertical;
   double bias;
-  __device__ __forceinline__ unsigned operator()(int c) const
+  __device__ __forceinline__ Q operator()(int c) const
   {
-    return (unsigned) conv1d_reference_sample<Q,C,BLEND>(src,W,H,vertical,x,y,c,taps,K,shift,bias);
+    return conv1d_reference_sample<Q,C,BLEND>(src,W,H,vertical,x,y,c,taps,K,shift,bias);
   }
 };
 
@@ -61,12 +61,17 @@ struct Accum
   static constexpr int NP=(C+1)/2;
   V2 sv[R][NP];
   T g[R];
+  // float Quantum under the tie check: the largest |sample| each channel's sums have seen
+  // (the error bound of a sum is relative to it) and (2K+6)*2^-53, see finish()
+  static constexpr bool kTracksMagnitude=A::tie_check && (sizeof(Q) == 4);
+  V2 magnitude[kTracksMagnitude ? NP : 1];
+  T error_unit;
 #define MH_S(r,c) sv[r][(c) >> 1][(c) & 1]
 
   struct In { V2 pv[NP]; T a; };
 #define MH_P(in,c) (in).pv[(c) >> 1][(c) & 1]
 
-  __device__ __forceinline__ void init(T bias)
+  __device__ __forceinline__ void init(T bias,int ntaps=0)
   {
 #pragma unroll
     for (int r=0; r < R; r++)
@@ -75,6 +80,25 @@ struct Accum
         for (int c=0; c < C; c++)
           MH_S(r,c)=A::premultiply ? (T) 0 : bias;
         g[r]=(T) 0;
+      }
+    error_unit=(T) 0;
+    if constexpr (kTracksMagnitude)
+      {
+#pragma unroll
+        for (int q2=0; q2 < NP; q2++)
+          magnitude[q2]=V2{(T) 0,(T) 0};
+        error_unit=(T) (2*ntaps+6)*(T) 1.1102230246251565e-16;
+      }
+  }
+
+  // one v_max_f64 per channel and streamed sample (|x| is a source modifier)
+  __device__ __forceinline__ void observe(const In &in)
+  {
+    if constexpr (kTracksMagnitude)
+      {
+#pragma unroll
+        for (int c=0; c < C; c++)
+          magnitude[c >> 1][c & 1]=__builtin_fmax(magnitude[c >> 1][c & 1],__builtin_fabs(MH_P(in,c)));
       }
   }
 
@@ -163,7 +187,60 @@ struct Accum
       {
         // fused fp64 sums of alpha-premultiplied samples (bias 0, no change count: the launcher
         // sends everything else to Exact64).  S_c = sum k*alpha*p, S_a = sum k*alpha.
-        static_assert((sizeof(Q) == 2) && (sizeof(T) == 8),"the tie check is for Q16 sums in fp64");
+        static_assert(((sizeof(Q) == 2) || (sizeof(Q) == 4)) && (sizeof(T) == 8),
+          "the tie check is for Q16 or float samples summed in fp64");
+        if constexpr (sizeof(Q) == 4)
+          {
+            // float Quantum (HDRI): the result is the fp64 value rounded to float, so a "tie" is a
+            // value closer to the midpoint of two neighbouring floats than the two summation
+            // orders can differ.  Per channel that is at most (2K+6)*2^-53 * max|sample| * sum|k|
+            // (K roundings of each order's running sum plus the reference's three per term; the
+            // launcher admits normalised positive taps only, sum|k| <= 1); the alpha-weighted
+            // colour channels add the quotient's share.  NaN fails every comparison below and
+            // lands in the reference path, as do infinities, denormals and powers of two (whose
+            // lower neighbour is half as far away).
+            T inverse=(T) 1,alpha_error=(T) 0;
+            bool doubtful=false;
+            if constexpr (BLEND)
+              {
+                const T sa=MH_S(r,C-1);
+                doubtful=(sa != (T) 0) && !(__builtin_fabs((T) kQS*sa) >= (T) kEps*(T) 1.000001);
+                inverse=sa == (T) 0 ? (T) 0 : perceptible_reciprocal_fast(sa);
+                alpha_error=error_unit*magnitude[(C-1) >> 1][(C-1) & 1];
+              }
+#pragma unroll
+            for (int c=0; c < C; c++)
+              {
+                if ((copy_mask >> c) & 1u)
+                  {
+                    out[c]=center[c];
+                    continue;
+                  }
+                T value=MH_S(r,c);
+                T error=error_unit*magnitude[c >> 1][c & 1];
+                if (BLEND && (c != C-1))
+                  {
+                    value=value*inverse;
+                    error=__builtin_fma(__builtin_fabs(value),alpha_error,error)*__builtin_fabs(inverse)+
+                      __builtin_fabs(value)*(T) 1.0e-15;
+                  }
+                const float nearest=(float) value;
+                const uint32_t bits=__float_as_uint(nearest);
+                const int exponent=(int) ((bits >> 23) & 0xffu);
+                const bool power_of_two=(bits & 0x7fffffu) == 0u;
+                const bool ordinary=(exponent != 0xff) && ((exponent != 0) || ((bits & 0x7fffffffu) == 0u));
+                // half an ulp of `nearest`: 2^(e-127-24), a quarter below a power of two
+                const int half_exponent=(exponent > 0 ? exponent : 1)-151-(power_of_two ? 1 : 0);
+                const T half_ulp=__longlong_as_double((long long) (half_exponent+1023) << 52);
+                const T distance=__builtin_fabs(value-(T) nearest);
+                const bool decided=ordinary && (half_ulp-distance > error);
+                Q level=nearest;
+                if (!decided || (doubtful && BLEND && (c != C-1)))
+                  level=reference(c);
+                out[c]=level;
+              }
+            return 0;
+          }
         T inverse=(T) 1;
         bool doubtful=false;
         if constexpr (BLEND)
@@ -945,6 +1022,7 @@ static __device__ __forceinline__ void tri_accumulate(Accum<Q,C,BLEND,A,R> &acc,
         for (int jj=0; jj < U; jj++)
           {
             typename Acc::In in=Acc::prepare(cur[jj]);
+            acc.observe(in);
 #pragma unroll
             for (int r=0; r < R; r++)
               if (r <= c0*U+jj)
@@ -966,6 +1044,7 @@ static __device__ __forceinline__ void tri_accumulate(Accum<Q,C,BLEND,A,R> &acc,
       for (int jj=0; jj < U; jj++)
         {
           typename Acc::In in=Acc::prepare(cur[jj]);
+            acc.observe(in);
 #pragma unroll
           for (int r=0; r < R; r++)
             acc.tap(r,tw[jj-r+R-1],in);
@@ -982,6 +1061,7 @@ static __device__ __forceinline__ void tri_accumulate(Accum<Q,C,BLEND,A,R> &acc,
       for (int i=0; i < R; i++)
         tw[i]=table[pos-(R-1)+i];
       typename Acc::In in=Acc::prepare(cur[0]);
+      acc.observe(in);
 #pragma unroll
       for (int r=0; r < R; r++)
         acc.tap(r,tw[R-1-r],in);
@@ -1003,6 +1083,7 @@ static __device__ __forceinline__ void tri_accumulate(Accum<Q,C,BLEND,A,R> &acc,
         for (int jj=0; jj < U; jj++)
           {
             typename Acc::In in=Acc::prepare(cur[jj]);
+            acc.observe(in);
 #pragma unroll
             for (int r=0; r < R; r++)
               if (r >= c0*U+jj)
@@ -1044,7 +1125,7 @@ void conv_column_tri(Conv1DArgs args)
     return;
 
   Acc acc;
-  acc.init((T) args.bias);
+  acc.init((T) args.bias,K);
   Q nxt[U][C];
   const bool interior=(ybase >= 0) && (ybase+R+K+U <= H);
   const char *base0=reinterpret_cast<const char *>(args.src)+(size_t) xc*(size_t) (C*sizeof(Q));
@@ -1177,7 +1258,7 @@ void conv_column_lds(Conv1DArgs args)
     return;
 
   Acc acc;
-  acc.init((T) args.bias);
+  acc.init((T) args.bias,K);
   const Q *mine=tile+((size_t) wave*R*64+(size_t) lane)*C;      // sample j lives at mine + j*64*C
   Q nxt[U][C];
   auto fetch_u=[&](int pos)
@@ -1282,7 +1363,7 @@ void conv_row_tri(Conv1DArgs args)
     return;
 
   Acc acc;
-  acc.init((T) args.bias);
+  acc.init((T) args.bias,K);
   const Q *mine=strip+(size_t) lane*(R+1)*C;     // slot of sample lane*R
   Q nxt[U][C];
   auto fetch_u=[&](int pos)
@@ -1434,11 +1515,10 @@ static MhStatus launch_tri(const View &src,const View &dst,bool vertical,
   return launch_tri_waves<Q,C,BLEND,A,R,U,4>(src,dst,vertical,p,roles,changed);
 }
 
-template<class A,int R,int U>
+template<class A,int R,int U,typename Q=uint16_t>
 static MhStatus dispatch_tri(const View &src,const View &dst,bool vertical,
   const Conv1DParams &p,const Roles &roles,unsigned long long *changed)
 {
-  typedef uint16_t Q;
   const bool blend=roles.blend && (roles.alpha == src.channels-1);
   switch (src.channels)
   {
@@ -1705,7 +1785,22 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
       return dispatch_blocked<Exact64,8,8>(src,dst,vertical,params,roles,changed);
     }
   // float Quantum always accumulates in double: an FP32 sum cannot stay
-  // within 1 ULP of a float result.
+  // within 1 ULP of a float result.  Long normalised positive kernels (BlurImage's) take the
+  // fused sums with the float-rounding tie check of Accum::finish(): the same bits as the
+  // reference's order at 4 fused multiply-adds per tap instead of 11 separately rounded operations.
+  if ((params.ntaps >= 16) && (params.bias == 0.0) && (changed == nullptr) &&
+      (getenv("MAGICKHIP_NO_TRI") == nullptr) && (getenv("MAGICKHIP_NO_TIE64") == nullptr))
+    {
+      bool positive=true;
+      double total=0.0;
+      for (int v=0; v < params.ntaps; v++)
+        {
+          positive=positive && (params.taps[v] >= 0.0);
+          total+=params.taps[v];
+        }
+      if (positive && (total <= 1.0+1.0e-9))
+        return dispatch_tri<Tie64,8,8,float>(src,dst,vertical,params,roles,changed);
+    }
   return dispatch_channels<float,Exact64,8>(src,dst,vertical,params,roles,changed);
 }
 

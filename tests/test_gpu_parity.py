@@ -54,6 +54,49 @@ def test_blur_exact_on_rounding_ties(im, refmod, pattern, sigma):
                   "blur on ties, %s sigma %g" % (pattern, sigma))
 
 
+@pytest.mark.parametrize("pattern", ["float_ties", "mixed_sign", "wide_range", "small_alpha",
+                                     "negative_alpha", "powers_of_two", "integers"])
+@pytest.mark.parametrize("sigma", [3.0, 10.0])
+def test_blur_hdri_on_float_rounding_ties(im, refmod, pattern, sigma):
+    """float Quantum, long kernels: fused fp64 sums plus the float-rounding tie check of
+    Accum::finish() (convolve.hip).  A frame that alternates between a float and its upper
+    neighbour blurs to the midpoint of the two (to 1e-16), where the float the reference stores
+    is decided by the last bits of its own summation order; mixed signs, 60 decades of range,
+    alpha sums around PerceptibleReciprocal's clamp and negative alpha stress the error bound the
+    check relies on.  All bit-identical."""
+    rows, cols = 90, 150
+    rng = np.random.default_rng(77)
+    y, x = np.mgrid[0:rows, 0:cols]
+    px = (rng.random((rows, cols, 4)) * 65535.0).astype(np.float32)
+    if pattern == "float_ties":
+        for c, level in enumerate((1000.25, 32767.5, 3.0e-3)):
+            low = np.float32(level)
+            px[:, :, c] = np.where(((x + y) & 1) == 1, np.nextafter(low, np.float32(np.inf)), low)
+        px[:, :, 3] = 65535.0
+    elif pattern == "mixed_sign":
+        px[:, :, :3] -= 32768.0
+        px[:, :, 3] = np.where((x & 3) == 0, 0.0, px[:, :, 3])
+    elif pattern == "wide_range":
+        px[:, :, :3] = (10.0 ** rng.uniform(-30, 30, (rows, cols, 3))).astype(np.float32)
+        px[:, :, 3] = 65535.0
+    elif pattern == "small_alpha":
+        px[:, :, 3] = (10.0 ** rng.uniform(-12, 0, (rows, cols))).astype(np.float32)
+        px[:, : cols // 3, 3] = 0.0
+    elif pattern == "negative_alpha":
+        px[:, :, 3] -= 20000.0
+    elif pattern == "powers_of_two":
+        px[:, :, :3] = np.where(((x & 1) == 1)[:, :, None], 4096.0, np.nextafter(np.float32(4096.0), np.float32(0)))
+        px[:, :, 3] = 65535.0
+    else:
+        px = np.floor(px)
+    dev, ref = run_pair(im, refmod, px)
+    got = im.blur_image(dev, 0.0, sigma).numpy()
+    want = ref.blur(0.0, sigma).numpy()
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), "HDRI blur, %s sigma %g: %d of %d samples differ, first at %s" % (
+        pattern, sigma, int((~same).sum()), same.size, np.argwhere(~same)[:3].tolist())
+
+
 @pytest.mark.parametrize("sigma", [0.303, 2.0, 10.05])
 def test_blur_fast_structured_ties_bound(im, refmod, sigma):
     """FAST is +-1 BY CONSTRUCTION: the row pass is the exact-integer one
