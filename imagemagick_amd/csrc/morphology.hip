@@ -936,6 +936,316 @@ static MhStatus launch_rects(bool dilate,int shape,const RectsArgs &args,size_t 
   return dilate ? launch_rects_typed<C,true,8,6>(args,lds,stream) : launch_rects_typed<C,false,8,6>(args,lds,stream);
 }
 
+// ------------------------------------------------ the same evaluation as a walk down a strip
+// morph_rects_kernel spends a third of its vector instructions on columns it discards (a wave of
+// 128 columns keeps 128-2*hmax) and on the v_mov_dpp that fetch a neighbour lane's edge column, and
+// it stages TH+2*vmax rows for TH rows of output.  This kernel gives a lane FOUR adjacent columns
+// (a wave = 256 columns, 256-2*hmax kept; Row(1) costs 6 packed min/max + 2 cross-lane moves per
+// word plane instead of 8 + 4 for the same four columns: the pair maxima (a,b) and (c,d) are shared
+// by the two columns next to them) and lets a workgroup walk DOWN its strip: the 2*vmax rows two
+// successive tiles share stay in LDS (moved to the top of the tile), and the TH new rows are
+// fetched into registers while the previous tile is evaluated — every source row is read once per
+// strip, so the frame is read 256/(256-2*hmax) times instead of (128/(128-2*hmax))*(TH+2*vmax)/TH.
+// One workgroup per CU (the tile is 2 KiB a row for RGBA): the overlap of memory and arithmetic
+// that two resident workgroups gave the other kernel comes from the register prefetch.
+struct StripsArgs
+{
+  RectsArgs r;                // tiles_x = strips, tiles_y = ceil(rows/TH): steps of a whole strip
+  int segments;               // vertical cuts of a strip: work items = strips*segments
+  int steps_per_segment;
+  int items_per_xcd;
+};
+
+template<int C,bool DILATE,int SY,int NWAVES>
+__global__ __launch_bounds__(64*NWAVES)
+void morph_strips_kernel(StripsArgs sargs)
+{
+  static_assert((C == 2) || (C == 4),"whole 32-bit words per pixel");
+  const RectsArgs &args=sargs.r;
+  constexpr int SX=4;                          // columns per lane
+  constexpr int NW=C/2;                        // 32-bit words per pixel
+  constexpr int WPR=SX*NW;                     // words a lane holds per row
+  constexpr int HW=WPR/2;                      // ... per half (two columns): one LDS access
+  constexpr int TH=SY*NWAVES;                  // output rows per step
+  typedef uint32_t Half __attribute__((ext_vector_type(HW)));
+  typedef Half __attribute__((aligned(4))) LooseHalf;        // global memory: pixel alignment only
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  Half *tile=reinterpret_cast<Half *>(smem_raw);             // [TH+2*vmax][2 halves][64 lanes]
+  const int W=args.columns,H=args.rows;
+  const int hmax=args.hmax,vmax=args.vmax,halo=2*vmax;
+  const int tid=(int) threadIdx.x,lane=tid & 63;
+  const int wave=__builtin_amdgcn_readfirstlane(tid >> 6);
+  const int item=((int) blockIdx.x & 7)*sargs.items_per_xcd+((int) blockIdx.x >> 3);
+  if (item >= args.tiles_x*sargs.segments)
+    return;
+  const int segment=item/args.tiles_x,strip=item-segment*args.tiles_x;
+  const int step_begin=segment*sargs.steps_per_segment;
+  const int step_end=step_begin+sargs.steps_per_segment < args.tiles_y ? step_begin+sargs.steps_per_segment : args.tiles_y;
+  const int valid_w=64*SX-2*hmax;
+  const int bx=strip*valid_w;
+
+  // ---- source access: tile column t is image column bx+cx-hmax+t, clamped (cache.c:2663-2679);
+  // a lane keeps its four columns for the whole walk
+  const int sx=bx+args.cx-hmax+SX*lane;
+  const bool inside=(sx >= 0) && (sx+SX-1 <= W-1);
+  unsigned xoff[SX];
+#pragma unroll
+  for (int j=0; j < SX; j++)
+    {
+      int x=sx+j;
+      x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
+      xoff[j]=(unsigned) x*(unsigned) (C*sizeof(uint16_t));
+    }
+  const unsigned row_bytes=(unsigned) W*(unsigned) (C*sizeof(uint16_t));
+  const unsigned char *base=reinterpret_cast<const unsigned char *>(args.src);
+  auto load_row=[&](int sy,Half (&out)[2])
+  {
+    sy=sy < 0 ? 0 : (sy > H-1 ? H-1 : sy);
+    const unsigned char *row=base+(unsigned) sy*row_bytes;
+    if (inside)
+      {
+        out[0]=*reinterpret_cast<const LooseHalf *>(row+xoff[0]);
+        out[1]=*reinterpret_cast<const LooseHalf *>(row+xoff[2]);
+      }
+    else
+      {
+#pragma unroll
+        for (int j=0; j < SX; j++)
+#pragma unroll
+          for (int w=0; w < NW; w++)
+            out[j >> 1][(j & 1)*NW+w]=*reinterpret_cast<const uint32_t *>(row+xoff[j]+4*w);
+      }
+  };
+  auto tile_at=[&](int row,int half) -> Half * { return tile+(size_t) (row*2+half)*64+lane; };
+
+  // tile row q of step s is image row s*TH+cy-vmax+q
+  {
+    const int sy0=step_begin*TH+args.cy-vmax;
+    for (int q=wave; q < halo; q+=NWAVES)
+      {
+        Half g[2];
+        load_row(sy0+q,g);
+        *tile_at(q,0)=g[0];
+        *tile_at(q,1)=g[1];
+      }
+  }
+  Half pre[SY][2];                             // the wave's share of the TH new rows of a step
+  auto prefetch=[&](int step)
+  {
+    const int sy0=step*TH+args.cy-vmax+halo;
+#pragma unroll
+    for (int k=0; k < SY; k++)
+      load_row(sy0+wave+NWAVES*k,pre[k]);
+  };
+  prefetch(step_begin);
+
+  const int u0=SX*lane-hmax;                   // first of the lane's columns within the valid span
+  const bool centred=(args.cx == 0) && (args.cy == 0);
+  bool ok[SX];
+  bool all=true;
+#pragma unroll
+  for (int j=0; j < SX; j++)
+    {
+      ok[j]=(u0+j >= 0) && (u0+j < valid_w) && (bx+u0+j < W);
+      all=all && ok[j];
+    }
+  unsigned changed=0;
+  for (int step=step_begin; step < step_end; step++)
+    {
+#pragma unroll
+      for (int k=0; k < SY; k++)
+        {
+          *tile_at(halo+wave+NWAVES*k,0)=pre[k][0];
+          *tile_at(halo+wave+NWAVES*k,1)=pre[k][1];
+        }
+      __syncthreads();
+      if (step+1 < step_end)
+        prefetch(step+1);
+
+      // ---- the wave's SY output rows: tile rows wave*SY+vmax+i
+      const int by=step*TH;
+      const int centre_row=wave*SY+vmax;
+      uint32_t column[SY][WPR],spread[SY][WPR];    // C and S of the header above morph_rects_kernel
+#pragma unroll
+      for (int i=0; i < SY; i++)
+        {
+          const Half a=*tile_at(centre_row+i,0),b=*tile_at(centre_row+i,1);
+#pragma unroll
+          for (int p=0; p < HW; p++)
+            {
+              column[i][p]=a[p];
+              column[i][HW+p]=b[p];
+            }
+#pragma unroll
+          for (int p=0; p < WPR; p++)
+            spread[i][p]=DILATE ? 0u : 0xffffffffu;
+        }
+      int folded=0;                                // rows +-1..folded are in `column`
+      for (int l=args.nlevels-1; l >= 0; l--)
+        {
+          const int reach=(int) args.reach[l];
+          for (int k=folded+1; k <= reach; k++)
+            {
+              // rows i-k, then rows i+k (one side at a time: 16 registers a row quad less)
+#pragma unroll
+              for (int side=-1; side <= 1; side+=2)
+                {
+                  Half far[SY][2];
+#pragma unroll
+                  for (int i=0; i < SY; i++)
+                    {
+                      far[i][0]=*tile_at(centre_row+i+side*k,0);
+                      far[i][1]=*tile_at(centre_row+i+side*k,1);
+                    }
+#pragma unroll
+                  for (int i=0; i < SY; i++)
+#pragma unroll
+                    for (int p=0; p < WPR; p++)
+                      column[i][p]=pk_pick<DILATE>(column[i][p],far[i][p/HW][p%HW]);
+                }
+            }
+          folded=reach > folded ? reach : folded;
+#pragma unroll
+          for (int i=0; i < SY; i++)
+#pragma unroll
+            for (int p=0; p < WPR; p++)
+              spread[i][p]=pk_pick<DILATE>(spread[i][p],column[i][p]);
+          const int widen=(int) args.widen[l];
+          for (int stride=0; stride < widen; stride++)
+            {
+              // Row(1) over the lane's columns a b c d and the neighbours' d' (left) and a' (right):
+              //   a <- d' v (a v b),  b <- (a v b) v c,  c <- b v (c v d),  d <- (c v d) v a'
+#pragma unroll
+              for (int i=0; i < SY; i++)
+#pragma unroll
+                for (int w=0; w < NW; w++)
+                  {
+                    const uint32_t a=spread[i][w],b=spread[i][NW+w],c=spread[i][2*NW+w],d=spread[i][3*NW+w];
+                    // wave_shr:1 — lane n reads lane n-1 (0x138); wave_shl:1 — lane n reads lane n+1 (0x130)
+                    const uint32_t left=(uint32_t) __builtin_amdgcn_mov_dpp((int) d,0x138,0xf,0xf,true);
+                    const uint32_t right=(uint32_t) __builtin_amdgcn_mov_dpp((int) a,0x130,0xf,0xf,true);
+                    const uint32_t ab=pk_pick<DILATE>(a,b),cd=pk_pick<DILATE>(c,d);
+                    spread[i][w]=pk_pick<DILATE>(left,ab);
+                    spread[i][NW+w]=pk_pick<DILATE>(ab,c);
+                    spread[i][2*NW+w]=pk_pick<DILATE>(b,cd);
+                    spread[i][3*NW+w]=pk_pick<DILATE>(cd,right);
+                  }
+            }
+        }
+
+      // ---- copy out: morphology.c:3180-3196 (channels without the update trait keep the source
+      // value; `changed` counts the updated samples that differ from the source)
+#pragma unroll
+      for (int i=0; i < SY; i++)
+        {
+          const int y=by+wave*SY+i;
+          if (y >= H)
+            break;
+          unsigned char *out=reinterpret_cast<unsigned char *>(args.dst)+(unsigned) y*row_bytes;
+          uint32_t result[WPR];
+          if (DILATE && (args.copy_mask == 0u) && (args.changed == nullptr))
+            {
+              // every channel updated, nobody counts: the maxima are the result
+#pragma unroll
+              for (int p=0; p < WPR; p++)
+                result[p]=spread[i][p];
+            }
+          else
+            {
+              uint32_t original[WPR];
+              if (centred)
+                {
+                  // the output pixel is the centre of its own window
+                  const Half a=*tile_at(centre_row+i,0),b=*tile_at(centre_row+i,1);
+#pragma unroll
+                  for (int p=0; p < HW; p++)
+                    {
+                      original[p]=a[p];
+                      original[HW+p]=b[p];
+                    }
+                }
+              else
+                {
+                  const unsigned char *in=base+(unsigned) y*row_bytes;
+#pragma unroll
+                  for (int j=0; j < SX; j++)
+#pragma unroll
+                    for (int w=0; w < NW; w++)
+                      original[j*NW+w]=ok[j] ? *reinterpret_cast<const uint32_t *>(in+(unsigned) (bx+u0+j)*(unsigned) (C*sizeof(uint16_t))+4*w) : 0u;
+                }
+#pragma unroll
+              for (int p=0; p < WPR; p++)
+                {
+                  // Erode starts from the output pixel itself (morphology.c:2905-2912)
+                  const uint32_t value=DILATE ? spread[i][p] : pk_pick<false>(spread[i][p],original[p]);
+                  const int c0=2*(p % NW);             // channels of this word's halves
+                  uint32_t keep=0u;
+                  keep|=((args.copy_mask >> c0) & 1u) != 0u ? 0x0000ffffu : 0u;
+                  keep|=((args.copy_mask >> (c0+1)) & 1u) != 0u ? 0xffff0000u : 0u;
+                  result[p]=(original[p] & keep) | (value & ~keep);
+                  const uint32_t differs=(value ^ original[p]) & ~keep;
+                  if (ok[p/NW])
+                    changed+=((differs & 0xffffu) != 0u ? 1u : 0u)+((differs >> 16) != 0u ? 1u : 0u);
+                }
+            }
+          if (all)
+            {
+              Half lo,hi;
+#pragma unroll
+              for (int p=0; p < HW; p++)
+                {
+                  lo[p]=result[p];
+                  hi[p]=result[HW+p];
+                }
+              unsigned char *at=out+(unsigned) (bx+u0)*(unsigned) (C*sizeof(uint16_t));
+              *reinterpret_cast<LooseHalf *>(at)=lo;
+              *reinterpret_cast<LooseHalf *>(at+sizeof(Half))=hi;
+            }
+          else
+            {
+#pragma unroll
+              for (int j=0; j < SX; j++)
+                if (ok[j])
+#pragma unroll
+                  for (int w=0; w < NW; w++)
+                    *reinterpret_cast<uint32_t *>(out+(unsigned) (bx+u0+j)*(unsigned) (C*sizeof(uint16_t))+4*w)=result[j*NW+w];
+            }
+        }
+      __syncthreads();                             // every read of this tile is done
+      if (step+1 < step_end)
+        {
+          // the 2*vmax rows the next tile shares with this one move to its top (TH >= 2*vmax: the
+          // two ranges are disjoint, and the rows written are read by nobody else)
+          for (int q=wave; q < halo; q+=NWAVES)
+            {
+              const Half a=*tile_at(TH+q,0),b=*tile_at(TH+q,1);
+              *tile_at(q,0)=a;
+              *tile_at(q,1)=b;
+            }
+          __syncthreads();                         // ... before the new rows overwrite their source
+        }
+    }
+  if (args.changed != nullptr)
+    {
+      changed=wave_sum(changed);
+      if ((lane == 0) && (changed != 0))
+        atomicAdd(args.changed,(unsigned long long) changed);
+    }
+}
+
+template<int C,bool DILATE>
+static MhStatus launch_strips_typed(const StripsArgs &args,unsigned items,size_t lds,hipStream_t stream)
+{
+  constexpr int SY=4,WAVES=12;
+  const dim3 grid(8u*(unsigned) args.items_per_xcd),block(64*WAVES);
+  (void) items;
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&morph_strips_kernel<C,DILATE,SY,WAVES>),
+    hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+  hipLaunchKernelGGL((morph_strips_kernel<C,DILATE,SY,WAVES>),grid,block,lds,stream,args);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 // half[k]: half-width of kernel row dy_min+k (every row non-empty, runs centred on cx).  Handles
 // the kernel when its rows are symmetric about the middle row and do not widen away from it.
 static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std::vector<int> &half,
@@ -989,6 +1299,51 @@ static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std:
   a.cy=dy_min+vmax;
   a.hmax=hmax;
   a.vmax=vmax;
+  a.copy_mask=roles.copy_mask;
+  a.changed=changed;
+  {
+    // frames of several strips by several steps: the walk down 256-column strips
+    constexpr int kStripRows=48;
+    const size_t strip_lds=(size_t) (kStripRows+2*vmax)*2u*row_lds;
+    const int strip_w=256-2*hmax;
+    if ((2*vmax <= kStripRows) && (strip_lds <= 160u*1024u) && ((int) src.columns >= 2*strip_w) &&
+        ((int) src.rows >= 4*kStripRows) && (getenv("MAGICKHIP_NO_STRIPS") == nullptr))
+      {
+        StripsArgs sa;
+        sa.r=a;
+        sa.r.tiles_x=((int) src.columns+strip_w-1)/strip_w;
+        sa.r.tiles_y=((int) src.rows+kStripRows-1)/kStripRows;
+        // cuts of a strip: the schedule (one workgroup per CU, 256 CUs) that finishes first; a
+        // cut costs its 2*vmax rows of halo
+        int best=1;
+        double best_cost=1.0e300;
+        for (int cuts=1; cuts <= sa.r.tiles_y; cuts++)
+          {
+            const int steps=(sa.r.tiles_y+cuts-1)/cuts;
+            const int rounds=(sa.r.tiles_x*((sa.r.tiles_y+steps-1)/steps)+255)/256;
+            const double cost=(double) rounds*((double) steps*kStripRows+2.0*vmax);
+            if (cost < best_cost-1.0e-9)
+              {
+                best_cost=cost;
+                best=cuts;
+              }
+          }
+        if (const char *e=getenv("MAGICKHIP_STRIP_CUTS"))         // tests: walks of several steps on small frames
+          best=(atoi(e) >= 1) && (atoi(e) <= sa.r.tiles_y) ? atoi(e) : best;
+        sa.steps_per_segment=(sa.r.tiles_y+best-1)/best;
+        sa.segments=(sa.r.tiles_y+sa.steps_per_segment-1)/sa.steps_per_segment;
+        sa.items_per_xcd=(sa.r.tiles_x*sa.segments+7)/8;
+        sa.r.tiles_per_xcd=sa.items_per_xcd;
+        ProfileScope prof("morph_rects",src.stream);
+        const unsigned items=(unsigned) (sa.r.tiles_x*sa.segments);
+        if (src.channels == 4)
+          MH_TRY((dilate ? launch_strips_typed<4,true>(sa,items,strip_lds,src.stream) : launch_strips_typed<4,false>(sa,items,strip_lds,src.stream)));
+        else
+          MH_TRY((dilate ? launch_strips_typed<2,true>(sa,items,strip_lds,src.stream) : launch_strips_typed<2,false>(sa,items,strip_lds,src.stream)));
+        *handled=true;
+        return MH_OK;
+      }
+  }
   const int valid_w=128-2*hmax;
   a.tiles_x=((int) src.columns+valid_w-1)/valid_w;
   a.tiles_y=((int) src.rows+th-1)/th;

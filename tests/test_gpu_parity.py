@@ -632,6 +632,53 @@ def test_symmetric_convex_kernels_over_several_tiles(im, refmod, method, kernel,
     assert_parity(im.morphology_image(dev, method, 1, kernel).numpy(), want, True, "%s %s (planes)" % (method, kernel))
 
 
+@pytest.mark.parametrize("channels,cuts", [(4, 1), (4, 2), (2, 1), (4, None)])
+@pytest.mark.parametrize("method,kernel", [
+    ("Dilate", "Disk:15"), ("Erode", "Disk:15"), ("Erode", "Octagon:6"), ("Dilate", "Square:3"),
+    ("Dilate", "Rectangle:9x5+2+1"), ("Erode", "Diamond:11"), ("Dilate", "Rectangle:1x9"), ("Erode", "Rectangle:13x1"),
+])
+def test_symmetric_convex_kernels_down_a_strip(im, refmod, method, kernel, channels, cuts, monkeypatch):
+    """The same union-of-rectangles evaluation as a walk down 256-column strips (morph_strips_kernel:
+    four columns per lane, the rows two successive tiles share kept in LDS, the new rows prefetched
+    into registers) on a frame of three ragged strips by six ragged steps; walks of six, three and
+    one step (MAGICKHIP_STRIP_CUTS).  Bit-identical to the reference and to the tile kernel."""
+    import bench
+    if cuts is not None:
+        monkeypatch.setenv("MAGICKHIP_STRIP_CUTS", str(cuts))
+    px = make_pixels(271, 530, channels, Q16, seed=len(kernel) + channels)
+    dev, ref = run_pair(im, refmod, px)
+    holder = {}
+    launched = set(bench.kernel_profile(
+        im, lambda: holder.update(out=im.morphology_image(dev, method, 1, kernel)), 1))
+    assert launched == {"morph_rects"}, launched
+    got = holder["out"].numpy()
+    monkeypatch.setenv("MAGICKHIP_NO_STRIPS", "1")
+    tiles = im.morphology_image(dev, method, 1, kernel).numpy()
+    assert np.array_equal(got, tiles), "%s %s c%d: strip walk != tile kernel at %s" % (
+        method, kernel, channels, np.argwhere(got != tiles)[:4].tolist())
+    if cuts in (1, None):
+        assert_parity(got, ref.morphology(method, 1, kernel).numpy(), True, "%s %s c%d" % (method, kernel, channels))
+
+
+def test_strip_walk_channel_mask_and_change_count(im, refmod, monkeypatch):
+    """morph_strips_kernel's general epilogue: channels without the update trait, the `changed`
+    count that ends an unbounded iteration, and a kernel whose origin is off centre."""
+    monkeypatch.setenv("MAGICKHIP_STRIP_CUTS", "2")
+    px = make_pixels(200, 470, 4, Q16, seed=78)
+    dev = im.Image(to_device(px), copy_channels=(1, 3))
+    ref = refmod.RefImage(px).set_channel_mask("RB")
+    got = im.morphology_image(dev, "Erode", 1, "Disk:6").numpy()
+    assert_parity(got, ref.morphology("Erode", 1, "Disk:6").numpy(), True, "Erode Disk:6 -channel RB")
+    sparse = np.zeros((200, 460, 4), dtype=np.uint16)
+    sparse[100, 230] = 65535
+    sparse[199, 459] = 40000
+    dev, ref = run_pair(im, refmod, sparse)
+    assert_parity(im.morphology_image(dev, "Dilate", 6, "Square:2").numpy(),
+                  ref.morphology("Dilate", 6, "Square:2").numpy(), True, "Dilate Square:2 x6")
+    assert_parity(im.morphology_image(dev, "Dilate", 2, "Rectangle:7x5+1+3").numpy(),
+                  ref.morphology("Dilate", 2, "Rectangle:7x5+1+3").numpy(), True, "Dilate Rectangle:7x5+1+3 x2")
+
+
 def test_symmetric_convex_kernel_channel_mask_and_change_count(im, refmod):
     """Channels without the update trait keep the source value; an unbounded iteration count
     stops on the `changed` count of the kernel (morphology.c:3180-3196, :3892-3905)."""

@@ -1,4 +1,5 @@
-"""C5 Dilate Disk:15 on 16384^2 RGBA Q16: the union-of-rectangles kernel against the
+"""C5 Dilate Disk:15 on 16384^2 RGBA Q16: the union-of-rectangles strip walk against the
+tile kernel (MAGICKHIP_NO_STRIPS=1) and the
 plane-per-width kernel (MAGICKHIP_NO_RECTS=1); same bits, compared."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,11 +15,10 @@ img = im.Image(a)
 hold = {}
 for kernel in kernels:
     results = []
-    for label, env in (("rects", None), ("planes", "1")):
-        if env is None:
-            os.environ.pop("MAGICKHIP_NO_RECTS", None)
-        else:
-            os.environ["MAGICKHIP_NO_RECTS"] = env
+    for label, env in (("strips", {}), ("tiles", {"MAGICKHIP_NO_STRIPS": "1"}), ("planes", {"MAGICKHIP_NO_RECTS": "1"})):
+        os.environ.pop("MAGICKHIP_NO_RECTS", None)
+        os.environ.pop("MAGICKHIP_NO_STRIPS", None)
+        os.environ.update(env)
 
         def f():
             hold["o"] = im.morphology_image(img, "Dilate", 1, kernel)
@@ -27,4 +27,4 @@ for kernel in kernels:
         results.append(hold["o"].pixels.clone())
         print("%-10s %-7s %.3f ms  %.1f Mpixels/s  kernels(ms) %s" % (kernel, label, sec * 1e3, n * n / sec / 1e6,
               {k: round(v["avg_ms"], 3) for k, v in prof.items()}), flush=True)
-    print("   identical:", bool(torch.equal(results[0], results[1])))
+    print("   identical:", bool(torch.equal(results[0], results[1])) and bool(torch.equal(results[0], results[2])))
