@@ -751,10 +751,18 @@ void morph_rects_kernel(RectsArgs args)
   // ---- the wave's SY output rows: tile rows wave*SY+vmax+i
   const Group *centre=tile+(size_t) (wave*SY+vmax)*64+lane;
   uint32_t column[SY][WPR],spread[SY][WPR];    // C and S of the header
+  // The rows a fold depth takes in slide: at depth k output row i needs tile rows i-k and i+k, and
+  // row i-k = row (i+1)-(k+1) was read one depth earlier for output row i+1.  `upper` holds the
+  // rows 0-j (j = k-SY+1 .. k) in slot j mod SY, `lower` the rows SY-1+j: a depth costs two row
+  // reads instead of 2*SY (the LDS pipe, not the vector unit, set the pace of the fold), and
+  // with the depths unrolled SY at a time every slot is a compile-time register.
+  Group upper[SY],lower[SY];
 #pragma unroll
   for (int i=0; i < SY; i++)
     {
       const Group g=centre[i*64];
+      upper[(SY-i)%SY]=g;                      // row i = row 0-(-i)
+      lower[(i+1)%SY]=g;                       // row i = row SY-1+(i-SY+1)
 #pragma unroll
       for (int p=0; p < WPR; p++)
         {
@@ -762,54 +770,67 @@ void morph_rects_kernel(RectsArgs args)
           spread[i][p]=DILATE ? 0u : 0xffffffffu;
         }
     }
-  int folded=0;                                // rows +-1..folded are in `column`
-  for (int l=args.nlevels-1; l >= 0; l--)
-    {
-      const int reach=(int) args.reach[l];
-      for (int k=folded+1; k <= reach; k++)
-        {
-          Group above[SY],below[SY];
+  // lane l keeps level l's reach and widening: a v_readlane per level instead of a load from the
+  // kernel arguments
+  const int lane_reach=lane < args.nlevels ? (int) args.reach[lane] : 0;
+  const int lane_widen=lane < args.nlevels ? (int) args.widen[lane] : 0;
+  // every level whose reach the fold depth has arrived at: merge the column windows into the
+  // spread and widen it (the levels' reaches grow as l falls)
+  int level=args.nlevels-1;
+  auto settle=[&](int depth)
+  {
+    while ((level >= 0) && (__builtin_amdgcn_readlane(lane_reach,level) <= depth))
+      {
 #pragma unroll
-          for (int i=0; i < SY; i++)
-            {
-              above[i]=centre[(i-k)*64];
-              below[i]=centre[(i+k)*64];
-            }
+        for (int i=0; i < SY; i++)
 #pragma unroll
-          for (int i=0; i < SY; i++)
+          for (int p=0; p < WPR; p++)
+            spread[i][p]=pk_pick<DILATE>(spread[i][p],column[i][p]);
+        const int widen=__builtin_amdgcn_readlane(lane_widen,level);
+        for (int step=0; step < widen; step++)
+          {
+            // Row(1): every column takes in its two neighbours.  The lane's columns a b share their
+            // pair maximum: a <- b' v (a v b), b <- (a v b) v a' (b', a': the neighbour lanes')
+            static_assert(SX == 2,"the pair form");
 #pragma unroll
-            for (int p=0; p < WPR; p++)
-              column[i][p]=pk_pick<DILATE>(pk_pick<DILATE>(column[i][p],above[i][p]),below[i][p]);
-        }
-      folded=reach > folded ? reach : folded;
+            for (int i=0; i < SY; i++)
 #pragma unroll
-      for (int i=0; i < SY; i++)
-#pragma unroll
-        for (int p=0; p < WPR; p++)
-          spread[i][p]=pk_pick<DILATE>(spread[i][p],column[i][p]);
-      const int widen=(int) args.widen[l];
-      for (int step=0; step < widen; step++)
-        {
-          // Row(1): every column takes in its two neighbours
-#pragma unroll
-          for (int i=0; i < SY; i++)
-            {
-              uint32_t next[WPR];
-#pragma unroll
-              for (int p=0; p < WPR; p++)
+              for (int w=0; w < NW; w++)
                 {
-                  const int j=p/NW;
+                  const uint32_t a=spread[i][w],b=spread[i][NW+w];
                   // wave_shr:1 — lane n reads lane n-1 (0x138); wave_shl:1 — lane n reads lane n+1 (0x130)
-                  const uint32_t left=j > 0 ? spread[i][p-NW] :
-                    (uint32_t) __builtin_amdgcn_mov_dpp((int) spread[i][p+(SX-1)*NW],0x138,0xf,0xf,true);
-                  const uint32_t right=j < SX-1 ? spread[i][p+NW] :
-                    (uint32_t) __builtin_amdgcn_mov_dpp((int) spread[i][p-(SX-1)*NW],0x130,0xf,0xf,true);
-                  next[p]=pk_pick<DILATE>(pk_pick<DILATE>(left,spread[i][p]),right);
+                  const uint32_t left=(uint32_t) __builtin_amdgcn_mov_dpp((int) b,0x138,0xf,0xf,true);
+                  const uint32_t right=(uint32_t) __builtin_amdgcn_mov_dpp((int) a,0x130,0xf,0xf,true);
+                  const uint32_t both=pk_pick<DILATE>(a,b);
+                  spread[i][w]=pk_pick<DILATE>(left,both);
+                  spread[i][NW+w]=pk_pick<DILATE>(both,right);
                 }
+          }
+        level--;
+      }
+  };
+  settle(0);
+  for (int k0=1; k0 <= vmax; k0+=SY)
+    {
+#pragma unroll
+      for (int u=0; u < SY; u++)
+        {
+          const int k=k0+u;                    // k mod SY = (1+u) mod SY
+          if (k > vmax)
+            break;
+          upper[(1+u)%SY]=centre[-k*64];
+          lower[(1+u)%SY]=centre[(SY-1+k)*64];
+#pragma unroll
+          for (int i=0; i < SY; i++)
+            {
+              // row i-k is row 0-(k-i), row i+k is row SY-1+(k+i-SY+1)
+              const Group &above=upper[(1+u+SY-i)%SY];
+              const Group &below=lower[(2+u+i)%SY];
 #pragma unroll
               for (int p=0; p < WPR; p++)
-                spread[i][p]=next[p];
+                column[i][p]=pk_pick<DILATE>(pk_pick<DILATE>(column[i][p],above[p]),below[p]);
             }
+          settle(k);
         }
     }
 
@@ -938,16 +959,20 @@ static MhStatus launch_rects(bool dilate,int shape,const RectsArgs &args,size_t 
 
 // ------------------------------------------------ the same evaluation as a walk down a strip
 // morph_rects_kernel spends a third of its vector instructions on columns it discards (a wave of
-// 128 columns keeps 128-2*hmax) and on the v_mov_dpp that fetch a neighbour lane's edge column, and
-// it stages TH+2*vmax rows for TH rows of output.  This kernel gives a lane FOUR adjacent columns
-// (a wave = 256 columns, 256-2*hmax kept; Row(1) costs 6 packed min/max + 2 cross-lane moves per
-// word plane instead of 8 + 4 for the same four columns: the pair maxima (a,b) and (c,d) are shared
-// by the two columns next to them) and lets a workgroup walk DOWN its strip: the 2*vmax rows two
-// successive tiles share stay in LDS (moved to the top of the tile), and the TH new rows are
-// fetched into registers while the previous tile is evaluated — every source row is read once per
-// strip, so the frame is read 256/(256-2*hmax) times instead of (128/(128-2*hmax))*(TH+2*vmax)/TH.
-// One workgroup per CU (the tile is 2 KiB a row for RGBA): the overlap of memory and arithmetic
-// that two resident workgroups gave the other kernel comes from the register prefetch.
+// 128 columns keeps 128-2*hmax) and on the v_mov_dpp that fetch a neighbour lane's edge column, it
+// reads every staged row 2*SY times per output row quad, and it stages TH+2*vmax rows for TH rows
+// of output.  This kernel
+//   * gives a lane FOUR adjacent columns: a wave = 256 columns, 256-2*hmax kept; Row(1) costs 6
+//     packed min/max + 2 cross-lane moves per word plane instead of 8 + 4 for the same four
+//     columns (the pair maxima (a,b) and (c,d) are shared by the columns next to them);
+//   * lets a wave slide over its rows: output rows c and c+1 at fold depth k need rows c-k, c+k and
+//     c+1-k, c+1+k — two of the four were loaded for depth k-1, so a depth costs two row reads;
+//   * lets a workgroup walk DOWN its strip through a ring of 2*TH+2*vmax rows in LDS: the rows two
+//     successive tiles share stay where they are, and the TH new rows of the next tile are written
+//     by global_load_lds_dwordx4 (memory -> LDS without passing through registers) while this tile
+//     is evaluated.  Every source row is read once per strip: the frame is read 256/(256-2*hmax)
+//     times instead of (128/(128-2*hmax))*(TH+2*vmax)/TH.
+// One workgroup per CU (a ring row is 2 KiB for RGBA), one barrier per tile.
 struct StripsArgs
 {
   RectsArgs r;                // tiles_x = strips, tiles_y = ceil(rows/TH): steps of a whole strip
@@ -956,23 +981,26 @@ struct StripsArgs
   int items_per_xcd;
 };
 
-template<int C,bool DILATE,int SY,int NWAVES>
+template<int C,bool DILATE,int NWAVES>
 __global__ __launch_bounds__(64*NWAVES)
 void morph_strips_kernel(StripsArgs sargs)
 {
   static_assert((C == 2) || (C == 4),"whole 32-bit words per pixel");
   const RectsArgs &args=sargs.r;
   constexpr int SX=4;                          // columns per lane
+  constexpr int SY=2;                          // rows per wave
   constexpr int NW=C/2;                        // 32-bit words per pixel
   constexpr int WPR=SX*NW;                     // words a lane holds per row
   constexpr int HW=WPR/2;                      // ... per half (two columns): one LDS access
   constexpr int TH=SY*NWAVES;                  // output rows per step
+  constexpr int kStoreDepth=4;                 // 1 + a multiple of 3
   typedef uint32_t Half __attribute__((ext_vector_type(HW)));
   typedef Half __attribute__((aligned(4))) LooseHalf;        // global memory: pixel alignment only
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  Half *tile=reinterpret_cast<Half *>(smem_raw);             // [TH+2*vmax][2 halves][64 lanes]
+  Half *ring=reinterpret_cast<Half *>(smem_raw);             // [2*TH+2*vmax][2 halves][64 lanes]
   const int W=args.columns,H=args.rows;
   const int hmax=args.hmax,vmax=args.vmax,halo=2*vmax;
+  const int R=2*TH+halo;                       // ring rows
   const int tid=(int) threadIdx.x,lane=tid & 63;
   const int wave=__builtin_amdgcn_readfirstlane(tid >> 6);
   const int item=((int) blockIdx.x & 7)*sargs.items_per_xcd+((int) blockIdx.x >> 3);
@@ -985,7 +1013,9 @@ void morph_strips_kernel(StripsArgs sargs)
   const int bx=strip*valid_w;
 
   // ---- source access: tile column t is image column bx+cx-hmax+t, clamped (cache.c:2663-2679);
-  // a lane keeps its four columns for the whole walk
+  // a lane keeps its four columns for the whole walk.  Lanes whose four columns are inside the
+  // frame (all but a few of the first and the last strip) fetch straight into LDS; the others
+  // through registers.
   const int sx=bx+args.cx-hmax+SX*lane;
   const bool inside=(sx >= 0) && (sx+SX-1 <= W-1);
   unsigned xoff[SX];
@@ -998,14 +1028,28 @@ void morph_strips_kernel(StripsArgs sargs)
     }
   const unsigned row_bytes=(unsigned) W*(unsigned) (C*sizeof(uint16_t));
   const unsigned char *base=reinterpret_cast<const unsigned char *>(args.src);
-  auto load_row=[&](int sy,Half (&out)[2])
+  const unsigned lds_base=(unsigned) (size_t) (__attribute__((address_space(3))) unsigned char *) smem_raw;
+  auto ring_at=[&](int row,int half) -> Half * { return ring+(size_t) (row*2+half)*64+lane; };
+  // image row sy -> ring row `row`; `held`: the columns of a lane at the frame's edge
+  auto fetch_row=[&](int sy,int row,Half (&held)[2])
   {
     sy=sy < 0 ? 0 : (sy > H-1 ? H-1 : sy);
-    const unsigned char *row=base+(unsigned) sy*row_bytes;
+    const unsigned at=(unsigned) sy*row_bytes;
     if (inside)
       {
-        out[0]=*reinterpret_cast<const LooseHalf *>(row+xoff[0]);
-        out[1]=*reinterpret_cast<const LooseHalf *>(row+xoff[2]);
+        if constexpr (C == 4)
+          {
+            // 64 lanes x 16 bytes land at M0 + 16*lane: one (row, half) plane of the ring
+            const unsigned to=(unsigned) __builtin_amdgcn_readfirstlane((int) (lds_base+(unsigned) row*2048u));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+                         "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %2"
+                         : : "s"(to),"v"(at+xoff[0]),"s"(base),"s"(to+1024u),"v"(at+xoff[2]) : "memory");
+          }
+        else
+          {
+            held[0]=*reinterpret_cast<const LooseHalf *>(base+at+xoff[0]);
+            held[1]=*reinterpret_cast<const LooseHalf *>(base+at+xoff[2]);
+          }
       }
     else
       {
@@ -1013,32 +1057,36 @@ void morph_strips_kernel(StripsArgs sargs)
         for (int j=0; j < SX; j++)
 #pragma unroll
           for (int w=0; w < NW; w++)
-            out[j >> 1][(j & 1)*NW+w]=*reinterpret_cast<const uint32_t *>(row+xoff[j]+4*w);
+            held[j >> 1][(j & 1)*NW+w]=*reinterpret_cast<const uint32_t *>(base+at+xoff[j]+4*w);
       }
   };
-  auto tile_at=[&](int row,int half) -> Half * { return tile+(size_t) (row*2+half)*64+lane; };
+  auto commit_row=[&](int row,const Half (&held)[2])
+  {
+    if ((C != 4) || !inside)
+      {
+        *ring_at(row,0)=held[0];
+        *ring_at(row,1)=held[1];
+      }
+  };
+  auto wrapped=[&](int row) { return row >= R ? row-R : row; };
 
-  // tile row q of step s is image row s*TH+cy-vmax+q
+  // tile row q of step s is image row s*TH+cy-vmax+q and ring row (origin+q) mod R, `origin`
+  // advancing by TH a step
+  int origin=0;
   {
     const int sy0=step_begin*TH+args.cy-vmax;
-    for (int q=wave; q < halo; q+=NWAVES)
+    for (int q=wave; q < halo+TH; q+=NWAVES)
       {
-        Half g[2];
-        load_row(sy0+q,g);
-        *tile_at(q,0)=g[0];
-        *tile_at(q,1)=g[1];
+        Half held[2];
+        fetch_row(sy0+q,q,held);
+        commit_row(q,held);
       }
   }
-  Half pre[SY][2];                             // the wave's share of the TH new rows of a step
-  auto prefetch=[&](int step)
-  {
-    const int sy0=step*TH+args.cy-vmax+halo;
-#pragma unroll
-    for (int k=0; k < SY; k++)
-      load_row(sy0+wave+NWAVES*k,pre[k]);
-  };
-  prefetch(step_begin);
-
+  Half held[SY][2];                            // the new rows of the next step, frame-edge lanes
+  // lane l keeps level l's reach and widening (a v_readlane per level instead of a load from the
+  // kernel arguments, whose latency nothing hides)
+  const int lane_reach=lane < args.nlevels ? (int) args.reach[lane] : 0;
+  const int lane_widen=lane < args.nlevels ? (int) args.widen[lane] : 0;
   const int u0=SX*lane-hmax;                   // first of the lane's columns within the valid span
   const bool centred=(args.cx == 0) && (args.cy == 0);
   bool ok[SX];
@@ -1050,89 +1098,163 @@ void morph_strips_kernel(StripsArgs sargs)
       all=all && ok[j];
     }
   unsigned changed=0;
-  for (int step=step_begin; step < step_end; step++)
-    {
+  // the results of a step are stored at the beginning of the next one: the s_waitcnt vmcnt(0) that
+  // ends a step (the fetched rows are in LDS) would otherwise wait for the stores just issued
+  uint32_t result[SY][WPR];
+  int result_by=-1;
+  auto store_results=[&]()
+  {
+    if (result_by < 0)
+      return;
 #pragma unroll
-      for (int k=0; k < SY; k++)
-        {
-          *tile_at(halo+wave+NWAVES*k,0)=pre[k][0];
-          *tile_at(halo+wave+NWAVES*k,1)=pre[k][1];
-        }
-      __syncthreads();
-      if (step+1 < step_end)
-        prefetch(step+1);
-
-      // ---- the wave's SY output rows: tile rows wave*SY+vmax+i
-      const int by=step*TH;
-      const int centre_row=wave*SY+vmax;
-      uint32_t column[SY][WPR],spread[SY][WPR];    // C and S of the header above morph_rects_kernel
+    for (int i=0; i < SY; i++)
+      {
+        const int y=result_by+wave*SY+i;
+        if (y >= H)
+          break;
+        unsigned char *out=reinterpret_cast<unsigned char *>(args.dst)+(unsigned) y*row_bytes;
+        if (all)
+          {
+            Half lo,hi;
 #pragma unroll
-      for (int i=0; i < SY; i++)
-        {
-          const Half a=*tile_at(centre_row+i,0),b=*tile_at(centre_row+i,1);
+            for (int p=0; p < HW; p++)
+              {
+                lo[p]=result[i][p];
+                hi[p]=result[i][HW+p];
+              }
+            unsigned char *at=out+(unsigned) (bx+u0)*(unsigned) (C*sizeof(uint16_t));
+            *reinterpret_cast<LooseHalf *>(at)=lo;
+            *reinterpret_cast<LooseHalf *>(at+sizeof(Half))=hi;
+          }
+        else
+          {
 #pragma unroll
-          for (int p=0; p < HW; p++)
-            {
-              column[i][p]=a[p];
-              column[i][HW+p]=b[p];
-            }
-#pragma unroll
-          for (int p=0; p < WPR; p++)
-            spread[i][p]=DILATE ? 0u : 0xffffffffu;
-        }
-      int folded=0;                                // rows +-1..folded are in `column`
-      for (int l=args.nlevels-1; l >= 0; l--)
-        {
-          const int reach=(int) args.reach[l];
-          for (int k=folded+1; k <= reach; k++)
-            {
-              // rows i-k, then rows i+k (one side at a time: 16 registers a row quad less)
-#pragma unroll
-              for (int side=-1; side <= 1; side+=2)
-                {
-                  Half far[SY][2];
-#pragma unroll
-                  for (int i=0; i < SY; i++)
-                    {
-                      far[i][0]=*tile_at(centre_row+i+side*k,0);
-                      far[i][1]=*tile_at(centre_row+i+side*k,1);
-                    }
-#pragma unroll
-                  for (int i=0; i < SY; i++)
-#pragma unroll
-                    for (int p=0; p < WPR; p++)
-                      column[i][p]=pk_pick<DILATE>(column[i][p],far[i][p/HW][p%HW]);
-                }
-            }
-          folded=reach > folded ? reach : folded;
-#pragma unroll
-          for (int i=0; i < SY; i++)
-#pragma unroll
-            for (int p=0; p < WPR; p++)
-              spread[i][p]=pk_pick<DILATE>(spread[i][p],column[i][p]);
-          const int widen=(int) args.widen[l];
-          for (int stride=0; stride < widen; stride++)
-            {
-              // Row(1) over the lane's columns a b c d and the neighbours' d' (left) and a' (right):
-              //   a <- d' v (a v b),  b <- (a v b) v c,  c <- b v (c v d),  d <- (c v d) v a'
-#pragma unroll
-              for (int i=0; i < SY; i++)
+            for (int j=0; j < SX; j++)
+              if (ok[j])
 #pragma unroll
                 for (int w=0; w < NW; w++)
-                  {
-                    const uint32_t a=spread[i][w],b=spread[i][NW+w],c=spread[i][2*NW+w],d=spread[i][3*NW+w];
-                    // wave_shr:1 — lane n reads lane n-1 (0x138); wave_shl:1 — lane n reads lane n+1 (0x130)
-                    const uint32_t left=(uint32_t) __builtin_amdgcn_mov_dpp((int) d,0x138,0xf,0xf,true);
-                    const uint32_t right=(uint32_t) __builtin_amdgcn_mov_dpp((int) a,0x130,0xf,0xf,true);
-                    const uint32_t ab=pk_pick<DILATE>(a,b),cd=pk_pick<DILATE>(c,d);
-                    spread[i][w]=pk_pick<DILATE>(left,ab);
-                    spread[i][NW+w]=pk_pick<DILATE>(ab,c);
-                    spread[i][2*NW+w]=pk_pick<DILATE>(b,cd);
-                    spread[i][3*NW+w]=pk_pick<DILATE>(cd,right);
-                  }
+                  *reinterpret_cast<uint32_t *>(out+(unsigned) (bx+u0+j)*(unsigned) (C*sizeof(uint16_t))+4*w)=result[i][j*NW+w];
+          }
+      }
+  };
+  for (int step=step_begin; step < step_end; step++)
+    {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the rows fetched for this step are in LDS
+      __syncthreads();                                     // ... everybody's, and the previous tile is done with
+      if (step+1 < step_end)
+        {
+          // the TH new rows of step+1: tile rows halo+TH .. halo+2*TH-1 of this step
+          const int sy0=(step+1)*TH+args.cy-vmax+halo;
+#pragma unroll
+          for (int j=0; j < SY; j++)
+            fetch_row(sy0+wave+NWAVES*j,wrapped(wrapped(origin+TH)+halo+wave+NWAVES*j),held[j]);
+        }
+
+      // ---- the wave's two output rows: tile rows centre, centre+1
+      const int by=step*TH;
+      const int centre=origin+vmax+wave*SY;      // < 2R: wrapped() per access
+      uint32_t column[SY][WPR],spread[SY][WPR];    // C and S of the header above morph_rects_kernel
+      // rows centre-k (`up`) and centre+1+k (`down`) of three successive depths k: the previous
+      // one, the one being folded in and the next one, whose reads are already under way;
+      // depth 0: the output rows themselves
+      Half up[3][2],down[3][2];
+      auto read_depth=[&](int k,Half (&to_up)[2],Half (&to_down)[2])
+      {
+        const int above=wrapped(centre-k),below=wrapped(wrapped(centre+1+k));     // centre-k >= origin >= 0
+        to_up[0]=*ring_at(above,0);
+        to_up[1]=*ring_at(above,1);
+        to_down[0]=*ring_at(below,0);
+        to_down[1]=*ring_at(below,1);
+      };
+      read_depth(0,up[0],down[0]);
+      if (vmax >= 1)
+        read_depth(1,up[1],down[1]);
+#pragma unroll
+      for (int p=0; p < WPR; p++)
+        {
+          column[0][p]=up[0][p/HW][p%HW];
+          column[1][p]=down[0][p/HW][p%HW];
+          spread[0][p]=DILATE ? 0u : 0xffffffffu;
+          spread[1][p]=DILATE ? 0u : 0xffffffffu;
+        }
+      // depth k: row 0 takes centre-k (new `up`) and centre+k (previous `down`), row 1 takes
+      // centre+1-k (previous `up`) and centre+1+k (new `down`)
+      auto fold=[&](const Half (&new_up)[2],const Half (&new_down)[2],const Half (&old_up)[2],const Half (&old_down)[2])
+      {
+#pragma unroll
+        for (int p=0; p < WPR; p++)
+          {
+            column[0][p]=pk_pick<DILATE>(pk_pick<DILATE>(column[0][p],new_up[p/HW][p%HW]),old_down[p/HW][p%HW]);
+            column[1][p]=pk_pick<DILATE>(pk_pick<DILATE>(column[1][p],old_up[p/HW][p%HW]),new_down[p/HW][p%HW]);
+          }
+      };
+      // every level whose reach the fold depth has arrived at: merge the column windows into the
+      // spread and widen it (the levels' reaches grow as l falls)
+      int level=args.nlevels-1;
+      auto settle=[&](int depth)
+      {
+        while ((level >= 0) && (__builtin_amdgcn_readlane(lane_reach,level) <= depth))
+          {
+#pragma unroll
+            for (int i=0; i < SY; i++)
+#pragma unroll
+              for (int p=0; p < WPR; p++)
+                spread[i][p]=pk_pick<DILATE>(spread[i][p],column[i][p]);
+            const int widen=__builtin_amdgcn_readlane(lane_widen,level);
+            for (int stride=0; stride < widen; stride++)
+              {
+                // Row(1) over the lane's columns a b c d and the neighbours' d' (left) and a' (right):
+                //   a <- d' v (a v b),  b <- (a v b) v c,  c <- b v (c v d),  d <- (c v d) v a'
+#pragma unroll
+                for (int i=0; i < SY; i++)
+#pragma unroll
+                  for (int w=0; w < NW; w++)
+                    {
+                      const uint32_t a=spread[i][w],b=spread[i][NW+w],c=spread[i][2*NW+w],d=spread[i][3*NW+w];
+                      // wave_shr:1 — lane n reads lane n-1 (0x138); wave_shl:1 — lane n reads lane n+1 (0x130)
+                      const uint32_t left=(uint32_t) __builtin_amdgcn_mov_dpp((int) d,0x138,0xf,0xf,true);
+                      const uint32_t right=(uint32_t) __builtin_amdgcn_mov_dpp((int) a,0x130,0xf,0xf,true);
+                      const uint32_t ab=pk_pick<DILATE>(a,b),cd=pk_pick<DILATE>(c,d);
+                      spread[i][w]=pk_pick<DILATE>(left,ab);
+                      spread[i][NW+w]=pk_pick<DILATE>(ab,c);
+                      spread[i][2*NW+w]=pk_pick<DILATE>(b,cd);
+                      spread[i][3*NW+w]=pk_pick<DILATE>(cd,right);
+                    }
+              }
+            level--;
+          }
+      };
+      // the fold depths in threes, so that which register set holds which depth's rows is known at
+      // compile time
+      settle(0);
+      for (int k=1; k <= vmax; k+=3)
+        {
+          // the previous step's rows leave here, apart from the burst of fetches at the step's start
+          // (measured: 2.25 -> 2.10 ms against storing them first thing)
+          if (k == kStoreDepth)
+            store_results();
+          if (k+1 <= vmax)
+            read_depth(k+1,up[2],down[2]);
+          fold(up[1],down[1],up[0],down[0]);
+          settle(k);
+          if (k+1 <= vmax)
+            {
+              if (k+2 <= vmax)
+                read_depth(k+2,up[0],down[0]);
+              fold(up[2],down[2],up[1],down[1]);
+              settle(k+1);
+            }
+          if (k+2 <= vmax)
+            {
+              if (k+3 <= vmax)
+                read_depth(k+3,up[1],down[1]);
+              fold(up[0],down[0],up[2],down[2]);
+              settle(k+2);
             }
         }
 
+      if (vmax < kStoreDepth)
+        store_results();
       // ---- copy out: morphology.c:3180-3196 (channels without the update trait keep the source
       // value; `changed` counts the updated samples that differ from the source)
 #pragma unroll
@@ -1141,14 +1263,12 @@ void morph_strips_kernel(StripsArgs sargs)
           const int y=by+wave*SY+i;
           if (y >= H)
             break;
-          unsigned char *out=reinterpret_cast<unsigned char *>(args.dst)+(unsigned) y*row_bytes;
-          uint32_t result[WPR];
           if (DILATE && (args.copy_mask == 0u) && (args.changed == nullptr))
             {
               // every channel updated, nobody counts: the maxima are the result
 #pragma unroll
               for (int p=0; p < WPR; p++)
-                result[p]=spread[i][p];
+                result[i][p]=spread[i][p];
             }
           else
             {
@@ -1156,7 +1276,7 @@ void morph_strips_kernel(StripsArgs sargs)
               if (centred)
                 {
                   // the output pixel is the centre of its own window
-                  const Half a=*tile_at(centre_row+i,0),b=*tile_at(centre_row+i,1);
+                  const Half a=*ring_at(wrapped(centre+i),0),b=*ring_at(wrapped(centre+i),1);
 #pragma unroll
                   for (int p=0; p < HW; p++)
                     {
@@ -1182,49 +1302,24 @@ void morph_strips_kernel(StripsArgs sargs)
                   uint32_t keep=0u;
                   keep|=((args.copy_mask >> c0) & 1u) != 0u ? 0x0000ffffu : 0u;
                   keep|=((args.copy_mask >> (c0+1)) & 1u) != 0u ? 0xffff0000u : 0u;
-                  result[p]=(original[p] & keep) | (value & ~keep);
+                  result[i][p]=(original[p] & keep) | (value & ~keep);
                   const uint32_t differs=(value ^ original[p]) & ~keep;
                   if (ok[p/NW])
                     changed+=((differs & 0xffffu) != 0u ? 1u : 0u)+((differs >> 16) != 0u ? 1u : 0u);
                 }
             }
-          if (all)
-            {
-              Half lo,hi;
-#pragma unroll
-              for (int p=0; p < HW; p++)
-                {
-                  lo[p]=result[p];
-                  hi[p]=result[HW+p];
-                }
-              unsigned char *at=out+(unsigned) (bx+u0)*(unsigned) (C*sizeof(uint16_t));
-              *reinterpret_cast<LooseHalf *>(at)=lo;
-              *reinterpret_cast<LooseHalf *>(at+sizeof(Half))=hi;
-            }
-          else
-            {
-#pragma unroll
-              for (int j=0; j < SX; j++)
-                if (ok[j])
-#pragma unroll
-                  for (int w=0; w < NW; w++)
-                    *reinterpret_cast<uint32_t *>(out+(unsigned) (bx+u0+j)*(unsigned) (C*sizeof(uint16_t))+4*w)=result[j*NW+w];
-            }
         }
-      __syncthreads();                             // every read of this tile is done
+      result_by=by;
       if (step+1 < step_end)
         {
-          // the 2*vmax rows the next tile shares with this one move to its top (TH >= 2*vmax: the
-          // two ranges are disjoint, and the rows written are read by nobody else)
-          for (int q=wave; q < halo; q+=NWAVES)
-            {
-              const Half a=*tile_at(TH+q,0),b=*tile_at(TH+q,1);
-              *tile_at(q,0)=a;
-              *tile_at(q,1)=b;
-            }
-          __syncthreads();                         // ... before the new rows overwrite their source
+          // rows that came through registers (nobody reads these ring rows during this step)
+#pragma unroll
+          for (int j=0; j < SY; j++)
+            commit_row(wrapped(wrapped(origin+TH)+halo+wave+NWAVES*j),held[j]);
         }
+      origin=wrapped(origin+TH);
     }
+  store_results();
   if (args.changed != nullptr)
     {
       changed=wave_sum(changed);
@@ -1234,14 +1329,13 @@ void morph_strips_kernel(StripsArgs sargs)
 }
 
 template<int C,bool DILATE>
-static MhStatus launch_strips_typed(const StripsArgs &args,unsigned items,size_t lds,hipStream_t stream)
+static MhStatus launch_strips_typed(const StripsArgs &args,size_t lds,hipStream_t stream)
 {
-  constexpr int SY=4,WAVES=12;
+  constexpr int WAVES=12;
   const dim3 grid(8u*(unsigned) args.items_per_xcd),block(64*WAVES);
-  (void) items;
-  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&morph_strips_kernel<C,DILATE,SY,WAVES>),
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&morph_strips_kernel<C,DILATE,WAVES>),
     hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
-  hipLaunchKernelGGL((morph_strips_kernel<C,DILATE,SY,WAVES>),grid,block,lds,stream,args);
+  hipLaunchKernelGGL((morph_strips_kernel<C,DILATE,WAVES>),grid,block,lds,stream,args);
   MH_HIP(hipGetLastError());
   return MH_OK;
 }
@@ -1302,12 +1396,15 @@ static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std:
   a.copy_mask=roles.copy_mask;
   a.changed=changed;
   {
-    // frames of several strips by several steps: the walk down 256-column strips
-    constexpr int kStripRows=48;
-    const size_t strip_lds=(size_t) (kStripRows+2*vmax)*2u*row_lds;
+    // frames of several strips by several steps: the walk down 256-column strips.  Opt-in
+    // (MAGICKHIP_STRIPS=1): on MI355X it reads the frame 1.13 times instead of 1.31 but takes
+    // 2.10 ms where the tile kernel takes 1.95 (16384^2 RGBA, Disk:15) — three waves a SIMD hide
+    // less than the tile kernel's six (profiles/r3_notes/dilate_experiments.txt).
+    constexpr int kStripRows=24;
+    const size_t strip_lds=(size_t) (2*kStripRows+2*vmax)*2u*row_lds;
     const int strip_w=256-2*hmax;
-    if ((2*vmax <= kStripRows) && (strip_lds <= 160u*1024u) && ((int) src.columns >= 2*strip_w) &&
-        ((int) src.rows >= 4*kStripRows) && (getenv("MAGICKHIP_NO_STRIPS") == nullptr))
+    if ((strip_lds <= 160u*1024u) && ((int) src.columns >= 2*strip_w) &&
+        ((int) src.rows >= 4*kStripRows) && (getenv("MAGICKHIP_STRIPS") != nullptr))
       {
         StripsArgs sa;
         sa.r=a;
@@ -1321,7 +1418,7 @@ static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std:
           {
             const int steps=(sa.r.tiles_y+cuts-1)/cuts;
             const int rounds=(sa.r.tiles_x*((sa.r.tiles_y+steps-1)/steps)+255)/256;
-            const double cost=(double) rounds*((double) steps*kStripRows+2.0*vmax);
+            const double cost=(double) rounds*((double) (steps+1)*kStripRows+2.0*vmax);
             if (cost < best_cost-1.0e-9)
               {
                 best_cost=cost;
@@ -1335,11 +1432,10 @@ static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std:
         sa.items_per_xcd=(sa.r.tiles_x*sa.segments+7)/8;
         sa.r.tiles_per_xcd=sa.items_per_xcd;
         ProfileScope prof("morph_rects",src.stream);
-        const unsigned items=(unsigned) (sa.r.tiles_x*sa.segments);
         if (src.channels == 4)
-          MH_TRY((dilate ? launch_strips_typed<4,true>(sa,items,strip_lds,src.stream) : launch_strips_typed<4,false>(sa,items,strip_lds,src.stream)));
+          MH_TRY((dilate ? launch_strips_typed<4,true>(sa,strip_lds,src.stream) : launch_strips_typed<4,false>(sa,strip_lds,src.stream)));
         else
-          MH_TRY((dilate ? launch_strips_typed<2,true>(sa,items,strip_lds,src.stream) : launch_strips_typed<2,false>(sa,items,strip_lds,src.stream)));
+          MH_TRY((dilate ? launch_strips_typed<2,true>(sa,strip_lds,src.stream) : launch_strips_typed<2,false>(sa,strip_lds,src.stream)));
         *handled=true;
         return MH_OK;
       }

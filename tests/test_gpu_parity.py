@@ -638,11 +638,13 @@ def test_symmetric_convex_kernels_over_several_tiles(im, refmod, method, kernel,
     ("Dilate", "Rectangle:9x5+2+1"), ("Erode", "Diamond:11"), ("Dilate", "Rectangle:1x9"), ("Erode", "Rectangle:13x1"),
 ])
 def test_symmetric_convex_kernels_down_a_strip(im, refmod, method, kernel, channels, cuts, monkeypatch):
-    """The same union-of-rectangles evaluation as a walk down 256-column strips (morph_strips_kernel:
-    four columns per lane, the rows two successive tiles share kept in LDS, the new rows prefetched
-    into registers) on a frame of three ragged strips by six ragged steps; walks of six, three and
-    one step (MAGICKHIP_STRIP_CUTS).  Bit-identical to the reference and to the tile kernel."""
+    """The same union-of-rectangles evaluation as a walk down 256-column strips (morph_strips_kernel,
+    opt-in with MAGICKHIP_STRIPS=1: four columns per lane, a ring of rows in LDS that
+    global_load_lds_dwordx4 refills while the tile is evaluated) on a frame of three ragged strips
+    by twelve ragged steps; walks of twelve, six and one step (MAGICKHIP_STRIP_CUTS).
+    Bit-identical to the reference and to the tile kernel."""
     import bench
+    monkeypatch.setenv("MAGICKHIP_STRIPS", "1")
     if cuts is not None:
         monkeypatch.setenv("MAGICKHIP_STRIP_CUTS", str(cuts))
     px = make_pixels(271, 530, channels, Q16, seed=len(kernel) + channels)
@@ -652,7 +654,7 @@ def test_symmetric_convex_kernels_down_a_strip(im, refmod, method, kernel, chann
         im, lambda: holder.update(out=im.morphology_image(dev, method, 1, kernel)), 1))
     assert launched == {"morph_rects"}, launched
     got = holder["out"].numpy()
-    monkeypatch.setenv("MAGICKHIP_NO_STRIPS", "1")
+    monkeypatch.delenv("MAGICKHIP_STRIPS")
     tiles = im.morphology_image(dev, method, 1, kernel).numpy()
     assert np.array_equal(got, tiles), "%s %s c%d: strip walk != tile kernel at %s" % (
         method, kernel, channels, np.argwhere(got != tiles)[:4].tolist())
@@ -663,6 +665,7 @@ def test_symmetric_convex_kernels_down_a_strip(im, refmod, method, kernel, chann
 def test_strip_walk_channel_mask_and_change_count(im, refmod, monkeypatch):
     """morph_strips_kernel's general epilogue: channels without the update trait, the `changed`
     count that ends an unbounded iteration, and a kernel whose origin is off centre."""
+    monkeypatch.setenv("MAGICKHIP_STRIPS", "1")
     monkeypatch.setenv("MAGICKHIP_STRIP_CUTS", "2")
     px = make_pixels(200, 470, 4, Q16, seed=78)
     dev = im.Image(to_device(px), copy_channels=(1, 3))

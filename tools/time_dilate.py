@@ -1,5 +1,5 @@
-"""C5 Dilate Disk:15 on 16384^2 RGBA Q16: the union-of-rectangles strip walk against the
-tile kernel (MAGICKHIP_NO_STRIPS=1) and the
+"""C5 Dilate Disk:15 on 16384^2 RGBA Q16: the union-of-rectangles tile kernel against the
+strip walk (MAGICKHIP_STRIPS=1) and the
 plane-per-width kernel (MAGICKHIP_NO_RECTS=1); same bits, compared."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,9 +15,9 @@ img = im.Image(a)
 hold = {}
 for kernel in kernels:
     results = []
-    for label, env in (("strips", {}), ("tiles", {"MAGICKHIP_NO_STRIPS": "1"}), ("planes", {"MAGICKHIP_NO_RECTS": "1"})):
+    for label, env in (("strips", {"MAGICKHIP_STRIPS": "1"}), ("tiles", {}), ("planes", {"MAGICKHIP_NO_RECTS": "1"})):
         os.environ.pop("MAGICKHIP_NO_RECTS", None)
-        os.environ.pop("MAGICKHIP_NO_STRIPS", None)
+        os.environ.pop("MAGICKHIP_STRIPS", None)
         os.environ.update(env)
 
         def f():
