@@ -478,13 +478,27 @@ MH_API MhStatus MagickHipTransformColorspaceContrastStretchImage(MhImage *image,
       InPlace io;
       MH_TRY(io.open(image));
       const View &view=io.img.view;
+      MhImage lab=*image;
+      lab.colorspace=(uint32_t) MH_COLORSPACE_LAB;
+      bool fused=false;
+      {
+        // three launches: convert + bin, levels, map (pointwise.hip)
+        uint32_t update=0;
+        for (uint32_t c=0; c < image->number_channels; c++)
+          if ((image->channel_traits[c] & MH_TRAIT_UPDATE) != 0)
+            update|=1u<<c;
+        MH_TRY(launch_lab_fast_contrast_stretch(view,&lab,black_point,
+          (double) image->columns*(double) image->rows-white_point,update,&fused));
+        if (fused)
+          {
+            image->colorspace=(uint32_t) MH_COLORSPACE_LAB;
+            return io.img.commit();
+          }
+      }
       const size_t n=(size_t) MH_HISTOGRAM_BINS*(size_t) view.channels;
       Temp hist;
       MH_TRY(hist.alloc(view.device,n*sizeof(unsigned long long),view.stream));
       MH_HIP(hipMemsetAsync(hist.ptr,0,n*sizeof(unsigned long long),view.stream));
-      MhImage lab=*image;
-      lab.colorspace=(uint32_t) MH_COLORSPACE_LAB;
-      bool fused=false;
       MH_TRY(launch_lab_fast_with_histogram(view,&lab,hist.as<unsigned long long>(),&fused));
       if (fused)
         {

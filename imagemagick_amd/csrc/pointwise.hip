@@ -347,12 +347,37 @@ static __device__ __forceinline__ float lab_f_fast(float t)
   return t > (float) MH_CIE_EPSILON ? root : (((float) MH_CIE_K)*t+16.0f)*(1.0f/116.0f);
 }
 
-static __device__ __forceinline__ uint2 srgb_to_lab_fast_pixel(uint2 px)
+// The decode as a table in LDS: 2048 linear pieces of the curve, (value, rise) per piece.  The
+// curve's second derivative is at most 3.1, so a piece is within (1/2048)^2/8*3.1 = 9e-8 of it —
+// a tenth of the hardware log2/exp2 route's error — for a conversion, a multiply, a fraction, one
+// ds_read_b64 and one FMA per sample instead of two quarter-rate transcendentals and six other
+// operations.  Both FAST kernels decode through it (the one-call Lab + ContrastStretch leaves the
+// frame TransformImageColorspace leaves, bit for bit).
+constexpr int kDecodePieces=2048;
+static __device__ __forceinline__ void build_decode_table(float2 *table)
 {
-  constexpr float qs=1.0f/65535.0f;
-  const float r=srgb_decode_fast((float) (px.x & 0xffffu)*qs);
-  const float g=srgb_decode_fast((float) (px.x >> 16)*qs);
-  const float b=srgb_decode_fast((float) (px.y & 0xffffu)*qs);
+  for (int i=(int) threadIdx.x; i < kDecodePieces; i+=(int) blockDim.x)
+    {
+      const float here=srgb_decode_fast((float) i*(1.0f/kDecodePieces));
+      const float next=srgb_decode_fast((float) (i+1)*(1.0f/kDecodePieces));
+      table[i]=make_float2(here,next-here);
+    }
+}
+
+static __device__ __forceinline__ float srgb_decode_table(const float2 *table,unsigned quantum)
+{
+  // quantum/65535 in pieces; 65535 is the END of the last piece (fraction 1)
+  const float at=(float) quantum*((float) kDecodePieces/65535.0f);
+  const float whole=__builtin_fminf(__builtin_floorf(at),(float) (kDecodePieces-1));
+  const float2 piece=table[(int) whole];
+  return __builtin_fmaf(at-whole,piece.y,piece.x);
+}
+
+static __device__ __forceinline__ uint2 srgb_to_lab_fast_pixel(uint2 px,const float2 *decode)
+{
+  const float r=srgb_decode_table(decode,px.x & 0xffffu);
+  const float g=srgb_decode_table(decode,px.x >> 16);
+  const float b=srgb_decode_table(decode,px.y & 0xffffu);
   const float X=0.4123955889674142161f*r+0.3575834307637148171f*g+0.1804926473817015735f*b;
   const float Y=0.2125862307855955516f*r+0.7151703037034108499f*g+0.07220049864333622685f*b;
   const float Z=0.01929721549174694484f*r+0.1191838645808485318f*g+0.9504971251315797660f*b;
@@ -367,9 +392,12 @@ static __device__ __forceinline__ uint2 srgb_to_lab_fast_pixel(uint2 px)
   return make_uint2((unsigned) la[0] | ((unsigned) la[1] << 16),(unsigned) b0[0] | (px.y & 0xffff0000u));
 }
 
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(1024)
 void colorspace_lab_fast_kernel(uint4 *__restrict__ pairs,size_t npairs,uint2 *__restrict__ last)
 {
+  __shared__ float2 decode[kDecodePieces];
+  build_decode_table(decode);
+  __syncthreads();
   // two 8-byte pixels per lane and load; `last` is the odd pixel of the frame, if any
   constexpr int BATCH=4;
   const size_t stride=(size_t) gridDim.x*blockDim.x*BATCH;
@@ -385,15 +413,15 @@ void colorspace_lab_fast_kernel(uint4 *__restrict__ pairs,size_t npairs,uint2 *_
 #pragma unroll
       for (int k=0; k < BATCH; k++)
         {
-          const uint2 first=srgb_to_lab_fast_pixel(make_uint2(v[k].x,v[k].y));
-          const uint2 second=srgb_to_lab_fast_pixel(make_uint2(v[k].z,v[k].w));
+          const uint2 first=srgb_to_lab_fast_pixel(make_uint2(v[k].x,v[k].y),decode);
+          const uint2 second=srgb_to_lab_fast_pixel(make_uint2(v[k].z,v[k].w),decode);
           const size_t i=i0+(size_t) k*blockDim.x;
           if (i < npairs)
             pairs[i]=make_uint4(first.x,first.y,second.x,second.y);
         }
     }
   if ((last != nullptr) && (blockIdx.x == 0) && (threadIdx.x == 0))
-    *last=srgb_to_lab_fast_pixel(*last);
+    *last=srgb_to_lab_fast_pixel(*last,decode);
 }
 
 template<typename Q,int C,int OP>
@@ -551,14 +579,16 @@ static MhStatus colorspace_step(const View &img,int op)
       uint2 *last=(n & 1) != 0 ? static_cast<uint2 *>(img.pixels)+(n-1) : nullptr;
       if (npairs == 0)
         {
-          hipLaunchKernelGGL(colorspace_lab_fast_kernel,dim3(1),dim3(256),0,img.stream,
+          hipLaunchKernelGGL(colorspace_lab_fast_kernel,dim3(1),dim3(1024),0,img.stream,
             static_cast<uint4 *>(img.pixels),(size_t) 0,last);
           MH_HIP(hipGetLastError());
           return MH_OK;
         }
       ProfileScope prof("colorspace",img.stream);
-      hipLaunchKernelGGL(colorspace_lab_fast_kernel,dim3(stream_grid((npairs+3)/4)),dim3(256),0,img.stream,
-        static_cast<uint4 *>(img.pixels),npairs,last);
+      // persistent workgroups, two per CU: each builds the decode table once
+      const size_t wanted=(npairs+4095)/4096,most=2*(size_t) compute_units(img.device);
+      hipLaunchKernelGGL(colorspace_lab_fast_kernel,dim3((unsigned) (wanted < most ? wanted : most)),dim3(1024),0,
+        img.stream,static_cast<uint4 *>(img.pixels),npairs,last);
       MH_HIP(hipGetLastError());
       return MH_OK;
     }
@@ -1125,15 +1155,33 @@ static MhStatus histogram_intensity_packed(const View &src,const IntensityParams
 // (config C4) at one frame read and one frame write.  Converts as colorspace_lab_fast_kernel
 // and bins the values it stores as histogram_packed_kernel does, so the table is exactly the
 // histogram of the frame it leaves behind.
+__device__ __forceinline__ unsigned long long lut_block_sum(unsigned long long v,unsigned long long *shared16);
+__device__ __forceinline__ double lut_scale_map_to_quantum(double value,int is_u16);
+
+// What the levels kernels below need besides the slabs: a workgroup's pixels beyond the 16-bit
+// counters' capacity as a list of bins (count first).
+constexpr int kExtraPitch=264;                 // 1 + the 258 pixels a share may exceed the capacity by, padded
+struct StretchScratch
+{
+  int black,white;                             // the levels, enhance.c:1652-1678
+  unsigned apply;                              // black != white: the map is applied (enhance.c:1690)
+  unsigned pad;
+};
+
 template<bool PLAIN>
 __global__ __launch_bounds__(1024)
 void lab_histogram_fast_kernel(uint16_t *pixels,size_t npixels,IntensityParams ip,unsigned *slabs,
-  unsigned long long *counts)
+  unsigned long long *counts,unsigned short *extras)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ unsigned extra_count;
   unsigned *table=reinterpret_cast<unsigned *>(smem_raw);
+  float2 *decode=reinterpret_cast<float2 *>(smem_raw+32768*sizeof(unsigned));
   for (int i=(int) threadIdx.x; i < 32768; i+=1024)
     table[i]=0u;
+  build_decode_table(decode);
+  if (threadIdx.x == 0)
+    extra_count=0u;
   __syncthreads();
   size_t per=(npixels+gridDim.x-1)/gridDim.x;
   per+=per & 1;
@@ -1168,8 +1216,8 @@ void lab_histogram_fast_kernel(uint16_t *pixels,size_t npixels,IntensityParams i
       for (int k=0; k < BATCH; k++)
         if (i0+(size_t) 1024*k < npairs)
           {
-            const uint2 first=srgb_to_lab_fast_pixel(make_uint2(v[k].x,v[k].y));
-            const uint2 second=srgb_to_lab_fast_pixel(make_uint2(v[k].z,v[k].w));
+            const uint2 first=srgb_to_lab_fast_pixel(make_uint2(v[k].x,v[k].y),decode);
+            const uint2 second=srgb_to_lab_fast_pixel(make_uint2(v[k].z,v[k].w),decode);
             pairs[i0+(size_t) 1024*k]=make_uint4(first.x,first.y,second.x,second.y);
             count(first);
             count(second);
@@ -1179,19 +1227,262 @@ void lab_histogram_fast_kernel(uint16_t *pixels,size_t npixels,IntensityParams i
   uint2 *single=reinterpret_cast<uint2 *>(pixels);
   for (size_t i=begin+2*npairs+threadIdx.x; i < end; i+=1024)
     {
-      const uint2 lab=srgb_to_lab_fast_pixel(single[i]);
+      const uint2 lab=srgb_to_lab_fast_pixel(single[i],decode);
       single[i]=lab;
       if (i < packed_end)
         count(lab);
       else
         {
           const unsigned bin=bin_of(lab);
-          for (int c=0; c < 4; c++)
-            atomicAdd(counts+(size_t) bin*4+c,1ull);
+          if (extras != nullptr)
+            extras[(size_t) blockIdx.x*kExtraPitch+1u+atomicAdd(&extra_count,1u)]=(unsigned short) bin;
+          else
+            for (int c=0; c < 4; c++)
+              atomicAdd(counts+(size_t) bin*4+c,1ull);
         }
     }
   __syncthreads();
+  if ((extras != nullptr) && (threadIdx.x == 0))
+    extras[(size_t) blockIdx.x*kExtraPitch]=(unsigned short) extra_count;
   packed_table_to_slab(table,slabs);
+}
+
+// ContrastStretchImage's levels straight from the slabs, two small launches and no table of
+// 65536 x channels 64-bit counts: stretch_bins_kernel sums the slabs (as
+// histogram_packed_reduce_kernel) into 32-bit `bins` and leaves each workgroup's share (256 bins)
+// in `shares`; stretch_levels_kernel, ONE workgroup, adds the listed extra pixels and finds the
+// black and the white level (enhance.c:1652-1678: the first bin from below whose running count
+// exceeds black_point, the last bin from above whose count exceeds white_limit) by locating the
+// 1024-bin chunk from the 64 chunk sums and scanning it.  Intensity binning: all channels share
+// the histogram, hence the levels.  Replaces a 2 MB memset, the slab reduction and the three LUT
+// kernels; the map itself is evaluated by stretch_apply_kernel.  (One launch with a last-
+// workgroup-done ticket measured 32 us: every __threadfence() writes back an L2 full of the
+// frame the previous kernel stored.)
+__global__ __launch_bounds__(1024)
+void stretch_bins_kernel(const unsigned *slabs,int nblocks,unsigned *bins,unsigned long long *shares)
+{
+  // 256 bins = 32 groups of four packed words; thread (group, slice) sums every 32nd slab with
+  // 16-byte loads, all in flight at once
+  __shared__ unsigned partial[32][32][8];
+  __shared__ unsigned long long wave_sums[16];
+  {
+    const int group=(int) threadIdx.x & 31,slice=(int) threadIdx.x >> 5;
+    const uint4 *words=reinterpret_cast<const uint4 *>(slabs)+(size_t) blockIdx.x*32+group;
+    unsigned sum[8]={0u,0u,0u,0u,0u,0u,0u,0u};     // at most 65 534 per slab: 65 536 slabs fit 32 bits
+#pragma unroll 8
+    for (int b=slice; b < nblocks; b+=32)
+      {
+        const uint4 v=words[(size_t) b*8192];
+        sum[0]+=v.x & 0xffffu; sum[1]+=v.x >> 16;
+        sum[2]+=v.y & 0xffffu; sum[3]+=v.y >> 16;
+        sum[4]+=v.z & 0xffffu; sum[5]+=v.z >> 16;
+        sum[6]+=v.w & 0xffffu; sum[7]+=v.w >> 16;
+      }
+#pragma unroll
+    for (int k=0; k < 8; k++)
+      partial[slice][group][k]=sum[k];
+  }
+  __syncthreads();
+  unsigned long long mine=0ull;
+  if (threadIdx.x < 256u)
+    {
+      unsigned total=0u;
+#pragma unroll 8
+      for (int slice=0; slice < 32; slice++)
+        total+=partial[slice][threadIdx.x >> 3][threadIdx.x & 7u];
+      bins[blockIdx.x*256u+threadIdx.x]=total;
+      mine=total;
+    }
+  const unsigned long long share=lut_block_sum(mine,wave_sums);
+  if (threadIdx.x == 0)
+    shares[blockIdx.x]=share;
+}
+
+__global__ __launch_bounds__(1024)
+void stretch_levels_kernel(const unsigned *bins,const unsigned long long *shares,const unsigned short *extras,
+  int nblocks,StretchScratch *levels,double black_point,double white_limit)
+{
+  __shared__ unsigned long long chunk_s[64];
+  __shared__ unsigned long long wave_sums[16];
+  __shared__ unsigned low_s[1024],high_s[1024];    // the bins of the black and of the white chunk
+  __shared__ int found_s;
+  const int t=(int) threadIdx.x,lane=t & 63;
+  if (t < 64)
+    chunk_s[t]=shares[4*t]+shares[4*t+1]+shares[4*t+2]+shares[4*t+3];
+  __syncthreads();
+  // the pixels a share held beyond the packed counters' capacity (a thread per list: a couple of
+  // entries each unless the shares were ragged)
+  for (int w=t; w < nblocks; w+=1024)
+    {
+      const unsigned short *list=extras+(size_t) w*kExtraPitch;
+      const int listed=(int) list[0];
+      for (int i=1; i <= listed; i++)
+        atomicAdd(&chunk_s[list[i] >> 10],1ull);
+    }
+  __syncthreads();
+  // counts below each chunk (every wave computes them: 64 chunks, 64 lanes)
+  const unsigned long long chunk=chunk_s[lane];
+  unsigned long long inclusive=chunk;
+  for (int off=1; off < 64; off<<=1)
+    {
+      const unsigned long long up=__shfl_up(inclusive,off,64);
+      if (lane >= off)
+        inclusive+=up;
+    }
+  const unsigned long long total=__shfl(inclusive,63,64);
+  const unsigned long long below=inclusive-chunk;
+  // black lies in the first chunk whose inclusive running count exceeds black_point, white in the
+  // last chunk whose count from its first bin upwards exceeds white_limit
+  const unsigned long long low_hit=__ballot((double) inclusive > black_point);
+  const unsigned long long high_hit=__ballot((double) (total-below) > white_limit);
+  const int low_chunk=low_hit != 0ull ? __builtin_ctzll(low_hit) : -1;
+  const int high_chunk=high_hit != 0ull ? 63-__builtin_clzll(high_hit) : -1;
+  low_s[t]=low_chunk >= 0 ? bins[low_chunk*1024+t] : 0u;
+  high_s[t]=high_chunk >= 0 ? bins[high_chunk*1024+t] : 0u;
+  __syncthreads();
+  for (int w=t; w < nblocks; w+=1024)
+    {
+      const unsigned short *list=extras+(size_t) w*kExtraPitch;
+      const int listed=(int) list[0];
+      for (int i=1; i <= listed; i++)
+        {
+          const int b=(int) list[i];
+          if ((b >> 10) == low_chunk)
+            atomicAdd(&low_s[b & 1023],1u);
+          if ((b >> 10) == high_chunk)
+            atomicAdd(&high_s[b & 1023],1u);
+        }
+    }
+  __syncthreads();
+  // inclusive running count of a chunk's 1024 bins, one per thread
+  auto scan=[&](unsigned long long h,unsigned long long prefix) -> unsigned long long
+  {
+    unsigned long long cum=h;
+    for (int off=1; off < 64; off<<=1)
+      {
+        const unsigned long long up=__shfl_up(cum,off,64);
+        if (lane >= off)
+          cum+=up;
+      }
+    __syncthreads();
+    if (lane == 63)
+      wave_sums[t >> 6]=cum;
+    __syncthreads();
+    for (int w=0; w < (t >> 6); w++)
+      cum+=wave_sums[w];
+    return cum+prefix;
+  };
+  int black=65536;                                 // none: the reference's loop ends with j = 65536
+  if (low_chunk >= 0)
+    {
+      const unsigned long long cum=scan(low_s[t],__shfl(below,low_chunk,64));
+      if (t == 0)
+        found_s=65536;
+      __syncthreads();
+      if ((double) cum > black_point)
+        atomicMin(&found_s,low_chunk*1024+t);
+      __syncthreads();
+      black=found_s;
+      __syncthreads();
+    }
+  int white=0;                                     // none
+  if (high_chunk >= 0)
+    {
+      const unsigned long long h=high_s[t];
+      const unsigned long long cum=scan(h,__shfl(below,high_chunk,64));
+      if (t == 0)
+        found_s=0;
+      __syncthreads();
+      const int j=high_chunk*1024+t;
+      if ((j >= 1) && ((double) (total-(cum-h)) > white_limit))
+        atomicMax(&found_s,j);
+      __syncthreads();
+      white=found_s;
+    }
+  if (t == 0)
+    {
+      // black[i]=(Quantum) j, enhance.c:1668: a scan that found no bin above black_point ends with
+      // j = 65536, which the Q16 build stores as (unsigned short) 65536 = 0
+      const int black_i=black == 65536 ? 0 : black;
+      levels->black=black_i;
+      levels->white=white;
+      levels->apply=black_i != white ? 1u : 0u;
+    }
+}
+
+// The stretch map of enhance.c:1685-1706 evaluated per sample (Q16, the levels from
+// stretch_levels_kernel): no 65536-entry table to build, stage or gather from.
+template<int C>
+__global__ __launch_bounds__(256)
+void stretch_apply_kernel(uint16_t *pixels,size_t npixels,const StretchScratch *levels,uint32_t mask)
+{
+  if ((levels->apply == 0u) || (mask == 0u))
+    return;
+  const int black_i=levels->black,white_i=levels->white;
+  const double black=(double) black_i;
+  const double scale=65535.0*perceptible_reciprocal((double) white_i-black);
+  auto map=[&](unsigned j) -> unsigned
+  {
+    const double value=scale*((double) j-black);           // 65535.0*gamma*((double) j-black)
+    unsigned v=(unsigned) lut_scale_map_to_quantum(value,1);
+    v=(int) j > white_i ? 65535u : v;
+    v=(int) j < black_i ? 0u : v;                         // (tested first in enhance.c:1694)
+    return v;
+  };
+  constexpr int BATCH=4;
+  if constexpr (C == 4)
+    {
+      if ((reinterpret_cast<uintptr_t>(pixels) & 15u) == 0)
+        {
+          // two RGBA pixels per lane and load
+          uint4 *pairs=reinterpret_cast<uint4 *>(pixels);
+          const size_t npairs=npixels/2;
+          const size_t stride=(size_t) gridDim.x*blockDim.x*BATCH;
+          for (size_t i0=(size_t) blockIdx.x*blockDim.x*BATCH+threadIdx.x; i0 < npairs; i0+=stride)
+            {
+              uint4 v[BATCH];
+#pragma unroll
+              for (int k=0; k < BATCH; k++)
+                {
+                  const size_t i=i0+(size_t) k*blockDim.x;
+                  v[k]=pairs[i < npairs ? i : npairs-1];
+                }
+#pragma unroll
+              for (int k=0; k < BATCH; k++)
+                {
+                  unsigned words[4]={v[k].x,v[k].y,v[k].z,v[k].w};
+#pragma unroll
+                  for (int w=0; w < 4; w++)
+                    {
+                      const int c0=2*(w & 1);
+                      unsigned lo=words[w] & 0xffffu,hi=words[w] >> 16;
+                      if ((mask >> c0) & 1u)
+                        lo=map(lo);
+                      if ((mask >> (c0+1)) & 1u)
+                        hi=map(hi);
+                      words[w]=lo | (hi << 16);
+                    }
+                  const size_t i=i0+(size_t) k*blockDim.x;
+                  if (i < npairs)
+                    pairs[i]=make_uint4(words[0],words[1],words[2],words[3]);
+                }
+            }
+          if (((npixels & 1u) != 0) && (blockIdx.x == 0) && (threadIdx.x < 4u) && ((mask >> threadIdx.x) & 1u))
+            pixels[(npixels-1)*4+threadIdx.x]=(uint16_t) map(pixels[(npixels-1)*4+threadIdx.x]);
+          return;
+        }
+    }
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
+    {
+      uint16_t q[C];
+      load_pixel<uint16_t,C>(pixels+i*C,q);
+#pragma unroll
+      for (int c=0; c < C; c++)
+        if ((mask >> c) & 1u)
+          q[c]=(uint16_t) map(q[c]);
+      store_pixel<uint16_t,C>(pixels+i*C,q);
+    }
 }
 
 // *fused stays false when the frame does not qualify (the caller then runs the two operators)
@@ -1212,7 +1503,7 @@ MhStatus launch_lab_fast_with_histogram(const View &img,const MhImage *lab_desc,
   const IntensityParams ip=intensity_params(lab_desc);
   Temp slabs;
   MH_TRY(slabs.alloc(img.device,nblocks*32768*sizeof(unsigned),img.stream));
-  const size_t lds=32768*sizeof(unsigned);
+  const size_t lds=32768*sizeof(unsigned)+kDecodePieces*sizeof(float2);
   const bool plain=intensity_is_plain_luma(ip,4);
   MH_HIP(hipFuncSetAttribute(plain ? reinterpret_cast<const void *>(&lab_histogram_fast_kernel<true>) :
     reinterpret_cast<const void *>(&lab_histogram_fast_kernel<false>),
@@ -1221,12 +1512,82 @@ MhStatus launch_lab_fast_with_histogram(const View &img,const MhImage *lab_desc,
     ProfileScope prof("colorspace_histogram",img.stream);
     if (plain)
       hipLaunchKernelGGL(lab_histogram_fast_kernel<true>,dim3((unsigned) nblocks),dim3(1024),lds,img.stream,
-        static_cast<uint16_t *>(img.pixels),n,ip,slabs.as<unsigned>(),hist);
+        static_cast<uint16_t *>(img.pixels),n,ip,slabs.as<unsigned>(),hist,nullptr);
     else
       hipLaunchKernelGGL(lab_histogram_fast_kernel<false>,dim3((unsigned) nblocks),dim3(1024),lds,img.stream,
-        static_cast<uint16_t *>(img.pixels),n,ip,slabs.as<unsigned>(),hist);
+        static_cast<uint16_t *>(img.pixels),n,ip,slabs.as<unsigned>(),hist,nullptr);
     hipLaunchKernelGGL(histogram_packed_reduce_kernel,dim3(256),dim3(1024),0,img.stream,
       slabs.as<unsigned>(),(int) nblocks,hist,4);
+  }
+  MH_HIP(hipGetLastError());
+  *fused=true;
+  return MH_OK;
+}
+
+// FAST sRGB -> Lab followed by ContrastStretchImage on RGBA Q16 in FOUR launches: convert + bin
+// (lab_histogram_fast_kernel), bins and levels (stretch_bins_kernel, stretch_levels_kernel), map
+// (stretch_apply_kernel) — the general route takes seven (memset, convert + bin, slab reduction, three LUT kernels, LUT apply).
+// The results are the general route's, bit for bit: the same bins, the same levels, the same map
+// expression.  *fused stays false when the frame does not qualify.
+MhStatus launch_lab_fast_contrast_stretch(const View &img,const MhImage *lab_desc,double black_point,
+  double white_limit,uint32_t update_mask,bool *fused)
+{
+  *fused=false;
+  const size_t n=img.columns*img.rows;
+  if ((img.quantum != MH_QUANTUM_U16) || (img.channels != 4) || (precision() != MH_PRECISION_FAST) ||
+      (n < ((size_t) 1 << 20)) || (n >= ((size_t) 1 << 31)) ||
+      ((reinterpret_cast<uintptr_t>(img.pixels) & 15u) != 0) ||
+      (getenv("MAGICKHIP_NO_FAST_LAB") != nullptr) || (getenv("MAGICKHIP_NO_PACKED_HISTOGRAM") != nullptr) ||
+      (getenv("MAGICKHIP_NO_LDS_HISTOGRAM") != nullptr) || (getenv("MAGICKHIP_NO_FUSED_LAB_HISTOGRAM") != nullptr) ||
+      (getenv("MAGICKHIP_NO_STRETCH_LEVELS") != nullptr))
+    return MH_OK;
+  const size_t nblocks=packed_histogram_blocks(img.device,n);
+  if (nblocks == 0)
+    return MH_OK;
+  const IntensityParams ip=intensity_params(lab_desc);
+  // one allocation: slabs, the reduced bins, the extra-pixel lists, the scratch
+  const size_t slab_bytes=nblocks*32768*sizeof(unsigned);
+  const size_t bins_bytes=65536*sizeof(unsigned);
+  const size_t extras_bytes=((nblocks*kExtraPitch*sizeof(unsigned short))+15u) & ~(size_t) 15u;
+  const size_t shares_bytes=256*sizeof(unsigned long long);
+  Temp work;
+  MH_TRY(work.alloc(img.device,slab_bytes+bins_bytes+extras_bytes+shares_bytes+sizeof(StretchScratch),img.stream));
+  unsigned char *at=static_cast<unsigned char *>(work.ptr);
+  unsigned *slabs=reinterpret_cast<unsigned *>(at);
+  unsigned *bins=reinterpret_cast<unsigned *>(at+slab_bytes);
+  unsigned short *extras=reinterpret_cast<unsigned short *>(at+slab_bytes+bins_bytes);
+  unsigned long long *shares=reinterpret_cast<unsigned long long *>(at+slab_bytes+bins_bytes+extras_bytes);
+  StretchScratch *scratch=reinterpret_cast<StretchScratch *>(at+slab_bytes+bins_bytes+extras_bytes+shares_bytes);
+  const size_t lds=32768*sizeof(unsigned)+kDecodePieces*sizeof(float2);
+  const bool plain=intensity_is_plain_luma(ip,4);
+  static bool configured[2][64]={};
+  if ((img.device < 0) || (img.device >= 64) || !configured[plain ? 1 : 0][img.device])
+    {
+      MH_HIP(hipFuncSetAttribute(plain ? reinterpret_cast<const void *>(&lab_histogram_fast_kernel<true>) :
+        reinterpret_cast<const void *>(&lab_histogram_fast_kernel<false>),
+        hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+      if ((img.device >= 0) && (img.device < 64))
+        configured[plain ? 1 : 0][img.device]=true;
+    }
+  {
+    ProfileScope prof("colorspace_histogram",img.stream);
+    if (plain)
+      hipLaunchKernelGGL(lab_histogram_fast_kernel<true>,dim3((unsigned) nblocks),dim3(1024),lds,img.stream,
+        static_cast<uint16_t *>(img.pixels),n,ip,slabs,nullptr,extras);
+    else
+      hipLaunchKernelGGL(lab_histogram_fast_kernel<false>,dim3((unsigned) nblocks),dim3(1024),lds,img.stream,
+        static_cast<uint16_t *>(img.pixels),n,ip,slabs,nullptr,extras);
+  }
+  {
+    ProfileScope prof("build_lut",img.stream);
+    hipLaunchKernelGGL(stretch_bins_kernel,dim3(256),dim3(1024),0,img.stream,slabs,(int) nblocks,bins,shares);
+    hipLaunchKernelGGL(stretch_levels_kernel,dim3(1),dim3(1024),0,img.stream,bins,shares,extras,(int) nblocks,
+      scratch,black_point,white_limit);
+  }
+  {
+    ProfileScope prof("apply_lut",img.stream);
+    hipLaunchKernelGGL(stretch_apply_kernel<4>,dim3(stream_grid((n/2+3)/4)),dim3(256),0,img.stream,
+      static_cast<uint16_t *>(img.pixels),n,scratch,update_mask);
   }
   MH_HIP(hipGetLastError());
   *fused=true;

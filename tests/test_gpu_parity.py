@@ -1024,6 +1024,45 @@ def test_colorspace(im, refmod, dtype, src, dst, channels):
     assert_parity(got, want, True, "%s->%s" % (src, dst), max_ulp=1 if uses_pow else 0)
 
 
+@pytest.mark.parametrize("frame", ["random", "constant", "two_levels", "dark", "odd_size"])
+@pytest.mark.parametrize("black,white", [(0.02, 0.01), (0.0, 0.0), (0.7, 0.6), (1.5, 0.0), (0.0, 1.5)])
+def test_lab_contrast_stretch_three_launches(im, frame, black, white, monkeypatch):
+    """FAST sRGB->Lab + ContrastStretch in one call on RGBA Q16 takes three launches (convert + bin,
+    stretch_levels_kernel, stretch_apply_kernel: pointwise.hip); the levels and the map are those
+    of the general route (slab reduction, three LUT kernels, LUT apply), bit for bit — on frames
+    whose shares overflow the packed counters' capacity into the extra-pixel lists, on a constant
+    frame (one bin holds everything), with thresholds no bin reaches and thresholds every bin
+    reaches."""
+    import bench
+    rng = np.random.default_rng(9)
+    rows, cols = (1031, 1021) if frame == "odd_size" else (1024, 1280)
+    px = rng.integers(0, 65536, (rows, cols, 4), dtype=np.uint16)
+    if frame == "constant":
+        px[:, :, :3] = (30000, 20000, 10000)
+    elif frame == "two_levels":
+        px[:, :, :3] = np.where((np.arange(cols) % 3 == 0)[None, :, None], 60000, 900)
+    elif frame == "dark":
+        px[:, :, :3] = rng.integers(0, 40, (rows, cols, 3), dtype=np.uint16)
+    n = rows * cols
+    results = []
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        for general in (False, True):
+            if general:
+                monkeypatch.setenv("MAGICKHIP_NO_STRETCH_LEVELS", "1")
+            img = im.Image(to_device(px))
+            launched = bench.kernel_profile(im, lambda: im.transform_colorspace_contrast_stretch_image(
+                img, "Lab", black * n, n - white * n), 1)
+            assert "colorspace_histogram" in launched, launched
+            results.append(img.numpy().copy())
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    same = results[0] == results[1]
+    assert same.all(), "%s black %g white %g: %d samples differ, first %s: %s vs %s" % (
+        frame, black, white, int((~same).sum()), np.argwhere(~same)[0].tolist(),
+        results[0][~same][:4].tolist(), results[1][~same][:4].tolist())
+
+
 # ------------------------------------------------ Equalize / ContrastStretch
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
 @pytest.mark.parametrize("kind", ["random", "smooth"])
