@@ -118,6 +118,16 @@ struct ResizeAcc
           s[c]=A::mac(s[c],w,p[c]);
       }
   }
+  // kDerive with a sample staged as (alpha*p .., alpha): sum w*(alpha*p) instead of
+  // sum (w*alpha)*p — one fused multiply-add per channel and tap, no product per tap (the staging
+  // pays the three products once per SOURCE sample, which ~4*taps outputs share)
+  __device__ __forceinline__ void tap_premultiplied(T w,const T (&p)[C])
+  {
+    static_assert(kDerive,"the premultiplied form is the derived-gamma mode's");
+#pragma unroll
+    for (int c=0; c < C; c++)
+      s[c]=A::mac(s[c],w,p[c]);
+  }
   __device__ __forceinline__ void finish(const Q (&copy)[C],uint32_t copy_mask,Q (&out)[C]) const
   {
     if constexpr (kDerive)
@@ -126,17 +136,14 @@ struct ResizeAcc
         // with inv = 1/S_alpha, or (+-1/MagickEpsilon)*QuantumScale under the clamp
         const double sa=(double) s[C-1];
         const double mag=sa < 0.0 ? -sa : sa;
-        double inv;
-        if ((mag*kQS) >= kEps)
-          {
-            double r=__builtin_amdgcn_rcp(sa);
-            double e=__builtin_fma(-sa,r,1.0);
-            r=__builtin_fma(r,e,r);
-            e=__builtin_fma(-sa,r,1.0);
-            inv=__builtin_fma(r,e,r);
-          }
-        else
-          inv=(sa < 0.0 ? -kInvEps : kInvEps)*kQS;
+        // (branch-free: the Newton reciprocal of a clamped sum is computed and discarded)
+        double r=__builtin_amdgcn_rcp(sa);
+        double e=__builtin_fma(-sa,r,1.0);
+        r=__builtin_fma(r,e,r);
+        e=__builtin_fma(-sa,r,1.0);
+        r=__builtin_fma(r,e,r);
+        const double clamped=(sa < 0.0 ? -kInvEps : kInvEps)*kQS;
+        const double inv=(mag*kQS) >= kEps ? r : clamped;
         if (copy_mask == 0)
           {
 #pragma unroll
@@ -366,11 +373,13 @@ void resize_horizontal_kernel(ResizeArgs args,int tile_rows)
 // Quantum->double conversion costs as much issue time as a multiply-add), and
 // every lane runs the same number of taps (the tile's maximum; the extra taps
 // carry zero weights) so the tap loop has no per-lane predicates.
-template<typename Q,int C,bool BLEND,class A,int MAXT>
+template<typename Q,int C,bool BLEND,class A,int MAXT,bool PREMUL=false>
 __global__ __launch_bounds__(256)
 void resize_horizontal_cvt_kernel(ResizeArgs args,int tile_rows,int lds_span)
 {
   typedef typename A::T T;
+  // PREMUL (Fma64, alpha-weighted, every channel updated): the tile holds alpha*colour, alpha
+  static_assert(!PREMUL || ResizeAcc<Q,C,BLEND,A>::kDerive,"premultiplied staging needs the derived gamma");
   constexpr bool kSkipZeros=std::is_same<A,Exact64>::value && QuantumOps<Q>::is_float;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T *tile=reinterpret_cast<T *>(smem_raw);
@@ -412,9 +421,10 @@ void resize_horizontal_cvt_kernel(ResizeArgs args,int tile_rows,int lds_span)
         for (int k=0; k < BATCH; k++)
           if (i0+256*k < items)
             {
+              const T scale=PREMUL ? (T) v[k][C-1] : (T) 1;
 #pragma unroll
               for (int c=0; c < C; c++)
-                tile[(size_t) slot[k]*C+c]=(T) v[k][c];
+                tile[(size_t) slot[k]*C+c]=(PREMUL && (c != C-1)) ? scale*(T) v[k][c] : (T) v[k][c];
             }
       }
   }
@@ -455,7 +465,12 @@ void resize_horizontal_cvt_kernel(ResizeArgs args,int tile_rows,int lds_span)
 #pragma unroll
       for (int j=0; j < MAXT; j++)
         if (!kSkipZeros || (j < count))           // zero-weight taps are exact no-ops
-          acc.tap_converted(w[j],wq[j],p[j]);
+          {
+            if constexpr (PREMUL)
+              acc.tap_premultiplied(w[j],p[j]);
+            else
+              acc.tap_converted(w[j],wq[j],p[j]);
+          }
       Q copy[C],out[C];
 #pragma unroll
       for (int c=0; c < C; c++)
@@ -1435,14 +1450,29 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
               size_t lds=(size_t) lds_span*cpx*(size_t) tile_rows;
               dim3 grid((unsigned) ((dst.columns+255)/256),(unsigned) ((dst.rows+tile_rows-1)/tile_rows));
               ProfileScope prof("resize_horizontal",src.stream);
+              constexpr bool kCanPremultiply=ResizeAcc<Q,C,BLEND,A>::kDerive;
+              const bool premultiply=kCanPremultiply && (args.copy_mask == 0) &&
+                (getenv("MAGICKHIP_NO_RESIZE_PREMULTIPLY") == nullptr);
 #define MH_LAUNCH_H(N)                                                                        \
               {                                                                                \
-                if (lds > 64u*1024u)                                                           \
-                  MH_HIP(hipFuncSetAttribute(                                                  \
-                    reinterpret_cast<const void *>(&resize_horizontal_cvt_kernel<Q,C,BLEND,A,N>),\
-                    hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));                    \
-                hipLaunchKernelGGL((resize_horizontal_cvt_kernel<Q,C,BLEND,A,N>),grid,dim3(256),lds, \
-                  src.stream,args,tile_rows,lds_span);                                         \
+                if (premultiply)                                                               \
+                  {                                                                            \
+                    if (lds > 64u*1024u)                                                       \
+                      MH_HIP(hipFuncSetAttribute(                                              \
+                        reinterpret_cast<const void *>(&resize_horizontal_cvt_kernel<Q,C,BLEND,A,N,kCanPremultiply>),\
+                        hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));                \
+                    hipLaunchKernelGGL((resize_horizontal_cvt_kernel<Q,C,BLEND,A,N,kCanPremultiply>),grid,dim3(256),lds, \
+                      src.stream,args,tile_rows,lds_span);                                     \
+                  }                                                                            \
+                else                                                                           \
+                  {                                                                            \
+                    if (lds > 64u*1024u)                                                       \
+                      MH_HIP(hipFuncSetAttribute(                                              \
+                        reinterpret_cast<const void *>(&resize_horizontal_cvt_kernel<Q,C,BLEND,A,N>),\
+                        hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));                \
+                    hipLaunchKernelGGL((resize_horizontal_cvt_kernel<Q,C,BLEND,A,N>),grid,dim3(256),lds, \
+                      src.stream,args,tile_rows,lds_span);                                     \
+                  }                                                                            \
               }
               if (maxt == 4) MH_LAUNCH_H(4)
               else if (maxt == 6) MH_LAUNCH_H(6)
