@@ -1,4 +1,5 @@
-// Non-separable 2-D ConvolveMorphology on the f16 matrix cores (FAST, Q16, 8-byte pixels).
+// Non-separable 2-D ConvolveMorphology on the f16 matrix cores (FAST, Q16; RGBA, four plain
+// channels or RGB).
 //
 // Reference: the reflected-kernel loops of MorphologyPrimitive, MagickCore/morphology.c:2925-2979
 // (a w x h weighted sum per channel, alpha-weighted for Blend channels, NaN cells skipped) with
@@ -69,7 +70,11 @@ template<int NC,int MODE>
 __global__ __launch_bounds__(512)
 void conv2d_mfma_kernel(Conv2DArgs args)
 {
-  static_assert((MODE == MFMA_BLEND4) || (MODE == MFMA_PLAIN4),"8-byte pixels");
+  // MFMA_PLAIN3 (RGB, 6-byte pixels) runs as four plain channels whose fourth is zero: only the
+  // pixel loads and stores differ
+  constexpr int PX=MODE == MFMA_PLAIN3 ? 3 : 4;          // u16 per pixel in memory
+  constexpr int SAMPLES=MODE == MFMA_PLAIN3 ? MFMA_PLAIN4 : MODE;
+  typedef unsigned __attribute__((aligned(2))) LooseDword;
   typedef Conv2DGeometry<NC> G;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int SR=args.stride,CH=args.plane;
@@ -122,7 +127,11 @@ void conv2d_mfma_kernel(Conv2DArgs args)
               {
                 int x=xin0+4*quad+i;
                 x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
-                raw[k][i]=*reinterpret_cast<const uint2 *>(args.src+pixel_index(y,W,x)*4);
+                const uint16_t *at=args.src+pixel_index(y,W,x)*PX;
+                if constexpr (MODE == MFMA_PLAIN3)
+                  raw[k][i]=make_uint2(*reinterpret_cast<const LooseDword *>(at),(unsigned) at[2]);
+                else
+                  raw[k][i]=*reinterpret_cast<const uint2 *>(at);
               }
           }
 #pragma unroll
@@ -133,7 +142,7 @@ void conv2d_mfma_kernel(Conv2DArgs args)
               continue;
             const int row=idx/QUADS,quad=idx-row*QUADS;
             f32x2 v[4][2];
-            quantum_to_samples<MODE>(raw[k],v);
+            quantum_to_samples<SAMPLES>(raw[k],v);
 #pragma unroll
             for (int c=0; c < 4; c++)
               {
@@ -228,8 +237,17 @@ void conv2d_mfma_kernel(Conv2DArgs args)
         {
           const int x=x0+16*t+e;
           if (x < W)
-            *reinterpret_cast<uint2 *>(args.dst+pixel_index(y,W,x)*4)=
-              sums_to_quantum<MODE>(acc[t][0],acc[t][1],acc[t][2],acc[t][3]);
+            {
+              const uint2 result=sums_to_quantum<SAMPLES>(acc[t][0],acc[t][1],acc[t][2],acc[t][3]);
+              uint16_t *at=args.dst+pixel_index(y,W,x)*PX;
+              if constexpr (MODE == MFMA_PLAIN3)
+                {
+                  *reinterpret_cast<LooseDword *>(at)=result.x;
+                  at[2]=(uint16_t) result.y;
+                }
+              else
+                *reinterpret_cast<uint2 *>(at)=result;
+            }
         }
     }
 }
@@ -246,14 +264,15 @@ static MhStatus launch_conv2d_typed(const View &src,Conv2DArgs &args,size_t lds)
   return MH_OK;
 }
 
-// w x h Convolve of an RGBA (alpha-weighted colour, alpha last) or four-plain-channel Q16 frame.
+// w x h Convolve of an RGBA (alpha-weighted colour, alpha last), four-plain-channel or RGB Q16 frame.
 // *handled stays false (nothing launched) when the kernel or the frame does not qualify.
 MhStatus launch_conv2d_mfma(const View &src,const View &dst,const MhKernelInfo *kernel,bool blend,
   bool *handled)
 {
   *handled=false;
-  if ((src.quantum != MH_QUANTUM_U16) || (dst.quantum != MH_QUANTUM_U16) || (src.channels != 4) ||
-      (dst.channels != 4) || (src.columns != dst.columns) || (src.rows != dst.rows))
+  if ((src.quantum != MH_QUANTUM_U16) || (dst.quantum != MH_QUANTUM_U16) ||
+      ((src.channels != 4) && ((src.channels != 3) || blend)) ||
+      (dst.channels != src.channels) || (src.columns != dst.columns) || (src.rows != dst.rows))
     return MH_OK;
   if ((src.columns >= (1u << 24)) || (src.rows >= (1u << 24)) ||
       ((unsigned long long) src.columns*src.rows >= (1ull << 32)))
@@ -317,6 +336,8 @@ MhStatus launch_conv2d_mfma(const View &src,const View &dst,const MhKernelInfo *
   args.groups=(args.rows+kC2Rows-1)/kC2Rows;
   args.items_per_xcd=(args.strips*args.groups+7)/8;
   *handled=true;
+  if (src.channels == 3)
+    return nc == 1 ? launch_conv2d_typed<1,MFMA_PLAIN3>(src,args,lds) : launch_conv2d_typed<2,MFMA_PLAIN3>(src,args,lds);
   if (nc == 1)
     return blend ? launch_conv2d_typed<1,MFMA_BLEND4>(src,args,lds) : launch_conv2d_typed<1,MFMA_PLAIN4>(src,args,lds);
   return blend ? launch_conv2d_typed<2,MFMA_BLEND4>(src,args,lds) : launch_conv2d_typed<2,MFMA_PLAIN4>(src,args,lds);

@@ -247,10 +247,11 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
       if (handled)
         return MH_OK;
     }
-  // FAST, Q16, RGBA (alpha-weighted, alpha last) or four plain channels, kernels of 5 x 5 and
+  // FAST, Q16, RGBA (alpha-weighted, alpha last), four plain channels or RGB, kernels of 5 x 5 and
   // more: the w x h sum as h banded products on the matrix cores (convolve2d_mfma.hip)
   if ((method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
-      (mode == MH_PRECISION_FAST) && (src.quantum == MH_QUANTUM_U16) && (src.channels == 4) &&
+      (mode == MH_PRECISION_FAST) && (src.quantum == MH_QUANTUM_U16) &&
+      ((src.channels == 4) || ((src.channels == 3) && !roles.blend)) &&
       (roles.copy_mask == 0) && (!roles.blend || (roles.alpha == 3)) &&
       (getenv("MAGICKHIP_NO_MFMA") == nullptr) && (getenv("MAGICKHIP_NO_MFMA_2D") == nullptr))
     {

@@ -470,6 +470,27 @@ def test_convolve_2d_fast_on_matrix_cores(im, refmod, kernel, alpha, monkeypatch
     assert_parity(generic, want, False, "generic 2-D convolve %s" % kernel)
 
 
+@pytest.mark.parametrize("kernel", ["Disk:15", "Octagon:5", "Ring:10,14",
+                                    "6x6+1+4: 1,0,2,nan,1,3 0,1,1,2,nan,1 2,2,0,1,1,1 nan,1,3,1,0,2 1,1,1,1,2,0 3,0,1,2,1,1"])
+def test_convolve_2d_fast_on_matrix_cores_rgb(im, refmod, kernel):
+    """The same kernel on an RGB frame (6-byte pixels): three plain channels, the matrix tile's
+    fourth entry zero (convolve2d_mfma.hip, MFMA_PLAIN3); frames ragged against the tiles.
+    Within one level of the reference."""
+    import bench
+    px = make_pixels(75, 150, 3, Q16, seed=len(kernel) + 3)
+    dev, ref = run_pair(im, refmod, px)
+    holder = {}
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        launched = set(bench.kernel_profile(
+            im, lambda: holder.update(out=im.morphology_image(dev, "Convolve", 1, kernel, scale=(1.0, 1))), 1))
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert launched == {"conv2d_mfma"}, launched
+    want = ref.set_artifact("convolve:scale", "!").morphology("Convolve", 1, kernel).numpy()
+    assert_parity(holder["out"].numpy(), want, False, "2-D convolve %s RGB" % kernel)
+
+
 @pytest.mark.parametrize("shape", [(64, 80), (33, 71), (2, 2), (70, 2), (1, 40), (129, 17)])
 @pytest.mark.parametrize("gain,threshold", [(1.0, 0.02), (2.5, 0.0), (0.6, 0.2), (1.3, 1.0 / 65535.0)])
 @pytest.mark.parametrize("single_launch", [True, False])
