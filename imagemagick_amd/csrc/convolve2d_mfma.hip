@@ -13,10 +13,16 @@
 // Operands are hi/lo-split f16 with three products per term (mfma_common.hpp); the scale
 // factors and the epilogue are those of the 1-D passes.
 //
-// MI355X mapping.  A workgroup (8 waves) owns 64 output columns x 32 output rows:
-//   * the (32+h-1) x (64+w-1) source window is staged ONCE in LDS as alpha-premultiplied hi/lo
-//     f16 planes [channel][row][column] — 119 KB for 31 x 31; the stride comes from the same
-//     bank-conflict search as the fused blur's planes;
+// MI355X mapping.  A workgroup (8 waves) walks DOWN a strip of 64 output columns, 32 output rows
+// a step:
+//   * the (32+h-1) x (64+w-1) source window lives in LDS as alpha-premultiplied hi/lo f16 planes
+//     [channel][row][column] — 119 KB for 31 x 31; the stride comes from the same bank-conflict
+//     search as the fused blur's planes.  The rows are a RING: a step replaces the 32 oldest rows
+//     with the 32 new ones, which were fetched into registers (two pixel quads per thread) while
+//     the previous step's products ran, so neither the h-1 shared rows nor the tap tables are
+//     staged again and no load latency stands in front of the products (round 2 staged a whole
+//     window per 64 x 32 tile behind a barrier: 9.8 ms for Disk:15 on 16384^2, 52 % of the
+//     matrix pipe);
 //   * wave = one quad of output rows (entries e = 4*row+channel: D hands a lane the four
 //     channels of one pixel, so the division by the alpha sum is lane-local and the result
 //     leaves as one 8-byte store) x the four 16-column tiles of the strip.  The Toeplitz operand
@@ -47,9 +53,10 @@ struct Conv2DArgs
   int kw,kh;                  // kernel size
   int shiftx,shifty;          // output (x,y) reads source (x-shiftx+u, y-shifty+v)
   const float *taps;          // float[4][kh][TL]: the four shifted Toeplitz tables, 256*tap, reflected walk
-  int stage_rows;             // 32+kh-1
+  int stage_rows;             // 32+kh-1: rows of the ring
   int stride,plane;           // LDS row stride and channel-plane size of the staged window (halves)
-  int strips,groups,items_per_xcd;
+  int strips,groups;          // 64-column strips, 32-row steps of a whole strip
+  int segments,steps_per_segment,items_per_xcd;   // vertical cuts of a strip: work items = strips*segments
 };
 
 constexpr int kC2Rows=32;     // output rows per workgroup
@@ -85,13 +92,16 @@ void conv2d_mfma_kernel(Conv2DArgs args)
   const int tid=(int) threadIdx.x,lane=tid & 63;
   const int wave=__builtin_amdgcn_readfirstlane(tid >> 6);
   const int W=args.columns,H=args.rows;
-  const int items=args.strips*args.groups;
+  const int items=args.strips*args.segments;
   const int item=((int) blockIdx.x & 7)*args.items_per_xcd+((int) blockIdx.x >> 3);
   if (item >= items)
     return;
-  const int group=item/args.strips,strip=item-group*args.strips;
-  const int x0=kC2Cols*strip,y0=kC2Rows*group;
-  const int xin0=x0-args.shiftx,yin0=y0-args.shifty;
+  const int segment=item/args.strips,strip=item-segment*args.strips;
+  const int step_begin=segment*args.steps_per_segment;
+  const int step_end=step_begin+args.steps_per_segment < args.groups ? step_begin+args.steps_per_segment : args.groups;
+  const int x0=kC2Cols*strip;
+  const int xin0=x0-args.shiftx;
+  const int R=args.stage_rows;
 
   // ---- tap tables: copy b holds T[v][m] = 256*tap[v][m-16-b], zero outside the kernel row
   // (laid out by the host: args.taps is float[4][kh][TL])
@@ -105,79 +115,107 @@ void conv2d_mfma_kernel(Conv2DArgs args)
         taps_lo[idx]=l;
       }
   }
-  // ---- the source window, edge-clamped (cache.c:2663-2679), four pixels per thread and item;
-  // every load of the thread is in flight before the first conversion
+  // ---- source rows, edge-clamped (cache.c:2663-2679), as quads of four pixels: item idx = (row,
+  // quad) of a block of rows that starts at image row `first`
+  constexpr int QUADS=G::XS/4;
+  auto load_quad=[&](int first,int idx,uint2 (&raw)[4])
   {
-    constexpr int QUADS=G::XS/4;
-    constexpr int ITEMS=4;                       // (32+63) rows x 28 quads / 512 threads < 6: two rounds at most
-    const int total=args.stage_rows*QUADS;
+    const int row=idx/QUADS,quad=idx-row*QUADS;
+    int y=first+row;
+    y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
+#pragma unroll
+    for (int i=0; i < 4; i++)
+      {
+        int x=xin0+4*quad+i;
+        x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
+        const uint16_t *at=args.src+pixel_index(y,W,x)*PX;
+        if constexpr (MODE == MFMA_PLAIN3)
+          raw[i]=make_uint2(*reinterpret_cast<const LooseDword *>(at),(unsigned) at[2]);
+        else
+          raw[i]=*reinterpret_cast<const uint2 *>(at);
+      }
+  };
+  // ... converted and written to ring row (ring_first + row) mod R
+  auto store_quad=[&](int ring_first,int idx,const uint2 (&raw)[4])
+  {
+    const int row=idx/QUADS,quad=idx-row*QUADS;
+    int ring_row=ring_first+row;
+    ring_row=ring_row >= R ? ring_row-R : ring_row;
+    f32x2 v[4][2];
+    quantum_to_samples<SAMPLES>(raw,v);
+#pragma unroll
+    for (int c=0; c < 4; c++)
+      {
+        uint2 hi,lo;
+        split_f16_pair(v[c][0],hi.x,lo.x);
+        split_f16_pair(v[c][1],hi.y,lo.y);
+        const int at=c*CH+ring_row*SR+4*quad;
+        *reinterpret_cast<uint2 *>(stage_hi+at)=hi;
+        *reinterpret_cast<uint2 *>(stage_lo+at)=lo;
+      }
+  };
+  // the whole window of the first step: every load of a thread's batch is in flight before the
+  // first conversion
+  {
+    constexpr int ITEMS=4;
+    const int total=R*QUADS;
+    const int first=kC2Rows*step_begin-args.shifty;
     for (int i0=tid; i0 < total; i0+=512*ITEMS)
       {
         uint2 raw[ITEMS][4];
 #pragma unroll
         for (int k=0; k < ITEMS; k++)
           {
-            int idx=i0+512*k;
-            idx=idx < total ? idx : total-1;
-            const int row=idx/QUADS,quad=idx-row*QUADS;
-            int y=yin0+row;
-            y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
-#pragma unroll
-            for (int i=0; i < 4; i++)
-              {
-                int x=xin0+4*quad+i;
-                x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
-                const uint16_t *at=args.src+pixel_index(y,W,x)*PX;
-                if constexpr (MODE == MFMA_PLAIN3)
-                  raw[k][i]=make_uint2(*reinterpret_cast<const LooseDword *>(at),(unsigned) at[2]);
-                else
-                  raw[k][i]=*reinterpret_cast<const uint2 *>(at);
-              }
+            const int idx=i0+512*k;
+            load_quad(first,idx < total ? idx : total-1,raw[k]);
           }
 #pragma unroll
         for (int k=0; k < ITEMS; k++)
-          {
-            const int idx=i0+512*k;
-            if (idx >= total)
-              continue;
-            const int row=idx/QUADS,quad=idx-row*QUADS;
-            f32x2 v[4][2];
-            quantum_to_samples<SAMPLES>(raw[k],v);
-#pragma unroll
-            for (int c=0; c < 4; c++)
-              {
-                uint2 hi,lo;
-                split_f16_pair(v[c][0],hi.x,lo.x);
-                split_f16_pair(v[c][1],hi.y,lo.y);
-                const int at=c*CH+row*SR+4*quad;
-                *reinterpret_cast<uint2 *>(stage_hi+at)=hi;
-                *reinterpret_cast<uint2 *>(stage_lo+at)=lo;
-              }
-          }
+          if (i0+512*k < total)
+            store_quad(0,i0+512*k,raw[k]);
       }
   }
   __syncthreads();
 
   // ---- wave = row quad `wave`, tiles 0..3; lane (e, kq): entry e = 4*row+channel
   const int e=lane & 15,kq=lane >> 4;
-  const int a_base=(e & 3)*CH+(4*wave+(e >> 2))*SR+8*kq;
+  const int a_column=(e & 3)*CH+8*kq;           // + ring row * SR
+  const int a_row=4*wave+(e >> 2);               // window row of kernel row 0
   // Toeplitz window of lane (n = e, kq): taps 32c+8kq+i-n = T_b[32c + 8kq - 4a + 16 + i], n = 4a+b
   const int t_base=(e & 3)*args.kh*G::TL+8*kq-4*(e >> 2)+16;
+  // the 32 new rows of the next step: 32 x QUADS items, two per thread (QUADS <= 32)
+  constexpr int NEW_ITEMS=(kC2Rows*QUADS+511)/512;
+  static_assert(NEW_ITEMS <= 2,"two pixel quads per thread");
+  int origin=0;                                  // ring row of the window's first row
+  for (int step=step_begin; step < step_end; step++)
+    {
+  const int y0=kC2Rows*step;
+  uint2 ahead[NEW_ITEMS][4];
+  if (step+1 < step_end)
+    {
+#pragma unroll
+      for (int k=0; k < NEW_ITEMS; k++)
+        {
+          const int idx=tid+512*k;
+          load_quad(y0+kC2Rows-args.shifty+R-kC2Rows,idx < kC2Rows*QUADS ? idx : kC2Rows*QUADS-1,ahead[k]);
+        }
+    }
   floatx4 acc[4];
 #pragma unroll
   for (int t=0; t < 4; t++)
     acc[t]=floatx4{0.0f,0.0f,0.0f,0.0f};
   // The operands of kernel row v+1 are read while the 24 products of row v run (two register
   // sets, the loop unrolled by two), so that the LDS latency of a row's 20 reads does not sit in
-  // front of its first product.  (Measured neutral at two waves per SIMD — 9.7 ms either way for
-  // Disk:15 on 16384^2, 55 % of the matrix pipe at nominal clock: what is left is the staging of
-  // the next window, which one workgroup per CU cannot overlap with its products.)
+  // front of its first product.  (Tried and dropped, round 3: sliding the data operand — a row
+  // quad's window moves by one row per kernel row, so three quarters of it can come from the lane
+  // four up with v_mov_b32_dpp row_shl:4 and only the new row from LDS: 7 KB instead of 16 KB of
+  // LDS reads per wave and kernel row, same time, 8.8 against 8.4 ms.)
   struct Operands
   {
     half8 b_hi[NC],b_lo[NC];
     half8 a_hi[G::BLOCKS],a_lo[G::BLOCKS];
   };
-  auto fetch=[&](Operands &o,int v)
+  auto fetch_taps=[&](Operands &o,int v)
   {
 #pragma unroll
     for (int c=0; c < NC; c++)
@@ -190,7 +228,12 @@ void conv2d_mfma_kernel(Conv2DArgs args)
         o.b_hi[c]=half8{h0[0],h0[1],h0[2],h0[3],h1[0],h1[1],h1[2],h1[3]};
         o.b_lo[c]=half8{l0[0],l0[1],l0[2],l0[3],l1[0],l1[1],l1[2],l1[3]};
       }
-    const int row_at=a_base+v*SR;
+  };
+  auto read_rows=[&](Operands &o,int v)
+  {
+    int ring_row=origin+a_row+v;                 // < 2R
+    ring_row=ring_row >= R ? ring_row-R : ring_row;
+    const int row_at=a_column+ring_row*SR;
 #pragma unroll
     for (int q=0; q < G::BLOCKS; q++)
       {
@@ -198,32 +241,42 @@ void conv2d_mfma_kernel(Conv2DArgs args)
         o.a_lo[q]=*reinterpret_cast<const half8 *>(stage_lo+row_at+16*q);
       }
   };
+  auto fetch=[&](Operands &o,int v)
+  {
+    fetch_taps(o,v);
+    read_rows(o,v);
+  };
   auto multiply=[&](const Operands &o)
   {
+    // (tile t, chunk c: columns 16t+32c = data block t+2c.)  Three other products stand between
+    // two that accumulate into the same tile: a dependent v_mfma waits for its predecessor's passes
 #pragma unroll
     for (int c=0; c < NC; c++)
+      {
 #pragma unroll
-      for (int t=0; t < 4; t++)
-        {
-          const int q=t+2*c;                       // tile t, chunk c: columns 16t+32c
-          acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(o.a_hi[q],o.b_hi[c],acc[t],0,0,0);
-          acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(o.a_lo[q],o.b_hi[c],acc[t],0,0,0);
-          acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(o.a_hi[q],o.b_lo[c],acc[t],0,0,0);
-        }
+        for (int t=0; t < 4; t++)
+          acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(o.a_hi[t+2*c],o.b_hi[c],acc[t],0,0,0);
+#pragma unroll
+        for (int t=0; t < 4; t++)
+          acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(o.a_lo[t+2*c],o.b_hi[c],acc[t],0,0,0);
+#pragma unroll
+        for (int t=0; t < 4; t++)
+          acc[t]=__builtin_amdgcn_mfma_f32_16x16x32_f16(o.a_hi[t+2*c],o.b_lo[c],acc[t],0,0,0);
+      }
   };
   Operands even,odd;
   fetch(even,0);
   for (int v=0; v < args.kh; v+=2)
     {
-      const int next=v+1 < args.kh ? v+1 : v;       // (a harmless re-read at the tail)
-      fetch(odd,next);
+      if (v+1 < args.kh)
+        fetch(odd,v+1);
       __builtin_amdgcn_sched_barrier(0);
       multiply(even);
       __builtin_amdgcn_sched_barrier(0);
       if (v+1 >= args.kh)
         break;
-      const int after=v+2 < args.kh ? v+2 : v+1;
-      fetch(even,after);
+      if (v+2 < args.kh)
+        fetch(even,v+2);
       __builtin_amdgcn_sched_barrier(0);
       multiply(odd);
       __builtin_amdgcn_sched_barrier(0);
@@ -249,6 +302,17 @@ void conv2d_mfma_kernel(Conv2DArgs args)
                 *reinterpret_cast<uint2 *>(at)=result;
             }
         }
+    }
+  if (step+1 < step_end)
+    {
+      __syncthreads();                           // every read of the 32 oldest rows is done
+#pragma unroll
+      for (int k=0; k < NEW_ITEMS; k++)
+        if (tid+512*k < kC2Rows*QUADS)
+          store_quad(origin,tid+512*k,ahead[k]);
+      origin=origin+kC2Rows >= R ? origin+kC2Rows-R : origin+kC2Rows;
+      __syncthreads();
+    }
     }
 }
 
@@ -334,7 +398,29 @@ MhStatus launch_conv2d_mfma(const View &src,const View &dst,const MhKernelInfo *
   args.taps=table.as<float>();
   args.strips=(args.columns+kC2Cols-1)/kC2Cols;
   args.groups=(args.rows+kC2Rows-1)/kC2Rows;
-  args.items_per_xcd=(args.strips*args.groups+7)/8;
+  {
+    // cuts of a strip: the schedule (one workgroup per CU) that finishes first; a cut costs the
+    // staging of its first window, about a step's worth
+    const int cus=compute_units(src.device);
+    int best=1;
+    double best_cost=1.0e300;
+    for (int cuts=1; cuts <= args.groups; cuts++)
+      {
+        const int steps=(args.groups+cuts-1)/cuts;
+        const int rounds=(args.strips*((args.groups+steps-1)/steps)+cus-1)/cus;
+        const double cost=(double) rounds*((double) steps+1.0);
+        if (cost < best_cost-1.0e-9)
+          {
+            best_cost=cost;
+            best=cuts;
+          }
+      }
+    if (const char *e=getenv("MAGICKHIP_CONV2D_CUTS"))          // tests: long walks on small frames
+      best=(atoi(e) >= 1) && (atoi(e) <= args.groups) ? atoi(e) : best;
+    args.steps_per_segment=(args.groups+best-1)/best;
+    args.segments=(args.groups+args.steps_per_segment-1)/args.steps_per_segment;
+  }
+  args.items_per_xcd=(args.strips*args.segments+7)/8;
   *handled=true;
   if (src.channels == 3)
     return nc == 1 ? launch_conv2d_typed<1,MFMA_PLAIN3>(src,args,lds) : launch_conv2d_typed<2,MFMA_PLAIN3>(src,args,lds);

@@ -431,20 +431,24 @@ def test_convolve_fast_non_separable_kernel_stays_exact(im, refmod):
         im.set_precision(im.PRECISION_EXACT)
 
 
+@pytest.mark.parametrize("walk", [False, True])
 @pytest.mark.parametrize("alpha", [True, False])
 @pytest.mark.parametrize("kernel", ["Disk:15", "Disk:7.3", "Octagon:5", "Diamond:4", "Plus:3",
                                     "7x5: 1,2,3,4,3,2,1 2,4,6,8,6,4,2 3,6,9,13,9,6,2 2,4,6,8,6,4,2 1,2,3,4,3,2,1",
                                     "6x6+1+4: 1,0,2,nan,1,3 0,1,1,2,nan,1 2,2,0,1,1,1 nan,1,3,1,0,2 1,1,1,1,2,0 3,0,1,2,1,1",
                                     "Ring:10,14"])
-def test_convolve_2d_fast_on_matrix_cores(im, refmod, kernel, alpha, monkeypatch):
+def test_convolve_2d_fast_on_matrix_cores(im, refmod, kernel, alpha, walk, monkeypatch):
     """FAST ConvolveMorphology with a non-separable kernel of 5 x 5 cells or more (RGBA with
     alpha-weighted colour, or four plain channels): the w x h sum as h banded products on the
     matrix cores (convolve2d_mfma.hip) — flat disks, weighted and asymmetric user kernels, NaN
-    cells, origins off centre, frames ragged against the 64 x 32 tiles; the kernel normalised as
-    `-define convolve:scale='!'` does.  Within one level of the reference, and of the generic
-    kernel it replaces."""
+    cells, origins off centre, frames ragged against the 64-column strips and 32-row steps; the
+    kernel normalised as `-define convolve:scale='!'` does; `walk`: one workgroup per strip walks
+    all four steps through its ring of rows (a small frame is otherwise cut into single steps).
+    Within one level of the reference, and of the generic kernel it replaces."""
     import bench
-    px = make_pixels(75, 150, 4, Q16, seed=len(kernel))
+    if walk:
+        monkeypatch.setenv("MAGICKHIP_CONV2D_CUTS", "1")
+    px = make_pixels(107 if walk else 75, 150, 4, Q16, seed=len(kernel))
     if alpha:
         px[10:30, 20:60, 3] = np.random.default_rng(3).integers(0, 4, (20, 40))       # tiny alpha
         px[40:50, 100:140, 3] = 0                                                         # transparent
@@ -465,7 +469,7 @@ def test_convolve_2d_fast_on_matrix_cores(im, refmod, kernel, alpha, monkeypatch
         want = ref.set_artifact("convolve:scale", "!").morphology("Convolve", 1, kernel).numpy()
     else:
         want = np.concatenate([refmod.RefImage(px[:, :, c].copy()).set_artifact("convolve:scale", "!")
-                               .morphology("Convolve", 1, kernel).numpy().reshape(75, 150, 1) for c in range(4)], axis=2)
+                               .morphology("Convolve", 1, kernel).numpy().reshape(px.shape[0], 150, 1) for c in range(4)], axis=2)
     assert_parity(got, want, False, "2-D convolve %s alpha=%s" % (kernel, alpha))
     assert_parity(generic, want, False, "generic 2-D convolve %s" % kernel)
 
