@@ -503,6 +503,19 @@ def extra_measurements(im, torch, args, image):
         for _ in range(4):
             im.blur_image(host_image, 0.0, args.sigma, out=host_out)
         extra["blur_host_buffers_Mpixels_per_s"] = round(4 * n * n / (time.perf_counter() - t0) / 1e6, 1)
+        # ... and with both pixel caches page-locked (MhHostAlloc: what the shim's allocator hands
+        # MagickCore once acceleration is on): one DMA transfer per direction, no staging threads
+        pinned_in = im.host_alloc(host.shape, host.dtype)
+        pinned_in[:] = host
+        pinned_image = im.Image(pinned_in)
+        pinned_out = im.Image(im.host_alloc(host.shape, host.dtype))
+        pinned_out.pixels[:] = 0
+        im.blur_image(pinned_image, 0.0, args.sigma, out=pinned_out)
+        t0 = time.perf_counter()
+        for _ in range(4):
+            im.blur_image(pinned_image, 0.0, args.sigma, out=pinned_out)
+        extra["blur_pinned_host_buffers_Mpixels_per_s"] = round(4 * n * n / (time.perf_counter() - t0) / 1e6, 1)
+        del pinned_image, pinned_out, pinned_in
         extra["host_link"] = ("PCIe: 57 GB/s either direction, 57 GB/s combined when both run (half duplex on "
                               "this box, tools/pcie_probe.py): 1.07 GB per 8192^2 call = 18.8 ms at best")
         del host_out

@@ -199,6 +199,27 @@ def kernel_to_numpy(kernel_string, index=0):
 
 
 # --------------------------------------------------------------------- runtime
+def host_alloc(shape, dtype):
+    """A NumPy array in page-locked host memory (MhHostAlloc): what a MagickCore pixel cache is
+    once the shim's allocator is installed (SetMagickAlignedMemoryMethods).  Operators move such
+    a buffer with one DMA transfer per direction instead of through the staging threads.  The
+    memory is released when the array (and every view of it) is gone."""
+    import weakref
+    L = _lib.load()
+    dtype = np.dtype(dtype)
+    count = int(np.prod(shape))
+    block = L.MhHostAlloc(max(count * dtype.itemsize, 1))
+    if not block:
+        raise MemoryError("MhHostAlloc(%d bytes)" % (count * dtype.itemsize))
+    raw = (ctypes.c_char * (count * dtype.itemsize)).from_address(block)
+    weakref.finalize(raw, L.MhHostFree, ctypes.c_void_p(block))
+    return np.frombuffer(raw, dtype=dtype, count=count).reshape(shape)
+
+
+def host_allocated_bytes():
+    return int(_lib.load().MhHostAllocatedBytes())
+
+
 def device_count():
     return _lib.load().MhDeviceCount()
 

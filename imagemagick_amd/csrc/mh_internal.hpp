@@ -37,6 +37,7 @@ MhStatus runtime_ready();                 // lazy MhInitialize + enabled check
 int default_device();
 int device_count();
 int compute_units(int device);          // cached multiProcessorCount
+bool host_block_is_pinned(const void *block,size_t bytes);   // inside a block of MhHostAlloc's
 MhPrecision precision();
 hipStream_t library_stream(int device);   // non-blocking stream owned by the library
 

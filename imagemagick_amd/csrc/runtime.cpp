@@ -653,6 +653,13 @@ MhStatus Resident::open(const MhImage *image,int mode,hipStream_t stream_hint,in
           hipMemcpyHostToDevice,view.stream));
       return MH_OK;
     }
+  // a pixel cache that is page-locked already (MhHostAlloc): one DMA transfer, no staging
+  if (host_block_is_pinned(image->pixels,view.bytes()))
+    {
+      if ((mode == 0) || (mode == 2))
+        MH_HIP(hipMemcpyAsync(view.pixels,image->pixels,view.bytes(),hipMemcpyHostToDevice,view.stream));
+      return MH_OK;
+    }
   pipelined_=true;
   if ((mode == 0) || (mode == 2))
     MH_TRY(transfer_image(view.device,view.stream,view.pixels,image->pixels,view.bytes(),true));
@@ -728,6 +735,32 @@ static void drain_profile()
 // ===================================================================== C ABI
 using namespace mh;
 
+// ------------------------------------------------------------ page-locked pixel caches
+namespace mh {
+struct PinnedBlocks
+{
+  std::mutex lock;
+  std::map<const char *,size_t> blocks;         // base -> bytes
+  size_t total=0;
+};
+static PinnedBlocks &pinned_blocks() { static PinnedBlocks &p=*new PinnedBlocks; return p; }
+
+// [block, block+bytes) lies inside a block of MhHostAlloc's
+bool host_block_is_pinned(const void *block,size_t bytes)
+{
+  PinnedBlocks &p=pinned_blocks();
+  std::lock_guard<std::mutex> guard(p.lock);
+  if (p.blocks.empty())
+    return false;
+  const char *at=static_cast<const char *>(block);
+  auto it=p.blocks.upper_bound(at);
+  if (it == p.blocks.begin())
+    return false;
+  --it;
+  return (at >= it->first) && (at+bytes <= it->first+it->second);
+}
+} // namespace mh
+
 extern "C" {
 
 MH_API MhStatus MhInitialize(void)
@@ -796,6 +829,48 @@ MH_API MhPrecision MhSetPrecision(MhPrecision p)
   return r.precision;
 }
 
+
+MH_API void *MhHostAlloc(size_t bytes)
+{
+  if ((runtime_ready() != MH_OK) || (bytes == 0))
+    return nullptr;
+  void *block=nullptr;
+  if (hipHostMalloc(&block,bytes,hipHostMallocPortable) != hipSuccess)
+    {
+      (void) hipGetLastError();
+      return nullptr;
+    }
+  PinnedBlocks &p=pinned_blocks();
+  std::lock_guard<std::mutex> guard(p.lock);
+  p.blocks[static_cast<const char *>(block)]=bytes;
+  p.total+=bytes;
+  return block;
+}
+
+MH_API int MhHostFree(void *block)
+{
+  if (block == nullptr)
+    return 0;
+  PinnedBlocks &p=pinned_blocks();
+  {
+    std::lock_guard<std::mutex> guard(p.lock);
+    auto it=p.blocks.find(static_cast<const char *>(block));
+    if (it == p.blocks.end())
+      return 0;
+    p.total-=it->second;
+    p.blocks.erase(it);
+  }
+  (void) hipHostFree(block);
+  return 1;
+}
+
+MH_API size_t MhHostAllocatedBytes(void)
+{
+  PinnedBlocks &p=pinned_blocks();
+  std::lock_guard<std::mutex> guard(p.lock);
+  return p.total;
+}
+
 MH_API MhStatus MhDeviceAlloc(int device,size_t bytes,void **ptr)
 {
   MH_TRY(runtime_ready());
@@ -830,7 +905,7 @@ MH_API MhStatus MhDeviceFree(int device,void *ptr)
 MH_API MhStatus MhUpload(int device,void *dst,const void *src,size_t bytes,void *stream)
 {
   MH_TRY(runtime_ready());
-  if ((bytes >= 2*kPiece) && (device >= 0) && (device < device_count()))
+  if ((bytes >= 2*kPiece) && (device >= 0) && (device < device_count()) && !host_block_is_pinned(src,bytes))
     return transfer_image(device,(hipStream_t) stream,dst,const_cast<void *>(src),bytes,true);
   MH_HIP(hipMemcpyAsync(dst,src,bytes,hipMemcpyHostToDevice,(hipStream_t) stream));
   return MH_OK;
@@ -839,7 +914,7 @@ MH_API MhStatus MhUpload(int device,void *dst,const void *src,size_t bytes,void 
 MH_API MhStatus MhDownload(int device,void *dst,const void *src,size_t bytes,void *stream)
 {
   MH_TRY(runtime_ready());
-  if ((bytes >= 2*kPiece) && (device >= 0) && (device < device_count()))
+  if ((bytes >= 2*kPiece) && (device >= 0) && (device < device_count()) && !host_block_is_pinned(dst,bytes))
     MH_TRY(transfer_image(device,(hipStream_t) stream,const_cast<void *>(src),dst,bytes,false));
   else
     MH_HIP(hipMemcpyAsync(dst,src,bytes,hipMemcpyDeviceToHost,(hipStream_t) stream));

@@ -208,6 +208,16 @@ MH_API MhStatus MhUpload(int device,void *dst_device,const void *src_host,size_t
 MH_API MhStatus MhDownload(int device,void *dst_host,const void *src_device,size_t bytes,void *stream);
 MH_API MhStatus MhSynchronize(int device,void *stream);
 
+/* Page-locked host memory for pixel caches (what SetMagickAlignedMemoryMethods,
+   MagickCore/memory.c:1541, lets an application install behind AcquireAlignedMemory,
+   cache.c:3754-3758): a host image whose `pixels` block came from MhHostAlloc moves over the
+   link with one DMA transfer per direction, no staging threads.  MhHostFree returns 1 when the
+   block was one of MhHostAlloc's (and is now released), 0 when it is not known (the caller then
+   releases it its own way).  MhHostAllocatedBytes: the bytes currently handed out. */
+MH_API void *MhHostAlloc(size_t bytes);
+MH_API int MhHostFree(void *block);
+MH_API size_t MhHostAllocatedBytes(void);
+
 /* Kernel profile records (GetOpenCLKernelProfileRecords analogue). */
 typedef struct MhKernelProfileRecord
 {

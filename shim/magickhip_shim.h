@@ -21,6 +21,9 @@ typedef struct _HipLibrary
   MhStatus (*Upload)(int,void *,const void *,size_t,void *);
   MhStatus (*Download)(int,void *,const void *,size_t,void *);
   MhStatus (*Synchronize)(int,void *);
+  void *(*HostAlloc)(size_t);
+  int (*HostFree)(void *);
+  size_t (*HostAllocatedBytes)(void);
   MhStatus (*BlurImage)(const MhImage *,MhImage *,double,double);
   MhStatus (*UnsharpMaskImage)(const MhImage *,MhImage *,double,double,double,double);
   MhStatus (*ResizeImageWithFilter)(const MhImage *,MhImage *,const MhResizeFilter *);

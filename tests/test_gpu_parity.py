@@ -1088,6 +1088,27 @@ def test_lab_contrast_stretch_three_launches(im, frame, black, white, monkeypatc
         results[0][~same][:4].tolist(), results[1][~same][:4].tolist())
 
 
+def test_page_locked_host_buffers(im, refmod):
+    """A host image whose pixels are MhHostAlloc memory (the shim's pixel-cache allocator) goes
+    up and comes down with one DMA transfer each, not through the staging threads: same result,
+    and the memory is handed back when the array dies."""
+    import gc
+    px = make_pixels(1100, 1301, 4, Q16, seed=12)             # 11 MB: above the staging threshold
+    before = im.host_allocated_bytes()
+    pinned = im.host_alloc(px.shape, px.dtype)
+    pinned[:] = px
+    out = im.host_alloc(px.shape, px.dtype)
+    assert im.host_allocated_bytes() == before + 2 * px.nbytes
+    result = im.Image(out)
+    im.blur_image(im.Image(pinned), 0.0, 2.0, out=result)
+    assert_parity(result.pixels, refmod.RefImage(px).blur(0.0, 2.0).numpy(), True, "blur, page-locked buffers")
+    plain = im.blur_image(im.Image(px), 0.0, 2.0).numpy()
+    assert np.array_equal(plain, out)
+    del result, pinned, out
+    gc.collect()
+    assert im.host_allocated_bytes() == before
+
+
 # ------------------------------------------------ Equalize / ContrastStretch
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
 @pytest.mark.parametrize("kind", ["random", "smooth"])

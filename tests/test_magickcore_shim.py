@@ -62,6 +62,39 @@ def test_large_frame_moves_through_the_staged_transfers(shim, dtype):
     assert accelerated_calls(shim, hdri) == before + 1
 
 
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_pixel_caches_are_page_locked_once_acceleration_is_switched_on(shim, dtype):
+    """SetOpenCLEnabled(MagickTrue) installs the library's page-locked allocator behind
+    AcquireAlignedMemory (SetMagickAlignedMemoryMethods, memory.c:1541): the pixel cache of an image
+    created afterwards (4 MiB and more) is hipHostMalloc memory, moves with one DMA transfer per
+    direction, and is given back when the image is destroyed; smaller caches and blocks that predate
+    the switch keep using the C allocator.  Same pixels as the CPU MagickCore."""
+    import gc
+    hdri = dtype == np.float32
+    lib = shim._load(hdri, True)
+    lib.GetMagickHipPinnedCacheExtent.restype = ctypes.c_size_t
+    lib.SetOpenCLEnabled.argtypes = [ctypes.c_int]
+    old = shim.RefImage(make_pixels(600, 700, 4, dtype, seed=5), shim=True)      # predates the switch (or not: both fine)
+    assert lib.SetOpenCLEnabled(1) == 1
+    gc.collect()
+    base = lib.GetMagickHipPinnedCacheExtent()
+    px = make_pixels(1100, 1301, 4, dtype, seed=4)
+    before = accelerated_calls(shim, hdri)
+    gpu = shim.RefImage(px, shim=True)
+    held = lib.GetMagickHipPinnedCacheExtent()
+    assert held >= base + px.nbytes, (base, held, px.nbytes)
+    small = shim.RefImage(make_pixels(40, 50, 4, dtype), shim=True)
+    assert lib.GetMagickHipPinnedCacheExtent() == held, "a 16 KB cache must not be page-locked"
+    cpu = shim.RefImage(px)
+    assert_parity(gpu.blur(0.0, 1.5).numpy(), cpu.blur(0.0, 1.5).numpy(), True, "BlurImage, page-locked cache")
+    assert accelerated_calls(shim, hdri) == before + 1
+    assert_parity(old.blur(0.0, 1.5).numpy(), shim.RefImage(make_pixels(600, 700, 4, dtype, seed=5)).blur(0.0, 1.5).numpy(),
+                  True, "BlurImage, cache from before the switch")
+    del gpu, small, old
+    gc.collect()
+    assert lib.GetMagickHipPinnedCacheExtent() <= held - px.nbytes
+
+
 def test_fast_precision_through_magickcore(shim, im):
     """MAGICK_HIP_PRECISION=fast (here: MhSetPrecision on the library instance the shim loaded):
     MagickCore's own BlurImage, GaussianBlurImage (a 2-D kernel, separated by the library) and
