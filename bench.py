@@ -73,6 +73,8 @@ def parse_args():
                          "exact: fp64 in the CPU's operation order, bit-identical")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline only: no modes / resize / configs")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from profiles/pmc_traffic.json instead of two rocprofv3 --pmc passes")
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds of back-to-back calls (0: skip)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N>1 (nccl = RCCL; gloo rehearses the N>1 control "
@@ -141,6 +143,46 @@ def pmc_traffic(kernel):
         except Exception:
             _TRAFFIC = {}
     return _TRAFFIC.get(kernel)
+
+
+def live_traffic(mode, sigma, kernel_substring="blur_fused"):
+    """HBM bytes per launch of the headline kernel, measured NOW: two `rocprofv3 --kernel-trace
+    --pmc` passes (FETCH_SIZE, WRITE_SIZE: separate passes, no other trace domain) of
+    tools/time_blur_modes.py on this GPU, corrected as profiles/pmc_traffic.json is (FETCH_SIZE in
+    KiB and doubled on gfx950, WRITE_SIZE in KiB).  None when rocprofv3 is missing or fails; about
+    five seconds."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    tool = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(tool):
+        return None
+    totals = {}
+    work = tempfile.mkdtemp(prefix="mh_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = [tool, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "pass", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "time_blur_modes.py"), mode, "8192", str(sigma), "4"]
+            done = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180)
+            if done.returncode != 0:
+                return None
+            values = []
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if kernel_substring in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        values.append(float(row["Counter_Value"]))
+            if not values:
+                return None
+            totals[counter] = sum(values) / len(values)
+        return int(round(totals["FETCH_SIZE"] * 1024.0 * 2.0 + totals["WRITE_SIZE"] * 1024.0))
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def roofline(kernel, algorithmic_bytes, avg_ms, traffic_key=None):
@@ -769,6 +811,15 @@ def main():
                                    "unit": "f16 MFMA dense" if mfma else
                                            ("f32 vector" if args.precision == "fast" else "f64 vector"),
                                    "note": "algorithmic multiply-adds only"}
+                if world == 1 and not args.no_live_traffic and dominant.startswith("blur_fused") and n == 8192:
+                    # counters of THIS run in place of the table kept under profiles/
+                    live = live_traffic(args.precision, args.sigma)
+                    roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, two passes in this run" if live
+                                              else "profiles/pmc_traffic.json (rocprofv3 did not run here)")
+                    if live:
+                        roof["traffic"] = live
+                else:
+                    roof["traffic_source"] = "profiles/pmc_traffic.json"
                 result["roofline"] = roof
             if not args.no_extra and world == 1:
                 result.update(extra_measurements(im, torch, args, image))

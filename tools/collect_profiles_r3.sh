@@ -16,10 +16,10 @@ OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- \
-  python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra > $OUT/stats.log 2>&1
+  python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra --no-live-traffic > $OUT/stats.log 2>&1
 if [ -z "$QUICK" ]; then
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_full -o bench -- \
-  python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/stats_full.log 2>&1
+  python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-live-traffic > $OUT/stats_full.log 2>&1
 fi
 workload() {
   case $1 in
