@@ -771,6 +771,60 @@ void blur_fused_exact_kernel(BlurExactArgs args)
           if (g+1 < ngroups)
             fetch(g+1);
         }
+      // ---- (COLX = false) row epilogue of group g-1: exact levels -> the f16 column pass's samples.
+      // Runs in interval A.  (-DMH_HYBRID_EPILOGUE_IN_B puts it beside the row chain of group g in
+      // interval B, which otherwise holds nothing but matrix instructions; legal — ring group g-1 is
+      // then complete at barrier Y and first read in interval A of iteration g+1 — and measured
+      // 2 % SLOWER, 0.724 against 0.707 ms: vector instructions of one wave do not hide behind the
+      // matrix instructions of another beyond what the issue model of tools/ubench says.)
+      auto row_epilogue16=[&]()
+      {
+            unsigned q[4];
+            const bool doubtful=exact_levels<BLEND>(sums_row,args,q);
+            const int x=x0+16*ot+n;
+            {
+              // source pixel (y clamped like the intermediate's rows) of lane `from`, sample v
+              auto fetch=[&](int from,int v,unsigned (&level)[4])
+              {
+                int yy=in0+G::GROUP*(g-1)+4*rq+(from >> 4);
+                yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
+                int xx=x0+16*ot+(from & 15)-args.shift+v;
+                xx=xx < 0 ? 0 : (xx > W-1 ? W-1 : xx);
+                const uint2 pixel=load_pixel16(args.src+pixel_index(yy,W,xx)*PX);
+                level[0]=pixel.x & 0xffffu; level[1]=pixel.x >> 16; level[2]=pixel.y & 0xffffu;
+                level[3]=PX == 4 ? pixel.y >> 16 : 0u;
+              };
+              recomputed+=settle_doubtful_pixels<BLEND,PX>(doubtful && (g >= 1) && (g-1 < ngroups) && (x < W),lane,
+                args.taps64,K,fetch,q);
+            }
+            // alpha*colour*2^-17 and alpha/2 (plain: level/2)
+            float v[4];
+            const f32x2 c01={(float) q[0],(float) q[1]};
+            const f32x2 c23={(float) q[2],(float) q[3]};
+            if constexpr (BLEND)
+              {
+                const float alpha=c23[1];
+                const float weight=alpha*(0.5f/65536.0f);
+                const f32x2 v01=c01*f32x2{weight,weight};
+                v[0]=v01[0]; v[1]=v01[1];
+                v[2]=c23[0]*weight;
+                v[3]=alpha*0.5f;
+              }
+            else
+              {
+                const f32x2 v01=c01*0.5f,v23=c23*0.5f;
+                v[0]=v01[0]; v[1]=v01[1]; v[2]=v23[0]; v[3]=v23[1];
+              }
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
+                         "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"
+                         : "+v"(v[0]),"+v"(v[1]),"+v"(v[2]),"+v"(v[3]));
+            uint2 hi,lo;
+            split_f16_pair(f32x2{v[0],v[1]},hi.x,lo.x);
+            split_f16_pair(f32x2{v[2],v[3]},hi.y,lo.y);
+            const int at=ring_entry16+previous*GROUP_STRIDE;
+            *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
+            *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
+                };
       MH_XTRACE_MARK(3);
       // ======================================================================== interval A
       if constexpr (COLX)
@@ -906,54 +960,9 @@ void blur_fused_exact_kernel(BlurExactArgs args)
               else if (ctiles == CT-1)
                 column_tiles(std::integral_constant<int,CT-1>{});
             }
-          // ---- row epilogue of group g-1: exact levels -> the f16 column pass's samples
-          {
-            unsigned q[4];
-            const bool doubtful=exact_levels<BLEND>(sums_row,args,q);
-            const int x=x0+16*ot+n;
-            {
-              // source pixel (y clamped like the intermediate's rows) of lane `from`, sample v
-              auto fetch=[&](int from,int v,unsigned (&level)[4])
-              {
-                int yy=in0+G::GROUP*(g-1)+4*rq+(from >> 4);
-                yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
-                int xx=x0+16*ot+(from & 15)-args.shift+v;
-                xx=xx < 0 ? 0 : (xx > W-1 ? W-1 : xx);
-                const uint2 pixel=load_pixel16(args.src+pixel_index(yy,W,xx)*PX);
-                level[0]=pixel.x & 0xffffu; level[1]=pixel.x >> 16; level[2]=pixel.y & 0xffffu;
-                level[3]=PX == 4 ? pixel.y >> 16 : 0u;
-              };
-              recomputed+=settle_doubtful_pixels<BLEND,PX>(doubtful && (g >= 1) && (g-1 < ngroups) && (x < W),lane,
-                args.taps64,K,fetch,q);
-            }
-            // alpha*colour*2^-17 and alpha/2 (plain: level/2)
-            float v[4];
-            const f32x2 c01={(float) q[0],(float) q[1]};
-            const f32x2 c23={(float) q[2],(float) q[3]};
-            if constexpr (BLEND)
-              {
-                const float alpha=c23[1];
-                const float weight=alpha*(0.5f/65536.0f);
-                const f32x2 v01=c01*f32x2{weight,weight};
-                v[0]=v01[0]; v[1]=v01[1];
-                v[2]=c23[0]*weight;
-                v[3]=alpha*0.5f;
-              }
-            else
-              {
-                const f32x2 v01=c01*0.5f,v23=c23*0.5f;
-                v[0]=v01[0]; v[1]=v01[1]; v[2]=v23[0]; v[3]=v23[1];
-              }
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
-                         "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"
-                         : "+v"(v[0]),"+v"(v[1]),"+v"(v[2]),"+v"(v[3]));
-            uint2 hi,lo;
-            split_f16_pair(f32x2{v[0],v[1]},hi.x,lo.x);
-            split_f16_pair(f32x2{v[2],v[3]},hi.y,lo.y);
-            const int at=ring_entry16+previous*GROUP_STRIDE;
-            *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
-            *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
-          }
+#ifndef MH_HYBRID_EPILOGUE_IN_B
+          row_epilogue16();
+#endif
         }
 #ifdef MH_EXACT_TRACE
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -963,6 +972,10 @@ void blur_fused_exact_kernel(BlurExactArgs args)
       MH_XTRACE_MARK(5);
       // ======================================================================== interval B
       {
+#ifdef MH_HYBRID_EPILOGUE_IN_B
+        if constexpr (!COLX)
+          row_epilogue16();
+#endif
         // ---- row chain of group g
         intx4 acc[5];
         init_tiles(acc);
