@@ -650,8 +650,8 @@ static MhStatus launch_convex(bool dilate,const ConvexArgs &args,dim3 grid,size_
 // fill with garbage (one per Row(1)) and are not stored: a workgroup produces 128-2*hmax columns.
 struct RectsArgs
 {
-  const uint16_t *src;
-  uint16_t *dst;
+  const void *src;            // Q16 or float Quantum, 4-byte multiples per pixel
+  void *dst;
   int columns,rows;
   int cx,cy;                  // centre of the shape relative to the output pixel
   int hmax,vmax;              // half-width of the widest row, half-height
@@ -671,14 +671,43 @@ static __device__ __forceinline__ uint32_t pk_pick(uint32_t a,uint32_t b)
   return __builtin_bit_cast(uint32_t,DILATE ? __builtin_elementwise_max(va,vb) : __builtin_elementwise_min(va,vb));
 }
 
-template<int C,bool DILATE,int SY,int NWAVES>
+// one 32-bit word of samples: two Q16 channels (packed compare) or one float channel.  The float
+// forms are v_max_f32 / v_min_f32: a NaN operand yields the other one, which is what the
+// reference's `if (pixels[i] > pixel)` does with a NaN neighbour (morphology.c:2995-3030).
+// (fmaxf / fminf: hipcc canonicalises both operands first — a v_max_f32 x,x each — and fuses pairs
+// into v_max3_f32 / v_min3_f32.  The bare instructions through inline asm measured slower, 5.3
+// against 4.8 ms for Dilate Disk:15 on 16384^2 float RGBA: the scheduler cannot see into them.)
+template<typename Q,bool DILATE>
+static __device__ __forceinline__ uint32_t word_pick(uint32_t a,uint32_t b)
+{
+  if constexpr (sizeof(Q) == 2)
+    return pk_pick<DILATE>(a,b);
+  else
+    {
+      const float fa=__builtin_bit_cast(float,a),fb=__builtin_bit_cast(float,b);
+      return __builtin_bit_cast(uint32_t,DILATE ? __builtin_fmaxf(fa,fb) : __builtin_fminf(fa,fb));
+    }
+}
+
+template<typename Q,bool DILATE>
+static __device__ __forceinline__ uint32_t word_pick3(uint32_t a,uint32_t b,uint32_t c)
+{
+  return word_pick<Q,DILATE>(word_pick<Q,DILATE>(a,b),c);
+}
+
+// Q: uint16_t (2 or 4 channels) or float (1, 2 or 4 channels: the reference's default build is
+// HDRI; min/max are exact in any type).  A lane holds SX columns = WPR words; RGBA float is one
+// column per lane (a wave keeps 64-2*hmax of its 64 columns).
+template<typename Q,int C,bool DILATE,int SY,int NWAVES>
 __global__ __launch_bounds__(64*NWAVES)
 void morph_rects_kernel(RectsArgs args)
 {
-  static_assert((C == 2) || (C == 4),"whole 32-bit words per pixel");
-  constexpr int SX=2;                          // columns per lane
-  constexpr int NW=C/2;                        // 32-bit words per pixel
+  constexpr int PXB=C*(int) sizeof(Q);         // bytes per pixel
+  static_assert((PXB % 4) == 0,"whole 32-bit words per pixel");
+  constexpr int NW=PXB/4;                      // 32-bit words per pixel
+  constexpr int SX=NW >= 4 ? 1 : 2;            // columns per lane
   constexpr int WPR=SX*NW;                     // words a lane holds per row
+  constexpr bool kFloat=sizeof(Q) == 4;
   constexpr int TH=SY*NWAVES;                  // output rows per workgroup
   typedef uint32_t Group __attribute__((ext_vector_type(WPR)));
   typedef Group __attribute__((aligned(4))) LooseGroup;      // global memory: pixel alignment only
@@ -697,14 +726,12 @@ void morph_rects_kernel(RectsArgs args)
   const int valid_w=64*SX-2*hmax;
   const int bx=tile_x*valid_w,by=tile_y*TH;
   const int tile_rows=TH+2*vmax;
-  const size_t pitch=(size_t) W*C;
 
   // ---- stage the edge-clamped source window (cache.c:2663-2679): tile column t is image
   // column bx+cx-hmax+t, tile row q is image row by+cy-vmax+q
   {
-    // a thread keeps its column pair and walks down the rows NWAVES apart: the column clamp and
-    // the in-frame test are done once, a row costs its clamp and one 32-bit offset (the host
-    // checks that the frame is below 4 GiB)
+    // a thread keeps its columns and walks down the rows NWAVES apart: the column clamp and the
+    // in-frame test are done once, a row costs its clamp and one (wave-uniform, 64-bit) offset
     const int sx=bx+args.cx-hmax+SX*lane,sy0=by+args.cy-vmax;
     const bool inside=(sx >= 0) && (sx+SX-1 <= W-1);
     unsigned xoff[SX];
@@ -713,9 +740,9 @@ void morph_rects_kernel(RectsArgs args)
       {
         int x=sx+j;
         x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
-        xoff[j]=(unsigned) x*(unsigned) (C*sizeof(uint16_t));
+        xoff[j]=(unsigned) x*(unsigned) PXB;
       }
-    const unsigned row_bytes=(unsigned) W*(unsigned) (C*sizeof(uint16_t));
+    const unsigned row_bytes=(unsigned) W*(unsigned) PXB;
     const unsigned char *base=reinterpret_cast<const unsigned char *>(args.src);
     constexpr int BATCH=NWAVES >= 16 ? 5 : (NWAVES >= 12 ? 4 : 7);  // Disk:15: 13 (6 waves) or 7 (12 waves) rows per thread, two round trips
     for (int q0=wave; q0 < tile_rows; q0+=NWAVES*BATCH)
@@ -728,7 +755,7 @@ void morph_rects_kernel(RectsArgs args)
             q=q < tile_rows ? q : tile_rows-1;
             int sy=sy0+q;
             sy=sy < 0 ? 0 : (sy > H-1 ? H-1 : sy);
-            const unsigned char *row=base+(unsigned) sy*row_bytes;
+            const unsigned char *row=base+(size_t) sy*row_bytes;
             if (inside)
               g[k]=*reinterpret_cast<const LooseGroup *>(row+xoff[0]);
             else
@@ -767,7 +794,7 @@ void morph_rects_kernel(RectsArgs args)
       for (int p=0; p < WPR; p++)
         {
           column[i][p]=g[p];
-          spread[i][p]=DILATE ? 0u : 0xffffffffu;
+          spread[i][p]=DILATE ? 0u : (kFloat ? 0x7f800000u : 0xffffffffu);   // 0 / QuantumRange or +inf
         }
     }
   // lane l keeps level l's reach and widening: a v_readlane per level instead of a load from the
@@ -785,25 +812,35 @@ void morph_rects_kernel(RectsArgs args)
         for (int i=0; i < SY; i++)
 #pragma unroll
           for (int p=0; p < WPR; p++)
-            spread[i][p]=pk_pick<DILATE>(spread[i][p],column[i][p]);
+            spread[i][p]=word_pick<Q,DILATE>(spread[i][p],column[i][p]);
         const int widen=__builtin_amdgcn_readlane(lane_widen,level);
         for (int step=0; step < widen; step++)
           {
-            // Row(1): every column takes in its two neighbours.  The lane's columns a b share their
-            // pair maximum: a <- b' v (a v b), b <- (a v b) v a' (b', a': the neighbour lanes')
-            static_assert(SX == 2,"the pair form");
+            // Row(1): every column takes in its two neighbours.  Two columns a b per lane share
+            // their pair maximum: a <- b' v (a v b), b <- (a v b) v a' (b', a': the neighbour lanes');
+            // one column per lane: a <- a' v a v a''
 #pragma unroll
             for (int i=0; i < SY; i++)
 #pragma unroll
               for (int w=0; w < NW; w++)
                 {
-                  const uint32_t a=spread[i][w],b=spread[i][NW+w];
                   // wave_shr:1 — lane n reads lane n-1 (0x138); wave_shl:1 — lane n reads lane n+1 (0x130)
-                  const uint32_t left=(uint32_t) __builtin_amdgcn_mov_dpp((int) b,0x138,0xf,0xf,true);
-                  const uint32_t right=(uint32_t) __builtin_amdgcn_mov_dpp((int) a,0x130,0xf,0xf,true);
-                  const uint32_t both=pk_pick<DILATE>(a,b);
-                  spread[i][w]=pk_pick<DILATE>(left,both);
-                  spread[i][NW+w]=pk_pick<DILATE>(both,right);
+                  if constexpr (SX == 2)
+                    {
+                      const uint32_t a=spread[i][w],b=spread[i][NW+w];
+                      const uint32_t left=(uint32_t) __builtin_amdgcn_mov_dpp((int) b,0x138,0xf,0xf,true);
+                      const uint32_t right=(uint32_t) __builtin_amdgcn_mov_dpp((int) a,0x130,0xf,0xf,true);
+                      const uint32_t both=word_pick<Q,DILATE>(a,b);
+                      spread[i][w]=word_pick<Q,DILATE>(left,both);
+                      spread[i][NW+w]=word_pick<Q,DILATE>(both,right);
+                    }
+                  else
+                    {
+                      const uint32_t a=spread[i][w];
+                      const uint32_t left=(uint32_t) __builtin_amdgcn_mov_dpp((int) a,0x138,0xf,0xf,true);
+                      const uint32_t right=(uint32_t) __builtin_amdgcn_mov_dpp((int) a,0x130,0xf,0xf,true);
+                      spread[i][w]=word_pick3<Q,DILATE>(left,a,right);
+                    }
                 }
           }
         level--;
@@ -828,7 +865,7 @@ void morph_rects_kernel(RectsArgs args)
               const Group &below=lower[(2+u+i)%SY];
 #pragma unroll
               for (int p=0; p < WPR; p++)
-                column[i][p]=pk_pick<DILATE>(pk_pick<DILATE>(column[i][p],above[p]),below[p]);
+                column[i][p]=word_pick3<Q,DILATE>(column[i][p],above[p],below[p]);
             }
           settle(k);
         }
@@ -849,13 +886,13 @@ void morph_rects_kernel(RectsArgs args)
           const int y=by+wave*SY+i;
           if (y >= H)
             break;
-          unsigned char *out=reinterpret_cast<unsigned char *>(args.dst)+(unsigned) y*((unsigned) W*(unsigned) (C*sizeof(uint16_t)));
+          unsigned char *out=reinterpret_cast<unsigned char *>(args.dst)+(size_t) y*((size_t) W*(size_t) PXB);
           Group result;
 #pragma unroll
           for (int p=0; p < WPR; p++)
             result[p]=spread[i][p];
           if (whole)
-            *reinterpret_cast<LooseGroup *>(out+(unsigned) (bx+u0)*(unsigned) (C*sizeof(uint16_t)))=result;
+            *reinterpret_cast<LooseGroup *>(out+(unsigned) (bx+u0)*(unsigned) PXB)=result;
           else
             {
 #pragma unroll
@@ -863,7 +900,7 @@ void morph_rects_kernel(RectsArgs args)
                 if ((u0+j >= 0) && (u0+j < valid_w) && (bx+u0+j < W))
 #pragma unroll
                   for (int w=0; w < NW; w++)
-                    *reinterpret_cast<uint32_t *>(out+(unsigned) (bx+u0+j)*(unsigned) (C*sizeof(uint16_t))+4*w)=result[j*NW+w];
+                    *reinterpret_cast<uint32_t *>(out+(unsigned) (bx+u0+j)*(unsigned) PXB+4*w)=result[j*NW+w];
             }
         }
       return;
@@ -874,8 +911,8 @@ void morph_rects_kernel(RectsArgs args)
       const int y=by+wave*SY+i;
       if (y >= H)
         break;
-      uint16_t *out_row=args.dst+(size_t) y*pitch;
-      const uint16_t *in_row=args.src+(size_t) y*pitch;
+      unsigned char *out_row=reinterpret_cast<unsigned char *>(args.dst)+(size_t) y*((size_t) W*(size_t) PXB);
+      const unsigned char *in_row=reinterpret_cast<const unsigned char *>(args.src)+(size_t) y*((size_t) W*(size_t) PXB);
       bool ok[SX];
 #pragma unroll
       for (int j=0; j < SX; j++)
@@ -888,32 +925,52 @@ void morph_rects_kernel(RectsArgs args)
       if (centred)
         original=centre[i*64];                 // the output pixel is the centre of its own window
       else if (all)
-        original=*reinterpret_cast<const LooseGroup *>(in_row+(size_t) (bx+u0)*C);
+        original=*reinterpret_cast<const LooseGroup *>(in_row+(unsigned) (bx+u0)*(unsigned) PXB);
       else
         {
 #pragma unroll
           for (int j=0; j < SX; j++)
 #pragma unroll
             for (int w=0; w < NW; w++)
-              original[j*NW+w]=ok[j] ? *reinterpret_cast<const uint32_t *>(in_row+(size_t) (bx+u0+j)*C+2*w) : 0u;
+              original[j*NW+w]=ok[j] ? *reinterpret_cast<const uint32_t *>(in_row+(unsigned) (bx+u0+j)*(unsigned) PXB+4*w) : 0u;
         }
       Group result;
 #pragma unroll
       for (int p=0; p < WPR; p++)
         {
-          // Erode starts from the output pixel itself (morphology.c:2905-2912)
-          const uint32_t value=DILATE ? spread[i][p] : pk_pick<false>(spread[i][p],original[p]);
-          const int c0=2*(p % NW);             // channels of this word's halves
-          uint32_t keep=0u;
-          keep|=((args.copy_mask >> c0) & 1u) != 0u ? 0x0000ffffu : 0u;
-          keep|=((args.copy_mask >> (c0+1)) & 1u) != 0u ? 0xffff0000u : 0u;
-          result[p]=(original[p] & keep) | (value & ~keep);
-          const uint32_t differs=(value ^ original[p]) & ~keep;
-          if (ok[p/NW])
-            changed+=((differs & 0xffffu) != 0u ? 1u : 0u)+((differs >> 16) != 0u ? 1u : 0u);
+          if constexpr (kFloat)
+            {
+              // one channel per word.  Erode starts from the output pixel itself
+              // (morphology.c:2905-2912): a NaN there stays (no `<` is true against it)
+              const int c=p % NW;
+              const uint32_t mine_bits=original[p];    // (a copy: __builtin_bit_cast of the vector
+              const float mine=__builtin_bit_cast(float,mine_bits);   // element itself reads element 0)
+              uint32_t value=spread[i][p];
+              if (!DILATE)
+                value=mine != mine ? mine_bits : word_pick<Q,false>(value,mine_bits);
+              const bool keep=((args.copy_mask >> c) & 1u) != 0u;
+              result[p]=keep ? mine_bits : value;
+              // morphology.c:3195: fabs(pixel-p[center+i]) >= MagickEpsilon
+              if (!keep && ok[p/NW] &&
+                  (fabs((double) __builtin_bit_cast(float,value)-(double) mine) >= kEps))
+                changed++;
+            }
+          else
+            {
+              // Erode starts from the output pixel itself (morphology.c:2905-2912)
+              const uint32_t value=DILATE ? spread[i][p] : pk_pick<false>(spread[i][p],original[p]);
+              const int c0=2*(p % NW);             // channels of this word's halves
+              uint32_t keep=0u;
+              keep|=((args.copy_mask >> c0) & 1u) != 0u ? 0x0000ffffu : 0u;
+              keep|=((args.copy_mask >> (c0+1)) & 1u) != 0u ? 0xffff0000u : 0u;
+              result[p]=(original[p] & keep) | (value & ~keep);
+              const uint32_t differs=(value ^ original[p]) & ~keep;
+              if (ok[p/NW])
+                changed+=((differs & 0xffffu) != 0u ? 1u : 0u)+((differs >> 16) != 0u ? 1u : 0u);
+            }
         }
       if (all)
-        *reinterpret_cast<LooseGroup *>(out_row+(size_t) (bx+u0)*C)=result;
+        *reinterpret_cast<LooseGroup *>(out_row+(unsigned) (bx+u0)*(unsigned) PXB)=result;
       else
         {
 #pragma unroll
@@ -921,7 +978,7 @@ void morph_rects_kernel(RectsArgs args)
             if (ok[j])
 #pragma unroll
               for (int w=0; w < NW; w++)
-                *reinterpret_cast<uint32_t *>(out_row+(size_t) (bx+u0+j)*C+2*w)=result[j*NW+w];
+                *reinterpret_cast<uint32_t *>(out_row+(unsigned) (bx+u0+j)*(unsigned) PXB+4*w)=result[j*NW+w];
         }
     }
   if (args.changed != nullptr)
@@ -932,29 +989,32 @@ void morph_rects_kernel(RectsArgs args)
     }
 }
 
-template<int C,bool DILATE,int SY,int WAVES>
+template<typename Q,int C,bool DILATE,int SY,int WAVES>
 static MhStatus launch_rects_typed(const RectsArgs &args,size_t lds,hipStream_t stream)
 {
   const dim3 grid((unsigned) (8*args.tiles_per_xcd)),block(64*WAVES);
-  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&morph_rects_kernel<C,DILATE,SY,WAVES>),
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&morph_rects_kernel<Q,C,DILATE,SY,WAVES>),
     hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
-  hipLaunchKernelGGL((morph_rects_kernel<C,DILATE,SY,WAVES>),grid,block,lds,stream,args);
+  hipLaunchKernelGGL((morph_rects_kernel<Q,C,DILATE,SY,WAVES>),grid,block,lds,stream,args);
   MH_HIP(hipGetLastError());
   return MH_OK;
 }
 
 // shape: 0 = 6 waves x 8 rows, 1 = 12 waves x 4 rows, 3 = 16 waves x 3 rows (48 output rows
-// each), 2 = 12 waves x 8 rows
-template<int C>
+// each), 2 = 12 waves x 8 rows (Q16; float Quantum runs shape 1)
+template<typename Q,int C>
 static MhStatus launch_rects(bool dilate,int shape,const RectsArgs &args,size_t lds,hipStream_t stream)
 {
-  if (shape == 3)
-    return dilate ? launch_rects_typed<C,true,3,16>(args,lds,stream) : launch_rects_typed<C,false,3,16>(args,lds,stream);
-  if (shape == 2)
-    return dilate ? launch_rects_typed<C,true,8,12>(args,lds,stream) : launch_rects_typed<C,false,8,12>(args,lds,stream);
-  if (shape == 1)
-    return dilate ? launch_rects_typed<C,true,4,12>(args,lds,stream) : launch_rects_typed<C,false,4,12>(args,lds,stream);
-  return dilate ? launch_rects_typed<C,true,8,6>(args,lds,stream) : launch_rects_typed<C,false,8,6>(args,lds,stream);
+  if constexpr (sizeof(Q) == 2)
+    {
+      if (shape == 3)
+        return dilate ? launch_rects_typed<Q,C,true,3,16>(args,lds,stream) : launch_rects_typed<Q,C,false,3,16>(args,lds,stream);
+      if (shape == 2)
+        return dilate ? launch_rects_typed<Q,C,true,8,12>(args,lds,stream) : launch_rects_typed<Q,C,false,8,12>(args,lds,stream);
+      if (shape == 0)
+        return dilate ? launch_rects_typed<Q,C,true,8,6>(args,lds,stream) : launch_rects_typed<Q,C,false,8,6>(args,lds,stream);
+    }
+  return dilate ? launch_rects_typed<Q,C,true,4,12>(args,lds,stream) : launch_rects_typed<Q,C,false,4,12>(args,lds,stream);
 }
 
 // ------------------------------------------------ the same evaluation as a walk down a strip
@@ -1347,8 +1407,11 @@ static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std:
 {
   *handled=false;
   const int span=(int) half.size();
-  if ((src.quantum != MH_QUANTUM_U16) || ((src.channels != 4) && (src.channels != 2)) || ((span & 1) == 0) ||
-      (getenv("MAGICKHIP_NO_RECTS") != nullptr))
+  const bool is_float=src.quantum != MH_QUANTUM_U16;
+  const bool layout=is_float ? ((src.channels == 1) || (src.channels == 2) || (src.channels == 4)) :
+    ((src.channels == 2) || (src.channels == 4));
+  if (!layout || ((span & 1) == 0) || (getenv("MAGICKHIP_NO_RECTS") != nullptr) ||
+      (is_float && (getenv("MAGICKHIP_NO_FLOAT_RECTS") != nullptr)))
     return MH_OK;
   const int vmax=span/2;
   for (int d=0; d <= vmax; d++)
@@ -1359,14 +1422,19 @@ static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std:
         return MH_OK;
     }
   const int hmax=half[(size_t) vmax];
-  const size_t row_lds=64u*2u*(size_t) src.channels*sizeof(uint16_t);
+  // a lane holds one (16-byte pixels) or two columns, a wave 64 or 128 (morph_rects_kernel)
+  const size_t pixel_bytes=(size_t) src.channels*(is_float ? sizeof(float) : sizeof(uint16_t));
+  const int lane_columns=pixel_bytes >= 16 ? 1 : 2;
+  const int wave_columns=64*lane_columns;
+  const size_t row_lds=(size_t) wave_columns*pixel_bytes;
   int shape=1;
   if (const char *e=getenv("MAGICKHIP_RECTS_SHAPE"))
     shape=(atoi(e) >= 0) && (atoi(e) <= 3) ? atoi(e) : 0;
+  if (is_float)
+    shape=1;
   const int th=shape == 2 ? 96 : 48;
   const size_t lds=(size_t) (th+2*vmax)*row_lds;
-  if ((hmax > 32) || (lds > 160u*1024u) ||
-      ((unsigned long long) src.columns*src.rows*src.channels*sizeof(uint16_t) >= (1ull << 32)))
+  if ((wave_columns-2*hmax < 16) || (lds > 160u*1024u))
     return MH_OK;
   RectsArgs a;
   // levels: distinct half-widths ascending; reach = the outermost row at least that wide
@@ -1385,8 +1453,8 @@ static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std:
       a.widen[l]=(unsigned char) (widths[l]-(l == 0 ? 0 : widths[l-1]));
       a.reach[l]=(unsigned char) reach;
     }
-  a.src=static_cast<const uint16_t *>(src.pixels);
-  a.dst=static_cast<uint16_t *>(dst.pixels);
+  a.src=src.pixels;
+  a.dst=dst.pixels;
   a.columns=(int) src.columns;
   a.rows=(int) src.rows;
   a.cx=cx;
@@ -1403,7 +1471,8 @@ static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std:
     constexpr int kStripRows=24;
     const size_t strip_lds=(size_t) (2*kStripRows+2*vmax)*2u*row_lds;
     const int strip_w=256-2*hmax;
-    if ((strip_lds <= 160u*1024u) && ((int) src.columns >= 2*strip_w) &&
+    if (!is_float && ((unsigned long long) src.columns*src.rows*pixel_bytes < (1ull << 32)) &&
+        (strip_lds <= 160u*1024u) && ((int) src.columns >= 2*strip_w) &&
         ((int) src.rows >= 4*kStripRows) && (getenv("MAGICKHIP_STRIPS") != nullptr))
       {
         StripsArgs sa;
@@ -1440,17 +1509,26 @@ static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std:
         return MH_OK;
       }
   }
-  const int valid_w=128-2*hmax;
+  const int valid_w=wave_columns-2*hmax;
   a.tiles_x=((int) src.columns+valid_w-1)/valid_w;
   a.tiles_y=((int) src.rows+th-1)/th;
   a.tiles_per_xcd=(a.tiles_x*a.tiles_y+7)/8;
   a.copy_mask=roles.copy_mask;
   a.changed=changed;
   ProfileScope prof("morph_rects",src.stream);
-  if (src.channels == 4)
-    MH_TRY(launch_rects<4>(dilate,shape,a,lds,src.stream));
+  if (is_float)
+    {
+      if (src.channels == 4)
+        MH_TRY((launch_rects<float,4>(dilate,shape,a,lds,src.stream)));
+      else if (src.channels == 2)
+        MH_TRY((launch_rects<float,2>(dilate,shape,a,lds,src.stream)));
+      else
+        MH_TRY((launch_rects<float,1>(dilate,shape,a,lds,src.stream)));
+    }
+  else if (src.channels == 4)
+    MH_TRY((launch_rects<uint16_t,4>(dilate,shape,a,lds,src.stream)));
   else
-    MH_TRY(launch_rects<2>(dilate,shape,a,lds,src.stream));
+    MH_TRY((launch_rects<uint16_t,2>(dilate,shape,a,lds,src.stream)));
   *handled=true;
   return MH_OK;
 }
