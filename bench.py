@@ -453,6 +453,27 @@ def c5_config(im, torch, gen):
         "kernels": kernel_rooflines(prof, {"morph_rects": 2.0 * frame, "morph_convex": 2.0 * frame,
                                            "morph2d": 2.0 * frame}, "c5:")}
     holder.clear()
+    # the same frame as float Quantum (HDRI, the reference's configure default): 4.3 GB in, 4.3 GB out
+    try:
+        srcf = src5.view(torch.int16).to(torch.float32)
+        srcf = torch.where(srcf < 0, srcf + 65536.0, srcf)
+        imgf = im.Image(srcf)
+
+        def dilate_float():
+            holder["o"] = None
+            holder["o"] = im.morphology_image(imgf, "Dilate", 1, "Disk:15")
+        sec = timed(torch, dilate_float, 2)
+        prof = kernel_profile(im, dilate_float, 2)
+        out["c5_dilate_disk15_hdri"] = {
+            "workload": "16384x16384 RGBA float Quantum MorphologyImage(Dilate, Disk:15)",
+            "Mpixels_per_s": round(k * k / sec / 1e6, 1), "ms": round(sec * 1e3, 3),
+            "kernels": kernel_rooflines(prof, {"morph_rects": 4.0 * frame, "morph_convex": 4.0 * frame,
+                                               "morph2d": 4.0 * frame}, "c5hdri:")}
+        holder.clear()
+        del imgf, srcf
+        torch.cuda.empty_cache()
+    except Exception as exc:                                 # (memory: 3 x 4.3 GB beside the Q16 frames)
+        out["c5_dilate_disk15_hdri"] = {"error": str(exc)[:200]}
 
     def convolve():
         holder["o"] = im.morphology_image(img5, "Convolve", 1, "Disk:15", scale=(1.0, 1))
