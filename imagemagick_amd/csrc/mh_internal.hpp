@@ -328,6 +328,8 @@ MhStatus launch_wavelet_denoise(const View &src,const View &dst,double threshold
 void release_color_tables();          // frees the per-device transfer-function tables
 MhStatus launch_gray_check(const View &img,const MhImage *desc,unsigned int *flag_device);
 MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,const MhImage *desc);
+MhStatus launch_stretch_levels_apply(const View &img,const unsigned long long *hist,double black_point,
+  double white_limit,uint32_t update_mask,const unsigned int *colour_flag);
 MhStatus launch_lab_fast_contrast_stretch(const View &img,const MhImage *lab_desc,double black_point,
   double white_limit,uint32_t update_mask,bool *fused);
 MhStatus launch_lab_fast_with_histogram(const View &img,const MhImage *lab_desc,unsigned long long *hist,

@@ -138,6 +138,16 @@ static MhStatus apply_lut_host(const View &view,const MhImage *desc,const double
 MhStatus apply_histogram_lut(const View &view,const MhImage *image,const unsigned long long *hist,
   int mode,bool equalize,double black_point,double white_limit,const unsigned int *colour_flag)
 {
+  if (!equalize && (view.channels <= 4) && (getenv("MAGICKHIP_NO_STRETCH_LEVELS") == nullptr))
+    {
+      // ContrastStretchImage: the levels of every channel, then the map evaluated per sample — no
+      // table to build and gather from (pointwise.hip)
+      uint32_t update=0;
+      for (uint32_t c=0; c < image->number_channels; c++)
+        if ((image->channel_traits[c] & MH_TRAIT_UPDATE) != 0)
+          update|=1u<<c;
+      return launch_stretch_levels_apply(view,hist,black_point,white_limit,update,colour_flag);
+    }
   const size_t n=(size_t) MH_HISTOGRAM_BINS*(size_t) view.channels;
   Temp lut,mask;
   MH_TRY(lut.alloc(view.device,n*(view.quantum == MH_QUANTUM_U16 ? sizeof(unsigned short) :

@@ -1878,6 +1878,112 @@ MhStatus launch_build_lut(const View &img,const unsigned long long *hist,bool eq
   return MH_OK;
 }
 
+// ContrastStretchImage without the 65536 x channels table: the two scan kernels above leave the
+// black and the white level of every channel in the scratch block, and this kernel evaluates
+// enhance.c:1685-1706's map per sample (as lut_stretch_map_kernel would have tabulated it — the
+// same expressions, so the same bits) for Q16 and float Quantum, any channel count, intensity or
+// per-channel binning.  A float frame gathered four floats per pixel from a 1 MB table before
+// (1.4 ms per 8192^2 RGBA frame); a Q16 frame staged a 128 KB column in LDS per workgroup.
+template<typename Q,int C>
+__global__ __launch_bounds__(256)
+void stretch_apply_levels_kernel(Q *pixels,size_t npixels,const LutScratch *scratch,uint32_t mask,
+  const unsigned int *colour_flag)
+{
+  if ((colour_flag != nullptr) && (*colour_flag == 0))
+    return;                                      // the image is gray: every channel is left alone
+  constexpr int is_u16=sizeof(Q) == 2 ? 1 : 0;
+  int black_i[C],white_i[C];
+  double black[C],scale[C];
+  uint32_t apply=0;
+#pragma unroll
+  for (int c=0; c < C; c++)
+    {
+      // black[i]=(Quantum) j, enhance.c:1668: a scan that found no bin above black_point ends with
+      // j = 65536, which the Q16 build stores as (unsigned short) 65536 = 0
+      black_i[c]=((is_u16 != 0) && (scratch->black[c] == 65536)) ? 0 : scratch->black[c];
+      white_i[c]=scratch->white[c];
+      black[c]=(double) black_i[c];
+      scale[c]=65535.0*perceptible_reciprocal((double) white_i[c]-black[c]);
+      if ((black_i[c] != white_i[c]) && (((mask >> c) & 1u) != 0u))
+        apply|=1u << c;
+    }
+  if (apply == 0u)
+    return;
+  constexpr int BATCH=4;
+  const size_t stride=(size_t) gridDim.x*blockDim.x*BATCH;
+  for (size_t i0=(size_t) blockIdx.x*blockDim.x*BATCH+threadIdx.x; i0 < npixels; i0+=stride)
+    {
+      Q q[BATCH][C];
+#pragma unroll
+      for (int k=0; k < BATCH; k++)
+        {
+          const size_t i=i0+(size_t) k*blockDim.x;
+          load_pixel<Q,C>(pixels+(i < npixels ? i : npixels-1)*C,q[k]);
+        }
+#pragma unroll
+      for (int k=0; k < BATCH; k++)
+        {
+          const size_t i=i0+(size_t) k*blockDim.x;
+          if (i >= npixels)
+            continue;
+#pragma unroll
+          for (int c=0; c < C; c++)
+            if ((apply >> c) & 1u)
+              {
+                const int j=(int) QuantumOps<Q>::map_index(q[k][c]);
+                double v=lut_scale_map_to_quantum(scale[c]*((double) j-black[c]),is_u16);   // 65535.0*gamma*((double) j-black)
+                v=j > white_i[c] ? 65535.0 : v;
+                v=j < black_i[c] ? 0.0 : v;        // (tested first in enhance.c:1694)
+                q[k][c]=(Q) v;
+              }
+          store_pixel<Q,C>(pixels+i*C,q[k]);
+        }
+    }
+}
+
+// levels of every channel from the table [65536][channels], then the map: three launches
+MhStatus launch_stretch_levels_apply(const View &img,const unsigned long long *hist,double black_point,
+  double white_limit,uint32_t update_mask,const unsigned int *colour_flag)
+{
+  LutBuildArgs a;
+  a.hist=hist;
+  a.channels=img.channels;
+  a.equalize=0;
+  a.black_point=black_point;
+  a.white_limit=white_limit;
+  a.is_u16=img.quantum == MH_QUANTUM_U16 ? 1 : 0;
+  a.lut=nullptr;
+  a.colour_flag=colour_flag;
+  Temp scratch;
+  MH_TRY(scratch.alloc(img.device,sizeof(LutScratch)+sizeof(uint32_t),img.stream));
+  LutScratch *levels=scratch.as<LutScratch>();
+  a.mask=reinterpret_cast<uint32_t *>(levels+1);   // (the scan kernels keep their mask word)
+  const dim3 grid((unsigned) img.channels,kLutChunks);
+  {
+    ProfileScope prof("build_lut",img.stream);
+    hipLaunchKernelGGL(lut_chunk_sums_kernel,grid,dim3(1024),0,img.stream,a,levels);
+    hipLaunchKernelGGL(lut_scan_kernel,grid,dim3(1024),0,img.stream,a,levels);
+  }
+  const size_t n=img.columns*img.rows;
+  {
+    ProfileScope prof("apply_lut",img.stream);
+    const dim3 apply_grid(stream_grid((n+3)/4)),block(256);
+#define MH_CASE(QT) \
+    switch (img.channels) { \
+      case 1: hipLaunchKernelGGL((stretch_apply_levels_kernel<QT,1>),apply_grid,block,0,img.stream,static_cast<QT *>(img.pixels),n,levels,update_mask,colour_flag); break; \
+      case 2: hipLaunchKernelGGL((stretch_apply_levels_kernel<QT,2>),apply_grid,block,0,img.stream,static_cast<QT *>(img.pixels),n,levels,update_mask,colour_flag); break; \
+      case 3: hipLaunchKernelGGL((stretch_apply_levels_kernel<QT,3>),apply_grid,block,0,img.stream,static_cast<QT *>(img.pixels),n,levels,update_mask,colour_flag); break; \
+      default: hipLaunchKernelGGL((stretch_apply_levels_kernel<QT,4>),apply_grid,block,0,img.stream,static_cast<QT *>(img.pixels),n,levels,update_mask,colour_flag); break; }
+    if (img.quantum == MH_QUANTUM_U16)
+      { MH_CASE(uint16_t) }
+    else
+      { MH_CASE(float) }
+#undef MH_CASE
+  }
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 // ---------------------------------------------------------------- LUT apply
 template<typename Q,int C>
 __global__ __launch_bounds__(256)
@@ -2618,12 +2724,42 @@ MhStatus launch_function(const View &img,int function,size_t count,const double 
 }
 
 // ---------------------------------------------------------------- gray scan
+// SetImageGray's scan (attribute.c:1416-1450: IsPixelGray on every pixel).  A wave leaves at its
+// first colour pixel and reports it with a plain store — on a colour frame the kernel used to be
+// 32 768 atomicOr on one word (0.4 ms per 8192^2 RGBA call, more than the histogram) — and Q16
+// pixels are compared as integers (|a-b| <
+// MagickEpsilon on integer levels is a == b), two RGBA pixels per 16-byte load.
 template<typename Q,int C>
 __global__ __launch_bounds__(256)
 void gray_check_kernel(const Q *pixels,size_t npixels,unsigned int *not_gray)
 {
   const size_t stride=(size_t) gridDim.x*blockDim.x;
   bool bad=false;
+  if constexpr ((sizeof(Q) == 2) && (C == 4))
+    {
+      if ((reinterpret_cast<uintptr_t>(pixels) & 15u) == 0)
+        {
+          const uint4 *pairs=reinterpret_cast<const uint4 *>(pixels);
+          const size_t npairs=npixels/2;
+          for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npairs; i+=stride)
+            {
+              const uint4 v=pairs[i];
+              // red == green and green == blue, both pixels
+              bad=(((v.x >> 16) ^ v.x) & 0xffffu) != 0u || ((v.y ^ v.x) & 0xffffu) != 0u ||
+                  (((v.z >> 16) ^ v.z) & 0xffffu) != 0u || ((v.w ^ v.z) & 0xffffu) != 0u;
+              if (__any(bad))
+                break;
+            }
+          if (((npixels & 1u) != 0) && (blockIdx.x == 0) && (threadIdx.x == 0))
+            {
+              const uint16_t *last=pixels+(npixels-1)*4;
+              bad=bad || (last[0] != last[1]) || (last[1] != last[2]);
+            }
+          if (__any(bad) && ((threadIdx.x & 63) == 0))
+            *not_gray=1u;                        // (a plain store: every writer writes the same 1)
+          return;
+        }
+    }
   for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
     {
       Q q[C];
@@ -2632,9 +2768,11 @@ void gray_check_kernel(const Q *pixels,size_t npixels,unsigned int *not_gray)
       double rg=(double) q[0]-(double) q[1],gb=(double) q[1]-(double) q[2];
       if (!((fabs(rg) < kEps) && (fabs(gb) < kEps)))
         bad=true;
+      if (__any(bad))
+        break;
     }
   if (__any(bad) && ((threadIdx.x & 63) == 0))
-    atomicOr(not_gray,1u);
+    *not_gray=1u;
 }
 
 MhStatus launch_gray_check(const View &img,const MhImage *,unsigned int *flag)
