@@ -542,6 +542,21 @@ def extra_measurements(im, torch, args, image):
         if args.precision == "fast":
             sec = timed(torch, lambda: im.gaussian_blur_image(image, 0.0, args.sigma), 5)
             extra["gaussian_blur_2d_kernel_Mpixels_per_s"] = round(n * n / sec / 1e6, 1)
+            # GaussianBlurImage (a 79 x 79 kernel for sigma 10) bit-identical: two fp64 passes over
+            # alpha-premultiplied doubles + tie check (convolve_separable.hip), Q16 and float Quantum
+            try:
+                im.set_precision(im.PRECISION_EXACT)
+                sec = timed(torch, lambda: im.gaussian_blur_image(image, 0.0, args.sigma), 3)
+                extra["gaussian_blur_2d_exact_Mpixels_per_s"] = round(n * n / sec / 1e6, 1)
+                as_float = image.pixels.view(torch.int16).to(torch.float32)
+                as_float = torch.where(as_float < 0, as_float + 65536.0, as_float)
+                float_image = im.Image(as_float)
+                sec = timed(torch, lambda: im.gaussian_blur_image(float_image, 0.0, args.sigma), 3)
+                extra["gaussian_blur_2d_exact_hdri_Mpixels_per_s"] = round(n * n / sec / 1e6, 1)
+                del float_image, as_float
+            finally:
+                im.set_precision(im.PRECISION_FAST)
+            torch.cuda.empty_cache()
         # reference point for the roofline: what a plain device copy of the same frame reaches
         mirror = torch.empty_like(image.pixels)
         sec = timed(torch, lambda: mirror.copy_(image.pixels), 10)

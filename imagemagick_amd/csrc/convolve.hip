@@ -1669,6 +1669,18 @@ static MhStatus launch_row_alpha_audit(const View &src,const View &dst,const Con
   return MH_OK;
 }
 
+// One 1-D pass over [rows][columns][4] DOUBLES (un-normalised sums in, sums out): fused
+// multiply-adds, nothing rounded to a Quantum — the passes of convolve_separable.hip.  The Views'
+// `pixels` point at doubles; their quantum field is not looked at.
+MhStatus launch_conv1d_sums64(const View &src,const View &dst,bool vertical,const Conv1DParams &params)
+{
+  Roles plain;
+  plain.update_mask=0xfu;
+  if ((params.ntaps >= 16) && (getenv("MAGICKHIP_NO_TRI") == nullptr))
+    return launch_tri<double,4,false,Fma64,8,8>(src,dst,vertical,params,plain,nullptr);
+  return launch_one<double,4,false,Fma64,8>(src,dst,vertical,params,plain,nullptr);
+}
+
 MhStatus launch_conv1d_sums(const View &src,const View &dst,bool vertical,const Conv1DParams &params,
   bool blend,bool *handled)
 {

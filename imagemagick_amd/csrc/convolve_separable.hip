@@ -1,0 +1,412 @@
+// 2-D ConvolveMorphology with a kernel that is an outer product (GaussianBlurImage's Gaussian:RxS,
+// Square, Rectangle, any column x row product), BIT-IDENTICAL to the reference at the cost of two
+// 1-D passes — for Q16 and for float Quantum, every layout.
+//
+// The reference walks the whole w x h window per sample (MagickCore/morphology.c:2919-2979:
+// pixel += alpha*k*p, gamma += alpha*k over the reflected kernel, then gamma = 1/gamma, ClampTo-
+// Quantum(gamma*pixel), :3192-3194): 361 cells for GaussianBlur 0x3, 6241 for 0x10 — 22 ms and
+// 260 ms per 8192^2 frame in the generic kernel.  Here
+//   1. separable_premultiply_kernel   P = (alpha*p .., alpha) as four DOUBLES per pixel (a product
+//                                     of two Quantum values is exact in fp64), and the largest
+//                                     |P_c| of the frame per channel (float Quantum);
+//   2. two passes of the fp64 1-D kernels of convolve.hip over P (launch_conv1d_sums64): fused
+//      multiply-adds, nothing rounded to a Quantum in between — S = sum_v col[v] sum_u row[u] P;
+//   3. separable_finish_kernel        value = S_c/S_alpha (or S_c), rounded to the Quantum — unless
+//      it lies closer to a rounding boundary than the two evaluations can differ: the kernel's cells
+//      are the outer product only to 1e-13 of the largest cell (rank_one_factors, operators.cpp), the
+//      summation orders differ by a few 1e-16 per term.  Those samples (a few per million) are
+//      recomputed by conv2d_reference_sample in the reference's own order from the source frame.
+// Edge policy: the reference clamps the window per axis (cache.c:2663-2679), so does each pass.
+#include "mh_internal.hpp"
+#include "device_common.hpp"
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+namespace mh {
+
+// One output sample exactly as morphology.c:2919-2979 forms it, by a whole wave (every lane calls
+// it with the same arguments and gets the same result).  `values`: the kernel's cells in its own
+// order ([kh][kw], no NaN); the window's top-left is (x-shiftx, y-shifty).  The reference's terms
+// alpha*k*p and alpha*k are rounded on their own, so 64 of them are formed at a time, one per
+// lane; its two running sums take them in the reference's order through v_readlane — a scalar
+// walk of the 6241 cells of GaussianBlur 0x10 paid a full memory latency per cell (1.5 ms per
+// sample; 86 000 undecided samples of a float 8192^2 frame: 46 ms).
+template<typename Q,int C,bool BLEND>
+static __device__ __forceinline__ Q conv2d_reference_sample(const Q *src,int W,int H,int x,int y,int c,
+  const double *values,int kw,int kh,int shiftx,int shifty,int lane)
+{
+  const int cells=kw*kh;
+  const bool weighted=BLEND && (c != C-1);
+  double pixel=0.0,gamma=weighted ? 0.0 : 1.0;
+  for (int base=0; base < cells; base+=64)
+    {
+      const int at=base+lane;
+      double term=0.0,weight=0.0;
+      if (at < cells)
+        {
+          const int v=at/kw,u=at-v*kw;
+          int yy=y-shifty+v,xx=x-shiftx+u;
+          yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
+          xx=xx < 0 ? 0 : (xx > W-1 ? W-1 : xx);
+          const Q *sample=src+((size_t) yy*W+(size_t) xx)*C;
+          const double cell=values[cells-1-at];      // k starts at the last cell and walks backwards
+          if (weighted)
+            {
+              const double alpha=kQS*(double) sample[C-1];
+              weight=alpha*cell;
+              term=weight*(double) sample[c];          // alpha*(*k)*pixels[i]
+            }
+          else
+            term=cell*(double) sample[c];
+        }
+      const int count=cells-base < 64 ? cells-base : 64;
+      for (int j=0; j < count; j++)
+        {
+          const int lo=__builtin_amdgcn_readlane((int) (unsigned) __double_as_longlong(term),j);
+          const int hi=__builtin_amdgcn_readlane((int) (unsigned) (__double_as_longlong(term) >> 32),j);
+          pixel+=__longlong_as_double(((long long) hi << 32) | (long long) (unsigned) lo);
+          if (weighted)
+            {
+              const int wlo=__builtin_amdgcn_readlane((int) (unsigned) __double_as_longlong(weight),j);
+              const int whi=__builtin_amdgcn_readlane((int) (unsigned) (__double_as_longlong(weight) >> 32),j);
+              gamma+=__longlong_as_double(((long long) whi << 32) | (long long) (unsigned) wlo);
+            }
+        }
+    }
+  gamma=perceptible_reciprocal(gamma);
+  return QuantumOps<Q>::clamp(gamma*pixel);
+}
+
+struct SeparableArgs
+{
+  const void *src;
+  void *dst;
+  double *sums;               // [rows][columns][4]
+  double *bound;              // [4]: largest |P_c| of the frame (float Quantum)
+  int columns,rows;
+  const double *values;       // the kernel's cells (device)
+  int kw,kh,shiftx,shifty;
+  double error_unit;          // |difference of the two evaluations| <= error_unit * max|P_c|
+  double tie_margin;          // Q16: levels within this of n+1/2 are recomputed
+  unsigned long long *recomputed;
+};
+
+template<typename Q,int C,bool BLEND>
+__global__ __launch_bounds__(256)
+void separable_premultiply_kernel(SeparableArgs a)
+{
+  const Q *src=static_cast<const Q *>(a.src);
+  const size_t n=(size_t) a.columns*a.rows;
+  double most[4]={0.0,0.0,0.0,0.0};
+  for (size_t i=(size_t) blockIdx.x*256u+threadIdx.x; i < n; i+=(size_t) gridDim.x*256u)
+    {
+      Q q[C];
+      load_pixel<Q,C>(src+i*C,q);
+      double p[4]={0.0,0.0,0.0,0.0};
+      const double alpha=BLEND ? (double) q[C-1] : 1.0;
+#pragma unroll
+      for (int c=0; c < C; c++)
+        {
+          p[c]=(BLEND && (c != C-1)) ? alpha*(double) q[c] : (double) q[c];
+          most[c]=__builtin_fmax(most[c],__builtin_fabs(p[c]));      // (NaN: skipped)
+        }
+      double *out=a.sums+i*4;
+      reinterpret_cast<double2 *>(out)[0]=make_double2(p[0],p[1]);
+      reinterpret_cast<double2 *>(out)[1]=make_double2(p[2],p[3]);
+    }
+  if constexpr (QuantumOps<Q>::is_float)
+    {
+      // one atomic per workgroup and channel, and only when it would raise the bound (8192 x 4
+      // atomics on four words cost more than the pass itself)
+      __shared__ double wave_most[4][4];
+#pragma unroll
+      for (int c=0; c < C; c++)
+        {
+          double m=most[c];
+          for (int off=32; off > 0; off>>=1)
+            m=__builtin_fmax(m,__shfl_xor(m,off,64));
+          if ((threadIdx.x & 63) == 0)
+            wave_most[threadIdx.x >> 6][c]=m;
+        }
+      __syncthreads();
+      if (threadIdx.x < (unsigned) C)
+        {
+          const int c=(int) threadIdx.x;
+          const double m=__builtin_fmax(__builtin_fmax(wave_most[0][c],wave_most[1][c]),
+            __builtin_fmax(wave_most[2][c],wave_most[3][c]));
+          // non-negative doubles order as their bit patterns
+          const unsigned long long bits=(unsigned long long) __double_as_longlong(m);
+          unsigned long long *word=reinterpret_cast<unsigned long long *>(a.bound+c);
+          if (bits > __hip_atomic_load(word,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(word,bits);
+        }
+    }
+}
+
+template<typename Q,int C,bool BLEND>
+__global__ __launch_bounds__(256)
+void separable_finish_kernel(SeparableArgs a)
+{
+  const Q *src=static_cast<const Q *>(a.src);
+  Q *dst=static_cast<Q *>(a.dst);
+  const size_t n=(size_t) a.columns*a.rows;
+  unsigned recomputed=0;
+  double error[4]={0.0,0.0,0.0,0.0};
+  if constexpr (QuantumOps<Q>::is_float)
+    {
+#pragma unroll
+      for (int c=0; c < C; c++)
+        error[c]=a.error_unit*a.bound[c];
+    }
+  // (the loop is uniform over the wave: the undecided samples are settled by all of its lanes)
+  const int lane=(int) threadIdx.x & 63;
+  for (size_t i0=(size_t) blockIdx.x*256u+(threadIdx.x & ~63u); i0 < n; i0+=(size_t) gridDim.x*256u)
+    {
+      const size_t i=i0+(size_t) lane < n ? i0+(size_t) lane : n-1;
+      const bool mine=i0+(size_t) lane < n;
+      const double2 s01=reinterpret_cast<const double2 *>(a.sums+i*4)[0];
+      const double2 s23=reinterpret_cast<const double2 *>(a.sums+i*4)[1];
+      const double s[4]={s01.x,s01.y,s23.x,s23.y};
+      double inverse=1.0,alpha_error=0.0;
+      bool unsure=false;
+      if constexpr (BLEND)
+        {
+          const double sa=s[C-1];
+          // PerceptibleReciprocal's clamp acts on QuantumScale*S_alpha below MagickEpsilon
+          unsure=(sa != 0.0) && !(__builtin_fabs(kQS*sa) >= kEps*1.000001);
+          inverse=sa == 0.0 ? 0.0 : perceptible_reciprocal_fast(sa);
+          alpha_error=error[C-1];
+        }
+      Q out[C];
+      uint32_t doubtful=0;
+#pragma unroll
+      for (int c=0; c < C; c++)
+        {
+          const bool weighted=BLEND && (c != C-1);
+          double value=s[c];
+          if (weighted)
+            value=value*inverse;
+          if constexpr (QuantumOps<Q>::is_float)
+            {
+              double bound=error[c];
+              if (weighted)
+                bound=__builtin_fma(__builtin_fabs(value),alpha_error,bound)*__builtin_fabs(inverse)+
+                  __builtin_fabs(value)*1.0e-15;
+              const float nearest=(float) value;
+              const uint32_t bits=__float_as_uint(nearest);
+              const int exponent=(int) ((bits >> 23) & 0xffu);
+              const bool power_of_two=(bits & 0x7fffffu) == 0u;
+              const bool ordinary=(exponent != 0xff) && ((exponent != 0) || ((bits & 0x7fffffffu) == 0u));
+              const int half_exponent=(exponent > 0 ? exponent : 1)-151-(power_of_two ? 1 : 0);
+              const double half_ulp=__longlong_as_double((long long) (half_exponent+1023) << 52);
+              const double distance=__builtin_fabs(value-(double) nearest);
+              const bool decided=ordinary && (half_ulp-distance > bound);
+              out[c]=nearest;
+              if (!decided || (unsure && weighted))
+                doubtful|=1u << c;
+            }
+          else
+            {
+              const double shifted=value+0.5;
+              const double fraction=shifted-__builtin_floor(shifted);
+              out[c]=QuantumOps<Q>::clamp(value);
+              if ((fraction < a.tie_margin) || (fraction > 1.0-a.tie_margin) || (unsure && weighted) ||
+                  !(value == value))
+                doubtful|=1u << c;
+            }
+        }
+      unsigned long long pending=__ballot(mine && (doubtful != 0u));
+      while (pending != 0ull)
+        {
+          const int who=__builtin_ctzll(pending);
+          pending&=pending-1ull;
+          const uint32_t which=(uint32_t) __builtin_amdgcn_readlane((int) doubtful,who);
+          const size_t at=i0+(size_t) who;
+          const int y=(int) (at/(size_t) a.columns),x=(int) (at-(size_t) y*a.columns);
+#pragma unroll
+          for (int c=0; c < C; c++)
+            if ((which >> c) & 1u)
+              {
+                const Q settled=conv2d_reference_sample<Q,C,BLEND>(src,a.columns,a.rows,x,y,c,a.values,a.kw,a.kh,
+                  a.shiftx,a.shifty,lane);
+                if (lane == who)
+                  {
+                    out[c]=settled;
+                    recomputed++;
+                  }
+              }
+        }
+      if (mine)
+        store_pixel<Q,C>(dst+i*C,out);
+    }
+  if (a.recomputed != nullptr)
+    {
+      for (int off=32; off > 0; off>>=1)
+        recomputed+=__shfl_xor(recomputed,off,64);
+      if (((threadIdx.x & 63) == 0) && (recomputed != 0))
+        atomicAdd(a.recomputed,(unsigned long long) recomputed);
+    }
+}
+
+static unsigned long long *g_separable_recomputed[64]={};
+static bool g_separable_count=false;
+
+template<typename Q,int C,bool BLEND>
+static MhStatus separable_typed(const View &src,SeparableArgs &a,const Conv1DParams &horizontal,
+  const Conv1DParams &vertical,double *work)
+{
+  const size_t n=(size_t) a.columns*a.rows;
+  size_t blocks=(n+255)/256;
+  blocks=blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks);
+  {
+    ProfileScope prof("separable_premultiply",src.stream);
+    hipLaunchKernelGGL((separable_premultiply_kernel<Q,C,BLEND>),dim3((unsigned) blocks),dim3(256),0,src.stream,a);
+  }
+  View sums=src,other=src;
+  sums.channels=4;
+  other.channels=4;
+  sums.pixels=a.sums;
+  other.pixels=work;
+  MH_TRY(launch_conv1d_sums64(sums,other,false,horizontal));
+  MH_TRY(launch_conv1d_sums64(other,sums,true,vertical));
+  {
+    ProfileScope prof("separable_finish",src.stream);
+    hipLaunchKernelGGL((separable_finish_kernel<Q,C,BLEND>),dim3((unsigned) blocks),dim3(256),0,src.stream,a);
+  }
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+MhStatus launch_separable_exact(const View &src,const View &dst,const MhKernelInfo *kernel,
+  const double *row,const double *column,const Roles &roles,bool *handled)
+{
+  *handled=false;
+  const int kw=(int) kernel->width,kh=(int) kernel->height;
+  if ((src.channels < 1) || (src.channels > 4) || (roles.copy_mask != 0) ||
+      (src.columns != dst.columns) || (src.rows != dst.rows) || (kw > 255) || (kh > 255) ||
+      (getenv("MAGICKHIP_NO_SEPARABLE_EXACT") != nullptr))
+    return MH_OK;
+  const bool blend=roles.blend && (roles.alpha == src.channels-1) && (src.channels >= 2);
+  if (roles.blend && !blend)
+    return MH_OK;
+  // how far the separable evaluation can be from the reference's: the cells are the outer product
+  // to 1e-13 of the largest cell (rank_one_factors), every one of the (kw+kh) fused multiply-adds
+  // of a sample and of the reference's 3*kw*kh operations rounds to 2^-53
+  double residual=0.0,magnitude=0.0,running=0.0,partials=0.0;
+  bool negative=false;
+  for (int i=kw*kh-1; i >= 0; i--)                  // the reference's walk: from the last cell backwards
+    {
+      const double cell=kernel->values[i];
+      if (std::isnan(cell))
+        return MH_OK;
+      // what the outer product misses of this cell (rank_one_factors admits up to 1e-13 of the
+      // largest cell; a Gaussian's cells are products to the last bit or two), plus the rounding
+      // of the product that stands in for it
+      const double product=column[i/kw]*row[i % kw];
+      residual+=std::fabs(cell-product)+std::fabs(product)*2.220446049250313e-16;
+      magnitude+=std::fabs(cell);
+      // the reference's running sum after this cell is at most `running` * max|sample|: its
+      // addition rounds to half an ulp of that
+      running+=std::fabs(cell);
+      partials+=running;
+      negative=negative || (cell < 0.0);
+    }
+  if (blend && negative)
+    return MH_OK;                                  // sum(k*alpha) may cancel: the generic kernel's job
+  // reference: one rounding per addition (`partials`), two per term (alpha*k, *p); the two
+  // separable passes: a fused multiply-add per tap on sums of at most `magnitude` * max|sample|
+  const double unit=1.1102230246251565e-16;
+  const double error_unit=2.0*(residual+unit*(partials+2.0*magnitude)+unit*((double) (kw+kh)+6.0)*magnitude);
+  const bool is_float=src.quantum != MH_QUANTUM_U16;
+  double tie_margin=1.0e-6;
+  if (!is_float)
+    {
+      // levels: alpha*p <= 65535^2 over an alpha sum that carries the same relative error
+      const double level_error=error_unit*65535.0*(blend ? 2.0 : 1.0)/(magnitude > 0.0 ? magnitude : 1.0);
+      tie_margin=level_error*16.0 > tie_margin ? level_error*16.0 : tie_margin;
+      if (tie_margin > 1.0e-3)
+        return MH_OK;                              // (a kernel of tens of thousands of cells)
+    }
+  const size_t n=(size_t) src.columns*src.rows;
+  Temp memory,table;
+  MH_TRY(memory.alloc(src.device,2*n*4*sizeof(double)+4*sizeof(double),src.stream));
+  MH_TRY(upload_table(table,src.device,src.stream,kernel->values,(size_t) kw*kh*sizeof(double)));
+  SeparableArgs a;
+  a.src=src.pixels;
+  a.dst=dst.pixels;
+  a.sums=static_cast<double *>(memory.ptr);
+  double *work=a.sums+n*4;
+  a.bound=work+n*4;
+  a.columns=(int) src.columns;
+  a.rows=(int) src.rows;
+  a.values=table.as<double>();
+  a.kw=kw;
+  a.kh=kh;
+  a.shiftx=kw-1-(int) kernel->x;
+  a.shifty=kh-1-(int) kernel->y;
+  a.error_unit=error_unit;
+  a.tie_margin=tie_margin;
+  a.recomputed=nullptr;
+  if (g_separable_count && (src.device >= 0) && (src.device < 64))
+    {
+      if (g_separable_recomputed[src.device] == nullptr)
+        {
+          MH_HIP(hipMalloc(reinterpret_cast<void **>(&g_separable_recomputed[src.device]),sizeof(unsigned long long)));
+          MH_HIP(hipMemsetAsync(g_separable_recomputed[src.device],0,sizeof(unsigned long long),src.stream));
+        }
+      a.recomputed=g_separable_recomputed[src.device];
+    }
+  MH_HIP(hipMemsetAsync(a.bound,0,4*sizeof(double),src.stream));
+  Conv1DParams horizontal,vertical;
+  horizontal.taps=row;
+  horizontal.ntaps=kw;
+  horizontal.origin=(int) kernel->x;
+  vertical.taps=column;
+  vertical.ntaps=kh;
+  vertical.origin=(int) kernel->y;
+  MhStatus status=MH_OK;
+#define MH_LAYOUT(QT) \
+  switch (src.channels) \
+  { \
+    case 1: status=separable_typed<QT,1,false>(src,a,horizontal,vertical,work); break; \
+    case 2: status=blend ? separable_typed<QT,2,true>(src,a,horizontal,vertical,work) : \
+      separable_typed<QT,2,false>(src,a,horizontal,vertical,work); break; \
+    case 3: status=separable_typed<QT,3,false>(src,a,horizontal,vertical,work); break; \
+    default: status=blend ? separable_typed<QT,4,true>(src,a,horizontal,vertical,work) : \
+      separable_typed<QT,4,false>(src,a,horizontal,vertical,work); break; \
+  }
+  if (is_float)
+    { MH_LAYOUT(float) }
+  else
+    { MH_LAYOUT(uint16_t) }
+#undef MH_LAYOUT
+  MH_TRY(status);
+  *handled=true;
+  return MH_OK;
+}
+
+} // namespace mh
+
+using namespace mh;
+
+// Diagnostic: samples the separable EXACT path recomputed in the reference's order since the
+// counter was last read (enable = 1 switches the counting on and reads, 0 reads and switches off).
+extern "C" MH_API unsigned long long MhSeparableRecomputed(int enable)
+{
+  unsigned long long total=0;
+  for (int d=0; d < 64; d++)
+    if (g_separable_recomputed[d] != nullptr)
+      {
+        unsigned long long value=0;
+        if (hipSetDevice(d) == hipSuccess)
+          {
+            (void) hipDeviceSynchronize();
+            (void) hipMemcpy(&value,g_separable_recomputed[d],sizeof(value),hipMemcpyDeviceToHost);
+            (void) hipMemset(g_separable_recomputed[d],0,sizeof(value));
+          }
+        total+=value;
+      }
+  g_separable_count=enable != 0;
+  return total;
+}

@@ -53,6 +53,13 @@ template<> struct QuantumOps<float>
   }
 };
 
+// fp64 sums between the passes of a separable 2-D kernel (convolve_separable.hip): no Quantum
+template<> struct QuantumOps<double>
+{
+  static constexpr bool is_float=true;
+  static __device__ __forceinline__ double clamp(double v) { return v; }
+};
+
 // PerceptibleReciprocal, MagickCore/pixel-accessor.h:242-254
 static __device__ __forceinline__ double perceptible_reciprocal(double x)
 {

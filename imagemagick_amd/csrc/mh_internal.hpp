@@ -253,6 +253,10 @@ MhStatus launch_conv1d_unsharp(const View &rows,const View &dst,const View &orig
   const Conv1DParams &params,bool blend,double gain,double threshold,bool *handled);
 // One pass of a separated 2-D kernel through launch_conv1d_mfma (taps uploaded here):
 // vertical = false: src Quantum RGBA -> dst float sums; vertical = true: the reverse
+MhStatus launch_conv1d_sums64(const View &src,const View &dst,bool vertical,const Conv1DParams &params);
+// EXACT (and float-Quantum FAST) 2-D Convolve with an outer-product kernel: two fp64 passes + tie check
+MhStatus launch_separable_exact(const View &src,const View &dst,const MhKernelInfo *kernel,
+  const double *row,const double *column,const Roles &roles,bool *handled);
 MhStatus launch_conv1d_sums(const View &src,const View &dst,bool vertical,const Conv1DParams &params,
   bool blend,bool *handled);
 

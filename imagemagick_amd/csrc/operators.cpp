@@ -247,6 +247,21 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
       if (handled)
         return MH_OK;
     }
+  // an outer-product kernel in EXACT mode, or on float Quantum in either mode: two fp64 passes and
+  // a tie check, bit-identical to the w x h walk (convolve_separable.hip)
+  if ((method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
+      !kernel_has_nan(kernel) && (kernel->width >= 2) && (kernel->height >= 2) &&
+      (kernel->width*kernel->height >= 25) && (getenv("MAGICKHIP_NO_SEPARABLE") == nullptr))
+    {
+      std::vector<double> row,column;
+      if (rank_one_factors(kernel,row,column))
+        {
+          bool handled=false;
+          MH_TRY(launch_separable_exact(src,dst,kernel,row.data(),column.data(),roles,&handled));
+          if (handled)
+            return MH_OK;
+        }
+    }
   // FAST, Q16, RGBA (alpha-weighted, alpha last), four plain channels or RGB, kernels of 5 x 5 and
   // more: the w x h sum as h banded products on the matrix cores (convolve2d_mfma.hip)
   if ((method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&

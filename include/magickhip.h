@@ -234,6 +234,9 @@ MH_API void MhResetProfileRecords(void);
    reference's own operation order (morphology.c:2746-2764).  enable != 0 starts counting on the
    current device (the counter is read and reset by every call); returns the count so far. */
 MH_API unsigned long long MhExactBlurRecomputed(int enable);
+/* The same for the separable EXACT 2-D Convolve (GaussianBlurImage in EXACT mode and on float
+   Quantum): samples recomputed in the reference's w x h order. */
+MH_API unsigned long long MhSeparableRecomputed(int enable);
 
 /* ------------------------------------------------------ kernels and filters */
 

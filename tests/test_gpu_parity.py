@@ -936,6 +936,66 @@ def test_gaussian_blur_sharpen_edge_emboss(im, refmod, dtype, channels):
         assert_parity(got.numpy(), want.numpy(), True, "%s c%d" % (name, channels))
 
 
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("channels,alpha", [(4, True), (4, False), (3, False), (2, True), (1, False)])
+@pytest.mark.parametrize("kernel", ["Gaussian:0x2", "Gaussian:0x3.7", "Gaussian:4x1.1", "Square:3", "Rectangle:7x5+1+3",
+                                    "5x5: 1,2,3,2,1 2,4,6,4,2 3,6,9,6,3 2,4,6,4,2 1,2,3,2,1"])
+def test_separable_2d_convolve_exact(im, refmod, dtype, channels, alpha, kernel):
+    """EXACT 2-D Convolve with a kernel that is an outer product (GaussianBlurImage's kernels,
+    boxes, column x row products): two fp64 1-D passes over alpha-premultiplied doubles and a tie
+    check, the undecided samples recomputed in the reference's w x h order
+    (convolve_separable.hip) — bit-identical on Q16 and on float Quantum, every layout, small and
+    zero alpha, frames ragged against the kernels' tiles."""
+    import bench
+    rng = np.random.default_rng(len(kernel) + channels)
+    px = make_pixels(83, 141, channels, dtype, seed=len(kernel))
+    if alpha:
+        px[10:30, 20:60, channels - 1] = rng.integers(0, 4, (20, 40)).astype(px.dtype)
+        px[40:50, 100:130, channels - 1] = 0
+    dev = im.Image(to_device(px), has_alpha=alpha)
+    if alpha or channels in (1, 3):
+        ref = refmod.RefImage(px)
+        want = ref.set_artifact("convolve:scale", "!").morphology("Convolve", 1, kernel).numpy()
+    else:
+        want = np.concatenate([refmod.RefImage(px[:, :, c].copy()).set_artifact("convolve:scale", "!")
+                               .morphology("Convolve", 1, kernel).numpy().reshape(83, 141, 1) for c in range(channels)], axis=2)
+    holder = {}
+    launched = set(bench.kernel_profile(
+        im, lambda: holder.update(out=im.morphology_image(dev, "Convolve", 1, kernel, scale=(1.0, 1))), 1))
+    assert "separable_finish" in launched, launched
+    got = holder["out"].numpy()
+    if dtype == HDRI:
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), "%s c%d: %d float samples differ" % (kernel, channels, int((~same).sum()))
+    else:
+        assert_parity(got, want, True, "separable %s c%d alpha=%s" % (kernel, channels, alpha))
+
+
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+def test_separable_2d_convolve_exact_on_ties(im, refmod, dtype):
+    """A checkerboard of two adjacent levels under a symmetric kernel puts every blurred value on
+    a rounding tie (Q16) or on the midpoint of two floats (HDRI): all of them go through the
+    reference-order recomputation, and GaussianBlurImage / a 2x3 kernel stay bit-identical."""
+    rows, cols = 70, 110
+    y, x = np.mgrid[0:rows, 0:cols]
+    px = np.empty((rows, cols, 4), dtype=dtype)
+    if dtype == HDRI:
+        for c, level in enumerate((1000.25, 32767.5, 3.0e-3)):
+            low = np.float32(level)
+            px[:, :, c] = np.where(((x + y) & 1) == 1, np.nextafter(low, np.float32(np.inf)), low)
+    else:
+        for c, level in enumerate((1000, 32767, 65534)):
+            px[:, :, c] = level + ((x + y) & 1)
+    px[:, :, 3] = 65535
+    dev, ref = run_pair(im, refmod, px)
+    im._lib.load().MhSeparableRecomputed(1)
+    got = im.gaussian_blur_image(dev, 0.0, 2.0).numpy()
+    recomputed = im._lib.load().MhSeparableRecomputed(0)
+    assert recomputed > rows * cols, recomputed
+    want = ref.gaussian_blur(0.0, 2.0).numpy()
+    assert np.array_equal(got.view(np.uint32 if dtype == HDRI else np.uint16), want.view(np.uint32 if dtype == HDRI else np.uint16))
+
+
 # ----------------------------------------------------------- ImportImagePixels / ExportImagePixels
 IO_TYPES = ["uint8", "uint16", "uint32", "uint64", "float32", "float64"]
 
