@@ -340,7 +340,34 @@ struct Conv1DArgs
   const void *taps;          // T[K], reversed so that taps[v] multiplies input o-shift+v
   unsigned long long *changed;
   int nblocks;               // blocked kernels: number of U-sample blocks of the padded tap table
+  // triangular column kernels: UnsharpMaskImage's epilogue on the way out (effect.c:4364-4369);
+  // unsharp_src = the unblurred frame, or NULL
+  const void *unsharp_src;
+  double unsharp_gain,unsharp_threshold;
 };
+
+// blurred sample -> unsharp-masked sample, as unsharp_kernel (pointwise.hip) does in its own pass
+template<typename Q,int C>
+static __device__ __forceinline__ void unsharp_on_the_way_out(const Conv1DArgs &args,size_t pixel,Q (&out)[C])
+{
+  Q p[C];
+  load_pixel<Q,C>(static_cast<const Q *>(args.unsharp_src)+pixel*C,p);
+#pragma unroll
+  for (int c=0; c < C; c++)
+    {
+      if ((args.copy_mask >> c) & 1u)
+        {
+          out[c]=p[c];
+          continue;
+        }
+      double value=(double) p[c]-(double) out[c];
+      if (fabs(2.0*value) < args.unsharp_threshold)
+        value=(double) p[c];
+      else
+        value=(double) p[c]+args.unsharp_gain*value;
+      out[c]=QuantumOps<Q>::clamp(value);
+    }
+}
 
 template<typename Q,int C,bool BLEND,class A>
 static __device__ __forceinline__ auto make_reference(const Conv1DArgs &args,bool vertical,int x,int y)
@@ -456,6 +483,8 @@ void conv_column_kernel(Conv1DArgs args)
           unsigned ch=acc.finish(r,center,args.copy_mask,out,(T) args.bias);
           if (x < W)
             {
+              if (args.unsharp_src != nullptr)
+                unsharp_on_the_way_out<Q,C>(args,(size_t) y*W+(size_t) x,out);
               store_pixel<Q,C>(dst+(size_t) y*pitch+(size_t) x*C,out);
               changed+=ch;
             }
@@ -742,6 +771,8 @@ void conv_column_blocked(Conv1DArgs args)
           unsigned ch=acc.finish(r,center,args.copy_mask,out,(T) args.bias,args.changed != nullptr);
           if (x < W)
             {
+              if (args.unsharp_src != nullptr)
+                unsharp_on_the_way_out<Q,C>(args,(size_t) y*W+(size_t) x,out);
               store_pixel<Q,C>(dst+(size_t) y*pitch+(size_t) x*C,out);
               changed+=ch;
             }
@@ -904,6 +935,9 @@ static MhStatus launch_blocked(const View &src,const View &dst,bool vertical,
   MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(T)));
 
   Conv1DArgs args;
+  args.unsharp_src=nullptr;
+  args.unsharp_gain=0.0;
+  args.unsharp_threshold=0.0;
   args.src=src.pixels;
   args.dst=dst.pixels;
   args.columns=(int) src.columns;
@@ -1179,6 +1213,8 @@ void conv_column_tri(Conv1DArgs args)
             make_reference<Q,C,BLEND,A>(args,true,xc,y));
           if (x < W)
             {
+              if (args.unsharp_src != nullptr)
+                unsharp_on_the_way_out<Q,C>(args,(size_t) y*W+(size_t) x,out);
               store_pixel<Q,C>(dst+(size_t) y*pitch+(size_t) x*C,out);
               changed+=ch;
             }
@@ -1290,6 +1326,8 @@ void conv_column_lds(Conv1DArgs args)
             make_reference<Q,C,BLEND,A>(args,true,x < W ? x : W-1,y));
           if (x < W)
             {
+              if (args.unsharp_src != nullptr)
+                unsharp_on_the_way_out<Q,C>(args,(size_t) y*W+(size_t) x,out);
               store_pixel<Q,C>(dst+(size_t) y*pitch+(size_t) x*C,out);
               changed+=ch;
             }
@@ -1442,6 +1480,9 @@ static MhStatus launch_tri_waves(const View &src,const View &dst,bool vertical,
   Temp taps;
   MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(T)));
   Conv1DArgs args;
+  args.unsharp_src=nullptr;
+  args.unsharp_gain=0.0;
+  args.unsharp_threshold=0.0;
   args.src=src.pixels;
   args.dst=dst.pixels;
   args.columns=(int) src.columns;
@@ -1453,6 +1494,12 @@ static MhStatus launch_tri_waves(const View &src,const View &dst,bool vertical,
   args.taps=taps.ptr;
   args.changed=changed;
   args.nblocks=0;
+  if (vertical)
+    {
+      args.unsharp_src=p.unsharp_source;
+      args.unsharp_gain=p.unsharp_gain;
+      args.unsharp_threshold=p.unsharp_threshold;
+    }
   const int W=args.columns,H=args.rows;
   if (vertical)
     {
@@ -1552,6 +1599,9 @@ static MhStatus launch_one(const View &src,const View &dst,bool vertical,
   MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(T)));
 
   Conv1DArgs args;
+  args.unsharp_src=nullptr;
+  args.unsharp_gain=0.0;
+  args.unsharp_threshold=0.0;
   args.src=src.pixels;
   args.dst=dst.pixels;
   args.columns=(int) src.columns;
@@ -1667,6 +1717,37 @@ static MhStatus launch_row_alpha_audit(const View &src,const View &dst,const Con
       (int) src.rows,taps.as<double>(),K,K-1-params.origin);
   MH_HIP(hipGetLastError());
   return MH_OK;
+}
+
+MhStatus launch_conv1d_column_unsharp(const View &rows,const View &dst,const View &original,
+  const Conv1DParams &params,const Roles &roles,MhPrecision prec,double gain,double threshold,
+  bool *handled)
+{
+  *handled=false;
+  const bool is_float=rows.quantum != MH_QUANTUM_U16;
+  if ((!is_float && (prec != MH_PRECISION_EXACT)) || (params.ntaps < 16) || (params.bias != 0.0) ||
+      (original.columns != rows.columns) || (original.rows != rows.rows) ||
+      (original.channels != rows.channels) || (original.quantum != rows.quantum) ||
+      (getenv("MAGICKHIP_NO_TRI") != nullptr) || (getenv("MAGICKHIP_NO_TIE64") != nullptr) ||
+      (getenv("MAGICKHIP_NO_FUSED_UNSHARP") != nullptr))
+    return MH_OK;
+  double total=0.0;
+  for (int v=0; v < params.ntaps; v++)
+    {
+      if (!(params.taps[v] >= 0.0))
+        return MH_OK;
+      total+=params.taps[v];
+    }
+  if (is_float && !(total <= 1.0+1.0e-9))
+    return MH_OK;
+  Conv1DParams with=params;
+  with.unsharp_source=original.pixels;
+  with.unsharp_gain=gain;
+  with.unsharp_threshold=65535.0*threshold;    // QuantumRange*threshold, effect.c:4300
+  *handled=true;
+  if (is_float)
+    return dispatch_tri<Tie64,8,8,float>(rows,dst,true,with,roles,nullptr);
+  return dispatch_tri<Tie64,8,8>(rows,dst,true,with,roles,nullptr);
 }
 
 // One 1-D pass over [rows][columns][4] DOUBLES (un-normalised sums in, sums out): fused

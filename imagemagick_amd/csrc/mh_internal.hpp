@@ -204,7 +204,17 @@ struct Conv1DParams
   int ntaps=0;
   int origin=0;                // kernel->x (row kernel) or kernel->y (column kernel)
   double bias=0.0;
+  // launch_conv1d_column_unsharp only: the unblurred frame and UnsharpMaskImage's gain /
+  // ceil-free threshold (QuantumRange*threshold), applied as the column pass stores its results
+  const void *unsharp_source=nullptr;
+  double unsharp_gain=0.0,unsharp_threshold=0.0;
 };
+// The column pass of a blur with UnsharpMaskImage's epilogue applied on the way out (the fp64
+// triangular kernels: float Quantum, and Q16 in EXACT mode).  *handled = false: not this case,
+// nothing launched (the caller runs the pass and the epilogue kernel).
+MhStatus launch_conv1d_column_unsharp(const View &rows,const View &dst,const View &original,
+  const Conv1DParams &params,const Roles &roles,MhPrecision precision,double gain,double threshold,
+  bool *handled);
 // One MorphologyPrimitive(Convolve) pass with a 1-D kernel without NaN cells:
 // horizontal (1 x ntaps, morphology.c:2811-2979) or vertical (ntaps x 1,
 // column fast path morphology.c:2654-2807).

@@ -944,6 +944,47 @@ static MhStatus unsharp_fused(const View &src,const View &dst,const MhKernelInfo
   return MH_OK;
 }
 
+// Any layout on the fp64 vector kernels (float Quantum; Q16 in EXACT mode outside the fused
+// kernel's reach): the row pass, then the column pass with the epilogue applied as it stores —
+// no blurred frame written and read back, no third kernel.
+static MhStatus unsharp_vector_fused(const View &src,const View &dst,const MhKernelInfo *kernels,
+  const Roles &roles,double gain,double threshold,bool *fused)
+{
+  *fused=false;
+  const MhKernelInfo *horizontal=kernels,*vertical=kernels != nullptr ? kernels->next : nullptr;
+  if ((horizontal == nullptr) || (vertical == nullptr) || (vertical->next != nullptr) ||
+      (horizontal->height != 1) || (vertical->width != 1) || (vertical->height < 16) ||
+      kernel_has_nan(horizontal) || kernel_has_nan(vertical) ||
+      ((src.quantum == MH_QUANTUM_U16) && (precision() != MH_PRECISION_EXACT)))
+    return MH_OK;
+  View rows=src;
+  Temp memory;
+  MH_TRY(memory.alloc(src.device,rows.bytes(),src.stream));
+  rows.pixels=memory.ptr;
+  Conv1DParams first,second;
+  first.taps=horizontal->values;
+  first.ntaps=(int) horizontal->width;
+  first.origin=(int) horizontal->x;
+  second.taps=vertical->values;
+  second.ntaps=(int) vertical->height;
+  second.origin=(int) vertical->y;
+  // (decide before the row pass is spent: the column entry point declines on its own terms)
+  for (int v=0; v < second.ntaps; v++)
+    if (!(second.taps[v] >= 0.0))
+      return MH_OK;
+  MH_TRY(launch_conv1d(src,rows,false,first,roles,MH_PRECISION_EXACT,nullptr));
+  bool handled=false;
+  MH_TRY(launch_conv1d_column_unsharp(rows,dst,src,second,roles,precision(),gain,threshold,&handled));
+  if (!handled)
+    {
+      // the column pass and the epilogue kernel after all
+      MH_TRY(launch_conv1d(rows,dst,true,second,roles,precision(),nullptr));
+      MH_TRY(launch_unsharp_epilogue(src,dst,dst,gain,threshold,roles));
+    }
+  *fused=true;
+  return MH_OK;
+}
+
 MH_API MhStatus MagickHipUnsharpMaskImage(const MhImage *image,MhImage *unsharp_image,
   double radius,double sigma,double gain,double threshold)
 {
@@ -974,6 +1015,8 @@ MH_API MhStatus MagickHipUnsharpMaskImage(const MhImage *image,MhImage *unsharp_
       Roles roles=channel_roles(image,unsharp_image);
       bool fused=false;
       status=unsharp_fused(pair.src.view,pair.dst.view,kernel,roles,gain,threshold,&fused);
+      if ((status == MH_OK) && !fused)
+        status=unsharp_vector_fused(pair.src.view,pair.dst.view,kernel,roles,gain,threshold,&fused);
       if ((status == MH_OK) && !fused)
         {
           status=morphology_apply(pair.src.view,pair.dst.view,image,roles,MH_MORPHOLOGY_CONVOLVE,1,

@@ -1093,6 +1093,23 @@ def test_unsharp_mask(im, refmod, dtype):
     assert_parity(got, want, True, "unsharp")
 
 
+@pytest.mark.parametrize("dtype,channels", [(HDRI, 4), (HDRI, 3), (HDRI, 2), (HDRI, 1), (Q16, 2), (Q16, 1)])
+@pytest.mark.parametrize("gain,threshold", [(1.0, 0.02), (2.5, 0.0)])
+def test_unsharp_mask_epilogue_in_the_column_pass(im, refmod, dtype, channels, gain, threshold):
+    """Float Quantum (and the Q16 layouts the matrix kernel does not take, EXACT): the fp64
+    column pass applies UnsharpMaskImage's threshold / gain as it stores (convolve.hip,
+    unsharp_on_the_way_out) — two launches, no epilogue kernel, bit-identical."""
+    import bench
+    px = make_pixels(75, 101, channels, dtype, seed=channels)
+    dev, ref = run_pair(im, refmod, px)
+    holder = {}
+    launched = set(bench.kernel_profile(
+        im, lambda: holder.update(out=im.unsharp_mask_image(dev, 0.0, 4.0, gain, threshold)), 1))
+    assert launched == {"conv_row", "conv_column"}, launched
+    assert_parity(holder["out"].numpy(), ref.unsharp(0.0, 4.0, gain, threshold).numpy(), True,
+                  "unsharp c%d gain %g" % (channels, gain))
+
+
 # ----------------------------------------------------------------- ResizeImage
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
 @pytest.mark.parametrize("shape,target,filt", [
