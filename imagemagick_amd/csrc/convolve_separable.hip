@@ -88,7 +88,13 @@ struct SeparableArgs
   const double *values;       // the kernel's cells (device)
   int kw,kh,shiftx,shifty;
   double error_unit;          // |difference of the two evaluations| <= error_unit * max|P_c|
-  double tie_margin;          // Q16: levels within this of n+1/2 are recomputed
+  double fixed_bound[4];      // Q16: max|P_c| is known (65535^2 for alpha-weighted colour, 65535)
+  // kernel = column x row + delta at one cell (SharpenImage, EdgeImage: a negated Gaussian / a
+  // box whose centre carries the normalisation): delta times the sample that cell sees, which
+  // is (x+delta_dx, y+delta_dy)
+  double delta;
+  int delta_dx,delta_dy;
+  int mixed_signs;            // cells of both signs: an alpha sum of exactly zero is not "all transparent"
   unsigned long long *recomputed;
 };
 
@@ -153,12 +159,9 @@ void separable_finish_kernel(SeparableArgs a)
   const size_t n=(size_t) a.columns*a.rows;
   unsigned recomputed=0;
   double error[4]={0.0,0.0,0.0,0.0};
-  if constexpr (QuantumOps<Q>::is_float)
-    {
 #pragma unroll
-      for (int c=0; c < C; c++)
-        error[c]=a.error_unit*a.bound[c];
-    }
+  for (int c=0; c < C; c++)
+    error[c]=a.error_unit*(QuantumOps<Q>::is_float ? a.bound[c] : a.fixed_bound[c]);
   // (the loop is uniform over the wave: the undecided samples are settled by all of its lanes)
   const int lane=(int) threadIdx.x & 63;
   for (size_t i0=(size_t) blockIdx.x*256u+(threadIdx.x & ~63u); i0 < n; i0+=(size_t) gridDim.x*256u)
@@ -167,16 +170,32 @@ void separable_finish_kernel(SeparableArgs a)
       const bool mine=i0+(size_t) lane < n;
       const double2 s01=reinterpret_cast<const double2 *>(a.sums+i*4)[0];
       const double2 s23=reinterpret_cast<const double2 *>(a.sums+i*4)[1];
-      const double s[4]={s01.x,s01.y,s23.x,s23.y};
+      double s[4]={s01.x,s01.y,s23.x,s23.y};
+      if (a.delta != 0.0)
+        {
+          // + delta * (alpha*p .., alpha) of the one sample the extra cell sees
+          const int y=(int) (i/(size_t) a.columns),x=(int) (i-(size_t) y*a.columns);
+          int xx=x+a.delta_dx,yy=y+a.delta_dy;
+          xx=xx < 0 ? 0 : (xx > a.columns-1 ? a.columns-1 : xx);
+          yy=yy < 0 ? 0 : (yy > a.rows-1 ? a.rows-1 : yy);
+          Q q[C];
+          load_pixel<Q,C>(src+((size_t) yy*a.columns+(size_t) xx)*C,q);
+          const double alpha=BLEND ? (double) q[C-1] : 1.0;
+#pragma unroll
+          for (int c=0; c < C; c++)
+            s[c]=__builtin_fma(a.delta,(BLEND && (c != C-1)) ? alpha*(double) q[c] : (double) q[c],s[c]);
+        }
       double inverse=1.0,alpha_error=0.0;
       bool unsure=false;
       if constexpr (BLEND)
         {
           const double sa=s[C-1];
-          // PerceptibleReciprocal's clamp acts on QuantumScale*S_alpha below MagickEpsilon
-          unsure=(sa != 0.0) && !(__builtin_fabs(kQS*sa) >= kEps*1.000001);
-          inverse=sa == 0.0 ? 0.0 : perceptible_reciprocal_fast(sa);
           alpha_error=error[C-1];
+          // PerceptibleReciprocal's clamp acts on QuantumScale*S_alpha below MagickEpsilon; and an
+          // alpha sum of mixed-sign cells that has cancelled down to its own error says nothing
+          unsure=((sa != 0.0) || (a.mixed_signs != 0)) &&
+            (!(__builtin_fabs(kQS*sa) >= kEps*1.000001) || !(__builtin_fabs(sa) > 8.0*alpha_error));
+          inverse=sa == 0.0 ? 0.0 : perceptible_reciprocal_fast(sa);
         }
       Q out[C];
       uint32_t doubtful=0;
@@ -185,14 +204,15 @@ void separable_finish_kernel(SeparableArgs a)
         {
           const bool weighted=BLEND && (c != C-1);
           double value=s[c];
+          double bound=error[c];
           if (weighted)
-            value=value*inverse;
+            {
+              value=value*inverse;
+              bound=__builtin_fma(__builtin_fabs(value),alpha_error,bound)*__builtin_fabs(inverse)+
+                __builtin_fabs(value)*1.0e-15;
+            }
           if constexpr (QuantumOps<Q>::is_float)
             {
-              double bound=error[c];
-              if (weighted)
-                bound=__builtin_fma(__builtin_fabs(value),alpha_error,bound)*__builtin_fabs(inverse)+
-                  __builtin_fabs(value)*1.0e-15;
               const float nearest=(float) value;
               const uint32_t bits=__float_as_uint(nearest);
               const int exponent=(int) ((bits >> 23) & 0xffu);
@@ -208,11 +228,14 @@ void separable_finish_kernel(SeparableArgs a)
             }
           else
             {
+              // ClampToQuantum (quantum.h:86-97): the only boundaries are the n+1/2 inside the
+              // range; beyond it the level is 0 or 65535 whatever the last bits say
               const double shifted=value+0.5;
               const double fraction=shifted-__builtin_floor(shifted);
+              const double distance=fraction < 0.5 ? fraction : 1.0-fraction;
+              const bool inside=(value > -1.0) && (value < 65536.0);
               out[c]=QuantumOps<Q>::clamp(value);
-              if ((fraction < a.tie_margin) || (fraction > 1.0-a.tie_margin) || (unsure && weighted) ||
-                  !(value == value))
+              if ((inside && !(distance > bound+1.0e-9)) || (unsure && weighted) || !(value == value))
                 doubtful|=1u << c;
             }
         }
@@ -279,7 +302,8 @@ static MhStatus separable_typed(const View &src,SeparableArgs &a,const Conv1DPar
 }
 
 MhStatus launch_separable_exact(const View &src,const View &dst,const MhKernelInfo *kernel,
-  const double *row,const double *column,const Roles &roles,bool *handled)
+  const double *row,const double *column,const Roles &roles,bool *handled,int delta_x,int delta_y,
+  double delta)
 {
   *handled=false;
   const int kw=(int) kernel->width,kh=(int) kernel->height;
@@ -293,41 +317,48 @@ MhStatus launch_separable_exact(const View &src,const View &dst,const MhKernelIn
   // how far the separable evaluation can be from the reference's: the cells are the outer product
   // to 1e-13 of the largest cell (rank_one_factors), every one of the (kw+kh) fused multiply-adds
   // of a sample and of the reference's 3*kw*kh operations rounds to 2^-53
-  double residual=0.0,magnitude=0.0,running=0.0,partials=0.0;
-  bool negative=false;
+  double residual=0.0,magnitude=0.0,running=0.0,partials=0.0,total=0.0;
+  bool negative=false,positive=false;
   for (int i=kw*kh-1; i >= 0; i--)                  // the reference's walk: from the last cell backwards
     {
       const double cell=kernel->values[i];
       if (std::isnan(cell))
         return MH_OK;
-      // what the outer product misses of this cell (rank_one_factors admits up to 1e-13 of the
-      // largest cell; a Gaussian's cells are products to the last bit or two), plus the rounding
-      // of the product that stands in for it
-      const double product=column[i/kw]*row[i % kw];
-      residual+=std::fabs(cell-product)+std::fabs(product)*2.220446049250313e-16;
+      total+=cell;
+      negative=negative || (cell < 0.0);
+      positive=positive || (cell > 0.0);
+      // what the outer product (+ delta at its one cell) misses of this cell (rank_one_factors
+      // admits up to 1e-13 of the largest cell; a Gaussian's cells are products to the last bit
+      // or two), plus the rounding of the product that stands in for it
+      double product=column[i/kw]*row[i % kw];
+      double rounding=std::fabs(product)*2.220446049250313e-16;
+      if ((delta != 0.0) && (i == delta_y*kw+delta_x))
+        {
+          rounding+=std::fabs(delta)*2.220446049250313e-16;
+          product+=delta;
+        }
+      residual+=std::fabs(cell-product)+rounding;
       magnitude+=std::fabs(cell);
       // the reference's running sum after this cell is at most `running` * max|sample|: its
       // addition rounds to half an ulp of that
       running+=std::fabs(cell);
       partials+=running;
-      negative=negative || (cell < 0.0);
     }
-  if (blend && negative)
-    return MH_OK;                                  // sum(k*alpha) may cancel: the generic kernel's job
   // reference: one rounding per addition (`partials`), two per term (alpha*k, *p); the two
   // separable passes: a fused multiply-add per tap on sums of at most `magnitude` * max|sample|
+  // (+ |delta| for the extra cell).  Cells of both signs are fine: every bound is absolute, and
+  // the finish kernel recomputes where an alpha sum has cancelled down to its error.
   const double unit=1.1102230246251565e-16;
-  const double error_unit=2.0*(residual+unit*(partials+2.0*magnitude)+unit*((double) (kw+kh)+6.0)*magnitude);
+  const double error_unit=2.0*(residual+unit*(partials+2.0*magnitude)+
+    unit*((double) (kw+kh)+8.0)*(magnitude+std::fabs(delta)));
   const bool is_float=src.quantum != MH_QUANTUM_U16;
-  double tie_margin=1.0e-6;
-  if (!is_float)
-    {
-      // levels: alpha*p <= 65535^2 over an alpha sum that carries the same relative error
-      const double level_error=error_unit*65535.0*(blend ? 2.0 : 1.0)/(magnitude > 0.0 ? magnitude : 1.0);
-      tie_margin=level_error*16.0 > tie_margin ? level_error*16.0 : tie_margin;
-      if (tie_margin > 1.0e-3)
-        return MH_OK;                              // (a kernel of tens of thousands of cells)
-    }
+  if (!is_float && (error_unit*65535.0*65535.0 > 65535.0*1.0e-3))
+    return MH_OK;                                  // (a kernel of tens of thousands of cells)
+  // alpha-weighted frames under a kernel whose cells (nearly) cancel — EdgeImage's sums to zero:
+  // sum(k*alpha) is all cancellation on any smooth alpha, PerceptibleReciprocal's clamp decides
+  // every pixel and every pixel would go through the reference-order walk: the generic kernel's job
+  if (blend && negative && positive && !(std::fabs(total) > 0.05*magnitude))
+    return MH_OK;
   const size_t n=(size_t) src.columns*src.rows;
   Temp memory,table;
   MH_TRY(memory.alloc(src.device,2*n*4*sizeof(double)+4*sizeof(double),src.stream));
@@ -346,7 +377,14 @@ MhStatus launch_separable_exact(const View &src,const View &dst,const MhKernelIn
   a.shiftx=kw-1-(int) kernel->x;
   a.shifty=kh-1-(int) kernel->y;
   a.error_unit=error_unit;
-  a.tie_margin=tie_margin;
+  for (int c=0; c < 4; c++)
+    a.fixed_bound[c]=(blend && (c != src.channels-1)) ? 65535.0*65535.0 : 65535.0;
+  a.delta=delta;
+  // kernel cell (delta_y, delta_x) multiplies window position (kh-1-delta_y, kw-1-delta_x) of the
+  // reflected walk: source (x + kernel->x - delta_x, y + kernel->y - delta_y)
+  a.mixed_signs=(negative && positive) ? 1 : 0;
+  a.delta_dx=(int) kernel->x-delta_x;
+  a.delta_dy=(int) kernel->y-delta_y;
   a.recomputed=nullptr;
   if (g_separable_count && (src.device >= 0) && (src.device < 64))
     {

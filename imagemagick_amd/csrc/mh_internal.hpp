@@ -265,8 +265,10 @@ MhStatus launch_conv1d_unsharp(const View &rows,const View &dst,const View &orig
 // vertical = false: src Quantum RGBA -> dst float sums; vertical = true: the reverse
 MhStatus launch_conv1d_sums64(const View &src,const View &dst,bool vertical,const Conv1DParams &params);
 // EXACT (and float-Quantum FAST) 2-D Convolve with an outer-product kernel: two fp64 passes + tie check
+// (delta: the kernel is column x row + delta at cell (delta_y, delta_x) — SharpenImage, EdgeImage)
 MhStatus launch_separable_exact(const View &src,const View &dst,const MhKernelInfo *kernel,
-  const double *row,const double *column,const Roles &roles,bool *handled);
+  const double *row,const double *column,const Roles &roles,bool *handled,int delta_x=0,int delta_y=0,
+  double delta=0.0);
 MhStatus launch_conv1d_sums(const View &src,const View &dst,bool vertical,const Conv1DParams &params,
   bool blend,bool *handled);
 

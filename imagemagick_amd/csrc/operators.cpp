@@ -107,6 +107,45 @@ static bool rank_one_factors(const MhKernelInfo *k,std::vector<double> &row,std:
   return true;
 }
 
+// ... or an outer product everywhere but at its origin cell: SharpenImage's negated Gaussian and
+// EdgeImage's box of -1, whose centre carries the normalisation (effect.c:3640-3660, :1530-1545).
+// The pivot is the largest cell off the origin's row and column, so that neither factor is read
+// from the odd cell; delta = what the origin cell holds beyond column[y]*row[x].
+static bool rank_one_plus_delta(const MhKernelInfo *k,std::vector<double> &row,std::vector<double> &column,
+  double *delta)
+{
+  const size_t w=k->width,h=k->height;
+  const size_t ox=(size_t) k->x,oy=(size_t) k->y;
+  if ((w < 3) || (h < 3) || (k->x < 0) || (k->y < 0) || (ox >= w) || (oy >= h))
+    return false;
+  size_t pivot=0;
+  double largest=0.0;
+  for (size_t y=0; y < h; y++)
+    for (size_t x=0; x < w; x++)
+      if ((y != oy) && (x != ox) && (std::fabs(k->values[y*w+x]) > largest))
+        {
+          largest=std::fabs(k->values[y*w+x]);
+          pivot=y*w+x;
+        }
+  if (!(largest > 0.0) || !std::isfinite(largest) || !std::isfinite(k->values[oy*w+ox]))
+    return false;
+  const size_t py=pivot/w,px=pivot % w;
+  row.assign(k->values+py*w,k->values+(py+1)*w);
+  column.resize(h);
+  for (size_t y=0; y < h; y++)
+    column[y]=k->values[y*w+px]/k->values[pivot];
+  double scale=largest;
+  for (size_t i=0; i < w*h; i++)
+    if ((i != oy*w+ox) && (std::fabs(k->values[i]) > scale))
+      scale=std::fabs(k->values[i]);
+  for (size_t y=0; y < h; y++)
+    for (size_t x=0; x < w; x++)
+      if (((y != oy) || (x != ox)) && !(std::fabs(k->values[y*w+x]-column[y]*row[x]) <= 1.0e-13*scale))
+        return false;
+  *delta=k->values[oy*w+ox]-column[oy]*row[ox];
+  return true;
+}
+
 extern "C" MH_API int MhKernelOuterProductFactors(const MhKernelInfo *kernel,double *row,double *column)
 {
   if ((kernel == nullptr) || (kernel->values == nullptr) || (kernel->width == 0) || (kernel->height == 0))
@@ -254,10 +293,19 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
       (kernel->width*kernel->height >= 25) && (getenv("MAGICKHIP_NO_SEPARABLE") == nullptr))
     {
       std::vector<double> row,column;
+      double delta=0.0;
       if (rank_one_factors(kernel,row,column))
         {
           bool handled=false;
           MH_TRY(launch_separable_exact(src,dst,kernel,row.data(),column.data(),roles,&handled));
+          if (handled)
+            return MH_OK;
+        }
+      else if (rank_one_plus_delta(kernel,row,column,&delta))
+        {
+          bool handled=false;
+          MH_TRY(launch_separable_exact(src,dst,kernel,row.data(),column.data(),roles,&handled,
+            (int) kernel->x,(int) kernel->y,delta));
           if (handled)
             return MH_OK;
         }
