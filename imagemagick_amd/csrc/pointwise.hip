@@ -999,9 +999,9 @@ static __device__ __forceinline__ void packed_table_to_slab(const unsigned *tabl
     slab[i]=packed[i];
 }
 
-template<int C,bool PLAIN>
+template<typename Q,int C,bool PLAIN>
 __global__ __launch_bounds__(1024)
-void histogram_packed_kernel(const uint16_t *pixels,size_t npixels,IntensityParams ip,unsigned *slabs,
+void histogram_packed_kernel(const Q *pixels,size_t npixels,IntensityParams ip,unsigned *slabs,
   unsigned long long *counts,int wide)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1016,13 +1016,13 @@ void histogram_packed_kernel(const uint16_t *pixels,size_t npixels,IntensityPara
   size_t end=begin+per;
   end=end < npixels ? end : npixels;
   const size_t packed_end=end-begin > kPackedCapacity ? begin+kPackedCapacity : end;
-  auto count=[&](const uint16_t (&q)[C])
+  auto count=[&](const Q (&q)[C])
   {
-    const unsigned bin=QuantumOps<uint16_t>::map_index(QuantumOps<uint16_t>::clamp(pixel_intensity_of<PLAIN,uint16_t,C>(q,ip)));
+    const unsigned bin=QuantumOps<Q>::map_index(QuantumOps<Q>::clamp(pixel_intensity_of<PLAIN,Q,C>(q,ip)));
     atomicAdd(table+(bin >> 1),(bin & 1u) != 0u ? 0x10000u : 1u);
   };
   size_t done=begin;                           // pixels [begin, done) are in the LDS table
-  if constexpr (C == 4)
+  if constexpr ((C == 4) && (sizeof(Q) == 2))
     if (wide != 0)
       {
         // 16-byte loads: two RGBA pixels per lane, eight loads in flight
@@ -1053,12 +1053,12 @@ void histogram_packed_kernel(const uint16_t *pixels,size_t npixels,IntensityPara
   constexpr int BATCH=4;
   for (size_t i0=done+threadIdx.x; i0 < end; i0+=(size_t) 1024*BATCH)
     {
-      uint16_t q[BATCH][C];
+      Q q[BATCH][C];
 #pragma unroll
       for (int k=0; k < BATCH; k++)
         {
           const size_t i=i0+(size_t) 1024*k;
-          load_pixel<uint16_t,C>(pixels+(i < end ? i : end-1)*C,q[k]);
+          load_pixel<Q,C>(pixels+(i < end ? i : end-1)*C,q[k]);
         }
 #pragma unroll
       for (int k=0; k < BATCH; k++)
@@ -1071,7 +1071,7 @@ void histogram_packed_kernel(const uint16_t *pixels,size_t npixels,IntensityPara
           else
             {
               // beyond what the 16-bit counters may hold: the caller's table directly
-              const unsigned bin=QuantumOps<uint16_t>::map_index(QuantumOps<uint16_t>::clamp(pixel_intensity_of<PLAIN,uint16_t,C>(q[k],ip)));
+              const unsigned bin=QuantumOps<Q>::map_index(QuantumOps<Q>::clamp(pixel_intensity_of<PLAIN,Q,C>(q[k],ip)));
               for (int c=0; c < C; c++)
                 atomicAdd(counts+(size_t) bin*C+c,1ull);
             }
@@ -1120,29 +1120,29 @@ static size_t packed_histogram_blocks(int device,size_t n)
   return nblocks > 65536 ? 0 : nblocks;
 }
 
-template<int C>
+template<typename Q,int C>
 static MhStatus histogram_intensity_packed(const View &src,const IntensityParams &ip,unsigned long long *hist)
 {
   const size_t n=src.columns*src.rows;
   const size_t nblocks=packed_histogram_blocks(src.device,n);
   if (nblocks == 0)
-    return histogram_intensity_lds<uint16_t,C>(src,ip,hist);
+    return histogram_intensity_lds<Q,C>(src,ip,hist);
   Temp slabs;
   MH_TRY(slabs.alloc(src.device,nblocks*32768*sizeof(unsigned),src.stream));
   const size_t lds=32768*sizeof(unsigned);
   const bool plain=intensity_is_plain_luma(ip,C);
-  MH_HIP(hipFuncSetAttribute(plain ? reinterpret_cast<const void *>(&histogram_packed_kernel<C,true>) :
-    reinterpret_cast<const void *>(&histogram_packed_kernel<C,false>),
+  MH_HIP(hipFuncSetAttribute(plain ? reinterpret_cast<const void *>(&histogram_packed_kernel<Q,C,true>) :
+    reinterpret_cast<const void *>(&histogram_packed_kernel<Q,C,false>),
     hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
-  const int wide=(C == 4) && ((reinterpret_cast<uintptr_t>(src.pixels) & 15u) == 0) ? 1 : 0;
+  const int wide=(C == 4) && (sizeof(Q) == 2) && ((reinterpret_cast<uintptr_t>(src.pixels) & 15u) == 0) ? 1 : 0;
   {
     ProfileScope prof("histogram",src.stream);
     if (plain)
-      hipLaunchKernelGGL((histogram_packed_kernel<C,true>),dim3((unsigned) nblocks),dim3(1024),lds,src.stream,
-        static_cast<const uint16_t *>(src.pixels),n,ip,slabs.as<unsigned>(),hist,wide);
+      hipLaunchKernelGGL((histogram_packed_kernel<Q,C,true>),dim3((unsigned) nblocks),dim3(1024),lds,src.stream,
+        static_cast<const Q *>(src.pixels),n,ip,slabs.as<unsigned>(),hist,wide);
     else
-      hipLaunchKernelGGL((histogram_packed_kernel<C,false>),dim3((unsigned) nblocks),dim3(1024),lds,src.stream,
-        static_cast<const uint16_t *>(src.pixels),n,ip,slabs.as<unsigned>(),hist,wide);
+      hipLaunchKernelGGL((histogram_packed_kernel<Q,C,false>),dim3((unsigned) nblocks),dim3(1024),lds,src.stream,
+        static_cast<const Q *>(src.pixels),n,ip,slabs.as<unsigned>(),hist,wide);
     hipLaunchKernelGGL(histogram_packed_reduce_kernel,dim3(256),dim3(1024),0,src.stream,
       slabs.as<unsigned>(),(int) nblocks,hist,C);
   }
@@ -1603,9 +1603,10 @@ static MhStatus histogram_typed(const View &src,int mode,const IntensityParams &
   // does not amortise the 2 x 256 x 128 KB slab traffic)
   if ((mode != 0) && (n >= ((size_t) 1 << 20)) && (getenv("MAGICKHIP_NO_LDS_HISTOGRAM") == nullptr))
     {
-      if constexpr (sizeof(Q) == 2)
-        if ((getenv("MAGICKHIP_NO_PACKED_HISTOGRAM") == nullptr) && (n < ((size_t) 1 << 31)))
-          return histogram_intensity_packed<C>(src,ip,hist);
+      // one pass with 16-bit counters, Q16 and float Quantum alike (the bin of a float sample is
+      // ScaleQuantumToMap's)
+      if ((getenv("MAGICKHIP_NO_PACKED_HISTOGRAM") == nullptr) && (n < ((size_t) 1 << 31)))
+        return histogram_intensity_packed<Q,C>(src,ip,hist);
       return histogram_intensity_lds<Q,C>(src,ip,hist);
     }
   Temp before;
