@@ -41,6 +41,39 @@ def pixels(rows, cols, kind):
     return px
 
 
+def dev_float(px, **kw):
+    return im.Image(torch.from_numpy(px).cuda(), **kw)
+
+
+def float_pixels(rows, cols, kind):
+    """Float Quantum frames: fractional levels, values beyond the Quantum range and below zero,
+    small / zero alpha, neighbouring floats (values on float-rounding midpoints after a blur)."""
+    px = (rng.random((rows, cols, 4)) * 65535.0).astype(np.float32)
+    if kind == 1:
+        px[:, :, 3] = 65535.0
+    elif kind == 2:
+        px[:, :, 3] = (10.0 ** rng.uniform(-9, 0, (rows, cols))).astype(np.float32)
+    elif kind == 3:
+        px[:, :, :3] = (rng.random((rows, cols, 3)) * 90000.0 - 12000.0).astype(np.float32)
+        px[:, :, 3] = np.where(rng.random((rows, cols)) < 0.3, 0.0, 65535.0)
+    elif kind == 4:
+        low = np.float32(rng.uniform(1.0, 60000.0))
+        board = (np.add.outer(np.arange(rows), np.arange(cols)) % 2) == 1
+        px[:, :, :3] = np.where(board, np.nextafter(low, np.float32(np.inf)), low)[:, :, None]
+        px[:, :, 3] = 65535.0
+    return px
+
+
+def check_bits(name, got, want, detail):
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    if not same.all():
+        bad = np.argwhere(~same)
+        print("MISMATCH %s %s: %d float samples differ, first at %s: %r vs %r" % (
+            name, detail, len(bad), bad[0].tolist(), got[tuple(bad[0])], want[tuple(bad[0])]), flush=True)
+        return 1
+    return 0
+
+
 def check(name, got, want, limit, detail):
     d = np.abs(got.astype(np.int64) - want.astype(np.int64))
     if d.max(initial=0) > limit:
@@ -52,7 +85,9 @@ def check(name, got, want, limit, detail):
 
 
 # STRESS_OPS=0,1,2 restricts the operators (0 FAST blur, 1 EXACT blur, 2 FAST unsharp, 3 Erode/Dilate,
-# 4 histogram operators, 5 FAST 2-D convolve, 6 FAST Lab)
+# 4 histogram operators, 5 FAST 2-D convolve, 6 FAST Lab, 7 EXACT GaussianBlur / Sharpen (separable +
+# tie check), 8 float-Quantum blur / unsharp, 9 float-Quantum Erode / Dilate, 10 float-Quantum
+# GaussianBlur / Sharpen, 11 float-Quantum ContrastStretch / Equalize)
 only_ops = [int(t) for t in os.environ.get("STRESS_OPS", "").split(",") if t.strip()]
 t0 = time.time()
 cases = failures = 0
@@ -62,7 +97,7 @@ while time.time() - t0 < budget:
         rows, cols = int(rng.integers(1, 40)), int(rng.integers(300, 1400))
     kind = int(rng.integers(0, 5))
     px = pixels(rows, cols, kind)
-    op = int(rng.integers(0, 7))
+    op = int(rng.integers(0, 12))
     if only_ops:
         op = only_ops[int(rng.integers(0, len(only_ops)))]
     detail = "%dx%d kind %d" % (rows, cols, kind)
@@ -121,6 +156,59 @@ while time.time() - t0 < budget:
         im.set_precision(im.PRECISION_EXACT)
         want = ref.set_artifact("convolve:scale", "!").morphology("Convolve", 1, kernel).numpy()
         failures += check("fast convolve 2-D", got, want, 1, detail + " " + kernel)
+    elif op == 7:                                  # EXACT 2-D separable kernels (+ the odd centre cell)
+        sigma = float(rng.uniform(0.8, 4.5))
+        if rng.random() < 0.6:
+            got = im.gaussian_blur_image(dev(px), 0.0, sigma).numpy()
+            failures += check("exact gaussian", got, ref.gaussian_blur(0.0, sigma).numpy(), 0, detail + " sigma %.3f" % sigma)
+        else:
+            got = im.sharpen_image(dev(px), 0.0, sigma).numpy()
+            failures += check("exact sharpen", got, ref.sharpen(0.0, sigma).numpy(), 0, detail + " sigma %.3f" % sigma)
+    elif op == 8:                                  # float Quantum: blur / unsharp on the fp64 kernels
+        fpx = float_pixels(rows, cols, kind)
+        fref = refmod.RefImage(fpx)
+        sigma = float(rng.uniform(0.5, 12.0))
+        if rng.random() < 0.5:
+            got = im.blur_image(dev_float(fpx), 0.0, sigma).numpy()
+            failures += check_bits("float blur", got, fref.blur(0.0, sigma).numpy(), detail + " sigma %.3f" % sigma)
+        else:
+            gain, threshold = float(rng.uniform(0.3, 3.0)), float(rng.uniform(0.0, 0.2))
+            got = im.unsharp_mask_image(dev_float(fpx), 0.0, sigma, gain, threshold).numpy()
+            failures += check_bits("float unsharp", got, fref.unsharp(0.0, sigma, gain, threshold).numpy(),
+                                   detail + " sigma %.3f gain %.2f thr %.3f" % (sigma, gain, threshold))
+    elif op == 9:                                  # float Quantum: union-of-rectangles Erode / Dilate
+        fpx = float_pixels(rows, cols, kind)
+        family = ["Disk:%.1f" % rng.uniform(0.5, 16.0), "Square:%d" % rng.integers(1, 9),
+                  "Diamond:%d" % rng.integers(1, 12), "Octagon:%d" % rng.integers(1, 10),
+                  "Rectangle:%dx%d" % (2 * rng.integers(0, 9) + 1, 2 * rng.integers(0, 9) + 1)]
+        kernel = family[int(rng.integers(0, len(family)))]
+        method = "Dilate" if rng.random() < 0.5 else "Erode"
+        got = im.morphology_image(dev_float(fpx), method, 1, kernel).numpy()
+        failures += check_bits("float " + method, got, refmod.RefImage(fpx).morphology(method, 1, kernel).numpy(),
+                               detail + " " + kernel)
+    elif op == 10:                                 # float Quantum: separable 2-D kernels
+        fpx = float_pixels(rows, cols, kind)
+        sigma = float(rng.uniform(0.8, 4.5))
+        if rng.random() < 0.6:
+            got = im.gaussian_blur_image(dev_float(fpx), 0.0, sigma).numpy()
+            failures += check_bits("float gaussian", got, refmod.RefImage(fpx).gaussian_blur(0.0, sigma).numpy(),
+                                   detail + " sigma %.3f" % sigma)
+        else:
+            got = im.sharpen_image(dev_float(fpx), 0.0, sigma).numpy()
+            failures += check_bits("float sharpen", got, refmod.RefImage(fpx).sharpen(0.0, sigma).numpy(),
+                                   detail + " sigma %.3f" % sigma)
+    elif op == 11:                                 # float Quantum: histogram operators above a megapixel
+        rows2, cols2 = int(rng.integers(1000, 1400)), int(rng.integers(1050, 1500))
+        fpx = float_pixels(rows2, cols2, int(rng.integers(0, 2)))
+        n = rows2 * cols2
+        black, white = float(rng.uniform(0, 0.1)) * n, n - float(rng.uniform(0, 0.1)) * n
+        if rng.random() < 0.5:
+            got = im.contrast_stretch_image(dev_float(fpx), black, white).numpy()
+            want = refmod.RefImage(fpx).contrast_stretch(black, white).numpy()
+        else:
+            got = im.equalize_image(dev_float(fpx)).numpy()
+            want = refmod.RefImage(fpx).equalize().numpy()
+        failures += check_bits("float histogram op", got, want, "%dx%d" % (rows2, cols2))
     else:                                          # FAST Lab
         im.set_precision(im.PRECISION_FAST)
         d2 = dev(px)
