@@ -361,7 +361,12 @@ MhStatus launch_separable_exact(const View &src,const View &dst,const MhKernelIn
     return MH_OK;
   const size_t n=(size_t) src.columns*src.rows;
   Temp memory,table;
-  MH_TRY(memory.alloc(src.device,2*n*4*sizeof(double)+4*sizeof(double),src.stream));
+  if (memory.alloc(src.device,2*n*4*sizeof(double)+4*sizeof(double),src.stream) != MH_OK)
+    {
+      // 64 bytes of fp64 sums per pixel do not fit next to the frames: the generic walk needs none
+      (void) hipGetLastError();
+      return MH_OK;
+    }
   MH_TRY(upload_table(table,src.device,src.stream,kernel->values,(size_t) kw*kh*sizeof(double)));
   SeparableArgs a;
   a.src=src.pixels;
