@@ -1204,7 +1204,10 @@ struct PassTables
   }
 };
 
-constexpr int kVerticalRows=4;      // output rows per tile of resize_vertical_kernel
+#ifndef MH_VERTICAL_ROWS
+#define MH_VERTICAL_ROWS 4
+#endif
+constexpr int kVerticalRows=MH_VERTICAL_ROWS;      // output rows per tile of resize_vertical_kernel
 
 template<typename T>
 static MhStatus build_pass_tables(PassTables &p,const TapTable &table,bool vertical,int device,
