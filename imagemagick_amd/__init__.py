@@ -173,6 +173,26 @@ def kernel_outer_product_factors(kernel_string):
         lib.MhDestroyKernelInfo(ptr)
 
 
+def kernel_outer_product_plus_delta(kernel_string):
+    """(kind, row, column, delta) with kind 1 = outer product, 2 = outer product + delta at the
+    origin cell (what the EXACT separable path takes), or None."""
+    lib = _lib.load()
+    ptr = lib.MhAcquireKernelInfo(kernel_string.encode())
+    if not ptr:
+        raise MagickHipError(3, lib.MhGetLastError().decode())
+    try:
+        k = ptr.contents
+        row = np.empty(k.width, dtype=np.float64)
+        column = np.empty(k.height, dtype=np.float64)
+        delta = ctypes.c_double(0.0)
+        kind = lib.MhKernelOuterProductPlusDelta(ptr, row.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                 column.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                 ctypes.byref(delta))
+        return (kind, row, column, delta.value) if kind else None
+    finally:
+        lib.MhDestroyKernelInfo(ptr)
+
+
 def kernel_to_numpy(kernel_string, index=0):
     """Build a kernel list with the product's host builder and return kernel
     `index` as (values[h,w], x, y, count)."""

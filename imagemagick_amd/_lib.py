@@ -152,6 +152,8 @@ PROTOTYPES = [
     ("MhScaleKernelInfo", None, [_P(MhKernelInfo), ctypes.c_double, ctypes.c_uint]),
     ("MhGetOptimalKernelWidth1D", ctypes.c_size_t, [ctypes.c_double, ctypes.c_double]),
     ("MhKernelOuterProductFactors", ctypes.c_int, [_P(MhKernelInfo), _P(ctypes.c_double), _P(ctypes.c_double)]),
+    ("MhKernelOuterProductPlusDelta", ctypes.c_int, [_P(MhKernelInfo), _P(ctypes.c_double), _P(ctypes.c_double),
+                                                   _P(ctypes.c_double)]),
     ("MhGetOptimalKernelWidth2D", ctypes.c_size_t, [ctypes.c_double, ctypes.c_double]),
     ("MhAcquireResizeFilter", ctypes.c_void_p, [ctypes.c_int, ctypes.c_int]),
     ("MhAcquireResizeFilterFromCallback", ctypes.c_void_p,

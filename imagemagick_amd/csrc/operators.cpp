@@ -163,6 +163,34 @@ extern "C" MH_API int MhKernelOuterProductFactors(const MhKernelInfo *kernel,dou
   return 1;
 }
 
+// ... and the form with one odd cell at the origin: returns 1 (outer product), 2 (outer product +
+// *delta at the origin cell) or 0; what convolve_separable.hip takes
+extern "C" MH_API int MhKernelOuterProductPlusDelta(const MhKernelInfo *kernel,double *row,double *column,
+  double *delta)
+{
+  if ((kernel == nullptr) || (kernel->values == nullptr) || (kernel->width == 0) || (kernel->height == 0))
+    return 0;
+  for (size_t i=0; i < kernel->width*kernel->height; i++)
+    if (std::isnan(kernel->values[i]))
+      return 0;
+  std::vector<double> r,c;
+  double d=0.0;
+  int kind=0;
+  if (rank_one_factors(kernel,r,c))
+    kind=1;
+  else if (rank_one_plus_delta(kernel,r,c,&d))
+    kind=2;
+  if (kind == 0)
+    return 0;
+  if (row != nullptr)
+    std::memcpy(row,r.data(),r.size()*sizeof(double));
+  if (column != nullptr)
+    std::memcpy(column,c.data(),c.size()*sizeof(double));
+  if (delta != nullptr)
+    *delta=d;
+  return kind;
+}
+
 // FAST precision, Q16, a 2-D Convolve kernel that is an outer product: two 1-D passes over
 // float sums instead of width*height taps per pixel (GaussianBlurImage 0x10: 79+79 instead of
 // 6241).  Same window, same edge clamp (clamping is per axis) and one division at the end as in

@@ -283,6 +283,12 @@ MH_API size_t MhGetOptimalKernelWidth2D(double radius,double sigma);
    ConvolveImage runs such kernels (Gaussian:RxS, i.e. GaussianBlurImage) as two 1-D passes
    with one division at the end instead of morphology.c:2892-2979's width*height taps. */
 MH_API int MhKernelOuterProductFactors(const MhKernelInfo *kernel,double *row,double *column);
+/* ... or an outer product everywhere but at its origin cell (SharpenImage's negated Gaussian,
+   EdgeImage's box of -1: effect.c:3640-3660, :1530-1545)?  Returns 1 (outer product, *delta = 0),
+   2 (values[y][x] = column[y]*row[x] + *delta at the origin cell) or 0.  EXACT mode and float
+   Quantum run both forms as two fp64 passes with a tie check, bit-identical to the w x h walk. */
+MH_API int MhKernelOuterProductPlusDelta(const MhKernelInfo *kernel,double *row,double *column,
+  double *delta);
 
 /* MorphologyMethod, MagickCore/morphology.h:72-98 (same values) */
 typedef enum

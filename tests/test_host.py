@@ -144,6 +144,44 @@ def test_outer_product_kernels_are_recognised(im):
         assert im.kernel_outer_product_factors(spec) is None, spec
 
 
+def test_outer_product_plus_origin_cell_kernels_are_recognised(im):
+    """Host logic of the EXACT separated ConvolveImage: SharpenImage's negated Gaussian whose centre
+    carries the normalisation (effect.c:3640-3660) and EdgeImage's box of -1 with w*h-1 in the middle
+    (effect.c:1530-1545) are an outer product + one cell; the factors never read the odd cell."""
+    def spec_of(values):
+        h, w = values.shape
+        return "%dx%d: %s" % (w, h, " ".join(",".join("%.17g" % v for v in r) for r in values))
+
+    x = np.arange(-3, 4, dtype=np.float64)
+    gauss = -np.exp(-(x[:, None] ** 2 + x[None, :] ** 2) / (2.0 * 1.5 ** 2))
+    sharpen = gauss.copy()
+    sharpen[3, 3] = -2.0 * (gauss.sum() - gauss[3, 3])
+    edge = -np.ones((5, 5))
+    edge[2, 2] = 24.0
+    wide = -np.outer([1.0, 2.0, 1.0], [1.0, 3.0, 5.0, 3.0, 1.0])
+    wide[1, 2] += 40.0
+    for values in (sharpen, edge, wide):
+        got = im.kernel_outer_product_plus_delta(spec_of(values))
+        assert got is not None
+        kind, row, column, delta = got
+        assert kind == 2 and delta != 0.0
+        rebuilt = np.outer(column, row)
+        rebuilt[values.shape[0] // 2, values.shape[1] // 2] += delta
+        assert np.abs(rebuilt - values).max() <= 1e-13 * np.abs(values).max()
+        assert im.kernel_outer_product_factors(spec_of(values)) is None
+    # a plain outer product reports kind 1 and no delta
+    kind, row, column, delta = im.kernel_outer_product_plus_delta("Gaussian:0x2")
+    assert kind == 1 and delta == 0.0
+    # two odd cells, an odd cell off the origin, NaN holes, kernels too small: no
+    two = sharpen.copy(); two[0, 0] += 0.5
+    off = gauss.copy(); off[1, 1] += 3.0
+    for values in (two, off):
+        assert im.kernel_outer_product_plus_delta(spec_of(values)) is None
+    for spec in ("Disk:2.5", "Ring:1,2.5", "3x3: 1,nan,1 1,9,1 1,1,1", "1x3: 1,5,1"):
+        got = im.kernel_outer_product_plus_delta(spec)
+        assert got is None or got[0] == 1, spec
+
+
 def test_optimal_kernel_width(im):
     from imagemagick_amd import _lib
     lib = _lib.load()
