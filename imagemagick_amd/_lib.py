@@ -143,6 +143,7 @@ PROTOTYPES = [
     ("MhResetProfileRecords", None, []),
     ("MhExactBlurRecomputed", ctypes.c_ulonglong, [ctypes.c_int]),
     ("MhSeparableRecomputed", ctypes.c_ulonglong, [ctypes.c_int]),
+    ("MhConvolve2DRecomputed", ctypes.c_ulonglong, [ctypes.c_int]),
     ("MhHostAlloc", ctypes.c_void_p, [ctypes.c_size_t]),
     ("MhHostFree", ctypes.c_int, [ctypes.c_void_p]),
     ("MhHostAllocatedBytes", ctypes.c_size_t, []),

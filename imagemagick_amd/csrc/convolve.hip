@@ -1818,6 +1818,20 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
           prec=MH_PRECISION_EXACT;
           break;
         }
+  // ... and taps of both signs with a large gain on any layout: the float sums are good to 2^-21 of
+  // sum|k|*65535, which cancellation does not shrink
+  if (prec == MH_PRECISION_FAST)
+    {
+      double magnitude=0.0;
+      bool negative=false;
+      for (int v=0; v < params.ntaps; v++)
+        {
+          magnitude+=std::fabs(params.taps[v]);
+          negative=negative || (params.taps[v] < 0.0);
+        }
+      if (negative && !(magnitude <= 8.0))
+        prec=MH_PRECISION_EXACT;
+    }
   if (src.quantum == MH_QUANTUM_U16)
     {
       if (prec == MH_PRECISION_FAST)

@@ -351,6 +351,16 @@ MhStatus launch_conv2d_mfma(const View &src,const View &dst,const MhKernelInfo *
     return MH_OK;
   // the reflected walk of morphology.c:2925: cell (v,u) carries values[(kh-1-v)*kw+(kw-1-u)]
   std::vector<float> taps((size_t) kw*kh);
+  {
+    // three f16 products per term are good to 2^-21 of sum|k|*65535: within a level for kernels
+    // that average, not for one with a gain of tens (and those of both signs cancel)
+    double magnitude=0.0;
+    for (int i=0; i < kw*kh; i++)
+      if (!std::isnan(kernel->values[i]))
+        magnitude+=std::fabs(kernel->values[i]);
+    if (!(magnitude <= 8.0))
+      return MH_OK;
+  }
   for (int v=0; v < kh; v++)
     for (int u=0; u < kw; u++)
       {

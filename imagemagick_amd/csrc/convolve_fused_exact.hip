@@ -160,17 +160,6 @@ struct ExactGeometry
   static_assert((SRX % 16) == 0,"16-byte operand reads");
 };
 
-// 4 x 4 byte transpose: x[t] = the 32-bit sample of position t -> p[i] = byte i of positions 0..3
-static __device__ __forceinline__ void byte_planes(const unsigned (&x)[4],unsigned (&p)[4])
-{
-  const unsigned l01=__builtin_amdgcn_perm(x[1],x[0],0x05010400u),h01=__builtin_amdgcn_perm(x[1],x[0],0x07030602u);
-  const unsigned l23=__builtin_amdgcn_perm(x[3],x[2],0x05010400u),h23=__builtin_amdgcn_perm(x[3],x[2],0x07030602u);
-  p[0]=__builtin_amdgcn_perm(l23,l01,0x05040100u);
-  p[1]=__builtin_amdgcn_perm(l23,l01,0x07060302u);
-  p[2]=__builtin_amdgcn_perm(h23,h01,0x05040100u);
-  p[3]=__builtin_amdgcn_perm(h23,h01,0x07060302u);
-}
-
 // The kept digit products of one chunk of the band: a[i] = byte plane i of the samples, t[j] =
 // digit j of the Toeplitz taps, class i+j-3.  First chunk: 64 slots (v_mfma_i32_16x16x64_i8,
 // 16 bytes per lane); second chunk (kernels of more than 49 taps): 32 slots

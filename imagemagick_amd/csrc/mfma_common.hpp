@@ -33,6 +33,17 @@ static __device__ __forceinline__ void split_f16(float v,_Float16 &hi,_Float16 &
   lo=(_Float16) (v-top);
 }
 
+// 4 x 4 byte transpose: x[t] = the 32-bit sample of position t -> p[i] = byte i of positions 0..3
+static __device__ __forceinline__ void byte_planes(const unsigned (&x)[4],unsigned (&p)[4])
+{
+  const unsigned l01=__builtin_amdgcn_perm(x[1],x[0],0x05010400u),h01=__builtin_amdgcn_perm(x[1],x[0],0x07030602u);
+  const unsigned l23=__builtin_amdgcn_perm(x[3],x[2],0x05010400u),h23=__builtin_amdgcn_perm(x[3],x[2],0x07030602u);
+  p[0]=__builtin_amdgcn_perm(l23,l01,0x05040100u);
+  p[1]=__builtin_amdgcn_perm(l23,l01,0x07060302u);
+  p[2]=__builtin_amdgcn_perm(h23,h01,0x05040100u);
+  p[3]=__builtin_amdgcn_perm(h23,h01,0x07060302u);
+}
+
 // y*W+x for rows and columns below 2^24 and fewer than 2^32 pixels (the launchers check):
 // one full-rate v_mad_u32_u24 instead of a 64-bit multiply
 static __device__ __forceinline__ size_t pixel_index(int y,int W,int x)

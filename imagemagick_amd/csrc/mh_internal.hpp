@@ -242,6 +242,10 @@ MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const 
 // morphology.c:2746 (taps[v] multiplies the input at o-shift+v), as floats and as doubles
 // (the doubles feed the exact recomputation of ambiguous small alpha levels).
 // *handled=false when the shape is outside the kernel's reach and nothing was launched.
+// ... with cells that are integer multiples of a unit: exact sums on the i8 matrix cores,
+// bit-identical in both precision modes (convolve2d_exact.hip)
+MhStatus launch_conv2d_exact(const View &src,const View &dst,const MhKernelInfo *kernel,bool blend,
+  bool *handled);
 MhStatus launch_conv2d_mfma(const View &src,const View &dst,const MhKernelInfo *kernel,bool blend,
   bool *handled);
 MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_device,

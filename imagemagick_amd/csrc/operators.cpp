@@ -211,6 +211,16 @@ static MhStatus separable_convolve(const View &src,const View &dst,const MhKerne
   std::vector<double> row,column;
   if (!rank_one_factors(kernel,row,column))
     return MH_OK;
+  {
+    // float / f16 intermediates are good to 2^-21 of sum|k|*65535: within a level for kernels
+    // that average (sum|k| about 1), not for a derivative kernel with a gain of 96 — and the f16
+    // planes of the matrix-core passes are scaled for sums below 2*65535
+    double magnitude=0.0;
+    for (size_t i=0; i < kernel->width*kernel->height; i++)
+      magnitude+=std::fabs(kernel->values[i]);
+    if (!(magnitude <= 8.0))
+      return MH_OK;
+  }
   if (blend)
     {
       // alpha-weighted sums with cells of both signs (Sobel ...): sum(k*alpha) may vanish, the
@@ -314,6 +324,30 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
       if (handled)
         return MH_OK;
     }
+  // Q16, RGBA (alpha-weighted, alpha last), four plain channels or RGB, cells that are integer
+  // multiples of a unit (flat shapes, integer kernels; NaN cells are fine), 5 x 5 and more: exact
+  // sums on the i8 matrix cores, bit-identical in either mode (convolve2d_exact.hip)
+  const bool matrix_2d=(method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
+    (src.quantum == MH_QUANTUM_U16) && ((src.channels == 4) || ((src.channels == 3) && !roles.blend)) &&
+    (roles.copy_mask == 0) && (!roles.blend || (roles.alpha == 3)) &&
+    (getenv("MAGICKHIP_NO_MFMA") == nullptr) && (getenv("MAGICKHIP_NO_MFMA_2D") == nullptr);
+  // (FAST, up to 17 cells wide: the f16 kernel's band is one 32-slot chunk where the integer one
+  // always multiplies two — Octagon:5 on 8192^2 RGBA 0.59 against 0.92 ms; from 18 cells on the
+  // integer kernel is the faster one as well: Disk:15 on 16384^2 6.4 against 8.3 ms)
+  if (matrix_2d && (mode == MH_PRECISION_FAST) && (kernel->width <= 17))
+    {
+      bool handled=false;
+      MH_TRY(launch_conv2d_mfma(src,dst,kernel,roles.blend,&handled));
+      if (handled)
+        return MH_OK;
+    }
+  if (matrix_2d && (getenv("MAGICKHIP_NO_EXACT_2D") == nullptr))
+    {
+      bool handled=false;
+      MH_TRY(launch_conv2d_exact(src,dst,kernel,roles.blend,&handled));
+      if (handled)
+        return MH_OK;
+    }
   // an outer-product kernel in EXACT mode, or on float Quantum in either mode: two fp64 passes and
   // a tie check, bit-identical to the w x h walk (convolve_separable.hip)
   if ((method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
@@ -340,11 +374,7 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
     }
   // FAST, Q16, RGBA (alpha-weighted, alpha last), four plain channels or RGB, kernels of 5 x 5 and
   // more: the w x h sum as h banded products on the matrix cores (convolve2d_mfma.hip)
-  if ((method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
-      (mode == MH_PRECISION_FAST) && (src.quantum == MH_QUANTUM_U16) &&
-      ((src.channels == 4) || ((src.channels == 3) && !roles.blend)) &&
-      (roles.copy_mask == 0) && (!roles.blend || (roles.alpha == 3)) &&
-      (getenv("MAGICKHIP_NO_MFMA") == nullptr) && (getenv("MAGICKHIP_NO_MFMA_2D") == nullptr))
+  if (matrix_2d && (mode == MH_PRECISION_FAST))
     {
       bool handled=false;
       MH_TRY(launch_conv2d_mfma(src,dst,kernel,roles.blend,&handled));

@@ -237,6 +237,11 @@ MH_API unsigned long long MhExactBlurRecomputed(int enable);
 /* The same for the separable EXACT 2-D Convolve (GaussianBlurImage in EXACT mode and on float
    Quantum): samples recomputed in the reference's w x h order. */
 MH_API unsigned long long MhSeparableRecomputed(int enable);
+/* Diagnostic of the exact-integer 2-D convolve (cells that are integer multiples of a unit: every
+   flat shape kernel; morphology.c:2919-2979 on the i8 matrix cores, bit-identical): samples that
+   lay within the reference's own rounding error of a Quantum boundary and were recomputed in the
+   reference's order since the last call (enable as above). */
+MH_API unsigned long long MhConvolve2DRecomputed(int enable);
 
 /* ------------------------------------------------------ kernels and filters */
 

@@ -446,6 +446,7 @@ def test_convolve_2d_fast_on_matrix_cores(im, refmod, kernel, alpha, walk, monke
     all four steps through its ring of rows (a small frame is otherwise cut into single steps).
     Within one level of the reference, and of the generic kernel it replaces."""
     import bench
+    monkeypatch.setenv("MAGICKHIP_NO_EXACT_2D", "1")     # (integer cells otherwise take convolve2d_exact.hip)
     if walk:
         monkeypatch.setenv("MAGICKHIP_CONV2D_CUTS", "1")
     px = make_pixels(107 if walk else 75, 150, 4, Q16, seed=len(kernel))
@@ -476,11 +477,12 @@ def test_convolve_2d_fast_on_matrix_cores(im, refmod, kernel, alpha, walk, monke
 
 @pytest.mark.parametrize("kernel", ["Disk:15", "Octagon:5", "Ring:10,14",
                                     "6x6+1+4: 1,0,2,nan,1,3 0,1,1,2,nan,1 2,2,0,1,1,1 nan,1,3,1,0,2 1,1,1,1,2,0 3,0,1,2,1,1"])
-def test_convolve_2d_fast_on_matrix_cores_rgb(im, refmod, kernel):
+def test_convolve_2d_fast_on_matrix_cores_rgb(im, refmod, kernel, monkeypatch):
     """The same kernel on an RGB frame (6-byte pixels): three plain channels, the matrix tile's
     fourth entry zero (convolve2d_mfma.hip, MFMA_PLAIN3); frames ragged against the tiles.
     Within one level of the reference."""
     import bench
+    monkeypatch.setenv("MAGICKHIP_NO_EXACT_2D", "1")
     px = make_pixels(75, 150, 3, Q16, seed=len(kernel) + 3)
     dev, ref = run_pair(im, refmod, px)
     holder = {}
@@ -945,13 +947,14 @@ def test_gaussian_blur_sharpen_edge_emboss(im, refmod, dtype, channels):
                                     "5x5: -1,-2,0,2,1 -4,-8,0,8,4 -6,-12,0,12,6 -4,-8,0,8,4 -1,-2,0,2,1",
                                     "5x5: -1,-2,-3,-2,-1 -2,-4,-6,-4,-2 -3,-6,100,-6,-3 -2,-4,-6,-4,-2 -1,-2,-3,-2,-1",
                                     "5x5: -1,-1,-1,-1,-1 -1,-1,-1,-1,-1 -1,-1,24.5,-1,-1 -1,-1,-1,-1,-1 -1,-1,-1,-1,-1"])
-def test_separable_2d_convolve_exact(im, refmod, dtype, channels, alpha, kernel):
+def test_separable_2d_convolve_exact(im, refmod, dtype, channels, alpha, kernel, monkeypatch):
     """EXACT 2-D Convolve with a kernel that is an outer product (GaussianBlurImage's kernels,
     boxes, column x row products): two fp64 1-D passes over alpha-premultiplied doubles and a tie
     check, the undecided samples recomputed in the reference's w x h order
     (convolve_separable.hip) — bit-identical on Q16 and on float Quantum, every layout, small and
     zero alpha, frames ragged against the kernels' tiles."""
     import bench
+    monkeypatch.setenv("MAGICKHIP_NO_EXACT_2D", "1")     # (Q16 boxes and integer kernels otherwise take convolve2d_exact.hip)
     rng = np.random.default_rng(len(kernel) + channels)
     px = make_pixels(83, 141, channels, dtype, seed=len(kernel))
     if alpha:
@@ -987,11 +990,12 @@ def test_separable_2d_convolve_exact(im, refmod, dtype, channels, alpha, kernel)
 
 
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
-def test_separable_2d_convolve_exact_on_ties(im, refmod, dtype):
+def test_separable_2d_convolve_exact_on_ties(im, refmod, dtype, monkeypatch):
     """A checkerboard of two adjacent levels under an even box puts every value exactly on a
     rounding tie (Q16) or on the midpoint of two floats (HDRI): all of them go through the
     reference-order recomputation; GaussianBlurImage of the same frame lands 1e-5 beside the ties.
     Both bit-identical."""
+    monkeypatch.setenv("MAGICKHIP_NO_EXACT_2D", "1")
     rows, cols = 70, 110
     y, x = np.mgrid[0:rows, 0:cols]
     px = np.empty((rows, cols, 4), dtype=dtype)
@@ -1016,6 +1020,113 @@ def test_separable_2d_convolve_exact_on_ties(im, refmod, dtype):
     ref = refmod.RefImage(px)
     got = im.gaussian_blur_image(dev, 0.0, 2.0).numpy()
     assert np.array_equal(got.view(bits), ref.gaussian_blur(0.0, 2.0).numpy().view(bits))
+
+
+INTEGER_KERNELS = ["Disk:15", "Disk:7.3", "Octagon:5", "Diamond:4", "Plus:3", "Ring:10,14", "Square:3",
+                   "Rectangle:8x4", "Rectangle:49x5+3+1", "Rectangle:65x3+40+1",
+                   "7x5: 1,2,3,4,3,2,1 2,4,6,8,6,4,2 3,6,9,13,9,6,2 2,4,6,8,6,4,2 1,2,3,4,3,2,1",
+                   "6x6+1+4: 1,0,2,nan,1,3 0,1,1,2,nan,1 2,2,0,1,1,1 nan,1,3,1,0,2 1,1,1,1,2,0 3,0,1,2,1,1",
+                   # cells 2s and 3s (the unit is half the smallest cell), 0.25 steps, and both signs
+                   "5x5: 2,3,2,3,2 3,2,3,2,3 2,3,2,3,2 3,2,3,2,3 2,3,2,3,2",
+                   "5x5: -1,-2,0,2,1 -4,-8,0,8,4 -6,-12,0,12,6 -4,-8,0,8,4 -1,-2,0,2,1",
+                   "5x5: -1,-1,-1,-1,-1 -1,-1,-1,-1,-1 -1,-1,24.5,-1,-1 -1,-1,-1,-1,-1 -1,-1,-1,-1,-1"]
+
+
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+@pytest.mark.parametrize("layout", ["rgba", "plain4", "rgb"])
+@pytest.mark.parametrize("kernel", INTEGER_KERNELS)
+def test_convolve_2d_integer_cells_on_matrix_cores(im, refmod, kernel, layout, mode, monkeypatch):
+    """2-D Convolve whose cells are integer multiples of a unit (flat shapes, integer and
+    half-integer user kernels, NaN holes, origins off centre, the widest window the band holds):
+    exact integer sums on the i8 matrix cores + tie check (convolve2d_exact.hip) — BIT-IDENTICAL in
+    both precision modes, on RGBA with alpha-weighted colour (tiny and zero alpha included), four
+    plain channels and RGB, frames ragged against the 64-column strips and 32-row steps, one
+    workgroup walking its whole strip through the ring of rows."""
+    import bench
+    monkeypatch.setenv("MAGICKHIP_CONV2D_CUTS", "1")
+    channels = 3 if layout == "rgb" else 4
+    alpha = layout == "rgba"
+    rows, cols = 107, 150
+    px = make_pixels(rows, cols, channels, Q16, seed=len(kernel) + channels)
+    if alpha:
+        px[10:30, 20:60, 3] = np.random.default_rng(3).integers(0, 4, (20, 40))       # tiny alpha
+        px[40:50, 100:140, 3] = 0                                                         # transparent
+        px[60:100, 5:50, 3] = 65535                                                       # opaque
+    signed = "-1" in kernel
+    zero_sum = kernel.startswith("5x5: -1,-2,0")
+    scale = None if zero_sum else (1.0, 1)
+    dev = im.Image(to_device(px), has_alpha=alpha)
+
+    def reference(pixels):
+        r = refmod.RefImage(pixels)
+        if not zero_sum:
+            r = r.set_artifact("convolve:scale", "!")
+        return r.morphology("Convolve", 1, kernel).numpy()
+    if alpha or channels == 3:
+        want = reference(px)
+    else:
+        want = np.concatenate([reference(px[:, :, c].copy()).reshape(rows, cols, 1) for c in range(4)], axis=2)
+    holder = {}
+    im.set_precision(im.PRECISION_FAST if mode == "fast" else im.PRECISION_EXACT)
+    try:
+        launched = set(bench.kernel_profile(
+            im, lambda: holder.update(out=im.morphology_image(dev, "Convolve", 1, kernel, scale=scale)), 1))
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    outer_product = zero_sum or kernel.startswith(("Square", "Rectangle"))
+    wide = kernel in ("Disk:15", "Ring:10,14")
+    if not (signed and alpha) and (mode == "exact" or wide):
+        # (alpha-weighted sums of signed cells keep the fp64 kernels; FAST separates an outer product
+        # first and gives kernels of up to 17 columns to the f16 kernel, whose band is one chunk)
+        assert launched == {"conv2d_exact"}, launched
+    elif mode == "fast" and not outer_product and not signed:
+        assert launched == {"conv2d_mfma"}, launched
+    assert_parity(holder["out"].numpy(), want, mode == "exact" or "conv2d_exact" in launched,
+                  "integer 2-D convolve %s %s %s" % (kernel, layout, mode))
+
+
+@pytest.mark.parametrize("layout", ["rgba", "plain4", "rgb"])
+def test_convolve_2d_integer_cells_on_ties(im, refmod, layout):
+    """A checkerboard of two adjacent levels under an 8 x 4 box (16 cells on either colour): the
+    real value of every sample IS the rounding tie, so all of them go through the reference-order
+    recomputation of convolve2d_exact.hip; bit-identical.  A Disk on the same frame has an odd
+    cell count: never within 1/(2*count) of a tie, nothing is recomputed."""
+    rows, cols = 70, 110
+    channels = 3 if layout == "rgb" else 4
+    y, x = np.mgrid[0:rows, 0:cols]
+    px = np.empty((rows, cols, channels), dtype=Q16)
+    for c, level in enumerate((1000, 32767, 65534)):
+        px[:, :, c] = level + ((x + y) & 1)
+    if channels == 4:
+        px[:, :, 3] = 65535 if layout == "rgba" else 7 + 2 * ((x + y) & 1)
+    dev = im.Image(to_device(px), has_alpha=layout == "rgba")
+
+    def reference(kernel):
+        if layout == "plain4":
+            return np.concatenate([refmod.RefImage(px[:, :, c].copy()).set_artifact("convolve:scale", "!")
+                                   .morphology("Convolve", 1, kernel).numpy().reshape(rows, cols, 1) for c in range(4)], axis=2)
+        return refmod.RefImage(px).set_artifact("convolve:scale", "!").morphology("Convolve", 1, kernel).numpy()
+    lib = im._lib.load()
+    lib.MhConvolve2DRecomputed(1)
+    got = im.morphology_image(dev, "Convolve", 1, "Rectangle:8x4", scale=(1.0, 1)).numpy()
+    recomputed = lib.MhConvolve2DRecomputed(1)
+    assert recomputed >= rows * cols * 3 // 2, recomputed
+    assert np.array_equal(got, reference("Rectangle:8x4"))
+    got = im.morphology_image(dev, "Convolve", 1, "Disk:4.3", scale=(1.0, 1)).numpy()
+    recomputed = lib.MhConvolve2DRecomputed(0)
+    assert recomputed == 0, recomputed
+    assert np.array_equal(got, reference("Disk:4.3"))
+
+
+def test_c5_convolve_disk15_exact_full_rows(im, refmod):
+    """ConvolveMorphology Disk:15 (SURVEY 8d's MAC-bound variant of C5) bit-identical on a frame
+    wide enough for several strips per XCD and tall enough for the ring to wrap more than once
+    (704 x 1100 RGBA, alpha random): the reference takes a few seconds."""
+    px = make_pixels(1100, 704, 4, Q16, seed=15)
+    dev, ref = run_pair(im, refmod, px)
+    got = im.morphology_image(dev, "Convolve", 1, "Disk:15", scale=(1.0, 1)).numpy()
+    want = ref.set_artifact("convolve:scale", "!").morphology("Convolve", 1, "Disk:15").numpy()
+    assert np.array_equal(got, want)
 
 
 # ----------------------------------------------------------- ImportImagePixels / ExportImagePixels
