@@ -87,7 +87,8 @@ def check(name, got, want, limit, detail):
 # STRESS_OPS=0,1,2 restricts the operators (0 FAST blur, 1 EXACT blur, 2 FAST unsharp, 3 Erode/Dilate,
 # 4 histogram operators, 5 FAST 2-D convolve, 6 FAST Lab, 7 EXACT GaussianBlur / Sharpen (separable +
 # tie check), 8 float-Quantum blur / unsharp, 9 float-Quantum Erode / Dilate, 10 float-Quantum
-# GaussianBlur / Sharpen, 11 float-Quantum ContrastStretch / Equalize)
+# GaussianBlur / Sharpen, 11 float-Quantum ContrastStretch / Equalize, 12 integer-cell 2-D convolve on the
+# i8 matrix cores in both modes and three layouts)
 only_ops = [int(t) for t in os.environ.get("STRESS_OPS", "").split(",") if t.strip()]
 t0 = time.time()
 cases = failures = 0
@@ -97,7 +98,7 @@ while time.time() - t0 < budget:
         rows, cols = int(rng.integers(1, 40)), int(rng.integers(300, 1400))
     kind = int(rng.integers(0, 5))
     px = pixels(rows, cols, kind)
-    op = int(rng.integers(0, 12))
+    op = int(rng.integers(0, 13))
     if only_ops:
         op = only_ops[int(rng.integers(0, len(only_ops)))]
     detail = "%dx%d kind %d" % (rows, cols, kind)
@@ -209,6 +210,39 @@ while time.time() - t0 < budget:
             got = im.equalize_image(dev_float(fpx)).numpy()
             want = refmod.RefImage(fpx).equalize().numpy()
         failures += check_bits("float histogram op", got, want, "%dx%d" % (rows2, cols2))
+    elif op == 12:                                 # integer-cell 2-D convolve (i8 matrix cores), both modes: bit-identical
+        choice = int(rng.integers(0, 4))
+        if choice == 0:
+            kernel = ["Disk:%.1f" % rng.uniform(2.0, 16.4), "Octagon:%d" % rng.integers(2, 16),
+                      "Diamond:%d" % rng.integers(2, 16), "Plus:%d" % rng.integers(2, 16),
+                      "Ring:%d,%d" % (rng.integers(2, 6), rng.integers(7, 16)),
+                      "Rectangle:%dx%d" % (rng.integers(5, 66), rng.integers(2, 9))][int(rng.integers(0, 6))]
+        else:
+            kw, kh = int(rng.integers(5, 34)), int(rng.integers(5, 12))
+            cells = rng.integers(0 if choice < 3 else -9, 10, (kh, kw)).astype(np.float64)
+            cells[rng.random((kh, kw)) < 0.1] = np.nan
+            if not (np.nansum(np.abs(cells)) > 0) or abs(np.nansum(cells)) < 1:
+                cells[kh // 2, kw // 2] = 77.0
+            kernel = "%dx%d+%d+%d: %s" % (kw, kh, rng.integers(0, kw), rng.integers(0, kh), " ".join(
+                ",".join("nan" if np.isnan(v) else "%d" % v for v in r) for r in cells))
+        layout = int(rng.integers(0, 3))               # RGBA alpha-weighted, four plain channels, RGB
+        fast = rng.random() < 0.3
+        if layout == 0:
+            image, want = dev(px), ref.set_artifact("convolve:scale", "!").morphology("Convolve", 1, kernel).numpy()
+        elif layout == 1:
+            image = dev(px, has_alpha=False)
+            want = np.concatenate([refmod.RefImage(px[:, :, c].copy()).set_artifact("convolve:scale", "!")
+                                   .morphology("Convolve", 1, kernel).numpy().reshape(rows, cols, 1) for c in range(4)], axis=2)
+        else:
+            rgb = np.ascontiguousarray(px[:, :, :3])
+            image = dev(rgb)
+            want = refmod.RefImage(rgb).set_artifact("convolve:scale", "!").morphology("Convolve", 1, kernel).numpy()
+        if fast:
+            im.set_precision(im.PRECISION_FAST)
+        got = im.morphology_image(image, "Convolve", 1, kernel, scale=(1.0, 1)).numpy()
+        im.set_precision(im.PRECISION_EXACT)
+        failures += check("integer convolve 2-D", got, want, 1 if fast else 0, detail + " layout %d %s %s" % (
+            layout, "fast" if fast else "exact", kernel[:60]))
     else:                                          # FAST Lab
         im.set_precision(im.PRECISION_FAST)
         d2 = dev(px)
