@@ -473,10 +473,25 @@ def c5_config(im, torch, gen):
             "kernels": kernel_rooflines(prof, {"morph_rects": 4.0 * frame, "morph_convex": 4.0 * frame,
                                                "morph2d": 4.0 * frame}, "c5hdri:")}
         holder.clear()
+
+        # ... and the MAC-bound variant on the float frame: its samples are integers (what a 16-bit file
+        # decodes to), so the exact-integer i8 kernel takes it (convolve2d_exact.hip; a frame with one
+        # fractional sample falls back to the generic kernel: tools/time_convolve2d_hdri.py)
+        def convolve_float():
+            holder["o"] = None
+            holder["o"] = im.morphology_image(imgf, "Convolve", 1, "Disk:15", scale=(1.0, 1))
+        sec = timed(torch, convolve_float, 2)
+        prof = kernel_profile(im, convolve_float, 2)
+        out["c5_convolve_disk15_hdri"] = {
+            "workload": "16384x16384 RGBA float Quantum (integer samples) MorphologyImage(Convolve, Disk:15), "
+                        "convolve:scale='!'",
+            "Mpixels_per_s": round(k * k / sec / 1e6, 1), "ms": round(sec * 1e3, 3), "tolerance": "bit-identical",
+            "kernels": kernel_rooflines(prof, {"conv2d_exact": 4.0 * frame, "morph2d": 4.0 * frame}, "c5hdri:")}
+        holder.clear()
         del imgf, srcf
         torch.cuda.empty_cache()
     except Exception as exc:                                 # (memory: 3 x 4.3 GB beside the Q16 frames)
-        out["c5_dilate_disk15_hdri"] = {"error": str(exc)[:200]}
+        out.setdefault("c5_dilate_disk15_hdri", {"error": str(exc)[:200]})
 
     def convolve():
         holder["o"] = im.morphology_image(img5, "Convolve", 1, "Disk:15", scale=(1.0, 1))

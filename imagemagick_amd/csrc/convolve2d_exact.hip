@@ -53,13 +53,14 @@
 #include <vector>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace mh {
 
 struct Conv2DXArgs
 {
-  const uint16_t *src;
-  uint16_t *dst;
+  const void *src;
+  void *dst;
   int columns,rows;
   int kw,kh;                  // kernel size
   int shiftx,shifty;          // output (x,y) reads source (x-shiftx+u, y-shifty+v)
@@ -75,6 +76,7 @@ struct Conv2DXArgs
   double error[4];            // how far unit*sum can be from the reference's running sums, per channel
   double relative;            // > 0 (no negative cell): ... as a fraction of the sum itself instead
   unsigned long long *recomputed;
+  unsigned *not_integral;     // float Quantum: set by whoever meets a sample that is not an integer of 0..65535
 };
 
 constexpr int kCXRows=32;     // output rows per step
@@ -143,16 +145,25 @@ static __device__ __forceinline__ uint32_t integer_sums_to_levels(const double (
   return doubtful;
 }
 
-template<int MODE,int NC>
+template<typename Q,int MODE,int NC>
 __global__ __launch_bounds__(512)
 void conv2d_exact_kernel(Conv2DXArgs args)
 {
+  // Q = float: a float-Quantum frame whose samples are all integers of 0..65535 (what an 8- or 16-bit
+  // file decodes to) has the same exact integer sums; the results are floats, the boundaries those
+  // of the float rounding (tie_check.hpp).  The staging checks every sample; the first one that is
+  // not such an integer raises args.not_integral, every workgroup leaves at its next step and the
+  // caller's generic kernel — launched behind this one, returning at once otherwise — does the frame.
+  constexpr bool kFloat=sizeof(Q) == 4;
   constexpr bool BLEND=MODE == MFMA_BLEND4;
   constexpr int NP=BLEND ? 4 : 2;                          // byte planes of a sample
   constexpr int PX=MODE == MFMA_PLAIN3 ? 3 : 4;            // u16 per pixel in memory
   constexpr int STAGED=32*(NC+1);                          // columns staged: 64 outputs + 32*(NC-1) of halo
   typedef unsigned __attribute__((aligned(2))) LooseDword;
+  typedef typename std::conditional<kFloat,uint4,uint2>::type Raw;      // one pixel as loaded
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Q *src=static_cast<const Q *>(args.src);
+  Q *dst=static_cast<Q *>(args.dst);
   const int CH=args.plane;
   unsigned char *stage=smem_raw;                           // [NP][4][R][128]
   unsigned char *taps_lds=stage+NP*4*CH;                   // [kh+1][kw+17][16], the last row zero
@@ -171,13 +182,14 @@ void conv2d_exact_kernel(Conv2DXArgs args)
   const int xin0=x0-args.shiftx;
   const int R=args.stage_rows,NEEDED=args.window_rows;
   const int windows=args.kw+17;
+  const int flag_at=(args.kh+1)*windows*16;       // one word behind the cell table
 
   for (int idx=tid; idx < (args.kh+1)*windows; idx+=512)
     reinterpret_cast<uint4 *>(taps_lds)[idx]=reinterpret_cast<const uint4 *>(args.taps)[idx];
   // ---- source rows, edge-clamped (cache.c:2663-2679), as quads of four pixels: item idx = (row,
   // quad) of a block of rows that starts at image row `first`
   constexpr int QUADS=STAGED/4;
-  auto load_quad=[&](int first,int idx,uint2 (&raw)[4])
+  auto load_quad=[&](int first,int idx,Raw (&raw)[4])
   {
     const int row=idx/QUADS,quad=idx-row*QUADS;
     int y=first+row;
@@ -187,8 +199,15 @@ void conv2d_exact_kernel(Conv2DXArgs args)
       {
         int x=xin0+4*quad+i;
         x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
-        const uint16_t *at=args.src+pixel_index(y,W,x)*PX;
-        if constexpr (MODE == MFMA_PLAIN3)
+        const Q *at=src+pixel_index(y,W,x)*PX;
+        if constexpr (kFloat)
+          {
+            if constexpr (MODE == MFMA_PLAIN3)
+              raw[i]=make_uint4(__float_as_uint(at[0]),__float_as_uint(at[1]),__float_as_uint(at[2]),0u);
+            else
+              raw[i]=*reinterpret_cast<const uint4 *>(at);
+          }
+        else if constexpr (MODE == MFMA_PLAIN3)
           raw[i]=make_uint2(*reinterpret_cast<const LooseDword *>(at),(unsigned) at[2]);
         else
           raw[i]=*reinterpret_cast<const uint2 *>(at);
@@ -197,16 +216,31 @@ void conv2d_exact_kernel(Conv2DXArgs args)
   // ... as byte planes of alpha*p (alpha itself for the alpha channel) or p, each byte b stored as
   // b-128, written to ring row (ring_first + row) mod R; the 16-byte block of a column is XORed
   // with bit 1 of the ring row
-  auto store_quad=[&](int ring_first,int idx,const uint2 (&raw)[4])
+  auto store_quad=[&](int ring_first,int idx,const Raw (&raw)[4])
   {
     const int row=idx/QUADS,quad=idx-row*QUADS;
     int ring_row=ring_first+row;
     ring_row=ring_row >= R ? ring_row-R : ring_row;
     unsigned sample[4][4];                                  // [channel][pixel]
+    bool integral=true;
 #pragma unroll
     for (int i=0; i < 4; i++)
       {
-        const unsigned c0=raw[i].x & 0xffffu,c1=raw[i].x >> 16,c2=raw[i].y & 0xffffu,c3=raw[i].y >> 16;
+        unsigned c0,c1,c2,c3;
+        if constexpr (kFloat)
+          {
+            // (v_cvt_u32_f32 truncates and saturates; NaN -> 0; -0.0 passes as 0, which it is
+            // to every sum)
+            const float f0=__uint_as_float(raw[i].x),f1=__uint_as_float(raw[i].y);
+            const float f2=__uint_as_float(raw[i].z),f3=__uint_as_float(raw[i].w);
+            c0=(unsigned) f0; c1=(unsigned) f1; c2=(unsigned) f2; c3=(unsigned) f3;
+            integral=integral && ((float) c0 == f0) && ((float) c1 == f1) && ((float) c2 == f2) && ((float) c3 == f3) &&
+              ((c0 | c1 | c2 | c3) <= 0xffffu);
+          }
+        else
+          {
+            c0=raw[i].x & 0xffffu; c1=raw[i].x >> 16; c2=raw[i].y & 0xffffu; c3=raw[i].y >> 16;
+          }
         sample[0][i]=BLEND ? __umul24(c0,c3) : c0;
         sample[1][i]=BLEND ? __umul24(c1,c3) : c1;
         sample[2][i]=BLEND ? __umul24(c2,c3) : c2;
@@ -222,6 +256,9 @@ void conv2d_exact_kernel(Conv2DXArgs args)
         for (int b=0; b < NP; b++)
           *reinterpret_cast<unsigned *>(stage+(b*4+c)*CH+at)=p[b] ^ 0x80808080u;
       }
+    if constexpr (kFloat)
+      if (!integral)
+        *args.not_integral=1u;
   };
   // the whole window of the first step: every load of a thread's batch is in flight before the
   // first conversion
@@ -231,7 +268,7 @@ void conv2d_exact_kernel(Conv2DXArgs args)
     const int first=kCXRows*step_begin-args.shifty;
     for (int i0=tid; i0 < total; i0+=512*ITEMS)
       {
-        uint2 raw[ITEMS][4];
+        Raw raw[ITEMS][4];
 #pragma unroll
         for (int k=0; k < ITEMS; k++)
           {
@@ -270,7 +307,7 @@ void conv2d_exact_kernel(Conv2DXArgs args)
   for (int step=step_begin; step < step_end; step++)
     {
       const int y0=kCXRows*step;
-      uint2 ahead[NEW_ITEMS][4];
+      Raw ahead[NEW_ITEMS][4];
       if (step+1 < step_end)
         {
 #pragma unroll
@@ -418,20 +455,46 @@ void conv2d_exact_kernel(Conv2DXArgs args)
                   M[c]=__builtin_fma((double) high,65536.0,M[c]);
                 }
             }
-          uint16_t out[PX];
+          Q out[PX];
 #if defined(MH_CX_KNOCK) && (MH_CX_KNOCK & 2)
           uint32_t undecided=0;
 #pragma unroll
           for (int c=0; c < PX; c++)
-            out[c]=(uint16_t) (acc[0][4*q+c]+acc[NP-1][4*q+c]);
+            out[c]=(Q) (acc[0][4*q+c]+acc[NP-1][4*q+c]);
 #else
-          const uint32_t undecided=integer_sums_to_levels<PX,BLEND>(M,args,out);
+          uint32_t undecided;
+          if constexpr (kFloat)
+            {
+              // the float nearest to unit*M or M_c/M_alpha, unless that lies within the reference's
+              // rounding error of the midpoint of two floats (settle_sums, tie_check.hpp)
+              double sums[4],error[4];
+#pragma unroll
+              for (int c=0; c < 4; c++)
+                {
+                  sums[c]=args.unit*M[c];
+                  error[c]=args.relative > 0.0 ? args.relative*__builtin_fabs(sums[c]) : args.error[c];
+                }
+              undecided=settle_sums<float,PX,BLEND>(sums,error,0,out);
+            }
+          else
+            undecided=integer_sums_to_levels<PX,BLEND>(M,args,out);
 #endif
           if ((y < H) && (x < W))
             {
               doubtful|=undecided << (4*q);
-              uint16_t *at=args.dst+pixel_index(y,W,x)*PX;
-              if constexpr (MODE == MFMA_PLAIN3)
+              Q *at=dst+pixel_index(y,W,x)*PX;
+              if constexpr (kFloat)
+                {
+                  if constexpr (MODE == MFMA_PLAIN3)
+                    {
+                      at[0]=out[0];
+                      at[1]=out[1];
+                      at[2]=out[2];
+                    }
+                  else
+                    *reinterpret_cast<float4 *>(at)=make_float4(out[0],out[1],out[2],out[3]);
+                }
+              else if constexpr (MODE == MFMA_PLAIN3)
                 {
                   *reinterpret_cast<LooseDword *>(at)=(unsigned) out[0] | ((unsigned) out[1] << 16);
                   at[2]=out[2];
@@ -455,18 +518,25 @@ void conv2d_exact_kernel(Conv2DXArgs args)
               const int bit=__builtin_ctz(which);
               which&=which-1u;
               const int yy=y0+8*rg+2*(bit >> 2)+(who >> 5),c=bit & 3;
-              const uint16_t settled=conv2d_reference_sample<uint16_t,PX,BLEND>(args.src,W,H,xx,yy,c,args.values,
+              const Q settled=conv2d_reference_sample<Q,PX,BLEND>(src,W,H,xx,yy,c,args.values,
                 args.kw,args.kh,args.shiftx,args.shifty,lane);
               if (lane == who)
                 {
-                  args.dst[pixel_index(yy,W,xx)*PX+c]=settled;
+                  dst[pixel_index(yy,W,xx)*PX+c]=settled;
                   recomputed++;
                 }
             }
         }
       if (step+1 < step_end)
         {
+          if constexpr (kFloat)
+            if (tid == 0)
+              *reinterpret_cast<volatile unsigned *>(taps_lds+flag_at)=
+                __hip_atomic_load(args.not_integral,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
           __syncthreads();                           // every read of the 32 oldest rows is done
+          if constexpr (kFloat)
+            if (*reinterpret_cast<volatile unsigned *>(taps_lds+flag_at) != 0u)
+              break;                                 // (the same word for every thread: all leave)
           // the new rows follow the window: ring rows origin+NEEDED .. +31 (mod R) — the slack of
           // the rounded-up ring and the oldest rows
           int first=origin+NEEDED;
@@ -494,13 +564,13 @@ void conv2d_exact_kernel(Conv2DXArgs args)
 static unsigned long long *g_conv2d_recomputed[64]={};
 static bool g_conv2d_count=false;
 
-template<int MODE,int NC>
+template<typename Q,int MODE,int NC>
 static MhStatus launch_conv2d_exact_typed(const View &src,Conv2DXArgs &args,size_t lds)
 {
-  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2d_exact_kernel<MODE,NC>),
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2d_exact_kernel<Q,MODE,NC>),
     hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
   ProfileScope prof("conv2d_exact",src.stream);
-  hipLaunchKernelGGL((conv2d_exact_kernel<MODE,NC>),dim3((unsigned) (8*args.items_per_xcd)),dim3(512),lds,
+  hipLaunchKernelGGL((conv2d_exact_kernel<Q,MODE,NC>),dim3((unsigned) (8*args.items_per_xcd)),dim3(512),lds,
     src.stream,args);
   MH_HIP(hipGetLastError());
   return MH_OK;
@@ -549,14 +619,17 @@ static bool integer_cells(const MhKernelInfo *kernel,std::vector<int> &m,double 
   return false;
 }
 
-// w x h Convolve of an RGBA (alpha-weighted colour, alpha last), four-plain-channel or RGB Q16 frame
+// w x h Convolve of an RGBA (alpha-weighted colour, alpha last), four-plain-channel or RGB frame
 // with integer-multiple cells.  *handled stays false (nothing launched) when the kernel or the
-// frame does not qualify.
+// frame does not qualify.  Float Quantum: `flag` receives a device word that the kernel raises
+// when the frame is not made of integers of 0..65535 — the caller then has to run the generic
+// kernel behind this one, conditional on that word (Morph2DParams::only_if).
 MhStatus launch_conv2d_exact(const View &src,const View &dst,const MhKernelInfo *kernel,bool blend,
-  bool *handled)
+  bool *handled,Temp *flag)
 {
   *handled=false;
-  if ((src.quantum != MH_QUANTUM_U16) || (dst.quantum != MH_QUANTUM_U16) ||
+  const bool is_float=src.quantum != MH_QUANTUM_U16;
+  if ((src.quantum != dst.quantum) || (is_float && ((src.quantum != MH_QUANTUM_F32) || (flag == nullptr))) ||
       ((src.channels != 4) && ((src.channels != 3) || blend)) ||
       (dst.channels != src.channels) || (src.columns != dst.columns) || (src.rows != dst.rows) ||
       (src.pixels == dst.pixels))
@@ -616,7 +689,7 @@ MhStatus launch_conv2d_exact(const View &src,const View &dst,const MhKernelInfo 
   // channel stride = 32 mod 256, a multiple of four rows: conv2d_exact_kernel's operand reads
   const int plane_bytes=ring_rows*kCXStride+32;
   const int windows=kw+17;
-  const size_t lds=(size_t) planes*4*plane_bytes+(size_t) (kh+1)*windows*16;
+  const size_t lds=(size_t) planes*4*plane_bytes+(size_t) (kh+1)*windows*16+16;
   if ((nc < 2) || (nc > 3) || (lds > 160u*1024u))
     return MH_OK;
   // the reflected walk of morphology.c:2925: cell (v,u) of the window carries values[(kh-1-v)*kw+
@@ -636,8 +709,15 @@ MhStatus launch_conv2d_exact(const View &src,const View &dst,const MhKernelInfo 
   const size_t t_values=tables.add(kernel->values,(size_t) kw*kh*sizeof(double));
   MH_TRY(tables.upload(src.device,src.stream));
   Conv2DXArgs args;
-  args.src=static_cast<const uint16_t *>(src.pixels);
-  args.dst=static_cast<uint16_t *>(dst.pixels);
+  args.src=src.pixels;
+  args.dst=dst.pixels;
+  args.not_integral=nullptr;
+  if (is_float)
+    {
+      MH_TRY(flag->alloc(src.device,sizeof(unsigned),src.stream));
+      MH_HIP(hipMemsetAsync(flag->ptr,0,sizeof(unsigned),src.stream));
+      args.not_integral=flag->as<unsigned>();
+    }
   args.columns=(int) src.columns;
   args.rows=(int) src.rows;
   args.kw=kw;
@@ -693,7 +773,9 @@ MhStatus launch_conv2d_exact(const View &src,const View &dst,const MhKernelInfo 
   args.items_per_xcd=(args.strips*args.segments+7)/8;
   *handled=true;
 #define MH_LAUNCH(MODE) \
-  return nc == 2 ? launch_conv2d_exact_typed<MODE,2>(src,args,lds) : launch_conv2d_exact_typed<MODE,3>(src,args,lds)
+  return is_float ? \
+    (nc == 2 ? launch_conv2d_exact_typed<float,MODE,2>(src,args,lds) : launch_conv2d_exact_typed<float,MODE,3>(src,args,lds)) : \
+    (nc == 2 ? launch_conv2d_exact_typed<uint16_t,MODE,2>(src,args,lds) : launch_conv2d_exact_typed<uint16_t,MODE,3>(src,args,lds))
   if (src.channels == 3)
     MH_LAUNCH(MFMA_PLAIN3);
   if (blend)

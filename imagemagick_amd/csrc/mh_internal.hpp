@@ -245,7 +245,7 @@ MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const 
 // ... with cells that are integer multiples of a unit: exact sums on the i8 matrix cores,
 // bit-identical in both precision modes (convolve2d_exact.hip)
 MhStatus launch_conv2d_exact(const View &src,const View &dst,const MhKernelInfo *kernel,bool blend,
-  bool *handled);
+  bool *handled,Temp *flag=nullptr);
 MhStatus launch_conv2d_mfma(const View &src,const View &dst,const MhKernelInfo *kernel,bool blend,
   bool *handled);
 MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_device,
@@ -283,6 +283,9 @@ struct Morph2DParams
   double bias=0.0;
   MhIntensityMethod intensity=MH_INTENSITY_REC709LUMA;
   MhColorspace colorspace=MH_COLORSPACE_SRGB;
+  // device word: the generic kernel does the frame only if it is non-zero (the fallback behind an
+  // optimistic kernel that found, on the device, that the frame is not for it)
+  const unsigned *only_if=nullptr;
 };
 MhStatus launch_morph2d(const View &src,const View &dst,const Morph2DParams &params,
   const Roles &roles,unsigned long long *changed_device);

@@ -50,6 +50,7 @@ struct Morph2DArgs
   int hmt_mode;              // 0 HitAndMiss, 1 Thinning, 2 Thicken
   int linear,nonlinear,gray,intensity_method;
   unsigned long long *changed;
+  const unsigned *only_if;   // nullptr, or: leave at once when the word is zero
 };
 
 constexpr int kTW=64;
@@ -95,6 +96,8 @@ __global__ __launch_bounds__(256)
 void morph2d_kernel(Morph2DArgs args)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if ((args.only_if != nullptr) && (*args.only_if == 0u))
+    return;
   Q *tile=reinterpret_cast<Q *>(smem_raw);
   const int W=args.columns,H=args.rows;
   const Q *src=static_cast<const Q *>(args.src);
@@ -1753,6 +1756,7 @@ MhStatus launch_morph2d(const View &src,const View &dst,const Morph2DParams &par
   if ((mc == MC_CONVOLVE) && (w == 1) && (non_nan != 0))
     args.rescale=(double) h/(double) non_nan;
   args.copy_mask=roles.copy_mask;
+  args.only_if=params.only_if;
   args.hmt_mode=hmt_mode;
   args.linear=linear;
   args.nonlinear=nonlinear;

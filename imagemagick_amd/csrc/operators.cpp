@@ -327,6 +327,34 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
   // Q16, RGBA (alpha-weighted, alpha last), four plain channels or RGB, cells that are integer
   // multiples of a unit (flat shapes, integer kernels; NaN cells are fine), 5 x 5 and more: exact
   // sums on the i8 matrix cores, bit-identical in either mode (convolve2d_exact.hip)
+  // float Quantum, the same layouts and kernels: a frame whose samples are integers of 0..65535 (what
+  // an 8- or 16-bit file decodes to) has the same exact sums; the kernel finds out while it stages
+  // the frame, and the generic kernel behind it runs only if it was not
+  if ((method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
+      (src.quantum == MH_QUANTUM_F32) && ((src.channels == 4) || ((src.channels == 3) && !roles.blend)) &&
+      (roles.copy_mask == 0) && (!roles.blend || (roles.alpha == 3)) &&
+      (getenv("MAGICKHIP_NO_MFMA") == nullptr) && (getenv("MAGICKHIP_NO_MFMA_2D") == nullptr) &&
+      (getenv("MAGICKHIP_NO_EXACT_2D") == nullptr) && (getenv("MAGICKHIP_NO_EXACT_2D_FLOAT") == nullptr))
+    {
+      // (outer products — boxes — have the separable path below, which takes any float frame)
+      std::vector<double> row,column;
+      double delta=0.0;
+      bool handled=false;
+      Temp flag;
+      if (kernel_has_nan(kernel) || (!rank_one_factors(kernel,row,column) && !rank_one_plus_delta(kernel,row,column,&delta)))
+        MH_TRY(launch_conv2d_exact(src,dst,kernel,roles.blend,&handled,&flag));
+      if (handled)
+        {
+          Morph2DParams fallback;
+          fallback.method=method;
+          fallback.kernel=kernel;
+          fallback.bias=bias;
+          fallback.intensity=desc->intensity != 0 ? (MhIntensityMethod) desc->intensity : MH_INTENSITY_REC709LUMA;
+          fallback.colorspace=(MhColorspace) desc->colorspace;
+          fallback.only_if=flag.as<unsigned>();
+          return launch_morph2d(src,dst,fallback,roles,nullptr);
+        }
+    }
   const bool matrix_2d=(method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
     (src.quantum == MH_QUANTUM_U16) && ((src.channels == 4) || ((src.channels == 3) && !roles.blend)) &&
     (roles.copy_mask == 0) && (!roles.blend || (roles.alpha == 3)) &&

@@ -227,6 +227,25 @@ while time.time() - t0 < budget:
                 ",".join("nan" if np.isnan(v) else "%d" % v for v in r) for r in cells))
         layout = int(rng.integers(0, 3))               # RGBA alpha-weighted, four plain channels, RGB
         fast = rng.random() < 0.3
+        if rng.random() < 0.3:
+            # the same on a float-Quantum frame of integer samples (sometimes with one that is not:
+            # the generic kernel behind the integer one then does the frame)
+            fpx = px.astype(np.float32)
+            if rng.random() < 0.25:
+                fpx[int(rng.integers(0, rows)), int(rng.integers(0, cols)), int(rng.integers(0, 4))] = \
+                    [0.5, -1.0, 65536.0, 12345.678][int(rng.integers(0, 4))]
+            if layout == 2:
+                fpx = np.ascontiguousarray(fpx[:, :, :3])
+            if layout == 1:
+                want = np.concatenate([refmod.RefImage(fpx[:, :, c].copy()).set_artifact("convolve:scale", "!")
+                                       .morphology("Convolve", 1, kernel).numpy().reshape(rows, cols, 1) for c in range(4)], axis=2)
+            else:
+                want = refmod.RefImage(fpx).set_artifact("convolve:scale", "!").morphology("Convolve", 1, kernel).numpy()
+            got = im.morphology_image(dev_float(fpx, has_alpha=layout == 0) if layout != 2 else dev_float(fpx),
+                                      "Convolve", 1, kernel, scale=(1.0, 1)).numpy()
+            failures += check_bits("integer convolve 2-D, float frame", got, want, detail + " layout %d %s" % (layout, kernel[:60]))
+            cases += 1
+            continue
         if layout == 0:
             image, want = dev(px), ref.set_artifact("convolve:scale", "!").morphology("Convolve", 1, kernel).numpy()
         elif layout == 1:

@@ -1024,6 +1024,7 @@ def test_separable_2d_convolve_exact_on_ties(im, refmod, dtype, monkeypatch):
 
 INTEGER_KERNELS = ["Disk:15", "Disk:7.3", "Octagon:5", "Diamond:4", "Plus:3", "Ring:10,14", "Square:3",
                    "Rectangle:8x4", "Rectangle:49x5+3+1", "Rectangle:65x3+40+1",
+                   "41x5+30+1: " + " ".join(",".join(str((7 * x + 3 * y) % 5) for x in range(41)) for y in range(5)),
                    "7x5: 1,2,3,4,3,2,1 2,4,6,8,6,4,2 3,6,9,13,9,6,2 2,4,6,8,6,4,2 1,2,3,4,3,2,1",
                    "6x6+1+4: 1,0,2,nan,1,3 0,1,1,2,nan,1 2,2,0,1,1,1 nan,1,3,1,0,2 1,1,1,1,2,0 3,0,1,2,1,1",
                    # cells 2s and 3s (the unit is half the smallest cell), 0.25 steps, and both signs
@@ -1074,7 +1075,7 @@ def test_convolve_2d_integer_cells_on_matrix_cores(im, refmod, kernel, layout, m
     finally:
         im.set_precision(im.PRECISION_EXACT)
     outer_product = zero_sum or kernel.startswith(("Square", "Rectangle"))
-    wide = kernel in ("Disk:15", "Ring:10,14")
+    wide = kernel in ("Disk:15", "Ring:10,14") or kernel.startswith("41x5")        # more than 17 columns
     if not (signed and alpha) and (mode == "exact" or wide):
         # (alpha-weighted sums of signed cells keep the fp64 kernels; FAST separates an outer product
         # first and gives kernels of up to 17 columns to the f16 kernel, whose band is one chunk)
@@ -1116,6 +1117,70 @@ def test_convolve_2d_integer_cells_on_ties(im, refmod, layout):
     recomputed = lib.MhConvolve2DRecomputed(0)
     assert recomputed == 0, recomputed
     assert np.array_equal(got, reference("Disk:4.3"))
+
+
+# 41 x 5 integer cells that are no outer product: three 32-slot chunks per band
+WIDE_INTEGER_KERNEL = "41x5+30+1: " + " ".join(",".join(str((7 * x + 3 * y) % 5) for x in range(41)) for y in range(5))
+
+
+@pytest.mark.parametrize("layout", ["rgba", "plain4", "rgb"])
+@pytest.mark.parametrize("kernel", ["Disk:15", "Octagon:5", "Ring:10,14", WIDE_INTEGER_KERNEL,
+                                    "6x6+1+4: 1,0,2,nan,1,3 0,1,1,2,nan,1 2,2,0,1,1,1 nan,1,3,1,0,2 1,1,1,1,2,0 3,0,1,2,1,1",
+                                    "5x5: -1,-2,0,2,1 -4,-8,0,8,4 -6,-12,0,12,7 -4,-8,0,8,4 -1,-2,0,2,1"])
+def test_convolve_2d_integer_cells_float_quantum(im, refmod, kernel, layout, monkeypatch):
+    """A float-Quantum frame whose samples are integers of 0..65535 (what an 8- or 16-bit file
+    decodes to in the reference's default HDRI build) under a kernel with integer-multiple cells:
+    the same exact integer sums on the i8 matrix cores, the results rounded to float with the tie
+    check at float-rounding midpoints — bit-identical to the reference's w x h walk; the generic
+    kernel is launched behind it and leaves at once."""
+    import bench
+    monkeypatch.setenv("MAGICKHIP_CONV2D_CUTS", "1")
+    channels = 3 if layout == "rgb" else 4
+    alpha = layout == "rgba"
+    rows, cols = 107, 150
+    q = make_pixels(rows, cols, channels, Q16, seed=len(kernel) + channels)
+    if alpha:
+        q[10:30, 20:60, 3] = np.random.default_rng(3).integers(0, 4, (20, 40))
+        q[40:50, 100:140, 3] = 0
+        q[60:100, 5:50, 3] = 65535
+    px = q.astype(np.float32)
+    signed = "-1" in kernel
+    scale = None if signed else (1.0, 1)
+    dev = im.Image(to_device(px), has_alpha=alpha)
+
+    def reference(pixels):
+        r = refmod.RefImage(pixels)
+        if not signed:
+            r = r.set_artifact("convolve:scale", "!")
+        return r.morphology("Convolve", 1, kernel).numpy()
+    if alpha or channels == 3:
+        want = reference(px)
+    else:
+        want = np.concatenate([reference(px[:, :, c].copy()).reshape(rows, cols, 1) for c in range(4)], axis=2)
+    holder = {}
+    launched = bench.kernel_profile(
+        im, lambda: holder.update(out=im.morphology_image(dev, "Convolve", 1, kernel, scale=scale)), 1)
+    if not (signed and alpha):
+        assert set(launched) == {"conv2d_exact", "morph2d"}, launched
+        assert launched["morph2d"]["avg_ms"] < 0.05, launched
+    got = holder["out"].numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "%d float samples differ" % int(
+        (got.view(np.uint32) != want.view(np.uint32)).sum())
+
+
+@pytest.mark.parametrize("spoiler", [1000.25, -3.0, 65536.0, 1.0e9, float("nan"), float("inf")])
+def test_convolve_2d_integer_cells_float_quantum_falls_back(im, refmod, spoiler):
+    """One sample that is not an integer of 0..65535 anywhere in the frame — a fraction, a negative
+    value, one beyond the range, NaN, inf — and the generic kernel behind the integer one does the
+    whole frame: bit-identical (NaN where the reference has NaN)."""
+    rows, cols = 150, 131
+    px = make_pixels(rows, cols, 4, Q16, seed=77).astype(np.float32)
+    px[140, 120, 1] = spoiler
+    dev, ref = run_pair(im, refmod, px)
+    got = im.morphology_image(dev, "Convolve", 1, "Disk:6.3", scale=(1.0, 1)).numpy()
+    want = ref.set_artifact("convolve:scale", "!").morphology("Convolve", 1, "Disk:6.3").numpy()
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), int((~same).sum())
 
 
 def test_c5_convolve_disk15_exact_full_rows(im, refmod):
