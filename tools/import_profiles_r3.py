@@ -17,6 +17,7 @@ base.LABELS = [
     (r"blur_fused_exact_kernel<\d+, \d+, false, true>", "blur_fused_exact"),
     (r"blur_fused_exact_kernel<\d+, \d+, true, false>", "unsharp_fused_exact_row"),
     (r"blur_fused_exact_kernel<\d+, \d+, false, false>", "blur_fused_exact_row"),
+    (r"conv2d_exact_kernel", "conv2d_exact"),
     (r"stretch_apply", "apply_lut"), (r"stretch_", "build_lut"), (r"morph_strips", "morph_rects"),
 ] + base.LABELS
 base.PREFIX = {"fast": "", "exact": "", "legacy": "", "hdri": "hdri:", "resize": "", "c4": "c4:", "c5": "c5:"}
