@@ -79,7 +79,6 @@ struct Conv2DXArgs
   unsigned *not_integral;     // float Quantum: set by whoever meets a sample that is not an integer of 0..65535
 };
 
-constexpr int kCXRows=32;     // output rows per step
 constexpr int kCXCols=64;     // output columns per strip
 constexpr int kCXStride=128;  // bytes per ring row of a plane
 
@@ -145,10 +144,20 @@ static __device__ __forceinline__ uint32_t integer_sums_to_levels(const double (
   return doubtful;
 }
 
-template<typename Q,int MODE,int NC>
+template<typename Q,int MODE,int NC,int ROWS>
 __global__ __launch_bounds__(512)
 void conv2d_exact_kernel(Conv2DXArgs args)
 {
+  // ROWS output rows per step, eight waves: 32 = four row groups x two column tiles, a wave does
+  // 8 rows x 32 columns; 64 (plain layouts, when the taller ring fits) = eight row groups, a wave
+  // does 8 rows x both tiles — the middle 32-column block of a row serves both tiles and the cells
+  // are read once for both: 8 LDS reads per 8 products where the 32-row form of a plain layout
+  // needs 12 (its two byte planes give the cell reads half the products to spread over), which
+  // kept its LDS 75 % busy: 3.5 ms of products against 2.0 of instructions.  (Also measured:
+  // 16-row steps with two workgroups per CU out of step with each other — the same time.)
+  constexpr int NT=512;                                    // threads
+  constexpr int TILES=ROWS == 64 ? 2 : 1;                  // column tiles per wave
+  constexpr int BLOCKS=NC+TILES-1;                         // 32-column data blocks per plane and row
   // Q = float: a float-Quantum frame whose samples are all integers of 0..65535 (what an 8- or 16-bit
   // file decodes to) has the same exact integer sums; the results are floats, the boundaries those
   // of the float rounding (tie_check.hpp).  The staging checks every sample; the first one that is
@@ -184,7 +193,7 @@ void conv2d_exact_kernel(Conv2DXArgs args)
   const int windows=args.kw+17;
   const int flag_at=(args.kh+1)*windows*16;       // one word behind the cell table
 
-  for (int idx=tid; idx < (args.kh+1)*windows; idx+=512)
+  for (int idx=tid; idx < (args.kh+1)*windows; idx+=NT)
     reinterpret_cast<uint4 *>(taps_lds)[idx]=reinterpret_cast<const uint4 *>(args.taps)[idx];
   // ---- source rows, edge-clamped (cache.c:2663-2679), as quads of four pixels: item idx = (row,
   // quad) of a block of rows that starts at image row `first`
@@ -265,20 +274,20 @@ void conv2d_exact_kernel(Conv2DXArgs args)
   {
     constexpr int ITEMS=4;
     const int total=NEEDED*QUADS;
-    const int first=kCXRows*step_begin-args.shifty;
-    for (int i0=tid; i0 < total; i0+=512*ITEMS)
+    const int first=ROWS*step_begin-args.shifty;
+    for (int i0=tid; i0 < total; i0+=NT*ITEMS)
       {
         Raw raw[ITEMS][4];
 #pragma unroll
         for (int k=0; k < ITEMS; k++)
           {
-            const int idx=i0+512*k;
+            const int idx=i0+NT*k;
             load_quad(first,idx < total ? idx : total-1,raw[k]);
           }
 #pragma unroll
         for (int k=0; k < ITEMS; k++)
-          if (i0+512*k < total)
-            store_quad(0,i0+512*k,raw[k]);
+          if (i0+NT*k < total)
+            store_quad(0,i0+NT*k,raw[k]);
       }
   }
   __syncthreads();
@@ -286,7 +295,7 @@ void conv2d_exact_kernel(Conv2DXArgs args)
   // ---- wave = row group rg (8 rows), column tile T (32 columns); lane (e, h): entry e = 4*row +
   // channel of the data operand / output column n = e of the cell operand, slot block h
   const int e=lane & 31,h=lane >> 5;
-  const int rg=wave & 3,T=wave >> 2;
+  const int rg=wave % (ROWS/8),T=TILES*(wave/(ROWS/8));   // row group, first column tile
   const int a_row=8*rg+(e >> 2);                 // window row of kernel row 0
   const unsigned a_column=lds_base+(unsigned) ((e & 3)*CH);
   const int a_block=2*T+h;                       // 16-byte block of chunk 0 (chunk c: + 2c)
@@ -300,29 +309,31 @@ void conv2d_exact_kernel(Conv2DXArgs args)
       cell_at[c]=lds_base+(unsigned) (NP*4*CH+(o+16)*16);
     }
   const int cell_row=windows*16;
-  constexpr int NEW_ITEMS=(kCXRows*QUADS+511)/512;
-  static_assert(NEW_ITEMS <= 2,"two pixel quads per thread");
+  constexpr int NEW_ITEMS=(ROWS*QUADS+NT-1)/NT;
+  static_assert(NEW_ITEMS <= 4,"four pixel quads per thread");
   unsigned recomputed=0;
   int origin=0;                                  // ring row of the window's first row
   for (int step=step_begin; step < step_end; step++)
     {
-      const int y0=kCXRows*step;
+      const int y0=ROWS*step;
       Raw ahead[NEW_ITEMS][4];
       if (step+1 < step_end)
         {
 #pragma unroll
           for (int k=0; k < NEW_ITEMS; k++)
             {
-              const int idx=tid+512*k;
-              load_quad(y0-args.shifty+NEEDED,idx < kCXRows*QUADS ? idx : kCXRows*QUADS-1,ahead[k]);
+              const int idx=tid+NT*k;
+              load_quad(y0-args.shifty+NEEDED,idx < ROWS*QUADS ? idx : ROWS*QUADS-1,ahead[k]);
             }
         }
-      intx16 acc[NP];
+      intx16 acc[NP][TILES];
 #pragma unroll
       for (int b=0; b < NP; b++)
 #pragma unroll
-        for (int i=0; i < 16; i++)
-          acc[b][i]=0;
+        for (int t=0; t < TILES; t++)
+#pragma unroll
+          for (int i=0; i < 16; i++)
+            acc[b][t][i]=0;
       // ---- the products.  A pass is four groups of NC products (one byte plane of one kernel row);
       // alpha-weighted: the four planes of one kernel row, plain: the two planes of two kernel
       // rows.  The operands of group g of the NEXT pass are read into the registers group g has just
@@ -335,7 +346,7 @@ void conv2d_exact_kernel(Conv2DXArgs args)
       // ISA after changing it: make asm FILE=convolve2d_exact.)
       constexpr int ROWS_PER_PASS=BLEND ? 1 : 2;
       constexpr int CELL_READS=NC*ROWS_PER_PASS;
-      intx4 data[4][NC];
+      intx4 data[4][BLOCKS];
       auto row_address=[&](int v) -> unsigned
       {
         int ring_row=origin+a_row+v;               // < 2R
@@ -355,15 +366,20 @@ void conv2d_exact_kernel(Conv2DXArgs args)
         const unsigned at=BLEND ? row_at[0]+(unsigned) (g*4*CH) : row_at[g >> 1]+(unsigned) ((g & 1)*4*CH);
         lds_read128<0>(data[g][0],at);
         lds_read128<32>(data[g][1],at);
-        if constexpr (NC == 3)
+        if constexpr (BLOCKS >= 3)
           lds_read128<64>(data[g][2],at);
+        if constexpr (BLOCKS >= 4)
+          lds_read128<96>(data[g][3],at);
       };
       auto multiply_group=[&](int g,const intx4 (&cells)[ROWS_PER_PASS][NC])
       {
+        // (tile t, chunk c: the data block t+c)
         const int b=BLEND ? g : (g & 1);
 #pragma unroll
         for (int c=0; c < NC; c++)
-          acc[b]=__builtin_amdgcn_mfma_i32_32x32x32_i8(data[g][c],cells[BLEND ? 0 : (g >> 1)][c],acc[b],0,0,0);
+#pragma unroll
+          for (int t=0; t < TILES; t++)
+            acc[b][t]=__builtin_amdgcn_mfma_i32_32x32x32_i8(data[g][t+c],cells[BLEND ? 0 : (g >> 1)][c],acc[b][t],0,0,0);
       };
       auto addresses=[&](int v,unsigned (&row_at)[ROWS_PER_PASS])
       {
@@ -394,9 +410,9 @@ void conv2d_exact_kernel(Conv2DXArgs args)
             // the cells and group g's operands are the oldest reads in flight; younger: the
             // three groups behind it and, after group 0, the next pass's cells
             if (g == 0)
-              lds_wait<3*NC>();
+              lds_wait<3*BLOCKS>();
             else
-              lds_wait<3*NC+CELL_READS>();
+              lds_wait<3*BLOCKS+CELL_READS>();
             __builtin_amdgcn_sched_barrier(0);
             multiply_group(g,cells);
             __builtin_amdgcn_sched_barrier(0);
@@ -433,13 +449,17 @@ void conv2d_exact_kernel(Conv2DXArgs args)
       // block; the loop's exit is a branch: convolve_fused_exact.hip, settle_tiles)
 #pragma unroll
       for (int b=0; b < NP; b++)
-        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[b]));
+#pragma unroll
+        for (int t=0; t < TILES; t++)
+          asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[b][t]));
       // ---- D: register 4q+c of lane (n, h) = channel c of pixel (row 8*rg+2q+h, column 32T+n)
-      const int x=x0+32*T+e;
-      uint32_t doubtful=0;                         // bit 4q+c: channel c of pixel q
+      uint32_t doubtful=0;                         // bit 16t+4q+c: channel c of pixel q of tile t
+#pragma unroll
+      for (int t=0; t < TILES; t++)
 #pragma unroll
       for (int q=0; q < 4; q++)
         {
+          const int x=x0+32*(T+t)+e;
           const int y=y0+8*rg+2*q+h;
           double M[4];
 #pragma unroll
@@ -447,11 +467,11 @@ void conv2d_exact_kernel(Conv2DXArgs args)
             {
               // |acc| <= 128*sum|m| and 257*128*sum|m| <= 2^30 (the host checks): plane + 256*plane'
               // + the signed-byte constant stays in i32
-              const int low=acc[0][4*q+c]+256*acc[1][4*q+c]+args.offset;
+              const int low=acc[0][t][4*q+c]+256*acc[1][t][4*q+c]+args.offset;
               M[c]=(double) low;
               if constexpr (BLEND)
                 {
-                  const int high=acc[2][4*q+c]+256*acc[3][4*q+c]+args.offset;
+                  const int high=acc[2][t][4*q+c]+256*acc[3][t][4*q+c]+args.offset;
                   M[c]=__builtin_fma((double) high,65536.0,M[c]);
                 }
             }
@@ -460,7 +480,7 @@ void conv2d_exact_kernel(Conv2DXArgs args)
           uint32_t undecided=0;
 #pragma unroll
           for (int c=0; c < PX; c++)
-            out[c]=(Q) (acc[0][4*q+c]+acc[NP-1][4*q+c]);
+            out[c]=(Q) (acc[0][t][4*q+c]+acc[NP-1][t][4*q+c]);
 #else
           uint32_t undecided;
           if constexpr (kFloat)
@@ -481,7 +501,7 @@ void conv2d_exact_kernel(Conv2DXArgs args)
 #endif
           if ((y < H) && (x < W))
             {
-              doubtful|=undecided << (4*q);
+              doubtful|=undecided << (16*t+4*q);
               Q *at=dst+pixel_index(y,W,x)*PX;
               if constexpr (kFloat)
                 {
@@ -512,12 +532,12 @@ void conv2d_exact_kernel(Conv2DXArgs args)
           const int who=__builtin_ctzll(pending);
           pending&=pending-1ull;
           uint32_t which=(uint32_t) __builtin_amdgcn_readlane((int) doubtful,who);
-          const int xx=x0+32*T+(who & 31);
           while (which != 0u)
             {
               const int bit=__builtin_ctz(which);
               which&=which-1u;
-              const int yy=y0+8*rg+2*(bit >> 2)+(who >> 5),c=bit & 3;
+              const int xx=x0+32*(T+(bit >> 4))+(who & 31);
+              const int yy=y0+8*rg+2*((bit >> 2) & 3)+(who >> 5),c=bit & 3;
               const Q settled=conv2d_reference_sample<Q,PX,BLEND>(src,W,H,xx,yy,c,args.values,
                 args.kw,args.kh,args.shiftx,args.shifty,lane);
               if (lane == who)
@@ -546,9 +566,9 @@ void conv2d_exact_kernel(Conv2DXArgs args)
 #endif
 #pragma unroll
           for (int k=0; k < NEW_ITEMS; k++)
-            if (tid+512*k < kCXRows*QUADS)
-              store_quad(first,tid+512*k,ahead[k]);
-          origin=origin+kCXRows >= R ? origin+kCXRows-R : origin+kCXRows;
+            if (tid+NT*k < ROWS*QUADS)
+              store_quad(first,tid+NT*k,ahead[k]);
+          origin=origin+ROWS >= R ? origin+ROWS-R : origin+ROWS;
           __syncthreads();
         }
     }
@@ -564,13 +584,13 @@ void conv2d_exact_kernel(Conv2DXArgs args)
 static unsigned long long *g_conv2d_recomputed[64]={};
 static bool g_conv2d_count=false;
 
-template<typename Q,int MODE,int NC>
+template<typename Q,int MODE,int NC,int ROWS>
 static MhStatus launch_conv2d_exact_typed(const View &src,Conv2DXArgs &args,size_t lds)
 {
-  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2d_exact_kernel<Q,MODE,NC>),
+  MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv2d_exact_kernel<Q,MODE,NC,ROWS>),
     hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
   ProfileScope prof("conv2d_exact",src.stream);
-  hipLaunchKernelGGL((conv2d_exact_kernel<Q,MODE,NC>),dim3((unsigned) (8*args.items_per_xcd)),dim3(512),lds,
+  hipLaunchKernelGGL((conv2d_exact_kernel<Q,MODE,NC,ROWS>),dim3((unsigned) (8*args.items_per_xcd)),dim3(512),lds,
     src.stream,args);
   MH_HIP(hipGetLastError());
   return MH_OK;
@@ -684,12 +704,23 @@ MhStatus launch_conv2d_exact(const View &src,const View &dst,const MhKernelInfo 
     return MH_OK;
   const int planes=blend ? 4 : 2;
   const int nc=(32+kw-1+31)/32;                  // 32 outputs + kw-1 of halo, in 32-slot chunks
-  const int window_rows=kCXRows+kh-1;
-  const int ring_rows=(window_rows+3) & ~3;
-  // channel stride = 32 mod 256, a multiple of four rows: conv2d_exact_kernel's operand reads
-  const int plane_bytes=ring_rows*kCXStride+32;
   const int windows=kw+17;
-  const size_t lds=(size_t) planes*4*plane_bytes+(size_t) (kh+1)*windows*16+16;
+  // plain layouts: 64-row steps (a wave does both column tiles) when the taller ring fits the LDS
+  // (two chunks only: with three, the operands of two tiles do not fit beside the prefetched rows)
+  int step_rows=(blend || (nc != 2) || (getenv("MAGICKHIP_CONV2D_ROWS32") != nullptr)) ? 32 : 64;
+  int window_rows=0,ring_rows=0,plane_bytes=0;
+  size_t lds=0;
+  for (;;)
+    {
+      window_rows=step_rows+kh-1;
+      ring_rows=(window_rows+3) & ~3;
+      // channel stride = 32 mod 256, a multiple of four rows: conv2d_exact_kernel's operand reads
+      plane_bytes=ring_rows*kCXStride+32;
+      lds=(size_t) planes*4*plane_bytes+(size_t) (kh+1)*windows*16+16;
+      if ((step_rows == 32) || (lds <= 160u*1024u))
+        break;
+      step_rows=32;
+    }
   if ((nc < 2) || (nc > 3) || (lds > 160u*1024u))
     return MH_OK;
   // the reflected walk of morphology.c:2925: cell (v,u) of the window carries values[(kh-1-v)*kw+
@@ -747,7 +778,7 @@ MhStatus launch_conv2d_exact(const View &src,const View &dst,const MhKernelInfo 
       args.recomputed=g_conv2d_recomputed[src.device];
     }
   args.strips=(args.columns+kCXCols-1)/kCXCols;
-  args.groups=(args.rows+kCXRows-1)/kCXRows;
+  args.groups=(args.rows+step_rows-1)/step_rows;
   {
     // cuts of a strip: the schedule (one workgroup per CU) that finishes first; a cut costs the
     // staging of its first window, about a step's worth
@@ -772,15 +803,23 @@ MhStatus launch_conv2d_exact(const View &src,const View &dst,const MhKernelInfo 
   }
   args.items_per_xcd=(args.strips*args.segments+7)/8;
   *handled=true;
-#define MH_LAUNCH(MODE) \
+#define MH_LAUNCH_ROWS(MODE,ROWS) \
   return is_float ? \
-    (nc == 2 ? launch_conv2d_exact_typed<float,MODE,2>(src,args,lds) : launch_conv2d_exact_typed<float,MODE,3>(src,args,lds)) : \
-    (nc == 2 ? launch_conv2d_exact_typed<uint16_t,MODE,2>(src,args,lds) : launch_conv2d_exact_typed<uint16_t,MODE,3>(src,args,lds))
+    (nc == 2 ? launch_conv2d_exact_typed<float,MODE,2,ROWS>(src,args,lds) : launch_conv2d_exact_typed<float,MODE,3,ROWS>(src,args,lds)) : \
+    (nc == 2 ? launch_conv2d_exact_typed<uint16_t,MODE,2,ROWS>(src,args,lds) : launch_conv2d_exact_typed<uint16_t,MODE,3,ROWS>(src,args,lds))
+#define MH_LAUNCH(MODE) \
+  if (step_rows == 64) \
+    return is_float ? launch_conv2d_exact_typed<float,MODE,2,64>(src,args,lds) : \
+      launch_conv2d_exact_typed<uint16_t,MODE,2,64>(src,args,lds); \
+  MH_LAUNCH_ROWS(MODE,32)
   if (src.channels == 3)
-    MH_LAUNCH(MFMA_PLAIN3);
+    {
+      MH_LAUNCH(MFMA_PLAIN3);
+    }
   if (blend)
-    MH_LAUNCH(MFMA_BLEND4);
+    MH_LAUNCH_ROWS(MFMA_BLEND4,32);
   MH_LAUNCH(MFMA_PLAIN4);
+#undef MH_LAUNCH_ROWS
 #undef MH_LAUNCH
 }
 

@@ -1183,11 +1183,13 @@ def test_convolve_2d_integer_cells_float_quantum_falls_back(im, refmod, spoiler)
     assert same.all(), int((~same).sum())
 
 
-def test_c5_convolve_disk15_exact_full_rows(im, refmod):
+@pytest.mark.parametrize("channels", [4, 3])
+def test_c5_convolve_disk15_exact_full_rows(im, refmod, channels):
     """ConvolveMorphology Disk:15 (SURVEY 8d's MAC-bound variant of C5) bit-identical on a frame
     wide enough for several strips per XCD and tall enough for the ring to wrap more than once
-    (704 x 1100 RGBA, alpha random): the reference takes a few seconds."""
-    px = make_pixels(1100, 704, 4, Q16, seed=15)
+    (704 x 1100; RGBA with random alpha: 32-row steps; RGB: 64-row steps, a wave on both column
+    tiles): the reference takes a few seconds."""
+    px = make_pixels(1100, 704, channels, Q16, seed=15)
     dev, ref = run_pair(im, refmod, px)
     got = im.morphology_image(dev, "Convolve", 1, "Disk:15", scale=(1.0, 1)).numpy()
     want = ref.set_artifact("convolve:scale", "!").morphology("Convolve", 1, "Disk:15").numpy()
