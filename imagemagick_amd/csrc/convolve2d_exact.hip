@@ -452,101 +452,111 @@ void conv2d_exact_kernel(Conv2DXArgs args)
 #pragma unroll
         for (int t=0; t < TILES; t++)
           asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[b][t]));
-      // ---- D: register 4q+c of lane (n, h) = channel c of pixel (row 8*rg+2q+h, column 32T+n)
-      uint32_t doubtful=0;                         // bit 16t+4q+c: channel c of pixel q of tile t
-#pragma unroll
-      for (int t=0; t < TILES; t++)
-#pragma unroll
-      for (int q=0; q < 4; q++)
-        {
-          const int x=x0+32*(T+t)+e;
-          const int y=y0+8*rg+2*q+h;
-          double M[4];
-#pragma unroll
-          for (int c=0; c < 4; c++)
-            {
-              // |acc| <= 128*sum|m| and 257*128*sum|m| <= 2^30 (the host checks): plane + 256*plane'
-              // + the signed-byte constant stays in i32
-              const int low=acc[0][t][4*q+c]+256*acc[1][t][4*q+c]+args.offset;
-              M[c]=(double) low;
-              if constexpr (BLEND)
-                {
-                  const int high=acc[2][t][4*q+c]+256*acc[3][t][4*q+c]+args.offset;
-                  M[c]=__builtin_fma((double) high,65536.0,M[c]);
-                }
-            }
-          Q out[PX];
-#if defined(MH_CX_KNOCK) && (MH_CX_KNOCK & 2)
-          uint32_t undecided=0;
-#pragma unroll
-          for (int c=0; c < PX; c++)
-            out[c]=(Q) (acc[0][t][4*q+c]+acc[NP-1][t][4*q+c]);
-#else
-          uint32_t undecided;
-          if constexpr (kFloat)
-            {
-              // the float nearest to unit*M or M_c/M_alpha, unless that lies within the reference's
-              // rounding error of the midpoint of two floats (settle_sums, tie_check.hpp)
-              double sums[4],error[4];
-#pragma unroll
-              for (int c=0; c < 4; c++)
-                {
-                  sums[c]=args.unit*M[c];
-                  error[c]=args.relative > 0.0 ? args.relative*__builtin_fabs(sums[c]) : args.error[c];
-                }
-              undecided=settle_sums<float,PX,BLEND>(sums,error,0,out);
-            }
-          else
-            undecided=integer_sums_to_levels<PX,BLEND>(M,args,out);
-#endif
-          if ((y < H) && (x < W))
-            {
-              doubtful|=undecided << (16*t+4*q);
-              Q *at=dst+pixel_index(y,W,x)*PX;
-              if constexpr (kFloat)
-                {
-                  if constexpr (MODE == MFMA_PLAIN3)
-                    {
-                      at[0]=out[0];
-                      at[1]=out[1];
-                      at[2]=out[2];
-                    }
-                  else
-                    *reinterpret_cast<float4 *>(at)=make_float4(out[0],out[1],out[2],out[3]);
-                }
-              else if constexpr (MODE == MFMA_PLAIN3)
-                {
-                  *reinterpret_cast<LooseDword *>(at)=(unsigned) out[0] | ((unsigned) out[1] << 16);
-                  at[2]=out[2];
-                }
-              else
-                *reinterpret_cast<uint2 *>(at)=make_uint2((unsigned) out[0] | ((unsigned) out[1] << 16),
-                  (unsigned) out[2] | ((unsigned) out[3] << 16));
-            }
-        }
-      // ---- the samples the bound could not decide: the whole wave walks the reference's loop for
-      // each and the lane that owns it overwrites what it stored above
-      unsigned long long pending=__ballot(doubtful != 0u);
-      while (pending != 0ull)
-        {
-          const int who=__builtin_ctzll(pending);
-          pending&=pending-1ull;
-          uint32_t which=(uint32_t) __builtin_amdgcn_readlane((int) doubtful,who);
-          while (which != 0u)
-            {
-              const int bit=__builtin_ctz(which);
-              which&=which-1u;
-              const int xx=x0+32*(T+(bit >> 4))+(who & 31);
-              const int yy=y0+8*rg+2*((bit >> 2) & 3)+(who >> 5),c=bit & 3;
-              const Q settled=conv2d_reference_sample<Q,PX,BLEND>(src,W,H,xx,yy,c,args.values,
-                args.kw,args.kh,args.shiftx,args.shifty,lane);
-              if (lane == who)
-                {
-                  dst[pixel_index(yy,W,xx)*PX+c]=settled;
-                  recomputed++;
-                }
-            }
-        }
+      // The two waves of a SIMD (w and w+4) do their epilogues at different points of the step: w
+      // before the step's barriers, w+4 behind them — the vector work of one then runs beside the
+      // products of the other instead of both idling the matrix pipe at the same time (the tiles
+      // of w+4 stay in their registers across the staging, which needs none of the operands').
+      const bool deferred=wave >= 4;
+      auto epilogue=[&]()
+      {
+        // ---- D: register 4q+c of lane (n, h) = channel c of pixel (row 8*rg+2q+h, column 32T+n)
+        uint32_t doubtful=0;                         // bit 16t+4q+c: channel c of pixel q of tile t
+  #pragma unroll
+        for (int t=0; t < TILES; t++)
+  #pragma unroll
+        for (int q=0; q < 4; q++)
+          {
+            const int x=x0+32*(T+t)+e;
+            const int y=y0+8*rg+2*q+h;
+            double M[4];
+  #pragma unroll
+            for (int c=0; c < 4; c++)
+              {
+                // |acc| <= 128*sum|m| and 257*128*sum|m| <= 2^30 (the host checks): plane + 256*plane'
+                // + the signed-byte constant stays in i32
+                const int low=acc[0][t][4*q+c]+256*acc[1][t][4*q+c]+args.offset;
+                M[c]=(double) low;
+                if constexpr (BLEND)
+                  {
+                    const int high=acc[2][t][4*q+c]+256*acc[3][t][4*q+c]+args.offset;
+                    M[c]=__builtin_fma((double) high,65536.0,M[c]);
+                  }
+              }
+            Q out[PX];
+  #if defined(MH_CX_KNOCK) && (MH_CX_KNOCK & 2)
+            uint32_t undecided=0;
+  #pragma unroll
+            for (int c=0; c < PX; c++)
+              out[c]=(Q) (acc[0][t][4*q+c]+acc[NP-1][t][4*q+c]);
+  #else
+            uint32_t undecided;
+            if constexpr (kFloat)
+              {
+                // the float nearest to unit*M or M_c/M_alpha, unless that lies within the reference's
+                // rounding error of the midpoint of two floats (settle_sums, tie_check.hpp)
+                double sums[4],error[4];
+  #pragma unroll
+                for (int c=0; c < 4; c++)
+                  {
+                    sums[c]=args.unit*M[c];
+                    error[c]=args.relative > 0.0 ? args.relative*__builtin_fabs(sums[c]) : args.error[c];
+                  }
+                undecided=settle_sums<float,PX,BLEND>(sums,error,0,out);
+              }
+            else
+              undecided=integer_sums_to_levels<PX,BLEND>(M,args,out);
+  #endif
+            if ((y < H) && (x < W))
+              {
+                doubtful|=undecided << (16*t+4*q);
+                Q *at=dst+pixel_index(y,W,x)*PX;
+                if constexpr (kFloat)
+                  {
+                    if constexpr (MODE == MFMA_PLAIN3)
+                      {
+                        at[0]=out[0];
+                        at[1]=out[1];
+                        at[2]=out[2];
+                      }
+                    else
+                      *reinterpret_cast<float4 *>(at)=make_float4(out[0],out[1],out[2],out[3]);
+                  }
+                else if constexpr (MODE == MFMA_PLAIN3)
+                  {
+                    *reinterpret_cast<LooseDword *>(at)=(unsigned) out[0] | ((unsigned) out[1] << 16);
+                    at[2]=out[2];
+                  }
+                else
+                  *reinterpret_cast<uint2 *>(at)=make_uint2((unsigned) out[0] | ((unsigned) out[1] << 16),
+                    (unsigned) out[2] | ((unsigned) out[3] << 16));
+              }
+          }
+        // ---- the samples the bound could not decide: the whole wave walks the reference's loop for
+        // each and the lane that owns it overwrites what it stored above
+        unsigned long long pending=__ballot(doubtful != 0u);
+        while (pending != 0ull)
+          {
+            const int who=__builtin_ctzll(pending);
+            pending&=pending-1ull;
+            uint32_t which=(uint32_t) __builtin_amdgcn_readlane((int) doubtful,who);
+            while (which != 0u)
+              {
+                const int bit=__builtin_ctz(which);
+                which&=which-1u;
+                const int xx=x0+32*(T+(bit >> 4))+(who & 31);
+                const int yy=y0+8*rg+2*((bit >> 2) & 3)+(who >> 5),c=bit & 3;
+                const Q settled=conv2d_reference_sample<Q,PX,BLEND>(src,W,H,xx,yy,c,args.values,
+                  args.kw,args.kh,args.shiftx,args.shifty,lane);
+                if (lane == who)
+                  {
+                    dst[pixel_index(yy,W,xx)*PX+c]=settled;
+                    recomputed++;
+                  }
+              }
+          }
+      };
+      if (!deferred || (step+1 >= step_end))
+        epilogue();
       if (step+1 < step_end)
         {
           if constexpr (kFloat)
@@ -570,6 +580,8 @@ void conv2d_exact_kernel(Conv2DXArgs args)
               store_quad(first,tid+NT*k,ahead[k]);
           origin=origin+ROWS >= R ? origin+ROWS-R : origin+ROWS;
           __syncthreads();
+          if (deferred)
+            epilogue();
         }
     }
   if (args.recomputed != nullptr)
