@@ -640,7 +640,7 @@ static bool integer_cells(const MhKernelInfo *kernel,std::vector<int> &m,double 
             }
           const double q=cell/u,nearest=std::nearbyint(q);
           fits=(std::fabs(nearest) <= 127.0) && (std::fabs(q-nearest) <= 1.0e-9);
-          m[i]=(int) nearest;
+          m[i]=fits ? (int) nearest : 0;
         }
       if (fits)
         {
@@ -844,6 +844,8 @@ using namespace mh;
 extern "C" MH_API unsigned long long MhConvolve2DRecomputed(int enable)
 {
   unsigned long long total=0;
+  int current=-1;
+  (void) hipGetDevice(&current);
   for (int d=0; d < 64; d++)
     if (g_conv2d_recomputed[d] != nullptr)
       {
@@ -856,6 +858,8 @@ extern "C" MH_API unsigned long long MhConvolve2DRecomputed(int enable)
           }
         total+=value;
       }
+  if (current >= 0)
+    (void) hipSetDevice(current);
   g_conv2d_count=enable != 0;
   return total;
 }

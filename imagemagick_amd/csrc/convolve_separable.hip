@@ -334,6 +334,8 @@ using namespace mh;
 extern "C" MH_API unsigned long long MhSeparableRecomputed(int enable)
 {
   unsigned long long total=0;
+  int current=-1;
+  (void) hipGetDevice(&current);
   for (int d=0; d < 64; d++)
     if (g_separable_recomputed[d] != nullptr)
       {
@@ -346,6 +348,8 @@ extern "C" MH_API unsigned long long MhSeparableRecomputed(int enable)
           }
         total+=value;
       }
+  if (current >= 0)
+    (void) hipSetDevice(current);
   g_separable_count=enable != 0;
   return total;
 }
