@@ -193,6 +193,26 @@ def kernel_outer_product_plus_delta(kernel_string):
         lib.MhDestroyKernelInfo(ptr)
 
 
+def kernel_integer_cells(kernel_string, scale=None):
+    """(cells, unit) with kernel = cells * unit (integers of at most seven bits; NaN cells as 0) — the
+    form the exact-integer 2-D convolve takes — or None.  scale: (factor, normalize flags) applied
+    first, as `-define convolve:scale` does."""
+    lib = _lib.load()
+    ptr = lib.MhAcquireKernelInfo(kernel_string.encode())
+    if not ptr:
+        raise MagickHipError(3, lib.MhGetLastError().decode())
+    try:
+        if scale is not None:
+            lib.MhScaleKernelInfo(ptr, float(scale[0]), int(scale[1]))
+        k = ptr.contents
+        cells = np.empty((k.height, k.width), dtype=np.int32)
+        unit = ctypes.c_double(0.0)
+        ok = lib.MhKernelIntegerCells(ptr, cells.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(unit))
+        return (cells, unit.value) if ok else None
+    finally:
+        lib.MhDestroyKernelInfo(ptr)
+
+
 def kernel_to_numpy(kernel_string, index=0):
     """Build a kernel list with the product's host builder and return kernel
     `index` as (values[h,w], x, y, count)."""

@@ -53,6 +53,7 @@
 #include <vector>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace mh {
@@ -838,6 +839,24 @@ MhStatus launch_conv2d_exact(const View &src,const View &dst,const MhKernelInfo 
 } // namespace mh
 
 using namespace mh;
+
+// Host logic of the path, for tests and callers that want to know in advance: are the kernel's cells
+// integer multiples (|m| <= 127) of one unit?  cells[] (width*height ints, NaN cells as 0; may be
+// NULL) and *unit (may be NULL) receive the form; returns 1 or 0.
+extern "C" MH_API int MhKernelIntegerCells(const MhKernelInfo *kernel,int *cells,double *unit)
+{
+  if ((kernel == nullptr) || (kernel->values == nullptr) || (kernel->width == 0) || (kernel->height == 0))
+    return 0;
+  std::vector<int> m;
+  double u=0.0;
+  if (!integer_cells(kernel,m,&u))
+    return 0;
+  if (cells != nullptr)
+    std::memcpy(cells,m.data(),m.size()*sizeof(int));
+  if (unit != nullptr)
+    *unit=u;
+  return 1;
+}
 
 // Diagnostic: samples the integer 2-D convolve recomputed in the reference's order since the
 // counter was last read (enable = 1 switches the counting on and reads, 0 reads and switches off).

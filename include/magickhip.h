@@ -243,6 +243,7 @@ MH_API unsigned long long MhSeparableRecomputed(int enable);
    reference's order since the last call (enable as above). */
 MH_API unsigned long long MhConvolve2DRecomputed(int enable);
 
+
 /* ------------------------------------------------------ kernels and filters */
 
 /* KernelInfoType, MagickCore/morphology.h:30-70 (same order) */
@@ -294,6 +295,11 @@ MH_API int MhKernelOuterProductFactors(const MhKernelInfo *kernel,double *row,do
    Quantum run both forms as two fp64 passes with a tie check, bit-identical to the w x h walk. */
 MH_API int MhKernelOuterProductPlusDelta(const MhKernelInfo *kernel,double *row,double *column,
   double *delta);
+/* Host test of the exact-integer 2-D convolve (MhConvolve2DRecomputed above): are the kernel's cells integer multiples (|m| <= 127) of one unit — every
+   flat shape kernel after `convolve:scale`, binomial and hand-written integer kernels?  cells[]
+   (width*height ints in the kernel's own order, NaN cells as 0; may be NULL) and *unit (may be NULL)
+   receive the form values[i] = cells[i] * unit (to 1e-9 of a cell); returns 1 or 0. */
+MH_API int MhKernelIntegerCells(const MhKernelInfo *kernel,int *cells,double *unit);
 
 /* MorphologyMethod, MagickCore/morphology.h:72-98 (same values) */
 typedef enum

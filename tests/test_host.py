@@ -182,6 +182,32 @@ def test_outer_product_plus_origin_cell_kernels_are_recognised(im):
         assert got is None or got[0] == 1, spec
 
 
+def test_integer_multiple_kernels_are_recognised(im):
+    """Host logic of the exact-integer 2-D convolve (convolve2d_exact.hip): after `convolve:scale='!'`
+    every flat shape kernel is one unit times 0/1 cells, integer kernels are small multiples, NaN
+    cells count as no cell; Gaussians, LoG and kernels with a cell beyond 127 units are not."""
+    for spec in ("Disk:15", "Disk:7.3", "Octagon:5", "Diamond:4", "Plus:3", "Ring:10,14", "Square:3", "Rectangle:8x4",
+                 "7x5: 1,2,3,4,3,2,1 2,4,6,8,6,4,2 3,6,9,13,9,6,2 2,4,6,8,6,4,2 1,2,3,4,3,2,1",
+                 "3x3: 1,nan,2 0,3,0 2,nan,1", "3x3: 2,3,2 3,2,3 2,3,2", "3x3: -1,-1,-1 -1,24.5,-1 -1,-1,-1"):
+        values, _, _, _ = im.kernel_to_numpy(spec)
+        for scale in (None, (1.0, 1)):
+            got = im.kernel_integer_cells(spec, scale=scale)
+            assert got is not None, (spec, scale)
+            cells, unit = got
+            assert cells.shape == values.shape and unit > 0.0 and np.abs(cells).max() <= 127
+            assert (cells[np.isnan(values)] == 0).all()
+            if scale is None:
+                # cells * unit reproduces the kernel, and the unit is a cell or a simple fraction of one
+                assert np.allclose(np.where(np.isnan(values), 0.0, values), cells * unit, rtol=1e-9, atol=0.0)
+    cells, unit = im.kernel_integer_cells("Disk:15", scale=(1.0, 1))
+    assert int(cells.sum()) == 709 and set(np.unique(cells)) == {0, 1} and abs(unit * 709.0 - 1.0) < 1e-12
+    cells, unit = im.kernel_integer_cells("3x3: 2,3,2 3,2,3 2,3,2")
+    assert unit == 1.0 and cells.min() == 2                       # the unit is half the smallest cell
+    for spec in ("Gaussian:0x2", "LoG:0x2", "DoG:0,1,2", "3x3: 1,1,1 1,300,1 1,1,1", "3x3: 1,1,1 1,0.123456,1 1,1,1",
+                 "3x3: nan,0,nan 0,0,0 nan,0,nan"):
+        assert im.kernel_integer_cells(spec) is None, spec
+
+
 def test_optimal_kernel_width(im):
     from imagemagick_amd import _lib
     lib = _lib.load()
