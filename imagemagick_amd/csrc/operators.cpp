@@ -359,10 +359,13 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
     (src.quantum == MH_QUANTUM_U16) && ((src.channels == 4) || ((src.channels == 3) && !roles.blend)) &&
     (roles.copy_mask == 0) && (!roles.blend || (roles.alpha == 3)) &&
     (getenv("MAGICKHIP_NO_MFMA") == nullptr) && (getenv("MAGICKHIP_NO_MFMA_2D") == nullptr);
-  // (FAST, up to 17 cells wide: the f16 kernel's band is one 32-slot chunk where the integer one
-  // always multiplies two — Octagon:5 on 8192^2 RGBA 0.59 against 0.92 ms; from 18 cells on the
-  // integer kernel is the faster one as well: Disk:15 on 16384^2 6.4 against 8.3 ms)
-  if (matrix_2d && (mode == MH_PRECISION_FAST) && (kernel->width <= 17))
+  // (FAST, narrow kernels: the f16 kernel's band is one 32-slot chunk up to 17 cells where the
+  // integer one always multiplies two, on four byte planes of alpha-weighted samples — Octagon:8 on
+  // 16384^2 RGBA 3.0 against 4.0 ms; with the two planes of plain samples the integer kernel is the
+  // faster one from 11 cells on (four channels: Octagon:5 2.05 against 2.13 ms, Octagon:3 1.87
+  // against 1.68) and never the slower one on RGB.  Wider: Disk:15 RGBA 6.4 against 8.3 ms.)
+  if (matrix_2d && (mode == MH_PRECISION_FAST) &&
+      (roles.blend ? (kernel->width <= 17) : ((src.channels == 4) && (kernel->width <= 9))))
     {
       bool handled=false;
       MH_TRY(launch_conv2d_mfma(src,dst,kernel,roles.blend,&handled));

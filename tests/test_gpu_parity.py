@@ -1075,12 +1075,14 @@ def test_convolve_2d_integer_cells_on_matrix_cores(im, refmod, kernel, layout, m
     finally:
         im.set_precision(im.PRECISION_EXACT)
     outer_product = zero_sum or kernel.startswith(("Square", "Rectangle"))
-    wide = kernel in ("Disk:15", "Ring:10,14") or kernel.startswith("41x5")        # more than 17 columns
-    if not (signed and alpha) and (mode == "exact" or wide):
-        # (alpha-weighted sums of signed cells keep the fp64 kernels; FAST separates an outer product
-        # first and gives kernels of up to 17 columns to the f16 kernel, whose band is one chunk)
+    width = im.kernel_to_numpy(kernel)[0].shape[1]
+    # FAST gives narrow kernels to the f16 kernel, whose band is one chunk up to 17 columns: alpha-
+    # weighted frames up to there, four plain channels up to 9, RGB never (operators.cpp)
+    f16_first = (width <= 17) if alpha else (layout == "plain4" and width <= 9)
+    if not (signed and alpha) and (mode == "exact" or not (f16_first or outer_product)):
+        # (alpha-weighted sums of signed cells keep the fp64 kernels; FAST separates an outer product first)
         assert launched == {"conv2d_exact"}, launched
-    elif mode == "fast" and not outer_product and not signed:
+    elif mode == "fast" and f16_first and not outer_product and not signed:
         assert launched == {"conv2d_mfma"}, launched
     assert_parity(holder["out"].numpy(), want, mode == "exact" or "conv2d_exact" in launched,
                   "integer 2-D convolve %s %s %s" % (kernel, layout, mode))
