@@ -144,6 +144,7 @@ PROTOTYPES = [
     ("MhExactBlurRecomputed", ctypes.c_ulonglong, [ctypes.c_int]),
     ("MhSeparableRecomputed", ctypes.c_ulonglong, [ctypes.c_int]),
     ("MhConvolve2DRecomputed", ctypes.c_ulonglong, [ctypes.c_int]),
+    ("MhConvolve2DTieRecomputed", ctypes.c_ulonglong, [ctypes.c_int]),
     ("MhKernelIntegerCells", ctypes.c_int, [_P(MhKernelInfo), _P(ctypes.c_int), _P(ctypes.c_double)]),
     ("MhHostAlloc", ctypes.c_void_p, [ctypes.c_size_t]),
     ("MhHostFree", ctypes.c_int, [ctypes.c_void_p]),

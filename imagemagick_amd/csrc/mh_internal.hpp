@@ -246,6 +246,10 @@ MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const 
 // bit-identical in both precision modes (convolve2d_exact.hip)
 MhStatus launch_conv2d_exact(const View &src,const View &dst,const MhKernelInfo *kernel,bool blend,
   bool *handled,Temp *flag=nullptr);
+// ... any cells, any layout, Q16 or float: fused multiply-adds over premultiplied doubles + tie check,
+// bit-identical (convolve2d_tie.hip); only_if: device word, the kernel leaves at once when it is zero
+MhStatus launch_conv2d_tie(const View &src,const View &dst,const MhKernelInfo *kernel,const Roles &roles,
+  bool *handled,const unsigned *only_if=nullptr);
 MhStatus launch_conv2d_mfma(const View &src,const View &dst,const MhKernelInfo *kernel,bool blend,
   bool *handled);
 MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_device,

@@ -345,6 +345,10 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
         MH_TRY(launch_conv2d_exact(src,dst,kernel,roles.blend,&handled,&flag));
       if (handled)
         {
+          bool fused=false;
+          MH_TRY(launch_conv2d_tie(src,dst,kernel,roles,&fused,flag.as<unsigned>()));
+          if (fused)
+            return MH_OK;
           Morph2DParams fallback;
           fallback.method=method;
           fallback.kernel=kernel;
@@ -409,6 +413,16 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
     {
       bool handled=false;
       MH_TRY(launch_conv2d_mfma(src,dst,kernel,roles.blend,&handled));
+      if (handled)
+        return MH_OK;
+    }
+  // what is left of Convolve — cells that are no outer product and no integer multiples, float frames
+  // that are not made of integers, one- and two-channel layouts, EXACT mode: fused multiply-adds over
+  // premultiplied doubles and a tie check, bit-identical (convolve2d_tie.hip)
+  if ((method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0))
+    {
+      bool handled=false;
+      MH_TRY(launch_conv2d_tie(src,dst,kernel,roles,&handled));
       if (handled)
         return MH_OK;
     }

@@ -242,6 +242,9 @@ MH_API unsigned long long MhSeparableRecomputed(int enable);
    lay within the reference's own rounding error of a Quantum boundary and were recomputed in the
    reference's order since the last call (enable as above). */
 MH_API unsigned long long MhConvolve2DRecomputed(int enable);
+/* ... and of the fused fp64 2-D convolve that takes every other kernel and frame (one fused
+   multiply-add per cell and channel over alpha-premultiplied doubles + tie check, bit-identical). */
+MH_API unsigned long long MhConvolve2DTieRecomputed(int enable);
 
 
 /* ------------------------------------------------------ kernels and filters */

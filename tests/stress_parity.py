@@ -88,7 +88,8 @@ def check(name, got, want, limit, detail):
 # 4 histogram operators, 5 FAST 2-D convolve, 6 FAST Lab, 7 EXACT GaussianBlur / Sharpen (separable +
 # tie check), 8 float-Quantum blur / unsharp, 9 float-Quantum Erode / Dilate, 10 float-Quantum
 # GaussianBlur / Sharpen, 11 float-Quantum ContrastStretch / Equalize, 12 integer-cell 2-D convolve on the
-# i8 matrix cores in both modes and three layouts)
+# i8 matrix cores in both modes and three layouts, 13 2-D convolve with random real cells on every layout and
+# Quantum type: the fused fp64 kernel)
 only_ops = [int(t) for t in os.environ.get("STRESS_OPS", "").split(",") if t.strip()]
 t0 = time.time()
 cases = failures = 0
@@ -98,7 +99,7 @@ while time.time() - t0 < budget:
         rows, cols = int(rng.integers(1, 40)), int(rng.integers(300, 1400))
     kind = int(rng.integers(0, 5))
     px = pixels(rows, cols, kind)
-    op = int(rng.integers(0, 13))
+    op = int(rng.integers(0, 14))
     if only_ops:
         op = only_ops[int(rng.integers(0, len(only_ops)))]
     detail = "%dx%d kind %d" % (rows, cols, kind)
@@ -262,6 +263,32 @@ while time.time() - t0 < budget:
         im.set_precision(im.PRECISION_EXACT)
         failures += check("integer convolve 2-D", got, want, 1 if fast else 0, detail + " layout %d %s %s" % (
             layout, "fast" if fast else "exact", kernel[:60]))
+    elif op == 13:                                 # any-cell 2-D convolve (fused fp64 + tie check): bit-identical
+        kw, kh = int(rng.integers(3, 24)), int(rng.integers(3, 16))
+        if kw * kh < 25:
+            kw, kh = 7, 5
+        signed_cells = rng.random() < 0.3
+        cells = rng.uniform(-1.0 if signed_cells else 0.0, 1.0, (kh, kw))
+        cells[rng.random((kh, kw)) < 0.1] = np.nan
+        cells[kh // 2, kw // 2] = 3.0
+        kernel = "%dx%d+%d+%d: %s" % (kw, kh, rng.integers(0, kw), rng.integers(0, kh), " ".join(
+            ",".join("nan" if np.isnan(v) else "%.17g" % v for v in r) for r in cells))
+        channels = int(rng.integers(1, 5))
+        blend = channels in (2, 4) and rng.random() < 0.6
+        is_float = rng.random() < 0.5
+        frame = float_pixels(rows, cols, kind) if is_float else px
+        if channels < 4:
+            frame = np.ascontiguousarray(frame[:, :, 4 - channels:] if blend else frame[:, :, :channels])
+        if blend or channels in (1, 3):
+            want = refmod.RefImage(frame).set_artifact("convolve:scale", "!").morphology("Convolve", 1, kernel).numpy()
+        else:
+            want = np.concatenate([refmod.RefImage(frame[:, :, c].copy()).set_artifact("convolve:scale", "!")
+                                   .morphology("Convolve", 1, kernel).numpy().reshape(rows, cols, 1) for c in range(channels)], axis=2)
+        image = (dev_float if is_float else dev)(frame, has_alpha=blend)
+        got = im.morphology_image(image, "Convolve", 1, kernel, scale=(1.0, 1)).numpy()
+        what = detail + " c%d blend=%s %s" % (channels, blend, kernel[:50])
+        failures += check_bits("fused 2-D convolve, float", got, want, what) if is_float else \
+            check("fused 2-D convolve", got, want, 0, what)
     else:                                          # FAST Lab
         im.set_precision(im.PRECISION_FAST)
         d2 = dev(px)

@@ -22,10 +22,11 @@ for kernel in kernels:
     outs = {}
     for label, env, mode in (("i8 exact", {}, im.PRECISION_EXACT),
                              ("f16 (FAST)", {"MAGICKHIP_NO_EXACT_2D": "1"}, im.PRECISION_FAST),
-                             ("generic", {"MAGICKHIP_NO_MFMA_2D": "1"}, im.PRECISION_EXACT)):
+                             ("fused fp64", {"MAGICKHIP_NO_MFMA_2D": "1"}, im.PRECISION_EXACT),
+                             ("generic", {"MAGICKHIP_NO_MFMA_2D": "1", "MAGICKHIP_NO_TIE_2D": "1"}, im.PRECISION_EXACT)):
         if label == "generic" and n > 8192 and os.environ.get("TIME_GENERIC") is None:
             continue
-        for k in ("MAGICKHIP_NO_EXACT_2D", "MAGICKHIP_NO_MFMA_2D"):
+        for k in ("MAGICKHIP_NO_EXACT_2D", "MAGICKHIP_NO_MFMA_2D", "MAGICKHIP_NO_TIE_2D"):
             os.environ.pop(k, None)
         os.environ.update(env)
         im.set_precision(mode)
