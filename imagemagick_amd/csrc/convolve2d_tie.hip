@@ -254,7 +254,8 @@ MhStatus launch_conv2d_tie(const View &src,const View &dst,const MhKernelInfo *k
   if ((src.channels < 1) || (src.channels > 4) || (roles.copy_mask != 0) || (src.quantum != dst.quantum) ||
       (src.channels != dst.channels) || (src.columns != dst.columns) || (src.rows != dst.rows) ||
       (src.pixels == dst.pixels) || (kw < 1) || (kh < 1) || (kw*kh < 25) || (kernel->x < 0) || (kernel->y < 0) ||
-      (kernel->x >= kw) || (kernel->y >= kh) || (src.columns >= (1u << 30)) || (src.rows >= (1u << 30)) ||
+      (kernel->x >= kw) || (kernel->y >= kh) || (src.columns >= (1u << 30)) ||
+      ((src.rows+kTieH-1)/kTieH > 65535u) ||                 // (gridDim.y)
       (getenv("MAGICKHIP_NO_TIE_2D") != nullptr))
     return MH_OK;
   const bool blend=roles.blend && (roles.alpha == src.channels-1) && (src.channels >= 2);
