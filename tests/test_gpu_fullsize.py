@@ -203,6 +203,35 @@ def test_c5_dilate_disk15_full_size(im, refmod):
 
 
 @pytest.mark.parametrize("precision", ["exact", "fast"])
+def test_c5_convolve_disk15_full_size(im, refmod, precision):
+    """16384^2 RGBA Q16 ConvolveMorphology Disk:15 with convolve:scale='!' (SURVEY 8d's MAC-bound
+    variant of C5; 709 cells of 1/709): exact integer sums on the i8 matrix cores in BOTH precision
+    modes — bit-identical to three full-width bands and one full-height band of the reference,
+    15-pixel halo."""
+    n, band, reach = 16384, 192, 15
+    rng = np.random.default_rng(56)
+    px = rng.integers(0, 65536, (n, n, 4), dtype=np.uint16)
+    refmod.set_thread_limit(os.cpu_count() or 1)
+    im.set_precision(im.PRECISION_FAST if precision == "fast" else im.PRECISION_EXACT)
+    try:
+        out = im.morphology_image(im.Image(to_device(px)), "Convolve", 1, "Disk:15", scale=(1.0, 1)).pixels
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+
+    def reference(pixels):
+        return refmod.RefImage(pixels).set_artifact("convolve:scale", "!").morphology("Convolve", 1, "Disk:15").numpy()
+    for y0 in _band_starts(n, band):
+        lo, hi = max(y0 - reach, 0), min(y0 + band + reach, n)
+        want = reference(px[lo:hi])
+        _compare_q16(out[y0:y0 + band], want[y0 - lo:y0 - lo + band], True, "C5 Convolve rows %d.." % y0)
+    x0 = n // 3
+    lo, hi = x0 - reach, x0 + 64 + reach
+    want = reference(np.ascontiguousarray(px[:, lo:hi]))
+    _compare_q16(out[:, x0:x0 + 64].contiguous(), np.ascontiguousarray(want[:, reach:reach + 64]), True,
+                 "C5 Convolve columns %d.." % x0)
+
+
+@pytest.mark.parametrize("precision", ["exact", "fast"])
 def test_c5_unsharp_full_size(im, refmod, precision):
     """16384^2 RGBA Q16 UnsharpMask(0x10+1.0+0.02): bands of the reference with the blur's
     39-pixel reach as halo.  FAST: a blurred sample one level off moves the result by at most
