@@ -258,7 +258,8 @@ MhStatus launch_conv2d_tie(const View &src,const View &dst,const MhKernelInfo *k
       ((src.rows+kTieH-1)/kTieH > 65535u) ||                 // (gridDim.y)
       (getenv("MAGICKHIP_NO_TIE_2D") != nullptr))
     return MH_OK;
-  const bool blend=roles.blend && (roles.alpha == src.channels-1) && (src.channels >= 2);
+  // (alpha-weighted: gray + alpha and RGBA; other layouts with an alpha trait keep the generic kernel)
+  const bool blend=roles.blend && (roles.alpha == src.channels-1) && ((src.channels == 2) || (src.channels == 4));
   if (roles.blend && !blend)
     return MH_OK;
   const int tile_w=(kTieW+kw-1+1) & ~1,tile_h=kTieH+kh-1;

@@ -207,7 +207,8 @@ MhStatus launch_separable_exact(const View &src,const View &dst,const MhKernelIn
       (src.columns != dst.columns) || (src.rows != dst.rows) || (kw > 255) || (kh > 255) ||
       (getenv("MAGICKHIP_NO_SEPARABLE_EXACT") != nullptr))
     return MH_OK;
-  const bool blend=roles.blend && (roles.alpha == src.channels-1) && (src.channels >= 2);
+  // (alpha-weighted: gray + alpha and RGBA; other layouts with an alpha trait keep the generic kernel)
+  const bool blend=roles.blend && (roles.alpha == src.channels-1) && ((src.channels == 2) || (src.channels == 4));
   if (roles.blend && !blend)
     return MH_OK;
   // how far the separable evaluation can be from the reference's: the cells are the outer product
