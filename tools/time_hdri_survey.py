@@ -1,5 +1,7 @@
 """Float Quantum (HDRI, the reference's default build) against Q16, operator by operator, on an
-n x n RGBA frame: whole-call ms and the kernels that ran.   python tools/time_hdri_survey.py [n]"""
+n x n RGBA frame: whole-call ms and the kernels that ran.   python tools/time_hdri_survey.py [n]
+(The float frame holds fractional samples: Convolve with a flat kernel takes the fused fp64 kernel
+there; tools/time_convolve2d_hdri.py times the integer-sample case.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,6 +20,8 @@ OPS = [
     ("unsharp 0x10", lambda i: im.unsharp_mask_image(i, 0.0, 10.0, 1.0, 0.02)),
     ("sharpen 0x2", lambda i: im.sharpen_image(i, 0.0, 2.0)),
     ("convolve Disk:5", lambda i: im.morphology_image(i, "Convolve", 1, "Disk:5", scale=(1.0, 1))),
+    ("convolve Disk:15", lambda i: im.morphology_image(i, "Convolve", 1, "Disk:15", scale=(1.0, 1))),
+    ("convolve LoG:0x2", lambda i: im.morphology_image(i, "Convolve", 1, "LoG:0x2")),
     ("dilate Disk:15", lambda i: im.morphology_image(i, "Dilate", 1, "Disk:15")),
     ("erode Octagon:5", lambda i: im.morphology_image(i, "Erode", 1, "Octagon:5")),
     ("open Disk:5", lambda i: im.morphology_image(i, "Open", 1, "Disk:5")),
