@@ -1255,7 +1255,6 @@ def test_convolve_2d_integer_cells_float_quantum(im, refmod, kernel, layout, mon
     if not (signed and alpha):
         # (the fused fp64 kernel stands behind it for frames that turn out not to be integers)
         assert set(launched) == {"conv2d_exact", "conv2d_tie"}, launched
-        assert launched["conv2d_tie"]["avg_ms"] < 0.05, launched
     got = holder["out"].numpy()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "%d float samples differ" % int(
         (got.view(np.uint32) != want.view(np.uint32)).sum())
