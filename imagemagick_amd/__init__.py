@@ -213,14 +213,17 @@ def kernel_integer_cells(kernel_string, scale=None):
         lib.MhDestroyKernelInfo(ptr)
 
 
-def kernel_to_numpy(kernel_string, index=0):
+def kernel_to_numpy(kernel_string, index=0, scale=None):
     """Build a kernel list with the product's host builder and return kernel
-    `index` as (values[h,w], x, y, count)."""
+    `index` as (values[h,w], x, y, count).  scale: (factor, normalize flags) applied first, as
+    `-define convolve:scale` does."""
     lib = _lib.load()
     ptr = lib.MhAcquireKernelInfo(kernel_string.encode())
     if not ptr:
         raise MagickHipError(3, lib.MhGetLastError().decode())
     try:
+        if scale is not None:
+            lib.MhScaleKernelInfo(ptr, float(scale[0]), int(scale[1]))
         count = 0
         k = ptr
         chosen = None
