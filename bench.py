@@ -312,7 +312,7 @@ def blur_mode(im, torch, image, sigma, mode, reps=24, ramp=0.3):
     pixels = float(image.rows) * image.columns
     im.set_precision(im.PRECISION_EXACT if mode in ("exact", "hdri") else im.PRECISION_FAST)
     if mode == "fast_f16_legacy":
-        os.environ["MAGICKHIP_NO_EXACT_MFMA"] = "1"
+        im.set_option("MAGICKHIP_NO_EXACT_MFMA", "1")      # (the library reads the environment only at start-up)
     holder = {}
     try:
         def call():
@@ -326,7 +326,8 @@ def blur_mode(im, torch, image, sigma, mode, reps=24, ramp=0.3):
         sec = timed(torch, call, reps)
         prof = kernel_profile(im, call, max(2, reps // 2))
     finally:
-        os.environ.pop("MAGICKHIP_NO_EXACT_MFMA", None)
+        if mode == "fast_f16_legacy":
+            im.set_option("MAGICKHIP_NO_EXACT_MFMA", os.environ.get("MAGICKHIP_NO_EXACT_MFMA"))
     conv = {k: v for k, v in prof.items() if k.startswith("conv_") or k.startswith("blur_fused")}
     dominant = max(conv, key=lambda k: conv[k]["avg_ms"])
     frame = pixels * (16.0 if mode == "hdri" else 8.0)
@@ -631,8 +632,13 @@ def extra_measurements(im, torch, args, image):
         del pinned_image, pinned_out, pinned_in
         extra["host_link"] = ("PCIe: 57 GB/s either direction, 57 GB/s combined when both run (half duplex on "
                               "this box, tools/pcie_probe.py): 1.07 GB per 8192^2 call = 18.8 ms at best")
-        del host_out
-        del host, host_image
+        del host_out, host_image
+        torch.cuda.empty_cache()
+        try:
+            extra.update(shim_measurements(n, args.sigma, host))
+        except Exception as exc:                          # the shim build is optional on a box
+            extra["shim"] = "%s: %s" % (type(exc).__name__, exc)
+        del host
         torch.cuda.empty_cache()
         result["resize"] = resize_config(im, torch, gen)
         torch.cuda.empty_cache()
@@ -645,6 +651,66 @@ def extra_measurements(im, torch, args, image):
         extra["error"] = "%s: %s" % (type(exc).__name__, exc)
     result["extra"] = extra
     return result
+
+
+def shim_measurements(n, sigma, host):
+    """The drop-in boundary itself: MagickCore's own operators on the
+    HIP-backed MagickCore build (shim/), as an unchanged application calls them.
+
+    shim_blur: BlurImage on the 8192^2 RGBA Q16 frame, source NOT resident (the CPU wrote it), result
+    brought back to the host by the cache's lazy sync — upload + kernel + download + CloneImage of
+    a page-locked result cache, per call.  shim_blur_resident: the same with the source left on the
+    device and the result not read (a link of a chain).  shim_batch: 64 x 4096^2 sRGB -> Lab +
+    ContrastStretch from 8 host threads — every call arbitrated over the devices and their streams
+    (AcquireHipQueue), results read back."""
+    import threading
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "shim"))
+    import magickcore as mc
+    out = {}
+    if not mc.available(False):
+        return {"shim": "shim/_build is not built"}
+    before = mc.accelerated_calls()
+    source = mc.Image(host)
+    source.blur(0.0, sigma).sync()                         # warm-up: library load, tables, pool
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        source.touch()
+        source.blur(0.0, sigma).sync()
+    out["shim_blur_Mpixels_per_s"] = round(reps * float(n) * n / (time.perf_counter() - t0) / 1e6, 1)
+    source.blur(0.0, sigma)
+    t0 = time.perf_counter()
+    keep = [source.blur(0.0, sigma) for _ in range(reps)]
+    keep[-1].sync()
+    out["shim_blur_resident_Mpixels_per_s"] = round(reps * float(n) * n / (time.perf_counter() - t0) / 1e6, 1)
+    del keep, source
+    edge, count, threads = 4096, 64, 8
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 65536, (edge, edge, 4), dtype=np.uint16)
+    images = [mc.Image(frame) for _ in range(count)]
+    pixels = float(edge) * edge
+    errors = []
+
+    def work(t):
+        try:
+            for image in images[t::threads]:
+                image.colorspace("Lab").contrast_stretch(0.02 * pixels, pixels - 0.01 * pixels).sync()
+        except Exception as exc:                          # noqa: BLE001
+            errors.append(repr(exc))
+    t0 = time.perf_counter()
+    pool = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    for th in pool:
+        th.start()
+    for th in pool:
+        th.join()
+    sec = time.perf_counter() - t0
+    out["shim_batch_Mpixels_per_s"] = round(count * pixels / sec / 1e6, 1)
+    out["shim_batch"] = {"images": count, "edge": edge, "threads": threads, "seconds": round(sec, 3),
+                         "devices": [{"calls": c, "streams": s} for c, s in mc.device_statistics()],
+                         "errors": errors}
+    out["shim_accelerated_calls"] = mc.accelerated_calls() - before
+    return out
 
 
 # ------------------------------------------------------------------ N-rank configurations

@@ -22,7 +22,8 @@ __all__ = ["Image", "blur_image", "convolve_image", "morphology_image", "morphol
            "unsharp_mask_image", "resize_image", "contrast_stretch_image", "equalize_image",
            "transform_image_colorspace", "wavelet_denoise_image", "despeckle_image", "local_contrast_image", "rotational_blur_image", "motion_blur_image", "gaussian_blur_image", "sharpen_image", "edge_image",
            "emboss_image", "import_image_pixels", "export_image_pixels", "contrast_image", "modulate_image", "grayscale_image", "function_image", "histogram", "apply_lut", "contrast_stretch_lut",
-           "equalize_lut", "is_image_gray", "set_precision", "get_precision", "device_count",
+           "equalize_lut", "is_image_gray", "set_precision", "get_precision", "set_option", "get_option", "option",
+           "logical_device_count", "device_info", "device_count",
            "build", "load", "MagickHipError"]
 
 build = _lib.build
@@ -38,10 +39,13 @@ class Image:
     MagickCore shim reads from ``Image``): channel traits, alpha, colourspace."""
 
     def __init__(self, pixels, colorspace="srgb", has_alpha=None, channel_mask=ALL_CHANNELS,
-                 copy_channels=(), intensity=0, stream=None):
+                 copy_channels=(), intensity=0, stream=None, precision=None):
         # stream: the raw HIP stream handle the pixels belong to (device memory; default: torch's
         # current stream of the tensor's device when a descriptor is made)
         self.stream = stream
+        # precision: PRECISION_EXACT / PRECISION_FAST for the operators called on THIS image
+        # (MhImage::precision), None = the library default (set_precision)
+        self.precision = precision
         if pixels.ndim == 2:
             pixels = pixels.reshape(pixels.shape[0], pixels.shape[1], 1)
         if pixels.ndim != 3:
@@ -93,6 +97,7 @@ class Image:
         d.colorspace = COLORSPACES[self.colorspace]
         d.intensity = self.intensity
         d.channel_mask = self.channel_mask
+        d.precision = 0 if self.precision is None else int(self.precision) + 1
         for c in self.copy_channels:
             d.channel_traits[c] = TRAIT_COPY
         if self.memory == _lib.MEMORY_DEVICE:
@@ -112,7 +117,7 @@ class Image:
         else:
             px = np.empty((rows, columns, self.channels), dtype=self.pixels.dtype)
         return Image(px, self.colorspace, self.has_alpha, self.channel_mask, self.copy_channels,
-                     self.intensity)
+                     self.intensity, precision=self.precision)
 
     def numpy(self):
         if self.memory == _lib.MEMORY_DEVICE:
@@ -273,6 +278,45 @@ def set_precision(precision):
 
 def get_precision():
     return _lib.load().MhGetPrecision()
+
+
+def set_option(name, value):
+    """MhSetOption: the library reads MAGICKHIP_* / MAGICK_HIP_* from the environment once, at
+    start-up; this changes the value it holds (None = unset).  Tests and A/B timings only."""
+    _lib.check(_lib.load().MhSetOption(name.encode(), None if value is None else str(value).encode()))
+
+
+def get_option(name):
+    v = _lib.load().MhGetOption(name.encode())
+    return None if v is None else v.decode()
+
+
+class option:
+    """with option("MAGICKHIP_NO_MFMA", "1"): ...  — a switch for the duration of a block."""
+
+    def __init__(self, name, value="1"):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.previous = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.previous)
+        return False
+
+
+def logical_device_count():
+    return _lib.load().MhLogicalDeviceCount()
+
+
+def device_info(device=0):
+    info = _lib.MhDeviceInfo()
+    _lib.check(_lib.load().MhGetDeviceInfo(device, ctypes.byref(info)))
+    return {"name": info.name.decode(), "architecture": info.architecture.decode(),
+            "compute_units": info.compute_units, "clock_mhz": info.clock_mhz,
+            "global_memory": info.global_memory, "local_memory": info.local_memory}
 
 
 # ------------------------------------------------------------------- operators

@@ -73,7 +73,14 @@ class MhImage(ctypes.Structure):
         ("intensity", ctypes.c_uint32),
         ("channel_mask", ctypes.c_uint32),
         ("stream", ctypes.c_void_p),
+        ("precision", ctypes.c_uint32),      # 0 = library default, else MhPrecision + 1
     ]
+
+
+class MhDeviceInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 128), ("architecture", ctypes.c_char * 64),
+                ("compute_units", ctypes.c_int32), ("clock_mhz", ctypes.c_int32),
+                ("global_memory", ctypes.c_uint64), ("local_memory", ctypes.c_uint64)]
 
 
 class MhKernelInfo(ctypes.Structure):
@@ -131,6 +138,15 @@ PROTOTYPES = [
     ("MhGetVersion", ctypes.c_char_p, []),
     ("MhGetPrecision", ctypes.c_int, []),
     ("MhSetPrecision", ctypes.c_int, [ctypes.c_int]),
+    ("MhSetOption", ctypes.c_int, [ctypes.c_char_p, ctypes.c_char_p]),
+    ("MhGetOption", ctypes.c_char_p, [ctypes.c_char_p]),
+    ("MhLogicalDeviceCount", ctypes.c_int, []),
+    ("MhGetDeviceInfo", ctypes.c_int, [ctypes.c_int, _P(MhDeviceInfo)]),
+    ("MhStreamCreate", ctypes.c_int, [ctypes.c_int, _P(ctypes.c_void_p)]),
+    ("MhStreamDestroy", ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
+    ("MhDeviceAllocAsync", ctypes.c_int, [ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p, _P(ctypes.c_void_p)]),
+    ("MhDeviceFreeAsync", ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    ("MhGetDeviceProfileRecords", ctypes.c_size_t, [ctypes.c_int, _P(MhKernelProfileRecord), ctypes.c_size_t]),
     ("MhDeviceAlloc", ctypes.c_int, [ctypes.c_int, ctypes.c_size_t, _P(ctypes.c_void_p)]),
     ("MhDeviceFree", ctypes.c_int, [ctypes.c_int, ctypes.c_void_p]),
     ("MhUpload", ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t,

@@ -315,7 +315,7 @@ static int logical_devices(int requested)
 {
   const int physical=device_count();
   int n=requested <= 0 ? physical : requested;
-  if (const char *e=getenv("MAGICKHIP_LOGICAL_DEVICES"))
+  if (const char *e=option("MAGICKHIP_LOGICAL_DEVICES"))
     if ((requested <= 0) && (atoi(e) > 0))
       n=atoi(e);
   return n > 16 ? 16 : (n < 1 ? 1 : n);
@@ -341,7 +341,7 @@ static Rccl &rccl()
   static std::once_flag once;
   std::call_once(once,[]()
   {
-    const char *off=getenv("MAGICKHIP_RCCL");
+    const char *off=option("MAGICKHIP_RCCL");
     if ((off != nullptr) && (strcmp(off,"0") == 0))
       return;
     r.handle=dlopen("librccl.so.1",RTLD_NOW | RTLD_LOCAL);
@@ -361,17 +361,22 @@ static Rccl &rccl()
 }
 
 // communicators by device set (all_reduce_tables), destroyed by MhTerminus
+struct CommSet { std::mutex lock; std::vector<ncclComm_t> comms; };
 static std::mutex g_comm_lock;
-static std::map<std::vector<int>,std::vector<ncclComm_t>> g_comms;
+static std::map<std::vector<int>,std::shared_ptr<CommSet>> g_comms;
 
 void release_rccl_communicators()
 {
   std::lock_guard<std::mutex> guard(g_comm_lock);
   Rccl &r=rccl();
   for (auto &entry : g_comms)
-    for (ncclComm_t comm : entry.second)
-      if (r.CommDestroy != nullptr)
-        (void) r.CommDestroy(comm);
+    {
+      std::lock_guard<std::mutex> set_guard(entry.second->lock);
+      for (ncclComm_t comm : entry.second->comms)
+        if (r.CommDestroy != nullptr)
+          (void) r.CommDestroy(comm);
+      entry.second->comms.clear();
+    }
   g_comms.clear();
 }
 
@@ -396,22 +401,33 @@ static MhStatus all_reduce_tables(std::vector<TableView> &bands,size_t count,boo
       std::vector<int> devices;
       for (const TableView &v : bands)
         devices.push_back(v.device);
-      std::lock_guard<std::mutex> guard(g_comm_lock);       // also serialises collectives on a set
-      auto it=g_comms.find(devices);
-      if (it == g_comms.end())
+      // the global lock covers the lookup only; a set of devices has its own lock for the
+      // collective itself, so operators on disjoint sets of GPUs do not wait for each other
+      std::shared_ptr<CommSet> set;
+      {
+        std::lock_guard<std::mutex> guard(g_comm_lock);
+        auto it=g_comms.find(devices);
+        if (it == g_comms.end())
+          {
+            auto fresh=std::make_shared<CommSet>();
+            fresh->comms.resize(bands.size());
+            if (r.CommInitAll(fresh->comms.data(),(int) bands.size(),devices.data()) == ncclSuccess)
+              it=g_comms.emplace(devices,fresh).first;
+          }
+        if (it != g_comms.end())
+          set=it->second;
+      }
+      if (set)
         {
-          std::vector<ncclComm_t> comms(bands.size());
-          if (r.CommInitAll(comms.data(),(int) bands.size(),devices.data()) == ncclSuccess)
-            it=g_comms.emplace(devices,std::move(comms)).first;
-        }
-      if (it != g_comms.end())
-        {
-          const std::vector<ncclComm_t> &comms=it->second;
-          bool ok=r.GroupStart() == ncclSuccess;
-          for (size_t b=0; ok && (b < bands.size()); b++)
-            ok=r.AllReduce(bands[b].table,bands[b].table,count,ncclUint64,ncclSum,comms[b],
-              bands[b].stream) == ncclSuccess;
-          ok=(r.GroupEnd() == ncclSuccess) && ok;
+          bool ok;
+          {
+            std::lock_guard<std::mutex> guard(set->lock);        // one collective at a time per communicator
+            ok=r.GroupStart() == ncclSuccess;
+            for (size_t b=0; ok && (b < bands.size()); b++)
+              ok=r.AllReduce(bands[b].table,bands[b].table,count,ncclUint64,ncclSum,set->comms[b],
+                bands[b].stream) == ncclSuccess;
+            ok=(r.GroupEnd() == ncclSuccess) && ok;
+          }
           for (size_t b=0; b < bands.size(); b++)
             ok=(hipStreamSynchronize(bands[b].stream) == hipSuccess) && ok;
           if (ok)
@@ -419,6 +435,20 @@ static MhStatus all_reduce_tables(std::vector<TableView> &bands,size_t count,boo
               *used_rccl=true;
               return MH_OK;
             }
+          // a communicator that failed once is not retried: drop it (the next call builds a new one)
+          {
+            std::lock_guard<std::mutex> guard(g_comm_lock);
+            auto it=g_comms.find(devices);
+            if ((it != g_comms.end()) && (it->second == set))
+              g_comms.erase(it);
+          }
+          {
+            std::lock_guard<std::mutex> guard(set->lock);
+            for (ncclComm_t comm : set->comms)
+              if (r.CommDestroy != nullptr)
+                (void) r.CommDestroy(comm);
+            set->comms.clear();
+          }
           // (the tables may be partly reduced: the caller cannot recover the inputs)
           return fail(MH_DEVICE_ERROR,"ncclAllReduce of the histogram table failed");
         }
@@ -455,7 +485,7 @@ MhStatus host_banded_operator(const MhOperator &op,const MhKernelInfo *kernel,co
 {
   *handled=false;
   if ((image->memory != MH_MEMORY_HOST) || (result->memory != MH_MEMORY_HOST) ||
-      (getenv("MAGICKHIP_NO_BANDED") != nullptr))
+      (option("MAGICKHIP_NO_BANDED") != nullptr))
     return MH_OK;
   // the bands are described by the SOURCE's descriptor: a result with other channel traits, alpha
   // trait or channel mask (the whole-frame path honours them, channel_roles(image, result)) keeps
@@ -467,7 +497,7 @@ MhStatus host_banded_operator(const MhOperator &op,const MhKernelInfo *kernel,co
   const size_t row_bytes=image->columns*(size_t) image->number_channels*
     (image->quantum == MH_QUANTUM_U16 ? 2u : 4u);
   size_t minimum=64u << 20;
-  if (const char *e=getenv("MAGICKHIP_BANDED_MIN_BYTES"))
+  if (const char *e=option("MAGICKHIP_BANDED_MIN_BYTES"))
     minimum=(size_t) atoll(e);
   if (row_bytes*image->rows < minimum)
     return MH_OK;
@@ -486,7 +516,7 @@ MhStatus host_banded_operator(const MhOperator &op,const MhKernelInfo *kernel,co
   if (nbands < 3)
     return MH_OK;
   int workers=4;
-  if (const char *e=getenv("MAGICKHIP_BANDED_WORKERS"))
+  if (const char *e=option("MAGICKHIP_BANDED_WORKERS"))
     workers=atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
   const int device=resolve_device(image);
   std::atomic<size_t> next{0};

@@ -1510,7 +1510,7 @@ static MhStatus launch_tri_waves(const View &src,const View &dst,bool vertical,
       size_t table_bytes=A::taps_in_lds ? (((size_t) K*sizeof(T)+15u) & ~(size_t) 15u) : 0;
       size_t lds_tile=table_bytes+(size_t) (WAVES*R+K-1)*64*C*sizeof(Q);
       ProfileScope prof("conv_column",src.stream);
-      if ((lds_tile <= 80u*1024u) && (getenv("MAGICKHIP_NO_COLUMN_LDS") == nullptr))
+      if ((lds_tile <= 80u*1024u) && (option("MAGICKHIP_NO_COLUMN_LDS") == nullptr))
         {
           if (lds_tile > 64u*1024u)
             MH_HIP(hipFuncSetAttribute(
@@ -1728,8 +1728,8 @@ MhStatus launch_conv1d_column_unsharp(const View &rows,const View &dst,const Vie
   if ((!is_float && (prec != MH_PRECISION_EXACT)) || (params.ntaps < 16) || (params.bias != 0.0) ||
       (original.columns != rows.columns) || (original.rows != rows.rows) ||
       (original.channels != rows.channels) || (original.quantum != rows.quantum) ||
-      (getenv("MAGICKHIP_NO_TRI") != nullptr) || (getenv("MAGICKHIP_NO_TIE64") != nullptr) ||
-      (getenv("MAGICKHIP_NO_FUSED_UNSHARP") != nullptr))
+      (option("MAGICKHIP_NO_TRI") != nullptr) || (option("MAGICKHIP_NO_TIE64") != nullptr) ||
+      (option("MAGICKHIP_NO_FUSED_UNSHARP") != nullptr))
     return MH_OK;
   double total=0.0;
   for (int v=0; v < params.ntaps; v++)
@@ -1757,7 +1757,7 @@ MhStatus launch_conv1d_sums64(const View &src,const View &dst,bool vertical,cons
 {
   Roles plain;
   plain.update_mask=0xfu;
-  if ((params.ntaps >= 16) && (getenv("MAGICKHIP_NO_TRI") == nullptr))
+  if ((params.ntaps >= 16) && (option("MAGICKHIP_NO_TRI") == nullptr))
     return launch_tri<double,4,false,Fma64,8,8>(src,dst,vertical,params,plain,nullptr);
   return launch_one<double,4,false,Fma64,8>(src,dst,vertical,params,plain,nullptr);
 }
@@ -1767,7 +1767,7 @@ MhStatus launch_conv1d_sums(const View &src,const View &dst,bool vertical,const 
 {
   *handled=false;
   if ((params.ntaps < 2) || (params.origin < 0) || (params.origin >= params.ntaps) ||
-      (getenv("MAGICKHIP_NO_MFMA") != nullptr))
+      (option("MAGICKHIP_NO_MFMA") != nullptr))
     return MH_OK;
   const int K=params.ntaps;
   std::vector<float> host((size_t) K);
@@ -1784,8 +1784,8 @@ MhStatus launch_conv1d_unsharp(const View &rows,const View &dst,const View &orig
 {
   *handled=false;
   if ((params.ntaps < 2) || (params.origin < 0) || (params.origin >= params.ntaps) ||
-      (params.bias != 0.0) || (getenv("MAGICKHIP_NO_MFMA") != nullptr) ||
-      (getenv("MAGICKHIP_NO_FUSED_UNSHARP") != nullptr))
+      (params.bias != 0.0) || (option("MAGICKHIP_NO_MFMA") != nullptr) ||
+      (option("MAGICKHIP_NO_FUSED_UNSHARP") != nullptr))
     return MH_OK;
   const int K=params.ntaps;
   std::vector<float> host((size_t) K);
@@ -1841,7 +1841,7 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
           // convolve_mfma.hip
           if ((roles.blend ? (src.channels == 4) && (roles.alpha == 3) :
                (src.channels == 3) || (src.channels == 4)) && (roles.copy_mask == 0) &&
-              (params.bias == 0.0) && (changed == nullptr) && (getenv("MAGICKHIP_NO_MFMA") == nullptr))
+              (params.bias == 0.0) && (changed == nullptr) && (option("MAGICKHIP_NO_MFMA") == nullptr))
             {
               const int K=params.ntaps;
               // one table: K doubles (the exact recomputation of ambiguous small alpha levels),
@@ -1866,7 +1866,7 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
           // long kernels: the triangular kernels with 32 outputs per lane; short ones: blocked
           // K >= R+1: the ramp-free triangular kernels (measured +7.5 % at K=79 on MI355X;
           // R=24/32 variants were slower: 240 VGPRs leave two waves per SIMD)
-          if ((params.ntaps >= 24) && (getenv("MAGICKHIP_NO_TRI") == nullptr))
+          if ((params.ntaps >= 24) && (option("MAGICKHIP_NO_TRI") == nullptr))
             MH_TRY((dispatch_tri<Fast32,16,4>(src,dst,vertical,params,roles,changed)));
           else
             MH_TRY((dispatch_blocked<Fast32,16,4>(src,dst,vertical,params,roles,changed)));
@@ -1876,7 +1876,7 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
             MH_TRY(launch_row_alpha_audit(src,dst,params));
           return MH_OK;
         }
-      if ((params.ntaps >= 16) && (getenv("MAGICKHIP_NO_TRI") == nullptr))
+      if ((params.ntaps >= 16) && (option("MAGICKHIP_NO_TRI") == nullptr))
         {
           // fused sums + reference-order recomputation of the results they cannot decide: the
           // same bits at less than half the fp64 work (device_common.hpp, Tie64).  Positive taps
@@ -1885,7 +1885,7 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
           bool positive=true;
           for (int v=0; v < params.ntaps; v++)
             positive=positive && (params.taps[v] >= 0.0);
-          if (positive && (params.bias == 0.0) && (changed == nullptr) && (getenv("MAGICKHIP_NO_TIE64") == nullptr))
+          if (positive && (params.bias == 0.0) && (changed == nullptr) && (option("MAGICKHIP_NO_TIE64") == nullptr))
             return dispatch_tri<Tie64,8,8>(src,dst,vertical,params,roles,changed);
           return dispatch_tri<Exact64,8,8>(src,dst,vertical,params,roles,changed);
         }
@@ -1896,7 +1896,7 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
   // fused sums with the float-rounding tie check of Accum::finish(): the same bits as the
   // reference's order at 4 fused multiply-adds per tap instead of 11 separately rounded operations.
   if ((params.ntaps >= 16) && (params.bias == 0.0) && (changed == nullptr) &&
-      (getenv("MAGICKHIP_NO_TRI") == nullptr) && (getenv("MAGICKHIP_NO_TIE64") == nullptr))
+      (option("MAGICKHIP_NO_TRI") == nullptr) && (option("MAGICKHIP_NO_TIE64") == nullptr))
     {
       bool positive=true;
       double total=0.0;

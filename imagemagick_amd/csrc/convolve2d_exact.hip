@@ -720,7 +720,7 @@ MhStatus launch_conv2d_exact(const View &src,const View &dst,const MhKernelInfo 
   const int windows=kw+17;
   // plain layouts: 64-row steps (a wave does both column tiles) when the taller ring fits the LDS
   // (two chunks only: with three, the operands of two tiles do not fit beside the prefetched rows)
-  int step_rows=(blend || (nc != 2) || (getenv("MAGICKHIP_CONV2D_ROWS32") != nullptr)) ? 32 : 64;
+  int step_rows=(blend || (nc != 2) || (option("MAGICKHIP_CONV2D_ROWS32") != nullptr)) ? 32 : 64;
   int window_rows=0,ring_rows=0,plane_bytes=0;
   size_t lds=0;
   for (;;)
@@ -809,7 +809,7 @@ MhStatus launch_conv2d_exact(const View &src,const View &dst,const MhKernelInfo 
             best=cuts;
           }
       }
-    if (const char *e=getenv("MAGICKHIP_CONV2D_CUTS"))          // tests: long walks on small frames
+    if (const char *e=option("MAGICKHIP_CONV2D_CUTS"))          // tests: long walks on small frames
       best=(atoi(e) >= 1) && (atoi(e) <= args.groups) ? atoi(e) : best;
     args.steps_per_segment=(args.groups+best-1)/best;
     args.segments=(args.groups+args.steps_per_segment-1)/args.steps_per_segment;

@@ -425,7 +425,7 @@ MhStatus launch_conv2d_mfma(const View &src,const View &dst,const MhKernelInfo *
             best=cuts;
           }
       }
-    if (const char *e=getenv("MAGICKHIP_CONV2D_CUTS"))          // tests: long walks on small frames
+    if (const char *e=option("MAGICKHIP_CONV2D_CUTS"))          // tests: long walks on small frames
       best=(atoi(e) >= 1) && (atoi(e) <= args.groups) ? atoi(e) : best;
     args.steps_per_segment=(args.groups+best-1)/best;
     args.segments=(args.groups+args.steps_per_segment-1)/args.steps_per_segment;

@@ -253,11 +253,15 @@ MhStatus launch_conv2d_tie(const View &src,const View &dst,const MhKernelInfo *k
   const int kw=(int) kernel->width,kh=(int) kernel->height;
   if ((src.channels < 1) || (src.channels > 4) || (roles.copy_mask != 0) || (src.quantum != dst.quantum) ||
       (src.channels != dst.channels) || (src.columns != dst.columns) || (src.rows != dst.rows) ||
-      (src.pixels == dst.pixels) || (kw < 1) || (kh < 1) || (kw*kh < 25) || (kernel->x < 0) || (kernel->y < 0) ||
+      (src.pixels == dst.pixels) || (kw < 2) || (kh < 1) || (kw*kh < 25) ||     // kw == 1: see below (kernel->x < 0) || (kernel->y < 0) ||
       (kernel->x >= kw) || (kernel->y >= kh) || (src.columns >= (1u << 30)) ||
       ((src.rows+kTieH-1)/kTieH > 65535u) ||                 // (gridDim.y)
-      (getenv("MAGICKHIP_NO_TIE_2D") != nullptr))
+      (option("MAGICKHIP_NO_TIE_2D") != nullptr))
     return MH_OK;
+  // (a one-column kernel is the reference's width == 1 fast path, morphology.c:2654-2807, which
+  // scales gamma by height / count when NaN cells leave fewer than `height` terms — :2775-2776.
+  // NaN-free columns run in launch_conv1d; columns WITH NaN cells keep the generic kernel, which
+  // applies that factor.)
   // (alpha-weighted: gray + alpha and RGBA; other layouts with an alpha trait keep the generic kernel)
   const bool blend=roles.blend && (roles.alpha == src.channels-1) && ((src.channels == 2) || (src.channels == 4));
   if (roles.blend && !blend)

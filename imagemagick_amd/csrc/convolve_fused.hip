@@ -497,7 +497,7 @@ static MhStatus launch_fused16_typed(const View &src,BlurFusedArgs &args)
   const int max_segments=args.blocks/16 > 1 ? args.blocks/16 : 1;
   int segments=(cus+args.strips-1)/args.strips;
   segments=segments < 1 ? 1 : (segments > max_segments ? max_segments : segments);
-  if (const char *e=getenv("MAGICKHIP_FUSED_SEGMENTS"))
+  if (const char *e=option("MAGICKHIP_FUSED_SEGMENTS"))
     segments=atoi(e) < 1 ? 1 : (atoi(e) > args.blocks ? args.blocks : atoi(e));
   args.blocks_per_segment=(args.blocks+segments-1)/segments;
   args.segments=(args.blocks+args.blocks_per_segment-1)/args.blocks_per_segment;   // no empty segment
@@ -507,7 +507,7 @@ static MhStatus launch_fused16_typed(const View &src,BlurFusedArgs &args)
   MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&blur_fused16_kernel<NC,MODE,UNSHARP>),
     hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
 #ifdef MH_FUSED_TRACE
-  const char *trace_path=getenv("MAGICKHIP_FUSED_TRACE");
+  const char *trace_path=option("MAGICKHIP_FUSED_TRACE");
   const size_t trace_bytes=4u*4u*48u*10u*sizeof(unsigned long long);
   if (trace_path != nullptr)
     {

@@ -1197,7 +1197,7 @@ static MhStatus launch_exact_typed(const View &src,BlurExactArgs &args)
   const int max_segments=args.blocks/16 > 1 ? args.blocks/16 : 1;
   int segments=(cus+args.strips-1)/args.strips;
   segments=segments < 1 ? 1 : (segments > max_segments ? max_segments : segments);
-  static const int forced_segments=getenv("MAGICKHIP_FUSED_SEGMENTS") != nullptr ? atoi(getenv("MAGICKHIP_FUSED_SEGMENTS")) : 0;
+  const int forced_segments=(int) option_long("MAGICKHIP_FUSED_SEGMENTS",0);
   if (forced_segments > 0)
     segments=forced_segments > args.blocks ? args.blocks : forced_segments;
   args.blocks_per_segment=(args.blocks+segments-1)/segments;
@@ -1215,7 +1215,7 @@ static MhStatus launch_exact_typed(const View &src,BlurExactArgs &args)
       attribute_set[slot]=true;
     }
 #ifdef MH_EXACT_TRACE
-  const char *trace_path=getenv("MAGICKHIP_EXACT_TRACE");
+  const char *trace_path=option("MAGICKHIP_EXACT_TRACE");
   const size_t trace_bytes=4u*4u*48u*12u*sizeof(unsigned long long);
   if (trace_path != nullptr)
     {

@@ -603,7 +603,7 @@ static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
   // 0.515 / 0.559 ms (3 / 4 per CU, sigma 4) and 0.538 / 0.543 ms (sigma 10) — the passes run
   // against the power limit, more waves in flight only lower the clock
   int per_cu=resident > 3 ? 3 : resident;
-  if (const char *e=getenv("MAGICKHIP_MFMA_PER_CU"))
+  if (const char *e=option("MAGICKHIP_MFMA_PER_CU"))
     per_cu=atoi(e) < 1 ? 1 : (atoi(e) < per_cu ? atoi(e) : per_cu);
   const int nblocks=compute_units(src.device)*per_cu;
   // Cut the strips into segments so that the work items divide evenly among the resident
@@ -627,7 +627,7 @@ static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
   args.steps_per_segment=(args.steps+segments-1)/segments;
 #ifdef MH_MFMA_TRACE
   args.trace=nullptr;
-  const char *trace_path=getenv("MAGICKHIP_MFMA_TRACE");
+  const char *trace_path=option("MAGICKHIP_MFMA_TRACE");
   const size_t trace_bytes=8u*48u*8u*sizeof(unsigned long long);
   if (trace_path != nullptr)
     {

@@ -203,9 +203,12 @@ MhStatus launch_separable_exact(const View &src,const View &dst,const MhKernelIn
 {
   *handled=false;
   const int kw=(int) kernel->width,kh=(int) kernel->height;
+  // (the finish kernel re-reads src in the reference's order for undecided samples while other
+  // workgroups store to dst: the two must be different buffers of one layout)
   if ((src.channels < 1) || (src.channels > 4) || (roles.copy_mask != 0) ||
+      (src.pixels == dst.pixels) || (src.quantum != dst.quantum) || (src.channels != dst.channels) ||
       (src.columns != dst.columns) || (src.rows != dst.rows) || (kw > 255) || (kh > 255) ||
-      (getenv("MAGICKHIP_NO_SEPARABLE_EXACT") != nullptr))
+      (option("MAGICKHIP_NO_SEPARABLE_EXACT") != nullptr))
     return MH_OK;
   // (alpha-weighted: gray + alpha and RGBA; other layouts with an alpha trait keep the generic kernel)
   const bool blend=roles.blend && (roles.alpha == src.channels-1) && ((src.channels == 2) || (src.channels == 4));

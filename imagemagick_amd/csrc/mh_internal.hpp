@@ -38,7 +38,15 @@ int default_device();
 int device_count();
 int compute_units(int device);          // cached multiProcessorCount
 bool host_block_is_pinned(const void *block,size_t bytes);   // inside a block of MhHostAlloc's
+int logical_device_count();               // device_count(), or MAGICKHIP_LOGICAL_DEVICES when larger
+// the precision of the operator call this thread is in (MhImage::precision of the image the entry
+// point was gated with), else the library default
 MhPrecision precision();
+void set_call_precision(const MhImage *image);
+// MAGICKHIP_* / MAGICK_HIP_* switches: the environment as it was when the runtime initialised,
+// plus what MhSetOption changed since.  NULL = unset.  Never reads the environment again.
+const char *option(const char *name);
+long option_long(const char *name,long fallback);
 hipStream_t library_stream(int device);   // non-blocking stream owned by the library
 
 // stream-tagged caching device allocator (workspace / staging)
@@ -193,6 +201,7 @@ struct ProfileScope
   ProfileScope(const char *name,hipStream_t stream);
   ~ProfileScope();
   const char *name; hipStream_t stream; hipEvent_t start=nullptr,stop=nullptr; bool on=false;
+  int device=0;
 };
 
 // ------------------------------------------------------------ launchers

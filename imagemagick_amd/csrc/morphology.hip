@@ -1413,8 +1413,8 @@ static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std:
   const bool is_float=src.quantum != MH_QUANTUM_U16;
   const bool layout=is_float ? ((src.channels == 1) || (src.channels == 2) || (src.channels == 4)) :
     ((src.channels == 2) || (src.channels == 4));
-  if (!layout || ((span & 1) == 0) || (getenv("MAGICKHIP_NO_RECTS") != nullptr) ||
-      (is_float && (getenv("MAGICKHIP_NO_FLOAT_RECTS") != nullptr)))
+  if (!layout || ((span & 1) == 0) || (option("MAGICKHIP_NO_RECTS") != nullptr) ||
+      (is_float && (option("MAGICKHIP_NO_FLOAT_RECTS") != nullptr)))
     return MH_OK;
   const int vmax=span/2;
   for (int d=0; d <= vmax; d++)
@@ -1431,7 +1431,7 @@ static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std:
   const int wave_columns=64*lane_columns;
   const size_t row_lds=(size_t) wave_columns*pixel_bytes;
   int shape=1;
-  if (const char *e=getenv("MAGICKHIP_RECTS_SHAPE"))
+  if (const char *e=option("MAGICKHIP_RECTS_SHAPE"))
     shape=(atoi(e) >= 0) && (atoi(e) <= 3) ? atoi(e) : 0;
   if (is_float)
     shape=1;
@@ -1476,7 +1476,7 @@ static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std:
     const int strip_w=256-2*hmax;
     if (!is_float && ((unsigned long long) src.columns*src.rows*pixel_bytes < (1ull << 32)) &&
         (strip_lds <= 160u*1024u) && ((int) src.columns >= 2*strip_w) &&
-        ((int) src.rows >= 4*kStripRows) && (getenv("MAGICKHIP_STRIPS") != nullptr))
+        ((int) src.rows >= 4*kStripRows) && (option("MAGICKHIP_STRIPS") != nullptr))
       {
         StripsArgs sa;
         sa.r=a;
@@ -1497,7 +1497,7 @@ static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std:
                 best=cuts;
               }
           }
-        if (const char *e=getenv("MAGICKHIP_STRIP_CUTS"))         // tests: walks of several steps on small frames
+        if (const char *e=option("MAGICKHIP_STRIP_CUTS"))         // tests: walks of several steps on small frames
           best=(atoi(e) >= 1) && (atoi(e) <= sa.r.tiles_y) ? atoi(e) : best;
         sa.steps_per_segment=(sa.r.tiles_y+best-1)/best;
         sa.segments=(sa.r.tiles_y+sa.steps_per_segment-1)/sa.steps_per_segment;
@@ -1734,7 +1734,7 @@ MhStatus launch_morph2d(const View &src,const View &dst,const Morph2DParams &par
         c.value=value;
         cells.push_back(c);
       }
-  if (((mc == MC_ERODE) || (mc == MC_DILATE)) && (getenv("MAGICKHIP_NO_CONVEX") == nullptr))
+  if (((mc == MC_ERODE) || (mc == MC_DILATE)) && (option("MAGICKHIP_NO_CONVEX") == nullptr))
     {
       bool handled=false;
       MH_TRY(try_convex(src,dst,mc == MC_DILATE,cells,roles,changed,&handled));

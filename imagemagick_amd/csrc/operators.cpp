@@ -21,6 +21,7 @@ static MhStatus gate(const MhImage *image,const char *what)
 {
   MH_TRY(runtime_ready());
   MH_TRY(validate_image(image,what));
+  set_call_precision(image);       // MhImage::precision of this call, else the library default
   return MH_OK;
 }
 
@@ -202,7 +203,7 @@ static MhStatus separable_convolve(const View &src,const View &dst,const MhKerne
   *handled=false;
   if ((precision() != MH_PRECISION_FAST) || (src.quantum != MH_QUANTUM_U16) ||
       (kernel->width < 2) || (kernel->height < 2) || (roles.copy_mask != 0) ||
-      (src.channels < 1) || (src.channels > 4) || (getenv("MAGICKHIP_NO_SEPARABLE") != nullptr))
+      (src.channels < 1) || (src.channels > 4) || (option("MAGICKHIP_NO_SEPARABLE") != nullptr))
     return MH_OK;
   const bool blend=roles.blend && (roles.alpha == src.channels-1) &&
     ((src.channels == 2) || (src.channels == 4));
@@ -333,8 +334,8 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
   if ((method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
       (src.quantum == MH_QUANTUM_F32) && ((src.channels == 4) || ((src.channels == 3) && !roles.blend)) &&
       (roles.copy_mask == 0) && (!roles.blend || (roles.alpha == 3)) &&
-      (getenv("MAGICKHIP_NO_MFMA") == nullptr) && (getenv("MAGICKHIP_NO_MFMA_2D") == nullptr) &&
-      (getenv("MAGICKHIP_NO_EXACT_2D") == nullptr) && (getenv("MAGICKHIP_NO_EXACT_2D_FLOAT") == nullptr))
+      (option("MAGICKHIP_NO_MFMA") == nullptr) && (option("MAGICKHIP_NO_MFMA_2D") == nullptr) &&
+      (option("MAGICKHIP_NO_EXACT_2D") == nullptr) && (option("MAGICKHIP_NO_EXACT_2D_FLOAT") == nullptr))
     {
       // (outer products — boxes — have the separable path below, which takes any float frame)
       std::vector<double> row,column;
@@ -362,7 +363,7 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
   const bool matrix_2d=(method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
     (src.quantum == MH_QUANTUM_U16) && ((src.channels == 4) || ((src.channels == 3) && !roles.blend)) &&
     (roles.copy_mask == 0) && (!roles.blend || (roles.alpha == 3)) &&
-    (getenv("MAGICKHIP_NO_MFMA") == nullptr) && (getenv("MAGICKHIP_NO_MFMA_2D") == nullptr);
+    (option("MAGICKHIP_NO_MFMA") == nullptr) && (option("MAGICKHIP_NO_MFMA_2D") == nullptr);
   // (FAST, narrow kernels: the f16 kernel's band is one 32-slot chunk up to 17 cells where the
   // integer one always multiplies two, on four byte planes of alpha-weighted samples — Octagon:8 on
   // 16384^2 RGBA 3.0 against 4.0 ms; with the two planes of plain samples the integer kernel is the
@@ -376,7 +377,7 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
       if (handled)
         return MH_OK;
     }
-  if (matrix_2d && (getenv("MAGICKHIP_NO_EXACT_2D") == nullptr))
+  if (matrix_2d && (option("MAGICKHIP_NO_EXACT_2D") == nullptr))
     {
       bool handled=false;
       MH_TRY(launch_conv2d_exact(src,dst,kernel,roles.blend,&handled));
@@ -387,7 +388,7 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
   // a tie check, bit-identical to the w x h walk (convolve_separable.hip)
   if ((method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
       !kernel_has_nan(kernel) && (kernel->width >= 2) && (kernel->height >= 2) &&
-      (kernel->width*kernel->height >= 25) && (getenv("MAGICKHIP_NO_SEPARABLE") == nullptr))
+      (kernel->width*kernel->height >= 25) && (option("MAGICKHIP_NO_SEPARABLE") == nullptr))
     {
       std::vector<double> row,column;
       double delta=0.0;
@@ -494,11 +495,11 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
   const Roles &roles,double bias,bool *handled,bool unsharp=false,double gain=0.0,double threshold=0.0)
 {
   *handled=false;
-  // (switches for tests and A/B runs; four getenv calls cost well under a microsecond)
-  const bool no_mfma=getenv("MAGICKHIP_NO_MFMA") != nullptr;
-  const bool no_fused=getenv("MAGICKHIP_NO_FUSED_BLUR") != nullptr;
-  const bool no_exact_mfma=getenv("MAGICKHIP_NO_EXACT_MFMA") != nullptr;
-  const bool fused_rgb=getenv("MAGICKHIP_FUSED_RGB") != nullptr;
+  // (switches for tests and A/B runs, from the option table: the environment at start-up + MhSetOption)
+  const bool no_mfma=option("MAGICKHIP_NO_MFMA") != nullptr;
+  const bool no_fused=option("MAGICKHIP_NO_FUSED_BLUR") != nullptr;
+  const bool no_exact_mfma=option("MAGICKHIP_NO_EXACT_MFMA") != nullptr;
+  const bool fused_rgb=option("MAGICKHIP_FUSED_RGB") != nullptr;
   const bool exact=precision() == MH_PRECISION_EXACT;
   if ((src.quantum != MH_QUANTUM_U16) || ((src.channels != 4) && (src.channels != 3)) ||
       (roles.copy_mask != 0) || (bias != 0.0) || no_mfma || no_fused || (exact && no_exact_mfma))
@@ -1059,8 +1060,8 @@ static MhStatus unsharp_fused(const View &src,const View &dst,const MhKernelInfo
   const MhKernelInfo *horizontal=kernels,*vertical=kernels != nullptr ? kernels->next : nullptr;
   if ((src.quantum != MH_QUANTUM_U16) ||
       ((src.channels != 4) && (src.channels != 3)) ||
-      (src.columns < 2) || (getenv("MAGICKHIP_NO_FUSED_UNSHARP") != nullptr) ||
-      (getenv("MAGICKHIP_NO_MFMA") != nullptr) ||
+      (src.columns < 2) || (option("MAGICKHIP_NO_FUSED_UNSHARP") != nullptr) ||
+      (option("MAGICKHIP_NO_MFMA") != nullptr) ||
       (roles.copy_mask != 0) || (horizontal == nullptr) || (vertical == nullptr) ||
       (vertical->next != nullptr) || (horizontal->height != 1) || (vertical->width != 1) ||
       kernel_has_nan(horizontal) || kernel_has_nan(vertical))

@@ -56,6 +56,7 @@ static MhStatus check_image(const MhImage *image,const char *what)
 {
   MH_TRY(runtime_ready());
   MH_TRY(validate_image(image,what));
+  set_call_precision(image);       // MhImage::precision of this call, else the library default
   return MH_OK;
 }
 
@@ -138,7 +139,7 @@ static MhStatus apply_lut_host(const View &view,const MhImage *desc,const double
 MhStatus apply_histogram_lut(const View &view,const MhImage *image,const unsigned long long *hist,
   int mode,bool equalize,double black_point,double white_limit,const unsigned int *colour_flag)
 {
-  if (!equalize && (view.channels <= 4) && (getenv("MAGICKHIP_NO_STRETCH_LEVELS") == nullptr))
+  if (!equalize && (view.channels <= 4) && (option("MAGICKHIP_NO_STRETCH_LEVELS") == nullptr))
     {
       // ContrastStretchImage: the levels of every channel, then the map evaluated per sample — no
       // table to build and gather from (pointwise.hip)

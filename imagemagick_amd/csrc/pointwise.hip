@@ -572,7 +572,7 @@ static MhStatus apply_q16_column(const View &img,const uint16_t *column,uint32_t
 static MhStatus colorspace_step(const View &img,int op)
 {
   if ((op == OP_SRGB_TO_LAB) && (img.quantum == MH_QUANTUM_U16) && (img.channels == 4) &&
-      (precision() == MH_PRECISION_FAST) && (getenv("MAGICKHIP_NO_FAST_LAB") == nullptr) &&
+      (precision() == MH_PRECISION_FAST) && (option("MAGICKHIP_NO_FAST_LAB") == nullptr) &&
       ((reinterpret_cast<uintptr_t>(img.pixels) & 15u) == 0))
     {
       const size_t n=img.columns*img.rows,npairs=n/2;
@@ -592,7 +592,7 @@ static MhStatus colorspace_step(const View &img,int op)
       MH_HIP(hipGetLastError());
       return MH_OK;
     }
-  if ((img.quantum == MH_QUANTUM_U16) && (getenv("MAGICKHIP_NO_COLOR_TABLES") == nullptr) &&
+  if ((img.quantum == MH_QUANTUM_U16) && (option("MAGICKHIP_NO_COLOR_TABLES") == nullptr) &&
       ((op == OP_SRGB_TO_RGB) || (op == OP_RGB_TO_SRGB) || (op == OP_SRGB_TO_LAB) ||
        (op == OP_SRGB_TO_XYZ)))
     {
@@ -1494,8 +1494,8 @@ MhStatus launch_lab_fast_with_histogram(const View &img,const MhImage *lab_desc,
   if ((img.quantum != MH_QUANTUM_U16) || (img.channels != 4) || (precision() != MH_PRECISION_FAST) ||
       (n < ((size_t) 1 << 20)) || (n >= ((size_t) 1 << 31)) ||
       ((reinterpret_cast<uintptr_t>(img.pixels) & 15u) != 0) ||
-      (getenv("MAGICKHIP_NO_FAST_LAB") != nullptr) || (getenv("MAGICKHIP_NO_PACKED_HISTOGRAM") != nullptr) ||
-      (getenv("MAGICKHIP_NO_LDS_HISTOGRAM") != nullptr) || (getenv("MAGICKHIP_NO_FUSED_LAB_HISTOGRAM") != nullptr))
+      (option("MAGICKHIP_NO_FAST_LAB") != nullptr) || (option("MAGICKHIP_NO_PACKED_HISTOGRAM") != nullptr) ||
+      (option("MAGICKHIP_NO_LDS_HISTOGRAM") != nullptr) || (option("MAGICKHIP_NO_FUSED_LAB_HISTOGRAM") != nullptr))
     return MH_OK;
   const size_t nblocks=packed_histogram_blocks(img.device,n);
   if (nblocks == 0)
@@ -1537,9 +1537,9 @@ MhStatus launch_lab_fast_contrast_stretch(const View &img,const MhImage *lab_des
   if ((img.quantum != MH_QUANTUM_U16) || (img.channels != 4) || (precision() != MH_PRECISION_FAST) ||
       (n < ((size_t) 1 << 20)) || (n >= ((size_t) 1 << 31)) ||
       ((reinterpret_cast<uintptr_t>(img.pixels) & 15u) != 0) ||
-      (getenv("MAGICKHIP_NO_FAST_LAB") != nullptr) || (getenv("MAGICKHIP_NO_PACKED_HISTOGRAM") != nullptr) ||
-      (getenv("MAGICKHIP_NO_LDS_HISTOGRAM") != nullptr) || (getenv("MAGICKHIP_NO_FUSED_LAB_HISTOGRAM") != nullptr) ||
-      (getenv("MAGICKHIP_NO_STRETCH_LEVELS") != nullptr))
+      (option("MAGICKHIP_NO_FAST_LAB") != nullptr) || (option("MAGICKHIP_NO_PACKED_HISTOGRAM") != nullptr) ||
+      (option("MAGICKHIP_NO_LDS_HISTOGRAM") != nullptr) || (option("MAGICKHIP_NO_FUSED_LAB_HISTOGRAM") != nullptr) ||
+      (option("MAGICKHIP_NO_STRETCH_LEVELS") != nullptr))
     return MH_OK;
   const size_t nblocks=packed_histogram_blocks(img.device,n);
   if (nblocks == 0)
@@ -1601,11 +1601,11 @@ static MhStatus histogram_typed(const View &src,int mode,const IntensityParams &
   const size_t n=src.columns*src.rows;
   // large frames in intensity mode: the LDS-privatised kernel (a frame below ~1 Mpixel
   // does not amortise the 2 x 256 x 128 KB slab traffic)
-  if ((mode != 0) && (n >= ((size_t) 1 << 20)) && (getenv("MAGICKHIP_NO_LDS_HISTOGRAM") == nullptr))
+  if ((mode != 0) && (n >= ((size_t) 1 << 20)) && (option("MAGICKHIP_NO_LDS_HISTOGRAM") == nullptr))
     {
       // one pass with 16-bit counters, Q16 and float Quantum alike (the bin of a float sample is
       // ScaleQuantumToMap's)
-      if ((getenv("MAGICKHIP_NO_PACKED_HISTOGRAM") == nullptr) && (n < ((size_t) 1 << 31)))
+      if ((option("MAGICKHIP_NO_PACKED_HISTOGRAM") == nullptr) && (n < ((size_t) 1 << 31)))
         return histogram_intensity_packed<Q,C>(src,ip,hist);
       return histogram_intensity_lds<Q,C>(src,ip,hist);
     }

@@ -1026,7 +1026,7 @@ static MhStatus launch_fused_stage_typed(const View &src,const View &dst,const T
   const size_t head=2u*8u*kFusedRows*sizeof(T)+(size_t) (3*kFusedRows+4)*sizeof(int);
   // four workgroups per CU (as the horizontal kernel): 40 KB each, tables included
   int tile_rows=(int) ((40u*1024u-head)/((size_t) lds_span*cpx));
-  if (const char *e=getenv("MAGICKHIP_FUSED_TILE_ROWS"))
+  if (const char *e=option("MAGICKHIP_FUSED_TILE_ROWS"))
     tile_rows=atoi(e);
   tile_rows=tile_rows > kFusedRows ? kFusedRows : tile_rows;
   if (tile_rows < 4)
@@ -1139,7 +1139,7 @@ MhStatus launch_resize_fused(const View &src,const View &dst,const TapTable &ver
   // passes together (stage form 6.04 ms against 4.62 + 1.35; the first form 8.6 ms) — the passes
   // are bound by fp64 issue and LDS reads, not by the 8.6 GB of intermediate traffic a fused
   // kernel saves.  MAGICKHIP_FUSED_RESIZE=stage | 1 selects them.
-  const char *choice=getenv("MAGICKHIP_FUSED_RESIZE");
+  const char *choice=option("MAGICKHIP_FUSED_RESIZE");
   if (choice == nullptr)
     return MH_OK;
   if (strcmp(choice,"stage") == 0)
@@ -1447,7 +1447,7 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
             {
               int tile_rows=(int) (budget/((size_t) lds_span*cpx));
               int cap=16;
-              if (const char *e=getenv("MAGICKHIP_HTILE"))
+              if (const char *e=option("MAGICKHIP_HTILE"))
                 cap=atoi(e);
               tile_rows=tile_rows < 1 ? 1 : (tile_rows > cap ? cap : tile_rows);
               size_t lds=(size_t) lds_span*cpx*(size_t) tile_rows;
@@ -1455,7 +1455,7 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
               ProfileScope prof("resize_horizontal",src.stream);
               constexpr bool kCanPremultiply=ResizeAcc<Q,C,BLEND,A>::kDerive;
               const bool premultiply=kCanPremultiply && (args.copy_mask == 0) &&
-                (getenv("MAGICKHIP_NO_RESIZE_PREMULTIPLY") == nullptr);
+                (option("MAGICKHIP_NO_RESIZE_PREMULTIPLY") == nullptr);
 #define MH_LAUNCH_H(N)                                                                        \
               {                                                                                \
                 if (premultiply)                                                               \

@@ -11,9 +11,13 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <strings.h>
 #include <thread>
+#include <unistd.h>
+
+extern char **environ;
 
 namespace mh {
 
@@ -66,11 +70,14 @@ struct Runtime
   std::mutex lock;
   // profiling
   int profiling=0;
-  struct Pending { const char *name; hipEvent_t start,stop; };
+  struct Pending { const char *name; int device; hipEvent_t start,stop; };
   std::vector<Pending> pending;
   struct Rec { unsigned long count=0; double min_ms=1e300,max_ms=0,total_ms=0; };
-  std::map<std::string,Rec> records;
-  std::vector<std::string> record_names;   // stable storage for returned names
+  std::map<std::pair<int,std::string>,Rec> records;     // (device, kernel)
+  std::map<std::string,const char *> record_names;       // stable storage for returned names
+  int logical_devices=0;
+  // streams handed out by MhStreamCreate (destroyed by MhStreamDestroy or MhTerminus)
+  std::vector<std::pair<int,hipStream_t>> caller_streams;
 };
 
 static Runtime &rt()
@@ -79,14 +86,74 @@ static Runtime &rt()
   return *r;
 }
 
+// ----------------------------------------------------------------- options
+// The environment is read ONCE, here: every MAGICKHIP_* / MAGICK_HIP_* variable goes into a
+// table that option() reads from then on (getenv racing a setenv is undefined, and a library
+// that re-reads the environment per call follows whatever the host process does to it).  Values
+// are interned and never freed, so a pointer option() returned stays valid.
+struct Options
+{
+  std::shared_mutex lock;
+  std::map<std::string,const char *> values;
+};
+static Options &options() { static Options &o=*new Options; return o; }
+
+static void load_options()
+{
+  Options &o=options();
+  std::unique_lock<std::shared_mutex> guard(o.lock);
+  for (char **e=environ; (e != nullptr) && (*e != nullptr); e++)
+    {
+      if ((strncmp(*e,"MAGICKHIP_",10) != 0) && (strncmp(*e,"MAGICK_HIP_",11) != 0))
+        continue;
+      const char *eq=strchr(*e,'=');
+      if (eq == nullptr)
+        continue;
+      o.values[std::string(*e,(size_t) (eq-*e))]=strdup(eq+1);
+    }
+}
+
+static const char *lookup_option(const char *name)
+{
+  Options &o=options();
+  std::shared_lock<std::shared_mutex> guard(o.lock);
+  auto it=o.values.find(name);
+  return it == o.values.end() ? nullptr : it->second;
+}
+
+static void do_init();
+
+const char *option(const char *name)
+{
+  std::call_once(rt().once,do_init);
+  return lookup_option(name);
+}
+
+long option_long(const char *name,long fallback)
+{
+  const char *value=option(name);
+  return value != nullptr ? atol(value) : fallback;
+}
+
+// the precision of the operator call this thread is in: MhImage::precision of the image the
+// entry point was gated with, -1 = the library default
+static thread_local int t_call_precision=-1;
+
+void set_call_precision(const MhImage *image)
+{
+  t_call_precision=((image != nullptr) && (image->precision != 0)) ?
+    (image->precision == MH_IMAGE_PRECISION(MH_PRECISION_FAST) ? (int) MH_PRECISION_FAST : (int) MH_PRECISION_EXACT) : -1;
+}
+
 static void do_init()
 {
   Runtime &r=rt();
-  const char *env=getenv("MAGICK_HIP_DEVICE");
+  load_options();
+  const char *env=lookup_option("MAGICK_HIP_DEVICE");
   if ((env != nullptr) && ((strcasecmp(env,"off") == 0) ||
       (strcasecmp(env,"false") == 0) || (strcasecmp(env,"cpu") == 0)))
     r.enabled=0;
-  env=getenv("MAGICK_HIP_PRECISION");
+  env=lookup_option("MAGICK_HIP_PRECISION");
   if ((env != nullptr) && (strcasecmp(env,"fast") == 0))
     r.precision=MH_PRECISION_FAST;
   int n=0;
@@ -102,13 +169,17 @@ static void do_init()
     }
   r.ndevices=n;
   r.devices.resize((size_t) n);
-  env=getenv("MAGICK_HIP_DEVICE");
+  env=lookup_option("MAGICK_HIP_DEVICE");
   if ((env != nullptr) && (env[0] >= '0') && (env[0] <= '9'))
     {
       int d=atoi(env);
       if (d < n)
         r.default_device=d;
     }
+  r.logical_devices=n;
+  env=lookup_option("MAGICKHIP_LOGICAL_DEVICES");
+  if ((env != nullptr) && (atoi(env) > n))
+    r.logical_devices=atoi(env) > 64 ? 64 : atoi(env);
   r.init_status=MH_OK;
 }
 
@@ -125,7 +196,11 @@ MhStatus runtime_ready()
 
 int default_device() { return rt().default_device; }
 int device_count() { Runtime &r=rt(); std::call_once(r.once,do_init); return r.ndevices; }
-MhPrecision precision() { return rt().precision; }
+int logical_device_count() { Runtime &r=rt(); std::call_once(r.once,do_init); return r.logical_devices; }
+MhPrecision precision()
+{
+  return t_call_precision >= 0 ? (MhPrecision) t_call_precision : rt().precision;
+}
 
 int compute_units(int device)
 {
@@ -524,7 +599,7 @@ MhStatus transfer_image(int device,hipStream_t stream,void *dev,void *host,size_
   size_t workers=std::thread::hardware_concurrency()/4;
   workers=workers > 4 ? 4 : (workers < 1 ? 1 : workers);      // 1/2/4/8/16 threads: 75/54/44/47/48 ms
   workers=workers > pieces ? pieces : workers;
-  if (const char *e=getenv("MAGICKHIP_TRANSFER_THREADS"))
+  if (const char *e=option("MAGICKHIP_TRANSFER_THREADS"))
     {
       const long n=atol(e);
       workers=n < 1 ? 1 : (n > 32 ? 32 : (size_t) n);
@@ -641,7 +716,7 @@ MhStatus Resident::open(const MhImage *image,int mode,hipStream_t stream_hint,in
   staged_=true;
   // MAGICKHIP_HOST_COPY=register: page-lock the pixel-cache block in place instead (cache.c:
   // 3754-3758 allocates it with AcquireAlignedMemory, so that is legal) — slower for one call
-  const char *how=getenv("MAGICKHIP_HOST_COPY");
+  const char *how=option("MAGICKHIP_HOST_COPY");
   if ((how != nullptr) && (strcasecmp(how,"register") == 0))
     {
       if (hipHostRegister(image->pixels,view.bytes(),hipHostRegisterDefault) == hipSuccess)
@@ -691,6 +766,8 @@ ProfileScope::ProfileScope(const char *n,hipStream_t s) : name(n), stream(s)
   if ((hipEventCreate(&start) != hipSuccess) || (hipEventCreate(&stop) != hipSuccess))
     return;
   on=true;
+  if (hipGetDevice(&device) != hipSuccess)
+    device=0;
   (void) hipEventRecord(start,stream);
 }
 
@@ -701,7 +778,7 @@ ProfileScope::~ProfileScope()
   (void) hipEventRecord(stop,stream);
   Runtime &r=rt();
   std::lock_guard<std::mutex> guard(r.lock);
-  r.pending.push_back({name,start,stop});
+  r.pending.push_back({name,device,start,stop});
 }
 
 static void drain_profile()
@@ -719,7 +796,7 @@ static void drain_profile()
           (hipEventElapsedTime(&ms,p.start,p.stop) == hipSuccess))
         {
           std::lock_guard<std::mutex> guard(r.lock);
-          Runtime::Rec &rec=r.records[p.name];
+          Runtime::Rec &rec=r.records[std::make_pair(p.device,std::string(p.name))];
           rec.count++;
           rec.total_ms+=ms;
           if (ms < rec.min_ms) rec.min_ms=ms;
@@ -783,6 +860,20 @@ MH_API void MhTerminus(void)
   staging_trim();
   release_color_tables();
   release_batch_streams();
+  std::vector<std::pair<int,hipStream_t>> streams;
+  {
+    std::lock_guard<std::mutex> guard(r.lock);
+    streams.swap(r.caller_streams);
+  }
+  for (auto &entry : streams)
+    {
+      DeviceGuard device;
+      if (device.enter(entry.first) == hipSuccess)
+        {
+          (void) hipStreamSynchronize(entry.second);
+          (void) hipStreamDestroy(entry.second);
+        }
+    }
 }
 
 MH_API int MhDeviceCount(void) { return device_count(); }
@@ -829,6 +920,106 @@ MH_API MhPrecision MhSetPrecision(MhPrecision p)
   return r.precision;
 }
 
+MH_API MhStatus MhSetOption(const char *name,const char *value)
+{
+  if ((name == nullptr) || ((strncmp(name,"MAGICKHIP_",10) != 0) && (strncmp(name,"MAGICK_HIP_",11) != 0)))
+    return fail(MH_BAD_ARGUMENT,"MhSetOption: option names begin with MAGICKHIP_ or MAGICK_HIP_");
+  Runtime &r=rt();
+  std::call_once(r.once,do_init);
+  Options &o=options();
+  std::unique_lock<std::shared_mutex> guard(o.lock);
+  if (value == nullptr)
+    o.values.erase(name);
+  else
+    o.values[name]=strdup(value);      // interned (a few bytes per change of a diagnostic switch)
+  return MH_OK;
+}
+
+MH_API const char *MhGetOption(const char *name)
+{
+  return name != nullptr ? option(name) : nullptr;
+}
+
+MH_API int MhLogicalDeviceCount(void) { return logical_device_count(); }
+
+MH_API MhStatus MhGetDeviceInfo(int device,MhDeviceInfo *info)
+{
+  MH_TRY(runtime_ready());
+  if ((info == nullptr) || (device < 0) || (device >= device_count()))
+    return fail(MH_BAD_ARGUMENT,"MhGetDeviceInfo: device %d out of range",device);
+  hipDeviceProp_t prop;
+  MH_HIP(hipGetDeviceProperties(&prop,device));
+  memset(info,0,sizeof(*info));
+  snprintf(info->name,sizeof(info->name),"%s",prop.name);
+  snprintf(info->architecture,sizeof(info->architecture),"%s",prop.gcnArchName);
+  info->compute_units=prop.multiProcessorCount;
+  info->clock_mhz=prop.clockRate/1000;
+  info->global_memory=prop.totalGlobalMem;
+  info->local_memory=prop.sharedMemPerBlock;
+  return MH_OK;
+}
+
+MH_API MhStatus MhStreamCreate(int device,void **stream)
+{
+  MH_TRY(runtime_ready());
+  if ((stream == nullptr) || (device < 0) || (device >= device_count()))
+    return fail(MH_BAD_ARGUMENT,"MhStreamCreate: device %d out of range",device);
+  DeviceGuard guard;
+  MH_HIP(guard.enter(device));
+  hipStream_t s=nullptr;
+  MH_HIP(hipStreamCreateWithFlags(&s,hipStreamNonBlocking));
+  Runtime &r=rt();
+  std::lock_guard<std::mutex> lock(r.lock);
+  r.caller_streams.emplace_back(device,s);
+  *stream=s;
+  return MH_OK;
+}
+
+MH_API MhStatus MhStreamDestroy(int device,void *stream)
+{
+  MH_TRY(runtime_ready());
+  Runtime &r=rt();
+  {
+    std::lock_guard<std::mutex> lock(r.lock);
+    bool known=false;
+    for (size_t i=0; i < r.caller_streams.size(); i++)
+      if (r.caller_streams[i].second == (hipStream_t) stream)
+        {
+          device=r.caller_streams[i].first;
+          r.caller_streams.erase(r.caller_streams.begin()+(ptrdiff_t) i);
+          known=true;
+          break;
+        }
+    if (!known)
+      return fail(MH_BAD_ARGUMENT,"MhStreamDestroy: not a stream of MhStreamCreate");
+  }
+  DeviceGuard guard;
+  MH_HIP(guard.enter(device));
+  MH_HIP(hipStreamSynchronize((hipStream_t) stream));
+  MH_HIP(hipStreamDestroy((hipStream_t) stream));
+  return MH_OK;
+}
+
+MH_API MhStatus MhDeviceAllocAsync(int device,size_t bytes,void *stream,void **ptr)
+{
+  MH_TRY(runtime_ready());
+  if (ptr == nullptr)
+    return fail(MH_BAD_ARGUMENT,"null ptr");
+  if (device < 0) device=default_device();
+  if (device >= device_count())
+    return fail(MH_BAD_ARGUMENT,"device %d out of range",device);
+  return pool_alloc(device,bytes,(hipStream_t) stream,ptr);
+}
+
+MH_API MhStatus MhDeviceFreeAsync(int device,void *ptr,void *stream)
+{
+  MH_TRY(runtime_ready());
+  if (device < 0) device=default_device();
+  if (device >= device_count())
+    return fail(MH_BAD_ARGUMENT,"device %d out of range",device);
+  pool_free(device,ptr,(hipStream_t) stream);
+  return MH_OK;
+}
 
 MH_API void *MhHostAlloc(size_t bytes)
 {
@@ -905,6 +1096,9 @@ MH_API MhStatus MhDeviceFree(int device,void *ptr)
 MH_API MhStatus MhUpload(int device,void *dst,const void *src,size_t bytes,void *stream)
 {
   MH_TRY(runtime_ready());
+  DeviceGuard guard;
+  if ((device >= 0) && (device < device_count()))
+    MH_HIP(guard.enter(device));
   if ((bytes >= 2*kPiece) && (device >= 0) && (device < device_count()) && !host_block_is_pinned(src,bytes))
     return transfer_image(device,(hipStream_t) stream,dst,const_cast<void *>(src),bytes,true);
   MH_HIP(hipMemcpyAsync(dst,src,bytes,hipMemcpyHostToDevice,(hipStream_t) stream));
@@ -914,6 +1108,9 @@ MH_API MhStatus MhUpload(int device,void *dst,const void *src,size_t bytes,void 
 MH_API MhStatus MhDownload(int device,void *dst,const void *src,size_t bytes,void *stream)
 {
   MH_TRY(runtime_ready());
+  DeviceGuard guard;
+  if ((device >= 0) && (device < device_count()))
+    MH_HIP(guard.enter(device));
   if ((bytes >= 2*kPiece) && (device >= 0) && (device < device_count()) && !host_block_is_pinned(dst,bytes))
     MH_TRY(transfer_image(device,(hipStream_t) stream,const_cast<void *>(src),dst,bytes,false));
   else
@@ -924,8 +1121,10 @@ MH_API MhStatus MhDownload(int device,void *dst,const void *src,size_t bytes,voi
 
 MH_API MhStatus MhSynchronize(int device,void *stream)
 {
-  (void) device;
   MH_TRY(runtime_ready());
+  DeviceGuard guard;
+  if ((device >= 0) && (device < device_count()))
+    MH_HIP(guard.enter(device));
   MH_HIP(hipStreamSynchronize((hipStream_t) stream));
   return MH_OK;
 }
@@ -938,20 +1137,32 @@ MH_API int MhSetProfileEnabled(int enabled)
   return r.profiling;
 }
 
-MH_API size_t MhGetProfileRecords(MhKernelProfileRecord *records,size_t capacity)
+static size_t profile_records(int device,MhKernelProfileRecord *records,size_t capacity)
 {
   Runtime &r=rt();
   drain_profile();
   std::lock_guard<std::mutex> guard(r.lock);
-  r.record_names.clear();
-  r.record_names.reserve(r.records.size());
-  size_t n=0;
+  // device < 0: every device, a kernel's records summed over the devices
+  std::map<std::string,Runtime::Rec> merged;
   for (auto &kv : r.records)
+    {
+      if ((device >= 0) && (kv.first.first != device))
+        continue;
+      Runtime::Rec &m=merged[kv.first.second];
+      m.count+=kv.second.count;
+      m.total_ms+=kv.second.total_ms;
+      if (kv.second.min_ms < m.min_ms) m.min_ms=kv.second.min_ms;
+      if (kv.second.max_ms > m.max_ms) m.max_ms=kv.second.max_ms;
+    }
+  size_t n=0;
+  for (auto &kv : merged)
     {
       if ((records != nullptr) && (n < capacity))
         {
-          r.record_names.push_back(kv.first);
-          records[n].kernel_name=r.record_names.back().c_str();
+          const char *&name=r.record_names[kv.first];
+          if (name == nullptr)
+            name=strdup(kv.first.c_str());       // interned: the pointer outlives the call
+          records[n].kernel_name=name;
           records[n].count=kv.second.count;
           records[n].min_ms=kv.second.min_ms;
           records[n].max_ms=kv.second.max_ms;
@@ -960,6 +1171,18 @@ MH_API size_t MhGetProfileRecords(MhKernelProfileRecord *records,size_t capacity
       n++;
     }
   return n;
+}
+
+MH_API size_t MhGetProfileRecords(MhKernelProfileRecord *records,size_t capacity)
+{
+  return profile_records(-1,records,capacity);
+}
+
+MH_API size_t MhGetDeviceProfileRecords(int device,MhKernelProfileRecord *records,size_t capacity)
+{
+  if ((device < 0) || (device >= device_count()))
+    return 0;
+  return profile_records(device,records,capacity);
 }
 
 MH_API void MhResetProfileRecords(void)

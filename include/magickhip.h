@@ -169,6 +169,8 @@ typedef struct MhImage
   uint32_t intensity;                       /* MhIntensityMethod; 0 = default (Rec709Luma) */
   uint32_t channel_mask;                    /* image->channel_mask (ChannelType bits); MH_ALL_CHANNELS by default */
   void *stream;                             /* hipStream_t to run on; NULL = library stream.  DEVICE images only */
+  uint32_t precision;                       /* 0 = the library default (MhSetPrecision); else MhPrecision + 1:
+                                               the precision of THIS call, whatever other threads run with */
 } MhImage;
 
 /* Fill the traits the way InitializePixelChannelMap does for an image with
@@ -194,8 +196,48 @@ typedef enum
   MH_PRECISION_EXACT = 0,  /* FP64, the CPU's operation order, no FMA contraction: bit-identical results */
   MH_PRECISION_FAST = 1    /* FP32 FMA accumulation where the result is still within +-1 Quantum level (Q16 only) */
 } MhPrecision;
+/* The library-wide DEFAULT (also MAGICK_HIP_PRECISION=fast at start-up).  A call whose first image
+   carries a non-zero MhImage::precision runs with that precision instead: two threads can run
+   EXACT and FAST operators at the same time. */
 MH_API MhPrecision MhGetPrecision(void);
 MH_API MhPrecision MhSetPrecision(MhPrecision precision);
+#define MH_IMAGE_PRECISION(p) ((uint32_t) (p)+1u)      /* value for MhImage::precision */
+
+/* Options.  Every MAGICKHIP_* / MAGICK_HIP_* environment variable is read ONCE, when the runtime
+   initialises (MhInitialize or the first call); later changes of the environment are not seen.
+   MhSetOption changes the value the library holds (value == NULL: as if the variable were unset)
+   — for tests and A/B measurements; MhGetOption returns it (NULL when unset; the pointer stays
+   valid).  Names as documented in DESIGN.md, e.g. "MAGICKHIP_NO_EXACT_MFMA". */
+MH_API MhStatus MhSetOption(const char *name,const char *value);
+MH_API const char *MhGetOption(const char *name);
+
+/* What the device arbitration of the MagickCore binding needs (the reference: RequestOpenCLDevice,
+   opencl.c:3056-3102; AcquireOpenCLCommandQueue, opencl.c:656; GetOpenCLDevices and the device
+   getters, opencl.c:1823-2130).  `device` is a HIP ordinal below MhDeviceCount().
+   MhLogicalDeviceCount: the number of devices a caller should arbitrate over — MhDeviceCount(),
+   or MAGICKHIP_LOGICAL_DEVICES when that is larger (logical device d runs on physical device
+   d mod MhDeviceCount(): how a one-GPU box rehearses the multi-GPU paths). */
+typedef struct MhDeviceInfo
+{
+  char name[128];            /* e.g. "AMD Instinct MI355X" */
+  char architecture[64];     /* e.g. "gfx950:sramecc+:xnack-" */
+  int32_t compute_units;
+  int32_t clock_mhz;
+  uint64_t global_memory;    /* bytes */
+  uint64_t local_memory;     /* LDS bytes per workgroup */
+} MhDeviceInfo;
+MH_API int MhLogicalDeviceCount(void);
+MH_API MhStatus MhGetDeviceInfo(int device,MhDeviceInfo *info);
+/* A non-blocking stream on `device` (the caller passes it as MhImage::stream and to the transfer
+   helpers); destroyed by MhStreamDestroy or MhTerminus. */
+MH_API MhStatus MhStreamCreate(int device,void **stream);
+MH_API MhStatus MhStreamDestroy(int device,void *stream);
+/* Image-sized device blocks from the library's stream-ordered caching pool: no hipMalloc /
+   hipFree (a device-wide synchronisation) per operator result.  `stream` = the stream the block
+   was last used on; MhDeviceFreeAsync returns at once, and the block is handed out again only
+   behind the work enqueued on that stream. */
+MH_API MhStatus MhDeviceAllocAsync(int device,size_t bytes,void *stream,void **ptr);
+MH_API MhStatus MhDeviceFreeAsync(int device,void *ptr,void *stream);
 
 /* Device memory helpers for callers that keep images resident.  MhUpload returns once the
    transfer is enqueued on `stream` and `src_host` may be reused; MhDownload returns once
@@ -227,6 +269,8 @@ typedef struct MhKernelProfileRecord
 } MhKernelProfileRecord;
 MH_API int MhSetProfileEnabled(int enabled);      /* SetOpenCLKernelProfileEnabled, opencl.c:3162 */
 MH_API size_t MhGetProfileRecords(MhKernelProfileRecord *records,size_t capacity);
+/* ... of one device only (GetOpenCLKernelProfileRecords(device, &length), opencl.c:2081) */
+MH_API size_t MhGetDeviceProfileRecords(int device,MhKernelProfileRecord *records,size_t capacity);
 MH_API void MhResetProfileRecords(void);
 
 /* Diagnostics of the exact-integer blur (convolve_fused_exact.hip): the number of samples whose

@@ -203,13 +203,21 @@ static CacheInfo *AcquireHeapCache(const Image *image,ExceptionInfo *exception)
 }
 
 /*
-  The device copy of an image's pixels.  upload != 0: an operator input — reuse the
-  resident copy, or allocate one and upload the host block (once).  upload == 0: an
-  operator result — allocate only; the host block is stale until the cache hooks
-  download it (record marked dirty).
+  The device copy of an image's pixels, and the queue (device + stream) the call runs on.
+
+  upload != 0: an operator input.  Resident already: its own device and stream are retained —
+  an image stays where its pixels are, and on the stream that produced them, so a chain of
+  operators needs no cross-stream ordering (a device that has been switched off meanwhile,
+  SetOpenCLDeviceEnabled: the pixels come back to the host first, then as below).  Not
+  resident: the arbitration picks a device and a stream (AcquireHipQueue: RequestOpenCLDevice +
+  AcquireOpenCLCommandQueue, opencl.c:3056-3102, :656), the host block is uploaded once.  On
+  success the caller owns `queue` and gives it back with ReleaseHipQueue.
+
+  upload == 0: an operator result — allocated on the given queue's device and tagged with its
+  stream; the host block is stale until the cache hooks download it (record marked dirty).
 */
 static void *AcquireDevicePixels(HipLibrary *library,const Image *image,const int upload,
-  ExceptionInfo *exception)
+  HipQueue *queue,ExceptionInfo *exception)
 {
   CacheInfo
     *cache_info;
@@ -225,31 +233,55 @@ static void *AcquireDevicePixels(HipLibrary *library,const Image *image,const in
     return(NULL);
   LockSemaphoreInfo(cache_info->semaphore);
   info=cache_info->opencl;
+  if ((info != (MagickCLCacheInfo) NULL) && (upload != 0) &&
+      (GetOpenCLDeviceEnabled(info->device) == MagickFalse))
+    info=cache_info->opencl=CopyMagickCLCacheInfo(info);     /* back to the host: NULL now */
   if (info != (MagickCLCacheInfo) NULL)
     {
+      if (upload != 0)
+        RetainHipQueue(info->device,(void *) info->events,queue);
+      else
+        if (info->device != queue->device)
+          {
+            /* a result cache that is resident elsewhere: not something this file creates */
+            UnlockSemaphoreInfo(cache_info->semaphore);
+            return(NULL);
+          }
       UnlockSemaphoreInfo(cache_info->semaphore);
       return((void *) info->buffer);            /* resident: no transfer */
     }
-  device_pixels=NULL;
-  if (library->DeviceAlloc(-1,(size_t) cache_info->length,&device_pixels) != MH_OK)
+  if ((upload != 0) && (AcquireHipQueue(library,queue) == MagickFalse))
     {
       UnlockSemaphoreInfo(cache_info->semaphore);
       return(NULL);
     }
-  if (upload != 0)
+  device_pixels=NULL;
+  if (library->DeviceAllocAsync(queue->physical,(size_t) cache_info->length,queue->stream,
+        &device_pixels) != MH_OK)
+    device_pixels=NULL;
+  if ((device_pixels != NULL) && (upload != 0))
     {
-      if (library->Upload(-1,device_pixels,cache_info->pixels,(size_t) cache_info->length,
-            NULL) != MH_OK)
+      if (library->Upload(queue->physical,device_pixels,cache_info->pixels,
+            (size_t) cache_info->length,queue->stream) != MH_OK)
         {
-          (void) library->DeviceFree(-1,device_pixels);
-          UnlockSemaphoreInfo(cache_info->semaphore);
-          return(NULL);
+          (void) library->DeviceFreeAsync(queue->physical,device_pixels,queue->stream);
+          device_pixels=NULL;
         }
-      CountHipTransfer(1);
+      else
+        CountHipTransfer(1);
+    }
+  if (device_pixels == NULL)
+    {
+      if (upload != 0)
+        ReleaseHipQueue(queue);
+      UnlockSemaphoreInfo(cache_info->semaphore);
+      return(NULL);
     }
   info=(MagickCLCacheInfo) AcquireCriticalMemory(sizeof(*info));
   (void) memset(info,0,sizeof(*info));
   info->buffer=(cl_mem) device_pixels;
+  info->device=queue->device;
+  info->events=(cl_event *) queue->stream;      /* the stream the copy is used on */
   info->pixels=cache_info->pixels;
   info->length=cache_info->length;
   info->event_count=upload != 0 ? 0U : 1U;      /* dirty: the device copy is the newer one */
@@ -269,7 +301,7 @@ static void MarkDeviceCopyNewer(const Image *image)
 }
 
 static MagickBooleanType DescribeImage(HipLibrary *library,const Image *image,
-  void *device_pixels,MhImage *description)
+  void *device_pixels,const HipQueue *queue,MhImage *description)
 {
   ssize_t
     i;
@@ -285,8 +317,8 @@ static MagickBooleanType DescribeImage(HipLibrary *library,const Image *image,
     MH_QUANTUM_U16,
 #endif
     MH_MEMORY_DEVICE);
-  description->device=(-1);
-  description->stream=NULL;                    /* the device's null stream, like the transfers */
+  description->device=queue->physical;         /* the device the arbitration chose ... */
+  description->stream=queue->stream;           /* ... and the stream of this call */
   for (i=0; i < (ssize_t) image->number_channels; i++)
   {
     PixelChannel channel = GetPixelChannelChannel(image,i);
@@ -302,22 +334,75 @@ static MagickBooleanType DescribeImage(HipLibrary *library,const Image *image,
   return(MagickTrue);
 }
 
-/* A new image of the given size whose pixels live on the device (host block allocated, stale). */
-static Image *AcquireResultImage(HipLibrary *library,const Image *image,const size_t columns,
-  const size_t rows,void **device_pixels,ExceptionInfo *exception)
+/*
+  One accelerated call.  New-image operators: BeginHipCall(call,image,columns,rows) brings the
+  source onto a device (or finds it there), clones the result image (CloneImage with a new
+  size: a fresh, uninitialised cache, accelerate.c:239-256) whose pixels live on the same device,
+  and describes both; the operator runs on call->source / call->destination; EndHipCall returns
+  the result image or, when the library declined, destroys it and returns NULL — the CPU path
+  then runs.  In-place operators: columns = rows = 0, no result image; EndHipCall marks the
+  device copy as the newer one.
+*/
+typedef struct _HipCall
 {
+  HipLibrary
+    *library;
+
+  HipQueue
+    queue;
+
   Image
     *result;
 
-  result=CloneImage(image,columns,rows,MagickTrue,exception);
-  if (result == (Image *) NULL)
-    return((Image *) NULL);
-  if (SetImageStorageClass(result,DirectClass,exception) == MagickFalse)
-    return(HipDeclined(image,DestroyImage(result)));
-  *device_pixels=AcquireDevicePixels(library,result,0,exception);
-  if (*device_pixels == NULL)
-    return(HipDeclined(image,DestroyImage(result)));
-  return(result);
+  MhImage
+    source,
+    destination;
+} HipCall;
+
+static MagickBooleanType BeginHipCall(HipCall *call,const Image *image,const size_t columns,
+  const size_t rows,ExceptionInfo *exception)
+{
+  void
+    *p,
+    *q;
+
+  call->result=(Image *) NULL;
+  call->queue.device=(MagickCLDevice) NULL;
+  call->library=AcquireHipLibrary();
+  if (call->library == (HipLibrary *) NULL)
+    return(MagickFalse);
+  p=AcquireDevicePixels(call->library,image,1,&call->queue,exception);
+  if (p == NULL)
+    return(MagickFalse);
+  if (DescribeImage(call->library,image,p,&call->queue,&call->source) == MagickFalse)
+    {
+      ReleaseHipQueue(&call->queue);
+      return(MagickFalse);
+    }
+  if ((columns == 0) || (rows == 0))
+    return(MagickTrue);
+  call->result=CloneImage(image,columns,rows,MagickTrue,exception);
+  if ((call->result != (Image *) NULL) &&
+      (SetImageStorageClass(call->result,DirectClass,exception) != MagickFalse))
+    {
+      q=AcquireDevicePixels(call->library,call->result,0,&call->queue,exception);
+      if ((q != NULL) && (DescribeImage(call->library,call->result,q,&call->queue,
+            &call->destination) != MagickFalse))
+        return(MagickTrue);
+    }
+  if (call->result != (Image *) NULL)
+    call->result=DestroyImage(call->result);
+  ReleaseHipQueue(&call->queue);
+  return(MagickFalse);
+}
+
+/* the result image (new-image operators) or NULL when the library declined */
+static Image *EndHipCall(HipCall *call,const MhStatus status)
+{
+  ReleaseHipQueue(&call->queue);
+  if ((status != MH_OK) && (call->result != (Image *) NULL))
+    call->result=DestroyImage(call->result);
+  return(call->result);
 }
 
 /*
@@ -342,37 +427,21 @@ static MagickBooleanType HasMorphologyArtifacts(const Image *image)
 MagickPrivate Image *AccelerateBlurImage(const Image *image,const double radius,
   const double sigma,ExceptionInfo *exception)
 {
-  HipLibrary
-    *library;
+  HipCall
+    call;
 
   Image
     *blur_image;
-
-  MhImage
-    source,
-    destination;
-
-  void
-    *p,
-    *q;
 
   assert(image != NULL);
   assert(exception != (ExceptionInfo *) NULL);
   if ((IsImageAcceleratable(image) == MagickFalse) || (HasMorphologyArtifacts(image) != MagickFalse))
     return(HipDeclined(image,(Image *) NULL));
-  library=AcquireHipLibrary();
-  if (library == (HipLibrary *) NULL)
+  if (BeginHipCall(&call,image,image->columns,image->rows,exception) == MagickFalse)
     return(HipDeclined(image,(Image *) NULL));
-  p=AcquireDevicePixels(library,image,1,exception);
-  if (p == NULL)
-    return(HipDeclined(image,(Image *) NULL));
-  blur_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
+  blur_image=EndHipCall(&call,call.library->BlurImage(&call.source,&call.destination,radius,sigma));
   if (blur_image == (Image *) NULL)
     return(HipDeclined(image,(Image *) NULL));
-  if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
-      (DescribeImage(library,blur_image,q,&destination) == MagickFalse) ||
-      (library->BlurImage(&source,&destination,radius,sigma) != MH_OK))
-    return(HipDeclined(image,DestroyImage(blur_image)));
   blur_image->type=image->type;      /* as MorphologyPrimitive does, morphology.c:2800 */
   HipAccepted(image);
   return(blur_image);
@@ -382,35 +451,20 @@ MagickPrivate Image *AccelerateUnsharpMaskImage(const Image *image,
   const double radius,const double sigma,const double gain,const double threshold,
   ExceptionInfo *exception)
 {
-  HipLibrary
-    *library;
+  HipCall
+    call;
 
   Image
     *unsharp_image;
 
-  MhImage
-    source,
-    destination;
-
-  void
-    *p,
-    *q;
-
   if ((IsImageAcceleratable(image) == MagickFalse) || (HasMorphologyArtifacts(image) != MagickFalse))
     return(HipDeclined(image,(Image *) NULL));
-  library=AcquireHipLibrary();
-  if (library == (HipLibrary *) NULL)
+  if (BeginHipCall(&call,image,image->columns,image->rows,exception) == MagickFalse)
     return(HipDeclined(image,(Image *) NULL));
-  p=AcquireDevicePixels(library,image,1,exception);
-  if (p == NULL)
-    return(HipDeclined(image,(Image *) NULL));
-  unsharp_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
+  unsharp_image=EndHipCall(&call,call.library->UnsharpMaskImage(&call.source,&call.destination,
+    radius,sigma,gain,threshold));
   if (unsharp_image == (Image *) NULL)
     return(HipDeclined(image,(Image *) NULL));
-  if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
-      (DescribeImage(library,unsharp_image,q,&destination) == MagickFalse) ||
-      (library->UnsharpMaskImage(&source,&destination,radius,sigma,gain,threshold) != MH_OK))
-    return(HipDeclined(image,DestroyImage(unsharp_image)));
   unsharp_image->type=image->type;   /* effect.c:4385 */
   HipAccepted(image);
   return(unsharp_image);
@@ -425,15 +479,11 @@ MagickPrivate Image *AccelerateResizeImage(const Image *image,
   const size_t resizedColumns,const size_t resizedRows,
   const ResizeFilter *resizeFilter,ExceptionInfo *exception)
 {
-  HipLibrary
-    *library;
+  HipCall
+    call;
 
   Image
     *resize_image;
-
-  MhImage
-    source,
-    destination;
 
   MhResizeFilter
     *filter;
@@ -441,33 +491,22 @@ MagickPrivate Image *AccelerateResizeImage(const Image *image,
   MhStatus
     status;
 
-  void
-    *p,
-    *q;
-
-  if (IsImageAcceleratable(image) == MagickFalse)
+  if ((IsImageAcceleratable(image) == MagickFalse) || (resizedColumns == 0) || (resizedRows == 0))
     return(HipDeclined(image,(Image *) NULL));
-  library=AcquireHipLibrary();
-  if (library == (HipLibrary *) NULL)
-    return(HipDeclined(image,(Image *) NULL));
-  p=AcquireDevicePixels(library,image,1,exception);
-  if (p == NULL)
-    return(HipDeclined(image,(Image *) NULL));
-  resize_image=AcquireResultImage(library,image,resizedColumns,resizedRows,&q,exception);
-  if (resize_image == (Image *) NULL)
+  if (BeginHipCall(&call,image,resizedColumns,resizedRows,exception) == MagickFalse)
     return(HipDeclined(image,(Image *) NULL));
   /* the weights are the reference's own: expert filter:* artifacts included */
-  filter=library->AcquireResizeFilterFromCallback(ReferenceFilterWeight,
+  filter=call.library->AcquireResizeFilterFromCallback(ReferenceFilterWeight,
     (void *) resizeFilter,GetResizeFilterSupport(resizeFilter));
   status=MH_BAD_ARGUMENT;
-  if ((filter != (MhResizeFilter *) NULL) &&
-      (DescribeImage(library,image,p,&source) != MagickFalse) &&
-      (DescribeImage(library,resize_image,q,&destination) != MagickFalse))
-    status=library->ResizeImageWithFilter(&source,&destination,filter);
   if (filter != (MhResizeFilter *) NULL)
-    (void) library->DestroyResizeFilter(filter);
-  if (status != MH_OK)
-    return(HipDeclined(image,DestroyImage(resize_image)));
+    {
+      status=call.library->ResizeImageWithFilter(&call.source,&call.destination,filter);
+      (void) call.library->DestroyResizeFilter(filter);
+    }
+  resize_image=EndHipCall(&call,status);
+  if (resize_image == (Image *) NULL)
+    return(HipDeclined(image,(Image *) NULL));
   resize_image->type=image->type;    /* resize.c:3872 */
   HipAccepted(image);
   return(resize_image);
@@ -476,24 +515,19 @@ MagickPrivate Image *AccelerateResizeImage(const Image *image,
 MagickPrivate MagickBooleanType AccelerateEqualizeImage(Image *image,
   ExceptionInfo *exception)
 {
-  HipLibrary
-    *library;
+  HipCall
+    call;
 
-  MhImage
-    description;
-
-  void
-    *q;
+  MhStatus
+    status;
 
   if (IsHistogramOperatorAcceleratable(image) == MagickFalse)
     return(HipDeclined(image,MagickFalse));
-  library=AcquireHipLibrary();
-  if (library == (HipLibrary *) NULL)
+  if (BeginHipCall(&call,image,0,0,exception) == MagickFalse)
     return(HipDeclined(image,MagickFalse));
-  q=AcquireDevicePixels(library,image,1,exception);
-  if ((q == NULL) ||
-      (DescribeImage(library,image,q,&description) == MagickFalse) ||
-      (library->EqualizeImage(&description) != MH_OK))
+  status=call.library->EqualizeImage(&call.source);
+  (void) EndHipCall(&call,status);
+  if (status != MH_OK)
     return(HipDeclined(image,MagickFalse));
   MarkDeviceCopyNewer(image);
   HipAccepted(image);
@@ -528,31 +562,26 @@ static MagickBooleanType IsHistogramOperatorAcceleratable(const Image *image)
 MagickPrivate MagickBooleanType AccelerateContrastStretchImage(Image *image,
   const double black_point,const double white_point,ExceptionInfo *exception)
 {
-  HipLibrary
-    *library;
+  HipCall
+    call;
 
   int
     became_gray;
 
-  MhImage
-    description;
-
-  void
-    *q;
+  MhStatus
+    status;
 
   if (IsHistogramOperatorAcceleratable(image) == MagickFalse)
     return(HipDeclined(image,MagickFalse));
-  library=AcquireHipLibrary();
-  if (library == (HipLibrary *) NULL)
+  if (BeginHipCall(&call,image,0,0,exception) == MagickFalse)
     return(HipDeclined(image,MagickFalse));
-  q=AcquireDevicePixels(library,image,1,exception);
   became_gray=0;
-  if ((q == NULL) ||
-      (DescribeImage(library,image,q,&description) == MagickFalse) ||
-      (library->ContrastStretchImage(&description,black_point,white_point,&became_gray) != MH_OK))
-    return(HipDeclined(image,MagickFalse));
-  /* (an all-gray colour image comes back as MH_UNSUPPORTED above: the CPU path then does the
+  status=call.library->ContrastStretchImage(&call.source,black_point,white_point,&became_gray);
+  (void) EndHipCall(&call,status);
+  /* (an all-gray colour image comes back as MH_UNSUPPORTED: the CPU path then does the
      IdentifyImageType re-layout itself, enhance.c:1586-1588) */
+  if (status != MH_OK)
+    return(HipDeclined(image,MagickFalse));
   MarkDeviceCopyNewer(image);
   HipAccepted(image);
   return(MagickTrue);
@@ -573,15 +602,11 @@ MagickPrivate Image *AccelerateMorphologyApply(const Image *image,
   const KernelInfo
     *k;
 
-  HipLibrary
-    *library;
+  HipCall
+    call;
 
   Image
     *morphology_image;
-
-  MhImage
-    source,
-    destination;
 
   MhKernelInfo
     kernels[MaxAcceleratedKernels];
@@ -591,10 +616,6 @@ MagickPrivate Image *AccelerateMorphologyApply(const Image *image,
 
   size_t
     n;
-
-  void
-    *p,
-    *q;
 
   /* the user's morphology:compose (morphology.c:4206): the operators the backend composes with */
   switch (compose)
@@ -628,21 +649,13 @@ MagickPrivate Image *AccelerateMorphologyApply(const Image *image,
       kernels[n-1].next=&kernels[n];
     n++;
   }
-  library=AcquireHipLibrary();
-  if (library == (HipLibrary *) NULL)
-    return(HipDeclined(image,(Image *) NULL));
-  p=AcquireDevicePixels(library,image,1,exception);
-  if (p == NULL)
-    return(HipDeclined(image,(Image *) NULL));
-  morphology_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
-  if (morphology_image == (Image *) NULL)
+  if (BeginHipCall(&call,image,image->columns,image->rows,exception) == MagickFalse)
     return(HipDeclined(image,(Image *) NULL));
   /* MorphologyMethod and MhMorphologyMethod share their values (morphology.h:72-98) */
-  if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
-      (DescribeImage(library,morphology_image,q,&destination) == MagickFalse) ||
-      (library->MorphologyImageCompose(&source,&destination,(MhMorphologyMethod) method,iterations,
-         kernels,bias,override) != MH_OK))
-    return(HipDeclined(image,DestroyImage(morphology_image)));
+  morphology_image=EndHipCall(&call,call.library->MorphologyImageCompose(&call.source,
+    &call.destination,(MhMorphologyMethod) method,iterations,kernels,bias,override));
+  if (morphology_image == (Image *) NULL)
+    return(HipDeclined(image,(Image *) NULL));
   morphology_image->type=image->type;                /* morphology.c:2800, :3222 */
   HipAccepted(image);
   return(morphology_image);
@@ -713,17 +726,18 @@ static MagickBooleanType SetResidentImageColorspace(HipLibrary *library,Image *i
     cache_info->opencl=info;
   else
     {
+      const int physical=GetHipDevicePhysical(info->device);
       if ((cache_info->type == MemoryCache) && (cache_info->pixels != (Quantum *) NULL) &&
           (cache_info->length == info->length))
         {
-          if (library->Download(-1,cache_info->pixels,(const void *) info->buffer,
-                (size_t) info->length,NULL) != MH_OK)
+          if (library->Download(physical,cache_info->pixels,(const void *) info->buffer,
+                (size_t) info->length,(void *) info->events) != MH_OK)
             status=MagickFalse;
           CountHipTransfer(0);
         }
       else
         status=MagickFalse;
-      (void) library->DeviceFree(-1,(void *) info->buffer);
+      (void) library->DeviceFreeAsync(physical,(void *) info->buffer,(void *) info->events);
       info=(MagickCLCacheInfo) RelinquishMagickMemory(info);
     }
   UnlockSemaphoreInfo(cache_info->semaphore);
@@ -733,14 +747,11 @@ static MagickBooleanType SetResidentImageColorspace(HipLibrary *library,Image *i
 MagickPrivate MagickBooleanType AccelerateTransformImageColorspace(Image *image,
   const ColorspaceType colorspace,ExceptionInfo *exception)
 {
-  HipLibrary
-    *library;
+  HipCall
+    call;
 
-  MhImage
-    description;
-
-  void
-    *q;
+  MhStatus
+    status;
 
   if (((colorspace == GRAYColorspace) || (colorspace == LinearGRAYColorspace)) &&
       (image->colorspace == sRGBColorspace) && (image->number_channels >= 3) &&
@@ -752,12 +763,11 @@ MagickPrivate MagickBooleanType AccelerateTransformImageColorspace(Image *image,
         (it finds the device copy newer and fetches it first: CopyOpenCLBuffer, cache.c:1711) —
         the same hand-over as after AccelerateGrayscaleImage (enhance.c:2500-2510).
       */
-      library=AcquireHipLibrary();
-      if (library == (HipLibrary *) NULL)
+      if (BeginHipCall(&call,image,0,0,exception) == MagickFalse)
         return(HipDeclined(image,MagickFalse));
-      q=AcquireDevicePixels(library,image,1,exception);
-      if ((q == NULL) || (DescribeImage(library,image,q,&description) == MagickFalse) ||
-          (library->TransformImageColorspace(&description,(MhColorspace) colorspace) != MH_OK))
+      status=call.library->TransformImageColorspace(&call.source,(MhColorspace) colorspace);
+      (void) EndHipCall(&call,status);
+      if (status != MH_OK)
         return(HipDeclined(image,MagickFalse));
       MarkDeviceCopyNewer(image);
       HipAccepted(image);
@@ -773,53 +783,34 @@ MagickPrivate MagickBooleanType AccelerateTransformImageColorspace(Image *image,
       (GetImageArtifact(image,"color:illuminant") != (const char *) NULL) ||
       (GetImageProperty(image,"white-luminance",exception) != (const char *) NULL))
     return(HipDeclined(image,MagickFalse));          /* D65 and the default Jzazbz white luminance only (colorspace.c:993-995) */
-  library=AcquireHipLibrary();
-  if (library == (HipLibrary *) NULL)
+  if (BeginHipCall(&call,image,0,0,exception) == MagickFalse)
     return(HipDeclined(image,MagickFalse));
-  q=AcquireDevicePixels(library,image,1,exception);
   /* ColorspaceType and MhColorspace share their values (colorspace.h:27-66) */
-  if ((q == NULL) ||
-      (DescribeImage(library,image,q,&description) == MagickFalse) ||
-      (library->TransformImageColorspace(&description,(MhColorspace) colorspace) != MH_OK))
+  status=call.library->TransformImageColorspace(&call.source,(MhColorspace) colorspace);
+  (void) EndHipCall(&call,status);
+  if (status != MH_OK)
     return(HipDeclined(image,MagickFalse));
   MarkDeviceCopyNewer(image);
   HipAccepted(image);
-  return(SetResidentImageColorspace(library,image,colorspace,exception));
+  return(SetResidentImageColorspace(call.library,image,colorspace,exception));
 }
 
-/* ---- operators outside the hot path: always "not handled", the CPU code runs ---- */
 /* DespeckleImage's call site: effect.c:1342-1346 */
 MagickPrivate Image *AccelerateDespeckleImage(const Image *image,ExceptionInfo *exception)
 {
-  HipLibrary
-    *library;
+  HipCall
+    call;
 
   Image
     *despeckle_image;
 
-  MhImage
-    source,
-    destination;
-
-  void
-    *p,
-    *q;
-
   if (IsImageAcceleratable(image) == MagickFalse)
     return(HipDeclined(image,(Image *) NULL));
-  library=AcquireHipLibrary();
-  if (library == (HipLibrary *) NULL)
+  if (BeginHipCall(&call,image,image->columns,image->rows,exception) == MagickFalse)
     return(HipDeclined(image,(Image *) NULL));
-  p=AcquireDevicePixels(library,image,1,exception);
-  if (p == NULL)
-    return(HipDeclined(image,(Image *) NULL));
-  despeckle_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
+  despeckle_image=EndHipCall(&call,call.library->DespeckleImage(&call.source,&call.destination));
   if (despeckle_image == (Image *) NULL)
     return(HipDeclined(image,(Image *) NULL));
-  if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
-      (DescribeImage(library,despeckle_image,q,&destination) == MagickFalse) ||
-      (library->DespeckleImage(&source,&destination) != MH_OK))
-    return(HipDeclined(image,DestroyImage(despeckle_image)));
   despeckle_image->type=image->type;       /* effect.c:1486 */
   HipAccepted(image);
   return(despeckle_image);
@@ -829,35 +820,20 @@ MagickPrivate Image *AccelerateDespeckleImage(const Image *image,ExceptionInfo *
 MagickPrivate Image *AccelerateLocalContrastImage(const Image *image,const double radius,
   const double strength,ExceptionInfo *exception)
 {
-  HipLibrary
-    *library;
+  HipCall
+    call;
 
   Image
     *contrast_image;
 
-  MhImage
-    source,
-    destination;
-
-  void
-    *p,
-    *q;
-
   if (IsImageAcceleratable(image) == MagickFalse)
     return(HipDeclined(image,(Image *) NULL));
-  library=AcquireHipLibrary();
-  if (library == (HipLibrary *) NULL)
+  if (BeginHipCall(&call,image,image->columns,image->rows,exception) == MagickFalse)
     return(HipDeclined(image,(Image *) NULL));
-  p=AcquireDevicePixels(library,image,1,exception);
-  if (p == NULL)
-    return(HipDeclined(image,(Image *) NULL));
-  contrast_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
+  contrast_image=EndHipCall(&call,call.library->LocalContrastImage(&call.source,&call.destination,
+    radius,strength));
   if (contrast_image == (Image *) NULL)
     return(HipDeclined(image,(Image *) NULL));
-  if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
-      (DescribeImage(library,contrast_image,q,&destination) == MagickFalse) ||
-      (library->LocalContrastImage(&source,&destination,radius,strength) != MH_OK))
-    return(HipDeclined(image,DestroyImage(contrast_image)));
   HipAccepted(image);
   return(contrast_image);
 }
@@ -866,18 +842,11 @@ MagickPrivate Image *AccelerateLocalContrastImage(const Image *image,const doubl
 MagickPrivate Image *AccelerateMotionBlurImage(const Image *image,const double *kernel,
   const size_t width,const OffsetInfo *offset,ExceptionInfo *exception)
 {
-  HipLibrary
-    *library;
+  HipCall
+    call;
 
   Image
     *blur_image;
-
-  MhImage
-    source,
-    destination;
-
-  MhStatus
-    status;
 
   ptrdiff_t
     *offsets;
@@ -885,14 +854,7 @@ MagickPrivate Image *AccelerateMotionBlurImage(const Image *image,const double *
   size_t
     i;
 
-  void
-    *p,
-    *q;
-
   if ((IsImageAcceleratable(image) == MagickFalse) || (width == 0))
-    return(HipDeclined(image,(Image *) NULL));
-  library=AcquireHipLibrary();
-  if (library == (HipLibrary *) NULL)
     return(HipDeclined(image,(Image *) NULL));
   offsets=(ptrdiff_t *) AcquireQuantumMemory(width,2*sizeof(*offsets));
   if (offsets == (ptrdiff_t *) NULL)
@@ -903,21 +865,12 @@ MagickPrivate Image *AccelerateMotionBlurImage(const Image *image,const double *
     offsets[2*i+1]=(ptrdiff_t) offset[i].y;
   }
   blur_image=(Image *) NULL;
-  status=MH_BAD_ARGUMENT;
-  p=AcquireDevicePixels(library,image,1,exception);
-  if (p != NULL)
-    blur_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
-  if ((blur_image != (Image *) NULL) &&
-      (DescribeImage(library,image,p,&source) != MagickFalse) &&
-      (DescribeImage(library,blur_image,q,&destination) != MagickFalse))
-    status=library->MotionBlurImageWithKernel(&source,&destination,kernel,width,offsets);
+  if (BeginHipCall(&call,image,image->columns,image->rows,exception) != MagickFalse)
+    blur_image=EndHipCall(&call,call.library->MotionBlurImageWithKernel(&call.source,
+      &call.destination,kernel,width,offsets));
   offsets=(ptrdiff_t *) RelinquishMagickMemory(offsets);
-  if (status != MH_OK)
-    {
-      if (blur_image != (Image *) NULL)
-        blur_image=DestroyImage(blur_image);
-      return(HipDeclined(image,(Image *) NULL));
-    }
+  if (blur_image == (Image *) NULL)
+    return(HipDeclined(image,(Image *) NULL));
   HipAccepted(image);
   return(blur_image);
 }
@@ -926,35 +879,19 @@ MagickPrivate Image *AccelerateMotionBlurImage(const Image *image,const double *
 MagickPrivate Image *AccelerateRotationalBlurImage(const Image *image,const double angle,
   ExceptionInfo *exception)
 {
-  HipLibrary
-    *library;
+  HipCall
+    call;
 
   Image
     *blur_image;
 
-  MhImage
-    source,
-    destination;
-
-  void
-    *p,
-    *q;
-
   if (IsImageAcceleratable(image) == MagickFalse)
     return(HipDeclined(image,(Image *) NULL));
-  library=AcquireHipLibrary();
-  if (library == (HipLibrary *) NULL)
+  if (BeginHipCall(&call,image,image->columns,image->rows,exception) == MagickFalse)
     return(HipDeclined(image,(Image *) NULL));
-  p=AcquireDevicePixels(library,image,1,exception);
-  if (p == NULL)
-    return(HipDeclined(image,(Image *) NULL));
-  blur_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
+  blur_image=EndHipCall(&call,call.library->RotationalBlurImage(&call.source,&call.destination,angle));
   if (blur_image == (Image *) NULL)
     return(HipDeclined(image,(Image *) NULL));
-  if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
-      (DescribeImage(library,blur_image,q,&destination) == MagickFalse) ||
-      (library->RotationalBlurImage(&source,&destination,angle) != MH_OK))
-    return(HipDeclined(image,DestroyImage(blur_image)));
   HipAccepted(image);
   return(blur_image);
 }
@@ -973,73 +910,42 @@ MagickPrivate Image *AccelerateWaveletDenoiseImage(const Image *magick_unused(im
 MagickPrivate Image *AccelerateWaveletDenoiseImageSoft(const Image *image,
   const double threshold,const double softness,ExceptionInfo *exception)
 {
-  HipLibrary
-    *library;
+  HipCall
+    call;
 
   Image
     *noise_image;
 
-  MhImage
-    source,
-    destination;
-
-  void
-    *p,
-    *q;
-
   if (IsImageAcceleratable(image) == MagickFalse)
     return(HipDeclined(image,(Image *) NULL));
-  library=AcquireHipLibrary();
-  if (library == (HipLibrary *) NULL)
+  if (BeginHipCall(&call,image,image->columns,image->rows,exception) == MagickFalse)
     return(HipDeclined(image,(Image *) NULL));
-  p=AcquireDevicePixels(library,image,1,exception);
-  if (p == NULL)
-    return(HipDeclined(image,(Image *) NULL));
-  noise_image=AcquireResultImage(library,image,image->columns,image->rows,&q,exception);
+  noise_image=EndHipCall(&call,call.library->WaveletDenoiseImage(&call.source,&call.destination,
+    threshold,softness));
   if (noise_image == (Image *) NULL)
     return(HipDeclined(image,(Image *) NULL));
-  if ((DescribeImage(library,image,p,&source) == MagickFalse) ||
-      (DescribeImage(library,noise_image,q,&destination) == MagickFalse) ||
-      (library->WaveletDenoiseImage(&source,&destination,threshold,softness) != MH_OK))
-    return(HipDeclined(image,DestroyImage(noise_image)));
   HipAccepted(image);
   return(noise_image);
-}
-
-/* In-place operator on the device copy of `image`; marks that copy as the newer one. */
-static MagickBooleanType AcquireInPlace(const Image *image,HipLibrary **library,
-  MhImage *description,ExceptionInfo *exception)
-{
-  void
-    *q;
-
-  if (IsImageAcceleratable(image) == MagickFalse)
-    return(HipDeclined(image,MagickFalse));
-  *library=AcquireHipLibrary();
-  if (*library == (HipLibrary *) NULL)
-    return(HipDeclined(image,MagickFalse));
-  q=AcquireDevicePixels(*library,image,1,exception);
-  if (q == NULL)
-    return(HipDeclined(image,MagickFalse));
-  return(DescribeImage(*library,image,q,description));
 }
 
 MagickPrivate MagickBooleanType AccelerateFunctionImage(Image *image,
   const MagickFunction function,const size_t number_parameters,
   const double *parameters,ExceptionInfo *exception)
 {
-  HipLibrary
-    *library;
+  HipCall
+    call;
 
-  MhImage
-    description;
+  MhStatus
+    status;
 
-  if ((image->storage_class != DirectClass) ||
-      (AcquireInPlace(image,&library,&description,exception) == MagickFalse))
+  if ((image->storage_class != DirectClass) || (IsImageAcceleratable(image) == MagickFalse) ||
+      (BeginHipCall(&call,image,0,0,exception) == MagickFalse))
     return(HipDeclined(image,MagickFalse));
   /* MagickFunction and MhFunction share their values (statistic.h:129-136) */
-  if (library->FunctionImage(&description,(MhFunction) function,number_parameters,
-        parameters) != MH_OK)
+  status=call.library->FunctionImage(&call.source,(MhFunction) function,number_parameters,
+    parameters);
+  (void) EndHipCall(&call,status);
+  if (status != MH_OK)
     return(HipDeclined(image,MagickFalse));
   MarkDeviceCopyNewer(image);
   HipAccepted(image);
@@ -1049,18 +955,20 @@ MagickPrivate MagickBooleanType AccelerateFunctionImage(Image *image,
 MagickPrivate MagickBooleanType AccelerateGrayscaleImage(Image *image,
   const PixelIntensityMethod method,ExceptionInfo *exception)
 {
-  HipLibrary
-    *library;
+  HipCall
+    call;
 
-  MhImage
-    description;
+  MhStatus
+    status;
 
   /* only layouts whose first three channels are R,G,B (GrayscaleImage reads all three) */
-  if ((image->number_channels < 3) ||
-      (AcquireInPlace(image,&library,&description,exception) == MagickFalse))
+  if ((image->number_channels < 3) || (IsImageAcceleratable(image) == MagickFalse) ||
+      (BeginHipCall(&call,image,0,0,exception) == MagickFalse))
     return(HipDeclined(image,MagickFalse));
   /* PixelIntensityMethod and MhIntensityMethod share their values (pixel.h) */
-  if (library->GrayscaleImage(&description,(MhIntensityMethod) method) != MH_OK)
+  status=call.library->GrayscaleImage(&call.source,(MhIntensityMethod) method);
+  (void) EndHipCall(&call,status);
+  if (status != MH_OK)
     return(HipDeclined(image,MagickFalse));
   MarkDeviceCopyNewer(image);
   HipAccepted(image);
@@ -1071,16 +979,18 @@ MagickPrivate MagickBooleanType AccelerateGrayscaleImage(Image *image,
 MagickPrivate MagickBooleanType AccelerateContrastImage(Image *image,
   const MagickBooleanType sharpen,ExceptionInfo *exception)
 {
-  HipLibrary
-    *library;
+  HipCall
+    call;
 
-  MhImage
-    description;
+  MhStatus
+    status;
 
-  if ((image->number_channels < 3) ||
-      (AcquireInPlace(image,&library,&description,exception) == MagickFalse))
+  if ((image->number_channels < 3) || (IsImageAcceleratable(image) == MagickFalse) ||
+      (BeginHipCall(&call,image,0,0,exception) == MagickFalse))
     return(HipDeclined(image,MagickFalse));
-  if (library->ContrastImage(&description,sharpen != MagickFalse ? 1 : 0) != MH_OK)
+  status=call.library->ContrastImage(&call.source,sharpen != MagickFalse ? 1 : 0);
+  (void) EndHipCall(&call,status);
+  if (status != MH_OK)
     return(HipDeclined(image,MagickFalse));
   MarkDeviceCopyNewer(image);
   HipAccepted(image);
@@ -1098,14 +1008,14 @@ MagickPrivate MagickBooleanType AccelerateModulateImage(Image *image,
   const double percent_saturation,const ColorspaceType colorspace,
   ExceptionInfo *exception)
 {
-  HipLibrary
-    *library;
-
-  MhImage
-    description;
-
   ColorspaceType
     model;
+
+  HipCall
+    call;
+
+  MhStatus
+    status;
 
   /* the nine models of enhance.c:3826-3890; every other value takes ModulateHSL's `default:` */
   switch (colorspace)
@@ -1119,13 +1029,15 @@ MagickPrivate MagickBooleanType AccelerateModulateImage(Image *image,
       model=HSLColorspace;
       break;
   }
-  if ((image->number_channels < 3) ||
+  if ((image->number_channels < 3) || (IsImageAcceleratable(image) == MagickFalse) ||
       (GetImageArtifact(image,"color:illuminant") != (const char *) NULL) ||
-      (AcquireInPlace(image,&library,&description,exception) == MagickFalse))
+      (BeginHipCall(&call,image,0,0,exception) == MagickFalse))
     return(HipDeclined(image,MagickFalse));
   /* ColorspaceType and MhColorspace share their values (colorspace.h:27-66) */
-  if (library->ModulateImage(&description,percent_brightness,percent_saturation,percent_hue,
-        (int) model) != MH_OK)
+  status=call.library->ModulateImage(&call.source,percent_brightness,percent_saturation,
+    percent_hue,(int) model);
+  (void) EndHipCall(&call,status);
+  if (status != MH_OK)
     return(HipDeclined(image,MagickFalse));
   MarkDeviceCopyNewer(image);
   HipAccepted(image);

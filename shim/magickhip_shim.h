@@ -16,8 +16,14 @@ typedef struct _HipLibrary
   int (*GetEnabled)(void);
   int (*SetEnabled)(int);
   void (*InitImage)(MhImage *,void *,size_t,size_t,uint32_t,int,MhQuantumKind,MhMemoryKind);
-  MhStatus (*DeviceAlloc)(int,size_t,void **);
-  MhStatus (*DeviceFree)(int,void *);
+  int (*DeviceCount)(void);
+  int (*LogicalDeviceCount)(void);
+  MhStatus (*GetDeviceInfo)(int,MhDeviceInfo *);
+  MhStatus (*StreamCreate)(int,void **);
+  MhStatus (*DeviceAllocAsync)(int,size_t,void *,void **);
+  MhStatus (*DeviceFreeAsync)(int,void *,void *);
+  int (*SetProfileEnabled)(int);
+  size_t (*GetDeviceProfileRecords)(int,MhKernelProfileRecord *,size_t);
   MhStatus (*Upload)(int,void *,const void *,size_t,void *);
   MhStatus (*Download)(int,void *,const void *,size_t,void *);
   MhStatus (*Synchronize)(int,void *);
@@ -50,6 +56,27 @@ typedef struct _HipLibrary
 
 /* NULL when the library, a GPU or the enable switch is missing: the caller runs the CPU path */
 extern MagickPrivate HipLibrary *AcquireHipLibrary(void);
+
+/*
+  What one operator call runs on: a device picked by RequestHipDevice (the reference:
+  RequestOpenCLDevice, opencl.c:3056-3102) and one of its streams (AcquireOpenCLCommandQueue,
+  opencl.c:656).  `physical` is the HIP ordinal the library is called with; several logical
+  devices may share one (MAGICKHIP_LOGICAL_DEVICES).
+*/
+typedef struct _HipQueue
+{
+  MagickCLDevice device;
+  int physical;
+  void *stream;
+} HipQueue;
+
+/* the enabled device with the least outstanding work + the next of its streams; MagickFalse when
+   no device is enabled.  Every successful call is paired with ReleaseHipQueue. */
+extern MagickPrivate MagickBooleanType AcquireHipQueue(HipLibrary *,HipQueue *);
+/* the queue an image that is already resident on `device` keeps using (its own stream) */
+extern MagickPrivate void RetainHipQueue(MagickCLDevice device,void *stream,HipQueue *);
+extern MagickPrivate void ReleaseHipQueue(HipQueue *);
+extern MagickPrivate int GetHipDevicePhysical(const MagickCLDevice device);
 
 /* transfer counters, for tests (uploads / downloads of whole pixel caches) */
 extern MagickPrivate void CountHipTransfer(int upload);

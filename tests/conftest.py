@@ -29,6 +29,32 @@ def im():
     return imagemagick_amd
 
 
+class _Options:
+    """Library switches for one test (MhSetOption): the library reads MAGICKHIP_* from the
+    environment once, at start-up, so tests flip its switches through the API; undone afterwards."""
+
+    def __init__(self, im):
+        self.im, self.saved = im, {}
+
+    def set(self, name, value="1"):
+        self.saved.setdefault(name, self.im.get_option(name))
+        self.im.set_option(name, value)
+
+    def setenv(self, name, value):          # the spelling the tests used with monkeypatch
+        self.set(name, value)
+
+    def restore(self):
+        for name, value in self.saved.items():
+            self.im.set_option(name, value)
+
+
+@pytest.fixture
+def options(im):
+    o = _Options(im)
+    yield o
+    o.restore()
+
+
 @pytest.fixture(scope="session")
 def vectors():
     """Committed outputs of the reference's own CPU code (tests/golden/make_golden.py)."""

@@ -265,13 +265,13 @@ def test_convolve_fast_signed_separable_kernel_plain_channels(im):
 
 @pytest.mark.parametrize("shape", [(150, 331), (70, 64), (33, 65), (1, 200), (200, 1), (17, 2)])
 @pytest.mark.parametrize("sigma", [0.6, 2.5, 10.0])
-def test_blur_and_unsharp_fast_rgb_single_launch(im, refmod, shape, sigma, monkeypatch):
+def test_blur_and_unsharp_fast_rgb_single_launch(im, refmod, shape, sigma, options):
     """RGB (6-byte pixels, no alpha) through the single-launch fused kernel as four plain channels
     whose fourth is zero (MFMA_PLAIN3: only the pixel loads and stores differ): UnsharpMaskImage
     by default, BlurImage with MAGICKHIP_FUSED_RGB=1 (measured level with its two-launch form);
     strips and segments ragged at both edges."""
     import bench
-    monkeypatch.setenv("MAGICKHIP_FUSED_RGB", "1")
+    options.set("MAGICKHIP_FUSED_RGB", "1")
     px = make_pixels(shape[0], shape[1], 3, Q16, seed=shape[0] + shape[1])
     dev, ref = run_pair(im, refmod, px)
     holder = {}
@@ -437,7 +437,7 @@ def test_convolve_fast_non_separable_kernel_stays_exact(im, refmod):
                                     "7x5: 1,2,3,4,3,2,1 2,4,6,8,6,4,2 3,6,9,13,9,6,2 2,4,6,8,6,4,2 1,2,3,4,3,2,1",
                                     "6x6+1+4: 1,0,2,nan,1,3 0,1,1,2,nan,1 2,2,0,1,1,1 nan,1,3,1,0,2 1,1,1,1,2,0 3,0,1,2,1,1",
                                     "Ring:10,14"])
-def test_convolve_2d_fast_on_matrix_cores(im, refmod, kernel, alpha, walk, monkeypatch):
+def test_convolve_2d_fast_on_matrix_cores(im, refmod, kernel, alpha, walk, options):
     """FAST ConvolveMorphology with a non-separable kernel of 5 x 5 cells or more (RGBA with
     alpha-weighted colour, or four plain channels): the w x h sum as h banded products on the
     matrix cores (convolve2d_mfma.hip) — flat disks, weighted and asymmetric user kernels, NaN
@@ -446,9 +446,9 @@ def test_convolve_2d_fast_on_matrix_cores(im, refmod, kernel, alpha, walk, monke
     all four steps through its ring of rows (a small frame is otherwise cut into single steps).
     Within one level of the reference, and of the generic kernel it replaces."""
     import bench
-    monkeypatch.setenv("MAGICKHIP_NO_EXACT_2D", "1")     # (integer cells otherwise take convolve2d_exact.hip)
+    options.set("MAGICKHIP_NO_EXACT_2D", "1")     # (integer cells otherwise take convolve2d_exact.hip)
     if walk:
-        monkeypatch.setenv("MAGICKHIP_CONV2D_CUTS", "1")
+        options.set("MAGICKHIP_CONV2D_CUTS", "1")
     px = make_pixels(107 if walk else 75, 150, 4, Q16, seed=len(kernel))
     if alpha:
         px[10:30, 20:60, 3] = np.random.default_rng(3).integers(0, 4, (20, 40))       # tiny alpha
@@ -460,7 +460,7 @@ def test_convolve_2d_fast_on_matrix_cores(im, refmod, kernel, alpha, walk, monke
     try:
         launched = set(bench.kernel_profile(
             im, lambda: holder.update(out=im.morphology_image(dev, "Convolve", 1, kernel, scale=(1.0, 1))), 1))
-        monkeypatch.setenv("MAGICKHIP_NO_MFMA_2D", "1")
+        options.set("MAGICKHIP_NO_MFMA_2D", "1")
         generic = im.morphology_image(dev, "Convolve", 1, kernel, scale=(1.0, 1)).numpy()
     finally:
         im.set_precision(im.PRECISION_EXACT)
@@ -477,12 +477,12 @@ def test_convolve_2d_fast_on_matrix_cores(im, refmod, kernel, alpha, walk, monke
 
 @pytest.mark.parametrize("kernel", ["Disk:15", "Octagon:5", "Ring:10,14",
                                     "6x6+1+4: 1,0,2,nan,1,3 0,1,1,2,nan,1 2,2,0,1,1,1 nan,1,3,1,0,2 1,1,1,1,2,0 3,0,1,2,1,1"])
-def test_convolve_2d_fast_on_matrix_cores_rgb(im, refmod, kernel, monkeypatch):
+def test_convolve_2d_fast_on_matrix_cores_rgb(im, refmod, kernel, options):
     """The same kernel on an RGB frame (6-byte pixels): three plain channels, the matrix tile's
     fourth entry zero (convolve2d_mfma.hip, MFMA_PLAIN3); frames ragged against the tiles.
     Within one level of the reference."""
     import bench
-    monkeypatch.setenv("MAGICKHIP_NO_EXACT_2D", "1")
+    options.set("MAGICKHIP_NO_EXACT_2D", "1")
     px = make_pixels(75, 150, 3, Q16, seed=len(kernel) + 3)
     dev, ref = run_pair(im, refmod, px)
     holder = {}
@@ -500,7 +500,7 @@ def test_convolve_2d_fast_on_matrix_cores_rgb(im, refmod, kernel, monkeypatch):
 @pytest.mark.parametrize("shape", [(64, 80), (33, 71), (2, 2), (70, 2), (1, 40), (129, 17)])
 @pytest.mark.parametrize("gain,threshold", [(1.0, 0.02), (2.5, 0.0), (0.6, 0.2), (1.3, 1.0 / 65535.0)])
 @pytest.mark.parametrize("single_launch", [True, False])
-def test_unsharp_mask_fast_fused(im, refmod, shape, gain, threshold, single_launch, monkeypatch):
+def test_unsharp_mask_fast_fused(im, refmod, shape, gain, threshold, single_launch, options):
     """FAST UnsharpMaskImage on RGBA Q16: the column pass applies the threshold/gain epilogue
     while it copies its results out (no blurred frame in memory) — in the one launch that does
     both passes (convolve_fused.hip), or, with that switched off, after a separate row pass.  A
@@ -508,7 +508,7 @@ def test_unsharp_mask_fast_fused(im, refmod, shape, gain, threshold, single_laun
     1+gain levels, and can flip the threshold test only when 2|p-b| sits on the threshold itself."""
     import bench
     if not single_launch:
-        monkeypatch.setenv("MAGICKHIP_NO_FUSED_BLUR", "1")
+        options.set("MAGICKHIP_NO_FUSED_BLUR", "1")
     px = make_pixels(shape[0], shape[1], 4, Q16, seed=shape[0] + 3 * shape[1])
     dev, ref = run_pair(im, refmod, px)
     want = ref.unsharp(0.0, 2.0, gain, threshold).numpy().astype(np.int64)
@@ -547,11 +547,8 @@ def test_unsharp_mask_fast_four_plain_channels_and_fallbacks(im, refmod):
     try:
         got4 = im.unsharp_mask_image(im.Image(to_device(px), has_alpha=False), 0.0, 3.0, 1.5, 0.01).numpy()
         got3 = im.unsharp_mask_image(im.Image(to_device(rgb)), 0.0, 3.0, 1.5, 0.01).numpy()
-        os.environ["MAGICKHIP_NO_FUSED_UNSHARP"] = "1"
-        try:
+        with im.option("MAGICKHIP_NO_FUSED_UNSHARP"):
             unfused = im.unsharp_mask_image(im.Image(to_device(px)), 0.0, 3.0, 1.5, 0.01).numpy()
-        finally:
-            del os.environ["MAGICKHIP_NO_FUSED_UNSHARP"]
     finally:
         im.set_precision(im.PRECISION_EXACT)
     for name, got, want in (("plain4", got4, want4), ("rgb", got3, want3), ("unfused", unfused, want_blend)):
@@ -570,11 +567,8 @@ def test_blur_fast_matrix_and_vector_paths_agree_within_one_level(im, refmod):
     im.set_precision(im.PRECISION_FAST)
     try:
         matrix = im.blur_image(dev, 0.0, 4.0).numpy()
-        os.environ["MAGICKHIP_NO_MFMA"] = "1"
-        try:
+        with im.option("MAGICKHIP_NO_MFMA"):
             vector = im.blur_image(dev, 0.0, 4.0).numpy()
-        finally:
-            del os.environ["MAGICKHIP_NO_MFMA"]
     finally:
         im.set_precision(im.PRECISION_EXACT)
     assert_parity(matrix, want, False, "matrix-core FAST")
@@ -641,7 +635,7 @@ def test_morphology(im, refmod, dtype, method, kernel, iterations):
     ("Dilate", "Diamond:9"), ("Erode", "Square:4"), ("Dilate", "Rectangle:9x5+2+1"), ("Dilate", "Plus:11"),
     ("Erode", "Rectangle:1x9"), ("Dilate", "Rectangle:13x1"), ("Dilate", "Disk:31"),
 ])
-def test_symmetric_convex_kernels_over_several_tiles(im, refmod, method, kernel, channels, monkeypatch):
+def test_symmetric_convex_kernels_over_several_tiles(im, refmod, method, kernel, channels, options):
     """Erode / Dilate with a kernel that is a union of centred rectangles (morph_rects_kernel:
     column windows from the staged tile, row windows across lanes) on a frame that spans several
     workgroup tiles in both directions, ragged at the right and bottom edges; bit-identical to
@@ -655,7 +649,7 @@ def test_symmetric_convex_kernels_over_several_tiles(im, refmod, method, kernel,
     assert launched == {"morph_rects"}, launched
     want = ref.morphology(method, 1, kernel).numpy()
     assert_parity(holder["out"].numpy(), want, True, "%s %s c%d" % (method, kernel, channels))
-    monkeypatch.setenv("MAGICKHIP_NO_RECTS", "1")
+    options.set("MAGICKHIP_NO_RECTS", "1")
     assert_parity(im.morphology_image(dev, method, 1, kernel).numpy(), want, True, "%s %s (planes)" % (method, kernel))
 
 
@@ -665,7 +659,7 @@ def test_symmetric_convex_kernels_over_several_tiles(im, refmod, method, kernel,
     ("Dilate", "Diamond:9"), ("Erode", "Square:4"), ("Dilate", "Rectangle:9x5+2+1"), ("Dilate", "Plus:11"),
     ("Erode", "Rectangle:1x9"), ("Dilate", "Rectangle:13x1"),
 ])
-def test_symmetric_convex_kernels_float_quantum(im, refmod, method, kernel, channels, monkeypatch):
+def test_symmetric_convex_kernels_float_quantum(im, refmod, method, kernel, channels, options):
     """The union-of-rectangles kernel on float Quantum (the reference's default build is HDRI; the
     generic 2-D kernel took 102 ms for Dilate Disk:15 on 16384^2): one float channel per 32-bit
     word, v_max_f32 / v_min_f32, RGBA as one column per lane.  Values beyond the Quantum range
@@ -683,7 +677,7 @@ def test_symmetric_convex_kernels_float_quantum(im, refmod, method, kernel, chan
     got = holder["out"].numpy()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "%s %s c%d: %d samples differ" % (
         method, kernel, channels, int((got.view(np.uint32) != want.view(np.uint32)).sum()))
-    monkeypatch.setenv("MAGICKHIP_NO_FLOAT_RECTS", "1")
+    options.set("MAGICKHIP_NO_FLOAT_RECTS", "1")
     generic = im.morphology_image(dev, method, 1, kernel).numpy()
     assert np.array_equal(generic.view(np.uint32), want.view(np.uint32))
 
@@ -718,16 +712,16 @@ def test_float_rects_channel_mask_change_count_and_nan(im, refmod):
     ("Dilate", "Disk:15"), ("Erode", "Disk:15"), ("Erode", "Octagon:6"), ("Dilate", "Square:3"),
     ("Dilate", "Rectangle:9x5+2+1"), ("Erode", "Diamond:11"), ("Dilate", "Rectangle:1x9"), ("Erode", "Rectangle:13x1"),
 ])
-def test_symmetric_convex_kernels_down_a_strip(im, refmod, method, kernel, channels, cuts, monkeypatch):
+def test_symmetric_convex_kernels_down_a_strip(im, refmod, method, kernel, channels, cuts, options):
     """The same union-of-rectangles evaluation as a walk down 256-column strips (morph_strips_kernel,
     opt-in with MAGICKHIP_STRIPS=1: four columns per lane, a ring of rows in LDS that
     global_load_lds_dwordx4 refills while the tile is evaluated) on a frame of three ragged strips
     by twelve ragged steps; walks of twelve, six and one step (MAGICKHIP_STRIP_CUTS).
     Bit-identical to the reference and to the tile kernel."""
     import bench
-    monkeypatch.setenv("MAGICKHIP_STRIPS", "1")
+    options.set("MAGICKHIP_STRIPS", "1")
     if cuts is not None:
-        monkeypatch.setenv("MAGICKHIP_STRIP_CUTS", str(cuts))
+        options.set("MAGICKHIP_STRIP_CUTS", str(cuts))
     px = make_pixels(271, 530, channels, Q16, seed=len(kernel) + channels)
     dev, ref = run_pair(im, refmod, px)
     holder = {}
@@ -735,7 +729,7 @@ def test_symmetric_convex_kernels_down_a_strip(im, refmod, method, kernel, chann
         im, lambda: holder.update(out=im.morphology_image(dev, method, 1, kernel)), 1))
     assert launched == {"morph_rects"}, launched
     got = holder["out"].numpy()
-    monkeypatch.delenv("MAGICKHIP_STRIPS")
+    options.set("MAGICKHIP_STRIPS", None)
     tiles = im.morphology_image(dev, method, 1, kernel).numpy()
     assert np.array_equal(got, tiles), "%s %s c%d: strip walk != tile kernel at %s" % (
         method, kernel, channels, np.argwhere(got != tiles)[:4].tolist())
@@ -743,11 +737,11 @@ def test_symmetric_convex_kernels_down_a_strip(im, refmod, method, kernel, chann
         assert_parity(got, ref.morphology(method, 1, kernel).numpy(), True, "%s %s c%d" % (method, kernel, channels))
 
 
-def test_strip_walk_channel_mask_and_change_count(im, refmod, monkeypatch):
+def test_strip_walk_channel_mask_and_change_count(im, refmod, options):
     """morph_strips_kernel's general epilogue: channels without the update trait, the `changed`
     count that ends an unbounded iteration, and a kernel whose origin is off centre."""
-    monkeypatch.setenv("MAGICKHIP_STRIPS", "1")
-    monkeypatch.setenv("MAGICKHIP_STRIP_CUTS", "2")
+    options.set("MAGICKHIP_STRIPS", "1")
+    options.set("MAGICKHIP_STRIP_CUTS", "2")
     px = make_pixels(200, 470, 4, Q16, seed=78)
     dev = im.Image(to_device(px), copy_channels=(1, 3))
     ref = refmod.RefImage(px).set_channel_mask("RB")
@@ -947,14 +941,14 @@ def test_gaussian_blur_sharpen_edge_emboss(im, refmod, dtype, channels):
                                     "5x5: -1,-2,0,2,1 -4,-8,0,8,4 -6,-12,0,12,6 -4,-8,0,8,4 -1,-2,0,2,1",
                                     "5x5: -1,-2,-3,-2,-1 -2,-4,-6,-4,-2 -3,-6,100,-6,-3 -2,-4,-6,-4,-2 -1,-2,-3,-2,-1",
                                     "5x5: -1,-1,-1,-1,-1 -1,-1,-1,-1,-1 -1,-1,24.5,-1,-1 -1,-1,-1,-1,-1 -1,-1,-1,-1,-1"])
-def test_separable_2d_convolve_exact(im, refmod, dtype, channels, alpha, kernel, monkeypatch):
+def test_separable_2d_convolve_exact(im, refmod, dtype, channels, alpha, kernel, options):
     """EXACT 2-D Convolve with a kernel that is an outer product (GaussianBlurImage's kernels,
     boxes, column x row products): two fp64 1-D passes over alpha-premultiplied doubles and a tie
     check, the undecided samples recomputed in the reference's w x h order
     (convolve_separable.hip) — bit-identical on Q16 and on float Quantum, every layout, small and
     zero alpha, frames ragged against the kernels' tiles."""
     import bench
-    monkeypatch.setenv("MAGICKHIP_NO_EXACT_2D", "1")     # (Q16 boxes and integer kernels otherwise take convolve2d_exact.hip)
+    options.set("MAGICKHIP_NO_EXACT_2D", "1")     # (Q16 boxes and integer kernels otherwise take convolve2d_exact.hip)
     rng = np.random.default_rng(len(kernel) + channels)
     px = make_pixels(83, 141, channels, dtype, seed=len(kernel))
     if alpha:
@@ -990,12 +984,12 @@ def test_separable_2d_convolve_exact(im, refmod, dtype, channels, alpha, kernel,
 
 
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
-def test_separable_2d_convolve_exact_on_ties(im, refmod, dtype, monkeypatch):
+def test_separable_2d_convolve_exact_on_ties(im, refmod, dtype, options):
     """A checkerboard of two adjacent levels under an even box puts every value exactly on a
     rounding tie (Q16) or on the midpoint of two floats (HDRI): all of them go through the
     reference-order recomputation; GaussianBlurImage of the same frame lands 1e-5 beside the ties.
     Both bit-identical."""
-    monkeypatch.setenv("MAGICKHIP_NO_EXACT_2D", "1")
+    options.set("MAGICKHIP_NO_EXACT_2D", "1")
     rows, cols = 70, 110
     y, x = np.mgrid[0:rows, 0:cols]
     px = np.empty((rows, cols, 4), dtype=dtype)
@@ -1036,7 +1030,7 @@ INTEGER_KERNELS = ["Disk:15", "Disk:7.3", "Octagon:5", "Diamond:4", "Plus:3", "R
 @pytest.mark.parametrize("mode", ["exact", "fast"])
 @pytest.mark.parametrize("layout", ["rgba", "plain4", "rgb"])
 @pytest.mark.parametrize("kernel", INTEGER_KERNELS)
-def test_convolve_2d_integer_cells_on_matrix_cores(im, refmod, kernel, layout, mode, monkeypatch):
+def test_convolve_2d_integer_cells_on_matrix_cores(im, refmod, kernel, layout, mode, options):
     """2-D Convolve whose cells are integer multiples of a unit (flat shapes, integer and
     half-integer user kernels, NaN holes, origins off centre, the widest window the band holds):
     exact integer sums on the i8 matrix cores + tie check (convolve2d_exact.hip) — BIT-IDENTICAL in
@@ -1044,7 +1038,7 @@ def test_convolve_2d_integer_cells_on_matrix_cores(im, refmod, kernel, layout, m
     plain channels and RGB, frames ragged against the 64-column strips and 32-row steps, one
     workgroup walking its whole strip through the ring of rows."""
     import bench
-    monkeypatch.setenv("MAGICKHIP_CONV2D_CUTS", "1")
+    options.set("MAGICKHIP_CONV2D_CUTS", "1")
     channels = 3 if layout == "rgb" else 4
     alpha = layout == "rgba"
     rows, cols = 107, 150
@@ -1130,14 +1124,14 @@ TIE_KERNELS = ["Disk:7.3", "LoG:0x1.4", "DoG:0,1.2,2.5", "Comet:0x2+30",
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
 @pytest.mark.parametrize("channels,alpha", [(4, True), (4, False), (3, False), (2, True), (1, False)])
 @pytest.mark.parametrize("kernel", TIE_KERNELS)
-def test_convolve_2d_fused_fp64_with_tie_check(im, refmod, dtype, channels, alpha, kernel, monkeypatch):
+def test_convolve_2d_fused_fp64_with_tie_check(im, refmod, dtype, channels, alpha, kernel, options):
     """What is left of 2-D Convolve after the outer-product and integer-cell paths — cells of any
     value and sign, NaN holes, off-centre origins, one- and two-channel layouts, float frames with
     fractional levels and values beyond the Quantum range: one fused multiply-add per cell and channel
     over alpha-premultiplied doubles and a tie check (convolve2d_tie.hip), bit-identical on Q16 and
     on float Quantum; tiny and zero alpha included."""
     import bench
-    monkeypatch.setenv("MAGICKHIP_NO_EXACT_2D", "1")         # (Disk on Q16 would take the integer kernel)
+    options.set("MAGICKHIP_NO_EXACT_2D", "1")         # (Disk on Q16 would take the integer kernel)
     rng = np.random.default_rng(len(kernel) + channels)
     px = make_pixels(83, 141, channels, dtype, seed=len(kernel) + 5)
     if alpha:
@@ -1172,13 +1166,39 @@ def test_convolve_2d_fused_fp64_with_tie_check(im, refmod, dtype, channels, alph
 
 
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
-def test_convolve_2d_fused_fp64_on_ties_and_non_finite_samples(im, refmod, dtype, monkeypatch):
+@pytest.mark.parametrize("channels,alpha", [(4, True), (4, False), (1, False)])
+def test_tall_column_kernel_with_nan_cells(im, refmod, dtype, channels, alpha):
+    """A 1 x 31 column kernel with NaN cells is the reference's width == 1 fast path, whose gamma
+    carries height / count when cells are missing (morphology.c:2775-2776): 25 cells and more must
+    not reach convolve2d_tie.hip, alpha-weighted and plain, Q16 and float."""
+    cells = ["nan" if i in (3, 4, 17, 29) else "%.3f" % (0.2 + 0.05 * ((7 * i) % 11)) for i in range(31)]
+    kernel = "1x31+0+12: " + ",".join(cells)
+    px = make_pixels(77, 91, channels, dtype, seed=77 + channels)
+    if alpha:
+        px[20:40, 10:50, channels - 1] = 0
+    dev = im.Image(to_device(px), has_alpha=alpha)
+    ref = refmod.RefImage(px) if (alpha or channels == 1) else None
+    if ref is not None:
+        want = ref.morphology("Convolve", 1, kernel).numpy()
+    else:
+        want = np.concatenate([refmod.RefImage(px[:, :, c].copy()).morphology("Convolve", 1, kernel).numpy()
+                               .reshape(77, 91, 1) for c in range(channels)], axis=2)
+    got = im.morphology_image(dev, "Convolve", 1, kernel).numpy()
+    if dtype == HDRI:
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), "1x31 NaN column, c%d: %d float samples differ" % (channels, int((~same).sum()))
+    else:
+        assert_parity(got, want, True, "1x31 column kernel with NaN cells c%d alpha=%s" % (channels, alpha))
+
+
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+def test_convolve_2d_fused_fp64_on_ties_and_non_finite_samples(im, refmod, dtype, options):
     """A checkerboard of two adjacent levels (adjacent floats) under a kernel whose two colours of
     cells weigh the same puts every value on a rounding tie: all of them are recomputed in the
     reference's order; a float frame with an infinity and a NaN under a kernel with NaN cells (where
     a zero cannot stand in for "no cell") recomputes the tiles that hold them.  Bit-identical."""
-    monkeypatch.setenv("MAGICKHIP_NO_EXACT_2D", "1")
-    monkeypatch.setenv("MAGICKHIP_NO_SEPARABLE_EXACT", "1")
+    options.set("MAGICKHIP_NO_EXACT_2D", "1")
+    options.set("MAGICKHIP_NO_SEPARABLE_EXACT", "1")
     rows, cols = 70, 110
     y, x = np.mgrid[0:rows, 0:cols]
     px = np.empty((rows, cols, 4), dtype=dtype)
@@ -1219,14 +1239,14 @@ WIDE_INTEGER_KERNEL = "41x5+30+1: " + " ".join(",".join(str((7 * x + 3 * y) % 5)
 @pytest.mark.parametrize("kernel", ["Disk:15", "Octagon:5", "Ring:10,14", WIDE_INTEGER_KERNEL,
                                     "6x6+1+4: 1,0,2,nan,1,3 0,1,1,2,nan,1 2,2,0,1,1,1 nan,1,3,1,0,2 1,1,1,1,2,0 3,0,1,2,1,1",
                                     "5x5: -1,-2,0,2,1 -4,-8,0,8,4 -6,-12,0,12,7 -4,-8,0,8,4 -1,-2,0,2,1"])
-def test_convolve_2d_integer_cells_float_quantum(im, refmod, kernel, layout, monkeypatch):
+def test_convolve_2d_integer_cells_float_quantum(im, refmod, kernel, layout, options):
     """A float-Quantum frame whose samples are integers of 0..65535 (what an 8- or 16-bit file
     decodes to in the reference's default HDRI build) under a kernel with integer-multiple cells:
     the same exact integer sums on the i8 matrix cores, the results rounded to float with the tie
     check at float-rounding midpoints — bit-identical to the reference's w x h walk; the generic
     kernel is launched behind it and leaves at once."""
     import bench
-    monkeypatch.setenv("MAGICKHIP_CONV2D_CUTS", "1")
+    options.set("MAGICKHIP_CONV2D_CUTS", "1")
     channels = 3 if layout == "rgb" else 4
     alpha = layout == "rgba"
     rows, cols = 107, 150
@@ -1474,7 +1494,7 @@ def test_colorspace(im, refmod, dtype, src, dst, channels):
 
 @pytest.mark.parametrize("frame", ["random", "constant", "two_levels", "dark", "odd_size"])
 @pytest.mark.parametrize("black,white", [(0.02, 0.01), (0.0, 0.0), (0.7, 0.6), (1.5, 0.0), (0.0, 1.5)])
-def test_lab_contrast_stretch_three_launches(im, frame, black, white, monkeypatch):
+def test_lab_contrast_stretch_three_launches(im, frame, black, white, options):
     """FAST sRGB->Lab + ContrastStretch in one call on RGBA Q16 takes three launches (convert + bin,
     stretch_levels_kernel, stretch_apply_kernel: pointwise.hip); the levels and the map are those
     of the general route (slab reduction, three LUT kernels, LUT apply), bit for bit — on frames
@@ -1497,7 +1517,7 @@ def test_lab_contrast_stretch_three_launches(im, frame, black, white, monkeypatc
     try:
         for general in (False, True):
             if general:
-                monkeypatch.setenv("MAGICKHIP_NO_STRETCH_LEVELS", "1")
+                options.set("MAGICKHIP_NO_STRETCH_LEVELS", "1")
             img = im.Image(to_device(px))
             launched = bench.kernel_profile(im, lambda: im.transform_colorspace_contrast_stretch_image(
                 img, "Lab", black * n, n - white * n), 1)
@@ -1560,7 +1580,7 @@ def test_contrast_stretch(im, refmod, dtype, kind, channels):
 
 @pytest.mark.parametrize("shape", [(1100, 1000), (1024, 1025), (3000, 5600)])
 @pytest.mark.parametrize("kind", ["random", "flat", "two-level"])
-def test_intensity_histogram_packed_counters(im, refmod, shape, kind, monkeypatch):
+def test_intensity_histogram_packed_counters(im, refmod, shape, kind, options):
     """Frames above a megapixel bin their intensity in one pass into 16-bit LDS counters, two to a
     word (histogram_packed_kernel); a share of more than 65 535 pixels per workgroup, a frame that
     is ONE level (every pixel of a workgroup in one counter) and an odd pixel count must give the
@@ -1580,7 +1600,7 @@ def test_intensity_histogram_packed_counters(im, refmod, shape, kind, monkeypatc
     want_equal = refmod.RefImage(px).equalize().numpy()
     for packed in (True, False):
         if not packed:
-            monkeypatch.setenv("MAGICKHIP_NO_PACKED_HISTOGRAM", "1")
+            options.set("MAGICKHIP_NO_PACKED_HISTOGRAM", "1")
         dev = im.Image(to_device(px))
         im.contrast_stretch_image(dev, 0.02 * n, n - 0.01 * n)
         assert_parity(dev.numpy(), want_stretch, True, "contrast stretch %s packed=%s" % (kind, packed))
@@ -1713,7 +1733,7 @@ def test_histogram_operators_large_frame(im, refmod, dtype, kind):
 @pytest.mark.parametrize("form", ["stage", "1"])
 @pytest.mark.parametrize("shape,target,filt", [((37, 53, 4), (148, 212), "Lanczos"), ((64, 300, 4), (200, 700), "Mitchell"),
                                                ((50, 41, 3), (150, 164), "Triangle"), ((23, 600, 4), (92, 2400), "Lanczos")])
-def test_resize_fused_forms(im, refmod, shape, target, filt, form, dtype, monkeypatch):
+def test_resize_fused_forms(im, refmod, shape, target, filt, form, dtype, options):
     """The opt-in one-launch enlargements (MAGICKHIP_FUSED_RESIZE=stage: VerticalFilter inside the
     horizontal kernel's staging; =1: both tiles in LDS) give the two passes' bits — the
     intermediate is rounded to Quantum as the reference's filter image is."""
@@ -1721,7 +1741,7 @@ def test_resize_fused_forms(im, refmod, shape, target, filt, form, dtype, monkey
     px = make_pixels(shape[0], shape[1], shape[2], dtype, seed=shape[1])
     dev, ref = run_pair(im, refmod, px)
     want = ref.resize(target[1], target[0], filt).numpy()
-    monkeypatch.setenv("MAGICKHIP_FUSED_RESIZE", form)
+    options.set("MAGICKHIP_FUSED_RESIZE", form)
     holder = {}
     launched = set(bench.kernel_profile(
         im, lambda: holder.update(out=im.resize_image(dev, target[1], target[0], filt)), 1))

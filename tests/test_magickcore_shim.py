@@ -324,3 +324,147 @@ def test_srgb_to_gray_through_magickcore(shim, dtype, target):
     assert_parity(g.numpy(), c.numpy(), True, "sRGB -> %s via MagickCore" % target, max_ulp=1)
     # and the gray image goes on through the accelerated operators (the gate admits GRAY)
     assert_parity(g.blur(0.0, 2.0).numpy(), c.blur(0.0, 2.0).numpy(), True, "BlurImage of the gray image")
+
+
+# ----------------------------------------------------------------------- devices and queues
+class _KernelProfileRecord(ctypes.Structure):          # MagickCore/opencl.h:33-43
+    _fields_ = [("kernel_name", ctypes.c_char_p), ("count", ctypes.c_ulong), ("max", ctypes.c_ulong),
+                ("min", ctypes.c_ulong), ("total", ctypes.c_ulong)]
+
+
+def _device_api(lib):
+    vp = ctypes.c_void_p
+    lib.GetOpenCLDevices.restype = ctypes.POINTER(vp)
+    lib.GetOpenCLDevices.argtypes = [ctypes.POINTER(ctypes.c_size_t), vp]
+    for name in ("GetOpenCLDeviceName", "GetOpenCLDeviceVendorName", "GetOpenCLDeviceVersion"):
+        getattr(lib, name).restype = ctypes.c_char_p
+        getattr(lib, name).argtypes = [vp]
+    lib.GetOpenCLDeviceType.restype = ctypes.c_int
+    lib.GetOpenCLDeviceType.argtypes = [vp]
+    lib.GetOpenCLDeviceEnabled.restype = ctypes.c_int
+    lib.GetOpenCLDeviceEnabled.argtypes = [vp]
+    lib.GetOpenCLDeviceBenchmarkScore.restype = ctypes.c_double
+    lib.GetOpenCLDeviceBenchmarkScore.argtypes = [vp]
+    lib.SetOpenCLDeviceEnabled.restype = None
+    lib.SetOpenCLDeviceEnabled.argtypes = [vp, ctypes.c_int]
+    lib.SetOpenCLKernelProfileEnabled.restype = None
+    lib.SetOpenCLKernelProfileEnabled.argtypes = [vp, ctypes.c_int]
+    lib.GetOpenCLKernelProfileRecords.restype = ctypes.POINTER(ctypes.POINTER(_KernelProfileRecord))
+    lib.GetOpenCLKernelProfileRecords.argtypes = [vp, ctypes.POINTER(ctypes.c_size_t)]
+    n = ctypes.c_size_t(0)
+    devices = lib.GetOpenCLDevices(ctypes.byref(n), None)
+    return [devices[i] for i in range(n.value)]
+
+
+def test_public_device_api_lists_the_gpus_and_masks_them(shim, im):
+    """MagickCore/opencl.h's device API on the HIP backend (the reference: opencl.c:1823-2130,
+    :3127-3168): GetOpenCLDevices returns one MagickCLDevice per GPU with name / vendor / version /
+    type / score / enabled; SetOpenCLDeviceEnabled is the arbitration's device mask — with every
+    device off BlurImage runs on the CPU, back on it is accelerated again."""
+    lib = shim._load(False, True)
+    devices = _device_api(lib)
+    assert len(devices) == im.logical_device_count() >= 1
+    info = im.device_info(0)
+    for d in devices:
+        assert lib.GetOpenCLDeviceName(d).decode() == info["name"] or len(devices) > im.device_count()
+        assert b"Advanced Micro Devices" in lib.GetOpenCLDeviceVendorName(d)
+        assert lib.GetOpenCLDeviceVersion(d).decode().startswith("HIP gfx")
+        assert lib.GetOpenCLDeviceType(d) == 2                       # GpuCLDeviceType
+        assert lib.GetOpenCLDeviceEnabled(d) == 1
+        assert lib.GetOpenCLDeviceBenchmarkScore(d) > 0.0
+    assert lib.GetOpenCLDeviceName(None) is None and lib.GetOpenCLDeviceEnabled(None) == 0
+    px = make_pixels(60, 70, 4, np.uint16, seed=31)
+    want = shim.RefImage(px).blur(0.0, 1.5).numpy()
+    try:
+        for d in devices:
+            lib.SetOpenCLDeviceEnabled(d, 0)
+        before = accelerated_calls(shim, False)
+        assert_parity(shim.RefImage(px, shim=True).blur(0.0, 1.5).numpy(), want, True, "every device off: CPU path")
+        assert accelerated_calls(shim, False) == before
+    finally:
+        for d in devices:
+            lib.SetOpenCLDeviceEnabled(d, 1)
+    before = accelerated_calls(shim, False)
+    resident = shim.RefImage(px, shim=True)
+    first = resident.blur(0.0, 1.5)
+    assert accelerated_calls(shim, False) == before + 1
+    # the source is resident on a device that is then switched off: the next operator brings the
+    # pixels back and runs elsewhere (here: the CPU, or another logical device)
+    try:
+        for d in devices:
+            lib.SetOpenCLDeviceEnabled(d, 0)
+        assert_parity(resident.blur(0.0, 1.5).numpy(), want, True, "resident on a disabled device")
+    finally:
+        for d in devices:
+            lib.SetOpenCLDeviceEnabled(d, 1)
+    assert_parity(first.numpy(), want, True, "BlurImage, devices back on")
+
+
+def test_kernel_profile_records_through_the_device_api(shim):
+    """SetOpenCLKernelProfileEnabled + GetOpenCLKernelProfileRecords (opencl.c:3162, :2081): the
+    library's hipEvent records of the device, one per kernel, microseconds."""
+    lib = shim._load(False, True)
+    devices = _device_api(lib)
+    px = make_pixels(300, 280, 4, np.uint16, seed=32)
+    for d in devices:
+        lib.SetOpenCLKernelProfileEnabled(d, 1)
+    try:
+        image = shim.RefImage(px, shim=True)
+        image.blur(0.0, 2.0).numpy()
+        image.equalize().numpy()
+    finally:
+        for d in devices:
+            lib.SetOpenCLKernelProfileEnabled(d, 0)
+    names, total = set(), 0
+    for d in devices:
+        n = ctypes.c_size_t(0)
+        records = lib.GetOpenCLKernelProfileRecords(d, ctypes.byref(n))
+        for i in range(n.value):
+            r = records[i].contents
+            assert r.count >= 1 and r.min <= r.max <= r.total
+            names.add(r.kernel_name.decode())
+            total += r.count
+        if n.value:
+            assert not records[n.value]                  # NULL-terminated like the reference's array
+    assert total >= 2 and any("blur" in name or "conv" in name for name in names), names
+
+
+def _run_threads_worker(threads, per_thread, env_extra, hdri=False):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    env["MAGICK_HIP_LIBRARY"] = os.path.join(ROOT, "imagemagick_amd", "lib", "libmagickhip.so")
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "helpers", "shim_threads.py"), str(threads), str(per_thread)]
+    if hdri:
+        cmd.append("hdri")
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("hdri", [False, True])
+def test_eight_threads_spread_over_devices_and_streams(shim, hdri):
+    """an unchanged MagickCore caller that converts a batch from 8 host threads
+    reaches several GPUs.  MAGICKHIP_LOGICAL_DEVICES=4 maps four logical devices onto the GPUs
+    present; every operator call is arbitrated (least-busy enabled device, RequestOpenCLDevice
+    opencl.c:3056-3102) and gets one of the device's streams round-robin
+    (AcquireOpenCLCommandQueue, opencl.c:656); chained operators stay on the device and stream of
+    their image.  Bit-identical to the CPU MagickCore."""
+    report = _run_threads_worker(8, 3, {"MAGICKHIP_LOGICAL_DEVICES": "4"}, hdri)
+    assert report["errors"] == [] and report["mismatches"] == 0 and report["images"] == 24, report
+    assert report["devices"] == 4
+    assert report["accelerated"] == 48                               # 24 x (BlurImage + EqualizeImage)
+    assert sum(report["calls"]) == 48
+    assert sum(1 for c in report["calls"] if c > 0) >= 2, report     # landed on >= 2 logical devices
+    assert all(s >= 2 for c, s in zip(report["calls"], report["streams"]) if c >= 4), report
+
+
+def test_eight_threads_on_two_physical_gpus(shim, im):
+    """The same through the physical devices of a multi-GPU node (no logical mapping)."""
+    if im.device_count() < 2:
+        pytest.skip("needs two physical GPUs")
+    report = _run_threads_worker(8, 3, {})
+    assert report["errors"] == [] and report["mismatches"] == 0 and report["images"] == 24, report
+    assert report["devices"] == im.device_count()
+    assert sum(1 for c in report["calls"] if c > 0) >= 2, report
