@@ -38,17 +38,17 @@ I8_MFMA_PEAK_TOPS = 5000.0        # dense i8 matrix peak (= the fp8 figure of MI
 
 # What each precision mode of the blur computes in, and what it promises
 MODE_DTYPE = {
-    "fast": "row pass: u8 digit products on the i8 matrix cores, exact i32 sums, f64 epilogue (the "
-            "intermediate is the reference's, bit for bit); column pass: f16x2 products, f32 accumulate",
+    "fast": "f16x2 products, f32 accumulate for the colour sums of both passes; the row pass's alpha (the "
+            "column pass's weights) as u8 digit products on the i8 matrix cores: exact i32 sums, f64 rounding",
     "exact": "u8 digit products on the i8 matrix cores, exact i32 sums, f64 epilogue; the few pixels the "
              "error bound cannot decide recomputed in the reference's f64 operation order",
     "fast_f16_legacy": "f16x2 products, f32 accumulate in both passes (round 2's kernel, MAGICKHIP_NO_EXACT_MFMA=1)",
     "hdri": "f64 in the CPU's operation order, float Quantum",
 }
 MODE_TOLERANCE = {
-    "fast": "within +-1 Quantum level of the reference CPU path on ANY input, by construction: the row pass's "
-            "Quantum-rounded intermediate is bit-identical to the reference's, the column pass is within +-1 of "
-            "the reference's column pass on that input",
+    "fast": "within +-1 Quantum level of the reference CPU path on ANY input, by construction: the intermediate "
+            "alpha is the reference's level bit for bit, the intermediate colour is NOT rounded (the reference's "
+            "rounding moves the value the column pass rounds by at most 0.5 level), the f16 sums add < 0.1",
     "exact": "bit-identical to the reference CPU path",
     "fast_f16_legacy": "out of contract, reported for comparison only: each pass within +-1, the two-pass result "
                        "+-1 on the full-size frame but up to +-2 on inputs whose intermediate sits on rounding ties",

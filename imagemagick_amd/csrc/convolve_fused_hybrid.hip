@@ -1,0 +1,679 @@
+// BlurImage's two passes in ONE launch, MH_PRECISION_FAST (Q16; RGBA with alpha-weighted colour,
+// four plain channels, RGB): f16 matrix-core sums for the colour, EXACT integer sums for the one
+// thing the +-1 contract needs exactly — the row pass's alpha.
+// MagickCore/effect.c:765-796 -> morphology.c:2811-2979 (row kernel) -> :2654-2807 (column kernel),
+// the Quantum-rounded intermediate of :4012-4022.
+//
+// Why this is within +-1 level of the reference on any content:
+//
+//   The reference's column pass forms  O_c = round( sum_j k_j A_j C_j / sum_j k_j A_j )  over the
+//   ROUNDED row-pass results A_j = round(alpha sum), C_j = round(R_j), R_j = N_j/D_j.
+//   * A_j is a WEIGHT.  A weight that is one level off moves O_c by (C_j - O_c)/A per sample —
+//     many levels where alpha is small or the colour varies.  So A_j has to be the reference's
+//     own level: the alpha sums of the row pass are formed as exact integers on the i8 matrix
+//     cores, with the certificate and the recomputation of convolve_fused_exact.hip
+//     (blur_exact_common.hpp) — bit-identical to the reference's intermediate alpha.
+//   * C_j enters linearly under non-negative weights: replacing C_j by the UNROUNDED value R_j
+//     (+ the f16 path's error eps) moves the real value the column pass rounds by a weighted mean
+//     of (R_j + eps_j - round(R_j)), i.e. by at most 0.5 + eps.  With the column pass's own error
+//     delta the two real values differ by less than 1 — and |a - b| < 1 implies
+//     |round(a) - round(b)| <= 1.  No tie structure of the frame can line the differences up to 2
+//     (round 2's kernel ROUNDED its approximate intermediate: +-1 per sample, +-2 after the second
+//     pass on checkerboards), because nothing is rounded here that the reference does not round.
+//   * plain channels (no alpha weighting): the same argument with A_j = 1 — no exact part at all.
+//   eps + delta: f16 hi/lo operands (22 bits), f32 accumulation: measured < 0.05 level.
+//
+// Per 16 x 64 pixels the row pass is 16 x 9 v_mfma_f32_16x16x32_f16 (colour; the alpha entry of a
+// tile idles) + 4 x 18 v_mfma_i32_16x16x64_i8 (four waves, one 16-row x 16-column alpha tile
+// each: nine digit products, two chunks) against 16 x 28 i8 instructions for the all-exact row
+// pass of convolve_fused_exact.hip, and its epilogue is f32 — one reciprocal and three multiplies
+// per pixel instead of ~68 fp64-rate instructions.
+//
+// Walk, ring, roles of the waves and the software pipeline over the two barrier intervals are
+// those of convolve_fused_exact.hip (COLX = false).
+#include "blur_exact_common.hpp"
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+namespace mh {
+
+// worst number of ds_read_b128 lines of one lane group that share a 16-byte slot, for the alpha
+// tile's byte-plane operand: entry e = lane&15 = row, k quarter = lane>>4 -> the next 16 columns
+static constexpr int alpha_plane_degree(int stride)
+{
+  int worst=1;
+  for (int g=0; g < 4; g++)
+    {
+      int count[16]={0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
+      for (int i=0; i < 16; i++)
+        {
+          const int base=(g & 1) == 0 ? (i < 4 ? i : (i < 8 ? i+8 : i+12)) : (i < 8 ? i+4 : (i < 12 ? i+8 : i+16));
+          const int lane=base+32*(g >> 1);
+          const int e=lane & 15,kq=lane >> 4;
+          const int slot=((e*stride+16*kq) % 256)/16;
+          count[slot]++;
+          worst=count[slot] > worst ? count[slot] : worst;
+        }
+    }
+  return worst;
+}
+
+static constexpr int alpha_plane_stride(int extent)
+{
+  int best=(extent+15) & ~15,best_degree=99;
+  for (int stride=(extent+15) & ~15; stride <= extent+96; stride+=16)
+    if (alpha_plane_degree(stride) < best_degree)
+      {
+        best_degree=alpha_plane_degree(stride);
+        best=stride;
+      }
+  return best;
+}
+
+template<int NC,bool BLEND>
+struct HybridGeometry
+{
+  typedef Fused16Geometry<NC> F;
+  static constexpr int COLS=64,GROUP=16;
+  static constexpr int NG=2*NC,NR=NG+1;
+  static constexpr int NX=(NC+1)/2;            // 64-slot chunks of the alpha tile's band
+  static constexpr int XS=F::XS;
+  // f16 staging planes: three colour channels (alpha-weighted frames: the alpha sums are the
+  // integer ones) or four plain channels
+  static constexpr int STAGE_CHANNELS=BLEND ? 3 : 4;
+  static constexpr int STAGE_PLANE=STAGE_CHANNELS*F::CHR;           // halves
+  static constexpr int ring_bytes=(int) (2*F::RING_PLANE*sizeof(_Float16));
+  static constexpr int stage_bytes=(int) (2*STAGE_PLANE*sizeof(_Float16));
+  // the alpha levels of the staged window as two signed-byte planes [row][column] (low, high)
+  static constexpr int ASTRIDE=alpha_plane_stride(XS);
+  static constexpr int alpha_bytes=BLEND ? 2*GROUP*ASTRIDE : 0;
+  // the row pass's real alpha sums (levels, f32) on their way from the alpha waves to every pixel's lane
+  static constexpr int DSTRIDE=COLS+1;
+  static constexpr int sum_bytes=BLEND ? (int) (GROUP*DSTRIDE*sizeof(float)) : 0;
+  static constexpr int OUT_STRIDE=COLS+1;
+  static constexpr int out_bytes=(int) (GROUP*OUT_STRIDE*sizeof(uint2));
+  // the taps' digits for the alpha tiles' Toeplitz operands: digit j of tap v at [j][v+15], v =
+  // -15..95 (zeros outside the kernel), in four copies shifted by 0..3 bytes so that every lane's
+  // 16-byte window (it begins at tap 16*kq-n) starts on a dword of one of them.  The operands
+  // are read from here for every group: sixty registers of per-lane constants do not fit beside
+  // the f16 operands (the compiler spilled them to scratch and reloaded them inside the walk).
+  static constexpr int DLP=116;
+  static constexpr int digit_bytes=BLEND ? 4*kExactDigits*DLP : 0;
+  static constexpr size_t lds_bytes=(size_t) ring_bytes+stage_bytes+alpha_bytes+sum_bytes+out_bytes+digit_bytes;
+  static_assert(lds_bytes <= 163840,"more than the 160 KiB of a CU");
+  static constexpr int GROUPS_PER_ROW=XS/4;
+  static constexpr int FETCH_GROUPS=GROUP*GROUPS_PER_ROW;
+  static_assert(FETCH_GROUPS <= 1024,"one staging round");
+  static_assert((FETCH_GROUPS % 64) == 0,"whole staging waves");
+  static_assert((alpha_bytes % 16) == 0,"aligned planes");
+};
+
+// Diagnostic builds only (-DMH_HYBRID_KNOCK, tools/gpu_hybrid_knock.sh): parts of the alpha path are
+// skipped at run time (bits of MAGICKHIP_HYBRID_KNOCK, handed over in args.threshold) to see what
+// each costs.  The results are wrong.  1 the alpha tiles' digit loads and products, 2 the alpha
+// epilogue of interval A, 4 the colour epilogue's reads of the exact alpha, 8 exact_sums,
+// 16 the staging of the alpha byte planes
+#ifdef MH_HYBRID_KNOCK
+#define MH_HKNOCKED(bit) ((args.threshold & (bit)) != 0)
+#else
+#define MH_HKNOCKED(bit) false
+#endif
+
+template<int NC,int MODE>
+__global__ __launch_bounds__(1024)
+void blur_fused_hybrid_kernel(BlurExactArgs args)
+{
+  // MFMA_PLAIN3 (RGB, 6-byte pixels) runs as four plain channels whose fourth is zero: only the
+  // pixel loads and stores differ
+  constexpr int PX=MODE == MFMA_PLAIN3 ? 3 : 4;          // u16 per pixel in memory
+  constexpr int SAMPLES=MODE == MFMA_PLAIN3 ? MFMA_PLAIN4 : MODE;
+  constexpr bool BLEND=SAMPLES == MFMA_BLEND4;
+  typedef unsigned __attribute__((aligned(2))) LooseDword;
+  auto load_pixel16=[&](const uint16_t *at) -> uint2
+  {
+    if constexpr (MODE == MFMA_PLAIN3)
+      return make_uint2(*reinterpret_cast<const LooseDword *>(at),(unsigned) at[2]);
+    else
+      return *reinterpret_cast<const uint2 *>(at);
+  };
+  auto store_pixel16=[&](uint16_t *at,uint2 value)
+  {
+    if constexpr (MODE == MFMA_PLAIN3)
+      {
+        *reinterpret_cast<LooseDword *>(at)=value.x;
+        at[2]=(uint16_t) value.y;
+      }
+    else
+      *reinterpret_cast<uint2 *>(at)=value;
+  };
+  typedef HybridGeometry<NC,BLEND> G;
+  typedef Fused16Geometry<NC> F;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16 *ring_hi=reinterpret_cast<_Float16 *>(smem_raw);
+  _Float16 *ring_lo=ring_hi+F::RING_PLANE;
+  _Float16 *stage_hi=reinterpret_cast<_Float16 *>(smem_raw+G::ring_bytes);
+  _Float16 *stage_lo=stage_hi+G::STAGE_PLANE;
+  unsigned char *alpha_plane=smem_raw+G::ring_bytes+G::stage_bytes;      // [2][GROUP][ASTRIDE]
+  float *alpha_sum=reinterpret_cast<float *>(alpha_plane+G::alpha_bytes); // [GROUP][DSTRIDE]
+  uint2 *out_tile=reinterpret_cast<uint2 *>(alpha_plane+G::alpha_bytes+G::sum_bytes);
+  unsigned char *digit_table=alpha_plane+G::alpha_bytes+G::sum_bytes+G::out_bytes;   // [4][kExactDigits][DLP]
+  const int tid=(int) threadIdx.x,lane=tid & 63;
+  const int wave=__builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n=lane & 15,kq=lane >> 4;
+  const int K=args.ntaps;
+  const int W=args.columns,H=args.rows;
+
+  const int items=args.strips*args.segments;
+  const int item=((int) blockIdx.x & 7)*args.items_per_xcd+((int) blockIdx.x >> 3);
+  if (item >= items)
+    return;
+  const int segment=item/args.strips,strip=item-segment*args.strips;
+  const int x0=G::COLS*strip;
+  const int block_begin=segment*args.blocks_per_segment;
+  const int block_end=block_begin+args.blocks_per_segment < args.blocks ?
+    block_begin+args.blocks_per_segment : args.blocks;
+  const int nblocks=block_end-block_begin;     // blocks of 16 output rows
+  const int out_begin=G::GROUP*block_begin;
+  const int in0=out_begin-args.shift;
+  const int xin0=x0-args.shift;
+  const int ngroups=nblocks+G::NG-1;
+
+  // ---- Toeplitz operands of the f16 products (both passes): T[c][i] = 256*tap[32c+8*kq+i-n], hi/lo
+  // split; and the digit table of the alpha tiles (HybridGeometry)
+  half8 t_hi[NC],t_lo[NC];
+  {
+    float *tap_lds=reinterpret_cast<float *>(stage_hi);
+    for (int j=tid; j < K; j+=1024)
+      tap_lds[j]=args.taps[j];
+    if constexpr (BLEND)
+      for (int at=tid; at < G::digit_bytes; at+=1024)
+        {
+          const int copy=at/(kExactDigits*G::DLP),rest=at-copy*(kExactDigits*G::DLP);
+          const int j=rest/G::DLP,v=rest-j*G::DLP+copy-15;
+          digit_table[at]=(unsigned char) (((v >= 0) && (v < K)) ? args.digits[j*kExactDigitPitch+v] : (signed char) 0);
+        }
+    __syncthreads();
+#pragma unroll
+    for (int c=0; c < NC; c++)
+#pragma unroll
+      for (int i=0; i < 8; i++)
+        {
+          int j=32*c+8*kq+i-n;
+          const bool inside=(j >= 0) && (j < K);
+          j=inside ? j : 0;
+          const float tap=inside ? 256.0f*tap_lds[j] : 0.0f;
+          _Float16 h,l;
+          split_f16(tap,h,l);
+          t_hi[c][i]=h;
+          t_lo[c][i]=l;
+        }
+    __syncthreads();                             // tap_lds is the staging plane
+  }
+
+  // ---- staging: thread -> (row, 4 consecutive columns) of the 16 x XS source window
+  // (the walk recomputes a stager's row and column group from its thread index in every iteration
+  // — a handful of vector instructions — instead of keeping them, the addresses derived from
+  // them and the other loop-invariant indices in registers: the kernel sits at the 128 registers
+  // of a wave, and what the compiler spills it reloads from scratch INSIDE the walk, each reload
+  // behind an s_waitcnt vmcnt(0) that also waits for the prefetched pixels: 9 such reloads cost
+  // 0.25 ms per 8192^2 frame.)
+  const bool stager=tid < G::FETCH_GROUPS;     // wave-uniform (FETCH_GROUPS is a multiple of 64)
+  uint2 raw[4];
+  auto fetch=[&](int g,int srow,int sxg)
+  {
+    if (stager)
+      {
+        int y=in0+G::GROUP*g+srow;
+        y=y < 0 ? 0 : (y > H-1 ? H-1 : y);       // the intermediate's edge clamp (cache.c:2663-2679)
+        const int xs=xin0+4*sxg;
+        if ((MODE == MFMA_PLAIN3) && (xs >= 0) && (xs+3 <= W-1))
+          {
+            // four RGB pixels = 24 contiguous bytes, re-cut into pixels
+            const uint16_t *at=args.src+pixel_index(y,W,xs)*3;
+            const LooseDword *words=reinterpret_cast<const LooseDword *>(at);
+            const uint2 a=make_uint2(words[0],words[1]),b=make_uint2(words[2],words[3]),c=make_uint2(words[4],words[5]);
+            raw[0]=make_uint2(a.x,a.y & 0xffffu);
+            raw[1]=make_uint2((a.y >> 16) | (b.x << 16),b.x >> 16);
+            raw[2]=make_uint2(b.y,c.x & 0xffffu);
+            raw[3]=make_uint2((c.x >> 16) | (c.y << 16),c.y >> 16);
+          }
+        else if ((MODE != MFMA_PLAIN3) && (xs >= 0) && (xs+3 <= W-1))
+          {
+            typedef unsigned LooseQuad __attribute__((ext_vector_type(4),aligned(8)));
+            const LooseQuad *at=reinterpret_cast<const LooseQuad *>(args.src+pixel_index(y,W,xs)*4);
+            const LooseQuad a=at[0],b=at[1];
+            raw[0]=make_uint2(a[0],a[1]);
+            raw[1]=make_uint2(a[2],a[3]);
+            raw[2]=make_uint2(b[0],b[1]);
+            raw[3]=make_uint2(b[2],b[3]);
+          }
+        else
+          {
+            // (the strips at the left and right image edges only; opaque to the optimiser so that
+            // the four clamped columns are not kept in registers across the whole walk)
+            int edge=xs;
+            asm volatile("" : "+v"(edge));
+#pragma unroll
+            for (int i=0; i < 4; i++)
+              {
+                int x=edge+i;
+                x=x < 0 ? 0 : (x > W-1 ? W-1 : x);
+                raw[i]=load_pixel16(args.src+pixel_index(y,W,x)*PX);
+              }
+          }
+      }
+  };
+  // raw Quantum pixels -> the f16 operand planes (alpha*p*2^-17 per colour channel, or level/2 of
+  // a plain channel: hi/lo split) and, alpha-weighted frames, the alpha levels as two byte planes
+  auto stage_group=[&](int srow,int sxg)
+  {
+    if (stager)
+      {
+        f32x2 v[4][2];
+        quantum_to_samples<SAMPLES>(raw,v);
+        // (one address + immediate offsets)
+        unsigned char *to=smem_raw+G::ring_bytes+2*(srow*F::SR+4*sxg);
+#pragma unroll
+        for (int c=0; c < G::STAGE_CHANNELS; c++)
+          {
+            uint2 hi,lo;
+            split_f16_pair(v[c][0],hi.x,lo.x);
+            split_f16_pair(v[c][1],hi.y,lo.y);
+            *reinterpret_cast<uint2 *>(to+2*c*F::CHR)=hi;
+            *reinterpret_cast<uint2 *>(to+2*(G::STAGE_PLANE+c*F::CHR))=lo;
+          }
+        if constexpr (BLEND)
+          if (!MH_HKNOCKED(16))
+          {
+            // bytes 2,3 of the second word of each pixel = the alpha level, paired over the four positions
+            const unsigned hy01=__builtin_amdgcn_perm(raw[1].y,raw[0].y,0x07030602u),hy23=__builtin_amdgcn_perm(raw[3].y,raw[2].y,0x07030602u);
+            unsigned char *line=smem_raw+G::ring_bytes+G::stage_bytes+srow*G::ASTRIDE+4*sxg;
+            *reinterpret_cast<unsigned *>(line)=__builtin_amdgcn_perm(hy23,hy01,0x05040100u) ^ 0x80808080u;
+            *reinterpret_cast<unsigned *>(line+G::GROUP*G::ASTRIDE)=__builtin_amdgcn_perm(hy23,hy01,0x07060302u) ^ 0x80808080u;
+          }
+      }
+  };
+
+  // row pass: wave = row quad (4 rows) x output tile (16 columns); entry e = 4*row + channel, so
+  // D hands a lane the four channels of ONE pixel.  Alpha-weighted frames stage no alpha plane:
+  // the alpha entry of a tile reads what lies a channel stride behind the third plane (the lo
+  // plane's first channel, the byte planes) — its sum is not used, an entry's garbage stays in
+  // its own row of the tile, and the address keeps the 16 lanes of a read group in 16 different
+  // bank slots (re-reading channel 0 instead made every operand read a two-way conflict:
+  // 0.07 ms per 8192^2 frame)
+  const int rq=wave & 3,ot=wave >> 2;
+  const int row_entry=(n & 3)*F::CHR+(4*rq+(n >> 2))*F::SR+16*ot+8*kq;
+  // the exact alpha tiles: waves 12..15 (one per SIMD; tile waves with two column tiles, not
+  // stagers), tile t = wave & 3 = 16 rows x columns 16*t..+15; entry e = row, so D hands lane
+  // (n, kq) the rows 4*kq..4*kq+3 (registers) of column 16*t+n
+#ifndef MH_HYBRID_ALPHA_LOW
+  const bool alpha_wave=BLEND && (wave >= 12);
+#else
+  const bool alpha_wave=BLEND && (wave < 4);       // (A/B: staging waves instead of tile waves)
+#endif
+  const int alpha_tile=wave & 3;
+  const int alpha_entry=n*G::ASTRIDE+16*alpha_tile+16*kq;
+  // this lane's window of the digit table: taps 16*kq-n .. +15 (and 64+8*kq-n .. +7 of the second chunk)
+  const int digit_copy=(3-n) & 3;
+  const int digit_entry=digit_copy*(kExactDigits*G::DLP)+16*kq+15-n-digit_copy;
+  // column pass: the tiles belong to the waves that do not stage (convolve_fused.hip)
+  constexpr int TILE_WAVES=16-G::FETCH_GROUPS/64;
+  constexpr int CT=(16+TILE_WAVES-1)/TILE_WAVES;
+  const int tile_wave=wave-(16-TILE_WAVES);    // < 0: a staging wave
+  const int ctiles=tile_wave < 0 ? 0 : 16/TILE_WAVES+(tile_wave < 16 % TILE_WAVES ? 1 : 0);
+  const int ctile0=tile_wave < 0 ? 0 : tile_wave*(16/TILE_WAVES)+(tile_wave < 16 % TILE_WAVES ? tile_wave : 16 % TILE_WAVES);
+  constexpr int GROUP_STRIDE=2*F::OB;          // f16 ring: halves per 16-row group
+  const int col_entry16=(n & 3)*F::CHC+(4*ctile0+(n >> 2))*8+(kq & 1)*F::OB;
+  // the row epilogue's ring store: after the 4 x 4 transpose lane (n, kq) holds channel kq of rows 4*rq..+3
+  const int ring_entry16=kq*F::CHC+(rq >> 1)*F::OB+(16*ot+n)*8+4*(rq & 1);
+  // ... the alpha wave's: rows 4*kq..+3 of the alpha channel, column 16*t+n
+  const int ring_alpha16=3*F::CHC+(kq >> 1)*F::OB+(16*alpha_tile+n)*8+4*(kq & 1);
+  // ... and where a pixel's lane finds its own alpha half-level again: row 4*rq+kq
+  const int ring_own_alpha16=3*F::CHC+(rq >> 1)*F::OB+(16*ot+n)*8+4*(rq & 1)+kq;
+  int ring_group=0;                            // g mod NR (wave-uniform)
+  unsigned recomputed=0u;
+
+  // ---- The walk (convolve_fused_exact.hip).  Iteration g:
+  //   interval A: stage group g, fetch g+1 | column pass of block cb = g-NG-1 -> out_tile
+  //               | alpha waves: the exact alpha sums of group g-1 -> levels (+ the few recomputed)
+  //                 -> ring slot (alpha channel) and alpha_sum
+  //   interval B: f16 row chain of group g (all waves) and the alpha tiles' integer chain (alpha
+  //               waves): matrix pipe  ||  colour epilogue of group g-1: f32 sums + the alpha of
+  //               interval A -> ring slot;  store of block cb's rows: vector pipe
+  // What crosses a barrier: the f32 sums of a pixel (4 floats) and, alpha waves, five class tiles.
+  // (First version: alpha chain, its fp64 epilogue and the wave's own f16 chain one after the other
+  // in interval B — everyone else waited at barrier Y: 0.80 ms per 8192^2 frame against 0.44 for
+  // four plain channels.)
+  floatx4 sums_row={0.0f,0.0f,0.0f,0.0f};
+  intx4 tiles[5];
+#pragma unroll
+  for (int c=0; c < 5; c++)
+    tiles[c]=intx4{0,0,0,0};
+  auto store_row=[&](int block,int lane)
+  {
+    if ((block >= 0) && (block < nblocks))
+      {
+        const uint2 result=out_tile[wave*G::OUT_STRIDE+lane];
+        const int x=x0+lane,y=out_begin+G::GROUP*block+wave;
+        if ((x < W) && (y < H))
+          store_pixel16(args.dst+pixel_index(y,W,x)*PX,result);
+      }
+  };
+  fetch(0,tid/G::GROUPS_PER_ROW,tid % G::GROUPS_PER_ROW);
+  for (int g=0; g <= ngroups+1; g++)
+    {
+      int opaque_tid=tid;
+      asm volatile("" : "+v"(opaque_tid));       // not loop-invariant to the optimiser (see `stager`)
+      const int srow=opaque_tid/G::GROUPS_PER_ROW,sxg=opaque_tid-srow*G::GROUPS_PER_ROW;
+      const int cb=g-G::NG-1;                    // the column pass's block of this iteration
+      const int first=ring_group;                // ring slot of group cb: (g-NG-1) mod NR = g mod NR
+      const int previous=ring_group == 0 ? G::NR-1 : ring_group-1;   // ring slot of group g-1
+      if (g < ngroups)
+        {
+          stage_group(srow,sxg);
+          if (g+1 < ngroups)
+            fetch(g+1,srow,sxg);
+        }
+      // ======================================================================== interval A
+      if constexpr (BLEND)
+        if (alpha_wave && !MH_HKNOCKED(2))
+          {
+            // ---- the alpha levels of group g-1 from the class tiles of interval B: first thing in
+            // the interval (the tiles free their registers for the column pass below)
+            double sums_alpha[4];
+            if (!MH_HKNOCKED(8))
+              exact_sums(tiles,args.offset,sums_alpha);
+            else
+              sums_alpha[0]=sums_alpha[1]=sums_alpha[2]=sums_alpha[3]=0.0;
+            unsigned q[4];
+            const bool doubtful=exact_levels<false>(sums_alpha,args,q);
+            // the real sums (levels) for the colour quotients
+#pragma unroll
+            for (int r=0; r < 4; r++)
+              alpha_sum[(4*kq+r)*G::DSTRIDE+16*alpha_tile+n]=(float) (sums_alpha[r]*args.alpha_scale);
+            const int x=x0+16*alpha_tile+n;
+            {
+              // the alpha levels of sample v of the windows of lane `from`'s four rows
+              auto fetch_alpha=[&](int from,int v,unsigned (&level)[4])
+              {
+                int xx=x0+16*alpha_tile+(from & 15)-args.shift+v;
+                xx=xx < 0 ? 0 : (xx > W-1 ? W-1 : xx);
+#pragma unroll
+                for (int r=0; r < 4; r++)
+                  {
+                    int yy=in0+G::GROUP*(g-1)+4*(from >> 4)+r;
+                    yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
+                    level[r]=(unsigned) args.src[pixel_index(yy,W,xx)*4+3];
+                  }
+              };
+              recomputed+=settle_doubtful_pixels<false,4>(doubtful && (g >= 1) && (g-1 < ngroups) && (x < W),lane,
+                args.taps64,K,fetch_alpha,q);
+            }
+            // the levels as the column pass's alpha samples (level/2: hi + lo is exact)
+            uint2 hi,lo;
+            split_f16_pair(f32x2{0.5f*(float) q[0],0.5f*(float) q[1]},hi.x,lo.x);
+            split_f16_pair(f32x2{0.5f*(float) q[2],0.5f*(float) q[3]},hi.y,lo.y);
+            const int at=ring_alpha16+previous*GROUP_STRIDE;     // group g-1's slot
+            *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
+            *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
+          }
+      // ---- f16 column pass of block cb, whole (products, division, rounding) -> out_tile
+      if ((cb >= 0) && (cb < nblocks))
+        {
+          int chunk_at[NC];
+#pragma unroll
+          for (int c=0; c < NC; c++)
+            {
+              const unsigned wide=(unsigned) (first+2*c+(kq >> 1));
+              const unsigned group=wide < wide-(unsigned) G::NR ? wide : wide-(unsigned) G::NR;
+              chunk_at[c]=col_entry16+GROUP_STRIDE*(int) group;
+            }
+          auto column_tiles=[&](auto count)
+          {
+            constexpr int N=decltype(count)::value;
+            floatx4 acc[N > 0 ? N : 1];
+#pragma unroll
+            for (int i=0; i < N; i++)
+              acc[i]=floatx4{0.0f,0.0f,0.0f,0.0f};
+#pragma unroll
+            for (int c=0; c < NC; c++)
+              {
+                half8 a_hi[N > 0 ? N : 1],a_lo[N > 0 ? N : 1];
+#pragma unroll
+                for (int i=0; i < N; i++)
+                  {
+                    a_hi[i]=*reinterpret_cast<const half8 *>(ring_hi+chunk_at[c]+4*i*F::SC);
+                    a_lo[i]=*reinterpret_cast<const half8 *>(ring_lo+chunk_at[c]+4*i*F::SC);
+                  }
+#pragma unroll
+                for (int i=0; i < N; i++)
+                  acc[i]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[i],t_hi[c],acc[i],0,0,0);
+#pragma unroll
+                for (int i=0; i < N; i++)
+                  acc[i]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[i],t_hi[c],acc[i],0,0,0);
+#pragma unroll
+                for (int i=0; i < N; i++)
+                  acc[i]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[i],t_lo[c],acc[i],0,0,0);
+              }
+#pragma unroll
+            for (int i=0; i < N; i++)
+              out_tile[n*G::OUT_STRIDE+4*(ctile0+i)+kq]=sums_to_quantum<SAMPLES>(acc[i][0],acc[i][1],acc[i][2],acc[i][3]);
+          };
+          if (ctiles == CT)
+            column_tiles(std::integral_constant<int,CT>{});
+          else if (ctiles == CT-1)
+            column_tiles(std::integral_constant<int,CT-1>{});
+        }
+      __syncthreads();                           // X: group g staged, the alpha of group g-1 published
+      // ======================================================================== interval B
+      {
+        // the colour epilogue's view of the exact alpha of group g-1, read first: the chains below hide
+        // the LDS latency (at the head of the epilogue's dependent chain it cost 0.04 ms per frame)
+        float half_alpha=32767.5f,total=65535.0f;
+        if constexpr (BLEND)
+          if (!MH_HKNOCKED(4))
+            {
+              const int own=ring_own_alpha16+previous*GROUP_STRIDE;
+              half_alpha=(float) ring_hi[own]+(float) ring_lo[own];
+              total=alpha_sum[(4*rq+kq)*G::DSTRIDE+16*ot+n];
+            }
+        if constexpr (BLEND)
+          if (alpha_wave && !MH_HKNOCKED(1))
+            {
+              // ---- the exact alpha sums of this wave's 16 x 16 tile.  Sample = level*2^16: byte
+              // planes 2 (low) and 3 (high); the products b_3 x d_j (class j) and b_2 x d_j
+              // (class j-1; b_2 x d_0 is dropped: part of the error bound) digit by digit, so that
+              // a digit's operand lives for two instructions (blur_exact_common.hpp)
+#pragma unroll
+              for (int c=0; c < 5; c++)
+                tiles[c]=intx4{0,0,0,0};
+              {
+                const intx4 low=*reinterpret_cast<const intx4 *>(alpha_plane+alpha_entry);
+                const intx4 high=*reinterpret_cast<const intx4 *>(alpha_plane+G::GROUP*G::ASTRIDE+alpha_entry);
+#pragma unroll
+                for (int j=0; j < kExactDigits; j++)
+                  {
+                    const unsigned *window=reinterpret_cast<const unsigned *>(digit_table+digit_entry+j*G::DLP);
+                    const intx4 digit={(int) window[0],(int) window[1],(int) window[2],(int) window[3]};
+                    tiles[j]=digit_product(high,digit,tiles[j]);
+                    if (j >= 1)
+                      tiles[j-1]=digit_product(low,digit,tiles[j-1]);
+                  }
+              }
+              if constexpr (G::NX == 2)
+                {
+                  const int at=alpha_entry+64-8*kq;          // columns 64+8*kq .. +7
+                  const long low=*reinterpret_cast<const long *>(alpha_plane+at);
+                  const long high=*reinterpret_cast<const long *>(alpha_plane+G::GROUP*G::ASTRIDE+at);
+#pragma unroll
+                  for (int j=0; j < kExactDigits; j++)
+                    {
+                      const unsigned *window=reinterpret_cast<const unsigned *>(digit_table+digit_entry+64-8*kq+j*G::DLP);
+                      const long digit=(long) (((unsigned long) window[1] << 32) | (unsigned long) window[0]);
+                      tiles[j]=digit_product(high,digit,tiles[j]);
+                      if (j >= 1)
+                        tiles[j-1]=digit_product(low,digit,tiles[j-1]);
+                    }
+                }
+            }
+        // ---- f16 row chain of group g
+        floatx4 acc={0.0f,0.0f,0.0f,0.0f};
+#pragma unroll
+        for (int c=0; c < NC; c++)
+          {
+            const half8 a_hi=*reinterpret_cast<const half8 *>(stage_hi+row_entry+32*c);
+            const half8 a_lo=*reinterpret_cast<const half8 *>(stage_lo+row_entry+32*c);
+            acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi,t_hi[c],acc,0,0,0);
+            acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo,t_hi[c],acc,0,0,0);
+            acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi,t_lo[c],acc,0,0,0);
+          }
+        // ---- colour epilogue of group g-1 (beside the chains above): lane (n, kq) = the four channels of pixel (row 4*rq+kq,
+        // column 16*ot+n).  The column pass's samples, UNROUNDED:
+        //   alpha-weighted: A*R_c*2^-17 with A = the exact alpha level (ring, interval B) and
+        //                   R_c = sum(k*alpha*p)/sum(k*alpha) = 2^9*S_c/D;  A/2 for the alpha channel
+        //   plain:          level/2 = S/256
+        {
+          float v[4];
+          if constexpr (BLEND)
+            {
+              // all-transparent window: D = 0 and A = 0 -> 0*inf = NaN -> v_max_f32 returns the 0
+              // (PerceptibleReciprocal's clamp times a zero pixel sum, morphology.c:2974-2977)
+              const float weight=half_alpha*(1.0f/128.0f)*__builtin_amdgcn_rcpf(total);
+              v[0]=__builtin_fmaxf(sums_row[0]*weight,0.0f);
+              v[1]=__builtin_fmaxf(sums_row[1]*weight,0.0f);
+              v[2]=__builtin_fmaxf(sums_row[2]*weight,0.0f);
+              v[3]=half_alpha;
+            }
+          else
+            {
+              v[0]=sums_row[0]*(1.0f/256.0f); v[1]=sums_row[1]*(1.0f/256.0f);
+              v[2]=sums_row[2]*(1.0f/256.0f); v[3]=sums_row[3]*(1.0f/256.0f);
+            }
+          // 4x4 transpose between the registers (channels) and the four 16-lane rows (pixel rows)
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
+                       "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"
+                       : "+v"(v[0]),"+v"(v[1]),"+v"(v[2]),"+v"(v[3]));
+          uint2 hi,lo;
+          split_f16_pair(f32x2{v[0],v[1]},hi.x,lo.x);
+          split_f16_pair(f32x2{v[2],v[3]},hi.y,lo.y);
+          // (alpha-weighted: the lanes of channel 3 rewrite what the alpha wave stored — same bits)
+          const int at=ring_entry16+previous*GROUP_STRIDE;
+          *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
+          *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
+        }
+        // the store of the column pass's rows
+        store_row(cb,opaque_tid & 63);
+        // (the five class tiles cross barrier Y as they are: exact_sums at the end of this interval
+        // kept everybody waiting for the alpha waves, 0.05 ms per frame)
+        // (the wait states between the chain and the first vector read of its tile, whatever the
+        // block layout: hipcc pads them per basic block — see settle_tiles)
+        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));
+        sums_row=acc;
+      }
+      __syncthreads();                           // Y: ring group g-1 complete, out_tile read, staging reads done
+      ring_group=ring_group+1 == G::NR ? 0 : ring_group+1;
+    }
+  if ((args.recomputed != nullptr) && (recomputed != 0u) && (lane == 0))     // a wave-uniform count
+    atomicAdd(args.recomputed,(unsigned long long) recomputed);
+}
+
+template<int NC,int MODE>
+static MhStatus launch_hybrid_typed(const View &src,BlurExactArgs &args)
+{
+  constexpr bool BLEND=MODE == MFMA_BLEND4;
+  typedef HybridGeometry<NC,BLEND> G;
+  args.strips=(args.columns+G::COLS-1)/G::COLS;
+  args.blocks=(args.rows+G::GROUP-1)/G::GROUP;
+  // Cut the strips so that every CU gets a work item.  A segment recomputes NG-1 ring groups
+  // (the K-1 halo rows of its first block), so it stays at least 16 blocks long.
+  const int cus=compute_units(src.device);
+  const int max_segments=args.blocks/16 > 1 ? args.blocks/16 : 1;
+  int segments=(cus+args.strips-1)/args.strips;
+  segments=segments < 1 ? 1 : (segments > max_segments ? max_segments : segments);
+  const int forced_segments=(int) option_long("MAGICKHIP_FUSED_SEGMENTS",0);
+  if (forced_segments > 0)
+    segments=forced_segments > args.blocks ? args.blocks : forced_segments;
+  args.blocks_per_segment=(args.blocks+segments-1)/segments;
+  args.segments=(args.blocks+args.blocks_per_segment-1)/args.blocks_per_segment;   // no empty segment
+  const int items=args.strips*args.segments;
+  args.items_per_xcd=(items+7)/8;
+  const size_t lds=G::lds_bytes;
+  static bool attribute_set[64]={};              // once per kernel and device
+  const int slot=src.device >= 0 && src.device < 64 ? src.device : 0;
+  if (!attribute_set[slot])
+    {
+      MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&blur_fused_hybrid_kernel<NC,MODE>),
+        hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+      attribute_set[slot]=true;
+    }
+  ProfileScope prof("blur_fused_hybrid",src.stream);
+  hipLaunchKernelGGL((blur_fused_hybrid_kernel<NC,MODE>),dim3((unsigned) (8*args.items_per_xcd)),dim3(1024),lds,
+    src.stream,args);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+template<int NC>
+static MhStatus launch_hybrid_modes(const View &src,BlurExactArgs &args,bool blend)
+{
+  if (src.channels == 3)
+    return launch_hybrid_typed<NC,MFMA_PLAIN3>(src,args);
+  return blend ? launch_hybrid_typed<NC,MFMA_BLEND4>(src,args) : launch_hybrid_typed<NC,MFMA_PLAIN4>(src,args);
+}
+
+// taps: host doubles in the reversed walk of morphology.c:2746 (taps[v] multiplies the input at
+// o-shift+v), all positive.  *handled = false: the shape or the taps are outside the kernel's
+// reach, nothing was launched.
+MhStatus launch_blur_fused_hybrid(const View &src,const View &dst,const double *taps,int ntaps,int shift,
+  bool blend,bool *handled)
+{
+  *handled=false;
+  if ((src.quantum != MH_QUANTUM_U16) || (dst.quantum != MH_QUANTUM_U16) ||
+      ((src.channels != 4) && ((src.channels != 3) || blend)) ||
+      (dst.channels != src.channels) || (src.columns != dst.columns) || (src.rows != dst.rows) || (ntaps < 2))
+    return MH_OK;
+  if ((src.columns >= (1u << 24)) || (src.rows >= (1u << 24)) ||
+      ((unsigned long long) src.columns*src.rows >= (1ull << 32)))
+    return MH_OK;                                // pixel_index()
+  if (ntaps > 81)
+    return MH_OK;                                // three 32-row ring chunks hold 94 band slots
+  // the digits and the certificate of the alpha sums (plain frames use the f16 taps only, but the
+  // plan's conditions — positive, finite taps — are what the f16 error argument assumes too)
+  const ExactTapPlan plan=plan_exact_taps(taps,ntaps);
+  if (!plan.ok)
+    return MH_OK;
+  ExactDeviceTaps device;
+  MH_TRY(upload_exact_taps(src,taps,ntaps,plan,&device));
+  BlurExactArgs args;
+  args.src=static_cast<const uint16_t *>(src.pixels);
+  args.dst=static_cast<uint16_t *>(dst.pixels);
+  args.columns=(int) src.columns;
+  args.rows=(int) src.rows;
+  args.ntaps=ntaps;
+  args.shift=shift;
+  args.taps64=device.taps64;
+  args.taps=device.taps;
+  args.digits=device.digits;
+  args.offset=plan.offset_plain;                 // the alpha tiles: samples level*2^16
+  args.alpha_scale=plan.alpha_scale;
+  args.colour_window=plan.colour_window;
+  args.alpha_half_window=0.5-plan.alpha_window_plain;
+  args.alpha_floor=plan.alpha_floor;
+  args.gain=0.0f;
+  args.threshold=(int) option_long("MAGICKHIP_HYBRID_KNOCK",0);       // diagnostic builds only (MH_HKNOCKED)
+  args.recomputed=exact_recomputed_counter(src.device);
+  args.trace=nullptr;
+  *handled=true;
+  const int nc=(ntaps+15+31)/32;                 // 16 outputs + K-1 halo, in 32-sample chunks
+  if (nc == 1)
+    return launch_hybrid_modes<1>(src,args,blend);
+  if (nc == 2)
+    return launch_hybrid_modes<2>(src,args,blend);
+  if (nc == 3)
+    return launch_hybrid_modes<3>(src,args,blend);
+  *handled=false;
+  return MH_OK;
+}
+
+} // namespace mh

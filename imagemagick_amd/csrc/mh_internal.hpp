@@ -274,6 +274,10 @@ constexpr int kExactDigitPitch=96;       // digits of one weight, padded (K <= 8
 MhStatus launch_blur_fused_exact(const View &src,const View &dst,const double *taps,int ntaps,int shift,
   bool blend,bool exact_column,bool *handled,bool unsharp=false,double gain=0.0,double threshold=0.0,
   unsigned long long *recomputed_device=nullptr);
+// FAST BlurImage in one launch: f16 colour sums in both passes, the row pass's alpha as exact integer
+// sums (convolve_fused_hybrid.hip); within +-1 level by construction.  taps as above.
+MhStatus launch_blur_fused_hybrid(const View &src,const View &dst,const double *taps,int ntaps,int shift,
+  bool blend,bool *handled);
 // UnsharpMaskImage's column pass + epilogue in one launch: rows = the row pass's result,
 // original = the unblurred frame (effect.c:4343-4372)
 MhStatus launch_conv1d_unsharp(const View &rows,const View &dst,const View &original,

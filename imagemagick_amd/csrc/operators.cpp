@@ -529,7 +529,20 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
       std::vector<double> reversed((size_t) K);
       for (int v=0; v < K; v++)
         reversed[(size_t) v]=row->values[K-1-v];
-      MH_TRY(launch_blur_fused_exact(src,dst,reversed.data(),K,K-1-(int) row->x,roles.blend,exact,handled,
+      // FAST BlurImage: f16 colour sums + exact alpha sums (convolve_fused_hybrid.hip), +-1 level
+      // by construction at 0.6 of the all-exact row pass's matrix instructions.
+      // FAST UnsharpMaskImage takes the all-exact kernel: a blurred sample one level off moves the
+      // sharpened one by `gain` levels and flips the threshold test next to it — only the
+      // reference's own blur keeps effect.c:4364-4369 within the +-1 contract (it is then
+      // bit-identical).  MAGICKHIP_NO_HYBRID=1: the exact row pass + f16 column pass of round 3.
+      if (!exact && !unsharp && (option("MAGICKHIP_NO_HYBRID") == nullptr))
+        {
+          MH_TRY(launch_blur_fused_hybrid(src,dst,reversed.data(),K,K-1-(int) row->x,roles.blend,handled));
+          if (*handled)
+            return MH_OK;
+        }
+      const bool exact_column=exact || (unsharp && (option("MAGICKHIP_FAST_UNSHARP") == nullptr));
+      MH_TRY(launch_blur_fused_exact(src,dst,reversed.data(),K,K-1-(int) row->x,roles.blend,exact_column,handled,
         unsharp,gain,threshold,nullptr));
       if (*handled)
         return MH_OK;

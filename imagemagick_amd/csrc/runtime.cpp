@@ -817,8 +817,12 @@ namespace mh {
 struct PinnedBlocks
 {
   std::mutex lock;
-  std::map<const char *,size_t> blocks;         // base -> bytes
+  std::map<const char *,size_t> blocks;         // base -> bytes (handed out)
   size_t total=0;
+  // released blocks kept for the next pixel cache of that size: page-locking 537 MB costs ~25 ms,
+  // more than the BlurImage it is allocated for (CloneImage -> AcquireAlignedMemory per result)
+  std::multimap<size_t,void *> spare;           // bytes -> base
+  size_t spare_total=0;
 };
 static PinnedBlocks &pinned_blocks() { static PinnedBlocks &p=*new PinnedBlocks; return p; }
 
@@ -837,6 +841,8 @@ bool host_block_is_pinned(const void *block,size_t bytes)
   return (at >= it->first) && (at+bytes <= it->first+it->second);
 }
 } // namespace mh
+
+static void release_spare_pinned_blocks(size_t keep_bytes);
 
 extern "C" {
 
@@ -860,6 +866,7 @@ MH_API void MhTerminus(void)
   staging_trim();
   release_color_tables();
   release_batch_streams();
+  release_spare_pinned_blocks(0);
   std::vector<std::pair<int,hipStream_t>> streams;
   {
     std::lock_guard<std::mutex> guard(r.lock);
@@ -1026,16 +1033,48 @@ MH_API void *MhHostAlloc(size_t bytes)
   if ((runtime_ready() != MH_OK) || (bytes == 0))
     return nullptr;
   void *block=nullptr;
+  PinnedBlocks &p=pinned_blocks();
+  {
+    std::lock_guard<std::mutex> guard(p.lock);
+    auto it=p.spare.lower_bound(bytes);
+    if ((it != p.spare.end()) && (it->first <= bytes+bytes/8))
+      {
+        block=it->second;
+        p.spare_total-=it->first;
+        p.blocks[static_cast<const char *>(block)]=it->first;
+        p.total+=it->first;
+        p.spare.erase(it);
+        return block;
+      }
+  }
   if (hipHostMalloc(&block,bytes,hipHostMallocPortable) != hipSuccess)
     {
       (void) hipGetLastError();
       return nullptr;
     }
-  PinnedBlocks &p=pinned_blocks();
   std::lock_guard<std::mutex> guard(p.lock);
   p.blocks[static_cast<const char *>(block)]=bytes;
   p.total+=bytes;
   return block;
+}
+
+// the spare page-locked blocks go back to the system (MhTerminus, or to make room)
+static void release_spare_pinned_blocks(size_t keep_bytes)
+{
+  PinnedBlocks &p=pinned_blocks();
+  std::vector<void *> victims;
+  {
+    std::lock_guard<std::mutex> guard(p.lock);
+    while ((p.spare_total > keep_bytes) && !p.spare.empty())
+      {
+        auto it=p.spare.begin();
+        p.spare_total-=it->first;
+        victims.push_back(it->second);
+        p.spare.erase(it);
+      }
+  }
+  for (void *block : victims)
+    (void) hipHostFree(block);
 }
 
 MH_API int MhHostFree(void *block)
@@ -1043,15 +1082,27 @@ MH_API int MhHostFree(void *block)
   if (block == nullptr)
     return 0;
   PinnedBlocks &p=pinned_blocks();
+  // MAGICKHIP_PINNED_SPARE_BYTES: how much released page-locked memory is kept for reuse (default 4 GiB)
+  const size_t spare_limit=(size_t) option_long("MAGICKHIP_PINNED_SPARE_BYTES",(long) 4 << 30);
   {
     std::lock_guard<std::mutex> guard(p.lock);
     auto it=p.blocks.find(static_cast<const char *>(block));
     if (it == p.blocks.end())
       return 0;
-    p.total-=it->second;
+    const size_t bytes=it->second;
+    p.total-=bytes;
     p.blocks.erase(it);
+    if (bytes <= spare_limit)
+      {
+        p.spare.emplace(bytes,block);
+        p.spare_total+=bytes;
+        block=nullptr;
+      }
   }
-  (void) hipHostFree(block);
+  if (block != nullptr)
+    (void) hipHostFree(block);
+  else
+    release_spare_pinned_blocks(spare_limit);
   return 1;
 }
 
