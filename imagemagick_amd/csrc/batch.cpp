@@ -284,7 +284,11 @@ static MhStatus working_copy(const MhImage &source,int device,hipStream_t stream
 }
 
 // Copy the chain's output into the caller's descriptor and wait for it.
-static MhStatus deliver(const Working &cur,MhImage &result)
+// pending (optional): streams whose work the CALLER of deliver() waits for later — a result in
+// device memory is then only enqueued here, and the worker does not drain its stream after every
+// image (a drained stream idles the GPU while the host prepares the next chain: 512 images of
+// config C4 took 109 ms for 69 ms of kernels)
+static MhStatus deliver(const Working &cur,MhImage &result,std::vector<std::pair<int,hipStream_t>> *pending=nullptr)
 {
   if ((result.columns != cur.image.columns) || (result.rows != cur.image.rows) ||
       (result.number_channels != cur.image.number_channels) || (result.quantum != cur.image.quantum))
@@ -304,8 +308,18 @@ static MhStatus deliver(const Working &cur,MhImage &result)
           else
             MH_HIP(hipMemcpyPeerAsync(result.pixels,home,cur.image.pixels,cur.device,bytes,cur.stream));
         }
-      // the caller's stream is not ours: the result is complete when this returns
-      MH_HIP(hipStreamSynchronize(cur.stream));
+      // the caller's stream is not ours: the result is complete when this returns, or — pending —
+      // when the caller has waited for the stream
+      if (pending == nullptr)
+        MH_HIP(hipStreamSynchronize(cur.stream));
+      else
+        {
+          bool known=false;
+          for (const auto &entry : *pending)
+            known=known || (entry.second == cur.stream);
+          if (!known)
+            pending->emplace_back(cur.device,cur.stream);
+        }
     }
   result.colorspace=cur.image.colorspace;
   return MH_OK;
@@ -626,6 +640,8 @@ MH_API MhStatus MagickHipBatchImages(const MhOperator *operators,size_t number_o
     MhStatus setup=MH_OK;
     if ((guard.enter(device) != hipSuccess) || (stream == nullptr))
       setup=fail(MH_DEVICE_ERROR,"BatchImages: cannot set up device %d",device);
+    // results in device memory are waited for once, when the worker has enqueued all its images
+    std::vector<std::pair<int,hipStream_t>> pending;
     for (;;)
       {
         const size_t i=next.fetch_add(1);
@@ -678,7 +694,7 @@ MH_API MhStatus MagickHipBatchImages(const MhOperator *operators,size_t number_o
             if (status == MH_OK)
               {
                 MhImage *target=results != nullptr ? &results[i] : const_cast<MhImage *>(&images[i]);
-                status=deliver(cur,*target);
+                status=deliver(cur,*target,&pending);
               }
             else if (cur.stream != nullptr)
               (void) hipStreamSynchronize(cur.stream);
@@ -695,6 +711,22 @@ MH_API MhStatus MagickHipBatchImages(const MhOperator *operators,size_t number_o
           }
         else
           counts[(size_t) logical]++;
+      }
+    for (const auto &entry : pending)
+      {
+        DeviceGuard home;
+        MhStatus status=MH_OK;
+        if ((home.enter(entry.first) != hipSuccess) || (hipStreamSynchronize(entry.second) != hipSuccess))
+          status=fail(MH_DEVICE_ERROR,"BatchImages: a stream of device %d failed",entry.first);
+        if (status != MH_OK)
+          {
+            std::lock_guard<std::mutex> lock(error_lock);
+            if (first_status == MH_OK)
+              {
+                first_status=status;
+                first_error=MhGetLastError();
+              }
+          }
       }
   };
   std::vector<std::thread> pool;

@@ -188,9 +188,11 @@ struct ResizeAcc
 // r's window), so the kernel is a loop over the union rows that loads each
 // source row once and feeds all RY accumulators with wave-uniform weights —
 // no per-(row, output) window tests.  Zero weights are exact no-ops
-// (s + 0*p == s) for finite pixels; the EXACT policy still skips them through a
-// per-row bit mask so that a non-finite float pixel outside an output's window
-// cannot leak into it.
+// (s + 0*p == s) for finite pixels; a FLOAT frame still skips them (both
+// policies) through a per-row bit mask — a wave-uniform test, the weights are
+// scalars — so that a non-finite pixel outside an output's window cannot leak
+// into it (0*inf = NaN; resize.c:3494-3530 only ever multiplies the samples of
+// the window).
 struct VerticalDenseArgs
 {
   const void *src;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256)
 void resize_vertical_kernel(VerticalDenseArgs args)
 {
   typedef typename A::T T;
-  constexpr bool kSkipZeros=std::is_same<A,Exact64>::value && QuantumOps<Q>::is_float;
+  constexpr bool kSkipZeros=QuantumOps<Q>::is_float;
   const int W=args.columns;
   const int lane_x=(int) (blockIdx.x*blockDim.x+threadIdx.x);
   const int tile=(int) blockIdx.y;
@@ -380,9 +382,17 @@ void resize_horizontal_cvt_kernel(ResizeArgs args,int tile_rows,int lds_span)
   typedef typename A::T T;
   // PREMUL (Fma64, alpha-weighted, every channel updated): the tile holds alpha*colour, alpha
   static_assert(!PREMUL || ResizeAcc<Q,C,BLEND,A>::kDerive,"premultiplied staging needs the derived gamma");
+  // Zero-weight padding taps (j >= count) multiply a sample OUTSIDE the output's window by 0: an
+  // exact no-op unless that sample is not finite (0*inf = NaN where the reference never looks,
+  // resize.c:3494-3530).  EXACT on a float frame tests every tap; FAST on a float frame looks at
+  // the samples while it stages them and only a tile that holds a non-finite one takes the tested
+  // loop (kWatch) — two integer instructions per staged sample instead of a test per tap.
   constexpr bool kSkipZeros=std::is_same<A,Exact64>::value && QuantumOps<Q>::is_float;
+  constexpr bool kWatch=!kSkipZeros && QuantumOps<Q>::is_float;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T *tile=reinterpret_cast<T *>(smem_raw);
+  __shared__ int wave_not_finite[4];            // one word per wave of the workgroup: written once, no init
+  bool not_finite=false;
   const int OUT=args.out_size;
   const int x0=(int) blockIdx.x*256;
   const int x=x0+(int) threadIdx.x;
@@ -417,6 +427,14 @@ void resize_horizontal_cvt_kernel(ResizeArgs args,int tile_rows,int lds_span)
             slot[k]=idx;
             load_pixel<Q,C>(src+(size_t) (y0+r)*src_pitch+(size_t) col*C,v[k]);
           }
+        if constexpr (kWatch)
+          {
+#pragma unroll
+            for (int k=0; k < BATCH; k++)
+#pragma unroll
+              for (int c=0; c < C; c++)
+                not_finite=not_finite || ((__builtin_bit_cast(unsigned,(float) v[k][c]) & 0x7f800000u) == 0x7f800000u);
+          }
 #pragma unroll
         for (int k=0; k < BATCH; k++)
           if (i0+256*k < items)
@@ -428,7 +446,15 @@ void resize_horizontal_cvt_kernel(ResizeArgs args,int tile_rows,int lds_span)
             }
       }
   }
+  if constexpr (kWatch)
+    {
+      const int raised=__any(not_finite) ? 1 : 0;
+      if ((threadIdx.x & 63) == 0)
+        wave_not_finite[threadIdx.x >> 6]=raised;
+    }
   __syncthreads();
+  const bool careful=kSkipZeros ||
+    (kWatch && ((wave_not_finite[0] | wave_not_finite[1] | wave_not_finite[2] | wave_not_finite[3]) != 0));
   if (x >= OUT)
     return;
   const int start=args.start[x]-lo;
@@ -464,7 +490,7 @@ void resize_horizontal_cvt_kernel(ResizeArgs args,int tile_rows,int lds_span)
           p[j][c]=line[(size_t) j*C+c];
 #pragma unroll
       for (int j=0; j < MAXT; j++)
-        if (!kSkipZeros || (j < count))           // zero-weight taps are exact no-ops
+        if (!careful || (j < count))              // zero-weight taps are exact no-ops on finite samples
           {
             if constexpr (PREMUL)
               acc.tap_premultiplied(w[j],p[j]);

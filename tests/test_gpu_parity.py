@@ -1480,6 +1480,44 @@ def test_resize_fast_precision(im, refmod, dtype, target):
     assert exact > 0.999
 
 
+@pytest.mark.parametrize("precision", ["exact", "fast"])
+@pytest.mark.parametrize("target", [(560, 940), (31, 47), (300, 33)])
+@pytest.mark.parametrize("alpha", [True, False])
+def test_resize_float_frame_with_non_finite_samples(im, refmod, precision, target, alpha):
+    """A float frame with +-Inf and NaN samples: the passes pad their tap lists
+    with zero weights, and 0*inf = NaN must not reach an output whose window does not hold the
+    sample — the reference only ever multiplies the samples of the window (resize.c:3494-3530).
+    The vertical pass skips zero weights (a scalar test), the horizontal pass watches the samples
+    it stages and takes a tested tap loop for a tile that holds a non-finite one.  Same NaN / Inf
+    pattern as the reference, everything else within the mode's contract; enlargement, reduction
+    and a mixed resize."""
+    rng = np.random.default_rng(target[0] + (3 if alpha else 0))
+    px = make_pixels(140, 235, 4, HDRI, seed=target[1])
+    for value in (np.inf, -np.inf, np.nan):
+        for _ in range(6):
+            y, x, c = int(rng.integers(0, 140)), int(rng.integers(0, 235)), int(rng.integers(0, 4))
+            px[y, x, c] = value
+    px[70, 100:104, :] = np.inf                       # a run of whole pixels
+    dev = im.Image(to_device(px), has_alpha=alpha)
+    if alpha:
+        want = refmod.RefImage(px).resize(target[0], target[1], "Lanczos").numpy()
+    else:
+        want = np.concatenate([refmod.RefImage(px[:, :, c].copy()).resize(target[0], target[1], "Lanczos").numpy()
+                               .reshape(target[1], target[0], 1) for c in range(4)], axis=2)
+    im.set_precision(im.PRECISION_FAST if precision == "fast" else im.PRECISION_EXACT)
+    try:
+        got = im.resize_image(dev, target[0], target[1], "Lanczos").numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), "NaN pattern differs: %d vs %d" % (
+        int(np.isnan(got).sum()), int(np.isnan(want).sum()))
+    assert np.array_equal(np.isinf(got), np.isinf(want)) and np.array_equal(got[np.isinf(got)], want[np.isinf(want)])
+    finite = np.isfinite(want)
+    assert finite.sum() > 0.5 * want.size
+    assert_parity(np.where(finite, got, 0.0).astype(np.float32), np.where(finite, want, 0.0).astype(np.float32),
+                  precision == "exact", "resize of a frame with non-finite samples", max_ulp=0 if precision == "exact" else 1)
+
+
 # ------------------------------------------------------------------ colourspace
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
 @pytest.mark.parametrize("src,dst", [("sRGB", "RGB"), ("RGB", "sRGB"), ("sRGB", "Lab"),
