@@ -113,7 +113,8 @@ struct HybridGeometry
 // skipped at run time (bits of MAGICKHIP_HYBRID_KNOCK, handed over in args.threshold) to see what
 // each costs.  The results are wrong.  1 the alpha tiles' digit loads and products, 2 the alpha
 // epilogue of interval A, 4 the colour epilogue's reads of the exact alpha, 8 exact_sums,
-// 16 the staging of the alpha byte planes
+// 16 the staging of the alpha byte planes; 32 / 64 / 128: plain-channel arithmetic in the staging /
+// the colour epilogue / the column pass's epilogue of an alpha-weighted frame
 #ifdef MH_HYBRID_KNOCK
 #define MH_HKNOCKED(bit) ((args.threshold & (bit)) != 0)
 #else
@@ -271,7 +272,10 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
     if (stager)
       {
         f32x2 v[4][2];
-        quantum_to_samples<SAMPLES>(raw,v);
+        if (MH_HKNOCKED(32))
+          quantum_to_samples<MFMA_PLAIN4>(raw,v);
+        else
+          quantum_to_samples<SAMPLES>(raw,v);
         // (one address + immediate offsets)
         unsigned char *to=smem_raw+G::ring_bytes+2*(srow*F::SR+4*sxg);
 #pragma unroll
@@ -458,7 +462,9 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
               }
 #pragma unroll
             for (int i=0; i < N; i++)
-              out_tile[n*G::OUT_STRIDE+4*(ctile0+i)+kq]=sums_to_quantum<SAMPLES>(acc[i][0],acc[i][1],acc[i][2],acc[i][3]);
+              out_tile[n*G::OUT_STRIDE+4*(ctile0+i)+kq]=MH_HKNOCKED(128) ?
+                sums_to_quantum<MFMA_PLAIN4>(acc[i][0],acc[i][1],acc[i][2],acc[i][3]) :
+                sums_to_quantum<SAMPLES>(acc[i][0],acc[i][1],acc[i][2],acc[i][3]);
           };
           if (ctiles == CT)
             column_tiles(std::integral_constant<int,CT>{});
@@ -483,38 +489,47 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
             {
               // ---- the exact alpha sums of this wave's 16 x 16 tile.  Sample = level*2^16: byte
               // planes 2 (low) and 3 (high); the products b_3 x d_j (class j) and b_2 x d_j
-              // (class j-1; b_2 x d_0 is dropped: part of the error bound) digit by digit, so that
-              // a digit's operand lives for two instructions (blur_exact_common.hpp)
+              // (class j-1; b_2 x d_0 is dropped: part of the error bound), blur_exact_common.hpp
 #pragma unroll
               for (int c=0; c < 5; c++)
                 tiles[c]=intx4{0,0,0,0};
               {
                 const intx4 low=*reinterpret_cast<const intx4 *>(alpha_plane+alpha_entry);
                 const intx4 high=*reinterpret_cast<const intx4 *>(alpha_plane+G::GROUP*G::ASTRIDE+alpha_entry);
+                intx4 digit[kExactDigits];
 #pragma unroll
                 for (int j=0; j < kExactDigits; j++)
                   {
                     const unsigned *window=reinterpret_cast<const unsigned *>(digit_table+digit_entry+j*G::DLP);
-                    const intx4 digit={(int) window[0],(int) window[1],(int) window[2],(int) window[3]};
-                    tiles[j]=digit_product(high,digit,tiles[j]);
-                    if (j >= 1)
-                      tiles[j-1]=digit_product(low,digit,tiles[j-1]);
+                    digit[j]=intx4{(int) window[0],(int) window[1],(int) window[2],(int) window[3]};
                   }
+                // five tiles, then four: an instruction's tile was last written five instructions
+                // earlier (a dependent v_mfma waits for its predecessor's passes)
+#pragma unroll
+                for (int j=0; j < kExactDigits; j++)
+                  tiles[j]=digit_product(high,digit[j],tiles[j]);
+#pragma unroll
+                for (int j=1; j < kExactDigits; j++)
+                  tiles[j-1]=digit_product(low,digit[j],tiles[j-1]);
               }
               if constexpr (G::NX == 2)
                 {
                   const int at=alpha_entry+64-8*kq;          // columns 64+8*kq .. +7
                   const long low=*reinterpret_cast<const long *>(alpha_plane+at);
                   const long high=*reinterpret_cast<const long *>(alpha_plane+G::GROUP*G::ASTRIDE+at);
+                  long digit[kExactDigits];
 #pragma unroll
                   for (int j=0; j < kExactDigits; j++)
                     {
                       const unsigned *window=reinterpret_cast<const unsigned *>(digit_table+digit_entry+64-8*kq+j*G::DLP);
-                      const long digit=(long) (((unsigned long) window[1] << 32) | (unsigned long) window[0]);
-                      tiles[j]=digit_product(high,digit,tiles[j]);
-                      if (j >= 1)
-                        tiles[j-1]=digit_product(low,digit,tiles[j-1]);
+                      digit[j]=(long) (((unsigned long) window[1] << 32) | (unsigned long) window[0]);
                     }
+#pragma unroll
+                  for (int j=0; j < kExactDigits; j++)
+                    tiles[j]=digit_product(high,digit[j],tiles[j]);
+#pragma unroll
+                  for (int j=1; j < kExactDigits; j++)
+                    tiles[j-1]=digit_product(low,digit[j],tiles[j-1]);
                 }
             }
         // ---- f16 row chain of group g
@@ -535,7 +550,7 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
         //   plain:          level/2 = S/256
         {
           float v[4];
-          if constexpr (BLEND)
+          if (BLEND && !MH_HKNOCKED(64))
             {
               // all-transparent window: D = 0 and A = 0 -> 0*inf = NaN -> v_max_f32 returns the 0
               // (PerceptibleReciprocal's clamp times a zero pixel sum, morphology.c:2974-2977)

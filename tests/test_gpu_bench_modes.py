@@ -23,7 +23,8 @@ def free_port():
 
 @pytest.mark.parametrize("config,size", [("c2", 1024), ("c4", 256), ("c5", 1536), ("equalize", 2048)])
 def test_bench_two_ranks(config, size):
-    env = dict(os.environ, MAGICKHIP_BENCH_RAMP="0.05", MAGICKHIP_BENCH_WATCHDOG="150")
+    env = dict(os.environ, MAGICKHIP_BENCH_RAMP="0.05", MAGICKHIP_BENCH_WATCHDOG="150",
+               MAGICKHIP_BENCH_SECONDARY_SIZE="1280")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", config, "--size", str(size),
@@ -35,3 +36,13 @@ def test_bench_two_ranks(config, size):
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0
     assert line["scaling"] == ("weak" if config == "c2" else "strong")
     assert line["unit"] == "Mpixels/s" and line["config"]["config"] == config
+    assert len(line["per_rank_ms_per_step"]) == 2
+    if config == "c2":
+        # the default invocation (what the driver launches on 2/4/8 GPUs) also reports the configurations
+        # with a collective / with row bands, a few steps each
+        multi = line["multi_gpu"]
+        assert set(multi) == {"equalize", "c5", "c4"}, multi
+        for name, entry in multi.items():
+            assert entry["Mpixels_per_s"] > 0 and len(entry["per_rank_ms_per_step"]) == 2, (name, entry)
+        assert "used_rccl" in line["collective"] and line["collective"]["equalize_ms_per_step"] > 0
+        assert line["collective"]["backend"] == "gloo" and line["collective"]["used_rccl"] is False
