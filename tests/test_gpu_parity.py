@@ -2004,33 +2004,61 @@ def test_function(im, refmod, dtype, function, params):
 
 def test_operators_are_reentrant_across_threads_and_streams(im, refmod):
     """SURVEY §8b threading: operators may be called concurrently from user threads; each call
-    here runs on its own torch stream (MhImage::stream) with its own image."""
+    here runs on its own torch stream (MhImage::stream) with its own image.  EXACT and FAST
+    threads run AT THE SAME TIME: the precision belongs to the call
+    (MhImage::precision), not to the process — the even threads ask for EXACT and must be
+    bit-identical, the odd ones for FAST (the hybrid blur kernel) and must be within +-1, while
+    the library-wide default is flipped back and forth underneath them."""
     import threading
     import torch
     jobs = []
     for i in range(6):
         px = make_pixels(120 + 8 * i, 150, 4, Q16, seed=100 + i)
-        jobs.append((px, refmod.RefImage(px).blur(0.0, 3.0).resize(90, 70, "Lanczos").numpy()))
+        jobs.append((px, refmod.RefImage(px).blur(0.0, 3.0).resize(90, 70, "Lanczos").numpy(),
+                     refmod.RefImage(px).blur(0.0, 3.0).numpy()))
     results = [None] * len(jobs)
+    blurred = [None] * len(jobs)
+    launched = [None] * len(jobs)
     errors = []
 
     def work(k):
         try:
             stream = torch.cuda.Stream()
             with torch.cuda.stream(stream):
-                dev = im.Image(to_device(jobs[k][0]))
-                out = im.resize_image(im.blur_image(dev, 0.0, 3.0), 90, 70, "Lanczos")
+                precision = im.PRECISION_FAST if k % 2 else im.PRECISION_EXACT
+                dev = im.Image(to_device(jobs[k][0]), precision=precision)
+                blur = im.blur_image(dev, 0.0, 3.0)
+                out = im.resize_image(blur, 90, 70, "Lanczos")
                 stream.synchronize()
                 results[k] = out.numpy()
+                blurred[k] = blur.numpy()
         except Exception as exc:                      # surfaced below
             errors.append(exc)
 
-    for _ in range(3):
-        threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+    for round_ in range(3):
+        im.set_precision(im.PRECISION_FAST if round_ % 2 else im.PRECISION_EXACT)     # the default: nobody's business
+        try:
+            threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            im.set_precision(im.PRECISION_EXACT)
         assert not errors, errors
-        for k, (_, want) in enumerate(jobs):
-            assert_parity(results[k], want, True, "thread %d" % k)
+        for k, (_, want, want_blur) in enumerate(jobs):
+            if k % 2 == 0:
+                assert_parity(blurred[k], want_blur, True, "EXACT thread %d: blur" % k)
+                assert_parity(results[k], want, True, "EXACT thread %d" % k)
+            else:
+                assert_parity(blurred[k], want_blur, False, "FAST thread %d: blur" % k)
+    # ... and the FAST calls really took the FAST kernel (not the default's)
+    import bench
+    dev = im.Image(to_device(jobs[1][0]), precision=im.PRECISION_FAST)
+    assert set(bench.kernel_profile(im, lambda: im.blur_image(dev, 0.0, 3.0), 1)) == {"blur_fused_hybrid"}
+    dev = im.Image(to_device(jobs[1][0]), precision=im.PRECISION_EXACT)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        assert set(bench.kernel_profile(im, lambda: im.blur_image(dev, 0.0, 3.0), 1)) == {"blur_fused_exact"}
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
