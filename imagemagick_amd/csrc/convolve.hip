@@ -19,6 +19,8 @@
 // one-slot-per-R padding that makes the stride-R reads bank-conflict free.
 #include "mh_internal.hpp"
 #include "device_common.hpp"
+#include "tie_check.hpp"
+#include "separable_args.hpp"
 #include <cstdlib>
 #include <vector>
 #include <type_traits>
@@ -1579,6 +1581,450 @@ static MhStatus dispatch_tri(const View &src,const View &dst,bool vertical,
       return launch_tri<Q,4,false,A,R,U>(src,dst,vertical,p,roles,changed);
     default: break;
   }
+  return fail(MH_UNSUPPORTED,"%d channels",src.channels);
+}
+
+// ---------------------------------------------------------------- folded separable passes
+// convolve_separable.hip's four steps (premultiply -> row sums -> column sums -> finish: 216 bytes
+// per RGBA Q16 pixel through HBM) as TWO launches moving 80: the row pass reads the frame's
+// Quantum samples, forms P = (alpha*p .., alpha) on the way into its sums (Accum::prepare of a
+// premultiplying fp64 policy: the product of two Quantum values is exact) and stores 4 doubles
+// per pixel; the column pass reads those, and what leaves its accumulators goes straight through
+// settle_sums (tie_check.hpp) to the destination frame — the undecided samples recomputed by
+// the whole wave in the reference's order, as separable_finish_kernel does.
+struct Premultiplied64
+{
+  typedef double T;
+  static constexpr bool premultiply=true;
+  static constexpr bool taps_in_lds=false;
+  static constexpr bool tie_check=false;
+  static __device__ __forceinline__ T mul(T a,T b) { return a*b; }
+  static __device__ __forceinline__ T add(T a,T b) { return a+b; }
+  static __device__ __forceinline__ T mac(T acc,T a,T b) { return __builtin_fma(a,b,acc); }
+};
+
+template<typename Q,int C,bool BLEND,int R,int U,int WAVES>
+__global__ __launch_bounds__(64*WAVES)
+void separable_row_sums_kernel(Conv1DArgs args,double *bound)
+{
+  typedef Premultiplied64 A;
+  typedef double T;
+  typedef Accum<Q,C,BLEND,A,R> Acc;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane=(int) (threadIdx.x & 63);
+  const int wave=__builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const int W=args.columns,H=args.rows,K=args.ntaps;
+  const int SEG=64*R;
+  const int NS=63*R+R+K-1+U;
+  const int slots=NS+NS/R+1;
+  Q *strip=reinterpret_cast<Q *>(smem_raw)+(size_t) wave*slots*C;
+
+  const unsigned ntx=(unsigned) ((W+SEG-1)/SEG);
+  const unsigned nty=(unsigned) ((H+WAVES-1)/WAVES);
+  const unsigned total=ntx*nty;
+  const unsigned id=blockIdx.x;
+  const unsigned per=(total+7u)/8u;
+  const unsigned tile=(id & 7u)*per+(id >> 3);
+  if (tile >= total)
+    return;
+  const int tx=(int) (tile%ntx),ty=(int) (tile/ntx);
+  const int y=ty*WAVES+wave;
+  const int x0=tx*SEG;
+  const Q *src=static_cast<const Q *>(args.src);
+  const T *table=static_cast<const T *>(args.taps);
+  const size_t pitch=(size_t) W*C;
+  const bool row_ok=y < H;
+  const Q *row=src+(size_t) (row_ok ? y : H-1)*pitch;
+  // float Quantum: the largest |P_c| of the frame, which the column pass's error bound is
+  // relative to — every pixel is staged by at least one wave
+  double most[C];
+#pragma unroll
+  for (int c=0; c < C; c++)
+    most[c]=0.0;
+  {
+    constexpr int BATCH=10;
+    for (int i0=lane; i0 < NS; i0+=64*BATCH)
+      {
+        Q v[BATCH][C];
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          {
+            int i=i0+64*k;
+            int xx=x0-args.shift+(i < NS ? i : NS-1);
+            xx=xx < 0 ? 0 : (xx > W-1 ? W-1 : xx);
+            load_pixel<Q,C>(row+(size_t) xx*C,v[k]);
+          }
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          {
+            int i=i0+64*k;
+            if (i < NS)
+              store_pixel<Q,C>(strip+(size_t) (i+i/R)*C,v[k]);
+            if constexpr (QuantumOps<Q>::is_float)
+              {
+                const double alpha=BLEND ? (double) v[k][C-1] : 1.0;
+#pragma unroll
+                for (int c=0; c < C; c++)
+                  most[c]=__builtin_fmax(most[c],__builtin_fabs((BLEND && (c != C-1)) ? alpha*(double) v[k][c] :
+                    (double) v[k][c]));                                    // (NaN: skipped)
+              }
+          }
+      }
+  }
+  __syncthreads();
+  if constexpr (QuantumOps<Q>::is_float)
+    {
+#pragma unroll
+      for (int c=0; c < C; c++)
+        {
+          double m=most[c];
+          for (int off=32; off > 0; off>>=1)
+            m=__builtin_fmax(m,__shfl_xor(m,off,64));
+          // non-negative doubles order as their bit patterns; an atomic only where it raises the bound
+          const unsigned long long bits=(unsigned long long) __double_as_longlong(m);
+          unsigned long long *word=reinterpret_cast<unsigned long long *>(bound+c);
+          if ((lane == 0) && (bits > __hip_atomic_load(word,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT)))
+            atomicMax(word,bits);
+        }
+    }
+  if (!row_ok)
+    return;
+
+  Acc acc;
+  acc.init((T) 0,K);
+  const Q *mine=strip+(size_t) lane*(R+1)*C;
+  Q nxt[U][C];
+  auto fetch_u=[&](int pos)
+  {
+#pragma unroll
+    for (int jj=0; jj < U; jj++)
+      {
+        const int j=pos+jj;
+        load_pixel<Q,C>(mine+(size_t) (j+j/R)*C,nxt[jj]);
+      }
+  };
+  auto fetch_1=[&](int pos)
+  {
+    load_pixel<Q,C>(mine+(size_t) (pos+pos/R)*C,nxt[0]);
+  };
+  tri_accumulate<Q,C,BLEND,A,R,U>(acc,table,K,fetch_u,fetch_1,nxt);
+
+  double *sums=static_cast<double *>(args.dst)+((size_t) y*W+(size_t) (x0+lane*R))*4;
+#pragma unroll
+  for (int r=0; r < R; r++)
+    if (x0+lane*R+r < W)
+      {
+        double s[4]={0.0,0.0,0.0,0.0};
+#pragma unroll
+        for (int c=0; c < C; c++)
+          s[c]=acc.MH_S(r,c);
+        reinterpret_cast<double2 *>(sums+(size_t) r*4)[0]=make_double2(s[0],s[1]);
+        reinterpret_cast<double2 *>(sums+(size_t) r*4)[1]=make_double2(s[2],s[3]);
+      }
+}
+
+template<typename Q,int C,bool BLEND,int R,int U,int WAVES>
+__global__ __launch_bounds__(64*WAVES)
+void separable_column_finish_kernel(Conv1DArgs args,SeparableArgs sep)
+{
+  typedef Fma64 A;
+  typedef double T;
+  typedef Accum<double,4,false,A,R> Acc;
+  static_assert(R <= 8,"four doubtful bits per output row in one word");
+  const int lane=(int) (threadIdx.x & 63);
+  const int wave=__builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const int W=args.columns,H=args.rows,K=args.ntaps;
+  const unsigned ntx=(unsigned) ((W+63)/64);
+  const unsigned nty=(unsigned) ((H+R*WAVES-1)/(R*WAVES));
+  const unsigned total=ntx*nty;
+  const unsigned id=blockIdx.x;
+  const unsigned per=(total+7u)/8u;
+  const unsigned tile=(id & 7u)*per+(id >> 3);       // XCD-aware: see conv_column_kernel
+  if (tile >= total)
+    return;
+  const int tx=(int) (tile/nty),ty=(int) (tile%nty);
+  const int x=tx*64+lane;
+  const int xc=x < W ? x : W-1;
+  const int y0=(ty*WAVES+wave)*R;
+  if (y0 >= H)
+    return;
+  const double *in=static_cast<const double *>(args.src)+(size_t) xc*4;
+  const size_t pitch=(size_t) W*4;
+  const int ybase=y0-args.shift;
+  const T *table=static_cast<const T *>(args.taps);
+
+  Acc acc;
+  acc.init((T) 0,K);
+  double nxt[U][4];
+  const bool interior=(ybase >= 0) && (ybase+R+K+U <= H);
+  auto fetch_u=[&](int pos)
+  {
+    if (interior)
+      {
+        const double *rowp=in+(size_t) (ybase+pos)*pitch;
+#pragma unroll
+        for (int jj=0; jj < U; jj++)
+          {
+            load_pixel<double,4>(rowp,nxt[jj]);
+            rowp+=pitch;
+          }
+      }
+    else
+      {
+#pragma unroll
+        for (int jj=0; jj < U; jj++)
+          {
+            int yy=ybase+pos+jj;
+            yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
+            load_pixel<double,4>(in+(size_t) yy*pitch,nxt[jj]);
+          }
+      }
+  };
+  auto fetch_1=[&](int pos)
+  {
+    int yy=ybase+pos;
+    yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
+    load_pixel<double,4>(in+(size_t) yy*pitch,nxt[0]);
+  };
+  tri_accumulate<double,4,false,A,R,U>(acc,table,K,fetch_u,fetch_1,nxt);
+
+  const Q *src=static_cast<const Q *>(sep.src);
+  Q *dst=static_cast<Q *>(sep.dst);
+  double error[4]={0.0,0.0,0.0,0.0};
+#pragma unroll
+  for (int c=0; c < C; c++)
+    error[c]=sep.error_unit*(QuantumOps<Q>::is_float ? sep.bound[c] : sep.fixed_bound[c]);
+  uint32_t doubtful=0;                               // four bits per output row of this lane
+#pragma unroll
+  for (int r=0; r < R; r++)
+    {
+      const int y=y0+r;
+      if (y < H)
+        {
+          double s[4];
+#pragma unroll
+          for (int c=0; c < 4; c++)
+            s[c]=acc.MH_S(r,c);
+          if (sep.delta != 0.0)
+            {
+              // + delta * (alpha*p .., alpha) of the one sample the extra cell sees
+              int xx=xc+sep.delta_dx,yy=y+sep.delta_dy;
+              xx=xx < 0 ? 0 : (xx > W-1 ? W-1 : xx);
+              yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
+              Q q[C];
+              load_pixel<Q,C>(src+((size_t) yy*W+(size_t) xx)*C,q);
+              const double alpha=BLEND ? (double) q[C-1] : 1.0;
+#pragma unroll
+              for (int c=0; c < C; c++)
+                s[c]=__builtin_fma(sep.delta,(BLEND && (c != C-1)) ? alpha*(double) q[c] : (double) q[c],s[c]);
+            }
+          Q out[C];
+          const uint32_t which=settle_sums<Q,C,BLEND>(s,error,sep.mixed_signs,out);
+          if (x < W)
+            {
+              store_pixel<Q,C>(dst+((size_t) y*W+(size_t) x)*C,out);
+              doubtful|=which << (4*r);
+            }
+        }
+    }
+  // The undecided samples go to a queue that separable_settle_kernel works through with the whole
+  // chip (a wave of this kernel holds 200 registers and its workgroup's tile while it walks the
+  // reference's kw x kh cells: 15 000 such samples of a float 8192^2 frame under a 79 x 79 Gaussian
+  // cost 4.4 ms here, 0.2 ms there).  What does not fit the queue is settled in place, by all lanes
+  // of the wave (the loops are wave-uniform), and patched into the pixel its lane has just stored.
+  unsigned recomputed=0;
+  for (int r=0; r < R; r++)
+    {
+      const int y=y0+r;
+      if (y >= H)
+        break;
+      const uint32_t mine=(doubtful >> (4*r)) & 15u;
+      unsigned long long pending=__ballot(mine != 0u);
+      if (pending == 0ull)
+        continue;
+      unsigned base=0;
+      if (lane == 0)
+        base=atomicAdd(sep.queue_count,(unsigned) __builtin_popcountll(pending));
+      base=(unsigned) __builtin_amdgcn_readfirstlane((int) base);
+      const unsigned rank=(unsigned) __builtin_popcountll(pending & ((1ull << lane)-1ull));
+      const bool queued=(base < sep.queue_capacity) && (rank < sep.queue_capacity-base);
+      if ((mine != 0u) && queued)
+        sep.queue[base+rank]=((unsigned long long) ((size_t) y*W+(size_t) x) << 4) | (unsigned long long) mine;
+      pending=__ballot((mine != 0u) && !queued);
+      while (pending != 0ull)
+        {
+          const int who=__builtin_ctzll(pending);
+          pending&=pending-1ull;
+          const uint32_t which=(uint32_t) __builtin_amdgcn_readlane((int) mine,who);
+          const int xw=tx*64+who;
+          for (int c=0; c < C; c++)
+            if ((which >> c) & 1u)
+              {
+                const Q settled=conv2d_reference_sample<Q,C,BLEND>(src,W,H,xw,y,c,sep.values,sep.kw,sep.kh,
+                  sep.shiftx,sep.shifty,lane);
+                if (lane == who)
+                  {
+                    dst[((size_t) y*W+(size_t) xw)*C+c]=settled;
+                    recomputed++;
+                  }
+              }
+        }
+    }
+  if (sep.recomputed != nullptr)
+    {
+      recomputed=wave_sum(recomputed);
+      if ((lane == 0) && (recomputed != 0))
+        atomicAdd(sep.recomputed,(unsigned long long) recomputed);
+    }
+}
+
+// The queued samples of the column pass, one wave each, in the reference's own w x h order.
+template<typename Q,int C,bool BLEND>
+__global__ __launch_bounds__(256)
+void separable_settle_kernel(SeparableArgs sep)
+{
+  const unsigned filled=*sep.queue_count;
+  const unsigned count=filled < sep.queue_capacity ? filled : sep.queue_capacity;
+  const int lane=(int) (threadIdx.x & 63);
+  const unsigned wave=blockIdx.x*4u+(threadIdx.x >> 6),waves=gridDim.x*4u;
+  const Q *src=static_cast<const Q *>(sep.src);
+  Q *dst=static_cast<Q *>(sep.dst);
+  unsigned recomputed=0;
+  for (unsigned i=wave; i < count; i+=waves)
+    {
+      const unsigned long long entry=sep.queue[i];
+      const uint32_t which=(uint32_t) (entry & 15ull);
+      const size_t at=(size_t) (entry >> 4);
+      const int y=(int) (at/(size_t) sep.columns),x=(int) (at-(size_t) y*sep.columns);
+      for (int c=0; c < C; c++)
+        if ((which >> c) & 1u)
+          {
+            const Q settled=conv2d_reference_sample<Q,C,BLEND>(src,sep.columns,sep.rows,x,y,c,sep.values,
+              sep.kw,sep.kh,sep.shiftx,sep.shifty,lane);
+            if (lane == 0)
+              dst[at*C+c]=settled;
+            recomputed++;
+          }
+    }
+  if ((sep.recomputed != nullptr) && (lane == 0) && (recomputed != 0))
+    atomicAdd(sep.recomputed,(unsigned long long) recomputed);
+}
+
+template<typename Q,int C,bool BLEND,int R,int U>
+static MhStatus launch_folded_row(const View &src,const SeparableArgs &sep,const Conv1DParams &p)
+{
+  constexpr int WAVES=4;
+  const int K=p.ntaps;
+  std::vector<double> host((size_t) K);
+  for (int v=0; v < K; v++)
+    host[(size_t) v]=p.taps[K-1-v];             // reversed: morphology.c:2919
+  Temp taps;
+  MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(double)));
+  Conv1DArgs args={};
+  args.src=sep.src;
+  args.dst=sep.sums;
+  args.columns=sep.columns;
+  args.rows=sep.rows;
+  args.ntaps=K;
+  args.shift=K-1-p.origin;
+  args.taps=taps.ptr;
+  const int W=args.columns,H=args.rows;
+  const int SEG=64*R,NS=63*R+R+K-1+U,slots=NS+NS/R+1;
+  const size_t lds=(size_t) WAVES*slots*C*sizeof(Q);
+  if (lds > 160u*1024u)
+    return fail(MH_UNSUPPORTED,"row kernel of %d taps needs %zu bytes of LDS",K,lds);
+  const unsigned ntx=(unsigned) ((W+SEG-1)/SEG),nty=(unsigned) ((H+WAVES-1)/WAVES);
+  const unsigned grid=((ntx*nty+7u)/8u)*8u;
+  if (lds > 64u*1024u)
+    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&separable_row_sums_kernel<Q,C,BLEND,R,U,WAVES>),
+      hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+  ProfileScope prof("separable_row_sums",src.stream);
+  hipLaunchKernelGGL((separable_row_sums_kernel<Q,C,BLEND,R,U,WAVES>),dim3(grid),dim3(64*WAVES),lds,
+    src.stream,args,sep.bound);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+template<typename Q,int C,bool BLEND,int R,int U>
+static MhStatus launch_folded_column(const View &src,const SeparableArgs &sep,const Conv1DParams &p)
+{
+  constexpr int WAVES=4;
+  const int K=p.ntaps;
+  std::vector<double> host((size_t) K);
+  for (int v=0; v < K; v++)
+    host[(size_t) v]=p.taps[K-1-v];
+  Temp taps;
+  MH_TRY(upload_table(taps,src.device,src.stream,host.data(),host.size()*sizeof(double)));
+  Conv1DArgs args={};
+  args.src=sep.sums;
+  args.dst=sep.dst;
+  args.columns=sep.columns;
+  args.rows=sep.rows;
+  args.ntaps=K;
+  args.shift=K-1-p.origin;
+  args.taps=taps.ptr;
+  const int W=args.columns,H=args.rows;
+  const unsigned ntx=(unsigned) ((W+63)/64),nty=(unsigned) ((H+R*WAVES-1)/(R*WAVES));
+  const unsigned grid=((ntx*nty+7u)/8u)*8u;
+  ProfileScope prof("separable_column_finish",src.stream);
+  hipLaunchKernelGGL((separable_column_finish_kernel<Q,C,BLEND,R,U,WAVES>),dim3(grid),dim3(64*WAVES),0,
+    src.stream,args,sep);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+template<typename Q,int C,bool BLEND>
+static MhStatus launch_folded(const View &src,const SeparableArgs &sep,const Conv1DParams &horizontal,
+  const Conv1DParams &vertical)
+{
+  // a lane owns R consecutive outputs of a K-tap pass; the triangular walk needs K >= R+1
+  if (horizontal.ntaps >= 9)
+    MH_TRY((launch_folded_row<Q,C,BLEND,8,8>(src,sep,horizontal)));
+  else if (horizontal.ntaps >= 5)
+    MH_TRY((launch_folded_row<Q,C,BLEND,4,4>(src,sep,horizontal)));
+  else
+    MH_TRY((launch_folded_row<Q,C,BLEND,2,2>(src,sep,horizontal)));
+  if (vertical.ntaps >= 9)
+    MH_TRY((launch_folded_column<Q,C,BLEND,8,8>(src,sep,vertical)));
+  else if (vertical.ntaps >= 5)
+    MH_TRY((launch_folded_column<Q,C,BLEND,4,4>(src,sep,vertical)));
+  else
+    MH_TRY((launch_folded_column<Q,C,BLEND,2,2>(src,sep,vertical)));
+  {
+    // (the queue's fill is on the device: a grid that covers a full queue at four samples per wave,
+    // whose workgroups leave at once when there is nothing for them)
+    unsigned blocks=(sep.queue_capacity+15u)/16u;
+    blocks=blocks > 2048u ? 2048u : (blocks < 1u ? 1u : blocks);
+    ProfileScope prof("separable_settle",src.stream);
+    hipLaunchKernelGGL((separable_settle_kernel<Q,C,BLEND>),dim3(blocks),dim3(256),0,src.stream,sep);
+  }
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+// src: the frame (its layout picks the instantiation); sep: src, dst, sums ([rows][columns][4]
+// doubles of work space), bound and the finish step's arguments.  Both kernels need 3 taps or more.
+MhStatus launch_separable_folded(const View &src,const SeparableArgs &sep,const Conv1DParams &horizontal,
+  const Conv1DParams &vertical,bool blend)
+{
+  if ((horizontal.ntaps < 3) || (vertical.ntaps < 3))
+    return fail(MH_BAD_ARGUMENT,"folded separable passes: %d x %d taps",horizontal.ntaps,vertical.ntaps);
+#define MH_LAYOUT(QT) \
+  switch (src.channels) \
+  { \
+    case 1: return launch_folded<QT,1,false>(src,sep,horizontal,vertical); \
+    case 2: return blend ? launch_folded<QT,2,true>(src,sep,horizontal,vertical) : \
+      launch_folded<QT,2,false>(src,sep,horizontal,vertical); \
+    case 3: return launch_folded<QT,3,false>(src,sep,horizontal,vertical); \
+    case 4: return blend ? launch_folded<QT,4,true>(src,sep,horizontal,vertical) : \
+      launch_folded<QT,4,false>(src,sep,horizontal,vertical); \
+    default: break; \
+  }
+  if (src.quantum != MH_QUANTUM_U16)
+    { MH_LAYOUT(float) }
+  else
+    { MH_LAYOUT(uint16_t) }
+#undef MH_LAYOUT
   return fail(MH_UNSUPPORTED,"%d channels",src.channels);
 }
 

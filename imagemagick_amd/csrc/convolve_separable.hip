@@ -20,31 +20,12 @@
 #include "mh_internal.hpp"
 #include "device_common.hpp"
 #include "tie_check.hpp"
+#include "separable_args.hpp"
 #include <cmath>
 #include <cstdlib>
 #include <vector>
 
 namespace mh {
-
-struct SeparableArgs
-{
-  const void *src;
-  void *dst;
-  double *sums;               // [rows][columns][4]
-  double *bound;              // [4]: largest |P_c| of the frame (float Quantum)
-  int columns,rows;
-  const double *values;       // the kernel's cells (device)
-  int kw,kh,shiftx,shifty;
-  double error_unit;          // |difference of the two evaluations| <= error_unit * max|P_c|
-  double fixed_bound[4];      // Q16: max|P_c| is known (65535^2 for alpha-weighted colour, 65535)
-  // kernel = column x row + delta at one cell (SharpenImage, EdgeImage: a negated Gaussian / a
-  // box whose centre carries the normalisation): delta times the sample that cell sees, which
-  // is (x+delta_dx, y+delta_dy)
-  double delta;
-  int delta_dx,delta_dy;
-  int mixed_signs;            // cells of both signs: an alpha sum of exactly zero is not "all transparent"
-  unsigned long long *recomputed;
-};
 
 template<typename Q,int C,bool BLEND>
 __global__ __launch_bounds__(256)
@@ -260,8 +241,18 @@ MhStatus launch_separable_exact(const View &src,const View &dst,const MhKernelIn
   if (blend && negative && positive && !(std::fabs(total) > 0.05*magnitude))
     return MH_OK;
   const size_t n=(size_t) src.columns*src.rows;
+  // two launches (premultiply inside the row pass, this file's finish step inside the column
+  // pass: convolve.hip) and one 32-byte-per-pixel intermediate where both axes have three taps
+  const bool folded=(kw >= 3) && (kh >= 3) && (option("MAGICKHIP_NO_SEPARABLE_FOLD") == nullptr);
   Temp memory,table;
-  if (memory.alloc(src.device,2*n*4*sizeof(double)+4*sizeof(double),src.stream) != MH_OK)
+  // (folded: + the queue of undecided samples, at most 4 M entries; what overflows it is settled
+  // inside the column pass)
+  size_t queue_capacity=folded ? (n < ((size_t) 1 << 22) ? n : ((size_t) 1 << 22)) : 0;
+  const long forced_capacity=option_long("MAGICKHIP_SEPARABLE_QUEUE",-1);      // (tests: the overflow path)
+  if (folded && (forced_capacity >= 0) && ((size_t) forced_capacity < queue_capacity))
+    queue_capacity=(size_t) forced_capacity;
+  if (memory.alloc(src.device,(folded ? 1 : 2)*n*4*sizeof(double)+(4+1+queue_capacity)*sizeof(double),
+        src.stream) != MH_OK)
     {
       // 64 bytes of fp64 sums per pixel do not fit next to the frames: the generic walk needs none
       (void) hipGetLastError();
@@ -272,8 +263,11 @@ MhStatus launch_separable_exact(const View &src,const View &dst,const MhKernelIn
   a.src=src.pixels;
   a.dst=dst.pixels;
   a.sums=static_cast<double *>(memory.ptr);
-  double *work=a.sums+n*4;
+  double *work=folded ? a.sums : a.sums+n*4;
   a.bound=work+n*4;
+  a.queue_count=reinterpret_cast<unsigned *>(a.bound+4);
+  a.queue=reinterpret_cast<unsigned long long *>(a.bound+5);
+  a.queue_capacity=(unsigned) queue_capacity;
   a.columns=(int) src.columns;
   a.rows=(int) src.rows;
   a.values=table.as<double>();
@@ -300,7 +294,7 @@ MhStatus launch_separable_exact(const View &src,const View &dst,const MhKernelIn
         }
       a.recomputed=g_separable_recomputed[src.device];
     }
-  MH_HIP(hipMemsetAsync(a.bound,0,4*sizeof(double),src.stream));
+  MH_HIP(hipMemsetAsync(a.bound,0,5*sizeof(double),src.stream));     // and the queue's fill
   Conv1DParams horizontal,vertical;
   horizontal.taps=row;
   horizontal.ntaps=kw;
@@ -308,6 +302,12 @@ MhStatus launch_separable_exact(const View &src,const View &dst,const MhKernelIn
   vertical.taps=column;
   vertical.ntaps=kh;
   vertical.origin=(int) kernel->y;
+  if (folded)
+    {
+      MH_TRY(launch_separable_folded(src,a,horizontal,vertical,blend));
+      *handled=true;
+      return MH_OK;
+    }
   MhStatus status=MH_OK;
 #define MH_LAYOUT(QT) \
   switch (src.channels) \

@@ -944,14 +944,19 @@ def test_gaussian_blur_sharpen_edge_emboss(im, refmod, dtype, channels):
                                     "5x5: -1,-2,0,2,1 -4,-8,0,8,4 -6,-12,0,12,6 -4,-8,0,8,4 -1,-2,0,2,1",
                                     "5x5: -1,-2,-3,-2,-1 -2,-4,-6,-4,-2 -3,-6,100,-6,-3 -2,-4,-6,-4,-2 -1,-2,-3,-2,-1",
                                     "5x5: -1,-1,-1,-1,-1 -1,-1,-1,-1,-1 -1,-1,24.5,-1,-1 -1,-1,-1,-1,-1 -1,-1,-1,-1,-1"])
-def test_separable_2d_convolve_exact(im, refmod, dtype, channels, alpha, kernel, options):
+@pytest.mark.parametrize("folded", [True, False])
+def test_separable_2d_convolve_exact(im, refmod, dtype, channels, alpha, kernel, folded, options):
     """EXACT 2-D Convolve with a kernel that is an outer product (GaussianBlurImage's kernels,
     boxes, column x row products): two fp64 1-D passes over alpha-premultiplied doubles and a tie
     check, the undecided samples recomputed in the reference's w x h order
     (convolve_separable.hip) — bit-identical on Q16 and on float Quantum, every layout, small and
-    zero alpha, frames ragged against the kernels' tiles."""
+    zero alpha, frames ragged against the kernels' tiles.  folded: the premultiplication inside
+    the row pass and the tie check inside the column pass (two launches + the queue of undecided
+    samples) or round 3's four launches."""
     import bench
     options.set("MAGICKHIP_NO_EXACT_2D", "1")     # (Q16 boxes and integer kernels otherwise take convolve2d_exact.hip)
+    if not folded:
+        options.set("MAGICKHIP_NO_SEPARABLE_FOLD", "1")
     rng = np.random.default_rng(len(kernel) + channels)
     px = make_pixels(83, 141, channels, dtype, seed=len(kernel))
     if alpha:
@@ -977,7 +982,9 @@ def test_separable_2d_convolve_exact(im, refmod, dtype, channels, alpha, kernel,
     # (alpha-weighted frames under cells that cancel keep the generic kernel: sum(k*alpha) is all
     # cancellation and PerceptibleReciprocal's clamp decides every pixel)
     cancelling = zero_sum or "24.5" in kernel            # |sum of cells| <= 5 % of sum |cell|
-    assert ("separable_finish" in launched) == (not (cancelling and alpha)), launched
+    assert (("separable_column_finish" if folded else "separable_finish") in launched) == (not (cancelling and alpha)), launched
+    if folded and not (cancelling and alpha):
+        assert launched == {"separable_row_sums", "separable_column_finish", "separable_settle"}, launched
     got = holder["out"].numpy()
     if dtype == HDRI:
         same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
@@ -986,13 +993,19 @@ def test_separable_2d_convolve_exact(im, refmod, dtype, channels, alpha, kernel,
         assert_parity(got, want, True, "separable %s c%d alpha=%s" % (kernel, channels, alpha))
 
 
+@pytest.mark.parametrize("queue", ["queue", "overflow", "four launches"])
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
-def test_separable_2d_convolve_exact_on_ties(im, refmod, dtype, options):
+def test_separable_2d_convolve_exact_on_ties(im, refmod, dtype, queue, options):
     """A checkerboard of two adjacent levels under an even box puts every value exactly on a
     rounding tie (Q16) or on the midpoint of two floats (HDRI): all of them go through the
     reference-order recomputation; GaussianBlurImage of the same frame lands 1e-5 beside the ties.
-    Both bit-identical."""
+    Both bit-identical.  queue: the folded column pass hands them all to separable_settle_kernel;
+    overflow: a queue of 1000 entries, the rest settled inside the column pass."""
     options.set("MAGICKHIP_NO_EXACT_2D", "1")
+    if queue == "overflow":
+        options.set("MAGICKHIP_SEPARABLE_QUEUE", "1000")
+    elif queue == "four launches":
+        options.set("MAGICKHIP_NO_SEPARABLE_FOLD", "1")
     rows, cols = 70, 110
     y, x = np.mgrid[0:rows, 0:cols]
     px = np.empty((rows, cols, 4), dtype=dtype)
