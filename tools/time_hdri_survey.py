@@ -22,6 +22,9 @@ OPS = [
     ("convolve Disk:5", lambda i: im.morphology_image(i, "Convolve", 1, "Disk:5", scale=(1.0, 1))),
     ("convolve Disk:15", lambda i: im.morphology_image(i, "Convolve", 1, "Disk:15", scale=(1.0, 1))),
     ("convolve LoG:0x2", lambda i: im.morphology_image(i, "Convolve", 1, "LoG:0x2")),
+    # (a zero-sum kernel on an alpha-weighted frame is the reference's own walk by necessity, DESIGN.md 8;
+    # without the alpha trait it is fused sums + tie check)
+    ("convolve LoG:0x2 (rgb)", lambda i: im.morphology_image(i, "Convolve", 1, "LoG:0x2")),
     ("dilate Disk:15", lambda i: im.morphology_image(i, "Dilate", 1, "Disk:15")),
     ("erode Octagon:5", lambda i: im.morphology_image(i, "Erode", 1, "Octagon:5")),
     ("open Disk:5", lambda i: im.morphology_image(i, "Open", 1, "Disk:5")),
@@ -42,7 +45,7 @@ for prec_name, prec in (("exact", im.PRECISION_EXACT), ("fast", im.PRECISION_FAS
     for name, op in OPS:
         row = []
         for label, px in (("q16", q16), ("hdri", flt)):
-            img = im.Image(px)
+            img = im.Image(px[:, :, :3].contiguous()) if name.endswith("(rgb)") else im.Image(px)
             def f():
                 hold["o"] = None
                 hold["o"] = op(img)
@@ -53,7 +56,7 @@ for prec_name, prec in (("exact", im.PRECISION_EXACT), ("fast", im.PRECISION_FAS
             except Exception as exc:
                 row.append("%s failed: %s" % (label, str(exc)[:60]))
             hold.clear()
-        print("%-20s %s" % (name, "   |   ".join(row)), flush=True)
+        print("%-24s %s" % (name, "   |   ".join(row)), flush=True)
     for name, op in INPLACE:
         row = []
         for label, px in (("q16", q16), ("hdri", flt)):
@@ -68,4 +71,4 @@ for prec_name, prec in (("exact", im.PRECISION_EXACT), ("fast", im.PRECISION_FAS
             except Exception as exc:
                 row.append("%s failed: %s" % (label, str(exc)[:60]))
             del work
-        print("%-20s %s" % (name, "   |   ".join(row)), flush=True)
+        print("%-24s %s" % (name, "   |   ".join(row)), flush=True)
