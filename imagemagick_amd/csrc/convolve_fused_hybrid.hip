@@ -34,6 +34,8 @@
 #include "blur_exact_common.hpp"
 #include <cmath>
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 #include <type_traits>
 
 namespace mh {
@@ -114,11 +116,29 @@ struct HybridGeometry
 // each costs.  The results are wrong.  1 the alpha tiles' digit loads and products, 2 the alpha
 // epilogue of interval A, 4 the colour epilogue's reads of the exact alpha, 8 exact_sums,
 // 16 the staging of the alpha byte planes; 32 / 64 / 128: plain-channel arithmetic in the staging /
-// the colour epilogue / the column pass's epilogue of an alpha-weighted frame
+// the colour epilogue / the column pass's epilogue of an alpha-weighted frame; 256: every fetch reads
+// the strip's first group (cache-resident: no memory latency, no read traffic); 512: no stores
 #ifdef MH_HYBRID_KNOCK
 #define MH_HKNOCKED(bit) ((args.threshold & (bit)) != 0)
 #else
 #define MH_HKNOCKED(bit) false
+#endif
+
+// Diagnostic build only (-DMH_HYBRID_TRACE, tools/trace_hybrid_blur.py): every wave of the first four
+// workgroups stamps the shader clock at the phase boundaries of 48 steady-state iterations:
+// trace[block][wave][iteration][mark].
+#ifdef MH_HYBRID_TRACE
+#define MH_HTRACE_MARK(id) \
+  do { \
+    if (traced && (g >= 64) && (g < 112)) \
+      { \
+        const unsigned long long now=__builtin_readcyclecounter(); \
+        if (lane == 0) \
+          args.trace[((((int) blockIdx.x*16+wave)*48)+(g-64))*12+(id)]=now; \
+      } \
+  } while (0)
+#else
+#define MH_HTRACE_MARK(id) do { } while (0)
 #endif
 
 template<int NC,int MODE>
@@ -169,6 +189,9 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
   const int item=((int) blockIdx.x & 7)*args.items_per_xcd+((int) blockIdx.x >> 3);
   if (item >= items)
     return;
+#ifdef MH_HYBRID_TRACE
+  const bool traced=(args.trace != nullptr) && (blockIdx.x < 4);
+#endif
   const int segment=item/args.strips,strip=item-segment*args.strips;
   const int x0=G::COLS*strip;
   const int block_begin=segment*args.blocks_per_segment;
@@ -225,7 +248,7 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
   {
     if (stager)
       {
-        int y=in0+G::GROUP*g+srow;
+        int y=in0+G::GROUP*(MH_HKNOCKED(256) ? 0 : g)+srow;
         y=y < 0 ? 0 : (y > H-1 ? H-1 : y);       // the intermediate's edge clamp (cache.c:2663-2679)
         const int xs=xin0+4*sxg;
         if ((MODE == MFMA_PLAIN3) && (xs >= 0) && (xs+3 <= W-1))
@@ -360,7 +383,7 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
       {
         const uint2 result=out_tile[wave*G::OUT_STRIDE+lane];
         const int x=x0+lane,y=out_begin+G::GROUP*block+wave;
-        if ((x < W) && (y < H))
+        if ((x < W) && (y < H) && !MH_HKNOCKED(512))
           store_pixel16(args.dst+pixel_index(y,W,x)*PX,result);
       }
   };
@@ -373,12 +396,15 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
       const int cb=g-G::NG-1;                    // the column pass's block of this iteration
       const int first=ring_group;                // ring slot of group cb: (g-NG-1) mod NR = g mod NR
       const int previous=ring_group == 0 ? G::NR-1 : ring_group-1;   // ring slot of group g-1
+      MH_HTRACE_MARK(0);
       if (g < ngroups)
         {
           stage_group(srow,sxg);
+          MH_HTRACE_MARK(1);
           if (g+1 < ngroups)
             fetch(g+1,srow,sxg);
         }
+      MH_HTRACE_MARK(2);
       // ======================================================================== interval A
       if constexpr (BLEND)
         if (alpha_wave && !MH_HKNOCKED(2))
@@ -422,6 +448,7 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
             *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
             *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
           }
+      MH_HTRACE_MARK(3);
       // ---- f16 column pass of block cb, whole (products, division, rounding) -> out_tile
       if ((cb >= 0) && (cb < nblocks))
         {
@@ -471,7 +498,9 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
           else if (ctiles == CT-1)
             column_tiles(std::integral_constant<int,CT-1>{});
         }
+      MH_HTRACE_MARK(4);
       __syncthreads();                           // X: group g staged, the alpha of group g-1 published
+      MH_HTRACE_MARK(5);
       // ======================================================================== interval B
       {
         // the colour epilogue's view of the exact alpha of group g-1, read first: the chains below hide
@@ -532,6 +561,7 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
                     tiles[j-1]=digit_product(low,digit[j],tiles[j-1]);
                 }
             }
+        MH_HTRACE_MARK(6);
         // ---- f16 row chain of group g
         floatx4 acc={0.0f,0.0f,0.0f,0.0f};
 #pragma unroll
@@ -586,7 +616,9 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
         asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));
         sums_row=acc;
       }
+      MH_HTRACE_MARK(7);
       __syncthreads();                           // Y: ring group g-1 complete, out_tile read, staging reads done
+      MH_HTRACE_MARK(8);
       ring_group=ring_group+1 == G::NR ? 0 : ring_group+1;
     }
   if ((args.recomputed != nullptr) && (recomputed != 0u) && (lane == 0))     // a wave-uniform count
@@ -622,10 +654,36 @@ static MhStatus launch_hybrid_typed(const View &src,BlurExactArgs &args)
         hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
       attribute_set[slot]=true;
     }
-  ProfileScope prof("blur_fused_hybrid",src.stream);
-  hipLaunchKernelGGL((blur_fused_hybrid_kernel<NC,MODE>),dim3((unsigned) (8*args.items_per_xcd)),dim3(1024),lds,
-    src.stream,args);
-  MH_HIP(hipGetLastError());
+#ifdef MH_HYBRID_TRACE
+  const char *trace_path=option("MAGICKHIP_HYBRID_TRACE");
+  const size_t trace_bytes=4u*16u*48u*12u*sizeof(unsigned long long);
+  if (trace_path != nullptr)
+    {
+      MH_HIP(hipMalloc(reinterpret_cast<void **>(&args.trace),trace_bytes));
+      MH_HIP(hipMemsetAsync(args.trace,0,trace_bytes,src.stream));
+    }
+#endif
+  {
+    ProfileScope prof("blur_fused_hybrid",src.stream);
+    hipLaunchKernelGGL((blur_fused_hybrid_kernel<NC,MODE>),dim3((unsigned) (8*args.items_per_xcd)),dim3(1024),lds,
+      src.stream,args);
+    MH_HIP(hipGetLastError());
+  }
+#ifdef MH_HYBRID_TRACE
+  if (args.trace != nullptr)
+    {
+      std::vector<unsigned long long> host(trace_bytes/sizeof(unsigned long long));
+      MH_HIP(hipMemcpyAsync(host.data(),args.trace,trace_bytes,hipMemcpyDeviceToHost,src.stream));
+      MH_HIP(hipStreamSynchronize(src.stream));
+      MH_HIP(hipFree(args.trace));
+      if (FILE *f=fopen(trace_path,"wb"))
+        {
+          fwrite(host.data(),1,trace_bytes,f);
+          fclose(f);
+        }
+      args.trace=nullptr;
+    }
+#endif
   return MH_OK;
 }
 
