@@ -266,7 +266,7 @@ def cpu_baseline_configs():
                 "cores": int(ref.thread_limit(hdri)), "kind": "reference",
                 "sample": "%s, reference MagickCore OpenMP path, 1 call, %.2f s" % (sample, sec)}
     try:
-        m = 2048
+        m = 4096                                   # (a quarter of C3's pixels: 4.3 GB of result on the host)
         src = (rng.random((m, m, 4), dtype=np.float32) * 65535.0).astype(np.float32)
         r = ref.RefImage(src).resize(4 * m, 4 * m, "Lanczos")
         out["c3_resize"] = entry(16.0 * m * m, r.last_seconds,
@@ -389,9 +389,6 @@ def resize_config(im, torch, gen):
     def resize():
         holder["o"] = None
         holder["o"] = im.resize_image(imgf, 4 * m, 4 * m, "Lanczos")
-    sec = timed(torch, resize, 3)
-    prof = kernel_profile(im, resize, 2)
-    holder.clear()
     out_px = 16.0 * m * m
     px16 = 16.0                                   # bytes per float RGBA pixel
     bytes_by_kernel = {
@@ -399,16 +396,40 @@ def resize_config(im, torch, gen):
         "resize_horizontal": (4.0 * m * m + 16.0 * m * m) * px16,    # 8192x32768 in, 32768^2 out
         "resize_fused": (1.0 * m * m + 16.0 * m * m) * px16,
     }
-    kernels = kernel_rooflines(prof, bytes_by_kernel)
-    kernel_ms = sum(v["avg_ms"] for v in prof.values())
-    dominant = max(prof, key=lambda k: prof[k]["avg_ms"])
     compulsory = (1.0 * m * m + 16.0 * m * m) * px16
-    return {"workload": "8192x8192 -> 32768x32768 Lanczos ResizeImage, float Quantum RGBA (BASELINE configs[2])",
-            "Mpixels_per_s": round(out_px / sec / 1e6, 1), "ms": round(sec * 1e3, 3),
-            "kernel_only_Mpixels_per_s": round(out_px / (kernel_ms * 1e-3) / 1e6, 1),
-            "dtype": "f64 accumulation, float Quantum", "roofline": kernels.get(dominant),
-            "operator_frac_of_compulsory_bytes": round(compulsory / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-            "kernels": kernels}
+
+    def measure():
+        sec = timed(torch, resize, 3)
+        prof = kernel_profile(im, resize, 2)
+        holder.clear()
+        kernels = kernel_rooflines(prof, bytes_by_kernel)
+        kernel_ms = sum(v["avg_ms"] for v in prof.values())
+        dominant = max(prof, key=lambda k: prof[k]["avg_ms"])
+        return {"Mpixels_per_s": round(out_px / sec / 1e6, 1), "ms": round(sec * 1e3, 3),
+                "kernel_only_Mpixels_per_s": round(out_px / (kernel_ms * 1e-3) / 1e6, 1),
+                "roofline": kernels.get(dominant),
+                "operator_frac_of_compulsory_bytes": round(compulsory / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "kernels": kernels}
+    out = {"workload": "8192x8192 -> 32768x32768 Lanczos ResizeImage, float Quantum RGBA (BASELINE configs[2])",
+           "dtype": "f64 accumulation, float Quantum"}
+    out.update(measure())                         # the precision mode of the line (--precision)
+    # both modes side by side (EXACT: the reference's own operation order, bit-identical; FAST: fused
+    # multiply-adds, within one float ULP)
+    modes = {}
+    try:
+        for name, precision in (("fast", im.PRECISION_FAST), ("exact", im.PRECISION_EXACT)):
+            if PRECISION_IS_FAST[0] == (name == "fast"):
+                modes[name] = {k: out[k] for k in ("Mpixels_per_s", "ms", "operator_frac_of_compulsory_bytes")}
+                modes[name]["kernels_ms"] = {k: v["avg_ms"] for k, v in out["kernels"].items()}
+                continue
+            im.set_precision(precision)
+            other = measure()
+            modes[name] = {k: other[k] for k in ("Mpixels_per_s", "ms", "operator_frac_of_compulsory_bytes")}
+            modes[name]["kernels_ms"] = {k: v["avg_ms"] for k, v in other["kernels"].items()}
+    finally:
+        im.set_precision(im.PRECISION_FAST if PRECISION_IS_FAST[0] else im.PRECISION_EXACT)
+    out["modes"] = modes
+    return out
 
 
 def c4_config(im, torch, gen):

@@ -136,6 +136,14 @@ void blur_fused_exact_kernel(BlurExactArgs args)
         *reinterpret_cast<LooseDword *>(at)=value.x;
         at[2]=(uint16_t) value.y;
       }
+    else if constexpr (UNSHARP)
+      {
+        // UnsharpMask reads every source pixel twice — for the window, and 94 rows later for the
+        // epilogue: results that stream THROUGH the L2 push those lines out before their second use
+        // (PMC: 1.34x the compulsory traffic on 16384^2).  Non-temporal stores: 4.82 -> 4.46 ms.
+        typedef unsigned NativePair __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(NativePair{value.x,value.y},reinterpret_cast<NativePair *>(at));
+      }
     else
       *reinterpret_cast<uint2 *>(at)=value;
   };
@@ -377,7 +385,9 @@ void blur_fused_exact_kernel(BlurExactArgs args)
   {
     const int x=x0+lane,y=out_begin+G::GROUP*block+wave;
     if ((block >= 0) && (block < nblocks) && (x < W) && (y < H))
-      original=load_pixel16(args.src+pixel_index(y,W,x)*PX);
+      {
+        original=load_pixel16(args.src+pixel_index(y,W,x)*PX);
+      }
   };
   unsigned recomputed=0u;
 
