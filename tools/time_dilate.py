@@ -16,9 +16,8 @@ hold = {}
 for kernel in kernels:
     results = []
     for label, env in (("strips", {"MAGICKHIP_STRIPS": "1"}), ("tiles", {}), ("planes", {"MAGICKHIP_NO_RECTS": "1"})):
-        os.environ.pop("MAGICKHIP_NO_RECTS", None)
-        os.environ.pop("MAGICKHIP_STRIPS", None)
-        os.environ.update(env)
+        for name in ("MAGICKHIP_NO_RECTS", "MAGICKHIP_STRIPS"):
+            im.set_option(name, env.get(name))
 
         def f():
             hold["o"] = im.morphology_image(img, "Dilate", 1, kernel)
