@@ -26,8 +26,8 @@ ALL_CHANNELS = 0x7FFFFFF
 SYNC_CHANNELS = 0x20000
 
 COLORSPACES = {"undefined": 0, "cmy": 1, "gray": 3, "hcl": 4, "hclp": 5, "hsb": 6, "hsi": 7, "hsl": 8,
-               "hsv": 9, "hwb": 10, "lab": 11, "lch": 12, "lchab": 13, "lchuv": 14, "lms": 16, "luv": 17,
-               "rgb": 21, "srgb": 23, "xyy": 25, "xyz": 26, "ycbcr": 27, "ydbdr": 29, "yiq": 30,
+               "hsv": 9, "hwb": 10, "lab": 11, "lch": 12, "lchab": 13, "lchuv": 14, "log": 15, "lms": 16, "luv": 17,
+               "ohta": 18, "rec601ycbcr": 19, "rec709ycbcr": 20, "rgb": 21, "scrgb": 22, "srgb": 23, "xyy": 25, "xyz": 26, "ycbcr": 27, "ycc": 28, "ydbdr": 29, "yiq": 30,
                "ypbpr": 31, "yuv": 32, "lineargray": 33, "jzazbz": 34, "displayp3": 35, "adobe98": 36,
                "prophoto": 37, "oklab": 38, "oklch": 39, "cat02lms": 40}
 

@@ -645,7 +645,7 @@ MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,con
       int op=-1;
       switch (from)
       {
-        case MH_COLORSPACE_RGB: op=OP_RGB_TO_SRGB; break;
+        case MH_COLORSPACE_RGB: case MH_COLORSPACE_SCRGB: op=OP_RGB_TO_SRGB; break;   // (one case: colorspace.c:2502-2503)
         case MH_COLORSPACE_LAB: op=OP_LAB_TO_SRGB; break;
         case MH_COLORSPACE_XYZ: op=OP_XYZ_TO_SRGB; break;
         default:
@@ -663,7 +663,7 @@ MhStatus launch_colorspace(const View &img,MhColorspace from,MhColorspace to,con
       int op=-1;
       switch (to)
       {
-        case MH_COLORSPACE_RGB: op=OP_SRGB_TO_RGB; break;
+        case MH_COLORSPACE_RGB: case MH_COLORSPACE_SCRGB: op=OP_SRGB_TO_RGB; break;   // (colorspace.c:1164-1165)
         case MH_COLORSPACE_LAB: op=OP_SRGB_TO_LAB; break;
         case MH_COLORSPACE_XYZ: op=OP_SRGB_TO_XYZ; break;
         default:
@@ -2473,8 +2473,10 @@ static bool generic_colorspace(MhColorspace c)
 
 bool colorspace_is_accelerated(MhColorspace c)
 {
-  return (c == MH_COLORSPACE_SRGB) || (c == MH_COLORSPACE_RGB) || (c == MH_COLORSPACE_LAB) ||
-    (c == MH_COLORSPACE_XYZ) || generic_colorspace(c);
+  return (c == MH_COLORSPACE_SRGB) || (c == MH_COLORSPACE_RGB) || (c == MH_COLORSPACE_SCRGB) ||
+    (c == MH_COLORSPACE_LAB) || (c == MH_COLORSPACE_XYZ) || generic_colorspace(c) ||
+    (c == MH_COLORSPACE_OHTA) || (c == MH_COLORSPACE_REC601YCBCR) || (c == MH_COLORSPACE_REC709YCBCR) ||
+    (c == MH_COLORSPACE_YCC) || (c == MH_COLORSPACE_LOG);
 }
 
 template<typename Q,int C>
@@ -2504,9 +2506,260 @@ static MhStatus colorspace_generic_step(const View &img,MhColorspace colorspace,
     colorspace_generic_typed<float,4>(img,colorspace,forward,white_luminance);
 }
 
-static bool colorspace_is_generic(MhColorspace c) { return generic_colorspace(c); }
+// ---------------------------------------------------------------- the table-driven colourspaces
+// OHTA, Rec601YCbCr, Rec709YCbCr and YCC are the half of sRGBTransformImage / TransformsRGBImage
+// that works through three tables of MaxMap+1 TransformPackets (colorspace.c:1226-1420,
+// :2560-2790): x_map[i], y_map[i], z_map[i] hold what map index i of the red, green and blue sample
+// contributes to each result, the pixel loop adds the three entries (+ the primary offsets) and
+// ScaleMapToQuantum rounds.  Every entry is ONE rounded product k*f(i) — f(i) = i (forward; the
+// inverse's first table), 2i - MaxMap (inverse, second and third table: the constant 0.5*k is
+// folded by the compiler as it would be multiplied), 1.099i - 0.099 (YCC above 0.018 MaxMap) — so
+// the kernel forms the entries in place, in the table's own operations, instead of reading them.
+// YCC -> sRGB goes through a 1389-entry film curve (YCCMap) and stays on the CPU.
+struct MatrixColorspaceArgs
+{
+  double k[3][3];             // [table: red, green, blue index][result channel]
+  double low[3][3];           // YCC forward: the entries of indices up to 0.018 MaxMap
+  double primary[3];
+  int form;                   // 0 forward, 1 inverse, 2 YCC forward
+};
+
+template<typename Q,int C>
+__global__ __launch_bounds__(256)
+void colorspace_matrix_kernel(Q *pixels,size_t npixels,MatrixColorspaceArgs a)
+{
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  for (size_t at=(size_t) blockIdx.x*blockDim.x+threadIdx.x; at < npixels; at+=stride)
+    {
+      Q q[C];
+      load_pixel<Q,C>(pixels+at*C,q);
+      double entry[3][3];
+#pragma unroll
+      for (int t=0; t < 3; t++)
+        {
+          // ScaleQuantumToMap(ClampToQuantum(sample)), colorspace.c:1459-1464, :2738-2740
+          const unsigned index=QuantumOps<Q>::map_index(q[t]);
+          const double i=(double) index;
+          if (a.form == 2)
+            {
+              const bool low=index <= 1179u;      // (ssize_t) (0.018*MaxMap)
+              const double upper=1.099*i-0.099;
+#pragma unroll
+              for (int c=0; c < 3; c++)
+                entry[t][c]=low ? a.low[t][c]*i : a.k[t][c]*upper;
+            }
+          else
+            {
+              const double f=((a.form == 1) && (t != 0)) ? 2.0*i-65535.0 : i;
+#pragma unroll
+              for (int c=0; c < 3; c++)
+                entry[t][c]=a.k[t][c]*f;
+            }
+        }
+#pragma unroll
+      for (int c=0; c < 3; c++)
+        {
+          double value=entry[0][c]+entry[1][c]+entry[2][c];
+          if (a.form != 1)
+            value=value+a.primary[c];
+          // ScaleMapToQuantum, quantum-private.h:465-476
+          if (value <= 0.0)
+            q[c]=(Q) 0;
+          else if (value >= 65535.0)
+            q[c]=(Q) 65535;
+          else
+            q[c]=QuantumOps<Q>::is_float ? (Q) value : (Q) (value+0.5);
+        }
+      store_pixel<Q,C>(pixels+at*C,q);
+    }
+}
+
+static bool matrix_colorspace(MhColorspace c)
+{
+  return (c == MH_COLORSPACE_OHTA) || (c == MH_COLORSPACE_REC601YCBCR) || (c == MH_COLORSPACE_REC709YCBCR) ||
+    (c == MH_COLORSPACE_YCC);
+}
+
+static MhStatus colorspace_matrix_step(const View &img,MhColorspace colorspace,bool forward)
+{
+  MatrixColorspaceArgs a={};
+  auto rows=[&](double (&to)[3][3],const double (&red)[3],const double (&green)[3],const double (&blue)[3])
+  {
+    for (int c=0; c < 3; c++)
+      {
+        to[0][c]=red[c];
+        to[1][c]=green[c];
+        to[2][c]=blue[c];
+      }
+  };
+  a.form=forward ? 0 : 1;
+  if (forward)
+    {
+      a.primary[0]=0.0;
+      a.primary[1]=a.primary[2]=32768.0;          // (MaxMap+1)/2
+    }
+  switch (colorspace)
+  {
+    case MH_COLORSPACE_OHTA:
+      if (forward)
+        rows(a.k,{0.33333,0.50000,-0.25000},{0.33334,0.00000,0.50000},{0.33333,-0.50000,-0.25000});
+      else
+        rows(a.k,{1.0,1.0,1.0},{0.5*1.00000,0.5*0.00000,-0.5*1.00000},{-0.5*0.66668,0.5*1.33333,-0.5*0.66668});
+      break;
+    case MH_COLORSPACE_REC601YCBCR:
+      if (forward)
+        rows(a.k,{0.298839,-0.1687367,0.500000},{0.586811,-0.331264,-0.418688},{0.114350,0.500000,-0.081312});
+      else
+        rows(a.k,{0.99999999999914679361,0.99999975910502514331,1.00000124040004623180},
+          {0.5*(-1.2188941887145875e-06),0.5*(-0.34413567816504303521),0.5*1.77200006607230409200},
+          {0.5*1.4019995886561440468,0.5*(-0.71413649331646789076),0.5*2.1453384174593273e-06});
+      break;
+    case MH_COLORSPACE_REC709YCBCR:
+      if (forward)
+        rows(a.k,{0.212656,-0.114572,0.500000},{0.715158,-0.385428,-0.454153},{0.072186,0.500000,-0.045847});
+      else
+        rows(a.k,{1.0,1.0,1.0},{0.5*0.000000,0.5*(-0.187324),0.5*1.855600},{0.5*1.574800,0.5*(-0.468124),0.5*0.000000});
+      break;
+    case MH_COLORSPACE_YCC:
+      if (!forward)
+        return fail(MH_UNSUPPORTED,"YCC -> sRGB (the YCCMap film curve) is not accelerated");
+      a.form=2;
+      rows(a.low,{0.005382,-0.003296,0.009410},{0.010566,-0.006471,-0.007880},{0.002052,0.009768,-0.001530});
+      rows(a.k,{0.298839,-0.298839,0.70100},{0.586811,-0.586811,-0.586811},{0.114350,0.88600,-0.114350});
+      a.primary[1]=40092.0;                        // ScaleQuantumToMap(ScaleCharToQuantum(156))
+      a.primary[2]=35209.0;                        // ... (137)
+      break;
+    default:
+      return fail(MH_UNSUPPORTED,"colourspace %d is not table-driven",(int) colorspace);
+  }
+  const size_t n=img.columns*img.rows;
+  dim3 grid(stream_grid(n)),block(256);
+  ProfileScope prof("colorspace",img.stream);
+  if (img.quantum == MH_QUANTUM_U16)
+    {
+      if (img.channels == 3)
+        hipLaunchKernelGGL((colorspace_matrix_kernel<uint16_t,3>),grid,block,0,img.stream,static_cast<uint16_t *>(img.pixels),n,a);
+      else
+        hipLaunchKernelGGL((colorspace_matrix_kernel<uint16_t,4>),grid,block,0,img.stream,static_cast<uint16_t *>(img.pixels),n,a);
+    }
+  else
+    {
+      if (img.channels == 3)
+        hipLaunchKernelGGL((colorspace_matrix_kernel<float,3>),grid,block,0,img.stream,static_cast<float *>(img.pixels),n,a);
+      else
+        hipLaunchKernelGGL((colorspace_matrix_kernel<float,4>),grid,block,0,img.stream,static_cast<float *>(img.pixels),n,a);
+    }
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+// Log (Cineon film density, colorspace.c:1055-1163, :2391-2501): a table of MaxMap+1 Quantum values
+// built from four film parameters — here with their defaults (the image properties "gamma",
+// "film-gamma", "reference-black", "reference-white" change them: the caller declines then) —
+// indexed by the DECODED sample on the way in, and followed by EncodePixelGamma on the way back.
+// The table is built on the host in the reference's own expressions (libm's pow and log10).
+template<typename Q>
+static void build_log_table(bool forward,std::vector<Q> &table)
+{
+  const double density=1.0/1.7,gamma=1.0/1.7,film_gamma=0.6,reference_black=95.0,reference_white=685.0;
+  const double max_map=65535.0;
+  // PerceptibleReciprocal (pixel-accessor.h: 1/x, clamped at MagickEpsilon)
+  auto reciprocal=[](double x) { const double sign=x < 0.0 ? -1.0 : 1.0; return (sign*x) >= 1.0e-12 ? 1.0/x : sign/1.0e-12; };
+  auto map_to_quantum=[&](double value) -> Q    // ScaleMapToQuantum, quantum-private.h:465-476
+  {
+    if (value <= 0.0)
+      return (Q) 0;
+    if (value >= max_map)
+      return (Q) 65535;
+    return std::is_same<Q,float>::value ? (Q) value : (Q) (value+0.5);
+  };
+  table.assign(65536,(Q) 0);
+  const double black=std::pow(10.0,(reference_black-reference_white)*(gamma/density)*0.002*reciprocal(film_gamma));
+  if (forward)
+    {
+      for (long i=0; i <= 65535; i++)
+        table[(size_t) i]=map_to_quantum((max_map*(reference_white+std::log10(black+(1.0*(double) i/max_map)*(1.0-black))/
+          ((gamma/density)*0.002*reciprocal(film_gamma)))/1024.0));
+      return;
+    }
+  long i=0;
+  for ( ; i <= (long) (reference_black*max_map/1024.0); i++)
+    table[(size_t) i]=(Q) 0;
+  for ( ; i < (long) (reference_white*max_map/1024.0); i++)
+    {
+      const double value=65535.0/(1.0-black)*(std::pow(10.0,(1024.0*(double) i/max_map-reference_white)*(gamma/density)*0.002*
+        reciprocal(film_gamma))-black);
+      // ClampToQuantum (quantum.h:86-97)
+      if (std::is_same<Q,float>::value)
+        table[(size_t) i]=(Q) value;
+      else
+        table[(size_t) i]=!(value > 0.0) ? (Q) 0 : (value >= 65535.0 ? (Q) 65535 : (Q) (value+0.5));
+    }
+  for ( ; i <= 65535; i++)
+    table[(size_t) i]=(Q) 65535;
+}
+
+template<typename Q,int C,bool FORWARD>
+__global__ __launch_bounds__(256)
+void colorspace_log_kernel(Q *pixels,size_t npixels,const Q *table)
+{
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  for (size_t at=(size_t) blockIdx.x*blockDim.x+threadIdx.x; at < npixels; at+=stride)
+    {
+      Q q[C];
+      load_pixel<Q,C>(pixels+at*C,q);
+#pragma unroll
+      for (int c=0; c < 3; c++)
+        {
+          if constexpr (FORWARD)
+            q[c]=table[QuantumOps<Q>::map_index(QuantumOps<Q>::clamp(decode_pixel_gamma((double) q[c])))];
+          else
+            q[c]=QuantumOps<Q>::clamp(encode_pixel_gamma((double) table[QuantumOps<Q>::map_index(q[c])]));
+        }
+      store_pixel<Q,C>(pixels+at*C,q);
+    }
+}
+
+template<typename Q>
+static MhStatus colorspace_log_typed(const View &img,bool forward)
+{
+  std::vector<Q> host;
+  build_log_table<Q>(forward,host);
+  Temp table;
+  MH_TRY(upload_table(table,img.device,img.stream,host.data(),host.size()*sizeof(Q)));
+  const size_t n=img.columns*img.rows;
+  dim3 grid(stream_grid(n)),block(256);
+  Q *pixels=static_cast<Q *>(img.pixels);
+  ProfileScope prof("colorspace",img.stream);
+  if (img.channels == 3)
+    {
+      if (forward)
+        hipLaunchKernelGGL((colorspace_log_kernel<Q,3,true>),grid,block,0,img.stream,pixels,n,table.as<Q>());
+      else
+        hipLaunchKernelGGL((colorspace_log_kernel<Q,3,false>),grid,block,0,img.stream,pixels,n,table.as<Q>());
+    }
+  else
+    {
+      if (forward)
+        hipLaunchKernelGGL((colorspace_log_kernel<Q,4,true>),grid,block,0,img.stream,pixels,n,table.as<Q>());
+      else
+        hipLaunchKernelGGL((colorspace_log_kernel<Q,4,false>),grid,block,0,img.stream,pixels,n,table.as<Q>());
+    }
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+static bool colorspace_is_generic(MhColorspace c)
+{
+  return generic_colorspace(c) || matrix_colorspace(c) || (c == MH_COLORSPACE_LOG);
+}
 static MhStatus colorspace_generic_forward_or_inverse(const View &img,MhColorspace colorspace,bool forward)
 {
+  if (colorspace == MH_COLORSPACE_LOG)
+    return img.quantum == MH_QUANTUM_U16 ? colorspace_log_typed<uint16_t>(img,forward) :
+      colorspace_log_typed<float>(img,forward);
+  if (matrix_colorspace(colorspace))
+    return colorspace_matrix_step(img,colorspace,forward);
   return colorspace_generic_step(img,colorspace,forward);
 }
 

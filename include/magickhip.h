@@ -109,13 +109,19 @@ typedef enum
   MH_COLORSPACE_LCH = 12,      /* alias of LCHab in the pixel loops (colorspace.c:488-489) */
   MH_COLORSPACE_LCHAB = 13,
   MH_COLORSPACE_LCHUV = 14,
+  MH_COLORSPACE_LOG = 15,          /* default film parameters only (colorspace.c:1057-1060) */
   MH_COLORSPACE_LMS = 16,
   MH_COLORSPACE_LUV = 17,
+  MH_COLORSPACE_OHTA = 18,         /* the table-driven transforms, colorspace.c:1254-1420, :2591-2790 */
+  MH_COLORSPACE_REC601YCBCR = 19,
+  MH_COLORSPACE_REC709YCBCR = 20,
   MH_COLORSPACE_RGB = 21,      /* linear RGB */
+  MH_COLORSPACE_SCRGB = 22,        /* the same pixel loops as RGB (colorspace.c:1164-1165, :2502-2503) */
   MH_COLORSPACE_SRGB = 23,
   MH_COLORSPACE_XYY = 25,
   MH_COLORSPACE_XYZ = 26,
   MH_COLORSPACE_YCBCR = 27,
+  MH_COLORSPACE_YCC = 28,          /* as a target only: YCC -> sRGB (YCCMap) is declined */
   MH_COLORSPACE_YDBDR = 29,
   MH_COLORSPACE_YIQ = 30,
   MH_COLORSPACE_YPBPR = 31,

@@ -681,6 +681,10 @@ static MagickBooleanType IsColorspaceAccelerated(const ColorspaceType colorspace
     case YIQColorspace: case YPbPrColorspace: case YUVColorspace: case JzazbzColorspace:
     case DisplayP3Colorspace: case Adobe98Colorspace: case ProPhotoColorspace:
     case OklabColorspace: case OklchColorspace: case CAT02LMSColorspace:
+    /* ... and the table-driven ones (colorspace.c:1254-1420, :2591-2790; YCC as a source is
+       declined by the library: its way back goes through YCCMap) */
+    case OHTAColorspace: case Rec601YCbCrColorspace: case Rec709YCbCrColorspace: case YCCColorspace:
+    case scRGBColorspace: case LogColorspace:
       return(MagickTrue);
     default:
       break;
@@ -783,6 +787,12 @@ MagickPrivate MagickBooleanType AccelerateTransformImageColorspace(Image *image,
       (GetImageArtifact(image,"color:illuminant") != (const char *) NULL) ||
       (GetImageProperty(image,"white-luminance",exception) != (const char *) NULL))
     return(HipDeclined(image,MagickFalse));          /* D65 and the default Jzazbz white luminance only (colorspace.c:993-995) */
+  if (((image->colorspace == LogColorspace) || (colorspace == LogColorspace)) &&
+      ((GetImageProperty(image,"gamma",exception) != (const char *) NULL) ||
+       (GetImageProperty(image,"film-gamma",exception) != (const char *) NULL) ||
+       (GetImageProperty(image,"reference-black",exception) != (const char *) NULL) ||
+       (GetImageProperty(image,"reference-white",exception) != (const char *) NULL)))
+    return(HipDeclined(image,MagickFalse));          /* the default film parameters only (colorspace.c:1073-1088) */
   if (BeginHipCall(&call,image,0,0,exception) == MagickFalse)
     return(HipDeclined(image,MagickFalse));
   /* ColorspaceType and MhColorspace share their values (colorspace.h:27-66) */

@@ -49,7 +49,61 @@ def test_colorspace_to_srgb(im, refmod, space, dtype):
     assert_parity(dev.numpy(), want, True, "%s -> sRGB" % space, max_ulp=1)
 
 
-@pytest.mark.parametrize("pair", [("HSL", "Lab"), ("YUV", "RGB"), ("OkLab", "LCHuv"), ("XYZ", "HWB")])
+# the table-driven half of sRGBTransformImage / TransformsRGBImage (colorspace.c:1226-1420, :2560-2790)
+TABLE_SPACES = ["OHTA", "Rec601YCbCr", "Rec709YCbCr", "YCC", "scRGB", "Log"]
+
+
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("space", TABLE_SPACES)
+def test_srgb_to_table_driven_colorspace(im, refmod, space, dtype):
+    """Every table entry is one rounded product of the map index: formed in place, in the table's
+    own operations — bit-identical on both Quantum types (scRGB: linear RGB's loop, whose float
+    results may differ by an ULP of the device pow)."""
+    px = special_pixels(make_pixels(45, 67, 4, dtype, seed=len(space) * 5 + 2))
+    if dtype == HDRI:
+        px[3, :8, 0] = [-5.0, 70000.0, 0.25, 0.5, 65534.5, 65535.0, 1.5, 2.5]      # clamps and .5 indices
+    dev = im.Image(to_device(px), colorspace="sRGB")
+    im.transform_image_colorspace(dev, space)
+    want = refmod.RefImage(px, "sRGB").colorspace(space).numpy()
+    if space == "scRGB":
+        assert_parity(dev.numpy(), want, True, "sRGB -> scRGB", max_ulp=1)
+    elif space == "Log" and dtype == HDRI:
+        # the table index is the decoded float sample rounded: where the device pow's last bit moves it
+        # across n + 1/2 the result is the neighbouring table entry (a handful of samples per million)
+        same = dev.numpy().view(np.uint32) == want.view(np.uint32)
+        assert same.mean() > 0.9999 and np.abs(dev.numpy() - want).max() < 2.0, "sRGB -> Log (float)"
+    else:
+        bits = np.uint32 if dtype == HDRI else np.uint16
+        assert np.array_equal(dev.numpy().view(bits), want.view(bits)), "sRGB -> %s" % space
+    assert np.array_equal(dev.numpy()[:, :, 3], px[:, :, 3])
+
+
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("space", ["OHTA", "Rec601YCbCr", "Rec709YCbCr", "scRGB", "Log"])
+def test_table_driven_colorspace_to_srgb(im, refmod, space, dtype):
+    px = special_pixels(make_pixels(39, 51, 3, dtype, seed=len(space) * 3 + 4))
+    dev = im.Image(to_device(px), colorspace=space)
+    im.transform_image_colorspace(dev, "sRGB")
+    want = refmod.RefImage(px, space).colorspace("sRGB").numpy()
+    if space in ("scRGB", "Log"):
+        assert_parity(dev.numpy(), want, True, "%s -> sRGB" % space, max_ulp=1)
+    else:
+        bits = np.uint32 if dtype == HDRI else np.uint16
+        assert np.array_equal(dev.numpy().view(bits), want.view(bits)), "%s -> sRGB" % space
+
+
+def test_ycc_to_srgb_is_declined(im):
+    """YCC's way back goes through the 1389-entry film curve YCCMap (colorspace.c:2789-2797): not
+    accelerated, and the image is left as it was."""
+    px = make_pixels(8, 9, 3, Q16, seed=1)
+    dev = im.Image(to_device(px), colorspace="YCC")
+    with pytest.raises(Exception):
+        im.transform_image_colorspace(dev, "sRGB")
+    assert np.array_equal(dev.numpy(), px)
+
+
+@pytest.mark.parametrize("pair", [("HSL", "Lab"), ("YUV", "RGB"), ("OkLab", "LCHuv"), ("XYZ", "HWB"),
+                                  ("OHTA", "Rec709YCbCr"), ("Lab", "YCC")])
 def test_colorspace_to_colorspace_goes_through_srgb(im, refmod, pair):
     """TransformImageColorspace X -> Y is X -> sRGB -> Y (colorspace.c:1751-1783), each step
     rounded to Quantum."""

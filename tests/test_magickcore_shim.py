@@ -251,6 +251,16 @@ def test_colorspace_and_contrast_stretch_chain(shim, dtype):
         c.colorspace(target)
         assert g.info()["colorspace"] == c.info()["colorspace"], target
         assert_parity(g.numpy(), c.numpy(), True, "-> %s via MagickCore" % target, max_ulp=1)
+    # ... and of the table-driven ones (round 4): accelerated in both directions, except YCC -> sRGB,
+    # which the library declines (YCCMap) — MagickCore's CPU path runs and the bits are the same
+    g, c = shim.RefImage(px, shim=True), shim.RefImage(px)
+    before = accelerated_calls(shim, hdri)
+    for target in ("OHTA", "Rec709YCbCr", "sRGB", "Rec601YCbCr", "scRGB", "YCC", "sRGB"):
+        g.colorspace(target)
+        c.colorspace(target)
+        assert g.info()["colorspace"] == c.info()["colorspace"], target
+        assert_parity(g.numpy(), c.numpy(), True, "-> %s via MagickCore" % target, max_ulp=1)
+    assert accelerated_calls(shim, hdri) == before + 6
 
 
 @pytest.mark.parametrize("dtype", [np.uint16, np.float32])
