@@ -342,14 +342,15 @@ def convolve_image(image, kernel):
     return out
 
 
-MORPHOLOGY_COMPOSE = {None: 0, "undefined": 0, "none": 1, "no": 1, "lighten": 2, "difference": 3}
+MORPHOLOGY_COMPOSE = {None: 0, "undefined": 0, "none": 1, "no": 1, "lighten": 2, "difference": 3, "darken": 5,
+                      "plus": 6, "multiply": 7, "screen": 8}
 
 
 def morphology_image(image, method, iterations, kernel, bias=0.0, scale=None, compose=None):
     """MorphologyImage(image, method, iterations, kernel) — MagickCore/morphology.c:4129.
     scale=(1.0, 1) is `-define convolve:scale='!'` (the kernel normalised before use);
     compose is `-define morphology:compose=` (None: the method's default; "None", "Lighten",
-    "Difference": how the results of a kernel list are merged; any other operator raises
+    "Difference", "Darken", "Plus", "Multiply", "Screen": how the results of a kernel list are merged; any other operator raises
     MagickHipError: the CPU path's business)."""
     lib = _lib.load()
     out = image.like()

@@ -640,6 +640,10 @@ static MhStatus morphology_apply(const View &src,const View &dst,const MhImage *
     case MH_MORPHOLOGY_COMPOSE_NONE: compose=-1; break;
     case MH_MORPHOLOGY_COMPOSE_LIGHTEN: compose=MH_COMPOSITE_LIGHTEN; break;
     case MH_MORPHOLOGY_COMPOSE_DIFFERENCE: compose=MH_COMPOSITE_DIFFERENCE; break;
+    case MH_MORPHOLOGY_COMPOSE_DARKEN: compose=MH_COMPOSITE_DARKEN; break;
+    case MH_MORPHOLOGY_COMPOSE_PLUS: compose=MH_COMPOSITE_PLUS; break;
+    case MH_MORPHOLOGY_COMPOSE_MULTIPLY: compose=MH_COMPOSITE_MULTIPLY; break;
+    case MH_MORPHOLOGY_COMPOSE_SCREEN: compose=MH_COMPOSITE_SCREEN; break;
     default:
       return fail(MH_UNSUPPORTED,"morphology:compose operator %d is not accelerated",(int) compose_override);
   }

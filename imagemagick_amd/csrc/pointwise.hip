@@ -2126,7 +2126,8 @@ static MhStatus apply_q16_column(const View &img,const uint16_t *column,uint32_t
 // 0,0, default artifacts (compose:sync and compose:clamp on): composite.c:2396-2428 (alpha),
 // :2523-2711 (alpha channel), :2716-2751 (Sca/Dca/gamma), :2922-2933 (Difference),
 // :3110-3124 (Lighten), ClampPixel pixel-accessor.h:35-46.
-enum CompositeKind { COMPOSITE_DIFFERENCE=0,COMPOSITE_LIGHTEN=1 };
+enum CompositeKind { COMPOSITE_DIFFERENCE=0,COMPOSITE_LIGHTEN=1,COMPOSITE_DARKEN=2,COMPOSITE_PLUS=3,COMPOSITE_MULTIPLY=4,
+  COMPOSITE_SCREEN=5 };
 
 template<typename Q> static __device__ __forceinline__ Q clamp_pixel(double pixel);
 template<> __device__ __forceinline__ uint16_t clamp_pixel<uint16_t>(double pixel)
@@ -2160,14 +2161,18 @@ void composite_kernel(Q *__restrict__ canvas,const Q *__restrict__ source,size_t
       // GetPixelAlpha gives OpaqueAlpha for an image without an alpha channel
       const double Sa=kQS*(alpha_index >= 0 ? (double) s[alpha_index < 0 ? 0 : alpha_index] : kQR);
       const double Da=kQS*(alpha_index >= 0 ? (double) d[alpha_index < 0 ? 0 : alpha_index] : kQR);
-      double alpha=Sa+Da-Sa*Da;                                  // RoundToUnity
+      // Plus: RoundToUnity(source_dissolve*Sa+canvas_dissolve*Da), both 1 (composite.c:2462-2467);
+      // the others RoundToUnity(Sa+Da-Sa*Da) (:2398-2426)
+      double alpha=OP == COMPOSITE_PLUS ? 1.0*Sa+1.0*Da : Sa+Da-Sa*Da;
       alpha=alpha < 0.0 ? 0.0 : (alpha > 1.0 ? 1.0 : alpha);
-      const double gamma=perceptible_reciprocal(OP == COMPOSITE_LIGHTEN ? 1.0-alpha : alpha);
+      // composite.c:2737-2751
+      const double gamma=perceptible_reciprocal(((OP == COMPOSITE_LIGHTEN) || (OP == COMPOSITE_DARKEN)) ? 1.0-alpha : alpha);
 #pragma unroll
       for (int c=0; c < C; c++)
         {
           if ((c == alpha_index) && (((update_mask >> c) & 1u) != 0))
             {
+              // composite.c:2580-2712 (Multiply with synchronised channels: the default case)
               const double pixel=OP == COMPOSITE_DIFFERENCE ? kQR*fabs(Sa-Da) : kQR*alpha;
               d[c]=clamp_pixel<Q>(pixel);
               continue;
@@ -2182,8 +2187,14 @@ void composite_kernel(Q *__restrict__ canvas,const Q *__restrict__ source,size_t
               const double a=Sca*Da,b=Dca*Sa;
               pixel=kQR*gamma*(Sca+Dca-2.0*(a < b ? a : b));
             }
-          else if ((Sca*Da) > (Dca*Sa))
-            pixel=kQR*(Sca+Dca*(1.0-Sa));
+          else if (OP == COMPOSITE_PLUS)
+            pixel=kQR*(Sca+Dca);                                 // composite.c:3369-3378
+          else if (OP == COMPOSITE_MULTIPLY)
+            pixel=kQR*gamma*(Sca*Dca+Sca*(1.0-Da)+Dca*(1.0-Sa)); // :3288-3299
+          else if (OP == COMPOSITE_SCREEN)
+            pixel=kQR*gamma*(Sca+Dca-Sca*Dca);                   // :3447-3461
+          else if (OP == COMPOSITE_DARKEN ? (Sca*Da) < (Dca*Sa) : (Sca*Da) > (Dca*Sa))
+            pixel=kQR*(Sca+Dca*(1.0-Sa));                        // :2892-2910, :3110-3124
           else
             pixel=kQR*(Dca+Sca*(1.0-Da));
           d[c]=clamp_pixel<Q>(pixel);
@@ -2198,14 +2209,20 @@ static MhStatus composite_typed(const View &canvas,const View &source,int kind,c
   const size_t n=canvas.columns*canvas.rows;
   dim3 grid(stream_grid(n)),block(256);
   ProfileScope prof("composite",canvas.stream);
-  if (kind == COMPOSITE_DIFFERENCE)
-    hipLaunchKernelGGL((composite_kernel<Q,C,COMPOSITE_DIFFERENCE>),grid,block,0,canvas.stream,
-      static_cast<Q *>(canvas.pixels),static_cast<const Q *>(source.pixels),n,roles.alpha,
-      roles.update_mask,roles.copy_mask);
-  else
-    hipLaunchKernelGGL((composite_kernel<Q,C,COMPOSITE_LIGHTEN>),grid,block,0,canvas.stream,
-      static_cast<Q *>(canvas.pixels),static_cast<const Q *>(source.pixels),n,roles.alpha,
-      roles.update_mask,roles.copy_mask);
+#define MH_COMPOSE(OP) \
+  hipLaunchKernelGGL((composite_kernel<Q,C,OP>),grid,block,0,canvas.stream,static_cast<Q *>(canvas.pixels), \
+    static_cast<const Q *>(source.pixels),n,roles.alpha,roles.update_mask,roles.copy_mask)
+  switch (kind)
+  {
+    case COMPOSITE_DIFFERENCE: MH_COMPOSE(COMPOSITE_DIFFERENCE); break;
+    case COMPOSITE_LIGHTEN: MH_COMPOSE(COMPOSITE_LIGHTEN); break;
+    case COMPOSITE_DARKEN: MH_COMPOSE(COMPOSITE_DARKEN); break;
+    case COMPOSITE_PLUS: MH_COMPOSE(COMPOSITE_PLUS); break;
+    case COMPOSITE_MULTIPLY: MH_COMPOSE(COMPOSITE_MULTIPLY); break;
+    case COMPOSITE_SCREEN: MH_COMPOSE(COMPOSITE_SCREEN); break;
+    default: return fail(MH_UNSUPPORTED,"composite operator %d",kind);
+  }
+#undef MH_COMPOSE
   MH_HIP(hipGetLastError());
   return MH_OK;
 }

@@ -468,15 +468,20 @@ MH_API MhStatus MagickHipMorphologyImage(const MhImage *image,MhImage *morpholog
 
 /* The same with the user's `morphology:compose` (morphology.c:4206-4215, :3779-3782): how the
    results of the kernels of a list are merged.  DEFAULT = UndefinedCompositeOp, NONE =
-   NoCompositeOp (re-iterate the previous result), LIGHTEN / DIFFERENCE = CompositeImage with that
-   operator.  Other operators: MH_UNSUPPORTED (the CPU path runs). */
+   NoCompositeOp (re-iterate the previous result), LIGHTEN / DIFFERENCE / DARKEN / PLUS / MULTIPLY /
+   SCREEN = CompositeImage with that operator (composite.c:2396-3124, synchronised channels).
+   Other operators: MH_UNSUPPORTED (the CPU path runs). */
 typedef enum
 {
   MH_MORPHOLOGY_COMPOSE_DEFAULT = 0,
   MH_MORPHOLOGY_COMPOSE_NONE = 1,
   MH_MORPHOLOGY_COMPOSE_LIGHTEN = 2,
   MH_MORPHOLOGY_COMPOSE_DIFFERENCE = 3,
-  MH_MORPHOLOGY_COMPOSE_OTHER = 4
+  MH_MORPHOLOGY_COMPOSE_OTHER = 4,
+  MH_MORPHOLOGY_COMPOSE_DARKEN = 5,
+  MH_MORPHOLOGY_COMPOSE_PLUS = 6,      /* `-define morphology:compose=Plus`, morphology.c:772 */
+  MH_MORPHOLOGY_COMPOSE_MULTIPLY = 7,
+  MH_MORPHOLOGY_COMPOSE_SCREEN = 8
 } MhMorphologyCompose;
 MH_API MhStatus MagickHipMorphologyImageCompose(const MhImage *image,MhImage *morphology_image,
   MhMorphologyMethod method,ptrdiff_t iterations,const MhKernelInfo *kernel,

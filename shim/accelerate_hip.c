@@ -77,7 +77,7 @@ static const char *DescribeGate(const Image *image)
       (GetImageArtifact(image,"morphology:compose") != (const char *) NULL) ||
       (GetImageArtifact(image,"morphology:showKernel") != (const char *) NULL))
     return("a convolve: / morphology: artifact is set (Blur, UnsharpMask and Convolve hooks decline; "
-      "MorphologyApply honours bias, scale and the compose operators None, Lighten, Difference)");
+      "MorphologyApply honours bias, scale and the compose operators None, Lighten, Difference, Darken, Plus, Multiply, Screen)");
   switch (GetImageVirtualPixelMethod(image))
   {
     case UndefinedVirtualPixelMethod:
@@ -624,9 +624,18 @@ MagickPrivate Image *AccelerateMorphologyApply(const Image *image,
     case NoCompositeOp: override=MH_MORPHOLOGY_COMPOSE_NONE; break;
     case LightenCompositeOp: override=MH_MORPHOLOGY_COMPOSE_LIGHTEN; break;
     case DifferenceCompositeOp: override=MH_MORPHOLOGY_COMPOSE_DIFFERENCE; break;
+    case DarkenCompositeOp: override=MH_MORPHOLOGY_COMPOSE_DARKEN; break;
+    case PlusCompositeOp: override=MH_MORPHOLOGY_COMPOSE_PLUS; break;
+    case MultiplyCompositeOp: override=MH_MORPHOLOGY_COMPOSE_MULTIPLY; break;
+    case ScreenCompositeOp: override=MH_MORPHOLOGY_COMPOSE_SCREEN; break;
     default: return(HipDeclined(image,(Image *) NULL));
   }
   if ((iterations == 0) || (IsImageAcceleratable(image) == MagickFalse))
+    return(HipDeclined(image,(Image *) NULL));
+  /* CompositeImage's own switches (composite.c:1530-1536): the backend composes with synchronised
+     channels and ClampPixel, the defaults */
+  if ((GetImageArtifact(image,"compose:sync") != (const char *) NULL) ||
+      (GetImageArtifact(image,"compose:clamp") != (const char *) NULL))
     return(HipDeclined(image,(Image *) NULL));
   n=0;
   for (k=kernel; k != (const KernelInfo *) NULL; k=k->next)

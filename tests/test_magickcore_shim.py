@@ -225,6 +225,22 @@ def test_hit_and_miss_list_through_magickcore(shim):
     assert accelerated_calls(shim, False) == before + 2
 
 
+@pytest.mark.parametrize("compose,accelerated", [("Plus", True), ("Darken", True), ("Screen", True), ("Exclusion", False)])
+def test_morphology_compose_through_magickcore(shim, compose, accelerated):
+    """`-define morphology:compose=` (morphology.c:4206-4215) reaches the hook as MorphologyApply's
+    compose argument: Plus / Darken / Multiply / Screen (round 4) compose on the device, any other
+    operator is MagickCore's CPU path."""
+    px = make_pixels(44, 60, 4, np.uint16, kind="smooth")
+    g, c = shim.RefImage(px, shim=True), shim.RefImage(px)
+    before = accelerated_calls(shim, False)
+    for image in (g, c):
+        image.set_artifact("morphology:compose", compose)
+    got = g.morphology("Convolve", 1, "Sobel:>").numpy()
+    want = c.morphology("Convolve", 1, "Sobel:>").numpy()
+    assert accelerated_calls(shim, False) == before + (1 if accelerated else 0)
+    assert_parity(got, want, True, "Convolve Sobel:> compose %s via MagickCore" % compose)
+
+
 @pytest.mark.parametrize("dtype", [np.uint16, np.float32])
 def test_colorspace_and_contrast_stretch_chain(shim, dtype):
     """BASELINE config C4 through MagickCore: TransformImageColorspace(Lab) (new hook,
