@@ -17,12 +17,13 @@
 // zero stands in for a NaN cell here, and 0*inf is not "no cell".
 //
 // MI355X mapping.  A workgroup of four waves owns 64 x 16 outputs and stages the (16+kh-1) x
-// (64+kw-1) source window as CHANNEL PLANES of doubles (138 KB for 31 x 31 RGBA; consecutive lanes
-// read consecutive doubles: no bank conflicts).  Lane = output column, wave = four output rows:
-// for a kernel column u the lane walks DOWN its window column once, and every sample it reads
-// feeds four multiply-adds — output row r takes it with cell v-r — so an LDS read of 8 bytes a
-// lane serves four fused multiply-adds: 16 a channel set against 5 reads (4 planes + the cell,
-// broadcast), the fp64 pipe is the bound: 16384^2 x 4 x 709 FMAs = 19 ms at 64 a clock and CU.
+// (64+kw-1) source window as PIXEL SLOTS of four 4-byte samples (69 KB for 31 x 31: two workgroups
+// a CU; consecutive lanes read consecutive slots: no bank conflicts).  Lane = output column, wave =
+// four output rows: for a kernel column u the lane walks DOWN its window column once, and every
+// pixel it reads — one ds_read_b128 — feeds four multiply-adds per channel: output row r takes it
+// with cell v-r.  16 multiply-adds against two LDS reads (the pixel, the cell: broadcast) and four
+// conversions (seven vector instructions for an alpha-weighted float frame, whose alpha*p is formed
+// here), the fp64 pipe is the bound: 16384^2 x 4 x 709 FMAs = 19 ms at 64 a clock and CU.
 #include "mh_internal.hpp"
 #include "device_common.hpp"
 #include "tie_check.hpp"
@@ -65,12 +66,17 @@ void conv2d_tie_kernel(Conv2DTieArgs args)
   const int W=args.columns,H=args.rows;
   const int TW=args.tile_w,TH=args.tile_h;
   const int plane=TW*TH;
-  // the staged samples: alpha*p of a Q16 frame is an integer below 2^32, a plain float sample a
-  // float — four bytes each, two workgroups a CU; alpha*p of a float frame needs the double
-  typedef typename std::conditional<sizeof(Q) == 2,uint32_t,
-    typename std::conditional<BLEND,double,float>::type>::type Staged;
-  Staged *tile=reinterpret_cast<Staged *>(smem_raw);               // [C][TH][TW]
-  double *cells=reinterpret_cast<double *>(smem_raw+(((size_t) C*plane*sizeof(Staged)+15u) & ~(size_t) 15u));   // [kh][kw]
+  // the staged samples, four bytes each and a pixel's channels side by side (one ds_read_b128 — or
+  // b64 for one and two channels — hands a lane the whole pixel): alpha*p of a Q16 frame as the
+  // integer below 2^32 it is, a float frame's samples as the floats they are — alpha*p of two floats
+  // needs a double, so an alpha-weighted float frame stages (p.., alpha) and multiplies in the walk,
+  // in fp64, exactly.  (First version: channel planes, the alpha-weighted float frame as DOUBLES —
+  // 138 KB for 31 x 31, one workgroup of four waves a CU, five LDS reads per 16 multiply-adds:
+  // Disk:15 on 4096^2 5.7 ms.)
+  constexpr int SLOT=C <= 2 ? 2 : 4;
+  typedef uint32_t Slot __attribute__((ext_vector_type(SLOT)));
+  Slot *tile=reinterpret_cast<Slot *>(smem_raw);                   // [TH][TW]
+  double *cells=reinterpret_cast<double *>(smem_raw+(((size_t) plane*sizeof(Slot)+15u) & ~(size_t) 15u));   // [kh][kw]
   double *wave_most=cells+args.kw*args.kh;                          // [4 waves][4 channels]
   int *spans=reinterpret_cast<int *>(wave_most+16);                 // [kw][2]
   const int tid=(int) threadIdx.x,lane=tid & 63,wave=tid >> 6;
@@ -92,6 +98,10 @@ void conv2d_tie_kernel(Conv2DTieArgs args)
       Q q[C];
       load_pixel<Q,C>(src+((size_t) y*W+(size_t) x)*C,q);
       const double alpha=BLEND ? (double) q[C-1] : 1.0;
+      Slot staged;
+#pragma unroll
+      for (int c=0; c < SLOT; c++)
+        staged[c]=0u;
 #pragma unroll
       for (int c=0; c < C; c++)
         {
@@ -99,17 +109,18 @@ void conv2d_tie_kernel(Conv2DTieArgs args)
           if constexpr (sizeof(Q) == 2)
             {
               const uint32_t product=(BLEND && (c != C-1)) ? (uint32_t) q[C-1]*(uint32_t) q[c] : (uint32_t) q[c];
-              tile[c*plane+i]=product;
+              staged[c]=product;
               p=(double) product;
             }
           else
             {
               p=(BLEND && (c != C-1)) ? alpha*(double) q[c] : (double) q[c];
-              tile[c*plane+i]=(Staged) p;              // (plain: the float it was)
+              staged[c]=__float_as_uint((float) q[c]);
             }
           const double magnitude=__builtin_fabs(p);
           most[c]=(magnitude > most[c]) || !(magnitude == magnitude) ? magnitude : most[c];
         }
+      tile[i]=staged;
     }
 #pragma unroll
   for (int c=0; c < C; c++)
@@ -147,7 +158,7 @@ void conv2d_tie_kernel(Conv2DTieArgs args)
 #pragma unroll
     for (int c=0; c < C; c++)
       acc[r][c]=0.0;
-  const Staged *column=tile+(4*wave)*TW+lane;
+  const Slot *column=tile+(4*wave)*TW+lane;
   for (int u=0; u < args.kw; u++)
     {
       // down the window column x+u: the sample of window row v (of output row 0) is the sample of
@@ -155,20 +166,39 @@ void conv2d_tie_kernel(Conv2DTieArgs args)
       // (a disk's columns are short at its sides), and three more for the rows behind.
       const int first=spans[2*u],last=spans[2*u+1];
       double k1=0.0,k2=0.0,k3=0.0;               // the cells of rows v-1, v-2, v-3
-      const Staged *at=column+u+first*TW;
+      const Slot *at=column+u+first*TW;
       const double *cell=cells+u;
 #pragma unroll 4
       for (int v=first; v < last+3; v++)
         {
           const double k0=v < last ? cell[v*args.kw] : 0.0;
+          const Slot raw=*at;
+          double p[C];
+          if constexpr (sizeof(Q) == 2)
+            {
+#pragma unroll
+              for (int c=0; c < C; c++)
+                p[c]=(double) raw[c];
+            }
+          else
+            {
+#pragma unroll
+              for (int c=0; c < C; c++)
+                p[c]=(double) __uint_as_float(raw[c]);
+              if constexpr (BLEND)
+                {
+#pragma unroll
+                  for (int c=0; c < C-1; c++)
+                    p[c]=p[C-1]*p[c];              // alpha*p: exact in fp64
+                }
+            }
 #pragma unroll
           for (int c=0; c < C; c++)
             {
-              const double p=(double) at[c*plane];
-              acc[0][c]=__builtin_fma(k0,p,acc[0][c]);
-              acc[1][c]=__builtin_fma(k1,p,acc[1][c]);
-              acc[2][c]=__builtin_fma(k2,p,acc[2][c]);
-              acc[3][c]=__builtin_fma(k3,p,acc[3][c]);
+              acc[0][c]=__builtin_fma(k0,p[c],acc[0][c]);
+              acc[1][c]=__builtin_fma(k1,p[c],acc[1][c]);
+              acc[2][c]=__builtin_fma(k2,p[c],acc[2][c]);
+              acc[3][c]=__builtin_fma(k3,p[c],acc[3][c]);
             }
           k3=k2;
           k2=k1;
@@ -268,8 +298,8 @@ MhStatus launch_conv2d_tie(const View &src,const View &dst,const MhKernelInfo *k
     return MH_OK;
   const int tile_w=(kTieW+kw-1+1) & ~1,tile_h=kTieH+kh-1;
   const bool is_float=src.quantum != MH_QUANTUM_U16;
-  const size_t staged_bytes=(is_float && blend) ? sizeof(double) : 4u;     // conv2d_tie_kernel's Staged
-  const size_t lds=(((size_t) src.channels*tile_w*tile_h*staged_bytes+15u) & ~(size_t) 15u)+
+  const size_t slot_bytes=src.channels <= 2 ? 8u : 16u;                     // conv2d_tie_kernel's Slot
+  const size_t lds=(((size_t) tile_w*tile_h*slot_bytes+15u) & ~(size_t) 15u)+
     ((size_t) kw*kh+16)*sizeof(double)+(size_t) 2*kw*sizeof(int);
   if (lds > 160u*1024u)
     return MH_OK;
