@@ -326,9 +326,15 @@ MhStatus launch_histogram(const View &src,int intensity_mode,const MhImage *desc
 MhStatus launch_apply_lut(const View &img,const void *lut_device,uint32_t apply_mask,
   const Roles &roles,int shared_column,const uint32_t *device_mask=nullptr);
 // histogram [65536][channels] -> Quantum-typed LUT + per-channel apply mask, on the device
+// cdf_device (optional, equalize): the running counts of channel cdf_column as 65536 uint32 (all of
+// them 0xffffffff when the frame has 2^32 pixels or more)
 MhStatus launch_build_lut(const View &img,const unsigned long long *hist_device,bool equalize,
   double black_point,double white_limit,void *lut_device,uint32_t *mask_device,
-  const unsigned int *colour_flag_device);
+  const unsigned int *colour_flag_device,uint32_t *cdf_device=nullptr,int cdf_column=0);
+// EqualizeImage's map evaluated per sample from the running counts (float Quantum, one histogram
+// for every channel); lut_device: the tabulated map, the fallback
+MhStatus launch_equalize_cdf_apply(const View &img,const uint32_t *cdf_device,const void *lut_device,
+  uint32_t apply_mask,const Roles &roles,int shared_column,const uint32_t *device_mask);
 // (operators_enhance.cpp) device histogram -> LUT -> apply: the second half of
 // ContrastStretchImage / EqualizeImage
 MhStatus apply_histogram_lut(const View &view,const MhImage *image,const unsigned long long *hist,

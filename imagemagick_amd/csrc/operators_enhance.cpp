@@ -154,8 +154,6 @@ MhStatus apply_histogram_lut(const View &view,const MhImage *image,const unsigne
   MH_TRY(lut.alloc(view.device,n*(view.quantum == MH_QUANTUM_U16 ? sizeof(unsigned short) :
     sizeof(float)),view.stream));
   MH_TRY(mask.alloc(view.device,sizeof(uint32_t),view.stream));
-  MH_TRY(launch_build_lut(view,hist,equalize,black_point,white_limit,
-    lut.ptr,mask.as<uint32_t>(),colour_flag));
   Roles roles=channel_roles(image,image);
   // enhance.c:1781, :2255: only channels whose traits carry Update
   uint32_t update=0;
@@ -167,6 +165,19 @@ MhStatus apply_histogram_lut(const View &view,const MhImage *image,const unsigne
   int shared_column=-1;
   if (((mode != 0) || (view.channels == 1)) && (update != 0))
     shared_column=__builtin_ctz(update);
+  // EqualizeImage on a float frame: the map evaluated per sample from the running counts in LDS
+  // instead of gathered from a 65536-float table (pointwise.hip)
+  if (equalize && (view.quantum != MH_QUANTUM_U16) && (shared_column >= 0) && (view.channels <= 4) &&
+      (view.columns*view.rows >= ((size_t) 1 << 20)) && (option("MAGICKHIP_NO_EQUALIZE_COUNTS") == nullptr))
+    {
+      Temp counts;
+      MH_TRY(counts.alloc(view.device,(size_t) MH_HISTOGRAM_BINS*sizeof(uint32_t),view.stream));
+      MH_TRY(launch_build_lut(view,hist,equalize,black_point,white_limit,
+        lut.ptr,mask.as<uint32_t>(),colour_flag,counts.as<uint32_t>(),shared_column));
+      return launch_equalize_cdf_apply(view,counts.as<uint32_t>(),lut.ptr,~0u,roles,shared_column,mask.as<uint32_t>());
+    }
+  MH_TRY(launch_build_lut(view,hist,equalize,black_point,white_limit,
+    lut.ptr,mask.as<uint32_t>(),colour_flag));
   return launch_apply_lut(view,lut.ptr,~0u,roles,shared_column,mask.as<uint32_t>());
 }
 

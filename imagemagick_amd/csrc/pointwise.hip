@@ -1660,6 +1660,8 @@ struct LutBuildArgs
   void *lut;                          // Quantum-typed [65536][channels]
   uint32_t *mask;                     // out: bit c set when channel c has black != white
   const unsigned int *colour_flag;    // optional: 0 => image is gray => leave every channel alone
+  uint32_t *cdf;                      // optional (equalize): the running counts of channel cdf_column
+  int cdf_column;
 };
 
 __device__ __forceinline__ double lut_scale_map_to_quantum(double value,int is_u16)
@@ -1787,6 +1789,8 @@ void lut_scan_kernel(LutBuildArgs a,LutScratch *scratch)
     {
       // integrate, enhance.c:2138-2152; map, :2162-2168
       const double black=(double) a.hist[c],white=(double) total;
+      if ((a.cdf != nullptr) && (c == a.cdf_column))
+        a.cdf[j]=(total >> 32) != 0ull ? 0xffffffffu : (uint32_t) cum;
       if (black == white)
         return;
       lut_store(a,j,c,lut_scale_map_to_quantum(
@@ -1855,9 +1859,12 @@ MhStatus launch_table_add(unsigned long long *dst,const unsigned long long *src,
 }
 
 MhStatus launch_build_lut(const View &img,const unsigned long long *hist,bool equalize,
-  double black_point,double white_limit,void *lut,uint32_t *mask,const unsigned int *colour_flag)
+  double black_point,double white_limit,void *lut,uint32_t *mask,const unsigned int *colour_flag,
+  uint32_t *cdf,int cdf_column)
 {
   LutBuildArgs a;
+  a.cdf=equalize ? cdf : nullptr;
+  a.cdf_column=cdf_column;
   a.hist=hist;
   a.channels=img.channels;
   a.equalize=equalize ? 1 : 0;
@@ -1950,6 +1957,8 @@ MhStatus launch_stretch_levels_apply(const View &img,const unsigned long long *h
   a.hist=hist;
   a.channels=img.channels;
   a.equalize=0;
+  a.cdf=nullptr;
+  a.cdf_column=0;
   a.black_point=black_point;
   a.white_limit=white_limit;
   a.is_u16=img.quantum == MH_QUANTUM_U16 ? 1 : 0;
@@ -2079,6 +2088,110 @@ static MhStatus apply_lut_shared(const View &img,const void *lut,int column,uint
   hipLaunchKernelGGL((apply_lut_shared_kernel<C>),dim3(cus),dim3(1024),lds,img.stream,
     static_cast<uint16_t *>(img.pixels),n,static_cast<const uint16_t *>(lut),single_column ? 0 : column,mask,
     device_mask,single_column ? 1 : C);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+// EqualizeImage on a float frame whose channels share one histogram (intensity binning: the
+// default, synchronised channels).  Its map is  ScaleMapToQuantum(65535*(cum[j]-black)/(white-black))
+// (enhance.c:2162-2168) with INTEGER running counts cum[j]: 65536 floats of table (256 KB, a
+// gather through L2 per sample: 0.32 ms per 4096^2 RGBA frame) do not fit the LDS, the counts do —
+// a uint32 every 16 bins (16 KB) and a uint16 offset per bin (128 KB) — and the map is three
+// fp64 operations on them, the table's own, so the same bits.  A 16-bin group that holds more than
+// 65535 pixels (a frame with a flat background) or a frame of 2^32 pixels sends the workgroup to
+// the tabulated map.
+template<int C>
+__global__ __launch_bounds__(1024)
+void equalize_cdf_apply_kernel(float *pixels,size_t npixels,const uint32_t *cdf,const float *lut,int column,
+  uint32_t mask,const uint32_t *device_mask)
+{
+  if (device_mask != nullptr)
+    mask&=*device_mask;                 // (zero: gray frame, or black == white)
+  if (mask == 0)
+    return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint32_t *base=reinterpret_cast<uint32_t *>(smem_raw);                     // [4096]
+  uint16_t *offset=reinterpret_cast<uint16_t *>(smem_raw+4096*sizeof(uint32_t));   // [65536]
+  __shared__ int overflow;
+  if (threadIdx.x == 0)
+    overflow=cdf[65535] == 0xffffffffu ? 1 : 0;
+  __syncthreads();
+  for (int j=(int) threadIdx.x; j < 65536; j+=1024)
+    {
+      const uint32_t count=cdf[j],first=cdf[j & ~15];
+      const uint32_t d=count-first;
+      if (d > 65535u)
+        overflow=1;                     // (every writer writes the same 1)
+      offset[j]=(uint16_t) d;
+      if ((j & 15) == 0)
+        base[j >> 4]=count;
+    }
+  __syncthreads();
+  const bool tabulated=overflow != 0;
+  const double black=(double) cdf[0],white=(double) cdf[65535];
+  constexpr int BATCH=4;
+  const size_t stride=(size_t) gridDim.x*1024*BATCH;
+  for (size_t i0=(size_t) blockIdx.x*1024*BATCH+threadIdx.x; i0 < npixels; i0+=stride)
+    {
+      float q[BATCH][C];
+#pragma unroll
+      for (int k=0; k < BATCH; k++)
+        {
+          const size_t i=i0+(size_t) 1024*k;
+          load_pixel<float,C>(pixels+(i < npixels ? i : npixels-1)*C,q[k]);
+        }
+#pragma unroll
+      for (int k=0; k < BATCH; k++)
+        {
+          const size_t i=i0+(size_t) 1024*k;
+          if (i < npixels)
+            {
+#pragma unroll
+              for (int c=0; c < C; c++)
+                if ((mask >> c) & 1u)
+                  {
+                    const unsigned j=QuantumOps<float>::map_index(q[k][c]);
+                    if (tabulated)
+                      {
+                        q[k][c]=lut[(size_t) j*C+column];
+                        continue;
+                      }
+                    const double cum=(double) (base[j >> 4]+(uint32_t) offset[j]);
+                    const double value=(65535.0*(cum-black))/(white-black);
+                    q[k][c]=value <= 0.0 ? 0.0f : (value >= 65535.0 ? 65535.0f : (float) value);
+                  }
+              store_pixel<float,C>(pixels+i*C,q[k]);
+            }
+        }
+    }
+}
+
+MhStatus launch_equalize_cdf_apply(const View &img,const uint32_t *cdf,const void *lut,uint32_t apply_mask,
+  const Roles &roles,int shared_column,const uint32_t *device_mask)
+{
+  const uint32_t mask=apply_mask & roles.update_mask;
+  const size_t n=img.columns*img.rows;
+  const int cus=compute_units(img.device);
+  const size_t lds=4096*sizeof(uint32_t)+65536*sizeof(uint16_t);
+  float *pixels=static_cast<float *>(img.pixels);
+  const float *table=static_cast<const float *>(lut);
+#define MH_CASE(CH) \
+  { \
+    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&equalize_cdf_apply_kernel<CH>), \
+      hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds)); \
+    ProfileScope prof("apply_lut",img.stream); \
+    hipLaunchKernelGGL((equalize_cdf_apply_kernel<CH>),dim3(cus),dim3(1024),lds,img.stream,pixels,n,cdf,table, \
+      shared_column,mask,device_mask); \
+  }
+  switch (img.channels)
+  {
+    case 1: MH_CASE(1) break;
+    case 2: MH_CASE(2) break;
+    case 3: MH_CASE(3) break;
+    case 4: MH_CASE(4) break;
+    default: return fail(MH_UNSUPPORTED,"%d channels",img.channels);
+  }
+#undef MH_CASE
   MH_HIP(hipGetLastError());
   return MH_OK;
 }

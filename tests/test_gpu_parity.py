@@ -1789,6 +1789,29 @@ def test_histogram_operators_large_frame(im, refmod, dtype, kind):
     assert_parity(got, ref.contrast_stretch(0.02 * n, n - 0.01 * n).numpy(), True, "contrast-stretch (large)")
 
 
+@pytest.mark.parametrize("background", [False, True])
+@pytest.mark.parametrize("counts", [True, False])
+def test_equalize_float_frame_from_running_counts(im, refmod, background, counts, options):
+    """EqualizeImage on a float frame of a megapixel or more evaluates its map per sample from the
+    running counts held in LDS (a uint32 every 16 bins + uint16 offsets) instead of gathering from
+    a 65536-float table: the table's own three fp64 operations, the same bits.  A flat background
+    puts more than 65535 pixels into one 16-bin group: the workgroups fall back to the table."""
+    import bench
+    rows, cols = 1030, 1100
+    px = make_pixels(rows, cols, 4, HDRI, kind="random", seed=5)
+    px[:7, :9, :3] = [[-3.0, 70000.0, 0.49]]                 # clamped indices
+    if background:
+        px[:, :500, :3] = np.float32(12345.25)
+    if not counts:
+        options.set("MAGICKHIP_NO_EQUALIZE_COUNTS", "1")
+    dev, ref = run_pair(im, refmod, px)
+    holder = {}
+    launched = bench.kernel_profile(im, lambda: holder.update(out=im.equalize_image(dev)), 1)
+    assert "apply_lut" in launched, launched
+    got, want = holder["out"].numpy(), ref.equalize().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int((got != want).sum())
+
+
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
 @pytest.mark.parametrize("form", ["stage", "1"])
 @pytest.mark.parametrize("shape,target,filt", [((37, 53, 4), (148, 212), "Lanczos"), ((64, 300, 4), (200, 700), "Mitchell"),
