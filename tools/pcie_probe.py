@@ -52,7 +52,7 @@ from imagemagick_amd import _lib
 lib = im.load()
 import ctypes
 for threads in ("4", "8", "16"):
-    os.environ["MAGICKHIP_TRANSFER_THREADS"] = threads
+    im.set_option("MAGICKHIP_TRANSFER_THREADS", threads)
     def up():
         _lib.check(lib.MhUpload(0, dev_a.data_ptr(), page.ctypes.data, n, None))
     def down():

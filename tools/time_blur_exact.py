@@ -17,10 +17,7 @@ modes = (("Tie64 (fused sums + tie check)", None), ("Exact64 (separately rounded
 if len(sys.argv) > 2 and sys.argv[2] == "tie":          # under rocprofv3: the default kernels only
     modes = modes[:1]
 for label, env in modes:
-    if env is None:
-        os.environ.pop("MAGICKHIP_NO_TIE64", None)
-    else:
-        os.environ["MAGICKHIP_NO_TIE64"] = env
+    im.set_option("MAGICKHIP_NO_TIE64", env)      # (the library reads the environment once, at start-up)
 
     def f():
         hold["o"] = im.blur_image(img, 0.0, 10.0)

@@ -11,10 +11,7 @@ gen = torch.Generator(device="cuda").manual_seed(5)
 src = torch.randint(-32768, 32768, (n, n, 4), generator=gen, device="cuda", dtype=torch.int16).view(torch.uint16)
 work = src.clone()
 for label, env in (("decode table", None), ("Chebyshev in registers", "1")):
-    if env is None:
-        os.environ.pop("MAGICKHIP_NO_COLOR_TABLES", None)
-    else:
-        os.environ["MAGICKHIP_NO_COLOR_TABLES"] = env
+    im.set_option("MAGICKHIP_NO_COLOR_TABLES", env)      # (the library reads the environment once, at start-up)
 
     def f():
         work.copy_(src)

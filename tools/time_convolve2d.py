@@ -27,8 +27,7 @@ for kernel in kernels:
         if label == "generic" and n > 8192 and os.environ.get("TIME_GENERIC") is None:
             continue
         for k in ("MAGICKHIP_NO_EXACT_2D", "MAGICKHIP_NO_MFMA_2D", "MAGICKHIP_NO_TIE_2D"):
-            os.environ.pop(k, None)
-        os.environ.update(env)
+            im.set_option(k, env.get(k))      # (the library reads the environment once, at start-up)
         im.set_precision(mode)
 
         def f():

@@ -9,7 +9,7 @@ def run(ch, alpha, n=8192):
     torch.cuda.synchronize(); t=time.perf_counter()
     for _ in range(10): im.blur_image(img,0.0,10.0)
     torch.cuda.synchronize(); dt=(time.perf_counter()-t)/10
-    print("ch",ch,"alpha",alpha,"NO_MFMA",os.environ.get("MAGICKHIP_NO_MFMA"),"%.3f ms %.1f Gpix/s"%(dt*1e3,n*n/dt/1e9),flush=True)
+    print("ch",ch,"alpha",alpha,"NO_MFMA",im.get_option("MAGICKHIP_NO_MFMA"),"%.3f ms %.1f Gpix/s"%(dt*1e3,n*n/dt/1e9),flush=True)
 for env in (None,"1"):
-    if env: os.environ["MAGICKHIP_NO_MFMA"]=env
+    im.set_option("MAGICKHIP_NO_MFMA", env)
     run(3,False); run(4,False); run(4,True)

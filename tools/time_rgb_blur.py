@@ -13,10 +13,7 @@ a = torch.randint(-32768, 32768, (n, n, 3), generator=gen, device="cuda", dtype=
 img = im.Image(a)
 hold = {}
 for label, env in (("one launch", None), ("two launches", "1")):
-    if env is None:
-        os.environ.pop("MAGICKHIP_NO_FUSED_BLUR", None)
-    else:
-        os.environ["MAGICKHIP_NO_FUSED_BLUR"] = env
+    im.set_option("MAGICKHIP_NO_FUSED_BLUR", env)      # (the library reads the environment once, at start-up)
     for name, fn in (("blur", lambda: hold.update(o=im.blur_image(img, 0.0, 10.0))),
                      ("unsharp", lambda: hold.update(o=im.unsharp_mask_image(img, 0.0, 10.0, 1.0, 0.02)))):
         sec = timed(torch, fn, 5)
