@@ -281,7 +281,7 @@ def cpu_baseline_configs():
         sec += img.last_seconds
         out["c4_lab_contrast_stretch"] = entry(float(k) * k, sec, "%dx%d RGBA Q16 sRGB->Lab + ContrastStretch 2%%x1%%" % (k, k))
         del img
-        d = 2048
+        d = 4096                                   # (a sixteenth of C5's pixels)
         px = rng.integers(0, 65536, (d, d, 4), dtype=np.uint16)
         r = ref.RefImage(px).morphology("Dilate", 1, "Disk:15")
         out["c5_dilate_disk15"] = entry(float(d) * d, r.last_seconds, "%dx%d RGBA Q16 Dilate Disk:15" % (d, d))
