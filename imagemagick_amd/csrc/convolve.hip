@@ -1978,13 +1978,17 @@ static MhStatus launch_folded(const View &src,const SeparableArgs &sep,const Con
   const Conv1DParams &vertical)
 {
   // a lane owns R consecutive outputs of a K-tap pass; the triangular walk needs K >= R+1
-  if (horizontal.ntaps >= 9)
+  // (measured on 4096^2, tools/time_fold_variants.py: the column pass of a short kernel is faster with four
+  // outputs a lane — 106 registers, four waves a SIMD — than with eight: 0.19 / 0.22 / 0.25 ms against
+  // 0.24 / 0.28 / 0.28 for 7 / 13 / 19 taps; from 25 taps on the fewer re-read rows of eight win)
+  const int r8_rows=(int) option_long("MAGICKHIP_FOLD_R8_ROW_MIN",9),r8_columns=(int) option_long("MAGICKHIP_FOLD_R8_COLUMN_MIN",25);
+  if (horizontal.ntaps >= (r8_rows < 9 ? 9 : r8_rows))
     MH_TRY((launch_folded_row<Q,C,BLEND,8,8>(src,sep,horizontal)));
   else if (horizontal.ntaps >= 5)
     MH_TRY((launch_folded_row<Q,C,BLEND,4,4>(src,sep,horizontal)));
   else
     MH_TRY((launch_folded_row<Q,C,BLEND,2,2>(src,sep,horizontal)));
-  if (vertical.ntaps >= 9)
+  if (vertical.ntaps >= (r8_columns < 9 ? 9 : r8_columns))
     MH_TRY((launch_folded_column<Q,C,BLEND,8,8>(src,sep,vertical)));
   else if (vertical.ntaps >= 5)
     MH_TRY((launch_folded_column<Q,C,BLEND,4,4>(src,sep,vertical)));
@@ -1994,7 +1998,7 @@ static MhStatus launch_folded(const View &src,const SeparableArgs &sep,const Con
     // (the queue's fill is on the device: a grid that covers a full queue at four samples per wave,
     // whose workgroups leave at once when there is nothing for them)
     unsigned blocks=(sep.queue_capacity+15u)/16u;
-    blocks=blocks > 2048u ? 2048u : (blocks < 1u ? 1u : blocks);
+    blocks=blocks > 1024u ? 1024u : (blocks < 1u ? 1u : blocks);
     ProfileScope prof("separable_settle",src.stream);
     hipLaunchKernelGGL((separable_settle_kernel<Q,C,BLEND>),dim3(blocks),dim3(256),0,src.stream,sep);
   }
