@@ -1617,7 +1617,7 @@ void separable_row_sums_kernel(Conv1DArgs args,double *bound)
   const int SEG=64*R;
   const int NS=63*R+R+K-1+U;
   const int slots=NS+NS/R+1;
-  Q *strip=reinterpret_cast<Q *>(smem_raw)+(size_t) wave*slots*C;
+  Q *strip=reinterpret_cast<Q *>(smem_raw+(size_t) wave*args.nblocks);      // (nblocks: bytes of LDS a wave owns)
 
   const unsigned ntx=(unsigned) ((W+SEG-1)/SEG);
   const unsigned nty=(unsigned) ((H+WAVES-1)/WAVES);
@@ -1709,6 +1709,7 @@ void separable_row_sums_kernel(Conv1DArgs args,double *bound)
   };
   tri_accumulate<Q,C,BLEND,A,R,U>(acc,table,K,fetch_u,fetch_1,nxt);
 
+#ifdef MH_ROW_SUMS_DIRECT
   double *sums=static_cast<double *>(args.dst)+((size_t) y*W+(size_t) (x0+lane*R))*4;
 #pragma unroll
   for (int r=0; r < R; r++)
@@ -1721,6 +1722,49 @@ void separable_row_sums_kernel(Conv1DArgs args,double *bound)
         reinterpret_cast<double2 *>(sums+(size_t) r*4)[0]=make_double2(s[0],s[1]);
         reinterpret_cast<double2 *>(sums+(size_t) r*4)[1]=make_double2(s[2],s[3]);
       }
+#else
+  // A lane owns R consecutive pixels, 32 R bytes of sums: stored from the lane they are 64 scattered
+  // 16-byte pieces an instruction (the pass ran at 3.5 TB/s).  They leave through the wave's own
+  // strip instead (dead by now; LDS operations of one wave complete in order, no barrier): sixteen
+  // lanes at a time deposit their 16 R pixels, then all 64 lanes store them as contiguous kilobytes.
+  double2 *stash=reinterpret_cast<double2 *>(smem_raw+(size_t) wave*args.nblocks);   // (nblocks: bytes of LDS a wave owns)
+  double *out_row=static_cast<double *>(args.dst)+((size_t) y*W+(size_t) x0)*4;
+#pragma unroll
+  for (int pass=0; pass < 4; pass++)
+    {
+      if ((lane >> 4) == pass)
+        {
+#pragma unroll
+          for (int r=0; r < R; r++)
+            {
+              double s[4]={0.0,0.0,0.0,0.0};
+#pragma unroll
+              for (int c=0; c < C; c++)
+                s[c]=acc.MH_S(r,c);
+              double2 *to=stash+((lane & 15)*(R+1)+r)*2;        // (a 32-byte gap a lane: the 16 lanes' banks)
+              to[0]=make_double2(s[0],s[1]);
+              to[1]=make_double2(s[2],s[3]);
+            }
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE,"wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE,"wavefront");
+#pragma unroll
+      for (int k=0; k < (R+1)/2; k++)
+        {
+          const int item=lane+64*k;                             // 16 R pixels x two halves
+          const int pixel=item >> 1,half=item & 1;
+          if (pixel < 16*R)
+            {
+              const double2 v=stash[((pixel/R)*(R+1)+(pixel % R))*2+half];
+              const int x=x0+pass*16*R+pixel;
+              if (x < W)
+                reinterpret_cast<double2 *>(out_row+(size_t) (pass*16*R+pixel)*4)[half]=v;
+            }
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE,"wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE,"wavefront");
+    }
+#endif
 }
 
 template<typename Q,int C,bool BLEND,int R,int U,int WAVES>
@@ -1930,7 +1974,13 @@ static MhStatus launch_folded_row(const View &src,const SeparableArgs &sep,const
   args.taps=taps.ptr;
   const int W=args.columns,H=args.rows;
   const int SEG=64*R,NS=63*R+R+K-1+U,slots=NS+NS/R+1;
-  const size_t lds=(size_t) WAVES*slots*C*sizeof(Q);
+  // a wave's LDS: its strip of samples, and room for the 16 (R+1) pixels of sums it stores at a time
+  size_t wave_bytes=(size_t) slots*C*sizeof(Q);
+  if (wave_bytes < (size_t) 16*(R+1)*32)
+    wave_bytes=(size_t) 16*(R+1)*32;
+  wave_bytes=(wave_bytes+15u) & ~(size_t) 15u;
+  args.nblocks=(int) wave_bytes;
+  const size_t lds=(size_t) WAVES*wave_bytes;
   if (lds > 160u*1024u)
     return fail(MH_UNSUPPORTED,"row kernel of %d taps needs %zu bytes of LDS",K,lds);
   const unsigned ntx=(unsigned) ((W+SEG-1)/SEG),nty=(unsigned) ((H+WAVES-1)/WAVES);
