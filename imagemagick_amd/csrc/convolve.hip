@@ -1425,6 +1425,41 @@ void conv_row_tri(Conv1DArgs args)
 
   unsigned changed=0;
   const int xo=x0+lane*R;
+  // 16-byte pixels (float RGBA: the HDRI blur): a lane's R consecutive results are 64 scattered
+  // 16-byte pieces per store instruction when the lane stores them itself.  They leave through the
+  // wave's strip instead — dead once no centre sample is needed — as contiguous kilobytes (see
+  // separable_row_sums_kernel).  Whole segments only; rows' last segments keep the direct stores.
+  if constexpr (C*sizeof(Q) == 16)
+    {
+      constexpr int LS=R*16+16;                 // a lane's deposit + a 16-byte gap (banks)
+      const bool whole=x0+SEG <= W;
+      if (whole && (args.changed == nullptr) && (args.copy_mask == 0) && (64*LS <= slots*16))
+        {
+          unsigned char *stash=reinterpret_cast<unsigned char *>(strip);
+#pragma unroll
+          for (int r=0; r < R; r++)
+            {
+              Q center[C],out[C];
+#pragma unroll
+              for (int c=0; c < C; c++)
+                center[c]=(Q) 0;
+              (void) acc.finish(r,center,0u,out,(T) args.bias,false,make_reference<Q,C,BLEND,A>(args,false,xo+r,y));
+              store_pixel<Q,C>(reinterpret_cast<Q *>(stash+lane*LS+r*16),out);
+            }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE,"wavefront");
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE,"wavefront");
+          unsigned char *to=reinterpret_cast<unsigned char *>(dst+(size_t) y*pitch+(size_t) x0*C);
+#pragma unroll
+          for (int k=0; k < R; k++)
+            {
+              const int item=lane+64*k;           // 64 R pixels of 16 bytes
+              const int from=item/R,within=item-from*R;
+              const uint4 v=*reinterpret_cast<const uint4 *>(stash+from*LS+within*16);
+              *reinterpret_cast<uint4 *>(to+(size_t) item*16)=v;
+            }
+          return;
+        }
+    }
   // a lane's R outputs are contiguous in the row: store them two pixels (16 bytes for
   // RGBA Q16) at a time — half the store instructions of this lane-strided pattern
   constexpr bool kPair=((R & 1) == 0) && (C*sizeof(Q) == 8);
