@@ -2441,7 +2441,15 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
           total+=params.taps[v];
         }
       if (positive && (total <= 1.0+1.0e-9))
-        return dispatch_tri<Tie64,8,8,float>(src,dst,vertical,params,roles,changed);
+        {
+          // (the row pass with four samples in flight instead of eight: 138 registers instead of 194,
+          // three waves a SIMD — the fp64 pipe sustains more with more waves, tools/ubench/
+          // fma_f64_rate.hip — 1.25 -> 1.15 ms per 8192^2 frame; the column pass keeps its 182
+          // registers either way and is slower with four)
+          if (!vertical)
+            return dispatch_tri<Tie64,8,4,float>(src,dst,vertical,params,roles,changed);
+          return dispatch_tri<Tie64,8,8,float>(src,dst,vertical,params,roles,changed);
+        }
     }
   return dispatch_channels<float,Exact64,8>(src,dst,vertical,params,roles,changed);
 }
