@@ -2067,14 +2067,20 @@ static MhStatus launch_folded(const View &src,const SeparableArgs &sep,const Con
   // outputs a lane — 106 registers, four waves a SIMD — than with eight: 0.19 / 0.22 / 0.25 ms against
   // 0.24 / 0.28 / 0.28 for 7 / 13 / 19 taps; from 25 taps on the fewer re-read rows of eight win)
   const int r8_rows=(int) option_long("MAGICKHIP_FOLD_R8_ROW_MIN",9),r8_columns=(int) option_long("MAGICKHIP_FOLD_R8_COLUMN_MIN",25);
-  if (horizontal.ntaps >= (r8_rows < 9 ? 9 : r8_rows))
+  // (samples in flight: four instead of eight where that buys a wave more per SIMD — the float
+  // frame's row pass, 194 -> ~140 registers, and every column pass, whose samples are doubles: the
+  // fp64 pipe sustains more with more waves, tools/ubench/fma_f64_rate.hip.  0x10 on 8192^2: column
+  // 1.44 -> 1.28 ms, float row 1.24 -> 1.14.)
+  if ((horizontal.ntaps >= (r8_rows < 9 ? 9 : r8_rows)) && QuantumOps<Q>::is_float)
+    MH_TRY((launch_folded_row<Q,C,BLEND,8,4>(src,sep,horizontal)));
+  else if (horizontal.ntaps >= (r8_rows < 9 ? 9 : r8_rows))
     MH_TRY((launch_folded_row<Q,C,BLEND,8,8>(src,sep,horizontal)));
   else if (horizontal.ntaps >= 5)
     MH_TRY((launch_folded_row<Q,C,BLEND,4,4>(src,sep,horizontal)));
   else
     MH_TRY((launch_folded_row<Q,C,BLEND,2,2>(src,sep,horizontal)));
   if (vertical.ntaps >= (r8_columns < 9 ? 9 : r8_columns))
-    MH_TRY((launch_folded_column<Q,C,BLEND,8,8>(src,sep,vertical)));
+    MH_TRY((launch_folded_column<Q,C,BLEND,8,4>(src,sep,vertical)));
   else if (vertical.ntaps >= 5)
     MH_TRY((launch_folded_column<Q,C,BLEND,4,4>(src,sep,vertical)));
   else
