@@ -342,6 +342,7 @@ struct Conv1DArgs
   const void *taps;          // T[K], reversed so that taps[v] multiplies input o-shift+v
   unsigned long long *changed;
   int nblocks;               // blocked kernels: number of U-sample blocks of the padded tap table
+  int wave_bytes;            // separable_row_sums_kernel: bytes of LDS a wave owns (strip / stash)
   // triangular column kernels: UnsharpMaskImage's epilogue on the way out (effect.c:4364-4369);
   // unsharp_src = the unblurred frame, or NULL
   const void *unsharp_src;
@@ -951,6 +952,7 @@ static MhStatus launch_blocked(const View &src,const View &dst,bool vertical,
   args.taps=taps.ptr;
   args.changed=changed;
   args.nblocks=nblocks;
+  args.wave_bytes=0;
   const int W=args.columns,H=args.rows;
   if (vertical)
     {
@@ -1531,6 +1533,7 @@ static MhStatus launch_tri_waves(const View &src,const View &dst,bool vertical,
   args.taps=taps.ptr;
   args.changed=changed;
   args.nblocks=0;
+  args.wave_bytes=0;
   if (vertical)
     {
       args.unsharp_src=p.unsharp_source;
@@ -1652,7 +1655,7 @@ void separable_row_sums_kernel(Conv1DArgs args,double *bound)
   const int SEG=64*R;
   const int NS=63*R+R+K-1+U;
   const int slots=NS+NS/R+1;
-  Q *strip=reinterpret_cast<Q *>(smem_raw+(size_t) wave*args.nblocks);      // (nblocks: bytes of LDS a wave owns)
+  Q *strip=reinterpret_cast<Q *>(smem_raw+(size_t) wave*args.wave_bytes);
 
   const unsigned ntx=(unsigned) ((W+SEG-1)/SEG);
   const unsigned nty=(unsigned) ((H+WAVES-1)/WAVES);
@@ -1762,7 +1765,7 @@ void separable_row_sums_kernel(Conv1DArgs args,double *bound)
   // 16-byte pieces an instruction (the pass ran at 3.5 TB/s).  They leave through the wave's own
   // strip instead (dead by now; LDS operations of one wave complete in order, no barrier): sixteen
   // lanes at a time deposit their 16 R pixels, then all 64 lanes store them as contiguous kilobytes.
-  double2 *stash=reinterpret_cast<double2 *>(smem_raw+(size_t) wave*args.nblocks);   // (nblocks: bytes of LDS a wave owns)
+  double2 *stash=reinterpret_cast<double2 *>(smem_raw+(size_t) wave*args.wave_bytes);
   double *out_row=static_cast<double *>(args.dst)+((size_t) y*W+(size_t) x0)*4;
 #pragma unroll
   for (int pass=0; pass < 4; pass++)
@@ -2014,7 +2017,7 @@ static MhStatus launch_folded_row(const View &src,const SeparableArgs &sep,const
   if (wave_bytes < (size_t) 16*(R+1)*32)
     wave_bytes=(size_t) 16*(R+1)*32;
   wave_bytes=(wave_bytes+15u) & ~(size_t) 15u;
-  args.nblocks=(int) wave_bytes;
+  args.wave_bytes=(int) wave_bytes;
   const size_t lds=(size_t) WAVES*wave_bytes;
   if (lds > 160u*1024u)
     return fail(MH_UNSUPPORTED,"row kernel of %d taps needs %zu bytes of LDS",K,lds);
@@ -2153,6 +2156,8 @@ static MhStatus launch_one(const View &src,const View &dst,bool vertical,
   args.copy_mask=roles.copy_mask;
   args.taps=taps.ptr;
   args.changed=changed;
+  args.nblocks=0;
+  args.wave_bytes=0;
 
   const int W=args.columns,H=args.rows;
   if (vertical)
