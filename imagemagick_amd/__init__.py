@@ -343,7 +343,8 @@ def convolve_image(image, kernel):
 
 
 MORPHOLOGY_COMPOSE = {None: 0, "undefined": 0, "none": 1, "no": 1, "lighten": 2, "difference": 3, "darken": 5,
-                      "plus": 6, "multiply": 7, "screen": 8}
+                      "plus": 6, "multiply": 7, "screen": 8, "exclusion": 9, "minussrc": 10, "minusdst": 11,
+                      "lineardodge": 12, "over": 13, "srcover": 13, "dstover": 14}
 
 
 def morphology_image(image, method, iterations, kernel, bias=0.0, scale=None, compose=None):

@@ -349,7 +349,8 @@ MhStatus host_banded_operator(const MhOperator &op,const MhKernelInfo *kernel,co
   MhImage *result,bool *handled);
 // CompositeImage(canvas,source,Difference|Lighten,clip_to_self,0,0) in place on the canvas
 enum { MH_COMPOSITE_DIFFERENCE=0,MH_COMPOSITE_LIGHTEN=1,MH_COMPOSITE_DARKEN=2,MH_COMPOSITE_PLUS=3,MH_COMPOSITE_MULTIPLY=4,
-  MH_COMPOSITE_SCREEN=5 };
+  MH_COMPOSITE_SCREEN=5,MH_COMPOSITE_EXCLUSION=6,MH_COMPOSITE_MINUS_SRC=7,MH_COMPOSITE_MINUS_DST=8,MH_COMPOSITE_LINEAR_DODGE=9,
+  MH_COMPOSITE_OVER=10,MH_COMPOSITE_DST_OVER=11 };
 MhStatus launch_composite(const View &canvas,const View &source,int kind,const Roles &roles);
 MhStatus launch_contrast(const View &img,bool sharpen);
 MhStatus launch_modulate(const View &img,bool hsb,double hue_shift,double saturation_scale,

@@ -644,6 +644,12 @@ static MhStatus morphology_apply(const View &src,const View &dst,const MhImage *
     case MH_MORPHOLOGY_COMPOSE_PLUS: compose=MH_COMPOSITE_PLUS; break;
     case MH_MORPHOLOGY_COMPOSE_MULTIPLY: compose=MH_COMPOSITE_MULTIPLY; break;
     case MH_MORPHOLOGY_COMPOSE_SCREEN: compose=MH_COMPOSITE_SCREEN; break;
+    case MH_MORPHOLOGY_COMPOSE_EXCLUSION: compose=MH_COMPOSITE_EXCLUSION; break;
+    case MH_MORPHOLOGY_COMPOSE_MINUS_SRC: compose=MH_COMPOSITE_MINUS_SRC; break;
+    case MH_MORPHOLOGY_COMPOSE_MINUS_DST: compose=MH_COMPOSITE_MINUS_DST; break;
+    case MH_MORPHOLOGY_COMPOSE_LINEAR_DODGE: compose=MH_COMPOSITE_LINEAR_DODGE; break;
+    case MH_MORPHOLOGY_COMPOSE_OVER: compose=MH_COMPOSITE_OVER; break;
+    case MH_MORPHOLOGY_COMPOSE_DST_OVER: compose=MH_COMPOSITE_DST_OVER; break;
     default:
       return fail(MH_UNSUPPORTED,"morphology:compose operator %d is not accelerated",(int) compose_override);
   }

@@ -2240,7 +2240,8 @@ static MhStatus apply_q16_column(const View &img,const uint16_t *column,uint32_t
 // :2523-2711 (alpha channel), :2716-2751 (Sca/Dca/gamma), :2922-2933 (Difference),
 // :3110-3124 (Lighten), ClampPixel pixel-accessor.h:35-46.
 enum CompositeKind { COMPOSITE_DIFFERENCE=0,COMPOSITE_LIGHTEN=1,COMPOSITE_DARKEN=2,COMPOSITE_PLUS=3,COMPOSITE_MULTIPLY=4,
-  COMPOSITE_SCREEN=5 };
+  COMPOSITE_SCREEN=5,COMPOSITE_EXCLUSION=6,COMPOSITE_MINUS_SRC=7,COMPOSITE_MINUS_DST=8,COMPOSITE_LINEAR_DODGE=9,
+  COMPOSITE_OVER=10,COMPOSITE_DST_OVER=11 };
 
 template<typename Q> static __device__ __forceinline__ Q clamp_pixel(double pixel);
 template<> __device__ __forceinline__ uint16_t clamp_pixel<uint16_t>(double pixel)
@@ -2277,7 +2278,8 @@ void composite_kernel(Q *__restrict__ canvas,const Q *__restrict__ source,size_t
       // Plus: RoundToUnity(source_dissolve*Sa+canvas_dissolve*Da), both 1 (composite.c:2462-2467);
       // the others RoundToUnity(Sa+Da-Sa*Da) (:2398-2426)
       double alpha=OP == COMPOSITE_PLUS ? 1.0*Sa+1.0*Da : Sa+Da-Sa*Da;
-      alpha=alpha < 0.0 ? 0.0 : (alpha > 1.0 ? 1.0 : alpha);
+      if ((OP != COMPOSITE_OVER) && (OP != COMPOSITE_DST_OVER))      // (Over / DstOver: not rounded to unity, :2443-2449)
+        alpha=alpha < 0.0 ? 0.0 : (alpha > 1.0 ? 1.0 : alpha);
       // composite.c:2737-2751
       const double gamma=perceptible_reciprocal(((OP == COMPOSITE_LIGHTEN) || (OP == COMPOSITE_DARKEN)) ? 1.0-alpha : alpha);
 #pragma unroll
@@ -2291,7 +2293,13 @@ void composite_kernel(Q *__restrict__ canvas,const Q *__restrict__ source,size_t
               continue;
             }
           if (((copy_mask >> c) & 1u) != 0)
-            continue;                                            // ClampToQuantum(Dc) = Dc
+            {
+              // ClampToQuantum(Dc) = Dc; Over runs CompositeOverImage (composite.c:1489-1495), whose
+              // copy channels take the SOURCE (:1115-1121)
+              if (OP == COMPOSITE_OVER)
+                d[c]=s[c];
+              continue;
+            }
           const double Sc=(double) s[c],Dc=(double) d[c];
           const double Sca=kQS*Sa*Sc,Dca=kQS*Da*Dc;
           double pixel;
@@ -2306,6 +2314,18 @@ void composite_kernel(Q *__restrict__ canvas,const Q *__restrict__ source,size_t
             pixel=kQR*gamma*(Sca*Dca+Sca*(1.0-Da)+Dca*(1.0-Sa)); // :3288-3299
           else if (OP == COMPOSITE_SCREEN)
             pixel=kQR*gamma*(Sca+Dca-Sca*Dca);                   // :3447-3461
+          else if (OP == COMPOSITE_EXCLUSION)
+            pixel=kQR*gamma*(Sca*Da+Dca*Sa-2.0*Sca*Dca+Sca*(1.0-Da)+Dca*(1.0-Sa));   // :3011-3016
+          else if (OP == COMPOSITE_MINUS_SRC)
+            pixel=gamma*(Da*Dc+Sa*Sc-2.0*Sa*Sc*Da);              // :3211-3224
+          else if (OP == COMPOSITE_MINUS_DST)
+            pixel=gamma*(Sa*Sc+Da*Dc-2.0*Da*Dc*Sa);              // :3201-3210
+          else if (OP == COMPOSITE_LINEAR_DODGE)
+            pixel=gamma*(Sa*Sc+Da*Dc);                           // :3094-3098
+          else if (OP == COMPOSITE_OVER)
+            pixel=kQR*gamma*(Sca+Dca*(1.0-Sa));                  // :3310-3315
+          else if (OP == COMPOSITE_DST_OVER)
+            pixel=kQR*gamma*(Dca+Sca*(1.0-Da));                  // :3006-3010
           else if (OP == COMPOSITE_DARKEN ? (Sca*Da) < (Dca*Sa) : (Sca*Da) > (Dca*Sa))
             pixel=kQR*(Sca+Dca*(1.0-Sa));                        // :2892-2910, :3110-3124
           else
@@ -2333,6 +2353,12 @@ static MhStatus composite_typed(const View &canvas,const View &source,int kind,c
     case COMPOSITE_PLUS: MH_COMPOSE(COMPOSITE_PLUS); break;
     case COMPOSITE_MULTIPLY: MH_COMPOSE(COMPOSITE_MULTIPLY); break;
     case COMPOSITE_SCREEN: MH_COMPOSE(COMPOSITE_SCREEN); break;
+    case COMPOSITE_EXCLUSION: MH_COMPOSE(COMPOSITE_EXCLUSION); break;
+    case COMPOSITE_MINUS_SRC: MH_COMPOSE(COMPOSITE_MINUS_SRC); break;
+    case COMPOSITE_MINUS_DST: MH_COMPOSE(COMPOSITE_MINUS_DST); break;
+    case COMPOSITE_LINEAR_DODGE: MH_COMPOSE(COMPOSITE_LINEAR_DODGE); break;
+    case COMPOSITE_OVER: MH_COMPOSE(COMPOSITE_OVER); break;
+    case COMPOSITE_DST_OVER: MH_COMPOSE(COMPOSITE_DST_OVER); break;
     default: return fail(MH_UNSUPPORTED,"composite operator %d",kind);
   }
 #undef MH_COMPOSE

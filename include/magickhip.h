@@ -469,7 +469,8 @@ MH_API MhStatus MagickHipMorphologyImage(const MhImage *image,MhImage *morpholog
 /* The same with the user's `morphology:compose` (morphology.c:4206-4215, :3779-3782): how the
    results of the kernels of a list are merged.  DEFAULT = UndefinedCompositeOp, NONE =
    NoCompositeOp (re-iterate the previous result), LIGHTEN / DIFFERENCE / DARKEN / PLUS / MULTIPLY /
-   SCREEN = CompositeImage with that operator (composite.c:2396-3124, synchronised channels).
+   SCREEN / EXCLUSION / MINUS_SRC / MINUS_DST / LINEAR_DODGE / OVER / DST_OVER = CompositeImage with
+   that operator (composite.c:2396-3124, synchronised channels).
    Other operators: MH_UNSUPPORTED (the CPU path runs). */
 typedef enum
 {
@@ -481,7 +482,13 @@ typedef enum
   MH_MORPHOLOGY_COMPOSE_DARKEN = 5,
   MH_MORPHOLOGY_COMPOSE_PLUS = 6,      /* `-define morphology:compose=Plus`, morphology.c:772 */
   MH_MORPHOLOGY_COMPOSE_MULTIPLY = 7,
-  MH_MORPHOLOGY_COMPOSE_SCREEN = 8
+  MH_MORPHOLOGY_COMPOSE_SCREEN = 8,
+  MH_MORPHOLOGY_COMPOSE_EXCLUSION = 9,
+  MH_MORPHOLOGY_COMPOSE_MINUS_SRC = 10,
+  MH_MORPHOLOGY_COMPOSE_MINUS_DST = 11,
+  MH_MORPHOLOGY_COMPOSE_LINEAR_DODGE = 12,
+  MH_MORPHOLOGY_COMPOSE_OVER = 13,     /* OverCompositeOp and SrcOverCompositeOp: CompositeOverImage, composite.c:917 */
+  MH_MORPHOLOGY_COMPOSE_DST_OVER = 14
 } MhMorphologyCompose;
 MH_API MhStatus MagickHipMorphologyImageCompose(const MhImage *image,MhImage *morphology_image,
   MhMorphologyMethod method,ptrdiff_t iterations,const MhKernelInfo *kernel,

@@ -77,7 +77,7 @@ static const char *DescribeGate(const Image *image)
       (GetImageArtifact(image,"morphology:compose") != (const char *) NULL) ||
       (GetImageArtifact(image,"morphology:showKernel") != (const char *) NULL))
     return("a convolve: / morphology: artifact is set (Blur, UnsharpMask and Convolve hooks decline; "
-      "MorphologyApply honours bias, scale and the compose operators None, Lighten, Difference, Darken, Plus, Multiply, Screen)");
+      "MorphologyApply honours bias, scale and the compose operators None, Lighten, Difference, Darken, Plus, Multiply, Screen, Exclusion, MinusSrc, MinusDst, LinearDodge, Over, DstOver)");
   switch (GetImageVirtualPixelMethod(image))
   {
     case UndefinedVirtualPixelMethod:
@@ -628,6 +628,13 @@ MagickPrivate Image *AccelerateMorphologyApply(const Image *image,
     case PlusCompositeOp: override=MH_MORPHOLOGY_COMPOSE_PLUS; break;
     case MultiplyCompositeOp: override=MH_MORPHOLOGY_COMPOSE_MULTIPLY; break;
     case ScreenCompositeOp: override=MH_MORPHOLOGY_COMPOSE_SCREEN; break;
+    case ExclusionCompositeOp: override=MH_MORPHOLOGY_COMPOSE_EXCLUSION; break;
+    case MinusSrcCompositeOp: override=MH_MORPHOLOGY_COMPOSE_MINUS_SRC; break;
+    case MinusDstCompositeOp: override=MH_MORPHOLOGY_COMPOSE_MINUS_DST; break;
+    case LinearDodgeCompositeOp: override=MH_MORPHOLOGY_COMPOSE_LINEAR_DODGE; break;
+    case OverCompositeOp: case SrcOverCompositeOp:                        /* both run CompositeOverImage, composite.c:1489 */
+      override=MH_MORPHOLOGY_COMPOSE_OVER; break;
+    case DstOverCompositeOp: override=MH_MORPHOLOGY_COMPOSE_DST_OVER; break;
     default: return(HipDeclined(image,(Image *) NULL));
   }
   if ((iterations == 0) || (IsImageAcceleratable(image) == MagickFalse))

@@ -817,6 +817,12 @@ def test_morphology_kernel_lists(im, refmod, method, kernel, iterations):
     ("Erode", "Diamond:2;Ring:1,2", "Darken"),     # intersection
     ("Convolve", "3x3: 0,1,0 1,2,1 0,1,0;3x3: 1,0,1 0,2,0 1,0,1", "Multiply"),
     ("Dilate", "Plus:1;Square:1", "Screen"),
+    ("Convolve", "Sobel:>", "Exclusion"),
+    ("Convolve", "3x3: 0,1,0 1,2,1 0,1,0;3x3: 1,0,1 0,2,0 1,0,1", "MinusSrc"),
+    ("Convolve", "3x3: 0,1,0 1,2,1 0,1,0;3x3: 1,0,1 0,2,0 1,0,1", "MinusDst"),
+    ("Dilate", "Plus:1;Square:1", "LinearDodge"),
+    ("Erode", "Diamond:2;Ring:1,2", "Over"),
+    ("Convolve", "Sobel:>", "DstOver"),
 ])
 def test_morphology_compose_override(im, refmod, method, kernel, compose):
     """The user's `-define morphology:compose=` (morphology.c:4206-4215, :3779-3782) for the
@@ -831,7 +837,7 @@ def test_morphology_compose_override(im, refmod, method, kernel, compose):
     want = ref.morphology(method, 1, kernel).numpy()
     assert_parity(got, want, True, "%s %s compose %s" % (method, kernel, compose))
     with pytest.raises(im.MagickHipError):
-        im.morphology_image(dev, method, 1, kernel, scale=scale, compose="Exclusion")
+        im.morphology_image(dev, method, 1, kernel, scale=scale, compose="Overlay")
 
 
 def test_hit_and_miss_union_with_alpha(im, refmod):

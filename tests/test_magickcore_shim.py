@@ -225,7 +225,7 @@ def test_hit_and_miss_list_through_magickcore(shim):
     assert accelerated_calls(shim, False) == before + 2
 
 
-@pytest.mark.parametrize("compose,accelerated", [("Plus", True), ("Darken", True), ("Screen", True), ("Exclusion", False)])
+@pytest.mark.parametrize("compose,accelerated", [("Plus", True), ("Darken", True), ("Screen", True), ("MinusSrc", True), ("Overlay", False)])
 def test_morphology_compose_through_magickcore(shim, compose, accelerated):
     """`-define morphology:compose=` (morphology.c:4206-4215) reaches the hook as MorphologyApply's
     compose argument: Plus / Darken / Multiply / Screen (round 4) compose on the device, any other
