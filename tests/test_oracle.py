@@ -344,3 +344,10 @@ def test_restatement_against_live_reference(refmod):
         assert_identical(R.transform_image_colorspace(px, "srgb", "lab"),
                          refmod.RefImage(px).colorspace("Lab").numpy(), "lab")
         assert_identical(R.equalize_image(px), refmod.RefImage(px).equalize().numpy(), "equalize")
+        # the table-driven colourspaces (round 4): entries formed in place of the three tables
+        for space in ("OHTA", "Rec601YCbCr", "Rec709YCbCr", "YCC"):
+            assert_identical(R.transform_image_colorspace(px, "srgb", space),
+                             refmod.RefImage(px).colorspace(space).numpy(), "srgb -> " + space)
+        for space in ("OHTA", "Rec601YCbCr", "Rec709YCbCr"):
+            assert_identical(R.transform_image_colorspace(px, space, "srgb"),
+                             refmod.RefImage(px, space).colorspace("sRGB").numpy(), space + " -> srgb")
