@@ -395,6 +395,7 @@ def resize_config(im, torch, gen):
         "resize_vertical": (1.0 * m * m + 4.0 * m * m) * px16,       # 8192^2 in, 8192x32768 out
         "resize_horizontal": (4.0 * m * m + 16.0 * m * m) * px16,    # 8192x32768 in, 32768^2 out
         "resize_fused": (1.0 * m * m + 16.0 * m * m) * px16,
+        "resize_mfma": (1.0 * m * m + 16.0 * m * m) * px16,          # one launch: 8192^2 in, 32768^2 out
     }
     compulsory = (1.0 * m * m + 16.0 * m * m) * px16
 

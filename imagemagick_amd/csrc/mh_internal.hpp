@@ -316,6 +316,11 @@ MhStatus launch_resize_pass(const View &src,const View &dst,bool vertical,
 MhStatus launch_resize_fused(const View &src,const View &dst,const TapTable &vertical,
   const TapTable &horizontal,const Roles &roles,MhPrecision precision,bool *handled);
 
+// the FAST one-launch enlargement on the fp64 matrix pipe (resize_mfma.hip)
+MhStatus launch_resize_mfma(const View &src,const View &dst,const TapTable &vertical,
+  const TapTable &horizontal,const Roles &roles,bool *handled);
+void release_resize_mfma_plans();
+
 MhStatus launch_unsharp_epilogue(const View &src,const View &blur,const View &dst,
   double gain,double threshold,const Roles &roles);
 

@@ -862,6 +862,7 @@ MH_API void MhTerminus(void)
   release_rccl_communicators();
   release_shared_tables();
   release_resize_tables();
+  release_resize_mfma_plans();
   pool_trim();
   staging_trim();
   release_color_tables();

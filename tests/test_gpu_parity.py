@@ -1841,6 +1841,62 @@ def test_resize_fused_forms(im, refmod, shape, target, filt, form, dtype, option
     assert_parity(holder["out"].numpy(), want, True, "fused resize (%s) %s" % (form, filt), max_ulp=0)
 
 
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("alpha", [True, False])
+@pytest.mark.parametrize("shape,target,filt", [
+    ((37, 53, 4), (212, 148), "Lanczos"), ((64, 300, 4), (1200, 256), "Lanczos"),
+    ((23, 600, 4), (2400, 92), "Lanczos"), ((90, 100, 4), (150, 135), "Mitchell"),
+    ((29, 33, 4), (330, 290), "Lanczos"), ((41, 50, 4), (150, 164), "Triangle"),
+    ((1, 1, 4), (40, 40), "Lanczos"), ((150, 70, 4), (141, 600), "Catrom"),
+])
+def test_resize_fast_one_launch_on_the_matrix_pipe(im, refmod, dtype, alpha, shape, target, filt):
+    """FAST enlargements of four-channel frames run VerticalFilter and HorizontalFilter as banded
+    matrix products on the fp64 matrix pipe in ONE launch (resize_mfma.hip): the Quantum-rounded
+    intermediate stays in registers.  Within one level / one float ULP of the reference, and in
+    practice identical; partial tiles, strips and row groups, a mixed enlargement, one source pixel."""
+    import bench
+    px = make_pixels(shape[0], shape[1], 4, dtype, seed=shape[1] + target[0])
+    if alpha:
+        px[: shape[0] // 2, :, 3] = 65535                # half opaque
+        px[:, : shape[1] // 5, 3] = 0                    # a transparent band
+    dev = im.Image(to_device(px), has_alpha=alpha)
+    if alpha:
+        want = refmod.RefImage(px).resize(target[0], target[1], filt).numpy()
+    else:
+        want = np.concatenate([refmod.RefImage(px[:, :, c].copy()).resize(target[0], target[1], filt).numpy()
+                               .reshape(target[1], target[0], 1) for c in range(4)], axis=2)
+    im.set_precision(im.PRECISION_FAST)
+    holder = {}
+    try:
+        launched = set(bench.kernel_profile(
+            im, lambda: holder.update(out=im.resize_image(dev, target[0], target[1], filt)), 1))
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert launched == {"resize_mfma"}, launched
+    same = assert_parity(holder["out"].numpy(), want, False, "one-launch resize %s -> %s %s" % (shape, target, filt),
+                         max_ulp=1)
+    assert same > 0.999
+
+
+def test_resize_fast_falls_back_to_two_passes(im, refmod):
+    """What the matrix-pipe form declines keeps the two-pass kernels: reductions, barely-enlarging
+    geometries whose windows are wider than its ring, three-channel frames."""
+    import bench
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        for shape, target in (((60, 80, 4), (33, 21)), ((40, 40, 4), (41, 43)), ((30, 30, 3), (120, 120))):
+            px = make_pixels(shape[0], shape[1], shape[2], Q16)
+            dev, ref = run_pair(im, refmod, px)
+            holder = {}
+            launched = set(bench.kernel_profile(
+                im, lambda: holder.update(out=im.resize_image(dev, target[0], target[1], "Lanczos")), 1))
+            assert launched == {"resize_horizontal", "resize_vertical"}, launched
+            assert_parity(holder["out"].numpy(), ref.resize(target[0], target[1], "Lanczos").numpy(), False,
+                          "two-pass resize %s" % (shape,), max_ulp=1)
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+
+
 def test_histogram_large_frame_linear_rgb_intensity(im, refmod):
     """A linear-RGB frame's intensity goes through EncodePixelGamma (pixel.c:2446-2452): the
     packed-table kernel's general form (the whole GetPixelIntensity switch behind a call)."""
