@@ -27,8 +27,8 @@
 // pipe's fused sums differ from the reference's separately rounded ones by ~1e-16 relative.
 // Zero-weight padding multiplies samples outside an output's window by 0, which is exact unless
 // a sample is not finite: a float frame's patch is watched while it is staged and a workgroup
-// step that holds a non-finite sample (or produces a non-finite intermediate) recomputes its
-// outputs tap by tap in the reference's own window (careful_step).
+// step that holds a non-finite (or huge, see not_tame_f32) sample computes its outputs tap by tap
+// in the reference's own windows instead (careful_step).
 #include "mh_internal.hpp"
 #include "resize_filter.hpp"
 #include "resize_mfma_plan.hpp"
@@ -46,10 +46,11 @@ struct MfmaResizeArgs
   const void *src;
   void *dst;
   int src_columns,src_rows,dst_columns,dst_rows;
-  int tps,nstrips,nrg,nvb_max,strips_per_xcd,steps;
-  unsigned wlds_bytes;
-  const int *strip_col_lo,*strip_nvb,*strip_wbase,*strip_wcount,*strip_ready;
-  const int *tile_kb0,*tile_nkb,*tile_woff;
+  int tps,ntiles,nstrips,nrg,strips_per_xcd,steps;
+  int nvk_max;
+  unsigned wlds_bytes,meta_bytes,wv_bytes;
+  const int *strip_col_lo,*strip_nvb,*strip_wbase,*strip_wcount;
+  const unsigned *tile_meta;
   const double *wh;
   const int *rg_row_lo,*rg_nvk,*rg_woff;
   const double *wv;
@@ -66,9 +67,13 @@ static __device__ __forceinline__ float4 load_patch_pixel(const Q *p)
   return make_float4((float) v[0],(float) v[1],(float) v[2],(float) v[3]);
 }
 
-static __device__ __forceinline__ bool not_finite_f32(float v)
+// Inf, NaN or a magnitude above 2^20: such a sample sends its workgroup step down the careful
+// path.  With every staged sample at most 2^20 the intermediate stays finite — gamma is at most
+// QuantumRange/MagickEpsilon (PerceptibleReciprocal's clamp), so |colour| < 1.3*2^40*6.6e16 — and a
+// finite intermediate times a zero weight is an exact zero.
+static __device__ __forceinline__ unsigned not_tame_f32(float v)
 {
-  return (__builtin_bit_cast(unsigned,v) & 0x7f800000u) == 0x7f800000u;
+  return (__builtin_bit_cast(unsigned,v) & 0x7fffffffu) > 0x49800000u ? 1u : 0u;
 }
 
 // the four sums of one pixel -> the Quantum the reference stores
@@ -117,15 +122,34 @@ static __device__ __forceinline__ void careful_step(const MfmaResizeArgs &a,int 
     }
 }
 
-template<typename Q,bool BLEND>
-__global__ __launch_bounds__(256,2)
+// the matrix chain of one out tile whose first K-block sits in ring slot S0: straight-line code
+template<int S0,int NK>
+static __device__ __forceinline__ void tile_chain(const double (&ring)[8][4],const double *wb,d4 (&o)[4])
+{
+  if constexpr (S0+NK <= 8)
+    {
+#pragma unroll
+      for (int j=0; j < NK; j++)
+        {
+          const double b=wb[j*64];
+#pragma unroll
+          for (int c=0; c < 4; c++)
+            o[c]=__builtin_amdgcn_mfma_f64_16x16x4f64(ring[S0+j][c],b,o[c],0,0,0);
+        }
+    }
+}
+
+template<typename Q,bool BLEND,int WAVES,int NK>
+__global__ __launch_bounds__(64*WAVES)
 void resize_mfma_kernel(MfmaResizeArgs a)
 {
   constexpr bool kFloat=QuantumOps<Q>::is_float;
-  constexpr int kMaxVK=MfmaResizePlan::kMaxVK;
+  constexpr int THREADS=64*WAVES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double *wlds=reinterpret_cast<double *>(smem_raw);
-  float4 *patch=reinterpret_cast<float4 *>(smem_raw+a.wlds_bytes);
+  double *wlds=reinterpret_cast<double *>(smem_raw);                          // [tps*NK][64]
+  unsigned *tmeta=reinterpret_cast<unsigned *>(smem_raw+a.wlds_bytes);       // [tps+1]
+  double *wvlds=reinterpret_cast<double *>(smem_raw+a.wlds_bytes+a.meta_bytes);   // [WAVES][nvk_max][64]
+  float4 *patch=reinterpret_cast<float4 *>(smem_raw+a.wlds_bytes+a.meta_bytes+a.wv_bytes);
   __shared__ int flag[2];
 
   // workgroup -> (strip, chunk of steps).  Block b runs on XCD b%8: give an XCD a contiguous set
@@ -143,60 +167,78 @@ void resize_mfma_kernel(MfmaResizeArgs a)
   const int pc=16*nvb;                       // patch pitch in pixels
   const Q *src=static_cast<const Q *>(a.src);
   Q *dst=static_cast<Q *>(a.dst);
+  int strip_tiles=a.ntiles-strip*a.tps;
+  strip_tiles=strip_tiles < a.tps ? strip_tiles : a.tps;
 
+  // everything the walk looks up per tile goes to LDS once: no global load (and so no vmcnt wait
+  // behind the pixel stores) inside the walk
   {
     const int count=a.strip_wcount[strip]*64;
     const double *from=a.wh+(size_t) a.strip_wbase[strip]*64;
-    for (int i=tid; i < count; i+=256)
+    for (int i=tid; i < count; i+=THREADS)
       wlds[i]=from[i];
+    for (int i=tid; i <= a.tps; i+=THREADS)
+      tmeta[i]=i < strip_tiles ? a.tile_meta[strip*a.tps+i] : 0xff00u;        // sentinel: never ready
     if (tid < 2)
       flag[tid]=0;
   }
+  // a staging thread keeps its patch column and walks rows
+  const int stage_r0=tid/pc,stage_i=tid-stage_r0*pc;
+  const int stage_rows=THREADS/pc;           // rows one sweep of the workgroup covers (pc <= THREADS)
+  int stage_col=col_lo+stage_i;
+  stage_col=stage_col < a.src_columns ? stage_col : a.src_columns-1;
+  double *wvmine=wvlds+(size_t) wave*(size_t) a.nvk_max*64+lane;
 
   for (int step=0; step < a.steps; step++)
     {
-      const int rg0=(chunk*a.steps+step)*MfmaResizePlan::kWaves;
+      const int rg0=(chunk*a.steps+step)*WAVES;
       if (rg0 >= a.nrg)
         break;
       // source rows of this step's row groups
       const int prow_lo=a.rg_row_lo[rg0];
       int prow_hi=prow_lo;
-      for (int i=0; (i < MfmaResizePlan::kWaves) && (rg0+i < a.nrg); i++)
-        {
-          const int hi=a.rg_row_lo[rg0+i]+4*a.rg_nvk[rg0+i];
-          prow_hi=hi > prow_hi ? hi : prow_hi;
-        }
-      const int items=(prow_hi-prow_lo)*pc;
-      __syncthreads();                       // the previous step's readers are done (weights staged)
-      {
-        constexpr int BATCH=8;
-        bool bad=false;
-        for (int i0=tid; i0 < items; i0+=256*BATCH)
+#pragma unroll
+      for (int i=0; i < WAVES; i++)
+        if (rg0+i < a.nrg)
           {
-            float4 v[BATCH];
-#pragma unroll
-            for (int k=0; k < BATCH; k++)
-              {
-                int idx=i0+256*k;
-                idx=idx < items ? idx : items-1;
-                const int r=idx/pc,i=idx-r*pc;
-                int row=prow_lo+r,col=col_lo+i;
-                row=row < a.src_rows ? row : a.src_rows-1;
-                col=col < a.src_columns ? col : a.src_columns-1;
-                v[k]=load_patch_pixel<Q>(src+((size_t) row*(size_t) a.src_columns+(size_t) col)*4);
-              }
-#pragma unroll
-            for (int k=0; k < BATCH; k++)
-              {
-                if constexpr (kFloat)
-                  bad=bad || not_finite_f32(v[k].x) || not_finite_f32(v[k].y) || not_finite_f32(v[k].z) ||
-                    not_finite_f32(v[k].w);
-                if (i0+256*k < items)
-                  patch[i0+256*k]=v[k];
-              }
+            const int hi=a.rg_row_lo[rg0+i]+4*a.rg_nvk[rg0+i];
+            prow_hi=hi > prow_hi ? hi : prow_hi;
           }
+      const int prows=prow_hi-prow_lo;
+      // this wave's row group
+      const int rg=rg0+wave;
+      const bool active=rg < a.nrg;
+      const int rgc=active ? rg : a.nrg-1;
+      const int rrow=a.rg_row_lo[rgc]-prow_lo,nvk=a.rg_nvk[rgc];
+      const double *wvp=a.wv+(size_t) a.rg_woff[rgc]*64+lane;
+      __syncthreads();                       // the previous step's readers are done (weights staged)
+      for (int kb=0; kb < nvk; kb++)         // the wave's own weight blocks, beside the patch
+        wvmine[kb*64]=wvp[kb*64];
+      {
+        constexpr int BATCH=4;
+        unsigned bad=0u;
+        if (stage_r0 < stage_rows)
+          for (int r0=stage_r0; r0 < prows; r0+=stage_rows*BATCH)
+            {
+              float4 v[BATCH];
+#pragma unroll
+              for (int k=0; k < BATCH; k++)
+                {
+                  int row=prow_lo+r0+stage_rows*k;
+                  row=row < a.src_rows ? row : a.src_rows-1;
+                  v[k]=load_patch_pixel<Q>(src+((size_t) row*(size_t) a.src_columns+(size_t) stage_col)*4);
+                }
+#pragma unroll
+              for (int k=0; k < BATCH; k++)
+                if (r0+stage_rows*k < prows)
+                  {
+                    if constexpr (kFloat)
+                      bad=bad | not_tame_f32(v[k].x) | not_tame_f32(v[k].y) | not_tame_f32(v[k].z) | not_tame_f32(v[k].w);
+                    patch[(r0+stage_rows*k)*pc+stage_i]=v[k];
+                  }
+            }
         if constexpr (kFloat)
-          if (bad)
+          if (bad != 0u)
             flag[step & 1]=1;
       }
       __syncthreads();
@@ -207,53 +249,52 @@ void resize_mfma_kernel(MfmaResizeArgs a)
           if (tid == 0)
             flag[(step+1) & 1]=0;            // nobody reads the other word between these barriers
         }
-      const int rg=rg0+wave;
-      if (!careful && (rg < a.nrg))
+      if (careful)
         {
-          const int rrow=a.rg_row_lo[rg]-prow_lo,nvk=a.rg_nvk[rg];
-          double wvr[kMaxVK];
-          {
-            const double *wvp=a.wv+(size_t) a.rg_woff[rg]*64+lane;
-#pragma unroll
-            for (int kb=0; kb < kMaxVK; kb++)
-              wvr[kb]=kb < nvk ? wvp[kb*64] : 0.0;
-          }
+          const int x0=strip*a.tps*16;
+          int x1=x0+a.tps*16,y1=16*rg0+16*WAVES;
+          x1=x1 < a.dst_columns ? x1 : a.dst_columns;
+          y1=y1 < a.dst_rows ? y1 : a.dst_rows;
+          careful_step<Q,BLEND>(a,x0,x1,16*rg0,y1);
+        }
+      else if (active)
+        {
           double ring[8][4];
 #pragma unroll
           for (int s=0; s < 8; s++)
 #pragma unroll
             for (int c=0; c < 4; c++)
               ring[s][c]=0.0;
-          bool bad=false;
           int tdone=0;
+          unsigned meta=__builtin_amdgcn_readfirstlane(tmeta[0]);
           const int y_base=16*rg+g;
+          const float4 *prow=patch+(rrow+g)*pc+n;
           for (int vb=0; vb < nvb; vb++)
             {
               d4 acc[4];
 #pragma unroll
               for (int c=0; c < 4; c++)
                 acc[c]=(d4) {0.0,0.0,0.0,0.0};
+              for (int kb=0; kb < nvk; kb++)
+                {
+                  const float4 px=prow[4*kb*pc+16*vb];
+                  const double b=wvmine[kb*64];
+                  double av[4];
+                  if constexpr (BLEND)
+                    {
+                      av[3]=(double) px.w;
+                      av[0]=av[3]*(double) px.x;       // exact: two 24-bit significands
+                      av[1]=av[3]*(double) px.y;
+                      av[2]=av[3]*(double) px.z;
+                    }
+                  else
+                    {
+                      av[0]=(double) px.x; av[1]=(double) px.y; av[2]=(double) px.z; av[3]=(double) px.w;
+                    }
 #pragma unroll
-              for (int kb=0; kb < kMaxVK; kb++)
-                if (kb < nvk)
-                  {
-                    const float4 px=patch[(rrow+4*kb+g)*pc+16*vb+n];
-                    double av[4];
-                    if constexpr (BLEND)
-                      {
-                        av[3]=(double) px.w;
-                        av[0]=av[3]*(double) px.x;       // exact: two 24-bit significands
-                        av[1]=av[3]*(double) px.y;
-                        av[2]=av[3]*(double) px.z;
-                      }
-                    else
-                      {
-                        av[0]=(double) px.x; av[1]=(double) px.y; av[2]=(double) px.z; av[3]=(double) px.w;
-                      }
-#pragma unroll
-                    for (int c=0; c < 4; c++)
-                      acc[c]=__builtin_amdgcn_mfma_f64_16x16x4f64(av[c],wvr[kb],acc[c],0,0,0);
-                  }
+                  for (int c=0; c < 4; c++)
+                    acc[c]=__builtin_amdgcn_mfma_f64_16x16x4f64(av[c],b,acc[c],0,0,0);
+                }
               // the previous block's K-blocks move down, this block's take slots 4..7
 #pragma unroll
               for (int s=0; s < 4; s++)
@@ -265,9 +306,6 @@ void resize_mfma_kernel(MfmaResizeArgs a)
                 {
                   Q q[4];
                   finish_pixel<Q,BLEND>(acc[0][r],acc[1][r],acc[2][r],acc[3][r],q);
-                  if constexpr (kFloat)
-                    bad=bad || not_finite_f32((float) q[0]) || not_finite_f32((float) q[1]) ||
-                      not_finite_f32((float) q[2]) || not_finite_f32((float) q[3]);
                   if constexpr (BLEND)
                     {
                       const double qa=(double) q[3];
@@ -283,27 +321,29 @@ void resize_mfma_kernel(MfmaResizeArgs a)
                         ring[4+r][c]=(double) q[c];
                     }
                 }
-              // out tiles whose window ends in this block
-              const int tend=a.strip_ready[strip*a.nvb_max+vb];
-              for (; tdone < tend; tdone++)
+              // out tiles whose window ends in this block (the word of the next tile is read a tile ahead)
+              while ((int) (meta >> 8) <= vb)
                 {
-                  const int t=strip*a.tps+tdone;
-                  const int sl0=a.tile_kb0[t]-4*(vb-1),sl1=sl0+a.tile_nkb[t];
-                  const double *wb=wlds+(size_t) a.tile_woff[t]*64+lane;
+                  const int sl0=(int) (meta & 255u);
+                  const double *wb=wlds+(size_t) tdone*(NK*64)+lane;
+                  const int x=16*(strip*a.tps+tdone)+n;
+                  tdone++;
+                  meta=__builtin_amdgcn_readfirstlane(tmeta[tdone]);
                   d4 o[4];
 #pragma unroll
                   for (int c=0; c < 4; c++)
                     o[c]=(d4) {0.0,0.0,0.0,0.0};
-#pragma unroll
-                  for (int s=0; s < 8; s++)
-                    if ((s >= sl0) && (s < sl1))
-                      {
-                        const double b=wb[(s-sl0)*64];
-#pragma unroll
-                        for (int c=0; c < 4; c++)
-                          o[c]=__builtin_amdgcn_mfma_f64_16x16x4f64(ring[s][c],b,o[c],0,0,0);
-                      }
-                  const int x=16*t+n;
+                  switch (sl0)
+                  {
+                    case 0: tile_chain<0,NK>(ring,wb,o); break;
+                    case 1: tile_chain<1,NK>(ring,wb,o); break;
+                    case 2: tile_chain<2,NK>(ring,wb,o); break;
+                    case 3: tile_chain<3,NK>(ring,wb,o); break;
+                    case 4: tile_chain<4,NK>(ring,wb,o); break;
+                    case 5: tile_chain<5,NK>(ring,wb,o); break;
+                    case 6: tile_chain<6,NK>(ring,wb,o); break;
+                    default: tile_chain<7,NK>(ring,wb,o); break;
+                  }
 #pragma unroll
                   for (int r=0; r < 4; r++)
                     {
@@ -315,21 +355,6 @@ void resize_mfma_kernel(MfmaResizeArgs a)
                     }
                 }
             }
-          if constexpr (kFloat)
-            if (__any(bad))
-              flag[step & 1]=1;
-        }
-      if constexpr (kFloat)
-        {
-          __syncthreads();
-          if (flag[step & 1] != 0)
-            {
-              const int x0=strip*a.tps*16;
-              int x1=x0+a.tps*16,y1=16*rg0+16*MfmaResizePlan::kWaves;
-              x1=x1 < a.dst_columns ? x1 : a.dst_columns;
-              y1=y1 < a.dst_rows ? y1 : a.dst_rows;
-              careful_step<Q,BLEND>(a,x0,x1,16*rg0,y1);
-            }
         }
     }
 }
@@ -339,7 +364,7 @@ struct MfmaPlanDevice
 {
   MfmaResizePlan plan;
   TableBundle tables;
-  size_t i_col_lo=0,i_nvb=0,i_wbase=0,i_wcount=0,i_ready=0,i_kb0=0,i_nkb=0,i_woff=0,i_wh=0;
+  size_t i_col_lo=0,i_nvb=0,i_wbase=0,i_wcount=0,i_meta=0,i_wh=0;
   size_t i_row_lo=0,i_nvk=0,i_rwoff=0,i_wv=0,i_vstart=0,i_vcount=0,i_hstart=0,i_hcount=0,i_vw=0,i_hw=0;
   hipEvent_t ready=nullptr;
   int device=-1;
@@ -359,7 +384,7 @@ struct MfmaPlanDevice
 
 struct MfmaPlanEntry
 {
-  unsigned long long vserial,hserial; int device,tps; std::shared_ptr<MfmaPlanDevice> plan;
+  unsigned long long vserial,hserial; int device,tps,waves; std::shared_ptr<MfmaPlanDevice> plan;
 };
 static std::mutex &mfma_plans_lock() { static std::mutex &m=*new std::mutex; return m; }
 static std::vector<MfmaPlanEntry> &mfma_plans() { static std::vector<MfmaPlanEntry> &v=*new std::vector<MfmaPlanEntry>; return v; }
@@ -370,17 +395,16 @@ void release_resize_mfma_plans()
   mfma_plans().clear();
 }
 
-static MhStatus build_plan_device(MfmaPlanDevice &d,const TapTable &vt,const TapTable &ht,int tps,int device,
-  hipStream_t stream)
+static MhStatus build_plan_device(MfmaPlanDevice &d,const TapTable &vt,const TapTable &ht,int tps,int waves,
+  int device,hipStream_t stream)
 {
-  d.ok=build_mfma_resize_plan(d.plan,vt,ht,tps);
+  d.ok=build_mfma_resize_plan(d.plan,vt,ht,tps,waves);
   if (!d.ok)
     return MH_OK;
   const MfmaResizePlan &p=d.plan;
 #define MH_ADD(vec) d.tables.add((vec).data(),(vec).size()*sizeof((vec)[0]))
   d.i_col_lo=MH_ADD(p.strip_col_lo); d.i_nvb=MH_ADD(p.strip_nvb); d.i_wbase=MH_ADD(p.strip_wbase);
-  d.i_wcount=MH_ADD(p.strip_wcount); d.i_ready=MH_ADD(p.strip_ready);
-  d.i_kb0=MH_ADD(p.tile_kb0); d.i_nkb=MH_ADD(p.tile_nkb); d.i_woff=MH_ADD(p.tile_woff); d.i_wh=MH_ADD(p.wh);
+  d.i_wcount=MH_ADD(p.strip_wcount); d.i_meta=MH_ADD(p.tile_meta); d.i_wh=MH_ADD(p.wh);
   d.i_row_lo=MH_ADD(p.rg_row_lo); d.i_nvk=MH_ADD(p.rg_nvk); d.i_rwoff=MH_ADD(p.rg_woff); d.i_wv=MH_ADD(p.wv);
   d.i_vstart=MH_ADD(vt.start); d.i_vcount=MH_ADD(vt.count); d.i_hstart=MH_ADD(ht.start); d.i_hcount=MH_ADD(ht.count);
   d.i_vw=MH_ADD(vt.weight); d.i_hw=MH_ADD(ht.weight);
@@ -396,7 +420,7 @@ static MhStatus build_plan_device(MfmaPlanDevice &d,const TapTable &vt,const Tap
 }
 
 static MhStatus acquire_plan(std::shared_ptr<MfmaPlanDevice> *out,const TapTable &vt,const TapTable &ht,int tps,
-  int device,hipStream_t stream)
+  int waves,int device,hipStream_t stream)
 {
   const bool shared=(vt.serial != 0) && (ht.serial != 0);
   constexpr size_t kEntries=6;
@@ -406,7 +430,7 @@ static MhStatus acquire_plan(std::shared_ptr<MfmaPlanDevice> *out,const TapTable
       std::vector<MfmaPlanEntry> &entries=mfma_plans();
       for (size_t i=0; i < entries.size(); i++)
         if ((entries[i].vserial == vt.serial) && (entries[i].hserial == ht.serial) &&
-            (entries[i].device == device) && (entries[i].tps == tps))
+            (entries[i].device == device) && (entries[i].tps == tps) && (entries[i].waves == waves))
           {
             MfmaPlanEntry hit=entries[i];
             entries.erase(entries.begin()+(ptrdiff_t) i);
@@ -418,20 +442,28 @@ static MhStatus acquire_plan(std::shared_ptr<MfmaPlanDevice> *out,const TapTable
           }
     }
   auto built=std::make_shared<MfmaPlanDevice>();
-  MH_TRY(build_plan_device(*built,vt,ht,tps,device,stream));
+  MH_TRY(build_plan_device(*built,vt,ht,tps,waves,device,stream));
   *out=built;
   if (shared)
     {
       std::lock_guard<std::mutex> guard(mfma_plans_lock());
       std::vector<MfmaPlanEntry> &entries=mfma_plans();
-      entries.insert(entries.begin(),MfmaPlanEntry{vt.serial,ht.serial,device,tps,built});
+      entries.insert(entries.begin(),MfmaPlanEntry{vt.serial,ht.serial,device,tps,waves,built});
       if (entries.size() > kEntries)
         entries.pop_back();
     }
   return MH_OK;
 }
 
-template<typename Q,bool BLEND>
+static size_t mfma_weight_bytes(const MfmaResizePlan &p) { return ((size_t) p.wblocks_max*512u+15u) & ~(size_t) 15u; }
+static size_t mfma_meta_bytes(const MfmaResizePlan &p) { return ((size_t) (p.tps+1)*4u+15u) & ~(size_t) 15u; }
+static size_t mfma_wv_bytes(const MfmaResizePlan &p) { return (size_t) p.waves*(size_t) p.nvk_max*512u; }
+static size_t mfma_lds_bytes(const MfmaResizePlan &p)
+{
+  return mfma_weight_bytes(p)+mfma_meta_bytes(p)+mfma_wv_bytes(p)+(size_t) p.patch_rows_max*(size_t) (16*p.nvb_max)*16u;
+}
+
+template<typename Q,bool BLEND,int WAVES,int NK>
 static MhStatus launch_mfma_typed(const View &src,const View &dst,const MfmaPlanDevice &d,int steps)
 {
   const MfmaResizePlan &p=d.plan;
@@ -440,30 +472,55 @@ static MhStatus launch_mfma_typed(const View &src,const View &dst,const MfmaPlan
   a.src=src.pixels; a.dst=dst.pixels;
   a.src_columns=(int) src.columns; a.src_rows=(int) src.rows;
   a.dst_columns=(int) dst.columns; a.dst_rows=(int) dst.rows;
-  a.tps=p.tps; a.nstrips=p.nstrips; a.nrg=p.nrg; a.nvb_max=p.nvb_max;
+  a.tps=p.tps; a.ntiles=p.ntiles; a.nstrips=p.nstrips; a.nrg=p.nrg;
   a.strips_per_xcd=(p.nstrips+7)/8;
   a.steps=steps;
-  a.wlds_bytes=(unsigned) (((size_t) p.wblocks_max*512u+15u) & ~(size_t) 15u);
+  a.wlds_bytes=(unsigned) mfma_weight_bytes(p);
+  a.meta_bytes=(unsigned) mfma_meta_bytes(p);
+  a.wv_bytes=(unsigned) mfma_wv_bytes(p);
+  a.nvk_max=p.nvk_max;
   a.strip_col_lo=t.at<int>(d.i_col_lo); a.strip_nvb=t.at<int>(d.i_nvb); a.strip_wbase=t.at<int>(d.i_wbase);
-  a.strip_wcount=t.at<int>(d.i_wcount); a.strip_ready=t.at<int>(d.i_ready);
-  a.tile_kb0=t.at<int>(d.i_kb0); a.tile_nkb=t.at<int>(d.i_nkb); a.tile_woff=t.at<int>(d.i_woff);
+  a.strip_wcount=t.at<int>(d.i_wcount); a.tile_meta=t.at<unsigned>(d.i_meta);
   a.wh=t.at<double>(d.i_wh);
   a.rg_row_lo=t.at<int>(d.i_row_lo); a.rg_nvk=t.at<int>(d.i_nvk); a.rg_woff=t.at<int>(d.i_rwoff);
   a.wv=t.at<double>(d.i_wv);
   a.vstart=t.at<int>(d.i_vstart); a.vcount=t.at<int>(d.i_vcount);
   a.hstart=t.at<int>(d.i_hstart); a.hcount=t.at<int>(d.i_hcount);
   a.vweight=t.at<double>(d.i_vw); a.hweight=t.at<double>(d.i_hw);
-  const size_t lds=(size_t) a.wlds_bytes+(size_t) p.patch_rows_max*(size_t) (16*p.nvb_max)*16u;
-  const int quads=(p.nrg+MfmaResizePlan::kWaves-1)/MfmaResizePlan::kWaves;
-  const int chunks=(quads+steps-1)/steps;
+  const size_t lds=mfma_lds_bytes(p);
+  const int groups=(p.nrg+WAVES-1)/WAVES;
+  const int chunks=(groups+steps-1)/steps;
   dim3 grid((unsigned) (8*a.strips_per_xcd*chunks));
   if (lds > 64u*1024u)
-    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resize_mfma_kernel<Q,BLEND>),
+    MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resize_mfma_kernel<Q,BLEND,WAVES,NK>),
       hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
   ProfileScope prof("resize_mfma",src.stream);
-  hipLaunchKernelGGL((resize_mfma_kernel<Q,BLEND>),grid,dim3(256),lds,src.stream,a);
+  hipLaunchKernelGGL((resize_mfma_kernel<Q,BLEND,WAVES,NK>),grid,dim3(64*WAVES),lds,src.stream,a);
   MH_HIP(hipGetLastError());
   return MH_OK;
+}
+
+template<int WAVES,int NK>
+static MhStatus launch_mfma_waves(const View &src,const View &dst,const MfmaPlanDevice &d,int steps,bool blend)
+{
+  if (src.quantum == MH_QUANTUM_U16)
+    return blend ? launch_mfma_typed<uint16_t,true,WAVES,NK>(src,dst,d,steps) :
+                   launch_mfma_typed<uint16_t,false,WAVES,NK>(src,dst,d,steps);
+  return blend ? launch_mfma_typed<float,true,WAVES,NK>(src,dst,d,steps) :
+                 launch_mfma_typed<float,false,WAVES,NK>(src,dst,d,steps);
+}
+
+template<int WAVES>
+static MhStatus launch_mfma_blocks(const View &src,const View &dst,const MfmaPlanDevice &d,int steps,bool blend)
+{
+  switch (d.plan.nk)
+  {
+    case 1: return launch_mfma_waves<WAVES,1>(src,dst,d,steps,blend);
+    case 2: return launch_mfma_waves<WAVES,2>(src,dst,d,steps,blend);
+    case 3: return launch_mfma_waves<WAVES,3>(src,dst,d,steps,blend);
+    case 4: return launch_mfma_waves<WAVES,4>(src,dst,d,steps,blend);
+    default: return launch_mfma_waves<WAVES,5>(src,dst,d,steps,blend);
+  }
 }
 
 // *handled = false (nothing launched) when the frame or the geometry is not this kernel's.
@@ -480,25 +537,28 @@ MhStatus launch_resize_mfma(const View &src,const View &dst,const TapTable &vert
   // enlargements only: a reduction's windows are wider than the two blocks the ring holds
   if ((dst.rows < src.rows) || (dst.columns < src.columns))
     return MH_OK;
-  int tps=16,steps=8;
+  // 16 tiles (256 columns) a strip, six waves a workgroup: two workgroups = three waves a SIMD fit
+  // a CU's LDS (weights 24 KB + patch 41 KB each for a 4x Lanczos)
+  int tps=16,steps=8,waves=6;
   if (const char *e=option("MAGICKHIP_RESIZE_MFMA_TPS"))
     tps=atoi(e) > 0 ? atoi(e) : tps;
   if (const char *e=option("MAGICKHIP_RESIZE_MFMA_STEPS"))
     steps=atoi(e) > 0 ? atoi(e) : steps;
+  if (const char *e=option("MAGICKHIP_RESIZE_MFMA_WAVES"))
+    waves=atoi(e);
+  if ((waves != 4) && (waves != 6))
+    waves=6;
   std::shared_ptr<MfmaPlanDevice> plan;
-  MH_TRY(acquire_plan(&plan,vertical,horizontal,tps,src.device,src.stream));
+  MH_TRY(acquire_plan(&plan,vertical,horizontal,tps,waves,src.device,src.stream));
   if (!plan->ok)
     return MH_OK;
-  const size_t lds=(((size_t) plan->plan.wblocks_max*512u+15u) & ~(size_t) 15u)+
-    (size_t) plan->plan.patch_rows_max*(size_t) (16*plan->plan.nvb_max)*16u;
-  if (lds > 76u*1024u)                       // two workgroups a CU
+  // (the staging threads each keep one patch column: the patch is at most a workgroup wide)
+  if ((mfma_lds_bytes(plan->plan) > 78u*1024u) || (16*plan->plan.nvb_max > 64*waves) || (plan->plan.nk > 5))
     return MH_OK;
   *handled=true;
-  if (src.quantum == MH_QUANTUM_U16)
-    return roles.blend ? launch_mfma_typed<uint16_t,true>(src,dst,*plan,steps) :
-                         launch_mfma_typed<uint16_t,false>(src,dst,*plan,steps);
-  return roles.blend ? launch_mfma_typed<float,true>(src,dst,*plan,steps) :
-                       launch_mfma_typed<float,false>(src,dst,*plan,steps);
+  if (waves == 4)
+    return launch_mfma_blocks<4>(src,dst,*plan,steps,roles.blend);
+  return launch_mfma_blocks<6>(src,dst,*plan,steps,roles.blend);
 }
 
 } // namespace mh

@@ -29,15 +29,21 @@ namespace mh {
 struct MfmaResizePlan
 {
   static constexpr int kTile=16;       // output columns per tile, output rows per row group
-  static constexpr int kWaves=4;       // row groups per workgroup step
+  int waves=4;                         // row groups (waves) per workgroup step
   static constexpr int kMaxVK=6;       // K-blocks of 4 source rows per row group the kernel unrolls
   int tps=16;                          // tiles per strip
   int out_columns=0,out_rows=0;
   int ntiles=0,nstrips=0,nrg=0;
   int nvb_max=1,nvk_max=1,patch_rows_max=1,wblocks_max=1;
   std::vector<int> strip_col_lo,strip_nvb,strip_wbase,strip_wcount;   // [nstrips]
-  std::vector<int> strip_ready;        // [nstrips][nvb_max]: tiles of the strip complete after block vb
-  std::vector<int> tile_kb0,tile_nkb,tile_woff;                       // [ntiles]
+  // Every tile takes exactly `nk` K-blocks (the widest window's count; narrower windows are padded
+  // with zero-weight blocks), so the kernel's matrix chain is straight-line code: tile i of a strip
+  // owns weight blocks [i*nk, (i+1)*nk) of the strip and its first K-block sits in ring slot sl0.
+  int nk=1;
+  std::vector<int> tile_kb0;                                          // [ntiles] first K-block (may be < 0)
+  // per tile, the word the kernel keeps in LDS: sl0 | vb<<8 (vb: the block after which the tile's
+  // window is complete; the ring then holds blocks vb-1 (slots 0..3) and vb (slots 4..7))
+  std::vector<unsigned> tile_meta;                                    // [ntiles]
   std::vector<double> wh;              // [blocks][64]
   std::vector<int> rg_row_lo,rg_nvk,rg_woff;                          // [nrg]
   std::vector<double> wv;              // [blocks][64]
@@ -48,13 +54,14 @@ struct MfmaResizePlan
 // an output without contributions, a tile window that does not fit two 16-column blocks, a row
 // group that needs more than kMaxVK K-blocks.
 template<class Table>
-static bool build_mfma_resize_plan(MfmaResizePlan &p,const Table &vt,const Table &ht,int tps)
+static bool build_mfma_resize_plan(MfmaResizePlan &p,const Table &vt,const Table &ht,int tps,int waves)
 {
   constexpr int T=MfmaResizePlan::kTile;
   p.tps=tps;
+  p.waves=waves;
   p.out_columns=ht.out_size;
   p.out_rows=vt.out_size;
-  if ((p.out_columns <= 0) || (p.out_rows <= 0) || (tps < 1))
+  if ((p.out_columns <= 0) || (p.out_rows <= 0) || (tps < 1) || (waves < 1))
     return false;
   for (int i=0; i < ht.out_size; i++)
     if (ht.count[(size_t) i] <= 0)
@@ -86,12 +93,10 @@ static bool build_mfma_resize_plan(MfmaResizePlan &p,const Table &vt,const Table
   p.strip_wbase.assign((size_t) p.nstrips,0);
   p.strip_wcount.assign((size_t) p.nstrips,0);
   p.tile_kb0.assign((size_t) p.ntiles,0);
-  p.tile_nkb.assign((size_t) p.ntiles,0);
-  p.tile_woff.assign((size_t) p.ntiles,0);
+  p.tile_meta.assign((size_t) p.ntiles,0u);
   p.nvb_max=1;
-  p.wblocks_max=1;
+  p.nk=1;
   std::vector<int> tile_vb((size_t) p.ntiles,0);
-  int wtotal=0;
   for (int s=0; s < p.nstrips; s++)
     {
       const int t0=s*tps,t1=std::min(p.ntiles,t0+tps);
@@ -100,45 +105,46 @@ static bool build_mfma_resize_plan(MfmaResizePlan &p,const Table &vt,const Table
       const int nvb=(col_hi-col_lo+15)/16;
       p.strip_col_lo[(size_t) s]=col_lo;
       p.strip_nvb[(size_t) s]=nvb;
-      p.strip_wbase[(size_t) s]=wtotal;
       p.nvb_max=std::max(p.nvb_max,nvb);
-      int woff=0;
       for (int t=t0; t < t1; t++)
         {
           const int kb0=(tlo[(size_t) t]-col_lo)/4;
           const int kbe=(thi[(size_t) t]-1-col_lo)/4;
           const int vb=kbe/4;
           // the ring holds the K-blocks of vertical blocks vb-1 and vb
-          if (kb0 < 4*(vb-1))
+          if ((kb0 < 4*(vb-1)) || (vb > 254))
             return false;
           p.tile_kb0[(size_t) t]=kb0;
-          p.tile_nkb[(size_t) t]=kbe-kb0+1;
-          p.tile_woff[(size_t) t]=woff;
           tile_vb[(size_t) t]=vb;
-          woff+=kbe-kb0+1;
+          p.nk=std::max(p.nk,kbe-kb0+1);
         }
-      p.strip_wcount[(size_t) s]=woff;
-      p.wblocks_max=std::max(p.wblocks_max,woff);
-      wtotal+=woff;
     }
+  int wtotal=0;
+  for (int s=0; s < p.nstrips; s++)
+    {
+      const int t0=s*tps,t1=std::min(p.ntiles,t0+tps);
+      p.strip_wbase[(size_t) s]=wtotal;
+      p.strip_wcount[(size_t) s]=(t1-t0)*p.nk;
+      wtotal+=(t1-t0)*p.nk;
+      for (int t=t0; t < t1; t++)
+        {
+          // pad to nk blocks: move the first block down until the last one is the ring's slot 7 at most
+          const int vb=tile_vb[(size_t) t];
+          const int kb0=std::min(p.tile_kb0[(size_t) t],4*vb+4-p.nk);
+          p.tile_kb0[(size_t) t]=kb0;
+          p.tile_meta[(size_t) t]=(unsigned) (kb0-4*(vb-1)) | ((unsigned) vb << 8);
+        }
+    }
+  p.wblocks_max=tps*p.nk;
   p.wh.assign((size_t) wtotal*64,0.0);
-  p.strip_ready.assign((size_t) p.nstrips*(size_t) p.nvb_max,0);
   for (int s=0; s < p.nstrips; s++)
     {
       const int t0=s*tps,t1=std::min(p.ntiles,t0+tps);
       const int col_lo=p.strip_col_lo[(size_t) s];
-      for (int vb=0; vb < p.nvb_max; vb++)
-        {
-          int ready=0;
-          for (int t=t0; t < t1; t++)
-            if (tile_vb[(size_t) t] <= vb)
-              ready++;
-          p.strip_ready[(size_t) s*(size_t) p.nvb_max+(size_t) vb]=ready;
-        }
       for (int t=t0; t < t1; t++)
-        for (int j=0; j < p.tile_nkb[(size_t) t]; j++)
+        for (int j=0; j < p.nk; j++)
           {
-            double *blk=&p.wh[((size_t) p.strip_wbase[(size_t) s]+(size_t) p.tile_woff[(size_t) t]+(size_t) j)*64];
+            double *blk=&p.wh[((size_t) p.strip_wbase[(size_t) s]+(size_t) (t-t0)*(size_t) p.nk+(size_t) j)*64];
             for (int lane=0; lane < 64; lane++)
               {
                 const int g=lane >> 4,n=lane & 15;
@@ -195,12 +201,12 @@ static bool build_mfma_resize_plan(MfmaResizePlan &p,const Table &vt,const Table
               blk[lane]=vt.weight[(size_t) k*(size_t) vt.out_size+(size_t) y];
           }
       }
-  // source rows one workgroup step (kWaves row groups) stages
+  // source rows one workgroup step (`waves` row groups) stages
   p.patch_rows_max=1;
-  for (int rg0=0; rg0 < p.nrg; rg0+=MfmaResizePlan::kWaves)
+  for (int rg0=0; rg0 < p.nrg; rg0+=waves)
     {
       int hi=0;
-      for (int rg=rg0; (rg < rg0+MfmaResizePlan::kWaves) && (rg < p.nrg); rg++)
+      for (int rg=rg0; (rg < rg0+waves) && (rg < p.nrg); rg++)
         hi=std::max(hi,p.rg_row_lo[(size_t) rg]+4*p.rg_nvk[(size_t) rg]);
       p.patch_rows_max=std::max(p.patch_rows_max,hi-p.rg_row_lo[(size_t) rg0]);
     }

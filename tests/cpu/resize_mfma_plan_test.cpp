@@ -67,13 +67,13 @@ static void mfma(const Frag a,const Frag b,double d[64][4])
       }
 }
 
-static int run(int W,int H,int OW,int OH,int tps,bool expect_ok)
+static int run(int W,int H,int OW,int OH,int tps,bool expect_ok,int waves=4)
 {
   Table vt,ht;
   build(vt,H,OH);
   build(ht,W,OW);
   mh::MfmaResizePlan p;
-  const bool ok=mh::build_mfma_resize_plan(p,vt,ht,tps);
+  const bool ok=mh::build_mfma_resize_plan(p,vt,ht,tps,waves);
   if (ok != expect_ok)
     {
       std::printf("FAIL %dx%d -> %dx%d: plan ok=%d, expected %d\n",W,H,OW,OH,(int) ok,(int) expect_ok);
@@ -107,19 +107,19 @@ static int run(int W,int H,int OW,int OH,int tps,bool expect_ok)
   const int pitch=16*p.nvb_max;
   std::vector<double> patch((size_t) p.patch_rows_max*pitch);
   for (int strip=0; strip < p.nstrips; strip++)
-    for (int rg0=0; rg0 < p.nrg; rg0+=mh::MfmaResizePlan::kWaves)
+    for (int rg0=0; rg0 < p.nrg; rg0+=p.waves)
       {
         const int col_lo=p.strip_col_lo[strip],nvb=p.strip_nvb[strip],pc=16*nvb;
         const int prow_lo=p.rg_row_lo[rg0];
         int prow_hi=prow_lo;
-        for (int i=0; (i < mh::MfmaResizePlan::kWaves) && (rg0+i < p.nrg); i++)
+        for (int i=0; (i < p.waves) && (rg0+i < p.nrg); i++)
           prow_hi=std::max(prow_hi,p.rg_row_lo[rg0+i]+4*p.rg_nvk[rg0+i]);
-        if ((prow_hi-prow_lo > p.patch_rows_max) || (nvb > p.nvb_max) || (p.strip_wcount[strip] > p.wblocks_max))
+        if ((prow_hi-prow_lo > p.patch_rows_max) || (nvb > p.nvb_max) || (p.strip_wcount[strip] > p.wblocks_max) || (p.nk > 5))
           { std::printf("FAIL: patch or weights exceed the plan's maxima\n"); return 1; }
         for (int r=0; r < prow_hi-prow_lo; r++)
           for (int i=0; i < pc; i++)
             patch[(size_t) r*pc+i]=src[(size_t) std::min(prow_lo+r,H-1)*W+std::min(col_lo+i,W-1)];
-        for (int wave=0; wave < mh::MfmaResizePlan::kWaves; wave++)
+        for (int wave=0; wave < p.waves; wave++)
           {
             const int rg=rg0+wave;
             if (rg >= p.nrg)
@@ -148,12 +148,15 @@ static int run(int W,int H,int OW,int OH,int tps,bool expect_ok)
                 for (int r=0; r < 4; r++)
                   for (int lane=0; lane < 64; lane++)
                     ring[4+r][lane]=acc[lane][r];
-                const int tend=p.strip_ready[(size_t) strip*p.nvb_max+vb];
-                for (; tdone < tend; tdone++)
+                for (; (tdone < std::min(p.tps,p.ntiles-strip*p.tps)) && ((int) (p.tile_meta[strip*p.tps+tdone] >> 8) <= vb); tdone++)
                   {
                     const int t=strip*p.tps+tdone;
-                    const int sl0=p.tile_kb0[t]-4*(vb-1),sl1=sl0+p.tile_nkb[t];
-                    if ((sl0 < 0) || (sl1 > 8) || ((vb == 0) && (sl0 < 4)))
+                    const unsigned meta=p.tile_meta[t];
+                    const int sl0=(int) (meta & 255u),sl1=sl0+p.nk;
+                    const int woff=tdone*p.nk;
+                    if (sl0 != p.tile_kb0[t]-4*(vb-1))
+                      { std::printf("FAIL: tile %d meta word disagrees with the tables\n",t); return 1; }
+                    if ((sl0 < 0) || (sl1 > 8))
                       { std::printf("FAIL: tile %d outside the ring (slots %d..%d at block %d)\n",t,sl0,sl1,vb); return 1; }
                     double o[64][4]={};
                     for (int s=0; s < 8; s++)
@@ -161,7 +164,7 @@ static int run(int W,int H,int OW,int OH,int tps,bool expect_ok)
                         {
                           Frag b;
                           for (int lane=0; lane < 64; lane++)
-                            b[lane]=p.wh[((size_t) p.strip_wbase[strip]+p.tile_woff[t]+(s-sl0))*64+lane];
+                            b[lane]=p.wh[((size_t) p.strip_wbase[strip]+woff+(s-sl0))*64+lane];
                           mfma(ring[s],b,o);
                         }
                     for (int lane=0; lane < 64; lane++)
@@ -185,8 +188,8 @@ static int run(int W,int H,int OW,int OH,int tps,bool expect_ok)
       std::printf("FAIL %dx%d -> %dx%d tps %d: worst relative difference %g\n",W,H,OW,OH,tps,worst);
       return 1;
     }
-  std::printf("ok   %dx%d -> %dx%d tps %d: %d strips, nvb<=%d, nvk<=%d, patch rows<=%d, %d weight blocks a strip, worst %g\n",
-    W,H,OW,OH,tps,p.nstrips,p.nvb_max,p.nvk_max,p.patch_rows_max,p.wblocks_max,worst);
+  std::printf("ok   %dx%d -> %dx%d tps %d: %d strips, nvb<=%d, nvk<=%d, patch rows<=%d, %d K-blocks a tile, worst %g\n",
+    W,H,OW,OH,tps,p.nstrips,p.nvb_max,p.nvk_max,p.patch_rows_max,p.nk,worst);
   return 0;
 }
 
@@ -204,6 +207,8 @@ int main()
   bad+=run(17,9,16*17,16*9,16,true);        // 16x
   bad+=run(1,1,40,40,16,true);              // one source pixel
   bad+=run(600,23,2400,92,16,true);
+  bad+=run(64,100,256,400,16,true,6);       // six waves a workgroup
+  bad+=run(53,37,212,148,16,true,6);
   if (bad == 0)
     std::printf("ALL OK\n");
   return bad != 0;
