@@ -320,6 +320,11 @@ MhStatus launch_resize_fused(const View &src,const View &dst,const TapTable &ver
 MhStatus launch_resize_mfma(const View &src,const View &dst,const TapTable &vertical,
   const TapTable &horizontal,const Roles &roles,bool *handled);
 void release_resize_mfma_plans();
+// the FAST one-launch enlargement by a whole-number horizontal factor on the fp64 vector pipe
+// (resize_stream.hip)
+MhStatus launch_resize_stream(const View &src,const View &dst,const TapTable &vertical,
+  const TapTable &horizontal,const Roles &roles,bool *handled);
+void release_resize_stream_plans();
 
 MhStatus launch_unsharp_epilogue(const View &src,const View &blur,const View &dst,
   double gain,double threshold,const Roles &roles);

@@ -1043,7 +1043,17 @@ MhStatus launch_resize_fused(const View &src,const View &dst,const TapTable &ver
     {
       // FAST, four channels, enlargement: both filters on the fp64 matrix pipe, the intermediate
       // in registers (resize_mfma.hip); MAGICKHIP_NO_RESIZE_MFMA=1 keeps the two passes
-      if ((prec == MH_PRECISION_FAST) && (option("MAGICKHIP_NO_RESIZE_MFMA") == nullptr))
+      if (prec != MH_PRECISION_FAST)
+        return MH_OK;
+      // ... by a whole-number horizontal factor: plain fp64 multiply-adds out of registers with
+      // scalar-register weights (resize_stream.hip); MAGICKHIP_NO_RESIZE_STREAM=1 skips it
+      if (option("MAGICKHIP_NO_RESIZE_STREAM") == nullptr)
+        {
+          MH_TRY(launch_resize_stream(src,dst,vertical,horizontal,roles,handled));
+          if (*handled)
+            return MH_OK;
+        }
+      if (option("MAGICKHIP_NO_RESIZE_MFMA") == nullptr)
         return launch_resize_mfma(src,dst,vertical,horizontal,roles,handled);
       return MH_OK;
     }

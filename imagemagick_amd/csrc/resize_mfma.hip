@@ -537,9 +537,10 @@ MhStatus launch_resize_mfma(const View &src,const View &dst,const TapTable &vert
   // enlargements only: a reduction's windows are wider than the two blocks the ring holds
   if ((dst.rows < src.rows) || (dst.columns < src.columns))
     return MH_OK;
-  // 16 tiles (256 columns) a strip, six waves a workgroup: two workgroups = three waves a SIMD fit
-  // a CU's LDS (weights 24 KB + patch 41 KB each for a 4x Lanczos)
-  int tps=16,steps=8,waves=6;
+  // 16 tiles (256 columns) a strip, four waves a workgroup: three workgroups = three waves a SIMD
+  // fit a CU's LDS (weights 24 KB + patch 29 KB each for a 4x Lanczos); measured 4.83 ms against
+  // 5.75 with six waves a workgroup (8192^2 -> 32768^2, profiles/r5_notes)
+  int tps=16,steps=8,waves=4;
   if (const char *e=option("MAGICKHIP_RESIZE_MFMA_TPS"))
     tps=atoi(e) > 0 ? atoi(e) : tps;
   if (const char *e=option("MAGICKHIP_RESIZE_MFMA_STEPS"))
@@ -547,14 +548,20 @@ MhStatus launch_resize_mfma(const View &src,const View &dst,const TapTable &vert
   if (const char *e=option("MAGICKHIP_RESIZE_MFMA_WAVES"))
     waves=atoi(e);
   if ((waves != 4) && (waves != 6))
-    waves=6;
+    waves=4;
   std::shared_ptr<MfmaPlanDevice> plan;
-  MH_TRY(acquire_plan(&plan,vertical,horizontal,tps,waves,src.device,src.stream));
-  if (!plan->ok)
-    return MH_OK;
-  // (the staging threads each keep one patch column: the patch is at most a workgroup wide)
-  if ((mfma_lds_bytes(plan->plan) > 78u*1024u) || (16*plan->plan.nvb_max > 64*waves) || (plan->plan.nk > 5))
-    return MH_OK;
+  // (the staging threads each keep one patch column: the patch is at most a workgroup wide; a
+  // barely-enlarging geometry's wide patch gets narrower strips)
+  for ( ; ; tps/=2)
+    {
+      MH_TRY(acquire_plan(&plan,vertical,horizontal,tps,waves,src.device,src.stream));
+      if (!plan->ok || (plan->plan.nk > 5))
+        return MH_OK;
+      if ((mfma_lds_bytes(plan->plan) <= 78u*1024u) && (16*plan->plan.nvb_max <= 64*waves))
+        break;
+      if (tps <= 4)
+        return MH_OK;
+    }
   *handled=true;
   if (waves == 4)
     return launch_mfma_blocks<4>(src,dst,*plan,steps,roles.blend);

@@ -275,7 +275,8 @@ MhStatus pool_alloc(int device,size_t bytes,hipStream_t stream,void **ptr)
       // last used on another stream: order behind it — outside the runtime lock, so that the
       // workers of the other devices and streams keep allocating meanwhile
       if (reused_from != stream)
-        (void) hipStreamSynchronize(reused_from);
+        if (hipStreamSynchronize(reused_from) != hipSuccess)
+          (void) hipGetLastError();      // never leave a sticky error for the next launch check
       return MH_OK;
     }
   int prev=0;
@@ -863,6 +864,7 @@ MH_API void MhTerminus(void)
   release_shared_tables();
   release_resize_tables();
   release_resize_mfma_plans();
+  release_resize_stream_plans();
   pool_trim();
   staging_trim();
   release_color_tables();
@@ -1004,6 +1006,16 @@ MH_API MhStatus MhStreamDestroy(int device,void *stream)
   DeviceGuard guard;
   MH_HIP(guard.enter(device));
   MH_HIP(hipStreamSynchronize((hipStream_t) stream));
+  {
+    // cached pool blocks last used on this stream are complete now: retag them to the device's
+    // null stream (always a valid handle), so that pool_alloc never waits on a destroyed or
+    // recycled one
+    std::lock_guard<std::mutex> lock(r.lock);
+    for (DeviceState &d : r.devices)
+      for (auto &entry : d.free_blocks)
+        if (entry.second.stream == (hipStream_t) stream)
+          entry.second.stream=nullptr;
+  }
   MH_HIP(hipStreamDestroy((hipStream_t) stream));
   return MH_OK;
 }
@@ -1029,6 +1041,8 @@ MH_API MhStatus MhDeviceFreeAsync(int device,void *ptr,void *stream)
   return MH_OK;
 }
 
+static void release_spare_pinned_blocks(size_t keep_bytes);
+
 MH_API void *MhHostAlloc(size_t bytes)
 {
   if ((runtime_ready() != MH_OK) || (bytes == 0))
@@ -1051,7 +1065,12 @@ MH_API void *MhHostAlloc(size_t bytes)
   if (hipHostMalloc(&block,bytes,hipHostMallocPortable) != hipSuccess)
     {
       (void) hipGetLastError();
-      return nullptr;
+      release_spare_pinned_blocks(0);    // make room out of the spare list and try once more
+      if (hipHostMalloc(&block,bytes,hipHostMallocPortable) != hipSuccess)
+        {
+          (void) hipGetLastError();
+          return nullptr;
+        }
     }
   std::lock_guard<std::mutex> guard(p.lock);
   p.blocks[static_cast<const char *>(block)]=bytes;
@@ -1083,8 +1102,8 @@ MH_API int MhHostFree(void *block)
   if (block == nullptr)
     return 0;
   PinnedBlocks &p=pinned_blocks();
-  // MAGICKHIP_PINNED_SPARE_BYTES: how much released page-locked memory is kept for reuse (default 4 GiB)
-  const size_t spare_limit=(size_t) option_long("MAGICKHIP_PINNED_SPARE_BYTES",(long) 4 << 30);
+  // MAGICKHIP_PINNED_SPARE_BYTES: how much released page-locked memory is kept for reuse (default 1 GiB)
+  const size_t spare_limit=(size_t) option_long("MAGICKHIP_PINNED_SPARE_BYTES",(long) 1 << 30);
   {
     std::lock_guard<std::mutex> guard(p.lock);
     auto it=p.blocks.find(static_cast<const char *>(block));
@@ -1111,7 +1130,7 @@ MH_API size_t MhHostAllocatedBytes(void)
 {
   PinnedBlocks &p=pinned_blocks();
   std::lock_guard<std::mutex> guard(p.lock);
-  return p.total;
+  return p.total+p.spare_total;          // spare blocks are still page-locked: they count against a budget
 }
 
 MH_API MhStatus MhDeviceAlloc(int device,size_t bytes,void **ptr)

@@ -466,8 +466,31 @@ MagickPrivate void RetainOpenCLMemObject(cl_mem magick_unused(memobj))
 
 MagickPrivate void OpenCLTerminus(void)
 {
-  if (hip_library_state > 0)
-    hip_library.Terminus();
+  size_t
+    i;
+
+  ssize_t
+    j;
+
+  if (hip_library_state <= 0)
+    return;
+  /*
+    MhTerminus synchronises and destroys every stream MhStreamCreate handed out: forget the
+    handles first, so that a later MagickCoreGenesis (or an operator call after Terminus) creates
+    its streams afresh in AcquireHipQueue instead of launching on destroyed ones.
+  */
+  for (i=0; i < hip_number_devices; i++)
+  {
+    LockSemaphoreInfo(hip_devices[i]->lock);
+    for (j=0; j < HipStreamsPerDevice; j++)
+      hip_devices[i]->command_queues[j]=(cl_command_queue) NULL;
+    hip_devices[i]->command_queues_index=0;
+    UnlockSemaphoreInfo(hip_devices[i]->lock);
+    LockSemaphoreInfo(hip_devices_semaphore);
+    hip_devices[i]->requested=0;
+    UnlockSemaphoreInfo(hip_devices_semaphore);
+  }
+  hip_library.Terminus();
 }
 
 /* -------------------------------------------------------------- public API */

@@ -1849,12 +1849,15 @@ def test_resize_fused_forms(im, refmod, shape, target, filt, form, dtype, option
     ((29, 33, 4), (330, 290), "Lanczos"), ((41, 50, 4), (150, 164), "Triangle"),
     ((1, 1, 4), (40, 40), "Lanczos"), ((150, 70, 4), (141, 600), "Catrom"),
 ])
-def test_resize_fast_one_launch_on_the_matrix_pipe(im, refmod, dtype, alpha, shape, target, filt):
-    """FAST enlargements of four-channel frames run VerticalFilter and HorizontalFilter as banded
+def test_resize_fast_one_launch_on_the_matrix_pipe(im, refmod, options, dtype, alpha, shape, target, filt):
+    """FAST enlargements of four-channel frames that the vector-pipe form (resize_stream.hip: whole-number
+    horizontal factors up to 4) does not take run VerticalFilter and HorizontalFilter as banded
     matrix products on the fp64 matrix pipe in ONE launch (resize_mfma.hip): the Quantum-rounded
     intermediate stays in registers.  Within one level / one float ULP of the reference, and in
-    practice identical; partial tiles, strips and row groups, a mixed enlargement, one source pixel."""
+    practice identical; partial tiles, strips and row groups, a mixed enlargement, one source pixel.
+    (Every geometry is sent here: MAGICKHIP_NO_RESIZE_STREAM.)"""
     import bench
+    options.set("MAGICKHIP_NO_RESIZE_STREAM", "1")
     px = make_pixels(shape[0], shape[1], 4, dtype, seed=shape[1] + target[0])
     if alpha:
         px[: shape[0] // 2, :, 3] = 65535                # half opaque
@@ -1876,6 +1879,102 @@ def test_resize_fast_one_launch_on_the_matrix_pipe(im, refmod, dtype, alpha, sha
     same = assert_parity(holder["out"].numpy(), want, False, "one-launch resize %s -> %s %s" % (shape, target, filt),
                          max_ulp=1)
     assert same > 0.999
+
+
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("alpha", [True, False])
+@pytest.mark.parametrize("shape,target,filt", [
+    ((37, 53, 4), (212, 148), "Lanczos"),        # 4x both ways, one partial strip
+    ((64, 300, 4), (1200, 256), "Lanczos"),      # six strips of 58 source columns, the last partial
+    ((23, 600, 4), (2400, 92), "Lanczos"),
+    ((90, 100, 4), (200, 180), "Mitchell"),      # 2x, five neighbours
+    ((41, 50, 4), (150, 164), "Triangle"),       # 3x: a weight of 1e-12 beside a transparent band
+    ((150, 61, 4), (244, 701), "Lanczos"),       # 4x across, 4.67x down (seven rows under the window): more than one chunk of rows
+    ((20, 116, 4), (464, 90), "Lanczos"),        # exactly two full strips (cut at column 64: three)
+    ((12, 58, 4), (232, 54), "Catrom"),
+    ((33, 130, 4), (260, 99), "Lanczos"),        # 2x across, 3x down
+])
+def test_resize_fast_one_launch_on_the_vector_pipe(im, refmod, dtype, alpha, shape, target, filt):
+    """FAST enlargements of four-channel frames by a whole-number horizontal factor (2, 3, 4) run both
+    filters in ONE launch on the fp64 vector pipe (resize_stream.hip): a lane owns a source column, the
+    window rows live in registers, the weights in scalar registers, the Quantum-rounded intermediate
+    crosses lanes through the wave's own LDS row.  Within one level / one float ULP of the reference
+    and in practice identical; clipped windows at the image edges take their listed weights."""
+    import bench
+    px = make_pixels(shape[0], shape[1], 4, dtype, seed=shape[1] + target[0])
+    if alpha:
+        px[: shape[0] // 2, :, 3] = 65535                # half opaque
+        px[:, : shape[1] // 5, 3] = 0                    # a transparent band
+    dev = im.Image(to_device(px), has_alpha=alpha)
+    if alpha:
+        want = refmod.RefImage(px).resize(target[0], target[1], filt).numpy()
+    else:
+        want = np.concatenate([refmod.RefImage(px[:, :, c].copy()).resize(target[0], target[1], filt).numpy()
+                               .reshape(target[1], target[0], 1) for c in range(4)], axis=2)
+    im.set_precision(im.PRECISION_FAST)
+    holder = {}
+    try:
+        launched = set(bench.kernel_profile(
+            im, lambda: holder.update(out=im.resize_image(dev, target[0], target[1], filt)), 1))
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert "resize_stream" in launched and launched <= {"resize_stream", "resize_stream_careful"}, launched
+    same = assert_parity(holder["out"].numpy(), want, False, "vector-pipe resize %s -> %s %s" % (shape, target, filt),
+                         max_ulp=1)
+    assert same > 0.999
+
+
+def test_resize_vector_pipe_float_frame_with_nan_and_inf(im, refmod, options):
+    """Zero-weight padding must not spread a NaN / Inf / huge sample beyond the outputs whose window
+    holds it: the items that meet one are recomputed in the reference's own windows."""
+    options.set("MAGICKHIP_RESIZE_STREAM_ROWS", "32")
+    px = make_pixels(70, 130, 4, HDRI, seed=11)
+    px[10, 20, 1] = np.nan
+    px[33, 64, 3] = np.inf
+    px[50, 100, 0] = -np.inf
+    px[60, 5, 2] = 3.0e30
+    px[69, 129, 2] = np.nan
+    dev = im.Image(to_device(px), has_alpha=True)
+    want = refmod.RefImage(px).resize(520, 175, "Lanczos").numpy()
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got = im.resize_image(dev, 520, 175, "Lanczos").numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(np.isinf(got), np.isinf(want))
+    finite = np.isfinite(want)
+    assert finite.mean() > 0.7
+    g, w = got[finite].astype(np.float64), want[finite].astype(np.float64)
+    assert np.all(np.abs(g - w) <= np.spacing(np.abs(want[finite]).astype(np.float32)).astype(np.float64) + 1e-30)
+
+
+def test_resize_vector_pipe_weights_born_of_cancellation_and_tiny_frames(im, refmod):
+    """Triangle at 3x: the middle output of a source column has a tap at distance 1-MagickEpsilon whose
+    weight, 1e-12, differs by a part in a thousand from binade to binade of the column index — and
+    decides the result where the other tap's pixel is transparent (PerceptibleReciprocal's clamp).  The
+    strips are cut at the powers of two and carry their own weights (bit-identical to the table's
+    inside a binade); frames of a few columns whose every window is clipped are declined and the
+    matrix-pipe form takes them."""
+    import bench
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        for shape, target, filt, stream in (((41, 50, 4), (150, 164), "Triangle", True),
+                                            ((9, 5, 4), (20, 36), "Lanczos", False),
+                                            ((12, 158, 4), (474, 40), "Lanczos", True),
+                                            ((7, 3, 4), (6, 7), "Lanczos", False)):
+            for dtype in (Q16, HDRI):
+                px = make_pixels(shape[0], shape[1], 4, dtype, seed=5)
+                px[:, : shape[1] // 5, 3] = 0                # a transparent band
+                dev = im.Image(to_device(px), has_alpha=True)
+                holder = {}
+                launched = set(bench.kernel_profile(
+                    im, lambda: holder.update(out=im.resize_image(dev, target[0], target[1], filt)), 1))
+                assert ("resize_stream" in launched) == stream, (shape, launched)
+                assert_parity(holder["out"].numpy(), refmod.RefImage(px).resize(target[0], target[1], filt).numpy(),
+                              False, "vector-pipe form or its fallback %s %s" % (shape, filt), max_ulp=1)
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
 
 
 def test_resize_fast_falls_back_to_two_passes(im, refmod):
