@@ -71,7 +71,7 @@ typedef const int __attribute__((address_space(4))) *scalar_ints;
 // most 2^20 the intermediate stays finite and a finite value times a zero weight is an exact zero
 static __device__ __forceinline__ bool wild_f32(float v)
 {
-  return (__builtin_bit_cast(unsigned,v) & 0x7fffffffu) > 0x49800000u;
+  return !(__builtin_fabsf(v) <= 1048576.0f);  // one v_cmp_nle_f32 |v|: true for a NaN too
 }
 
 template<typename Q,bool BLEND>
@@ -183,7 +183,8 @@ void resize_stream_careful_kernel(StreamResizeArgs a,int f)
 }
 
 template<typename Q,bool BLEND,int F,int NT,int ROWS>
-__global__ __launch_bounds__(256,3)           // three waves a SIMD: at most 168 registers
+// three waves a SIMD (at most 168 registers); two for the eight-row window of a 3x / 4x enlargement
+__global__ __launch_bounds__(256,((ROWS == 8) && (F >= 3)) ? 2 : 3)
 void resize_stream_kernel(StreamResizeArgs a)
 {
   constexpr bool kFloat=QuantumOps<Q>::is_float;
@@ -281,13 +282,34 @@ void resize_stream_kernel(StreamResizeArgs a)
   y1=y1 < a.dst_rows ? y1 : a.dst_rows;
   const scalar_ints vbase=(scalar_ints) a.vbase;
   int base=vbase[y0];
+  // Source row r lives in window slot r % ROWS for as long as it is under the window (the dense
+  // weights of a row are stored by slot, resize_stream_plan.hpp): a new row replaces the one that
+  // left, nothing moves.  (A slot is a set of registers: the slot number selects a copy of the code.)
+  auto enter=[&](int slot,const Q (&q)[4])
+  {
+    const unsigned bad=is_wild(q);
+#pragma unroll
+    for (int j=0; j < ROWS; j++)
+      if (slot == j)
+        {
+          premultiplied<Q,BLEND>(q,win[j]);
+          // (the optimiser otherwise sinks the copies' stores into one, win[slot]: a dynamically
+          // indexed array in scratch memory)
+#pragma unroll
+          for (int k=0; k < 4; k++)
+            asm volatile("" : "+v"(win[j][k]));
+          wild=(wild & ~(1u << j)) | (bad << j);
+        }
+  };
+  int slot=base % ROWS;                        // of source row `base`, and of the row that follows the window
 #pragma unroll
   for (int j=0; j < ROWS; j++)
     {
       Q q[4];
       fetch(base+j,q);
-      wild|=is_wild(q) << j;
-      premultiplied<Q,BLEND>(q,win[j]);
+      int at=slot+j;
+      at=at >= ROWS ? at-ROWS : at;
+      enter(at,q);
     }
   Q ahead[4];                                  // the next source row, on its way
   fetch(base+ROWS,ahead);
@@ -325,6 +347,14 @@ void resize_stream_kernel(StreamResizeArgs a)
     finish_fast<Q,BLEND,2>(s,q);
     premultiplied<Q,BLEND>(q,iv);
   };
+  // which lanes of store j hold a pixel of the strip: lane masks in scalar registers
+  unsigned long long keep_mask[F];
+#pragma unroll
+  for (int j=0; j < F; j++)
+    {
+      const int from=(64*j+lane)/F;
+      keep_mask[j]=__builtin_amdgcn_ballot_w64((from >= -lo) && (from < count-lo));
+    }
   // the transposed pixels of row y: store j writes pixels F*c0+64*j .. +63
   auto store_row=[&](int y,bool really)
   {
@@ -335,8 +365,7 @@ void resize_stream_kernel(StreamResizeArgs a)
       {
         typedef unsigned words4 __attribute__((ext_vector_type(4)));
         typedef unsigned words2 __attribute__((ext_vector_type(2)));
-        const int from=(64*j+lane)/F;
-        const bool keep=really && (from >= -lo) && (from < count-lo);
+        const bool keep=(((really ? keep_mask[j] : 0ull) >> lane) & 1ull) != 0ull;
         const unsigned char *at=kSteps ? xfrom[0]+(64/F)*j*PX : xfrom[kSteps ? 0 : j];
         const unsigned offset=keep ? (kSteps ? store_offset[0]+(unsigned) (64*j*PX) : store_offset[kSteps ? 0 : j]) : 0xffffffffu;
         if constexpr (PX == 16)
@@ -428,14 +457,9 @@ void resize_stream_kernel(StreamResizeArgs a)
       // ---- the window of row y+1, and its VerticalFilter
       if (base < vbase[y+1])
         {
-#pragma unroll
-          for (int j=0; j < ROWS-1; j++)
-#pragma unroll
-            for (int k=0; k < 4; k++)
-              win[j][k]=win[j+1][k];
-          wild=(wild >> 1) | (is_wild(ahead) << (ROWS-1));
-          premultiplied<Q,BLEND>(ahead,win[ROWS-1]);
+          enter(slot,ahead);                   // row base+ROWS takes the slot of row base
           base++;
+          slot=slot+1 == ROWS ? 0 : slot+1;
         }
       fetch(base+ROWS,ahead);
       seen|=wild;
@@ -602,7 +626,7 @@ static MhStatus launch_stream_factor(const View &src,const View &dst,const Strea
   // (five neighbours = a support of two source pixels: at most five rows under the window too)
   if (d.plan.nt == 5)
     return launch_stream_layout<F,5,6>(src,dst,d,blend);
-  if (d.plan.vmax <= 6)
+  if (d.plan.window_rows() == 6)
     return launch_stream_layout<F,7,6>(src,dst,d,blend);
   return launch_stream_layout<F,7,8>(src,dst,d,blend);
 }

@@ -38,6 +38,7 @@ struct StreamResizePlan
   int nvl=0;                           // source columns a wave finishes at most: 64-(nt-1)
   int edge_left=0,edge_right=0;        // columns c < edge_left or c >= edge_right: listed weights
   int vmax=0;                          // most source rows under VerticalFilter's window
+  int window_rows() const { return vmax <= 6 ? 6 : kRows; }   // the kernel's two window sizes
   // A strip = the source columns one wave finishes.  bisect = (x+0.5)/factor+MagickEpsilon
   // (resize.c:3404-3410) rounds MagickEpsilon to the grid of its binade, so the weights of the f
   // outputs of a column are bit-identical from column to column INSIDE a binade [2^k, 2^(k+1)) and
@@ -187,7 +188,8 @@ static bool build_stream_resize_plan(StreamResizePlan &p,const Table &vt,const T
   for (size_t i=0; i < p.listed.size(); i+=D)
     if (!trimmed(&p.listed[i]))
       return false;
-  // ---- vertical: window base and dense weights per output row
+  // ---- vertical: window base and dense weights per output row.  The kernel keeps source row r in
+  // window slot r % rows (rows = window_rows(): 6 or 8): the weights are stored by slot.
   p.vmax=0;
   p.vbase.assign((size_t) OH,0);
   p.vdense.assign((size_t) OH*StreamResizePlan::kRows,0.0);
@@ -201,9 +203,12 @@ static bool build_stream_resize_plan(StreamResizePlan &p,const Table &vt,const T
         return false;
       p.vbase[(size_t) y]=start;
       p.vmax=std::max(p.vmax,count);
-      for (int k=0; k < count; k++)
-        p.vdense[(size_t) y*StreamResizePlan::kRows+(size_t) k]=vt.weight[(size_t) k*(size_t) OH+(size_t) y];
     }
+  const int rows=p.window_rows();
+  for (int y=0; y < OH; y++)
+    for (int k=0; k < vt.count[(size_t) y]; k++)
+      p.vdense[(size_t) y*StreamResizePlan::kRows+(size_t) ((vt.start[(size_t) y]+k) % rows)]=
+        vt.weight[(size_t) k*(size_t) OH+(size_t) y];
   if ((p.nt == 5) && (p.vmax > 6))
     return false;                       // (a support of two source pixels has at most five rows: cannot happen)
   return true;
