@@ -195,6 +195,50 @@ def roofline(kernel, algorithmic_bytes, avg_ms, traffic_key=None):
             "algorithmic_bytes": int(algorithmic_bytes)}
 
 
+def issue_roofline(mode, avg_ms):
+    """The fused blur kernels are bound by instruction issue, not by HBM (traffic 1.03x the
+    compulsory bytes): the matrix-pipe and vector-issue shares of the launch, from the SQ instruction
+    counters kept under profiles/ (tools/collect_sq_counters.sh; one launch of the 8192^2 frame):
+    a 16x16x32 f16 / 16x16x64 i8 matrix instruction occupies its SIMD's matrix pipe for 16 cycles, a
+    vector instruction its issue port for 4 (wave64 on 16 lanes), 1024 SIMDs at the nominal 2.4 GHz."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters.json"))):
+        try:
+            table = json.load(open(path))
+        except Exception:
+            continue
+        if mode in table and "SQ_INSTS_VALU" in table[mode]:
+            best = (path, table[mode])
+    if best is None:
+        return None
+    path, c = best
+    simd_cycles_per_ms = 1024.0 * 2.4e9 * 1e-3
+    matrix_ms = c["SQ_INSTS_MFMA"] * 16.0 / simd_cycles_per_ms
+    vector_ms = c["SQ_INSTS_VALU"] * 4.0 / simd_cycles_per_ms
+    return {"bound": "issue", "kernel_ms": round(avg_ms, 4),
+            "matrix_pipe": {"instructions": int(c["SQ_INSTS_MFMA"]), "cycles_per_instruction": 16,
+                            "busy_ms": round(matrix_ms, 4), "frac": round(matrix_ms / avg_ms, 4)},
+            "vector_issue": {"instructions": int(c["SQ_INSTS_VALU"]), "cycles_per_instruction": 4,
+                             "busy_ms": round(vector_ms, 4), "frac": round(vector_ms / avg_ms, 4),
+                             "lane_instructions_per_pixel": round(c["SQ_INSTS_VALU"] * 64.0 / (8192.0 * 8192.0), 1)},
+            "perfect_overlap_ms": round(max(matrix_ms, vector_ms), 4),
+            "source": os.path.relpath(path, ROOT)}
+
+
+def add_measured_ceiling(node, copy_gbps):
+    """frac_of_measured_copy beside every HBM `frac`: this box's own device-to-device copy rate
+    (extra.device_copy_GBps) is what a kernel that only streams reaches here."""
+    if isinstance(node, dict):
+        if node.get("unit") == "GB/s" and "achieved" in node and "frac" in node:
+            node["frac_of_measured_copy"] = round(node["achieved"] / copy_gbps, 4)
+        for value in node.values():
+            add_measured_ceiling(value, copy_gbps)
+    elif isinstance(node, list):
+        for value in node:
+            add_measured_ceiling(value, copy_gbps)
+
+
 def traffic_key(mode, kernel):
     """How profiles/pmc_traffic.json names a blur kernel: the fused kernels by their own name, the
     two-pass fp64 kernels by workload (exact: Q16, hdri: float Quantum)."""
@@ -221,7 +265,7 @@ def _ref():
     return ref
 
 
-def cpu_baseline_blur(sigma, edge=8192, calls=3):
+def cpu_baseline_blur(sigma, edge=8192, calls=3, im=None, torch=None):
     """The reference's own CPU/OpenMP BlurImage (oracle/_ref) on the full BASELINE frame: the
     median of `calls` calls on edge x edge RGBA Q16, same distribution as the GPU
     workload.  About 13 s per call on the 128-thread hosts of the pool; MAGICKHIP_BENCH_CPU_EDGE
@@ -236,14 +280,36 @@ def cpu_baseline_blur(sigma, edge=8192, calls=3):
     px = rng.integers(0, 65536, (edge, edge, 4), dtype=np.uint16)
     image = ref.RefImage(px)
     seconds = []
+    last = None
     for _ in range(calls):
         out = image.blur(0.0, sigma)
         seconds.append(out.last_seconds)
+        last = out.numpy() if im is not None else None
         del out
         if sum(seconds) > 75.0:            # a slow host: what has been measured so far is the sample
             break
     sec = sorted(seconds)[len(seconds) // 2]
-    return {"value": round(edge * edge / sec / 1e6, 3), "unit": "Mpixels/s",
+    shares = None
+    if (im is not None) and (last is not None):
+        # the share of samples on which each mode returns the reference's own level, same frame
+        try:
+            shares = {}
+            dev = torch.from_numpy(px.view(np.int16)).to("cuda").view(torch.uint16)
+            before = im.get_precision()
+            for name, precision in (("fast", im.PRECISION_FAST), ("exact", im.PRECISION_EXACT)):
+                im.set_precision(precision)
+                got = im.blur_image(im.Image(dev), 0.0, sigma).numpy()
+                diff = np.abs(got.astype(np.int32) - last.astype(np.int32))
+                shares[name] = {"identical": round(float((diff == 0).mean()), 6), "max_abs_diff": int(diff.max())}
+                del got, diff
+            im.set_precision(before)
+            del dev
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            shares = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    del last
+    return {"identical_share": shares,
+            "value": round(edge * edge / sec / 1e6, 3), "unit": "Mpixels/s",
             "cores": int(ref.thread_limit()), "kind": "reference",
             "sample": "%dx%d RGBA Q16 BlurImage(0,%g), reference MagickCore OpenMP path, median of %d calls "
                       "(%s s)" % (edge, edge, sigma, len(seconds), ", ".join("%.2f" % t for t in seconds))}
@@ -260,6 +326,16 @@ def cpu_baseline_configs():
     ref.set_thread_limit(threads, True)
     rng = np.random.default_rng(43)
     out = {}
+    try:
+        px = rng.integers(0, 65536, (1024, 1024, 4), dtype=np.uint16)
+        image = ref.RefImage(px)
+        seconds = sorted(image.blur(0.0, 2.0).last_seconds for _ in range(5))
+        out["c1_blur_1024_sigma2"] = {"value": round(1024.0 * 1024.0 / seconds[2] / 1e6, 2), "unit": "Mpixels/s",
+                                      "ms": round(seconds[2] * 1e3, 3), "cores": int(threads), "kind": "reference",
+                                      "sample": "1024x1024 RGBA Q16 BlurImage(0x2), reference MagickCore OpenMP path, "
+                                                "median of 5 calls"}
+    except Exception as exc:
+        out["c1_blur_1024_sigma2"] = {"error": str(exc)[:200]}
 
     def entry(value_px, sec, sample, hdri=False):
         return {"value": round(value_px / sec / 1e6, 3), "unit": "Mpixels/s",
@@ -342,6 +418,10 @@ def blur_mode(im, torch, image, sigma, mode, reps=24, ramp=0.3):
            "operator_frac_of_compulsory_bytes": round(2.0 * frame / sec / 1e9 / HBM_PEAK_GBS, 4),
            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in prof.items()}}
     ntaps = im.optimal_kernel_width_1d(0.0, sigma)
+    if dominant.startswith("blur_fused") and mode in ("fast", "exact") and image.rows == 8192 and image.columns == 8192:
+        issue = issue_roofline(mode, conv[dominant]["avg_ms"])
+        if issue:
+            out["issue_roofline"] = issue
     if dominant.startswith("blur_fused_exact"):
         out["compute_roofline"] = i8_roofline(pixels, ntaps, conv[dominant]["avg_ms"], dominant)
     elif mode in ("exact", "hdri"):
@@ -396,6 +476,8 @@ def resize_config(im, torch, gen):
         "resize_horizontal": (4.0 * m * m + 16.0 * m * m) * px16,    # 8192x32768 in, 32768^2 out
         "resize_fused": (1.0 * m * m + 16.0 * m * m) * px16,
         "resize_mfma": (1.0 * m * m + 16.0 * m * m) * px16,          # one launch: 8192^2 in, 32768^2 out
+        "resize_stream": (1.0 * m * m + 16.0 * m * m) * px16,        # one launch on the vector pipe (FAST default)
+        "resize_stream_careful": 0.0,                                # the (normally empty) launch behind it
     }
     compulsory = (1.0 * m * m + 16.0 * m * m) * px16
 
@@ -577,7 +659,10 @@ def c5_config(im, torch, gen):
                 "achieved": round(2.0 * executed / sec / 1e12, 1),
                 "frac": round(2.0 * executed / sec / 1e12 / I8_MFMA_PEAK_TOPS, 4),
                 "algorithmic": round(2.0 * macs / sec / 1e12, 1),
-                "note": "achieved = the i8 multiply-adds the banded form executes (four byte planes of alpha*p, 31 "
+                "useful_frac": round(2.0 * macs / sec / 1e12 / I8_MFMA_PEAK_TOPS, 4),
+                "executed_frac": round(2.0 * executed / sec / 1e12 / I8_MFMA_PEAK_TOPS, 4),
+                "note": "`frac` / `executed_frac` count EXECUTED work, `useful_frac` the algorithmic multiply-adds: "
+                        "achieved = the i8 multiply-adds the banded form executes (four byte planes of alpha*p, 31 "
                         "kernel rows, two 32-slot chunks per 32 outputs: 22x the 709 algorithmic ones per sample, "
                         "which `algorithmic` counts) against the nominal dense i8 peak (bare instructions issue at 4200 TOP/s, "
                         "tools/ubench/mfma_i8_shapes.hip)"}}
@@ -702,11 +787,87 @@ def extra_measurements(im, torch, args, image):
         torch.cuda.empty_cache()
         configs.update(c5_config(im, torch, gen))
         torch.cuda.empty_cache()
+        torch.cuda.empty_cache()
+        configs["c1_blur_1024_sigma2"] = c1_config(im, torch, gen)
         result["configs"] = configs
+        result["inputs"] = input_variants(im, torch, gen, args.sigma)
+        torch.cuda.empty_cache()
+        im.set_precision(im.PRECISION_FAST if args.precision == "fast" else im.PRECISION_EXACT)
     except Exception as exc:
         extra["error"] = "%s: %s" % (type(exc).__name__, exc)
     result["extra"] = extra
+    if extra.get("device_copy_GBps"):
+        add_measured_ceiling(result, extra["device_copy_GBps"])
     return result
+
+
+def c1_config(im, torch, gen):
+    """C1 (BASELINE configs[0]): 1024^2 RGBA Q16 BlurImage(0x2) — the reference's own CPU-runnable case:
+    GPU ms per call in both modes here; the reference's OpenMP time is filled in by the CPU leg."""
+    img = im.Image(random_q16(torch, gen, 1024, 1024))
+    out = {"workload": "1024x1024 RGBA Q16 BlurImage(0x2) (BASELINE configs[0])"}
+    try:
+        for name, precision in (("fast", im.PRECISION_FAST), ("exact", im.PRECISION_EXACT)):
+            im.set_precision(precision)
+            sec = timed(torch, lambda: im.blur_image(img, 0.0, 2.0), 50)
+            out["ms_" + name] = round(sec * 1e3, 4)
+            out["Mpixels_per_s_" + name] = round(1024.0 * 1024.0 / sec / 1e6, 1)
+    finally:
+        im.set_precision(im.PRECISION_FAST if PRECISION_IS_FAST[0] else im.PRECISION_EXACT)
+    return out
+
+
+def input_variants(im, torch, gen, sigma):
+    """SURVEY 8(d)'s other input distributions: the BASELINE-size blur and one C4 image on an opaque frame
+    (alpha = QuantumRange everywhere: what most real images are) and on a smooth gradient with low noise
+    (the worst case for LDS-atomic contention in the histogram), next to the uniform-random headline."""
+    n, k = 8192, 4096
+
+    def frame(kind, edge):
+        px = random_q16(torch, gen, edge, edge)
+        if kind == "opaque":
+            px[:, :, 3] = 65535
+        elif kind == "smooth":
+            y = torch.arange(edge, device="cuda", dtype=torch.float32).view(edge, 1, 1)
+            x = torch.arange(edge, device="cuda", dtype=torch.float32).view(1, edge, 1)
+            scale = torch.tensor([0.6, 0.7, 0.8, 0.9], device="cuda").view(1, 1, 4)
+            noise = torch.randint(0, 400, (edge, edge, 4), generator=gen, device="cuda").to(torch.float32)
+            value = ((x * (40000.0 / (edge - 1)) + y * (20000.0 / (edge - 1))) * scale + noise).clamp_(0, 65535)
+            px = value.to(torch.int32).to(torch.int16).view(torch.uint16)      # (wraps: the low 16 bits)
+            del value, noise
+        return px
+    out = {}
+    try:
+        for kind in ("opaque", "smooth"):
+            img = im.Image(frame(kind, n))
+            entry = {}
+            for name, precision in (("fast", im.PRECISION_FAST), ("exact", im.PRECISION_EXACT)):
+                im.set_precision(precision)
+                sec = timed(torch, lambda: im.blur_image(img, 0.0, sigma), 10)
+                entry["blur_ms_" + name] = round(sec * 1e3, 4)
+                entry["blur_Mpixels_per_s_" + name] = round(float(n) * n / sec / 1e6, 1)
+            del img
+            torch.cuda.empty_cache()
+            im.set_precision(im.PRECISION_FAST)
+            fresh = [frame(kind, k) for _ in range(6)]
+            turn = {"i": 0}
+
+            def c4():
+                img4 = im.Image(fresh[turn["i"] % len(fresh)])
+                turn["i"] += 1
+                im.transform_colorspace_contrast_stretch_image(img4, "Lab", 0.02 * k * k, k * k - 0.01 * k * k)
+            sec = timed(torch, c4, 4)
+            prof = kernel_profile(im, c4, 2)
+            entry["c4_ms"] = round(sec * 1e3, 4)
+            entry["c4_kernels_ms"] = {name: round(v["avg_ms"], 4) for name, v in prof.items()}
+            del fresh
+            torch.cuda.empty_cache()
+            out[kind] = entry
+        out["note"] = ("8192^2 RGBA Q16 BlurImage(0x%g) per mode and one 4096^2 sRGB->Lab + ContrastStretch chain (FAST); "
+                       "the headline's frame is uniform random in every channel" % sigma)
+    finally:
+        im.set_precision(im.PRECISION_FAST if PRECISION_IS_FAST[0] else im.PRECISION_EXACT)
+    return out
 
 
 def shim_measurements(n, sigma, host):
@@ -1085,6 +1246,14 @@ def main():
                         roof["traffic"] = live
                 else:
                     roof["traffic_source"] = "profiles/pmc_traffic.json"
+                if dominant.startswith("blur_fused") and n == 8192:
+                    issue = issue_roofline(args.precision, conv[dominant]["avg_ms"])
+                    if issue:
+                        # achieved / peak / frac stay the HBM figures the metric asks for; what BOUNDS the
+                        # kernel is instruction issue (its HBM traffic is 1.03x the compulsory bytes)
+                        roof["bound"] = "issue"
+                        roof["hbm_frac"] = roof["frac"]
+                        roof["compute_roofline"] = issue
                 result["roofline"] = roof
             if not args.no_extra and world == 1:
                 result.update(extra_measurements(im, torch, args, image))
@@ -1099,9 +1268,17 @@ def main():
                 result["value_components"] = components
                 if "modes" in result and "exact" in result["modes"]:
                     result["value_exact"] = result["modes"]["exact"]["Mpixels_per_s"]
+            result["default_mode"] = ("fast: what an unchanged MagickCore caller gets since round 5 (the library's default; "
+                                      "MAGICK_HIP_PRECISION=exact selects the bit-identical mode, `value_exact`)")
             if world == 1 and not args.no_cpu_baseline:
                 try:
-                    result["cpu_baseline"] = cpu_baseline_blur(args.sigma)
+                    result["cpu_baseline"] = cpu_baseline_blur(args.sigma, im=im, torch=torch)
+                    shares = result["cpu_baseline"].pop("identical_share", None) if result["cpu_baseline"] else None
+                    if shares:
+                        result["identical_share"] = shares
+                        for name, share in shares.items():
+                            if name in result.get("modes", {}):
+                                result["modes"][name]["identical_share"] = share
                     if not args.no_extra:
                         for name, entry in cpu_baseline_configs().items():
                             if name == "c3_resize" and "resize" in result:

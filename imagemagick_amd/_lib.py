@@ -165,6 +165,7 @@ PROTOTYPES = [
     ("MhHostAlloc", ctypes.c_void_p, [ctypes.c_size_t]),
     ("MhHostFree", ctypes.c_int, [ctypes.c_void_p]),
     ("MhHostAllocatedBytes", ctypes.c_size_t, []),
+    ("MhHostPinnedBytes", ctypes.c_size_t, []),
     ("MhAcquireKernelInfo", _P(MhKernelInfo), [ctypes.c_char_p]),
     ("MhDestroyKernelInfo", _P(MhKernelInfo), [_P(MhKernelInfo)]),
     ("MhCloneKernelInfo", _P(MhKernelInfo), [_P(MhKernelInfo)]),

@@ -40,6 +40,13 @@ struct BlurExactArgs
   float gain;                // UnsharpMaskImage's epilogue
   int threshold;             // ceil(QuantumRange*threshold), see unsharp_sample
   unsigned long long *recomputed;   // optional device counter of recomputed samples (diagnostics)
+  // optional device word.  A frame whose alpha is a few levels everywhere widens the certificate's
+  // window (it grows with 1/alpha) until several samples of every group go down the
+  // reference-order recomputation, 79 dependent taps on one lane each: 22 ms per 8192^2 frame
+  // instead of 0.9.  A wave that has recomputed more than a sample per group on average raises
+  // the word, every workgroup leaves at its next group, and the fp64 passes queued behind the
+  // kernel (Conv1DParams::only_if) compute the frame: bit-identical too, 2.2 ms.
+  unsigned *give_up;
   unsigned long long *trace;        // diagnostic build (-DMH_EXACT_TRACE) only
 };
 

@@ -347,6 +347,7 @@ struct Conv1DArgs
   // unsharp_src = the unblurred frame, or NULL
   const void *unsharp_src;
   double unsharp_gain,unsharp_threshold;
+  const unsigned *only_if;   // nullptr, or: every workgroup leaves at once when the word is zero
 };
 
 // blurred sample -> unsharp-masked sample, as unsharp_kernel (pointwise.hip) does in its own pass
@@ -387,6 +388,8 @@ template<typename Q,int C,bool BLEND,class A,int R,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_column_kernel(Conv1DArgs args)
 {
+  if ((args.only_if != nullptr) && (*args.only_if == 0u))
+    return;
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
   const int lane=(int) (threadIdx.x & 63);
@@ -510,6 +513,8 @@ template<typename Q,int C,bool BLEND,class A,int R,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_row_kernel(Conv1DArgs args)
 {
+  if ((args.only_if != nullptr) && (*args.only_if == 0u))
+    return;
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -671,6 +676,8 @@ template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_column_blocked(Conv1DArgs args)
 {
+  if ((args.only_if != nullptr) && (*args.only_if == 0u))
+    return;
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -797,6 +804,8 @@ template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_row_blocked(Conv1DArgs args)
 {
+  if ((args.only_if != nullptr) && (*args.only_if == 0u))
+    return;
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
   static_assert((R%U) == 0,"a block of U samples must not straddle an LDS padding slot");
@@ -953,6 +962,7 @@ static MhStatus launch_blocked(const View &src,const View &dst,bool vertical,
   args.changed=changed;
   args.nblocks=nblocks;
   args.wave_bytes=0;
+  args.only_if=p.only_if;
   const int W=args.columns,H=args.rows;
   if (vertical)
     {
@@ -1136,6 +1146,8 @@ template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_column_tri(Conv1DArgs args)
 {
+  if ((args.only_if != nullptr) && (*args.only_if == 0u))
+    return;
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1244,6 +1256,8 @@ template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_column_lds(Conv1DArgs args)
 {
+  if ((args.only_if != nullptr) && (*args.only_if == 0u))
+    return;
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1349,6 +1363,8 @@ template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_row_tri(Conv1DArgs args)
 {
+  if ((args.only_if != nullptr) && (*args.only_if == 0u))
+    return;
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1534,6 +1550,7 @@ static MhStatus launch_tri_waves(const View &src,const View &dst,bool vertical,
   args.changed=changed;
   args.nblocks=0;
   args.wave_bytes=0;
+  args.only_if=p.only_if;
   if (vertical)
     {
       args.unsharp_src=p.unsharp_source;
@@ -2158,6 +2175,7 @@ static MhStatus launch_one(const View &src,const View &dst,bool vertical,
   args.changed=changed;
   args.nblocks=0;
   args.wave_bytes=0;
+  args.only_if=p.only_if;
 
   const int W=args.columns,H=args.rows;
   if (vertical)

@@ -424,8 +424,16 @@ void blur_fused_exact_kernel(BlurExactArgs args)
       }
   };
   fetch(0);
+  __shared__ unsigned stop_word;
+  if (tid == 0)
+    stop_word=0u;
   for (int g=0; g <= ngroups+1; g++)
     {
+      // BlurExactArgs::give_up: one lane looks at the word, the whole workgroup sees its copy behind
+      // barrier X and leaves behind barrier Y
+      unsigned seen_word=0u;
+      if ((args.give_up != nullptr) && (tid == 0))
+        seen_word=__hip_atomic_load(args.give_up,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
       const int cb=g-G::NG-1;                    // the column pass's block of this iteration
       const int first=ring_group;                // ring slot of group cb: (g-NG-1) mod NR = g mod NR
       const int previous=ring_group == 0 ? G::NR-1 : ring_group-1;   // ring slot of group g-1
@@ -650,6 +658,8 @@ void blur_fused_exact_kernel(BlurExactArgs args)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
       MH_XTRACE_MARK(4);
+      if ((args.give_up != nullptr) && (tid == 0))
+        stop_word=seen_word;
       __syncthreads();                           // X: group g staged, ring group g-1 complete
       MH_XTRACE_MARK(5);
       // ======================================================================== interval B
@@ -735,8 +745,17 @@ void blur_fused_exact_kernel(BlurExactArgs args)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
       MH_XTRACE_MARK(6);
+      bool stop=false;
+      if (args.give_up != nullptr)
+        {
+          stop=stop_word != 0u;                  // (written before barrier X, rewritten after barrier Y)
+          if ((recomputed > 32u+(unsigned) g) && (lane == 0))
+            __hip_atomic_store(args.give_up,1u,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+        }
       __syncthreads();                           // Y: out_tile complete, staging and ring reads done
       MH_XTRACE_MARK(7);
+      if (stop)
+        return;                                  // the passes behind this kernel write the frame
       ring_group=ring_group+1 == G::NR ? 0 : ring_group+1;
     }
   if constexpr (COLX)
@@ -834,7 +853,7 @@ static MhStatus launch_exact_modes(const View &src,BlurExactArgs &args,bool blen
 // *handled = false: the shape or the taps are outside the kernel's reach, nothing was launched.
 MhStatus launch_blur_fused_exact(const View &src,const View &dst,const double *taps,int ntaps,int shift,
   bool blend,bool exact_column,bool *handled,bool unsharp,double gain,double threshold,
-  unsigned long long *recomputed_device)
+  unsigned long long *recomputed_device,unsigned *give_up)
 {
   *handled=false;
   if ((src.quantum != MH_QUANTUM_U16) || (dst.quantum != MH_QUANTUM_U16) ||
@@ -872,6 +891,7 @@ MhStatus launch_blur_fused_exact(const View &src,const View &dst,const double *t
     args.threshold=level > 131072.0 ? 131072 : (level < 0.0 ? 0 : (int) level);
   }
   args.recomputed=recomputed_device;
+  args.give_up=give_up;
   args.trace=nullptr;
   if ((args.recomputed == nullptr) && g_count_recomputed && (src.device >= 0) && (src.device < 64))
     args.recomputed=g_recomputed[src.device];

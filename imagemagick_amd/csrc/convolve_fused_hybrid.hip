@@ -736,6 +736,7 @@ MhStatus launch_blur_fused_hybrid(const View &src,const View &dst,const double *
   args.gain=0.0f;
   args.threshold=(int) option_long("MAGICKHIP_HYBRID_KNOCK",0);       // diagnostic builds only (MH_HKNOCKED)
   args.recomputed=exact_recomputed_counter(src.device);
+  args.give_up=nullptr;
   args.trace=nullptr;
   *handled=true;
   const int nc=(ntaps+15+31)/32;                 // 16 outputs + K-1 halo, in 32-sample chunks

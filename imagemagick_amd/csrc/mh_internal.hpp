@@ -217,6 +217,9 @@ struct Conv1DParams
   // ceil-free threshold (QuantumRange*threshold), applied as the column pass stores its results
   const void *unsharp_source=nullptr;
   double unsharp_gain=0.0,unsharp_threshold=0.0;
+  // a device word: the pass's kernels leave at once when it is zero (the fp64 passes queued behind
+  // the exact-integer BlurImage kernel, which raises the word when it gives a frame up)
+  const unsigned *only_if=nullptr;
 };
 // The column pass of a blur with UnsharpMaskImage's epilogue applied on the way out (the fp64
 // triangular kernels: float Quantum, and Q16 in EXACT mode).  *handled = false: not this case,
@@ -273,7 +276,7 @@ constexpr int kExactDigits=5;            // balanced signed 8-bit digits of a fi
 constexpr int kExactDigitPitch=96;       // digits of one weight, padded (K <= 81)
 MhStatus launch_blur_fused_exact(const View &src,const View &dst,const double *taps,int ntaps,int shift,
   bool blend,bool exact_column,bool *handled,bool unsharp=false,double gain=0.0,double threshold=0.0,
-  unsigned long long *recomputed_device=nullptr);
+  unsigned long long *recomputed_device=nullptr,unsigned *give_up=nullptr);
 // FAST BlurImage in one launch: f16 colour sums in both passes, the row pass's alpha as exact integer
 // sums (convolve_fused_hybrid.hip); within +-1 level by construction.  taps as above.
 MhStatus launch_blur_fused_hybrid(const View &src,const View &dst,const double *taps,int ntaps,int shift,

@@ -542,8 +542,35 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
             return MH_OK;
         }
       const bool exact_column=exact || (unsharp && (option("MAGICKHIP_FAST_UNSHARP") == nullptr));
+      // EXACT BlurImage of an alpha-weighted frame: the kernel may give the frame up (alpha of a few
+      // levels everywhere: BlurExactArgs::give_up); the two fp64 passes queued behind it — bit-identical
+      // too — then compute it, and leave at once otherwise.  MAGICKHIP_NO_GIVE_UP=1: never.
+      Temp give_up,rows_memory;
+      const bool guarded=exact && !unsharp && roles.blend && (option("MAGICKHIP_NO_GIVE_UP") == nullptr);
+      if (guarded)
+        {
+          MH_TRY(give_up.alloc(src.device,sizeof(unsigned),src.stream));
+          MH_HIP(hipMemsetAsync(give_up.ptr,0,sizeof(unsigned),src.stream));
+        }
       MH_TRY(launch_blur_fused_exact(src,dst,reversed.data(),K,K-1-(int) row->x,roles.blend,exact_column,handled,
-        unsharp,gain,threshold,nullptr));
+        unsharp,gain,threshold,nullptr,guarded ? give_up.as<unsigned>() : nullptr));
+      if (*handled && guarded)
+        {
+          View rows=src;
+          MH_TRY(rows_memory.alloc(src.device,rows.bytes(),src.stream));
+          rows.pixels=rows_memory.ptr;
+          Conv1DParams first,second;
+          first.taps=row->values;
+          first.ntaps=K;
+          first.origin=(int) row->x;
+          first.only_if=give_up.as<unsigned>();
+          second.taps=column->values;
+          second.ntaps=K;
+          second.origin=(int) column->y;
+          second.only_if=give_up.as<unsigned>();
+          MH_TRY(launch_conv1d(src,rows,false,first,roles,MH_PRECISION_EXACT,nullptr));
+          MH_TRY(launch_conv1d(rows,dst,true,second,roles,MH_PRECISION_EXACT,nullptr));
+        }
       if (*handled)
         return MH_OK;
     }

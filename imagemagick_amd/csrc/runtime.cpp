@@ -65,7 +65,7 @@ struct Runtime
   int ndevices=0;
   int default_device=0;
   int enabled=1;
-  MhPrecision precision=MH_PRECISION_EXACT;
+  MhPrecision precision=MH_PRECISION_FAST;     // the drop-in's default (MAGICK_HIP_PRECISION=exact: bit-identical)
   std::vector<DeviceState> devices;
   std::mutex lock;
   // profiling
@@ -156,6 +156,8 @@ static void do_init()
   env=lookup_option("MAGICK_HIP_PRECISION");
   if ((env != nullptr) && (strcasecmp(env,"fast") == 0))
     r.precision=MH_PRECISION_FAST;
+  if ((env != nullptr) && (strcasecmp(env,"exact") == 0))
+    r.precision=MH_PRECISION_EXACT;
   int n=0;
   hipError_t err=hipGetDeviceCount(&n);
   if ((err != hipSuccess) || (n <= 0))
@@ -645,6 +647,9 @@ MhStatus validate_image(const MhImage *image,const char *what)
     return fail(MH_BAD_ARGUMENT,"%s: alpha offset out of range",what);
   if ((image->columns > 0x7fffffffu) || (image->rows > 0x7fffffffu))
     return fail(MH_UNSUPPORTED,"%s: geometry exceeds 2^31",what);
+  if (image->precision > MH_IMAGE_PRECISION(MH_PRECISION_FAST))
+    return fail(MH_BAD_ARGUMENT,"%s: MhImage::precision %u (0, or MH_IMAGE_PRECISION of a mode: fill the descriptor with MhInitImage)",
+      what,image->precision);
   return MH_OK;
 }
 
@@ -1127,6 +1132,13 @@ MH_API int MhHostFree(void *block)
 }
 
 MH_API size_t MhHostAllocatedBytes(void)
+{
+  PinnedBlocks &p=pinned_blocks();
+  std::lock_guard<std::mutex> guard(p.lock);
+  return p.total;
+}
+
+MH_API size_t MhHostPinnedBytes(void)
 {
   PinnedBlocks &p=pinned_blocks();
   std::lock_guard<std::mutex> guard(p.lock);

@@ -202,7 +202,10 @@ typedef enum
   MH_PRECISION_EXACT = 0,  /* FP64, the CPU's operation order, no FMA contraction: bit-identical results */
   MH_PRECISION_FAST = 1    /* FP32 FMA accumulation where the result is still within +-1 Quantum level (Q16 only) */
 } MhPrecision;
-/* The library-wide DEFAULT (also MAGICK_HIP_PRECISION=fast at start-up).  A call whose first image
+/* The library-wide DEFAULT: MH_PRECISION_FAST — what an unchanged MagickCore caller gets through the
+   shim, within the +-1 level / +-1 ULP the drop-in promises (the reference's own OpenCL path computes
+   in float and is not bit-identical to its CPU path either); MAGICK_HIP_PRECISION=exact at start-up
+   or MhSetPrecision(MH_PRECISION_EXACT) selects the bit-identical mode.  A call whose first image
    carries a non-zero MhImage::precision runs with that precision instead: two threads can run
    EXACT and FAST operators at the same time. */
 MH_API MhPrecision MhGetPrecision(void);
@@ -265,6 +268,9 @@ MH_API MhStatus MhSynchronize(int device,void *stream);
 MH_API void *MhHostAlloc(size_t bytes);
 MH_API int MhHostFree(void *block);
 MH_API size_t MhHostAllocatedBytes(void);
+/* ... plus the released blocks the library keeps page-locked for reuse (MAGICKHIP_PINNED_SPARE_BYTES,
+   1 GiB by default): what a budget on page-locked memory has to count */
+MH_API size_t MhHostPinnedBytes(void);
 
 /* Kernel profile records (GetOpenCLKernelProfileRecords analogue). */
 typedef struct MhKernelProfileRecord

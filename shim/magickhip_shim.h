@@ -30,6 +30,7 @@ typedef struct _HipLibrary
   void *(*HostAlloc)(size_t);
   int (*HostFree)(void *);
   size_t (*HostAllocatedBytes)(void);
+  size_t (*HostPinnedBytes)(void);     /* + the spare blocks the library keeps page-locked */
   MhStatus (*BlurImage)(const MhImage *,MhImage *,double,double);
   MhStatus (*UnsharpMaskImage)(const MhImage *,MhImage *,double,double,double,double);
   MhStatus (*ResizeImageWithFilter)(const MhImage *,MhImage *,const MhResizeFilter *);

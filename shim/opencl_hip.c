@@ -160,6 +160,7 @@ static void LoadHipLibrary(void)
   MH_RESOLVE(HostAlloc,"MhHostAlloc");
   MH_RESOLVE(HostFree,"MhHostFree");
   MH_RESOLVE(HostAllocatedBytes,"MhHostAllocatedBytes");
+  MH_RESOLVE(HostPinnedBytes,"MhHostPinnedBytes");
   MH_RESOLVE(BlurImage,"MagickHipBlurImage");
   MH_RESOLVE(UnsharpMaskImage,"MagickHipUnsharpMaskImage");
   MH_RESOLVE(ResizeImageWithFilter,"MagickHipResizeImageWithFilter");
@@ -525,7 +526,7 @@ static void *AcquireHipAlignedMemory(const size_t size,const size_t alignment)
   */
   if ((size >= HipPinnedCacheExtent) && (hip_enabled != MagickFalse) &&
       (__atomic_load_n(&hip_library_state,__ATOMIC_ACQUIRE) > 0) &&
-      (hip_library.HostAllocatedBytes()+size <= hip_pinned_budget))
+      (hip_library.HostPinnedBytes()+size <= hip_pinned_budget))
     {
       memory=hip_library.HostAlloc(size);
       if (memory != NULL)

@@ -63,6 +63,40 @@ def test_c2_blur_exact_full_size(im, c2_case):
     _compare_q16(got, want, True, "C2 BlurImage EXACT")
 
 
+def test_c2_blur_exact_tiny_alpha_frame_is_given_up_to_the_fp64_passes(im, refmod):
+    """EXACT BlurImage on an 8192^2 frame whose alpha is 0..3 levels EVERYWHERE: the certificate of the
+    exact-integer kernel cannot decide one sample in twelve there and their reference-order recomputation
+    cost 22 ms (round 4).  The kernel now gives such a frame up after a few groups and the two fp64 passes
+    queued behind it compute it: bit-identical (reference bands: top rows, left columns), <= 3 ms."""
+    import bench
+    import torch
+    n, band = 8192, 400
+    rng = np.random.default_rng(77)
+    px = rng.integers(0, 65536, (n, n, 4), dtype=np.uint16)
+    px[:, :, 3] = rng.integers(0, 4, (n, n))
+    refmod.set_thread_limit(os.cpu_count() or 1)
+    want_top = refmod.RefImage(px[:band]).blur(0.0, 10.0).numpy()
+    want_left = refmod.RefImage(np.ascontiguousarray(px[:, :band])).blur(0.0, 10.0).numpy()
+    keep = band - 48                                  # 39 rows / columns of the window + margin
+    dev = im.Image(to_device(px))
+    holder = {}
+    holder.update(out=im.blur_image(dev, 0.0, 10.0))          # (the kernels' code objects load on first use)
+    prof = bench.kernel_profile(im, lambda: holder.update(out=im.blur_image(dev, 0.0, 10.0)), 3)
+    total_ms = sum(v["avg_ms"] for v in prof.values())
+    got = holder["out"].pixels
+    _compare_q16(got[:keep], want_top[:keep], True, "tiny-alpha frame, top band")
+    _compare_q16(got[:, :keep].contiguous(), np.ascontiguousarray(want_left[:, :keep]), True, "tiny-alpha frame, left band")
+    assert "blur_fused_exact" in prof and any(k.startswith("conv_") for k in prof), prof
+    assert total_ms <= 3.0, prof
+    # an ordinary frame: the passes behind the kernel leave at once
+    ordinary = im.Image(to_device(rng.integers(0, 65536, (n, n, 4), dtype=np.uint16)))
+    prof = bench.kernel_profile(im, lambda: holder.update(out=im.blur_image(ordinary, 0.0, 10.0)), 3)
+    behind = sum(v["avg_ms"] for k, v in prof.items() if k.startswith("conv_"))
+    assert behind <= 0.12, prof
+    del holder, got
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("path", ["fused", "two_pass", "vector"])
 def test_c2_blur_fast_full_size(im, c2_case, path):
     """The mode bench.py times, on every path FAST can take: both passes in one launch

@@ -268,3 +268,20 @@ def test_lut_builders_reproduce_the_operators(im, vectors, hdri):
     assert np.array_equal(apply(lut, mask), vectors[tag + "_smooth_cstretch"])
     lut, mask = im.equalize_lut(hist, quantum)
     assert np.array_equal(apply(lut, mask), vectors[tag + "_smooth_equalize"])
+
+
+def test_default_precision_is_fast_and_the_environment_selects_exact():
+    """What an unchanged MagickCore caller gets is MH_PRECISION_FAST (within one level / one float ULP:
+    the drop-in's contract and bench.py's `value`); MAGICK_HIP_PRECISION=exact selects the bit-identical
+    mode.  A fresh process each: the library reads its environment once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import imagemagick_amd as im; im.load(); print('precision', im.get_precision())"
+    for value, want in ((None, 1), ("exact", 0), ("fast", 1)):
+        env = {k: v for k, v in os.environ.items() if k != "MAGICK_HIP_PRECISION"}
+        if value is not None:
+            env["MAGICK_HIP_PRECISION"] = value
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, stdout=subprocess.PIPE,
+                             stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert "precision %d" % want in out.stdout, (value, out.stdout[-2000:])
