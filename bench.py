@@ -42,7 +42,6 @@ MODE_DTYPE = {
             "column pass's weights) as u8 digit products on the i8 matrix cores: exact i32 sums, f64 rounding",
     "exact": "u8 digit products on the i8 matrix cores, exact i32 sums, f64 epilogue; the few pixels the "
              "error bound cannot decide recomputed in the reference's f64 operation order",
-    "fast_f16_legacy": "f16x2 products, f32 accumulate in both passes (round 2's kernel, MAGICKHIP_NO_EXACT_MFMA=1)",
     "hdri": "f64 in the CPU's operation order, float Quantum",
 }
 MODE_TOLERANCE = {
@@ -50,8 +49,6 @@ MODE_TOLERANCE = {
             "alpha is the reference's level bit for bit, the intermediate colour is NOT rounded (the reference's "
             "rounding moves the value the column pass rounds by at most 0.5 level), the f16 sums add < 0.1",
     "exact": "bit-identical to the reference CPU path",
-    "fast_f16_legacy": "out of contract, reported for comparison only: each pass within +-1, the two-pass result "
-                       "+-1 on the full-size frame but up to +-2 on inputs whose intermediate sits on rounding ties",
     "hdri": "bit-identical to the reference CPU path (float Quantum)",
 }
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
@@ -385,27 +382,21 @@ def random_q16(torch, gen, rows, cols):
 
 def blur_mode(im, torch, image, sigma, mode, reps=24, ramp=0.3):
     """One precision mode of the blur as a first-class object: rate + roofline of its dominant
-    kernel.  mode: fast | exact | fast_f16_legacy (round 2's f16 row pass) | hdri (float Quantum
-    frame, EXACT).  Same clock ramp as the headline and >= 20 timed calls."""
+    kernel.  mode: fast | exact | hdri (float Quantum frame, EXACT).  Same clock ramp as the headline and >= 20 timed calls."""
     pixels = float(image.rows) * image.columns
     im.set_precision(im.PRECISION_EXACT if mode in ("exact", "hdri") else im.PRECISION_FAST)
-    if mode == "fast_f16_legacy":
-        im.set_option("MAGICKHIP_NO_EXACT_MFMA", "1")      # (the library reads the environment only at start-up)
     holder = {}
-    try:
-        def call():
-            holder["o"] = im.blur_image(image, 0.0, sigma)
+
+    def call():
+        holder["o"] = im.blur_image(image, 0.0, sigma)
+    call()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < ramp:
         call()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        while time.perf_counter() - t0 < ramp:
-            call()
-            torch.cuda.synchronize()
-        sec = timed(torch, call, reps)
-        prof = kernel_profile(im, call, max(2, reps // 2))
-    finally:
-        if mode == "fast_f16_legacy":
-            im.set_option("MAGICKHIP_NO_EXACT_MFMA", os.environ.get("MAGICKHIP_NO_EXACT_MFMA"))
+    sec = timed(torch, call, reps)
+    prof = kernel_profile(im, call, max(2, reps // 2))
     conv = {k: v for k, v in prof.items() if k.startswith("conv_") or k.startswith("blur_fused")}
     dominant = max(conv, key=lambda k: conv[k]["avg_ms"])
     frame = pixels * (16.0 if mode == "hdri" else 8.0)
@@ -474,7 +465,6 @@ def resize_config(im, torch, gen):
     bytes_by_kernel = {
         "resize_vertical": (1.0 * m * m + 4.0 * m * m) * px16,       # 8192^2 in, 8192x32768 out
         "resize_horizontal": (4.0 * m * m + 16.0 * m * m) * px16,    # 8192x32768 in, 32768^2 out
-        "resize_fused": (1.0 * m * m + 16.0 * m * m) * px16,
         "resize_mfma": (1.0 * m * m + 16.0 * m * m) * px16,          # one launch: 8192^2 in, 32768^2 out
         "resize_stream": (1.0 * m * m + 16.0 * m * m) * px16,        # one launch on the vector pipe (FAST default)
         "resize_stream_careful": 0.0,                                # the (normally empty) launch behind it
@@ -692,7 +682,7 @@ def extra_measurements(im, torch, args, image):
     gen = torch.Generator(device="cuda").manual_seed(1)
     n = image.rows
     try:
-        result["modes"] = {p: blur_mode(im, torch, image, args.sigma, p) for p in ("fast", "exact", "fast_f16_legacy")}
+        result["modes"] = {p: blur_mode(im, torch, image, args.sigma, p) for p in ("fast", "exact")}
         # float Quantum (the reference's configure default, HDRI): the same 8192^2 RGBA frame as floats
         hdri_pixels = image.pixels.view(torch.int16).to(torch.float32)
         hdri_pixels = torch.where(hdri_pixels < 0, hdri_pixels + 65536.0, hdri_pixels)
@@ -1073,8 +1063,6 @@ def config_dtype(args):
     if args.config == "c2":
         if os.environ.get("MAGICKHIP_NO_MFMA"):
             return "f64" if args.precision == "exact" else "f32"
-        if os.environ.get("MAGICKHIP_NO_EXACT_MFMA"):
-            return "f64" if args.precision == "exact" else MODE_DTYPE["fast_f16_legacy"]
         return MODE_DTYPE[args.precision]
     if args.config == "c4":
         return ("f32 colour transform (v_log/v_exp), u16 histogram counters, f64 map" if args.precision == "fast"
@@ -1086,8 +1074,6 @@ def config_dtype(args):
 
 def config_tolerance(args):
     if args.config == "c2":
-        if os.environ.get("MAGICKHIP_NO_EXACT_MFMA") and args.precision == "fast":
-            return MODE_TOLERANCE["fast_f16_legacy"]
         return MODE_TOLERANCE[args.precision]
     if args.config == "c4":
         return ("sRGB->Lab within +-1 level of the reference, ContrastStretch of those levels bit-identical"

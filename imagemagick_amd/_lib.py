@@ -166,6 +166,7 @@ PROTOTYPES = [
     ("MhHostFree", ctypes.c_int, [ctypes.c_void_p]),
     ("MhHostAllocatedBytes", ctypes.c_size_t, []),
     ("MhHostPinnedBytes", ctypes.c_size_t, []),
+    ("MhBandedBands", ctypes.c_ulonglong, [ctypes.c_int]),
     ("MhAcquireKernelInfo", _P(MhKernelInfo), [ctypes.c_char_p]),
     ("MhDestroyKernelInfo", _P(MhKernelInfo), [_P(MhKernelInfo)]),
     ("MhCloneKernelInfo", _P(MhKernelInfo), [_P(MhKernelInfo)]),

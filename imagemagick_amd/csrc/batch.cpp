@@ -486,6 +486,9 @@ static MhStatus all_reduce_tables(std::vector<TableView> &bands,size_t count,boo
   return MH_OK;
 }
 
+// bands a logical device has finished (MhBandedBands: tests, bench)
+static std::atomic<unsigned long long> g_banded_bands[16];
+
 // ---------------------------------------------------------------- one host image, pipelined
 // A new-image stencil operator on HOST memory (the pixel cache): upload, kernels and download of
 // the whole frame in sequence leave the copy engines idle two thirds of the time (8192^2 RGBA
@@ -532,15 +535,26 @@ MhStatus host_banded_operator(const MhOperator &op,const MhKernelInfo *kernel,co
   int workers=4;
   if (const char *e=option("MAGICKHIP_BANDED_WORKERS"))
     workers=atoi(e) < 1 ? 1 : (atoi(e) > 16 ? 16 : atoi(e));
-  const int device=resolve_device(image);
+  // MhImage::device = MH_DEVICE_ALL: the bands go round the (logical) devices of the node, `workers`
+  // threads per device — one big pixel cache moves over every GPU's host link instead of one
+  // (the reference hands an operator one device, opencl.c:3056-3102: 2.1 GB up and down for a
+  // 16384^2 frame against 2 ms of kernel)
+  const bool spread=image->device == MH_DEVICE_ALL;
+  const int devices=spread ? logical_devices(0) : 1;
+  const int physical=device_count();
+  const int first_device=spread ? 0 : resolve_device(image);
+  workers*=devices;
+  workers=workers > 64 ? 64 : workers;
   std::atomic<size_t> next{0};
   std::mutex error_lock;
   MhStatus first_status=MH_OK;
   std::string first_error;
   auto work=[&](int w)
   {
+    const int logical=w % devices;
+    const int device=spread ? logical % physical : first_device;
     DeviceGuard guard;
-    hipStream_t stream=batch_stream(device,32+w);
+    hipStream_t stream=batch_stream(device,32+(spread ? w/devices+8*(logical/physical) : w));
     MhStatus setup=MH_OK;
     if ((guard.enter(device) != hipSuccess) || (stream == nullptr))
       setup=fail(MH_DEVICE_ERROR,"banded operator: cannot set up device %d",device);
@@ -567,6 +581,8 @@ MhStatus host_banded_operator(const MhOperator &op,const MhKernelInfo *kernel,co
             else
               (void) hipStreamSynchronize(stream);
             cur.release();
+            if (status == MH_OK)
+              g_banded_bands[logical & 15].fetch_add(1,std::memory_order_relaxed);
           }
         if (status != MH_OK)
           {
@@ -596,6 +612,13 @@ MhStatus host_banded_operator(const MhOperator &op,const MhKernelInfo *kernel,co
 using namespace mh;
 
 extern "C" {
+
+MH_API unsigned long long MhBandedBands(int logical_device)
+{
+  if ((logical_device < 0) || (logical_device >= 16))
+    return 0;
+  return g_banded_bands[logical_device].load(std::memory_order_relaxed);
+}
 
 MH_API MhStatus MagickHipBatchImages(const MhOperator *operators,size_t number_operators,
   const MhImage *images,MhImage *results,size_t number_images,int number_devices,

@@ -498,7 +498,16 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
   // (switches for tests and A/B runs, from the option table: the environment at start-up + MhSetOption)
   const bool no_mfma=option("MAGICKHIP_NO_MFMA") != nullptr;
   const bool no_fused=option("MAGICKHIP_NO_FUSED_BLUR") != nullptr;
+  // (round 2's all-f16 form of the RGBA blur — +-2 on structured ties, out of contract — and round
+  // 3's exact-row + f16-column form are superseded by convolve_fused_hybrid.hip; their switches
+  // exist in diagnostic builds only: make VDEFS=-DMH_DIAGNOSTIC)
+#ifdef MH_DIAGNOSTIC
   const bool no_exact_mfma=option("MAGICKHIP_NO_EXACT_MFMA") != nullptr;
+  const bool no_hybrid=option("MAGICKHIP_NO_HYBRID") != nullptr;
+  const bool fast_unsharp=option("MAGICKHIP_FAST_UNSHARP") != nullptr;
+#else
+  const bool no_exact_mfma=false,no_hybrid=false,fast_unsharp=false;
+#endif
   const bool fused_rgb=option("MAGICKHIP_FUSED_RGB") != nullptr;
   const bool exact=precision() == MH_PRECISION_EXACT;
   if ((src.quantum != MH_QUANTUM_U16) || ((src.channels != 4) && (src.channels != 3)) ||
@@ -535,13 +544,13 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
       // sharpened one by `gain` levels and flips the threshold test next to it — only the
       // reference's own blur keeps effect.c:4364-4369 within the +-1 contract (it is then
       // bit-identical).  MAGICKHIP_NO_HYBRID=1: the exact row pass + f16 column pass of round 3.
-      if (!exact && !unsharp && (option("MAGICKHIP_NO_HYBRID") == nullptr))
+      if (!exact && !unsharp && !no_hybrid)
         {
           MH_TRY(launch_blur_fused_hybrid(src,dst,reversed.data(),K,K-1-(int) row->x,roles.blend,handled));
           if (*handled)
             return MH_OK;
         }
-      const bool exact_column=exact || (unsharp && (option("MAGICKHIP_FAST_UNSHARP") == nullptr));
+      const bool exact_column=exact || (unsharp && !fast_unsharp);
       // EXACT BlurImage of an alpha-weighted frame: the kernel may give the frame up (alpha of a few
       // levels everywhere: BlurExactArgs::give_up); the two fp64 passes queued behind it — bit-identical
       // too — then compute it, and leave at once otherwise.  MAGICKHIP_NO_GIVE_UP=1: never.

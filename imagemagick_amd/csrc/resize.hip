@@ -385,642 +385,6 @@ void resize_horizontal_cvt_kernel(ResizeArgs args,int tile_rows,int lds_span)
     }
 }
 
-// ------------------------------------------------------------ fused V-then-H
-// ResizeImage runs VerticalFilter first when x_factor <= y_factor
-// (resize.c:3846-3861).  For enlargements the Quantum-typed intermediate
-// (columns x new rows) is 1/4..1/16 of the result but still costs a full HBM
-// write + read; this kernel keeps it in LDS.  A workgroup owns TW=256 output
-// columns x TH output rows:
-//   1. stage the source patch (row span of the TH rows x column span of the 256
-//      columns, both precomputed on the host) in LDS with coalesced loads;
-//   2. vertical pass into a second LDS tile, TH rows x column-span, one wave per
-//      output row (weights wave-uniform), results rounded to Quantum exactly as
-//      the reference's filter_image holds them;
-//   3. horizontal pass from that tile, lane = output column, weights in
-//      registers, fully coalesced 16-byte (float RGBA) stores.
-// Arithmetic per pass is ResizeAcc's, i.e. the CPU's order.
-struct FusedArgs
-{
-  ResizeArgs v,h;             // v: row tables (out_size = dst_rows), h: column tables
-  const int *row_lo,*row_span;// per row tile: first source row, number of source rows
-  int cstride;                // LDS row stride (pixels) of both tiles = widest column span
-  int rspan_max;              // tallest source row span of any row tile
-};
-
-template<typename Q,int C,bool BLEND,class A,int TH,int MAXT>
-__global__ __launch_bounds__(256)
-void resize_fused_kernel(FusedArgs a)
-{
-  typedef typename A::T T;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  // LDS: vertical weights of this row tile, then the source patch, then the
-  // Quantum-typed intermediate
-  T *vw=reinterpret_cast<T *>(smem_raw);                 // [MAXT][TH]
-  T *vwq=vw+MAXT*TH;                                     // [MAXT][TH]
-  int *vstart=reinterpret_cast<int *>(vwq+MAXT*TH);      // [TH]
-  int *vcount=vstart+TH;
-  int *vnear=vcount+TH;
-  const int cstride=a.cstride;
-  Q *src_tile=reinterpret_cast<Q *>(vnear+TH+(TH & 1));  // keeps 16-byte alignment (TH is even)
-  Q *mid_tile=src_tile+(size_t) a.rspan_max*cstride*C;
-  const int tid=(int) threadIdx.x;
-  const int X0=(int) blockIdx.x*256,Y0=(int) blockIdx.y*TH;
-  const int clo=a.h.tile_lo[blockIdx.x],cspan=a.h.tile_span[blockIdx.x];
-  const int rlo=a.row_lo[blockIdx.y],rspan=a.row_span[blockIdx.y];
-  int rows=a.h.dst_rows-Y0;
-  rows=rows < TH ? rows : TH;
-  const Q *src=static_cast<const Q *>(a.v.src);
-  Q *dst=static_cast<Q *>(a.h.dst);
-  const size_t src_pitch=(size_t) a.v.src_columns*C;
-  const size_t dst_pitch=(size_t) a.h.dst_columns*C;
-
-  // 0. this tile's vertical tables
-  if (tid < rows)
-    {
-      const int y=Y0+tid,OUTV=a.v.out_size;
-      const T *weight=static_cast<const T *>(a.v.weight);
-      const T *weight_qs=static_cast<const T *>(a.v.weight_qs);
-      const int cnt=a.v.count[y];
-      vstart[tid]=a.v.start[y]-rlo;
-      vcount[tid]=cnt;
-      vnear[tid]=cnt > 0 ? a.v.nearest[y]-rlo : 0;
-#pragma unroll
-      for (int j=0; j < MAXT; j++)
-        {
-          vw[j*TH+tid]=j < cnt ? weight[(size_t) j*OUTV+y] : (T) 0;
-          vwq[j*TH+tid]=(BLEND && (j < cnt)) ? weight_qs[(size_t) j*OUTV+y] : (T) 0;
-        }
-    }
-  // 1. source patch, all loads of a batch in flight before the first LDS store
-  {
-    constexpr int BATCH=6;
-    const int items=rspan*cspan;
-    for (int i0=tid; i0 < items; i0+=256*BATCH)
-      {
-        Q v[BATCH][C];
-        int slot[BATCH];
-#pragma unroll
-        for (int k=0; k < BATCH; k++)
-          {
-            int idx=i0+256*k;
-            idx=idx < items ? idx : items-1;
-            const int r=idx/cspan,i=idx-r*cspan;
-            slot[k]=r*cstride+i;
-            load_pixel<Q,C>(src+(size_t) (rlo+r)*src_pitch+(size_t) (clo+i)*C,v[k]);
-          }
-#pragma unroll
-        for (int k=0; k < BATCH; k++)
-          if (i0+256*k < items)
-            store_pixel<Q,C>(src_tile+(size_t) slot[k]*C,v[k]);
-      }
-  }
-  __syncthreads();
-
-  // 2. vertical pass over the (row, source column) items of the tile
-  {
-    const int items=rows*cspan;
-    for (int idx=tid; idx < items; idx+=256)
-      {
-        const int yy=idx/cspan,i=idx-yy*cspan;
-        const int start=vstart[yy],count=vcount[yy];
-        ResizeAcc<Q,C,BLEND,A> acc;
-        acc.init();
-#pragma unroll
-        for (int j=0; j < MAXT; j++)
-          if (j < count)
-            {
-              Q q[C];
-              load_pixel<Q,C>(src_tile+((size_t) (start+j)*cstride+i)*C,q);
-              acc.tap(vw[j*TH+yy],vwq[j*TH+yy],q);
-            }
-        Q copy[C],out[C];
-        load_pixel<Q,C>(src_tile+((size_t) vnear[yy]*cstride+i)*C,copy);
-        acc.finish(copy,a.v.copy_mask,out);
-        store_pixel<Q,C>(mid_tile+((size_t) yy*cstride+i)*C,out);
-      }
-  }
-  __syncthreads();
-
-  // 3. horizontal pass: lane = output column
-  const int OUT=a.h.out_size;
-  const int x=X0+tid;
-  if (x >= OUT)
-    return;
-  const int start=a.h.start[x]-clo;
-  const int count=a.h.count[x];
-  if (count <= 0)
-    return;
-  const int nearest=a.h.nearest[x]-clo;
-  const T *weight=static_cast<const T *>(a.h.weight);
-  const T *weight_qs=static_cast<const T *>(a.h.weight_qs);
-  T w[MAXT],wq[MAXT];
-#pragma unroll
-  for (int j=0; j < MAXT; j++)
-    {
-      w[j]=(T) 0;
-      wq[j]=(T) 0;
-      if (j < count)
-        {
-          w[j]=weight[(size_t) j*OUT+x];
-          if constexpr (BLEND)
-            wq[j]=weight_qs[(size_t) j*OUT+x];
-        }
-    }
-  for (int yy=0; yy < rows; yy++)
-    {
-      const Q *line=mid_tile+(size_t) yy*cstride*C;
-      ResizeAcc<Q,C,BLEND,A> acc;
-      acc.init();
-#pragma unroll
-      for (int j=0; j < MAXT; j++)
-        if (j < count)
-          {
-            Q q[C];
-            load_pixel<Q,C>(line+(size_t) (start+j)*C,q);
-            acc.tap(w[j],wq[j],q);
-          }
-      Q copy[C],out[C];
-      load_pixel<Q,C>(line+(size_t) nearest*C,copy);
-      acc.finish(copy,a.h.copy_mask,out);
-      store_pixel<Q,C>(dst+(size_t) (Y0+yy)*dst_pitch+(size_t) x*C,out);
-    }
-}
-
-// ------------------------------------------- fused V-then-H, vertical pass in the staging
-// The horizontal pass above is bound by its 16x output stream, not by arithmetic; its staging
-// phase reads the Quantum-typed intermediate (columns x new rows) that VerticalFilter wrote a
-// moment ago.  This form computes those intermediate samples instead of reading them: a staging
-// thread evaluates VerticalFilter for its (tile row, source column) from the source rows —
-// an 11 x 78 pixel patch per 256 x 16 output tile at 4x, served by the L1 — rounds the result to
-// Quantum exactly as the reference's filter image holds it (resize.c:3535-3543) and stores it
-// converted, and the horizontal part is unchanged.  The 4.3 GB intermediate of config C3 is
-// neither written nor read and the vertical launch disappears; results are those of the two
-// passes, operation by operation.
-struct FusedStageArgs
-{
-  ResizeArgs h;               // column tables; src unused, dst = the result
-  ResizeArgs v;               // row tables; src = the source image
-};
-
-constexpr int kFusedRows=16;  // tile rows (rows of vertical tables in LDS)
-
-template<typename Q,int C,bool BLEND,class A,int MAXT,int VMAXT,int ITEMS>
-__global__ __launch_bounds__(256)
-void resize_fused_stage_kernel(FusedStageArgs a,int tile_rows,int lds_span)
-{
-  typedef typename A::T T;
-  constexpr bool kSkipZeros=std::is_same<A,Exact64>::value && QuantumOps<Q>::is_float;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T *vw=reinterpret_cast<T *>(smem_raw);                  // [VMAXT][kFusedRows]
-  T *vwq=vw+VMAXT*kFusedRows;                             // [VMAXT][kFusedRows]
-  int *vstart=reinterpret_cast<int *>(vwq+VMAXT*kFusedRows);
-  int *vcount=vstart+kFusedRows;
-  int *vnear=vcount+kFusedRows;
-  T *tile=reinterpret_cast<T *>(vnear+kFusedRows+4);      // (3*16+4 ints: 16-byte aligned)
-  Q *patch=reinterpret_cast<Q *>(tile);                   // the source rows, before the tile exists
-  const ResizeArgs &args=a.h;
-  const int OUT=args.out_size;
-  const int x0=(int) blockIdx.x*256;
-  const int x=x0+(int) threadIdx.x;
-  const int y0=(int) blockIdx.y*tile_rows;
-  const Q *src=static_cast<const Q *>(a.v.src);
-  Q *dst=static_cast<Q *>(args.dst);
-  const T *weight=static_cast<const T *>(args.weight);
-  const T *weight_qs=static_cast<const T *>(args.weight_qs);
-  const size_t src_pitch=(size_t) a.v.src_columns*C;
-  const size_t dst_pitch=(size_t) args.dst_columns*C;
-  const int lo=args.tile_lo[blockIdx.x];
-  int rows=args.dst_rows-y0;
-  rows=rows < tile_rows ? rows : tile_rows;
-  const int last_row=a.v.src_rows-1;
-  // source rows of the tile: contribution starts do not decrease with y (resize.c:3623-3626), and
-  // the vertical taps read VMAXT rows from each start (zero weights past `count`)
-  const int row_lo=a.v.start[y0];
-  int row_hi=a.v.start[y0+rows-1]+VMAXT-1;
-  row_hi=row_hi < last_row ? row_hi : last_row;
-  const int patch_rows=row_hi-row_lo+1;
-
-  // the vertical tables of this tile's rows
-  if ((int) threadIdx.x < rows)
-    {
-      const int r=(int) threadIdx.x,y=y0+r,OUTV=a.v.out_size;
-      const T *vweight=static_cast<const T *>(a.v.weight);
-      const T *vweight_qs=static_cast<const T *>(a.v.weight_qs);
-      const int cnt=a.v.count[y];
-      vstart[r]=a.v.start[y]-row_lo;
-      vcount[r]=cnt;
-      vnear[r]=cnt > 0 ? a.v.nearest[y]-row_lo : 0;
-#pragma unroll
-      for (int j=0; j < VMAXT; j++)
-        {
-          vw[j*kFusedRows+r]=j < cnt ? vweight[(size_t) j*OUTV+y] : (T) 0;
-          vwq[j*kFusedRows+r]=(BLEND && (j < cnt)) ? vweight_qs[(size_t) j*OUTV+y] : (T) 0;
-        }
-    }
-  // the source patch: patch_rows x lds_span pixels, coalesced row segments
-  {
-    constexpr int BATCH=4;
-    const int items=patch_rows*lds_span;
-    for (int i0=(int) threadIdx.x; i0 < items; i0+=256*BATCH)
-      {
-        Q v[BATCH][C];
-#pragma unroll
-        for (int k=0; k < BATCH; k++)
-          {
-            int idx=i0+256*k;
-            idx=idx < items ? idx : items-1;
-            const int r=idx/lds_span,i=idx-r*lds_span;
-            int col=lo+i;
-            col=col < a.v.src_columns ? col : a.v.src_columns-1;
-            load_pixel<Q,C>(src+(size_t) (row_lo+r)*src_pitch+(size_t) col*C,v[k]);
-          }
-#pragma unroll
-        for (int k=0; k < BATCH; k++)
-          if (i0+256*k < items)
-            store_pixel<Q,C>(patch+(size_t) (i0+256*k)*C,v[k]);
-      }
-  }
-  __syncthreads();
-
-  // VerticalFilter of (tile row r, patch column i) out of the patch, into registers
-  Q mid[ITEMS][C];
-  {
-    const int items=lds_span*rows;
-    const int patch_last=patch_rows-1;
-#pragma unroll
-    for (int k=0; k < ITEMS; k++)
-      {
-        int idx=(int) threadIdx.x+256*k;
-        idx=idx < items ? idx : items-1;
-        const int r=idx/lds_span,i=idx-r*lds_span;
-        const int start=vstart[r],count=vcount[r];
-        const Q *column=patch+(size_t) i*C;
-        Q p[VMAXT][C];
-#pragma unroll
-        for (int j=0; j < VMAXT; j++)
-          {
-            int row=start+j;                       // taps past `count` carry zero weights
-            row=row < patch_last ? row : patch_last;
-            load_pixel<Q,C>(column+(size_t) row*lds_span*C,p[j]);
-          }
-        ResizeAcc<Q,C,BLEND,A> acc;
-        acc.init();
-#pragma unroll
-        for (int j=0; j < VMAXT; j++)
-          if (!kSkipZeros || (j < count))
-            acc.tap(vw[j*kFusedRows+r],vwq[j*kFusedRows+r],p[j]);
-        Q copy[C];
-#pragma unroll
-        for (int c=0; c < C; c++)
-          copy[c]=(Q) 0;
-        if (a.v.copy_mask != 0)
-          load_pixel<Q,C>(column+(size_t) vnear[r]*lds_span*C,copy);
-        acc.finish(copy,a.v.copy_mask,mid[k]);
-      }
-  }
-  __syncthreads();                                   // every read of the patch is done
-  {
-    const int items=lds_span*rows;
-#pragma unroll
-    for (int k=0; k < ITEMS; k++)
-      {
-        const int idx=(int) threadIdx.x+256*k;
-        if (idx < items)
-          {
-#pragma unroll
-            for (int c=0; c < C; c++)
-              tile[(size_t) idx*C+c]=(T) mid[k][c];
-          }
-      }
-  }
-  __syncthreads();
-  if (x >= OUT)
-    return;
-  const int start=args.start[x]-lo;
-  const int count=args.count[x];
-  if (count <= 0)
-    return;
-  const int nearest=args.nearest[x]-lo;
-  T w[MAXT],wq[MAXT];
-#pragma unroll
-  for (int j=0; j < MAXT; j++)
-    {
-      w[j]=(T) 0;
-      wq[j]=(T) 0;
-      if (j < count)
-        {
-          w[j]=weight[(size_t) j*OUT+x];
-          if constexpr (BLEND)
-            wq[j]=weight_qs[(size_t) j*OUT+x];
-        }
-    }
-  for (int r=0; r < rows; r++)
-    {
-      const T *line=tile+(size_t) r*lds_span*C+(size_t) start*C;
-      ResizeAcc<Q,C,BLEND,A> acc;
-      acc.init();
-      T p[MAXT][C];
-#pragma unroll
-      for (int j=0; j < MAXT; j++)
-#pragma unroll
-        for (int c=0; c < C; c++)
-          p[j][c]=line[(size_t) j*C+c];
-#pragma unroll
-      for (int j=0; j < MAXT; j++)
-        if (!kSkipZeros || (j < count))
-          acc.tap_converted(w[j],wq[j],p[j]);
-      Q copy[C],out[C];
-#pragma unroll
-      for (int c=0; c < C; c++)
-        copy[c]=(Q) 0;
-      if (args.copy_mask != 0)
-        {
-#pragma unroll
-          for (int c=0; c < C; c++)
-            copy[c]=(Q) tile[((size_t) r*lds_span+(size_t) nearest)*C+c];
-        }
-      acc.finish(copy,args.copy_mask,out);
-      store_pixel<Q,C>(dst+(size_t) (y0+r)*dst_pitch+(size_t) x*C,out);
-    }
-}
-
-// uploads one axis' tables
-struct DeviceTaps
-{
-  Temp start,count,nearest,w,wq;
-  template<typename T>
-  MhStatus upload(const TapTable &table,const View &on,ResizeArgs &args)
-  {
-    const size_t n=(size_t) table.max_taps*(size_t) table.out_size;
-    std::vector<T> hw(n),hwq(n);
-    for (size_t i=0; i < n; i++)
-      {
-        hw[i]=(T) table.weight[i];
-        hwq[i]=(T) (table.weight[i]*kQuantumScale);
-      }
-    const size_t ib=(size_t) table.out_size*sizeof(int);
-    MH_TRY(upload_table(start,on.device,on.stream,table.start.data(),ib));
-    MH_TRY(upload_table(count,on.device,on.stream,table.count.data(),ib));
-    MH_TRY(upload_table(nearest,on.device,on.stream,table.nearest.data(),ib));
-    MH_TRY(upload_table(w,on.device,on.stream,hw.data(),n*sizeof(T)));
-    MH_TRY(upload_table(wq,on.device,on.stream,hwq.data(),n*sizeof(T)));
-    args.out_size=table.out_size;
-    args.max_taps=table.max_taps;
-    args.start=start.as<int>();
-    args.count=count.as<int>();
-    args.nearest=nearest.as<int>();
-    args.weight=w.ptr;
-    args.weight_qs=wq.ptr;
-    return MH_OK;
-  }
-};
-
-// source span [lo, lo+span) of every tile of `tile` consecutive outputs
-static void tile_spans(const TapTable &table,int tile,std::vector<int> &lo_out,std::vector<int> &span_out,
-  int &max_span)
-{
-  max_span=1;
-  for (int o0=0; o0 < table.out_size; o0+=tile)
-    {
-      int oh=(o0+tile-1) < table.out_size ? (o0+tile-1) : table.out_size-1;
-      int lo=table.start[(size_t) o0],hi=0;
-      for (int i=o0; i <= oh; i++)
-        {
-          int s=table.start[(size_t) i],e=s+table.count[(size_t) i];
-          lo=s < lo ? s : lo;
-          hi=e > hi ? e : hi;
-        }
-      if (hi < lo)
-        hi=lo;
-      lo_out.push_back(lo);
-      span_out.push_back(hi-lo);
-      if ((hi-lo) > max_span)
-        max_span=hi-lo;
-    }
-}
-
-template<typename Q,int C,bool BLEND,class A>
-static MhStatus launch_fused_typed(const View &src,const View &dst,const TapTable &vt,
-  const TapTable &ht,const Roles &roles,bool &handled)
-{
-  typedef typename A::T T;
-  constexpr int TH=32,MAXT=8;
-  handled=false;
-  if ((ht.max_taps > MAXT) || (vt.max_taps > MAXT))
-    return MH_OK;
-  std::vector<int> col_lo,col_span,row_lo,row_span;
-  int cmax=1,rmax=1;
-  tile_spans(ht,256,col_lo,col_span,cmax);
-  tile_spans(vt,TH,row_lo,row_span,rmax);
-  const size_t px=(size_t) C*sizeof(Q);
-  const size_t head=2u*MAXT*TH*sizeof(T)+(size_t) (3*TH+(TH & 1))*sizeof(int);
-  const size_t lds=head+((size_t) rmax+(size_t) TH)*(size_t) cmax*px;
-  if (lds > 72u*1024u)          // two workgroups per CU
-    return MH_OK;
-  FusedArgs a;
-  DeviceTaps dv,dh;
-  MH_TRY(dv.template upload<T>(vt,src,a.v));
-  MH_TRY(dh.template upload<T>(ht,src,a.h));
-  Temp d_clo,d_cspan,d_rlo,d_rspan;
-  MH_TRY(upload_table(d_clo,src.device,src.stream,col_lo.data(),col_lo.size()*sizeof(int)));
-  MH_TRY(upload_table(d_cspan,src.device,src.stream,col_span.data(),col_span.size()*sizeof(int)));
-  MH_TRY(upload_table(d_rlo,src.device,src.stream,row_lo.data(),row_lo.size()*sizeof(int)));
-  MH_TRY(upload_table(d_rspan,src.device,src.stream,row_span.data(),row_span.size()*sizeof(int)));
-  a.v.src=src.pixels;
-  a.v.dst=nullptr;
-  a.v.src_columns=(int) src.columns;
-  a.v.src_rows=(int) src.rows;
-  a.v.dst_columns=(int) src.columns;
-  a.v.dst_rows=(int) dst.rows;
-  a.v.copy_mask=roles.copy_mask;
-  a.v.tile_lo=nullptr;
-  a.v.tile_span=nullptr;
-  a.h.src=nullptr;
-  a.h.dst=dst.pixels;
-  a.h.src_columns=(int) src.columns;
-  a.h.src_rows=(int) dst.rows;
-  a.h.dst_columns=(int) dst.columns;
-  a.h.dst_rows=(int) dst.rows;
-  a.h.copy_mask=roles.copy_mask;
-  a.h.tile_lo=d_clo.as<int>();
-  a.h.tile_span=d_cspan.as<int>();
-  a.row_lo=d_rlo.as<int>();
-  a.row_span=d_rspan.as<int>();
-  a.cstride=cmax;
-  a.rspan_max=rmax;
-  dim3 grid((unsigned) ((dst.columns+255)/256),(unsigned) ((dst.rows+TH-1)/TH));
-  if (lds > 64u*1024u)
-    MH_HIP(hipFuncSetAttribute(
-      reinterpret_cast<const void *>(&resize_fused_kernel<Q,C,BLEND,A,TH,MAXT>),
-      hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
-  {
-    ProfileScope prof("resize_fused",src.stream);
-    hipLaunchKernelGGL((resize_fused_kernel<Q,C,BLEND,A,TH,MAXT>),grid,dim3(256),lds,src.stream,a);
-  }
-  MH_HIP(hipGetLastError());
-  handled=true;
-  return MH_OK;
-}
-
-template<typename Q,class A>
-static MhStatus dispatch_fused(const View &src,const View &dst,const TapTable &vt,const TapTable &ht,
-  const Roles &roles,bool &handled)
-{
-  const bool blend=roles.blend && (roles.alpha == src.channels-1);
-  switch (src.channels)
-  {
-    case 1: return launch_fused_typed<Q,1,false,A>(src,dst,vt,ht,roles,handled);
-    case 2:
-      if (blend) return launch_fused_typed<Q,2,true,A>(src,dst,vt,ht,roles,handled);
-      return launch_fused_typed<Q,2,false,A>(src,dst,vt,ht,roles,handled);
-    case 3: return launch_fused_typed<Q,3,false,A>(src,dst,vt,ht,roles,handled);
-    case 4:
-      if (blend) return launch_fused_typed<Q,4,true,A>(src,dst,vt,ht,roles,handled);
-      return launch_fused_typed<Q,4,false,A>(src,dst,vt,ht,roles,handled);
-    default: break;
-  }
-  handled=false;
-  return MH_OK;
-}
-
-// the horizontal tiling of the converted-tile kernels: first source column and tap count of
-// every 256-column tile, the LDS span (widest tile span + the zero-weight overhang)
-static void horizontal_tiles(const TapTable &table,int maxt,std::vector<int> &tile_lo,int &lds_span)
-{
-  int max_span=1,overhang=0;
-  std::vector<int> span;
-  for (int x0=0; x0 < table.out_size; x0+=256)
-    {
-      int xh=(x0+255) < table.out_size ? (x0+255) : table.out_size-1;
-      int lo=table.start[(size_t) x0],hi=0,endmax=0;
-      for (int i=x0; i <= xh; i++)
-        {
-          int st=table.start[(size_t) i],e=st+table.count[(size_t) i];
-          lo=st < lo ? st : lo;
-          hi=e > hi ? e : hi;
-          endmax=(st+maxt) > endmax ? (st+maxt) : endmax;
-        }
-      if (hi < lo)
-        hi=lo;
-      tile_lo.push_back(lo);
-      max_span=(hi-lo) > max_span ? (hi-lo) : max_span;
-      overhang=(endmax-hi) > overhang ? (endmax-hi) : overhang;
-    }
-  lds_span=max_span+overhang;
-}
-
-template<typename Q,int C,bool BLEND,class A>
-static MhStatus launch_fused_stage_typed(const View &src,const View &dst,const TapTable &vt,
-  const TapTable &ht,const Roles &roles,bool &handled)
-{
-  typedef typename A::T T;
-  handled=false;
-  if ((ht.max_taps > 8) || (vt.max_taps > 8))
-    return MH_OK;
-  const int maxt=ht.max_taps <= 4 ? 4 : (ht.max_taps <= 6 ? 6 : 8);
-  std::vector<int> tile_lo;
-  int lds_span=1;
-  horizontal_tiles(ht,maxt,tile_lo,lds_span);
-  const size_t cpx=(size_t) C*sizeof(T);
-  const size_t head=2u*8u*kFusedRows*sizeof(T)+(size_t) (3*kFusedRows+4)*sizeof(int);
-  // four workgroups per CU (as the horizontal kernel): 40 KB each, tables included
-  int tile_rows=(int) ((40u*1024u-head)/((size_t) lds_span*cpx));
-  if (const char *e=option("MAGICKHIP_FUSED_TILE_ROWS"))
-    tile_rows=atoi(e);
-  tile_rows=tile_rows > kFusedRows ? kFusedRows : tile_rows;
-  if (tile_rows < 4)
-    return MH_OK;                                // a wide source span: the two passes
-  const size_t lds=head+(size_t) lds_span*cpx*(size_t) tile_rows;
-  // the source patch of a tile is staged in the memory its intermediate tile will occupy
-  int patch_rows=1;
-  for (int y0=0; y0 < vt.out_size; y0+=tile_rows)
-    {
-      const int yl=(y0+tile_rows-1) < vt.out_size ? (y0+tile_rows-1) : vt.out_size-1;
-      const int span=vt.start[(size_t) yl]+8-vt.start[(size_t) y0];
-      patch_rows=span > patch_rows ? span : patch_rows;
-      for (int y=y0; y < yl; y++)
-        if (vt.start[(size_t) y+1] < vt.start[(size_t) y])
-          return MH_OK;                          // (never for MagickCore's contribution lists)
-    }
-  if ((size_t) patch_rows*sizeof(Q) > (size_t) tile_rows*sizeof(T))
-    return MH_OK;
-  const int items=(lds_span*tile_rows+255)/256;
-  if (items > 10)
-    return MH_OK;
-  FusedStageArgs a;
-  DeviceTaps dv,dh;
-  MH_TRY(dv.template upload<T>(vt,src,a.v));
-  MH_TRY(dh.template upload<T>(ht,src,a.h));
-  Temp d_lo;
-  MH_TRY(upload_table(d_lo,src.device,src.stream,tile_lo.data(),tile_lo.size()*sizeof(int)));
-  a.v.src=src.pixels;
-  a.v.dst=nullptr;
-  a.v.src_columns=(int) src.columns;
-  a.v.src_rows=(int) src.rows;
-  a.v.dst_columns=(int) src.columns;
-  a.v.dst_rows=(int) dst.rows;
-  a.v.copy_mask=roles.copy_mask;
-  a.v.tile_lo=nullptr;
-  a.v.tile_span=nullptr;
-  a.h.src=nullptr;
-  a.h.dst=dst.pixels;
-  a.h.src_columns=(int) src.columns;
-  a.h.src_rows=(int) dst.rows;
-  a.h.dst_columns=(int) dst.columns;
-  a.h.dst_rows=(int) dst.rows;
-  a.h.copy_mask=roles.copy_mask;
-  a.h.tile_lo=d_lo.as<int>();
-  a.h.tile_span=nullptr;
-  dim3 grid((unsigned) ((dst.columns+255)/256),(unsigned) ((dst.rows+tile_rows-1)/tile_rows));
-  ProfileScope prof("resize_fused",src.stream);
-#define MH_LAUNCH_F(N,I)                                                                        \
-  {                                                                                              \
-    if (lds > 64u*1024u)                                                                         \
-      MH_HIP(hipFuncSetAttribute(                                                                \
-        reinterpret_cast<const void *>(&resize_fused_stage_kernel<Q,C,BLEND,A,N,8,I>),          \
-        hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));                                  \
-    hipLaunchKernelGGL((resize_fused_stage_kernel<Q,C,BLEND,A,N,8,I>),grid,dim3(256),lds,src.stream, \
-      a,tile_rows,lds_span);                                                                     \
-  }
-  if (items <= 5)
-    {
-      if (maxt == 4) MH_LAUNCH_F(4,5)
-      else if (maxt == 6) MH_LAUNCH_F(6,5)
-      else MH_LAUNCH_F(8,5)
-    }
-  else
-    {
-      if (maxt == 4) MH_LAUNCH_F(4,10)
-      else if (maxt == 6) MH_LAUNCH_F(6,10)
-      else MH_LAUNCH_F(8,10)
-    }
-#undef MH_LAUNCH_F
-  MH_HIP(hipGetLastError());
-  handled=true;
-  return MH_OK;
-}
-
-template<typename Q,class A>
-static MhStatus dispatch_fused_stage(const View &src,const View &dst,const TapTable &vt,const TapTable &ht,
-  const Roles &roles,bool &handled)
-{
-  const bool blend=roles.blend && (roles.alpha == src.channels-1);
-  switch (src.channels)
-  {
-    case 1: return launch_fused_stage_typed<Q,1,false,A>(src,dst,vt,ht,roles,handled);
-    case 2:
-      if (blend) return launch_fused_stage_typed<Q,2,true,A>(src,dst,vt,ht,roles,handled);
-      return launch_fused_stage_typed<Q,2,false,A>(src,dst,vt,ht,roles,handled);
-    case 3: return launch_fused_stage_typed<Q,3,false,A>(src,dst,vt,ht,roles,handled);
-    case 4:
-      if (blend) return launch_fused_stage_typed<Q,4,true,A>(src,dst,vt,ht,roles,handled);
-      return launch_fused_stage_typed<Q,4,false,A>(src,dst,vt,ht,roles,handled);
-    default: break;
-  }
-  handled=false;
-  return MH_OK;
-}
-
 // VerticalFilter followed by HorizontalFilter in one launch.  *handled is false
 // (and nothing was launched) when the tiles do not fit LDS or the tap count is
 // too large; the caller then runs the two passes separately.
@@ -1034,55 +398,25 @@ MhStatus launch_resize_fused(const View &src,const View &dst,const TapTable &ver
     return MH_OK;
   if (((int) dst.rows != vertical.out_size) || ((int) dst.columns != horizontal.out_size))
     return fail(MH_BAD_ARGUMENT,"resize: geometry mismatch");
-  // Both fused forms are opt-in: measured on config C3 the one launch takes as long as the two
-  // passes together (stage form 6.04 ms against 4.62 + 1.35; the first form 8.6 ms) — the passes
-  // are bound by fp64 issue and LDS reads, not by the 8.6 GB of intermediate traffic a fused
-  // kernel saves.  MAGICKHIP_FUSED_RESIZE=stage | 1 selects them.
-  const char *choice=option("MAGICKHIP_FUSED_RESIZE");
-  if (choice == nullptr)
+  // The one-launch forms are FAST forms (fused multiply-adds, derived gamma: within one ULP / one
+  // level).  (Rounds 1 and 2 had two EXACT-capable forms that kept the intermediate tile in LDS and
+  // cost as much as the two passes together — 8.6 and 6.0 ms on config C3; removed in round 5,
+  // DESIGN.md section 4.3.)
+  if (prec != MH_PRECISION_FAST)
+    return MH_OK;
+  // four channels, enlargement by a whole-number horizontal factor: plain fp64 multiply-adds out of
+  // registers with scalar-register weights (resize_stream.hip); MAGICKHIP_NO_RESIZE_STREAM=1 skips it
+  if (option("MAGICKHIP_NO_RESIZE_STREAM") == nullptr)
     {
-      // FAST, four channels, enlargement: both filters on the fp64 matrix pipe, the intermediate
-      // in registers (resize_mfma.hip); MAGICKHIP_NO_RESIZE_MFMA=1 keeps the two passes
-      if (prec != MH_PRECISION_FAST)
+      MH_TRY(launch_resize_stream(src,dst,vertical,horizontal,roles,handled));
+      if (*handled)
         return MH_OK;
-      // ... by a whole-number horizontal factor: plain fp64 multiply-adds out of registers with
-      // scalar-register weights (resize_stream.hip); MAGICKHIP_NO_RESIZE_STREAM=1 skips it
-      if (option("MAGICKHIP_NO_RESIZE_STREAM") == nullptr)
-        {
-          MH_TRY(launch_resize_stream(src,dst,vertical,horizontal,roles,handled));
-          if (*handled)
-            return MH_OK;
-        }
-      if (option("MAGICKHIP_NO_RESIZE_MFMA") == nullptr)
-        return launch_resize_mfma(src,dst,vertical,horizontal,roles,handled);
-      return MH_OK;
     }
-  if (strcmp(choice,"stage") == 0)
-    {
-      // enlargements (the vertical pass's source patch of a tile is small and L1-resident): the
-      // vertical pass inside the horizontal kernel's staging
-      if ((dst.rows < 2*src.rows) || (dst.columns < src.columns))
-        return MH_OK;
-      if (prec == MH_PRECISION_FAST)
-        {
-          if (src.quantum == MH_QUANTUM_U16)
-            return dispatch_fused_stage<uint16_t,Fma64>(src,dst,vertical,horizontal,roles,*handled);
-          return dispatch_fused_stage<float,Fma64>(src,dst,vertical,horizontal,roles,*handled);
-        }
-      if (src.quantum == MH_QUANTUM_U16)
-        return dispatch_fused_stage<uint16_t,Exact64>(src,dst,vertical,horizontal,roles,*handled);
-      return dispatch_fused_stage<float,Exact64>(src,dst,vertical,horizontal,roles,*handled);
-    }
-  // the first fused kernel: both tiles in LDS
-  if (prec == MH_PRECISION_FAST)
-    {
-      if (src.quantum == MH_QUANTUM_U16)
-        return dispatch_fused<uint16_t,Fma64>(src,dst,vertical,horizontal,roles,*handled);
-      return dispatch_fused<float,Fma64>(src,dst,vertical,horizontal,roles,*handled);
-    }
-  if (src.quantum == MH_QUANTUM_U16)
-    return dispatch_fused<uint16_t,Exact64>(src,dst,vertical,horizontal,roles,*handled);
-  return dispatch_fused<float,Exact64>(src,dst,vertical,horizontal,roles,*handled);
+  // any other enlargement of a four-channel frame: both filters on the fp64 matrix pipe, the
+  // intermediate in registers (resize_mfma.hip); MAGICKHIP_NO_RESIZE_MFMA=1 keeps the two passes
+  if (option("MAGICKHIP_NO_RESIZE_MFMA") == nullptr)
+    return launch_resize_mfma(src,dst,vertical,horizontal,roles,handled);
+  return MH_OK;
 }
 
 // ---------------------------------------------------------------- launcher

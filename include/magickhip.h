@@ -167,7 +167,9 @@ typedef struct MhImage
   uint32_t number_channels;                 /* 1..MH_MAX_CHANNELS */
   uint32_t quantum;                         /* MhQuantumKind */
   uint32_t memory;                          /* MhMemoryKind */
-  int32_t device;                           /* HIP device ordinal; -1 = library default */
+  int32_t device;                           /* HIP device ordinal; -1 = library default; MH_DEVICE_ALL (host memory,
+                                               new-image stencil operators on frames of 64 MB and more): the row
+                                               bands of the frame go round every (logical) device of the node */
   uint32_t channel_traits[MH_MAX_CHANNELS]; /* PixelTrait of the channel stored at each offset */
   int32_t alpha_offset;                     /* offset of the alpha channel, -1 if none (image->alpha_trait undefined) */
   uint32_t alpha_trait;                     /* image->alpha_trait: MH_TRAIT_BLEND when alpha is active */
@@ -191,7 +193,10 @@ MH_API void MhInitImage(MhImage *image,void *pixels,size_t columns,size_t rows,
 MH_API MhStatus MhInitialize(void);               /* InitializeOpenCL analogue, opencl.c:2430 */
 MH_API void MhTerminus(void);                     /* OpenCLTerminus, opencl.c:2576 */
 MH_API int MhDeviceCount(void);
+#define MH_DEVICE_ALL (-2)
 MH_API MhStatus MhSetDevice(int device);          /* default device for device=-1 images */
+/* bands the host-image pipeline (MH_DEVICE_ALL included) has finished on a logical device: tests, bench */
+MH_API unsigned long long MhBandedBands(int logical_device);
 MH_API int MhGetEnabled(void);                    /* GetOpenCLEnabled */
 MH_API int MhSetEnabled(int enabled);             /* SetOpenCLEnabled, opencl.c:3192; returns new state */
 MH_API const char *MhGetLastError(void);          /* thread-local description of the last non-OK status */

@@ -38,6 +38,7 @@ typedef struct _HipLibrary
   MhResizeFilter *(*DestroyResizeFilter)(MhResizeFilter *);
   MhStatus (*ContrastStretchImage)(MhImage *,double,double,int *);
   MhStatus (*EqualizeImage)(MhImage *);
+  MhStatus (*ShardedImage)(const MhOperator *,size_t,const MhImage *,MhImage *,int,MhBatchReport *);
   MhStatus (*GrayscaleImage)(MhImage *,MhIntensityMethod);
   MhStatus (*FunctionImage)(MhImage *,MhFunction,size_t,const double *);
   MhStatus (*MotionBlurImageWithKernel)(const MhImage *,MhImage *,const double *,size_t,
@@ -81,5 +82,10 @@ extern MagickPrivate int GetHipDevicePhysical(const MagickCLDevice device);
 
 /* transfer counters, for tests (uploads / downloads of whole pixel caches) */
 extern MagickPrivate void CountHipTransfer(int upload);
+/* one big host-resident image over every device (row bands): the number of devices to use — all of
+   them, when at least two exist and none has been switched off —, else 0; and the bookkeeping of
+   such a call (every device's call counter) */
+extern MagickPrivate size_t GetHipSpreadDevices(void);
+extern MagickPrivate void CountHipSpreadCall(size_t devices);
 
 #endif

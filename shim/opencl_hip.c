@@ -168,6 +168,7 @@ static void LoadHipLibrary(void)
   MH_RESOLVE(DestroyResizeFilter,"MhDestroyResizeFilter");
   MH_RESOLVE(ContrastStretchImage,"MagickHipContrastStretchImage");
   MH_RESOLVE(EqualizeImage,"MagickHipEqualizeImage");
+  MH_RESOLVE(ShardedImage,"MagickHipShardedImage");
   MH_RESOLVE(GrayscaleImage,"MagickHipGrayscaleImage");
   MH_RESOLVE(FunctionImage,"MagickHipFunctionImage");
   MH_RESOLVE(MotionBlurImageWithKernel,"MagickHipMotionBlurImageWithKernel");
@@ -396,6 +397,34 @@ MagickExport size_t GetMagickHipDeviceStatistics(const size_t index,size_t *call
   UnlockSemaphoreInfo(hip_devices[index]->lock);
   *streams=n;
   return(hip_number_devices);
+}
+
+MagickPrivate size_t GetHipSpreadDevices(void)
+{
+  size_t
+    i,
+    n;
+
+  if ((hip_library_state <= 0) || (hip_number_devices < 2))
+    return(0);
+  n=hip_number_devices;
+  LockSemaphoreInfo(hip_devices_semaphore);
+  for (i=0; i < hip_number_devices; i++)
+    if (hip_devices[i]->enabled == MagickFalse)
+      n=0;
+  UnlockSemaphoreInfo(hip_devices_semaphore);
+  return(n);
+}
+
+MagickPrivate void CountHipSpreadCall(size_t devices)
+{
+  size_t
+    i;
+
+  LockSemaphoreInfo(hip_devices_semaphore);
+  for (i=0; (i < devices) && (i < hip_number_devices); i++)
+    hip_device_calls[i]++;
+  UnlockSemaphoreInfo(hip_devices_semaphore);
 }
 
 MagickPrivate void CountHipTransfer(int upload)

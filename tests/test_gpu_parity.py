@@ -1819,28 +1819,6 @@ def test_equalize_float_frame_from_running_counts(im, refmod, background, counts
 
 
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
-@pytest.mark.parametrize("form", ["stage", "1"])
-@pytest.mark.parametrize("shape,target,filt", [((37, 53, 4), (148, 212), "Lanczos"), ((64, 300, 4), (200, 700), "Mitchell"),
-                                               ((50, 41, 3), (150, 164), "Triangle"), ((23, 600, 4), (92, 2400), "Lanczos")])
-def test_resize_fused_forms(im, refmod, shape, target, filt, form, dtype, options):
-    """The opt-in one-launch enlargements (MAGICKHIP_FUSED_RESIZE=stage: VerticalFilter inside the
-    horizontal kernel's staging; =1: both tiles in LDS) give the two passes' bits — the
-    intermediate is rounded to Quantum as the reference's filter image is."""
-    import bench
-    px = make_pixels(shape[0], shape[1], shape[2], dtype, seed=shape[1])
-    dev, ref = run_pair(im, refmod, px)
-    want = ref.resize(target[1], target[0], filt).numpy()
-    options.set("MAGICKHIP_FUSED_RESIZE", form)
-    holder = {}
-    launched = set(bench.kernel_profile(
-        im, lambda: holder.update(out=im.resize_image(dev, target[1], target[0], filt)), 1))
-    # (a tile whose source span does not fit LDS falls back to the two passes: the 2.3x Mitchell case)
-    assert launched in ({"resize_fused"}, {"resize_horizontal", "resize_vertical"}), launched
-    if filt == "Lanczos":
-        assert launched == {"resize_fused"}, launched
-    assert_parity(holder["out"].numpy(), want, True, "fused resize (%s) %s" % (form, filt), max_ulp=0)
-
-
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
 @pytest.mark.parametrize("alpha", [True, False])
 @pytest.mark.parametrize("shape,target,filt", [

@@ -461,6 +461,7 @@ def _run_threads_worker(threads, per_thread, env_extra, hdri=False):
     import sys
     env = dict(os.environ, **env_extra)
     env["MAGICK_HIP_LIBRARY"] = os.path.join(ROOT, "imagemagick_amd", "lib", "libmagickhip.so")
+    env["MAGICK_HIP_PRECISION"] = "exact"          # (the worker compares bit for bit; the default is FAST)
     cmd = [sys.executable, os.path.join(ROOT, "tests", "helpers", "shim_threads.py"), str(threads), str(per_thread)]
     if hdri:
         cmd.append("hdri")
@@ -484,6 +485,49 @@ def test_eight_threads_spread_over_devices_and_streams(shim, hdri):
     assert sum(report["calls"]) == 48
     assert sum(1 for c in report["calls"] if c > 0) >= 2, report     # landed on >= 2 logical devices
     assert all(s >= 2 for c, s in zip(report["calls"], report["streams"]) if c >= 4), report
+
+
+def _run_spread_worker(edge, extra_env, hdri=False):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.update(extra_env)
+    env["MAGICK_HIP_PRECISION"] = "exact"
+    env["MAGICK_HIP_LIBRARY"] = os.path.join(ROOT, "imagemagick_amd", "lib", "libmagickhip.so")
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "helpers", "shim_spread.py"), str(edge)]
+    if hdri:
+        cmd.append("hdri")
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("hdri", [False, True])
+def test_one_big_host_image_goes_over_every_device(shim, hdri):
+    """BASELINE configs[4] through the boundary: an unchanged caller's MorphologyImage (Dilate Disk:15),
+    BlurImage and EqualizeImage on ONE big host-resident image.  The reference hands an operator one
+    device (opencl.c:3056-3102) and that device's host link then carries the whole frame both ways; with
+    more than one device enabled and a frame of MAGICK_HIP_SPREAD_BYTES or more the binding runs the
+    stencil operators on the host blocks with MH_DEVICE_ALL (row bands round all devices) and the
+    histogram operator through MagickHipShardedImage (one band per device, the table all-reduced).
+    Four logical devices on the GPU present; bit-identical to the CPU MagickCore."""
+    report = _run_spread_worker(3072 if hdri else 4096, {"MAGICKHIP_LOGICAL_DEVICES": "4",
+                                                         "MAGICK_HIP_SPREAD_BYTES": str(100 << 20)}, hdri)
+    assert report["mismatches"] == [], report
+    assert report["accelerated"] == 3 and report["devices"] == 4, report
+    assert all(c == 3 for c in report["calls"]), report              # every device took part in every call
+    assert sum(1 for b in report["bands"] if b > 0) >= 2, report     # the stencil bands went round the devices
+
+
+def test_one_big_host_image_on_two_physical_gpus(shim, im):
+    """The same over the physical devices of a multi-GPU node (no logical mapping)."""
+    if im.device_count() < 2:
+        pytest.skip("needs two physical GPUs")
+    report = _run_spread_worker(8192, {"MAGICK_HIP_SPREAD_BYTES": str(256 << 20)})
+    assert report["mismatches"] == [], report
+    assert report["accelerated"] == 3 and report["devices"] == im.device_count(), report
+    assert sum(1 for b in report["bands"] if b > 0) >= 2, report
 
 
 def test_eight_threads_on_two_physical_gpus(shim, im):

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Round 4: gpurun_out/profiles_<tag>/ (tools/collect_profiles_r4.sh) -> profiles/<tag>_*.csv,
+"""Rounds 4-5: gpurun_out/profiles_<tag>/ (tools/collect_profiles.sh) -> profiles/<tag>_*.csv,
 profiles/pmc_traffic.json, profiles/<tag>_sq_counters.json.  Same files and unit corrections as
 tools/import_profiles_r3.py, plus the round's kernel: blur_fused_hybrid (FAST BlurImage: f16 colour
-sums + exact alpha sums), and round 3's FAST form as `r3fast`."""
+sums + exact alpha sums) and round 5's one-launch resize kernels (resize_stream, resize_mfma)."""
 import csv
 import glob
 import json
@@ -13,8 +13,10 @@ from collections import defaultdict
 import import_profiles_r2 as base
 import import_profiles_r3 as r3  # noqa: F401  (registers round 3's labels on base)
 
-base.LABELS = [(r"blur_fused_hybrid_kernel", "blur_fused_hybrid")] + base.LABELS
-base.PREFIX = {"fast": "", "exact": "", "r3fast": "", "hdri": "hdri:", "resize": "", "c4": "c4:", "c5": "c5:"}
+base.LABELS = [(r"blur_fused_hybrid_kernel", "blur_fused_hybrid"),
+               (r"resize_stream_careful", "resize_stream_careful"), (r"resize_stream", "resize_stream"),
+               (r"resize_mfma", "resize_mfma")] + base.LABELS
+base.PREFIX = {"fast": "", "exact": "", "hdri": "hdri:", "resize": "", "c4": "c4:", "c5": "c5:"}
 
 
 def sq_counters(tag):
