@@ -927,7 +927,34 @@ def shim_measurements(n, sigma, host):
                          "devices": [{"calls": c, "streams": s} for c, s in mc.device_statistics()],
                          "errors": errors}
     out["shim_accelerated_calls"] = mc.accelerated_calls() - before
+    # ONE big host-resident image (BASELINE configs[4] through the boundary): the row bands of the frame
+    # round every device, against the reference's one device per call.  Subprocesses: the shim lists its
+    # devices when it starts.  (On a one-GPU box the logical devices share one host link: the row shows
+    # the path, not the gain of several links.)
+    try:
+        import subprocess
+        physical = torch_device_count()
+        logical = max(2, physical)
+        rows = {}
+        for label, env_extra in (("one_device_per_call", {"MAGICK_HIP_SPREAD_BYTES": str(1 << 60)}),
+                                 ("spread_over_devices", {"MAGICK_HIP_SPREAD_BYTES": str(256 << 20),
+                                                          "MAGICKHIP_LOGICAL_DEVICES": str(logical)})):
+            env = dict(os.environ, **env_extra)
+            done = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shim_spread_bench.py"), "8192"],
+                                  env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+            rows[label] = (json.loads(done.stdout.strip().splitlines()[-1]) if done.returncode == 0
+                           else {"error": done.stderr[-300:]})
+        out["shim_sharded"] = {"workload": "8192x8192 RGBA Q16, source on the host, result read on the host: MagickCore's "
+                                           "MorphologyImage(Dilate, Disk:15), BlurImage(0x10), EqualizeImage",
+                               "physical_devices": physical, "logical_devices": logical, **rows}
+    except Exception as exc:                              # noqa: BLE001
+        out["shim_sharded"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     return out
+
+
+def torch_device_count():
+    import torch
+    return torch.cuda.device_count()
 
 
 # ------------------------------------------------------------------ N-rank configurations

@@ -41,6 +41,8 @@ def load(hdri=False):
     L.ref_colorspace.argtypes = [vp, cp, pd]
     L.ref_contrast_stretch.argtypes = [vp, dbl, dbl, pd]
     L.ref_equalize.argtypes = [vp, pd]
+    L.ref_morphology.restype = vp
+    L.ref_morphology.argtypes = [vp, cp, ctypes.c_long, cp, pd]
     L.shim_image_sync.argtypes = [vp]
     L.shim_image_touch.argtypes = [vp]
     L.shim_image_pixels.restype = vp
@@ -81,6 +83,19 @@ class Image:
         if not h:
             raise RuntimeError("BlurImage failed")
         return Image(handle=h, lib=self.L)
+
+    def morphology(self, method, iterations, kernel):
+        t = ctypes.c_double(0.0)
+        h = self.L.ref_morphology(self.handle, method.encode(), iterations, kernel.encode(), ctypes.byref(t))
+        if not h:
+            raise RuntimeError("MorphologyImage failed")
+        return Image(handle=h, lib=self.L)
+
+    def equalize(self):
+        t = ctypes.c_double(0.0)
+        if self.L.ref_equalize(self.handle, ctypes.byref(t)) != 0:
+            raise RuntimeError("EqualizeImage failed")
+        return self
 
     def colorspace(self, name):
         t = ctypes.c_double(0.0)

@@ -1819,7 +1819,6 @@ def test_equalize_float_frame_from_running_counts(im, refmod, background, counts
 
 
 @pytest.mark.parametrize("dtype", [Q16, HDRI])
-@pytest.mark.parametrize("dtype", [Q16, HDRI])
 @pytest.mark.parametrize("alpha", [True, False])
 @pytest.mark.parametrize("shape,target,filt", [
     ((37, 53, 4), (212, 148), "Lanczos"), ((64, 300, 4), (1200, 256), "Lanczos"),
