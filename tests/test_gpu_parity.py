@@ -2237,6 +2237,8 @@ def test_operators_are_reentrant_across_threads_and_streams(im, refmod):
     dev = im.Image(to_device(jobs[1][0]), precision=im.PRECISION_EXACT)
     im.set_precision(im.PRECISION_FAST)
     try:
-        assert set(bench.kernel_profile(im, lambda: im.blur_image(dev, 0.0, 3.0), 1)) == {"blur_fused_exact"}
+        # (+ the two fp64 passes queued behind the exact kernel for the frames it gives up: empty here)
+        launched = set(bench.kernel_profile(im, lambda: im.blur_image(dev, 0.0, 3.0), 1))
+        assert "blur_fused_exact" in launched and launched <= {"blur_fused_exact", "conv_row", "conv_column"}, launched
     finally:
         im.set_precision(im.PRECISION_EXACT)
