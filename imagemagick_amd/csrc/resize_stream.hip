@@ -184,7 +184,11 @@ void resize_stream_careful_kernel(StreamResizeArgs a,int f)
 
 template<typename Q,bool BLEND,int F,int NT,int ROWS>
 // three waves a SIMD (at most 168 registers); two for the eight-row window of a 3x / 4x enlargement
+#ifdef MH_STREAM_WAVES2
+__global__ __launch_bounds__(256,2)
+#else
 __global__ __launch_bounds__(256,((ROWS == 8) && (F >= 3)) ? 2 : 3)
+#endif
 void resize_stream_kernel(StreamResizeArgs a)
 {
   constexpr bool kFloat=QuantumOps<Q>::is_float;
@@ -368,10 +372,16 @@ void resize_stream_kernel(StreamResizeArgs a)
         const bool keep=(((really ? keep_mask[j] : 0ull) >> lane) & 1ull) != 0ull;
         const unsigned char *at=kSteps ? xfrom[0]+(64/F)*j*PX : xfrom[kSteps ? 0 : j];
         const unsigned offset=keep ? (kSteps ? store_offset[0]+(unsigned) (64*j*PX) : store_offset[kSteps ? 0 : j]) : 0xffffffffu;
+        // (A/B builds: -DMH_STREAM_NT stores non-temporally)
+#ifdef MH_STREAM_NT
+        constexpr int kAux=2;
+#else
+        constexpr int kAux=0;
+#endif
         if constexpr (PX == 16)
-          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const words4 *>(at),drow,offset,0,0);
+          __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const words4 *>(at),drow,offset,0,kAux);
         else
-          __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const words2 *>(at),drow,offset,0,0);
+          __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const words2 *>(at),drow,offset,0,kAux);
       }
   };
 
