@@ -319,11 +319,6 @@ MhStatus launch_resize_pass(const View &src,const View &dst,bool vertical,
 MhStatus launch_resize_fused(const View &src,const View &dst,const TapTable &vertical,
   const TapTable &horizontal,const Roles &roles,MhPrecision precision,bool *handled);
 
-// Erode / Dilate with a large symmetric convex flat kernel on a Q16 frame: running row maxima and a
-// walk down the frame (morphology_walk.hip); half[k] = half-width of kernel row dy_min+k
-MhStatus launch_morph_walk(const View &src,const View &dst,bool dilate,const std::vector<int> &half,
-  int cx,int dy_min,const Roles &roles,unsigned long long *changed,bool *handled);
-
 // the FAST one-launch enlargement on the fp64 matrix pipe (resize_mfma.hip)
 MhStatus launch_resize_mfma(const View &src,const View &dst,const TapTable &vertical,
   const TapTable &horizontal,const Roles &roles,bool *handled);

@@ -1425,10 +1425,6 @@ static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std:
         return MH_OK;
     }
   const int hmax=half[(size_t) vmax];
-  // large kernels on Q16 frames: the walk with running row maxima (morphology_walk.hip)
-  MH_TRY(launch_morph_walk(src,dst,dilate,half,cx,dy_min,roles,changed,handled));
-  if (*handled)
-    return MH_OK;
   // a lane holds one (16-byte pixels) or two columns, a wave 64 or 128 (morph_rects_kernel)
   const size_t pixel_bytes=(size_t) src.channels*(is_float ? sizeof(float) : sizeof(uint16_t));
   const int lane_columns=pixel_bytes >= 16 ? 1 : 2;
