@@ -1260,6 +1260,14 @@ MH_API MhStatus MagickHipResizeImageWithFilter(const MhImage *image,MhImage *res
   Roles roles=channel_roles(image,resize_image);
   View filter_view=pair.src.view;
   Temp scratch;
+  // The first filter's result is ROUNDED to a Quantum and feeds the second: it runs in the
+  // reference's own operation order in either mode.  (FAST's fused sums differ by ~1e-10 level —
+  // enough to flip a value that sits on a rounding boundary, and polynomial filters over small
+  // integers put whole families of sums exactly there; one level of a small intermediate alpha is
+  // thousands of levels of the colours the second filter weights with it.  tests/stress_parity.py
+  // found it.)  FAST belongs to the filter whose result leaves the operator; the one-launch forms
+  // below find such values themselves and recompute their rows (resize_acc.hpp).
+  const MhPrecision first_pass=MH_PRECISION_EXACT;
   if (x_factor > y_factor)
     {
       // HorizontalFilter then VerticalFilter, resize.c:3846-3853
@@ -1269,7 +1277,7 @@ MH_API MhStatus MagickHipResizeImageWithFilter(const MhImage *image,MhImage *res
       filter_view.pixels=scratch.ptr;
       auto horizontal=acquire_tap_table(filter,image->columns,columns,x_factor);
       auto vertical=acquire_tap_table(filter,image->rows,rows,y_factor);
-      MH_TRY(launch_resize_pass(pair.src.view,filter_view,false,*horizontal,roles,precision()));
+      MH_TRY(launch_resize_pass(pair.src.view,filter_view,false,*horizontal,roles,first_pass));
       MH_TRY(launch_resize_pass(filter_view,pair.dst.view,true,*vertical,roles,precision()));
     }
   else
@@ -1284,7 +1292,7 @@ MH_API MhStatus MagickHipResizeImageWithFilter(const MhImage *image,MhImage *res
           filter_view.rows=rows;
           MH_TRY(scratch.alloc(pair.src.view.device,filter_view.bytes(),pair.src.view.stream));
           filter_view.pixels=scratch.ptr;
-          MH_TRY(launch_resize_pass(pair.src.view,filter_view,true,*vertical,roles,precision()));
+          MH_TRY(launch_resize_pass(pair.src.view,filter_view,true,*vertical,roles,first_pass));
           MH_TRY(launch_resize_pass(filter_view,pair.dst.view,false,*horizontal,roles,precision()));
         }
     }

@@ -2285,7 +2285,9 @@ void composite_kernel(Q *__restrict__ canvas,const Q *__restrict__ source,size_t
 #pragma unroll
       for (int c=0; c < C; c++)
         {
-          if ((c == alpha_index) && (((update_mask >> c) & 1u) != 0))
+          // CompositeOverImage sets the alpha channel whatever its trait says, Update or Copy
+          // (composite.c:1096-1104): `-channel RGB` does not keep the merged alpha out
+          if ((c == alpha_index) && ((OP == COMPOSITE_OVER) || (((update_mask >> c) & 1u) != 0)))
             {
               // composite.c:2580-2712 (Multiply with synchronised channels: the default case)
               const double pixel=OP == COMPOSITE_DIFFERENCE ? kQR*fabs(Sa-Da) : kQR*alpha;

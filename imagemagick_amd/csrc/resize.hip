@@ -802,7 +802,12 @@ MhStatus launch_resize_pass(const View &src,const View &dst,bool vertical,
   // pass cannot keep the +-1 contract.  FAST selects the fused-multiply-add fp64
   // policy (Fma64), whose intermediate differs from the CPU's only when a value
   // lies within ~1e-11 of a rounding boundary.
-  if (prec == MH_PRECISION_FAST)
+  // (operators.cpp hands FAST to the SECOND filter only: the first one's result is rounded and
+  // feeds it.)  Alpha-weighted channels keep the reference's order in the second filter too: where
+  // the alpha sum cancels to nearly nothing the quotient — or PerceptibleReciprocal's clamp, a
+  // factor of 1.5e7 — turns the last bits of the sums into whole levels, and these kernels have no
+  // way back to the taps of a single output (the one-launch forms recompute such rows).
+  if ((prec == MH_PRECISION_FAST) && !(roles.blend && (roles.alpha == src.channels-1)))
     {
       if (src.quantum == MH_QUANTUM_U16)
         return dispatch<uint16_t,Fma64>(src,dst,vertical,table,roles);

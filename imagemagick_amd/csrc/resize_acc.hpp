@@ -136,4 +136,203 @@ struct ResizeAcc
   }
 };
 
+// ---- what the one-launch FAST kernels (resize_stream.hip, resize_mfma.hip) need to know about a
+// pixel of the INTERMEDIATE.  Their fused sums differ from the reference's separately rounded ones
+// by ~1e-10 level — but the intermediate is ROUNDED, and where the exact value sits on a rounding
+// boundary the last bits decide the level.  That is not a curiosity: polynomial filters at
+// rational positions (Triangle, Box, Catrom ...) over small integers put whole families of sums
+// exactly on x.5, and an intermediate ALPHA one level off moves the second filter's alpha-weighted
+// colours by thousands of levels where alpha is a few levels (tests/stress_parity.py found it).
+// A value closer to a boundary than the two summation orders can differ is reported, and the few
+// rows that hold it are recomputed in the reference's own operation order (resize_redo_rect).
+//
+// How far the orders can differ: a sum of K <= 8 terms, fused against the reference's 2K+3
+// separately rounded operations: 6e-15 * sum|terms|.  A plain sum of Q16 levels: 8e-10 level.  An
+// alpha-weighted colour is a quotient S_c/S_a: 65535 * 6e-15 * A with A = sum|w*alpha| / |S_a|,
+// and sum|w*alpha| <= 1.6 * 65535 for every filter of resize.c: 4.1e-5 / |S_a| level — the window
+// widens with the reciprocal of the alpha sum, which the finish has at hand.  (A fixed window with
+// a branch for small alpha sums cost more: on a frame of random alpha every other wave took the branch.)
+template<typename Q>
+struct TieWatch
+{
+  static constexpr bool kFloat=QuantumOps<Q>::is_float;
+  // Half-widths, in the tail's units.  Q16: value + 0.5 + 2^28 has its last place at 2^-24; its low
+  // word shifted left by 8 is the fraction of value + 0.5 as a 32-bit fixed-point number (rounded to
+  // 2^-24): units of 2^-32 level; the plain window is 1.5 * 2^-24 = 9e-8 level (values the clamp
+  // decides leave the binade: whatever their bits say is harmless).  float: (Quantum) value keeps
+  // 24 of the 53 significant bits, a tie is a tail of 29 bits at one half: units of the double's
+  // last place; the plain window is 2^8 of them = 5.7e-14 relative (sum|terms| up to ten times |sum|).
+  static constexpr unsigned kPlain=kFloat ? 0x100u : 0x180u;
+  static constexpr unsigned kWidest=kFloat ? 0x08000000u : 0x40000000u;
+  unsigned bias,twice;
+  __device__ __forceinline__ void set(unsigned half)
+  {
+    bias=kFloat ? half-0x10000000u : half;
+    twice=2u*half;
+  }
+  __device__ __forceinline__ void plain() { set(kPlain); }
+  // r = the reciprocal of the alpha sum: 4.12e-5 * |r| level = 176950 * |r| units (Q16);
+  // 6.3e-10 * |r| relative <= 5.7e6 * |r| units (float) — on top of the plain window
+  __device__ __forceinline__ void quotient(double r)
+  {
+    const double wide=kFloat ? __builtin_fma(5.7e6,__builtin_fabs(r),256.0) : __builtin_fma(176950.0,__builtin_fabs(r),384.0);
+    unsigned half=(unsigned) wide;               // (v_cvt_u32_f64 saturates)
+    set(half < kWidest ? half : kWidest);
+  }
+  __device__ __forceinline__ bool near(double v) const
+  {
+    if constexpr (kFloat)
+      return (((unsigned) __double2loint(v) & 0x1fffffffu)+bias) <= twice;
+    else
+      return (((unsigned) __double2loint(v+268435456.5) << 8)+bias) <= twice;
+  }
+};
+
+// an alpha sum of the SECOND filter below this many levels: the quotient's error (4.1e-5 / |S_a|
+// level) is no longer a small fraction of a level.  Where PerceptibleReciprocal's clamp acts (either
+// filter) the sums are multiplied by QuantumScale/MagickEpsilon = 1.5e7 instead: what cancelled under
+// the window to (nearly) nothing is noise of thousands of levels, in the reference's order or in any
+// other — unless every sum is an exact zero (a window of transparent pixels), the pixel is reported.
+constexpr double kOutputAlphaLimit=1.0e-3;
+static __device__ __forceinline__ bool clamped_sums_count(const double (&s)[4])
+{
+  return (s[0] != 0.0) || (s[1] != 0.0) || (s[2] != 0.0) || (s[3] != 0.0);    // (a NaN counts)
+}
+// (Over-cautious where the clamp acts on sums of rounding zeros — a sinc at a whole number, 1e-13,
+// times any alpha: a 3x enlargement has one output in three whose window is (0 .. 0, 1, 0 .. 0), and over
+// a transparent centre pixel beside opaque ones its sums are 1e-8 and both orders agree on them.  Telling
+// the two cases apart needs sum|w*alpha|, which cost the walk registers it does not have: such rows are
+// recomputed too.)
+
+
+// The reference's two filters over one rectangle of the output (VerticalFilter, then
+// HorizontalFilter: the one-launch kernels' order), tap by tap in the reference's own operation
+// order (Exact64; resize.c:3494-3530, :3709-3745), every sample multiplied only inside its
+// output's window.  The whole workgroup calls it; `scratch` is workgroup-shared memory of
+// `scratch_bytes` for the rectangle's intermediate (blocks of rows x columns that fit).  Ends
+// behind a barrier.
+struct RedoTables
+{
+  const int *vstart,*vcount,*hstart,*hcount;
+  const double *vweight,*hweight;              // [tap][out]
+  int src_columns,dst_columns,dst_rows;
+};
+
+// MAXT > 0: no contribution list is longer (the caller's plan has checked) — a thread then has the
+// loads of all taps of GROUP samples in flight together: the rectangles are small, a redo is a
+// chain of memory round trips, and the fewer of them the sooner the workgroup is gone.
+template<typename Q,bool BLEND,int MAXT>
+static __device__ __noinline__ void resize_redo_rect(const RedoTables &t,const Q *src,Q *dst,int x0,int x1,int y0,int y1,
+  unsigned char *scratch,int scratch_bytes)
+{
+  constexpr int PXB=4*(int) sizeof(Q);
+  constexpr int XC=256;                         // output columns per block
+  constexpr int TB=MAXT > 0 ? MAXT : 4;         // taps whose loads are in flight together
+  constexpr int GROUP=MAXT > 0 ? 2 : 1;         // samples of a thread in flight together
+  const int tid=(int) threadIdx.x,nthreads=(int) blockDim.x;
+  Q *inter=reinterpret_cast<Q *>(scratch);
+  // one filter over `count` samples: sample i reads taps start[i] .. of `from(i)` with the weights
+  // weight[tap*pitch+index(i)] and hands its pixel to put(i, pixel)
+  auto filter=[&](int count,auto geometry,auto put)
+  {
+    for (int i0=tid; i0 < count; i0+=GROUP*nthreads)
+      {
+        const Q *from[GROUP];
+        const double *weights[GROUP];
+        size_t step[GROUP],pitch[GROUP];
+        int taps[GROUP];
+#pragma unroll
+        for (int g=0; g < GROUP; g++)
+          {
+            const int i=i0+g*nthreads < count ? i0+g*nthreads : i0;
+            geometry(i,from[g],step[g],weights[g],pitch[g],taps[g]);
+          }
+        int longest=0;
+#pragma unroll
+        for (int g=0; g < GROUP; g++)
+          longest=taps[g] > longest ? taps[g] : longest;
+        ResizeAcc<Q,4,BLEND,Exact64> acc[GROUP];
+#pragma unroll
+        for (int g=0; g < GROUP; g++)
+          acc[g].init();
+        for (int k0=0; k0 < longest; k0+=TB)
+          {
+            Q p[GROUP][TB][4];
+            double w[GROUP][TB];
+#pragma unroll
+            for (int g=0; g < GROUP; g++)
+#pragma unroll
+              for (int k=0; k < TB; k++)
+                {
+                  const int kk=k0+k < taps[g] ? k0+k : taps[g]-1;
+                  load_pixel<Q,4>(from[g]+(size_t) kk*step[g],p[g][k]);
+                  w[g][k]=weights[g][(size_t) kk*pitch[g]];
+                }
+#pragma unroll
+            for (int g=0; g < GROUP; g++)
+#pragma unroll
+              for (int k=0; k < TB; k++)
+                if (k0+k < taps[g])
+                  acc[g].tap(w[g][k],w[g][k]*kQS,p[g][k]);
+          }
+#pragma unroll
+        for (int g=0; g < GROUP; g++)
+          if (i0+g*nthreads < count)
+            {
+              Q copy[4]={(Q) 0,(Q) 0,(Q) 0,(Q) 0},q[4];
+              acc[g].finish(copy,0u,q);
+              put(i0+g*nthreads,q);
+            }
+      }
+  };
+  for (int xa=x0; xa < x1; )
+    {
+      int xb=xa+XC < x1 ? xa+XC : x1;
+      const int cs=t.hstart[xa];
+      // (contribution lists move right with the output: the last output's window ends last)
+      while ((xb > xa+1) && ((t.hstart[xb-1]+t.hcount[xb-1]-cs)*PXB > scratch_bytes))
+        xb--;
+      const int span=t.hstart[xb-1]+t.hcount[xb-1]-cs;
+      int rb=scratch_bytes/(span*PXB);
+      rb=rb < 1 ? 1 : rb;
+      for (int ya=y0; ya < y1; ya+=rb)
+        {
+          const int yb=ya+rb < y1 ? ya+rb : y1;
+          __syncthreads();                      // the previous block's readers
+          // VerticalFilter: the block's rows of the intermediate, columns cs .. cs+span-1
+          filter((yb-ya)*span,
+            [&](int i,const Q *&from,size_t &step,const double *&weights,size_t &pitch,int &taps)
+            {
+              const int r=i/span,y=ya+r;
+              from=src+((size_t) t.vstart[y]*(size_t) t.src_columns+(size_t) (cs+(i-r*span)))*4;
+              step=(size_t) t.src_columns*4;
+              weights=t.vweight+(size_t) y;
+              pitch=(size_t) t.dst_rows;
+              taps=t.vcount[y];
+            },
+            [&](int i,const Q (&q)[4]) { store_pixel<Q,4>(inter+(size_t) i*4,q); });
+          __syncthreads();
+          // HorizontalFilter out of it
+          const int w=xb-xa;
+          filter((yb-ya)*w,
+            [&](int i,const Q *&from,size_t &step,const double *&weights,size_t &pitch,int &taps)
+            {
+              const int r=i/w,x=xa+(i-r*w);
+              from=inter+((size_t) r*(size_t) span+(size_t) (t.hstart[x]-cs))*4;
+              step=4;
+              weights=t.hweight+(size_t) x;
+              pitch=(size_t) t.dst_columns;
+              taps=t.hcount[x];
+            },
+            [&](int i,const Q (&q)[4])
+            {
+              const int r=i/w;
+              store_pixel<Q,4>(dst+((size_t) (ya+r)*(size_t) t.dst_columns+(size_t) (xa+(i-r*w)))*4,q);
+            });
+        }
+      xa=xb;
+    }
+  __syncthreads();
+}
+
 } // namespace mh

@@ -28,7 +28,11 @@
 // Zero-weight padding multiplies samples outside an output's window by 0, which is exact unless
 // a sample is not finite: a float frame's patch is watched while it is staged and a workgroup
 // step that holds a non-finite (or huge, see not_tame_f32) sample computes its outputs tap by tap
-// in the reference's own windows instead (careful_step).
+// in the reference's own windows and operation order instead (resize_acc.hpp: resize_redo_rect).
+// So does, after the fact, a step in which an intermediate value lay on a rounding boundary or an
+// alpha sum was small enough for the quotient to amplify the sums' last bits (finish_pixel): the
+// intermediate is rounded, and one level of a small intermediate alpha is thousands of levels of
+// the colours HorizontalFilter weights with it.
 #include "mh_internal.hpp"
 #include "resize_filter.hpp"
 #include "resize_mfma_plan.hpp"
@@ -54,9 +58,10 @@ struct MfmaResizeArgs
   const double *wh;
   const int *rg_row_lo,*rg_nvk,*rg_woff;
   const double *wv;
-  // the contribution lists themselves (careful_step)
+  // the contribution lists themselves (resize_redo_rect)
   const int *vstart,*vcount,*hstart,*hcount;
   const double *vweight,*hweight;            // [tap][out]
+  unsigned patch_bytes;                      // of the source patch in LDS: resize_redo_rect's scratch
 };
 
 template<typename Q>
@@ -76,50 +81,45 @@ static __device__ __forceinline__ unsigned not_tame_f32(float v)
   return (__builtin_bit_cast(unsigned,v) & 0x7fffffffu) > 0x49800000u ? 1u : 0u;
 }
 
-// the four sums of one pixel -> the Quantum the reference stores
-template<typename Q,bool BLEND>
-static __device__ __forceinline__ void finish_pixel(double s0,double s1,double s2,double s3,Q (&q)[4])
+// the four sums of one pixel -> the Quantum the reference stores (ResizeAcc<Fma64>::finish), and
+// whether the fused sums can vouch for it (resize_acc.hpp: TIES, the intermediate: a value too close
+// to a rounding boundary; the outputs: an alpha sum so small that the quotient's error counts)
+template<typename Q,bool BLEND,bool TIES>
+static __device__ __forceinline__ bool finish_pixel(double s0,double s1,double s2,double s3,Q (&q)[4])
 {
-  ResizeAcc<Q,4,BLEND,Fma64> f;
-  f.s[0]=s0; f.s[1]=s1; f.s[2]=s2; f.s[3]=s3;
-  f.g=0.0;
-  Q copy[4]={(Q) 0,(Q) 0,(Q) 0,(Q) 0};
-  f.finish(copy,0u,q);
-}
-
-// One workgroup step recomputed tap by tap, every sample multiplied only inside its output's
-// window (resize.c:3494-3530 twice), from global memory: the rare path of a float frame.
-template<typename Q,bool BLEND>
-static __device__ __forceinline__ void careful_step(const MfmaResizeArgs &a,int x0,int x1,int y0,int y1)
-{
-  const Q *src=static_cast<const Q *>(a.src);
-  Q *dst=static_cast<Q *>(a.dst);
-  const int w=x1-x0,n=w*(y1-y0);
-  for (int i=(int) threadIdx.x; i < n; i+=(int) blockDim.x)
+  double v[4]={s0,s1,s2,s3};
+  bool doubt=false;
+  TieWatch<Q> plain,colour;
+  plain.plain();
+  colour.plain();
+  if constexpr (BLEND)
     {
-      const int y=y0+i/w,x=x0+i%w;
-      const int hs=a.hstart[x],hc=a.hcount[x];
-      const int vs=a.vstart[y],vc=a.vcount[y];
-      ResizeAcc<Q,4,BLEND,Fma64> h;
-      h.init();
-      for (int j=0; j < hc; j++)
+      const double sa=s3;
+      const double mag=sa < 0.0 ? -sa : sa;
+      double r=__builtin_amdgcn_rcp(sa);
+      double e=__builtin_fma(-sa,r,1.0);
+      r=__builtin_fma(r,e,r);
+      e=__builtin_fma(-sa,r,1.0);
+      r=__builtin_fma(r,e,r);
+      const double clamped=(sa < 0.0 ? -kInvEps : kInvEps)*kQS;
+      const bool divides=(mag*kQS) >= kEps;
+      const double inv=divides ? r : clamped;
+      v[0]=s0*inv; v[1]=s1*inv; v[2]=s2*inv;
+      if constexpr (TIES)
         {
-          ResizeAcc<Q,4,BLEND,Fma64> v;
-          v.init();
-          for (int k=0; k < vc; k++)
-            {
-              Q p[4];
-              load_pixel<Q,4>(src+((size_t) (vs+k)*(size_t) a.src_columns+(size_t) (hs+j))*4,p);
-              v.tap(a.vweight[(size_t) k*(size_t) a.dst_rows+(size_t) y],0.0,p);
-            }
-          Q copy[4]={(Q) 0,(Q) 0,(Q) 0,(Q) 0},q[4];
-          v.finish(copy,0u,q);
-          h.tap(a.hweight[(size_t) j*(size_t) a.dst_columns+(size_t) x],0.0,q);
+          if (divides)
+            colour.quotient(r);
         }
-      Q copy[4]={(Q) 0,(Q) 0,(Q) 0,(Q) 0},out[4];
-      h.finish(copy,0u,out);
-      store_pixel<Q,4>(dst+((size_t) y*(size_t) a.dst_columns+(size_t) x)*4,out);
+      else
+        doubt=divides && (mag < kOutputAlphaLimit);
+      doubt=doubt || (!divides && clamped_sums_count(v));
     }
+#pragma unroll
+  for (int c=0; c < 4; c++)
+    q[c]=QuantumOps<Q>::clamp(v[c]);
+  if constexpr (TIES)
+    doubt=doubt || colour.near(v[0]) || colour.near(v[1]) || colour.near(v[2]) || plain.near(v[3]);
+  return doubt;
 }
 
 // the matrix chain of one out tile whose first K-block sits in ring slot S0: straight-line code
@@ -151,6 +151,7 @@ void resize_mfma_kernel(MfmaResizeArgs a)
   double *wvlds=reinterpret_cast<double *>(smem_raw+a.wlds_bytes+a.meta_bytes);   // [WAVES][nvk_max][64]
   float4 *patch=reinterpret_cast<float4 *>(smem_raw+a.wlds_bytes+a.meta_bytes+a.wv_bytes);
   __shared__ int flag[2];
+  __shared__ int redo[2];                    // a step of this parity met a value the fused sums cannot vouch for
 
   // workgroup -> (strip, chunk of steps).  Block b runs on XCD b%8: give an XCD a contiguous set
   // of strips so that neighbouring strips' shared source columns meet in one L2.
@@ -180,8 +181,23 @@ void resize_mfma_kernel(MfmaResizeArgs a)
     for (int i=tid; i <= a.tps; i+=THREADS)
       tmeta[i]=i < strip_tiles ? a.tile_meta[strip*a.tps+i] : 0xff00u;        // sentinel: never ready
     if (tid < 2)
-      flag[tid]=0;
+      flag[tid]=redo[tid]=0;
   }
+  RedoTables tables;
+  tables.vstart=a.vstart; tables.vcount=a.vcount; tables.hstart=a.hstart; tables.hcount=a.hcount;
+  tables.vweight=a.vweight; tables.hweight=a.hweight;
+  tables.src_columns=a.src_columns; tables.dst_columns=a.dst_columns; tables.dst_rows=a.dst_rows;
+  // the outputs of the step that began at row group rg0, again, in the reference's own operation
+  // order and windows (the patch is free between two steps: the rectangle's intermediate goes there)
+  auto redo_step=[&](int rg0)
+  {
+    const int x0=strip*a.tps*16;
+    int x1=x0+a.tps*16,y1=16*rg0+16*WAVES;
+    x1=x1 < a.dst_columns ? x1 : a.dst_columns;
+    y1=y1 < a.dst_rows ? y1 : a.dst_rows;
+    resize_redo_rect<Q,BLEND,0>(tables,src,dst,x0,x1,16*rg0,y1,reinterpret_cast<unsigned char *>(patch),(int) a.patch_bytes);
+  };
+  int previous_rg0=-1,last_parity=0;
   // a staging thread keeps its patch column and walks rows
   const int stage_r0=tid/pc,stage_i=tid-stage_r0*pc;
   const int stage_rows=THREADS/pc;           // rows one sweep of the workgroup covers (pc <= THREADS)
@@ -212,6 +228,13 @@ void resize_mfma_kernel(MfmaResizeArgs a)
       const int rrow=a.rg_row_lo[rgc]-prow_lo,nvk=a.rg_nvk[rgc];
       const double *wvp=a.wv+(size_t) a.rg_woff[rgc]*64+lane;
       __syncthreads();                       // the previous step's readers are done (weights staged)
+      if ((previous_rg0 >= 0) && (redo[(step+1) & 1] != 0))
+        {
+          redo_step(previous_rg0);
+          if (tid == 0)
+            redo[(step+1) & 1]=0;              // (written again two steps on)
+        }
+      previous_rg0=rg0;
       for (int kb=0; kb < nvk; kb++)         // the wave's own weight blocks, beside the patch
         wvmine[kb*64]=wvp[kb*64];
       {
@@ -250,15 +273,10 @@ void resize_mfma_kernel(MfmaResizeArgs a)
             flag[(step+1) & 1]=0;            // nobody reads the other word between these barriers
         }
       if (careful)
-        {
-          const int x0=strip*a.tps*16;
-          int x1=x0+a.tps*16,y1=16*rg0+16*WAVES;
-          x1=x1 < a.dst_columns ? x1 : a.dst_columns;
-          y1=y1 < a.dst_rows ? y1 : a.dst_rows;
-          careful_step<Q,BLEND>(a,x0,x1,16*rg0,y1);
-        }
+        redo_step(rg0);                        // (the patch holds samples that are not tame: nobody multiplies them by a zero)
       else if (active)
         {
+          unsigned long long doubt=0ull;
           double ring[8][4];
 #pragma unroll
           for (int s=0; s < 8; s++)
@@ -305,7 +323,7 @@ void resize_mfma_kernel(MfmaResizeArgs a)
               for (int r=0; r < 4; r++)
                 {
                   Q q[4];
-                  finish_pixel<Q,BLEND>(acc[0][r],acc[1][r],acc[2][r],acc[3][r],q);
+                  doubt|=__builtin_amdgcn_ballot_w64(finish_pixel<Q,BLEND,true>(acc[0][r],acc[1][r],acc[2][r],acc[3][r],q));
                   if constexpr (BLEND)
                     {
                       const double qa=(double) q[3];
@@ -348,15 +366,21 @@ void resize_mfma_kernel(MfmaResizeArgs a)
                   for (int r=0; r < 4; r++)
                     {
                       Q out[4];
-                      finish_pixel<Q,BLEND>(o[0][r],o[1][r],o[2][r],o[3][r],out);
+                      doubt|=__builtin_amdgcn_ballot_w64(finish_pixel<Q,BLEND,false>(o[0][r],o[1][r],o[2][r],o[3][r],out));
                       const int y=y_base+4*r;
                       if ((x < a.dst_columns) && (y < a.dst_rows))
                         store_pixel<Q,4>(dst+((size_t) y*(size_t) a.dst_columns+(size_t) x)*4,out);
                     }
                 }
             }
+          if (doubt != 0ull)
+            redo[step & 1]=1;                  // settled behind the next barrier
         }
+      last_parity=step & 1;
     }
+  __syncthreads();
+  if ((previous_rg0 >= 0) && (redo[last_parity] != 0))
+    redo_step(previous_rg0);
 }
 
 // ------------------------------------------------------------------ host side
@@ -479,6 +503,7 @@ static MhStatus launch_mfma_typed(const View &src,const View &dst,const MfmaPlan
   a.meta_bytes=(unsigned) mfma_meta_bytes(p);
   a.wv_bytes=(unsigned) mfma_wv_bytes(p);
   a.nvk_max=p.nvk_max;
+  a.patch_bytes=(unsigned) ((size_t) p.patch_rows_max*(size_t) (16*p.nvb_max)*16u);
   a.strip_col_lo=t.at<int>(d.i_col_lo); a.strip_nvb=t.at<int>(d.i_nvb); a.strip_wbase=t.at<int>(d.i_wbase);
   a.strip_wcount=t.at<int>(d.i_wcount); a.tile_meta=t.at<unsigned>(d.i_meta);
   a.wh=t.at<double>(d.i_wh);

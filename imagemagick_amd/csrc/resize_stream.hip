@@ -29,15 +29,23 @@
 //               writes 64 consecutive pixels
 // Semantics are resize.c:3494-3530 / :3709-3745 with the derived gamma of the Fma64 policy
 // (resize_acc.hpp): colour = sum(w*alpha*p) / sum(w*alpha), alpha = sum(w*alpha).
-// A float frame's samples are watched while they enter the window: zero-weight padding multiplies
-// samples outside an output's window by 0, which is exact unless a sample is not finite — a wave
-// that meets such a sample flags its item, and a second (normally empty) launch recomputes the
-// flagged items tap by tap in the reference's own windows (resize_stream_careful_kernel).
+// What the fused sums cannot vouch for is recomputed: a second (normally empty) launch redoes the
+// flagged items (a wave's strip x chunk of rows) in the reference's own operation order and
+// windows (resize_stream_careful_kernel).  A wave flags its item when
+//   * an intermediate value lies on a rounding boundary (the reference's last bits decide the
+//     level, and one level of a small intermediate alpha is thousands of levels of the colours the
+//     second filter weights with it: Triangle / Box / Catrom over small integers produce exact
+//     x.5 sums in families), or an alpha sum of either filter is small enough for the quotient to
+//     amplify the sums' last bits (resize_acc.hpp);
+//   * a float frame's sample is not finite or huge: zero-weight padding multiplies samples outside
+//     an output's window by 0, which is exact only for finite samples.
 #include "mh_internal.hpp"
 #include "resize_filter.hpp"
 #include "resize_stream_plan.hpp"
 #include "device_common.hpp"
 #include "resize_acc.hpp"
+#include <cstdio>
+#include <vector>
 #include <memory>
 #include <mutex>
 #include <type_traits>
@@ -57,7 +65,8 @@ struct StreamResizeArgs
   const double *vdense;
   const int *vstart,*vcount,*hstart,*hcount;
   const double *vweight,*hweight;            // [tap][out]
-  unsigned *wild_items;                      // [strips*chunks], float frames: the items whose rows are redone
+  unsigned *wild_items;                      // [strips*chunks]: bit b = the item's rows b << mark_shift .. are redone
+  int mark_shift;
   const double *listed;                      // [2*kListed][kMaxDense]: the listed columns' dense weights
 };
 
@@ -88,35 +97,46 @@ static __device__ __forceinline__ void finish_sums(const double (&s)[4],Q (&q)[4
 // 46, enough for a result that is rounded to a float or a Q16 level once; the intermediate, whose
 // rounding the horizontal sums amplify, keeps the two steps of resize_acc.hpp) and the rare case —
 // PerceptibleReciprocal's clamp acts, or the alpha sum is not a number — sent down resize_acc.hpp's
-// own arithmetic in a branch instead of through selects in every lane.
-template<typename Q,bool BLEND,int NEWTON>
-static __device__ __forceinline__ void finish_fast(const double (&s)[4],Q (&q)[4])
+// own arithmetic in a branch instead of through selects in every lane.  `doubt` collects the lanes
+// whose value the fused sums cannot vouch for (a lane mask in scalar registers: no vector register
+// across the walk): TIES (the intermediate) a value too close to a rounding boundary (resize_acc.hpp,
+// TieWatch); the outputs: an alpha sum so small that the quotient's error is no longer negligible.
+template<typename Q,bool BLEND,int NEWTON,bool TIES>
+static __device__ __forceinline__ void finish_fast(const double (&s)[4],Q (&q)[4],unsigned long long &doubt)
 {
-  if constexpr (!BLEND)
-    {
-#pragma unroll
-      for (int c=0; c < 4; c++)
-        q[c]=QuantumOps<Q>::clamp(s[c]);
-    }
-  else
+  double r=1.0;
+  TieWatch<Q> plain,colour;
+  plain.plain();
+  colour.plain();
+  if constexpr (BLEND)
     {
       const double sa=s[3];
       if (__builtin_expect(!((__builtin_fabs(sa)*kQS) >= kEps),0))
         {
           finish_sums<Q,BLEND>(s,q);
+          doubt|=__builtin_amdgcn_ballot_w64(clamped_sums_count(s));
           return;
         }
-      double r=__builtin_amdgcn_rcp(sa);
+      r=__builtin_amdgcn_rcp(sa);
 #pragma unroll
       for (int i=0; i < NEWTON; i++)
         {
           const double e=__builtin_fma(-sa,r,1.0);
           r=__builtin_fma(r,e,r);
         }
+      if constexpr (TIES)
+        colour.quotient(r);
+      else
+        doubt|=__builtin_amdgcn_ballot_w64(__builtin_fabs(sa) < kOutputAlphaLimit);
+    }
+  // (a value, its level, its verdict: one channel after the other — the kernels sit at their register limit)
 #pragma unroll
-      for (int c=0; c < 3; c++)
-        q[c]=QuantumOps<Q>::clamp(s[c]*r);
-      q[3]=QuantumOps<Q>::clamp(sa);
+  for (int c=0; c < 4; c++)
+    {
+      const double v=BLEND && (c < 3) ? s[c]*r : s[c];
+      q[c]=QuantumOps<Q>::clamp(v);
+      if constexpr (TIES)
+        doubt|=__builtin_amdgcn_ballot_w64(BLEND && (c < 3) ? colour.near(v) : plain.near(v));
     }
 }
 
@@ -137,57 +157,46 @@ static __device__ __forceinline__ void premultiplied(const Q (&q)[4],double (&v)
     }
 }
 
-// The items (strip x chunk of rows) in which resize_stream_kernel met a sample that is not tame,
-// tap by tap, every sample multiplied only inside its output's window (resize.c:3494-3530 twice),
-// from global memory: the rare path of a float frame.  One workgroup per item.
+// The items (strip x chunk of rows) resize_stream_kernel could not vouch for — a sample that is not
+// tame (float frames), an intermediate value on a rounding boundary, a small alpha sum — again, in
+// the reference's own operation order and windows (resize_acc.hpp: resize_redo_rect).  One
+// workgroup per item; it leaves at once when the item's flag is clear.
 template<typename Q,bool BLEND>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256,3)
 void resize_stream_careful_kernel(StreamResizeArgs a,int f)
 {
+  __shared__ __attribute__((aligned(16))) unsigned char scratch[12288];   // (a few rows of an item's intermediate: many workgroups a CU)
   const int item=(int) blockIdx.x;
-  if (a.wild_items[item] == 0u)
+  const unsigned marks=a.wild_items[item];
+  if (marks == 0u)
     return;
   const int chunk=item/a.strips,strip=item-chunk*a.strips;
-  const Q *src=static_cast<const Q *>(a.src);
-  Q *dst=static_cast<Q *>(a.dst);
   const int x0=f*a.strip_first[strip],x1=x0+f*a.strip_count[strip];
   const int y0=chunk*a.rows_per_chunk;
   int y1=y0+a.rows_per_chunk;
   y1=y1 < a.dst_rows ? y1 : a.dst_rows;
-  const int w=x1-x0,n=w*(y1-y0);
-  for (int i=(int) threadIdx.x; i < n; i+=(int) blockDim.x)
-    {
-      const int y=y0+i/w,x=x0+i%w;
-      const int vs=a.vstart[y],vc=a.vcount[y];
-      const int hs=a.hstart[x],hc=a.hcount[x];
-      ResizeAcc<Q,4,BLEND,Fma64> h;
-      h.init();
-      for (int j=0; j < hc; j++)
-        {
-          ResizeAcc<Q,4,BLEND,Fma64> v;
-          v.init();
-          for (int k=0; k < vc; k++)
-            {
-              Q p[4];
-              load_pixel<Q,4>(src+((size_t) (vs+k)*(size_t) a.src_columns+(size_t) (hs+j))*4,p);
-              v.tap(a.vweight[(size_t) k*(size_t) a.dst_rows+(size_t) y],0.0,p);
-            }
-          Q copy[4]={(Q) 0,(Q) 0,(Q) 0,(Q) 0},q[4];
-          v.finish(copy,0u,q);
-          h.tap(a.hweight[(size_t) j*(size_t) a.dst_columns+(size_t) x],0.0,q);
-        }
-      Q copy[4]={(Q) 0,(Q) 0,(Q) 0,(Q) 0},out[4];
-      h.finish(copy,0u,out);
-      store_pixel<Q,4>(dst+((size_t) y*(size_t) a.dst_columns+(size_t) x)*4,out);
-    }
+  RedoTables t;
+  t.vstart=a.vstart; t.vcount=a.vcount; t.hstart=a.hstart; t.hcount=a.hcount;
+  t.vweight=a.vweight; t.hweight=a.hweight;
+  t.src_columns=a.src_columns; t.dst_columns=a.dst_columns; t.dst_rows=a.dst_rows;
+  for (int b=0; b < 32; b++)
+    if (((marks >> b) & 1u) != 0u)
+      {
+        const int ya=y0+(b << a.mark_shift);
+        int yb=ya+(1 << a.mark_shift);
+        yb=yb < y1 ? yb : y1;
+        if (ya < yb)
+          resize_redo_rect<Q,BLEND,StreamResizePlan::kRows>(t,static_cast<const Q *>(a.src),static_cast<Q *>(a.dst),x0,x1,ya,yb,scratch,(int) sizeof(scratch));
+      }
 }
 
 template<typename Q,bool BLEND,int F,int NT,int ROWS>
-// three waves a SIMD (at most 168 registers); two for the eight-row window of a 3x / 4x enlargement
+// three waves a SIMD (at most 168 registers); two where that spills into the walk (a reload waits for
+// every store in flight): the eight-row window, and the seven-neighbour 3x enlargement of a float frame
 #ifdef MH_STREAM_WAVES2
 __global__ __launch_bounds__(256,2)
 #else
-__global__ __launch_bounds__(256,((ROWS == 8) && (F >= 3)) ? 2 : 3)
+__global__ __launch_bounds__(256,((ROWS == 8) || ((F == 3) && (NT == 7) && (sizeof(Q) == 4))) ? 2 : 3)
 #endif
 void resize_stream_kernel(StreamResizeArgs a)
 {
@@ -265,6 +274,7 @@ void resize_stream_kernel(StreamResizeArgs a)
   double win[ROWS][4];
   unsigned wild=0u;                            // bit j: window slot j holds a sample that is not tame
   unsigned seen=0u;
+  unsigned marks=0u;                           // blocks of rows in which a lane met a value the fused sums cannot vouch for (finish_fast)
   auto fetch=[&](int row,Q (&q)[4])
   {
     row=row < H-1 ? row : H-1;
@@ -348,9 +358,13 @@ void resize_stream_kernel(StreamResizeArgs a)
           s[k]=__builtin_fma(w,win[j][k],s[k]);
       }
     Q q[4];
-    finish_fast<Q,BLEND,2>(s,q);
+    unsigned long long doubt=0ull;
+    finish_fast<Q,BLEND,2,true>(s,q,doubt);
+    marks|=doubt != 0ull ? 1u << ((y-y0) >> a.mark_shift) : 0u;
     premultiplied<Q,BLEND>(q,iv);
   };
+  // the lanes whose source column is one of the strip's own: their F outputs are the ones stored
+  const unsigned long long own=__builtin_amdgcn_ballot_w64((lane >= -lo) && (lane < count-lo));
   // which lanes of store j hold a pixel of the strip: lane masks in scalar registers
   unsigned long long keep_mask[F];
 #pragma unroll
@@ -454,13 +468,16 @@ void resize_stream_kernel(StreamResizeArgs a)
             }
         }
       // ---- finish; the pixels go to the transposition buffer (read back in the next iteration)
+      unsigned long long doubt=0ull;
 #pragma unroll
       for (int p=0; p < F; p++)
         {
           Q out[4];
-          finish_fast<Q,BLEND,1>(h[p],out);
+          finish_fast<Q,BLEND,1,false>(h[p],out,doubt);
           store_pixel<Q,4>(reinterpret_cast<Q *>(xpose+p*XPLANE+lane*PX),out);
         }
+      // (the lanes beside the strip's own columns summed neighbours they do not have: their pixels are never stored)
+      marks|=(doubt & own) != 0ull ? 1u << ((y-y0) >> a.mark_shift) : 0u;
       asm volatile("" ::: "memory");
       if (y+1 >= y1)
         break;
@@ -476,9 +493,11 @@ void resize_stream_kernel(StreamResizeArgs a)
       vertical(y+1);
     }
   store_row(y1-1,true);
-  if constexpr (kFloat)
-    if ((seen != 0u) && (lane == 0))
-      a.wild_items[item]=1u;                   // its rows hold NaNs now: the careful launch rewrites them
+  // (the lanes beside the strip's own columns computed neighbours' intermediate pixels: they count)
+  if (seen != 0u)
+    marks=0xffffffffu;
+  if ((marks != 0u) && (lane == 0))
+    a.wild_items[item]=marks;                  // the careful launch rewrites these rows of the item
 }
 
 // ------------------------------------------------------------------ host side
@@ -591,6 +610,9 @@ static MhStatus launch_stream_typed(const View &src,const View &dst,const Stream
   int rows=(int) option_long("MAGICKHIP_RESIZE_STREAM_ROWS",128);
   rows=rows < 16 ? 16 : rows;
   a.rows_per_chunk=rows;
+  a.mark_shift=2;                              // a chunk's rows in at most 32 blocks of 4 .. rows
+  while (((rows-1) >> a.mark_shift) > 31)
+    a.mark_shift++;
   a.chunks=((int) dst.rows+rows-1)/rows;
   a.vbase=t.at<int>(d.i_vbase); a.vdense=t.at<double>(d.i_vdense); a.listed=t.at<double>(d.i_listed);
   a.vstart=t.at<int>(d.i_vstart); a.vcount=t.at<int>(d.i_vcount);
@@ -601,20 +623,30 @@ static MhStatus launch_stream_typed(const View &src,const View &dst,const Stream
     return fail(MH_BAD_ARGUMENT,"resize: frame too large");
   dim3 grid((unsigned) ((items+3)/4));
   Temp flags;
-  a.wild_items=nullptr;
-  if (QuantumOps<Q>::is_float)
-    {
-      MH_TRY(flags.alloc(src.device,(size_t) items*sizeof(unsigned),src.stream));
-      MH_HIP(hipMemsetAsync(flags.ptr,0,(size_t) items*sizeof(unsigned),src.stream));
-      a.wild_items=flags.as<unsigned>();
-    }
+  MH_TRY(flags.alloc(src.device,(size_t) items*sizeof(unsigned),src.stream));
+  MH_HIP(hipMemsetAsync(flags.ptr,0,(size_t) items*sizeof(unsigned),src.stream));
+  a.wild_items=flags.as<unsigned>();
   {
     ProfileScope prof("resize_stream",src.stream);
     hipLaunchKernelGGL((resize_stream_kernel<Q,BLEND,F,NT,ROWS>),grid,dim3(256),0,src.stream,a);
     MH_HIP(hipGetLastError());
   }
-  if (QuantumOps<Q>::is_float)
+  if (option("MAGICKHIP_RESIZE_STREAM_REPORT") != nullptr)
     {
+      // diagnostics: how many blocks of rows the walk handed to the careful launch
+      std::vector<unsigned> host((size_t) items);
+      MH_HIP(hipMemcpyAsync(host.data(),flags.ptr,(size_t) items*sizeof(unsigned),hipMemcpyDeviceToHost,src.stream));
+      MH_HIP(hipStreamSynchronize(src.stream));
+      long long marked=0,touched=0;
+      for (unsigned word : host)
+        {
+          marked+=__builtin_popcount(word);
+          touched+=word != 0u ? 1 : 0;
+        }
+      fprintf(stderr,"resize_stream: %lld of %lld items hold %lld marked blocks of %d rows\n",touched,items,marked,
+        1 << a.mark_shift);
+    }
+  {
       ProfileScope prof("resize_stream_careful",src.stream);
       hipLaunchKernelGGL((resize_stream_careful_kernel<Q,BLEND>),dim3((unsigned) items),dim3(256),0,src.stream,a,F);
       MH_HIP(hipGetLastError());

@@ -20,6 +20,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 im.load()
+im.set_precision(im.PRECISION_EXACT)               # (the library's default is FAST; the cases below switch per call)
 refmod.set_thread_limit(os.cpu_count() or 1)
 
 
@@ -74,6 +75,23 @@ def check_bits(name, got, want, detail):
     return 0
 
 
+def check_ulp(name, got, want, limit, detail):
+    """Float results within `limit` float ULPs of the reference's (same NaN pattern, same infinities)."""
+    if not np.array_equal(np.isnan(got), np.isnan(want)):
+        print("MISMATCH %s %s: NaN pattern differs" % (name, detail), flush=True)
+        return 1
+    def ordered(a):
+        bits = np.nan_to_num(a, nan=0.0).view(np.int32).astype(np.int64)
+        return np.where(bits < 0, -(bits & 0x7fffffff), bits)
+    d = np.abs(ordered(got) - ordered(want))
+    if d.max(initial=0) > limit:
+        bad = np.argwhere(d > limit)
+        print("MISMATCH %s %s: max %d ULP (limit %d), %d samples, first at %s: %r vs %r" % (
+            name, detail, d.max(), limit, len(bad), bad[0].tolist(), got[tuple(bad[0])], want[tuple(bad[0])]), flush=True)
+        return 1
+    return 0
+
+
 def check(name, got, want, limit, detail):
     d = np.abs(got.astype(np.int64) - want.astype(np.int64))
     if d.max(initial=0) > limit:
@@ -89,7 +107,9 @@ def check(name, got, want, limit, detail):
 # tie check), 8 float-Quantum blur / unsharp, 9 float-Quantum Erode / Dilate, 10 float-Quantum
 # GaussianBlur / Sharpen, 11 float-Quantum ContrastStretch / Equalize, 12 integer-cell 2-D convolve on the
 # i8 matrix cores in both modes and three layouts, 13 2-D convolve with random real cells on every layout and
-# Quantum type: the fused fp64 kernel)
+# Quantum type: the fused fp64 kernel, 14 ResizeImage: whole-number enlargements (one launch on the vector
+# pipe under FAST), other enlargements (matrix pipe), reductions and mixed geometries, Q16 and float,
+# alpha-weighted or four plain channels, both modes)
 only_ops = [int(t) for t in os.environ.get("STRESS_OPS", "").split(",") if t.strip()]
 t0 = time.time()
 cases = failures = 0
@@ -99,7 +119,7 @@ while time.time() - t0 < budget:
         rows, cols = int(rng.integers(1, 40)), int(rng.integers(300, 1400))
     kind = int(rng.integers(0, 5))
     px = pixels(rows, cols, kind)
-    op = int(rng.integers(0, 14))
+    op = int(rng.integers(0, 15))
     if only_ops:
         op = only_ops[int(rng.integers(0, len(only_ops)))]
     detail = "%dx%d kind %d" % (rows, cols, kind)
@@ -289,6 +309,40 @@ while time.time() - t0 < budget:
         what = detail + " c%d blend=%s %s" % (channels, blend, kernel[:50])
         failures += check_bits("fused 2-D convolve, float", got, want, what) if is_float else \
             check("fused 2-D convolve", got, want, 0, what)
+    elif op == 14:                                 # ResizeImage
+        filt = ["Lanczos", "Mitchell", "Catrom", "Triangle", "Hermite", "Gaussian", "Spline", "Lanczos2", "Cubic",
+                "Box", "Point", "Hann", "Robidoux"][int(rng.integers(0, 13))]
+        rows2, cols2 = int(rng.integers(1, 150)), int(rng.integers(1, 200))
+        shape = int(rng.integers(0, 4))
+        if shape == 0:                             # whole-number horizontal factor, the vertical one at least as large
+            f = int(rng.integers(2, 5))
+            target = (f * cols2, int(rng.integers(f * rows2, 5 * rows2 + 2)))
+        elif shape == 1:                           # any enlargement
+            target = (int(rng.integers(cols2, 4 * cols2 + 2)), int(rng.integers(rows2, 4 * rows2 + 2)))
+        elif shape == 2:                           # reduction
+            target = (int(rng.integers(1, cols2 + 1)), int(rng.integers(1, rows2 + 1)))
+        else:                                      # mixed
+            target = (int(rng.integers(1, 3 * cols2 + 2)), int(rng.integers(1, 3 * rows2 + 2)))
+        is_float = rng.random() < 0.4
+        alpha = rng.random() < 0.6
+        fast = rng.random() < 0.6
+        frame = float_pixels(rows2, cols2, int(rng.integers(0, 3))) if is_float else pixels(rows2, cols2, kind)
+        if alpha:
+            want = refmod.RefImage(frame).resize(target[0], target[1], filt).numpy()
+        else:
+            want = np.concatenate([refmod.RefImage(frame[:, :, c].copy()).resize(target[0], target[1], filt).numpy()
+                                   .reshape(target[1], target[0], 1) for c in range(4)], axis=2)
+        image = (dev_float if is_float else dev)(frame, has_alpha=alpha)
+        if fast:
+            im.set_precision(im.PRECISION_FAST)
+        got = im.resize_image(image, target[0], target[1], filt).numpy()
+        im.set_precision(im.PRECISION_EXACT)
+        what = "%dx%d -> %dx%d %s %s %s kind %d" % (cols2, rows2, target[0], target[1], filt,
+                                                      "alpha" if alpha else "plain", "fast" if fast else "exact", kind)
+        if is_float:
+            failures += check_ulp("float resize", got, want, 1, what) if fast else check_bits("float resize", got, want, what)
+        else:
+            failures += check("resize", got, want, 1 if fast else 0, what)
     else:                                          # FAST Lab
         im.set_precision(im.PRECISION_FAST)
         d2 = dev(px)

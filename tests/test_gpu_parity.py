@@ -840,6 +840,20 @@ def test_morphology_compose_override(im, refmod, method, kernel, compose):
         im.morphology_image(dev, method, 1, kernel, scale=scale, compose="Overlay")
 
 
+@pytest.mark.parametrize("compose", ["Over", "DstOver", "Screen", "Lighten"])
+def test_morphology_compose_with_alpha_outside_the_channel_mask(im, refmod, compose):
+    """`-channel RGB -define morphology:compose=...`: the alpha channel carries the Copy trait.
+    CompositeOverImage still writes the merged alpha (composite.c:1096-1104); the general
+    operators leave a copy channel alone (composite.c:2580-2590)."""
+    px = make_pixels(44, 60, 4, Q16, seed=7)
+    ref = refmod.RefImage(px).set_channel_mask("RGB")
+    ref.set_artifact("morphology:compose", compose)
+    want = ref.morphology("Dilate", 1, "Plus:1;Square:1").numpy()
+    dev = im.Image(to_device(px), channel_mask=0x7, copy_channels=(3,))
+    got = im.morphology_image(dev, "Dilate", 1, "Plus:1;Square:1", compose=compose).numpy()
+    assert_parity(got, want, True, "Dilate list compose %s, -channel RGB" % compose)
+
+
 def test_hit_and_miss_union_with_alpha(im, refmod):
     px = make_pixels(40, 52, 4, Q16)
     dev, ref = run_pair(im, refmod, px)
@@ -1952,6 +1966,49 @@ def test_resize_vector_pipe_weights_born_of_cancellation_and_tiny_frames(im, ref
                               False, "vector-pipe form or its fallback %s %s" % (shape, filt), max_ulp=1)
     finally:
         im.set_precision(im.PRECISION_EXACT)
+
+
+@pytest.mark.parametrize("case", [
+    # (rows, columns), (target columns, rows), filter, alpha kind, float frame
+    ((139, 70), (39, 60), "Triangle", "tiny", False),          # two passes (a reduction)
+    ((56, 105), (63, 4), "Triangle", "tiny", False),
+    ((64, 21), (10, 28), "Box", "tiny", False),
+    ((12, 182), (78, 5), "Box", "binary", True),
+    ((72, 49), (147, 269), "Catrom", "binary", False),         # one launch, vector pipe (3x)
+    ((84, 143), (572, 420), "Catrom", "tiny", False),          # ... 4x
+    ((60, 90), (180, 150), "Triangle", "tiny", False),         # ... 2x
+    ((114, 92), (276, 524), "Lanczos", "binary", False),       # alpha sums that cancel under the window
+    ((60, 90), (180, 150), "Box", "tiny", True),
+    ((72, 49), (120, 200), "Catrom", "tiny", False),           # one launch, matrix pipe
+    ((50, 70), (163, 129), "Triangle", "binary", False),
+    ((50, 70), (163, 129), "Hermite", "tiny", True),
+])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_resize_fast_intermediate_on_rounding_boundaries(im, refmod, case, seed):
+    """FAST ResizeImage on frames that put the INTERMEDIATE on rounding boundaries: polynomial filters at
+    rational positions over small integers produce exact x.5 sums in families, the last bits of the
+    summation order decide the level, and one level of a small intermediate alpha is thousands of levels
+    of the colours the second filter weights with it (tests/stress_parity.py found differences of up to
+    13 783 levels in round 5).  The first filter therefore runs in the reference's own order on the
+    two-pass route, the one-launch forms find such values (and alpha sums that cancel to nothing under
+    a window) and recompute their rows: within one level / one float ULP on every route."""
+    shape, target, filt, kind, is_float = case
+    rng = np.random.default_rng(seed * 1000 + shape[0])
+    px = rng.integers(0, 65536, (shape[0], shape[1], 4)).astype(np.uint16)
+    if kind == "tiny":
+        px[:, :, 3] = rng.integers(0, 4, shape)
+    else:
+        px[:, :, 3] = np.where(rng.random(shape) < 0.5, 0, 65535)
+    if is_float:
+        px = px.astype(np.float32)
+    want = refmod.RefImage(px).resize(target[0], target[1], filt).numpy()
+    dev = im.Image(to_device(px), has_alpha=True)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got = im.resize_image(dev, target[0], target[1], filt).numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert_parity(got, want, False, "FAST resize %s -> %s %s, %s alpha" % (shape, target, filt, kind), max_ulp=1)
 
 
 def test_resize_fast_falls_back_to_two_passes(im, refmod):
