@@ -109,7 +109,8 @@ def check(name, got, want, limit, detail):
 # i8 matrix cores in both modes and three layouts, 13 2-D convolve with random real cells on every layout and
 # Quantum type: the fused fp64 kernel, 14 ResizeImage: whole-number enlargements (one launch on the vector
 # pipe under FAST), other enlargements (matrix pipe), reductions and mixed geometries, Q16 and float,
-# alpha-weighted or four plain channels, both modes)
+# alpha-weighted or four plain channels, both modes, 15 FAST BlurImage / GaussianBlurImage / UnsharpMaskImage on
+# every layout: gray, gray + alpha, RGB, RGBA, four plain channels)
 only_ops = [int(t) for t in os.environ.get("STRESS_OPS", "").split(",") if t.strip()]
 t0 = time.time()
 cases = failures = 0
@@ -119,7 +120,7 @@ while time.time() - t0 < budget:
         rows, cols = int(rng.integers(1, 40)), int(rng.integers(300, 1400))
     kind = int(rng.integers(0, 5))
     px = pixels(rows, cols, kind)
-    op = int(rng.integers(0, 15))
+    op = int(rng.integers(0, 16))
     if only_ops:
         op = only_ops[int(rng.integers(0, len(only_ops)))]
     detail = "%dx%d kind %d" % (rows, cols, kind)
@@ -343,6 +344,38 @@ while time.time() - t0 < budget:
             failures += check_ulp("float resize", got, want, 1, what) if fast else check_bits("float resize", got, want, what)
         else:
             failures += check("resize", got, want, 1 if fast else 0, what)
+    elif op == 15:                                 # FAST blur family on every layout
+        channels = int(rng.integers(1, 5))
+        blend = channels in (2, 4) and rng.random() < 0.6
+        frame = np.ascontiguousarray(px[:, :, 4 - channels:] if blend else px[:, :, :channels])
+        which = int(rng.integers(0, 3))
+        sigma = float(rng.uniform(0.3, 13.4)) if which != 1 else float(rng.uniform(0.8, 4.5))
+        gain, threshold = float(rng.uniform(0.3, 3.0)), float(rng.uniform(0.0, 0.2))
+
+        def reference(a):
+            r = refmod.RefImage(a)
+            return (r.blur(0.0, sigma) if which == 0 else r.gaussian_blur(0.0, sigma) if which == 1 else
+                    r.unsharp(0.0, sigma, gain, threshold)).numpy()
+        if blend or channels in (1, 3):
+            want = reference(frame).reshape(rows, cols, channels)
+        else:
+            want = np.concatenate([reference(frame[:, :, c].copy()).reshape(rows, cols, 1) for c in range(channels)], axis=2)
+        image = dev(frame, has_alpha=blend)
+        im.set_precision(im.PRECISION_FAST)
+        got = (im.blur_image(image, 0.0, sigma) if which == 0 else im.gaussian_blur_image(image, 0.0, sigma) if which == 1 else
+               im.unsharp_mask_image(image, 0.0, sigma, gain, threshold)).numpy().reshape(rows, cols, channels)
+        im.set_precision(im.PRECISION_EXACT)
+        what = detail + " %s c%d blend=%s sigma %.3f" % (("blur", "gaussian", "unsharp")[which], channels, blend, sigma)
+        if which == 2:
+            blurred = (refmod.RefImage(frame).blur(0.0, sigma).numpy().reshape(rows, cols, channels).astype(np.int64)
+                       if (blend or channels in (1, 3)) else None)
+            d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+            if blurred is not None:
+                edge = np.abs(2 * np.abs(frame.astype(np.int64) - blurred) - 65535.0 * threshold) <= 2.0
+                d[edge] = 0
+                failures += check("fast unsharp, layout", d, np.zeros_like(d), int(np.ceil(1.0 + gain)), what)
+        else:
+            failures += check("fast blur, layout", got, want, 1, what)
     else:                                          # FAST Lab
         im.set_precision(im.PRECISION_FAST)
         d2 = dev(px)
