@@ -65,8 +65,11 @@ struct StreamResizeArgs
   const double *vdense;
   const int *vstart,*vcount,*hstart,*hcount;
   const double *vweight,*hweight;            // [tap][out]
-  unsigned *wild_items;                      // [strips*chunks]: bit b = the item's rows b << mark_shift .. are redone
+  // [strips*chunks][2]: bit b of the first word = the item's rows b << mark_shift .. are redone; the
+  // second word = the first and the last lane (source column) that asked for it, in bytes 0 and 1
+  unsigned *wild_items;
   int mark_shift;
+  int nt;                                    // neighbours a lane reads (the careful launch: how far a lane's value reaches)
   const double *listed;                      // [2*kListed][kMaxDense]: the listed columns' dense weights
 };
 
@@ -167,11 +170,22 @@ void resize_stream_careful_kernel(StreamResizeArgs a,int f)
 {
   __shared__ __attribute__((aligned(16))) unsigned char scratch[12288];   // (a few rows of an item's intermediate: many workgroups a CU)
   const int item=(int) blockIdx.x;
-  const unsigned marks=a.wild_items[item];
+  const unsigned marks=a.wild_items[2*item];
   if (marks == 0u)
     return;
   const int chunk=item/a.strips,strip=item-chunk*a.strips;
-  const int x0=f*a.strip_first[strip],x1=x0+f*a.strip_count[strip];
+  int x0=f*a.strip_first[strip],x1=x0+f*a.strip_count[strip];
+  {
+    // the intermediate pixel of lane l (source column strip_first+lo+l) is read by the lanes
+    // l-lo-(nt-1) .. l-lo: only their outputs can differ
+    const unsigned lanes=a.wild_items[2*item+1];
+    const int column0=a.strip_first[strip]+a.lo;
+    const int from=column0+(int) (lanes & 0xffu)-a.lo-(a.nt-1),to=column0+(int) ((lanes >> 8) & 0xffu)-a.lo+1;
+    x0=f*from > x0 ? f*from : x0;
+    x1=f*to < x1 ? f*to : x1;
+    if (x0 >= x1)
+      return;
+  }
   const int y0=chunk*a.rows_per_chunk;
   int y1=y0+a.rows_per_chunk;
   y1=y1 < a.dst_rows ? y1 : a.dst_rows;
@@ -275,6 +289,7 @@ void resize_stream_kernel(StreamResizeArgs a)
   unsigned wild=0u;                            // bit j: window slot j holds a sample that is not tame
   unsigned seen=0u;
   unsigned marks=0u;                           // blocks of rows in which a lane met a value the fused sums cannot vouch for (finish_fast)
+  unsigned lane_first=64u,lane_last=0u;        // ... and the first and the last such lane (scalar registers)
   auto fetch=[&](int row,Q (&q)[4])
   {
     row=row < H-1 ? row : H-1;
@@ -294,6 +309,18 @@ void resize_stream_kernel(StreamResizeArgs a)
   const int y0=chunk*a.rows_per_chunk;
   int y1=y0+a.rows_per_chunk;
   y1=y1 < a.dst_rows ? y1 : a.dst_rows;
+  auto note=[&](unsigned long long lanes,int y)
+  {
+    // (the mask is wave-uniform, but it was merged behind finish_fast's rare branch: made scalar
+    // again here, the rest is scalar arithmetic and selects — no branch in the walk)
+    const unsigned long long doubt=((unsigned long long) __builtin_amdgcn_readfirstlane((unsigned) (lanes >> 32)) << 32) |
+      (unsigned long long) __builtin_amdgcn_readfirstlane((unsigned) lanes);
+    marks|=doubt != 0ull ? 1u << ((y-y0) >> a.mark_shift) : 0u;
+    const unsigned first=doubt != 0ull ? (unsigned) __builtin_ctzll(doubt) : 64u;
+    const unsigned last=doubt != 0ull ? 63u-(unsigned) __builtin_clzll(doubt) : 0u;
+    lane_first=first < lane_first ? first : lane_first;
+    lane_last=last > lane_last ? last : lane_last;
+  };
   const scalar_ints vbase=(scalar_ints) a.vbase;
   int base=vbase[y0];
   // Source row r lives in window slot r % ROWS for as long as it is under the window (the dense
@@ -360,7 +387,7 @@ void resize_stream_kernel(StreamResizeArgs a)
     Q q[4];
     unsigned long long doubt=0ull;
     finish_fast<Q,BLEND,2,true>(s,q,doubt);
-    marks|=doubt != 0ull ? 1u << ((y-y0) >> a.mark_shift) : 0u;
+    note(doubt,y);
     premultiplied<Q,BLEND>(q,iv);
   };
   // the lanes whose source column is one of the strip's own: their F outputs are the ones stored
@@ -477,7 +504,7 @@ void resize_stream_kernel(StreamResizeArgs a)
           store_pixel<Q,4>(reinterpret_cast<Q *>(xpose+p*XPLANE+lane*PX),out);
         }
       // (the lanes beside the strip's own columns summed neighbours they do not have: their pixels are never stored)
-      marks|=(doubt & own) != 0ull ? 1u << ((y-y0) >> a.mark_shift) : 0u;
+      note(doubt & own,y);
       asm volatile("" ::: "memory");
       if (y+1 >= y1)
         break;
@@ -495,9 +522,16 @@ void resize_stream_kernel(StreamResizeArgs a)
   store_row(y1-1,true);
   // (the lanes beside the strip's own columns computed neighbours' intermediate pixels: they count)
   if (seen != 0u)
-    marks=0xffffffffu;
+    {
+      marks=0xffffffffu;
+      lane_first=0u;
+      lane_last=63u;
+    }
   if ((marks != 0u) && (lane == 0))
-    a.wild_items[item]=marks;                  // the careful launch rewrites these rows of the item
+    {
+      a.wild_items[2*item]=marks;              // the careful launch rewrites these rows of the item
+      a.wild_items[2*item+1]=lane_first | (lane_last << 8);
+    }
 }
 
 // ------------------------------------------------------------------ host side
@@ -623,9 +657,10 @@ static MhStatus launch_stream_typed(const View &src,const View &dst,const Stream
     return fail(MH_BAD_ARGUMENT,"resize: frame too large");
   dim3 grid((unsigned) ((items+3)/4));
   Temp flags;
-  MH_TRY(flags.alloc(src.device,(size_t) items*sizeof(unsigned),src.stream));
-  MH_HIP(hipMemsetAsync(flags.ptr,0,(size_t) items*sizeof(unsigned),src.stream));
+  MH_TRY(flags.alloc(src.device,(size_t) items*2u*sizeof(unsigned),src.stream));
+  MH_HIP(hipMemsetAsync(flags.ptr,0,(size_t) items*2u*sizeof(unsigned),src.stream));
   a.wild_items=flags.as<unsigned>();
+  a.nt=p.nt;
   {
     ProfileScope prof("resize_stream",src.stream);
     hipLaunchKernelGGL((resize_stream_kernel<Q,BLEND,F,NT,ROWS>),grid,dim3(256),0,src.stream,a);
@@ -634,17 +669,19 @@ static MhStatus launch_stream_typed(const View &src,const View &dst,const Stream
   if (option("MAGICKHIP_RESIZE_STREAM_REPORT") != nullptr)
     {
       // diagnostics: how many blocks of rows the walk handed to the careful launch
-      std::vector<unsigned> host((size_t) items);
-      MH_HIP(hipMemcpyAsync(host.data(),flags.ptr,(size_t) items*sizeof(unsigned),hipMemcpyDeviceToHost,src.stream));
+      std::vector<unsigned> host((size_t) items*2u);
+      MH_HIP(hipMemcpyAsync(host.data(),flags.ptr,(size_t) items*2u*sizeof(unsigned),hipMemcpyDeviceToHost,src.stream));
       MH_HIP(hipStreamSynchronize(src.stream));
-      long long marked=0,touched=0;
-      for (unsigned word : host)
+      long long marked=0,touched=0,lanes=0;
+      for (long long i=0; i < items; i++)
         {
+          const unsigned word=host[(size_t) (2*i)],range=host[(size_t) (2*i+1)];
           marked+=__builtin_popcount(word);
           touched+=word != 0u ? 1 : 0;
+          lanes+=word != 0u ? (long long) ((range >> 8) & 0xffu)-(long long) (range & 0xffu)+1 : 0;
         }
-      fprintf(stderr,"resize_stream: %lld of %lld items hold %lld marked blocks of %d rows\n",touched,items,marked,
-        1 << a.mark_shift);
+      fprintf(stderr,"resize_stream: %lld of %lld items hold %lld marked blocks of %d rows, %.1f lanes wide on average\n",touched,
+        items,marked,1 << a.mark_shift,touched > 0 ? (double) lanes/(double) touched : 0.0);
     }
   {
       ProfileScope prof("resize_stream_careful",src.stream);
