@@ -176,8 +176,11 @@ struct TieWatch
   __device__ __forceinline__ void quotient(double r)
   {
     const double wide=kFloat ? __builtin_fma(5.7e6,__builtin_fabs(r),256.0) : __builtin_fma(176950.0,__builtin_fabs(r),384.0);
-    unsigned half=(unsigned) wide;               // (v_cvt_u32_f64 saturates)
-    set(half < kWidest ? half : kWidest);
+    const unsigned half=(unsigned) wide;         // (v_cvt_u32_f64 saturates)
+    set(half);
+    // a window as wide as the tail's whole range (an alpha sum of 1e-3 and less): every value is reported
+    bias=half < kWidest ? bias : 0u;
+    twice=half < kWidest ? twice : 0xffffffffu;
   }
   __device__ __forceinline__ bool near(double v) const
   {
@@ -193,16 +196,19 @@ struct TieWatch
 // filter) the sums are multiplied by QuantumScale/MagickEpsilon = 1.5e7 instead: what cancelled under
 // the window to (nearly) nothing is noise of thousands of levels, in the reference's order or in any
 // other — unless every sum is an exact zero (a window of transparent pixels), the pixel is reported.
-constexpr double kOutputAlphaLimit=1.0e-3;
+// (Q16: 4.1e-5 / 1e-3 = 0.04 level.  A float result's contract is relative: 6e-15 * 1.6 * 65535 / |S_a| has to
+// stay a fraction of 2^-24 — an alpha sum of at least 0.05; found by a frame of opaque rectangles on a
+// transparent ground, where the ringing of the first filter leaves intermediate alphas of 1e-3.)
+template<typename Q> struct OutputAlphaLimit { static constexpr double value=QuantumOps<Q>::is_float ? 0.05 : 1.0e-3; };
 static __device__ __forceinline__ bool clamped_sums_count(const double (&s)[4])
 {
   return (s[0] != 0.0) || (s[1] != 0.0) || (s[2] != 0.0) || (s[3] != 0.0);    // (a NaN counts)
 }
-// (Over-cautious where the clamp acts on sums of rounding zeros — a sinc at a whole number, 1e-13,
-// times any alpha: a 3x enlargement has one output in three whose window is (0 .. 0, 1, 0 .. 0), and over
-// a transparent centre pixel beside opaque ones its sums are 1e-8 and both orders agree on them.  Telling
-// the two cases apart needs sum|w*alpha|, which cost the walk registers it does not have: such rows are
-// recomputed too.)
+// (Sums of rounding zeros — a sinc at a whole number, 1e-13, times any alpha: a 3x enlargement has one
+// output in three whose window is (0 .. 0, 1, 0 .. 0) — over a transparent centre pixel between opaque ones
+// are exactly this case: the two neighbours' weights are w and -w, the alpha sum is 0 or 1e-29, its SIGN
+// picks +-1/MagickEpsilon, and the reference's order is the only arbiter.  Suppressing the report for
+// such windows was tried and failed the binary-alpha runs.)
 
 
 // The reference's two filters over one rectangle of the output (VerticalFilter, then

@@ -111,7 +111,7 @@ static __device__ __forceinline__ bool finish_pixel(double s0,double s1,double s
             colour.quotient(r);
         }
       else
-        doubt=divides && (mag < kOutputAlphaLimit);
+        doubt=divides && (mag < OutputAlphaLimit<Q>::value);
       doubt=doubt || (!divides && clamped_sums_count(v));
     }
 #pragma unroll

@@ -130,7 +130,7 @@ static __device__ __forceinline__ void finish_fast(const double (&s)[4],Q (&q)[4
       if constexpr (TIES)
         colour.quotient(r);
       else
-        doubt|=__builtin_amdgcn_ballot_w64(__builtin_fabs(sa) < kOutputAlphaLimit);
+        doubt|=__builtin_amdgcn_ballot_w64(__builtin_fabs(sa) < OutputAlphaLimit<Q>::value);
     }
   // (a value, its level, its verdict: one channel after the other — the kernels sit at their register limit)
 #pragma unroll

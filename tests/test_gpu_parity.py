@@ -1982,6 +1982,8 @@ def test_resize_vector_pipe_weights_born_of_cancellation_and_tiny_frames(im, ref
     ((72, 49), (120, 200), "Catrom", "tiny", False),           # one launch, matrix pipe
     ((50, 70), (163, 129), "Triangle", "binary", False),
     ((50, 70), (163, 129), "Hermite", "tiny", True),
+    ((60, 90), (270, 180), "Lanczos", "blocks", False),        # 3x: one output in three sits on a source pixel's centre
+    ((60, 90), (270, 233), "Lanczos", "blocks", True),
 ])
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_resize_fast_intermediate_on_rounding_boundaries(im, refmod, case, seed):
@@ -1997,6 +1999,11 @@ def test_resize_fast_intermediate_on_rounding_boundaries(im, refmod, case, seed)
     px = rng.integers(0, 65536, (shape[0], shape[1], 4)).astype(np.uint16)
     if kind == "tiny":
         px[:, :, 3] = rng.integers(0, 4, shape)
+    elif kind == "blocks":                               # a sprite: opaque rectangles on a transparent ground
+        px[:, :, 3] = 0
+        for _ in range(6):
+            y, x = int(rng.integers(0, shape[0] - 8)), int(rng.integers(0, shape[1] - 8))
+            px[y: y + int(rng.integers(3, 25)), x: x + int(rng.integers(3, 25)), 3] = 65535
     else:
         px[:, :, 3] = np.where(rng.random(shape) < 0.5, 0, 65535)
     if is_float:
@@ -2008,7 +2015,8 @@ def test_resize_fast_intermediate_on_rounding_boundaries(im, refmod, case, seed)
         got = im.resize_image(dev, target[0], target[1], filt).numpy()
     finally:
         im.set_precision(im.PRECISION_EXACT)
-    assert_parity(got, want, False, "FAST resize %s -> %s %s, %s alpha" % (shape, target, filt, kind), max_ulp=1)
+    assert_parity(got, want, False, "FAST resize %s -> %s %s, %s alpha" % (shape, target, filt, kind), max_ulp=1,
+                  residue=65535.0e-9 if is_float else 0.0)
 
 
 def test_resize_fast_falls_back_to_two_passes(im, refmod):
