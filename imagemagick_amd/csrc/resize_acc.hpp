@@ -3,6 +3,7 @@
 #pragma once
 
 #include "device_common.hpp"
+#include "tie_watch.hpp"
 #include <type_traits>
 
 namespace mh {
@@ -152,44 +153,7 @@ struct ResizeAcc
 // and sum|w*alpha| <= 1.6 * 65535 for every filter of resize.c: 4.1e-5 / |S_a| level — the window
 // widens with the reciprocal of the alpha sum, which the finish has at hand.  (A fixed window with
 // a branch for small alpha sums cost more: on a frame of random alpha every other wave took the branch.)
-template<typename Q>
-struct TieWatch
-{
-  static constexpr bool kFloat=QuantumOps<Q>::is_float;
-  // Half-widths, in the tail's units.  Q16: value + 0.5 + 2^28 has its last place at 2^-24; its low
-  // word shifted left by 8 is the fraction of value + 0.5 as a 32-bit fixed-point number (rounded to
-  // 2^-24): units of 2^-32 level; the plain window is 1.5 * 2^-24 = 9e-8 level (values the clamp
-  // decides leave the binade: whatever their bits say is harmless).  float: (Quantum) value keeps
-  // 24 of the 53 significant bits, a tie is a tail of 29 bits at one half: units of the double's
-  // last place; the plain window is 2^8 of them = 5.7e-14 relative (sum|terms| up to ten times |sum|).
-  static constexpr unsigned kPlain=kFloat ? 0x100u : 0x180u;
-  static constexpr unsigned kWidest=kFloat ? 0x08000000u : 0x40000000u;
-  unsigned bias,twice;
-  __device__ __forceinline__ void set(unsigned half)
-  {
-    bias=kFloat ? half-0x10000000u : half;
-    twice=2u*half;
-  }
-  __device__ __forceinline__ void plain() { set(kPlain); }
-  // r = the reciprocal of the alpha sum: 4.12e-5 * |r| level = 176950 * |r| units (Q16);
-  // 6.3e-10 * |r| relative <= 5.7e6 * |r| units (float) — on top of the plain window
-  __device__ __forceinline__ void quotient(double r)
-  {
-    const double wide=kFloat ? __builtin_fma(5.7e6,__builtin_fabs(r),256.0) : __builtin_fma(176950.0,__builtin_fabs(r),384.0);
-    const unsigned half=(unsigned) wide;         // (v_cvt_u32_f64 saturates)
-    set(half);
-    // a window as wide as the tail's whole range (an alpha sum of 1e-3 and less): every value is reported
-    bias=half < kWidest ? bias : 0u;
-    twice=half < kWidest ? twice : 0xffffffffu;
-  }
-  __device__ __forceinline__ bool near(double v) const
-  {
-    if constexpr (kFloat)
-      return (((unsigned) __double2loint(v) & 0x1fffffffu)+bias) <= twice;
-    else
-      return (((unsigned) __double2loint(v+268435456.5) << 8)+bias) <= twice;
-  }
-};
+template<typename Q> struct TieWatch : TieWatchBits<QuantumOps<Q>::is_float> {};
 
 // an alpha sum of the SECOND filter below this many levels: the quotient's error (4.1e-5 / |S_a|
 // level) is no longer a small fraction of a level.  Where PerceptibleReciprocal's clamp acts (either
