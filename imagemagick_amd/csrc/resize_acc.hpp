@@ -161,8 +161,10 @@ template<typename Q> struct TieWatch : TieWatchBits<QuantumOps<Q>::is_float> {};
 // the window to (nearly) nothing is noise of thousands of levels, in the reference's order or in any
 // other — unless every sum is an exact zero (a window of transparent pixels), the pixel is reported.
 // (Q16: 4.1e-5 / 1e-3 = 0.04 level.  A float result's contract is relative: 6e-15 * 1.6 * 65535 / |S_a| has to
-// stay a fraction of 2^-24 — an alpha sum of at least 0.05; found by a frame of opaque rectangles on a
-// transparent ground, where the ringing of the first filter leaves intermediate alphas of 1e-3.)
+// stay a fraction of 2^-24 — an alpha sum of at least 0.05: the ringing of the first filter beside an
+// opaque rectangle leaves intermediate alphas of 1e-3 on a transparent ground.  What no window can
+// vouch for in a float frame is a PLAIN sum that is itself the residue of a cancellation — an alpha of
+// -4e-20 out of terms of 1e-8: DESIGN.md section 2 has the qualifier.)
 template<typename Q> struct OutputAlphaLimit { static constexpr double value=QuantumOps<Q>::is_float ? 0.05 : 1.0e-3; };
 static __device__ __forceinline__ bool clamped_sums_count(const double (&s)[4])
 {
