@@ -16,3 +16,15 @@ def test_tie_watch_windows_on_the_host():
                     os.path.join(ROOT, "tests", "cpu", "tie_watch_test.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout
+
+
+def test_tie_window_is_wide_enough_on_adversarial_frames():
+    """tests/cpu/tie_window_sufficiency_test.cpp: the first filter over frames of tiny, binary and random
+    alpha (Triangle, Catrom, Lanczos, Box; Q16 and float), in the one-launch kernels' order and in the
+    reference's, 18 million pixels: every pixel whose rounded intermediate differs between the two
+    orders was reported by the kernels' test."""
+    exe = os.path.join(tempfile.mkdtemp(prefix="mh_tie_"), "tie_window_sufficiency_test")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(ROOT, "imagemagick_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "cpu", "tie_window_sufficiency_test.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True)
+    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout
