@@ -107,40 +107,49 @@ static __device__ __forceinline__ void finish_sums(const double (&s)[4],Q (&q)[4
 template<typename Q,bool BLEND,int NEWTON,bool TIES>
 static __device__ __forceinline__ void finish_fast(const double (&s)[4],Q (&q)[4],unsigned long long &doubt)
 {
-  double r=1.0;
-  TieWatch<Q> plain,colour;
-  plain.plain();
-  colour.plain();
+  // (ONE ballot, behind the branch, where every lane of the wave is present again: a ballot inside a
+  // divergent branch reaches only the lanes that took it, and the wave's mask is read from one lane)
+  bool flagged=false;
+  bool clamped=false;
   if constexpr (BLEND)
+    clamped=!((__builtin_fabs(s[3])*kQS) >= kEps);
+  if (__builtin_expect(clamped,0))
     {
-      const double sa=s[3];
-      if (__builtin_expect(!((__builtin_fabs(sa)*kQS) >= kEps),0))
-        {
-          finish_sums<Q,BLEND>(s,q);
-          doubt|=__builtin_amdgcn_ballot_w64(clamped_sums_count(s));
-          return;
-        }
-      r=__builtin_amdgcn_rcp(sa);
-#pragma unroll
-      for (int i=0; i < NEWTON; i++)
-        {
-          const double e=__builtin_fma(-sa,r,1.0);
-          r=__builtin_fma(r,e,r);
-        }
-      if constexpr (TIES)
-        colour.quotient(r);
-      else
-        doubt|=__builtin_amdgcn_ballot_w64(__builtin_fabs(sa) < OutputAlphaLimit<Q>::value);
+      finish_sums<Q,BLEND>(s,q);
+      flagged=clamped_sums_count(s);
     }
-  // (a value, its level, its verdict: one channel after the other — the kernels sit at their register limit)
-#pragma unroll
-  for (int c=0; c < 4; c++)
+  else
     {
-      const double v=BLEND && (c < 3) ? s[c]*r : s[c];
-      q[c]=QuantumOps<Q>::clamp(v);
-      if constexpr (TIES)
-        doubt|=__builtin_amdgcn_ballot_w64(BLEND && (c < 3) ? colour.near(v) : plain.near(v));
+      double r=1.0;
+      TieWatch<Q> plain,colour;
+      plain.plain();
+      colour.plain();
+      if constexpr (BLEND)
+        {
+          const double sa=s[3];
+          r=__builtin_amdgcn_rcp(sa);
+#pragma unroll
+          for (int i=0; i < NEWTON; i++)
+            {
+              const double e=__builtin_fma(-sa,r,1.0);
+              r=__builtin_fma(r,e,r);
+            }
+          if constexpr (TIES)
+            colour.quotient(r);
+          else
+            flagged=__builtin_fabs(sa) < OutputAlphaLimit<Q>::value;
+        }
+      // (a value, its level, its verdict: one channel after the other — the kernels sit at their register limit)
+#pragma unroll
+      for (int c=0; c < 4; c++)
+        {
+          const double v=BLEND && (c < 3) ? s[c]*r : s[c];
+          q[c]=QuantumOps<Q>::clamp(v);
+          if constexpr (TIES)
+            flagged=flagged || (BLEND && (c < 3) ? colour.near(v) : plain.near(v));
+        }
     }
+  doubt|=__builtin_amdgcn_ballot_w64(flagged);
 }
 
 // a pixel as the filters sum it: (alpha*p .., alpha), or the four plain channels
