@@ -543,8 +543,14 @@ MhStatus host_banded_operator(const MhOperator &op,const MhKernelInfo *kernel,co
   const int devices=spread ? logical_devices(0) : 1;
   const int physical=device_count();
   const int first_device=spread ? 0 : resolve_device(image);
+  // per device: at most 8 threads in spread mode (the stream index below gives a logical device 8 slots of its
+  // physical device's table) and at most 64 threads in all, cut evenly across the devices
+  if (spread)
+    {
+      workers=workers > 8 ? 8 : workers;
+      workers=workers > 64/devices ? (64/devices > 0 ? 64/devices : 1) : workers;
+    }
   workers*=devices;
-  workers=workers > 64 ? 64 : workers;
   std::atomic<size_t> next{0};
   std::mutex error_lock;
   MhStatus first_status=MH_OK;

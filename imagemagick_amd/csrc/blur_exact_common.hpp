@@ -39,6 +39,10 @@ struct BlurExactArgs
   int items_per_xcd;         // ceil(strips*segments/8)
   float gain;                // UnsharpMaskImage's epilogue
   int threshold;             // ceil(QuantumRange*threshold), see unsharp_sample
+  // the f16 products' taps are tap_scale*tap, a power of two that puts the largest tap just under 2^15
+  // (f16_tap_scale); two_over_scale = 2/tap_scale undoes it in the epilogues, quantum_unit =
+  // two_over_scale/65535 in sums_to_quantum
+  float tap_scale,two_over_scale,quantum_unit;
   unsigned long long *recomputed;   // optional device counter of recomputed samples (diagnostics)
   // optional device word.  A frame whose alpha is a few levels everywhere widens the certificate's
   // window (it grows with 1/alpha) until several samples of every group go down the

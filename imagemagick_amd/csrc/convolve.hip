@@ -2355,10 +2355,12 @@ MhStatus launch_conv1d_unsharp(const View &rows,const View &dst,const View &orig
   std::vector<float> host((size_t) K);
   for (int v=0; v < K; v++)
     host[(size_t) v]=(float) params.taps[K-1-v];     // reversed walk, morphology.c:2746
+  if (blend && !f16_taps_resolved(params.taps,K))
+    return MH_OK;                                // (see launch_conv1d)
   Temp taps;
   MH_TRY(upload_table(taps,rows.device,rows.stream,host.data(),host.size()*sizeof(float)));
   return launch_conv1d_mfma(rows,dst,true,taps.as<float>(),K,K-1-params.origin,blend,MFMA_UNSHARP,
-    handled,&original,gain,threshold);
+    handled,&original,gain,threshold,nullptr,f16_tap_scale(params.taps,K));
 }
 
 MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
@@ -2396,6 +2398,12 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
       if (negative && !(magnitude <= 8.0))
         prec=MH_PRECISION_EXACT;
     }
+  // ... and alpha-weighted channels under a kernel whose outer taps are tiny beside the rest (BlurImage
+  // with a radius far beyond its sigma): where such a tap is the only one that meets an opaque sample — a
+  // sprite on a transparent ground — it IS the result (sum(k*alpha*p)/sum(k*alpha), morphology.c:2968-2977),
+  // and neither the f16 terms nor the f32 sums resolve it.  The fp64 kernels take those.
+  if ((prec == MH_PRECISION_FAST) && roles.blend && !f16_taps_resolved(params.taps,params.ntaps))
+    prec=MH_PRECISION_EXACT;
   if (src.quantum == MH_QUANTUM_U16)
     {
       if (prec == MH_PRECISION_FAST)
@@ -2423,7 +2431,8 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
               const double *taps64=static_cast<const double *>(taps);
               bool handled=false;
               MH_TRY(launch_conv1d_mfma(src,dst,vertical,reinterpret_cast<const float *>(taps64+K),K,
-                K-1-params.origin,roles.blend,MFMA_Q16,&handled,nullptr,0.0,0.0,taps64));
+                K-1-params.origin,roles.blend,MFMA_Q16,&handled,nullptr,0.0,0.0,taps64,
+                f16_tap_scale(params.taps,K)));
               if (handled)
                 return MH_OK;
             }

@@ -885,6 +885,9 @@ MhStatus launch_blur_fused_exact(const View &src,const View &dst,const double *t
   args.colour_window=plan.colour_window;
   args.alpha_half_window=0.5-(blend ? plan.alpha_window_blend : plan.alpha_window_plain);
   args.alpha_floor=plan.alpha_floor;
+  args.tap_scale=256.0f;                         // (the f16 column pass, COLX = false, keeps its fixed factor)
+  args.two_over_scale=1.0f/128.0f;
+  args.quantum_unit=1.0f/(128.0f*65535.0f);
   args.gain=(float) gain;
   {
     const double level=std::ceil(65535.0*threshold);

@@ -203,7 +203,7 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
   const int xin0=x0-args.shift;
   const int ngroups=nblocks+G::NG-1;
 
-  // ---- Toeplitz operands of the f16 products (both passes): T[c][i] = 256*tap[32c+8*kq+i-n], hi/lo
+  // ---- Toeplitz operands of the f16 products (both passes): T[c][i] = tap_scale*tap[32c+8*kq+i-n], hi/lo
   // split; and the digit table of the alpha tiles (HybridGeometry)
   half8 t_hi[NC],t_lo[NC];
   {
@@ -226,7 +226,7 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
           int j=32*c+8*kq+i-n;
           const bool inside=(j >= 0) && (j < K);
           j=inside ? j : 0;
-          const float tap=inside ? 256.0f*tap_lds[j] : 0.0f;
+          const float tap=inside ? args.tap_scale*tap_lds[j] : 0.0f;
           _Float16 h,l;
           split_f16(tap,h,l);
           t_hi[c][i]=h;
@@ -490,8 +490,8 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
 #pragma unroll
             for (int i=0; i < N; i++)
               out_tile[n*G::OUT_STRIDE+4*(ctile0+i)+kq]=MH_HKNOCKED(128) ?
-                sums_to_quantum<MFMA_PLAIN4>(acc[i][0],acc[i][1],acc[i][2],acc[i][3]) :
-                sums_to_quantum<SAMPLES>(acc[i][0],acc[i][1],acc[i][2],acc[i][3]);
+                sums_to_quantum<MFMA_PLAIN4>(acc[i][0],acc[i][1],acc[i][2],acc[i][3],args.quantum_unit) :
+                sums_to_quantum<SAMPLES>(acc[i][0],acc[i][1],acc[i][2],acc[i][3],args.quantum_unit);
           };
           if (ctiles == CT)
             column_tiles(std::integral_constant<int,CT>{});
@@ -576,15 +576,15 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
         // ---- colour epilogue of group g-1 (beside the chains above): lane (n, kq) = the four channels of pixel (row 4*rq+kq,
         // column 16*ot+n).  The column pass's samples, UNROUNDED:
         //   alpha-weighted: A*R_c*2^-17 with A = the exact alpha level (ring, interval B) and
-        //                   R_c = sum(k*alpha*p)/sum(k*alpha) = 2^9*S_c/D;  A/2 for the alpha channel
-        //   plain:          level/2 = S/256
+        //                   R_c = sum(k*alpha*p)/sum(k*alpha) = 2^17*S_c/(scale*D);  A/2 for the alpha channel
+        //   plain:          level/2 = S/scale
         {
           float v[4];
           if (BLEND && !MH_HKNOCKED(64))
             {
               // all-transparent window: D = 0 and A = 0 -> 0*inf = NaN -> v_max_f32 returns the 0
               // (PerceptibleReciprocal's clamp times a zero pixel sum, morphology.c:2974-2977)
-              const float weight=half_alpha*(1.0f/128.0f)*__builtin_amdgcn_rcpf(total);
+              const float weight=half_alpha*args.two_over_scale*__builtin_amdgcn_rcpf(total);
               v[0]=__builtin_fmaxf(sums_row[0]*weight,0.0f);
               v[1]=__builtin_fmaxf(sums_row[1]*weight,0.0f);
               v[2]=__builtin_fmaxf(sums_row[2]*weight,0.0f);
@@ -592,8 +592,9 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
             }
           else
             {
-              v[0]=sums_row[0]*(1.0f/256.0f); v[1]=sums_row[1]*(1.0f/256.0f);
-              v[2]=sums_row[2]*(1.0f/256.0f); v[3]=sums_row[3]*(1.0f/256.0f);
+              const float back=0.5f*args.two_over_scale;
+              v[0]=sums_row[0]*back; v[1]=sums_row[1]*back;
+              v[2]=sums_row[2]*back; v[3]=sums_row[3]*back;
             }
           // 4x4 transpose between the registers (channels) and the four 16-lane rows (pixel rows)
           asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
@@ -716,9 +717,15 @@ MhStatus launch_blur_fused_hybrid(const View &src,const View &dst,const double *
   const ExactTapPlan plan=plan_exact_taps(taps,ntaps);
   if (!plan.ok)
     return MH_OK;
+  // ... and every tap's f16 terms must carry the precision the +-1 argument counts on (f16_taps_resolved)
+  if (!f16_taps_resolved(taps,ntaps))
+    return MH_OK;
   ExactDeviceTaps device;
   MH_TRY(upload_exact_taps(src,taps,ntaps,plan,&device));
   BlurExactArgs args;
+  args.tap_scale=f16_tap_scale(taps,ntaps);
+  args.two_over_scale=2.0f/args.tap_scale;
+  args.quantum_unit=(float) (2.0/((double) args.tap_scale*65535.0));
   args.src=static_cast<const uint16_t *>(src.pixels);
   args.dst=static_cast<uint16_t *>(dst.pixels);
   args.columns=(int) src.columns;

@@ -63,6 +63,9 @@ struct ConvMfmaArgs
   int shift;                 // K-1-origin: offset of the first input sample
   const float *taps;         // float[K], taps[v] multiplies input o-shift+v
   const double *taps64;      // the same taps as doubles: exact_alpha_level (row pass, blend mode)
+  // the f16 operands are tap_scale*tap (f16_tap_scale, mfma_common.hpp; 256 where the sums leave or enter
+  // the pass as floats: MFMA_TO_SUMS / MFMA_FROM_SUMS); two_over_scale = 2/tap_scale, quantum_unit = that / 65535
+  float tap_scale,two_over_scale,quantum_unit;
   int strips,segments,steps_per_segment,steps;   // strips of UNITS units, steps of STEP outputs
 };
 
@@ -179,7 +182,7 @@ void conv_mfma_kernel(ConvMfmaArgs args)
   const int K=args.ntaps;
   const int W=args.columns,H=args.rows;
 
-  // ---- Toeplitz operands: T[q][i] = 256*tap[16q+8*half+i-n]; taps staged through LDS
+  // ---- Toeplitz operands: T[q][i] = tap_scale*tap[16q+8*half+i-n]; taps staged through LDS
   half8 t_hi[NQ],t_lo[NQ];
   {
     float *tap_lds=reinterpret_cast<float *>(smem_raw);
@@ -192,7 +195,7 @@ void conv_mfma_kernel(ConvMfmaArgs args)
       for (int i=0; i < 8; i++)
         {
           const int j=16*q+8*half+i-n;
-          const float t=((j >= 0) && (j < K)) ? 256.0f*tap_lds[j] : 0.0f;
+          const float t=((j >= 0) && (j < K)) ? args.tap_scale*tap_lds[j] : 0.0f;
           _Float16 h,l;
           split_f16(t,h,l);
           t_hi[q][i]=h;
@@ -408,7 +411,7 @@ void conv_mfma_kernel(ConvMfmaArgs args)
 #pragma unroll
           for (int pg=0; pg < 4; pg++)
             {
-              // S_c = 2^-9 * sum k*alpha*p, S_a = 128 * sum k*alpha:
+              // (with the taps' factor 256) S_c = 2^-9 * sum k*alpha*p, S_a = 128 * sum k*alpha:
               //   gamma*pixel = sum(k*alpha*p)/sum(k*alpha) = 65536 * S_c / S_a
               // v_rcp_f32(0) = inf and 0*inf = NaN convert to 0: PerceptibleReciprocal's clamp
               // for an all-transparent window (as the vector FAST epilogue)
@@ -416,7 +419,7 @@ void conv_mfma_kernel(ConvMfmaArgs args)
               // v_cvt_pknorm_u16_f32 rounds 65535*x to the nearest level, clamps to [0,65535],
               // maps NaN to 0 and packs two results: the whole quantisation in one instruction
               const float sa=acc[4*pg+3];
-              constexpr float unit=1.0f/(128.0f*65535.0f);
+              const float unit=args.quantum_unit;
               const float inv=MODE == MFMA_BLEND4 ? __builtin_amdgcn_rcpf(sa)*(65536.0f/65535.0f) : unit;
               const f32x2 scale01={inv,inv};
               const f32x2 scale23={inv,MODE == MFMA_BLEND4 ? unit : inv};
@@ -429,7 +432,7 @@ void conv_mfma_kernel(ConvMfmaArgs args)
                 {
                   // the row pass's alpha becomes a weight in the column pass: exact where it is small
                   // and the f32 sum cannot decide the level (mfma_common.hpp)
-                  if ((args.taps64 != nullptr) && alpha_sum_is_ambiguous(sa))
+                  if ((args.taps64 != nullptr) && alpha_sum_is_ambiguous(sa*args.two_over_scale))
                     {
                       const int x=out0+32*ng+n,y=unit0+8*mg+2*pg+half;
                       if ((x < W) && (y < H))
@@ -664,9 +667,13 @@ static MhStatus launch_mfma_typed(const View &src,ConvMfmaArgs &args)
 // MFMA_FROM_SUMS (column pass: src float sums, dst Quantum); the geometry is that of src
 MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const float *taps_device,
   int ntaps,int shift,bool blend,int io,bool *handled,const View *unsharp_original,double gain,
-  double threshold,const double *taps64_device)
+  double threshold,const double *taps64_device,float tap_scale)
 {
   *handled=false;
+  if (!(tap_scale > 0.0f))
+    return MH_OK;
+  if ((io == MFMA_TO_SUMS) || (io == MFMA_FROM_SUMS))
+    tap_scale=256.0f;                            // (the float sums between the two passes carry this factor)
   if ((io == MFMA_UNSHARP) && ((unsharp_original == nullptr) || !vertical || (src.channels != 4) ||
       (dst.channels != 4) ||
       (src.columns < 2) || (unsharp_original->quantum != MH_QUANTUM_U16)))
@@ -699,6 +706,9 @@ MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const 
   args.shift=shift;
   args.taps=taps_device;
   args.taps64=taps64_device;
+  args.tap_scale=tap_scale;
+  args.two_over_scale=2.0f/tap_scale;
+  args.quantum_unit=(float) (2.0/((double) tap_scale*65535.0));
   args.orig=nullptr;
   args.gain=0.0f;
   args.threshold=0;

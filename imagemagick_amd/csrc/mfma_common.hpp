@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cmath>
 
 namespace mh {
 
@@ -116,6 +117,7 @@ static __device__ __forceinline__ void quantum_to_samples(const uint2 (&r)[4],f3
 }
 
 // The epilogue of one pixel: the four f32 sums of a 1-D pass -> four Quantum levels, packed.
+// With the taps' factor 256 (`unit` = 2/(scale*65535) for any other):
 //   S_c = 2^-9 * sum k*alpha*p, S_a = 128 * sum k*alpha:
 //     gamma*pixel = sum(k*alpha*p)/sum(k*alpha) = 65536 * S_c / S_a
 //   v_rcp_f32(0) = inf and 0*inf = NaN convert to 0: PerceptibleReciprocal's clamp for an
@@ -123,9 +125,9 @@ static __device__ __forceinline__ void quantum_to_samples(const uint2 (&r)[4],f3
 // v_cvt_pknorm_u16_f32 rounds 65535*x to the nearest level, clamps to [0,65535], maps NaN to 0
 // and packs two results: the whole quantisation in one instruction.
 template<int MODE>
-static __device__ __forceinline__ uint2 sums_to_quantum(float s0,float s1,float s2,float sa)
+static __device__ __forceinline__ uint2 sums_to_quantum(float s0,float s1,float s2,float sa,
+  float unit=1.0f/(128.0f*65535.0f))
 {
-  constexpr float unit=1.0f/(128.0f*65535.0f);
   const float inv=MODE == MFMA_BLEND4 ? __builtin_amdgcn_rcpf(sa)*(65536.0f/65535.0f) : unit;
   const f32x2 scale01={inv,inv};
   const f32x2 scale23={inv,MODE == MFMA_BLEND4 ? unit : inv};
@@ -147,9 +149,9 @@ static __device__ __forceinline__ uint2 sums_to_quantum(float s0,float s1,float 
 constexpr float kSmallAlpha=8192.0f;
 constexpr float kAlphaSumError=0.0625f;
 
-static __device__ __forceinline__ bool alpha_sum_is_ambiguous(float sa)
+// (levels = the alpha sum in levels: S_a * 2/scale)
+static __device__ __forceinline__ bool alpha_sum_is_ambiguous(float levels)
 {
-  const float levels=sa*(1.0f/128.0f);
   const float fraction=levels-__builtin_floorf(levels);
   return (levels < kSmallAlpha) && (__builtin_fabsf(fraction-0.5f) < kAlphaSumError);
 }

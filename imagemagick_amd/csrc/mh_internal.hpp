@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstddef>
 #include <cstdarg>
+#include <cmath>
 #include <vector>
 #include <memory>
 
@@ -244,16 +245,46 @@ MhStatus launch_conv1d(const View &src,const View &dst,bool vertical,
 //                  the copy-out applies effect.c:4364-4369 against the unblurred frame
 //                  (unsharp_original, gain, threshold)
 enum MfmaIo { MFMA_Q16=0,MFMA_TO_SUMS=1,MFMA_FROM_SUMS=2,MFMA_UNSHARP=3 };
+// The f16 tap operands are scale*tap, hi + lo (split_f16, mfma_common.hpp).  A fixed factor of 256 left the small taps of a
+// kernel in f16's denormal range — absolute precision 2^-25, i.e. 2^-17 of BlurImage's outermost default
+// tap and 2^-12 of a tap of 4e-7 (-blur 25x5) — which is the whole result where such a tap is the only one
+// that meets a sample (a sprite on a transparent ground: up to 13 levels off, found by the stress run's
+// radius draws in round 6).  scale = the power of two that puts the largest tap in [2^14, 2^15): every tap
+// down to 2^-18 of the largest keeps its 22 bits, and the launchers decline kernels whose smallest tap lies
+// below 2^-19 of the largest.  Returns 0 when no tap is positive.
+static inline float f16_tap_scale(const double *taps,int K)
+{
+  double largest=0.0;
+  for (int v=0; v < K; v++)
+    largest=std::fabs(taps[v]) > largest ? std::fabs(taps[v]) : largest;
+  if (!(largest > 0.0) || !std::isfinite(largest))
+    return 0.0f;
+  int exponent=0;
+  (void) std::frexp(largest,&exponent);          // largest = m * 2^exponent, 0.5 <= m < 1
+  return (float) std::ldexp(1.0,15-exponent);
+}
+
+// ... and whether every tap is large enough beside the largest for its hi + lo terms to carry 19 bits
+static inline bool f16_taps_resolved(const double *taps,int K)
+{
+  double largest=0.0,smallest=INFINITY;
+  for (int v=0; v < K; v++)
+    {
+      const double t=std::fabs(taps[v]);
+      if (t == 0.0)
+        continue;
+      largest=t > largest ? t : largest;
+      smallest=t < smallest ? t : smallest;
+    }
+  return (largest > 0.0) && (smallest >= std::ldexp(largest,-19));
+}
+
 // FAST Q16 pass on the f16 matrix cores (convolve_mfma.hip); *handled=false when the shape is
-// outside its reach and nothing was launched.  io: an MfmaIo.
+// outside its reach and nothing was launched.  io: an MfmaIo.  tap_scale: f16_tap_scale of the taps
+// (above), MFMA_Q16 and MFMA_UNSHARP.
 MhStatus launch_conv1d_mfma(const View &src,const View &dst,bool vertical,const float *taps_device,
   int ntaps,int shift,bool blend,int io,bool *handled,const View *unsharp_original=nullptr,
-  double gain=0.0,double threshold=0.0,const double *taps64_device=nullptr);
-// BlurImage's two passes in one launch (convolve_fused.hip): the row pass's Quantum-rounded
-// result stays in an LDS ring and never reaches HBM.  taps in the reversed walk of
-// morphology.c:2746 (taps[v] multiplies the input at o-shift+v), as floats and as doubles
-// (the doubles feed the exact recomputation of ambiguous small alpha levels).
-// *handled=false when the shape is outside the kernel's reach and nothing was launched.
+  double gain=0.0,double threshold=0.0,const double *taps64_device=nullptr,float tap_scale=256.0f);
 // ... with cells that are integer multiples of a unit: exact sums on the i8 matrix cores,
 // bit-identical in both precision modes (convolve2d_exact.hip)
 MhStatus launch_conv2d_exact(const View &src,const View &dst,const MhKernelInfo *kernel,bool blend,
@@ -264,11 +295,9 @@ MhStatus launch_conv2d_tie(const View &src,const View &dst,const MhKernelInfo *k
   bool *handled,const unsigned *only_if=nullptr);
 MhStatus launch_conv2d_mfma(const View &src,const View &dst,const MhKernelInfo *kernel,bool blend,
   bool *handled);
-MhStatus launch_blur_fused(const View &src,const View &dst,const float *taps_device,
-  const double *taps64_device,int ntaps,int shift,bool blend,bool *handled,bool unsharp=false,
-  double gain=0.0,double threshold=0.0);
-// The same walk with an exact-integer row pass (convolve_fused_exact.hip): taps = HOST doubles in
-// the reversed walk, all positive.  exact_column = true: both passes exact, the result is
+// BlurImage's two passes in one launch: the row pass's Quantum-rounded result stays in an LDS ring and
+// never reaches HBM.  Exact-integer sums (convolve_fused_exact.hip): taps = HOST doubles in the reversed
+// walk of morphology.c:2746 (taps[v] multiplies the input at o-shift+v), all positive.  exact_column = true: both passes exact, the result is
 // bit-identical to the reference (MH_PRECISION_EXACT); false: exact row pass + f16 column pass,
 // within +-1 level by construction (MH_PRECISION_FAST).  recomputed_device (optional): a device
 // counter that receives the number of samples recomputed in the reference's operation order.

@@ -488,8 +488,10 @@ struct MorphologyWorkspace
 };
 
 // BlurImage's kernel list — a 1 x K row kernel followed by the same taps as a K x 1 column
-// kernel (effect.c:765-796, "blur:RxS;blur:RxS+90") — in FAST precision on Q16 RGBA: both passes
-// in one launch, the Quantum-rounded intermediate stays in LDS (convolve_fused.hip).
+// kernel (effect.c:765-796, "blur:RxS;blur:RxS+90") — on Q16 RGBA / RGB / four plain channels: both
+// passes in one launch, the Quantum-rounded intermediate stays in LDS.  EXACT and UnsharpMaskImage:
+// exact-integer sums in both passes, bit-identical (convolve_fused_exact.hip); FAST BlurImage: f16
+// colour sums + exact alpha sums, +-1 by construction (convolve_fused_hybrid.hip).
 // *handled = false: not this case, nothing launched.
 static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *kernel,
   const Roles &roles,double bias,bool *handled,bool unsharp=false,double gain=0.0,double threshold=0.0)
@@ -498,20 +500,9 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
   // (switches for tests and A/B runs, from the option table: the environment at start-up + MhSetOption)
   const bool no_mfma=option("MAGICKHIP_NO_MFMA") != nullptr;
   const bool no_fused=option("MAGICKHIP_NO_FUSED_BLUR") != nullptr;
-  // (round 2's all-f16 form of the RGBA blur — +-2 on structured ties, out of contract — and round
-  // 3's exact-row + f16-column form are superseded by convolve_fused_hybrid.hip; their switches
-  // exist in diagnostic builds only: make VDEFS=-DMH_DIAGNOSTIC)
-#ifdef MH_DIAGNOSTIC
-  const bool no_exact_mfma=option("MAGICKHIP_NO_EXACT_MFMA") != nullptr;
-  const bool no_hybrid=option("MAGICKHIP_NO_HYBRID") != nullptr;
-  const bool fast_unsharp=option("MAGICKHIP_FAST_UNSHARP") != nullptr;
-#else
-  const bool no_exact_mfma=false,no_hybrid=false,fast_unsharp=false;
-#endif
-  const bool fused_rgb=option("MAGICKHIP_FUSED_RGB") != nullptr;
   const bool exact=precision() == MH_PRECISION_EXACT;
   if ((src.quantum != MH_QUANTUM_U16) || ((src.channels != 4) && (src.channels != 3)) ||
-      (roles.copy_mask != 0) || (bias != 0.0) || no_mfma || no_fused || (exact && no_exact_mfma))
+      (roles.copy_mask != 0) || (bias != 0.0) || no_mfma || no_fused)
     return MH_OK;
   if (roles.blend && ((roles.alpha != 3) || (src.channels != 4)))
     return MH_OK;
@@ -529,82 +520,70 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
       if (roles.blend && (row->values[v] < 0.0))
         return MH_OK;
     }
-  // The exact-integer row pass on the matrix cores (convolve_fused_exact.hip), positive taps:
-  // EXACT = both passes exact, bit-identical to the reference; FAST = exact row pass + f16
-  // column pass, +-1 level by construction.  MAGICKHIP_NO_EXACT_MFMA=1 keeps round 2's paths
-  // (EXACT: the fp64 vector kernels; FAST: f16 products in both passes).
-  if (!no_exact_mfma)
+  // Taps the reference zeroed (|t| < 1e-12, morphology.c:2494-2495: BlurImage with a radius far beyond
+  // its sigma, "-blur 30x2") add +0.0 to sums of non-negative terms (:2746-2764, :2950-2971) and are
+  // counted like any other tap (`count`, :2775): dropping the leading and trailing ones — a shorter
+  // kernel with its origin moved — leaves every result bit for bit what it was.
+  int lead=0,trail=0;
+  while ((lead < K-1) && (row->values[K-1-lead] == 0.0))
+    lead++;                                       // (the reversed walk: taps[v] = values[K-1-v])
+  while ((trail < K-1-lead) && (row->values[trail] == 0.0))
+    trail++;
+  const int kept=K-lead-trail;
+  const int shift=K-1-(int) row->x-lead;          // taps[v] multiplies the input at o-shift+v
+  if ((kept < 2) || (shift < 0) || (shift >= kept))
+    return MH_OK;
+  std::vector<double> reversed((size_t) kept);
+  for (int v=0; v < kept; v++)
+    reversed[(size_t) v]=row->values[K-1-lead-v];
+  // FAST BlurImage: f16 colour sums + exact alpha sums (convolve_fused_hybrid.hip), +-1 level
+  // by construction at 0.6 of the all-exact row pass's matrix instructions.
+  // FAST UnsharpMaskImage takes the all-exact kernel: a blurred sample one level off moves the
+  // sharpened one by `gain` levels and flips the threshold test next to it — only the
+  // reference's own blur keeps effect.c:4364-4369 within the +-1 contract (it is then
+  // bit-identical).
+  if (!exact && !unsharp)
     {
-      std::vector<double> reversed((size_t) K);
-      for (int v=0; v < K; v++)
-        reversed[(size_t) v]=row->values[K-1-v];
-      // FAST BlurImage: f16 colour sums + exact alpha sums (convolve_fused_hybrid.hip), +-1 level
-      // by construction at 0.6 of the all-exact row pass's matrix instructions.
-      // FAST UnsharpMaskImage takes the all-exact kernel: a blurred sample one level off moves the
-      // sharpened one by `gain` levels and flips the threshold test next to it — only the
-      // reference's own blur keeps effect.c:4364-4369 within the +-1 contract (it is then
-      // bit-identical).  MAGICKHIP_NO_HYBRID=1: the exact row pass + f16 column pass of round 3.
-      if (!exact && !unsharp && !no_hybrid)
-        {
-          MH_TRY(launch_blur_fused_hybrid(src,dst,reversed.data(),K,K-1-(int) row->x,roles.blend,handled));
-          if (*handled)
-            return MH_OK;
-        }
-      const bool exact_column=exact || (unsharp && !fast_unsharp);
-      // EXACT BlurImage of an alpha-weighted frame: the kernel may give the frame up (alpha of a few
-      // levels everywhere: BlurExactArgs::give_up); the two fp64 passes queued behind it — bit-identical
-      // too — then compute it, and leave at once otherwise.  MAGICKHIP_NO_GIVE_UP=1: never.
-      Temp give_up,rows_memory;
-      const bool guarded=exact && !unsharp && roles.blend && (option("MAGICKHIP_NO_GIVE_UP") == nullptr);
-      if (guarded)
-        {
-          MH_TRY(give_up.alloc(src.device,sizeof(unsigned),src.stream));
-          MH_HIP(hipMemsetAsync(give_up.ptr,0,sizeof(unsigned),src.stream));
-        }
-      MH_TRY(launch_blur_fused_exact(src,dst,reversed.data(),K,K-1-(int) row->x,roles.blend,exact_column,handled,
-        unsharp,gain,threshold,nullptr,guarded ? give_up.as<unsigned>() : nullptr));
-      if (*handled && guarded)
-        {
-          View rows=src;
-          MH_TRY(rows_memory.alloc(src.device,rows.bytes(),src.stream));
-          rows.pixels=rows_memory.ptr;
-          Conv1DParams first,second;
-          first.taps=row->values;
-          first.ntaps=K;
-          first.origin=(int) row->x;
-          first.only_if=give_up.as<unsigned>();
-          second.taps=column->values;
-          second.ntaps=K;
-          second.origin=(int) column->y;
-          second.only_if=give_up.as<unsigned>();
-          MH_TRY(launch_conv1d(src,rows,false,first,roles,MH_PRECISION_EXACT,nullptr));
-          MH_TRY(launch_conv1d(rows,dst,true,second,roles,MH_PRECISION_EXACT,nullptr));
-        }
+      MH_TRY(launch_blur_fused_hybrid(src,dst,reversed.data(),kept,shift,roles.blend,handled));
       if (*handled)
         return MH_OK;
     }
-  if (exact)
-    return MH_OK;                                // the fp64 vector kernels (launch_conv1d)
-  // RGB (6-byte pixels): the one f16 launch is measured level with the two matrix-core launches
-  // for BlurImage (0.68 against 0.67 ms at 8192^2: its 6-byte loads and stores are narrower)
-  // and ahead of them for UnsharpMaskImage (0.85 against 0.95 ms), so only the latter takes it
-  // by default; MAGICKHIP_FUSED_RGB=1 sends both
-  if ((src.channels == 3) && !unsharp && !fused_rgb)
-    return MH_OK;
-  // one table: K doubles, then K floats; both in the reversed walk of morphology.c:2746
-  std::vector<double> host((size_t) K+((size_t) K+1)/2);
-  float *host_floats=reinterpret_cast<float *>(host.data()+K);
-  for (int v=0; v < K; v++)
+  // EXACT BlurImage of an alpha-weighted frame: the kernel may give the frame up (alpha of a few
+  // levels everywhere: BlurExactArgs::give_up); the two fp64 passes queued behind it — bit-identical
+  // too — then compute it, and leave at once otherwise.  MAGICKHIP_NO_GIVE_UP=1: never.  Without the
+  // memory for those passes' intermediate the kernel runs unguarded (it is exact either way, only slow
+  // on such frames).
+  Temp give_up,rows_memory;
+  bool guarded=exact && !unsharp && roles.blend && (option("MAGICKHIP_NO_GIVE_UP") == nullptr);
+  if (guarded)
     {
-      host[(size_t) v]=row->values[K-1-v];
-      host_floats[v]=(float) row->values[K-1-v];
+      if ((give_up.alloc(src.device,sizeof(unsigned),src.stream) != MH_OK) ||
+          (rows_memory.alloc(src.device,src.bytes(),src.stream) != MH_OK))
+        guarded=false;
+      else
+        MH_HIP(hipMemsetAsync(give_up.ptr,0,sizeof(unsigned),src.stream));
     }
-  const void *taps=nullptr;
-  std::shared_ptr<void> keep;                   // until the launch below is enqueued
-  MH_TRY(shared_table(src.device,src.stream,host.data(),host.size()*sizeof(double),&taps,&keep));
-  const double *taps64=static_cast<const double *>(taps);
-  return launch_blur_fused(src,dst,reinterpret_cast<const float *>(taps64+K),taps64,
-    K,K-1-(int) row->x,roles.blend,handled,unsharp,gain,threshold);
+  MH_TRY(launch_blur_fused_exact(src,dst,reversed.data(),kept,shift,roles.blend,true,handled,
+    unsharp,gain,threshold,nullptr,guarded ? give_up.as<unsigned>() : nullptr));
+  if (*handled && guarded)
+    {
+      View rows=src;
+      rows.pixels=rows_memory.ptr;
+      Conv1DParams first,second;
+      first.taps=row->values;
+      first.ntaps=K;
+      first.origin=(int) row->x;
+      first.only_if=give_up.as<unsigned>();
+      second.taps=column->values;
+      second.ntaps=K;
+      second.origin=(int) column->y;
+      second.only_if=give_up.as<unsigned>();
+      MH_TRY(launch_conv1d(src,rows,false,first,roles,MH_PRECISION_EXACT,nullptr));
+      MH_TRY(launch_conv1d(rows,dst,true,second,roles,MH_PRECISION_EXACT,nullptr));
+    }
+  // Neither form took it (taps of both signs on plain channels, taps below the certificate's floor,
+  // more than 81 of them): the two passes of MorphologyApply (launch_conv1d).
+  return MH_OK;
 }
 
 // MorphologyApply, morphology.c:3634-4077: the loops over method iterations, the kernel
@@ -1127,7 +1106,7 @@ static MhStatus unsharp_fused(const View &src,const View &dst,const MhKernelInfo
     return MH_OK;
   if (roles.blend && ((roles.alpha != 3) || (src.channels != 4)))
     return MH_OK;
-  // one launch: both passes and the epilogue (convolve_fused.hip), kernels of up to 81 taps,
+  // one launch: both passes and the epilogue (convolve_fused_exact.hip), kernels of up to 81 taps,
   // RGBA / four plain channels / RGB
   MH_TRY(fused_blur(src,dst,kernels,roles,0.0,fused,true,gain,threshold));
   if (*fused)
@@ -1136,6 +1115,8 @@ static MhStatus unsharp_fused(const View &src,const View &dst,const MhKernelInfo
     return MH_OK;                                // EXACT: blur + unsharp_epilogue
   if (src.channels != 4)
     return MH_OK;                                // the two-launch form copies 8-byte pixels out
+  if (roles.blend && !f16_taps_resolved(vertical->values,(int) vertical->height))
+    return MH_OK;                                // tiny outer taps on an alpha-weighted frame: launch_conv1d
   View rows=src;
   Temp memory;
   MH_TRY(memory.alloc(src.device,rows.bytes(),src.stream));

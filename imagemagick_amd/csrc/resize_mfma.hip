@@ -447,7 +447,7 @@ static MhStatus acquire_plan(std::shared_ptr<MfmaPlanDevice> *out,const TapTable
   int waves,int device,hipStream_t stream)
 {
   const bool shared=(vt.serial != 0) && (ht.serial != 0);
-  constexpr size_t kEntries=6;
+  constexpr size_t kEntries=16;
   if (shared)
     {
       std::lock_guard<std::mutex> guard(mfma_plans_lock());
@@ -468,13 +468,18 @@ static MhStatus acquire_plan(std::shared_ptr<MfmaPlanDevice> *out,const TapTable
   auto built=std::make_shared<MfmaPlanDevice>();
   MH_TRY(build_plan_device(*built,vt,ht,tps,waves,device,stream));
   *out=built;
+  // (the evicted plan is released after the lock: its destructor drains the device)
+  std::shared_ptr<MfmaPlanDevice> evicted;
   if (shared)
     {
       std::lock_guard<std::mutex> guard(mfma_plans_lock());
       std::vector<MfmaPlanEntry> &entries=mfma_plans();
       entries.insert(entries.begin(),MfmaPlanEntry{vt.serial,ht.serial,device,tps,waves,built});
       if (entries.size() > kEntries)
-        entries.pop_back();
+        {
+          evicted=std::move(entries.back().plan);
+          entries.pop_back();
+        }
     }
   return MH_OK;
 }

@@ -605,7 +605,7 @@ static MhStatus acquire_stream_plan(std::shared_ptr<StreamPlanDevice> *out,const
   int src_columns,int src_rows,int device,hipStream_t stream)
 {
   const bool shared=(vt.serial != 0) && (ht.serial != 0);
-  constexpr size_t kEntries=6;
+  constexpr size_t kEntries=16;
   if (shared)
     {
       std::lock_guard<std::mutex> guard(stream_plans_lock());
@@ -625,13 +625,18 @@ static MhStatus acquire_stream_plan(std::shared_ptr<StreamPlanDevice> *out,const
   auto built=std::make_shared<StreamPlanDevice>();
   MH_TRY(build_stream_plan_device(*built,vt,ht,src_columns,src_rows,device,stream));
   *out=built;
+  // (the evicted plan is released after the lock: its destructor drains the device)
+  std::shared_ptr<StreamPlanDevice> evicted;
   if (shared)
     {
       std::lock_guard<std::mutex> guard(stream_plans_lock());
       std::vector<StreamPlanEntry> &entries=stream_plans();
       entries.insert(entries.begin(),StreamPlanEntry{vt.serial,ht.serial,device,built});
       if (entries.size() > kEntries)
-        entries.pop_back();
+        {
+          evicted=std::move(entries.back().plan);
+          entries.pop_back();
+        }
     }
   return MH_OK;
 }

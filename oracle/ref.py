@@ -56,6 +56,7 @@ def _load(hdri, shim=False):
     L.ref_colorspace_name.restype = cp
     L.ref_colorspace_name.argtypes = [ctypes.c_int]
     L.ref_image_get.argtypes = [vp, vp]
+    L.ref_image_get_rows.argtypes = [vp, ctypes.c_ssize_t, ctypes.c_size_t, vp]
     L.ref_image_set_channel_mask.argtypes = [vp, cp]
     L.ref_image_set_artifact.argtypes = [vp, cp, cp]
     L.ref_image_get_property.restype = cp
@@ -144,6 +145,15 @@ class RefImage:
                        dtype=np.float32 if self.hdri else np.uint16)
         if self.L.ref_image_get(self.handle, out.ctypes.data) != 0:
             raise RuntimeError("ref_image_get failed")
+        return out
+
+    def numpy_rows(self, y0, rows, out=None):
+        """Rows [y0, y0+rows) of the pixel cache (a 17 GB frame is compared a band at a time)."""
+        i = self.info()
+        if out is None:
+            out = np.empty((rows, i["columns"], i["channels"]), dtype=np.float32 if self.hdri else np.uint16)
+        if self.L.ref_image_get_rows(self.handle, y0, rows, out.ctypes.data) != 0:
+            raise RuntimeError("ref_image_get_rows failed")
         return out
 
     def set_channel_mask(self, channels):

@@ -181,6 +181,27 @@ REF_API int ref_image_get(const void *handle,void *pixels)
   return(0);
 }
 
+/* rows [y0, y0+rows) only: a 17 GB result is compared a band at a time */
+REF_API int ref_image_get_rows(const void *handle,ssize_t y0,size_t rows,void *pixels)
+{
+  const Image *image=(const Image *) handle;
+  const Quantum *p;
+  size_t row_bytes;
+  ssize_t y;
+
+  if ((image == (const Image *) NULL) || (y0 < 0) || ((size_t) y0+rows > image->rows))
+    return(-1);
+  row_bytes=image->columns*GetPixelChannels(image)*sizeof(Quantum);
+  for (y=0; y < (ssize_t) rows; y++)
+  {
+    p=GetVirtualPixels(image,0,y0+y,image->columns,1,ref_exception);
+    if (p == (const Quantum *) NULL)
+      return(-1);
+    (void) memcpy((char *) pixels+(size_t) y*row_bytes,p,row_bytes);
+  }
+  return(0);
+}
+
 /* -channel style mask, e.g. "RGB", "R", "A", "All" ... returns previous mask */
 REF_API int ref_image_set_channel_mask(void *handle,const char *channels)
 {

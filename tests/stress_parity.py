@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised differential run against the compiled reference (not part of the suite: minutes of
-CPU reference time).  Shapes, kernel lengths and operators are drawn at random, every result
+"""Randomised differential run against the compiled reference.  tests/test_gpu_stress_slice.py runs a fixed-seed
+slice of every operator family below inside the suite; this script runs them for as long as asked.  Shapes, kernel lengths and operators are drawn at random, every result
 is compared with the reference: FAST blur / unsharp within +-1 (unsharp: 1+gain off the threshold
 edge), EXACT and the morphology / histogram operators bit-identical.
    python tests/stress_parity.py [seconds] [seed]"""
@@ -16,12 +16,19 @@ import torch
 import imagemagick_amd as im
 from oracle import ref as refmod
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-rng = np.random.default_rng(seed)
-im.load()
-im.set_precision(im.PRECISION_EXACT)               # (the library's default is FAST; the cases below switch per call)
-refmod.set_thread_limit(os.cpu_count() or 1)
+rng = np.random.default_rng(1)
+_ready = False
+
+
+def setup(seed=1):
+    """Load the library (once), pin the starting precision and reseed the case generator."""
+    global rng, _ready
+    rng = np.random.default_rng(seed)
+    if not _ready:
+        im.load()
+        refmod.set_thread_limit(os.cpu_count() or 1)
+        _ready = True
+    im.set_precision(im.PRECISION_EXACT)           # (the library's default is FAST; the cases below switch per call)
 
 
 def dev(px, **kw):
@@ -126,43 +133,56 @@ def check(name, got, want, limit, detail):
 # pipe under FAST), other enlargements (matrix pipe), reductions and mixed geometries, Q16 and float,
 # alpha-weighted or four plain channels, both modes, 15 FAST BlurImage / GaussianBlurImage / UnsharpMaskImage on
 # every layout: gray, gray + alpha, RGB, RGBA, four plain channels)
-only_ops = [int(t) for t in os.environ.get("STRESS_OPS", "").split(",") if t.strip()]
-t0 = time.time()
-cases = failures = 0
-while time.time() - t0 < budget:
+NUMBER_OF_OPS = 16
+
+
+def blur_radius(sigma):
+    """BlurImage's radius argument: 0 (the width from the sigma, gem.c:281-299) most of the time; otherwise a
+    radius of its own — short ones cut the Gaussian off, long ones give kernels whose outer taps the reference
+    zeroes (|t| < 1e-12, morphology.c:2494-2495) or leaves tiny."""
+    if rng.random() < 0.6:
+        return 0.0
+    return float(np.ceil(rng.uniform(1.0, min(40.0, 6.0 * sigma + 4.0))))
+
+
+def run_case(op=None):
+    """One random case of operator family `op` (None: any); returns the number of mismatches (0 or 1)."""
+    failures = 0
     rows, cols = int(rng.integers(1, 260)), int(rng.integers(1, 330))
     if rng.random() < 0.2:
         rows, cols = int(rng.integers(1, 40)), int(rng.integers(300, 1400))
     kind = int(rng.integers(0, 6))
     px = pixels(rows, cols, kind)
-    op = int(rng.integers(0, 16))
-    if only_ops:
-        op = only_ops[int(rng.integers(0, len(only_ops)))]
+    if op is None:
+        op = int(rng.integers(0, 16))
     detail = "%dx%d kind %d" % (rows, cols, kind)
     ref = refmod.RefImage(px)
     if op == 0:                                    # FAST blur, every kernel length of the fused launch
         sigma = float(rng.uniform(0.3, 13.4))
+        radius = blur_radius(sigma)
         im.set_precision(im.PRECISION_FAST)
-        got = im.blur_image(dev(px), 0.0, sigma).numpy()
+        got = im.blur_image(dev(px), radius, sigma).numpy()
         im.set_precision(im.PRECISION_EXACT)
-        failures += check("fast blur", got, ref.blur(0.0, sigma).numpy(), 1, detail + " sigma %.3f" % sigma)
+        failures += check("fast blur", got, ref.blur(radius, sigma).numpy(), 1, detail + " %gx%.3f" % (radius, sigma))
     elif op == 1:                                  # EXACT blur (Tie64)
         sigma = float(rng.uniform(0.3, 13.4))
-        got = im.blur_image(dev(px), 0.0, sigma).numpy()
-        failures += check("exact blur", got, ref.blur(0.0, sigma).numpy(), 0, detail + " sigma %.3f" % sigma)
+        radius = blur_radius(sigma)
+        got = im.blur_image(dev(px), radius, sigma).numpy()
+        failures += check("exact blur", got, ref.blur(radius, sigma).numpy(), 0, detail + " %gx%.3f" % (radius, sigma))
     elif op == 2:                                  # FAST unsharp in the fused launch
         sigma = float(rng.uniform(0.5, 12.0))
         gain, threshold = float(rng.uniform(0.3, 3.0)), float(rng.uniform(0.0, 0.2))
+        radius = blur_radius(sigma)
         im.set_precision(im.PRECISION_FAST)
-        got = im.unsharp_mask_image(dev(px), 0.0, sigma, gain, threshold).numpy()
+        got = im.unsharp_mask_image(dev(px), radius, sigma, gain, threshold).numpy()
         im.set_precision(im.PRECISION_EXACT)
-        want = ref.unsharp(0.0, sigma, gain, threshold).numpy()
-        blurred = ref.blur(0.0, sigma).numpy().astype(np.int64)
+        want = ref.unsharp(radius, sigma, gain, threshold).numpy()
+        blurred = ref.blur(radius, sigma).numpy().astype(np.int64)
         edge = np.abs(2 * np.abs(px.astype(np.int64) - blurred) - 65535.0 * threshold) <= 2.0
         d = np.abs(got.astype(np.int64) - want.astype(np.int64))
         d[edge] = 0
         failures += check("fast unsharp", d, np.zeros_like(d), int(np.ceil(1.0 + gain)),
-                          detail + " sigma %.3f gain %.2f thr %.3f" % (sigma, gain, threshold))
+                          detail + " %gx%.3f gain %.2f thr %.3f" % (radius, sigma, gain, threshold))
     elif op == 3:                                  # symmetric convex kernels (rects)
         family = ["Disk:%.1f" % rng.uniform(0.5, 16.0), "Square:%d" % rng.integers(1, 9),
                   "Diamond:%d" % rng.integers(1, 12), "Octagon:%d" % rng.integers(1, 10),
@@ -206,14 +226,15 @@ while time.time() - t0 < budget:
         fpx = float_pixels(rows, cols, kind)
         fref = refmod.RefImage(fpx)
         sigma = float(rng.uniform(0.5, 12.0))
+        radius = blur_radius(sigma)
         if rng.random() < 0.5:
-            got = im.blur_image(dev_float(fpx), 0.0, sigma).numpy()
-            failures += check_bits("float blur", got, fref.blur(0.0, sigma).numpy(), detail + " sigma %.3f" % sigma)
+            got = im.blur_image(dev_float(fpx), radius, sigma).numpy()
+            failures += check_bits("float blur", got, fref.blur(radius, sigma).numpy(), detail + " %gx%.3f" % (radius, sigma))
         else:
             gain, threshold = float(rng.uniform(0.3, 3.0)), float(rng.uniform(0.0, 0.2))
-            got = im.unsharp_mask_image(dev_float(fpx), 0.0, sigma, gain, threshold).numpy()
-            failures += check_bits("float unsharp", got, fref.unsharp(0.0, sigma, gain, threshold).numpy(),
-                                   detail + " sigma %.3f gain %.2f thr %.3f" % (sigma, gain, threshold))
+            got = im.unsharp_mask_image(dev_float(fpx), radius, sigma, gain, threshold).numpy()
+            failures += check_bits("float unsharp", got, fref.unsharp(radius, sigma, gain, threshold).numpy(),
+                                   detail + " %gx%.3f gain %.2f thr %.3f" % (radius, sigma, gain, threshold))
     elif op == 9:                                  # float Quantum: union-of-rectangles Erode / Dilate
         fpx = float_pixels(rows, cols, kind)
         family = ["Disk:%.1f" % rng.uniform(0.5, 16.0), "Square:%d" % rng.integers(1, 9),
@@ -281,8 +302,7 @@ while time.time() - t0 < budget:
             got = im.morphology_image(dev_float(fpx, has_alpha=layout == 0) if layout != 2 else dev_float(fpx),
                                       "Convolve", 1, kernel, scale=(1.0, 1)).numpy()
             failures += check_bits("integer convolve 2-D, float frame", got, want, detail + " layout %d %s" % (layout, kernel[:60]))
-            cases += 1
-            continue
+            return failures
         if layout == 0:
             image, want = dev(px), ref.set_artifact("convolve:scale", "!").morphology("Convolve", 1, kernel).numpy()
         elif layout == 1:
@@ -368,23 +388,24 @@ while time.time() - t0 < budget:
         which = int(rng.integers(0, 3))
         sigma = float(rng.uniform(0.3, 13.4)) if which != 1 else float(rng.uniform(0.8, 4.5))
         gain, threshold = float(rng.uniform(0.3, 3.0)), float(rng.uniform(0.0, 0.2))
+        radius = blur_radius(sigma) if which != 1 else 0.0
 
         def reference(a):
             r = refmod.RefImage(a)
-            return (r.blur(0.0, sigma) if which == 0 else r.gaussian_blur(0.0, sigma) if which == 1 else
-                    r.unsharp(0.0, sigma, gain, threshold)).numpy()
+            return (r.blur(radius, sigma) if which == 0 else r.gaussian_blur(0.0, sigma) if which == 1 else
+                    r.unsharp(radius, sigma, gain, threshold)).numpy()
         if blend or channels in (1, 3):
             want = reference(frame).reshape(rows, cols, channels)
         else:
             want = np.concatenate([reference(frame[:, :, c].copy()).reshape(rows, cols, 1) for c in range(channels)], axis=2)
         image = dev(frame, has_alpha=blend)
         im.set_precision(im.PRECISION_FAST)
-        got = (im.blur_image(image, 0.0, sigma) if which == 0 else im.gaussian_blur_image(image, 0.0, sigma) if which == 1 else
-               im.unsharp_mask_image(image, 0.0, sigma, gain, threshold)).numpy().reshape(rows, cols, channels)
+        got = (im.blur_image(image, radius, sigma) if which == 0 else im.gaussian_blur_image(image, 0.0, sigma) if which == 1 else
+               im.unsharp_mask_image(image, radius, sigma, gain, threshold)).numpy().reshape(rows, cols, channels)
         im.set_precision(im.PRECISION_EXACT)
-        what = detail + " %s c%d blend=%s sigma %.3f" % (("blur", "gaussian", "unsharp")[which], channels, blend, sigma)
+        what = detail + " %s c%d blend=%s %gx%.3f" % (("blur", "gaussian", "unsharp")[which], channels, blend, radius, sigma)
         if which == 2:
-            blurred = (refmod.RefImage(frame).blur(0.0, sigma).numpy().reshape(rows, cols, channels).astype(np.int64)
+            blurred = (refmod.RefImage(frame).blur(radius, sigma).numpy().reshape(rows, cols, channels).astype(np.int64)
                        if (blend or channels in (1, 3)) else None)
             d = np.abs(got.astype(np.int64) - want.astype(np.int64))
             if blurred is not None:
@@ -399,6 +420,21 @@ while time.time() - t0 < budget:
         im.transform_image_colorspace(d2, "Lab")
         im.set_precision(im.PRECISION_EXACT)
         failures += check("fast lab", d2.numpy(), ref.colorspace("Lab").numpy(), 1, detail)
-    cases += 1
-print("%d cases, %d failures, %.0f s" % (cases, failures, time.time() - t0))
-sys.exit(1 if failures else 0)
+    return failures
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    setup(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    only_ops = [int(t) for t in os.environ.get("STRESS_OPS", "").split(",") if t.strip()]
+    t0 = time.time()
+    cases = failures = 0
+    while time.time() - t0 < budget:
+        failures += run_case(only_ops[int(rng.integers(0, len(only_ops)))] if only_ops else None)
+        cases += 1
+    print("%d cases, %d failures, %.0f s" % (cases, failures, time.time() - t0))
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()

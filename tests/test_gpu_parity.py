@@ -158,6 +158,114 @@ def test_blur_radius_argument(im, refmod):
     assert_parity(im.blur_image(dev, 5.0, 2.0).numpy(), ref.blur(5.0, 2.0).numpy(), True, "blur 5x2")
 
 
+def adversarial_blur_frames(rows, cols):
+    """Frames on which a blur that rounds an APPROXIMATE intermediate leaves the +-1 contract: both passes on
+    rounding ties (levels v + (x&1) + (y&1): the even and the odd taps of a Gaussian each sum to 1/2), the
+    frames of test_blur_fast_structured_ties_bound, tiny / binary alpha, and a sprite (opaque rectangles on a
+    transparent ground: whole windows whose only opaque samples lie under the kernel's outermost taps)."""
+    rng = np.random.default_rng(31)
+    y, x = np.mgrid[0:rows, 0:cols]
+    ties = np.empty((rows, cols, 4), dtype=np.uint16)
+    for c, level in enumerate((1000, 32767, 65533, 40000)):
+        ties[:, :, c] = level + (x & 1) + (y & 1)
+    opaque_ties = ties.copy()
+    opaque_ties[:, :, 3] = 65535
+    checker = np.empty((rows, cols, 4), dtype=np.uint16)
+    checker[:] = ((x + y) % 2 * 40000 + 100)[:, :, None]
+    sparse = rng.integers(0, 65536, (rows, cols, 4), dtype=np.uint16)
+    sparse[:, :, 3] = rng.integers(0, 4, (rows, cols), dtype=np.uint16)
+    pair = np.empty((rows, cols, 4), dtype=np.uint16)
+    pair[:, :, :3] = np.where((np.arange(cols) % 2 == 0)[None, :, None], 20001, 40000)
+    pair[:, :, 3] = np.where(np.arange(cols) % 4 == 1, 0, 65535)[None, :]
+    binary = rng.integers(0, 65536, (rows, cols, 4), dtype=np.uint16)
+    binary[:, :, 3] = np.where(rng.random((rows, cols)) < 0.5, 0, 65535)
+    sprite = rng.integers(0, 65536, (rows, cols, 4), dtype=np.uint16)
+    sprite[:, :, 3] = 0
+    for _ in range(7):
+        y0, x0 = int(rng.integers(0, rows - 2)), int(rng.integers(0, cols - 2))
+        sprite[y0: y0 + int(rng.integers(1, 25)), x0: x0 + int(rng.integers(1, 25)), 3] = 65535
+    return (("ties in both passes", ties), ("opaque ties in both passes", opaque_ties), ("checkerboard", checker),
+            ("0..3-level alpha", sparse), ("colour pair", pair), ("binary alpha", binary), ("sprite", sprite))
+
+
+def layout_pair(im, refmod, px, layout, call):
+    """(device image, reference result of `call`) for RGBA (alpha-weighted), four plain channels or RGB."""
+    if layout == "rgb":
+        px = np.ascontiguousarray(px[:, :, :3])
+        return im.Image(to_device(px)), call(refmod.RefImage(px)).numpy()
+    if layout == "plain4":
+        want = np.concatenate([call(refmod.RefImage(px[:, :, c].copy())).numpy().reshape(px.shape[0], px.shape[1], 1)
+                               for c in range(4)], axis=2)
+        return im.Image(to_device(px), has_alpha=False), want
+    return im.Image(to_device(px)), call(refmod.RefImage(px)).numpy()
+
+
+@pytest.mark.parametrize("layout", ["rgba", "plain4", "rgb"])
+@pytest.mark.parametrize("radius,sigma", [(30.0, 2.0), (40.0, 3.0), (25.0, 2.0), (7.0, 0.856), (12.0, 2.0), (3.0, 0.47),
+                                          (25.0, 5.055)])
+def test_blur_fast_kernels_with_tiny_outer_taps(im, refmod, radius, sigma, layout):
+    """The DEFAULT mode on BlurImage / UnsharpMaskImage with a radius far beyond the sigma (-blur 30x2): the outer
+    taps are exact zeros (morphology.c:2494-2495) or tiny (1e-8) beside the centre.  Where such a tap is the only
+    one that meets an opaque sample (a sprite on a transparent ground) it IS the result — sum(k*alpha*p) /
+    sum(k*alpha), morphology.c:2746-2776 — and round 5's library answered tens of thousands of levels off
+    (round 2's all-f16 kernel, reachable through an untested fall-through; the f16 taps' fixed factor of 256
+    left a tap of 4e-7 with nine bits).  Now: zero taps are dropped (they add +0.0), f16 operands are scaled to
+    the kernel's largest tap, and an alpha-weighted frame under taps below 2^-19 of the largest takes the exact
+    kernels — BlurImage within one level (bit-identical on those), UnsharpMaskImage within the contract, on
+    the adversarial frames."""
+    import bench
+    # (smallest tap 4e-7 = 2^-17.6 of the largest: the f16 kernels keep it — the two matrix-core passes here, the
+    # alpha certificate of the one-launch form wants a tap of 1e-6)
+    resolved = (radius, sigma) == (25.0, 5.055)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        for name, px in adversarial_blur_frames(133, 310):
+            holder = {}
+            image, want = layout_pair(im, refmod, px, layout, lambda r: r.blur(radius, sigma))
+            launched = set(bench.kernel_profile(im, lambda: holder.update(o=im.blur_image(image, radius, sigma)), 1))
+            what = "fast blur %gx%g %s, %s (%s)" % (radius, sigma, layout, name, " ".join(sorted(launched)))
+            if layout == "rgba" and not resolved:
+                assert "blur_fused_hybrid" not in launched, launched
+            assert_parity(holder["o"].numpy().reshape(want.shape), want, layout == "rgba" and not resolved, what)
+            gain, threshold = 1.0, 0.02
+            image, want = layout_pair(im, refmod, px, layout, lambda r: r.unsharp(radius, sigma, gain, threshold))
+            blurred = layout_pair(im, refmod, px, layout, lambda r: r.blur(radius, sigma))[1].astype(np.int64)
+            launched = set(bench.kernel_profile(
+                im, lambda: holder.update(o=im.unsharp_mask_image(image, radius, sigma, gain, threshold)), 1))
+            got = holder["o"].numpy().reshape(want.shape)
+            what = "fast unsharp %gx%g %s, %s (%s)" % (radius, sigma, layout, name, " ".join(sorted(launched)))
+            if launched == {"unsharp_fused_exact"} or (layout == "rgba" and not resolved):
+                assert_parity(got, want, True, what)                  # on the reference's own blur: bit-identical
+            else:
+                # plain channels on the f16 column pass: a blurred sample one level off moves the sharpened one
+                # by 1 + gain levels, and flips the threshold test where |2(p - b)| sits on it (effect.c:4364-4369)
+                source = (px[:, :, :3] if layout == "rgb" else px).astype(np.int64)
+                d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+                d[np.abs(2 * np.abs(source - blurred.reshape(source.shape)) - 65535.0 * threshold) <= 2.0] = 0
+                assert d.max() <= 2, "%s: max %d" % (what, d.max())
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+
+
+@pytest.mark.parametrize("layout", ["rgba", "plain4", "rgb"])
+@pytest.mark.parametrize("radius,sigma", [(0.0, 11.0), (0.0, 13.4), (50.0, 20.0)])
+def test_blur_fast_outside_the_one_launch_kernels(im, refmod, radius, sigma, layout):
+    """FAST BlurImage with more than 81 taps takes MorphologyApply's two passes on the f16 matrix cores
+    (convolve_mfma.hip); still within one level on the adversarial frames."""
+    import bench
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        for name, px in adversarial_blur_frames(133, 310):
+            holder = {}
+            image, want = layout_pair(im, refmod, px, layout, lambda r: r.blur(radius, sigma))
+            launched = set(bench.kernel_profile(im, lambda: holder.update(o=im.blur_image(image, radius, sigma)), 1))
+            assert not any(k.startswith("blur_fused") for k in launched), launched
+            assert_parity(holder["o"].numpy().reshape(want.shape), want, False,
+                          "fast blur %gx%g %s, %s" % (radius, sigma, layout, name))
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+
+
 @pytest.mark.parametrize("kind", ["opaque", "smooth"])
 def test_blur_other_distributions(im, refmod, kind):
     px = make_pixels(120, 150, 4, Q16, kind=kind)
@@ -266,12 +374,10 @@ def test_convolve_fast_signed_separable_kernel_plain_channels(im):
 @pytest.mark.parametrize("shape", [(150, 331), (70, 64), (33, 65), (1, 200), (200, 1), (17, 2)])
 @pytest.mark.parametrize("sigma", [0.6, 2.5, 10.0])
 def test_blur_and_unsharp_fast_rgb_single_launch(im, refmod, shape, sigma, options):
-    """RGB (6-byte pixels, no alpha) through the single-launch fused kernel as four plain channels
-    whose fourth is zero (MFMA_PLAIN3: only the pixel loads and stores differ): UnsharpMaskImage
-    by default, BlurImage with MAGICKHIP_FUSED_RGB=1 (measured level with its two-launch form);
-    strips and segments ragged at both edges."""
+    """RGB (6-byte pixels, no alpha) through the single-launch fused kernels as four plain channels
+    whose fourth is zero (MFMA_PLAIN3: only the pixel loads and stores differ); strips and segments
+    ragged at both edges."""
     import bench
-    options.set("MAGICKHIP_FUSED_RGB", "1")
     px = make_pixels(shape[0], shape[1], 3, Q16, seed=shape[0] + shape[1])
     dev, ref = run_pair(im, refmod, px)
     holder = {}
@@ -2017,6 +2123,39 @@ def test_resize_fast_intermediate_on_rounding_boundaries(im, refmod, case, seed)
         im.set_precision(im.PRECISION_EXACT)
     assert_parity(got, want, False, "FAST resize %s -> %s %s, %s alpha" % (shape, target, filt, kind), max_ulp=1,
                   residue=65535.0e-9 if is_float else 0.0)
+
+
+@pytest.mark.parametrize("is_float", [False, True])
+@pytest.mark.parametrize("factor,period", [(2, 5), (2, 3), (4, 7), (3, 4), (4, 1)])
+def test_resize_fast_transparent_columns_beside_planted_ties(im, refmod, factor, period, is_float):
+    """Planted for the ballot fix of round 5 (resize_stream.hip, finish_fast): the intermediate ALPHA of every
+    ordinary column sits exactly on x.5 (Triangle at a whole-number enlargement weights two rows with k/2f and
+    1-k/2f: rows alternate between a and a + f give (2f*a + f)/(2f) = a + 1/2), and every `period`-th column is
+    fully transparent, so the lane that takes PerceptibleReciprocal's branch — the first lane of a strip among
+    them, which is where the wave's mark mask is read — sits beside lanes whose value must be marked.  A lost
+    mark leaves the fused sums' last bits to choose between alpha levels 1 and 2 (or 3 and 4 ...): half the weight
+    of a neighbour in the horizontal filter, thousands of levels of colour (resize.c:3494-3530, :3709-3745)."""
+    rows, cols = 90, 700                                 # several strips of source columns per row chunk
+    rng = np.random.default_rng(100 * factor + period)
+    px = rng.integers(0, 65536, (rows, cols, 4)).astype(np.uint16)
+    y = np.arange(rows)[:, None]
+    x = np.arange(cols)[None, :]
+    px[:, :, 3] = 1 + factor * (y & 1) + 2 * factor * ((x // 3) % 3)
+    if period > 1:
+        px[:, ::period, 3] = 0
+    else:                                                # every strip's first lane transparent: columns 0 mod 8 ... and 1 mod 64
+        px[:, (x[0] % 8 == 0) | (x[0] % 64 == 1), 3] = 0
+    frame = px.astype(np.float32) if is_float else px
+    target = (factor * cols, factor * rows + (7 if factor == 2 else 0))
+    want = refmod.RefImage(frame).resize(target[0], target[1], "Triangle").numpy()
+    dev = im.Image(to_device(frame), has_alpha=True)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got = im.resize_image(dev, target[0], target[1], "Triangle").numpy()
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert_parity(got, want, False, "FAST resize x%d Triangle, transparent columns every %d" % (factor, period),
+                  max_ulp=1, residue=65535.0e-9 if is_float else 0.0)
 
 
 def test_resize_fast_falls_back_to_two_passes(im, refmod):
