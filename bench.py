@@ -328,7 +328,7 @@ def cpu_baseline_configs():
         image = ref.RefImage(px)
         seconds = sorted(image.blur(0.0, 2.0).last_seconds for _ in range(5))
         out["c1_blur_1024_sigma2"] = {"value": round(1024.0 * 1024.0 / seconds[2] / 1e6, 2), "unit": "Mpixels/s",
-                                      "ms": round(seconds[2] * 1e3, 3), "cores": int(threads), "kind": "reference",
+                                      "ms": round(seconds[2] * 1e3, 3), "cores": int(ref.thread_limit(False)), "kind": "reference",
                                       "sample": "1024x1024 RGBA Q16 BlurImage(0x2), reference MagickCore OpenMP path, "
                                                 "median of 5 calls"}
     except Exception as exc:
@@ -363,6 +363,32 @@ def cpu_baseline_configs():
         out["c5_convolve_disk15"] = entry(float(d) * d, r.last_seconds,
                                           "%dx%d RGBA Q16 Convolve Disk:15, convolve:scale='!'" % (d, d))
         del r
+        # the reduction, whole frame (Q16 and float), and the reference's own device benchmark chain
+        m = 8192
+        px = rng.integers(0, 65536, (m, m, 4), dtype=np.uint16)
+        r = ref.RefImage(px).resize(2048, 2048, "Lanczos")
+        reduce_q16 = entry(2048.0 * 2048.0, r.last_seconds, "8192x8192 -> 2048x2048 Lanczos ResizeImage, Q16 RGBA (%.1f source Mpixel/s)"
+                           % (float(m) * m / r.last_seconds / 1e6))
+        del r
+        r = ref.RefImage(px.astype(np.float32)).resize(2048, 2048, "Lanczos")
+        reduce_hdri = entry(2048.0 * 2048.0, r.last_seconds, "8192x8192 -> 2048x2048 Lanczos ResizeImage, float Quantum RGBA "
+                            "(%.1f source Mpixel/s)" % (float(m) * m / r.last_seconds / 1e6), True)
+        del r, px
+        out["resize_reduce"] = {"q16": reduce_q16, "hdri": reduce_hdri}
+        chain = {}
+        for label, px in (("xc_none", np.zeros((1536, 2048, 4), dtype=np.uint16)),
+                          ("random", rng.integers(0, 65536, (1536, 2048, 4), dtype=np.uint16))):
+            image = ref.RefImage(px)
+            rounds = []
+            for _ in range(3):                     # (RunOpenCLBenchmark: the first round is not timed)
+                b = image.blur(10.0, 3.5)
+                usm = b.unsharp(2.0, 2.0, 50.0, 10.0)
+                rs = usm.resize(640, 480, "Lanczos")
+                rounds.append(b.last_seconds + usm.last_seconds + rs.last_seconds)
+            sec = sorted(rounds[1:])[0]
+            chain[label] = entry(2048.0 * 1536.0, sec, "2048x1536 RGBA Q16 %s: BlurImage(10,3.5) -> UnsharpMaskImage(2,2,50,10) -> "
+                                 "ResizeImage(640x480, Lanczos), best of 2 timed rounds" % label)
+        out["reference_device_benchmark"] = chain
         u = 4096
         px = rng.integers(0, 65536, (u, u, 4), dtype=np.uint16)
         r = ref.RefImage(px).unsharp(0.0, 10.0, 1.0, 0.02)
@@ -779,6 +805,8 @@ def extra_measurements(im, torch, args, image):
         torch.cuda.empty_cache()
         torch.cuda.empty_cache()
         configs["c1_blur_1024_sigma2"] = c1_config(im, torch, gen)
+        configs["resize_reduce"] = resize_reduce_config(im, torch, gen)
+        configs["reference_device_benchmark"] = reference_device_benchmark_config(im, torch, gen)
         result["configs"] = configs
         result["inputs"] = input_variants(im, torch, gen, args.sigma)
         torch.cuda.empty_cache()
@@ -789,6 +817,79 @@ def extra_measurements(im, torch, args, image):
     if extra.get("device_copy_GBps"):
         add_measured_ceiling(result, extra["device_copy_GBps"])
     return result
+
+
+def resize_reduce_config(im, torch, gen):
+    """The commonest resize there is, a REDUCTION: 8192^2 -> 2048^2 Lanczos on Q16 and float Quantum RGBA, both
+    modes.  Compulsory bytes = the source read + the result written; the work follows the SOURCE pixels
+    (every one of them is weighted into the first filter's output), so both pixel rates are given."""
+    m, t = 8192, 2048
+    out = {"workload": "8192x8192 -> 2048x2048 Lanczos ResizeImage (reduction), RGBA, Q16 and float Quantum"}
+    try:
+        for label, frame, px_bytes in (("q16", random_q16(torch, gen, m, m), 8.0),
+                                       ("hdri", torch.rand((m, m, 4), generator=gen, device="cuda",
+                                                           dtype=torch.float32) * 65535.0, 16.0)):
+            image = im.Image(frame)
+            compulsory = (float(m) * m + float(t) * t) * px_bytes
+            node = {}
+            for name, precision in (("fast", im.PRECISION_FAST), ("exact", im.PRECISION_EXACT)):
+                im.set_precision(precision)
+                sec = timed(torch, lambda: im.resize_image(image, t, t, "Lanczos"), 8)
+                prof = kernel_profile(im, lambda: im.resize_image(image, t, t, "Lanczos"), 3)
+                kernel_ms = sum(v["avg_ms"] for v in prof.values())
+                node[name] = {"ms": round(sec * 1e3, 4),
+                              "Mpixels_per_s": round(float(t) * t / sec / 1e6, 1),
+                              "source_Mpixels_per_s": round(float(m) * m / sec / 1e6, 1),
+                              "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in prof.items()},
+                              "roofline": {"bound": "hbm", "achieved": round(compulsory / (kernel_ms * 1e-3) / 1e9, 1),
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(compulsory / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "algorithmic_bytes": int(compulsory), "avg_ms": round(kernel_ms, 4),
+                                           "traffic": None}}
+            out[label] = node
+            del image, frame
+            torch.cuda.empty_cache()
+    finally:
+        im.set_precision(im.PRECISION_FAST if PRECISION_IS_FAST[0] else im.PRECISION_EXACT)
+    return out
+
+
+def reference_device_benchmark_config(im, torch, gen):
+    """The reference's OWN device benchmark (RunOpenCLBenchmark, opencl.c:1047-1110: what it times to rank
+    devices): a 2048x1536 RGBA frame through BlurImage(10, 3.5) -> UnsharpMaskImage(2, 2, 50, 10) ->
+    ResizeImage(640x480, Lanczos); one untimed round, then timed rounds.  The reference's frame is "xc:none"
+    (transparent black); a random frame is timed beside it."""
+    w, h = 2048, 1536
+    out = {"workload": "2048x1536 RGBA Q16: BlurImage(10,3.5) -> UnsharpMaskImage(2,2,50,10) -> ResizeImage(640x480, Lanczos) "
+                       "(RunOpenCLBenchmark, opencl.c:1066-1090)"}
+    frames = {"xc_none": torch.zeros((h, w, 4), dtype=torch.int16, device="cuda").view(torch.uint16),
+              "random": random_q16(torch, gen, h, w)}
+    compulsory = 3 * 2.0 * w * h * 8.0 - 1.0 * w * h * 8.0 + 640.0 * 480.0 * 8.0   # blur r+w, unsharp r+w, resize r + its result
+    try:
+        for label, frame in frames.items():
+            image = im.Image(frame)
+
+            def chain():
+                blurred = im.blur_image(image, 10.0, 3.5)
+                sharpened = im.unsharp_mask_image(blurred, 2.0, 2.0, 50.0, 10.0)
+                return im.resize_image(sharpened, 640, 480, "Lanczos")
+            node = {}
+            for name, precision in (("fast", im.PRECISION_FAST), ("exact", im.PRECISION_EXACT)):
+                im.set_precision(precision)
+                sec = timed(torch, chain, 20)
+                prof = kernel_profile(im, chain, 3)
+                kernel_ms = sum(v["avg_ms"] for v in prof.values())
+                node[name] = {"ms": round(sec * 1e3, 4), "Mpixels_per_s": round(float(w) * h / sec / 1e6, 1),
+                              "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in prof.items()},
+                              "roofline": {"bound": "hbm", "achieved": round(compulsory / (kernel_ms * 1e-3) / 1e9, 1),
+                                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(compulsory / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "algorithmic_bytes": int(compulsory), "avg_ms": round(kernel_ms, 4),
+                                           "traffic": None}}
+            out[label] = node
+    finally:
+        im.set_precision(im.PRECISION_FAST if PRECISION_IS_FAST[0] else im.PRECISION_EXACT)
+    return out
 
 
 def c1_config(im, torch, gen):

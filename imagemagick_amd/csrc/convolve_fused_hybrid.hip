@@ -90,9 +90,9 @@ struct HybridGeometry
   // the alpha levels of the staged window as two signed-byte planes [row][column] (low, high)
   static constexpr int ASTRIDE=alpha_plane_stride(XS);
   static constexpr int alpha_bytes=BLEND ? 2*GROUP*ASTRIDE : 0;
-  // the row pass's real alpha sums (levels, f32) on their way from the alpha waves to every pixel's lane
-  static constexpr int DSTRIDE=COLS+1;
-  static constexpr int sum_bytes=BLEND ? (int) (GROUP*DSTRIDE*sizeof(float)) : 0;
+  // the colour quotients' weights A/(scale*D) (f32) of a group's pixels on their way from the alpha waves to the
+  // row waves: [column][16 rows], a lane's four rows one 16-byte slot (swizzled with the column: weight_slot)
+  static constexpr int sum_bytes=BLEND ? (int) (COLS*GROUP*sizeof(float)) : 0;
   static constexpr int OUT_STRIDE=COLS+1;
   static constexpr int out_bytes=(int) (GROUP*OUT_STRIDE*sizeof(uint2));
   // the taps' digits for the alpha tiles' Toeplitz operands: digit j of tap v at [j][v+15], v =
@@ -176,7 +176,7 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
   _Float16 *stage_hi=reinterpret_cast<_Float16 *>(smem_raw+G::ring_bytes);
   _Float16 *stage_lo=stage_hi+G::STAGE_PLANE;
   unsigned char *alpha_plane=smem_raw+G::ring_bytes+G::stage_bytes;      // [2][GROUP][ASTRIDE]
-  float *alpha_sum=reinterpret_cast<float *>(alpha_plane+G::alpha_bytes); // [GROUP][DSTRIDE]
+  float *alpha_weight=reinterpret_cast<float *>(alpha_plane+G::alpha_bytes); // [COLS][GROUP]
   uint2 *out_tile=reinterpret_cast<uint2 *>(alpha_plane+G::alpha_bytes+G::sum_bytes);
   unsigned char *digit_table=alpha_plane+G::alpha_bytes+G::sum_bytes+G::out_bytes;   // [4][kExactDigits][DLP]
   const int tid=(int) threadIdx.x,lane=tid & 63;
@@ -203,9 +203,32 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
   const int xin0=x0-args.shift;
   const int ngroups=nblocks+G::NG-1;
 
-  // ---- Toeplitz operands of the f16 products (both passes): T[c][i] = tap_scale*tap[32c+8*kq+i-n], hi/lo
-  // split; and the digit table of the alpha tiles (HybridGeometry)
-  half8 t_hi[NC],t_lo[NC];
+  // the exact alpha tiles: waves 12..15 (one per SIMD; not stagers), tile t = wave & 3 = 16 rows x columns
+  // 16*t..+15; entry e = row, so D hands lane (n, kq) the rows 4*kq..4*kq+3 (registers) of column 16*t+n
+  const bool alpha_wave=BLEND && (wave >= 12);
+  const int alpha_tile=wave & 3;
+  const int alpha_entry=n*G::ASTRIDE+16*alpha_tile+16*kq;
+  // this lane's window of the digit table: taps 16*kq-n .. +15 (and 64+8*kq-n .. +7 of the second chunk)
+  const int digit_copy=(3-n) & 3;
+  const int digit_entry=digit_copy*(kExactDigits*G::DLP)+16*kq+15-n-digit_copy;
+
+  // ---- The matrix instructions' constant operands, in REGISTERS for the whole walk, one array for both kinds
+  // of wave (a wave is one or the other; two arrays would both be live across the loop — 54 registers — and the
+  // kernel sits at the 128 of four waves a SIMD):
+  //   every wave but the alpha waves: the Toeplitz operands of the f16 products (both passes),
+  //     T[c][i] = tap_scale*tap[32c+8*kq+i-n], hi/lo split: operand[c] (hi), operand[NC+c] (lo)
+  //   alpha waves: the taps' digits for the alpha tiles' Toeplitz operands — digit j of this lane's 16-byte
+  //     window: operand[j]; of the 8-byte window of the second chunk (kernels of more than 49 taps):
+  //     operand[5] (digits 0, 1) and the three pixel registers of a staging thread (digits 2..4: an alpha wave
+  //     does not stage).  Rounds 4-5 re-read them from an LDS table in every iteration (thirty 4-byte reads a
+  //     lane): eleven waits for the LDS in front of the integer chain, ~1000 of the 1500 cycles it took — the
+  //     longest thing in interval B.  The alpha waves therefore run no column tiles (those need the Toeplitz
+  //     operands); the tile waves share all sixteen.
+  constexpr int NOPERANDS=!BLEND ? 2*NC : (2*NC > (G::NX == 2 ? 6 : 5) ? 2*NC : (G::NX == 2 ? 6 : 5));
+  intx4 operand[NOPERANDS];
+  uint2 raw[4];
+  auto toeplitz_hi=[&](int c) { return __builtin_bit_cast(half8,operand[c]); };
+  auto toeplitz_lo=[&](int c) { return __builtin_bit_cast(half8,operand[NC+c]); };
   {
     float *tap_lds=reinterpret_cast<float *>(stage_hi);
     for (int j=tid; j < K; j+=1024)
@@ -219,19 +242,60 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
         }
     __syncthreads();
 #pragma unroll
-    for (int c=0; c < NC; c++)
+    for (int i=0; i < NOPERANDS; i++)
+      operand[i]=intx4{0,0,0,0};
 #pragma unroll
-      for (int i=0; i < 8; i++)
-        {
-          int j=32*c+8*kq+i-n;
-          const bool inside=(j >= 0) && (j < K);
-          j=inside ? j : 0;
-          const float tap=inside ? args.tap_scale*tap_lds[j] : 0.0f;
-          _Float16 h,l;
-          split_f16(tap,h,l);
-          t_hi[c][i]=h;
-          t_lo[c][i]=l;
-        }
+    for (int i=0; i < 4; i++)
+      raw[i]=make_uint2(0u,0u);
+    if (alpha_wave)
+      {
+        if constexpr (BLEND)
+          {
+#pragma unroll
+            for (int j=0; j < kExactDigits; j++)
+              {
+                const unsigned *window=reinterpret_cast<const unsigned *>(digit_table+digit_entry+j*G::DLP);
+                operand[j]=intx4{(int) window[0],(int) window[1],(int) window[2],(int) window[3]};
+              }
+            if constexpr (G::NX == 2)
+              {
+#pragma unroll
+                for (int j=0; j < kExactDigits; j++)
+                  {
+                    const unsigned *window=reinterpret_cast<const unsigned *>(digit_table+digit_entry+64-8*kq+j*G::DLP);
+                    if (j < 2)
+                      {
+                        operand[NOPERANDS-1][2*j]=(int) window[0];
+                        operand[NOPERANDS-1][2*j+1]=(int) window[1];
+                      }
+                    else
+                      raw[j-2]=make_uint2(window[0],window[1]);
+                  }
+              }
+          }
+      }
+    else
+      {
+#pragma unroll
+        for (int c=0; c < NC; c++)
+          {
+            half8 t_hi,t_lo;
+#pragma unroll
+            for (int i=0; i < 8; i++)
+              {
+                int j=32*c+8*kq+i-n;
+                const bool inside=(j >= 0) && (j < K);
+                j=inside ? j : 0;
+                const float tap=inside ? args.tap_scale*tap_lds[j] : 0.0f;
+                _Float16 h,l;
+                split_f16(tap,h,l);
+                t_hi[i]=h;
+                t_lo[i]=l;
+              }
+            operand[c]=__builtin_bit_cast(intx4,t_hi);
+            operand[NC+c]=__builtin_bit_cast(intx4,t_lo);
+          }
+      }
     __syncthreads();                             // tap_lds is the staging plane
   }
 
@@ -243,7 +307,6 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
   // behind an s_waitcnt vmcnt(0) that also waits for the prefetched pixels: 9 such reloads cost
   // 0.25 ms per 8192^2 frame.)
   const bool stager=tid < G::FETCH_GROUPS;     // wave-uniform (FETCH_GROUPS is a multiple of 64)
-  uint2 raw[4];
   auto fetch=[&](int g,int srow,int sxg)
   {
     if (stager)
@@ -322,61 +385,76 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
       }
   };
 
-  // row pass: wave = row quad (4 rows) x output tile (16 columns); entry e = 4*row + channel, so
-  // D hands a lane the four channels of ONE pixel.  Alpha-weighted frames stage no alpha plane:
-  // the alpha entry of a tile reads what lies a channel stride behind the third plane (the lo
-  // plane's first channel, the byte planes) — its sum is not used, an entry's garbage stays in
-  // its own row of the tile, and the address keeps the 16 lanes of a read group in 16 different
-  // bank slots (re-reading channel 0 instead made every operand read a two-way conflict:
-  // 0.07 ms per 8192^2 frame)
-  const int rq=wave & 3,ot=wave >> 2;
-  const int row_entry=(n & 3)*F::CHR+(4*rq+(n >> 2))*F::SR+16*ot+8*kq;
-  // the exact alpha tiles: waves 12..15 (one per SIMD; tile waves with two column tiles, not
-  // stagers), tile t = wave & 3 = 16 rows x columns 16*t..+15; entry e = row, so D hands lane
-  // (n, kq) the rows 4*kq..4*kq+3 (registers) of column 16*t+n
-#ifndef MH_HYBRID_ALPHA_LOW
-  const bool alpha_wave=BLEND && (wave >= 12);
-#else
-  const bool alpha_wave=BLEND && (wave < 4);       // (A/B: staging waves instead of tile waves)
-#endif
-  const int alpha_tile=wave & 3;
-  const int alpha_entry=n*G::ASTRIDE+16*alpha_tile+16*kq;
-  // this lane's window of the digit table: taps 16*kq-n .. +15 (and 64+8*kq-n .. +7 of the second chunk)
-  const int digit_copy=(3-n) & 3;
-  const int digit_entry=digit_copy*(kExactDigits*G::DLP)+16*kq+15-n-digit_copy;
-  // column pass: the tiles belong to the waves that do not stage (convolve_fused.hip)
-  constexpr int TILE_WAVES=16-G::FETCH_GROUPS/64;
-  constexpr int CT=(16+TILE_WAVES-1)/TILE_WAVES;
-  const int tile_wave=wave-(16-TILE_WAVES);    // < 0: a staging wave
-  const int ctiles=tile_wave < 0 ? 0 : 16/TILE_WAVES+(tile_wave < 16 % TILE_WAVES ? 1 : 0);
-  const int ctile0=tile_wave < 0 ? 0 : tile_wave*(16/TILE_WAVES)+(tile_wave < 16 % TILE_WAVES ? tile_wave : 16 % TILE_WAVES);
+  // row pass: wave = ONE channel x output tile (16 columns) x the group's 16 rows; entry e = row, so D hands
+  // lane (n, kq) rows 4*kq..4*kq+3 of column 16*ot+n — four consecutive rows of one ring column, the column
+  // pass's 8-byte unit, with no transpose.  Alpha-weighted frames: three channels x four tiles = waves 0..11
+  // (three a SIMD); the alpha waves 12..15 run the integer chain only.  (Rounds 4-5 made the entries
+  // 4 rows x 4 channels: on an alpha-weighted frame the alpha entry of every tile idled — a quarter of the row
+  // pass's matrix instructions and operand reads — and the alpha waves, last at both barriers, carried a row
+  // tile on top of their chain.)  The 16 lanes of a read group are 16 rows, SR halves apart: 16 different
+  // bank slots (alpha_plane_degree(2*SR) == 1).
+  static_assert(alpha_plane_degree(2*F::SR) == 1,"the row operands' reads are conflict-free");
+  const int rc=wave >> 2,ot=wave & 3;
+  const bool row_wave=!BLEND || (wave < 12);   // wave-uniform
+  const int row_entry=rc*F::CHR+n*F::SR+16*ot+8*kq;
+  // column pass: the sixteen tiles of a block belong to the waves that neither stage nor run the alpha tiles,
+  // three at a time (the operands of three tiles in flight are what the registers hold).  Where that leaves
+  // tiles over (81 taps, alpha-weighted: nine staging waves, four alpha waves, three tile waves = nine tiles) they
+  // go to staging waves 0..3 — the oldest wave of each SIMD, served first, done with its staging after 1750 of
+  // the interval's 2800 cycles — behind their staging.
+  constexpr int TILE_WAVES=16-G::FETCH_GROUPS/64-(BLEND ? 4 : 0);
+  static_assert(TILE_WAVES >= 1,"somebody runs the column pass");
+  constexpr int CT=3;
+  constexpr int SPILLED=16 > CT*TILE_WAVES ? 16-CT*TILE_WAVES : 0;   // tiles the tile waves cannot take
+  static_assert(SPILLED <= 4*CT,"four staging waves take the rest");
+  const int tile_wave=wave-G::FETCH_GROUPS/64; // < 0: a staging wave; >= TILE_WAVES: an alpha wave
+  int ctiles=0,ctile0=0;
+  if ((tile_wave >= 0) && (tile_wave < TILE_WAVES))
+    {
+      if constexpr (SPILLED == 0)
+        {
+          ctiles=16/TILE_WAVES+(tile_wave < 16 % TILE_WAVES ? 1 : 0);
+          ctile0=tile_wave*(16/TILE_WAVES)+(tile_wave < 16 % TILE_WAVES ? tile_wave : 16 % TILE_WAVES);
+        }
+      else
+        {
+          ctiles=CT;
+          ctile0=CT*tile_wave;
+        }
+    }
+  else if ((SPILLED > 0) && (wave < 4))
+    {
+      ctiles=SPILLED/4+(wave < SPILLED % 4 ? 1 : 0);
+      ctile0=CT*TILE_WAVES+wave*(SPILLED/4)+(wave < SPILLED % 4 ? wave : SPILLED % 4);
+    }
   constexpr int GROUP_STRIDE=2*F::OB;          // f16 ring: halves per 16-row group
   const int col_entry16=(n & 3)*F::CHC+(4*ctile0+(n >> 2))*8+(kq & 1)*F::OB;
-  // the row epilogue's ring store: after the 4 x 4 transpose lane (n, kq) holds channel kq of rows 4*rq..+3
-  const int ring_entry16=kq*F::CHC+(rq >> 1)*F::OB+(16*ot+n)*8+4*(rq & 1);
+  // the row epilogue's ring store: lane (n, kq) holds rows 4*kq..+3 of channel rc, column 16*ot+n
+  const int ring_entry16=rc*F::CHC+(kq >> 1)*F::OB+(16*ot+n)*8+4*(kq & 1);
   // ... the alpha wave's: rows 4*kq..+3 of the alpha channel, column 16*t+n
   const int ring_alpha16=3*F::CHC+(kq >> 1)*F::OB+(16*alpha_tile+n)*8+4*(kq & 1);
-  // ... and where a pixel's lane finds its own alpha half-level again: row 4*rq+kq
-  const int ring_own_alpha16=3*F::CHC+(rq >> 1)*F::OB+(16*ot+n)*8+4*(rq & 1)+kq;
+  // the weights of rows 4*kq..+3 of column 16*t+n: 16 bytes, the four row quads of a column swizzled with the
+  // column so that the 16 lanes of a b128 group (16 columns) fall into 16 different bank slots
+  auto weight_slot=[&](int tile) { return (16*tile+n)*G::GROUP+4*(kq ^ ((n >> 2) & 3)); };
   int ring_group=0;                            // g mod NR (wave-uniform)
   unsigned recomputed=0u;
 
-  // ---- The walk (convolve_fused_exact.hip).  Iteration g:
-  //   interval A: stage group g, fetch g+1 | column pass of block cb = g-NG-1 -> out_tile
-  //               | alpha waves: the exact alpha sums of group g-1 -> levels (+ the few recomputed)
-  //                 -> ring slot (alpha channel) and alpha_sum
-  //   interval B: f16 row chain of group g (all waves) and the alpha tiles' integer chain (alpha
-  //               waves): matrix pipe  ||  colour epilogue of group g-1: f32 sums + the alpha of
-  //               interval A -> ring slot;  store of block cb's rows: vector pipe
-  // What crosses a barrier: the f32 sums of a pixel (4 floats) and, alpha waves, five class tiles.
-  // (First version: alpha chain, its fp64 epilogue and the wave's own f16 chain one after the other
-  // in interval B — everyone else waited at barrier Y: 0.80 ms per 8192^2 frame against 0.44 for
-  // four plain channels.)
+  // ---- The walk.  Iteration g:
+  //   interval A: stage group g, fetch g+1 (staging waves) | column pass of block cb = g-NG-1 -> out_tile (tile
+  //               waves) | alpha waves: the integer chain of group g-1 on the byte planes they read in interval B
+  //               of the iteration before (matrix pipe, otherwise busy with the tile waves' column tiles only),
+  //               the exact sums -> levels (+ the few recomputed) -> ring slot (alpha channel) and the colour
+  //               quotients' weights (alpha_weight)
+  //   interval B: f16 row chain of group g (row waves): matrix pipe  ||  colour epilogue of group g-1: f32 sums x
+  //               the weights of interval A -> ring slot  ||  alpha waves: group g's byte-plane operands into
+  //               registers  ||  every wave: the store of one of block cb's rows
+  // What crosses a barrier: a row wave's f32 sums (4 floats); an alpha wave's plane operands (12 registers).
+  // (Rounds 4-5 ran the integer chain in interval B and carried its five class tiles across barrier Y: the
+  // youngest waves of their SIMDs, the alpha waves issued their 18 matrix instructions behind the 27 of the row
+  // waves, and the interval lasted until they were through.)
   floatx4 sums_row={0.0f,0.0f,0.0f,0.0f};
-  intx4 tiles[5];
-#pragma unroll
-  for (int c=0; c < 5; c++)
-    tiles[c]=intx4{0,0,0,0};
+  intx4 plane_low={0,0,0,0},plane_high={0,0,0,0};
+  long plane_low2=0,plane_high2=0;
   auto store_row=[&](int block,int lane)
   {
     if ((block >= 0) && (block < nblocks))
@@ -388,6 +466,8 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
       }
   };
   fetch(0,tid/G::GROUPS_PER_ROW,tid % G::GROUPS_PER_ROW);
+  // (s_setprio 3 for the alpha waves — the youngest waves of their SIMDs, with the longest chain of interval A —
+  // only changes who waits: 0.528 against 0.522 ms, profiles/r6_notes/hybrid_blur_steps.txt)
   for (int g=0; g <= ngroups+1; g++)
     {
       int opaque_tid=tid;
@@ -409,8 +489,39 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
       if constexpr (BLEND)
         if (alpha_wave && !MH_HKNOCKED(2))
           {
-            // ---- the alpha levels of group g-1 from the class tiles of interval B: first thing in
-            // the interval (the tiles free their registers for the column pass below)
+            // ---- the exact alpha sums of this wave's 16 x 16 tile of group g-1.  Sample = level*2^16: byte
+            // planes 2 (low) and 3 (high); the products b_3 x d_j (class j) and b_2 x d_j (class j-1; b_2 x d_0
+            // is dropped: part of the error bound), blur_exact_common.hpp
+            intx4 tiles[5];
+#pragma unroll
+            for (int c=0; c < 5; c++)
+              tiles[c]=intx4{0,0,0,0};
+            if (!MH_HKNOCKED(1))
+              {
+                // five tiles, then four: an instruction's tile was last written five instructions
+                // earlier (a dependent v_mfma waits for its predecessor's passes)
+#pragma unroll
+                for (int j=0; j < kExactDigits; j++)
+                  tiles[j]=digit_product(plane_high,operand[j],tiles[j]);
+#pragma unroll
+                for (int j=1; j < kExactDigits; j++)
+                  tiles[j-1]=digit_product(plane_low,operand[j],tiles[j-1]);
+                if constexpr (G::NX == 2)
+                  {
+                    auto join=[](unsigned lo,unsigned hi) { return (long) (((unsigned long) hi << 32) | (unsigned long) lo); };
+                    const long digit[kExactDigits]={
+                      join((unsigned) operand[NOPERANDS-1][0],(unsigned) operand[NOPERANDS-1][1]),
+                      join((unsigned) operand[NOPERANDS-1][2],(unsigned) operand[NOPERANDS-1][3]),
+                      join(raw[0].x,raw[0].y),join(raw[1].x,raw[1].y),join(raw[2].x,raw[2].y)};
+#pragma unroll
+                    for (int j=0; j < kExactDigits; j++)
+                      tiles[j]=digit_product(plane_high2,digit[j],tiles[j]);
+#pragma unroll
+                    for (int j=1; j < kExactDigits; j++)
+                      tiles[j-1]=digit_product(plane_low2,digit[j],tiles[j-1]);
+                  }
+              }
+            // ---- the alpha levels of group g-1 from the class tiles
             double sums_alpha[4];
             if (!MH_HKNOCKED(8))
               exact_sums(tiles,args.offset,sums_alpha);
@@ -418,10 +529,6 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
               sums_alpha[0]=sums_alpha[1]=sums_alpha[2]=sums_alpha[3]=0.0;
             unsigned q[4];
             const bool doubtful=exact_levels<false>(sums_alpha,args,q);
-            // the real sums (levels) for the colour quotients
-#pragma unroll
-            for (int r=0; r < 4; r++)
-              alpha_sum[(4*kq+r)*G::DSTRIDE+16*alpha_tile+n]=(float) (sums_alpha[r]*args.alpha_scale);
             const int x=x0+16*alpha_tile+n;
             {
               // the alpha levels of sample v of the windows of lane `from`'s four rows
@@ -441,12 +548,23 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
                 args.taps64,K,fetch_alpha,q);
             }
             // the levels as the column pass's alpha samples (level/2: hi + lo is exact)
+            const float half_level[4]={0.5f*(float) q[0],0.5f*(float) q[1],0.5f*(float) q[2],0.5f*(float) q[3]};
             uint2 hi,lo;
-            split_f16_pair(f32x2{0.5f*(float) q[0],0.5f*(float) q[1]},hi.x,lo.x);
-            split_f16_pair(f32x2{0.5f*(float) q[2],0.5f*(float) q[3]},hi.y,lo.y);
+            split_f16_pair(f32x2{half_level[0],half_level[1]},hi.x,lo.x);
+            split_f16_pair(f32x2{half_level[2],half_level[3]},hi.y,lo.y);
             const int at=ring_alpha16+previous*GROUP_STRIDE;     // group g-1's slot
             *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
             *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
+            // ... and the weight every colour sum of the pixel is multiplied with: the column pass's sample is
+            // A*R_c*2^-17 with A = the exact level, R_c = sum(k*alpha*p)/sum(k*alpha) = 2^17*S_c/(scale*D), D the
+            // REAL alpha sum in levels.  An all-transparent window: D = 0 and A = 0 -> 0*inf = NaN, which the
+            // row epilogue's v_max_f32 turns into the 0 of PerceptibleReciprocal's clamp times a zero pixel sum
+            // (morphology.c:2974-2977)
+            floatx4 weight;
+#pragma unroll
+            for (int r=0; r < 4; r++)
+              weight[r]=half_level[r]*args.two_over_scale*__builtin_amdgcn_rcpf((float) (sums_alpha[r]*args.alpha_scale));
+            *reinterpret_cast<floatx4 *>(alpha_weight+weight_slot(alpha_tile))=weight;
           }
       MH_HTRACE_MARK(3);
       // ---- f16 column pass of block cb, whole (products, division, rounding) -> out_tile
@@ -460,162 +578,118 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
               const unsigned group=wide < wide-(unsigned) G::NR ? wide : wide-(unsigned) G::NR;
               chunk_at[c]=col_entry16+GROUP_STRIDE*(int) group;
             }
-          auto column_tiles=[&](auto count)
+          auto column_tiles=[&](auto count,int done)
           {
             constexpr int N=decltype(count)::value;
-            floatx4 acc[N > 0 ? N : 1];
+            floatx4 acc[N];
 #pragma unroll
             for (int i=0; i < N; i++)
               acc[i]=floatx4{0.0f,0.0f,0.0f,0.0f};
 #pragma unroll
             for (int c=0; c < NC; c++)
               {
-                half8 a_hi[N > 0 ? N : 1],a_lo[N > 0 ? N : 1];
+                half8 a_hi[N],a_lo[N];
 #pragma unroll
                 for (int i=0; i < N; i++)
                   {
-                    a_hi[i]=*reinterpret_cast<const half8 *>(ring_hi+chunk_at[c]+4*i*F::SC);
-                    a_lo[i]=*reinterpret_cast<const half8 *>(ring_lo+chunk_at[c]+4*i*F::SC);
+                    a_hi[i]=*reinterpret_cast<const half8 *>(ring_hi+chunk_at[c]+4*(done+i)*F::SC);
+                    a_lo[i]=*reinterpret_cast<const half8 *>(ring_lo+chunk_at[c]+4*(done+i)*F::SC);
                   }
 #pragma unroll
                 for (int i=0; i < N; i++)
-                  acc[i]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[i],t_hi[c],acc[i],0,0,0);
+                  acc[i]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[i],toeplitz_hi(c),acc[i],0,0,0);
 #pragma unroll
                 for (int i=0; i < N; i++)
-                  acc[i]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[i],t_hi[c],acc[i],0,0,0);
+                  acc[i]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[i],toeplitz_hi(c),acc[i],0,0,0);
 #pragma unroll
                 for (int i=0; i < N; i++)
-                  acc[i]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[i],t_lo[c],acc[i],0,0,0);
+                  acc[i]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[i],toeplitz_lo(c),acc[i],0,0,0);
               }
 #pragma unroll
             for (int i=0; i < N; i++)
-              out_tile[n*G::OUT_STRIDE+4*(ctile0+i)+kq]=MH_HKNOCKED(128) ?
+              out_tile[n*G::OUT_STRIDE+4*(ctile0+done+i)+kq]=MH_HKNOCKED(128) ?
                 sums_to_quantum<MFMA_PLAIN4>(acc[i][0],acc[i][1],acc[i][2],acc[i][3],args.quantum_unit) :
                 sums_to_quantum<SAMPLES>(acc[i][0],acc[i][1],acc[i][2],acc[i][3],args.quantum_unit);
           };
-          if (ctiles == CT)
-            column_tiles(std::integral_constant<int,CT>{});
-          else if (ctiles == CT-1)
-            column_tiles(std::integral_constant<int,CT-1>{});
+          for (int done=0; done < ctiles; done+=CT)
+            {
+              const int left=ctiles-done;
+              if (left >= CT)
+                column_tiles(std::integral_constant<int,CT>{},done);
+              else if (left == 2)
+                column_tiles(std::integral_constant<int,2>{},done);
+              else
+                column_tiles(std::integral_constant<int,1>{},done);
+            }
         }
       MH_HTRACE_MARK(4);
       __syncthreads();                           // X: group g staged, the alpha of group g-1 published
       MH_HTRACE_MARK(5);
       // ======================================================================== interval B
       {
-        // the colour epilogue's view of the exact alpha of group g-1, read first: the chains below hide
-        // the LDS latency (at the head of the epilogue's dependent chain it cost 0.04 ms per frame)
-        float half_alpha=32767.5f,total=65535.0f;
+        // the weights of this lane's four pixels of group g-1, read first: the chains below hide the LDS latency
+        // (at the head of the epilogue's dependent chain it cost 0.04 ms per frame)
+        floatx4 weight={1.0f,1.0f,1.0f,1.0f};
         if constexpr (BLEND)
-          if (!MH_HKNOCKED(4))
-            {
-              const int own=ring_own_alpha16+previous*GROUP_STRIDE;
-              half_alpha=(float) ring_hi[own]+(float) ring_lo[own];
-              total=alpha_sum[(4*rq+kq)*G::DSTRIDE+16*ot+n];
-            }
+          if (row_wave && !MH_HKNOCKED(4))
+            weight=*reinterpret_cast<const floatx4 *>(alpha_weight+weight_slot(ot));
         if constexpr (BLEND)
-          if (alpha_wave && !MH_HKNOCKED(1))
+          if (alpha_wave)
             {
-              // ---- the exact alpha sums of this wave's 16 x 16 tile.  Sample = level*2^16: byte
-              // planes 2 (low) and 3 (high); the products b_3 x d_j (class j) and b_2 x d_j
-              // (class j-1; b_2 x d_0 is dropped: part of the error bound), blur_exact_common.hpp
-#pragma unroll
-              for (int c=0; c < 5; c++)
-                tiles[c]=intx4{0,0,0,0};
-              {
-                const intx4 low=*reinterpret_cast<const intx4 *>(alpha_plane+alpha_entry);
-                const intx4 high=*reinterpret_cast<const intx4 *>(alpha_plane+G::GROUP*G::ASTRIDE+alpha_entry);
-                intx4 digit[kExactDigits];
-#pragma unroll
-                for (int j=0; j < kExactDigits; j++)
-                  {
-                    const unsigned *window=reinterpret_cast<const unsigned *>(digit_table+digit_entry+j*G::DLP);
-                    digit[j]=intx4{(int) window[0],(int) window[1],(int) window[2],(int) window[3]};
-                  }
-                // five tiles, then four: an instruction's tile was last written five instructions
-                // earlier (a dependent v_mfma waits for its predecessor's passes)
-#pragma unroll
-                for (int j=0; j < kExactDigits; j++)
-                  tiles[j]=digit_product(high,digit[j],tiles[j]);
-#pragma unroll
-                for (int j=1; j < kExactDigits; j++)
-                  tiles[j-1]=digit_product(low,digit[j],tiles[j-1]);
-              }
+              // group g's byte-plane operands, for the chain of the next interval A (the planes are rewritten there)
+              plane_low=*reinterpret_cast<const intx4 *>(alpha_plane+alpha_entry);
+              plane_high=*reinterpret_cast<const intx4 *>(alpha_plane+G::GROUP*G::ASTRIDE+alpha_entry);
               if constexpr (G::NX == 2)
                 {
                   const int at=alpha_entry+64-8*kq;          // columns 64+8*kq .. +7
-                  const long low=*reinterpret_cast<const long *>(alpha_plane+at);
-                  const long high=*reinterpret_cast<const long *>(alpha_plane+G::GROUP*G::ASTRIDE+at);
-                  long digit[kExactDigits];
-#pragma unroll
-                  for (int j=0; j < kExactDigits; j++)
-                    {
-                      const unsigned *window=reinterpret_cast<const unsigned *>(digit_table+digit_entry+64-8*kq+j*G::DLP);
-                      digit[j]=(long) (((unsigned long) window[1] << 32) | (unsigned long) window[0]);
-                    }
-#pragma unroll
-                  for (int j=0; j < kExactDigits; j++)
-                    tiles[j]=digit_product(high,digit[j],tiles[j]);
-#pragma unroll
-                  for (int j=1; j < kExactDigits; j++)
-                    tiles[j-1]=digit_product(low,digit[j],tiles[j-1]);
+                  plane_low2=*reinterpret_cast<const long *>(alpha_plane+at);
+                  plane_high2=*reinterpret_cast<const long *>(alpha_plane+G::GROUP*G::ASTRIDE+at);
                 }
             }
         MH_HTRACE_MARK(6);
-        // ---- f16 row chain of group g
-        floatx4 acc={0.0f,0.0f,0.0f,0.0f};
-#pragma unroll
-        for (int c=0; c < NC; c++)
-          {
-            const half8 a_hi=*reinterpret_cast<const half8 *>(stage_hi+row_entry+32*c);
-            const half8 a_lo=*reinterpret_cast<const half8 *>(stage_lo+row_entry+32*c);
-            acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi,t_hi[c],acc,0,0,0);
-            acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo,t_hi[c],acc,0,0,0);
-            acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi,t_lo[c],acc,0,0,0);
-          }
-        // ---- colour epilogue of group g-1 (beside the chains above): lane (n, kq) = the four channels of pixel (row 4*rq+kq,
-        // column 16*ot+n).  The column pass's samples, UNROUNDED:
-        //   alpha-weighted: A*R_c*2^-17 with A = the exact alpha level (ring, interval B) and
-        //                   R_c = sum(k*alpha*p)/sum(k*alpha) = 2^17*S_c/(scale*D);  A/2 for the alpha channel
+        // ---- f16 row chain of group g (one channel, 16 rows x 16 columns) and, beside it, the colour epilogue
+        // of group g-1: the column pass's samples, UNROUNDED:
+        //   alpha-weighted: A*R_c*2^-17 = S_c*weight (the alpha waves' weight, interval A)
         //   plain:          level/2 = S/scale
-        {
-          float v[4];
-          if (BLEND && !MH_HKNOCKED(64))
-            {
-              // all-transparent window: D = 0 and A = 0 -> 0*inf = NaN -> v_max_f32 returns the 0
-              // (PerceptibleReciprocal's clamp times a zero pixel sum, morphology.c:2974-2977)
-              const float weight=half_alpha*args.two_over_scale*__builtin_amdgcn_rcpf(total);
-              v[0]=__builtin_fmaxf(sums_row[0]*weight,0.0f);
-              v[1]=__builtin_fmaxf(sums_row[1]*weight,0.0f);
-              v[2]=__builtin_fmaxf(sums_row[2]*weight,0.0f);
-              v[3]=half_alpha;
-            }
-          else
-            {
-              const float back=0.5f*args.two_over_scale;
-              v[0]=sums_row[0]*back; v[1]=sums_row[1]*back;
-              v[2]=sums_row[2]*back; v[3]=sums_row[3]*back;
-            }
-          // 4x4 transpose between the registers (channels) and the four 16-lane rows (pixel rows)
-          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
-                       "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"
-                       : "+v"(v[0]),"+v"(v[1]),"+v"(v[2]),"+v"(v[3]));
-          uint2 hi,lo;
-          split_f16_pair(f32x2{v[0],v[1]},hi.x,lo.x);
-          split_f16_pair(f32x2{v[2],v[3]},hi.y,lo.y);
-          // (alpha-weighted: the lanes of channel 3 rewrite what the alpha wave stored — same bits)
-          const int at=ring_entry16+previous*GROUP_STRIDE;
-          *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
-          *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
-        }
+        if (row_wave)
+          {
+            floatx4 acc={0.0f,0.0f,0.0f,0.0f};
+#pragma unroll
+            for (int c=0; c < NC; c++)
+              {
+                const half8 a_hi=*reinterpret_cast<const half8 *>(stage_hi+row_entry+32*c);
+                const half8 a_lo=*reinterpret_cast<const half8 *>(stage_lo+row_entry+32*c);
+                acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi,toeplitz_hi(c),acc,0,0,0);
+                acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo,toeplitz_hi(c),acc,0,0,0);
+                acc=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi,toeplitz_lo(c),acc,0,0,0);
+              }
+            float v[4];
+            if (BLEND && !MH_HKNOCKED(64))
+              {
+#pragma unroll
+                for (int r=0; r < 4; r++)
+                  v[r]=__builtin_fmaxf(sums_row[r]*weight[r],0.0f);
+              }
+            else
+              {
+                const float back=0.5f*args.two_over_scale;
+#pragma unroll
+                for (int r=0; r < 4; r++)
+                  v[r]=sums_row[r]*back;
+              }
+            uint2 hi,lo;
+            split_f16_pair(f32x2{v[0],v[1]},hi.x,lo.x);
+            split_f16_pair(f32x2{v[2],v[3]},hi.y,lo.y);
+            const int at=ring_entry16+previous*GROUP_STRIDE;
+            *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
+            *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
+            // (the wait states between the chain and the first vector read of its tile, whatever the
+            // block layout: hipcc pads them per basic block — see settle_tiles)
+            asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));
+            sums_row=acc;
+          }
         // the store of the column pass's rows
         store_row(cb,opaque_tid & 63);
-        // (the five class tiles cross barrier Y as they are: exact_sums at the end of this interval
-        // kept everybody waiting for the alpha waves, 0.05 ms per frame)
-        // (the wait states between the chain and the first vector read of its tile, whatever the
-        // block layout: hipcc pads them per basic block — see settle_tiles)
-        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc));
-        sums_row=acc;
       }
       MH_HTRACE_MARK(7);
       __syncthreads();                           // Y: ring group g-1 complete, out_tile read, staging reads done

@@ -38,6 +38,7 @@ MhStatus runtime_ready();                 // lazy MhInitialize + enabled check
 int default_device();
 int device_count();
 int compute_units(int device);          // cached multiProcessorCount
+int lds_bytes_per_workgroup(int device);   // cached MaxSharedMemoryPerBlock
 bool host_block_is_pinned(const void *block,size_t bytes);   // inside a block of MhHostAlloc's
 int logical_device_count();               // device_count(), or MAGICKHIP_LOGICAL_DEVICES when larger
 // the precision of the operator call this thread is in (MhImage::precision of the image the entry

@@ -579,6 +579,9 @@ MhStatus launch_resize_mfma(const View &src,const View &dst,const TapTable &vert
     waves=atoi(e);
   if ((waves != 4) && (waves != 6))
     waves=4;
+  // (sized for the 160 KiB of a gfx950 CU: two workgroups of up to 78 KiB; a part with less declines)
+  if (lds_bytes_per_workgroup(src.device) < 160*1024)
+    return MH_OK;
   std::shared_ptr<MfmaPlanDevice> plan;
   // (the staging threads each keep one patch column: the patch is at most a workgroup wide; a
   // barely-enlarging geometry's wide patch gets narrower strips)

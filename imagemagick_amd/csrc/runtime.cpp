@@ -52,6 +52,7 @@ struct DeviceState
 {
   hipStream_t stream=nullptr;
   int compute_units=0;
+  int lds_bytes=0;
   std::vector<StagingBlock> staging;
   std::multimap<size_t,PoolBlock> free_blocks;   // by capacity
   std::map<void *,size_t> live;                  // ptr -> capacity
@@ -224,6 +225,29 @@ int compute_units(int device)
       d.compute_units=n;
     }
   return d.compute_units;
+}
+
+// the LDS a workgroup may ask for (hipDeviceAttributeMaxSharedMemoryPerBlock; 160 KiB on gfx950): the
+// one-launch resize forms size their workgroups-per-CU on it and decline on a smaller part
+int lds_bytes_per_workgroup(int device)
+{
+  Runtime &r=rt();
+  std::call_once(r.once,do_init);
+  if ((device < 0) || (device >= r.ndevices))
+    return 65536;
+  std::lock_guard<std::mutex> guard(r.lock);
+  DeviceState &d=r.devices[(size_t) device];
+  if (d.lds_bytes == 0)
+    {
+      int n=0;
+      if ((hipDeviceGetAttribute(&n,hipDeviceAttributeMaxSharedMemoryPerBlock,device) != hipSuccess) || (n <= 0))
+        {
+          (void) hipGetLastError();
+          n=65536;
+        }
+      d.lds_bytes=n;
+    }
+  return d.lds_bytes;
 }
 
 hipStream_t library_stream(int device)

@@ -1,0 +1,24 @@
+"""FAST / EXACT BlurImage(0xsigma) on n^2 frames: RGBA, four plain channels, RGB — ms per call (hipEvent kernel time).
+    python tools/time_blur_quick.py [n]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import imagemagick_amd as im
+from bench import kernel_profile, timed
+im.load()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+g = torch.Generator(device="cuda").manual_seed(3)
+for channels, alpha, label in ((4, True, "rgba"), (4, False, "plain4"), (3, False, "rgb")):
+    a = torch.randint(-32768, 32768, (n, n, channels), generator=g, device="cuda", dtype=torch.int16).view(torch.uint16)
+    image = im.Image(a, has_alpha=alpha)
+    out = image.like()
+    for sigma in (10.0, 5.0, 2.0):
+        for mode, precision in (("fast", im.PRECISION_FAST), ("exact", im.PRECISION_EXACT)):
+            im.set_precision(precision)
+            f = lambda: im.blur_image(image, 0.0, sigma, out=out)
+            for _ in range(10):
+                f()
+            sec = timed(torch, f, 30)
+            prof = kernel_profile(im, f, 5)
+            print("%-6s sigma %-4g %-5s %.4f ms  kernels %s" % (label, sigma, mode, sec * 1e3,
+                  {k: round(v["avg_ms"], 4) for k, v in prof.items()}), flush=True)
