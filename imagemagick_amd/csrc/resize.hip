@@ -431,7 +431,7 @@ struct PassTables
   size_t i_start=0,i_count=0,i_near=0,i_w=0,i_wq=0;
   // vertical: dense W[tile][k][RY]
   size_t i_lo=0,i_rows=0,i_mask=0,i_dw=0,i_dwq=0;
-  int tiles=0,kmax=1;
+  int tiles=0,kmax=1,ry=0;
   // horizontal: per 256-column tile
   size_t i_tile_lo=0,i_tile_span=0;
   int max_span=1,overhang=0,maxt=8;
@@ -457,6 +457,14 @@ struct PassTables
 #define MH_VERTICAL_ROWS 4
 #endif
 constexpr int kVerticalRows=MH_VERTICAL_ROWS;      // output rows per tile of resize_vertical_kernel
+// (A reduction's windows are long and overlap — 4x Lanczos: 25 source rows per output, consecutive outputs four
+// rows apart — so a tile of 4 outputs reads 40 rows for 16 new ones, the frame 2.5 times: the pass is bound by
+// that traffic, 0.27 ms for 8192^2 -> 8192x2048 Q16.  Sixteen outputs a tile read it 1.4 times but, in the dense
+// form, run 88 x 16 multiply-adds for 16 x 25 useful ones: 0.82 ms; profiles/r6_notes/resize_reduction.txt.)
+static inline int vertical_rows_of(const TapTable &)
+{
+  return kVerticalRows;
+}
 
 template<typename T>
 static MhStatus build_pass_tables(PassTables &p,const TapTable &table,bool vertical,int device,
@@ -480,7 +488,8 @@ static MhStatus build_pass_tables(PassTables &p,const TapTable &table,bool verti
   std::vector<unsigned> mask;
   if (vertical)
     {
-      constexpr int RY=kVerticalRows;
+      const int RY=vertical_rows_of(table);
+      p.ry=RY;
       const int tiles=(table.out_size+RY-1)/RY;
       lo.assign((size_t) tiles,0);
       nrows.assign((size_t) tiles,0);
@@ -662,7 +671,6 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
 
   if (vertical)
     {
-      constexpr int RY=kVerticalRows;
       VerticalDenseArgs va;
       va.src=src.pixels;
       va.dst=dst.pixels;
@@ -679,7 +687,7 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
       va.copy_mask=roles.copy_mask;
       dim3 grid((unsigned) ((dst.columns+255)/256),(unsigned) pass->tiles);
       ProfileScope prof("resize_vertical",src.stream);
-      hipLaunchKernelGGL((resize_vertical_kernel<Q,C,BLEND,A,RY>),grid,dim3(256),0,src.stream,va);
+      hipLaunchKernelGGL((resize_vertical_kernel<Q,C,BLEND,A,kVerticalRows>),grid,dim3(256),0,src.stream,va);
     }
   else
     {
@@ -749,6 +757,26 @@ static MhStatus launch_typed(const View &src,const View &dst,bool vertical,
               reinterpret_cast<const void *>(&resize_horizontal_kernel<Q,C,BLEND,A,8>),
               hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
           hipLaunchKernelGGL((resize_horizontal_kernel<Q,C,BLEND,A,8>),grid,dim3(256),lds,
+            src.stream,args,tile_rows);
+        }
+      else if (table.max_taps <= 16)
+        {
+          // reductions (2x .. 2.6x Lanczos): the lane's weights in registers across the tile's rows
+          if (lds > 64u*1024u)
+            MH_HIP(hipFuncSetAttribute(
+              reinterpret_cast<const void *>(&resize_horizontal_kernel<Q,C,BLEND,A,16>),
+              hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+          hipLaunchKernelGGL((resize_horizontal_kernel<Q,C,BLEND,A,16>),grid,dim3(256),lds,
+            src.stream,args,tile_rows);
+        }
+      else if (table.max_taps <= 32)
+        {
+          // ... up to 5x (a 4x Lanczos reduction: 25 contributions per output)
+          if (lds > 64u*1024u)
+            MH_HIP(hipFuncSetAttribute(
+              reinterpret_cast<const void *>(&resize_horizontal_kernel<Q,C,BLEND,A,32>),
+              hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
+          hipLaunchKernelGGL((resize_horizontal_kernel<Q,C,BLEND,A,32>),grid,dim3(256),lds,
             src.stream,args,tile_rows);
         }
       else

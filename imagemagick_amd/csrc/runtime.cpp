@@ -99,6 +99,29 @@ struct Options
 };
 static Options &options() { static Options &o=*new Options; return o; }
 
+// What a USER may set from the environment: MAGICK_HIP_* (the binding's variables: LIBRARY, DEVICE, PRECISION,
+// PINNED_CACHES, ...) and the deployment knobs below.  Every other MAGICKHIP_* name in the sources selects between
+// kernels for a test or an A/B measurement: those are reachable through MhSetOption (what tests/ and tools/ use)
+// and, from the environment, only in a build with -DMH_DIAGNOSTIC.
+static bool user_option(const std::string &name)
+{
+  static const char *const deployment[]={
+    "MAGICKHIP_LOGICAL_DEVICES",      // logical devices mapped onto the node's GPUs (runtime.cpp)
+    "MAGICKHIP_BANDED_MIN_BYTES",     // host frames from this size on go through the band pipeline (batch.cpp)
+    "MAGICKHIP_BANDED_WORKERS",       // its threads per device
+    "MAGICKHIP_NO_BANDED",            // ... or not at all
+    "MAGICKHIP_PINNED_SPARE_BYTES",   // page-locked blocks kept for reuse
+    "MAGICKHIP_TRANSFER_THREADS",     // staging threads of MhUpload / MhDownload
+    "MAGICKHIP_HOST_COPY",            // how unpinned host memory moves
+    "MAGICKHIP_RCCL"};                // 0: the histogram all-reduce through the host instead of RCCL
+  if (name.compare(0,11,"MAGICK_HIP_") == 0)
+    return true;
+  for (const char *known : deployment)
+    if (name == known)
+      return true;
+  return false;
+}
+
 static void load_options()
 {
   Options &o=options();
@@ -110,7 +133,12 @@ static void load_options()
       const char *eq=strchr(*e,'=');
       if (eq == nullptr)
         continue;
-      o.values[std::string(*e,(size_t) (eq-*e))]=strdup(eq+1);
+      const std::string name(*e,(size_t) (eq-*e));
+#ifndef MH_DIAGNOSTIC
+      if (!user_option(name))
+        continue;
+#endif
+      o.values[name]=strdup(eq+1);
     }
 }
 

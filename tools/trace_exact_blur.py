@@ -16,6 +16,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "exact"
 sigma = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 n = 8192
 im.set_precision(im.PRECISION_EXACT if mode == "exact" else im.PRECISION_FAST)
+im.set_option("MAGICKHIP_EXACT_TRACE", os.environ["MAGICKHIP_EXACT_TRACE"])     # (a selector switch: not read from the environment)
 a = torch.randint(-32768, 32768, (n, n, 4), device="cuda", dtype=torch.int16).view(torch.uint16)
 img = im.Image(a)
 for _ in range(3):

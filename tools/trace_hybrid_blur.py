@@ -15,6 +15,7 @@ import imagemagick_amd as im
 layout = sys.argv[1] if len(sys.argv) > 1 else "rgba"
 n = 8192
 im.load()
+im.set_option("MAGICKHIP_HYBRID_TRACE", os.environ["MAGICKHIP_HYBRID_TRACE"])     # (a selector switch: not read from the environment)
 im.set_precision(im.PRECISION_FAST)
 a = torch.randint(-32768, 32768, (n, n, 4), device="cuda", dtype=torch.int16).view(torch.uint16)
 img = im.Image(a, has_alpha=layout == "rgba")
