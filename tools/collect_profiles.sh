@@ -1,16 +1,15 @@
 #!/bin/bash
 # Run on the GPU box (through gpurun):   tools/collect_profiles.sh <tag> [quick]
-# Produces under gpurun_out/profiles_<tag>/ (tools/import_profiles_r4.py turns it into profiles/<tag>_*):
+# Produces under gpurun_out/profiles_<tag>/ (tools/import_profiles.py turns it into profiles/<tag>_*):
 #   stats/, stats_full/   rocprofv3 --kernel-trace --stats of the default bench command
 #                         (headline only / with every secondary config)
 #   pmc_<workload>_<fetch|write>/   separate --pmc passes (kernel-trace only) of each workload:
-#                         fast (FAST blur, round 4: f16 colour + exact alpha, convolve_fused_hybrid.hip),
-#                         exact (EXACT blur, one launch), hdri (float Quantum blur), resize (C3, FAST: the
-#                         one-launch vector-pipe kernel of round 5), c4, c5
+#                         fast (FAST blur: f16 colour + exact alpha, convolve_fused_hybrid.hip), exact (EXACT
+#                         blur, one launch), hdri (float Quantum blur), resize (C3, FAST: resize_stream.hip), c4, c5
 #   sq_<fast|exact>_<a|b>/  SQ issue / wait / LDS counters of the two fused kernels
 #   bench.json            the bench line of the same box (with cpu_baseline)
 set -u
-TAG=${1:-r5a}
+TAG=${1:-r6a}
 QUICK=${2:-}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/profiles_$TAG

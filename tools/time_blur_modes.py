@@ -1,7 +1,5 @@
 """BlurImage(0,sigma) on n^2 RGBA Q16 in the mode the environment selects; one line per call.
-    python tools/time_blur_modes.py exact|fast|hdri [n] [sigma] [channels]
-MAGICKHIP_NO_EXACT_MFMA=1 selects round 2's kernels (EXACT: fp64 vector passes; FAST: f16 products
-in both passes)."""
+    python tools/time_blur_modes.py exact|fast|hdri [n] [sigma] [channels]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -34,7 +32,7 @@ f()
 recomputed = lib.MhExactBlurRecomputed(0)
 sec = timed(torch, f, 50 if mode != "hdri" else 5)
 prof = kernel_profile(im, f, 5)
-print("%-5s n=%d sigma=%g ch=%d %s: %.4f ms  %.1f Mpixel/s  recomputed %d of %d samples  kernels(ms) %s" % (
-    mode, n, sigma, channels, "old" if os.environ.get("MAGICKHIP_NO_EXACT_MFMA") else "i8",
+print("%-5s n=%d sigma=%g ch=%d: %.4f ms  %.1f Mpixel/s  recomputed %d of %d samples  kernels(ms) %s" % (
+    mode, n, sigma, channels,
     sec * 1e3, n * n / sec / 1e6, recomputed, n * n * channels * 2,
     {k: round(v["avg_ms"], 4) for k, v in prof.items()}), flush=True)
