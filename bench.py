@@ -233,9 +233,9 @@ def issue_roofline(mode, avg_ms):
                     "lds_bank_conflict_share": c.get("SQ_LDS_BANK_CONFLICT/SQ_LDS_IDX_ACTIVE"),
                     "wait_any_share_of_wave_cycles": c.get("SQ_WAIT_ANY/SQ_WAVE_CYCLES"),
                     "wait_inst_lds_share_of_wave_cycles": round(c.get("SQ_WAIT_INST_LDS", 0) / max(c.get("SQ_WAVE_CYCLES", 1), 1), 3)}
-        if c.get("GRBM_GUI_ACTIVE"):
-            # GRBM_GUI_ACTIVE sums the eight XCDs; busy CU cycles / 256 CUs is the launch in shader cycles
-            counters["shader_clock_GHz"] = round(busy / 256.0 / (avg_ms * 1e-3) / 1e9, 2)
+        clock = clock_under_load("blur_fused_hybrid" if mode == "fast" else "blur_fused_exact")
+        if clock:
+            counters["shader_clock_GHz"] = clock
         out["counters"] = counters
     return out
 

@@ -175,13 +175,28 @@ void resize_horizontal_kernel(ResizeArgs args,int tile_rows)
   const int lo=args.tile_lo[blockIdx.x],span=args.tile_span[blockIdx.x];
   int rows=args.dst_rows-y0;
   rows=rows < tile_rows ? rows : tile_rows;
-  for (int idx=(int) threadIdx.x; idx < span*rows; idx+=256)
-    {
-      int r=idx/span,i=idx-r*span;
-      Q v[C];
-      load_pixel<Q,C>(src+(size_t) (y0+r)*src_pitch+(size_t) (lo+i)*C,v);
-      store_pixel<Q,C>(tile+((size_t) r*span+i)*C,v);
-    }
+  {
+    // eight pixels of a thread in flight together: a reduction stages 4x the columns it writes (7 rows x 1048 pixels a
+    // workgroup for 4x Lanczos), and one pixel at a time that was 29 memory round trips in a row — most of the launch
+    constexpr int BATCH=8;
+    const int items=span*rows;
+    for (int i0=(int) threadIdx.x; i0 < items; i0+=256*BATCH)
+      {
+        Q v[BATCH][C];
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          {
+            int idx=i0+256*k;
+            idx=idx < items ? idx : items-1;
+            const int r=idx/span,i=idx-r*span;
+            load_pixel<Q,C>(src+(size_t) (y0+r)*src_pitch+(size_t) (lo+i)*C,v[k]);
+          }
+#pragma unroll
+        for (int k=0; k < BATCH; k++)
+          if (i0+256*k < items)
+            store_pixel<Q,C>(tile+(size_t) (i0+256*k)*C,v[k]);
+      }
+  }
   __syncthreads();
   if (x >= OUT)
     return;
@@ -190,20 +205,18 @@ void resize_horizontal_kernel(ResizeArgs args,int tile_rows)
   if (count <= 0)
     return;
   const int nearest=args.nearest[x]-lo;
-  T w[MAXT > 0 ? MAXT : 1],wq[MAXT > 0 ? MAXT : 1];
+  // the lane's weights, in registers across the tile's rows (weight*QuantumScale is formed where it is used: the
+  // same double product the host's table holds, and half the registers — with both arrays the compiler gave up
+  // at 32 contributions and re-read them from memory for every row)
+  T w[MAXT > 0 ? MAXT : 1];
   if constexpr (MAXT > 0)
     {
 #pragma unroll
       for (int j=0; j < MAXT; j++)
         {
           w[j]=(T) 0;
-          wq[j]=(T) 0;
           if (j < count)
-            {
-              w[j]=weight[(size_t) j*OUT+x];
-              if constexpr (BLEND)
-                wq[j]=weight_qs[(size_t) j*OUT+x];
-            }
+            w[j]=weight[(size_t) j*OUT+x];
         }
     }
   for (int r=0; r < rows; r++)
@@ -219,7 +232,7 @@ void resize_horizontal_kernel(ResizeArgs args,int tile_rows)
               {
                 Q q[C];
                 load_pixel<Q,C>(line+(size_t) (start+j)*C,q);
-                acc.tap(w[j],wq[j],q);
+                acc.tap(w[j],BLEND ? w[j]*(T) kQS : (T) 0,q);
               }
         }
       else
