@@ -8,9 +8,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-# seconds per family: the whole module stays under two minutes on the GPU box (the reference's CPU time dominates)
-BUDGET = {4: 9.0, 11: 9.0, 14: 14.0}
-DEFAULT_BUDGET = 5.5
+# seconds per family: the whole module stays under a minute and a half on the GPU box (the reference's CPU time dominates)
+BUDGET = {4: 7.0, 11: 7.0, 14: 10.0}
+DEFAULT_BUDGET = 4.0
 
 
 @pytest.fixture(scope="module")
