@@ -21,16 +21,20 @@
 //     (round 2's kernel ROUNDED its approximate intermediate: +-1 per sample, +-2 after the second
 //     pass on checkerboards), because nothing is rounded here that the reference does not round.
 //   * plain channels (no alpha weighting): the same argument with A_j = 1 — no exact part at all.
-//   eps + delta: f16 hi/lo operands (22 bits), f32 accumulation: measured < 0.05 level.
+//   eps + delta: f16 hi/lo operands (22 bits), f32 accumulation: measured < 0.05 level — while every tap's operand
+//   carries its bits: the operands are scale*tap with scale the power of two that puts the kernel's LARGEST tap
+//   just under 2^15 (f16_tap_scale), and the launcher declines a kernel with a tap below 2^-19 of the largest
+//   (f16_taps_resolved): where such a tap is the only one that meets an opaque sample it is the whole result.
 //
-// Per 16 x 64 pixels the row pass is 16 x 9 v_mfma_f32_16x16x32_f16 (colour; the alpha entry of a
-// tile idles) + 4 x 18 v_mfma_i32_16x16x64_i8 (four waves, one 16-row x 16-column alpha tile
-// each: nine digit products, two chunks) against 16 x 28 i8 instructions for the all-exact row
-// pass of convolve_fused_exact.hip, and its epilogue is f32 — one reciprocal and three multiplies
-// per pixel instead of ~68 fp64-rate instructions.
+// Per 16 x 64 pixels the row pass is 12 x 9 v_mfma_f32_16x16x32_f16 (three colour channels x four 16-column
+// tiles, entry = row: no tile entry idles on the alpha the integer path supplies) + 4 x 18 v_mfma_i32_16x16x64_i8
+// (four waves, one 16-row x 16-column alpha tile each: nine digit products, two chunks) against 16 x 28 i8
+// instructions for the all-exact row pass of convolve_fused_exact.hip, and its epilogue is f32 — one multiply by
+// the alpha waves' weight per value instead of ~68 fp64-rate instructions per pixel.
 //
-// Walk, ring, roles of the waves and the software pipeline over the two barrier intervals are
-// those of convolve_fused_exact.hip (COLX = false).
+// The walk (strips of 64 columns, groups of 16 rows, a ring of the unrounded row-pass result in LDS, two barrier
+// intervals an iteration, XCD-aware item order) is described at the loop; DESIGN.md section 4.1.1 has the LDS
+// budget and what bounds the kernel.
 #include "blur_exact_common.hpp"
 #include <cmath>
 #include <cstdlib>
