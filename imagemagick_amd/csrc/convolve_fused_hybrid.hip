@@ -368,8 +368,11 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
           quantum_to_samples<SAMPLES>(raw,v);
         // (one address + immediate offsets)
         unsigned char *to=smem_raw+G::ring_bytes+2*(srow*F::SR+4*sxg);
+        // (RGB frames: the fourth plane stays as it is — its row tiles are not run, what the column pass makes of it
+        // stays in the entries of the channel that is not stored)
+        constexpr int STAGED=MODE == MFMA_PLAIN3 ? 3 : G::STAGE_CHANNELS;
 #pragma unroll
-        for (int c=0; c < G::STAGE_CHANNELS; c++)
+        for (int c=0; c < STAGED; c++)
           {
             uint2 hi,lo;
             split_f16_pair(v[c][0],hi.x,lo.x);
@@ -399,7 +402,7 @@ void blur_fused_hybrid_kernel(BlurExactArgs args)
   // bank slots (alpha_plane_degree(2*SR) == 1).
   static_assert(alpha_plane_degree(2*F::SR) == 1,"the row operands' reads are conflict-free");
   const int rc=wave >> 2,ot=wave & 3;
-  const bool row_wave=!BLEND || (wave < 12);   // wave-uniform
+  const bool row_wave=!(BLEND || (MODE == MFMA_PLAIN3)) || (wave < 12);   // wave-uniform (three channels: twelve row tiles)
   const int row_entry=rc*F::CHR+n*F::SR+16*ot+8*kq;
   // column pass: the sixteen tiles of a block belong to the waves that neither stage nor run the alpha tiles,
   // three at a time (the operands of three tiles in flight are what the registers hold).  Where that leaves
