@@ -342,9 +342,13 @@ static __device__ __forceinline__ float srgb_decode_fast(float x)
 
 static __device__ __forceinline__ float lab_f_fast(float t)
 {
-  // ConvertXYZToLab, colorspace-private.h:1066-1089: cube root above epsilon, linear below
-  const float root=__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(t)*(1.0f/3.0f));
-  return t > (float) MH_CIE_EPSILON ? root : (((float) MH_CIE_K)*t+16.0f)*(1.0f/116.0f);
+  // ConvertXYZToLab, colorspace-private.h:1066-1089: cube root above epsilon, linear below.  Both sides are
+  // computed and one is selected: as a branch, the dark lanes of a wave — there almost always are some — made the
+  // wave run both sides behind six exec-mask switches per pixel pair.  (log2 of a t <= 0 is NaN / -inf: not selected.)
+  float root=__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(t)*(1.0f/3.0f));
+  asm volatile("" : "+v"(root));               // (evaluated here, for every lane: not sunk behind the comparison)
+  const float line=__builtin_fmaf((float) (MH_CIE_K/116.0),t,(float) (16.0/116.0));
+  return t > (float) MH_CIE_EPSILON ? root : line;
 }
 
 // The decode as a table in LDS: 2048 linear pieces of the curve, (value, rise) per piece.  The
@@ -378,13 +382,16 @@ static __device__ __forceinline__ uint2 srgb_to_lab_fast_pixel(uint2 px,const fl
   const float r=srgb_decode_table(decode,px.x & 0xffffu);
   const float g=srgb_decode_table(decode,px.x >> 16);
   const float b=srgb_decode_table(decode,px.y & 0xffffu);
-  const float X=0.4123955889674142161f*r+0.3575834307637148171f*g+0.1804926473817015735f*b;
-  const float Y=0.2125862307855955516f*r+0.7151703037034108499f*g+0.07220049864333622685f*b;
-  const float Z=0.01929721549174694484f*r+0.1191838645808485318f*g+0.9504971251315797660f*b;
-  const float fx=lab_f_fast(X*(float) (1.0/MH_ILL_X)),fy=lab_f_fast(Y),fz=lab_f_fast(Z*(float) (1.0/MH_ILL_Z));
-  const float L=(116.0f*fy-16.0f)*0.01f;
-  const float a=(500.0f/255.0f)*(fx-fy)+0.5f;
-  const float bb=(200.0f/255.0f)*(fy-fz)+0.5f;
+  // (fused multiply-adds written out: the library is compiled with -ffp-contract=off for the EXACT kernels' sake,
+  // and this f32 form has its own error budget; the illuminants folded into the X and Z rows)
+  constexpr float ix=(float) (1.0/MH_ILL_X),iz=(float) (1.0/MH_ILL_Z);
+  const float X=__builtin_fmaf(0.4123955889674142161f*ix,r,__builtin_fmaf(0.3575834307637148171f*ix,g,(0.1804926473817015735f*ix)*b));
+  const float Y=__builtin_fmaf(0.2125862307855955516f,r,__builtin_fmaf(0.7151703037034108499f,g,0.07220049864333622685f*b));
+  const float Z=__builtin_fmaf(0.01929721549174694484f*iz,r,__builtin_fmaf(0.1191838645808485318f*iz,g,(0.9504971251315797660f*iz)*b));
+  const float fx=lab_f_fast(X),fy=lab_f_fast(Y),fz=lab_f_fast(Z);
+  const float L=__builtin_fmaf(1.16f,fy,-0.16f);
+  const float a=__builtin_fmaf(500.0f/255.0f,fx-fy,0.5f);
+  const float bb=__builtin_fmaf(200.0f/255.0f,fy-fz,0.5f);
   // ClampToQuantum: v_cvt_pknorm_u16 clamps to [0,1] and rounds to nearest
   typedef unsigned short pk2 __attribute__((ext_vector_type(2)));
   const pk2 la=__builtin_amdgcn_cvt_pknorm_u16(L,a);
