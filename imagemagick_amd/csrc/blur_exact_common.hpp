@@ -25,7 +25,7 @@ struct BlurExactArgs
   int ntaps;
   int shift;                 // K-1-origin: offset of the first input sample (both axes)
   const double *taps64;      // double[K], taps64[v] multiplies input o-shift+v (the recomputation)
-  const float *taps;         // the same as floats (COLX = false: the f16 column pass)
+  const float *taps;         // the same as floats (the hybrid kernel's f16 products)
   const signed char *digits; // [kExactDigits][kExactDigitPitch]: balanced digits of rint(k*2^F)
   double offset;             // 128 * sum over the kept products of sum_v d_j[v] * 2^(8(i+j-3))
   double alpha_scale;        // level of a plain / alpha sum = M * alpha_scale  (2^(8-F))

@@ -1671,7 +1671,6 @@ void separable_row_sums_kernel(Conv1DArgs args,double *bound)
   const int W=args.columns,H=args.rows,K=args.ntaps;
   const int SEG=64*R;
   const int NS=63*R+R+K-1+U;
-  const int slots=NS+NS/R+1;
   Q *strip=reinterpret_cast<Q *>(smem_raw+(size_t) wave*args.wave_bytes);
 
   const unsigned ntx=(unsigned) ((W+SEG-1)/SEG);

@@ -26,14 +26,14 @@
 //            the lane itself with conv1d_reference_sample (row pass: from the source frame) or
 //            its twin over the ring (column pass: from the exact intermediate).
 //
-// COLX = true  (MH_PRECISION_EXACT): both passes exact -> the result is BIT-IDENTICAL to the
-//              reference's BlurImage / UnsharpMaskImage;
-// COLX = false (MH_PRECISION_FAST): exact row pass — the intermediate is the reference's own
-//              intermediate, bit for bit — and the f16 column pass of convolve_fused.hip, whose
-//              result is within +-1 level of the reference's column pass on the same input: the
-//              two-pass composite is +-1 BY CONSTRUCTION, on any content.
+// Both passes are exact: the result is BIT-IDENTICAL to the reference's BlurImage / UnsharpMaskImage
+// (MH_PRECISION_EXACT; UnsharpMaskImage in both modes).  MH_PRECISION_FAST BlurImage is
+// convolve_fused_hybrid.hip, which shares the alpha sums' arithmetic and certificate with this kernel.
+// (Rounds 3-5 also kept a variant with this row pass and an f16 column pass; nothing called it after the
+// hybrid kernel: removed in round 6.)
 //
-// The walk, the ring and the roles of the waves are those of convolve_fused.hip.
+// The walk (strips of 64 columns, groups of 16 rows, a ring of the intermediate in LDS, two barrier
+// intervals an iteration, XCD-aware item order) is described at the loop.
 #include "blur_exact_common.hpp"
 #include <cmath>
 #include <cstdlib>
@@ -83,7 +83,7 @@ static constexpr int exact_stage_pad(int SRX,int max_pad)
   return best;
 }
 
-template<int NC,bool COLX>
+template<int NC>
 struct ExactGeometry
 {
   typedef Fused16Geometry<NC> F;
@@ -101,7 +101,7 @@ struct ExactGeometry
   // ds_read_b128 group (4 columns x 4 channels) land in 16 different slots
   static constexpr int CHU=(NR*COLS+4)*16;               // bytes per channel of a ring plane
   static constexpr int RINGX_PLANE=4*CHU;
-  static constexpr int ring_bytes=COLX ? 4*RINGX_PLANE : (int) (2*F::RING_PLANE*sizeof(_Float16));
+  static constexpr int ring_bytes=4*RINGX_PLANE;
   static constexpr int OUT_STRIDE=COLS+1;
   static constexpr size_t lds_bytes=(size_t) ring_bytes+stage_bytes+(size_t) GROUP*OUT_STRIDE*sizeof(uint2);
   static_assert(lds_bytes <= 163840,"more than the 160 KiB of a CU");
@@ -112,7 +112,7 @@ struct ExactGeometry
   static_assert((SRX % 16) == 0,"16-byte operand reads");
 };
 
-template<int NC,int MODE,bool UNSHARP,bool COLX>
+template<int NC,int MODE,bool UNSHARP>
 __global__ __launch_bounds__(1024)
 void blur_fused_exact_kernel(BlurExactArgs args)
 {
@@ -147,12 +147,9 @@ void blur_fused_exact_kernel(BlurExactArgs args)
     else
       *reinterpret_cast<uint2 *>(at)=value;
   };
-  typedef ExactGeometry<NC,COLX> G;
-  typedef Fused16Geometry<NC> F;
+  typedef ExactGeometry<NC> G;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned char *ring=smem_raw;                          // COLX: byte planes
-  _Float16 *ring_hi=reinterpret_cast<_Float16 *>(smem_raw);   // !COLX: the f16 operand planes
-  _Float16 *ring_lo=ring_hi+F::RING_PLANE;
+  unsigned char *ring=smem_raw;                          // byte planes
   unsigned char *stage=smem_raw+G::ring_bytes;
   uint2 *out_tile=reinterpret_cast<uint2 *>(stage+G::stage_bytes);
   const int tid=(int) threadIdx.x,lane=tid & 63;
@@ -193,22 +190,17 @@ void blur_fused_exact_kernel(BlurExactArgs args)
   // ---- Toeplitz operands.  Digit j of chunk c for output n, k quarter kq: bytes b = 0..15 hold
   // d_j[64c+16kq+b-n] (0 outside the kernel).  Whatever order the instruction gives the 64 slots
   // of a chunk, it is the same for both operands: slot (kq, b) of the samples is position
-  // 64c+16kq+b.  COLX = false: also the f16 operands of the column pass (convolve_fused.hip).
+  // 64c+16kq+b.
   intx4 t0[kExactDigits];                       // slots 0..63: 16 per k quarter
   SecondOperand t1[kExactDigits];               // slots from 64: 8 or 16 per k quarter (NX = 2 only)
-  half8 t_hi[COLX ? 1 : NC],t_lo[COLX ? 1 : NC];
   {
     constexpr int DL=176;                        // digit line: tap v at [16+v], zeros around
     signed char *digit_lds=reinterpret_cast<signed char *>(stage);
-    float *tap_lds=reinterpret_cast<float *>(stage+kExactDigits*DL);
     for (int at=tid; at < kExactDigits*DL; at+=1024)
       {
         const int j=at/DL,v=at-j*DL-16;
         digit_lds[at]=((v >= 0) && (v < K)) ? args.digits[j*kExactDigitPitch+v] : (signed char) 0;
       }
-    if constexpr (!COLX)
-      for (int j=tid; j < K; j+=1024)
-        tap_lds[j]=args.taps[j];
     __syncthreads();
     auto packed=[&](const signed char *from) -> unsigned
     {
@@ -231,29 +223,12 @@ void blur_fused_exact_kernel(BlurExactArgs args)
           t1[j][w]=G::NX == 2 ? (int) packed(next+4*w) : 0;
 #endif
       }
-    if constexpr (!COLX)
-      {
-#pragma unroll
-        for (int c=0; c < NC; c++)
-#pragma unroll
-          for (int i=0; i < 8; i++)
-            {
-              int j=32*c+8*kq+i-n;
-              const bool inside=(j >= 0) && (j < K);
-              j=inside ? j : 0;
-              const float tap=inside ? 256.0f*tap_lds[j] : 0.0f;
-              _Float16 h,l;
-              split_f16(tap,h,l);
-              t_hi[c][i]=h;
-              t_lo[c][i]=l;
-            }
-      }
     __syncthreads();                             // digit_lds is the staging plane
     // every byte plane starts as 0x80 = the signed sample byte of zero: the planes 0 and 1 of an
     // alpha / plain channel (sample = level * 2^16) are never written again
     {
-      const int words=(int) ((COLX ? G::ring_bytes : 0)+G::stage_bytes)/4;
-      unsigned *fill=reinterpret_cast<unsigned *>(COLX ? ring : stage);
+      const int words=(int) (G::ring_bytes+G::stage_bytes)/4;
+      unsigned *fill=reinterpret_cast<unsigned *>(ring);
       for (int at=tid; at < words; at+=1024)
         fill[at]=0x80808080u;
     }
@@ -365,28 +340,46 @@ void blur_fused_exact_kernel(BlurExactArgs args)
   // D hands a lane the four channels of ONE pixel (lane-local division and rounding)
   const int rq=wave & 3,ot=wave >> 2;
   const int row_entry=(n & 3)*G::CHS+(4*rq+(n >> 2))*G::SRX+16*ot+16*kq;
-  // column pass: entry e = 4*column + channel, 16 outputs along y
-  //   COLX: every wave owns one tile (four columns);  a 64-row chunk spans four ring groups, one
-  //         per k quarter
-  //   else: the tiles belong to the waves that do not stage (convolve_fused.hip)
-  constexpr int TILE_WAVES=COLX ? 16 : 16-G::FETCH_GROUPS/64;
-  constexpr int CT=(16+TILE_WAVES-1)/TILE_WAVES;
-  const int tile_wave=wave-(16-TILE_WAVES);    // < 0: a staging wave
-  const int ctiles=tile_wave < 0 ? 0 : 16/TILE_WAVES+(tile_wave < 16 % TILE_WAVES ? 1 : 0);
-  const int ctile0=tile_wave < 0 ? 0 : tile_wave*(16/TILE_WAVES)+(tile_wave < 16 % TILE_WAVES ? tile_wave : 16 % TILE_WAVES);
-  constexpr int GROUP_STRIDE=2*F::OB;          // f16 ring: halves per 16-row group
-  const int col_entry16=(n & 3)*F::CHC+(4*ctile0+(n >> 2))*8+(kq & 1)*F::OB;
-  const int ring_entry16=kq*F::CHC+(rq >> 1)*F::OB+(16*ot+n)*8+4*(rq & 1);
+  // column pass: entry e = 4*column + channel, 16 outputs along y; every wave owns one tile (four columns); a
+  // 64-row chunk spans four ring groups, one per k quarter
   const int col_entryx=(n & 3)*G::CHU+(4*wave+(n >> 2))*16;                       // + group*1024
   const int ring_entryx=kq*G::CHU+(16*ot+n)*16+4*rq;                              // + group*1024
   int ring_group=0;                            // g mod NR (wave-uniform)
-  uint2 original=make_uint2(0u,0u);
+  // Who stores the rows of a finished block (interval A of the next iteration), and when.  The staging waves
+  // begin interval A with s_waitcnt vmcnt(0) for the pixels they fetched an iteration ago, and that counter also
+  // counts stores and younger loads: a store (or UnsharpMask's source pixel, or the give_up word) issued in front of
+  // it is waited for in full.  STORE_MODE 0: every wave stores row `wave` first thing (rounds 3-5); 1: the same,
+  // behind the staging; 2: the waves that do not stage store all sixteen rows.  Measured on one box, 8192^2,
+  // 79 taps, modes 0 / 1 / 2 (profiles/r6_notes/exact_store_modes.txt): RGBA 0.902 / 0.877 / 0.953 ms, UnsharpMask
+  // 1.17 / 1.07 / 1.29, four plain channels 0.709 / 0.751 / 0.701, RGB 0.78 / 0.771 / 0.768 — alpha-weighted
+  // frames, whose staging is the long one (twelve products and three byte-plane splits a thread), gain from not
+  // waiting for the store; the waves that do not stage are the youngest of their SIMDs and the last through both
+  // intervals, so handing them three rows each costs more than it frees unless staging is short (plain frames).
+#ifndef MH_EXACT_STORE_MODE
+#define MH_EXACT_STORE_MODE (-1)
+#endif
+  constexpr int STORE_MODE=MH_EXACT_STORE_MODE >= 0 ? MH_EXACT_STORE_MODE : (BLEND ? 1 : 2);
+  constexpr int STAGE_WAVES=G::FETCH_GROUPS/64;
+  constexpr bool SPREAD_STORES=(STORE_MODE == 2) && (STAGE_WAVES < 16);
+  constexpr int STORE_WAVES=SPREAD_STORES ? 16-STAGE_WAVES : 16;
+  constexpr int STORE_ROWS=(16+STORE_WAVES-1)/STORE_WAVES;            // rows of a block per storing wave
+  const int store_wave=SPREAD_STORES ? wave-STAGE_WAVES : wave;       // < 0: stores nothing
+  uint2 original[STORE_ROWS];
+#pragma unroll
+  for (int r=0; r < STORE_ROWS; r++)
+    original[r]=make_uint2(0u,0u);
   auto fetch_original=[&](int block)
   {
-    const int x=x0+lane,y=out_begin+G::GROUP*block+wave;
-    if ((block >= 0) && (block < nblocks) && (x < W) && (y < H))
+    if ((block >= 0) && (block < nblocks) && (store_wave >= 0))
       {
-        original=load_pixel16(args.src+pixel_index(y,W,x)*PX);
+#pragma unroll
+        for (int r=0; r < STORE_ROWS; r++)
+          {
+            const int row=store_wave+r*STORE_WAVES;
+            const int x=x0+lane,y=out_begin+G::GROUP*block+row;
+            if ((row < G::GROUP) && (x < W) && (y < H))
+              original[r]=load_pixel16(args.src+pixel_index(y,W,x)*PX);
+          }
       }
   };
   unsigned recomputed=0u;
@@ -413,40 +406,52 @@ void blur_fused_exact_kernel(BlurExactArgs args)
   };
   auto store_row=[&](int block)
   {
-    if ((block >= 0) && (block < nblocks))
+    if ((block >= 0) && (block < nblocks) && (store_wave >= 0))
       {
-        uint2 result=out_tile[wave*G::OUT_STRIDE+lane];
-        if constexpr (UNSHARP)
-          result=unsharp_pixel(original,result,args.gain,args.threshold);
-        const int x=x0+lane,y=out_begin+G::GROUP*block+wave;
-        if ((x < W) && (y < H))
-          store_pixel16(args.dst+pixel_index(y,W,x)*PX,result);
+#pragma unroll
+        for (int r=0; r < STORE_ROWS; r++)
+          {
+            const int row=store_wave+r*STORE_WAVES;
+            if (row < G::GROUP)                  // wave-uniform
+              {
+                uint2 result=out_tile[row*G::OUT_STRIDE+lane];
+                if constexpr (UNSHARP)
+                  result=unsharp_pixel(original[r],result,args.gain,args.threshold);
+                const int x=x0+lane,y=out_begin+G::GROUP*block+row;
+                if ((x < W) && (y < H))
+                  store_pixel16(args.dst+pixel_index(y,W,x)*PX,result);
+              }
+          }
       }
   };
   fetch(0);
   __shared__ unsigned stop_word;
   if (tid == 0)
     stop_word=0u;
+  // the lane that looks at the give_up word: on a wave that does not stage (see MH_EXACT_STORE_MODE)
+  constexpr int WORD_LANE=SPREAD_STORES ? 1023 : 0;
   for (int g=0; g <= ngroups+1; g++)
     {
-      // BlurExactArgs::give_up: one lane looks at the word, the whole workgroup sees its copy behind
-      // barrier X and leaves behind barrier Y
-      unsigned seen_word=0u;
-      if ((args.give_up != nullptr) && (tid == 0))
-        seen_word=__hip_atomic_load(args.give_up,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
       const int cb=g-G::NG-1;                    // the column pass's block of this iteration
       const int first=ring_group;                // ring slot of group cb: (g-NG-1) mod NR = g mod NR
       const int previous=ring_group == 0 ? G::NR-1 : ring_group-1;   // ring slot of group g-1
-      if constexpr (COLX)
-        {
-          // the rows of block cb-1 (out_tile was written in the previous interval B)
-          store_row(cb-1);
-          if constexpr (UNSHARP)
-            fetch_original(cb);
-        }
-      else if constexpr (UNSHARP)
-        fetch_original(cb);
+      unsigned seen_word=0u;
+      auto issue_rest=[&]()
+      {
+        if ((args.give_up != nullptr) && (tid == WORD_LANE))
+          seen_word=__hip_atomic_load(args.give_up,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+        // the rows of block cb-1 (out_tile was written in the previous interval B)
+        store_row(cb-1);
+        if constexpr (UNSHARP)
+          fetch_original(cb);
+      };
+      if constexpr (STORE_MODE == 0)
+        issue_rest();
       MH_XTRACE_MARK(0);
+      // Staging FIRST: it waits for the pixels fetched an iteration ago with s_waitcnt vmcnt(0) — the counter
+      // also counts stores and every younger load, so whatever is issued in front of it (rounds 3-5: the store of
+      // block cb-1's row, the give_up word, UnsharpMask's source pixel) is waited for in full, on the staging
+      // waves, the longest of interval A.
       if (g < ngroups)
         {
 #ifdef MH_EXACT_TRACE
@@ -461,213 +466,105 @@ void blur_fused_exact_kernel(BlurExactArgs args)
           if (g+1 < ngroups)
             fetch(g+1);
         }
-      // ---- (COLX = false) row epilogue of group g-1: exact levels -> the f16 column pass's samples.
-      // Runs in interval A.  (-DMH_HYBRID_EPILOGUE_IN_B puts it beside the row chain of group g in
-      // interval B, which otherwise holds nothing but matrix instructions; legal — ring group g-1 is
-      // then complete at barrier Y and first read in interval A of iteration g+1 — and measured
-      // 2 % SLOWER, 0.724 against 0.707 ms: vector instructions of one wave do not hide behind the
-      // matrix instructions of another beyond what the issue model of tools/ubench says.)
-      auto row_epilogue16=[&]()
-      {
-            unsigned q[4];
-            const bool doubtful=exact_levels<BLEND>(sums_row,args,q);
-            const int x=x0+16*ot+n;
-            {
-              // source pixel (y clamped like the intermediate's rows) of lane `from`, sample v
-              auto fetch=[&](int from,int v,unsigned (&level)[4])
-              {
-                int yy=in0+G::GROUP*(g-1)+4*rq+(from >> 4);
-                yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
-                int xx=x0+16*ot+(from & 15)-args.shift+v;
-                xx=xx < 0 ? 0 : (xx > W-1 ? W-1 : xx);
-                const uint2 pixel=load_pixel16(args.src+pixel_index(yy,W,xx)*PX);
-                level[0]=pixel.x & 0xffffu; level[1]=pixel.x >> 16; level[2]=pixel.y & 0xffffu;
-                level[3]=PX == 4 ? pixel.y >> 16 : 0u;
-              };
-              recomputed+=settle_doubtful_pixels<BLEND,PX>(doubtful && (g >= 1) && (g-1 < ngroups) && (x < W),lane,
-                args.taps64,K,fetch,q);
-            }
-            // alpha*colour*2^-17 and alpha/2 (plain: level/2)
-            float v[4];
-            const f32x2 c01={(float) q[0],(float) q[1]};
-            const f32x2 c23={(float) q[2],(float) q[3]};
-            if constexpr (BLEND)
-              {
-                const float alpha=c23[1];
-                const float weight=alpha*(0.5f/65536.0f);
-                const f32x2 v01=c01*f32x2{weight,weight};
-                v[0]=v01[0]; v[1]=v01[1];
-                v[2]=c23[0]*weight;
-                v[3]=alpha*0.5f;
-              }
-            else
-              {
-                const f32x2 v01=c01*0.5f,v23=c23*0.5f;
-                v[0]=v01[0]; v[1]=v01[1]; v[2]=v23[0]; v[3]=v23[1];
-              }
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
-                         "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"
-                         : "+v"(v[0]),"+v"(v[1]),"+v"(v[2]),"+v"(v[3]));
-            uint2 hi,lo;
-            split_f16_pair(f32x2{v[0],v[1]},hi.x,lo.x);
-            split_f16_pair(f32x2{v[2],v[3]},hi.y,lo.y);
-            const int at=ring_entry16+previous*GROUP_STRIDE;
-            *reinterpret_cast<uint2 *>(ring_hi+at)=hi;
-            *reinterpret_cast<uint2 *>(ring_lo+at)=lo;
-                };
+      // BlurExactArgs::give_up: one lane looks at the word, the whole workgroup sees its copy behind
+      // barrier X and leaves behind barrier Y
+      if constexpr (STORE_MODE != 0)
+        issue_rest();
       MH_XTRACE_MARK(3);
       // ======================================================================== interval A
-      if constexpr (COLX)
+      {
+        intx4 acc[5];
+        init_tiles(acc);
         {
-          intx4 acc[5];
-          init_tiles(acc);
+          // ring group of this lane's 16 rows of the first chunk: (first + kq) mod NR
+          unsigned group=(unsigned) (first+kq);
+          group=group >= (unsigned) G::NR ? group-(unsigned) G::NR : group;
+          const unsigned char *from=ring+col_entryx+(int) group*(G::COLS*16);
+          intx4 a[4];
+#pragma unroll
+          for (int i=BLEND ? 0 : 2; i < 4; i++)
+            a[i]=*reinterpret_cast<const intx4 *>(from+i*G::RINGX_PLANE);
+          exact_products<!BLEND,false>(a,t0,acc);
+        }
+        if constexpr (G::NX == 2)
           {
-            // ring group of this lane's 16 rows of the first chunk: (first + kq) mod NR
-            unsigned group=(unsigned) (first+kq);
+            // second chunk
+#ifndef MH_EXACT_K64
+            // rows 64..95: 8 rows per lane, groups first+4 and first+5
+            unsigned group=(unsigned) (first+4+(kq >> 1));
+            group=group >= (unsigned) G::NR ? group-(unsigned) G::NR : group;
+            const unsigned char *from=ring+col_entryx+(int) group*(G::COLS*16)+8*(kq & 1);
+#else
+            // rows 64..127: group (first + 4 + kq) mod NR.  Beyond the NG groups of the band the
+            // digits are zero: whatever the slot holds is multiplied by 0
+            unsigned group=(unsigned) (first+4+kq);
+            group=group >= (unsigned) G::NR ? group-(unsigned) G::NR : group;
             group=group >= (unsigned) G::NR ? group-(unsigned) G::NR : group;
             const unsigned char *from=ring+col_entryx+(int) group*(G::COLS*16);
-            intx4 a[4];
+#endif
+            SecondOperand a[4];
 #pragma unroll
             for (int i=BLEND ? 0 : 2; i < 4; i++)
-              a[i]=*reinterpret_cast<const intx4 *>(from+i*G::RINGX_PLANE);
-            exact_products<!BLEND,false>(a,t0,acc);
+              a[i]=*reinterpret_cast<const SecondOperand *>(from+i*G::RINGX_PLANE);
+            exact_products<!BLEND,true>(a,t1,acc);
           }
-          if constexpr (G::NX == 2)
-            {
-              // second chunk
-#ifndef MH_EXACT_K64
-              // rows 64..95: 8 rows per lane, groups first+4 and first+5
-              unsigned group=(unsigned) (first+4+(kq >> 1));
-              group=group >= (unsigned) G::NR ? group-(unsigned) G::NR : group;
-              const unsigned char *from=ring+col_entryx+(int) group*(G::COLS*16)+8*(kq & 1);
-#else
-              // rows 64..127: group (first + 4 + kq) mod NR.  Beyond the NG groups of the band the
-              // digits are zero: whatever the slot holds is multiplied by 0
-              unsigned group=(unsigned) (first+4+kq);
-              group=group >= (unsigned) G::NR ? group-(unsigned) G::NR : group;
-              group=group >= (unsigned) G::NR ? group-(unsigned) G::NR : group;
-              const unsigned char *from=ring+col_entryx+(int) group*(G::COLS*16);
-#endif
-              SecondOperand a[4];
-#pragma unroll
-              for (int i=BLEND ? 0 : 2; i < 4; i++)
-                a[i]=*reinterpret_cast<const SecondOperand *>(from+i*G::RINGX_PLANE);
-              exact_products<!BLEND,true>(a,t1,acc);
-            }
-          // ---- row epilogue of group g-1 (independent of the chain above)
-          {
-            unsigned q[4];
-            const bool doubtful=exact_levels<BLEND>(sums_row,args,q);
-            exact_sums(acc,args.offset,sums_col);
-            const int x=x0+16*ot+n;
-            {
-              // source pixel (y clamped like the intermediate's rows) of lane `from`, sample v
-              auto fetch=[&](int from,int v,unsigned (&level)[4])
-              {
-                int yy=in0+G::GROUP*(g-1)+4*rq+(from >> 4);
-                yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
-                int xx=x0+16*ot+(from & 15)-args.shift+v;
-                xx=xx < 0 ? 0 : (xx > W-1 ? W-1 : xx);
-                const uint2 pixel=load_pixel16(args.src+pixel_index(yy,W,xx)*PX);
-                level[0]=pixel.x & 0xffffu; level[1]=pixel.x >> 16; level[2]=pixel.y & 0xffffu;
-                level[3]=PX == 4 ? pixel.y >> 16 : 0u;
-              };
-              recomputed+=settle_doubtful_pixels<BLEND,PX>(doubtful && (g >= 1) && (g-1 < ngroups) && (x < W),lane,
-                args.taps64,K,fetch,q);
-            }
-            // the column pass's samples of this pixel, as signed bytes
-            unsigned v[4];
-            if constexpr (BLEND)
-              {
-                v[0]=__umul24(q[0],q[3]);
-                v[1]=__umul24(q[1],q[3]);
-                v[2]=__umul24(q[2],q[3]);
-                v[3]=q[3] << 16;
-              }
-            else
-              {
-                v[0]=q[0] << 16; v[1]=q[1] << 16; v[2]=q[2] << 16; v[3]=q[3] << 16;
-              }
-            // 4x4 transpose between the registers (channels) and the four 16-lane rows (pixel rows)
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
-                         "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"
-                         : "+v"(v[0]),"+v"(v[1]),"+v"(v[2]),"+v"(v[3]));
-            // lane (n, kq): channel kq of rows 4*rq+0..3 -> one dword per byte plane
-            unsigned p[4];
-            byte_planes(v,p);
-            unsigned char *to=ring+ring_entryx+previous*(G::COLS*16);
-#pragma unroll
-            for (int i=0; i < 4; i++)
-              *reinterpret_cast<unsigned *>(to+i*G::RINGX_PLANE)=p[i] ^ 0x80808080u;
-          }
-        }
-      else
+        // ---- row epilogue of group g-1 (independent of the chain above)
         {
-          // ---- f16 column pass of block cb, whole (products, division, rounding) -> out_tile
-          if ((cb >= 0) && (cb < nblocks))
+          unsigned q[4];
+          const bool doubtful=exact_levels<BLEND>(sums_row,args,q);
+          exact_sums(acc,args.offset,sums_col);
+          const int x=x0+16*ot+n;
+          {
+            // source pixel (y clamped like the intermediate's rows) of lane `from`, sample v
+            auto fetch=[&](int from,int v,unsigned (&level)[4])
             {
-              int chunk_at[NC];
-#pragma unroll
-              for (int c=0; c < NC; c++)
-                {
-                  const unsigned wide=(unsigned) (first+2*c+(kq >> 1));
-                  const unsigned group=wide < wide-(unsigned) G::NR ? wide : wide-(unsigned) G::NR;
-                  chunk_at[c]=col_entry16+GROUP_STRIDE*(int) group;
-                }
-              auto column_tiles=[&](auto count)
-              {
-                constexpr int N=decltype(count)::value;
-                floatx4 acc[N > 0 ? N : 1];
-#pragma unroll
-                for (int i=0; i < N; i++)
-                  acc[i]=floatx4{0.0f,0.0f,0.0f,0.0f};
-#pragma unroll
-                for (int c=0; c < NC; c++)
-                  {
-                    half8 a_hi[N > 0 ? N : 1],a_lo[N > 0 ? N : 1];
-#pragma unroll
-                    for (int i=0; i < N; i++)
-                      {
-                        a_hi[i]=*reinterpret_cast<const half8 *>(ring_hi+chunk_at[c]+4*i*F::SC);
-                        a_lo[i]=*reinterpret_cast<const half8 *>(ring_lo+chunk_at[c]+4*i*F::SC);
-                      }
-#pragma unroll
-                    for (int i=0; i < N; i++)
-                      acc[i]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[i],t_hi[c],acc[i],0,0,0);
-#pragma unroll
-                    for (int i=0; i < N; i++)
-                      acc[i]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[i],t_hi[c],acc[i],0,0,0);
-#pragma unroll
-                    for (int i=0; i < N; i++)
-                      acc[i]=__builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[i],t_lo[c],acc[i],0,0,0);
-                  }
-#pragma unroll
-                for (int i=0; i < N; i++)
-                  out_tile[n*G::OUT_STRIDE+4*(ctile0+i)+kq]=sums_to_quantum<SAMPLES>(acc[i][0],acc[i][1],acc[i][2],acc[i][3]);
-              };
-              if (ctiles == CT)
-                column_tiles(std::integral_constant<int,CT>{});
-              else if (ctiles == CT-1)
-                column_tiles(std::integral_constant<int,CT-1>{});
+              int yy=in0+G::GROUP*(g-1)+4*rq+(from >> 4);
+              yy=yy < 0 ? 0 : (yy > H-1 ? H-1 : yy);
+              int xx=x0+16*ot+(from & 15)-args.shift+v;
+              xx=xx < 0 ? 0 : (xx > W-1 ? W-1 : xx);
+              const uint2 pixel=load_pixel16(args.src+pixel_index(yy,W,xx)*PX);
+              level[0]=pixel.x & 0xffffu; level[1]=pixel.x >> 16; level[2]=pixel.y & 0xffffu;
+              level[3]=PX == 4 ? pixel.y >> 16 : 0u;
+            };
+            recomputed+=settle_doubtful_pixels<BLEND,PX>(doubtful && (g >= 1) && (g-1 < ngroups) && (x < W),lane,
+              args.taps64,K,fetch,q);
+          }
+          // the column pass's samples of this pixel, as signed bytes
+          unsigned v[4];
+          if constexpr (BLEND)
+            {
+              v[0]=__umul24(q[0],q[3]);
+              v[1]=__umul24(q[1],q[3]);
+              v[2]=__umul24(q[2],q[3]);
+              v[3]=q[3] << 16;
             }
-#ifndef MH_HYBRID_EPILOGUE_IN_B
-          row_epilogue16();
-#endif
+          else
+            {
+              v[0]=q[0] << 16; v[1]=q[1] << 16; v[2]=q[2] << 16; v[3]=q[3] << 16;
+            }
+          // 4x4 transpose between the registers (channels) and the four 16-lane rows (pixel rows)
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\t"
+                       "s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"
+                       : "+v"(v[0]),"+v"(v[1]),"+v"(v[2]),"+v"(v[3]));
+          // lane (n, kq): channel kq of rows 4*rq+0..3 -> one dword per byte plane
+          unsigned p[4];
+          byte_planes(v,p);
+          unsigned char *to=ring+ring_entryx+previous*(G::COLS*16);
+#pragma unroll
+          for (int i=0; i < 4; i++)
+            *reinterpret_cast<unsigned *>(to+i*G::RINGX_PLANE)=p[i] ^ 0x80808080u;
         }
+      }
 #ifdef MH_EXACT_TRACE
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
       MH_XTRACE_MARK(4);
-      if ((args.give_up != nullptr) && (tid == 0))
+      if ((args.give_up != nullptr) && (tid == WORD_LANE))
         stop_word=seen_word;
       __syncthreads();                           // X: group g staged, ring group g-1 complete
       MH_XTRACE_MARK(5);
       // ======================================================================== interval B
       {
-#ifdef MH_HYBRID_EPILOGUE_IN_B
-        if constexpr (!COLX)
-          row_epilogue16();
-#endif
         // ---- row chain of group g
         intx4 acc[5];
         init_tiles(acc);
@@ -686,60 +583,53 @@ void blur_fused_exact_kernel(BlurExactArgs args)
               a[i]=*reinterpret_cast<const SecondOperand *>(stage+i*G::STAGE_PLANE+row_entry+64-(16-kSecondBytes)*kq);
             exact_products<!BLEND,true>(a,t1,acc);
           }
-        if constexpr (COLX)
+        {
+          // ---- column epilogue of block cb (independent of the chain above)
+          // lane (n, kq): the four channels (registers) of pixel (column 4*wave+kq, row n)
+          unsigned q[4];
+          const bool doubtful=exact_levels<BLEND>(sums_col,args,q);
+          exact_sums(acc,args.offset,sums_row);
+          const int x=x0+4*wave+kq,y=out_begin+G::GROUP*cb+n;
           {
-            // ---- column epilogue of block cb (independent of the chain above)
-            // lane (n, kq): the four channels (registers) of pixel (column 4*wave+kq, row n)
-            unsigned q[4];
-            const bool doubtful=exact_levels<BLEND>(sums_col,args,q);
-            exact_sums(acc,args.offset,sums_row);
-            const int x=x0+4*wave+kq,y=out_begin+G::GROUP*cb+n;
+            // the exact intermediate out of the ring: pixel column 4*wave + (from>>4), output row
+            // from&15 of the block -> ring row (from&15)+v.  Samples alpha*p (colour; p is the
+            // exact quotient) and alpha*2^16 / p*2^16.
+            auto fetch=[&](int from,int v,unsigned (&level)[4])
             {
-              // the exact intermediate out of the ring: pixel column 4*wave + (from>>4), output row
-              // from&15 of the block -> ring row (from&15)+v.  Samples alpha*p (colour; p is the
-              // exact quotient) and alpha*2^16 / p*2^16.
-              auto fetch=[&](int from,int v,unsigned (&level)[4])
-              {
-                const int row=(from & 15)+v;
-                int group=first+(row >> 4);
-                group=group >= G::NR ? group-G::NR : group;
-                group=group >= G::NR ? group-G::NR : group;
-                const unsigned char *at=ring+(group*G::COLS+4*wave+(from >> 4))*16+(row & 15);
-                unsigned sample[4];
+              const int row=(from & 15)+v;
+              int group=first+(row >> 4);
+              group=group >= G::NR ? group-G::NR : group;
+              group=group >= G::NR ? group-G::NR : group;
+              const unsigned char *at=ring+(group*G::COLS+4*wave+(from >> 4))*16+(row & 15);
+              unsigned sample[4];
 #pragma unroll
-                for (int c=0; c < 4; c++)
-                  {
-                    const unsigned char *p=at+c*G::CHU;
-                    sample[c]=(((BLEND && (c != 3)) ? ((unsigned) p[0] | ((unsigned) p[G::RINGX_PLANE] << 8)) : 0x8080u) |
-                      ((unsigned) p[2*G::RINGX_PLANE] << 16) | ((unsigned) p[3*G::RINGX_PLANE] << 24)) ^ 0x80808080u;
-                  }
-                if constexpr (BLEND)
-                  {
-                    const unsigned a=sample[3] >> 16;
-                    const double inverse=a != 0u ? 1.0/(double) a : 0.0;
+              for (int c=0; c < 4; c++)
+                {
+                  const unsigned char *p=at+c*G::CHU;
+                  sample[c]=(((BLEND && (c != 3)) ? ((unsigned) p[0] | ((unsigned) p[G::RINGX_PLANE] << 8)) : 0x8080u) |
+                    ((unsigned) p[2*G::RINGX_PLANE] << 16) | ((unsigned) p[3*G::RINGX_PLANE] << 24)) ^ 0x80808080u;
+                }
+              if constexpr (BLEND)
+                {
+                  const unsigned a=sample[3] >> 16;
+                  const double inverse=a != 0u ? 1.0/(double) a : 0.0;
 #pragma unroll
-                    for (int c=0; c < 3; c++)
-                      level[c]=(unsigned) ((double) sample[c]*inverse+0.5);   // alpha*p / alpha
-                    level[3]=a;
-                  }
-                else
-                  {
+                  for (int c=0; c < 3; c++)
+                    level[c]=(unsigned) ((double) sample[c]*inverse+0.5);   // alpha*p / alpha
+                  level[3]=a;
+                }
+              else
+                {
 #pragma unroll
-                    for (int c=0; c < 4; c++)
-                      level[c]=sample[c] >> 16;
-                  }
-              };
-              recomputed+=settle_doubtful_pixels<BLEND,4>(doubtful && (cb >= 0) && (x < W) && (y < H),lane,
-                args.taps64,K,fetch,q);
-            }
-            out_tile[n*G::OUT_STRIDE+4*wave+kq]=make_uint2(q[0] | (q[1] << 16),q[2] | (q[3] << 16));
+                  for (int c=0; c < 4; c++)
+                    level[c]=sample[c] >> 16;
+                }
+            };
+            recomputed+=settle_doubtful_pixels<BLEND,4>(doubtful && (cb >= 0) && (x < W) && (y < H),lane,
+              args.taps64,K,fetch,q);
           }
-        else
-          {
-            // the store of the column pass's row in the shadow of the matrix chain
-            store_row(cb);
-            exact_sums(acc,args.offset,sums_row);
-          }
+          out_tile[n*G::OUT_STRIDE+4*wave+kq]=make_uint2(q[0] | (q[1] << 16),q[2] | (q[3] << 16));
+        }
       }
 #ifdef MH_EXACT_TRACE
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -758,8 +648,7 @@ void blur_fused_exact_kernel(BlurExactArgs args)
         return;                                  // the passes behind this kernel write the frame
       ring_group=ring_group+1 == G::NR ? 0 : ring_group+1;
     }
-  if constexpr (COLX)
-    store_row(nblocks-1);
+  store_row(nblocks-1);
   if ((args.recomputed != nullptr) && (recomputed != 0u) && (lane == 0))     // a wave-uniform count
     atomicAdd(args.recomputed,(unsigned long long) recomputed);
 }
@@ -773,10 +662,10 @@ unsigned long long *exact_recomputed_counter(int device)
   return (g_count_recomputed && (device >= 0) && (device < 64)) ? g_recomputed[device] : nullptr;
 }
 
-template<int NC,int MODE,bool UNSHARP,bool COLX>
+template<int NC,int MODE,bool UNSHARP>
 static MhStatus launch_exact_typed(const View &src,BlurExactArgs &args)
 {
-  typedef ExactGeometry<NC,COLX> G;
+  typedef ExactGeometry<NC> G;
   args.strips=(args.columns+G::COLS-1)/G::COLS;
   args.blocks=(args.rows+G::GROUP-1)/G::GROUP;
   // Cut the strips so that every CU gets a work item.  A segment recomputes NG-1 ring groups
@@ -798,7 +687,7 @@ static MhStatus launch_exact_typed(const View &src,BlurExactArgs &args)
   const int slot=src.device >= 0 && src.device < 64 ? src.device : 0;
   if (!attribute_set[slot])
     {
-      MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&blur_fused_exact_kernel<NC,MODE,UNSHARP,COLX>),
+      MH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&blur_fused_exact_kernel<NC,MODE,UNSHARP>),
         hipFuncAttributeMaxDynamicSharedMemorySize,(int) lds));
       attribute_set[slot]=true;
     }
@@ -812,9 +701,8 @@ static MhStatus launch_exact_typed(const View &src,BlurExactArgs &args)
     }
 #endif
   {
-  ProfileScope prof(UNSHARP ? (COLX ? "unsharp_fused_exact" : "unsharp_fused_exact_row") :
-    (COLX ? "blur_fused_exact" : "blur_fused_exact_row"),src.stream);
-  hipLaunchKernelGGL((blur_fused_exact_kernel<NC,MODE,UNSHARP,COLX>),dim3((unsigned) (8*args.items_per_xcd)),
+  ProfileScope prof(UNSHARP ? "unsharp_fused_exact" : "blur_fused_exact",src.stream);
+  hipLaunchKernelGGL((blur_fused_exact_kernel<NC,MODE,UNSHARP>),dim3((unsigned) (8*args.items_per_xcd)),
     dim3(1024),lds,src.stream,args);
   MH_HIP(hipGetLastError());
   }
@@ -835,24 +723,24 @@ static MhStatus launch_exact_typed(const View &src,BlurExactArgs &args)
   return MH_OK;
 }
 
-template<int NC,bool COLX>
+template<int NC>
 static MhStatus launch_exact_modes(const View &src,BlurExactArgs &args,bool blend,bool unsharp)
 {
   if (src.channels == 3)
-    return unsharp ? launch_exact_typed<NC,MFMA_PLAIN3,true,COLX>(src,args) :
-      launch_exact_typed<NC,MFMA_PLAIN3,false,COLX>(src,args);
+    return unsharp ? launch_exact_typed<NC,MFMA_PLAIN3,true>(src,args) :
+      launch_exact_typed<NC,MFMA_PLAIN3,false>(src,args);
   if (unsharp)
-    return blend ? launch_exact_typed<NC,MFMA_BLEND4,true,COLX>(src,args) :
-      launch_exact_typed<NC,MFMA_PLAIN4,true,COLX>(src,args);
-  return blend ? launch_exact_typed<NC,MFMA_BLEND4,false,COLX>(src,args) :
-    launch_exact_typed<NC,MFMA_PLAIN4,false,COLX>(src,args);
+    return blend ? launch_exact_typed<NC,MFMA_BLEND4,true>(src,args) :
+      launch_exact_typed<NC,MFMA_PLAIN4,true>(src,args);
+  return blend ? launch_exact_typed<NC,MFMA_BLEND4,false>(src,args) :
+    launch_exact_typed<NC,MFMA_PLAIN4,false>(src,args);
 }
 
 // taps: host doubles in the reversed walk of morphology.c:2746 (taps[v] multiplies the input at
-// o-shift+v).  exact_column: both passes exact (bit-identical result) or the f16 column pass.
+// o-shift+v).
 // *handled = false: the shape or the taps are outside the kernel's reach, nothing was launched.
 MhStatus launch_blur_fused_exact(const View &src,const View &dst,const double *taps,int ntaps,int shift,
-  bool blend,bool exact_column,bool *handled,bool unsharp,double gain,double threshold,
+  bool blend,bool *handled,bool unsharp,double gain,double threshold,
   unsigned long long *recomputed_device,unsigned *give_up)
 {
   *handled=false;
@@ -885,9 +773,7 @@ MhStatus launch_blur_fused_exact(const View &src,const View &dst,const double *t
   args.colour_window=plan.colour_window;
   args.alpha_half_window=0.5-(blend ? plan.alpha_window_blend : plan.alpha_window_plain);
   args.alpha_floor=plan.alpha_floor;
-  args.tap_scale=256.0f;                         // (the f16 column pass, COLX = false, keeps its fixed factor)
-  args.two_over_scale=1.0f/128.0f;
-  args.quantum_unit=1.0f/(128.0f*65535.0f);
+  args.tap_scale=args.two_over_scale=args.quantum_unit=0.0f;       // (the hybrid kernel's)
   args.gain=(float) gain;
   {
     const double level=std::ceil(65535.0*threshold);
@@ -900,24 +786,12 @@ MhStatus launch_blur_fused_exact(const View &src,const View &dst,const double *t
     args.recomputed=g_recomputed[src.device];
   *handled=true;
   const int nc=(ntaps+15+31)/32;                 // 16 outputs + K-1 halo, in 32-sample chunks
-  if (exact_column)
-    {
-      if (nc == 1)
-        return launch_exact_modes<1,true>(src,args,blend,unsharp);
-      if (nc == 2)
-        return launch_exact_modes<2,true>(src,args,blend,unsharp);
-      if (nc == 3)
-        return launch_exact_modes<3,true>(src,args,blend,unsharp);
-    }
-  else
-    {
-      if (nc == 1)
-        return launch_exact_modes<1,false>(src,args,blend,unsharp);
-      if (nc == 2)
-        return launch_exact_modes<2,false>(src,args,blend,unsharp);
-      if (nc == 3)
-        return launch_exact_modes<3,false>(src,args,blend,unsharp);
-    }
+  if (nc == 1)
+    return launch_exact_modes<1>(src,args,blend,unsharp);
+  if (nc == 2)
+    return launch_exact_modes<2>(src,args,blend,unsharp);
+  if (nc == 3)
+    return launch_exact_modes<3>(src,args,blend,unsharp);
   *handled=false;
   return MH_OK;
 }

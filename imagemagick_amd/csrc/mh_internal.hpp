@@ -298,14 +298,13 @@ MhStatus launch_conv2d_mfma(const View &src,const View &dst,const MhKernelInfo *
   bool *handled);
 // BlurImage's two passes in one launch: the row pass's Quantum-rounded result stays in an LDS ring and
 // never reaches HBM.  Exact-integer sums (convolve_fused_exact.hip): taps = HOST doubles in the reversed
-// walk of morphology.c:2746 (taps[v] multiplies the input at o-shift+v), all positive.  exact_column = true: both passes exact, the result is
-// bit-identical to the reference (MH_PRECISION_EXACT); false: exact row pass + f16 column pass,
-// within +-1 level by construction (MH_PRECISION_FAST).  recomputed_device (optional): a device
-// counter that receives the number of samples recomputed in the reference's operation order.
+// walk of morphology.c:2746 (taps[v] multiplies the input at o-shift+v), all positive.  Both passes exact: the result
+// is bit-identical to the reference (MH_PRECISION_EXACT; UnsharpMaskImage in both modes).  recomputed_device
+// (optional): a device counter that receives the number of samples recomputed in the reference's operation order.
 constexpr int kExactDigits=5;            // balanced signed 8-bit digits of a fixed-point tap
 constexpr int kExactDigitPitch=96;       // digits of one weight, padded (K <= 81)
 MhStatus launch_blur_fused_exact(const View &src,const View &dst,const double *taps,int ntaps,int shift,
-  bool blend,bool exact_column,bool *handled,bool unsharp=false,double gain=0.0,double threshold=0.0,
+  bool blend,bool *handled,bool unsharp=false,double gain=0.0,double threshold=0.0,
   unsigned long long *recomputed_device=nullptr,unsigned *give_up=nullptr);
 // FAST BlurImage in one launch: f16 colour sums in both passes, the row pass's alpha as exact integer
 // sums (convolve_fused_hybrid.hip); within +-1 level by construction.  taps as above.

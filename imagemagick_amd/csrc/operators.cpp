@@ -563,7 +563,7 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
       else
         MH_HIP(hipMemsetAsync(give_up.ptr,0,sizeof(unsigned),src.stream));
     }
-  MH_TRY(launch_blur_fused_exact(src,dst,reversed.data(),kept,shift,roles.blend,true,handled,
+  MH_TRY(launch_blur_fused_exact(src,dst,reversed.data(),kept,shift,roles.blend,handled,
     unsharp,gain,threshold,nullptr,guarded ? give_up.as<unsigned>() : nullptr));
   if (*handled && guarded)
     {
