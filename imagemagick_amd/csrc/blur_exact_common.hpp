@@ -51,6 +51,7 @@ struct BlurExactArgs
   // the word, every workgroup leaves at its next group, and the fp64 passes queued behind the
   // kernel (Conv1DParams::only_if) compute the frame: bit-identical too, 2.2 ms.
   unsigned *give_up;
+  unsigned give_up_token;    // "raised" = the word holds this value (the caller's own: nothing clears the word first)
   unsigned long long *trace;        // diagnostic build (-DMH_EXACT_TRACE) only
 };
 

@@ -347,8 +347,17 @@ struct Conv1DArgs
   // unsharp_src = the unblurred frame, or NULL
   const void *unsharp_src;
   double unsharp_gain,unsharp_threshold;
-  const unsigned *only_if;   // nullptr, or: every workgroup leaves at once when the word is zero
+  const unsigned *only_if;   // nullptr, or: every workgroup leaves at once unless the word is set:
+  unsigned only_if_token;    //   0: set = not zero;  otherwise: set = equal to the token (no clearing launch needed)
 };
+
+static __device__ __forceinline__ bool pass_not_wanted(const Conv1DArgs &args)
+{
+  if (args.only_if == nullptr)
+    return false;
+  const unsigned word=*args.only_if;
+  return args.only_if_token == 0u ? word == 0u : word != args.only_if_token;
+}
 
 // blurred sample -> unsharp-masked sample, as unsharp_kernel (pointwise.hip) does in its own pass
 template<typename Q,int C>
@@ -388,7 +397,7 @@ template<typename Q,int C,bool BLEND,class A,int R,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_column_kernel(Conv1DArgs args)
 {
-  if ((args.only_if != nullptr) && (*args.only_if == 0u))
+  if (pass_not_wanted(args))
     return;
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
@@ -513,7 +522,7 @@ template<typename Q,int C,bool BLEND,class A,int R,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_row_kernel(Conv1DArgs args)
 {
-  if ((args.only_if != nullptr) && (*args.only_if == 0u))
+  if (pass_not_wanted(args))
     return;
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
@@ -676,7 +685,7 @@ template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_column_blocked(Conv1DArgs args)
 {
-  if ((args.only_if != nullptr) && (*args.only_if == 0u))
+  if (pass_not_wanted(args))
     return;
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
@@ -804,7 +813,7 @@ template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_row_blocked(Conv1DArgs args)
 {
-  if ((args.only_if != nullptr) && (*args.only_if == 0u))
+  if (pass_not_wanted(args))
     return;
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
@@ -963,6 +972,7 @@ static MhStatus launch_blocked(const View &src,const View &dst,bool vertical,
   args.nblocks=nblocks;
   args.wave_bytes=0;
   args.only_if=p.only_if;
+  args.only_if_token=p.only_if_token;
   const int W=args.columns,H=args.rows;
   if (vertical)
     {
@@ -1146,7 +1156,7 @@ template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_column_tri(Conv1DArgs args)
 {
-  if ((args.only_if != nullptr) && (*args.only_if == 0u))
+  if (pass_not_wanted(args))
     return;
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
@@ -1256,7 +1266,7 @@ template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_column_lds(Conv1DArgs args)
 {
-  if ((args.only_if != nullptr) && (*args.only_if == 0u))
+  if (pass_not_wanted(args))
     return;
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
@@ -1363,7 +1373,7 @@ template<typename Q,int C,bool BLEND,class A,int R,int U,int WAVES>
 __global__ __launch_bounds__(64*WAVES)
 void conv_row_tri(Conv1DArgs args)
 {
-  if ((args.only_if != nullptr) && (*args.only_if == 0u))
+  if (pass_not_wanted(args))
     return;
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
@@ -1551,6 +1561,7 @@ static MhStatus launch_tri_waves(const View &src,const View &dst,bool vertical,
   args.nblocks=0;
   args.wave_bytes=0;
   args.only_if=p.only_if;
+  args.only_if_token=p.only_if_token;
   if (vertical)
     {
       args.unsharp_src=p.unsharp_source;
@@ -2175,6 +2186,7 @@ static MhStatus launch_one(const View &src,const View &dst,bool vertical,
   args.nblocks=0;
   args.wave_bytes=0;
   args.only_if=p.only_if;
+  args.only_if_token=p.only_if_token;
 
   const int W=args.columns,H=args.rows;
   if (vertical)

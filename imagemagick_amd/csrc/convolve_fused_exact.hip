@@ -638,9 +638,9 @@ void blur_fused_exact_kernel(BlurExactArgs args)
       bool stop=false;
       if (args.give_up != nullptr)
         {
-          stop=stop_word != 0u;                  // (written before barrier X, rewritten after barrier Y)
+          stop=stop_word == args.give_up_token;  // (written before barrier X, rewritten after barrier Y)
           if ((recomputed > 32u+(unsigned) g) && (lane == 0))
-            __hip_atomic_store(args.give_up,1u,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(args.give_up,args.give_up_token,__ATOMIC_RELAXED,__HIP_MEMORY_SCOPE_AGENT);
         }
       __syncthreads();                           // Y: out_tile complete, staging and ring reads done
       MH_XTRACE_MARK(7);
@@ -741,7 +741,7 @@ static MhStatus launch_exact_modes(const View &src,BlurExactArgs &args,bool blen
 // *handled = false: the shape or the taps are outside the kernel's reach, nothing was launched.
 MhStatus launch_blur_fused_exact(const View &src,const View &dst,const double *taps,int ntaps,int shift,
   bool blend,bool *handled,bool unsharp,double gain,double threshold,
-  unsigned long long *recomputed_device,unsigned *give_up)
+  unsigned long long *recomputed_device,unsigned *give_up,unsigned give_up_token)
 {
   *handled=false;
   if ((src.quantum != MH_QUANTUM_U16) || (dst.quantum != MH_QUANTUM_U16) ||
@@ -781,6 +781,7 @@ MhStatus launch_blur_fused_exact(const View &src,const View &dst,const double *t
   }
   args.recomputed=recomputed_device;
   args.give_up=give_up;
+  args.give_up_token=give_up_token;
   args.trace=nullptr;
   if ((args.recomputed == nullptr) && g_count_recomputed && (src.device >= 0) && (src.device < 64))
     args.recomputed=g_recomputed[src.device];

@@ -219,9 +219,12 @@ struct Conv1DParams
   // ceil-free threshold (QuantumRange*threshold), applied as the column pass stores its results
   const void *unsharp_source=nullptr;
   double unsharp_gain=0.0,unsharp_threshold=0.0;
-  // a device word: the pass's kernels leave at once when it is zero (the fp64 passes queued behind
-  // the exact-integer BlurImage kernel, which raises the word when it gives a frame up)
+  // a device word: the pass's kernels leave at once unless it is set (the fp64 passes queued behind
+  // the exact-integer BlurImage kernel, which sets the word when it gives a frame up).  only_if_token 0: set = not
+  // zero; otherwise set = equal to the token — a value of the call's own, so that nothing has to clear the word
+  // in front of the kernel (one dispatch less a call)
   const unsigned *only_if=nullptr;
+  unsigned only_if_token=0u;
 };
 // The column pass of a blur with UnsharpMaskImage's epilogue applied on the way out (the fp64
 // triangular kernels: float Quantum, and Q16 in EXACT mode).  *handled = false: not this case,
@@ -305,7 +308,7 @@ constexpr int kExactDigits=5;            // balanced signed 8-bit digits of a fi
 constexpr int kExactDigitPitch=96;       // digits of one weight, padded (K <= 81)
 MhStatus launch_blur_fused_exact(const View &src,const View &dst,const double *taps,int ntaps,int shift,
   bool blend,bool *handled,bool unsharp=false,double gain=0.0,double threshold=0.0,
-  unsigned long long *recomputed_device=nullptr,unsigned *give_up=nullptr);
+  unsigned long long *recomputed_device=nullptr,unsigned *give_up=nullptr,unsigned give_up_token=1u);
 // FAST BlurImage in one launch: f16 colour sums in both passes, the row pass's alpha as exact integer
 // sums (convolve_fused_hybrid.hip); within +-1 level by construction.  taps as above.
 MhStatus launch_blur_fused_hybrid(const View &src,const View &dst,const double *taps,int ntaps,int shift,

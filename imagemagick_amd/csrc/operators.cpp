@@ -9,6 +9,7 @@
 #include <cstdio>
 #include "resize_filter.hpp"
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -560,11 +561,16 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
       if ((give_up.alloc(src.device,sizeof(unsigned),src.stream) != MH_OK) ||
           (rows_memory.alloc(src.device,src.bytes(),src.stream) != MH_OK))
         guarded=false;
-      else
-        MH_HIP(hipMemsetAsync(give_up.ptr,0,sizeof(unsigned),src.stream));
     }
+  // "given up" = the word holds a value of this call's own, so that nothing has to clear it in front of the kernel
+  // (a dispatch less a call).  Whatever the word held before: should it be this very value (one in 2^32), kernel
+  // and passes agree that the frame was given up, and the passes compute it.
+  static std::atomic<unsigned> tokens{1u};
+  unsigned token=tokens.fetch_add(1u,std::memory_order_relaxed);
+  if (token == 0u)
+    token=tokens.fetch_add(1u,std::memory_order_relaxed);
   MH_TRY(launch_blur_fused_exact(src,dst,reversed.data(),kept,shift,roles.blend,handled,
-    unsharp,gain,threshold,nullptr,guarded ? give_up.as<unsigned>() : nullptr));
+    unsharp,gain,threshold,nullptr,guarded ? give_up.as<unsigned>() : nullptr,token));
   if (*handled && guarded)
     {
       View rows=src;
@@ -574,6 +580,7 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
       first.ntaps=K;
       first.origin=(int) row->x;
       first.only_if=give_up.as<unsigned>();
+      first.only_if_token=second.only_if_token=token;
       second.taps=column->values;
       second.ntaps=K;
       second.origin=(int) column->y;
