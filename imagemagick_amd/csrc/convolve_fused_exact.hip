@@ -237,9 +237,12 @@ void blur_fused_exact_kernel(BlurExactArgs args)
 
   // ---- staging: thread -> (row, 4 consecutive columns) of the 16 x XS source window
   const bool stager=tid < G::FETCH_GROUPS;     // wave-uniform (FETCH_GROUPS is a multiple of 64)
-  const int srow=tid/G::GROUPS_PER_ROW,sxg=tid-srow*G::GROUPS_PER_ROW;
+  // (the walk recomputes a stager's row and column group from its thread index in every iteration — a handful of
+  // vector instructions — instead of keeping them and what is derived from them in registers: the kernel sits at
+  // the 128 registers of a wave, and what the compiler spills it reloads from scratch INSIDE the walk, in front of
+  // the fetch, behind an s_waitcnt vmcnt(0): the alpha-weighted 79-tap kernel did, until round 6)
   uint2 raw[4];
-  auto fetch=[&](int g)
+  auto fetch=[&](int g,int srow,int sxg)
   {
     if (stager)
       {
@@ -285,7 +288,7 @@ void blur_fused_exact_kernel(BlurExactArgs args)
   };
   // raw Quantum pixels -> signed byte planes.  BLEND: colour sample alpha*p (four bytes), alpha
   // sample alpha*2^16 (planes 2, 3); plain: p*2^16 for every channel.
-  auto stage_group=[&]()
+  auto stage_group=[&](int srow,int sxg)
   {
     if (stager)
       {
@@ -424,7 +427,7 @@ void blur_fused_exact_kernel(BlurExactArgs args)
           }
       }
   };
-  fetch(0);
+  fetch(0,tid/G::GROUPS_PER_ROW,tid % G::GROUPS_PER_ROW);
   __shared__ unsigned stop_word;
   if (tid == 0)
     stop_word=0u;
@@ -432,6 +435,9 @@ void blur_fused_exact_kernel(BlurExactArgs args)
   constexpr int WORD_LANE=SPREAD_STORES ? 1023 : 0;
   for (int g=0; g <= ngroups+1; g++)
     {
+      int opaque_tid=tid;
+      asm volatile("" : "+v"(opaque_tid));       // not loop-invariant to the optimiser (see `stager`)
+      const int srow=opaque_tid/G::GROUPS_PER_ROW,sxg=opaque_tid-srow*G::GROUPS_PER_ROW;
       const int cb=g-G::NG-1;                    // the column pass's block of this iteration
       const int first=ring_group;                // ring slot of group cb: (g-NG-1) mod NR = g mod NR
       const int previous=ring_group == 0 ? G::NR-1 : ring_group-1;   // ring slot of group g-1
@@ -458,13 +464,13 @@ void blur_fused_exact_kernel(BlurExactArgs args)
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           MH_XTRACE_MARK(1);
 #endif
-          stage_group();
+          stage_group(srow,sxg);
 #ifdef MH_EXACT_TRACE
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           MH_XTRACE_MARK(2);
 #endif
           if (g+1 < ngroups)
-            fetch(g+1);
+            fetch(g+1,srow,sxg);
         }
       // BlurExactArgs::give_up: one lane looks at the word, the whole workgroup sees its copy behind
       // barrier X and leaves behind barrier Y
