@@ -350,18 +350,19 @@ void blur_fused_exact_kernel(BlurExactArgs args)
   int ring_group=0;                            // g mod NR (wave-uniform)
   // Who stores the rows of a finished block (interval A of the next iteration), and when.  The staging waves
   // begin interval A with s_waitcnt vmcnt(0) for the pixels they fetched an iteration ago, and that counter also
-  // counts stores and younger loads: a store (or UnsharpMask's source pixel, or the give_up word) issued in front of
-  // it is waited for in full.  STORE_MODE 0: every wave stores row `wave` first thing (rounds 3-5); 1: the same,
-  // behind the staging; 2: the waves that do not stage store all sixteen rows.  Measured on one box, 8192^2,
-  // 79 taps, modes 0 / 1 / 2 (profiles/r6_notes/exact_store_modes.txt): RGBA 0.902 / 0.877 / 0.953 ms, UnsharpMask
-  // 1.17 / 1.07 / 1.29, four plain channels 0.709 / 0.751 / 0.701, RGB 0.78 / 0.771 / 0.768 — alpha-weighted
-  // frames, whose staging is the long one (twelve products and three byte-plane splits a thread), gain from not
-  // waiting for the store; the waves that do not stage are the youngest of their SIMDs and the last through both
-  // intervals, so handing them three rows each costs more than it frees unless staging is short (plain frames).
+  // counts stores and younger loads: what is issued in front of it is waited for in full.  STORE_MODE 0: every wave
+  // stores row `wave` first thing (rounds 3-5); 1: the same, behind the staging; 2: the waves that do not stage
+  // store all sixteen rows.  One box, 8192^2, 79 taps, 40 launches each, modes 0 / 1 / 2
+  // (profiles/r6_notes/exact_store_modes.txt): RGBA 0.899 / 0.881 / 0.895 ms, UnsharpMask 0.994 / 1.008 / 1.205,
+  // four plain channels 0.710 / 0.696 / 0.689, RGB 0.783 / 0.773 / 0.778 — two or three per cent either way: the
+  // waves that do not stage are the youngest of their SIMDs and the last through both intervals, so handing them three
+  // rows each only pays where staging is short (plain frames), and UnsharpMask's second read of the source pixel
+  // prefers to be issued early.
 #ifndef MH_EXACT_STORE_MODE
 #define MH_EXACT_STORE_MODE (-1)
 #endif
-  constexpr int STORE_MODE=MH_EXACT_STORE_MODE >= 0 ? MH_EXACT_STORE_MODE : (BLEND ? 1 : 2);
+  constexpr int STORE_MODE=MH_EXACT_STORE_MODE >= 0 ? MH_EXACT_STORE_MODE :
+    (UNSHARP ? 0 : (BLEND ? 1 : (MODE == MFMA_PLAIN3 ? 1 : 2)));
   constexpr int STAGE_WAVES=G::FETCH_GROUPS/64;
   constexpr bool SPREAD_STORES=(STORE_MODE == 2) && (STAGE_WAVES < 16);
   constexpr int STORE_WAVES=SPREAD_STORES ? 16-STAGE_WAVES : 16;
@@ -435,9 +436,6 @@ void blur_fused_exact_kernel(BlurExactArgs args)
   constexpr int WORD_LANE=SPREAD_STORES ? 1023 : 0;
   for (int g=0; g <= ngroups+1; g++)
     {
-      int opaque_tid=tid;
-      asm volatile("" : "+v"(opaque_tid));       // not loop-invariant to the optimiser (see `stager`)
-      const int srow=opaque_tid/G::GROUPS_PER_ROW,sxg=opaque_tid-srow*G::GROUPS_PER_ROW;
       const int cb=g-G::NG-1;                    // the column pass's block of this iteration
       const int first=ring_group;                // ring slot of group cb: (g-NG-1) mod NR = g mod NR
       const int previous=ring_group == 0 ? G::NR-1 : ring_group-1;   // ring slot of group g-1
@@ -454,12 +452,13 @@ void blur_fused_exact_kernel(BlurExactArgs args)
       if constexpr (STORE_MODE == 0)
         issue_rest();
       MH_XTRACE_MARK(0);
-      // Staging FIRST: it waits for the pixels fetched an iteration ago with s_waitcnt vmcnt(0) — the counter
-      // also counts stores and every younger load, so whatever is issued in front of it (rounds 3-5: the store of
-      // block cb-1's row, the give_up word, UnsharpMask's source pixel) is waited for in full, on the staging
-      // waves, the longest of interval A.
-      if (g < ngroups)
+      // (STORE_MODE != 0: the staging, which waits for the pixels fetched an iteration ago, ahead of the store, the
+      // give_up word and UnsharpMask's source pixel)
+      if ((g < ngroups) && stager)
         {
+          int opaque_tid=tid;
+          asm volatile("" : "+v"(opaque_tid));   // not loop-invariant to the optimiser (see `stager`)
+          const int srow=opaque_tid/G::GROUPS_PER_ROW,sxg=opaque_tid-srow*G::GROUPS_PER_ROW;
 #ifdef MH_EXACT_TRACE
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           MH_XTRACE_MARK(1);

@@ -8,6 +8,7 @@ import imagemagick_amd as im
 from bench import kernel_profile, timed
 im.load()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+REPS = int(os.environ.get("TBQ_REPS", "5"))          # launches behind every kernel average (min in brackets)
 sigmas = tuple(float(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (10.0, 5.0, 2.0)
 g = torch.Generator(device="cuda").manual_seed(3)
 for channels, alpha, label in ((4, True, "rgba"), (4, False, "plain4"), (3, False, "rgb")):
@@ -21,9 +22,9 @@ for channels, alpha, label in ((4, True, "rgba"), (4, False, "plain4"), (3, Fals
             for _ in range(10):
                 f()
             sec = timed(torch, f, 30)
-            prof = kernel_profile(im, f, 5)
+            prof = kernel_profile(im, f, REPS)
             print("%-6s sigma %-4g %-5s %.4f ms  kernels %s" % (label, sigma, mode, sec * 1e3,
-                  {k: round(v["avg_ms"], 4) for k, v in prof.items()}), flush=True)
+                  {k: "%.4f [%.4f]" % (v["avg_ms"], v["min_ms"]) for k, v in prof.items()}), flush=True)
     if alpha:
         im.set_precision(im.PRECISION_FAST)
         for sigma in sigmas:
@@ -31,6 +32,6 @@ for channels, alpha, label in ((4, True, "rgba"), (4, False, "plain4"), (3, Fals
             for _ in range(5):
                 f()
             sec = timed(torch, f, 20)
-            prof = kernel_profile(im, f, 5)
+            prof = kernel_profile(im, f, REPS)
             print("%-6s sigma %-4g %-5s %.4f ms  kernels %s" % (label, sigma, "unsharp", sec * 1e3,
-                  {k: round(v["avg_ms"], 4) for k, v in prof.items()}), flush=True)
+                  {k: "%.4f [%.4f]" % (v["avg_ms"], v["min_ms"]) for k, v in prof.items()}), flush=True)
