@@ -9,7 +9,7 @@
 #   sq_<fast|exact>_<a|b>/  SQ issue / wait / LDS counters of the two fused kernels
 #   bench.json            the bench line of the same box (with cpu_baseline)
 set -u
-TAG=${1:-r6a}
+TAG=${1:-r6e}
 QUICK=${2:-}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/profiles_$TAG
