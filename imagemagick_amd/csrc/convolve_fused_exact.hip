@@ -412,6 +412,10 @@ void blur_fused_exact_kernel(BlurExactArgs args)
   {
     if ((block >= 0) && (block < nblocks) && (store_wave >= 0))
       {
+        // (addresses derived from an opaque copy of the lane: loop-invariant ones are hoisted into registers the
+        // kernel does not have, spilled, and reloaded in the walk — see `stager`)
+        int lane=tid & 63;
+        asm volatile("" : "+v"(lane));
 #pragma unroll
         for (int r=0; r < STORE_ROWS; r++)
           {

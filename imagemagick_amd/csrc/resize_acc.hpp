@@ -174,7 +174,9 @@ static __device__ __forceinline__ bool clamped_sums_count(const double (&s)[4])
 // output in three whose window is (0 .. 0, 1, 0 .. 0) — over a transparent centre pixel between opaque ones
 // are exactly this case: the two neighbours' weights are w and -w, the alpha sum is 0 or 1e-29, its SIGN
 // picks +-1/MagickEpsilon, and the reference's order is the only arbiter.  Suppressing the report for
-// such windows was tried and failed the binary-alpha runs.)
+// such windows was tried and failed the binary-alpha runs.  Round 6 withdraws it for the LAST filter of a Q16 frame
+// only where the window's own terms are all tiny AND the alpha sum is far above its rounding — resize_stream.hip,
+// finish_fast: the w / -w window above fails the second condition and stays reported.)
 
 
 // The reference's two filters over one rectangle of the output (VerticalFilter, then

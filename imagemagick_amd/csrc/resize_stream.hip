@@ -104,8 +104,22 @@ static __device__ __forceinline__ void finish_sums(const double (&s)[4],Q (&q)[4
 // whose value the fused sums cannot vouch for (a lane mask in scalar registers: no vector register
 // across the walk): TIES (the intermediate) a value too close to a rounding boundary (resize_acc.hpp,
 // TieWatch); the outputs: an alpha sum so small that the quotient's error is no longer negligible.
-template<typename Q,bool BLEND,int NEWTON,bool TIES>
-static __device__ __forceinline__ void finish_fast(const double (&s)[4],Q (&q)[4],unsigned long long &doubt)
+//
+// Where PerceptibleReciprocal's clamp acts in the LAST filter of a Q16 frame the report can be withdrawn when the
+// sums' own terms say that no order of summation matters (`magnitudes(a)`: a[c] = sum |weight * sample| of the
+// window, computed only inside this rare branch): the result is +-s_c * QuantumScale / MagickEpsilon, so two orders
+// differ by 1.5e7 * 6e-15 * a_c = 9e-8 * a_c level — nothing against the +-1 of the last filter while a_c < 1e4 —
+// and the SIGN is the alpha sum's, certain while |s_a| is far above its own rounding (6e-15 * a_a).  The case this
+// is for: a 3x enlargement has one output in three whose window is (~0 .. ~0, 1, ~0 .. ~0); over an intermediate
+// pixel whose alpha the first filter's negative lobes clamped to 0 — one in 77 on a frame of random alpha — the
+// alpha sum is 1e-8 out of terms of 1e-8 and the report sent three quarters of the frame down the careful launch
+// (12 ms against the walk's 3.2 on 8192^2).  The window it is NOT for: a transparent pixel between two equal
+// opaque ones, where the terms w and -w cancel to 0 or 1e-29 and the sign is the order's: |s_a| << a_a, reported.
+struct NoMagnitudes { __device__ __forceinline__ bool operator()(double (&)[4]) const { return false; } };
+
+template<typename Q,bool BLEND,int NEWTON,bool TIES,class Magnitudes=NoMagnitudes>
+static __device__ __forceinline__ void finish_fast(const double (&s)[4],Q (&q)[4],unsigned long long &doubt,
+  const Magnitudes &magnitudes=Magnitudes())
 {
   // (ONE ballot, behind the branch, where every lane of the wave is present again: a ballot inside a
   // divergent branch reaches only the lanes that took it, and the wave's mask is read from one lane)
@@ -117,6 +131,13 @@ static __device__ __forceinline__ void finish_fast(const double (&s)[4],Q (&q)[4
     {
       finish_sums<Q,BLEND>(s,q);
       flagged=clamped_sums_count(s);
+      if constexpr (!TIES && !QuantumOps<Q>::is_float)
+        if (flagged)
+          {
+            double a[4];
+            if (magnitudes(a))
+              flagged=!((a[0] < 1.0e4) && (a[1] < 1.0e4) && (a[2] < 1.0e4) && (__builtin_fabs(s[3]) >= 1.0e-9*a[3]));
+          }
     }
   else
     {
@@ -509,7 +530,29 @@ void resize_stream_kernel(StreamResizeArgs a)
       for (int p=0; p < F; p++)
         {
           Q out[4];
-          finish_fast<Q,BLEND,1,false>(h[p],out,doubt);
+          // (sum |weight * sample| of this output's window: only where the clamp acts, see finish_fast)
+          auto magnitudes=[&](double (&a)[4]) -> bool
+          {
+            a[0]=a[1]=a[2]=a[3]=0.0;
+            const bool own_weights=edge_wave && listed;
+#pragma unroll
+            for (int j=0; j < NT; j++)
+              if ((j >= phase_first(p)) && (j < phase_first(p)+NT-1))
+                {
+                  const double2_t n01=row01[lo+j],n23=row23[lo+j];
+                  const double w=__builtin_fabs(own_weights ? mine_listed[p*NT+j] : hw[p*NT+j]);
+                  a[0]=__builtin_fma(w,__builtin_fabs(n01[0]),a[0]);
+                  a[1]=__builtin_fma(w,__builtin_fabs(n01[1]),a[1]);
+                  a[2]=__builtin_fma(w,__builtin_fabs(n23[0]),a[2]);
+                  a[3]=__builtin_fma(w,__builtin_fabs(n23[1]),a[3]);
+                }
+            return true;
+          };
+          // (an odd factor only: no other has an output whose window is one sample's)
+          if constexpr ((F % 2) == 1)
+            finish_fast<Q,BLEND,1,false>(h[p],out,doubt,magnitudes);
+          else
+            finish_fast<Q,BLEND,1,false>(h[p],out,doubt);
           store_pixel<Q,4>(reinterpret_cast<Q *>(xpose+p*XPLANE+lane*PX),out);
         }
       // (the lanes beside the strip's own columns summed neighbours they do not have: their pixels are never stored)

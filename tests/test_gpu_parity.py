@@ -2158,6 +2158,38 @@ def test_resize_fast_transparent_columns_beside_planted_ties(im, refmod, factor,
                   max_ulp=1, residue=65535.0e-9 if is_float else 0.0)
 
 
+def test_resize_fast_x3_alpha_clamped_by_the_first_filter(im, refmod):
+    """A 3x enlargement has one output in three whose window is (~0 .. ~0, 1, ~0 .. ~0).  Where the first filter's
+    negative lobes clamp an intermediate alpha to 0 — one pixel in 77 on random alpha — that output's alpha sum is
+    1e-8 out of terms of 1e-8: PerceptibleReciprocal's clamp acts (resize.c:3522-3528 via pixel-accessor.h:242-254),
+    and until round 6 the walk reported every such lane: three quarters of the frame went down the careful launch
+    (12 ms against 3.2 per 8192^2).  The report is withdrawn where the window's own terms say no summation order
+    matters (resize_stream.hip, finish_fast) — and kept where it does: a transparent pixel between two EQUAL opaque
+    ones, whose terms w and -w cancel and leave the sign of the alpha sum to the order."""
+    import bench
+    rows, cols = 96, 640
+    rng = np.random.default_rng(333)
+    random_alpha = rng.integers(0, 65536, (rows, cols, 4)).astype(np.uint16)
+    cancelling = rng.integers(0, 65536, (rows, cols, 4)).astype(np.uint16)
+    cancelling[:, :, 3] = 65535
+    cancelling[:, 1::4, 3] = 0                          # transparent columns between opaque ones
+    cancelling[:, 0::4, :3] = cancelling[:, 2::4, :3]   # ... of equal colour either side
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        for label, px, few_blocks in (("random alpha", random_alpha, True), ("cancelling neighbours", cancelling, False)):
+            want = refmod.RefImage(px).resize(3 * cols, 3 * rows, "Lanczos").numpy()
+            dev = im.Image(to_device(px), has_alpha=True)
+            holder = {}
+            prof = bench.kernel_profile(im, lambda: holder.update(out=im.resize_image(dev, 3 * cols, 3 * rows, "Lanczos")), 1)
+            assert "resize_stream" in prof, prof
+            assert_parity(holder["out"].numpy(), want, False, "FAST resize x3 Lanczos, %s" % label, max_ulp=1)
+            if few_blocks:
+                # (the careful launch's workgroups leave at once where nothing is marked)
+                assert prof["resize_stream_careful"]["avg_ms"] < 0.5 * prof["resize_stream"]["avg_ms"], prof
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+
+
 def test_resize_fast_falls_back_to_two_passes(im, refmod):
     """What the matrix-pipe form declines keeps the two-pass kernels: reductions, barely-enlarging
     geometries whose windows are wider than its ring, three-channel frames."""
