@@ -417,9 +417,18 @@ MhStatus launch_resize_fused(const View &src,const View &dst,const TapTable &ver
   // DESIGN.md section 4.3.)
   if (prec != MH_PRECISION_FAST)
     return MH_OK;
+  // The one-launch walks need a frame that fills the chip: a wave of the streaming form walks a strip of 58 source
+  // columns down 32..128 result rows, a workgroup of the matrix form a 16-column strip.  Below that the two passes
+  // are the faster FAST form (tools/probe_resize_rows.py, Lanczos RGBA: 512^2 x2 0.05-0.25 ms against 0.03;
+  // 2048^2 x3 0.28-0.44 against 0.26; 4096^2 x3 0.92 against 1.06, x1.5 on the matrix pipe 0.57 against 0.48;
+  // 8192^2 x2.5 3.35 against 3.89).  MAGICKHIP_RESIZE_ONE_LAUNCH_MIN_PIXELS (MhSetOption) moves both thresholds —
+  // the suites set it to 0 so that small frames keep exercising these kernels.
+  const long long pixels=(long long) src.columns*(long long) src.rows;
+  const long long forced=option_long("MAGICKHIP_RESIZE_ONE_LAUNCH_MIN_PIXELS",-1);
+  const long long stream_from=forced >= 0 ? forced : 6000000ll,matrix_from=forced >= 0 ? forced : 40000000ll;
   // four channels, enlargement by a whole-number horizontal factor: plain fp64 multiply-adds out of
   // registers with scalar-register weights (resize_stream.hip); MAGICKHIP_NO_RESIZE_STREAM=1 skips it
-  if (option("MAGICKHIP_NO_RESIZE_STREAM") == nullptr)
+  if ((option("MAGICKHIP_NO_RESIZE_STREAM") == nullptr) && (pixels >= stream_from))
     {
       MH_TRY(launch_resize_stream(src,dst,vertical,horizontal,roles,handled));
       if (*handled)
@@ -427,7 +436,7 @@ MhStatus launch_resize_fused(const View &src,const View &dst,const TapTable &ver
     }
   // any other enlargement of a four-channel frame: both filters on the fp64 matrix pipe, the
   // intermediate in registers (resize_mfma.hip); MAGICKHIP_NO_RESIZE_MFMA=1 keeps the two passes
-  if (option("MAGICKHIP_NO_RESIZE_MFMA") == nullptr)
+  if ((option("MAGICKHIP_NO_RESIZE_MFMA") == nullptr) && (pixels >= matrix_from))
     return launch_resize_mfma(src,dst,vertical,horizontal,roles,handled);
   return MH_OK;
 }

@@ -698,7 +698,16 @@ static MhStatus launch_stream_typed(const View &src,const View &dst,const Stream
   a.strip_first=t.at<int>(d.i_first); a.strip_count=t.at<int>(d.i_count); a.strip_hw=t.at<double>(d.i_strip_hw);
   // a wave walks `rows` output rows (it re-reads the kRows source rows above its first one): enough
   // waves for a few rounds over the chip's 12 a CU
-  int rows=(int) option_long("MAGICKHIP_RESIZE_STREAM_ROWS",128);
+  // (... about eight: 128 rows where the frame has them, 64 or 32 on a smaller one — 4096^2 x4 1.47 -> 1.29 ms,
+  // 8192^2 x2 1.64 -> 1.60; C3's 8192^2 x4 keeps 128.  MAGICKHIP_RESIZE_STREAM_ROWS fixes it.)
+  int rows=(int) option_long("MAGICKHIP_RESIZE_STREAM_ROWS",0);
+  if (rows <= 0)
+    {
+      const long long wanted=8ll*12ll*(long long) compute_units(src.device);
+      rows=128;
+      while ((rows > 32) && ((long long) d.strips*(((long long) dst.rows+rows-1)/rows) < wanted))
+        rows/=2;
+    }
   rows=rows < 16 ? 16 : rows;
   a.rows_per_chunk=rows;
   a.mark_shift=2;                              // a chunk's rows in at most 32 blocks of 4 .. rows

@@ -27,6 +27,7 @@ def setup(seed=1):
     if not _ready:
         im.load()
         refmod.set_thread_limit(os.cpu_count() or 1)
+        im.set_option("MAGICKHIP_RESIZE_ONE_LAUNCH_MIN_PIXELS", "0")     # small frames through the one-launch resize kernels too
         _ready = True
     im.set_precision(im.PRECISION_EXACT)           # (the library's default is FAST; the cases below switch per call)
 

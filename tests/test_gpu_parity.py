@@ -2190,6 +2190,30 @@ def test_resize_fast_x3_alpha_clamped_by_the_first_filter(im, refmod):
         im.set_precision(im.PRECISION_EXACT)
 
 
+def test_resize_fast_one_launch_forms_wait_for_a_frame_that_fills_the_chip(im, refmod, options):
+    """The library's own routing (the suites run with MAGICKHIP_RESIZE_ONE_LAUNCH_MIN_PIXELS=0): a FAST enlargement
+    of a small frame keeps the two passes — the one-launch walks were 2-9 times slower there
+    (tools/probe_resize_rows.py) — a frame of six megapixels takes the streaming form."""
+    import bench
+    options.set("MAGICKHIP_RESIZE_ONE_LAUNCH_MIN_PIXELS", None)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        for shape, target, expected in (((300, 400), (800, 600), {"resize_horizontal", "resize_vertical"}),
+                                        ((300, 400), (700, 500), {"resize_horizontal", "resize_vertical"}),
+                                        ((2500, 2500), (5000, 5000), {"resize_stream", "resize_stream_careful"})):
+            px = make_pixels(shape[0], shape[1], 4, Q16)
+            dev = im.Image(to_device(px), has_alpha=True)
+            holder = {}
+            launched = set(bench.kernel_profile(
+                im, lambda: holder.update(out=im.resize_image(dev, target[0], target[1], "Lanczos")), 1))
+            assert launched == expected, (shape, launched)
+            if shape[0] <= 400:
+                want = refmod.RefImage(px).resize(target[0], target[1], "Lanczos").numpy()
+                assert_parity(holder["out"].numpy(), want, False, "FAST resize, default routing %s" % (shape,), max_ulp=1)
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+
+
 def test_resize_fast_falls_back_to_two_passes(im, refmod):
     """What the matrix-pipe form declines keeps the two-pass kernels: reductions, barely-enlarging
     geometries whose windows are wider than its ring, three-channel frames."""
