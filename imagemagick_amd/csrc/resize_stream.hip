@@ -797,6 +797,14 @@ MhStatus launch_resize_stream(const View &src,const View &dst,const TapTable &ve
   MH_TRY(acquire_stream_plan(&plan,vertical,horizontal,(int) src.columns,(int) src.rows,src.device,src.stream));
   if (!plan->ok)
     return MH_OK;
+  // a first filter whose sums land exactly on rounding boundaries once in a few values (StreamResizePlan::
+  // weights_denominator): the two passes then — unless the suites' switch is set
+  {
+    const int D=plan->plan.weights_denominator;
+    if ((D > 1) && ((src.quantum != MH_QUANTUM_U16) || ((D & 1) == 0)) &&
+        (option_long("MAGICKHIP_RESIZE_ONE_LAUNCH_MIN_PIXELS",-1) < 0))
+      return MH_OK;
+  }
   *handled=true;
   switch (plan->plan.f)
   {

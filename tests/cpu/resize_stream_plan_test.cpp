@@ -195,6 +195,25 @@ int main()
   failures+=check(41,50,164,150,triangle,1.0,true,"triangle 3x");
   failures+=check(29,33,290,330,lanczos3,3.0,false,"lanczos 10x");
   failures+=check(150,70,600,141,lanczos3,3.0,false,"lanczos 2.01x");
+  // weights_denominator: the first (vertical) filter's weights as fractions with a small denominator — Triangle at
+  // 2x: quarters (minus MagickEpsilon), at 3x: thirds; Lanczos: none
+  {
+    auto denominator=[&](int H,int OH,double (*filter)(double),double support) -> int
+    {
+      Table vt,ht;
+      build(vt,H,OH,filter,support);
+      build(ht,128,256,filter,support);
+      mh::StreamResizePlan plan;
+      if (!mh::build_stream_resize_plan(plan,vt,ht,128,H))
+        return -1;
+      return plan.weights_denominator;
+    };
+    const int t2=denominator(60,120,triangle,1.0),t4=denominator(60,240,triangle,1.0),t3=denominator(60,180,triangle,1.0);
+    const int l2=denominator(60,120,lanczos3,3.0),c2=denominator(60,120,catrom,2.0);
+    std::printf("weights denominators: triangle 2x %d, 4x %d, 3x %d; lanczos 2x %d; catrom 2x %d\n",t2,t4,t3,l2,c2);
+    if ((t2 != 4) || (t4 != 8) || (t3 != 3) || (l2 != 0) || (c2 != 128))
+      failures++;
+  }
   std::printf(failures == 0 ? "ALL OK\n" : "%d FAILURES\n",failures);
   return failures == 0 ? 0 : 1;
 }

@@ -2198,17 +2198,22 @@ def test_resize_fast_one_launch_forms_wait_for_a_frame_that_fills_the_chip(im, r
     options.set("MAGICKHIP_RESIZE_ONE_LAUNCH_MIN_PIXELS", None)
     im.set_precision(im.PRECISION_FAST)
     try:
-        for shape, target, expected in (((300, 400), (800, 600), {"resize_horizontal", "resize_vertical"}),
-                                        ((300, 400), (700, 500), {"resize_horizontal", "resize_vertical"}),
-                                        ((2500, 2500), (5000, 5000), {"resize_stream", "resize_stream_careful"})):
+        two_passes = {"resize_horizontal", "resize_vertical"}
+        for shape, target, filt, expected in (((300, 400), (800, 600), "Lanczos", two_passes),
+                                              ((300, 400), (700, 500), "Lanczos", two_passes),
+                                              ((2500, 2500), (5000, 5000), "Lanczos", {"resize_stream", "resize_stream_careful"}),
+                                              # quarters as weights: every fourth sum of integer samples on a rounding boundary
+                                              ((2500, 2500), (5000, 5000), "Triangle", two_passes),
+                                              # thirds: integer sums never reach a half (a float frame's can)
+                                              ((2500, 2500), (7500, 7500), "Triangle", {"resize_stream", "resize_stream_careful"})):
             px = make_pixels(shape[0], shape[1], 4, Q16)
             dev = im.Image(to_device(px), has_alpha=True)
             holder = {}
             launched = set(bench.kernel_profile(
-                im, lambda: holder.update(out=im.resize_image(dev, target[0], target[1], "Lanczos")), 1))
-            assert launched == expected, (shape, launched)
+                im, lambda: holder.update(out=im.resize_image(dev, target[0], target[1], filt)), 1))
+            assert launched == expected, (shape, filt, launched)
             if shape[0] <= 400:
-                want = refmod.RefImage(px).resize(target[0], target[1], "Lanczos").numpy()
+                want = refmod.RefImage(px).resize(target[0], target[1], filt).numpy()
                 assert_parity(holder["out"].numpy(), want, False, "FAST resize, default routing %s" % (shape,), max_ulp=1)
     finally:
         im.set_precision(im.PRECISION_EXACT)
