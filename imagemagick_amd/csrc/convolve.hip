@@ -63,10 +63,16 @@ struct Accum
   static constexpr int NP=(C+1)/2;
   V2 sv[R][NP];
   T g[R];
-  // float Quantum under the tie check: the largest |sample| each channel's sums have seen
-  // (the error bound of a sum is relative to it) and (2K+6)*2^-53, see finish()
+  // float Quantum under the tie check: the largest |sample| each channel has streamed (the error bound of a
+  // sum is relative to it) and (2K+6)*2^-53, see finish().  Kept as a float, two samples an instruction
+  // (v_max3_f32 with |x| source modifiers) where a running fp64 maximum of the premultiplied samples cost one
+  // v_max_f64 a sample and channel.  (The OR of the samples' bit patterns — one v_or3_b32 for two — is a bound too,
+  // but not a tight one: exponents 0x7f and 0x80 OR to 0xff, so a frame holding a 1.5 beside a 2.5 has an infinite
+  // "bound" and every lane takes the reference's order: the row pass of a uniform-random frame ran 3.5x slower,
+  // profiles/r6_notes/float_passes_and_dilate_order.txt.)  A NaN is dropped by the maximum as it was by
+  // v_max_f64 (the sums are NaN then, and decide nothing); an Inf makes the bound infinite.
   static constexpr bool kTracksMagnitude=A::tie_check && (sizeof(Q) == 4);
-  V2 magnitude[kTracksMagnitude ? NP : 1];
+  float seen[kTracksMagnitude ? C : 1];
   T error_unit;
 #define MH_S(r,c) sv[r][(c) >> 1][(c) & 1]
 
@@ -87,21 +93,45 @@ struct Accum
     if constexpr (kTracksMagnitude)
       {
 #pragma unroll
-        for (int q2=0; q2 < NP; q2++)
-          magnitude[q2]=V2{(T) 0,(T) 0};
+        for (int c=0; c < C; c++)
+          seen[c]=0.0f;
         error_unit=(T) (2*ntaps+6)*(T) 1.1102230246251565e-16;
       }
   }
 
-  // one v_max_f64 per channel and streamed sample (|x| is a source modifier)
-  __device__ __forceinline__ void observe(const In &in)
+  __device__ __forceinline__ void observe(const Q (&q)[C])
   {
     if constexpr (kTracksMagnitude)
       {
 #pragma unroll
         for (int c=0; c < C; c++)
-          magnitude[c >> 1][c & 1]=__builtin_fmax(magnitude[c >> 1][c & 1],__builtin_fabs(MH_P(in,c)));
+          asm("v_max_f32 %0, %1, |%2|" : "=v"(seen[c]) : "v"(seen[c]),"v"(q[c]));
       }
+  }
+
+  __device__ __forceinline__ void observe(const Q (&q0)[C],const Q (&q1)[C])
+  {
+    if constexpr (kTracksMagnitude)
+      {
+#pragma unroll
+        for (int c=0; c < C; c++)
+          asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(seen[c]) : "v"(seen[c]),"v"(q0[c]),"v"(q1[c]));
+      }
+  }
+
+  // ... as a magnitude of what channel c's sums are made of: alpha * p for a weighted colour channel
+  // (max |alpha * p| <= max |alpha| * max |p|; the product of two floats is exact in fp64)
+  __device__ __forceinline__ T magnitude(int c) const
+  {
+    if constexpr (kTracksMagnitude)
+      {
+        T m=(T) seen[c];
+        if (BLEND && A::premultiply && (c != C-1))
+          m=m*(T) seen[C-1];
+        return m;
+      }
+    else
+      return (T) 0;
   }
 
   static __device__ __forceinline__ In prepare(const Q (&q)[C])
@@ -208,7 +238,7 @@ struct Accum
                 const T sa=MH_S(r,C-1);
                 doubtful=(sa != (T) 0) && !(__builtin_fabs((T) kQS*sa) >= (T) kEps*(T) 1.000001);
                 inverse=sa == (T) 0 ? (T) 0 : perceptible_reciprocal_fast(sa);
-                alpha_error=error_unit*magnitude[(C-1) >> 1][(C-1) & 1];
+                alpha_error=error_unit*magnitude(C-1);
               }
 #pragma unroll
             for (int c=0; c < C; c++)
@@ -219,7 +249,7 @@ struct Accum
                     continue;
                   }
                 T value=MH_S(r,c);
-                T error=error_unit*magnitude[c >> 1][c & 1];
+                T error=error_unit*magnitude(c);
                 if (BLEND && (c != C-1))
                   {
                     value=value*inverse;
@@ -1044,6 +1074,7 @@ static __device__ __forceinline__ void tri_accumulate(Accum<Q,C,BLEND,A,R> &acc,
   typedef typename A::T T;
   typedef Accum<Q,C,BLEND,A,R> Acc;
   static_assert((R%U) == 0,"R must be a multiple of U");
+  static_assert((U%2) == 0,"samples are observed two at a time");
   const int M=K-1-R;                       // samples of phase B
   const int nfull=M/U,nrem=M-nfull*U;
   const int b2_begin=R+nfull*U,b2_end=K-1;
@@ -1080,7 +1111,8 @@ static __device__ __forceinline__ void tri_accumulate(Accum<Q,C,BLEND,A,R> &acc,
         for (int jj=0; jj < U; jj++)
           {
             typename Acc::In in=Acc::prepare(cur[jj]);
-            acc.observe(in);
+            if ((jj & 1) == 0)
+              acc.observe(cur[jj],cur[jj+1]);
 #pragma unroll
             for (int r=0; r < R; r++)
               if (r <= c0*U+jj)
@@ -1102,7 +1134,8 @@ static __device__ __forceinline__ void tri_accumulate(Accum<Q,C,BLEND,A,R> &acc,
       for (int jj=0; jj < U; jj++)
         {
           typename Acc::In in=Acc::prepare(cur[jj]);
-            acc.observe(in);
+          if ((jj & 1) == 0)
+            acc.observe(cur[jj],cur[jj+1]);
 #pragma unroll
           for (int r=0; r < R; r++)
             acc.tap(r,tw[jj-r+R-1],in);
@@ -1119,7 +1152,7 @@ static __device__ __forceinline__ void tri_accumulate(Accum<Q,C,BLEND,A,R> &acc,
       for (int i=0; i < R; i++)
         tw[i]=table[pos-(R-1)+i];
       typename Acc::In in=Acc::prepare(cur[0]);
-      acc.observe(in);
+      acc.observe(cur[0]);
 #pragma unroll
       for (int r=0; r < R; r++)
         acc.tap(r,tw[R-1-r],in);
@@ -1141,7 +1174,8 @@ static __device__ __forceinline__ void tri_accumulate(Accum<Q,C,BLEND,A,R> &acc,
         for (int jj=0; jj < U; jj++)
           {
             typename Acc::In in=Acc::prepare(cur[jj]);
-            acc.observe(in);
+            if ((jj & 1) == 0)
+              acc.observe(cur[jj],cur[jj+1]);
 #pragma unroll
             for (int r=0; r < R; r++)
               if (r >= c0*U+jj)
