@@ -1403,6 +1403,48 @@ static MhStatus launch_strips_typed(const StripsArgs &args,size_t lds,hipStream_
   return MH_OK;
 }
 
+static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std::vector<int> &half,
+  int cx,int dy_min,const Roles &roles,unsigned long long *changed,bool *handled);
+
+// A one-channel (gray) Q16 frame — the masks Erode and Dilate are mostly run on — has no 4- or 8-byte pixel for
+// the union-of-rectangles kernel's lanes and took morph_convex (Disk:15 on 8192^2: 1.35 ms, an RGBA frame 0.51).
+// Its rows cut into four bands ARE the four channels of a frame a quarter as tall (gray_bands_pack_kernel,
+// pointwise.hip: the kernel's reach in extra rows between bands, the frame's own edge rows repeated above the first
+// and below the last as cache.c:2663-2679 does); minima and maxima are taken per channel, so the result is the
+// frame's own.  The change count (morphology.c:3199) is taken while unpacking, over the frame's own samples.
+static MhStatus try_rects_gray_bands(const View &src,const View &dst,bool dilate,const std::vector<int> &half,
+  int cx,int dy_min,const Roles &roles,unsigned long long *changed,bool *handled)
+{
+  *handled=false;
+  const int span=(int) half.size();
+  const int above=dy_min < 0 ? -dy_min : 0,below=dy_min+span-1 > 0 ? dy_min+span-1 : 0;
+  const int halo=above > below ? above : below;
+  const size_t band=(src.rows+3)/4;
+  if ((roles.copy_mask != 0) || (halo < 1) ||
+      (src.columns*src.rows < (size_t) option_long("MAGICKHIP_GRAY_BANDS_MIN_PIXELS",1l << 18)) ||
+      (band < (size_t) 2*halo) || (band+2*(size_t) halo > 65535u) || (src.rows > 0x7fffffffu/4u) ||
+      (src.columns > 0x7fffffffu))
+    return MH_OK;
+  View packed=src,result=src;
+  packed.channels=result.channels=4;
+  packed.rows=result.rows=band+2*(size_t) halo;
+  Temp packed_memory,result_memory;
+  MH_TRY(packed_memory.alloc(src.device,packed.bytes(),src.stream));
+  MH_TRY(result_memory.alloc(src.device,result.bytes(),src.stream));
+  packed.pixels=packed_memory.ptr;
+  result.pixels=result_memory.ptr;
+  MH_TRY(launch_gray_bands_pack(src,packed,(int) band,halo));
+  Roles plain;
+  plain.update_mask=0xfu;
+  bool inner=false;
+  MH_TRY(try_rects(packed,result,dilate,half,cx,dy_min,plain,nullptr,&inner));
+  if (!inner)
+    return MH_OK;
+  MH_TRY(launch_gray_bands_unpack(result,dst,(int) band,halo,src.pixels,changed));
+  *handled=true;
+  return MH_OK;
+}
+
 // half[k]: half-width of kernel row dy_min+k (every row non-empty, runs centred on cx).  Handles
 // the kernel when its rows are symmetric about the middle row and do not widen away from it.
 static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std::vector<int> &half,
@@ -1411,6 +1453,9 @@ static MhStatus try_rects(const View &src,const View &dst,bool dilate,const std:
   *handled=false;
   const int span=(int) half.size();
   const bool is_float=src.quantum != MH_QUANTUM_U16;
+  if (!is_float && (src.channels == 1) && (option("MAGICKHIP_NO_RECTS") == nullptr) &&
+      (option("MAGICKHIP_NO_GRAY_BANDS") == nullptr))
+    return try_rects_gray_bands(src,dst,dilate,half,cx,dy_min,roles,changed,handled);
   const bool layout=is_float ? ((src.channels == 1) || (src.channels == 2) || (src.channels == 4)) :
     ((src.channels == 2) || (src.channels == 4));
   if (!layout || ((span & 1) == 0) || (option("MAGICKHIP_NO_RECTS") != nullptr) ||

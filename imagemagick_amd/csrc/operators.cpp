@@ -488,6 +488,51 @@ struct MorphologyWorkspace
   }
 };
 
+static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *kernel,
+  const Roles &roles,double bias,bool *handled,bool unsharp=false,double gain=0.0,double threshold=0.0);
+
+// A one-channel (gray) Q16 frame through the same one-launch kernels: its rows as four bands = the four
+// independent channels of a frame a quarter as tall (launch_gray_bands_pack, pointwise.hip), K-1 extra rows
+// between bands.  Each channel of the one-launch kernels is computed on its own — the result is what the frame's
+// own two passes give, +-1 in FAST and bit-identical in EXACT, like a four-channel frame's.  Frames from
+// MAGICKHIP_GRAY_BANDS_MIN_PIXELS on (the pack and unpack launches are two more dispatches), whose bands are at
+// least as tall as the rows added to them.
+static MhStatus fused_blur_gray_bands(const View &src,const View &dst,const MhKernelInfo *kernel,
+  double bias,bool *handled,bool unsharp,double gain,double threshold)
+{
+  *handled=false;
+  const MhKernelInfo *column=kernel->next;
+  if ((column == nullptr) || (column->width != 1) || (column->height < 2) || (column->y < 0) ||
+      ((size_t) column->y >= column->height) || (column->height > 81))
+    return MH_OK;
+  const int K=(int) column->height;
+  const int above=K-1-(int) column->y,below=(int) column->y;
+  const int halo=above > below ? above : below;
+  const size_t band=(src.rows+3)/4;
+  if ((src.columns*src.rows < (size_t) option_long("MAGICKHIP_GRAY_BANDS_MIN_PIXELS",1l << 23)) ||
+      (band < (size_t) 2*halo) || (band+2*(size_t) halo > 65535u) || (src.rows > 0x7fffffffu/4u) ||
+      (src.columns > 0x7fffffffu))
+    return MH_OK;
+  View packed=src,result=src;
+  packed.channels=result.channels=4;
+  packed.rows=result.rows=band+2*(size_t) halo;
+  Temp packed_memory,result_memory;
+  MH_TRY(packed_memory.alloc(src.device,packed.bytes(),src.stream));
+  MH_TRY(result_memory.alloc(src.device,result.bytes(),src.stream));
+  packed.pixels=packed_memory.ptr;
+  result.pixels=result_memory.ptr;
+  MH_TRY(launch_gray_bands_pack(src,packed,(int) band,halo));
+  Roles plain;
+  plain.update_mask=0xfu;
+  bool inner=false;
+  MH_TRY(fused_blur(packed,result,kernel,plain,bias,&inner,unsharp,gain,threshold));
+  if (!inner)
+    return MH_OK;                                // (a kernel the one-launch forms decline: the frame's own passes)
+  MH_TRY(launch_gray_bands_unpack(result,dst,(int) band,halo));
+  *handled=true;
+  return MH_OK;
+}
+
 // BlurImage's kernel list — a 1 x K row kernel followed by the same taps as a K x 1 column
 // kernel (effect.c:765-796, "blur:RxS;blur:RxS+90") — on Q16 RGBA / RGB / four plain channels: both
 // passes in one launch, the Quantum-rounded intermediate stays in LDS.  EXACT and UnsharpMaskImage:
@@ -495,13 +540,16 @@ struct MorphologyWorkspace
 // colour sums + exact alpha sums, +-1 by construction (convolve_fused_hybrid.hip).
 // *handled = false: not this case, nothing launched.
 static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *kernel,
-  const Roles &roles,double bias,bool *handled,bool unsharp=false,double gain=0.0,double threshold=0.0)
+  const Roles &roles,double bias,bool *handled,bool unsharp,double gain,double threshold)
 {
   *handled=false;
   // (switches for tests and A/B runs, from the option table: the environment at start-up + MhSetOption)
   const bool no_mfma=option("MAGICKHIP_NO_MFMA") != nullptr;
   const bool no_fused=option("MAGICKHIP_NO_FUSED_BLUR") != nullptr;
   const bool exact=precision() == MH_PRECISION_EXACT;
+  if ((src.quantum == MH_QUANTUM_U16) && (src.channels == 1) && !roles.blend && (roles.copy_mask == 0) &&
+      (bias == 0.0) && !no_mfma && !no_fused && (option("MAGICKHIP_NO_GRAY_BANDS") == nullptr))
+    return fused_blur_gray_bands(src,dst,kernel,bias,handled,unsharp,gain,threshold);
   if ((src.quantum != MH_QUANTUM_U16) || ((src.channels != 4) && (src.channels != 3)) ||
       (roles.copy_mask != 0) || (bias != 0.0) || no_mfma || no_fused)
     return MH_OK;
@@ -1104,7 +1152,7 @@ static MhStatus unsharp_fused(const View &src,const View &dst,const MhKernelInfo
   *fused=false;
   const MhKernelInfo *horizontal=kernels,*vertical=kernels != nullptr ? kernels->next : nullptr;
   if ((src.quantum != MH_QUANTUM_U16) ||
-      ((src.channels != 4) && (src.channels != 3)) ||
+      ((src.channels != 4) && (src.channels != 3) && (src.channels != 1)) ||
       (src.columns < 2) || (option("MAGICKHIP_NO_FUSED_UNSHARP") != nullptr) ||
       (option("MAGICKHIP_NO_MFMA") != nullptr) ||
       (roles.copy_mask != 0) || (horizontal == nullptr) || (vertical == nullptr) ||

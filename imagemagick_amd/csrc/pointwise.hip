@@ -3370,6 +3370,85 @@ MhStatus launch_separable_finish(const View &sums,const View &dst,bool blend)
   return MH_OK;
 }
 
+// ------------------------------------------------------------------ one-channel frames as four row bands
+// A gray Q16 frame has no wide pixel to hand the one-launch blur kernels (convolve_fused_hybrid.hip,
+// convolve_fused_exact.hip: 8-byte pixels, four independent channels).  Its rows cut into four bands ARE four
+// independent channels of a frame a quarter as tall: channel c of packed row r is source row c*band + r - halo,
+// clamped into the frame (the virtual pixels of cache.c:2663-2679 above the first and below the last row; between
+// bands, the neighbouring band's real rows).  The kernels' own edge clamp then only ever decides packed rows
+// [0, halo) and [band+halo, band+2*halo), which unpacking drops.
+__global__ __launch_bounds__(256)
+void gray_bands_pack_kernel(const uint16_t *src,uint16_t *dst,int W,int H,int band,int halo)
+{
+  const int x=(int) (blockIdx.x*blockDim.x+threadIdx.x);
+  const int r=(int) blockIdx.y;
+  if (x >= W)
+    return;
+  uint16_t p[4];
+#pragma unroll
+  for (int c=0; c < 4; c++)
+    {
+      int y=c*band+r-halo;
+      y=y < 0 ? 0 : (y > H-1 ? H-1 : y);
+      p[c]=src[(size_t) y*(size_t) W+(size_t) x];
+    }
+  store_pixel<uint16_t,4>(dst+((size_t) r*(size_t) W+(size_t) x)*4,p);
+}
+
+// ... and back; `changed` (MorphologyPrimitive's count, morphology.c:3199): the samples that differ from `original`
+__global__ __launch_bounds__(256)
+void gray_bands_unpack_kernel(const uint16_t *src,uint16_t *dst,int W,int H,int band,int halo,
+  const uint16_t *original,unsigned long long *changed)
+{
+  const int x=(int) (blockIdx.x*blockDim.x+threadIdx.x);
+  const int r=(int) blockIdx.y;
+  unsigned differ=0;
+  if (x < W)
+    {
+      uint16_t p[4];
+      load_pixel<uint16_t,4>(src+((size_t) (r+halo)*(size_t) W+(size_t) x)*4,p);
+#pragma unroll
+      for (int c=0; c < 4; c++)
+        {
+          const int y=c*band+r;
+          if (y < H)
+            {
+              const size_t at=(size_t) y*(size_t) W+(size_t) x;
+              if (changed != nullptr)
+                differ+=original[at] != p[c] ? 1u : 0u;
+              dst[at]=p[c];
+            }
+        }
+    }
+  if (changed != nullptr)
+    {
+      differ=wave_sum(differ);
+      if (((threadIdx.x & 63) == 0) && (differ != 0))
+        atomicAdd(changed,(unsigned long long) differ);
+    }
+}
+
+MhStatus launch_gray_bands_pack(const View &src,const View &packed,int band,int halo)
+{
+  ProfileScope prof("gray_bands_pack",src.stream);
+  hipLaunchKernelGGL(gray_bands_pack_kernel,dim3((unsigned) ((src.columns+255)/256),(unsigned) (band+2*halo)),dim3(256),0,
+    src.stream,static_cast<const uint16_t *>(src.pixels),static_cast<uint16_t *>(packed.pixels),(int) src.columns,
+    (int) src.rows,band,halo);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+MhStatus launch_gray_bands_unpack(const View &packed,const View &dst,int band,int halo,const void *original,
+  unsigned long long *changed)
+{
+  ProfileScope prof("gray_bands_unpack",dst.stream);
+  hipLaunchKernelGGL(gray_bands_unpack_kernel,dim3((unsigned) ((dst.columns+255)/256),(unsigned) band),dim3(256),0,
+    dst.stream,static_cast<const uint16_t *>(packed.pixels),static_cast<uint16_t *>(dst.pixels),(int) dst.columns,
+    (int) dst.rows,band,halo,static_cast<const uint16_t *>(original),changed);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 MhStatus launch_copy(const View &src,const View &dst)
 {
   MH_HIP(hipMemcpyAsync(dst.pixels,src.pixels,src.bytes(),hipMemcpyDeviceToDevice,src.stream));

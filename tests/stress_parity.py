@@ -28,6 +28,7 @@ def setup(seed=1):
         im.load()
         refmod.set_thread_limit(os.cpu_count() or 1)
         im.set_option("MAGICKHIP_RESIZE_ONE_LAUNCH_MIN_PIXELS", "0")     # small frames through the one-launch resize kernels too
+        im.set_option("MAGICKHIP_GRAY_BANDS_MIN_PIXELS", "0")            # ... and small gray frames through the four-band form of the fused blur
         _ready = True
     im.set_precision(im.PRECISION_EXACT)           # (the library's default is FAST; the cases below switch per call)
 

@@ -63,6 +63,50 @@ def test_c2_blur_exact_full_size(im, c2_case):
     _compare_q16(got, want, True, "C2 BlurImage EXACT")
 
 
+def test_gray_blur_and_unsharp_full_size_take_the_four_band_form(im, refmod):
+    """A 4099 x 4096 one-channel Q16 frame (16.8 Mpixel: above the route's default threshold, a height that is
+    not a multiple of four) with nothing set: BlurImage(0,10) and UnsharpMaskImage(0,10,1.5,0.01) run as four row
+    bands through the one-launch kernels (operators.cpp fused_blur_gray_bands) — FAST BlurImage within one
+    level, everything else bit-identical, on the whole frame; and a frame below the threshold keeps its own two
+    passes."""
+    import bench
+    rows, cols = 4099, 4096
+    rng = np.random.default_rng(409)
+    px = rng.integers(0, 65536, (rows, cols, 1), dtype=np.uint16)
+    px[:3] = 65535                                     # the frame's edges unlike what lies inside
+    px[-2:] = 0
+    px[1024:1030] = 0                                  # ... and the rows either side of a band boundary
+    px[1030:1036] = 65535
+    refmod.set_thread_limit(os.cpu_count() or 1)
+    ref = refmod.RefImage(px)
+    want_blur = ref.blur(0.0, 10.0).numpy().reshape(rows, cols, 1)
+    want_unsharp = ref.unsharp(0.0, 10.0, 1.5, 0.01).numpy().reshape(rows, cols, 1)
+    image = im.Image(to_device(px))
+    holder = {}
+    for precision, exact in ((im.PRECISION_FAST, False), (im.PRECISION_EXACT, True)):
+        im.set_precision(precision)
+        try:
+            launched = set(bench.kernel_profile(im, lambda: holder.update(b=im.blur_image(image, 0.0, 10.0)), 1))
+            assert launched == {"gray_bands_pack", "blur_fused_exact" if exact else "blur_fused_hybrid",
+                                "gray_bands_unpack"}, launched
+            launched = set(bench.kernel_profile(
+                im, lambda: holder.update(u=im.unsharp_mask_image(image, 0.0, 10.0, 1.5, 0.01)), 1))
+            assert launched == {"gray_bands_pack", "unsharp_fused_exact", "gray_bands_unpack"}, launched
+        finally:
+            im.set_precision(im.PRECISION_EXACT)
+        _compare_q16(holder["b"].pixels, want_blur, exact, "gray BlurImage, precision %d" % precision)
+        _compare_q16(holder["u"].pixels, want_unsharp, True, "gray UnsharpMaskImage, precision %d" % precision)
+    small = im.Image(to_device(px[:1024, :1024].copy()))
+    launched = set(bench.kernel_profile(im, lambda: holder.update(s=im.blur_image(small, 0.0, 10.0)), 1))
+    assert "gray_bands_pack" not in launched, launched
+    # ... and Erode / Dilate Disk:15 through the union-of-rectangles kernel (morphology.hip try_rects_gray_bands)
+    for method in ("Dilate", "Erode"):
+        launched = set(bench.kernel_profile(im, lambda: holder.update(m=im.morphology_image(image, method, 1, "Disk:15")), 1))
+        assert launched == {"gray_bands_pack", "morph_rects", "gray_bands_unpack"}, launched
+        want = ref.morphology(method, 1, "Disk:15").numpy().reshape(rows, cols, 1)
+        _compare_q16(holder["m"].pixels, want, True, "gray %s Disk:15" % method)
+
+
 def test_c2_blur_exact_tiny_alpha_frame_is_given_up_to_the_fp64_passes(im, refmod):
     """EXACT BlurImage on an 8192^2 frame whose alpha is 0..3 levels EVERYWHERE: the certificate of the
     exact-integer kernel cannot decide one sample in twelve there and their reference-order recomputation

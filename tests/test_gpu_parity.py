@@ -398,6 +398,45 @@ def test_blur_and_unsharp_fast_rgb_single_launch(im, refmod, shape, sigma, optio
         assert_parity(holder["u"].numpy(), ref.unsharp(0.0, sigma, 1.5, 0.01).numpy(), True, "fast RGB unsharp %s" % (shape,))
 
 
+@pytest.mark.parametrize("shape", [(150, 331), (67, 64), (130, 2), (257, 33), (516, 70)])
+@pytest.mark.parametrize("sigma", [0.6, 2.0, 5.0, 10.0])
+def test_gray_blur_and_unsharp_as_four_row_bands(im, refmod, shape, sigma, options):
+    """A one-channel Q16 frame through the one-launch kernels as four row bands = four channels of a frame a
+    quarter as tall (operators.cpp fused_blur_gray_bands, pointwise.hip gray_bands_pack_kernel): heights that
+    are not multiples of four, bands barely taller than the rows added to them (the route declines below that:
+    the frame's own two passes), every kind of frame edge.  FAST BlurImage within one level, EXACT BlurImage and
+    UnsharpMaskImage in both modes bit-identical (morphology.c:2654-2979, effect.c:4364-4369)."""
+    import bench
+    options.set("MAGICKHIP_GRAY_BANDS_MIN_PIXELS", "0")
+    px = make_pixels(shape[0], shape[1], 1, Q16, seed=shape[0] + shape[1] + int(sigma * 10))
+    # rows that tell the bands apart, and the frame's first and last row unlike their neighbours
+    px[0, :, 0] = 65535
+    px[-1, :, 0] = 0
+    dev, ref = run_pair(im, refmod, px)
+    taps = im.optimal_kernel_width_1d(0.0, sigma)
+    banded = (shape[0] + 3) // 4 >= 2 * (taps // 2) and taps <= 81
+    holder = {}
+    for precision, exact in ((im.PRECISION_FAST, False), (im.PRECISION_EXACT, True)):
+        im.set_precision(precision)
+        try:
+            launched = set(bench.kernel_profile(im, lambda: holder.update(b=im.blur_image(dev, 0.0, sigma)), 1))
+            if banded:
+                assert launched == {"gray_bands_pack", "blur_fused_exact" if exact else "blur_fused_hybrid",
+                                    "gray_bands_unpack"}, launched
+            else:
+                assert "gray_bands_pack" not in launched, launched
+            launched = set(bench.kernel_profile(
+                im, lambda: holder.update(u=im.unsharp_mask_image(dev, 0.0, sigma, 1.5, 0.01)), 1))
+            if banded:
+                assert launched == {"gray_bands_pack", "unsharp_fused_exact", "gray_bands_unpack"}, launched
+        finally:
+            im.set_precision(im.PRECISION_EXACT)
+        assert_parity(holder["b"].numpy(), ref.blur(0.0, sigma).numpy(), exact, "gray blur %s, precision %d" % (shape, precision))
+        if banded:
+            assert_parity(holder["u"].numpy(), ref.unsharp(0.0, sigma, 1.5, 0.01).numpy(), True,
+                          "gray unsharp %s, precision %d" % (shape, precision))
+
+
 @pytest.mark.parametrize("channels", [4, 3])
 @pytest.mark.parametrize("sigma", [3.2, 5.0, 8.0, 11.0, 14.0])
 def test_blur_fast_every_ring_size(im, refmod, channels, sigma):
@@ -760,6 +799,49 @@ def test_symmetric_convex_kernels_over_several_tiles(im, refmod, method, kernel,
     assert_parity(holder["out"].numpy(), want, True, "%s %s c%d" % (method, kernel, channels))
     options.set("MAGICKHIP_NO_RECTS", "1")
     assert_parity(im.morphology_image(dev, method, 1, kernel).numpy(), want, True, "%s %s (planes)" % (method, kernel))
+
+
+@pytest.mark.parametrize("rows", [90, 131, 258])
+@pytest.mark.parametrize("method,kernel,iterations", [
+    ("Dilate", "Disk:15", 1), ("Erode", "Disk:15", 1), ("Dilate", "Disk:7.3", 1), ("Erode", "Octagon:6", 2),
+    ("Dilate", "Diamond:9", 1), ("Erode", "Square:4", 1), ("Dilate", "Rectangle:9x5+2+1", 1), ("Erode", "Rectangle:9x5+2+3", 1),
+    ("Dilate", "Plus:11", 1), ("Erode", "Rectangle:1x9", 1), ("Dilate", "Square:1", 3),
+    ("Open", "Disk:5", 1), ("Close", "Octagon:3", 1), ("Smooth", "Square:2", 1), ("Edge", "Diamond:2", 1),
+    ("TopHat", "Disk:4", 1), ("Dilate", "Square:2", -1),
+])
+def test_gray_erode_dilate_as_four_row_bands(im, refmod, method, kernel, iterations, rows, options):
+    """Erode / Dilate (and the compound methods built on them) on a one-channel Q16 frame — the masks these
+    operators are mostly run on: the frame's rows as four bands = the four channels of a frame a quarter as tall,
+    through the union-of-rectangles kernel (morphology.hip try_rects_gray_bands).  Heights that are and are not
+    multiples of four, kernels whose origin is not their middle row, bands barely taller than the kernel's reach
+    (the form declines below that), an unbounded iteration that ends on the change count taken while unpacking
+    (morphology.c:3199, :3634-4077).  Bit-identical to the reference and to the form it replaces."""
+    import bench
+    options.set("MAGICKHIP_GRAY_BANDS_MIN_PIXELS", "0")
+    px = make_pixels(rows, 277, 1, Q16, seed=len(kernel) + rows)
+    px[0] = 65535
+    px[-1] = 0
+    if iterations < 0:
+        px[:] = 0
+        px[rows // 2, 100] = 40000
+        px[3, 270] = 65535
+    dev, ref = run_pair(im, refmod, px)
+    holder = {}
+    launched = set(bench.kernel_profile(
+        im, lambda: holder.update(out=im.morphology_image(dev, method, iterations, kernel)), 1))
+    want = ref.morphology(method, iterations, kernel).numpy()
+    assert_parity(holder["out"].numpy(), want, True, "gray %s %s x%d, %d rows" % (method, kernel, iterations, rows))
+    reach = {"Disk:15": 15, "Disk:7.3": 7, "Octagon:6": 6, "Diamond:9": 9, "Square:4": 4, "Rectangle:9x5+2+1": 3,
+             "Rectangle:9x5+2+3": 3, "Plus:11": 11, "Rectangle:1x9": 4, "Square:1": 1, "Disk:5": 5, "Octagon:3": 3,
+             "Square:2": 2, "Diamond:2": 2, "Disk:4": 4}[kernel]
+    if (rows + 3) // 4 >= 2 * reach:
+        assert {"gray_bands_pack", "morph_rects", "gray_bands_unpack"} <= launched, launched
+        assert "morph_convex" not in launched, launched
+    else:
+        assert "gray_bands_pack" not in launched, launched
+    options.set("MAGICKHIP_NO_GRAY_BANDS", "1")
+    assert_parity(im.morphology_image(dev, method, iterations, kernel).numpy(), want, True,
+                  "gray %s %s (the frame's own form)" % (method, kernel))
 
 
 @pytest.mark.parametrize("channels", [4, 2, 1])
