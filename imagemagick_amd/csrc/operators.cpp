@@ -318,6 +318,38 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
       p.origin=(int) kernel->x;
       return launch_conv1d(src,dst,false,p,roles,mode,changed);
     }
+  // A 2-D Convolve of a one-channel (gray) Q16 frame: the frame's rows as four bands = the four independent
+  // channels of a frame a quarter as tall (gray_bands_pack_kernel, pointwise.hip; the kernel's reach in extra rows
+  // between bands), so that the wide-pixel kernels below take it — the matrix-core forms, the separated passes.
+  // Every channel of a frame without alpha weighting is summed on its own (morphology.c:2892-2979): the result is
+  // the frame's own under the same contract.
+  if ((method == MH_MORPHOLOGY_CONVOLVE) && (src.quantum == MH_QUANTUM_U16) && (src.channels == 1) &&
+      !roles.blend && (roles.copy_mask == 0) && (kernel->width >= 2) && (kernel->height >= 2) &&
+      (option("MAGICKHIP_NO_GRAY_BANDS") == nullptr))
+    {
+      const int above=(int) kernel->y,below=(int) kernel->height-1-(int) kernel->y;
+      const int halo=above > below ? above : below;
+      const size_t band=(src.rows+3)/4;
+      if ((kernel->y >= 0) && ((size_t) kernel->y < kernel->height) &&
+          (src.columns*src.rows >= (size_t) option_long("MAGICKHIP_GRAY_BANDS_MIN_PIXELS",1l << 23)) &&
+          (band >= (size_t) 2*halo) && (band+2*(size_t) halo <= 65535u) && (src.rows <= 0x7fffffffu/4u) &&
+          (src.columns <= 0x7fffffffu))
+        {
+          View packed=src,result=src;
+          packed.channels=result.channels=4;
+          packed.rows=result.rows=band+2*(size_t) halo;
+          Temp packed_memory,result_memory;
+          MH_TRY(packed_memory.alloc(src.device,packed.bytes(),src.stream));
+          MH_TRY(result_memory.alloc(src.device,result.bytes(),src.stream));
+          packed.pixels=packed_memory.ptr;
+          result.pixels=result_memory.ptr;
+          MH_TRY(launch_gray_bands_pack(src,packed,(int) band,halo));
+          Roles plain;
+          plain.update_mask=0xfu;
+          MH_TRY(primitive(packed,result,method,kernel,bias,plain,desc,nullptr,mode));
+          return launch_gray_bands_unpack(result,dst,(int) band,halo,src.pixels,changed);
+        }
+    }
   if ((method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
       (mode == MH_PRECISION_FAST) && !kernel_has_nan(kernel))
     {

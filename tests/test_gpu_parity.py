@@ -801,6 +801,46 @@ def test_symmetric_convex_kernels_over_several_tiles(im, refmod, method, kernel,
     assert_parity(im.morphology_image(dev, method, 1, kernel).numpy(), want, True, "%s %s (planes)" % (method, kernel))
 
 
+@pytest.mark.parametrize("rows", [83, 258])
+@pytest.mark.parametrize("what", ["gaussian 0x1.5", "gaussian 0x4", "gaussian 2x3", "sharpen 0x2", "Disk:5", "Octagon:3",
+                                  "3x3: 1,2,3 4,5,6 7,8,9", "5x3+0+2: 1,2,3,4,5 0,1,0,1,0 -1,2,-1,2,-1", "LoG:0x2",
+                                  "Gaussian:0x2.5", "7x7+5+1: " + ",".join(str((i * 7) % 11 - 3) for i in range(49))])
+def test_gray_convolve_2d_as_four_row_bands(im, refmod, what, rows, options):
+    """2-D Convolve (GaussianBlurImage, SharpenImage, ConvolveImage, -morphology Convolve) of a one-channel Q16
+    frame as four row bands = four plain channels of a frame a quarter as tall (operators.cpp primitive()), through
+    whichever wide-pixel form takes the kernel: separated passes, integer cells on the matrix cores, fused fp64
+    sums.  Kernels with their origin off the middle row, cells of both signs.  EXACT bit-identical, FAST within one
+    level (morphology.c:2892-2979); the result of the frame's own form besides."""
+    import bench
+    options.set("MAGICKHIP_GRAY_BANDS_MIN_PIXELS", "0")
+    px = make_pixels(rows, 96, 1, Q16, seed=len(what) + rows)
+    px[0] = 65535
+    px[-1] = 0
+    dev, ref = run_pair(im, refmod, px)
+    if what.startswith("gaussian"):
+        radius, sigma = (float(v) for v in what.split()[1].split("x"))
+        call, want = (lambda: im.gaussian_blur_image(dev, radius, sigma)), ref.gaussian_blur(radius, sigma).numpy()
+        reach = (im.optimal_kernel_width_2d(radius, sigma) - 1) // 2 if hasattr(im, "optimal_kernel_width_2d") else None
+    elif what.startswith("sharpen"):
+        call, want = (lambda: im.sharpen_image(dev, 0.0, 2.0)), ref.sharpen(0.0, 2.0).numpy()
+        reach = None
+    else:
+        call, want = (lambda: im.morphology_image(dev, "Convolve", 1, what)), ref.morphology("Convolve", 1, what).numpy()
+        reach = None
+    holder = {}
+    for precision, exact in ((im.PRECISION_EXACT, True), (im.PRECISION_FAST, False)):
+        im.set_precision(precision)
+        try:
+            launched = set(bench.kernel_profile(im, lambda: holder.update(out=call()), 1))
+        finally:
+            im.set_precision(im.PRECISION_EXACT)
+        if rows == 258:
+            assert {"gray_bands_pack", "gray_bands_unpack"} <= launched, launched
+        assert_parity(holder["out"].numpy(), want, exact, "gray %s, precision %d, %d rows: %s" % (what, precision, rows, sorted(launched)))
+    options.set("MAGICKHIP_NO_GRAY_BANDS", "1")
+    assert_parity(call().numpy(), want, True, "gray %s (the frame's own form)" % what)
+
+
 @pytest.mark.parametrize("rows", [90, 131, 258])
 @pytest.mark.parametrize("method,kernel,iterations", [
     ("Dilate", "Disk:15", 1), ("Erode", "Disk:15", 1), ("Dilate", "Disk:7.3", 1), ("Erode", "Octagon:6", 2),

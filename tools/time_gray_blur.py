@@ -40,6 +40,21 @@ for n in (512, 1024, 1448, 2048, 4096, 8192):
                 f()
             row.append("%s %.4f" % ("bands" if bands else "own  ", timed(torch, f, 10) * 1e3))
         print("%5d^2 %-6s %-9s %s" % (n, method, kernel, "  ".join(row)), flush=True)
+    for name, op in (("gaussian 0x3", lambda: im.gaussian_blur_image(image, 0.0, 3.0)),
+                     ("sharpen 0x2", lambda: im.sharpen_image(image, 0.0, 2.0)),
+                     ("convolve Disk:5", lambda: im.morphology_image(image, "Convolve", 1, "Disk:5", scale=(1.0, 1))),
+                     ("convolve 3x3", lambda: im.morphology_image(image, "Convolve", 1, "3x3: 1,2,1 2,4,2 1,2,1", scale=(1.0, 1))),
+                     ("convolve LoG:0x2", lambda: im.morphology_image(image, "Convolve", 1, "LoG:0x2"))):
+        row = []
+        for mode, precision in (("fast", im.PRECISION_FAST), ("exact", im.PRECISION_EXACT)):
+            im.set_precision(precision)
+            for bands in (False, True):
+                im.set_option("MAGICKHIP_GRAY_BANDS_MIN_PIXELS", "0")
+                im.set_option("MAGICKHIP_NO_GRAY_BANDS", None if bands else "1")
+                for _ in range(3):
+                    op()
+                row.append("%s %s %.4f" % (mode, "bands" if bands else "own", timed(torch, op, 10) * 1e3))
+        print("%5d^2 %-16s %s" % (n, name, "  ".join(row)), flush=True)
     im.set_option("MAGICKHIP_NO_GRAY_BANDS", None)
     del image, out, a
     torch.cuda.empty_cache()
