@@ -431,6 +431,10 @@ MhStatus launch_copy(const View &src,const View &dst);
 // FAST separable 2-D convolution (pointwise.hip): Q16 -> float sums, float sums -> Q16
 MhStatus launch_premultiply(const View &src,const View &sums,bool blend);
 MhStatus launch_separable_finish(const View &sums,const View &dst,bool blend);
+// a three-channel frame padded to four (pointwise.hip)
+MhStatus launch_rgb_pad(const View &src,const View &padded);
+MhStatus launch_rgb_unpad(const View &padded,const View &dst,const void *original=nullptr,
+  unsigned long long *changed=nullptr);
 // a one-channel Q16 frame as four row bands = four channels (pointwise.hip)
 MhStatus launch_gray_bands_pack(const View &src,const View &packed,int band,int halo);
 MhStatus launch_gray_bands_unpack(const View &packed,const View &dst,int band,int halo,const void *original=nullptr,

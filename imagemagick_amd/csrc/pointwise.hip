@@ -3449,6 +3449,85 @@ MhStatus launch_gray_bands_unpack(const View &packed,const View &dst,int band,in
   return MH_OK;
 }
 
+// ------------------------------------------------------------------ three-channel frames with a fourth, empty one
+// RGB without alpha — 6-byte (Q16) or 12-byte (float) pixels — has no vector load of its own either; the
+// union-of-rectangles kernel (morphology.hip) takes 8- and 16-byte pixels.  Padded to four channels (the fourth 0) it
+// is an ordinary four-channel frame; minima and maxima are per channel.
+template<typename Q>
+__global__ __launch_bounds__(256)
+void rgb_pad_kernel(const Q *src,Q *dst,size_t npixels)
+{
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
+    {
+      Q p[3],o[4];
+      load_pixel<Q,3>(src+i*3,p);
+      o[0]=p[0]; o[1]=p[1]; o[2]=p[2]; o[3]=(Q) 0;
+      store_pixel<Q,4>(dst+i*4,o);
+    }
+}
+
+// ... and back; `changed` counts the samples with |result - original| >= MagickEpsilon (morphology.c:3195-3199; a
+// NaN difference is not one)
+template<typename Q>
+__global__ __launch_bounds__(256)
+void rgb_unpad_kernel(const Q *src,Q *dst,size_t npixels,const Q *original,unsigned long long *changed)
+{
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  unsigned differ=0;
+  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < npixels; i+=stride)
+    {
+      Q p[4],o[3];
+      load_pixel<Q,4>(src+i*4,p);
+      o[0]=p[0]; o[1]=p[1]; o[2]=p[2];
+      if (changed != nullptr)
+        {
+          Q was[3];
+          load_pixel<Q,3>(original+i*3,was);
+#pragma unroll
+          for (int c=0; c < 3; c++)
+            differ+=fabs((double) o[c]-(double) was[c]) >= 1.0e-12 ? 1u : 0u;
+        }
+      store_pixel<Q,3>(dst+i*3,o);
+    }
+  if (changed != nullptr)
+    {
+      differ=wave_sum(differ);
+      if (((threadIdx.x & 63) == 0) && (differ != 0))
+        atomicAdd(changed,(unsigned long long) differ);
+    }
+}
+
+MhStatus launch_rgb_pad(const View &src,const View &padded)
+{
+  const size_t n=src.columns*src.rows;
+  ProfileScope prof("rgb_pad",src.stream);
+  if (src.quantum == MH_QUANTUM_U16)
+    hipLaunchKernelGGL(rgb_pad_kernel<uint16_t>,dim3(stream_grid(n)),dim3(256),0,src.stream,
+      static_cast<const uint16_t *>(src.pixels),static_cast<uint16_t *>(padded.pixels),n);
+  else
+    hipLaunchKernelGGL(rgb_pad_kernel<float>,dim3(stream_grid(n)),dim3(256),0,src.stream,
+      static_cast<const float *>(src.pixels),static_cast<float *>(padded.pixels),n);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
+MhStatus launch_rgb_unpad(const View &padded,const View &dst,const void *original,unsigned long long *changed)
+{
+  const size_t n=dst.columns*dst.rows;
+  ProfileScope prof("rgb_unpad",dst.stream);
+  if (dst.quantum == MH_QUANTUM_U16)
+    hipLaunchKernelGGL((rgb_unpad_kernel<uint16_t>),dim3(stream_grid(n)),dim3(256),0,dst.stream,
+      static_cast<const uint16_t *>(padded.pixels),static_cast<uint16_t *>(dst.pixels),n,
+      static_cast<const uint16_t *>(original),changed);
+  else
+    hipLaunchKernelGGL((rgb_unpad_kernel<float>),dim3(stream_grid(n)),dim3(256),0,dst.stream,
+      static_cast<const float *>(padded.pixels),static_cast<float *>(dst.pixels),n,
+      static_cast<const float *>(original),changed);
+  MH_HIP(hipGetLastError());
+  return MH_OK;
+}
+
 MhStatus launch_copy(const View &src,const View &dst)
 {
   MH_HIP(hipMemcpyAsync(dst.pixels,src.pixels,src.bytes(),hipMemcpyDeviceToDevice,src.stream));

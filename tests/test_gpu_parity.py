@@ -841,6 +841,72 @@ def test_gray_convolve_2d_as_four_row_bands(im, refmod, what, rows, options):
     assert_parity(call().numpy(), want, True, "gray %s (the frame's own form)" % what)
 
 
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+@pytest.mark.parametrize("method,kernel,iterations", [
+    ("Dilate", "Disk:15", 1), ("Erode", "Disk:15", 1), ("Dilate", "Disk:7.3", 1), ("Erode", "Octagon:6", 2),
+    ("Dilate", "Diamond:9", 1), ("Erode", "Square:4", 1), ("Dilate", "Rectangle:9x5+2+1", 1), ("Dilate", "Plus:11", 1),
+    ("Erode", "Rectangle:1x9", 1), ("Dilate", "Square:1", 3), ("Open", "Disk:5", 1), ("Close", "Octagon:3", 1),
+    ("Smooth", "Square:2", 1), ("EdgeIn", "Diamond:2", 1), ("TopHat", "Disk:4", 1), ("Dilate", "Square:2", -1),
+])
+def test_rgb_erode_dilate_with_a_fourth_empty_channel(im, refmod, dtype, method, kernel, iterations, options):
+    """Erode / Dilate (and the compound methods built on them) on a three-channel frame — RGB without alpha, what
+    most photographs are, 6- or 12-byte pixels: padded to four channels for the union-of-rectangles kernel
+    (morphology.hip try_rects_rgb_padded; the fourth channel is empty and dropped again, the change count that
+    ends an unbounded iteration is taken on the way, morphology.c:3195-3199).  Bit-identical to the reference
+    and to the form it replaces; values below zero and beyond the Quantum range on float frames."""
+    import bench
+    options.set("MAGICKHIP_RGB_PAD_MIN_PIXELS", "0")
+    options.set("MAGICKHIP_RGB_PAD_FLOAT_ALWAYS", "1")   # (float frames take the form from Disk:8 on by themselves)
+    if dtype is Q16:
+        px = make_pixels(131, 277, 3, Q16, seed=len(kernel))
+    else:
+        px = (np.random.default_rng(len(kernel)).random((131, 277, 3)) * 90000.0 - 12000.0).astype(np.float32)
+    if iterations < 0:
+        px[:] = 0
+        px[60, 100] = (40000, 3, 65535)
+        px[3, 270, 1] = 1234
+    dev, ref = run_pair(im, refmod, px)
+    holder = {}
+    launched = set(bench.kernel_profile(
+        im, lambda: holder.update(out=im.morphology_image(dev, method, iterations, kernel)), 1))
+    assert {"rgb_pad", "morph_rects", "rgb_unpad"} <= launched and "morph_convex" not in launched, launched
+    want = ref.morphology(method, iterations, kernel).numpy()
+    assert_parity(holder["out"].numpy(), want, True, "RGB %s %s x%d" % (method, kernel, iterations))
+    options.set("MAGICKHIP_NO_RGB_PAD", "1")
+    assert_parity(im.morphology_image(dev, method, iterations, kernel).numpy(), want, True,
+                  "RGB %s %s (the frame's own form)" % (method, kernel))
+
+
+def test_rgb_padded_form_routing(im, options):
+    """With nothing set: Q16 RGB takes the padded form from 64 Kpixel on; float RGB only where morph_convex's tile
+    does not fit (Disk:8 and wider) — its small kernels are faster on their own."""
+    import bench
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(1)
+    q = torch.randint(-32768, 32768, (300, 300, 3), generator=g, device="cuda", dtype=torch.int16).view(torch.uint16)
+    f = torch.rand((300, 300, 3), generator=g, device="cuda", dtype=torch.float32) * 65535.0
+    small = q[:100, :100].contiguous()
+    run = lambda px, kernel: set(bench.kernel_profile(im, lambda: im.morphology_image(im.Image(px), "Dilate", 1, kernel), 1))
+    assert "rgb_pad" in run(q, "Disk:5") and "rgb_pad" in run(q, "Disk:15")
+    assert "rgb_pad" not in run(small, "Disk:5")
+    assert "rgb_pad" not in run(f, "Disk:5") and "rgb_pad" not in run(f, "Disk:7")
+    assert "rgb_pad" in run(f, "Disk:8") and "rgb_pad" in run(f, "Disk:15")
+
+
+@pytest.mark.parametrize("dtype", [Q16, HDRI])
+def test_rgb_padded_erode_with_a_channel_mask(im, refmod, dtype, options):
+    """... with channels that keep their source value (-channel RB): they come back bit for bit and are not
+    counted as changed."""
+    options.set("MAGICKHIP_RGB_PAD_MIN_PIXELS", "0")
+    options.set("MAGICKHIP_RGB_PAD_FLOAT_ALWAYS", "1")
+    px = make_pixels(90, 140, 3, dtype, seed=9)
+    dev = im.Image(to_device(px), copy_channels=(1,))
+    ref = refmod.RefImage(px).set_channel_mask("RB")
+    for method, kernel, iterations in (("Erode", "Disk:6", 1), ("Dilate", "Octagon:2", -1)):
+        assert_parity(im.morphology_image(dev, method, iterations, kernel).numpy(),
+                      ref.morphology(method, iterations, kernel).numpy(), True, "%s %s -channel RB" % (method, kernel))
+
+
 @pytest.mark.parametrize("rows", [90, 131, 258])
 @pytest.mark.parametrize("method,kernel,iterations", [
     ("Dilate", "Disk:15", 1), ("Erode", "Disk:15", 1), ("Dilate", "Disk:7.3", 1), ("Erode", "Octagon:6", 2),
