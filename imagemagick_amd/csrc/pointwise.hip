@@ -431,6 +431,37 @@ void colorspace_lab_fast_kernel(uint4 *__restrict__ pairs,size_t npairs,uint2 *_
     *last=srgb_to_lab_fast_pixel(*last,decode);
 }
 
+// ... on RGB frames (6-byte pixels, no alpha: what most photographs are; they took the table kernel of the bit-identical
+// route at 2.8x the time of an RGBA frame): four pixels = three 8-byte words a lane; `tail` = the frame's last
+// npixels mod 4 pixels.
+__global__ __launch_bounds__(1024)
+void colorspace_lab_fast_rgb_kernel(uint2 *__restrict__ words,size_t nquads,uint16_t *__restrict__ tail,int ntail)
+{
+  __shared__ float2 decode[kDecodePieces];
+  build_decode_table(decode);
+  __syncthreads();
+  const size_t stride=(size_t) gridDim.x*blockDim.x;
+  for (size_t i=(size_t) blockIdx.x*blockDim.x+threadIdx.x; i < nquads; i+=stride)
+    {
+      const uint2 w0=words[3*i],w1=words[3*i+1],w2=words[3*i+2];
+      const uint2 p0=srgb_to_lab_fast_pixel(make_uint2(w0.x,w0.y & 0xffffu),decode);
+      const uint2 p1=srgb_to_lab_fast_pixel(make_uint2((w0.y >> 16) | (w1.x << 16),w1.x >> 16),decode);
+      const uint2 p2=srgb_to_lab_fast_pixel(make_uint2(w1.y,w2.x & 0xffffu),decode);
+      const uint2 p3=srgb_to_lab_fast_pixel(make_uint2((w2.x >> 16) | (w2.y << 16),w2.y >> 16),decode);
+      words[3*i]=make_uint2(p0.x,(p0.y & 0xffffu) | (p1.x << 16));
+      words[3*i+1]=make_uint2((p1.x >> 16) | (p1.y << 16),p2.x);
+      words[3*i+2]=make_uint2((p2.y & 0xffffu) | (p3.x << 16),(p3.x >> 16) | (p3.y << 16));
+    }
+  if ((blockIdx.x == 0) && ((int) threadIdx.x < ntail))
+    {
+      uint16_t *q=tail+3*threadIdx.x;
+      const uint2 p=srgb_to_lab_fast_pixel(make_uint2((unsigned) q[0] | ((unsigned) q[1] << 16),(unsigned) q[2]),decode);
+      q[0]=(uint16_t) (p.x & 0xffffu);
+      q[1]=(uint16_t) (p.x >> 16);
+      q[2]=(uint16_t) (p.y & 0xffffu);
+    }
+}
+
 template<typename Q,int C,int OP>
 __global__ __launch_bounds__(256)
 void colorspace_kernel(Q *__restrict__ pixels,size_t npixels)
@@ -596,6 +627,19 @@ static MhStatus colorspace_step(const View &img,int op)
       const size_t wanted=(npairs+4095)/4096,most=2*(size_t) compute_units(img.device);
       hipLaunchKernelGGL(colorspace_lab_fast_kernel,dim3((unsigned) (wanted < most ? wanted : most)),dim3(1024),0,
         img.stream,static_cast<uint4 *>(img.pixels),npairs,last);
+      MH_HIP(hipGetLastError());
+      return MH_OK;
+    }
+  if ((op == OP_SRGB_TO_LAB) && (img.quantum == MH_QUANTUM_U16) && (img.channels == 3) &&
+      (precision() == MH_PRECISION_FAST) && (option("MAGICKHIP_NO_FAST_LAB") == nullptr) &&
+      ((reinterpret_cast<uintptr_t>(img.pixels) & 7u) == 0))
+    {
+      const size_t n=img.columns*img.rows,nquads=n/4;
+      ProfileScope prof("colorspace",img.stream);
+      const size_t wanted=(nquads+1023)/1024,most=2*(size_t) compute_units(img.device);
+      hipLaunchKernelGGL(colorspace_lab_fast_rgb_kernel,dim3((unsigned) (wanted < 1 ? 1 : (wanted < most ? wanted : most))),
+        dim3(1024),0,img.stream,static_cast<uint2 *>(img.pixels),nquads,
+        static_cast<uint16_t *>(img.pixels)+12*nquads,(int) (n-4*nquads));
       MH_HIP(hipGetLastError());
       return MH_OK;
     }

@@ -1991,6 +1991,32 @@ def test_contrast_stretch_per_channel_mask(im, refmod):
     assert_parity(got, want, True, "contrast-stretch -channel RGB")
 
 
+@pytest.mark.parametrize("shape", [(64, 64), (37, 41), (1, 1), (1, 2), (3, 1), (5, 7), (130, 259)])
+def test_fast_lab_on_rgb_frames(im, refmod, shape):
+    """FAST sRGB -> Lab on a three-channel Q16 frame (6-byte pixels: colorspace_lab_fast_rgb_kernel, four pixels =
+    three 8-byte words a lane, the last npixels mod 4 on their own): within one level of the reference
+    (colorspace.c:1089-1128 / gem.c ConvertRGBToLab) and sample for sample what the RGBA kernel gives."""
+    import bench
+    rows, cols = shape
+    px = make_pixels(rows, cols, 3, Q16, seed=rows * 31 + cols)
+    px.reshape(-1, 3)[:4] = ((0, 0, 0), (65535, 65535, 65535), (65535, 0, 0), (1, 2, 3))[: min(4, rows * cols)]
+    want = refmod.RefImage(px).colorspace("Lab").numpy()
+    rgba = np.concatenate([px, np.full((rows, cols, 1), 4660, dtype=np.uint16)], axis=2)
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        dev = im.Image(to_device(px))
+        launched = set(bench.kernel_profile(im, lambda: im.transform_image_colorspace(dev, "Lab"), 1))
+        wide = im.Image(to_device(rgba))
+        im.transform_image_colorspace(wide, "Lab")
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert launched == {"colorspace"}, launched
+    got = dev.numpy()
+    assert_parity(got, want, False, "fast Lab, RGB %s" % (shape,))
+    assert np.array_equal(got, wide.numpy()[:, :, :3]), "RGB and RGBA FAST Lab differ"
+    assert np.array_equal(wide.numpy()[:, :, 3], rgba[:, :, 3])
+
+
 def test_lab_then_contrast_stretch_chain(im, refmod):
     """BASELINE config C4's per-image pipeline."""
     rows, cols = 64, 64
