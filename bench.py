@@ -838,6 +838,9 @@ def extra_measurements(im, torch, args, image):
         configs["c1_blur_1024_sigma2"] = c1_config(im, torch, gen)
         configs["resize_reduce"] = resize_reduce_config(im, torch, gen)
         configs["reference_device_benchmark"] = reference_device_benchmark_config(im, torch, gen)
+        torch.cuda.empty_cache()
+        configs["narrow_pixel_layouts"] = narrow_layouts_config(im, torch, gen)
+        torch.cuda.empty_cache()
         result["configs"] = configs
         result["inputs"] = input_variants(im, torch, gen, args.sigma)
         torch.cuda.empty_cache()
@@ -939,6 +942,62 @@ def c1_config(im, torch, gen):
             out["ms_" + name] = round(sec * 1e3, 4)
             out["Mpixels_per_s_" + name] = round(1024.0 * 1024.0 / sec / 1e6, 1)
     finally:
+        im.set_precision(im.PRECISION_FAST if PRECISION_IS_FAST[0] else im.PRECISION_EXACT)
+    return out
+
+
+def narrow_layouts_config(im, torch, gen):
+    """Gray (one channel) and RGB (three channels, no alpha) Q16 frames — masks, scans, photographs — have 2- and
+    6-byte pixels; the wide-pixel kernels take them as four row bands = four channels / with a fourth, empty channel
+    (DESIGN 4.2.1).  8192^2, ms per call in the library's default mode, the frame's own form beside it, and the
+    fraction of the 8 TB/s roofline on the compulsory bytes (frame read + frame written)."""
+    n = 8192
+    out = {"workload": "8192x8192 Q16, one-channel (gray) and three-channel (RGB) frames: Dilate Disk:15, "
+                       "BlurImage(0x10), GaussianBlurImage(0x3), sRGB->Lab"}
+    try:
+        im.set_precision(im.PRECISION_FAST)
+        rgba = random_q16(torch, gen, n, n)
+        frames = {"gray": (rgba[:, :, :1].contiguous(), 2), "rgb": (rgba[:, :, :3].contiguous(), 6)}
+        del rgba
+        ops = {"gray": [("dilate_disk15", lambda i: im.morphology_image(i, "Dilate", 1, "Disk:15")),
+                        ("blur_0x10", lambda i: im.blur_image(i, 0.0, 10.0)),
+                        ("gaussian_blur_0x3", lambda i: im.gaussian_blur_image(i, 0.0, 3.0))],
+               "rgb": [("dilate_disk15", lambda i: im.morphology_image(i, "Dilate", 1, "Disk:15"))]}
+        for layout, (px, pixel_bytes) in frames.items():
+            img = im.Image(px)
+            for name, op in ops[layout]:
+                entry = {}
+                for form, switch in (("ms", None), ("ms_own_form", "1")):
+                    im.set_option("MAGICKHIP_NO_GRAY_BANDS", switch)
+                    im.set_option("MAGICKHIP_NO_RGB_PAD", switch)
+                    op(img)
+                    entry[form] = round(timed(torch, lambda: op(img), 5) * 1e3, 4)
+                entry["frac_of_8TBps_on_compulsory_bytes"] = round(2.0 * n * n * pixel_bytes / (entry["ms"] * 1e-3) / 8e12, 4)
+                out["%s_%s" % (layout, name)] = entry
+            del img
+        im.set_option("MAGICKHIP_NO_GRAY_BANDS", None)
+        im.set_option("MAGICKHIP_NO_RGB_PAD", None)
+        px = frames["rgb"][0]
+        entry = {}
+        for form, switch in (("ms", None), ("ms_own_form", "1")):
+            im.set_option("MAGICKHIP_NO_FAST_LAB", switch)
+            im.transform_image_colorspace(im.Image(px.clone()), "Lab")
+            copies = [px.clone() for _ in range(3)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for c in copies:
+                im.transform_image_colorspace(im.Image(c), "Lab")
+            torch.cuda.synchronize()
+            entry[form] = round((time.perf_counter() - t0) / 3 * 1e3, 4)
+            del copies
+        im.set_option("MAGICKHIP_NO_FAST_LAB", None)
+        entry["frac_of_8TBps_on_compulsory_bytes"] = round(2.0 * n * n * 6 / (entry["ms"] * 1e-3) / 8e12, 4)
+        out["rgb_srgb_to_lab"] = entry
+    except Exception as exc:
+        out["error"] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
+    finally:
+        for name in ("MAGICKHIP_NO_GRAY_BANDS", "MAGICKHIP_NO_RGB_PAD", "MAGICKHIP_NO_FAST_LAB"):
+            im.set_option(name, None)
         im.set_precision(im.PRECISION_FAST if PRECISION_IS_FAST[0] else im.PRECISION_EXACT)
     return out
 
