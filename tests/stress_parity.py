@@ -29,6 +29,8 @@ def setup(seed=1):
         refmod.set_thread_limit(os.cpu_count() or 1)
         im.set_option("MAGICKHIP_RESIZE_ONE_LAUNCH_MIN_PIXELS", "0")     # small frames through the one-launch resize kernels too
         im.set_option("MAGICKHIP_GRAY_BANDS_MIN_PIXELS", "0")            # ... and small gray frames through the four-band form of the fused blur
+        im.set_option("MAGICKHIP_RGB_PAD_MIN_PIXELS", "0")               # ... small RGB frames through the padded form of Erode / Dilate
+        im.set_option("MAGICKHIP_RGB_PAD_FLOAT_ALWAYS", "1")             #     (float: also under kernels morph_convex would take)
         _ready = True
     im.set_precision(im.PRECISION_EXACT)           # (the library's default is FAST; the cases below switch per call)
 
@@ -191,8 +193,16 @@ def run_case(op=None):
                   "Plus:%d" % rng.integers(1, 12), "Rectangle:%dx%d" % (2 * rng.integers(0, 9) + 1, 2 * rng.integers(0, 9) + 1)]
         kernel = family[int(rng.integers(0, len(family)))]
         method = "Dilate" if rng.random() < 0.5 else "Erode"
-        got = im.morphology_image(dev(px), method, 1, kernel).numpy()
-        failures += check(method, got, ref.morphology(method, 1, kernel).numpy(), 0, detail + " " + kernel)
+        layout = int(rng.integers(0, 3))           # RGBA; one channel (four row bands); RGB (a fourth, empty channel)
+        if layout == 0:
+            got = im.morphology_image(dev(px), method, 1, kernel).numpy()
+            failures += check(method, got, ref.morphology(method, 1, kernel).numpy(), 0, detail + " " + kernel)
+        else:
+            frame = np.ascontiguousarray(px[:, :, :1] if layout == 1 else px[:, :, :3])
+            iterations = 1 if rng.random() < 0.8 else int(rng.integers(2, 4))
+            got = im.morphology_image(dev(frame), method, iterations, kernel).numpy().reshape(frame.shape)
+            want = refmod.RefImage(frame).morphology(method, iterations, kernel).numpy().reshape(frame.shape)
+            failures += check(method, got, want, 0, detail + " %s x%d c%d" % (kernel, iterations, frame.shape[2]))
     elif op == 4:                                  # histogram operators above a megapixel
         rows2, cols2 = int(rng.integers(1000, 1500)), int(rng.integers(1050, 1900))
         px2 = pixels(rows2, cols2, int(rng.integers(0, 4)))
@@ -244,9 +254,11 @@ def run_case(op=None):
                   "Rectangle:%dx%d" % (2 * rng.integers(0, 9) + 1, 2 * rng.integers(0, 9) + 1)]
         kernel = family[int(rng.integers(0, len(family)))]
         method = "Dilate" if rng.random() < 0.5 else "Erode"
-        got = im.morphology_image(dev_float(fpx), method, 1, kernel).numpy()
-        failures += check_bits("float " + method, got, refmod.RefImage(fpx).morphology(method, 1, kernel).numpy(),
-                               detail + " " + kernel)
+        if rng.random() < 0.4:                     # RGB: a fourth, empty channel
+            fpx = np.ascontiguousarray(fpx[:, :, :3])
+        got = im.morphology_image(dev_float(fpx), method, 1, kernel).numpy().reshape(fpx.shape)
+        failures += check_bits("float " + method, got, refmod.RefImage(fpx).morphology(method, 1, kernel).numpy().reshape(fpx.shape),
+                               detail + " %s c%d" % (kernel, fpx.shape[2]))
     elif op == 10:                                 # float Quantum: separable 2-D kernels
         fpx = float_pixels(rows, cols, kind)
         sigma = float(rng.uniform(0.8, 4.5))
