@@ -361,6 +361,26 @@ MhStatus launch_conv2d_mfma(const View &src,const View &dst,const MhKernelInfo *
     if (!(magnitude <= 8.0))
       return MH_OK;
   }
+  if (blend)
+    {
+      // An alpha-weighted result is a QUOTIENT of sums: where a small cell is the only one that meets an opaque
+      // sample — a sprite on a transparent ground — it is the whole result (sum(k*alpha*p)/sum(k*alpha),
+      // morphology.c:2968-2977), and the f16 terms of a cell far below the largest carry too few bits for it (a 9 x 9
+      // Gaussian of sigma 1 on such a frame: ten levels off, found by the randomised run once small Gaussians were
+      // sent here).  The flat shapes this kernel was built for have one cell value; anything with a cell below
+      // 2^-13 of the largest keeps the fp64 / separated routes (as f16_taps_resolved does for the 1-D passes).
+      double largest=0.0,smallest=INFINITY;
+      for (int i=0; i < kw*kh; i++)
+        {
+          const double t=std::fabs(kernel->values[i]);
+          if (std::isnan(t) || (t == 0.0))
+            continue;
+          largest=t > largest ? t : largest;
+          smallest=t < smallest ? t : smallest;
+        }
+      if (!(largest > 0.0) || (smallest < std::ldexp(largest,-13)))
+        return MH_OK;
+    }
   for (int v=0; v < kh; v++)
     for (int u=0; u < kw; u++)
       {

@@ -236,6 +236,21 @@ static MhStatus separable_convolve(const View &src,const View &dst,const MhKerne
       if (positive && negative)
         return MH_OK;
     }
+  // Small kernels: the two separated passes cost what they cost (0.21 ms per 4096^2 frame, three frame transfers)
+  // whatever the kernel; the w x h sum in one launch is cheaper up to about 13 x 13 (convolve2d_mfma.hip: 5 x 5 0.10
+  // ms, 7 x 7 0.12, 9 x 9 0.13 on the same frame, +-1 level like this route), and below 5 x 5 so is the generic
+  // kernel, bit-identical (3 x 3: 0.11-0.20 ms against 0.21; tools/probe_small_separable.py,
+  // profiles/r6_notes/small_separable_kernels.txt).
+  if (kernel->width*kernel->height < 25)
+    return MH_OK;
+  if ((kernel->width <= 13) && (kernel->height <= 13) && ((src.channels == 4) || ((src.channels == 3) && !blend)) &&
+      (!blend || (roles.alpha == 3)) && (option("MAGICKHIP_NO_MFMA") == nullptr) &&
+      (option("MAGICKHIP_NO_MFMA_2D") == nullptr) && (option("MAGICKHIP_SEPARABLE_SMALL") == nullptr))
+    {
+      MH_TRY(launch_conv2d_mfma(src,dst,kernel,blend,handled));
+      if (*handled)
+        return MH_OK;
+    }
   if ((src.channels == 4) || ((src.channels == 3) && !blend))
     {
       // both passes on the matrix cores: Quantum pixels -> float sums -> Quantum pixels (four

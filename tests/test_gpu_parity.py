@@ -470,11 +470,53 @@ def test_gaussian_blur_fast_is_separated(im, refmod, channels, radius, sigma):
     finally:
         im.set_precision(im.PRECISION_EXACT)
     got = holder["out"].numpy()
-    if channels >= 3:       # both passes on the matrix cores, float sums in between
+    cells = im.kernel_to_numpy("Gaussian:%gx%g" % (radius, sigma))[0]
+    width = cells.shape[0]
+    # (alpha-weighted frames keep kernels with a cell below 2^-13 of the largest off the f16 2-D kernel: a sprite's
+    # result can be that cell alone, convolve2d_mfma.hip)
+    resolved = channels == 3 or float(cells.min()) >= float(cells.max()) * 2.0 ** -13
+    if channels >= 3 and width <= 13 and resolved:   # small kernels: the w x h sum in one launch is cheaper than two passes
+        assert launched == {"conv2d_mfma"}, launched
+    elif channels >= 3:                 # both passes on the matrix cores, float sums in between
         assert launched == {"conv_row", "conv_column"}, launched
     else:
         assert "separable_finish" in launched and "premultiply" in launched, launched
     assert_parity(got, want, False, "fast gaussian %gx%g c%d" % (radius, sigma, channels))
+
+
+@pytest.mark.parametrize("channels,alpha", [(4, True), (4, False), (3, False), (1, False), (2, True)])
+@pytest.mark.parametrize("kernel", ["3x3: 1,2,1 2,4,2 1,2,1", "5x5: 1,4,6,4,1 4,16,24,16,4 6,24,36,24,6 4,16,24,16,4 1,4,6,4,1",
+                                    "Gaussian:3x1.2", "Gaussian:6x2", "Gaussian:7x2", "Square:1", "Square:2",
+                                    "3x5: 1,2,1 2,4,2 3,6,3 2,4,2 1,2,1"])
+def test_convolve_fast_small_outer_product_kernels(im, refmod, kernel, channels, alpha, options):
+    """FAST Convolve with a small kernel that is an outer product: below 5 x 5 cells the generic kernel (bit-identical),
+    up to 13 x 13 the w x h sum in one launch on the matrix cores (convolve2d_mfma.hip), beyond that the two separated
+    passes — each faster than the next on its range (operators.cpp separable_convolve; 4096^2 RGBA 5 x 5: 0.10 ms
+    against 0.21).  Within one level of the reference on every route, and the separated passes' result beside it."""
+    import bench
+    px = make_pixels(97, 131, channels, Q16, seed=len(kernel) + channels)
+    dev, ref = run_pair(im, refmod, px, has_alpha=alpha) if channels in (2, 4) else run_pair(im, refmod, px)
+    if channels == 4 and not alpha:
+        want = np.concatenate([refmod.RefImage(px[:, :, c].copy()).set_artifact("convolve:scale", "!")
+                               .morphology("Convolve", 1, kernel).numpy().reshape(97, 131, 1) for c in range(4)], axis=2)
+    else:
+        want = ref.set_artifact("convolve:scale", "!").morphology("Convolve", 1, kernel).numpy().reshape(px.shape)
+    shape = im.kernel_to_numpy(kernel)[0].shape
+    holder = {}
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        launched = set(bench.kernel_profile(
+            im, lambda: holder.update(out=im.morphology_image(dev, "Convolve", 1, kernel, scale=(1.0, 1))), 1))
+        options.set("MAGICKHIP_SEPARABLE_SMALL", "1")
+        separated = im.morphology_image(dev, "Convolve", 1, kernel, scale=(1.0, 1)).numpy().reshape(px.shape)
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    if shape[0] * shape[1] < 25:
+        assert not ({"conv_row", "conv_column", "conv2d_mfma"} & launched), launched
+    elif max(shape) <= 13 and channels >= 3:
+        assert launched == {"conv2d_mfma"}, launched
+    assert_parity(holder["out"].numpy().reshape(px.shape), want, False, "fast %s c%d alpha=%s via %s" % (kernel[:20], channels, alpha, sorted(launched)))
+    assert_parity(separated, want, False, "fast %s c%d (separated passes)" % (kernel[:20], channels))
 
 
 def test_gaussian_blur_fast_opaque_and_plain_four_channels(im, refmod):
@@ -520,12 +562,41 @@ def test_gaussian_blur_fast_alpha_cases(im, refmod, case):
     assert_parity(got, want, False, "fast gaussian, %s" % case)
 
 
-@pytest.mark.parametrize("channels", [3, 4, 2])
-def test_convolve_fast_outer_product_kernel_with_offset_origin(im, refmod, channels):
-    """A hand-written outer-product kernel (5 x 3, origin off centre, unnormalised) is separated
-    like the Gaussian: the origin of each axis and the reversed walk must carry over."""
+@pytest.mark.parametrize("kernel", ["Gaussian:0x0.992", "Gaussian:0x1.375",
+                                    "5x5: 1e-7,0.04,0.04,0.04,2e-7 0.04,0.05,0.04,0.04,0.04 0.04,0.04,0.08,0.04,0.04 "
+                                    "0.04,0.04,0.04,0.03,0.04 3e-7,0.04,0.04,0.04,1e-7"])
+def test_convolve_2d_fast_tiny_cells_on_a_sprite_frame(im, refmod, kernel):
+    """An alpha-weighted result is a quotient of sums: on a sprite (opaque rectangles on a transparent ground) a pixel
+    beside a rectangle's corner sees ONE opaque sample under the kernel's corner cell, and that cell — 1e-7 of the
+    largest — is the whole result (morphology.c:2968-2977).  The f16 2-D kernel's terms do not carry it (ten levels off,
+    found by the randomised run when small Gaussians were first sent there): such kernels keep the separated / fp64
+    routes on alpha-weighted frames.  FAST within one level."""
     import bench
-    kernel = ("5x3+1+2: 0.01,0.02,0.03,0.02,0.01 0.02,0.04,0.06,0.04,0.02 0.03,0.06,0.09,0.06,0.03")
+    rng = np.random.default_rng(12)
+    px = rng.integers(0, 65536, (120, 150, 4), dtype=np.uint16)
+    px[:, :, 3] = 0
+    for y, x, h, w in ((10, 10, 20, 24), (50, 60, 1, 1), (70, 20, 13, 2), (90, 100, 25, 40), (31, 35, 3, 3)):
+        px[y: y + h, x: x + w, 3] = 65535
+    dev, ref = run_pair(im, refmod, px)
+    want = ref.morphology("Convolve", 1, kernel).numpy()
+    holder = {}
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        launched = set(bench.kernel_profile(im, lambda: holder.update(out=im.morphology_image(dev, "Convolve", 1, kernel)), 1))
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert "conv2d_mfma" not in launched, launched
+    assert_parity(holder["out"].numpy(), want, False, "fast %s on a sprite frame via %s" % (kernel[:18], sorted(launched)))
+
+
+@pytest.mark.parametrize("channels", [3, 4, 2])
+def test_convolve_fast_outer_product_kernel_with_offset_origin(im, refmod, channels, options):
+    """A hand-written outer-product kernel (5 x 5, origin off centre, unnormalised) is separated
+    like the Gaussian: the origin of each axis and the reversed walk must carry over — and, this small, takes the
+    w x h sum in one launch first (three and four channels; separable_convolve): both within one level."""
+    import bench
+    column, row = (0.1, 0.2, 0.3, 0.25, 0.15), (0.1, 0.2, 0.3, 0.2, 0.1)
+    kernel = "5x5+1+3: " + " ".join(",".join("%g" % (c * r) for r in row) for c in column)
     px = make_pixels(77, 93, channels, Q16, seed=channels)
     dev, ref = run_pair(im, refmod, px)
     want = ref.convolve(kernel).numpy()
@@ -533,10 +604,15 @@ def test_convolve_fast_outer_product_kernel_with_offset_origin(im, refmod, chann
     im.set_precision(im.PRECISION_FAST)
     try:
         launched = set(bench.kernel_profile(im, lambda: holder.update(out=im.convolve_image(dev, kernel)), 1))
+        options.set("MAGICKHIP_SEPARABLE_SMALL", "1")
+        separated = set(bench.kernel_profile(im, lambda: holder.update(sep=im.convolve_image(dev, kernel)), 1))
     finally:
         im.set_precision(im.PRECISION_EXACT)
-    assert "morph2d" not in launched, launched
+    assert "morph2d" not in launched and "morph2d" not in separated, (launched, separated)
+    assert launched == ({"conv2d_mfma"} if channels >= 3 else separated), launched
+    assert {"conv_row", "conv_column"} <= separated, separated
     assert_parity(holder["out"].numpy(), want, False, "outer-product kernel, %d channels" % channels)
+    assert_parity(holder["sep"].numpy(), want, False, "outer-product kernel, %d channels, separated" % channels)
 
 
 def test_convolve_fast_signed_outer_product_kernel(im, refmod):
