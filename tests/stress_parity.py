@@ -221,11 +221,14 @@ def run_case(op=None):
                   "Diamond:%d" % rng.integers(2, 14), "Plus:%d" % rng.integers(2, 14),
                   "Ring:%d,%d" % (rng.integers(2, 6), rng.integers(7, 15))]
         kernel = family[int(rng.integers(0, len(family)))]
+        layout = int(rng.integers(0, 4))           # RGBA three times in four; one channel (four row bands); RGB
+        frame = px if layout < 2 else np.ascontiguousarray(px[:, :, :1] if layout == 2 else px[:, :, :3])
         im.set_precision(im.PRECISION_FAST)
-        got = im.morphology_image(dev(px), "Convolve", 1, kernel, scale=(1.0, 1)).numpy()
+        got = im.morphology_image(dev(frame), "Convolve", 1, kernel, scale=(1.0, 1)).numpy().reshape(frame.shape)
         im.set_precision(im.PRECISION_EXACT)
-        want = ref.set_artifact("convolve:scale", "!").morphology("Convolve", 1, kernel).numpy()
-        failures += check("fast convolve 2-D", got, want, 1, detail + " " + kernel)
+        want = (ref if layout < 2 else refmod.RefImage(frame)).set_artifact("convolve:scale", "!") \
+            .morphology("Convolve", 1, kernel).numpy().reshape(frame.shape)
+        failures += check("fast convolve 2-D", got, want, 1, detail + " %s c%d" % (kernel, frame.shape[2]))
     elif op == 7:                                  # EXACT 2-D separable kernels (+ the odd centre cell)
         sigma = float(rng.uniform(0.8, 4.5))
         if rng.random() < 0.6:
