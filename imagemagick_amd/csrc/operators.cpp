@@ -550,7 +550,8 @@ static MhStatus fused_blur_gray_bands(const View &src,const View &dst,const MhKe
   *handled=false;
   const MhKernelInfo *column=kernel->next;
   if ((column == nullptr) || (column->width != 1) || (column->height < 2) || (column->y < 0) ||
-      ((size_t) column->y >= column->height) || (column->height > 81))
+      ((size_t) column->y >= column->height) ||
+      (column->height > ((precision() == MH_PRECISION_FAST) && !unsharp ? 113u : 81u)))
     return MH_OK;
   const int K=(int) column->height;
   const int above=K-1-(int) column->y,below=(int) column->y;
@@ -643,6 +644,51 @@ static MhStatus fused_blur(const View &src,const View &dst,const MhKernelInfo *k
       MH_TRY(launch_blur_fused_hybrid(src,dst,reversed.data(),kept,shift,roles.blend,handled));
       if (*handled)
         return MH_OK;
+      // Beyond the one-launch kernel's 81 taps (sigma > 10.3), frames WITHOUT alpha weighting: both passes on the f16
+      // matrix cores with undivided f32 sums between them (convolve_mfma.hip MFMA_TO_SUMS / MFMA_FROM_SUMS, up to 113
+      // taps) — the form FAST GaussianBlurImage takes.  The reference rounds the intermediate to a level
+      // (morphology.c:2772-2776), which moves the value its column pass rounds by at most half a level (normalised
+      // non-negative taps); the f16 terms add < 0.1: within one level, as the one-launch kernel's colour sums are.
+      // (The general route runs the row pass on the fp64 kernels so that the intermediate is the reference's own:
+      // 0.089 + 0.025 ms per 2048^2 frame at sigma 12 against 2 x 0.03 here.)  An alpha-weighted frame needs the
+      // reference's intermediate ALPHA bit for bit and stays there.
+      if (!roles.blend && (kept > 81) && (option("MAGICKHIP_NO_LONG_BLUR_SUMS") == nullptr))
+        {
+          bool normalised=true;
+          double total=0.0;
+          for (int v=0; v < kept; v++)
+            {
+              normalised=normalised && (reversed[(size_t) v] >= 0.0);
+              total+=reversed[(size_t) v];
+            }
+          if (normalised && (total <= 1.0+1.0e-9))
+            {
+              View sums=src;
+              sums.quantum=MH_QUANTUM_F32;
+              sums.channels=4;
+              Temp memory;
+              MH_TRY(memory.alloc(src.device,sums.bytes(),src.stream));
+              sums.pixels=memory.ptr;
+              Conv1DParams horizontal,vertical;
+              horizontal.taps=row->values;
+              horizontal.ntaps=K;
+              horizontal.origin=(int) row->x;
+              vertical.taps=column->values;
+              vertical.ntaps=K;
+              vertical.origin=(int) column->y;
+              bool first=false,second=false;
+              MH_TRY(launch_conv1d_sums(src,sums,false,horizontal,false,&first));
+              if (first)
+                {
+                  MH_TRY(launch_conv1d_sums(sums,dst,true,vertical,false,&second));
+                  if (second)
+                    {
+                      *handled=true;
+                      return MH_OK;
+                    }
+                }
+            }
+        }
     }
   // EXACT BlurImage of an alpha-weighted frame: the kernel may give the frame up (alpha of a few
   // levels everywhere: BlurExactArgs::give_up); the two fp64 passes queued behind it — bit-identical

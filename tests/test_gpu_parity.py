@@ -452,6 +452,51 @@ def test_blur_fast_every_ring_size(im, refmod, channels, sigma):
     assert_parity(got, ref.blur(0.0, sigma).numpy(), False, "fast blur sigma %g, %d channels" % (sigma, channels))
 
 
+@pytest.mark.parametrize("frame", ["random", "alternating columns", "alternating rows", "flat with spikes"])
+@pytest.mark.parametrize("layout", ["rgb", "plain4", "gray"])
+@pytest.mark.parametrize("sigma", [10.5, 12.5, 14.0])
+def test_blur_fast_beyond_81_taps_on_frames_without_alpha(im, refmod, sigma, layout, frame, options):
+    """FAST BlurImage beyond the one-launch kernel's reach (83 to 113 taps) on frames without alpha weighting: both
+    passes on the f16 matrix cores with undivided f32 sums between them (operators.cpp fused_blur; gray frames as
+    four row bands).  The reference rounds the intermediate to a level, this route does not: frames whose row sums
+    sit on x.5 (columns alternating v, v+1: the two halves of the taps are 0.5 each to 1e-9) put that difference at
+    its largest.  Within one level; MAGICKHIP_NO_LONG_BLUR_SUMS: the general route (fp64 row pass) beside it."""
+    channels = {"rgb": 3, "plain4": 4, "gray": 1}[layout]
+    rows, cols = (300, 131) if layout == "gray" else (150, 140)
+    options.set("MAGICKHIP_GRAY_BANDS_MIN_PIXELS", "0")
+    rng = np.random.default_rng(int(sigma * 10) + channels)
+    if frame == "random":
+        px = rng.integers(0, 65536, (rows, cols, channels), dtype=np.uint16)
+    elif frame == "alternating columns":
+        base = rng.integers(0, 65535, (1, 1, channels))
+        px = (base + (np.arange(cols) % 2)[None, :, None]).astype(np.uint16) * np.ones((rows, 1, 1), dtype=np.uint16)
+    elif frame == "alternating rows":
+        base = rng.integers(0, 65535, (1, 1, channels))
+        px = (base + (np.arange(rows) % 2)[:, None, None]).astype(np.uint16) * np.ones((1, cols, 1), dtype=np.uint16)
+    else:
+        px = np.full((rows, cols, channels), 31000, dtype=np.uint16)
+        px[rng.random((rows, cols)) < 0.01] = 65535
+        px[rng.random((rows, cols)) < 0.01] = 0
+    px = np.ascontiguousarray(px)
+    if channels == 4:
+        dev = im.Image(to_device(px), has_alpha=False)
+        want = np.concatenate([refmod.RefImage(px[:, :, c].copy()).blur(0.0, sigma).numpy().reshape(rows, cols, 1)
+                               for c in range(4)], axis=2)
+    else:
+        dev, ref = run_pair(im, refmod, px)
+        want = ref.blur(0.0, sigma).numpy().reshape(px.shape)
+    assert 81 < im.optimal_kernel_width_1d(0.0, sigma) <= 113
+    im.set_precision(im.PRECISION_FAST)
+    try:
+        got = im.blur_image(dev, 0.0, sigma).numpy().reshape(px.shape)
+        options.set("MAGICKHIP_NO_LONG_BLUR_SUMS", "1")
+        general = im.blur_image(dev, 0.0, sigma).numpy().reshape(px.shape)
+    finally:
+        im.set_precision(im.PRECISION_EXACT)
+    assert_parity(got, want, False, "fast blur 0x%g, %s, %s" % (sigma, layout, frame))
+    assert_parity(general, want, False, "fast blur 0x%g, %s, %s (general route)" % (sigma, layout, frame))
+
+
 @pytest.mark.parametrize("channels", [1, 2, 3, 4])
 @pytest.mark.parametrize("radius,sigma", [(0.0, 1.5), (0.0, 4.0), (2.0, 3.0)])
 def test_gaussian_blur_fast_is_separated(im, refmod, channels, radius, sigma):
