@@ -1,5 +1,8 @@
-import sys
-sys.path.insert(0, "/root/repo")
+"""FAST / EXACT Convolve with small outer-product kernels (3 x 3 ... 9 x 9) on a 4096^2 frame, with and without the separated
+route (MAGICKHIP_NO_SEPARABLE): ms per call and the kernels that ran — where the two passes stop paying
+(operators.cpp separable_convolve).   python tools/probe_small_separable.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import imagemagick_amd as im
 from bench import kernel_profile, timed
