@@ -439,6 +439,44 @@ MhStatus launch_rgb_unpad(const View &padded,const View &dst,const void *origina
 MhStatus launch_gray_bands_pack(const View &src,const View &packed,int band,int halo);
 MhStatus launch_gray_bands_unpack(const View &packed,const View &dst,int band,int halo,const void *original=nullptr,
   unsigned long long *changed=nullptr);
+// ... the two frames and the geometry of one call: band = ceil(rows / 4), `halo` extra rows either side
+// of every band.  fits(): the frame has `min_pixels` (MAGICKHIP_GRAY_BANDS_MIN_PIXELS overrides every caller's
+// default: the two extra dispatches must pay) and its bands are at least as tall as the rows added to them.
+struct GrayBands
+{
+  View packed,result;
+  int band=0,halo=0;
+  Temp packed_memory,result_memory;
+  static bool fits(const View &src,int halo,long min_pixels)
+  {
+    const size_t band=(src.rows+3)/4;
+    return (halo >= 0) && (src.columns*src.rows >= (size_t) option_long("MAGICKHIP_GRAY_BANDS_MIN_PIXELS",min_pixels)) &&
+      (band >= (size_t) 2*(size_t) halo) && (band+2*(size_t) halo <= 65535u) && (src.rows <= 0x7fffffffu/4u) &&
+      (src.columns <= 0x7fffffffu);
+  }
+  MhStatus pack(const View &src,int rows_beyond)
+  {
+    halo=rows_beyond;
+    band=(int) ((src.rows+3)/4);
+    packed=src;
+    packed.channels=4;
+    packed.rows=(size_t) band+2*(size_t) halo;
+    result=packed;
+    MH_TRY(packed_memory.alloc(src.device,packed.bytes(),src.stream));
+    MH_TRY(result_memory.alloc(src.device,result.bytes(),src.stream));
+    packed.pixels=packed_memory.ptr;
+    result.pixels=result_memory.ptr;
+    return launch_gray_bands_pack(src,packed,band,halo);
+  }
+  MhStatus unpack(const View &dst,const void *original=nullptr,unsigned long long *changed=nullptr) const
+  { return launch_gray_bands_unpack(result,dst,band,halo,original,changed); }
+  static Roles plain_roles()
+  {
+    Roles plain;
+    plain.update_mask=0xfu;
+    return plain;
+  }
+};
 MhStatus launch_grayscale(const View &img,int method,const MhImage *desc);
 MhStatus launch_function(const View &img,int function,size_t count,const double *parameters,uint32_t update_mask);
 

@@ -1419,28 +1419,15 @@ static MhStatus try_rects_gray_bands(const View &src,const View &dst,bool dilate
   const int span=(int) half.size();
   const int above=dy_min < 0 ? -dy_min : 0,below=dy_min+span-1 > 0 ? dy_min+span-1 : 0;
   const int halo=above > below ? above : below;
-  const size_t band=(src.rows+3)/4;
-  if ((roles.copy_mask != 0) || (halo < 1) ||
-      (src.columns*src.rows < (size_t) option_long("MAGICKHIP_GRAY_BANDS_MIN_PIXELS",1l << 18)) ||
-      (band < (size_t) 2*halo) || (band+2*(size_t) halo > 65535u) || (src.rows > 0x7fffffffu/4u) ||
-      (src.columns > 0x7fffffffu))
+  if ((roles.copy_mask != 0) || (halo < 1) || !GrayBands::fits(src,halo,1l << 18))
     return MH_OK;
-  View packed=src,result=src;
-  packed.channels=result.channels=4;
-  packed.rows=result.rows=band+2*(size_t) halo;
-  Temp packed_memory,result_memory;
-  MH_TRY(packed_memory.alloc(src.device,packed.bytes(),src.stream));
-  MH_TRY(result_memory.alloc(src.device,result.bytes(),src.stream));
-  packed.pixels=packed_memory.ptr;
-  result.pixels=result_memory.ptr;
-  MH_TRY(launch_gray_bands_pack(src,packed,(int) band,halo));
-  Roles plain;
-  plain.update_mask=0xfu;
+  GrayBands bands;
+  MH_TRY(bands.pack(src,halo));
   bool inner=false;
-  MH_TRY(try_rects(packed,result,dilate,half,cx,dy_min,plain,nullptr,&inner));
+  MH_TRY(try_rects(bands.packed,bands.result,dilate,half,cx,dy_min,GrayBands::plain_roles(),nullptr,&inner));
   if (!inner)
     return MH_OK;
-  MH_TRY(launch_gray_bands_unpack(result,dst,(int) band,halo,src.pixels,changed));
+  MH_TRY(bands.unpack(dst,src.pixels,changed));
   *handled=true;
   return MH_OK;
 }

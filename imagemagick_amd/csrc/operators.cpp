@@ -344,25 +344,12 @@ static MhStatus primitive(const View &src,const View &dst,MhMorphologyMethod met
     {
       const int above=(int) kernel->y,below=(int) kernel->height-1-(int) kernel->y;
       const int halo=above > below ? above : below;
-      const size_t band=(src.rows+3)/4;
-      if ((kernel->y >= 0) && ((size_t) kernel->y < kernel->height) &&
-          (src.columns*src.rows >= (size_t) option_long("MAGICKHIP_GRAY_BANDS_MIN_PIXELS",1l << 23)) &&
-          (band >= (size_t) 2*halo) && (band+2*(size_t) halo <= 65535u) && (src.rows <= 0x7fffffffu/4u) &&
-          (src.columns <= 0x7fffffffu))
+      if ((kernel->y >= 0) && ((size_t) kernel->y < kernel->height) && GrayBands::fits(src,halo,1l << 23))
         {
-          View packed=src,result=src;
-          packed.channels=result.channels=4;
-          packed.rows=result.rows=band+2*(size_t) halo;
-          Temp packed_memory,result_memory;
-          MH_TRY(packed_memory.alloc(src.device,packed.bytes(),src.stream));
-          MH_TRY(result_memory.alloc(src.device,result.bytes(),src.stream));
-          packed.pixels=packed_memory.ptr;
-          result.pixels=result_memory.ptr;
-          MH_TRY(launch_gray_bands_pack(src,packed,(int) band,halo));
-          Roles plain;
-          plain.update_mask=0xfu;
-          MH_TRY(primitive(packed,result,method,kernel,bias,plain,desc,nullptr,mode));
-          return launch_gray_bands_unpack(result,dst,(int) band,halo,src.pixels,changed);
+          GrayBands bands;
+          MH_TRY(bands.pack(src,halo));
+          MH_TRY(primitive(bands.packed,bands.result,method,kernel,bias,GrayBands::plain_roles(),desc,nullptr,mode));
+          return bands.unpack(dst,src.pixels,changed);
         }
     }
   if ((method == MH_MORPHOLOGY_CONVOLVE) && (changed == nullptr) && (bias == 0.0) &&
@@ -556,27 +543,15 @@ static MhStatus fused_blur_gray_bands(const View &src,const View &dst,const MhKe
   const int K=(int) column->height;
   const int above=K-1-(int) column->y,below=(int) column->y;
   const int halo=above > below ? above : below;
-  const size_t band=(src.rows+3)/4;
-  if ((src.columns*src.rows < (size_t) option_long("MAGICKHIP_GRAY_BANDS_MIN_PIXELS",1l << 23)) ||
-      (band < (size_t) 2*halo) || (band+2*(size_t) halo > 65535u) || (src.rows > 0x7fffffffu/4u) ||
-      (src.columns > 0x7fffffffu))
+  if (!GrayBands::fits(src,halo,1l << 23))
     return MH_OK;
-  View packed=src,result=src;
-  packed.channels=result.channels=4;
-  packed.rows=result.rows=band+2*(size_t) halo;
-  Temp packed_memory,result_memory;
-  MH_TRY(packed_memory.alloc(src.device,packed.bytes(),src.stream));
-  MH_TRY(result_memory.alloc(src.device,result.bytes(),src.stream));
-  packed.pixels=packed_memory.ptr;
-  result.pixels=result_memory.ptr;
-  MH_TRY(launch_gray_bands_pack(src,packed,(int) band,halo));
-  Roles plain;
-  plain.update_mask=0xfu;
+  GrayBands bands;
+  MH_TRY(bands.pack(src,halo));
   bool inner=false;
-  MH_TRY(fused_blur(packed,result,kernel,plain,bias,&inner,unsharp,gain,threshold));
+  MH_TRY(fused_blur(bands.packed,bands.result,kernel,GrayBands::plain_roles(),bias,&inner,unsharp,gain,threshold));
   if (!inner)
     return MH_OK;                                // (a kernel the one-launch forms decline: the frame's own passes)
-  MH_TRY(launch_gray_bands_unpack(result,dst,(int) band,halo));
+  MH_TRY(bands.unpack(dst));
   *handled=true;
   return MH_OK;
 }
