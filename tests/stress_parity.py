@@ -128,9 +128,10 @@ def check(name, got, want, limit, detail):
     return 0
 
 
-# STRESS_OPS=0,1,2 restricts the operators (0 FAST blur, 1 EXACT blur, 2 FAST unsharp, 3 Erode/Dilate,
-# 4 histogram operators, 5 FAST 2-D convolve, 6 FAST Lab, 7 EXACT GaussianBlur / Sharpen (separable +
-# tie check), 8 float-Quantum blur / unsharp, 9 float-Quantum Erode / Dilate, 10 float-Quantum
+# STRESS_OPS=0,1,2 restricts the operators (0 FAST blur, 1 EXACT blur, 2 FAST unsharp, 3 Erode/Dilate on RGBA, gray
+# (four row bands) and RGB (a fourth, empty channel) frames, 4 histogram operators, 5 FAST 2-D convolve on the same three
+# layouts, 6 FAST Lab, 7 EXACT GaussianBlur / Sharpen (separable +
+# tie check), 8 float-Quantum blur / unsharp, 9 float-Quantum Erode / Dilate (RGBA and RGB), 10 float-Quantum
 # GaussianBlur / Sharpen, 11 float-Quantum ContrastStretch / Equalize, 12 integer-cell 2-D convolve on the
 # i8 matrix cores in both modes and three layouts, 13 2-D convolve with random real cells on every layout and
 # Quantum type: the fused fp64 kernel, 14 ResizeImage: whole-number enlargements (one launch on the vector
